@@ -1,0 +1,14 @@
+"""distributed-sgd_amd -- MI355X-native engine for the hot path of zifeo/distributed-sgd.
+
+    Engine            one libdsgd_hip context (HIP kernels behind the C ABI of include/dsgd.h)
+    synth             synthetic RCV1-like CSR generator
+    host              host-side mirror of the reference's Master / Slave / SparseSVM surface
+
+The directory name is not an importable identifier; `import dsgd_amd` (repo root) aliases it.
+"""
+
+from . import _build, _lib, synth  # noqa: F401
+from ._lib import DsgdError, DsgdIndexError, DsgdInvalidArgument  # noqa: F401
+from .engine import Engine, Plan, device_count  # noqa: F401
+
+__all__ = ["Engine", "Plan", "device_count", "synth", "DsgdError", "DsgdIndexError", "DsgdInvalidArgument"]

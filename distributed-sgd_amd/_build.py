@@ -1,0 +1,104 @@
+"""Build the native pieces in-tree (the .so files travel to the GPU box with the snapshot).
+
+    libdsgd_hip.so    hipcc --offload-arch=gfx950   csrc/dsgd_hip.hip   (the product)
+    libdsgd_synth.so  gcc -fopenmp                  csrc/synth.c        (synthetic RCV1-like data)
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the build container too.
+
+The HIP runtime is referenced by its unversioned name (DT_NEEDED "libamdhip64.so"): a process
+that already holds a HIP runtime under that name -- e.g. one that imported torch, whose wheel
+bundles an un-SONAMEd libamdhip64.so -- keeps exactly ONE runtime; otherwise the loader finds
+/opt/rocm/lib/libamdhip64.so through the RUNPATH.  Two HIP runtimes in one process would each
+own separate streams and device state.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+HIP_SRC = os.path.join(CSRC, "dsgd_hip.hip")
+HIP_LIB = os.path.join(LIBDIR, "libdsgd_hip.so")
+SYNTH_SRC = os.path.join(CSRC, "synth.c")
+SYNTH_LIB = os.path.join(LIBDIR, "libdsgd_synth.so")
+
+
+def _stale(target: str, *sources: str) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd: list[str]) -> None:
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), proc.stdout))
+    if proc.stdout.strip() and os.environ.get("DSGD_BUILD_VERBOSE"):
+        print(proc.stdout)
+
+
+def hipcc_path() -> str:
+    for cand in (os.path.join(ROCM, "bin", "hipcc"), shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked in %s/bin and PATH)" % ROCM)
+
+
+def build_hip(force: bool = False) -> str:
+    header = os.path.join(HERE, "..", "include", "dsgd.h")
+    if not force and not _stale(HIP_LIB, HIP_SRC, header, __file__):
+        return HIP_LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    stub_dir = os.path.join(LIBDIR, "_stub")
+    os.makedirs(stub_dir, exist_ok=True)
+    stub = os.path.join(stub_dir, "libamdhip64.so")
+    empty = os.path.join(stub_dir, "empty.c")
+    with open(empty, "w") as f:
+        f.write("/* link-time stand-in so that DT_NEEDED records the unversioned name */\n")
+    _run(["gcc", "-shared", "-fPIC", "-o", stub, empty])
+    cmd = [
+        hipcc_path(),
+        "--offload-arch=gfx950",
+        "-O3",
+        "-std=c++17",
+        "-fPIC",
+        "-shared",
+        "-munsafe-fp-atomics",  # fp32 atomicAdd -> global_atomic_add_f32, not a CAS loop
+        "-Wall",
+        "-Wno-unused-function",
+        HIP_SRC,
+        "-o",
+        HIP_LIB,
+        "-L" + stub_dir,
+        "-Wl,-rpath," + os.path.join(ROCM, "lib"),
+        "-ldl",
+        "-lpthread",
+    ]
+    _run(cmd)
+    return HIP_LIB
+
+
+def build_synth(force: bool = False) -> str:
+    if not force and not _stale(SYNTH_LIB, SYNTH_SRC, __file__):
+        return SYNTH_LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    _run(["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-Wall", SYNTH_SRC, "-o", SYNTH_LIB, "-lm"])
+    return SYNTH_LIB
+
+
+def build_all(force: bool = False) -> dict:
+    return {"hip": build_hip(force), "synth": build_synth(force)}
+
+
+if __name__ == "__main__":
+    out = build_all(force="--force" in sys.argv)
+    for k, v in out.items():
+        print(k, v)

@@ -1,0 +1,1313 @@
+// libdsgd_hip -- MI355X (gfx950 / CDNA4) engine behind include/dsgd.h.
+//
+// Hot path of zifeo/distributed-sgd re-designed for one MI355X per process:
+//   * the CSR shard, w, g and dimSparsity stay resident in HBM (288 GB/GPU); w/g/ds are
+//     3 x 189 KB and live in the XCD L2s, so the only HBM stream is the CSR itself
+//     (8 B per non-zero + 12 B per row -- SURVEY.md 8(d));
+//   * gradient kernel: a group of G lanes of a 64-wide wavefront owns one row; gather-dot with
+//     an in-wave butterfly reduction, the reference's `activity >= 0` gate, then an fp32
+//     atomicAdd scatter of y*x into g (hardware global_atomic_add_f32, device scope);
+//   * regularise / aggregate / update are single-pass kernels over D+1 floats;
+//   * the synchronous master's Vec.mean over workers is one ncclAllReduce on the same stream.
+// Citations "ref:" are relative to /root/reference/src/main/scala/epfl/distributed/.
+//
+// This file is written for gfx950 only: wave64, no CUDA paths, no compatibility layers.
+
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/dsgd.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess) return fail(DSGD_EHIP, "%s: %s", #expr, hipGetErrorString(e__));   \
+  } while (0)
+
+#define DSGD_TRY(expr)        \
+  do {                        \
+    int rc__ = (expr);        \
+    if (rc__ != DSGD_OK) return rc__; \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, resolved lazily so that single-GPU users never map the (very large) library
+// ------------------------------------------------------------------------------------------------
+namespace rccl {
+typedef struct ncclComm* comm_t;
+typedef struct {
+  char internal[DSGD_UNIQUE_ID_BYTES];
+} unique_id_t;
+enum { kFloat32 = 7, kInt64 = 4, kSum = 0 };
+static int (*GetUniqueId)(unique_id_t*) = nullptr;
+static int (*CommInitRank)(comm_t*, int, unique_id_t, int) = nullptr;
+static int (*CommDestroy)(comm_t) = nullptr;
+static int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+static const char* (*GetErrorString)(int) = nullptr;
+static std::once_flag once;
+static bool ok = false;
+
+static void load() {
+  void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);  // reuse a copy the process already has
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) return;
+  GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
+  CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+  AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+  GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+  ok = GetUniqueId && CommInitRank && CommDestroy && AllReduce && GetErrorString;
+}
+static bool available() {
+  std::call_once(once, load);
+  return ok;
+}
+}  // namespace rccl
+
+#define RCCL_TRY(expr)                                                                          \
+  do {                                                                                          \
+    int r__ = (expr);                                                                           \
+    if (r__ != 0) return fail(DSGD_ERCCL, "%s: %s", #expr, rccl::GetErrorString(r__));          \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device-side helpers
+// ------------------------------------------------------------------------------------------------
+#define DSGD_EPS 1e-20f  // ref: math/Sparse.scala:104 (Sparse.epsilon); representable in fp32
+
+// Sparse(...) constructor filter: entries with abs(v) <= 1e-20 vanish (ref: math/Sparse.scala:108-118)
+__device__ __forceinline__ float filt(float v) { return fabsf(v) > DSGD_EPS ? v : 0.0f; }
+
+// device scalars shared by the kernels of one context
+struct DevScalars {
+  float s_reg;                 // 2 * lambda * (w . ds)            (ref: core/ml/SparseSVM.scala:31)
+  float wnorm2;                // |w|^2                            (ref: math/Vec.scala:55)
+  int err;                     // != 0: a sample index was out of range
+  int pad;
+  unsigned long long n_active;   // rows with y*(x.w) >= 0
+  unsigned long long n_samples;  // rows processed
+  unsigned long long counts[4];  // eval tallies {pred==y, pred==0, pred==-y, rows}
+};
+
+// one unit of gradient work: worker k processes items [begin, end) -- either positions in the
+// resident index list (idx != nullptr) or CSR row numbers themselves (contiguous range)
+struct WorkSeg {
+  long long begin;
+  long long end;
+};
+
+struct CsrView {
+  long long n_rows;
+  const long long* __restrict__ row_ptr;
+  const int* __restrict__ col;
+  const float* __restrict__ val;
+  const signed char* __restrict__ label;
+};
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  // butterfly over the G lanes of the group: fixed order -> x.w is reproducible run to run
+#pragma unroll
+  for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// x_row . w with G cooperating lanes; ref: math/Vec.scala:58 -> math/Sparse.scala:46,20-31
+template <int G>
+__device__ __forceinline__ float row_dot(const CsrView& m, long long start, long long end, const float* __restrict__ w,
+                                         int sub) {
+  float acc = 0.0f;
+  for (long long p = start + sub; p < end; p += G) {
+    int c = m.col[p];
+    float v = m.val[p];
+    acc += filt(v * w[c]);
+  }
+  return group_sum<G>(acc);
+}
+
+// ---- K1: gated sub-gradient sum ------------------------------------------------------------------
+// g_k += sum_{i in batch_k, y_i (x_i . w) >= 0} y_i x_i
+// ref: core/Slave.scala:147-153 (per-sample backward + Vec.sum), core/ml/SparseSVM.scala:26-29.
+// grid = (blocks, n_workers); a group of G lanes walks the worker's items with a grid stride.
+template <int G>
+__global__ void __launch_bounds__(256) dsgd_grad_rows_kernel(CsrView m, const float* __restrict__ w, float* g_base,
+                                                            long long g_stride, const int* __restrict__ idx,
+                                                            const WorkSeg* __restrict__ segs, DevScalars* sc) {
+  const int worker = blockIdx.y;
+  const WorkSeg seg = segs[worker];
+  float* g = g_base + (long long)worker * g_stride;
+  const int sub = threadIdx.x % G;
+  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
+  unsigned int active_local = 0;
+  for (long long t = seg.begin + group; t < seg.end; t += n_groups) {
+    long long row = idx ? (long long)idx[t] : t;
+    if (row < 0 || row >= m.n_rows) {
+      if (sub == 0) atomicExch(&sc->err, 1);
+      continue;
+    }
+    const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
+    const float y = (float)m.label[row];
+    const float d = row_dot<G>(m, start, end, w, sub);
+    const float activity = y * d;
+    if (activity < 0.0f) continue;  // zerosLike (ref: SparseSVM.scala:28)
+    if (sub == 0) active_local++;
+    for (long long p = start + sub; p < end; p += G) {
+      float xv = filt(m.val[p] * y);  // x * y (ref: SparseSVM.scala:28, math/Vec.scala:42)
+      if (xv != 0.0f) atomicAdd(&g[m.col[p]], xv);
+    }
+  }
+  // one atomic per wave for the Kamon-style counters (ref: core/Slave.scala:145,150)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) active_local += __shfl_xor(active_local, off, 64);
+  if ((threadIdx.x & 63) == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
+}
+
+// ---- K2: support-only scalar regulariser ----------------------------------------------------------
+// g_k[j] += s for j in supp(g_k), s = 2*lambda*(w.ds)  (ref: SparseSVM.scala:31, math/Vec.scala:65-75)
+__global__ void __launch_bounds__(1024) dsgd_regularize_kernel(float* g_base, long long g_stride, int dp,
+                                                              const DevScalars* sc) {
+  float* g = g_base + (long long)blockIdx.y * g_stride;
+  const float s = sc->s_reg;
+  const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) {
+    float v = filt(g[j]);
+    if (add && v != 0.0f) v = filt(v + s);
+    g[j] = v;
+  }
+}
+
+// sum of the per-worker regularised gradients hosted by this context (ref: math/Vec.scala:128-131)
+__global__ void __launch_bounds__(1024) dsgd_sum_workers_kernel(const float* g_base, long long g_stride, int n_workers,
+                                                               int dp, float* out) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) {
+    float a = 0.0f;
+    for (int k = 0; k < n_workers; ++k) a = filt(a + g_base[(long long)k * g_stride + j]);
+    out[j] = a;
+  }
+}
+
+__device__ __forceinline__ float block_sum_1024(float v, float* red /* 16 floats of LDS */) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.0f;
+  const int n_waves = blockDim.x >> 6;
+  for (int i = 0; i < n_waves; ++i) t += red[i];
+  return t;
+}
+
+// ---- K3: mean over workers + update + next regulariser scalar --------------------------------------
+// w <- w - lr * (g_sum / K); g <- 0; s <- 2*lambda*(w.ds); |w|^2
+// ref: core/Master.scala:194-197 (Vec.mean then batchWeights - learningRate * grad)
+// Single workgroup: D+1 = 47,237 floats is one pass of 1024 lanes x 47 elements and the two
+// dot products need no inter-workgroup reduction.
+__global__ void __launch_bounds__(1024) dsgd_apply_kernel(float* w, const float* gsum,
+                                                         float* zero_base, long long zero_stride, int n_zero, int dp,
+                                                         const float* __restrict__ ds, float n_workers_total, float lr,
+                                                         float lambda, DevScalars* sc) {
+  __shared__ float red[16];
+  float dot = 0.0f, nsq = 0.0f;
+  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
+    float mean = filt(gsum[j] / n_workers_total);  // Vec.mean (ref: math/Vec.scala:139)
+    float upd = filt(mean * lr);                   // learningRate * grad
+    float wn = filt(w[j] - upd);
+    w[j] = wn;
+    dot += filt(wn * ds[j]);
+    nsq += wn * wn;
+  }
+  __syncthreads();  // all reads of gsum done before it is zeroed (gsum may alias zero_base)
+  for (int k = 0; k < n_zero; ++k)
+    for (int j = threadIdx.x; j < dp; j += blockDim.x) zero_base[(long long)k * zero_stride + j] = 0.0f;
+  float dsum = block_sum_1024(dot, red);
+  float nsum = block_sum_1024(nsq, red);
+  if (threadIdx.x == 0) {
+    sc->s_reg = lambda * 2.0f * dsum;
+    sc->wnorm2 = nsum;
+  }
+}
+
+// s = 2*lambda*(w.ds) and |w|^2 for weights that were set from outside
+__global__ void __launch_bounds__(1024) dsgd_wstats_kernel(const float* __restrict__ w, const float* __restrict__ ds,
+                                                          int dp, float lambda, DevScalars* sc) {
+  __shared__ float red[16];
+  float dot = 0.0f, nsq = 0.0f;
+  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
+    float wn = w[j];
+    dot += filt(wn * ds[j]);
+    nsq += wn * wn;
+  }
+  float dsum = block_sum_1024(dot, red);
+  float nsum = block_sum_1024(nsq, red);
+  if (threadIdx.x == 0) {
+    sc->s_reg = lambda * 2.0f * dsum;
+    sc->wnorm2 = nsum;
+  }
+}
+
+// ---- async iteration (host-driven form of Slave.asyncTask) ----------------------------------------
+// grad = g_sum / n; delta = lr * regularize(grad, w); w -= delta  (ref: core/Slave.scala:93-101)
+__global__ void __launch_bounds__(1024) dsgd_async_finish_kernel(float* __restrict__ w, float* __restrict__ g, int dp,
+                                                                const float* __restrict__ ds, float n_samples, float lr,
+                                                                float lambda, float* delta_out, DevScalars* sc) {
+  __shared__ float red[16];
+  const float s = sc->s_reg;
+  const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+  float dot = 0.0f, nsq = 0.0f;
+  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
+    float v = filt(filt(g[j]) / n_samples);  // Vec.mean over samples
+    if (add && v != 0.0f) v = filt(v + s);   // regularize on the support
+    float upd = filt(v * lr);
+    if (delta_out) delta_out[j] = upd;
+    float wn = filt(w[j] - upd);
+    w[j] = wn;
+    g[j] = 0.0f;
+    dot += filt(wn * ds[j]);
+    nsq += wn * wn;
+  }
+  float dsum = block_sum_1024(dot, red);
+  float nsum = block_sum_1024(nsq, red);
+  if (threadIdx.x == 0) {
+    sc->s_reg = lambda * 2.0f * dsum;
+    sc->wnorm2 = nsum;
+  }
+}
+
+// w[key] -= dv (ref: core/Slave.scala:180, core/ml/GradState.scala:8)
+__global__ void dsgd_update_grad_kernel(float* w, const int* key, const float* dv, long long nnz, int dp,
+                                        DevScalars* sc) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
+    int k = key[i];
+    if (k < 0 || k >= dp) {
+      atomicExch(&sc->err, 1);
+      continue;
+    }
+    atomicAdd(&w[k], -dv[i]);
+  }
+}
+__global__ void dsgd_filter_kernel(float* w, int dp) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) w[j] = filt(w[j]);
+}
+
+// ---- K4: prediction  p = -signum(x.w)  (ref: core/ml/SparseSVM.scala:14, core/Slave.scala:129-140) ---
+template <int G>
+__global__ void __launch_bounds__(256) dsgd_forward_kernel(CsrView m, const float* __restrict__ w,
+                                                          const int* __restrict__ idx, long long n, float* pred,
+                                                          DevScalars* sc) {
+  const int sub = threadIdx.x % G;
+  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
+  for (long long t = group; t < n; t += n_groups) {
+    long long row = idx[t];
+    if (row < 0 || row >= m.n_rows) {
+      if (sub == 0) atomicExch(&sc->err, 1);
+      continue;
+    }
+    float d = row_dot<G>(m, m.row_ptr[row], m.row_ptr[row + 1], w, sub);
+    if (sub == 0) pred[t] = d > 0.0f ? -1.0f : (d < 0.0f ? 1.0f : 0.0f);
+  }
+}
+
+// ---- K5: loss / accuracy tallies over a row range ---------------------------------------------------
+// ref: core/Master.scala:100-107, core/ml/SparseSVM.scala:16-23: with p = -signum(x.w),
+//   y*p = +1 (loss 0, correct) iff y*(x.w) < 0;  p = 0 (loss 1) iff x.w == 0;  y*p = -1 (loss 2) otherwise
+template <int G>
+__global__ void __launch_bounds__(256) dsgd_eval_kernel(CsrView m, const float* __restrict__ w, long long row_begin,
+                                                       long long row_end, DevScalars* sc) {
+  const int sub = threadIdx.x % G;
+  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
+  unsigned int c0 = 0, c1 = 0, c2 = 0;
+  for (long long row = row_begin + group; row < row_end; row += n_groups) {
+    float d = row_dot<G>(m, m.row_ptr[row], m.row_ptr[row + 1], w, sub);
+    float yd = (float)m.label[row] * d;
+    if (sub == 0) {
+      if (yd < 0.0f) c0++;
+      else if (yd > 0.0f) c2++;
+      else c1++;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    c0 += __shfl_xor(c0, off, 64);
+    c1 += __shfl_xor(c1, off, 64);
+    c2 += __shfl_xor(c2, off, 64);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&sc->counts[3], (unsigned long long)(row_end - row_begin));
+  if ((threadIdx.x & 63) == 0) {
+    if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
+    if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
+    if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
+  }
+}
+
+// ---- dimSparsity on the device (ref: Main.scala:54-65) ---------------------------------------------
+__global__ void dsgd_colcount_kernel(const int* __restrict__ col, long long nnz, unsigned int* cnt, int dp,
+                                     DevScalars* sc) {
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (long long)gridDim.x * blockDim.x) {
+    int c = col[p];
+    if (c < 1 || c >= dp) {
+      atomicExch(&sc->err, 1);
+      continue;
+    }
+    atomicAdd(&cnt[c - 1], 1u);  // buff(idx - 1) += 1
+  }
+}
+__global__ void dsgd_ds_kernel(const unsigned int* cnt, float* ds, int dp) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dp; i += gridDim.x * blockDim.x) {
+    unsigned int c = (i < dp - 1) ? cnt[i] : 0u;  // buff has D entries (keys 0..D-1)
+    ds[i] = c ? filt(1.0f / ((float)c + 1.0f)) : 0.0f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct dsgd_plan {
+  int* d_idx = nullptr;
+  std::vector<long long> offsets;  // n_steps * n_workers + 1
+  WorkSeg* d_segs = nullptr;       // n_steps * n_workers
+  long long n_steps = 0;
+  int n_workers = 0;
+  long long max_items = 0;  // largest single list
+};
+
+struct dsgd_ctx {
+  dsgd_config cfg{};
+  int dp = 0;  // D + 1
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  // data
+  long long n_rows = 0, nnz = 0;
+  long long* d_row_ptr = nullptr;
+  int* d_col = nullptr;
+  float* d_val = nullptr;
+  signed char* d_label = nullptr;
+  int group = 16;  // lanes per row, chosen from the mean row length at load time
+  // vectors
+  float* d_w = nullptr;
+  float* d_ds = nullptr;
+  float* d_g = nullptr;  // g_cap x dp
+  int g_cap = 0;
+  float* d_gsum = nullptr;  // dp (all-reduce buffer / sum over hosted workers)
+  float* d_tmp = nullptr;   // dp scratch (delta_out staging)
+  DevScalars* d_sc = nullptr;
+  DevScalars* h_sc = nullptr;  // pinned
+  bool s_dirty = true;
+  bool have_ds = false;
+  // staging for host-provided index lists
+  int* d_idx = nullptr;
+  long long idx_cap = 0;
+  WorkSeg* d_segs = nullptr;
+  int segs_cap = 0;
+  std::vector<WorkSeg> segs_last;  // what d_segs currently holds
+  long long pending_samples = 0;   // rows enqueued by *_async calls since the last dsgd_synchronize
+  // comm
+  rccl::comm_t comm = nullptr;
+  int world = 1, rank = 0;
+  // profiling of the gradient kernel
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+  size_t prof_used = 0;
+  double prof_ms = 0.0;
+  long long prof_n = 0;
+  int n_cu = 256;
+};
+
+static int check_ctx(dsgd_ctx* c) {
+  if (!c) return fail(DSGD_EINVAL, "null context");
+  return DSGD_OK;
+}
+static int bind(dsgd_ctx* c) {  // host threads migrate (JVM pool): bind the device on every call
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  return DSGD_OK;
+}
+static CsrView view(dsgd_ctx* c) {
+  CsrView v;
+  v.n_rows = c->n_rows;
+  v.row_ptr = c->d_row_ptr;
+  v.col = c->d_col;
+  v.val = c->d_val;
+  v.label = c->d_label;
+  return v;
+}
+
+static int ensure_g(dsgd_ctx* c, int n_workers) {
+  if (n_workers <= c->g_cap) return DSGD_OK;
+  if (c->d_g) HIP_TRY(hipFree(c->d_g));
+  c->d_g = nullptr;
+  HIP_TRY(hipMalloc(&c->d_g, sizeof(float) * (size_t)n_workers * c->dp));
+  HIP_TRY(hipMemsetAsync(c->d_g, 0, sizeof(float) * (size_t)n_workers * c->dp, c->stream));
+  c->g_cap = n_workers;
+  return DSGD_OK;
+}
+static int ensure_idx(dsgd_ctx* c, long long n) {
+  if (n <= c->idx_cap) return DSGD_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->d_idx) HIP_TRY(hipFree(c->d_idx));
+  c->d_idx = nullptr;
+  long long cap = std::max<long long>(n, 2 * c->idx_cap);
+  HIP_TRY(hipMalloc(&c->d_idx, sizeof(int) * (size_t)cap));
+  c->idx_cap = cap;
+  return DSGD_OK;
+}
+static int ensure_segs(dsgd_ctx* c, int n) {
+  if (n <= c->segs_cap) return DSGD_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->d_segs) HIP_TRY(hipFree(c->d_segs));
+  c->d_segs = nullptr;
+  HIP_TRY(hipMalloc(&c->d_segs, sizeof(WorkSeg) * (size_t)n));
+  c->segs_cap = n;
+  c->segs_last.clear();
+  return DSGD_OK;
+}
+
+// upload work segments; identical consecutive uploads (timed loops over the same ranges) are skipped
+static int upload_segs(dsgd_ctx* c, const std::vector<WorkSeg>& segs) {
+  const int n = (int)segs.size();
+  DSGD_TRY(ensure_segs(c, n));
+  if ((int)c->segs_last.size() == n && memcmp(c->segs_last.data(), segs.data(), sizeof(WorkSeg) * n) == 0) return DSGD_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // earlier launches may still read d_segs
+  HIP_TRY(hipMemcpy(c->d_segs, segs.data(), sizeof(WorkSeg) * n, hipMemcpyHostToDevice));
+  c->segs_last = segs;
+  return DSGD_OK;
+}
+
+static int ensure_s(dsgd_ctx* c) {  // s = 2*lambda*(w.ds) must match the resident w
+  if (!c->s_dirty) return DSGD_OK;
+  hipLaunchKernelGGL(dsgd_wstats_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_ds, c->dp,
+                     (float)c->cfg.lambda, c->d_sc);
+  HIP_TRY(hipGetLastError());
+  c->s_dirty = false;
+  return DSGD_OK;
+}
+
+static int read_scalars(dsgd_ctx* c) {
+  HIP_TRY(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DSGD_OK;
+}
+static int reset_counters(dsgd_ctx* c) {
+  // err .. counts: everything after s_reg / wnorm2
+  HIP_TRY(hipMemsetAsync((char*)c->d_sc + offsetof(DevScalars, err), 0, sizeof(DevScalars) - offsetof(DevScalars, err),
+                         c->stream));
+  return DSGD_OK;
+}
+static int check_err_flag(dsgd_ctx* c) {
+  if (c->h_sc->err) {
+    HIP_TRY(hipMemsetAsync(&c->d_sc->err, 0, sizeof(int), c->stream));
+    return fail(DSGD_ERANGE, "sample index / key outside the loaded data");
+  }
+  return DSGD_OK;
+}
+
+static int grid_for(dsgd_ctx* c, long long items, int group) {
+  const long long groups_per_block = 256 / group;
+  long long blocks = (items + groups_per_block - 1) / groups_per_block;
+  const long long cap = (long long)c->n_cu * 8;  // memory-bound: ~8 blocks of 256 per CU, grid-stride the rest
+  return (int)std::max<long long>(1, std::min(blocks, cap));
+}
+
+static int prof_begin(dsgd_ctx* c, size_t* slot) {
+  if (!c->prof) return DSGD_OK;
+  if (c->prof_used == c->prof_ev.size()) {
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    c->prof_ev.emplace_back(a, b);
+  }
+  *slot = c->prof_used++;
+  HIP_TRY(hipEventRecord(c->prof_ev[*slot].first, c->stream));
+  return DSGD_OK;
+}
+static int prof_end(dsgd_ctx* c, size_t slot) {
+  if (!c->prof) return DSGD_OK;
+  HIP_TRY(hipEventRecord(c->prof_ev[slot].second, c->stream));
+  return DSGD_OK;
+}
+static int prof_collect(dsgd_ctx* c) {  // stream must be idle
+  for (size_t i = 0; i < c->prof_used; ++i) {
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->prof_ev[i].first, c->prof_ev[i].second));
+    c->prof_ms += ms;
+    c->prof_n++;
+  }
+  c->prof_used = 0;
+  return DSGD_OK;
+}
+
+// launch K1 for n_workers segments living at d_segs (device); max_items = largest segment
+static int launch_grad(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int n_workers, long long max_items) {
+  const int G = c->group;
+  dim3 grid(grid_for(c, max_items, G), n_workers);
+  size_t slot = 0;
+  DSGD_TRY(prof_begin(c, &slot));
+  CsrView m = view(c);
+  switch (G) {
+    case 64:
+      hipLaunchKernelGGL(dsgd_grad_rows_kernel<64>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_g, (long long)c->dp,
+                         d_idx, d_segs, c->d_sc);
+      break;
+    case 32:
+      hipLaunchKernelGGL(dsgd_grad_rows_kernel<32>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_g, (long long)c->dp,
+                         d_idx, d_segs, c->d_sc);
+      break;
+    case 16:
+      hipLaunchKernelGGL(dsgd_grad_rows_kernel<16>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_g, (long long)c->dp,
+                         d_idx, d_segs, c->d_sc);
+      break;
+    default:
+      hipLaunchKernelGGL(dsgd_grad_rows_kernel<8>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_g, (long long)c->dp,
+                         d_idx, d_segs, c->d_sc);
+      break;
+  }
+  HIP_TRY(hipGetLastError());
+  DSGD_TRY(prof_end(c, slot));
+  return DSGD_OK;
+}
+
+// regularise each hosted worker's sum, aggregate (locally and across ranks), update w
+static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
+  const int dp = c->dp;
+  const int blocks = (dp + 1023) / 1024;
+  hipLaunchKernelGGL(dsgd_regularize_kernel, dim3(blocks, n_workers), dim3(1024), 0, c->stream, c->d_g, (long long)dp,
+                     dp, c->d_sc);
+  HIP_TRY(hipGetLastError());
+  const float* gsum = c->d_g;
+  if (n_workers > 1 || c->comm) {
+    hipLaunchKernelGGL(dsgd_sum_workers_kernel, dim3(blocks), dim3(1024), 0, c->stream, c->d_g, (long long)dp, n_workers,
+                       dp, c->d_gsum);
+    HIP_TRY(hipGetLastError());
+    gsum = c->d_gsum;
+  }
+  if (c->comm) {
+    // the synchronous master's Future.sequence + Vec.mean (ref: core/Master.scala:190-194) as ONE
+    // all-reduce of D+1 floats over xGMI, ordered on the same stream as the kernels around it
+    RCCL_TRY(rccl::AllReduce(c->d_gsum, c->d_gsum, (size_t)dp, rccl::kFloat32, rccl::kSum, c->comm, c->stream));
+  }
+  const float k_total = (float)n_workers * (float)c->world;
+  hipLaunchKernelGGL(dsgd_apply_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_w, gsum, c->d_g, (long long)dp,
+                     n_workers, dp, c->d_ds, k_total, lr, (float)c->cfg.lambda, c->d_sc);
+  HIP_TRY(hipGetLastError());
+  c->s_dirty = false;
+  return DSGD_OK;
+}
+
+static int require_data(dsgd_ctx* c) {
+  if (!c->d_row_ptr) return fail(DSGD_ESTATE, "no data loaded (dsgd_load_csr)");
+  return DSGD_OK;
+}
+static int require_ds(dsgd_ctx* c) {
+  if (!c->have_ds) return fail(DSGD_ESTATE, "dimSparsity not set (dsgd_set_dim_sparsity / dsgd_build_dim_sparsity)");
+  return DSGD_OK;
+}
+
+extern "C" {
+
+int dsgd_abi_version(void) { return DSGD_ABI_VERSION; }
+const char* dsgd_last_error(void) { return g_err; }
+
+int dsgd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+  }
+  return ok;
+}
+
+int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
+  if (!cfg || !out) return fail(DSGD_EINVAL, "null argument");
+  if (cfg->n_features < 1) return fail(DSGD_EINVAL, "n_features must be >= 1");
+  if (!(cfg->lambda == cfg->lambda)) return fail(DSGD_EINVAL, "lambda is NaN");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    return fail(DSGD_EUNSUPPORTED, "no HIP device visible: libdsgd_hip has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= n) return fail(DSGD_EINVAL, "device %d out of range (%d devices)", cfg->device, n);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(DSGD_EUNSUPPORTED, "device %d is %s; this library is built for gfx950 only", cfg->device, prop.gcnArchName);
+  dsgd_ctx* c = new (std::nothrow) dsgd_ctx();
+  if (!c) return fail(DSGD_ENOMEM, "out of host memory");
+  c->cfg = *cfg;
+  c->dp = cfg->n_features + 1;
+  c->n_cu = prop.multiProcessorCount;
+  auto bail = [&](int rc) {
+    dsgd_destroy(c);
+    return rc;
+  };
+#define HIP_TRY_B(expr)                                                                               \
+  do {                                                                                                \
+    hipError_t e__ = (expr);                                                                          \
+    if (e__ != hipSuccess) return bail(fail(DSGD_EHIP, "%s: %s", #expr, hipGetErrorString(e__)));     \
+  } while (0)
+  HIP_TRY_B(hipSetDevice(cfg->device));
+  HIP_TRY_B(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY_B(hipMalloc(&c->d_w, sizeof(float) * c->dp));
+  HIP_TRY_B(hipMalloc(&c->d_ds, sizeof(float) * c->dp));
+  HIP_TRY_B(hipMalloc(&c->d_gsum, sizeof(float) * c->dp));
+  HIP_TRY_B(hipMalloc(&c->d_tmp, sizeof(float) * c->dp));
+  HIP_TRY_B(hipMalloc(&c->d_sc, sizeof(DevScalars)));
+  HIP_TRY_B(hipHostMalloc(&c->h_sc, sizeof(DevScalars), hipHostMallocDefault));
+  HIP_TRY_B(hipMemsetAsync(c->d_w, 0, sizeof(float) * c->dp, c->stream));
+  HIP_TRY_B(hipMemsetAsync(c->d_ds, 0, sizeof(float) * c->dp, c->stream));
+  HIP_TRY_B(hipMemsetAsync(c->d_gsum, 0, sizeof(float) * c->dp, c->stream));
+  HIP_TRY_B(hipMemsetAsync(c->d_sc, 0, sizeof(DevScalars), c->stream));
+  int rc = ensure_g(c, 1);
+  if (rc) return bail(rc);
+  HIP_TRY_B(hipStreamSynchronize(c->stream));
+#undef HIP_TRY_B
+  *out = c;
+  return DSGD_OK;
+}
+
+int dsgd_destroy(dsgd_ctx* c) {
+  if (!c) return DSGD_OK;
+  hipSetDevice(c->cfg.device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->comm && rccl::available()) rccl::CommDestroy(c->comm);
+  for (auto& e : c->prof_ev) {
+    hipEventDestroy(e.first);
+    hipEventDestroy(e.second);
+  }
+  hipFree(c->d_row_ptr);
+  hipFree(c->d_col);
+  hipFree(c->d_val);
+  hipFree(c->d_label);
+  hipFree(c->d_w);
+  hipFree(c->d_ds);
+  hipFree(c->d_g);
+  hipFree(c->d_gsum);
+  hipFree(c->d_tmp);
+  hipFree(c->d_sc);
+  hipFree(c->d_idx);
+  hipFree(c->d_segs);
+  if (c->h_sc) hipHostFree(c->h_sc);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return DSGD_OK;
+}
+
+int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr, const int32_t* col, const float* val,
+                  const int8_t* label) {
+  DSGD_TRY(check_ctx(c));
+  if (n_rows < 1 || !row_ptr || !label) return fail(DSGD_EINVAL, "n_rows must be >= 1 and arrays non-null");
+  if (row_ptr[0] != 0) return fail(DSGD_EINVAL, "row_ptr[0] must be 0");
+  const int64_t nnz = row_ptr[n_rows];
+  if (nnz < 0 || (nnz > 0 && (!col || !val))) return fail(DSGD_EINVAL, "bad nnz / null col,val");
+  for (int64_t i = 0; i < n_rows; ++i)
+    if (row_ptr[i + 1] < row_ptr[i]) return fail(DSGD_EINVAL, "row_ptr not monotone at row %lld", (long long)i);
+  // keys must be valid Sparse keys for a vector of size D (ref: math/Sparse.scala:61-68 accepts 0..size)
+  for (int64_t p = 0; p < nnz; ++p)
+    if (col[p] < 0 || col[p] > c->cfg.n_features)
+      return fail(DSGD_ERANGE, "column id %d at nnz %lld outside [0, %d]", col[p], (long long)p, c->cfg.n_features);
+  for (int64_t i = 0; i < n_rows; ++i)
+    if (label[i] != 1 && label[i] != -1) return fail(DSGD_EINVAL, "label[%lld] = %d, expected +1/-1", (long long)i, label[i]);
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  hipFree(c->d_row_ptr);
+  hipFree(c->d_col);
+  hipFree(c->d_val);
+  hipFree(c->d_label);
+  c->d_row_ptr = nullptr;
+  c->d_col = nullptr;
+  c->d_val = nullptr;
+  c->d_label = nullptr;
+  HIP_TRY(hipMalloc(&c->d_row_ptr, sizeof(long long) * (size_t)(n_rows + 1)));
+  HIP_TRY(hipMalloc(&c->d_col, sizeof(int) * (size_t)std::max<int64_t>(nnz, 1)));
+  HIP_TRY(hipMalloc(&c->d_val, sizeof(float) * (size_t)std::max<int64_t>(nnz, 1)));
+  HIP_TRY(hipMalloc(&c->d_label, (size_t)n_rows));
+  HIP_TRY(hipMemcpy(c->d_row_ptr, row_ptr, sizeof(long long) * (size_t)(n_rows + 1), hipMemcpyHostToDevice));
+  if (nnz) {
+    HIP_TRY(hipMemcpy(c->d_col, col, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_val, val, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMemcpy(c->d_label, label, (size_t)n_rows, hipMemcpyHostToDevice));
+  c->n_rows = n_rows;
+  c->nnz = nnz;
+  const double mean = (double)nnz / (double)n_rows;
+  c->group = mean > 192.0 ? 64 : (mean > 96.0 ? 32 : (mean > 12.0 ? 16 : 8));
+  return DSGD_OK;
+}
+
+int dsgd_n_rows(dsgd_ctx* c, int64_t* n_rows, int64_t* nnz) {
+  DSGD_TRY(check_ctx(c));
+  if (n_rows) *n_rows = c->n_rows;
+  if (nnz) *nnz = c->nnz;
+  return DSGD_OK;
+}
+
+int dsgd_set_dim_sparsity(dsgd_ctx* c, const float* ds) {
+  DSGD_TRY(check_ctx(c));
+  if (!ds) return fail(DSGD_EINVAL, "null ds");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  HIP_TRY(hipMemcpyAsync(c->d_ds, ds, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(dsgd_filter_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, c->d_ds, c->dp);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->have_ds = true;
+  c->s_dirty = true;
+  return DSGD_OK;
+}
+
+int dsgd_build_dim_sparsity(dsgd_ctx* c, int64_t n_train, float* ds_out) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(require_data(c));
+  if (n_train < 1 || n_train > c->n_rows) return fail(DSGD_EINVAL, "n_train %lld outside [1, %lld]", (long long)n_train, c->n_rows);
+  long long nnz_train = 0;
+  HIP_TRY(hipMemcpy(&nnz_train, c->d_row_ptr + n_train, sizeof(long long), hipMemcpyDeviceToHost));
+  unsigned int* d_cnt = nullptr;
+  HIP_TRY(hipMalloc(&d_cnt, sizeof(unsigned int) * c->dp));
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * c->dp, c->stream));
+  DSGD_TRY(reset_counters(c));
+  if (nnz_train > 0) {
+    int blocks = (int)std::min<long long>((nnz_train + 255) / 256, (long long)c->n_cu * 8);
+    hipLaunchKernelGGL(dsgd_colcount_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_col, nnz_train, d_cnt, c->dp,
+                       c->d_sc);
+  }
+  hipLaunchKernelGGL(dsgd_ds_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, d_cnt, c->d_ds, c->dp);
+  hipError_t le = hipGetLastError();
+  int rc = read_scalars(c);
+  hipFree(d_cnt);
+  if (le != hipSuccess) return fail(DSGD_EHIP, "dimSparsity kernels: %s", hipGetErrorString(le));
+  DSGD_TRY(rc);
+  if (c->h_sc->err) {
+    hipMemsetAsync(&c->d_sc->err, 0, sizeof(int), c->stream);
+    return fail(DSGD_ERANGE, "feature id 0 cannot be counted by Main.scala:60 (buff(idx - 1))");
+  }
+  c->have_ds = true;
+  c->s_dirty = true;
+  if (ds_out) HIP_TRY(hipMemcpy(ds_out, c->d_ds, sizeof(float) * c->dp, hipMemcpyDeviceToHost));
+  return DSGD_OK;
+}
+
+static int set_weights_locked(dsgd_ctx* c, const float* w) {
+  HIP_TRY(hipMemcpyAsync(c->d_w, w, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(dsgd_filter_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, c->d_w, c->dp);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));  // w is a pageable host buffer the caller may reuse
+  c->s_dirty = true;
+  return DSGD_OK;
+}
+
+int dsgd_set_weights(dsgd_ctx* c, const float* w) {
+  DSGD_TRY(check_ctx(c));
+  if (!w) return fail(DSGD_EINVAL, "null w");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  return set_weights_locked(c, w);
+}
+
+int dsgd_get_weights(dsgd_ctx* c, float* w_out) {
+  DSGD_TRY(check_ctx(c));
+  if (!w_out) return fail(DSGD_EINVAL, "null w_out");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  HIP_TRY(hipMemcpyAsync(w_out, c->d_w, sizeof(float) * c->dp, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DSGD_OK;
+}
+
+// stage host index lists for n_workers workers; returns the largest list length
+static int stage_lists(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int64_t* n_per_worker, int n_workers,
+                       long long* max_items, long long* total) {
+  long long tot = 0, mx = 0;
+  for (int k = 0; k < n_workers; ++k) {
+    if (n_per_worker[k] <= 0)
+      return fail(DSGD_EINVAL, "worker %d has an empty sample list: Vec.sum requires a non-empty list", k);
+    if (!idx_per_worker[k]) return fail(DSGD_EINVAL, "null index list for worker %d", k);
+    tot += n_per_worker[k];
+    mx = std::max<long long>(mx, n_per_worker[k]);
+  }
+  DSGD_TRY(ensure_idx(c, tot));
+  std::vector<WorkSeg> segs(n_workers);
+  long long off = 0;
+  // the previous step's kernels may still be reading d_idx
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < n_workers; ++k) {
+    HIP_TRY(hipMemcpy(c->d_idx + off, idx_per_worker[k], sizeof(int) * (size_t)n_per_worker[k], hipMemcpyHostToDevice));
+    segs[k].begin = off;
+    segs[k].end = off + n_per_worker[k];
+    off += n_per_worker[k];
+  }
+  DSGD_TRY(upload_segs(c, segs));
+  *max_items = mx;
+  *total = tot;
+  return DSGD_OK;
+}
+
+int dsgd_gradient(dsgd_ctx* c, const float* w, const int32_t* idx, int64_t n, float* g_out, dsgd_batch_stats* stats) {
+  DSGD_TRY(check_ctx(c));
+  if (!g_out) return fail(DSGD_EINVAL, "null g_out");
+  if (n <= 0 || !idx) return fail(DSGD_EINVAL, "Cannot sum an empty list of vectors");  // ref: math/Vec.scala:129
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(require_data(c));
+  DSGD_TRY(require_ds(c));
+  if (w) DSGD_TRY(set_weights_locked(c, w));
+  DSGD_TRY(ensure_s(c));
+  DSGD_TRY(reset_counters(c));
+  long long mx = 0, tot = 0;
+  const int64_t nn = n;
+  DSGD_TRY(stage_lists(c, &idx, &nn, 1, &mx, &tot));
+  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, 1, mx));
+  hipLaunchKernelGGL(dsgd_regularize_kernel, dim3((c->dp + 1023) / 1024, 1), dim3(1024), 0, c->stream, c->d_g,
+                     (long long)c->dp, c->dp, c->d_sc);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(g_out, c->d_g, sizeof(float) * c->dp, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_g, 0, sizeof(float) * c->dp, c->stream));
+  DSGD_TRY(read_scalars(c));
+  DSGD_TRY(prof_collect(c));
+  DSGD_TRY(check_err_flag(c));
+  if (stats) {
+    stats->n_samples = n;
+    stats->n_active = (int64_t)c->h_sc->n_active;
+  }
+  return DSGD_OK;
+}
+
+int dsgd_apply(dsgd_ctx* c, const float* g_mean, float lr) {
+  DSGD_TRY(check_ctx(c));
+  if (!g_mean) return fail(DSGD_EINVAL, "null g_mean");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(require_ds(c));
+  HIP_TRY(hipMemcpyAsync(c->d_gsum, g_mean, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(dsgd_apply_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_gsum, c->d_gsum,
+                     (long long)c->dp, 1, c->dp, c->d_ds, 1.0f, lr, (float)c->cfg.lambda, c->d_sc);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->s_dirty = false;
+  return DSGD_OK;
+}
+
+static int finish_stats(dsgd_ctx* c, dsgd_batch_stats* stats, long long total) {
+  DSGD_TRY(read_scalars(c));
+  DSGD_TRY(prof_collect(c));
+  DSGD_TRY(check_err_flag(c));
+  if (stats) {
+    stats->n_samples = total;
+    stats->n_active = (int64_t)c->h_sc->n_active;
+  }
+  return DSGD_OK;
+}
+
+int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int64_t* n_per_worker, int32_t n_workers,
+                   float lr, dsgd_batch_stats* stats) {
+  DSGD_TRY(check_ctx(c));
+  if (n_workers < 1 || !idx_per_worker || !n_per_worker) return fail(DSGD_EINVAL, "need at least one worker");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(require_data(c));
+  DSGD_TRY(require_ds(c));
+  DSGD_TRY(ensure_g(c, n_workers));
+  DSGD_TRY(ensure_s(c));
+  DSGD_TRY(reset_counters(c));
+  long long mx = 0, tot = 0;
+  DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
+  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, n_workers, mx));
+  DSGD_TRY(launch_finish_sync(c, n_workers, lr));
+  return finish_stats(c, stats, tot);
+}
+
+static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* row_end, int n_workers, float lr,
+                          long long* total) {
+  if (n_workers < 1 || !row_begin || !row_end) return fail(DSGD_EINVAL, "need at least one worker");
+  DSGD_TRY(require_data(c));
+  DSGD_TRY(require_ds(c));
+  std::vector<WorkSeg> segs(n_workers);
+  long long mx = 0, tot = 0;
+  for (int k = 0; k < n_workers; ++k) {
+    if (row_end[k] <= row_begin[k])
+      return fail(DSGD_EINVAL, "worker %d has an empty row range: Vec.sum requires a non-empty list", k);
+    if (row_begin[k] < 0 || row_end[k] > c->n_rows)
+      return fail(DSGD_ERANGE, "worker %d range [%lld, %lld) outside the %lld loaded rows", k, (long long)row_begin[k],
+                  (long long)row_end[k], c->n_rows);
+    segs[k].begin = row_begin[k];
+    segs[k].end = row_end[k];
+    mx = std::max<long long>(mx, row_end[k] - row_begin[k]);
+    tot += row_end[k] - row_begin[k];
+  }
+  DSGD_TRY(ensure_g(c, n_workers));
+  DSGD_TRY(upload_segs(c, segs));
+  DSGD_TRY(ensure_s(c));
+  DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx));
+  DSGD_TRY(launch_finish_sync(c, n_workers, lr));
+  *total = tot;
+  return DSGD_OK;
+}
+
+int dsgd_sync_step_ranges(dsgd_ctx* c, const int64_t* row_begin, const int64_t* row_end, int32_t n_workers, float lr,
+                          dsgd_batch_stats* stats) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(reset_counters(c));
+  long long tot = 0;
+  DSGD_TRY(ranges_enqueue(c, row_begin, row_end, n_workers, lr, &tot));
+  return finish_stats(c, stats, tot);
+}
+
+int dsgd_sync_step_ranges_async(dsgd_ctx* c, const int64_t* row_begin, const int64_t* row_end, int32_t n_workers,
+                                float lr) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  long long tot = 0;
+  DSGD_TRY(ranges_enqueue(c, row_begin, row_end, n_workers, lr, &tot));
+  c->pending_samples += tot;
+  return DSGD_OK;
+}
+
+int dsgd_synchronize(dsgd_ctx* c, dsgd_batch_stats* stats) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(read_scalars(c));
+  DSGD_TRY(prof_collect(c));
+  const long long act = (long long)c->h_sc->n_active;
+  const int err = c->h_sc->err;
+  DSGD_TRY(reset_counters(c));
+  if (err) return fail(DSGD_ERANGE, "sample index / key outside the loaded data");
+  if (stats) {
+    stats->n_active = act;
+    stats->n_samples = c->pending_samples;
+  }
+  c->pending_samples = 0;
+  return DSGD_OK;
+}
+
+int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, int64_t n_steps, int32_t n_workers,
+                     dsgd_plan** out) {
+  DSGD_TRY(check_ctx(c));
+  if (!idx || !offsets || !out || n_steps < 1 || n_workers < 1) return fail(DSGD_EINVAL, "bad plan arguments");
+  const int64_t n_lists = n_steps * n_workers;
+  if (offsets[0] != 0) return fail(DSGD_EINVAL, "offsets[0] must be 0");
+  long long mx = 0;
+  for (int64_t i = 0; i < n_lists; ++i) {
+    if (offsets[i + 1] <= offsets[i])
+      return fail(DSGD_EINVAL, "list %lld is empty: Vec.sum requires a non-empty list", (long long)i);
+    mx = std::max<long long>(mx, offsets[i + 1] - offsets[i]);
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  dsgd_plan* p = new (std::nothrow) dsgd_plan();
+  if (!p) return fail(DSGD_ENOMEM, "out of host memory");
+  p->n_steps = n_steps;
+  p->n_workers = n_workers;
+  p->max_items = mx;
+  p->offsets.assign(offsets, offsets + n_lists + 1);
+  std::vector<WorkSeg> segs((size_t)n_lists);
+  for (int64_t i = 0; i < n_lists; ++i) {
+    segs[i].begin = offsets[i];
+    segs[i].end = offsets[i + 1];
+  }
+  hipError_t e = hipMalloc(&p->d_idx, sizeof(int) * (size_t)offsets[n_lists]);
+  if (e == hipSuccess) e = hipMalloc(&p->d_segs, sizeof(WorkSeg) * (size_t)n_lists);
+  if (e == hipSuccess) e = hipMemcpy(p->d_idx, idx, sizeof(int) * (size_t)offsets[n_lists], hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->d_segs, segs.data(), sizeof(WorkSeg) * (size_t)n_lists, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    hipFree(p->d_idx);
+    hipFree(p->d_segs);
+    delete p;
+    return fail(DSGD_EHIP, "plan upload: %s", hipGetErrorString(e));
+  }
+  *out = p;
+  return DSGD_OK;
+}
+
+int dsgd_plan_destroy(dsgd_ctx* c, dsgd_plan* p) {
+  DSGD_TRY(check_ctx(c));
+  if (!p) return DSGD_OK;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  hipFree(p->d_idx);
+  hipFree(p->d_segs);
+  delete p;
+  return DSGD_OK;
+}
+
+int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_end, float lr) {
+  DSGD_TRY(check_ctx(c));
+  if (!p) return fail(DSGD_EINVAL, "null plan");
+  if (step_begin < 0 || step_end > p->n_steps || step_end < step_begin)
+    return fail(DSGD_EINVAL, "steps [%lld, %lld) outside the plan's %lld steps", (long long)step_begin, (long long)step_end,
+                p->n_steps);
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(require_data(c));
+  DSGD_TRY(require_ds(c));
+  DSGD_TRY(ensure_g(c, p->n_workers));
+  DSGD_TRY(ensure_s(c));
+  for (int64_t s = step_begin; s < step_end; ++s) {
+    const WorkSeg* segs = p->d_segs + s * p->n_workers;
+    long long mx = 0;
+    for (int k = 0; k < p->n_workers; ++k)
+      mx = std::max<long long>(mx, p->offsets[s * p->n_workers + k + 1] - p->offsets[s * p->n_workers + k]);
+    DSGD_TRY(launch_grad(c, p->d_idx, segs, p->n_workers, mx));
+    DSGD_TRY(launch_finish_sync(c, p->n_workers, lr));
+    c->pending_samples += p->offsets[(s + 1) * p->n_workers] - p->offsets[s * p->n_workers];
+  }
+  return DSGD_OK;
+}
+
+int dsgd_forward(dsgd_ctx* c, const float* w, const int32_t* idx, int64_t n, float* pred_out) {
+  DSGD_TRY(check_ctx(c));
+  if (n < 0 || (n > 0 && (!idx || !pred_out))) return fail(DSGD_EINVAL, "bad forward arguments");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(require_data(c));
+  if (w) DSGD_TRY(set_weights_locked(c, w));
+  if (n == 0) return DSGD_OK;  // samplesIdx.map over an empty Seq is an empty reply (ref: core/Slave.scala:133)
+  DSGD_TRY(ensure_idx(c, n));
+  DSGD_TRY(reset_counters(c));
+  float* d_pred = nullptr;
+  HIP_TRY(hipMalloc(&d_pred, sizeof(float) * (size_t)n));
+  HIP_TRY(hipMemcpyAsync(c->d_idx, idx, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  const int G = c->group;
+  dim3 grid(grid_for(c, n, G));
+  CsrView m = view(c);
+  switch (G) {
+    case 64: hipLaunchKernelGGL(dsgd_forward_kernel<64>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_idx, (long long)n, d_pred, c->d_sc); break;
+    case 32: hipLaunchKernelGGL(dsgd_forward_kernel<32>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_idx, (long long)n, d_pred, c->d_sc); break;
+    case 16: hipLaunchKernelGGL(dsgd_forward_kernel<16>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_idx, (long long)n, d_pred, c->d_sc); break;
+    default: hipLaunchKernelGGL(dsgd_forward_kernel<8>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_idx, (long long)n, d_pred, c->d_sc); break;
+  }
+  hipError_t le = hipGetLastError();
+  if (le == hipSuccess) le = hipMemcpyAsync(pred_out, d_pred, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  int rc = read_scalars(c);
+  hipFree(d_pred);
+  if (le != hipSuccess) return fail(DSGD_EHIP, "forward: %s", hipGetErrorString(le));
+  DSGD_TRY(rc);
+  return check_err_flag(c);
+}
+
+int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_end, double* loss, double* acc,
+                  int64_t* counts) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(require_data(c));
+  DSGD_TRY(require_ds(c));
+  if (row_end <= row_begin)  // samples.map(...).reduce on an empty collection throws (ref: SparseSVM.scala:21-23)
+    return fail(DSGD_EINVAL, "empty row range: reduce on an empty sample list");
+  if (row_begin < 0 || row_end > c->n_rows)
+    return fail(DSGD_ERANGE, "rows [%lld, %lld) outside the %lld loaded rows", (long long)row_begin, (long long)row_end, c->n_rows);
+  if (w) DSGD_TRY(set_weights_locked(c, w));
+  DSGD_TRY(ensure_s(c));  // also refreshes |w|^2
+  DSGD_TRY(reset_counters(c));
+  const int G = c->group;
+  dim3 grid(grid_for(c, row_end - row_begin, G));
+  CsrView m = view(c);
+  switch (G) {
+    case 64: hipLaunchKernelGGL(dsgd_eval_kernel<64>, grid, dim3(256), 0, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc); break;
+    case 32: hipLaunchKernelGGL(dsgd_eval_kernel<32>, grid, dim3(256), 0, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc); break;
+    case 16: hipLaunchKernelGGL(dsgd_eval_kernel<16>, grid, dim3(256), 0, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc); break;
+    default: hipLaunchKernelGGL(dsgd_eval_kernel<8>, grid, dim3(256), 0, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc); break;
+  }
+  HIP_TRY(hipGetLastError());
+  long long tallies[4] = {0, 0, 0, 0};
+  if (c->comm) {
+    // shard-wise evaluation: three tallies + row count summed over ranks
+    RCCL_TRY(rccl::AllReduce(c->d_sc->counts, c->d_sc->counts, 4, rccl::kInt64, rccl::kSum, c->comm, c->stream));
+  }
+  DSGD_TRY(read_scalars(c));
+  for (int i = 0; i < 4; ++i) tallies[i] = (long long)c->h_sc->counts[i];
+  const double n = (double)tallies[3];
+  if (loss) *loss = c->cfg.lambda * (double)c->h_sc->wnorm2 + ((double)tallies[1] + 2.0 * (double)tallies[2]) / n;
+  if (acc) *acc = (double)tallies[0] / n;
+  if (counts) {
+    counts[0] = tallies[0];
+    counts[1] = tallies[1];
+    counts[2] = tallies[2];
+  }
+  return DSGD_OK;
+}
+
+int dsgd_async_step(dsgd_ctx* c, const int32_t* idx, int64_t n, float lr, float* delta_out, dsgd_batch_stats* stats) {
+  DSGD_TRY(check_ctx(c));
+  if (n <= 0 || !idx) return fail(DSGD_EINVAL, "Cannot sum an empty list of vectors");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(require_data(c));
+  DSGD_TRY(require_ds(c));
+  DSGD_TRY(ensure_s(c));
+  DSGD_TRY(reset_counters(c));
+  long long mx = 0, tot = 0;
+  const int64_t nn = n;
+  DSGD_TRY(stage_lists(c, &idx, &nn, 1, &mx, &tot));
+  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, 1, mx));
+  hipLaunchKernelGGL(dsgd_async_finish_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_g, c->dp, c->d_ds, (float)n,
+                     lr, (float)c->cfg.lambda, delta_out ? c->d_tmp : (float*)nullptr, c->d_sc);
+  HIP_TRY(hipGetLastError());
+  c->s_dirty = false;
+  if (delta_out) HIP_TRY(hipMemcpyAsync(delta_out, c->d_tmp, sizeof(float) * c->dp, hipMemcpyDeviceToHost, c->stream));
+  return finish_stats(c, stats, tot);
+}
+
+int dsgd_update_grad(dsgd_ctx* c, const int32_t* key, const float* dv, int64_t nnz) {
+  DSGD_TRY(check_ctx(c));
+  if (nnz < 0 || (nnz > 0 && (!key || !dv))) return fail(DSGD_EINVAL, "bad update arguments");
+  if (nnz == 0) return DSGD_OK;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  int* d_key = nullptr;
+  float* d_dv = nullptr;
+  HIP_TRY(hipMalloc(&d_key, sizeof(int) * (size_t)nnz));
+  hipError_t e = hipMalloc(&d_dv, sizeof(float) * (size_t)nnz);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_key, key, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_dv, dv, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    reset_counters(c);
+    int blocks = (int)std::min<long long>((nnz + 255) / 256, 2048);
+    hipLaunchKernelGGL(dsgd_update_grad_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_w, d_key, d_dv, (long long)nnz,
+                       c->dp, c->d_sc);
+    hipLaunchKernelGGL(dsgd_filter_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, c->d_w, c->dp);
+    e = hipGetLastError();
+  }
+  int rc = read_scalars(c);
+  hipFree(d_key);
+  hipFree(d_dv);
+  c->s_dirty = true;
+  if (e != hipSuccess) return fail(DSGD_EHIP, "update_grad: %s", hipGetErrorString(e));
+  DSGD_TRY(rc);
+  return check_err_flag(c);
+}
+
+// ---- Hogwild persistent engine: implemented in round 1 part 2 -----------------------------------
+int dsgd_async_start(dsgd_ctx* c, const int64_t*, const int64_t*, int32_t, int32_t, float, int64_t, uint64_t, int32_t) {
+  DSGD_TRY(check_ctx(c));
+  return fail(DSGD_EUNSUPPORTED, "persistent Hogwild engine not built into this library version");
+}
+int dsgd_async_updates(dsgd_ctx* c, int64_t*, int32_t*) {
+  DSGD_TRY(check_ctx(c));
+  return fail(DSGD_EUNSUPPORTED, "persistent Hogwild engine not built into this library version");
+}
+int dsgd_async_stop(dsgd_ctx* c) {
+  DSGD_TRY(check_ctx(c));
+  return fail(DSGD_EUNSUPPORTED, "persistent Hogwild engine not built into this library version");
+}
+int dsgd_async_wait(dsgd_ctx* c) {
+  DSGD_TRY(check_ctx(c));
+  return fail(DSGD_EUNSUPPORTED, "persistent Hogwild engine not built into this library version");
+}
+
+int dsgd_comm_unique_id(char* id_out) {
+  if (!id_out) return fail(DSGD_EINVAL, "null id_out");
+  if (!rccl::available()) return fail(DSGD_ERCCL, "librccl could not be loaded: %s", dlerror());
+  rccl::unique_id_t id;
+  RCCL_TRY(rccl::GetUniqueId(&id));
+  memcpy(id_out, id.internal, DSGD_UNIQUE_ID_BYTES);
+  return DSGD_OK;
+}
+
+int dsgd_comm_init(dsgd_ctx* c, const char* unique_id, int32_t world_size, int32_t rank) {
+  DSGD_TRY(check_ctx(c));
+  if (!unique_id || world_size < 1 || rank < 0 || rank >= world_size) return fail(DSGD_EINVAL, "bad communicator arguments");
+  if (!rccl::available()) return fail(DSGD_ERCCL, "librccl could not be loaded");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  if (c->comm) return fail(DSGD_ESTATE, "communicator already attached");
+  rccl::unique_id_t id;
+  memcpy(id.internal, unique_id, DSGD_UNIQUE_ID_BYTES);
+  RCCL_TRY(rccl::CommInitRank(&c->comm, world_size, id, rank));
+  c->world = world_size;
+  c->rank = rank;
+  return DSGD_OK;
+}
+
+int dsgd_comm_destroy(dsgd_ctx* c) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  if (!c->comm) return DSGD_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  RCCL_TRY(rccl::CommDestroy(c->comm));
+  c->comm = nullptr;
+  c->world = 1;
+  c->rank = 0;
+  return DSGD_OK;
+}
+
+int dsgd_prof_enable(dsgd_ctx* c, int32_t on) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  DSGD_TRY(prof_collect(c));
+  c->prof = on != 0;
+  return DSGD_OK;
+}
+
+int dsgd_prof_read(dsgd_ctx* c, double* ms_avg, int64_t* n_launches, int32_t reset) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  DSGD_TRY(prof_collect(c));
+  if (ms_avg) *ms_avg = c->prof_n ? c->prof_ms / (double)c->prof_n : 0.0;
+  if (n_launches) *n_launches = c->prof_n;
+  if (reset) {
+    c->prof_ms = 0.0;
+    c->prof_n = 0;
+  }
+  return DSGD_OK;
+}
+
+const char* dsgd_grad_kernel_name(dsgd_ctx* c) {
+  if (!c) return "";
+  switch (c->group) {
+    case 64: return "dsgd_grad_rows_kernel<64>";
+    case 32: return "dsgd_grad_rows_kernel<32>";
+    case 16: return "dsgd_grad_rows_kernel<16>";
+    default: return "dsgd_grad_rows_kernel<8>";
+  }
+}
+
+int dsgd_device_ptrs(dsgd_ctx* c, void** w_dev, void** g_dev, void** stream) {
+  DSGD_TRY(check_ctx(c));
+  if (w_dev) *w_dev = c->d_w;
+  if (g_dev) *g_dev = c->d_gsum;
+  if (stream) *stream = c->stream;
+  return DSGD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,223 @@
+"""Engine: one libdsgd_hip context (one MI355X) as a Python object.
+
+Thin, typed face over the C ABI of include/dsgd.h; all arithmetic happens in the HIP library.
+Dense vectors are numpy float32 arrays of D+1 slots indexed by key (see include/dsgd.h).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BatchStats, Config, check, f32, i32, ptr
+
+
+class Plan:
+    """Resident schedule of index lists (steps x workers); see dsgd_plan_create."""
+
+    def __init__(self, engine, handle, n_steps, n_workers, n_samples):
+        self.engine, self.handle, self.n_steps, self.n_workers, self.n_samples = engine, handle, n_steps, n_workers, n_samples
+
+    def destroy(self):
+        if self.handle:
+            check(_lib.load().dsgd_plan_destroy(self.engine._ctx, self.handle))
+            self.handle = None
+
+
+class Engine:
+    def __init__(self, n_features, lam, device=0, flags=0):
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        self.dim = int(n_features)
+        self.dp = self.dim + 1
+        self.lam = float(lam)
+        cfg = Config(self.dim, int(device), self.lam, int(flags), 0)
+        check(self._lib.dsgd_create(C.byref(cfg), C.byref(self._ctx)))
+        self.n_rows = 0
+        self.nnz = 0
+
+    # -- lifecycle -----------------------------------------------------------------------------
+    def close(self):
+        if self._ctx:
+            self._lib.dsgd_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data ------------------------------------------------------------------------------------
+    def load_csr(self, row_ptr, col, val, label):
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        col = i32(col)
+        val = f32(val)
+        label = np.ascontiguousarray(label, dtype=np.int8)
+        n_rows = len(row_ptr) - 1
+        if len(label) != n_rows:
+            raise ValueError("label has %d entries for %d rows" % (len(label), n_rows))
+        if n_rows >= 1 and (len(col) < row_ptr[-1] or len(val) < row_ptr[-1]):
+            raise ValueError("col/val shorter than row_ptr[-1]")
+        check(self._lib.dsgd_load_csr(self._ctx, C.c_int64(n_rows), ptr(row_ptr), ptr(col), ptr(val), ptr(label)))
+        self.n_rows, self.nnz = n_rows, int(row_ptr[-1])
+
+    def set_dim_sparsity(self, ds):
+        check(self._lib.dsgd_set_dim_sparsity(self._ctx, ptr(f32(ds, self.dp))))
+
+    def build_dim_sparsity(self, n_train):
+        out = np.zeros(self.dp, dtype=np.float32)
+        check(self._lib.dsgd_build_dim_sparsity(self._ctx, C.c_int64(n_train), ptr(out)))
+        return out
+
+    def set_weights(self, w):
+        check(self._lib.dsgd_set_weights(self._ctx, ptr(f32(w, self.dp))))
+
+    def get_weights(self):
+        out = np.zeros(self.dp, dtype=np.float32)
+        check(self._lib.dsgd_get_weights(self._ctx, ptr(out)))
+        return out
+
+    # -- synchronous path ------------------------------------------------------------------------
+    def gradient(self, idx, w=None):
+        idx = i32(idx)
+        g = np.zeros(self.dp, dtype=np.float32)
+        st = BatchStats()
+        wv = None if w is None else f32(w, self.dp)
+        check(self._lib.dsgd_gradient(self._ctx, ptr(wv), ptr(idx), C.c_int64(len(idx)), ptr(g), C.byref(st)))
+        return g, {"n_samples": st.n_samples, "n_active": st.n_active}
+
+    def apply(self, g_mean, lr):
+        check(self._lib.dsgd_apply(self._ctx, ptr(f32(g_mean, self.dp)), C.c_float(lr)))
+
+    def sync_step(self, idx_per_worker, lr):
+        lists = [i32(a) for a in idx_per_worker]
+        k = len(lists)
+        ptrs = (C.c_void_p * max(k, 1))(*[ptr(a) for a in lists])
+        ns = (C.c_int64 * max(k, 1))(*[len(a) for a in lists])
+        st = BatchStats()
+        check(self._lib.dsgd_sync_step(self._ctx, ptrs, ns, C.c_int32(k), C.c_float(lr), C.byref(st)))
+        return {"n_samples": st.n_samples, "n_active": st.n_active}
+
+    def sync_step_ranges(self, ranges, lr, asynchronous=False):
+        k = len(ranges)
+        rb = (C.c_int64 * max(k, 1))(*[int(r[0]) for r in ranges])
+        re_ = (C.c_int64 * max(k, 1))(*[int(r[1]) for r in ranges])
+        if asynchronous:
+            check(self._lib.dsgd_sync_step_ranges_async(self._ctx, rb, re_, C.c_int32(k), C.c_float(lr)))
+            return None
+        st = BatchStats()
+        check(self._lib.dsgd_sync_step_ranges(self._ctx, rb, re_, C.c_int32(k), C.c_float(lr), C.byref(st)))
+        return {"n_samples": st.n_samples, "n_active": st.n_active}
+
+    def synchronize(self):
+        st = BatchStats()
+        check(self._lib.dsgd_synchronize(self._ctx, C.byref(st)))
+        return {"n_samples": st.n_samples, "n_active": st.n_active}
+
+    def plan(self, steps):
+        """steps: list (per step) of lists (per worker) of index arrays."""
+        n_steps = len(steps)
+        n_workers = len(steps[0]) if n_steps else 0
+        flat, offs = [], [0]
+        for s in steps:
+            if len(s) != n_workers:
+                raise ValueError("every step needs the same number of workers")
+            for a in s:
+                a = i32(a)
+                flat.append(a)
+                offs.append(offs[-1] + len(a))
+        idx = np.concatenate(flat) if flat else np.zeros(0, np.int32)
+        offsets = np.asarray(offs, dtype=np.int64)
+        h = C.c_void_p()
+        check(self._lib.dsgd_plan_create(self._ctx, ptr(idx), ptr(offsets), C.c_int64(n_steps), C.c_int32(n_workers), C.byref(h)))
+        return Plan(self, h, n_steps, n_workers, int(offsets[-1]))
+
+    def plan_run(self, plan, step_begin, step_end, lr):
+        check(self._lib.dsgd_plan_run(self._ctx, plan.handle, C.c_int64(step_begin), C.c_int64(step_end), C.c_float(lr)))
+
+    # -- evaluation --------------------------------------------------------------------------------
+    def forward(self, idx, w=None):
+        idx = i32(idx)
+        pred = np.zeros(len(idx), dtype=np.float32)
+        wv = None if w is None else f32(w, self.dp)
+        check(self._lib.dsgd_forward(self._ctx, ptr(wv), ptr(idx), C.c_int64(len(idx)), ptr(pred)))
+        return pred
+
+    def loss_acc(self, row_begin, row_end, w=None):
+        loss, acc = C.c_double(0), C.c_double(0)
+        counts = (C.c_int64 * 3)()
+        wv = None if w is None else f32(w, self.dp)
+        check(self._lib.dsgd_loss_acc(self._ctx, ptr(wv), C.c_int64(row_begin), C.c_int64(row_end), C.byref(loss), C.byref(acc), counts))
+        return loss.value, acc.value, list(counts)
+
+    # -- asynchronous path -------------------------------------------------------------------------
+    def async_step(self, idx, lr, want_delta=False):
+        idx = i32(idx)
+        delta = np.zeros(self.dp, dtype=np.float32) if want_delta else None
+        st = BatchStats()
+        check(self._lib.dsgd_async_step(self._ctx, ptr(idx), C.c_int64(len(idx)), C.c_float(lr), ptr(delta), C.byref(st)))
+        return delta, {"n_samples": st.n_samples, "n_active": st.n_active}
+
+    def update_grad(self, keys, values):
+        keys, values = i32(keys), f32(values)
+        if len(keys) != len(values):
+            raise ValueError("keys / values length mismatch")
+        check(self._lib.dsgd_update_grad(self._ctx, ptr(keys), ptr(values), C.c_int64(len(keys))))
+
+    def async_start(self, assigned_ranges, batch, lr, max_updates, seed=0, positional_bug=True):
+        k = len(assigned_ranges)
+        rb = (C.c_int64 * max(k, 1))(*[int(r[0]) for r in assigned_ranges])
+        re_ = (C.c_int64 * max(k, 1))(*[int(r[1]) for r in assigned_ranges])
+        check(self._lib.dsgd_async_start(self._ctx, rb, re_, C.c_int32(k), C.c_int32(batch), C.c_float(lr),
+                                         C.c_int64(max_updates), C.c_uint64(seed), C.c_int32(1 if positional_bug else 0)))
+
+    def async_updates(self):
+        n, running = C.c_int64(0), C.c_int32(0)
+        check(self._lib.dsgd_async_updates(self._ctx, C.byref(n), C.byref(running)))
+        return n.value, bool(running.value)
+
+    def async_stop(self):
+        check(self._lib.dsgd_async_stop(self._ctx))
+
+    def async_wait(self):
+        check(self._lib.dsgd_async_wait(self._ctx))
+
+    # -- multi-GPU ---------------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        check(_lib.load().dsgd_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, world_size, rank):
+        if len(unique_id) != _lib.UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % _lib.UNIQUE_ID_BYTES)
+        check(self._lib.dsgd_comm_init(self._ctx, C.c_char_p(unique_id), C.c_int32(world_size), C.c_int32(rank)))
+
+    def comm_destroy(self):
+        check(self._lib.dsgd_comm_destroy(self._ctx))
+
+    # -- profiling ---------------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        check(self._lib.dsgd_prof_enable(self._ctx, C.c_int32(1 if on else 0)))
+
+    def prof_read(self, reset=True):
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(self._lib.dsgd_prof_read(self._ctx, C.byref(ms), C.byref(n), C.c_int32(1 if reset else 0)))
+        return ms.value, n.value
+
+    def grad_kernel_name(self):
+        return self._lib.dsgd_grad_kernel_name(self._ctx).decode()
+
+
+def device_count():
+    return _lib.load().dsgd_device_count()

@@ -1,0 +1,202 @@
+/*
+ * dsgd.h -- C ABI of libdsgd_hip: the MI355X (gfx950) engine for the hot path of
+ * zifeo/distributed-sgd (sparse-SVM gradient step, synchronous aggregate+update,
+ * asynchronous "Hogwild" update, prediction and loss/accuracy evaluation).
+ *
+ * The reference has NO native/FFI interface (it is 100 % Scala on the JVM); this header is the
+ * boundary the new engine introduces behind the reference's natural seams.  Every entry point
+ * names the reference code whose body it replaces; citations are relative to
+ * /root/reference/src/main/scala/epfl/distributed/ unless they start with "proto.proto"
+ * (src/main/protobuf/proto.proto).  The JNI / ctypes stubs a maintainer would add on the
+ * reference side are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross the boundary
+ *   - every function returns int: 0 = DSGD_OK, < 0 = DSGD_E*; nothing throws or aborts.
+ *     dsgd_last_error() returns a thread-local message for the last failing call.
+ *     (The JNI shim maps DSGD_EINVAL / DSGD_ERANGE to IllegalArgumentException /
+ *     IndexOutOfBoundsException -- what `require` at math/Vec.scala:129 and
+ *     math/Sparse.scala:16,63 throw -- and the rest to RuntimeException.)
+ *   - dense vectors (w, g, ds, delta) have n_features + 1 float slots indexed by KEY: feature
+ *     ids are 1-based (utils/Dataset.scala:30 uses the file's ids as map keys), the
+ *     dimSparsity vector uses 0-based keys (Main.scala:60-62), so slot 0 and slot D both exist.
+ *     "absent from the map" == 0.0f.
+ *   - host buffers are owned by the caller; the library copies in / out.  Pointers ending in
+ *     `_dev` are device pointers (HIP) on the context's device.
+ *   - a context may be called from several host threads (the reference calls its model from an
+ *     8-thread pool, utils/Pool.scala:13); calls on one context are serialised internally.
+ *   - arithmetic is IEEE fp32 on the device ("fp32 CSR-SpMV gradient kernel" of BASELINE.json);
+ *     the reference is fp64.  Stated tolerance: tests/test_gpu_parity.py.
+ */
+#ifndef DSGD_H
+#define DSGD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSGD_ABI_VERSION 1
+
+enum {
+  DSGD_OK = 0,
+  DSGD_EINVAL = -1,       /* bad argument / a reference `require` would have failed            */
+  DSGD_ERANGE = -2,       /* sample index outside the loaded data                              */
+  DSGD_ESTATE = -3,       /* call order: no data loaded, async already running, ...            */
+  DSGD_EHIP = -4,         /* HIP runtime error (message has hipGetErrorString)                 */
+  DSGD_ERCCL = -5,        /* RCCL error                                                        */
+  DSGD_ENOMEM = -6,
+  DSGD_EUNSUPPORTED = -7  /* no gfx950 device / feature not available                          */
+};
+
+/* dsgd_config.flags */
+#define DSGD_F_DEFAULT 0u
+#define DSGD_F_NO_GRAPH 1u /* never capture step chains into hipGraphs (debugging)               */
+
+typedef struct dsgd_ctx dsgd_ctx;
+
+typedef struct {
+  int32_t n_features; /* D; 47236 for RCV1 (utils/Dataset.scala:16)                              */
+  int32_t device;     /* HIP device ordinal                                                      */
+  double lambda;      /* SparseSVM.lambda (core/ml/SparseSVM.scala:11; application.conf:21)      */
+  uint32_t flags;
+  uint32_t reserved;
+} dsgd_config;
+
+/* counters a batch call reports back (the reference increments Kamon counters per SAMPLE:
+ * core/Slave.scala:131,145,90 -- the host side does counter.increment(n_samples)) */
+typedef struct {
+  int64_t n_samples;  /* rows whose gradient / prediction was computed                          */
+  int64_t n_active;   /* rows with y * (x . w) >= 0 (core/ml/SparseSVM.scala:27-28)             */
+} dsgd_batch_stats;
+
+int dsgd_abi_version(void);
+const char* dsgd_last_error(void);
+/* number of visible gfx950 devices (0 if none / no HIP runtime) */
+int dsgd_device_count(void);
+
+/* ---- lifecycle: replaces `new SparseSVM(lambda, dimSparsity)` + the data array handed to
+ *      `new Slave(node, master, data, model, async)` (Main.scala:68,138,148-149) ------------- */
+int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out);
+int dsgd_destroy(dsgd_ctx* ctx);
+
+/* data: Array[(Vec, Int)] (utils/Dataset.scala:11) as CSR.  col ids 1-based ascending per row,
+ * label +1/-1.  Copied to HBM once; resident afterwards.  Indices in later calls refer to it,
+ * exactly as GradientRequest.samples / ForwardRequest.samples index Slave.data
+ * (core/Slave.scala:134,149; proto.proto:51-63). */
+int dsgd_load_csr(dsgd_ctx* ctx, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_1based, const float* val,
+                  const int8_t* label);
+int dsgd_n_rows(dsgd_ctx* ctx, int64_t* n_rows, int64_t* nnz);
+
+/* SparseSVM.dimSparsity: either given (dense, 0-based keys as Main.scala:62 builds them) ...  */
+int dsgd_set_dim_sparsity(dsgd_ctx* ctx, const float* ds /* D+1 */);
+/* ... or built on the device from rows [0, n_train) exactly as Main.scala:54-65 does
+ * (including the off-by-one: count of feature f lands on key f-1).  ds_out may be NULL.       */
+int dsgd_build_dim_sparsity(dsgd_ctx* ctx, int64_t n_train, float* ds_out /* D+1 or NULL */);
+
+/* resident weights (GradState.grad holds the WEIGHTS: core/ml/GradState.scala:6-10)           */
+int dsgd_set_weights(dsgd_ctx* ctx, const float* w /* D+1 */);
+int dsgd_get_weights(dsgd_ctx* ctx, float* w_out /* D+1 */);
+
+/* ---- synchronous path ----------------------------------------------------------------------
+ * SlaveImpl.gradient (core/Slave.scala:142-157): g = regularize(sum_i backward(w, x_i, y_i), w).
+ * w == NULL uses the resident weights (no transfer); otherwise w (D+1 floats) replaces them,
+ * like the full `weights` every GradientRequest carries (proto.proto:60-63).
+ * n == 0 fails with DSGD_EINVAL (Vec.sum requires a non-empty list, math/Vec.scala:129).      */
+int dsgd_gradient(dsgd_ctx* ctx, const float* w, const int32_t* idx, int64_t n, float* g_out /* D+1 */,
+                  dsgd_batch_stats* stats /* may be NULL */);
+
+/* Master.fit batch closure, update half (core/Master.scala:194-197): w <- w - lr * g_mean      */
+int dsgd_apply(dsgd_ctx* ctx, const float* g_mean /* D+1 */, float lr);
+
+/* The whole batch closure (core/Master.scala:184-197) for n_workers workers hosted by this
+ * context: per-worker regularised sums, MEAN over workers, w <- w - lr * mean.  Index lists are
+ * what `split.map(Random.shuffle(_)).slice(batch, batch + batchSize)` produced on the host.
+ * If a communicator is attached (dsgd_comm_init) the mean runs over n_workers * world_size
+ * workers with one RCCL all-reduce of the summed gradient.                    */
+int dsgd_sync_step(dsgd_ctx* ctx, const int32_t* const* idx_per_worker, const int64_t* n_per_worker,
+                   int32_t n_workers, float lr, dsgd_batch_stats* stats /* may be NULL */);
+
+/* Same, for batches that are whole contiguous row ranges (batch-size >= split size makes
+ * slice(0, B) of the shuffled split the entire split; a sum does not depend on the order).
+ * Streams the CSR rows [row_begin[k], row_end[k]) with fully coalesced reads.                  */
+int dsgd_sync_step_ranges(dsgd_ctx* ctx, const int64_t* row_begin, const int64_t* row_end, int32_t n_workers,
+                          float lr, dsgd_batch_stats* stats /* may be NULL */);
+
+/* Asynchronous launch variants: enqueue on the context's stream and return; results/errors are
+ * collected by dsgd_synchronize().  steps x workers index lists live in a resident plan so that
+ * no host->device traffic happens between steps (timed loops, hipGraph replay).                 */
+typedef struct dsgd_plan dsgd_plan;
+/* idx: concatenation of all lists; offsets: n_steps * n_workers + 1 prefix offsets into idx    */
+int dsgd_plan_create(dsgd_ctx* ctx, const int32_t* idx, const int64_t* offsets, int64_t n_steps, int32_t n_workers,
+                     dsgd_plan** out);
+int dsgd_plan_destroy(dsgd_ctx* ctx, dsgd_plan* plan);
+int dsgd_plan_run(dsgd_ctx* ctx, dsgd_plan* plan, int64_t step_begin, int64_t step_end, float lr);
+int dsgd_sync_step_ranges_async(dsgd_ctx* ctx, const int64_t* row_begin, const int64_t* row_end, int32_t n_workers,
+                                float lr);
+int dsgd_synchronize(dsgd_ctx* ctx, dsgd_batch_stats* stats_accum /* may be NULL */);
+
+/* ---- evaluation --------------------------------------------------------------------------
+ * SlaveImpl.forward (core/Slave.scala:129-140): pred_i = -signum(x_i . w) in {-1, 0, +1}       */
+int dsgd_forward(dsgd_ctx* ctx, const float* w /* or NULL */, const int32_t* idx, int64_t n, float* pred_out /* n */);
+
+/* Master.localLoss / localAccuracy (core/Master.scala:100-107; core/ml/SparseSVM.scala:16-23)
+ * over rows [row_begin, row_end): loss = lambda*|w|^2 + mean_i max(0, 1 - y_i p_i), acc =
+ * mean_i [p_i == y_i].  counts (may be NULL) gets the exact integer tallies
+ * {#p==y, #p==0, #p==-y}.  With a communicator attached, tallies are summed over ranks.        */
+int dsgd_loss_acc(dsgd_ctx* ctx, const float* w /* or NULL */, int64_t row_begin, int64_t row_end, double* loss,
+                  double* acc, int64_t* counts /* 3 or NULL */);
+
+/* ---- asynchronous ("Hogwild") path ---------------------------------------------------------
+ * one iteration of Slave.asyncTask (core/Slave.scala:92-101) on the resident weights with the
+ * given sample list: grad = MEAN_i backward; delta = lr * regularize(grad, w); w -= delta.
+ * delta_out (D+1, may be NULL) receives what Slave.scala:103-105 would gossip.                 */
+int dsgd_async_step(dsgd_ctx* ctx, const int32_t* idx, int64_t n, float lr, float* delta_out,
+                    dsgd_batch_stats* stats /* may be NULL */);
+
+/* SlaveImpl.updateGrad / MasterAsync.updateGrad / GradState.update
+ * (core/Slave.scala:177-185, core/MasterAsync.scala:164-177, core/ml/GradState.scala:8):
+ * w[key[i]] -= dv[i].  Keys as in the wire message Sparse.map (proto.proto:28-31).             */
+int dsgd_update_grad(dsgd_ctx* ctx, const int32_t* key, const float* dv, int64_t nnz);
+
+/* SlaveImpl.startAsync (core/Slave.scala:159-175) for n_workers lock-free workers sharing ONE
+ * device-resident weight vector: every worker (a workgroup) loops
+ *   draw `batch` of its assigned rows -> mean gated gradient on a snapshot -> regularize ->
+ *   atomicAdd(w[j], -lr * g_j)
+ * until dsgd_async_stop or until max_updates mini-batch updates have been applied in total
+ * (MasterAsync counts UPDATES, maxSteps = N * maxEpochs: core/MasterAsync.scala:83,171).
+ * assigned_begin/end: worker k samples rows [assigned_begin[k], assigned_end[k]) (the
+ * SplitStrategy.vanilla ranges); sampling is `shuffle take batch` (Slave.scala:87) or a single
+ * uniform draw when batch == 1 (Slave.scala:84).  positional_bug != 0 reproduces
+ * Slave.scala:87's indexing of `data` by POSITION (rows 0 .. n_k-1) instead of by assigned id. */
+int dsgd_async_start(dsgd_ctx* ctx, const int64_t* assigned_begin, const int64_t* assigned_end, int32_t n_workers,
+                     int32_t batch, float lr, int64_t max_updates, uint64_t seed, int32_t positional_bug);
+int dsgd_async_updates(dsgd_ctx* ctx, int64_t* updates, int32_t* running);
+int dsgd_async_stop(dsgd_ctx* ctx); /* SlaveImpl.stopAsync, core/Slave.scala:187-195 */
+int dsgd_async_wait(dsgd_ctx* ctx); /* block until max_updates reached */
+
+/* ---- multi-GPU (one process per GPU) ---------------------------------------
+ * The synchronous master's aggregate (core/Master.scala:190-194: Future.sequence barrier +
+ * Vec.mean) becomes ONE ncclAllReduce(sum, float, D+1) over xGMI on the context's stream.
+ * unique_id is the 128-byte ncclUniqueId produced on rank 0 and distributed by the host
+ * (torch.distributed / MPI / files).                                                           */
+#define DSGD_UNIQUE_ID_BYTES 128
+int dsgd_comm_unique_id(char* id_out /* DSGD_UNIQUE_ID_BYTES */);
+int dsgd_comm_init(dsgd_ctx* ctx, const char* unique_id, int32_t world_size, int32_t rank);
+int dsgd_comm_destroy(dsgd_ctx* ctx);
+
+/* ---- introspection for benchmarks ---------------------------------------------------------
+ * average device time (ms) of the dominant gradient kernel over its launches since the last
+ * reset, measured with HIP events on the launch stream; n_launches may be NULL.               */
+int dsgd_prof_enable(dsgd_ctx* ctx, int32_t on);
+int dsgd_prof_read(dsgd_ctx* ctx, double* grad_kernel_ms_avg, int64_t* n_launches, int32_t reset);
+/* name of the gradient kernel variant in use (for matching rocprofv3 kernel-trace rows)        */
+const char* dsgd_grad_kernel_name(dsgd_ctx* ctx);
+/* raw device pointers (float[D+1]) for hosts that own the collective (e.g. torch.distributed)  */
+int dsgd_device_ptrs(dsgd_ctx* ctx, void** w_dev, void** g_dev, void** stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSGD_H */
