@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""bench.py -- RCV1 examples/s of the synchronous SGD hot path on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one synchronous SGD step of the reference's Master.fit batch closure
+(core/Master.scala:184-197) over one batch of synthetic RCV1-like rows: per-worker gated
+sub-gradient sum + support-only regulariser (core/Slave.scala:142-157), mean over workers
+(an RCCL all-reduce when N > 1), w <- w - lr * mean.  The batch is the worker's whole train
+shard (batch-size >= split size), i.e. every step streams the resident CSR shard once --
+the configuration in which the path is HBM-bound; a batch sweep including
+the reference's default batch-size 100 is reported in "sweep".
+
+Inputs are generated on the host, uploaded once and resident in HBM before the timed region.
+Prints ONE JSON line (rank 0).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12      # B/s, spec (MI355X_MICROARCH.md "Chip-level parameters")
+HBM_MEASURED = 6.29e12  # B/s, float4-copy ceiling from the same table
+LR, LAMBDA = 0.5, 1e-5  # application.conf:18,21
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=int(os.environ.get("DSGD_BENCH_ROWS", 804414)),
+                    help="rows per GPU (804414 = RCV1 full=true, DatasetTests.scala:18)")
+    ap.add_argument("--workers", type=int, default=1, help="virtual workers (node-count share) per GPU")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for each CPU baseline leg")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+
+    # torch is plumbing only: rendezvous, barrier, the max-over-ranks reduction, cuda.synchronize
+    import torch  # imported BEFORE libdsgd_hip so the process holds exactly one HIP runtime
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    import dsgd_amd
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def sync_all(eng):
+        eng.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    t_gen = time.time()
+    data = dsgd_amd.synth.generate(args.rows, seed=args.seed, row0=rank * args.rows)
+    t_gen = time.time() - t_gen
+    n_train = int(args.rows * 0.8)  # Main.scala:52
+    nnz_train = int(data.row_ptr[n_train])
+    bytes_per_row = (8.0 * nnz_train + 12.0 * n_train) / n_train
+
+    eng = dsgd_amd.Engine(data.dim, LAMBDA, device=local_rank)
+    t_up = time.time()
+    eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+    t_up = time.time() - t_up
+    if world > 1:
+        uid = [dsgd_amd.Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(uid[0], world, rank)
+    eng.build_dim_sparsity(n_train)
+
+    k = args.workers
+    size = -(-n_train // k)
+    ranges = [(b, min(n_train, b + size)) for b in range(0, n_train, size)]  # SplitStrategy.vanilla
+
+    # ---- parity gate: must pass before any timing is reported ------------
+    parity = None
+    if rank == 0 and world == 1:
+        from oracle import oracle as orc  # checker only
+
+        n_chk = min(n_train, 50000)
+        o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, LAMBDA)
+        o.set_dim_sparsity(o.dim_sparsity(n_train))
+        w_ref = np.zeros(data.dim + 1)
+        err = 0.0
+        for _ in range(2):
+            eng.sync_step_ranges([(0, n_chk)], LR)
+            o.sync_step_range_omp(w_ref, 0, n_chk, LR)
+            w = eng.get_weights().astype(np.float64)
+            err = max(err, float(np.abs(w - w_ref).max()) / max(1.0, float(np.abs(w_ref).max())))
+            eng.set_weights(w_ref.astype(np.float32))
+        if not err <= 1e-4:
+            raise SystemExit("parity gate failed: max rel err %.3e vs the CPU oracle" % err)
+        parity = err
+    eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+
+    # ---- timed region ------------------------------------------------------------------------------
+    for _ in range(args.warmup):
+        eng.sync_step_ranges(ranges, LR, asynchronous=True)
+    sync_all(eng)
+    eng.prof_enable(True)
+    eng.prof_read(reset=True)
+    barrier()
+    sync_all(eng)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.sync_step_ranges(ranges, LR, asynchronous=True)
+    sync_all(eng)
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms, n_launch = eng.prof_read(reset=True)
+    eng.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    loss, acc, _ = eng.loss_acc(n_train, data.n_rows)
+    value = world * n_train * args.steps / dt
+
+    out = {
+        "metric": "RCV1 examples/sec (sync SGD, sparse hinge-SVM gradient step)",
+        "value": value,
+        "unit": "examples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "rcv1-synth sync SGD: %d rows/GPU (D=47236, nnz/row=%.1f), 80/20 split, whole-shard batch "
+                        "B=%d rows/GPU/step, %d worker(s)/GPU, lr=%.2f, lambda=%g" %
+                        (args.rows, data.nnz / data.n_rows, n_train, k, LR, LAMBDA),
+            "rows_per_gpu": args.rows,
+            "train_rows_per_gpu": n_train,
+            "workers_per_gpu": k,
+            "parallelism": "dp%d (row-partitioned, RCCL all-reduce of the %d-float gradient)" % (world, data.dim + 1),
+            "seed": args.seed,
+        },
+        "test_loss_after": loss,
+        "test_acc_after": acc,
+        "setup_s": {"generate": round(t_gen, 2), "upload": round(t_up, 2)},
+    }
+    if parity is not None:
+        out["parity_gate_max_rel_err"] = parity
+
+    # ---- roofline of the dominant kernel (the gradient kernel) ---------------------------------------
+    launches_per_step = n_launch / max(1, args.steps)
+    alg_bytes = bytes_per_row * n_train / max(1.0, launches_per_step)  # per launch
+    achieved = alg_bytes / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(str(args.rows))
+        except Exception:
+            traffic = None
+    out["roofline"] = {
+        "bound": "hbm",
+        "kernel": eng.grad_kernel_name(),
+        "achieved": achieved / 1e9,
+        "peak": HBM_PEAK / 1e9,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK,
+        "frac_of_measured_copy_peak": achieved / HBM_MEASURED,
+        "traffic": traffic,
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "algorithmic_bytes_per_example": bytes_per_row,
+        "kernel_ms_avg": kernel_ms,
+        "kernel_launches": n_launch,
+    }
+
+    # ---- batch sweep incl. the reference's default batch-size (N=1 only) ------------------------------
+    if rank == 0 and world == 1 and not args.no_sweep:
+        out["sweep"] = sweep(eng, n_train, bytes_per_row)
+
+    # ---- CPU baseline on this box's host cores (rank 0, N=1 only) --------------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"], out["cpu_literal"] = cpu_baseline(data, n_train, args.cpu_seconds)
+
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def sweep(eng, n_train, bytes_per_row):
+    """examples/s for index-list batches B in {100, 4096, 65536} (1 worker), resident plans."""
+    res = []
+    rng = np.random.default_rng(123)
+    for b, steps in ((100, 300), (4096, 100), (65536, 20)):
+        if b > n_train:
+            continue
+        eng.set_weights(np.zeros(eng.dp, dtype=np.float32))
+        lists = [[rng.permutation(n_train)[:b].astype(np.int32)] for _ in range(steps)]
+        plan = eng.plan(lists)
+        eng.plan_run(plan, 0, min(10, steps), LR)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        eng.plan_run(plan, 0, steps, LR)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        plan.destroy()
+        res.append({"batch": b, "steps": steps, "examples_per_s": b * steps / dt, "us_per_step": 1e6 * dt / steps,
+                    "frac_hbm_peak": b * steps / dt * bytes_per_row / HBM_PEAK})
+    return res
+
+
+def cpu_baseline(data, n_train, budget_s):
+    """The oracle timed on the host cores: (B) OpenMP CSR restatement on all cores, same whole-shard
+    step on a bounded sample; (A) literal per-sample sparse-map restatement, one thread, B=100."""
+    from oracle import oracle as orc
+
+    n_s = min(n_train, 200000)
+    sub = data.rows(0, n_s)
+    o = orc.Oracle(sub.dim, sub.row_ptr, sub.col, sub.val, sub.label, LAMBDA)
+    o.set_dim_sparsity(o.dim_sparsity(n_s))
+    w = np.zeros(sub.dim + 1)
+    o.sync_step_range_omp(w, 0, n_s, LR)  # warm
+    t0, steps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s and steps < 200:
+        o.sync_step_range_omp(w, 0, n_s, LR)
+        steps += 1
+    dt = time.perf_counter() - t0
+    fast = {
+        "value": n_s * steps / dt,
+        "unit": "examples/s",
+        "cores": orc.num_threads(),
+        "kind": "port",
+        "sample": "OpenMP CSR fp64 restatement (oracle.c orc_sync_step_range_omp): %d whole-shard steps over the "
+                  "first %d train rows of the same workload, %.1f s" % (steps, n_s, dt),
+        "host_cpus": os.cpu_count(),
+    }
+    # literal: Slave.gradient as one single-threaded request of 100 samples (core/Slave.scala:142)
+    rng = np.random.default_rng(5)
+    w = np.zeros(sub.dim + 1)
+    t0, steps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < min(budget_s, 6.0):
+        o.sync_step(w, [rng.permutation(n_s)[:100].astype(np.int32)], LR, literal=True)
+        steps += 1
+    dt = time.perf_counter() - t0
+    lit = {
+        "value": 100 * steps / dt,
+        "unit": "examples/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "literal per-sample sparse-vector restatement (oracle.c orc_lit_sync_step), 1 worker, "
+                  "batch-size 100, %d steps, %.1f s" % (steps, dt),
+    }
+    return fast, lit
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,7 @@ import os
 import shutil
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -57,8 +58,7 @@ def build_hip(force: bool = False) -> str:
     if not force and not _stale(HIP_LIB, HIP_SRC, header, __file__):
         return HIP_LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    stub_dir = os.path.join(LIBDIR, "_stub")
-    os.makedirs(stub_dir, exist_ok=True)
+    stub_dir = tempfile.mkdtemp(prefix="dsgd_stub_")
     stub = os.path.join(stub_dir, "libamdhip64.so")
     empty = os.path.join(stub_dir, "empty.c")
     with open(empty, "w") as f:
@@ -82,7 +82,10 @@ def build_hip(force: bool = False) -> str:
         "-ldl",
         "-lpthread",
     ]
-    _run(cmd)
+    try:
+        _run(cmd)
+    finally:
+        shutil.rmtree(stub_dir, ignore_errors=True)
     return HIP_LIB
 
 

@@ -62,7 +62,7 @@ typedef struct ncclComm* comm_t;
 typedef struct {
   char internal[DSGD_UNIQUE_ID_BYTES];
 } unique_id_t;
-enum { kFloat32 = 7, kInt64 = 4, kSum = 0 };
+enum { kFloat32 = 7, kInt64 = 4, kUint32 = 3, kSum = 0 };
 static int (*GetUniqueId)(unique_id_t*) = nullptr;
 static int (*CommInitRank)(comm_t*, int, unique_id_t, int) = nullptr;
 static int (*CommDestroy)(comm_t) = nullptr;
@@ -802,11 +802,15 @@ int dsgd_build_dim_sparsity(dsgd_ctx* c, int64_t n_train, float* ds_out) {
     hipLaunchKernelGGL(dsgd_colcount_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_col, nnz_train, d_cnt, c->dp,
                        c->d_sc);
   }
+  int rrc = 0;
+  if (c->comm)  // the reference counts over the WHOLE train set (Main.scala:57-60); shards sum their counts
+    rrc = rccl::AllReduce(d_cnt, d_cnt, (size_t)c->dp, rccl::kUint32, rccl::kSum, c->comm, c->stream);
   hipLaunchKernelGGL(dsgd_ds_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, d_cnt, c->d_ds, c->dp);
   hipError_t le = hipGetLastError();
   int rc = read_scalars(c);
   hipFree(d_cnt);
   if (le != hipSuccess) return fail(DSGD_EHIP, "dimSparsity kernels: %s", hipGetErrorString(le));
+  if (rrc) return fail(DSGD_ERCCL, "ncclAllReduce(feature counts): %s", rccl::GetErrorString(rrc));
   DSGD_TRY(rc);
   if (c->h_sc->err) {
     hipMemsetAsync(&c->d_sc->err, 0, sizeof(int), c->stream);

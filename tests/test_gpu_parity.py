@@ -1,0 +1,332 @@
+"""Parity tests proper (-m gpu): the HIP engine, called through the C ABI, against the fp64 CPU
+oracle on the same seeded inputs.
+
+STATED TOLERANCE (BASELINE.json: "within a stated fp32 tolerance"): the engine computes in IEEE
+fp32, the reference in fp64.  After T synchronous steps on identical index lists
+
+    max_j |w_gpu[j] - w_oracle[j]|  <=  1e-5 * max(1, |w_oracle|_inf)
+
+The only discontinuity is the gate `y * (x.w) >= 0` (core/ml/SparseSVM.scala:27-28): a row whose
+fp64 margin is within fp32 round-off of zero may be gated differently.  Such a flip is accepted
+only when the oracle reports |x.w| < 1e-5 for some row of that step; the test counts flips,
+re-synchronises the engine on the oracle's weights and requires that flips stay below 0.1 % of
+the processed rows (in practice: zero).  Integer results (predictions, loss/accuracy tallies,
+active-row counts) must match exactly unless such a near-zero margin exists.
+"""
+
+import numpy as np
+import pytest
+
+import dsgd_amd
+from conftest import has_gpu
+from oracle import oracle as orc
+from oracle import ref_dict as rd
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="no gfx950 device")]
+
+GATE_EPS = 1e-5
+
+
+def tol(w_ref):
+    return 1e-5 * max(1.0, float(np.abs(w_ref).max()))
+
+
+def make_pair(data, lam, n_train):
+    o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, lam)
+    o.set_dim_sparsity(o.dim_sparsity(n_train))
+    eng = dsgd_amd.Engine(data.dim, lam)
+    eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+    ds = eng.build_dim_sparsity(n_train)
+    # dimSparsity (Main.scala:54-65) built on the device == oracle's, to fp32 rounding of 1/(c+1)
+    np.testing.assert_allclose(ds, o.ds.astype(np.float32), rtol=0, atol=0)
+    return o, eng
+
+
+def run_sync(o, eng, lists_per_step, lr):
+    """Drive both sides through the same batches; returns (flips, rows)."""
+    w_ref = np.zeros(o.dim + 1)
+    flips = rows = 0
+    for lists in lists_per_step:
+        st = eng.sync_step(lists, lr)
+        o.sync_step(w_ref, lists, lr)
+        rows += st["n_samples"]
+        assert st["n_samples"] == sum(len(a) for a in lists)
+        if st["n_active"] != o.last_stats["n_active"]:
+            assert o.last_stats["min_abs_margin"] < GATE_EPS, (st, o.last_stats)
+            flips += abs(st["n_active"] - o.last_stats["n_active"])
+            eng.set_weights(w_ref.astype(np.float32))
+            continue
+        w = eng.get_weights().astype(np.float64)
+        err = np.abs(w - w_ref).max()
+        if err > tol(w_ref):
+            assert o.last_stats["min_abs_margin"] < GATE_EPS, (err, tol(w_ref), o.last_stats)
+            flips += 1
+            eng.set_weights(w_ref.astype(np.float32))
+    assert flips <= 1e-3 * rows, (flips, rows)
+    return w_ref, flips, rows
+
+
+def batches(rng, n_train, k_workers, batch, steps):
+    split = rd.split_vanilla(n_train, k_workers)
+    out = []
+    for _ in range(steps):
+        # Master.scala:184: every worker's split is reshuffled for every batch
+        out.append([rng.permutation(np.asarray(r))[:batch].astype(np.int32) for r in split])
+    return out
+
+
+# ---- KATs through the C ABI --------------------------------------------------------------------
+def test_kat1_through_the_abi():
+    from test_oracle_golden import KAT_ROWS
+
+    data = dsgd_amd.synth.from_rows(6, KAT_ROWS)
+    o, eng = make_pair(data, 0.1, 6)
+    with eng:
+        w_ref = np.zeros(7)
+        for step in range(3):
+            for idx in ([0, 1, 2], [3, 4, 5]):
+                g, st = eng.gradient(idx)
+                g_ref = o.gradient(w_ref, idx)
+                np.testing.assert_allclose(g, g_ref, rtol=0, atol=2e-7)
+                assert st["n_active"] == o.last_stats["n_active"]
+                assert set(np.nonzero(g)[0]) == set(np.nonzero(g_ref)[0])  # support-only regulariser
+            eng.sync_step([[0, 1, 2], [3, 4, 5]], 0.25)
+            o.sync_step(w_ref, [[0, 1, 2], [3, 4, 5]], 0.25)
+            np.testing.assert_allclose(eng.get_weights(), w_ref, rtol=0, atol=2e-7)
+            loss, acc, counts = eng.loss_acc(0, 6)
+            loss_ref, acc_ref, counts_ref, _ = o.loss_acc(w_ref, 0, 6)
+            assert counts == counts_ref and acc == acc_ref
+            assert abs(loss - loss_ref) < 1e-6
+        assert abs(loss - 0.340734158) < 1e-6 and acc == 5 / 6
+
+
+def test_kat2_inactive_rows_leave_weights_untouched():
+    from test_oracle_golden import KAT_ROWS
+
+    data = dsgd_amd.synth.from_rows(6, KAT_ROWS[:4])
+    o, eng = make_pair(data, 0.1, 4)
+    with eng:
+        eng.sync_step([[0, 1], [2, 3]], 0.5)
+        w1 = eng.get_weights()
+        np.testing.assert_allclose(w1, [0, -.35, .25, -.05, .2, 0, -.15], rtol=0, atol=1e-7)
+        for _ in range(2):
+            st = eng.sync_step([[0, 1], [2, 3]], 0.5)
+            assert st["n_active"] == 0
+            np.testing.assert_array_equal(eng.get_weights(), w1)
+        g, st = eng.gradient([0, 1])
+        assert not g.any() and st["n_active"] == 0  # empty-support path of valueLike (Vec.scala:66-67)
+
+
+# ---- synthetic RCV1-like data, reference default hyper-parameters ----------------------------------
+@pytest.mark.parametrize("n_rows,k_workers,batch,steps,seed", [
+    (4096, 3, 100, 40, 0),      # application.conf defaults: node-count 3, batch-size 100
+    (4096, 1, 100, 40, 1),      # BASELINE.json configs[0]: one worker
+    (6000, 4, 200, 30, 2),      # kube/config-sync.yaml: 4 nodes, batch 200
+    (3000, 2, 1, 60, 3),        # ragged: single-sample batches
+])
+def test_sync_training_matches_oracle(n_rows, k_workers, batch, steps, seed):
+    data = dsgd_amd.synth.generate(n_rows, seed=seed)
+    n_train = int(n_rows * 0.8)  # Main.scala:52
+    o, eng = make_pair(data, 1e-5, n_train)
+    rng = np.random.default_rng(seed)
+    with eng:
+        w_ref, flips, rows = run_sync(o, eng, batches(rng, n_train, k_workers, batch, steps), 0.5)
+        w = eng.get_weights().astype(np.float64)
+        if flips == 0:
+            assert np.abs(w - w_ref).max() <= tol(w_ref)
+        for lo, hi in ((0, n_train), (n_train, n_rows)):
+            loss, acc, counts = eng.loss_acc(lo, hi)
+            loss_ref, acc_ref, counts_ref, mam = o.loss_acc(w_ref, lo, hi)
+            if mam >= GATE_EPS and flips == 0:
+                assert counts == counts_ref
+                assert acc == acc_ref
+                assert abs(loss - loss_ref) <= 1e-6
+            else:
+                assert sum(abs(a - b) for a, b in zip(counts, counts_ref)) <= 4
+
+
+def test_config0_size_two_epochs():
+    """BASELINE.json configs[0] shape: N = 23,149 rows (full=false), 80/20 split, K=3, B=100."""
+    data = dsgd_amd.synth.generate(23149, seed=0)
+    n_train = int(23149 * 0.8)
+    assert n_train == 18519
+    o, eng = make_pair(data, 1e-5, n_train)
+    rng = np.random.default_rng(0)
+    steps = 2 * 62  # ceil(ceil(18519/3)/100) = 62 batches per epoch
+    with eng:
+        w_ref, flips, rows = run_sync(o, eng, batches(rng, n_train, 3, 100, steps), 0.5)
+        loss, acc, counts = eng.loss_acc(n_train, 23149)
+        loss_ref, acc_ref, counts_ref, mam = o.loss_acc(w_ref, n_train, 23149)
+        assert sum(abs(a - b) for a, b in zip(counts, counts_ref)) <= (0 if (mam >= GATE_EPS and flips == 0) else 4)
+        assert acc > 0.6  # it actually learns the planted separator
+
+
+def test_gradient_and_forward_against_oracle_with_given_weights():
+    data = dsgd_amd.synth.generate(5000, seed=5)
+    o, eng = make_pair(data, 1e-5, 4000)
+    rng = np.random.default_rng(5)
+    w0 = np.zeros(data.dim + 1, dtype=np.float32)
+    hot = rng.choice(np.arange(1, data.dim + 1), size=4000, replace=False)
+    w0[hot] = rng.normal(scale=0.05, size=4000).astype(np.float32)
+    idx = rng.permutation(4000)[:777].astype(np.int32)
+    with eng:
+        g, st = eng.gradient(idx, w=w0)  # the GradientRequest form: weights travel with the call
+        g_ref = o.gradient(w0.astype(np.float64), idx)
+        if o.last_stats["min_abs_margin"] >= GATE_EPS:
+            assert st["n_active"] == o.last_stats["n_active"]
+            np.testing.assert_allclose(g, g_ref, rtol=0, atol=1e-5 * max(1.0, np.abs(g_ref).max()))
+            # support-only regulariser: identical supports (up to exact fp32 cancellations)
+            sup, sup_ref = set(np.nonzero(g)[0]), set(np.nonzero(g_ref)[0])
+            assert len(sup ^ sup_ref) <= 2
+        pred = eng.forward(np.arange(4000, 5000))
+        pred_ref = o.forward(w0.astype(np.float64), np.arange(4000, 5000))
+        _, _, _, mam = o.loss_acc(w0.astype(np.float64), 4000, 5000)
+        if mam >= GATE_EPS:
+            np.testing.assert_array_equal(pred, pred_ref)
+        assert set(np.unique(pred)) <= {-1.0, 0.0, 1.0}
+        # apply half of the batch closure: w <- w - lr * g_mean
+        eng.apply(g_ref.astype(np.float32), 0.5)
+        np.testing.assert_allclose(eng.get_weights(), w0 - 0.5 * g_ref.astype(np.float32), rtol=0, atol=1e-6)
+
+
+def test_async_steps_against_oracle():
+    data = dsgd_amd.synth.generate(4000, seed=8)
+    o, eng = make_pair(data, 1e-5, 3200)
+    rng = np.random.default_rng(8)
+    w_ref = np.zeros(data.dim + 1)
+    with eng:
+        for step in range(40):
+            n = 1 if step % 4 == 0 else 100  # Slave.scala:83-88: batch 1 and batch > 1 forms
+            idx = rng.permutation(3200)[:n].astype(np.int32)
+            delta, st = eng.async_step(idx, 0.5, want_delta=True)
+            delta_ref = o.async_step(w_ref, idx, 0.5, want_delta=True)
+            if o.last_stats["min_abs_margin"] < GATE_EPS and st["n_active"] != o.last_stats["n_active"]:
+                eng.set_weights(w_ref.astype(np.float32))
+                continue
+            assert st["n_active"] == o.last_stats["n_active"]
+            np.testing.assert_allclose(delta, delta_ref, rtol=0, atol=1e-6)
+            np.testing.assert_allclose(eng.get_weights(), w_ref, rtol=0, atol=tol(w_ref))
+        # the receiving side of the gossip: w[key] -= dv (Slave.scala:180)
+        keys = np.nonzero(delta_ref)[0].astype(np.int32)
+        eng.update_grad(keys, delta_ref[keys].astype(np.float32))
+        w_ref[keys] -= delta_ref[keys]
+        np.testing.assert_allclose(eng.get_weights(), w_ref, rtol=0, atol=tol(w_ref))
+
+
+def test_plan_run_equals_step_by_step():
+    data = dsgd_amd.synth.generate(4096, seed=9)
+    o, eng = make_pair(data, 1e-5, 3276)
+    rng = np.random.default_rng(9)
+    steps = batches(rng, 3276, 3, 100, 20)
+    with eng:
+        w_ref, flips, rows = run_sync(o, eng, steps, 0.5)
+        w_a = eng.get_weights()
+        eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+        plan = eng.plan(steps)
+        eng.plan_run(plan, 0, 10, 0.5)
+        eng.plan_run(plan, 10, 20, 0.5)
+        st = eng.synchronize()
+        assert st["n_samples"] == rows
+        w_b = eng.get_weights()
+        plan.destroy()
+        if flips == 0:
+            np.testing.assert_allclose(w_b, w_a, rtol=0, atol=tol(w_ref))
+
+
+# ---- error behaviour mirrors the reference's require / exceptions ----------------------------------
+def test_error_behaviour():
+    data = dsgd_amd.synth.generate(256, seed=4)
+    with dsgd_amd.Engine(data.dim, 1e-5) as eng:
+        with pytest.raises(dsgd_amd.DsgdError):  # no data yet
+            eng.sync_step([[0]], 0.5)
+        eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+        with pytest.raises(dsgd_amd.DsgdError):  # no dimSparsity yet
+            eng.sync_step([[0]], 0.5)
+        eng.build_dim_sparsity(200)
+        with pytest.raises(ValueError):  # Vec.sum on an empty list (math/Vec.scala:129)
+            eng.gradient([])
+        with pytest.raises(ValueError):
+            eng.sync_step([[1, 2], []], 0.5)
+        with pytest.raises(IndexError):  # data(idx) out of bounds
+            eng.gradient([0, 256])
+        with pytest.raises(IndexError):
+            eng.forward([-1])
+        with pytest.raises(ValueError):
+            eng.loss_acc(10, 10)
+        with pytest.raises(IndexError):
+            eng.loss_acc(0, 257)
+        assert eng.forward([]).shape == (0,)  # empty ForwardRequest -> empty reply
+        # the engine is still usable after errors
+        st = eng.sync_step([[0, 1, 2]], 0.5)
+        assert st["n_samples"] == 3 and st["n_active"] == 3  # w = 0: every row is active (0 >= 0)
+    bad = data.col.copy()
+    bad[0] = data.dim + 1
+    with dsgd_amd.Engine(data.dim, 1e-5) as eng:
+        with pytest.raises(IndexError):
+            eng.load_csr(data.row_ptr, bad, data.val, data.label)
+        with pytest.raises(ValueError):
+            eng.load_csr(data.row_ptr, data.col, data.val, np.zeros(256, dtype=np.int8))
+
+
+# ---- BASELINE.json full size: direct oracle comparison + size-independent properties -----------------
+@pytest.fixture(scope="module")
+def full():
+    data = dsgd_amd.synth.generate(804414, seed=0)  # RCV1 full=true size (DatasetTests.scala:18)
+    n_train = int(804414 * 0.8)
+    o, eng = make_pair(data, 1e-5, n_train)
+    yield data, n_train, o, eng
+    eng.close()
+
+
+def test_full_size_whole_shard_steps_match_oracle(full):
+    data, n_train, o, eng = full
+    eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+    w_ref = np.zeros(data.dim + 1)
+    for step in range(3):
+        st = eng.sync_step_ranges([(0, n_train)], 0.5)
+        n_active_ref = o.sync_step_range_omp(w_ref, 0, n_train, 0.5)
+        assert st["n_samples"] == n_train
+        # 643,531 rows: a handful may sit within fp32 round-off of the gate
+        assert abs(st["n_active"] - n_active_ref) <= 8
+        w = eng.get_weights().astype(np.float64)
+        scale = max(1.0, np.abs(w_ref).max())
+        assert np.abs(w - w_ref).max() <= 2e-4 * scale  # sums of ~6e5 fp32 terms per coordinate
+        eng.set_weights(w_ref.astype(np.float32))
+    loss, acc, counts = eng.loss_acc(n_train, data.n_rows)
+    loss_ref, acc_ref, counts_ref, _ = o.loss_acc(w_ref, n_train, data.n_rows)
+    assert sum(counts) == data.n_rows - n_train
+    assert sum(abs(a - b) for a, b in zip(counts, counts_ref)) <= 8
+    assert abs(loss - loss_ref) < 1e-4
+
+
+def test_full_size_properties(full):
+    data, n_train, o, eng = full
+    rng = np.random.default_rng(1)
+    w0 = np.zeros(data.dim + 1, dtype=np.float32)
+    hot = rng.choice(np.arange(1, data.dim + 1), size=8000, replace=False)
+    w0[hot] = rng.normal(scale=0.05, size=8000).astype(np.float32)
+    # (1) additivity over a partition of the rows when the regulariser scalar is zero (w . ds = 0
+    #     because w = 0): g(A u B) = g(A) + g(B); ranges == index lists
+    eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+    half = n_train // 2
+    ga, _ = eng.gradient(np.arange(0, half, dtype=np.int32))
+    gb, _ = eng.gradient(np.arange(half, n_train, dtype=np.int32))
+    eng.sync_step_ranges([(0, n_train)], 1.0)  # w = 0 - 1.0 * g(all)
+    w = eng.get_weights()
+    scale = max(1.0, float(np.abs(w).max()))
+    assert np.abs(-(ga + gb) - w).max() <= 2e-4 * scale
+    # (2) two workers on the two halves = mean of the halves (Master.scala:194)
+    eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+    eng.sync_step_ranges([(0, half), (half, n_train)], 1.0)
+    w2 = eng.get_weights()
+    assert np.abs(-(ga + gb) / 2 - w2).max() <= 2e-4 * scale
+    # (3) evaluation tallies partition the rows and are consistent with forward()
+    eng.set_weights(w0)
+    loss, acc, counts = eng.loss_acc(n_train, data.n_rows)
+    assert sum(counts) == data.n_rows - n_train
+    pred = eng.forward(np.arange(n_train, n_train + 50000, dtype=np.int32))
+    y = data.label[n_train:n_train + 50000].astype(np.float32)
+    _, _, c_sub = eng.loss_acc(n_train, n_train + 50000)
+    assert c_sub == [int((pred == y).sum()), int((pred == 0).sum()), int((pred == -y).sum())]
+    # (4) idempotence: evaluation does not change the weights
+    np.testing.assert_array_equal(eng.get_weights(), w0)
