@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK = 8.0e12      # B/s, spec (MI355X_MICROARCH.md "Chip-level parameters")
 HBM_MEASURED = 6.29e12  # B/s, float4-copy ceiling from the same table
-LR, LAMBDA = 0.5, 1e-5  # application.conf:18,21
+LR0, LAMBDA = 0.5, 1e-5  # application.conf:18,21 (learning-rate is per batch of 100, application.conf:15)
 
 
 def parse():
@@ -98,6 +98,9 @@ def main():
     eng.build_dim_sparsity(n_train)
 
     k = args.workers
+    # the reference SUMS the gated sub-gradients of a batch (core/Slave.scala:153), so its step length
+    # scales with batch-size; keep the per-sample step of the defaults (0.5 per 100 samples)
+    LR = LR0 * 100.0 / (n_train / k)
     size = -(-n_train // k)
     ranges = [(b, min(n_train, b + size)) for b in range(0, n_train, size)]  # SplitStrategy.vanilla
 
@@ -161,7 +164,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "rcv1-synth sync SGD: %d rows/GPU (D=47236, nnz/row=%.1f), 80/20 split, whole-shard batch "
-                        "B=%d rows/GPU/step, %d worker(s)/GPU, lr=%.2f, lambda=%g" %
+                        "B=%d rows/GPU/step, %d worker(s)/GPU, lr=0.5*100/B=%.3g, lambda=%g" %
                         (args.rows, data.nnz / data.n_rows, n_train, k, LR, LAMBDA),
             "rows_per_gpu": args.rows,
             "train_rows_per_gpu": n_train,
@@ -219,6 +222,7 @@ def main():
 
 
 def sweep(eng, n_train, bytes_per_row):
+    LR = LR0
     """examples/s for index-list batches B in {100, 4096, 65536} (1 worker), resident plans."""
     res = []
     rng = np.random.default_rng(123)
@@ -241,6 +245,7 @@ def sweep(eng, n_train, bytes_per_row):
 
 
 def cpu_baseline(data, n_train, budget_s):
+    LR = LR0
     """The oracle timed on the host cores: (B) OpenMP CSR restatement on all cores, same whole-shard
     step on a bounded sample; (A) literal per-sample sparse-map restatement, one thread, B=100."""
     from oracle import oracle as orc

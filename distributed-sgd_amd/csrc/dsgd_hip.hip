@@ -97,298 +97,7 @@ static bool available() {
     if (r__ != 0) return fail(DSGD_ERCCL, "%s: %s", #expr, rccl::GetErrorString(r__));          \
   } while (0)
 
-// ------------------------------------------------------------------------------------------------
-// device-side helpers
-// ------------------------------------------------------------------------------------------------
-#define DSGD_EPS 1e-20f  // ref: math/Sparse.scala:104 (Sparse.epsilon); representable in fp32
-
-// Sparse(...) constructor filter: entries with abs(v) <= 1e-20 vanish (ref: math/Sparse.scala:108-118)
-__device__ __forceinline__ float filt(float v) { return fabsf(v) > DSGD_EPS ? v : 0.0f; }
-
-// device scalars shared by the kernels of one context
-struct DevScalars {
-  float s_reg;                 // 2 * lambda * (w . ds)            (ref: core/ml/SparseSVM.scala:31)
-  float wnorm2;                // |w|^2                            (ref: math/Vec.scala:55)
-  int err;                     // != 0: a sample index was out of range
-  int pad;
-  unsigned long long n_active;   // rows with y*(x.w) >= 0
-  unsigned long long n_samples;  // rows processed
-  unsigned long long counts[4];  // eval tallies {pred==y, pred==0, pred==-y, rows}
-};
-
-// one unit of gradient work: worker k processes items [begin, end) -- either positions in the
-// resident index list (idx != nullptr) or CSR row numbers themselves (contiguous range)
-struct WorkSeg {
-  long long begin;
-  long long end;
-};
-
-struct CsrView {
-  long long n_rows;
-  const long long* __restrict__ row_ptr;
-  const int* __restrict__ col;
-  const float* __restrict__ val;
-  const signed char* __restrict__ label;
-};
-
-template <int G>
-__device__ __forceinline__ float group_sum(float v) {
-  // butterfly over the G lanes of the group: fixed order -> x.w is reproducible run to run
-#pragma unroll
-  for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
-
-// x_row . w with G cooperating lanes; ref: math/Vec.scala:58 -> math/Sparse.scala:46,20-31
-template <int G>
-__device__ __forceinline__ float row_dot(const CsrView& m, long long start, long long end, const float* __restrict__ w,
-                                         int sub) {
-  float acc = 0.0f;
-  for (long long p = start + sub; p < end; p += G) {
-    int c = m.col[p];
-    float v = m.val[p];
-    acc += filt(v * w[c]);
-  }
-  return group_sum<G>(acc);
-}
-
-// ---- K1: gated sub-gradient sum ------------------------------------------------------------------
-// g_k += sum_{i in batch_k, y_i (x_i . w) >= 0} y_i x_i
-// ref: core/Slave.scala:147-153 (per-sample backward + Vec.sum), core/ml/SparseSVM.scala:26-29.
-// grid = (blocks, n_workers); a group of G lanes walks the worker's items with a grid stride.
-template <int G>
-__global__ void __launch_bounds__(256) dsgd_grad_rows_kernel(CsrView m, const float* __restrict__ w, float* g_base,
-                                                            long long g_stride, const int* __restrict__ idx,
-                                                            const WorkSeg* __restrict__ segs, DevScalars* sc) {
-  const int worker = blockIdx.y;
-  const WorkSeg seg = segs[worker];
-  float* g = g_base + (long long)worker * g_stride;
-  const int sub = threadIdx.x % G;
-  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
-  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
-  unsigned int active_local = 0;
-  for (long long t = seg.begin + group; t < seg.end; t += n_groups) {
-    long long row = idx ? (long long)idx[t] : t;
-    if (row < 0 || row >= m.n_rows) {
-      if (sub == 0) atomicExch(&sc->err, 1);
-      continue;
-    }
-    const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
-    const float y = (float)m.label[row];
-    const float d = row_dot<G>(m, start, end, w, sub);
-    const float activity = y * d;
-    if (activity < 0.0f) continue;  // zerosLike (ref: SparseSVM.scala:28)
-    if (sub == 0) active_local++;
-    for (long long p = start + sub; p < end; p += G) {
-      float xv = filt(m.val[p] * y);  // x * y (ref: SparseSVM.scala:28, math/Vec.scala:42)
-      if (xv != 0.0f) atomicAdd(&g[m.col[p]], xv);
-    }
-  }
-  // one atomic per wave for the Kamon-style counters (ref: core/Slave.scala:145,150)
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) active_local += __shfl_xor(active_local, off, 64);
-  if ((threadIdx.x & 63) == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
-}
-
-// ---- K2: support-only scalar regulariser ----------------------------------------------------------
-// g_k[j] += s for j in supp(g_k), s = 2*lambda*(w.ds)  (ref: SparseSVM.scala:31, math/Vec.scala:65-75)
-__global__ void __launch_bounds__(1024) dsgd_regularize_kernel(float* g_base, long long g_stride, int dp,
-                                                              const DevScalars* sc) {
-  float* g = g_base + (long long)blockIdx.y * g_stride;
-  const float s = sc->s_reg;
-  const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) {
-    float v = filt(g[j]);
-    if (add && v != 0.0f) v = filt(v + s);
-    g[j] = v;
-  }
-}
-
-// sum of the per-worker regularised gradients hosted by this context (ref: math/Vec.scala:128-131)
-__global__ void __launch_bounds__(1024) dsgd_sum_workers_kernel(const float* g_base, long long g_stride, int n_workers,
-                                                               int dp, float* out) {
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) {
-    float a = 0.0f;
-    for (int k = 0; k < n_workers; ++k) a = filt(a + g_base[(long long)k * g_stride + j]);
-    out[j] = a;
-  }
-}
-
-__device__ __forceinline__ float block_sum_1024(float v, float* red /* 16 floats of LDS */) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  const int wave = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[wave] = v;
-  __syncthreads();
-  float t = 0.0f;
-  const int n_waves = blockDim.x >> 6;
-  for (int i = 0; i < n_waves; ++i) t += red[i];
-  return t;
-}
-
-// ---- K3: mean over workers + update + next regulariser scalar --------------------------------------
-// w <- w - lr * (g_sum / K); g <- 0; s <- 2*lambda*(w.ds); |w|^2
-// ref: core/Master.scala:194-197 (Vec.mean then batchWeights - learningRate * grad)
-// Single workgroup: D+1 = 47,237 floats is one pass of 1024 lanes x 47 elements and the two
-// dot products need no inter-workgroup reduction.
-__global__ void __launch_bounds__(1024) dsgd_apply_kernel(float* w, const float* gsum,
-                                                         float* zero_base, long long zero_stride, int n_zero, int dp,
-                                                         const float* __restrict__ ds, float n_workers_total, float lr,
-                                                         float lambda, DevScalars* sc) {
-  __shared__ float red[16];
-  float dot = 0.0f, nsq = 0.0f;
-  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
-    float mean = filt(gsum[j] / n_workers_total);  // Vec.mean (ref: math/Vec.scala:139)
-    float upd = filt(mean * lr);                   // learningRate * grad
-    float wn = filt(w[j] - upd);
-    w[j] = wn;
-    dot += filt(wn * ds[j]);
-    nsq += wn * wn;
-  }
-  __syncthreads();  // all reads of gsum done before it is zeroed (gsum may alias zero_base)
-  for (int k = 0; k < n_zero; ++k)
-    for (int j = threadIdx.x; j < dp; j += blockDim.x) zero_base[(long long)k * zero_stride + j] = 0.0f;
-  float dsum = block_sum_1024(dot, red);
-  float nsum = block_sum_1024(nsq, red);
-  if (threadIdx.x == 0) {
-    sc->s_reg = lambda * 2.0f * dsum;
-    sc->wnorm2 = nsum;
-  }
-}
-
-// s = 2*lambda*(w.ds) and |w|^2 for weights that were set from outside
-__global__ void __launch_bounds__(1024) dsgd_wstats_kernel(const float* __restrict__ w, const float* __restrict__ ds,
-                                                          int dp, float lambda, DevScalars* sc) {
-  __shared__ float red[16];
-  float dot = 0.0f, nsq = 0.0f;
-  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
-    float wn = w[j];
-    dot += filt(wn * ds[j]);
-    nsq += wn * wn;
-  }
-  float dsum = block_sum_1024(dot, red);
-  float nsum = block_sum_1024(nsq, red);
-  if (threadIdx.x == 0) {
-    sc->s_reg = lambda * 2.0f * dsum;
-    sc->wnorm2 = nsum;
-  }
-}
-
-// ---- async iteration (host-driven form of Slave.asyncTask) ----------------------------------------
-// grad = g_sum / n; delta = lr * regularize(grad, w); w -= delta  (ref: core/Slave.scala:93-101)
-__global__ void __launch_bounds__(1024) dsgd_async_finish_kernel(float* __restrict__ w, float* __restrict__ g, int dp,
-                                                                const float* __restrict__ ds, float n_samples, float lr,
-                                                                float lambda, float* delta_out, DevScalars* sc) {
-  __shared__ float red[16];
-  const float s = sc->s_reg;
-  const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
-  float dot = 0.0f, nsq = 0.0f;
-  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
-    float v = filt(filt(g[j]) / n_samples);  // Vec.mean over samples
-    if (add && v != 0.0f) v = filt(v + s);   // regularize on the support
-    float upd = filt(v * lr);
-    if (delta_out) delta_out[j] = upd;
-    float wn = filt(w[j] - upd);
-    w[j] = wn;
-    g[j] = 0.0f;
-    dot += filt(wn * ds[j]);
-    nsq += wn * wn;
-  }
-  float dsum = block_sum_1024(dot, red);
-  float nsum = block_sum_1024(nsq, red);
-  if (threadIdx.x == 0) {
-    sc->s_reg = lambda * 2.0f * dsum;
-    sc->wnorm2 = nsum;
-  }
-}
-
-// w[key] -= dv (ref: core/Slave.scala:180, core/ml/GradState.scala:8)
-__global__ void dsgd_update_grad_kernel(float* w, const int* key, const float* dv, long long nnz, int dp,
-                                        DevScalars* sc) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
-    int k = key[i];
-    if (k < 0 || k >= dp) {
-      atomicExch(&sc->err, 1);
-      continue;
-    }
-    atomicAdd(&w[k], -dv[i]);
-  }
-}
-__global__ void dsgd_filter_kernel(float* w, int dp) {
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) w[j] = filt(w[j]);
-}
-
-// ---- K4: prediction  p = -signum(x.w)  (ref: core/ml/SparseSVM.scala:14, core/Slave.scala:129-140) ---
-template <int G>
-__global__ void __launch_bounds__(256) dsgd_forward_kernel(CsrView m, const float* __restrict__ w,
-                                                          const int* __restrict__ idx, long long n, float* pred,
-                                                          DevScalars* sc) {
-  const int sub = threadIdx.x % G;
-  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
-  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
-  for (long long t = group; t < n; t += n_groups) {
-    long long row = idx[t];
-    if (row < 0 || row >= m.n_rows) {
-      if (sub == 0) atomicExch(&sc->err, 1);
-      continue;
-    }
-    float d = row_dot<G>(m, m.row_ptr[row], m.row_ptr[row + 1], w, sub);
-    if (sub == 0) pred[t] = d > 0.0f ? -1.0f : (d < 0.0f ? 1.0f : 0.0f);
-  }
-}
-
-// ---- K5: loss / accuracy tallies over a row range ---------------------------------------------------
-// ref: core/Master.scala:100-107, core/ml/SparseSVM.scala:16-23: with p = -signum(x.w),
-//   y*p = +1 (loss 0, correct) iff y*(x.w) < 0;  p = 0 (loss 1) iff x.w == 0;  y*p = -1 (loss 2) otherwise
-template <int G>
-__global__ void __launch_bounds__(256) dsgd_eval_kernel(CsrView m, const float* __restrict__ w, long long row_begin,
-                                                       long long row_end, DevScalars* sc) {
-  const int sub = threadIdx.x % G;
-  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
-  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
-  unsigned int c0 = 0, c1 = 0, c2 = 0;
-  for (long long row = row_begin + group; row < row_end; row += n_groups) {
-    float d = row_dot<G>(m, m.row_ptr[row], m.row_ptr[row + 1], w, sub);
-    float yd = (float)m.label[row] * d;
-    if (sub == 0) {
-      if (yd < 0.0f) c0++;
-      else if (yd > 0.0f) c2++;
-      else c1++;
-    }
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    c0 += __shfl_xor(c0, off, 64);
-    c1 += __shfl_xor(c1, off, 64);
-    c2 += __shfl_xor(c2, off, 64);
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&sc->counts[3], (unsigned long long)(row_end - row_begin));
-  if ((threadIdx.x & 63) == 0) {
-    if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
-    if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
-    if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
-  }
-}
-
-// ---- dimSparsity on the device (ref: Main.scala:54-65) ---------------------------------------------
-__global__ void dsgd_colcount_kernel(const int* __restrict__ col, long long nnz, unsigned int* cnt, int dp,
-                                     DevScalars* sc) {
-  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (long long)gridDim.x * blockDim.x) {
-    int c = col[p];
-    if (c < 1 || c >= dp) {
-      atomicExch(&sc->err, 1);
-      continue;
-    }
-    atomicAdd(&cnt[c - 1], 1u);  // buff(idx - 1) += 1
-  }
-}
-__global__ void dsgd_ds_kernel(const unsigned int* cnt, float* ds, int dp) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dp; i += gridDim.x * blockDim.x) {
-    unsigned int c = (i < dp - 1) ? cnt[i] : 0u;  // buff has D entries (keys 0..D-1)
-    ds[i] = c ? filt(1.0f / ((float)c + 1.0f)) : 0.0f;
-  }
-}
+#include "dsgd_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -414,13 +123,21 @@ struct dsgd_ctx {
   float* d_val = nullptr;
   signed char* d_label = nullptr;
   int group = 16;  // lanes per row, chosen from the mean row length at load time
+  // column layout: external keys <-> internal frequency ranks (identity until prepare_layout)
+  int* d_perm = nullptr;   // key  -> rank
+  bool layout_ready = false;
+  int hw = 8192, hg = 32768;  // LDS tile sizes (floats) of the tiled gradient kernel; hw + hg <= 40960
+  int hw_eval = DSGD_LDS_FLOATS;
+  long long tiled_min = 8192;  // batches with at least this many rows use the tiled kernel
+  const char* last_grad_kernel = "";
   // vectors
   float* d_w = nullptr;
   float* d_ds = nullptr;
   float* d_g = nullptr;  // g_cap x dp
   int g_cap = 0;
   float* d_gsum = nullptr;  // dp (all-reduce buffer / sum over hosted workers)
-  float* d_tmp = nullptr;   // dp scratch (delta_out staging)
+  float* d_tmp = nullptr;   // dp scratch (ranked order)
+  float* d_io = nullptr;    // dp staging for vectors crossing the API in key order
   DevScalars* d_sc = nullptr;
   DevScalars* h_sc = nullptr;  // pinned
   bool s_dirty = true;
@@ -567,29 +284,42 @@ static int prof_collect(dsgd_ctx* c) {  // stream must be idle
 }
 
 // launch K1 for n_workers segments living at d_segs (device); max_items = largest segment
-static int launch_grad(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int n_workers, long long max_items) {
+static int launch_grad(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int n_workers, long long max_items,
+                       long long total_items) {
   const int G = c->group;
-  dim3 grid(grid_for(c, max_items, G), n_workers);
   size_t slot = 0;
-  DSGD_TRY(prof_begin(c, &slot));
   CsrView m = view(c);
-  switch (G) {
-    case 64:
-      hipLaunchKernelGGL(dsgd_grad_rows_kernel<64>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_g, (long long)c->dp,
-                         d_idx, d_segs, c->d_sc);
-      break;
-    case 32:
-      hipLaunchKernelGGL(dsgd_grad_rows_kernel<32>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_g, (long long)c->dp,
-                         d_idx, d_segs, c->d_sc);
-      break;
-    case 16:
-      hipLaunchKernelGGL(dsgd_grad_rows_kernel<16>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_g, (long long)c->dp,
-                         d_idx, d_segs, c->d_sc);
-      break;
-    default:
-      hipLaunchKernelGGL(dsgd_grad_rows_kernel<8>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_g, (long long)c->dp,
-                         d_idx, d_segs, c->d_sc);
-      break;
+  const bool tiled = total_items >= c->tiled_min;
+  DSGD_TRY(prof_begin(c, &slot));
+  if (tiled) {
+    // persistent workgroups: one 1024-lane block (all 160 KiB of LDS) per CU, shared out over the workers
+    const long long groups_per_block = 1024 / G;
+    long long bx = std::max<long long>(1, c->n_cu / n_workers);
+    bx = std::min(bx, (max_items + groups_per_block - 1) / groups_per_block);
+    dim3 grid((unsigned)std::max<long long>(1, bx), n_workers);
+    const size_t lds = sizeof(float) * (size_t)(c->hw + c->hg);
+#define DSGD_LAUNCH_TILED(GG)                                                                                        \
+  hipLaunchKernelGGL(dsgd_grad_tiled_kernel<GG>, grid, dim3(1024), lds, c->stream, m, c->d_w, c->d_g, (long long)c->dp, \
+                     d_idx, d_segs, c->d_sc, c->hw, c->hg)
+    switch (G) {
+      case 64: DSGD_LAUNCH_TILED(64); c->last_grad_kernel = "dsgd_grad_tiled_kernel<64>"; break;
+      case 32: DSGD_LAUNCH_TILED(32); c->last_grad_kernel = "dsgd_grad_tiled_kernel<32>"; break;
+      case 16: DSGD_LAUNCH_TILED(16); c->last_grad_kernel = "dsgd_grad_tiled_kernel<16>"; break;
+      default: DSGD_LAUNCH_TILED(8); c->last_grad_kernel = "dsgd_grad_tiled_kernel<8>"; break;
+    }
+#undef DSGD_LAUNCH_TILED
+  } else {
+    dim3 grid(grid_for(c, max_items, G), n_workers);
+#define DSGD_LAUNCH_ROWS(GG)                                                                                       \
+  hipLaunchKernelGGL(dsgd_grad_rows_kernel<GG>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_g, (long long)c->dp,   \
+                     d_idx, d_segs, c->d_sc)
+    switch (G) {
+      case 64: DSGD_LAUNCH_ROWS(64); c->last_grad_kernel = "dsgd_grad_rows_kernel<64>"; break;
+      case 32: DSGD_LAUNCH_ROWS(32); c->last_grad_kernel = "dsgd_grad_rows_kernel<32>"; break;
+      case 16: DSGD_LAUNCH_ROWS(16); c->last_grad_kernel = "dsgd_grad_rows_kernel<16>"; break;
+      default: DSGD_LAUNCH_ROWS(8); c->last_grad_kernel = "dsgd_grad_rows_kernel<8>"; break;
+    }
+#undef DSGD_LAUNCH_ROWS
   }
   HIP_TRY(hipGetLastError());
   DSGD_TRY(prof_end(c, slot));
@@ -600,26 +330,117 @@ static int launch_grad(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int
 static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
   const int dp = c->dp;
   const int blocks = (dp + 1023) / 1024;
+  const float k_total = (float)n_workers * (float)c->world;
+  if (n_workers == 1 && !c->comm) {
+    // one hosted worker, no peers: regularise + "mean" over one worker + update in a single pass
+    hipLaunchKernelGGL(dsgd_apply_kernel<true>, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_g, c->d_g, (long long)dp,
+                       1, dp, c->d_ds, 1.0f, lr, (float)c->cfg.lambda, c->d_sc);
+    HIP_TRY(hipGetLastError());
+    c->s_dirty = false;
+    return DSGD_OK;
+  }
   hipLaunchKernelGGL(dsgd_regularize_kernel, dim3(blocks, n_workers), dim3(1024), 0, c->stream, c->d_g, (long long)dp,
                      dp, c->d_sc);
   HIP_TRY(hipGetLastError());
-  const float* gsum = c->d_g;
-  if (n_workers > 1 || c->comm) {
-    hipLaunchKernelGGL(dsgd_sum_workers_kernel, dim3(blocks), dim3(1024), 0, c->stream, c->d_g, (long long)dp, n_workers,
-                       dp, c->d_gsum);
-    HIP_TRY(hipGetLastError());
-    gsum = c->d_gsum;
-  }
+  hipLaunchKernelGGL(dsgd_sum_workers_kernel, dim3(blocks), dim3(1024), 0, c->stream, c->d_g, (long long)dp, n_workers,
+                     dp, c->d_gsum);
+  HIP_TRY(hipGetLastError());
   if (c->comm) {
     // the synchronous master's Future.sequence + Vec.mean (ref: core/Master.scala:190-194) as ONE
     // all-reduce of D+1 floats over xGMI, ordered on the same stream as the kernels around it
     RCCL_TRY(rccl::AllReduce(c->d_gsum, c->d_gsum, (size_t)dp, rccl::kFloat32, rccl::kSum, c->comm, c->stream));
   }
-  const float k_total = (float)n_workers * (float)c->world;
-  hipLaunchKernelGGL(dsgd_apply_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_w, gsum, c->d_g, (long long)dp,
-                     n_workers, dp, c->d_ds, k_total, lr, (float)c->cfg.lambda, c->d_sc);
+  hipLaunchKernelGGL(dsgd_apply_kernel<false>, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_gsum, c->d_g,
+                     (long long)dp, n_workers, dp, c->d_ds, k_total, lr, (float)c->cfg.lambda, c->d_sc);
   HIP_TRY(hipGetLastError());
   c->s_dirty = false;
+  return DSGD_OK;
+}
+
+// ---- column layout -------------------------------------------------------------------------------------
+static int launch_permute_in(dsgd_ctx* c, const float* d_in, float* d_out) {
+  hipLaunchKernelGGL(dsgd_permute_in_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, d_in, d_out, c->d_perm,
+                     c->dp);
+  HIP_TRY(hipGetLastError());
+  return DSGD_OK;
+}
+static int launch_permute_out(dsgd_ctx* c, const float* d_in, float* d_out) {
+  hipLaunchKernelGGL(dsgd_permute_out_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, d_in, d_out, c->d_perm,
+                     c->dp);
+  HIP_TRY(hipGetLastError());
+  return DSGD_OK;
+}
+static int set_identity_perm(dsgd_ctx* c) {
+  std::vector<int> id(c->dp);
+  for (int j = 0; j < c->dp; ++j) id[j] = j;
+  HIP_TRY(hipMemcpy(c->d_perm, id.data(), sizeof(int) * c->dp, hipMemcpyHostToDevice));
+  return DSGD_OK;
+}
+static int count_columns(dsgd_ctx* c, long long nnz, unsigned int* d_cnt) {
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * c->dp, c->stream));
+  if (nnz > 0) {
+    const int hcnt = std::min(c->dp, DSGD_LDS_FLOATS);
+    const int blocks = (int)std::max<long long>(1, std::min<long long>((nnz + 4095) / 4096, c->n_cu));
+    hipLaunchKernelGGL(dsgd_colcount_kernel, dim3(blocks), dim3(1024), sizeof(unsigned int) * hcnt, c->stream, c->d_col, nnz,
+                       d_cnt, c->dp, hcnt, c->d_sc);
+    HIP_TRY(hipGetLastError());
+  }
+  return DSGD_OK;
+}
+
+// Rank the columns by how often they occur in the loaded rows (summed over ranks when a
+// communicator is attached, so every replica uses the same order) and relabel the CSR columns.
+// Runs once, lazily, at the first compute call after dsgd_load_csr.
+static int prepare_layout(dsgd_ctx* c) {
+  if (c->layout_ready) return DSGD_OK;
+  unsigned int* d_cnt = nullptr;
+  HIP_TRY(hipMalloc(&d_cnt, sizeof(unsigned int) * c->dp));
+  int rc = count_columns(c, c->nnz, d_cnt);
+  if (!rc && c->comm) {
+    int r = rccl::AllReduce(d_cnt, d_cnt, (size_t)c->dp, rccl::kUint32, rccl::kSum, c->comm, c->stream);
+    if (r) rc = fail(DSGD_ERCCL, "ncclAllReduce(column counts): %s", rccl::GetErrorString(r));
+  }
+  std::vector<unsigned int> cnt(c->dp);
+  if (!rc) {
+    hipError_t e = hipMemcpyAsync(cnt.data(), d_cnt, sizeof(unsigned int) * c->dp, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(DSGD_EHIP, "column counts: %s", hipGetErrorString(e));
+  }
+  hipFree(d_cnt);
+  DSGD_TRY(rc);
+  std::vector<int> order(c->dp);
+  for (int j = 0; j < c->dp; ++j) order[j] = j;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cnt[a] > cnt[b]; });  // ties: ascending key
+  std::vector<int> perm(c->dp);
+  for (int r = 0; r < c->dp; ++r) perm[order[r]] = r;
+  // bring the resident vectors (identity layout so far) into ranked order
+  HIP_TRY(hipMemcpy(c->d_perm, perm.data(), sizeof(int) * c->dp, hipMemcpyHostToDevice));
+  DSGD_TRY(launch_permute_in(c, c->d_w, c->d_tmp));
+  HIP_TRY(hipMemcpyAsync(c->d_w, c->d_tmp, sizeof(float) * c->dp, hipMemcpyDeviceToDevice, c->stream));
+  DSGD_TRY(launch_permute_in(c, c->d_ds, c->d_tmp));
+  HIP_TRY(hipMemcpyAsync(c->d_ds, c->d_tmp, sizeof(float) * c->dp, hipMemcpyDeviceToDevice, c->stream));
+  if (c->nnz > 0) {
+    const int blocks = (int)std::min<long long>((c->nnz + 255) / 256, (long long)c->n_cu * 8);
+    hipLaunchKernelGGL(dsgd_remap_cols_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_col, c->nnz, c->d_perm);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->layout_ready = true;
+  c->s_dirty = true;
+  return DSGD_OK;
+}
+// back to the identity layout (before new data is loaded): resident vectors return to key order
+static int reset_layout(dsgd_ctx* c) {
+  if (c->layout_ready) {
+    DSGD_TRY(launch_permute_out(c, c->d_w, c->d_tmp));
+    HIP_TRY(hipMemcpyAsync(c->d_w, c->d_tmp, sizeof(float) * c->dp, hipMemcpyDeviceToDevice, c->stream));
+    DSGD_TRY(launch_permute_out(c, c->d_ds, c->d_tmp));
+    HIP_TRY(hipMemcpyAsync(c->d_ds, c->d_tmp, sizeof(float) * c->dp, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  DSGD_TRY(set_identity_perm(c));
+  c->layout_ready = false;
+  c->s_dirty = true;
   return DSGD_OK;
 }
 
@@ -680,6 +501,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   HIP_TRY_B(hipMalloc(&c->d_ds, sizeof(float) * c->dp));
   HIP_TRY_B(hipMalloc(&c->d_gsum, sizeof(float) * c->dp));
   HIP_TRY_B(hipMalloc(&c->d_tmp, sizeof(float) * c->dp));
+  HIP_TRY_B(hipMalloc(&c->d_io, sizeof(float) * c->dp));
+  HIP_TRY_B(hipMalloc(&c->d_perm, sizeof(int) * c->dp));
   HIP_TRY_B(hipMalloc(&c->d_sc, sizeof(DevScalars)));
   HIP_TRY_B(hipHostMalloc(&c->h_sc, sizeof(DevScalars), hipHostMallocDefault));
   HIP_TRY_B(hipMemsetAsync(c->d_w, 0, sizeof(float) * c->dp, c->stream));
@@ -688,6 +511,30 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   HIP_TRY_B(hipMemsetAsync(c->d_sc, 0, sizeof(DevScalars), c->stream));
   int rc = ensure_g(c, 1);
   if (rc) return bail(rc);
+  rc = set_identity_perm(c);
+  if (rc) return bail(rc);
+  // LDS tile split of the tiled gradient kernel (tunable for experiments; hw + hg <= 40960 floats)
+  if (const char* e = getenv("DSGD_HW")) c->hw = atoi(e);
+  if (const char* e = getenv("DSGD_HG")) c->hg = atoi(e);
+  if (const char* e = getenv("DSGD_TILED_MIN")) c->tiled_min = atoll(e);
+  if (cfg->flags & DSGD_F_FORCE_TILED) c->tiled_min = 0;
+  if (cfg->flags & DSGD_F_FORCE_ROWS) c->tiled_min = (long long)1 << 62;
+  c->hw = std::max(0, std::min(c->hw, c->dp));
+  c->hg = std::max(0, std::min(c->hg, c->dp));
+  if (c->hw + c->hg > DSGD_LDS_FLOATS) return bail(fail(DSGD_EINVAL, "DSGD_HW + DSGD_HG exceed %d floats of LDS", DSGD_LDS_FLOATS));
+  c->hw_eval = std::min(c->dp, DSGD_LDS_FLOATS);
+  const int lds_max = DSGD_LDS_FLOATS * (int)sizeof(float);
+#define DSGD_ATTR(fn) HIP_TRY_B(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max))
+  DSGD_ATTR(dsgd_grad_tiled_kernel<64>);
+  DSGD_ATTR(dsgd_grad_tiled_kernel<32>);
+  DSGD_ATTR(dsgd_grad_tiled_kernel<16>);
+  DSGD_ATTR(dsgd_grad_tiled_kernel<8>);
+  DSGD_ATTR(dsgd_eval_kernel<64>);
+  DSGD_ATTR(dsgd_eval_kernel<32>);
+  DSGD_ATTR(dsgd_eval_kernel<16>);
+  DSGD_ATTR(dsgd_eval_kernel<8>);
+  DSGD_ATTR(dsgd_colcount_kernel);
+#undef DSGD_ATTR
   HIP_TRY_B(hipStreamSynchronize(c->stream));
 #undef HIP_TRY_B
   *out = c;
@@ -712,6 +559,8 @@ int dsgd_destroy(dsgd_ctx* c) {
   hipFree(c->d_g);
   hipFree(c->d_gsum);
   hipFree(c->d_tmp);
+  hipFree(c->d_io);
+  hipFree(c->d_perm);
   hipFree(c->d_sc);
   hipFree(c->d_idx);
   hipFree(c->d_segs);
@@ -739,6 +588,7 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr, const int
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  DSGD_TRY(reset_layout(c));
   hipFree(c->d_row_ptr);
   hipFree(c->d_col);
   hipFree(c->d_val);
@@ -776,9 +626,8 @@ int dsgd_set_dim_sparsity(dsgd_ctx* c, const float* ds) {
   if (!ds) return fail(DSGD_EINVAL, "null ds");
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
-  HIP_TRY(hipMemcpyAsync(c->d_ds, ds, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(dsgd_filter_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, c->d_ds, c->dp);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(c->d_io, ds, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
+  DSGD_TRY(launch_permute_in(c, c->d_io, c->d_ds));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->have_ds = true;
   c->s_dirty = true;
@@ -791,41 +640,50 @@ int dsgd_build_dim_sparsity(dsgd_ctx* c, int64_t n_train, float* ds_out) {
   DSGD_TRY(bind(c));
   DSGD_TRY(require_data(c));
   if (n_train < 1 || n_train > c->n_rows) return fail(DSGD_EINVAL, "n_train %lld outside [1, %lld]", (long long)n_train, c->n_rows);
+  DSGD_TRY(prepare_layout(c));
   long long nnz_train = 0;
   HIP_TRY(hipMemcpy(&nnz_train, c->d_row_ptr + n_train, sizeof(long long), hipMemcpyDeviceToHost));
   unsigned int* d_cnt = nullptr;
   HIP_TRY(hipMalloc(&d_cnt, sizeof(unsigned int) * c->dp));
-  HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * c->dp, c->stream));
-  DSGD_TRY(reset_counters(c));
-  if (nnz_train > 0) {
-    int blocks = (int)std::min<long long>((nnz_train + 255) / 256, (long long)c->n_cu * 8);
-    hipLaunchKernelGGL(dsgd_colcount_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_col, nnz_train, d_cnt, c->dp,
-                       c->d_sc);
+  int rc = reset_counters(c);
+  if (!rc) rc = count_columns(c, nnz_train, d_cnt);
+  if (!rc && c->comm) {
+    // the reference counts over the WHOLE train set (Main.scala:57-60); shards sum their counts
+    int r = rccl::AllReduce(d_cnt, d_cnt, (size_t)c->dp, rccl::kUint32, rccl::kSum, c->comm, c->stream);
+    if (r) rc = fail(DSGD_ERCCL, "ncclAllReduce(feature counts): %s", rccl::GetErrorString(r));
   }
-  int rrc = 0;
-  if (c->comm)  // the reference counts over the WHOLE train set (Main.scala:57-60); shards sum their counts
-    rrc = rccl::AllReduce(d_cnt, d_cnt, (size_t)c->dp, rccl::kUint32, rccl::kSum, c->comm, c->stream);
-  hipLaunchKernelGGL(dsgd_ds_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, d_cnt, c->d_ds, c->dp);
-  hipError_t le = hipGetLastError();
-  int rc = read_scalars(c);
+  unsigned int cnt_key0 = 0;
+  if (!rc) {
+    // Main.scala:60 does buff(idx - 1): a feature id 0 in a train row would index buff(-1)
+    int rank0 = 0;
+    hipError_t e = hipMemcpyAsync(&rank0, c->d_perm, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(&cnt_key0, d_cnt + rank0, sizeof(unsigned int), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(DSGD_EHIP, "dimSparsity: %s", hipGetErrorString(e));
+  }
+  if (!rc) {
+    hipLaunchKernelGGL(dsgd_ds_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, d_cnt, c->d_perm, c->d_ds, c->dp);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) rc = fail(DSGD_EHIP, "dimSparsity kernels: %s", hipGetErrorString(le));
+  }
+  if (!rc) rc = read_scalars(c);
   hipFree(d_cnt);
-  if (le != hipSuccess) return fail(DSGD_EHIP, "dimSparsity kernels: %s", hipGetErrorString(le));
-  if (rrc) return fail(DSGD_ERCCL, "ncclAllReduce(feature counts): %s", rccl::GetErrorString(rrc));
   DSGD_TRY(rc);
-  if (c->h_sc->err) {
-    hipMemsetAsync(&c->d_sc->err, 0, sizeof(int), c->stream);
-    return fail(DSGD_ERANGE, "feature id 0 cannot be counted by Main.scala:60 (buff(idx - 1))");
-  }
+  DSGD_TRY(check_err_flag(c));
+  if (cnt_key0) return fail(DSGD_ERANGE, "feature id 0 cannot be counted by Main.scala:60 (buff(idx - 1))");
   c->have_ds = true;
   c->s_dirty = true;
-  if (ds_out) HIP_TRY(hipMemcpy(ds_out, c->d_ds, sizeof(float) * c->dp, hipMemcpyDeviceToHost));
+  if (ds_out) {
+    DSGD_TRY(launch_permute_out(c, c->d_ds, c->d_io));
+    HIP_TRY(hipMemcpyAsync(ds_out, c->d_io, sizeof(float) * c->dp, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   return DSGD_OK;
 }
 
 static int set_weights_locked(dsgd_ctx* c, const float* w) {
-  HIP_TRY(hipMemcpyAsync(c->d_w, w, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(dsgd_filter_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, c->d_w, c->dp);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(c->d_io, w, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
+  DSGD_TRY(launch_permute_in(c, c->d_io, c->d_w));
   HIP_TRY(hipStreamSynchronize(c->stream));  // w is a pageable host buffer the caller may reuse
   c->s_dirty = true;
   return DSGD_OK;
@@ -844,7 +702,8 @@ int dsgd_get_weights(dsgd_ctx* c, float* w_out) {
   if (!w_out) return fail(DSGD_EINVAL, "null w_out");
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
-  HIP_TRY(hipMemcpyAsync(w_out, c->d_w, sizeof(float) * c->dp, hipMemcpyDeviceToHost, c->stream));
+  DSGD_TRY(launch_permute_out(c, c->d_w, c->d_io));
+  HIP_TRY(hipMemcpyAsync(w_out, c->d_io, sizeof(float) * c->dp, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return DSGD_OK;
 }
@@ -885,17 +744,19 @@ int dsgd_gradient(dsgd_ctx* c, const float* w, const int32_t* idx, int64_t n, fl
   DSGD_TRY(bind(c));
   DSGD_TRY(require_data(c));
   DSGD_TRY(require_ds(c));
+  DSGD_TRY(prepare_layout(c));
   if (w) DSGD_TRY(set_weights_locked(c, w));
   DSGD_TRY(ensure_s(c));
   DSGD_TRY(reset_counters(c));
   long long mx = 0, tot = 0;
   const int64_t nn = n;
   DSGD_TRY(stage_lists(c, &idx, &nn, 1, &mx, &tot));
-  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, 1, mx));
+  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, 1, mx, tot));
   hipLaunchKernelGGL(dsgd_regularize_kernel, dim3((c->dp + 1023) / 1024, 1), dim3(1024), 0, c->stream, c->d_g,
                      (long long)c->dp, c->dp, c->d_sc);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(g_out, c->d_g, sizeof(float) * c->dp, hipMemcpyDeviceToHost, c->stream));
+  DSGD_TRY(launch_permute_out(c, c->d_g, c->d_io));
+  HIP_TRY(hipMemcpyAsync(g_out, c->d_io, sizeof(float) * c->dp, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_g, 0, sizeof(float) * c->dp, c->stream));
   DSGD_TRY(read_scalars(c));
   DSGD_TRY(prof_collect(c));
@@ -913,8 +774,9 @@ int dsgd_apply(dsgd_ctx* c, const float* g_mean, float lr) {
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
   DSGD_TRY(require_ds(c));
-  HIP_TRY(hipMemcpyAsync(c->d_gsum, g_mean, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(dsgd_apply_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_gsum, c->d_gsum,
+  HIP_TRY(hipMemcpyAsync(c->d_io, g_mean, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
+  DSGD_TRY(launch_permute_in(c, c->d_io, c->d_gsum));
+  hipLaunchKernelGGL(dsgd_apply_kernel<false>, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_gsum, c->d_gsum,
                      (long long)c->dp, 1, c->dp, c->d_ds, 1.0f, lr, (float)c->cfg.lambda, c->d_sc);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -941,12 +803,13 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
   DSGD_TRY(bind(c));
   DSGD_TRY(require_data(c));
   DSGD_TRY(require_ds(c));
+  DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_g(c, n_workers));
   DSGD_TRY(ensure_s(c));
   DSGD_TRY(reset_counters(c));
   long long mx = 0, tot = 0;
   DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
-  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, n_workers, mx));
+  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, n_workers, mx, tot));
   DSGD_TRY(launch_finish_sync(c, n_workers, lr));
   return finish_stats(c, stats, tot);
 }
@@ -969,10 +832,11 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
     mx = std::max<long long>(mx, row_end[k] - row_begin[k]);
     tot += row_end[k] - row_begin[k];
   }
+  DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_g(c, n_workers));
   DSGD_TRY(upload_segs(c, segs));
   DSGD_TRY(ensure_s(c));
-  DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx));
+  DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx, tot));
   DSGD_TRY(launch_finish_sync(c, n_workers, lr));
   *total = tot;
   return DSGD_OK;
@@ -1079,6 +943,7 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
   DSGD_TRY(bind(c));
   DSGD_TRY(require_data(c));
   DSGD_TRY(require_ds(c));
+  DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_g(c, p->n_workers));
   DSGD_TRY(ensure_s(c));
   for (int64_t s = step_begin; s < step_end; ++s) {
@@ -1086,7 +951,8 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
     long long mx = 0;
     for (int k = 0; k < p->n_workers; ++k)
       mx = std::max<long long>(mx, p->offsets[s * p->n_workers + k + 1] - p->offsets[s * p->n_workers + k]);
-    DSGD_TRY(launch_grad(c, p->d_idx, segs, p->n_workers, mx));
+    const long long tot_s = p->offsets[(s + 1) * p->n_workers] - p->offsets[s * p->n_workers];
+    DSGD_TRY(launch_grad(c, p->d_idx, segs, p->n_workers, mx, tot_s));
     DSGD_TRY(launch_finish_sync(c, p->n_workers, lr));
     c->pending_samples += p->offsets[(s + 1) * p->n_workers] - p->offsets[s * p->n_workers];
   }
@@ -1099,6 +965,7 @@ int dsgd_forward(dsgd_ctx* c, const float* w, const int32_t* idx, int64_t n, flo
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
   DSGD_TRY(require_data(c));
+  DSGD_TRY(prepare_layout(c));
   if (w) DSGD_TRY(set_weights_locked(c, w));
   if (n == 0) return DSGD_OK;  // samplesIdx.map over an empty Seq is an empty reply (ref: core/Slave.scala:133)
   DSGD_TRY(ensure_idx(c, n));
@@ -1135,19 +1002,27 @@ int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_en
     return fail(DSGD_EINVAL, "empty row range: reduce on an empty sample list");
   if (row_begin < 0 || row_end > c->n_rows)
     return fail(DSGD_ERANGE, "rows [%lld, %lld) outside the %lld loaded rows", (long long)row_begin, (long long)row_end, c->n_rows);
+  DSGD_TRY(prepare_layout(c));
   if (w) DSGD_TRY(set_weights_locked(c, w));
   DSGD_TRY(ensure_s(c));  // also refreshes |w|^2
   DSGD_TRY(reset_counters(c));
-  const int G = c->group;
-  dim3 grid(grid_for(c, row_end - row_begin, G));
-  CsrView m = view(c);
-  switch (G) {
-    case 64: hipLaunchKernelGGL(dsgd_eval_kernel<64>, grid, dim3(256), 0, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc); break;
-    case 32: hipLaunchKernelGGL(dsgd_eval_kernel<32>, grid, dim3(256), 0, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc); break;
-    case 16: hipLaunchKernelGGL(dsgd_eval_kernel<16>, grid, dim3(256), 0, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc); break;
-    default: hipLaunchKernelGGL(dsgd_eval_kernel<8>, grid, dim3(256), 0, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc); break;
+  {
+    const int G = c->group;
+    const long long groups_per_block = 1024 / G;
+    const long long rows = row_end - row_begin;
+    dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(c->n_cu, (rows + groups_per_block - 1) / groups_per_block)));
+    // small ranges do not amortise staging 160 KiB of weights per workgroup: shrink the LDS tile
+    const int hw = rows >= 4096 ? c->hw_eval : std::min(c->hw_eval, 1024);
+    const size_t lds = sizeof(float) * (size_t)hw;
+    CsrView m = view(c);
+    switch (G) {
+      case 64: hipLaunchKernelGGL(dsgd_eval_kernel<64>, grid, dim3(1024), lds, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc, hw); break;
+      case 32: hipLaunchKernelGGL(dsgd_eval_kernel<32>, grid, dim3(1024), lds, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc, hw); break;
+      case 16: hipLaunchKernelGGL(dsgd_eval_kernel<16>, grid, dim3(1024), lds, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc, hw); break;
+      default: hipLaunchKernelGGL(dsgd_eval_kernel<8>, grid, dim3(1024), lds, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc, hw); break;
+    }
+    HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(hipGetLastError());
   long long tallies[4] = {0, 0, 0, 0};
   if (c->comm) {
     // shard-wise evaluation: three tallies + row count summed over ranks
@@ -1173,17 +1048,21 @@ int dsgd_async_step(dsgd_ctx* c, const int32_t* idx, int64_t n, float lr, float*
   DSGD_TRY(bind(c));
   DSGD_TRY(require_data(c));
   DSGD_TRY(require_ds(c));
+  DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_s(c));
   DSGD_TRY(reset_counters(c));
   long long mx = 0, tot = 0;
   const int64_t nn = n;
   DSGD_TRY(stage_lists(c, &idx, &nn, 1, &mx, &tot));
-  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, 1, mx));
+  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, 1, mx, tot));
   hipLaunchKernelGGL(dsgd_async_finish_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_g, c->dp, c->d_ds, (float)n,
                      lr, (float)c->cfg.lambda, delta_out ? c->d_tmp : (float*)nullptr, c->d_sc);
   HIP_TRY(hipGetLastError());
   c->s_dirty = false;
-  if (delta_out) HIP_TRY(hipMemcpyAsync(delta_out, c->d_tmp, sizeof(float) * c->dp, hipMemcpyDeviceToHost, c->stream));
+  if (delta_out) {
+    DSGD_TRY(launch_permute_out(c, c->d_tmp, c->d_io));
+    HIP_TRY(hipMemcpyAsync(delta_out, c->d_io, sizeof(float) * c->dp, hipMemcpyDeviceToHost, c->stream));
+  }
   return finish_stats(c, stats, tot);
 }
 
@@ -1202,8 +1081,8 @@ int dsgd_update_grad(dsgd_ctx* c, const int32_t* key, const float* dv, int64_t n
   if (e == hipSuccess) {
     reset_counters(c);
     int blocks = (int)std::min<long long>((nnz + 255) / 256, 2048);
-    hipLaunchKernelGGL(dsgd_update_grad_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_w, d_key, d_dv, (long long)nnz,
-                       c->dp, c->d_sc);
+    hipLaunchKernelGGL(dsgd_update_grad_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_w, c->d_perm, d_key, d_dv,
+                       (long long)nnz, c->dp, c->d_sc);
     hipLaunchKernelGGL(dsgd_filter_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, c->d_w, c->dp);
     e = hipGetLastError();
   }
@@ -1298,12 +1177,7 @@ int dsgd_prof_read(dsgd_ctx* c, double* ms_avg, int64_t* n_launches, int32_t res
 
 const char* dsgd_grad_kernel_name(dsgd_ctx* c) {
   if (!c) return "";
-  switch (c->group) {
-    case 64: return "dsgd_grad_rows_kernel<64>";
-    case 32: return "dsgd_grad_rows_kernel<32>";
-    case 16: return "dsgd_grad_rows_kernel<16>";
-    default: return "dsgd_grad_rows_kernel<8>";
-  }
+  return c->last_grad_kernel;
 }
 
 int dsgd_device_ptrs(dsgd_ctx* c, void** w_dev, void** g_dev, void** stream) {

@@ -1,0 +1,461 @@
+// Device code of libdsgd_hip (gfx950 / CDNA4 only: wave64, 160 KiB LDS per CU, 8 XCDs x 32 CUs).
+//
+// Citations "ref:" are relative to /root/reference/src/main/scala/epfl/distributed/.
+//
+// Column space: inside the library every dense vector (w, g, ds) and the CSR column array use
+// FREQUENCY-RANKED column ids (rank 0 = the most frequent feature).  RCV1-like data is Zipfian,
+// so the first H ranks cover most non-zeros; a workgroup stages those H weights in LDS and
+// accumulates those H gradient coordinates in LDS (ds_add_f32) instead of going to L2 for every
+// non-zero.  Measured on MI355X (tools/microbench.hip, 90 M non-zeros): scattered device-scope
+// fp32 atomics top out at ~5-14 G/s, the LDS-privatised scatter at 130-540 Gnnz/s, and an
+// LDS-staged gather at 667 Gnnz/s vs 216-349 Gnnz/s through L1/L2.  The API (include/dsgd.h)
+// speaks original keys; dsgd_hip.hip permutes at the boundary.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#define DSGD_EPS 1e-20f  // ref: math/Sparse.scala:104 (Sparse.epsilon); representable in fp32
+#define DSGD_LDS_FLOATS 40960  // 160 KiB / 4
+
+// Sparse(...) constructor filter: entries with abs(v) <= 1e-20 vanish (ref: math/Sparse.scala:108-118)
+__device__ __forceinline__ float filt(float v) { return fabsf(v) > DSGD_EPS ? v : 0.0f; }
+
+// device scalars shared by the kernels of one context
+struct DevScalars {
+  float s_reg;   // 2 * lambda * (w . ds)            (ref: core/ml/SparseSVM.scala:31)
+  float wnorm2;  // |w|^2                            (ref: math/Vec.scala:55)
+  int err;       // != 0: a sample index / key was out of range
+  int pad;
+  unsigned long long n_active;   // rows with y*(x.w) >= 0
+  unsigned long long n_samples;  // rows processed
+  unsigned long long counts[4];  // eval tallies {pred==y, pred==0, pred==-y, rows}
+};
+
+// one unit of gradient work: worker k processes items [begin, end) -- positions in the resident
+// index list (idx != nullptr) or CSR row numbers themselves (contiguous range)
+struct WorkSeg {
+  long long begin;
+  long long end;
+};
+
+struct CsrView {
+  long long n_rows;
+  const long long* __restrict__ row_ptr;
+  const int* __restrict__ col;  // frequency-ranked ids
+  const float* __restrict__ val;
+  const signed char* __restrict__ label;
+};
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  // butterfly over the G lanes of a group: fixed order -> x.w is reproducible run to run
+#pragma unroll
+  for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__device__ __forceinline__ unsigned int wave_sum_u32(unsigned int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// weight lookup: ranks < hw come from the LDS tile, the tail from L1/L2
+// (two separate loads and a select of VALUES: a select of pointers would become one flat_load)
+__device__ __forceinline__ float w_at(const float* wl, const float* __restrict__ w, int c, int hw) {
+  // the volatile qualifier keeps the LDS read a ds_read_b32 (LLVM otherwise folds the two loads
+  // into select(ptr) + flat_load_dword, which is slower than either address space's own path)
+  const bool hot = c < hw;
+  typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
+  float a = ((lds_cvfloat*)wl)[hot ? c : 0];
+  if (!hot) a = w[c];
+  return a;
+}
+
+// A row held by a group of G lanes: the first UNR*G non-zeros stay in registers between the
+// dot product and the scatter (no second trip to memory for ~half of the rows).
+template <int G, int UNR>
+struct RowRegs {
+  int c[UNR];
+  float v[UNR];
+};
+
+// x_row . w ; ref: math/Vec.scala:58 -> math/Sparse.scala:46,20-31 (products filtered at 1e-20)
+template <int G, int UNR, bool LDSW>
+__device__ __forceinline__ float row_dot(const CsrView& m, long long start, long long end, const float* wl,
+                                         const float* __restrict__ w, int hw, int sub, RowRegs<G, UNR>& r) {
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < UNR; ++k) {
+    const long long p = start + sub + k * G;
+    const bool in = p < end;
+    r.c[k] = in ? m.col[p] : -1;
+    r.v[k] = in ? m.val[p] : 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < UNR; ++k) {
+    if (r.c[k] >= 0) {
+      const float wv = LDSW ? w_at(wl, w, r.c[k], hw) : w[r.c[k]];
+      acc += filt(r.v[k] * wv);
+    }
+  }
+  for (long long p = start + sub + UNR * G; p < end; p += G) {
+    const int c = m.col[p];
+    const float wv = LDSW ? w_at(wl, w, c, hw) : w[c];
+    acc += filt(m.val[p] * wv);
+  }
+  return group_sum<G>(acc);
+}
+
+// ---- K1a: gated sub-gradient sum, small batches -----------------------------------------------------
+// g_k += sum_{i in batch_k, y_i (x_i . w) >= 0} y_i x_i
+// ref: core/Slave.scala:147-153 (per-sample backward + Vec.sum), core/ml/SparseSVM.scala:26-29.
+// grid = (blocks, n_workers); a group of G lanes walks the worker's items with a grid stride.
+// Batches of a few hundred rows (the reference's batch-size 100-200) touch ~10^4 non-zeros: the
+// scatter goes straight to L2 atomics and no LDS tile is staged.
+template <int G>
+__global__ void __launch_bounds__(256) dsgd_grad_rows_kernel(CsrView m, const float* __restrict__ w, float* g_base,
+                                                            long long g_stride, const int* __restrict__ idx,
+                                                            const WorkSeg* __restrict__ segs, DevScalars* sc) {
+  constexpr int UNR = 4;
+  const int worker = blockIdx.y;
+  const WorkSeg seg = segs[worker];
+  float* g = g_base + (long long)worker * g_stride;
+  const int sub = threadIdx.x % G;
+  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
+  unsigned int active_local = 0;
+  for (long long t = seg.begin + group; t < seg.end; t += n_groups) {
+    const long long row = idx ? (long long)idx[t] : t;
+    if (row < 0 || row >= m.n_rows) {
+      if (sub == 0) atomicExch(&sc->err, 1);
+      continue;
+    }
+    const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
+    const float y = (float)m.label[row];
+    RowRegs<G, UNR> r;
+    const float d = row_dot<G, UNR, false>(m, start, end, nullptr, w, 0, sub, r);
+    if (y * d < 0.0f) continue;  // zerosLike (ref: SparseSVM.scala:28)
+    if (sub == 0) active_local++;
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+      const float xv = filt(r.v[k] * y);  // x * y (ref: SparseSVM.scala:28, math/Vec.scala:42)
+      if (r.c[k] >= 0 && xv != 0.0f) atomicAdd(&g[r.c[k]], xv);
+    }
+    for (long long p = start + sub + UNR * G; p < end; p += G) {
+      const float xv = filt(m.val[p] * y);
+      if (xv != 0.0f) atomicAdd(&g[m.col[p]], xv);
+    }
+  }
+  // one atomic per wave for the Kamon-style counters (ref: core/Slave.scala:145,150)
+  active_local = wave_sum_u32(active_local);
+  if ((threadIdx.x & 63) == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
+}
+
+// ---- K1b: gated sub-gradient sum, large batches (the HBM-bound configuration) ----------------------------
+// One persistent 1024-lane workgroup per CU; LDS holds gl[0..hg) (private gradient accumulator for
+// the hg hottest columns) and wl[0..hw) (the hw hottest weights).  hg + hw <= 40960 floats = 160 KiB.
+// The CSR rows are the only HBM stream; every non-zero costs one LDS read (w) and, for active
+// rows, one LDS atomic; the cold tail goes to L2.  The tile is flushed once per workgroup with
+// coalesced atomics (64 consecutive floats per wave instruction).
+template <int G>
+__global__ void __launch_bounds__(1024) dsgd_grad_tiled_kernel(CsrView m, const float* __restrict__ w, float* g_base,
+                                                              long long g_stride, const int* __restrict__ idx,
+                                                              const WorkSeg* __restrict__ segs, DevScalars* sc, int hw,
+                                                              int hg) {
+  constexpr int UNR = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* gl = lds;
+  float* wl = lds + hg;
+  const int worker = blockIdx.y;
+  const WorkSeg seg = segs[worker];
+  float* g = g_base + (long long)worker * g_stride;
+  for (int j = threadIdx.x; j < hg; j += 1024) gl[j] = 0.0f;
+  for (int j = threadIdx.x; j < hw; j += 1024) wl[j] = w[j];
+  __syncthreads();
+  const int sub = threadIdx.x % G;
+  const long long group = ((long long)blockIdx.x * 1024 + threadIdx.x) / G;
+  const long long n_groups = (long long)gridDim.x * 1024 / G;
+  unsigned int active_local = 0;
+  for (long long t = seg.begin + group; t < seg.end; t += n_groups) {
+    const long long row = idx ? (long long)idx[t] : t;
+    if (row < 0 || row >= m.n_rows) {
+      if (sub == 0) atomicExch(&sc->err, 1);
+      continue;
+    }
+    const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
+    const float y = (float)m.label[row];
+    RowRegs<G, UNR> r;
+    const float d = row_dot<G, UNR, true>(m, start, end, wl, w, hw, sub, r);
+    if (y * d < 0.0f) continue;
+    if (sub == 0) active_local++;
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+      const float xv = filt(r.v[k] * y);
+      const int c = r.c[k];
+      if (c >= 0 && xv != 0.0f) {
+        if (c < hg) atomicAdd(&gl[c], xv);
+        else atomicAdd(&g[c], xv);
+      }
+    }
+    for (long long p = start + sub + UNR * G; p < end; p += G) {
+      const float xv = filt(m.val[p] * y);
+      const int c = m.col[p];
+      if (xv != 0.0f) {
+        if (c < hg) atomicAdd(&gl[c], xv);
+        else atomicAdd(&g[c], xv);
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < hg; j += 1024) {
+    const float v = gl[j];
+    if (v != 0.0f) atomicAdd(&g[j], v);
+  }
+  active_local = wave_sum_u32(active_local);
+  if ((threadIdx.x & 63) == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
+}
+
+// ---- K2: support-only scalar regulariser ------------------------------------------------------------------
+// g_k[j] += s for j in supp(g_k), s = 2*lambda*(w.ds)  (ref: SparseSVM.scala:31, math/Vec.scala:65-75)
+__global__ void __launch_bounds__(1024) dsgd_regularize_kernel(float* g_base, long long g_stride, int dp,
+                                                              const DevScalars* sc) {
+  float* g = g_base + (long long)blockIdx.y * g_stride;
+  const float s = sc->s_reg;
+  const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) {
+    float v = filt(g[j]);
+    if (add && v != 0.0f) v = filt(v + s);
+    g[j] = v;
+  }
+}
+
+// sum of the per-worker regularised gradients hosted by this context (ref: math/Vec.scala:128-131)
+__global__ void __launch_bounds__(1024) dsgd_sum_workers_kernel(const float* g_base, long long g_stride, int n_workers,
+                                                               int dp, float* out) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) {
+    float a = 0.0f;
+    for (int k = 0; k < n_workers; ++k) a = filt(a + g_base[(long long)k * g_stride + j]);
+    out[j] = a;
+  }
+}
+
+__device__ __forceinline__ float block_sum_1024(float v, float* red /* 16 floats of LDS */) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.0f;
+  const int n_waves = blockDim.x >> 6;
+  for (int i = 0; i < n_waves; ++i) t += red[i];
+  return t;
+}
+
+// ---- K3: mean over workers + update + next regulariser scalar ---------------------------------------------
+// w <- w - lr * (g_sum / K); g <- 0; s <- 2*lambda*(w.ds); |w|^2
+// ref: core/Master.scala:194-197 (Vec.mean then batchWeights - learningRate * grad)
+// REG: the (single hosted worker, no communicator) case folds K2 into the same pass.
+// Single workgroup: D+1 = 47,237 floats is one pass of 1024 lanes x 47 elements and the two dot
+// products need no inter-workgroup reduction.
+template <bool REG>
+__global__ void __launch_bounds__(1024) dsgd_apply_kernel(float* w, const float* gsum, float* zero_base,
+                                                         long long zero_stride, int n_zero, int dp,
+                                                         const float* __restrict__ ds, float n_workers_total, float lr,
+                                                         float lambda, DevScalars* sc) {
+  __shared__ float red[16];
+  const float s = sc->s_reg;
+  const bool add = REG && (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+  float dot = 0.0f, nsq = 0.0f;
+  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
+    float gv = gsum[j];
+    if (REG) {
+      gv = filt(gv);
+      if (add && gv != 0.0f) gv = filt(gv + s);
+    }
+    const float mean = filt(gv / n_workers_total);  // Vec.mean (ref: math/Vec.scala:139)
+    const float upd = filt(mean * lr);              // learningRate * grad
+    const float wn = filt(w[j] - upd);
+    w[j] = wn;
+    dot += filt(wn * ds[j]);
+    nsq += wn * wn;
+  }
+  __syncthreads();  // all reads of gsum done before it is zeroed (gsum may alias zero_base)
+  for (int k = 0; k < n_zero; ++k)
+    for (int j = threadIdx.x; j < dp; j += blockDim.x) zero_base[(long long)k * zero_stride + j] = 0.0f;
+  const float dsum = block_sum_1024(dot, red);
+  const float nsum = block_sum_1024(nsq, red);
+  if (threadIdx.x == 0) {
+    sc->s_reg = lambda * 2.0f * dsum;
+    sc->wnorm2 = nsum;
+  }
+}
+
+// s = 2*lambda*(w.ds) and |w|^2 for weights that were set from outside
+__global__ void __launch_bounds__(1024) dsgd_wstats_kernel(const float* __restrict__ w, const float* __restrict__ ds,
+                                                          int dp, float lambda, DevScalars* sc) {
+  __shared__ float red[16];
+  float dot = 0.0f, nsq = 0.0f;
+  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
+    const float wn = w[j];
+    dot += filt(wn * ds[j]);
+    nsq += wn * wn;
+  }
+  const float dsum = block_sum_1024(dot, red);
+  const float nsum = block_sum_1024(nsq, red);
+  if (threadIdx.x == 0) {
+    sc->s_reg = lambda * 2.0f * dsum;
+    sc->wnorm2 = nsum;
+  }
+}
+
+// ---- async iteration (host-driven form of Slave.asyncTask) -------------------------------------------------
+// grad = g_sum / n; delta = lr * regularize(grad, w); w -= delta  (ref: core/Slave.scala:93-101)
+__global__ void __launch_bounds__(1024) dsgd_async_finish_kernel(float* __restrict__ w, float* __restrict__ g, int dp,
+                                                                const float* __restrict__ ds, float n_samples, float lr,
+                                                                float lambda, float* delta_out, DevScalars* sc) {
+  __shared__ float red[16];
+  const float s = sc->s_reg;
+  const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+  float dot = 0.0f, nsq = 0.0f;
+  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
+    float v = filt(filt(g[j]) / n_samples);  // Vec.mean over samples
+    if (add && v != 0.0f) v = filt(v + s);   // regularize on the support
+    const float upd = filt(v * lr);
+    if (delta_out) delta_out[j] = upd;
+    const float wn = filt(w[j] - upd);
+    w[j] = wn;
+    g[j] = 0.0f;
+    dot += filt(wn * ds[j]);
+    nsq += wn * wn;
+  }
+  const float dsum = block_sum_1024(dot, red);
+  const float nsum = block_sum_1024(nsq, red);
+  if (threadIdx.x == 0) {
+    sc->s_reg = lambda * 2.0f * dsum;
+    sc->wnorm2 = nsum;
+  }
+}
+
+// w[perm[key]] -= dv (ref: core/Slave.scala:180, core/ml/GradState.scala:8)
+__global__ void dsgd_update_grad_kernel(float* w, const int* __restrict__ perm, const int* key, const float* dv,
+                                        long long nnz, int dp, DevScalars* sc) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
+    const int k = key[i];
+    if (k < 0 || k >= dp) {
+      atomicExch(&sc->err, 1);
+      continue;
+    }
+    atomicAdd(&w[perm[k]], -dv[i]);
+  }
+}
+__global__ void dsgd_filter_kernel(float* w, int dp) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) w[j] = filt(w[j]);
+}
+
+// ---- K4: prediction  p = -signum(x.w)  (ref: core/ml/SparseSVM.scala:14, core/Slave.scala:129-140) ---------
+template <int G>
+__global__ void __launch_bounds__(256) dsgd_forward_kernel(CsrView m, const float* __restrict__ w,
+                                                          const int* __restrict__ idx, long long n, float* pred,
+                                                          DevScalars* sc) {
+  constexpr int UNR = 4;
+  const int sub = threadIdx.x % G;
+  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
+  for (long long t = group; t < n; t += n_groups) {
+    const long long row = idx[t];
+    if (row < 0 || row >= m.n_rows) {
+      if (sub == 0) atomicExch(&sc->err, 1);
+      continue;
+    }
+    RowRegs<G, UNR> r;
+    const float d = row_dot<G, UNR, false>(m, m.row_ptr[row], m.row_ptr[row + 1], nullptr, w, 0, sub, r);
+    if (sub == 0) pred[t] = d > 0.0f ? -1.0f : (d < 0.0f ? 1.0f : 0.0f);
+  }
+}
+
+// ---- K5: loss / accuracy tallies over a row range -------------------------------------------------------------
+// ref: core/Master.scala:100-107, core/ml/SparseSVM.scala:16-23: with p = -signum(x.w),
+//   y*p = +1 (loss 0, correct) iff y*(x.w) < 0;  p = 0 (loss 1) iff x.w == 0;  y*p = -1 (loss 2) otherwise
+// Persistent 1024-lane workgroups with the hw hottest weights staged in LDS (hw up to 40960).
+template <int G>
+__global__ void __launch_bounds__(1024) dsgd_eval_kernel(CsrView m, const float* __restrict__ w, long long row_begin,
+                                                        long long row_end, DevScalars* sc, int hw) {
+  constexpr int UNR = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wl = lds;
+  for (int j = threadIdx.x; j < hw; j += 1024) wl[j] = w[j];
+  __syncthreads();
+  const int sub = threadIdx.x % G;
+  const long long group = ((long long)blockIdx.x * 1024 + threadIdx.x) / G;
+  const long long n_groups = (long long)gridDim.x * 1024 / G;
+  unsigned int c0 = 0, c1 = 0, c2 = 0;
+  for (long long row = row_begin + group; row < row_end; row += n_groups) {
+    RowRegs<G, UNR> r;
+    const float d = row_dot<G, UNR, true>(m, m.row_ptr[row], m.row_ptr[row + 1], wl, w, hw, sub, r);
+    const float yd = (float)m.label[row] * d;
+    if (sub == 0) {
+      if (yd < 0.0f) c0++;
+      else if (yd > 0.0f) c2++;
+      else c1++;
+    }
+  }
+  c0 = wave_sum_u32(c0);
+  c1 = wave_sum_u32(c1);
+  c2 = wave_sum_u32(c2);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&sc->counts[3], (unsigned long long)(row_end - row_begin));
+  if ((threadIdx.x & 63) == 0) {
+    if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
+    if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
+    if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
+  }
+}
+
+// ---- layout: column frequencies, ranking, permutations ---------------------------------------------------------
+// histogram of column ids with an LDS-privatised counter tile for ids < hcnt (same reasoning as K1b)
+__global__ void __launch_bounds__(1024) dsgd_colcount_kernel(const int* __restrict__ col, long long nnz,
+                                                            unsigned int* cnt, int dp, int hcnt, DevScalars* sc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int lcnt[];
+  for (int j = threadIdx.x; j < hcnt; j += 1024) lcnt[j] = 0u;
+  __syncthreads();
+  for (long long p = (long long)blockIdx.x * 1024 + threadIdx.x; p < nnz; p += (long long)gridDim.x * 1024) {
+    const int c = col[p];
+    if (c < 0 || c >= dp) {
+      atomicExch(&sc->err, 1);
+      continue;
+    }
+    if (c < hcnt) atomicAdd(&lcnt[c], 1u);
+    else atomicAdd(&cnt[c], 1u);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < hcnt; j += 1024) {
+    const unsigned int v = lcnt[j];
+    if (v) atomicAdd(&cnt[j], v);
+  }
+}
+
+// col[p] <- perm[col[p]]
+__global__ void dsgd_remap_cols_kernel(int* col, long long nnz, const int* __restrict__ perm) {
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (long long)gridDim.x * blockDim.x)
+    col[p] = perm[col[p]];
+}
+
+// out[perm[j]] = filt(in[j])  (external key order -> internal ranked order)
+__global__ void dsgd_permute_in_kernel(const float* __restrict__ in, float* out, const int* __restrict__ perm, int dp) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) out[perm[j]] = filt(in[j]);
+}
+// out[j] = in[perm[j]]  (internal ranked order -> external key order)
+__global__ void dsgd_permute_out_kernel(const float* __restrict__ in, float* out, const int* __restrict__ perm, int dp) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) out[j] = in[perm[j]];
+}
+
+// dimSparsity (ref: Main.scala:54-65): buff(idx - 1) += 1 over the train rows, then
+// ds[i] = 1 / (buff(i) + 1) for 0-based key i where buff(i) != 0 -- i.e. key i carries the count of
+// feature id i+1.  cnt is indexed by ranked id; ds is written in ranked order of KEY i.
+__global__ void dsgd_ds_kernel(const unsigned int* __restrict__ cnt, const int* __restrict__ perm, float* ds, int dp) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dp; i += gridDim.x * blockDim.x) {
+    const unsigned int c = (i < dp - 1) ? cnt[perm[i + 1]] : 0u;  // buff has D entries: keys 0..D-1
+    ds[perm[i]] = c ? filt(1.0f / ((float)c + 1.0f)) : 0.0f;
+  }
+}

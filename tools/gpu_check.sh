@@ -17,7 +17,7 @@ echo "== bench"
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 3 2> $OUT/bench.err | tee $OUT/bench.json
 tail -5 $OUT/bench.err
 echo "== rocprofv3 kernel trace"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline --no-sweep > $OLDPWD/$OUT/bench_prof.json 2> $OLDPWD/$OUT/bench_prof.err )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline --no-sweep > $OLDPWD/$OUT/bench_prof.json 2> $OLDPWD/$OUT/bench_prof.err )
 find $OUT/prof -name "*kernel_stats*" | head -3
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
 cat $OUT/env.txt
