@@ -129,6 +129,19 @@ struct dsgd_ctx {
   int hw = 8192, hg = 32768;  // LDS tile sizes (floats) of the tiled gradient kernel; hw + hg <= 40960
   int hw_eval = DSGD_LDS_FLOATS;
   long long tiled_min = 8192;  // batches with at least this many rows use the tiled kernel
+  // nnz-streaming kernels (contiguous row ranges): tiles of consecutive rows
+  std::vector<int> h_tile_row;       // n_tiles + 1
+  std::vector<long long> long_rows;  // rows with more than ST_MAXNNZ non-zeros (own tile, handled row-wise)
+  int* d_tile_row = nullptr;
+  long long* d_tile_pos = nullptr;
+  long long n_tiles = 0;
+  StreamSeg* d_ssegs = nullptr;
+  int ssegs_cap = 0;
+  std::vector<StreamSeg> ssegs_last;
+  int hw_s = 4096, hg_s = DSGD_LDS_FLOATS - ST_FIXED_FLOATS - 4096;  // LDS tiles of the streaming gradient kernel
+  int hw_se = DSGD_LDS_FLOATS - ST_FIXED_FLOATS;                     // ... of the streaming evaluation kernel
+  bool stream_ranges = true;
+  bool pf_early = false;
   const char* last_grad_kernel = "";
   // vectors
   float* d_w = nullptr;
@@ -444,6 +457,65 @@ static int reset_layout(dsgd_ctx* c) {
   return DSGD_OK;
 }
 
+// ---- nnz-streaming launches (contiguous row ranges) ----------------------------------------------------
+static int upload_ssegs(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
+  const int n = (int)segs.size();
+  if (n > c->ssegs_cap) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipFree(c->d_ssegs);
+    c->d_ssegs = nullptr;
+    HIP_TRY(hipMalloc(&c->d_ssegs, sizeof(StreamSeg) * (size_t)n));
+    c->ssegs_cap = n;
+    c->ssegs_last.clear();
+  }
+  if ((int)c->ssegs_last.size() == n && memcmp(c->ssegs_last.data(), segs.data(), sizeof(StreamSeg) * n) == 0) return DSGD_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(c->d_ssegs, segs.data(), sizeof(StreamSeg) * n, hipMemcpyHostToDevice));
+  c->ssegs_last = segs;
+  return DSGD_OK;
+}
+static StreamSeg make_sseg(dsgd_ctx* c, long long rb, long long re) {
+  const std::vector<int>& tr = c->h_tile_row;
+  StreamSeg s;
+  s.row_begin = rb;
+  s.row_end = re;
+  s.tile_begin = (std::upper_bound(tr.begin(), tr.end(), (int)rb) - tr.begin()) - 1;  // tile containing rb
+  s.tile_end = std::lower_bound(tr.begin(), tr.end(), (int)re) - tr.begin();          // one past the tile of re-1
+  return s;
+}
+template <bool SCATTER>
+static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
+  DSGD_TRY(upload_ssegs(c, segs));
+  long long max_tiles = 1;
+  for (const auto& s : segs) max_tiles = std::max(max_tiles, s.tile_end - s.tile_begin);
+  const int n_workers = (int)segs.size();
+  long long bx = std::max<long long>(1, c->n_cu / n_workers);
+  bx = std::min(bx, max_tiles);
+  dim3 grid((unsigned)bx, n_workers);
+  const int hw = SCATTER ? c->hw_s : c->hw_se;
+  const int hg = SCATTER ? c->hg_s : 0;
+  const size_t lds = sizeof(float) * (size_t)(ST_FIXED_FLOATS + hw + hg);
+  CsrView m = view(c);
+#define DSGD_LAUNCH_STREAM(GG)                                                                                          \
+  do {                                                                                                                  \
+    if (c->pf_early)                                                                                                    \
+      hipLaunchKernelGGL((dsgd_stream_kernel<GG, SCATTER, true>), grid, dim3(ST_THREADS), lds, c->stream, m,            \
+                         c->d_tile_row, c->d_tile_pos, c->d_w, c->d_g, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg);  \
+    else                                                                                                                \
+      hipLaunchKernelGGL((dsgd_stream_kernel<GG, SCATTER, false>), grid, dim3(ST_THREADS), lds, c->stream, m,           \
+                         c->d_tile_row, c->d_tile_pos, c->d_w, c->d_g, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg);  \
+  } while (0)
+  switch (c->group) {
+    case 64: DSGD_LAUNCH_STREAM(64); if (SCATTER) c->last_grad_kernel = "dsgd_stream_kernel<64, true"; break;
+    case 32: DSGD_LAUNCH_STREAM(32); if (SCATTER) c->last_grad_kernel = "dsgd_stream_kernel<32, true"; break;
+    case 16: DSGD_LAUNCH_STREAM(16); if (SCATTER) c->last_grad_kernel = "dsgd_stream_kernel<16, true"; break;
+    default: DSGD_LAUNCH_STREAM(8); if (SCATTER) c->last_grad_kernel = "dsgd_stream_kernel<8, true"; break;
+  }
+#undef DSGD_LAUNCH_STREAM
+  HIP_TRY(hipGetLastError());
+  return DSGD_OK;
+}
+
 static int require_data(dsgd_ctx* c) {
   if (!c->d_row_ptr) return fail(DSGD_ESTATE, "no data loaded (dsgd_load_csr)");
   return DSGD_OK;
@@ -523,6 +595,15 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   c->hg = std::max(0, std::min(c->hg, c->dp));
   if (c->hw + c->hg > DSGD_LDS_FLOATS) return bail(fail(DSGD_EINVAL, "DSGD_HW + DSGD_HG exceed %d floats of LDS", DSGD_LDS_FLOATS));
   c->hw_eval = std::min(c->dp, DSGD_LDS_FLOATS);
+  if (const char* e = getenv("DSGD_HW_S")) c->hw_s = atoi(e);
+  if (const char* e = getenv("DSGD_HG_S")) c->hg_s = atoi(e);
+  if (const char* e = getenv("DSGD_STREAM")) c->stream_ranges = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_PF_EARLY")) c->pf_early = atoi(e) != 0;
+  c->hw_s = std::max(0, std::min(c->hw_s, c->dp));
+  c->hg_s = std::max(0, std::min(c->hg_s, c->dp));
+  c->hw_se = std::min(c->hw_se, c->dp);
+  if (c->hw_s + c->hg_s > DSGD_LDS_FLOATS - ST_FIXED_FLOATS)
+    return bail(fail(DSGD_EINVAL, "DSGD_HW_S + DSGD_HG_S exceed %d floats of LDS", DSGD_LDS_FLOATS - ST_FIXED_FLOATS));
   const int lds_max = DSGD_LDS_FLOATS * (int)sizeof(float);
 #define DSGD_ATTR(fn) HIP_TRY_B(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max))
   DSGD_ATTR(dsgd_grad_tiled_kernel<64>);
@@ -534,6 +615,22 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_eval_kernel<16>);
   DSGD_ATTR(dsgd_eval_kernel<8>);
   DSGD_ATTR(dsgd_colcount_kernel);
+  DSGD_ATTR((dsgd_stream_kernel<64, true, true>));
+  DSGD_ATTR((dsgd_stream_kernel<64, true, false>));
+  DSGD_ATTR((dsgd_stream_kernel<64, false, true>));
+  DSGD_ATTR((dsgd_stream_kernel<64, false, false>));
+  DSGD_ATTR((dsgd_stream_kernel<32, true, true>));
+  DSGD_ATTR((dsgd_stream_kernel<32, true, false>));
+  DSGD_ATTR((dsgd_stream_kernel<32, false, true>));
+  DSGD_ATTR((dsgd_stream_kernel<32, false, false>));
+  DSGD_ATTR((dsgd_stream_kernel<16, true, true>));
+  DSGD_ATTR((dsgd_stream_kernel<16, true, false>));
+  DSGD_ATTR((dsgd_stream_kernel<16, false, true>));
+  DSGD_ATTR((dsgd_stream_kernel<16, false, false>));
+  DSGD_ATTR((dsgd_stream_kernel<8, true, true>));
+  DSGD_ATTR((dsgd_stream_kernel<8, true, false>));
+  DSGD_ATTR((dsgd_stream_kernel<8, false, true>));
+  DSGD_ATTR((dsgd_stream_kernel<8, false, false>));
 #undef DSGD_ATTR
   HIP_TRY_B(hipStreamSynchronize(c->stream));
 #undef HIP_TRY_B
@@ -564,6 +661,9 @@ int dsgd_destroy(dsgd_ctx* c) {
   hipFree(c->d_sc);
   hipFree(c->d_idx);
   hipFree(c->d_segs);
+  hipFree(c->d_tile_row);
+  hipFree(c->d_tile_pos);
+  hipFree(c->d_ssegs);
   if (c->h_sc) hipHostFree(c->h_sc);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -598,8 +698,12 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr, const int
   c->d_val = nullptr;
   c->d_label = nullptr;
   HIP_TRY(hipMalloc(&c->d_row_ptr, sizeof(long long) * (size_t)(n_rows + 1)));
-  HIP_TRY(hipMalloc(&c->d_col, sizeof(int) * (size_t)std::max<int64_t>(nnz, 1)));
-  HIP_TRY(hipMalloc(&c->d_val, sizeof(float) * (size_t)std::max<int64_t>(nnz, 1)));
+  if (n_rows >= (int64_t)1 << 31) return fail(DSGD_EUNSUPPORTED, "more than 2^31-1 rows per context");
+  // +8: the streaming kernels read whole 16-byte groups, the last one may reach past nnz
+  HIP_TRY(hipMalloc(&c->d_col, sizeof(int) * (size_t)(nnz + 8)));
+  HIP_TRY(hipMalloc(&c->d_val, sizeof(float) * (size_t)(nnz + 8)));
+  HIP_TRY(hipMemset(c->d_col + nnz, 0, sizeof(int) * 8));
+  HIP_TRY(hipMemset(c->d_val + nnz, 0, sizeof(float) * 8));
   HIP_TRY(hipMalloc(&c->d_label, (size_t)n_rows));
   HIP_TRY(hipMemcpy(c->d_row_ptr, row_ptr, sizeof(long long) * (size_t)(n_rows + 1), hipMemcpyHostToDevice));
   if (nnz) {
@@ -609,6 +713,49 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr, const int
   HIP_TRY(hipMemcpy(c->d_label, label, (size_t)n_rows, hipMemcpyHostToDevice));
   c->n_rows = n_rows;
   c->nnz = nnz;
+  {
+    // tiles of consecutive rows with <= ST_MAXNNZ non-zeros and <= ST_MAXROWS rows (greedy)
+    std::vector<int>& tr = c->h_tile_row;
+    std::vector<long long> tp;
+    tr.clear();
+    c->long_rows.clear();
+    tr.push_back(0);
+    tp.push_back(0);
+    int64_t start = 0;
+    for (int64_t i = 0; i < n_rows; ++i) {
+      const int64_t len = row_ptr[i + 1] - row_ptr[i];
+      if (len > ST_MAXNNZ) {  // over-long row: its own tile, skipped by the streaming kernels
+        if (i > start) {
+          tr.push_back((int)i);
+          tp.push_back(row_ptr[i]);
+        }
+        tr.push_back((int)(i + 1));
+        tp.push_back(row_ptr[i + 1]);
+        c->long_rows.push_back(i);
+        start = i + 1;
+        continue;
+      }
+      if (row_ptr[i + 1] - row_ptr[start] > ST_MAXNNZ || i - start >= ST_MAXROWS) {
+        tr.push_back((int)i);
+        tp.push_back(row_ptr[i]);
+        start = i;
+      }
+    }
+    if (tr.back() != (int)n_rows) {
+      tr.push_back((int)n_rows);
+      tp.push_back(row_ptr[n_rows]);
+    }
+    c->n_tiles = (long long)tr.size() - 1;
+    hipFree(c->d_tile_row);
+    hipFree(c->d_tile_pos);
+    c->d_tile_row = nullptr;
+    c->d_tile_pos = nullptr;
+    HIP_TRY(hipMalloc(&c->d_tile_row, sizeof(int) * tr.size()));
+    HIP_TRY(hipMalloc(&c->d_tile_pos, sizeof(long long) * tp.size()));
+    HIP_TRY(hipMemcpy(c->d_tile_row, tr.data(), sizeof(int) * tr.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_tile_pos, tp.data(), sizeof(long long) * tp.size(), hipMemcpyHostToDevice));
+    c->ssegs_last.clear();
+  }
   const double mean = (double)nnz / (double)n_rows;
   c->group = mean > 192.0 ? 64 : (mean > 96.0 ? 32 : (mean > 12.0 ? 16 : 8));
   return DSGD_OK;
@@ -814,6 +961,15 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
   return finish_stats(c, stats, tot);
 }
 
+static bool any_long_row(dsgd_ctx* c, const int64_t* row_begin, const int64_t* row_end, int n) {
+  if (c->long_rows.empty()) return false;
+  for (int k = 0; k < n; ++k) {
+    auto it = std::lower_bound(c->long_rows.begin(), c->long_rows.end(), (long long)row_begin[k]);
+    if (it != c->long_rows.end() && *it < row_end[k]) return true;
+  }
+  return false;
+}
+
 static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* row_end, int n_workers, float lr,
                           long long* total) {
   if (n_workers < 1 || !row_begin || !row_end) return fail(DSGD_EINVAL, "need at least one worker");
@@ -834,9 +990,19 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
   }
   DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_g(c, n_workers));
-  DSGD_TRY(upload_segs(c, segs));
   DSGD_TRY(ensure_s(c));
-  DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx, tot));
+  if (c->stream_ranges && tot >= c->tiled_min && !any_long_row(c, row_begin, row_end, n_workers)) {
+    // whole contiguous ranges: the nnz-streaming kernel (coalesced 16-byte loads, no per-row latency chain)
+    std::vector<StreamSeg> ssegs(n_workers);
+    for (int k = 0; k < n_workers; ++k) ssegs[k] = make_sseg(c, row_begin[k], row_end[k]);
+    size_t slot = 0;
+    DSGD_TRY(prof_begin(c, &slot));
+    DSGD_TRY(launch_stream<true>(c, ssegs));
+    DSGD_TRY(prof_end(c, slot));
+  } else {
+    DSGD_TRY(upload_segs(c, segs));
+    DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx, tot));
+  }
   DSGD_TRY(launch_finish_sync(c, n_workers, lr));
   *total = tot;
   return DSGD_OK;
@@ -1006,7 +1172,10 @@ int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_en
   if (w) DSGD_TRY(set_weights_locked(c, w));
   DSGD_TRY(ensure_s(c));  // also refreshes |w|^2
   DSGD_TRY(reset_counters(c));
-  {
+  if (c->stream_ranges && row_end - row_begin >= 4096 && !any_long_row(c, &row_begin, &row_end, 1)) {
+    std::vector<StreamSeg> ssegs(1, make_sseg(c, row_begin, row_end));
+    DSGD_TRY(launch_stream<false>(c, ssegs));
+  } else {
     const int G = c->group;
     const long long groups_per_block = 1024 / G;
     const long long rows = row_end - row_begin;

@@ -46,11 +46,25 @@ struct CsrView {
   const signed char* __restrict__ label;
 };
 
+// v + (v of the lane selected by a DPP control), no LDS crossbar round trip
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// Sum over the G lanes of a group, result on every lane.  Every step pairs lanes through an
+// involution (quad xor 1, quad xor 2, mirror within 8, mirror within 16, xor 16, xor 32), so all
+// lanes of the group hold the bitwise-identical sum (they must agree on the gate) and the order
+// is fixed: x.w is reproducible run to run.
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-  // butterfly over the G lanes of a group: fixed order -> x.w is reproducible run to run
-#pragma unroll
-  for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  static_assert(G == 8 || G == 16 || G == 32 || G == 64, "group width");
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  if (G >= 16) v = dpp_add<0x140>(v);  // row_mirror
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  if (G >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 
@@ -457,5 +471,185 @@ __global__ void dsgd_ds_kernel(const unsigned int* __restrict__ cnt, const int* 
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dp; i += gridDim.x * blockDim.x) {
     const unsigned int c = (i < dp - 1) ? cnt[perm[i + 1]] : 0u;  // buff has D entries: keys 0..D-1
     ds[perm[i]] = c ? filt(1.0f / ((float)c + 1.0f)) : 0.0f;
+  }
+}
+
+// ======================================================================================================
+// K1c / K5b: nnz-STREAMING kernels for contiguous row ranges (whole-shard batches, evaluation passes)
+// ======================================================================================================
+// The row-per-group kernels above chain two dependent memory round trips per row (row_ptr -> col/val)
+// and top out near 1.2 TB/s on MI355X.  Here the HBM stream is decoupled from the row structure:
+//   * at load time the rows are cut into TILES of consecutive rows with <= ST_MAXNNZ non-zeros;
+//   * a 1024-lane workgroup reads a tile's col/val with one 16-byte load per lane and array
+//     (lane l owns non-zeros [pos0 + 4l, pos0 + 4l + 4), pos0 16-byte aligned) -- addresses depend
+//     only on tile_pos[], so the NEXT tile's loads are issued before the current tile is processed;
+//   * products v * w[c] go to LDS; rows are reduced from LDS by groups of G lanes (fixed order, so
+//     x.w is reproducible); the gate coefficient y*[y(x.w) >= 0] is written back over the row's
+//     products; each lane then scatters its own four non-zeros (still in registers) into the LDS
+//     gradient tile (ds_add_f32) or, for the cold tail, into L2.
+// LDS per workgroup (floats): 2*4096 products (double buffer) + 1028 row offsets + 1024 labels
+//                             + hg gradient tile + hw weight tile  <= 40960.
+constexpr int ST_THREADS = 1024;
+constexpr int ST_TILE = 4096;             // non-zeros per tile slot (4 per lane)
+constexpr int ST_MAXNNZ = ST_TILE - 3;    // pos0 is rounded down to a multiple of 4
+constexpr int ST_MAXROWS = 1024;          // one lane stages one row offset
+constexpr int ST_FIXED_FLOATS = 2 * ST_TILE + (ST_MAXROWS + 4) + ST_MAXROWS;
+
+struct StreamSeg {
+  long long row_begin, row_end;    // rows of this worker's batch
+  long long tile_begin, tile_end;  // tiles intersecting [row_begin, row_end)
+};
+
+struct TileRegs {
+  int4 c;
+  float4 v;
+  long long rp;   // row_ptr of row r0 + lane (lanes <= nrows)
+  float y;        // label of row r0 + lane (lanes < nrows)
+  long long pos0, lo, hi;
+  int r0, nrows;
+};
+
+__device__ __forceinline__ void stream_issue(const CsrView& m, const int* __restrict__ tile_row,
+                                             const long long* __restrict__ tile_pos, long long t, int tid, TileRegs& r) {
+  r.lo = tile_pos[t];
+  r.hi = tile_pos[t + 1];
+  r.r0 = tile_row[t];
+  r.nrows = tile_row[t + 1] - r.r0;
+  if (r.hi - r.lo > ST_MAXNNZ) {  // a single over-long row: handled by the row-per-group kernel instead
+    r.hi = r.lo;
+    r.nrows = 0;
+  }
+  r.pos0 = r.lo & ~3LL;
+  const long long p = r.pos0 + 4 * tid;
+  if (p < r.hi) {  // col/val are allocated with 8 elements of padding: the 16-byte read stays in bounds
+    r.c = *reinterpret_cast<const int4*>(m.col + p);
+    r.v = *reinterpret_cast<const float4*>(m.val + p);
+  } else {
+    r.c = make_int4(0, 0, 0, 0);
+    r.v = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  r.rp = (tid <= r.nrows) ? m.row_ptr[r.r0 + tid] : 0;
+  r.y = (tid < r.nrows) ? (float)m.label[r.r0 + tid] : 0.0f;
+}
+
+// PF_EARLY: issue the prefetch of the next tile before (true) or after (false) the current tile's
+// weight gathers.  The gathers for cold columns are conditional global loads, for which hipcc
+// waits vmcnt(0): issued late, the prefetch is not drained by that wait and flies during the LDS phases.
+template <int G, bool SCATTER, bool PF_EARLY>
+__global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, const int* __restrict__ tile_row,
+                                                                const long long* __restrict__ tile_pos,
+                                                                const float* __restrict__ w, float* g_base,
+                                                                long long g_stride, const StreamSeg* __restrict__ segs,
+                                                                DevScalars* sc, int hw, int hg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* prods = lds;                                        // 2 x ST_TILE
+  int* rp = reinterpret_cast<int*>(lds + 2 * ST_TILE);       // ST_MAXROWS + 4
+  float* yl = lds + 2 * ST_TILE + (ST_MAXROWS + 4);          // ST_MAXROWS
+  float* gl = yl + ST_MAXROWS;                               // hg (SCATTER only)
+  float* wl = gl + (SCATTER ? hg : 0);                       // hw
+  constexpr int NG = ST_THREADS / G;
+  const int tid = threadIdx.x;
+  const int sub = tid % G, gidx = tid / G;
+  const StreamSeg seg = segs[blockIdx.y];
+  float* g = g_base + (long long)blockIdx.y * g_stride;
+  if (SCATTER)
+    for (int j = tid; j < hg; j += ST_THREADS) gl[j] = 0.0f;
+  for (int j = tid; j < hw; j += ST_THREADS) wl[j] = w[j];
+  __syncthreads();
+
+  unsigned int active_local = 0, c0 = 0, c1 = 0, c2 = 0;
+  long long tile = seg.tile_begin + blockIdx.x;
+  TileRegs cur, nxt, nn;
+  if (tile < seg.tile_end) stream_issue(m, tile_row, tile_pos, tile, tid, cur);
+  if (!PF_EARLY && tile + gridDim.x < seg.tile_end) stream_issue(m, tile_row, tile_pos, tile + gridDim.x, tid, nxt);
+  int buf = 0;
+  while (tile < seg.tile_end) {
+    const long long next = tile + gridDim.x;
+    if (PF_EARLY) {
+      if (next < seg.tile_end) stream_issue(m, tile_row, tile_pos, next, tid, nxt);  // in flight while we work
+    }
+
+    float* pr = prods + buf * ST_TILE;
+    const long long p = cur.pos0 + 4 * tid;
+    const int cc[4] = {cur.c.x, cur.c.y, cur.c.z, cur.c.w};
+    const float vv[4] = {cur.v.x, cur.v.y, cur.v.z, cur.v.w};
+    float pk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool valid = (p + k >= cur.lo) && (p + k < cur.hi);
+      const int c = valid ? cc[k] : 0;
+      const float wv = w_at(wl, w, c, hw);
+      pk[k] = valid ? filt(vv[k] * wv) : 0.0f;  // ref: math/Sparse.scala:46 (product map, filtered)
+    }
+    *reinterpret_cast<float4*>(pr + 4 * tid) = make_float4(pk[0], pk[1], pk[2], pk[3]);
+    if (tid <= cur.nrows) rp[tid] = (int)(cur.rp - cur.pos0);
+    if (tid < cur.nrows) yl[tid] = cur.y;
+    if (!PF_EARLY) {
+      // two tiles ahead: `nxt` (issued one iteration ago) is landing, `nn` starts now
+      if (next + gridDim.x < seg.tile_end) stream_issue(m, tile_row, tile_pos, next + gridDim.x, tid, nn);
+    }
+    __syncthreads();
+
+    // rows of the tile, G lanes each, reduced from LDS in a fixed order
+    for (int r = gidx; r < cur.nrows; r += NG) {
+      const int s = rp[r], e = rp[r + 1];
+      float acc = 0.0f;
+      for (int q = s + sub; q < e; q += G) acc += pr[q];
+      const float d = group_sum<G>(acc);  // x . w
+      const float y = yl[r];
+      const long long row = (long long)cur.r0 + r;
+      const bool in_range = row >= seg.row_begin && row < seg.row_end;
+      if (SCATTER) {
+        const bool active = in_range && !(y * d < 0.0f);  // ref: core/ml/SparseSVM.scala:27-28
+        const float coef = active ? y : 0.0f;
+        for (int q = s + sub; q < e; q += G) pr[q] = coef;
+        if (sub == 0 && active) active_local++;
+      } else if (sub == 0 && in_range) {
+        const float yd = y * d;  // ref: core/ml/SparseSVM.scala:14,16
+        if (yd < 0.0f) c0++;
+        else if (yd > 0.0f) c2++;
+        else c1++;
+      }
+    }
+    if (SCATTER) {
+      __syncthreads();
+      const float4 cf4 = *reinterpret_cast<const float4*>(pr + 4 * tid);
+      const float cf[4] = {cf4.x, cf4.y, cf4.z, cf4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (cf[k] != 0.0f) {
+          const float xv = filt(vv[k] * cf[k]);  // x * y (ref: SparseSVM.scala:28)
+          const int c = cc[k];
+          if (xv != 0.0f) {
+            if (c < hg) atomicAdd(&gl[c], xv);
+            else atomicAdd(&g[c], xv);
+          }
+        }
+      }
+    }
+    cur = nxt;
+    if (!PF_EARLY) nxt = nn;
+    tile = next;
+    buf ^= 1;
+  }
+
+  if (SCATTER) {
+    __syncthreads();
+    for (int j = tid; j < hg; j += ST_THREADS) {
+      const float v = gl[j];
+      if (v != 0.0f) atomicAdd(&g[j], v);
+    }
+    active_local = wave_sum_u32(active_local);
+    if ((tid & 63) == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
+  } else {
+    c0 = wave_sum_u32(c0);
+    c1 = wave_sum_u32(c1);
+    c2 = wave_sum_u32(c2);
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&sc->counts[3], (unsigned long long)(seg.row_end - seg.row_begin));
+    if ((tid & 63) == 0) {
+      if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
+      if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
+      if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
+    }
   }
 }

@@ -20,11 +20,22 @@ print("rows %d train %d nnz_train %d alg bytes %.1f MB" % (rows, n_train, nnz_tr
 B = n_train
 lr = 0.5 * 100.0 / B
 
-combos = [(8192, 32768), (4096, 36864), (0, 40960), (16384, 24576), (12288, 28672), (2048, 38912), (8192, 16384)]
+configs = [
+    {"DSGD_STREAM": "0"},
+    {"DSGD_STREAM": "1", "DSGD_PF_EARLY": "0"},
+    {"DSGD_STREAM": "1", "DSGD_PF_EARLY": "1"},
+    {"DSGD_STREAM": "1", "DSGD_PF_EARLY": "0", "DSGD_HW_S": "8192", "DSGD_HG_S": "22524"},
+    {"DSGD_STREAM": "1", "DSGD_PF_EARLY": "0", "DSGD_HW_S": "2048", "DSGD_HG_S": "28668"},
+    {"DSGD_STREAM": "1", "DSGD_PF_EARLY": "0", "DSGD_HW_S": "0", "DSGD_HG_S": "30716"},
+]
 if len(sys.argv) > 2:
-    combos = [tuple(int(x) for x in c.split(",")) for c in sys.argv[2:]]
-for hw, hg in combos:
-    os.environ["DSGD_HW"], os.environ["DSGD_HG"] = str(hw), str(hg)
+    configs = [dict(kv.split("=") for kv in c.split(",")) for c in sys.argv[2:]]
+for cfg in configs:
+    for k in ("DSGD_STREAM", "DSGD_PF_EARLY", "DSGD_HW_S", "DSGD_HG_S", "DSGD_HW", "DSGD_HG"):
+        os.environ.pop(k, None)
+    os.environ.update(cfg)
+    hw, hg = 0, 0
+    print(cfg, flush=True)
     eng = dsgd_amd.Engine(data.dim, 1e-5)
     eng.load_csr(data.row_ptr, data.col, data.val, data.label)
     eng.build_dim_sparsity(n_train)
