@@ -147,6 +147,8 @@ struct dsgd_ctx {
   float* d_w = nullptr;
   float* d_ds = nullptr;
   float* d_g = nullptr;  // g_cap x dp
+  long long* d_g64 = nullptr;  // g_cap x dp fixed-point accumulators of the streaming kernel (zero between steps)
+  float fix_scale = 4194304.0f;  // 2^FIX_SHIFT / vmax2
   int g_cap = 0;
   float* d_gsum = nullptr;  // dp (all-reduce buffer / sum over hosted workers)
   float* d_tmp = nullptr;   // dp scratch (ranked order)
@@ -194,10 +196,15 @@ static CsrView view(dsgd_ctx* c) {
 
 static int ensure_g(dsgd_ctx* c, int n_workers) {
   if (n_workers <= c->g_cap) return DSGD_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->d_g) HIP_TRY(hipFree(c->d_g));
+  if (c->d_g64) HIP_TRY(hipFree(c->d_g64));
   c->d_g = nullptr;
+  c->d_g64 = nullptr;
   HIP_TRY(hipMalloc(&c->d_g, sizeof(float) * (size_t)n_workers * c->dp));
+  HIP_TRY(hipMalloc(&c->d_g64, sizeof(long long) * (size_t)n_workers * c->dp));
   HIP_TRY(hipMemsetAsync(c->d_g, 0, sizeof(float) * (size_t)n_workers * c->dp, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_g64, 0, sizeof(long long) * (size_t)n_workers * c->dp, c->stream));
   c->g_cap = n_workers;
   return DSGD_OK;
 }
@@ -500,10 +507,12 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
   do {                                                                                                                  \
     if (c->pf_early)                                                                                                    \
       hipLaunchKernelGGL((dsgd_stream_kernel<GG, SCATTER, true>), grid, dim3(ST_THREADS), lds, c->stream, m,            \
-                         c->d_tile_row, c->d_tile_pos, c->d_w, c->d_g, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg);  \
+                         c->d_tile_row, c->d_tile_pos, c->d_w, c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg,  \
+                         c->fix_scale);  \
     else                                                                                                                \
       hipLaunchKernelGGL((dsgd_stream_kernel<GG, SCATTER, false>), grid, dim3(ST_THREADS), lds, c->stream, m,           \
-                         c->d_tile_row, c->d_tile_pos, c->d_w, c->d_g, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg);  \
+                         c->d_tile_row, c->d_tile_pos, c->d_w, c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg,  \
+                         c->fix_scale);  \
   } while (0)
   switch (c->group) {
     case 64: DSGD_LAUNCH_STREAM(64); if (SCATTER) c->last_grad_kernel = "dsgd_stream_kernel<64, true"; break;
@@ -513,6 +522,11 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
   }
 #undef DSGD_LAUNCH_STREAM
   HIP_TRY(hipGetLastError());
+  if (SCATTER) {
+    hipLaunchKernelGGL(dsgd_fix_finalize_kernel, dim3((c->dp + 1023) / 1024, n_workers), dim3(1024), 0, c->stream, c->d_g64,
+                       c->d_g, (long long)c->dp, c->dp, 1.0 / (double)c->fix_scale);
+    HIP_TRY(hipGetLastError());
+  }
   return DSGD_OK;
 }
 
@@ -654,6 +668,7 @@ int dsgd_destroy(dsgd_ctx* c) {
   hipFree(c->d_w);
   hipFree(c->d_ds);
   hipFree(c->d_g);
+  hipFree(c->d_g64);
   hipFree(c->d_gsum);
   hipFree(c->d_tmp);
   hipFree(c->d_io);
@@ -680,9 +695,14 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr, const int
   for (int64_t i = 0; i < n_rows; ++i)
     if (row_ptr[i + 1] < row_ptr[i]) return fail(DSGD_EINVAL, "row_ptr not monotone at row %lld", (long long)i);
   // keys must be valid Sparse keys for a vector of size D (ref: math/Sparse.scala:61-68 accepts 0..size)
-  for (int64_t p = 0; p < nnz; ++p)
+  float vmax = 0.0f;
+  for (int64_t p = 0; p < nnz; ++p) {
     if (col[p] < 0 || col[p] > c->cfg.n_features)
       return fail(DSGD_ERANGE, "column id %d at nnz %lld outside [0, %d]", col[p], (long long)p, c->cfg.n_features);
+    const float a = std::fabs(val[p]);
+    if (!(a <= 3.0e38f)) return fail(DSGD_EINVAL, "non-finite value at nnz %lld", (long long)p);  // Vec.scala:14 NaN guard
+    vmax = std::max(vmax, a);
+  }
   for (int64_t i = 0; i < n_rows; ++i)
     if (label[i] != 1 && label[i] != -1) return fail(DSGD_EINVAL, "label[%lld] = %d, expected +1/-1", (long long)i, label[i]);
   std::lock_guard<std::mutex> lk(c->mu);
@@ -713,6 +733,12 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr, const int
   HIP_TRY(hipMemcpy(c->d_label, label, (size_t)n_rows, hipMemcpyHostToDevice));
   c->n_rows = n_rows;
   c->nnz = nnz;
+  {
+    int e = 0;
+    std::frexp(vmax > 0.0f ? vmax : 1.0f, &e);  // vmax = f * 2^e, f in [0.5, 1)  ->  vmax2 = 2^e >= vmax
+    if (vmax > 0.0f && std::ldexp(1.0f, e - 1) == vmax) e -= 1;  // vmax itself a power of two
+    c->fix_scale = std::ldexp(1.0f, FIX_SHIFT - e);
+  }
   {
     // tiles of consecutive rows with <= ST_MAXNNZ non-zeros and <= ST_MAXROWS rows (greedy)
     std::vector<int>& tr = c->h_tile_row;

@@ -492,8 +492,19 @@ __global__ void dsgd_ds_kernel(const unsigned int* __restrict__ cnt, const int* 
 constexpr int ST_THREADS = 1024;
 constexpr int ST_TILE = 4096;             // non-zeros per tile slot (4 per lane)
 constexpr int ST_MAXNNZ = ST_TILE - 3;    // pos0 is rounded down to a multiple of 4
-constexpr int ST_MAXROWS = 1024;          // one lane stages one row offset
+constexpr int ST_MAXROWS = 496;           // rows per tile (<= FIX_ROWS_PER_FLUSH, one lane stages one row offset)
 constexpr int ST_FIXED_FLOATS = 2 * ST_TILE + (ST_MAXROWS + 4) + ST_MAXROWS;
+
+// Fixed-point gradient accumulation.  Measured on MI355X (tools/microbench3.hip): ds_add_f32 retires
+// 0.31 lanes/clk/CU (188 Gnnz/s chip-wide) while ds_add_u32 runs at the HBM streaming rate
+// (671 Gnnz/s).  The scatter therefore accumulates round(y*x * 2^22 / vmax2) as 32-bit integers in
+// LDS (vmax2 = max|x| rounded up to a power of two, so the scaling is exact) and drains the tile
+// into 64-bit global accumulators before 2^31 can be reached: a column receives at most one
+// contribution per row, |contribution| <= 2^22, so 511 rows never overflow.  Integer addition is
+// associative: the gradient of a whole-shard batch is bit-reproducible run to run.  Quantisation:
+// 2^-23 * vmax2 per contribution (about half an fp32 ulp of vmax2).
+constexpr int FIX_SHIFT = 22;
+constexpr int FIX_ROWS_PER_FLUSH = 511;
 
 struct StreamSeg {
   long long row_begin, row_end;    // rows of this worker's batch
@@ -538,22 +549,23 @@ __device__ __forceinline__ void stream_issue(const CsrView& m, const int* __rest
 template <int G, bool SCATTER, bool PF_EARLY>
 __global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, const int* __restrict__ tile_row,
                                                                 const long long* __restrict__ tile_pos,
-                                                                const float* __restrict__ w, float* g_base,
+                                                                const float* __restrict__ w, long long* g64_base,
                                                                 long long g_stride, const StreamSeg* __restrict__ segs,
-                                                                DevScalars* sc, int hw, int hg) {
+                                                                DevScalars* sc, int hw, int hg, float fix_scale) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* prods = lds;                                        // 2 x ST_TILE
   int* rp = reinterpret_cast<int*>(lds + 2 * ST_TILE);       // ST_MAXROWS + 4
   float* yl = lds + 2 * ST_TILE + (ST_MAXROWS + 4);          // ST_MAXROWS
-  float* gl = yl + ST_MAXROWS;                               // hg (SCATTER only)
-  float* wl = gl + (SCATTER ? hg : 0);                       // hw
+  int* gl = reinterpret_cast<int*>(yl + ST_MAXROWS);         // hg fixed-point accumulators (SCATTER only)
+  float* wl = yl + ST_MAXROWS + (SCATTER ? hg : 0);          // hw
   constexpr int NG = ST_THREADS / G;
   const int tid = threadIdx.x;
   const int sub = tid % G, gidx = tid / G;
   const StreamSeg seg = segs[blockIdx.y];
-  float* g = g_base + (long long)blockIdx.y * g_stride;
+  long long* g64 = g64_base + (long long)blockIdx.y * g_stride;
+  int rows_acc = 0;  // rows scattered into gl since it was last drained (uniform across the workgroup)
   if (SCATTER)
-    for (int j = tid; j < hg; j += ST_THREADS) gl[j] = 0.0f;
+    for (int j = tid; j < hg; j += ST_THREADS) gl[j] = 0;
   for (int j = tid; j < hw; j += ST_THREADS) wl[j] = w[j];
   __syncthreads();
 
@@ -611,8 +623,22 @@ __global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, cons
         else c1++;
       }
     }
+    __syncthreads();  // row phase done: rp/yl may be overwritten by the next tile, coefficients are visible
     if (SCATTER) {
-      __syncthreads();
+      if (rows_acc + cur.nrows > FIX_ROWS_PER_FLUSH) {
+        // drain the 32-bit LDS accumulators into the 64-bit global ones before they can overflow;
+        // every lane has passed two barriers since the previous tile's scatter, so gl is quiescent
+        for (int j = tid; j < hg; j += ST_THREADS) {
+          const int q = gl[j];
+          if (q != 0) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(&g64[j]), (unsigned long long)(long long)q);
+            gl[j] = 0;
+          }
+        }
+        rows_acc = 0;
+        __syncthreads();
+      }
+      rows_acc += cur.nrows;
       const float4 cf4 = *reinterpret_cast<const float4*>(pr + 4 * tid);
       const float cf[4] = {cf4.x, cf4.y, cf4.z, cf4.w};
 #pragma unroll
@@ -621,8 +647,9 @@ __global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, cons
           const float xv = filt(vv[k] * cf[k]);  // x * y (ref: SparseSVM.scala:28)
           const int c = cc[k];
           if (xv != 0.0f) {
-            if (c < hg) atomicAdd(&gl[c], xv);
-            else atomicAdd(&g[c], xv);
+            const int q = __float2int_rn(xv * fix_scale);
+            if (c < hg) atomicAdd(&gl[c], q);  // ds_add_u32: two's-complement wrap-around is exact
+            else atomicAdd(reinterpret_cast<unsigned long long*>(&g64[c]), (unsigned long long)(long long)q);
           }
         }
       }
@@ -636,8 +663,8 @@ __global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, cons
   if (SCATTER) {
     __syncthreads();
     for (int j = tid; j < hg; j += ST_THREADS) {
-      const float v = gl[j];
-      if (v != 0.0f) atomicAdd(&g[j], v);
+      const int q = gl[j];
+      if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[j]), (unsigned long long)(long long)q);
     }
     active_local = wave_sum_u32(active_local);
     if ((tid & 63) == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
@@ -650,6 +677,20 @@ __global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, cons
       if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
       if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
       if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
+    }
+  }
+}
+
+// fixed point -> fp32: g[j] += (float)(g64[j] * inv_scale); g64[j] = 0   (one rounding of the exact sum)
+__global__ void __launch_bounds__(1024) dsgd_fix_finalize_kernel(long long* g64_base, float* g_base, long long g_stride,
+                                                                int dp, double inv_scale) {
+  long long* g64 = g64_base + (long long)blockIdx.y * g_stride;
+  float* g = g_base + (long long)blockIdx.y * g_stride;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) {
+    const long long q = g64[j];
+    if (q != 0) {
+      g[j] += (float)((double)q * inv_scale);
+      g64[j] = 0;
     }
   }
 }
