@@ -86,6 +86,16 @@ __device__ __forceinline__ float w_at(const float* wl, const float* __restrict__
   return a;
 }
 
+// Same, with an unconditional global load (hot lanes all read w[0], one cache line): no branch
+// around a VMEM instruction, so the surrounding loop keeps counted vmcnt waits.
+__device__ __forceinline__ float w_at_uncond(const float* wl, const float* __restrict__ w, int c, int hw) {
+  const bool hot = c < hw;
+  typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
+  const float a = ((lds_cvfloat*)wl)[hot ? c : 0];
+  const float b = __builtin_nontemporal_load(w + (hot ? 0 : c));
+  return hot ? a : b;
+}
+
 // A row held by a group of G lanes: the first UNR*G non-zeros stay in registers between the
 // dot product and the scatter (no second trip to memory for ~half of the rows).
 template <int G, int UNR>
@@ -514,38 +524,151 @@ struct StreamSeg {
 struct TileRegs {
   int4 c;
   float4 v;
+  float gw[4];    // weights of the tile's COLD columns (gathered one tile ahead of their use)
   long long rp;   // row_ptr of row r0 + lane (lanes <= nrows)
   float y;        // label of row r0 + lane (lanes < nrows)
   long long pos0, lo, hi;
   int r0, nrows;
 };
 
+// Issue the loads of tile t.  Every load is UNCONDITIONAL (tile index and addresses are clamped,
+// results are masked later): with a branch around a VMEM instruction hipcc can no longer count its
+// s_waitcnt vmcnt(N) and falls back to vmcnt(0) in the middle of the tile.
 __device__ __forceinline__ void stream_issue(const CsrView& m, const int* __restrict__ tile_row,
-                                             const long long* __restrict__ tile_pos, long long t, int tid, TileRegs& r) {
-  r.lo = tile_pos[t];
-  r.hi = tile_pos[t + 1];
-  r.r0 = tile_row[t];
-  r.nrows = tile_row[t + 1] - r.r0;
-  if (r.hi - r.lo > ST_MAXNNZ) {  // a single over-long row: handled by the row-per-group kernel instead
+                                             const long long* __restrict__ tile_pos, long long t, long long t_end,
+                                             int tid, long long nnz_pad4, TileRegs& r) {
+  const bool live = t < t_end;
+  const long long tc = live ? t : t_end - 1;
+  r.lo = tile_pos[tc];
+  r.hi = tile_pos[tc + 1];
+  r.r0 = tile_row[tc];
+  r.nrows = tile_row[tc + 1] - r.r0;
+  if (!live || r.hi - r.lo > ST_MAXNNZ) {  // past the end, or a single over-long row (handled row-wise elsewhere)
     r.hi = r.lo;
     r.nrows = 0;
   }
   r.pos0 = r.lo & ~3LL;
-  const long long p = r.pos0 + 4 * tid;
-  if (p < r.hi) {  // col/val are allocated with 8 elements of padding: the 16-byte read stays in bounds
-    r.c = *reinterpret_cast<const int4*>(m.col + p);
-    r.v = *reinterpret_cast<const float4*>(m.val + p);
-  } else {
-    r.c = make_int4(0, 0, 0, 0);
-    r.v = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  r.rp = (tid <= r.nrows) ? m.row_ptr[r.r0 + tid] : 0;
-  r.y = (tid < r.nrows) ? (float)m.label[r.r0 + tid] : 0.0f;
+  long long p = r.pos0 + 4 * tid;
+  p = p < nnz_pad4 ? p : nnz_pad4;  // col/val carry 8 elements of padding: 16-byte reads stay in bounds
+  r.c = *reinterpret_cast<const int4*>(m.col + p);
+  r.v = *reinterpret_cast<const float4*>(m.val + p);
+  long long rr = (long long)r.r0 + tid;
+  rr = rr < m.n_rows ? rr : m.n_rows;
+  r.rp = m.row_ptr[rr];
+  r.y = (float)m.label[rr < m.n_rows ? rr : m.n_rows - 1];
 }
 
-// PF_EARLY: issue the prefetch of the next tile before (true) or after (false) the current tile's
-// weight gathers.  The gathers for cold columns are conditional global loads, for which hipcc
-// waits vmcnt(0): issued late, the prefetch is not drained by that wait and flies during the LDS phases.
+// cold-weight gathers of a tile whose column ids have landed (hot lanes read w[0]: one cache line)
+__device__ __forceinline__ void stream_gather(const float* __restrict__ w, int hw, TileRegs& r) {
+  r.gw[0] = w[r.c.x < hw ? 0 : r.c.x];
+  r.gw[1] = w[r.c.y < hw ? 0 : r.c.y];
+  r.gw[2] = w[r.c.z < hw ? 0 : r.c.z];
+  r.gw[3] = w[r.c.w < hw ? 0 : r.c.w];
+}
+
+struct StreamCtx {
+  float* prods;
+  int* rp;
+  float* yl;
+  int* gl;
+  float* wl;
+  long long* g64;
+  long long row_begin, row_end;
+  int hw, hg;
+  float fix_scale;
+};
+
+// One tile: products -> LDS, row sums, gate, scatter.  `cur` holds the tile (col/val/cold weights
+// landed), `nxt` is the next tile (col/val landed): its cold-weight gathers are issued here, and
+// the tile after that is issued into `nn`.  vmcnt completes in order, so everything in flight is
+// exactly one tile ahead of its use; the three register sets rotate by unrolling, never by copying
+// (a v_mov of a register with a pending load would wait for it).
+template <int G, bool SCATTER>
+__device__ __forceinline__ void stream_tile(const CsrView& m, const int* __restrict__ tile_row,
+                                            const long long* __restrict__ tile_pos, const float* __restrict__ w,
+                                            const StreamCtx& x, long long tile, long long stride, long long t_end,
+                                            long long nnz_pad4, int buf, TileRegs& cur, TileRegs& nxt, TileRegs& nn,
+                                            int& rows_acc, unsigned int& active_local, unsigned int& c0,
+                                            unsigned int& c1, unsigned int& c2) {
+  constexpr int NG = ST_THREADS / G;
+  const int tid = threadIdx.x;
+  const int sub = tid % G, gidx = tid / G;
+  stream_gather(w, x.hw, nxt);                                                            // tile t+1
+  stream_issue(m, tile_row, tile_pos, tile + 2 * stride, t_end, tid, nnz_pad4, nn);        // tile t+2
+
+  float* pr = x.prods + buf * ST_TILE;
+  const long long p = cur.pos0 + 4 * tid;
+  const int cc[4] = {cur.c.x, cur.c.y, cur.c.z, cur.c.w};
+  const float vv[4] = {cur.v.x, cur.v.y, cur.v.z, cur.v.w};
+  float pk[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool valid = (p + k >= cur.lo) && (p + k < cur.hi);
+    const bool hot = cc[k] < x.hw;
+    typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
+    const float a = ((lds_cvfloat*)x.wl)[(valid && hot) ? cc[k] : 0];
+    const float wv = hot ? a : cur.gw[k];
+    pk[k] = valid ? filt(vv[k] * wv) : 0.0f;  // ref: math/Sparse.scala:46 (product map, filtered)
+  }
+  *reinterpret_cast<float4*>(pr + 4 * tid) = make_float4(pk[0], pk[1], pk[2], pk[3]);
+  if (tid <= cur.nrows) x.rp[tid] = (int)(cur.rp - cur.pos0);
+  if (tid < cur.nrows) x.yl[tid] = cur.y;
+  __syncthreads();
+
+  // rows of the tile, G lanes each, reduced from LDS in a fixed order
+  for (int r = gidx; r < cur.nrows; r += NG) {
+    const int s = x.rp[r], e = x.rp[r + 1];
+    float acc = 0.0f;
+    for (int q = s + sub; q < e; q += G) acc += pr[q];
+    const float d = group_sum<G>(acc);  // x . w
+    const float y = x.yl[r];
+    const long long row = (long long)cur.r0 + r;
+    const bool in_range = row >= x.row_begin && row < x.row_end;
+    if (SCATTER) {
+      const bool active = in_range && !(y * d < 0.0f);  // ref: core/ml/SparseSVM.scala:27-28
+      const float coef = active ? y : 0.0f;
+      for (int q = s + sub; q < e; q += G) pr[q] = coef;
+      if (sub == 0 && active) active_local++;
+    } else if (sub == 0 && in_range) {
+      const float yd = y * d;  // ref: core/ml/SparseSVM.scala:14,16
+      if (yd < 0.0f) c0++;
+      else if (yd > 0.0f) c2++;
+      else c1++;
+    }
+  }
+  __syncthreads();  // row phase done: rp/yl may be overwritten by the next tile, coefficients are visible
+  if (SCATTER) {
+    if (rows_acc + cur.nrows > FIX_ROWS_PER_FLUSH) {
+      // drain the 32-bit LDS accumulators into the 64-bit global ones before they can overflow;
+      // every lane has passed two barriers since the previous tile's scatter, so gl is quiescent
+      for (int j = tid; j < x.hg; j += ST_THREADS) {
+        const int q = x.gl[j];
+        if (q != 0) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
+          x.gl[j] = 0;
+        }
+      }
+      rows_acc = 0;
+      __syncthreads();
+    }
+    rows_acc += cur.nrows;
+    const float4 cf4 = *reinterpret_cast<const float4*>(pr + 4 * tid);
+    const float cf[4] = {cf4.x, cf4.y, cf4.z, cf4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (cf[k] != 0.0f) {
+        const float xv = filt(vv[k] * cf[k]);  // x * y (ref: SparseSVM.scala:28)
+        const int c = cc[k];
+        if (xv != 0.0f) {
+          const int q = __float2int_rn(xv * x.fix_scale);
+          if (c < x.hg) atomicAdd(&x.gl[c], q);  // ds_add_u32: two's-complement wrap-around is exact
+          else atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[c]), (unsigned long long)(long long)q);
+        }
+      }
+    }
+  }
+}
+
 template <int G, bool SCATTER, bool PF_EARLY>
 __global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, const int* __restrict__ tile_row,
                                                                 const long long* __restrict__ tile_pos,
@@ -553,118 +676,55 @@ __global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, cons
                                                                 long long g_stride, const StreamSeg* __restrict__ segs,
                                                                 DevScalars* sc, int hw, int hg, float fix_scale) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* prods = lds;                                        // 2 x ST_TILE
-  int* rp = reinterpret_cast<int*>(lds + 2 * ST_TILE);       // ST_MAXROWS + 4
-  float* yl = lds + 2 * ST_TILE + (ST_MAXROWS + 4);          // ST_MAXROWS
-  int* gl = reinterpret_cast<int*>(yl + ST_MAXROWS);         // hg fixed-point accumulators (SCATTER only)
-  float* wl = yl + ST_MAXROWS + (SCATTER ? hg : 0);          // hw
-  constexpr int NG = ST_THREADS / G;
+  StreamCtx x;
+  x.prods = lds;                                                 // 2 x ST_TILE
+  x.rp = reinterpret_cast<int*>(lds + 2 * ST_TILE);              // ST_MAXROWS + 4
+  x.yl = lds + 2 * ST_TILE + (ST_MAXROWS + 4);                   // ST_MAXROWS
+  x.gl = reinterpret_cast<int*>(x.yl + ST_MAXROWS);              // hg fixed-point accumulators (SCATTER only)
+  x.wl = x.yl + ST_MAXROWS + (SCATTER ? hg : 0);                 // hw
   const int tid = threadIdx.x;
-  const int sub = tid % G, gidx = tid / G;
   const StreamSeg seg = segs[blockIdx.y];
-  long long* g64 = g64_base + (long long)blockIdx.y * g_stride;
+  x.g64 = g64_base + (long long)blockIdx.y * g_stride;
+  x.row_begin = seg.row_begin;
+  x.row_end = seg.row_end;
+  x.hw = hw;
+  x.hg = hg;
+  x.fix_scale = fix_scale;
   int rows_acc = 0;  // rows scattered into gl since it was last drained (uniform across the workgroup)
   if (SCATTER)
-    for (int j = tid; j < hg; j += ST_THREADS) gl[j] = 0;
-  for (int j = tid; j < hw; j += ST_THREADS) wl[j] = w[j];
+    for (int j = tid; j < hg; j += ST_THREADS) x.gl[j] = 0;
+  for (int j = tid; j < hw; j += ST_THREADS) x.wl[j] = w[j];
   __syncthreads();
 
   unsigned int active_local = 0, c0 = 0, c1 = 0, c2 = 0;
+  const long long nnz_pad4 = (m.row_ptr[m.n_rows] + 3) & ~3LL;  // last in-bounds 16-byte group start
+  const long long stride = gridDim.x;
+  const long long t_end = seg.tile_end;
   long long tile = seg.tile_begin + blockIdx.x;
-  TileRegs cur, nxt, nn;
-  if (tile < seg.tile_end) stream_issue(m, tile_row, tile_pos, tile, tid, cur);
-  if (!PF_EARLY && tile + gridDim.x < seg.tile_end) stream_issue(m, tile_row, tile_pos, tile + gridDim.x, tid, nxt);
-  int buf = 0;
-  while (tile < seg.tile_end) {
-    const long long next = tile + gridDim.x;
-    if (PF_EARLY) {
-      if (next < seg.tile_end) stream_issue(m, tile_row, tile_pos, next, tid, nxt);  // in flight while we work
+  if (tile < t_end) {
+    TileRegs A, B, C;
+    stream_issue(m, tile_row, tile_pos, tile, t_end, tid, nnz_pad4, A);
+    stream_gather(w, hw, A);
+    stream_issue(m, tile_row, tile_pos, tile + stride, t_end, tid, nnz_pad4, B);
+#define DSGD_TILE(CUR, NXT, NN, BUF) \
+  stream_tile<G, SCATTER>(m, tile_row, tile_pos, w, x, tile, stride, t_end, nnz_pad4, BUF, CUR, NXT, NN, rows_acc, \
+                          active_local, c0, c1, c2)
+    for (;;) {  // period 6 = lcm(3 register sets, 2 product buffers)
+      DSGD_TILE(A, B, C, 0); tile += stride; if (tile >= t_end) break;
+      DSGD_TILE(B, C, A, 1); tile += stride; if (tile >= t_end) break;
+      DSGD_TILE(C, A, B, 0); tile += stride; if (tile >= t_end) break;
+      DSGD_TILE(A, B, C, 1); tile += stride; if (tile >= t_end) break;
+      DSGD_TILE(B, C, A, 0); tile += stride; if (tile >= t_end) break;
+      DSGD_TILE(C, A, B, 1); tile += stride; if (tile >= t_end) break;
     }
-
-    float* pr = prods + buf * ST_TILE;
-    const long long p = cur.pos0 + 4 * tid;
-    const int cc[4] = {cur.c.x, cur.c.y, cur.c.z, cur.c.w};
-    const float vv[4] = {cur.v.x, cur.v.y, cur.v.z, cur.v.w};
-    float pk[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const bool valid = (p + k >= cur.lo) && (p + k < cur.hi);
-      const int c = valid ? cc[k] : 0;
-      const float wv = w_at(wl, w, c, hw);
-      pk[k] = valid ? filt(vv[k] * wv) : 0.0f;  // ref: math/Sparse.scala:46 (product map, filtered)
-    }
-    *reinterpret_cast<float4*>(pr + 4 * tid) = make_float4(pk[0], pk[1], pk[2], pk[3]);
-    if (tid <= cur.nrows) rp[tid] = (int)(cur.rp - cur.pos0);
-    if (tid < cur.nrows) yl[tid] = cur.y;
-    if (!PF_EARLY) {
-      // two tiles ahead: `nxt` (issued one iteration ago) is landing, `nn` starts now
-      if (next + gridDim.x < seg.tile_end) stream_issue(m, tile_row, tile_pos, next + gridDim.x, tid, nn);
-    }
-    __syncthreads();
-
-    // rows of the tile, G lanes each, reduced from LDS in a fixed order
-    for (int r = gidx; r < cur.nrows; r += NG) {
-      const int s = rp[r], e = rp[r + 1];
-      float acc = 0.0f;
-      for (int q = s + sub; q < e; q += G) acc += pr[q];
-      const float d = group_sum<G>(acc);  // x . w
-      const float y = yl[r];
-      const long long row = (long long)cur.r0 + r;
-      const bool in_range = row >= seg.row_begin && row < seg.row_end;
-      if (SCATTER) {
-        const bool active = in_range && !(y * d < 0.0f);  // ref: core/ml/SparseSVM.scala:27-28
-        const float coef = active ? y : 0.0f;
-        for (int q = s + sub; q < e; q += G) pr[q] = coef;
-        if (sub == 0 && active) active_local++;
-      } else if (sub == 0 && in_range) {
-        const float yd = y * d;  // ref: core/ml/SparseSVM.scala:14,16
-        if (yd < 0.0f) c0++;
-        else if (yd > 0.0f) c2++;
-        else c1++;
-      }
-    }
-    __syncthreads();  // row phase done: rp/yl may be overwritten by the next tile, coefficients are visible
-    if (SCATTER) {
-      if (rows_acc + cur.nrows > FIX_ROWS_PER_FLUSH) {
-        // drain the 32-bit LDS accumulators into the 64-bit global ones before they can overflow;
-        // every lane has passed two barriers since the previous tile's scatter, so gl is quiescent
-        for (int j = tid; j < hg; j += ST_THREADS) {
-          const int q = gl[j];
-          if (q != 0) {
-            atomicAdd(reinterpret_cast<unsigned long long*>(&g64[j]), (unsigned long long)(long long)q);
-            gl[j] = 0;
-          }
-        }
-        rows_acc = 0;
-        __syncthreads();
-      }
-      rows_acc += cur.nrows;
-      const float4 cf4 = *reinterpret_cast<const float4*>(pr + 4 * tid);
-      const float cf[4] = {cf4.x, cf4.y, cf4.z, cf4.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (cf[k] != 0.0f) {
-          const float xv = filt(vv[k] * cf[k]);  // x * y (ref: SparseSVM.scala:28)
-          const int c = cc[k];
-          if (xv != 0.0f) {
-            const int q = __float2int_rn(xv * fix_scale);
-            if (c < hg) atomicAdd(&gl[c], q);  // ds_add_u32: two's-complement wrap-around is exact
-            else atomicAdd(reinterpret_cast<unsigned long long*>(&g64[c]), (unsigned long long)(long long)q);
-          }
-        }
-      }
-    }
-    cur = nxt;
-    if (!PF_EARLY) nxt = nn;
-    tile = next;
-    buf ^= 1;
+#undef DSGD_TILE
   }
 
   if (SCATTER) {
     __syncthreads();
     for (int j = tid; j < hg; j += ST_THREADS) {
-      const int q = gl[j];
-      if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[j]), (unsigned long long)(long long)q);
+      const int q = x.gl[j];
+      if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
     }
     active_local = wave_sum_u32(active_local);
     if ((tid & 63) == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
