@@ -134,6 +134,9 @@ struct dsgd_ctx {
   std::vector<long long> long_rows;  // rows with more than ST_MAXNNZ non-zeros (own tile, handled row-wise)
   int* d_tile_row = nullptr;
   long long* d_tile_pos = nullptr;
+  long long* d_tile_vptr = nullptr;
+  int* d_vrow = nullptr;
+  long long n_vrow = 0;
   long long n_tiles = 0;
   StreamSeg* d_ssegs = nullptr;
   int ssegs_cap = 0;
@@ -503,17 +506,16 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
   const int hg = SCATTER ? c->hg_s : 0;
   const size_t lds = sizeof(float) * (size_t)(ST_FIXED_FLOATS + hw + hg);
   CsrView m = view(c);
-#define DSGD_LAUNCH_STREAM(GG)                                                                                          \
-  do {                                                                                                                  \
-    if (c->pf_early)                                                                                                    \
-      hipLaunchKernelGGL((dsgd_stream_kernel<GG, SCATTER, true>), grid, dim3(ST_THREADS), lds, c->stream, m,            \
-                         c->d_tile_row, c->d_tile_pos, c->d_w, c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg,  \
-                         c->fix_scale);  \
-    else                                                                                                                \
-      hipLaunchKernelGGL((dsgd_stream_kernel<GG, SCATTER, false>), grid, dim3(ST_THREADS), lds, c->stream, m,           \
-                         c->d_tile_row, c->d_tile_pos, c->d_w, c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg,  \
-                         c->fix_scale);  \
-  } while (0)
+  TileTables tt;
+  tt.tile_row = c->d_tile_row;
+  tt.tile_pos = c->d_tile_pos;
+  tt.tile_vptr = c->d_tile_vptr;
+  tt.vrow = c->d_vrow;
+  tt.n_vrow = c->n_vrow;
+  const float scale = c->fix_scale;
+#define DSGD_LAUNCH_STREAM(GG)                                                                                       \
+  hipLaunchKernelGGL((dsgd_stream_kernel<GG, SCATTER, false>), grid, dim3(ST_THREADS), lds, c->stream, m, tt, c->d_w,  \
+                     c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, scale)
   switch (c->group) {
     case 64: DSGD_LAUNCH_STREAM(64); if (SCATTER) c->last_grad_kernel = "dsgd_stream_kernel<64, true"; break;
     case 32: DSGD_LAUNCH_STREAM(32); if (SCATTER) c->last_grad_kernel = "dsgd_stream_kernel<32, true"; break;
@@ -629,21 +631,13 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_eval_kernel<16>);
   DSGD_ATTR(dsgd_eval_kernel<8>);
   DSGD_ATTR(dsgd_colcount_kernel);
-  DSGD_ATTR((dsgd_stream_kernel<64, true, true>));
   DSGD_ATTR((dsgd_stream_kernel<64, true, false>));
-  DSGD_ATTR((dsgd_stream_kernel<64, false, true>));
   DSGD_ATTR((dsgd_stream_kernel<64, false, false>));
-  DSGD_ATTR((dsgd_stream_kernel<32, true, true>));
   DSGD_ATTR((dsgd_stream_kernel<32, true, false>));
-  DSGD_ATTR((dsgd_stream_kernel<32, false, true>));
   DSGD_ATTR((dsgd_stream_kernel<32, false, false>));
-  DSGD_ATTR((dsgd_stream_kernel<16, true, true>));
   DSGD_ATTR((dsgd_stream_kernel<16, true, false>));
-  DSGD_ATTR((dsgd_stream_kernel<16, false, true>));
   DSGD_ATTR((dsgd_stream_kernel<16, false, false>));
-  DSGD_ATTR((dsgd_stream_kernel<8, true, true>));
   DSGD_ATTR((dsgd_stream_kernel<8, true, false>));
-  DSGD_ATTR((dsgd_stream_kernel<8, false, true>));
   DSGD_ATTR((dsgd_stream_kernel<8, false, false>));
 #undef DSGD_ATTR
   HIP_TRY_B(hipStreamSynchronize(c->stream));
@@ -678,6 +672,8 @@ int dsgd_destroy(dsgd_ctx* c) {
   hipFree(c->d_segs);
   hipFree(c->d_tile_row);
   hipFree(c->d_tile_pos);
+  hipFree(c->d_tile_vptr);
+  hipFree(c->d_vrow);
   hipFree(c->d_ssegs);
   if (c->h_sc) hipHostFree(c->h_sc);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -772,10 +768,36 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr, const int
       tp.push_back(row_ptr[n_rows]);
     }
     c->n_tiles = (long long)tr.size() - 1;
+    // virtual rows: every row is cut into chunks of <= ST_VCHUNK non-zeros; entry = (local row << 16) |
+    // (chunk index << 1) | last-chunk flag.  An empty row still gets one (empty, last) chunk.
+    std::vector<long long> vptr(tr.size());
+    std::vector<int> vrow;
+    vrow.reserve((size_t)(nnz / ST_VCHUNK + n_rows + 16));
+    for (size_t t = 0; t + 1 < tr.size(); ++t) {
+      vptr[t] = (long long)vrow.size();
+      if (tp[t + 1] - tp[t] > ST_MAXNNZ) continue;  // over-long row: no virtual rows, skipped by the kernel
+      for (int r = tr[t]; r < tr[t + 1]; ++r) {
+        const int64_t len = row_ptr[r + 1] - row_ptr[r];
+        const int nch = (int)std::max<int64_t>(1, (len + ST_VCHUNK - 1) / ST_VCHUNK);
+        for (int k = 0; k < nch; ++k) vrow.push_back(((r - tr[t]) << 16) | (k << 1) | (k == nch - 1 ? 1 : 0));
+      }
+      if ((long long)vrow.size() - vptr[t] > ST_MAXV) return fail(DSGD_EINVAL, "internal: tile with too many virtual rows");
+    }
+    vptr[tr.size() - 1] = (long long)vrow.size();
+    if (vrow.empty()) vrow.push_back(1);
+    c->n_vrow = (long long)vrow.size();
     hipFree(c->d_tile_row);
     hipFree(c->d_tile_pos);
+    hipFree(c->d_tile_vptr);
+    hipFree(c->d_vrow);
     c->d_tile_row = nullptr;
     c->d_tile_pos = nullptr;
+    c->d_tile_vptr = nullptr;
+    c->d_vrow = nullptr;
+    HIP_TRY(hipMalloc(&c->d_tile_vptr, sizeof(long long) * vptr.size()));
+    HIP_TRY(hipMalloc(&c->d_vrow, sizeof(int) * vrow.size()));
+    HIP_TRY(hipMemcpy(c->d_tile_vptr, vptr.data(), sizeof(long long) * vptr.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_vrow, vrow.data(), sizeof(int) * vrow.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&c->d_tile_row, sizeof(int) * tr.size()));
     HIP_TRY(hipMalloc(&c->d_tile_pos, sizeof(long long) * tp.size()));
     HIP_TRY(hipMemcpy(c->d_tile_row, tr.data(), sizeof(int) * tr.size(), hipMemcpyHostToDevice));

@@ -503,7 +503,11 @@ constexpr int ST_THREADS = 1024;
 constexpr int ST_TILE = 4096;             // non-zeros per tile slot (4 per lane)
 constexpr int ST_MAXNNZ = ST_TILE - 3;    // pos0 is rounded down to a multiple of 4
 constexpr int ST_MAXROWS = 496;           // rows per tile (<= FIX_ROWS_PER_FLUSH, one lane stages one row offset)
-constexpr int ST_FIXED_FLOATS = 2 * ST_TILE + (ST_MAXROWS + 4) + ST_MAXROWS;
+constexpr int ST_VCHUNK = 64;             // non-zeros per virtual row (a row is cut into chunks of <= 64)
+constexpr int ST_MAXV = ST_MAXROWS + ST_TILE / ST_VCHUNK + 16;  // virtual rows per tile, padded to 576
+// double-buffered small arrays: row offsets, labels, virtual-row entries, virtual-row partial sums
+constexpr int ST_SMALL = (ST_MAXROWS + 4) + ST_MAXROWS + ST_MAXV + ST_MAXV;
+constexpr int ST_FIXED_FLOATS = 2 * ST_TILE + 2 * ST_SMALL + ST_MAXROWS;
 
 // Fixed-point gradient accumulation.  Measured on MI355X (tools/microbench3.hip): ds_add_f32 retires
 // 0.31 lanes/clk/CU (188 Gnnz/s chip-wide) while ds_add_u32 runs at the HBM streaming rate
@@ -521,31 +525,43 @@ struct StreamSeg {
   long long tile_begin, tile_end;  // tiles intersecting [row_begin, row_end)
 };
 
+// tile tables built at load time (dsgd_hip.hip: build_tiles)
+struct TileTables {
+  const int* __restrict__ tile_row;        // n_tiles + 1: first row of each tile
+  const long long* __restrict__ tile_pos;  // n_tiles + 1: row_ptr[tile_row[t]]
+  const long long* __restrict__ tile_vptr; // n_tiles + 1: offsets into vrow
+  const int* __restrict__ vrow;            // virtual rows: (local row << 16) | (chunk index << 1) | last-chunk flag
+  long long n_vrow;
+};
+
 struct TileRegs {
   int4 c;
   float4 v;
   float gw[4];    // weights of the tile's COLD columns (gathered one tile ahead of their use)
   long long rp;   // row_ptr of row r0 + lane (lanes <= nrows)
   float y;        // label of row r0 + lane (lanes < nrows)
+  int ve;         // virtual-row entry of lane (lanes < nv)
   long long pos0, lo, hi;
-  int r0, nrows;
+  int r0, nrows, nv;
 };
 
 // Issue the loads of tile t.  Every load is UNCONDITIONAL (tile index and addresses are clamped,
 // results are masked later): with a branch around a VMEM instruction hipcc can no longer count its
 // s_waitcnt vmcnt(N) and falls back to vmcnt(0) in the middle of the tile.
-__device__ __forceinline__ void stream_issue(const CsrView& m, const int* __restrict__ tile_row,
-                                             const long long* __restrict__ tile_pos, long long t, long long t_end,
+__device__ __forceinline__ void stream_issue(const CsrView& m, const TileTables& tt, long long t, long long t_end,
                                              int tid, long long nnz_pad4, TileRegs& r) {
   const bool live = t < t_end;
   const long long tc = live ? t : t_end - 1;
-  r.lo = tile_pos[tc];
-  r.hi = tile_pos[tc + 1];
-  r.r0 = tile_row[tc];
-  r.nrows = tile_row[tc + 1] - r.r0;
+  r.lo = tt.tile_pos[tc];
+  r.hi = tt.tile_pos[tc + 1];
+  r.r0 = tt.tile_row[tc];
+  r.nrows = tt.tile_row[tc + 1] - r.r0;
+  const long long v0 = tt.tile_vptr[tc];
+  r.nv = (int)(tt.tile_vptr[tc + 1] - v0);
   if (!live || r.hi - r.lo > ST_MAXNNZ) {  // past the end, or a single over-long row (handled row-wise elsewhere)
     r.hi = r.lo;
     r.nrows = 0;
+    r.nv = 0;
   }
   r.pos0 = r.lo & ~3LL;
   long long p = r.pos0 + 4 * tid;
@@ -556,6 +572,9 @@ __device__ __forceinline__ void stream_issue(const CsrView& m, const int* __rest
   rr = rr < m.n_rows ? rr : m.n_rows;
   r.rp = m.row_ptr[rr];
   r.y = (float)m.label[rr < m.n_rows ? rr : m.n_rows - 1];
+  long long vi = v0 + tid;
+  vi = vi < tt.n_vrow ? vi : tt.n_vrow - 1;
+  r.ve = tt.vrow[vi];
 }
 
 // cold-weight gathers of a tile whose column ids have landed (hot lanes read w[0]: one cache line)
@@ -567,9 +586,9 @@ __device__ __forceinline__ void stream_gather(const float* __restrict__ w, int h
 }
 
 struct StreamCtx {
-  float* prods;
-  int* rp;
-  float* yl;
+  float* prods;   // 2 x ST_TILE
+  float* small;   // 2 x ST_SMALL
+  float* coefl;   // ST_MAXROWS
   int* gl;
   float* wl;
   long long* g64;
@@ -578,25 +597,37 @@ struct StreamCtx {
   float fix_scale;
 };
 
-// One tile: products -> LDS, row sums, gate, scatter.  `cur` holds the tile (col/val/cold weights
-// landed), `nxt` is the next tile (col/val landed): its cold-weight gathers are issued here, and
-// the tile after that is issued into `nn`.  vmcnt completes in order, so everything in flight is
-// exactly one tile ahead of its use; the three register sets rotate by unrolling, never by copying
-// (a v_mov of a register with a pending load would wait for it).
+// One tile.  `cur` holds the tile (col/val/cold weights landed), `nxt` is the next tile (col/val
+// landed): its cold-weight gathers are issued here, and the tile after that is issued into `nn`.
+// vmcnt completes in order, so everything in flight is exactly one tile ahead of its use; the three
+// register sets rotate by unrolling, never by copying (a v_mov of a register with a pending load
+// would wait for it).
+//   S2  products v * w[c] -> LDS (16-byte store per lane)                         | barrier
+//   A   every VIRTUAL ROW (<= 64 consecutive non-zeros of one row) is summed by G lanes: balanced
+//       work whatever the row-length distribution (one 1200-non-zero row no longer stalls the tile) | barrier
+//   B   the lane owning a row's last chunk adds the row's partial sums in order -> x.w, gate/tally
+//   (gradient only)                                                                | barrier
+//   C   the gate coefficient y*[y(x.w) >= 0] is written over the row's products    | barrier
+//   S5  each lane scatters its own four non-zeros (still in registers) with ds_add_u32
 template <int G, bool SCATTER>
-__device__ __forceinline__ void stream_tile(const CsrView& m, const int* __restrict__ tile_row,
-                                            const long long* __restrict__ tile_pos, const float* __restrict__ w,
+__device__ __forceinline__ void stream_tile(const CsrView& m, const TileTables& tt, const float* __restrict__ w,
                                             const StreamCtx& x, long long tile, long long stride, long long t_end,
                                             long long nnz_pad4, int buf, TileRegs& cur, TileRegs& nxt, TileRegs& nn,
                                             int& rows_acc, unsigned int& active_local, unsigned int& c0,
                                             unsigned int& c1, unsigned int& c2) {
   constexpr int NG = ST_THREADS / G;
+  constexpr int IT = ST_VCHUNK / G;
   const int tid = threadIdx.x;
   const int sub = tid % G, gidx = tid / G;
-  stream_gather(w, x.hw, nxt);                                                            // tile t+1
-  stream_issue(m, tile_row, tile_pos, tile + 2 * stride, t_end, tid, nnz_pad4, nn);        // tile t+2
+  stream_gather(w, x.hw, nxt);                                          // tile t+1
+  stream_issue(m, tt, tile + 2 * stride, t_end, tid, nnz_pad4, nn);      // tile t+2
 
   float* pr = x.prods + buf * ST_TILE;
+  float* sm = x.small + buf * ST_SMALL;
+  int* rp = reinterpret_cast<int*>(sm);                               // ST_MAXROWS + 4
+  float* yl = sm + (ST_MAXROWS + 4);                                  // ST_MAXROWS
+  int* ve = reinterpret_cast<int*>(sm + (ST_MAXROWS + 4) + ST_MAXROWS);  // ST_MAXV
+  float* vpart = sm + (ST_MAXROWS + 4) + ST_MAXROWS + ST_MAXV;        // ST_MAXV
   const long long p = cur.pos0 + 4 * tid;
   const int cc[4] = {cur.c.x, cur.c.y, cur.c.z, cur.c.w};
   const float vv[4] = {cur.v.x, cur.v.y, cur.v.z, cur.v.w};
@@ -611,36 +642,69 @@ __device__ __forceinline__ void stream_tile(const CsrView& m, const int* __restr
     pk[k] = valid ? filt(vv[k] * wv) : 0.0f;  // ref: math/Sparse.scala:46 (product map, filtered)
   }
   *reinterpret_cast<float4*>(pr + 4 * tid) = make_float4(pk[0], pk[1], pk[2], pk[3]);
-  if (tid <= cur.nrows) x.rp[tid] = (int)(cur.rp - cur.pos0);
-  if (tid < cur.nrows) x.yl[tid] = cur.y;
+  if (tid <= cur.nrows) rp[tid] = (int)(cur.rp - cur.pos0);
+  if (tid < cur.nrows) yl[tid] = cur.y;
+  if (tid < cur.nv) ve[tid] = cur.ve;
   __syncthreads();
 
-  // rows of the tile, G lanes each, reduced from LDS in a fixed order
-  for (int r = gidx; r < cur.nrows; r += NG) {
-    const int s = x.rp[r], e = x.rp[r + 1];
+  // A: partial sums of the virtual rows, G lanes each, fixed order
+  for (int v = gidx; v < cur.nv; v += NG) {
+    const int e = ve[v];
+    const int r = e >> 16, k = (e >> 1) & 0x7fff;
+    const int s = rp[r] + k * ST_VCHUNK;
+    const int eend = min(s + ST_VCHUNK, rp[r + 1]);
     float acc = 0.0f;
-    for (int q = s + sub; q < e; q += G) acc += pr[q];
-    const float d = group_sum<G>(acc);  // x . w
-    const float y = x.yl[r];
-    const long long row = (long long)cur.r0 + r;
-    const bool in_range = row >= x.row_begin && row < x.row_end;
-    if (SCATTER) {
-      const bool active = in_range && !(y * d < 0.0f);  // ref: core/ml/SparseSVM.scala:27-28
-      const float coef = active ? y : 0.0f;
-      for (int q = s + sub; q < e; q += G) pr[q] = coef;
-      if (sub == 0 && active) active_local++;
-    } else if (sub == 0 && in_range) {
-      const float yd = y * d;  // ref: core/ml/SparseSVM.scala:14,16
-      if (yd < 0.0f) c0++;
-      else if (yd > 0.0f) c2++;
-      else c1++;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int q = s + sub + i * G;
+      acc += (q < eend) ? pr[q] : 0.0f;
+    }
+    acc = group_sum<G>(acc);
+    if (sub == 0) vpart[v] = acc;
+  }
+  __syncthreads();
+
+  // B: x.w of every row = its partial sums added first chunk first; gate or tally
+  if (tid < cur.nv) {
+    const int e = cur.ve;
+    if (e & 1) {
+      const int r = e >> 16, k = (e >> 1) & 0x7fff;
+      float d = 0.0f;
+      for (int j = k; j >= 0; --j) d += vpart[tid - j];
+      const float y = yl[r];
+      const long long row = (long long)cur.r0 + r;
+      const bool in_range = row >= x.row_begin && row < x.row_end;
+      if (SCATTER) {
+        const bool active = in_range && !(y * d < 0.0f);  // ref: core/ml/SparseSVM.scala:27-28
+        x.coefl[r] = active ? y : 0.0f;
+        if (active) active_local++;
+      } else if (in_range) {
+        const float yd = y * d;  // ref: core/ml/SparseSVM.scala:14,16
+        if (yd < 0.0f) c0++;
+        else if (yd > 0.0f) c2++;
+        else c1++;
+      }
     }
   }
-  __syncthreads();  // row phase done: rp/yl may be overwritten by the next tile, coefficients are visible
   if (SCATTER) {
+    __syncthreads();
+    // C: coefficient of the row over the row's products
+    for (int v = gidx; v < cur.nv; v += NG) {
+      const int e = ve[v];
+      const int r = e >> 16, k = (e >> 1) & 0x7fff;
+      const int s = rp[r] + k * ST_VCHUNK;
+      const int eend = min(s + ST_VCHUNK, rp[r + 1]);
+      const float coef = x.coefl[r];
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int q = s + sub + i * G;
+        if (q < eend) pr[q] = coef;
+      }
+    }
+    __syncthreads();
     if (rows_acc + cur.nrows > FIX_ROWS_PER_FLUSH) {
       // drain the 32-bit LDS accumulators into the 64-bit global ones before they can overflow;
-      // every lane has passed two barriers since the previous tile's scatter, so gl is quiescent
+      // every lane has passed barriers since the previous tile's scatter, so gl is quiescent
       for (int j = tid; j < x.hg; j += ST_THREADS) {
         const int q = x.gl[j];
         if (q != 0) {
@@ -670,18 +734,17 @@ __device__ __forceinline__ void stream_tile(const CsrView& m, const int* __restr
 }
 
 template <int G, bool SCATTER, bool PF_EARLY>
-__global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, const int* __restrict__ tile_row,
-                                                                const long long* __restrict__ tile_pos,
-                                                                const float* __restrict__ w, long long* g64_base,
-                                                                long long g_stride, const StreamSeg* __restrict__ segs,
-                                                                DevScalars* sc, int hw, int hg, float fix_scale) {
+__global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, TileTables tt, const float* __restrict__ w,
+                                                                long long* g64_base, long long g_stride,
+                                                                const StreamSeg* __restrict__ segs, DevScalars* sc,
+                                                                int hw, int hg, float fix_scale) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   StreamCtx x;
-  x.prods = lds;                                                 // 2 x ST_TILE
-  x.rp = reinterpret_cast<int*>(lds + 2 * ST_TILE);              // ST_MAXROWS + 4
-  x.yl = lds + 2 * ST_TILE + (ST_MAXROWS + 4);                   // ST_MAXROWS
-  x.gl = reinterpret_cast<int*>(x.yl + ST_MAXROWS);              // hg fixed-point accumulators (SCATTER only)
-  x.wl = x.yl + ST_MAXROWS + (SCATTER ? hg : 0);                 // hw
+  x.prods = lds;                                               // 2 x ST_TILE
+  x.small = lds + 2 * ST_TILE;                                 // 2 x ST_SMALL
+  x.coefl = x.small + 2 * ST_SMALL;                            // ST_MAXROWS
+  x.gl = reinterpret_cast<int*>(x.coefl + ST_MAXROWS);         // hg fixed-point accumulators (SCATTER only)
+  x.wl = x.coefl + ST_MAXROWS + (SCATTER ? hg : 0);            // hw
   const int tid = threadIdx.x;
   const StreamSeg seg = segs[blockIdx.y];
   x.g64 = g64_base + (long long)blockIdx.y * g_stride;
@@ -703,13 +766,12 @@ __global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, cons
   long long tile = seg.tile_begin + blockIdx.x;
   if (tile < t_end) {
     TileRegs A, B, C;
-    stream_issue(m, tile_row, tile_pos, tile, t_end, tid, nnz_pad4, A);
+    stream_issue(m, tt, tile, t_end, tid, nnz_pad4, A);
     stream_gather(w, hw, A);
-    stream_issue(m, tile_row, tile_pos, tile + stride, t_end, tid, nnz_pad4, B);
+    stream_issue(m, tt, tile + stride, t_end, tid, nnz_pad4, B);
 #define DSGD_TILE(CUR, NXT, NN, BUF) \
-  stream_tile<G, SCATTER>(m, tile_row, tile_pos, w, x, tile, stride, t_end, nnz_pad4, BUF, CUR, NXT, NN, rows_acc, \
-                          active_local, c0, c1, c2)
-    for (;;) {  // period 6 = lcm(3 register sets, 2 product buffers)
+  stream_tile<G, SCATTER>(m, tt, w, x, tile, stride, t_end, nnz_pad4, BUF, CUR, NXT, NN, rows_acc, active_local, c0, c1, c2)
+    for (;;) {  // period 6 = lcm(3 register sets, 2 LDS buffers)
       DSGD_TILE(A, B, C, 0); tile += stride; if (tile >= t_end) break;
       DSGD_TILE(B, C, A, 1); tile += stride; if (tile >= t_end) break;
       DSGD_TILE(C, A, B, 0); tile += stride; if (tile >= t_end) break;
