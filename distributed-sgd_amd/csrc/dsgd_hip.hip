@@ -135,6 +135,8 @@ struct dsgd_ctx {
   int* d_tile_row = nullptr;
   long long* d_tile_pos = nullptr;
   long long* d_tile_vptr = nullptr;
+  int* d_tile_rp = nullptr;
+  long long n_tile_rp = 0;
   int* d_vrow = nullptr;
   long long n_vrow = 0;
   long long n_tiles = 0;
@@ -512,6 +514,8 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
   tt.tile_vptr = c->d_tile_vptr;
   tt.vrow = c->d_vrow;
   tt.n_vrow = c->n_vrow;
+  tt.tile_rp = c->d_tile_rp;
+  tt.n_tile_rp = c->n_tile_rp;
   const float scale = c->fix_scale;
 #define DSGD_LAUNCH_STREAM(GG)                                                                                       \
   hipLaunchKernelGGL((dsgd_stream_kernel<GG, SCATTER, false>), grid, dim3(ST_THREADS), lds, c->stream, m, tt, c->d_w,  \
@@ -673,6 +677,7 @@ int dsgd_destroy(dsgd_ctx* c) {
   hipFree(c->d_tile_row);
   hipFree(c->d_tile_pos);
   hipFree(c->d_tile_vptr);
+  hipFree(c->d_tile_rp);
   hipFree(c->d_vrow);
   hipFree(c->d_ssegs);
   if (c->h_sc) hipHostFree(c->h_sc);
@@ -786,6 +791,18 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr, const int
     vptr[tr.size() - 1] = (long long)vrow.size();
     if (vrow.empty()) vrow.push_back(1);
     c->n_vrow = (long long)vrow.size();
+    // per-tile row offsets relative to the tile's 16-byte aligned window start (int32: 4 B/row of traffic)
+    std::vector<int> trp((size_t)n_rows + tr.size() - 1);
+    for (size_t t = 0; t + 1 < tr.size(); ++t) {
+      const long long pos0 = tp[t] & ~3LL;
+      const size_t base = (size_t)tr[t] + t;
+      for (int r = tr[t]; r <= tr[t + 1]; ++r) trp[base + (size_t)(r - tr[t])] = (int)std::min<long long>(row_ptr[r] - pos0, 1 << 30);
+    }
+    c->n_tile_rp = (long long)trp.size();
+    hipFree(c->d_tile_rp);
+    c->d_tile_rp = nullptr;
+    HIP_TRY(hipMalloc(&c->d_tile_rp, sizeof(int) * trp.size()));
+    HIP_TRY(hipMemcpy(c->d_tile_rp, trp.data(), sizeof(int) * trp.size(), hipMemcpyHostToDevice));
     hipFree(c->d_tile_row);
     hipFree(c->d_tile_pos);
     hipFree(c->d_tile_vptr);

@@ -530,18 +530,21 @@ struct TileTables {
   const int* __restrict__ tile_row;        // n_tiles + 1: first row of each tile
   const long long* __restrict__ tile_pos;  // n_tiles + 1: row_ptr[tile_row[t]]
   const long long* __restrict__ tile_vptr; // n_tiles + 1: offsets into vrow
+  const int* __restrict__ tile_rp;         // n_rows + n_tiles: per tile nrows+1 row offsets relative to pos0,
+                                           //   tile t's block starts at tile_row[t] + t
   const int* __restrict__ vrow;            // virtual rows: (local row << 16) | (chunk index << 1) | last-chunk flag
   long long n_vrow;
+  long long n_tile_rp;
 };
 
 struct TileRegs {
   int4 c;
   float4 v;
   float gw[4];    // weights of the tile's COLD columns (gathered one tile ahead of their use)
-  long long rp;   // row_ptr of row r0 + lane (lanes <= nrows)
+  int rp;         // offset of row r0 + lane relative to pos0 (lanes <= nrows)
   float y;        // label of row r0 + lane (lanes < nrows)
   int ve;         // virtual-row entry of lane (lanes < nv)
-  long long pos0, lo, hi;
+  int lo_rel, hi_rel;  // the tile's non-zeros are slots [lo_rel, hi_rel) of the 4096-slot window at pos0
   int r0, nrows, nv;
 };
 
@@ -552,25 +555,29 @@ __device__ __forceinline__ void stream_issue(const CsrView& m, const TileTables&
                                              int tid, long long nnz_pad4, TileRegs& r) {
   const bool live = t < t_end;
   const long long tc = live ? t : t_end - 1;
-  r.lo = tt.tile_pos[tc];
-  r.hi = tt.tile_pos[tc + 1];
+  const long long lo = tt.tile_pos[tc];
+  const long long hi = tt.tile_pos[tc + 1];
+  const long long pos0 = lo & ~3LL;
   r.r0 = tt.tile_row[tc];
   r.nrows = tt.tile_row[tc + 1] - r.r0;
   const long long v0 = tt.tile_vptr[tc];
   r.nv = (int)(tt.tile_vptr[tc + 1] - v0);
-  if (!live || r.hi - r.lo > ST_MAXNNZ) {  // past the end, or a single over-long row (handled row-wise elsewhere)
-    r.hi = r.lo;
+  r.lo_rel = (int)(lo - pos0);
+  r.hi_rel = (int)(hi - pos0);
+  if (!live || hi - lo > ST_MAXNNZ) {  // past the end, or a single over-long row (handled row-wise elsewhere)
+    r.hi_rel = r.lo_rel;
     r.nrows = 0;
     r.nv = 0;
   }
-  r.pos0 = r.lo & ~3LL;
-  long long p = r.pos0 + 4 * tid;
+  long long p = pos0 + 4 * tid;
   p = p < nnz_pad4 ? p : nnz_pad4;  // col/val carry 8 elements of padding: 16-byte reads stay in bounds
   r.c = *reinterpret_cast<const int4*>(m.col + p);
   r.v = *reinterpret_cast<const float4*>(m.val + p);
+  const long long rp0 = (long long)r.r0 + tc;  // this tile's block of relative row offsets
+  long long ri = rp0 + tid;
+  ri = ri < tt.n_tile_rp ? ri : tt.n_tile_rp - 1;
+  r.rp = tt.tile_rp[ri];
   long long rr = (long long)r.r0 + tid;
-  rr = rr < m.n_rows ? rr : m.n_rows;
-  r.rp = m.row_ptr[rr];
   r.y = (float)m.label[rr < m.n_rows ? rr : m.n_rows - 1];
   long long vi = v0 + tid;
   vi = vi < tt.n_vrow ? vi : tt.n_vrow - 1;
@@ -598,10 +605,11 @@ struct StreamCtx {
 };
 
 // One tile.  `cur` holds the tile (col/val/cold weights landed), `nxt` is the next tile (col/val
-// landed): its cold-weight gathers are issued here, and the tile after that is issued into `nn`.
-// vmcnt completes in order, so everything in flight is exactly one tile ahead of its use; the three
-// register sets rotate by unrolling, never by copying (a v_mov of a register with a pending load
-// would wait for it).
+// landed): its cold-weight gathers are issued here; tile t+2 is in flight and tile t+3 is issued
+// into `far`, so two tiles (64 KiB per CU) of HBM reads stay in flight while this tile's LDS
+// phases run.  vmcnt completes in order: gathers are issued BEFORE the far tile so that the one
+// wait per tile is a counted vmcnt that leaves the far tile outstanding.  The four register sets
+// rotate by unrolling, never by copying (a v_mov of a register with a pending load would wait).
 //   S2  products v * w[c] -> LDS (16-byte store per lane)                         | barrier
 //   A   every VIRTUAL ROW (<= 64 consecutive non-zeros of one row) is summed by G lanes: balanced
 //       work whatever the row-length distribution (one 1200-non-zero row no longer stalls the tile) | barrier
@@ -612,15 +620,15 @@ struct StreamCtx {
 template <int G, bool SCATTER>
 __device__ __forceinline__ void stream_tile(const CsrView& m, const TileTables& tt, const float* __restrict__ w,
                                             const StreamCtx& x, long long tile, long long stride, long long t_end,
-                                            long long nnz_pad4, int buf, TileRegs& cur, TileRegs& nxt, TileRegs& nn,
+                                            long long nnz_pad4, int buf, TileRegs& cur, TileRegs& nxt, TileRegs& far,
                                             int& rows_acc, unsigned int& active_local, unsigned int& c0,
                                             unsigned int& c1, unsigned int& c2) {
   constexpr int NG = ST_THREADS / G;
   constexpr int IT = ST_VCHUNK / G;
   const int tid = threadIdx.x;
   const int sub = tid % G, gidx = tid / G;
-  stream_gather(w, x.hw, nxt);                                          // tile t+1
-  stream_issue(m, tt, tile + 2 * stride, t_end, tid, nnz_pad4, nn);      // tile t+2
+  stream_gather(w, x.hw, nxt);                                          // tile t+1 (its col ids landed)
+  stream_issue(m, tt, tile + 3 * stride, t_end, tid, nnz_pad4, far);     // tile t+3 (t+2 is still in flight)
 
   float* pr = x.prods + buf * ST_TILE;
   float* sm = x.small + buf * ST_SMALL;
@@ -628,13 +636,13 @@ __device__ __forceinline__ void stream_tile(const CsrView& m, const TileTables& 
   float* yl = sm + (ST_MAXROWS + 4);                                  // ST_MAXROWS
   int* ve = reinterpret_cast<int*>(sm + (ST_MAXROWS + 4) + ST_MAXROWS);  // ST_MAXV
   float* vpart = sm + (ST_MAXROWS + 4) + ST_MAXROWS + ST_MAXV;        // ST_MAXV
-  const long long p = cur.pos0 + 4 * tid;
+  const int p = 4 * tid;
   const int cc[4] = {cur.c.x, cur.c.y, cur.c.z, cur.c.w};
   const float vv[4] = {cur.v.x, cur.v.y, cur.v.z, cur.v.w};
   float pk[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const bool valid = (p + k >= cur.lo) && (p + k < cur.hi);
+    const bool valid = (p + k >= cur.lo_rel) && (p + k < cur.hi_rel);
     const bool hot = cc[k] < x.hw;
     typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
     const float a = ((lds_cvfloat*)x.wl)[(valid && hot) ? cc[k] : 0];
@@ -642,7 +650,7 @@ __device__ __forceinline__ void stream_tile(const CsrView& m, const TileTables& 
     pk[k] = valid ? filt(vv[k] * wv) : 0.0f;  // ref: math/Sparse.scala:46 (product map, filtered)
   }
   *reinterpret_cast<float4*>(pr + 4 * tid) = make_float4(pk[0], pk[1], pk[2], pk[3]);
-  if (tid <= cur.nrows) rp[tid] = (int)(cur.rp - cur.pos0);
+  if (tid <= cur.nrows) rp[tid] = cur.rp;
   if (tid < cur.nrows) yl[tid] = cur.y;
   if (tid < cur.nv) ve[tid] = cur.ve;
   __syncthreads();
@@ -765,19 +773,18 @@ __global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, Tile
   const long long t_end = seg.tile_end;
   long long tile = seg.tile_begin + blockIdx.x;
   if (tile < t_end) {
-    TileRegs A, B, C;
+    TileRegs A, B, C, D;
     stream_issue(m, tt, tile, t_end, tid, nnz_pad4, A);
-    stream_gather(w, hw, A);
     stream_issue(m, tt, tile + stride, t_end, tid, nnz_pad4, B);
-#define DSGD_TILE(CUR, NXT, NN, BUF) \
-  stream_tile<G, SCATTER>(m, tt, w, x, tile, stride, t_end, nnz_pad4, BUF, CUR, NXT, NN, rows_acc, active_local, c0, c1, c2)
-    for (;;) {  // period 6 = lcm(3 register sets, 2 LDS buffers)
-      DSGD_TILE(A, B, C, 0); tile += stride; if (tile >= t_end) break;
+    stream_issue(m, tt, tile + 2 * stride, t_end, tid, nnz_pad4, C);
+    stream_gather(w, hw, A);
+#define DSGD_TILE(CUR, NXT, FAR, BUF) \
+  stream_tile<G, SCATTER>(m, tt, w, x, tile, stride, t_end, nnz_pad4, BUF, CUR, NXT, FAR, rows_acc, active_local, c0, c1, c2)
+    for (;;) {  // period 4 = lcm(4 register sets, 2 LDS buffers)
+      DSGD_TILE(A, B, D, 0); tile += stride; if (tile >= t_end) break;
       DSGD_TILE(B, C, A, 1); tile += stride; if (tile >= t_end) break;
-      DSGD_TILE(C, A, B, 0); tile += stride; if (tile >= t_end) break;
-      DSGD_TILE(A, B, C, 1); tile += stride; if (tile >= t_end) break;
-      DSGD_TILE(B, C, A, 0); tile += stride; if (tile >= t_end) break;
-      DSGD_TILE(C, A, B, 1); tile += stride; if (tile >= t_end) break;
+      DSGD_TILE(C, D, B, 0); tile += stride; if (tile >= t_end) break;
+      DSGD_TILE(D, A, C, 1); tile += stride; if (tile >= t_end) break;
     }
 #undef DSGD_TILE
   }
