@@ -27,6 +27,9 @@
 #include <string>
 #include <vector>
 
+// one-time segmented sort of the cold-column lists (layout time, not the hot path)
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+
 #include "../../include/dsgd.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -147,6 +150,13 @@ struct dsgd_ctx {
   int hw_se = DSGD_LDS_FLOATS - ST_FIXED_FLOATS;                     // ... of the streaming evaluation kernel
   bool stream_ranges = true;
   bool pf_early = false;
+  // cold columns (rank >= hg_s): transposed (row, value) lists + per-row gate coefficients
+  unsigned int* d_cold_ptr = nullptr;  // n_cold + 1
+  int* d_cold_row = nullptr;
+  float* d_cold_val = nullptr;
+  signed char* d_coef8 = nullptr;  // n_rows
+  int n_cold = 0;
+  long long cold_nnz = 0;
   const char* last_grad_kernel = "";
   // vectors
   float* d_w = nullptr;
@@ -413,6 +423,101 @@ static int count_columns(dsgd_ctx* c, long long nnz, unsigned int* d_cnt) {
   return DSGD_OK;
 }
 
+// Transposed lists of the cold columns (rank >= hg_s) of the rows held by THIS context, sorted by
+// row: the streaming gradient kernel leaves those columns to dsgd_cold_scatter_kernel.
+static int build_cold_lists(dsgd_ctx* c) {
+  hipFree(c->d_cold_ptr);
+  hipFree(c->d_cold_row);
+  hipFree(c->d_cold_val);
+  hipFree(c->d_coef8);
+  c->d_cold_ptr = nullptr;
+  c->d_cold_row = nullptr;
+  c->d_cold_val = nullptr;
+  c->d_coef8 = nullptr;
+  c->n_cold = std::max(0, c->dp - c->hg_s);
+  c->cold_nnz = 0;
+  HIP_TRY(hipMalloc(&c->d_coef8, (size_t)std::max<long long>(c->n_rows, 1)));
+  HIP_TRY(hipMemset(c->d_coef8, 0, (size_t)std::max<long long>(c->n_rows, 1)));
+  if (!c->stream_ranges || c->n_cold == 0 || c->nnz == 0) {
+    c->n_cold = 0;
+    return DSGD_OK;
+  }
+  // local counts of the ranked columns
+  unsigned int* d_cnt = nullptr;
+  HIP_TRY(hipMalloc(&d_cnt, sizeof(unsigned int) * c->dp));
+  int rc = count_columns(c, c->nnz, d_cnt);
+  std::vector<unsigned int> cnt(c->dp);
+  if (!rc) {
+    hipError_t e = hipMemcpyAsync(cnt.data(), d_cnt, sizeof(unsigned int) * c->dp, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(DSGD_EHIP, "cold counts: %s", hipGetErrorString(e));
+  }
+  hipFree(d_cnt);
+  DSGD_TRY(rc);
+  std::vector<unsigned int> ptr((size_t)c->n_cold + 1, 0u);
+  unsigned long long tot = 0;
+  for (int j = 0; j < c->n_cold; ++j) {
+    ptr[j] = (unsigned int)tot;
+    tot += cnt[c->hg_s + j];
+  }
+  if (tot >= 0xFFFFFFFFull) {  // keep 32-bit list offsets; fall back to the row-wise kernels
+    c->n_cold = 0;
+    c->stream_ranges = false;
+    return DSGD_OK;
+  }
+  ptr[c->n_cold] = (unsigned int)tot;
+  c->cold_nnz = (long long)tot;
+  HIP_TRY(hipMalloc(&c->d_cold_ptr, sizeof(unsigned int) * ptr.size()));
+  HIP_TRY(hipMemcpy(c->d_cold_ptr, ptr.data(), sizeof(unsigned int) * ptr.size(), hipMemcpyHostToDevice));
+  if (tot == 0) return DSGD_OK;
+  unsigned int* d_cursor = nullptr;
+  int* d_row_tmp = nullptr;
+  float* d_val_tmp = nullptr;
+  void* d_temp = nullptr;
+  auto cleanup = [&]() {
+    hipFree(d_cursor);
+    hipFree(d_row_tmp);
+    hipFree(d_val_tmp);
+    hipFree(d_temp);
+  };
+#define HIP_TRY_C(expr)                                                                     \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      cleanup();                                                                            \
+      return fail(DSGD_EHIP, "%s: %s", #expr, hipGetErrorString(e__));                       \
+    }                                                                                       \
+  } while (0)
+  HIP_TRY_C(hipMalloc(&d_cursor, sizeof(unsigned int) * (size_t)c->n_cold));
+  HIP_TRY_C(hipMemcpy(d_cursor, ptr.data(), sizeof(unsigned int) * (size_t)c->n_cold, hipMemcpyHostToDevice));
+  HIP_TRY_C(hipMalloc(&d_row_tmp, sizeof(int) * tot));
+  HIP_TRY_C(hipMalloc(&d_val_tmp, sizeof(float) * tot));
+  HIP_TRY_C(hipMalloc(&c->d_cold_row, sizeof(int) * tot));
+  HIP_TRY_C(hipMalloc(&c->d_cold_val, sizeof(float) * tot));
+  {
+    CsrView m = view(c);
+    const int blocks = (int)std::max<long long>(1, std::min<long long>((c->n_rows + 15) / 16, (long long)c->n_cu * 8));
+    hipLaunchKernelGGL(dsgd_cold_fill_kernel<16>, dim3(blocks), dim3(256), 0, c->stream, m, c->hg_s, d_cursor, d_row_tmp,
+                       d_val_tmp);
+    HIP_TRY_C(hipGetLastError());
+  }
+  // canonical order inside every list: ascending row (the fill order depends on scheduling)
+  size_t temp_bytes = 0;
+  HIP_TRY_C(rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, reinterpret_cast<unsigned int*>(d_row_tmp),
+                                                reinterpret_cast<unsigned int*>(c->d_cold_row), d_val_tmp, c->d_cold_val,
+                                                (unsigned int)tot, (unsigned int)c->n_cold, c->d_cold_ptr,
+                                                c->d_cold_ptr + 1, 0, 32, c->stream));
+  HIP_TRY_C(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)));
+  HIP_TRY_C(rocprim::segmented_radix_sort_pairs(d_temp, temp_bytes, reinterpret_cast<unsigned int*>(d_row_tmp),
+                                                reinterpret_cast<unsigned int*>(c->d_cold_row), d_val_tmp, c->d_cold_val,
+                                                (unsigned int)tot, (unsigned int)c->n_cold, c->d_cold_ptr,
+                                                c->d_cold_ptr + 1, 0, 32, c->stream));
+  HIP_TRY_C(hipStreamSynchronize(c->stream));
+#undef HIP_TRY_C
+  cleanup();
+  return DSGD_OK;
+}
+
 // Rank the columns by how often they occur in the loaded rows (summed over ranks when a
 // communicator is attached, so every replica uses the same order) and relabel the CSR columns.
 // Runs once, lazily, at the first compute call after dsgd_load_csr.
@@ -450,6 +555,7 @@ static int prepare_layout(dsgd_ctx* c) {
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
+  DSGD_TRY(build_cold_lists(c));
   c->layout_ready = true;
   c->s_dirty = true;
   return DSGD_OK;
@@ -519,7 +625,7 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
   const float scale = c->fix_scale;
 #define DSGD_LAUNCH_STREAM(GG)                                                                                       \
   hipLaunchKernelGGL((dsgd_stream_kernel<GG, SCATTER, false>), grid, dim3(ST_THREADS), lds, c->stream, m, tt, c->d_w,  \
-                     c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, scale)
+                     c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, scale, c->d_coef8)
   switch (c->group) {
     case 64: DSGD_LAUNCH_STREAM(64); if (SCATTER) c->last_grad_kernel = "dsgd_stream_kernel<64, true"; break;
     case 32: DSGD_LAUNCH_STREAM(32); if (SCATTER) c->last_grad_kernel = "dsgd_stream_kernel<32, true"; break;
@@ -532,6 +638,13 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
     hipLaunchKernelGGL(dsgd_fix_finalize_kernel, dim3((c->dp + 1023) / 1024, n_workers), dim3(1024), 0, c->stream, c->d_g64,
                        c->d_g, (long long)c->dp, c->dp, 1.0 / (double)c->fix_scale);
     HIP_TRY(hipGetLastError());
+    if (c->n_cold > 0 && c->cold_nnz > 0) {
+      const int cg = 16;
+      const int blocks = std::max(1, std::min((c->n_cold * cg + 255) / 256, c->n_cu * 8 / n_workers + 1));
+      hipLaunchKernelGGL(dsgd_cold_scatter_kernel<16>, dim3(blocks, n_workers), dim3(256), 0, c->stream, c->d_cold_ptr,
+                         c->d_cold_row, c->d_cold_val, c->d_coef8, c->n_cold, c->hg_s, c->d_g, (long long)c->dp, c->d_ssegs);
+      HIP_TRY(hipGetLastError());
+    }
   }
   return DSGD_OK;
 }
@@ -680,6 +793,10 @@ int dsgd_destroy(dsgd_ctx* c) {
   hipFree(c->d_tile_rp);
   hipFree(c->d_vrow);
   hipFree(c->d_ssegs);
+  hipFree(c->d_cold_ptr);
+  hipFree(c->d_cold_row);
+  hipFree(c->d_cold_val);
+  hipFree(c->d_coef8);
   if (c->h_sc) hipHostFree(c->h_sc);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;

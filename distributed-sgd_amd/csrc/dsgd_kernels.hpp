@@ -593,6 +593,7 @@ __device__ __forceinline__ void stream_gather(const float* __restrict__ w, int h
 }
 
 struct StreamCtx {
+  signed char* coef8;  // per-row gate coefficient y*[active] for the cold-column pass
   float* prods;   // 2 x ST_TILE
   float* small;   // 2 x ST_SMALL
   float* coefl;   // ST_MAXROWS
@@ -685,6 +686,7 @@ __device__ __forceinline__ void stream_tile(const CsrView& m, const TileTables& 
       if (SCATTER) {
         const bool active = in_range && !(y * d < 0.0f);  // ref: core/ml/SparseSVM.scala:27-28
         x.coefl[r] = active ? y : 0.0f;
+        if (in_range) x.coef8[row] = (signed char)(active ? (int)y : 0);
         if (active) active_local++;
       } else if (in_range) {
         const float yd = y * d;  // ref: core/ml/SparseSVM.scala:14,16
@@ -732,9 +734,9 @@ __device__ __forceinline__ void stream_tile(const CsrView& m, const TileTables& 
         const float xv = filt(vv[k] * cf[k]);  // x * y (ref: SparseSVM.scala:28)
         const int c = cc[k];
         if (xv != 0.0f) {
-          const int q = __float2int_rn(xv * x.fix_scale);
-          if (c < x.hg) atomicAdd(&x.gl[c], q);  // ds_add_u32: two's-complement wrap-around is exact
-          else atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[c]), (unsigned long long)(long long)q);
+          // columns >= hg are COLD: scattered L2 atomics top out near 16 G/s on MI355X, so their
+          // gradient comes from the transposed cold-column lists instead (dsgd_cold_scatter_kernel)
+          if (c < x.hg) atomicAdd(&x.gl[c], __float2int_rn(xv * x.fix_scale));  // ds_add_u32: wrap-around is exact
         }
       }
     }
@@ -745,9 +747,10 @@ template <int G, bool SCATTER, bool PF_EARLY>
 __global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, TileTables tt, const float* __restrict__ w,
                                                                 long long* g64_base, long long g_stride,
                                                                 const StreamSeg* __restrict__ segs, DevScalars* sc,
-                                                                int hw, int hg, float fix_scale) {
+                                                                int hw, int hg, float fix_scale, signed char* coef8) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   StreamCtx x;
+  x.coef8 = coef8;
   x.prods = lds;                                               // 2 x ST_TILE
   x.small = lds + 2 * ST_TILE;                                 // 2 x ST_SMALL
   x.coefl = x.small + 2 * ST_SMALL;                            // ST_MAXROWS
@@ -821,5 +824,63 @@ __global__ void __launch_bounds__(1024) dsgd_fix_finalize_kernel(long long* g64_
       g[j] += (float)((double)q * inv_scale);
       g64[j] = 0;
     }
+  }
+}
+
+// ---- cold columns (rank >= hg): transposed lists built once at layout time ------------------------------
+// fill: every non-zero of a cold column appends (row, value) to the column's list
+template <int G>
+__global__ void __launch_bounds__(256) dsgd_cold_fill_kernel(CsrView m, int hg, unsigned int* cursor, int* cold_row,
+                                                            float* cold_val) {
+  const int sub = threadIdx.x % G;
+  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
+  for (long long row = group; row < m.n_rows; row += n_groups) {
+    const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
+    for (long long p = start + sub; p < end; p += G) {
+      const int c = m.col[p];
+      if (c >= hg) {
+        const unsigned int pos = atomicAdd(&cursor[c - hg], 1u);
+        cold_row[pos] = (int)row;
+        cold_val[pos] = m.val[p];
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned int lower_bound_rows(const int* __restrict__ rows, unsigned int b, unsigned int e,
+                                                          long long key) {
+  while (b < e) {
+    const unsigned int mid = b + ((e - b) >> 1);
+    if ((long long)rows[mid] < key) b = mid + 1;
+    else e = mid;
+  }
+  return b;
+}
+
+// g_k[hg + j] = sum over the entries of cold column j whose row lies in worker k's batch of
+// coef[row] * value, in list order (rows ascending): no atomics, reproducible.
+// ref: core/Slave.scala:147-153 restricted to the cold columns.
+template <int G>
+__global__ void __launch_bounds__(256) dsgd_cold_scatter_kernel(const unsigned int* __restrict__ cold_ptr,
+                                                               const int* __restrict__ cold_row,
+                                                               const float* __restrict__ cold_val,
+                                                               const signed char* __restrict__ coef8, int n_cold, int hg,
+                                                               float* g_base, long long g_stride,
+                                                               const StreamSeg* __restrict__ segs) {
+  const StreamSeg seg = segs[blockIdx.y];
+  float* g = g_base + (long long)blockIdx.y * g_stride;
+  const int sub = threadIdx.x % G;
+  const int group = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const int n_groups = gridDim.x * blockDim.x / G;
+  for (int j = group; j < n_cold; j += n_groups) {
+    unsigned int b = cold_ptr[j], e = cold_ptr[j + 1];
+    if (b == e) continue;
+    if ((long long)cold_row[b] < seg.row_begin) b = lower_bound_rows(cold_row, b, e, seg.row_begin);
+    if (b < e && (long long)cold_row[e - 1] >= seg.row_end) e = lower_bound_rows(cold_row, b, e, seg.row_end);
+    float acc = 0.0f;
+    for (unsigned int q = b + sub; q < e; q += G) acc += filt(cold_val[q] * (float)coef8[cold_row[q]]);
+    acc = group_sum<G>(acc);
+    if (sub == 0 && acc != 0.0f) g[hg + j] += acc;
   }
 }
