@@ -150,6 +150,11 @@ struct dsgd_ctx {
   int hw_se = DSGD_LDS_FLOATS - ST_FIXED_FLOATS;                     // ... of the streaming evaluation kernel
   bool stream_ranges = true;
   bool pf_early = false;
+  int stream_mode = 2;  // 1: LDS-staged products (dsgd_stream_kernel), 2: register segmented scan (dsgd_seg_kernel)
+  unsigned short* d_tile_meta = nullptr;  // n_tiles x 1024 lane descriptors of the seg kernels
+  int hw_g = 6144, hg_g = DSGD_LDS_FLOATS - SG_LDS_FIXED - 6144 - 2;  // LDS tiles of the seg gradient kernel
+  int hw_ge = DSGD_LDS_FLOATS - SG_LDS_FIXED - 2;                     // ... of the seg evaluation kernel
+  int hg_cold() const { return stream_mode == 2 ? hg_g : hg_s; }
   // cold columns (rank >= hg_s): transposed (row, value) lists + per-row gate coefficients
   unsigned int* d_cold_ptr = nullptr;  // n_cold + 1
   int* d_cold_row = nullptr;
@@ -416,8 +421,8 @@ static int count_columns(dsgd_ctx* c, long long nnz, unsigned int* d_cnt) {
   if (nnz > 0) {
     const int hcnt = std::min(c->dp, DSGD_LDS_FLOATS);
     const int blocks = (int)std::max<long long>(1, std::min<long long>((nnz + 4095) / 4096, c->n_cu));
-    hipLaunchKernelGGL(dsgd_colcount_kernel, dim3(blocks), dim3(1024), sizeof(unsigned int) * hcnt, c->stream, c->d_col, nnz,
-                       d_cnt, c->dp, hcnt, c->d_sc);
+    hipLaunchKernelGGL(dsgd_colcount_kernel, dim3(blocks), dim3(1024), sizeof(unsigned int) * hcnt, c->stream, c->d_col,
+                       c->d_val, nnz, d_cnt, c->dp, hcnt, c->d_sc);
     HIP_TRY(hipGetLastError());
   }
   return DSGD_OK;
@@ -434,7 +439,7 @@ static int build_cold_lists(dsgd_ctx* c) {
   c->d_cold_row = nullptr;
   c->d_cold_val = nullptr;
   c->d_coef8 = nullptr;
-  c->n_cold = std::max(0, c->dp - c->hg_s);
+  c->n_cold = std::max(0, c->dp - c->hg_cold());
   c->cold_nnz = 0;
   HIP_TRY(hipMalloc(&c->d_coef8, (size_t)std::max<long long>(c->n_rows, 1)));
   HIP_TRY(hipMemset(c->d_coef8, 0, (size_t)std::max<long long>(c->n_rows, 1)));
@@ -458,7 +463,7 @@ static int build_cold_lists(dsgd_ctx* c) {
   unsigned long long tot = 0;
   for (int j = 0; j < c->n_cold; ++j) {
     ptr[j] = (unsigned int)tot;
-    tot += cnt[c->hg_s + j];
+    tot += cnt[c->hg_cold() + j];
   }
   if (tot >= 0xFFFFFFFFull) {  // keep 32-bit list offsets; fall back to the row-wise kernels
     c->n_cold = 0;
@@ -497,7 +502,7 @@ static int build_cold_lists(dsgd_ctx* c) {
   {
     CsrView m = view(c);
     const int blocks = (int)std::max<long long>(1, std::min<long long>((c->n_rows + 15) / 16, (long long)c->n_cu * 8));
-    hipLaunchKernelGGL(dsgd_cold_fill_kernel<16>, dim3(blocks), dim3(256), 0, c->stream, m, c->hg_s, d_cursor, d_row_tmp,
+    hipLaunchKernelGGL(dsgd_cold_fill_kernel<16>, dim3(blocks), dim3(256), 0, c->stream, m, c->hg_cold(), d_cursor, d_row_tmp,
                        d_val_tmp);
     HIP_TRY_C(hipGetLastError());
   }
@@ -601,6 +606,23 @@ static StreamSeg make_sseg(dsgd_ctx* c, long long rb, long long re) {
   s.tile_end = std::lower_bound(tr.begin(), tr.end(), (int)re) - tr.begin();          // one past the tile of re-1
   return s;
 }
+// after a streaming gradient kernel: fixed point -> fp32, then the cold columns from their transposed lists
+template <bool SCATTER>
+static int finish_stream(dsgd_ctx* c, int n_workers) {
+  if (!SCATTER) return DSGD_OK;
+  hipLaunchKernelGGL(dsgd_fix_finalize_kernel, dim3((c->dp + 1023) / 1024, n_workers), dim3(1024), 0, c->stream, c->d_g64,
+                     c->d_g, (long long)c->dp, c->dp, 1.0 / (double)c->fix_scale);
+  HIP_TRY(hipGetLastError());
+  if (c->n_cold > 0 && c->cold_nnz > 0) {
+    const int cg = 16;
+    const int blocks = std::max(1, std::min((c->n_cold * cg + 255) / 256, c->n_cu * 8 / n_workers + 1));
+    hipLaunchKernelGGL(dsgd_cold_scatter_kernel<16>, dim3(blocks, n_workers), dim3(256), 0, c->stream, c->d_cold_ptr,
+                       c->d_cold_row, c->d_cold_val, c->d_coef8, c->n_cold, c->hg_cold(), c->d_g, (long long)c->dp, c->d_ssegs);
+    HIP_TRY(hipGetLastError());
+  }
+  return DSGD_OK;
+}
+
 template <bool SCATTER>
 static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
   DSGD_TRY(upload_ssegs(c, segs));
@@ -610,10 +632,24 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
   long long bx = std::max<long long>(1, c->n_cu / n_workers);
   bx = std::min(bx, max_tiles);
   dim3 grid((unsigned)bx, n_workers);
+  CsrView m = view(c);
+  if (c->stream_mode == 2) {
+    const int hw = SCATTER ? c->hw_g : c->hw_ge;
+    const int hg = SCATTER ? c->hg_g : 0;
+    const size_t lds = sizeof(float) * (size_t)(SG_LDS_FIXED + hw + hg + 2);
+    SegTables st;
+    st.tile_row = c->d_tile_row;
+    st.tile_pos = c->d_tile_pos;
+    st.tile_meta = c->d_tile_meta;
+    hipLaunchKernelGGL(dsgd_seg_kernel<SCATTER>, grid, dim3(ST_THREADS), lds, c->stream, m, st, c->d_w, c->d_g64,
+                       (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8);
+    HIP_TRY(hipGetLastError());
+    if (SCATTER) c->last_grad_kernel = "dsgd_seg_kernel<true>";
+    return finish_stream<SCATTER>(c, n_workers);
+  }
   const int hw = SCATTER ? c->hw_s : c->hw_se;
   const int hg = SCATTER ? c->hg_s : 0;
   const size_t lds = sizeof(float) * (size_t)(ST_FIXED_FLOATS + hw + hg);
-  CsrView m = view(c);
   TileTables tt;
   tt.tile_row = c->d_tile_row;
   tt.tile_pos = c->d_tile_pos;
@@ -634,19 +670,7 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
   }
 #undef DSGD_LAUNCH_STREAM
   HIP_TRY(hipGetLastError());
-  if (SCATTER) {
-    hipLaunchKernelGGL(dsgd_fix_finalize_kernel, dim3((c->dp + 1023) / 1024, n_workers), dim3(1024), 0, c->stream, c->d_g64,
-                       c->d_g, (long long)c->dp, c->dp, 1.0 / (double)c->fix_scale);
-    HIP_TRY(hipGetLastError());
-    if (c->n_cold > 0 && c->cold_nnz > 0) {
-      const int cg = 16;
-      const int blocks = std::max(1, std::min((c->n_cold * cg + 255) / 256, c->n_cu * 8 / n_workers + 1));
-      hipLaunchKernelGGL(dsgd_cold_scatter_kernel<16>, dim3(blocks, n_workers), dim3(256), 0, c->stream, c->d_cold_ptr,
-                         c->d_cold_row, c->d_cold_val, c->d_coef8, c->n_cold, c->hg_s, c->d_g, (long long)c->dp, c->d_ssegs);
-      HIP_TRY(hipGetLastError());
-    }
-  }
-  return DSGD_OK;
+  return finish_stream<SCATTER>(c, n_workers);
 }
 
 static int require_data(dsgd_ctx* c) {
@@ -730,7 +754,17 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   c->hw_eval = std::min(c->dp, DSGD_LDS_FLOATS);
   if (const char* e = getenv("DSGD_HW_S")) c->hw_s = atoi(e);
   if (const char* e = getenv("DSGD_HG_S")) c->hg_s = atoi(e);
-  if (const char* e = getenv("DSGD_STREAM")) c->stream_ranges = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_STREAM")) {
+    c->stream_ranges = atoi(e) != 0;
+    if (atoi(e) == 1 || atoi(e) == 2) c->stream_mode = atoi(e);
+  }
+  if (const char* e = getenv("DSGD_HW_G")) c->hw_g = atoi(e);
+  if (const char* e = getenv("DSGD_HG_G")) c->hg_g = atoi(e);
+  c->hw_g = std::max(0, std::min(c->hw_g, c->dp));
+  c->hg_g = std::max(0, std::min(c->hg_g, c->dp));
+  c->hw_ge = std::min(c->hw_ge, c->dp);
+  if (c->hw_g + c->hg_g > DSGD_LDS_FLOATS - SG_LDS_FIXED)
+    return bail(fail(DSGD_EINVAL, "DSGD_HW_G + DSGD_HG_G exceed %d floats of LDS", DSGD_LDS_FLOATS - SG_LDS_FIXED));
   if (const char* e = getenv("DSGD_PF_EARLY")) c->pf_early = atoi(e) != 0;
   c->hw_s = std::max(0, std::min(c->hw_s, c->dp));
   c->hg_s = std::max(0, std::min(c->hg_s, c->dp));
@@ -756,6 +790,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR((dsgd_stream_kernel<16, false, false>));
   DSGD_ATTR((dsgd_stream_kernel<8, true, false>));
   DSGD_ATTR((dsgd_stream_kernel<8, false, false>));
+  DSGD_ATTR(dsgd_seg_kernel<true>);
+  DSGD_ATTR(dsgd_seg_kernel<false>);
 #undef DSGD_ATTR
   HIP_TRY_B(hipStreamSynchronize(c->stream));
 #undef HIP_TRY_B
@@ -797,18 +833,22 @@ int dsgd_destroy(dsgd_ctx* c) {
   hipFree(c->d_cold_row);
   hipFree(c->d_cold_val);
   hipFree(c->d_coef8);
+  hipFree(c->d_tile_meta);
   if (c->h_sc) hipHostFree(c->h_sc);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return DSGD_OK;
 }
 
-int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr, const int32_t* col, const float* val,
+int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr_in, const int32_t* col_in, const float* val_in,
                   const int8_t* label) {
   DSGD_TRY(check_ctx(c));
-  if (n_rows < 1 || !row_ptr || !label) return fail(DSGD_EINVAL, "n_rows must be >= 1 and arrays non-null");
-  if (row_ptr[0] != 0) return fail(DSGD_EINVAL, "row_ptr[0] must be 0");
-  const int64_t nnz = row_ptr[n_rows];
+  if (n_rows < 1 || !row_ptr_in || !label) return fail(DSGD_EINVAL, "n_rows must be >= 1 and arrays non-null");
+  if (row_ptr_in[0] != 0) return fail(DSGD_EINVAL, "row_ptr[0] must be 0");
+  const int64_t* row_ptr = row_ptr_in;
+  const int32_t* col = col_in;
+  const float* val = val_in;
+  int64_t nnz = row_ptr[n_rows];
   if (nnz < 0 || (nnz > 0 && (!col || !val))) return fail(DSGD_EINVAL, "bad nnz / null col,val");
   for (int64_t i = 0; i < n_rows; ++i)
     if (row_ptr[i + 1] < row_ptr[i]) return fail(DSGD_EINVAL, "row_ptr not monotone at row %lld", (long long)i);
@@ -823,6 +863,36 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr, const int
   }
   for (int64_t i = 0; i < n_rows; ++i)
     if (label[i] != 1 && label[i] != -1) return fail(DSGD_EINVAL, "label[%lld] = %d, expected +1/-1", (long long)i, label[i]);
+  // Internal CSR: an empty row (Sparse.zeros) gets ONE explicit zero on key 0.  x.w, the gate and the
+  // gradient are unchanged (the product and y*x are 0 and every counting kernel skips abs(v) <= 1e-20),
+  // and the streaming kernels can rely on "every row owns at least one slot".
+  std::vector<int64_t> prow;
+  std::vector<int32_t> pcol;
+  std::vector<float> pval;
+  {
+    int64_t n_empty = 0;
+    for (int64_t i = 0; i < n_rows; ++i) n_empty += row_ptr[i + 1] == row_ptr[i];
+    if (n_empty > 0) {
+      prow.resize((size_t)n_rows + 1);
+      pcol.reserve((size_t)(nnz + n_empty));
+      pval.reserve((size_t)(nnz + n_empty));
+      prow[0] = 0;
+      for (int64_t i = 0; i < n_rows; ++i) {
+        if (row_ptr[i + 1] == row_ptr[i]) {
+          pcol.push_back(0);
+          pval.push_back(0.0f);
+        } else {
+          pcol.insert(pcol.end(), col + row_ptr[i], col + row_ptr[i + 1]);
+          pval.insert(pval.end(), val + row_ptr[i], val + row_ptr[i + 1]);
+        }
+        prow[i + 1] = (int64_t)pcol.size();
+      }
+      row_ptr = prow.data();
+      col = pcol.data();
+      val = pval.data();
+      nnz = row_ptr[n_rows];
+    }
+  }
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -920,6 +990,46 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr, const int
     c->d_tile_rp = nullptr;
     HIP_TRY(hipMalloc(&c->d_tile_rp, sizeof(int) * trp.size()));
     HIP_TRY(hipMemcpy(c->d_tile_rp, trp.data(), sizeof(int) * trp.size(), hipMemcpyHostToDevice));
+    // lane descriptors of the seg kernels: lane l of tile t owns slots [4l, 4l+4) of the window at pos0;
+    // descriptor = (row-start bits of its 4 slots) << 9 | local row of slot 4l.  Local rows are 1-based:
+    // 0 = padding before the tile's first non-zero, nrows + 1 = padding after its last one.
+    {
+      std::vector<unsigned short> meta((size_t)c->n_tiles * ST_THREADS, 0);
+      for (size_t t = 0; t + 1 < tr.size(); ++t) {
+        unsigned short* mt = meta.data() + t * ST_THREADS;
+        if (tp[t + 1] - tp[t] > ST_MAXNNZ) continue;  // over-long row: the kernel treats the tile as padding
+        const long long pos0 = tp[t] & ~3LL;
+        const int nr = tr[t + 1] - tr[t];
+        // row starts (slot index relative to pos0), plus the end mark that starts the trailing padding
+        int lane = 0;
+        int cur_row = 0;  // local row of the slot being visited
+        int next = 0;     // next row to start (0-based within the tile)
+        for (lane = 0; lane < ST_THREADS; ++lane) {
+          int bits = 0, first_row = -1;
+          for (int k = 0; k < 4; ++k) {
+            const long long slot = 4LL * lane + k;
+            bool start = false;
+            if (next < nr && row_ptr[tr[t] + next] - pos0 == slot) {
+              start = true;
+              ++next;
+            } else if (next == nr && row_ptr[tr[t + 1]] - pos0 == slot) {
+              start = true;  // end mark
+              ++next;
+            }
+            if (start) {
+              bits |= 1 << k;
+              ++cur_row;
+            }
+            if (k == 0) first_row = cur_row;
+          }
+          mt[lane] = (unsigned short)((bits << 9) | first_row);
+        }
+      }
+      hipFree(c->d_tile_meta);
+      c->d_tile_meta = nullptr;
+      HIP_TRY(hipMalloc(&c->d_tile_meta, sizeof(unsigned short) * std::max<size_t>(meta.size(), 1)));
+      HIP_TRY(hipMemcpy(c->d_tile_meta, meta.data(), sizeof(unsigned short) * meta.size(), hipMemcpyHostToDevice));
+    }
     hipFree(c->d_tile_row);
     hipFree(c->d_tile_pos);
     hipFree(c->d_tile_vptr);

@@ -438,13 +438,18 @@ __global__ void __launch_bounds__(1024) dsgd_eval_kernel(CsrView m, const float*
 
 // ---- layout: column frequencies, ranking, permutations ---------------------------------------------------------
 // histogram of column ids with an LDS-privatised counter tile for ids < hcnt (same reasoning as K1b)
-__global__ void __launch_bounds__(1024) dsgd_colcount_kernel(const int* __restrict__ col, long long nnz,
-                                                            unsigned int* cnt, int dp, int hcnt, DevScalars* sc) {
+// Entries with abs(value) <= 1e-20 are not counted: the reference's Sparse constructor drops them
+// before any key set is taken (math/Sparse.scala:108-118), and the padding element of an empty row
+// (value 0) must stay invisible.
+__global__ void __launch_bounds__(1024) dsgd_colcount_kernel(const int* __restrict__ col, const float* __restrict__ val,
+                                                            long long nnz, unsigned int* cnt, int dp, int hcnt,
+                                                            DevScalars* sc) {
   extern __shared__ __attribute__((aligned(16))) unsigned int lcnt[];
   for (int j = threadIdx.x; j < hcnt; j += 1024) lcnt[j] = 0u;
   __syncthreads();
   for (long long p = (long long)blockIdx.x * 1024 + threadIdx.x; p < nnz; p += (long long)gridDim.x * 1024) {
     const int c = col[p];
+    if (!(fabsf(val[p]) > DSGD_EPS)) continue;
     if (c < 0 || c >= dp) {
       atomicExch(&sc->err, 1);
       continue;
@@ -501,8 +506,8 @@ __global__ void dsgd_ds_kernel(const unsigned int* __restrict__ cnt, const int* 
 //                             + hg gradient tile + hw weight tile  <= 40960.
 constexpr int ST_THREADS = 1024;
 constexpr int ST_TILE = 4096;             // non-zeros per tile slot (4 per lane)
-constexpr int ST_MAXNNZ = ST_TILE - 3;    // pos0 is rounded down to a multiple of 4
-constexpr int ST_MAXROWS = 496;           // rows per tile (<= FIX_ROWS_PER_FLUSH, one lane stages one row offset)
+constexpr int ST_MAXNNZ = ST_TILE - 4;    // pos0 is rounded down to a multiple of 4; slot 4095 stays free for the end mark
+constexpr int ST_MAXROWS = 496;           // rows per tile (<= FIX_ROWS_PER_SCAN, one lane stages one row offset)
 constexpr int ST_VCHUNK = 64;             // non-zeros per virtual row (a row is cut into chunks of <= 64)
 constexpr int ST_MAXV = ST_MAXROWS + ST_TILE / ST_VCHUNK + 16;  // virtual rows per tile, padded to 576
 // double-buffered small arrays: row offsets, labels, virtual-row entries, virtual-row partial sums
@@ -511,14 +516,17 @@ constexpr int ST_FIXED_FLOATS = 2 * ST_TILE + 2 * ST_SMALL + ST_MAXROWS;
 
 // Fixed-point gradient accumulation.  Measured on MI355X (tools/microbench3.hip): ds_add_f32 retires
 // 0.31 lanes/clk/CU (188 Gnnz/s chip-wide) while ds_add_u32 runs at the HBM streaming rate
-// (671 Gnnz/s).  The scatter therefore accumulates round(y*x * 2^22 / vmax2) as 32-bit integers in
-// LDS (vmax2 = max|x| rounded up to a power of two, so the scaling is exact) and drains the tile
-// into 64-bit global accumulators before 2^31 can be reached: a column receives at most one
-// contribution per row, |contribution| <= 2^22, so 511 rows never overflow.  Integer addition is
-// associative: the gradient of a whole-shard batch is bit-reproducible run to run.  Quantisation:
-// 2^-23 * vmax2 per contribution (about half an fp32 ulp of vmax2).
-constexpr int FIX_SHIFT = 22;
-constexpr int FIX_ROWS_PER_FLUSH = 511;
+// (671 Gnnz/s).  The scatter therefore accumulates round(y*x * 2^21 / vmax2) as 32-bit integers in
+// LDS (vmax2 = max|x| rounded up to a power of two, so the scaling is exact).  Overflow control: a
+// column receives at most one contribution per row and |contribution| <= 2^21; every <= 700 rows the
+// workgroup scans its tile and moves only the entries with |q| >= 2^29 to the 64-bit global
+// accumulators, so an entry never exceeds 2^29 + 700 * 2^21 < 2^31.  Only truly hot columns are
+// ever moved; everything else leaves LDS once, at the end of the kernel.  Integer addition is
+// associative: the gradient of a whole-shard batch is bit-reproducible run to run, and exact up to
+// the 2^-22 * vmax2 rounding of each contribution (fp32 atomics round at the ulp of the RUNNING sum).
+constexpr int FIX_SHIFT = 21;
+constexpr int FIX_ROWS_PER_SCAN = 700;
+constexpr int FIX_SPILL_AT = 1 << 29;
 
 struct StreamSeg {
   long long row_begin, row_end;    // rows of this worker's batch
@@ -712,12 +720,13 @@ __device__ __forceinline__ void stream_tile(const CsrView& m, const TileTables& 
       }
     }
     __syncthreads();
-    if (rows_acc + cur.nrows > FIX_ROWS_PER_FLUSH) {
-      // drain the 32-bit LDS accumulators into the 64-bit global ones before they can overflow;
-      // every lane has passed barriers since the previous tile's scatter, so gl is quiescent
+    if (rows_acc + cur.nrows > FIX_ROWS_PER_SCAN) {
+      // move the entries that could overflow within the next FIX_ROWS_PER_SCAN rows to the 64-bit
+      // global accumulators; every lane has passed barriers since the previous tile's scatter, so
+      // gl is quiescent
       for (int j = tid; j < x.hg; j += ST_THREADS) {
         const int q = x.gl[j];
-        if (q != 0) {
+        if (q >= FIX_SPILL_AT || q <= -FIX_SPILL_AT) {
           atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
           x.gl[j] = 0;
         }
@@ -839,7 +848,7 @@ __global__ void __launch_bounds__(256) dsgd_cold_fill_kernel(CsrView m, int hg, 
     const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
     for (long long p = start + sub; p < end; p += G) {
       const int c = m.col[p];
-      if (c >= hg) {
+      if (c >= hg && fabsf(m.val[p]) > DSGD_EPS) {
         const unsigned int pos = atomicAdd(&cursor[c - hg], 1u);
         cold_row[pos] = (int)row;
         cold_val[pos] = m.val[p];
@@ -882,5 +891,295 @@ __global__ void __launch_bounds__(256) dsgd_cold_scatter_kernel(const unsigned i
     for (unsigned int q = b + sub; q < e; q += G) acc += filt(cold_val[q] * (float)coef8[cold_row[q]]);
     acc = group_sum<G>(acc);
     if (sub == 0 && acc != 0.0f) g[hg + j] += acc;
+  }
+}
+
+// ======================================================================================================
+// K1d / K5c: nnz-streaming kernels, register-level segmented reduction ("seg" kernels)
+// ======================================================================================================
+// Same HBM stream as dsgd_stream_kernel (one 16-byte col and val load per lane and tile, two tiles in
+// flight), but the row sums never touch LDS:
+//   * at load time every lane of every tile gets a 16-bit descriptor: the local row (1-based; 0 and
+//     nrows+1 are the padding before/after the tile's own non-zeros) of its first element and one
+//     bit per element "a row starts here";
+//   * a lane adds up its (<= 4) row fragments in registers; the fragment that continues into the next
+//     lane enters a wave-wide SEGMENTED SCAN built from DPP row_shr / row_bcast steps (VALU only);
+//   * waves exchange one carry through LDS (barrier 1); the lane holding the start of the NEXT row
+//     finalises a row: x.w, gate, tally / coefficient (LDS, 1 float per row; barrier 2);
+//   * each lane scatters its own non-zeros with ds_add_u32 (fixed point, see FIX_SHIFT).
+// LDS per workgroup: labels + coefficients + wave carries (~4 KiB); everything else is the weight
+// tile and the gradient tile: hw + hg <= 39,900 floats instead of 27,976.
+// Requires: no empty rows inside the internal CSR (dsgd_load_csr pads them with one explicit zero).
+constexpr int SG_LDS_FIXED = (ST_MAXROWS + 2) * 2 + 32 + 2;  // yl, coefl, wave carries
+
+struct SegTables {
+  const int* __restrict__ tile_row;               // n_tiles + 1
+  const long long* __restrict__ tile_pos;         // n_tiles + 1
+  const unsigned short* __restrict__ tile_meta;   // n_tiles x 1024 lane descriptors
+};
+
+struct SegRegs {
+  int4 c;
+  float4 v;
+  float gw[4];
+  float y;     // label of row r0 + lane (lanes < nrows)
+  int meta;    // (row-start bits b0..b3) << 9 | local row of element 0
+  int r0, nrows;
+};
+
+__device__ __forceinline__ void seg_issue(const CsrView& m, const SegTables& tt, long long t, long long t_end, int tid,
+                                          long long nnz_pad4, SegRegs& r) {
+  const bool live = t < t_end;
+  const long long tc = live ? t : t_end - 1;
+  const long long lo = tt.tile_pos[tc];
+  const long long hi = tt.tile_pos[tc + 1];
+  r.r0 = tt.tile_row[tc];
+  r.nrows = tt.tile_row[tc + 1] - r.r0;
+  if (!live || hi - lo > ST_MAXNNZ) r.nrows = -1;  // past the end / over-long row: every lane is padding
+  long long p = (lo & ~3LL) + 4 * tid;
+  p = p < nnz_pad4 ? p : nnz_pad4;
+  r.c = *reinterpret_cast<const int4*>(m.col + p);
+  r.v = *reinterpret_cast<const float4*>(m.val + p);
+  r.meta = tt.tile_meta[tc * ST_THREADS + tid];
+  const long long rr = (long long)r.r0 + tid;
+  r.y = (float)m.label[rr < m.n_rows ? rr : m.n_rows - 1];
+}
+
+__device__ __forceinline__ void seg_gather(const float* __restrict__ w, int hw, SegRegs& r) {
+  r.gw[0] = w[r.c.x < hw ? 0 : r.c.x];
+  r.gw[1] = w[r.c.y < hw ? 0 : r.c.y];
+  r.gw[2] = w[r.c.z < hw ? 0 : r.c.z];
+  r.gw[3] = w[r.c.w < hw ? 0 : r.c.w];
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get_f(float src) {  // lanes without a source (or masked rows) read 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_get_i(int src) {
+  return __builtin_amdgcn_update_dpp(0, src, CTRL, ROW_MASK, 0xf, false);
+}
+// one step of the inclusive segmented scan: add the partner's running sum unless a segment head
+// lies between the partner and this lane
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_scan_step(float& v, int& f) {
+  const float pv = dpp_get_f<CTRL, ROW_MASK>(v);
+  const int pf = dpp_get_i<CTRL, ROW_MASK>(f);
+  v = f ? v : v + pv;
+  f |= pf;
+}
+// inclusive segmented scan over the 64 lanes of a wave (f = 1 on lanes that start a new segment)
+__device__ __forceinline__ void wave_seg_scan(float& v, int& f) {
+  seg_scan_step<0x111, 0xf>(v, f);  // row_shr:1
+  seg_scan_step<0x112, 0xf>(v, f);  // row_shr:2
+  seg_scan_step<0x114, 0xf>(v, f);  // row_shr:4
+  seg_scan_step<0x118, 0xf>(v, f);  // row_shr:8
+  seg_scan_step<0x142, 0xa>(v, f);  // row_bcast:15 -> rows 1 and 3
+  seg_scan_step<0x143, 0xc>(v, f);  // row_bcast:31 -> rows 2 and 3
+}
+
+struct SegCtx {
+  signed char* coef8;
+  float* yl;      // ST_MAXROWS + 2 (local rows are 1-based)
+  float* coefl;   // ST_MAXROWS + 2
+  float* wc_v;    // 16 wave carries
+  int* wc_f;      // 16
+  int* gl;
+  float* wl;
+  long long* g64;
+  long long row_begin, row_end;
+  int hw, hg;
+  float fix_scale;
+};
+
+template <bool SCATTER>
+__device__ __forceinline__ void seg_tile(const CsrView& m, const SegTables& tt, const float* __restrict__ w,
+                                         const SegCtx& x, long long tile, long long stride, long long t_end,
+                                         long long nnz_pad4, SegRegs& cur, SegRegs& nxt, SegRegs& far, int& rows_acc,
+                                         unsigned int& active_local, unsigned int& c0, unsigned int& c1,
+                                         unsigned int& c2) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  seg_gather(w, x.hw, nxt);                                       // tile t+1 (its col ids landed)
+  seg_issue(m, tt, tile + 3 * stride, t_end, tid, nnz_pad4, far);  // tile t+3 (t+2 is still in flight)
+
+  const int nrows = cur.nrows;                    // -1: nothing to do in this tile (all padding)
+  const int rf = nrows < 0 ? 0 : (cur.meta & 511);
+  const int bits = nrows < 0 ? 0 : (cur.meta >> 9);
+  const int cc[4] = {cur.c.x, cur.c.y, cur.c.z, cur.c.w};
+  const float vv[4] = {cur.v.x, cur.v.y, cur.v.z, cur.v.w};
+  float pk[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool hot = cc[k] < x.hw;
+    typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
+    const float a = ((lds_cvfloat*)x.wl)[hot ? cc[k] : 0];
+    pk[k] = filt(vv[k] * (hot ? a : cur.gw[k]));  // ref: math/Sparse.scala:46 (product map, filtered)
+  }
+  if (tid < nrows) x.yl[tid + 1] = cur.y;
+
+  // fragment that continues into the next lane, and whether a row starts inside this lane
+  float trail = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if ((bits >> k) & 1) trail = 0.0f;
+    trail += pk[k];
+  }
+  float s = trail;
+  int f = bits != 0;
+  wave_seg_scan(s, f);
+  float incoming = dpp_get_f<0x138, 0xf>(s);  // wave_shr:1 -> running sum of the row entering this lane
+  const int head_before = dpp_get_i<0x138, 0xf>(f);
+  if (lane == 63) {
+    x.wc_v[wave] = s;
+    x.wc_f[wave] = f;
+  }
+  __syncthreads();
+  if (SCATTER && tid == 0) {  // (after the barrier: every lane is done with the previous tile's coefficients)
+    x.coefl[0] = 0.0f;                          // padding before the tile's first row
+    x.coefl[nrows < 0 ? 1 : nrows + 1] = 0.0f;  // ... and after its last row
+  }
+  {
+    // carry of the row entering this wave: sums of the preceding waves back to the last one holding a
+    // row start (wave 0 always holds one: the tile's first row starts in its lane 0), ascending order
+    float carry = 0.0f;
+    int j0 = wave;
+    while (j0 > 0 && !x.wc_f[j0 - 1]) --j0;
+    if (j0 > 0) --j0;
+    if (wave > 0)
+      for (int j = j0; j < wave; ++j) carry += x.wc_v[j];
+    if (!head_before) incoming += carry;
+  }
+
+  // rows that END in this lane are finalised here (the lane holding the start of the next row)
+  {
+    float run = incoming;
+    int r = rf - (bits & 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if ((bits >> k) & 1) {
+        if (r >= 1 && r <= nrows) {
+          const float d = run;  // x . w
+          const float y = x.yl[r];
+          const long long row = (long long)cur.r0 + r - 1;
+          const bool in_range = row >= x.row_begin && row < x.row_end;
+          if (SCATTER) {
+            const bool active = in_range && !(y * d < 0.0f);  // ref: core/ml/SparseSVM.scala:27-28
+            x.coefl[r] = active ? y : 0.0f;
+            if (in_range) x.coef8[row] = (signed char)(active ? (int)y : 0);
+            if (active) active_local++;
+          } else if (in_range) {
+            const float yd = y * d;  // ref: core/ml/SparseSVM.scala:14,16
+            if (yd < 0.0f) c0++;
+            else if (yd > 0.0f) c2++;
+            else c1++;
+          }
+        }
+        run = 0.0f;
+        ++r;
+      }
+      run += pk[k];
+    }
+  }
+  __syncthreads();  // coefficients visible; yl / carries may be overwritten by the next tile
+  if (SCATTER) {
+    if (rows_acc + (nrows < 0 ? 0 : nrows) > FIX_ROWS_PER_SCAN) {
+      for (int j = tid; j < x.hg; j += ST_THREADS) {
+        const int q = x.gl[j];
+        if (q >= FIX_SPILL_AT || q <= -FIX_SPILL_AT) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
+          x.gl[j] = 0;
+        }
+      }
+      rows_acc = 0;
+      __syncthreads();
+    }
+    rows_acc += nrows < 0 ? 0 : nrows;
+    int r = rf;
+    float coef = x.coefl[r];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k > 0 && ((bits >> k) & 1)) {
+        ++r;
+        coef = x.coefl[r];
+      }
+      if (coef != 0.0f) {
+        const float xv = filt(vv[k] * coef);  // x * y (ref: SparseSVM.scala:28)
+        const int c = cc[k];
+        if (xv != 0.0f && c < x.hg) atomicAdd(&x.gl[c], __float2int_rn(xv * x.fix_scale));
+      }
+    }
+  }
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(ST_THREADS) dsgd_seg_kernel(CsrView m, SegTables tt, const float* __restrict__ w,
+                                                             long long* g64_base, long long g_stride,
+                                                             const StreamSeg* __restrict__ segs, DevScalars* sc, int hw,
+                                                             int hg, float fix_scale, signed char* coef8) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  SegCtx x;
+  x.coef8 = coef8;
+  x.yl = lds;
+  x.coefl = lds + (ST_MAXROWS + 2);
+  x.wc_v = lds + 2 * (ST_MAXROWS + 2);
+  x.wc_f = reinterpret_cast<int*>(x.wc_v + 16);
+  x.gl = reinterpret_cast<int*>(lds + SG_LDS_FIXED);
+  x.wl = lds + SG_LDS_FIXED + (SCATTER ? hg : 0);
+  const int tid = threadIdx.x;
+  const StreamSeg seg = segs[blockIdx.y];
+  x.g64 = g64_base + (long long)blockIdx.y * g_stride;
+  x.row_begin = seg.row_begin;
+  x.row_end = seg.row_end;
+  x.hw = hw;
+  x.hg = hg;
+  x.fix_scale = fix_scale;
+  int rows_acc = 0;
+  if (SCATTER)
+    for (int j = tid; j < hg; j += ST_THREADS) x.gl[j] = 0;
+  for (int j = tid; j < hw; j += ST_THREADS) x.wl[j] = w[j];
+  __syncthreads();
+
+  unsigned int active_local = 0, c0 = 0, c1 = 0, c2 = 0;
+  const long long nnz_pad4 = (m.row_ptr[m.n_rows] + 3) & ~3LL;
+  const long long stride = gridDim.x;
+  const long long t_end = seg.tile_end;
+  long long tile = seg.tile_begin + blockIdx.x;
+  if (tile < t_end) {
+    SegRegs A, B, C, D;
+    seg_issue(m, tt, tile, t_end, tid, nnz_pad4, A);
+    seg_issue(m, tt, tile + stride, t_end, tid, nnz_pad4, B);
+    seg_issue(m, tt, tile + 2 * stride, t_end, tid, nnz_pad4, C);
+    seg_gather(w, hw, A);
+#define DSGD_SEG(CUR, NXT, FAR) \
+  seg_tile<SCATTER>(m, tt, w, x, tile, stride, t_end, nnz_pad4, CUR, NXT, FAR, rows_acc, active_local, c0, c1, c2)
+    for (;;) {
+      DSGD_SEG(A, B, D); tile += stride; if (tile >= t_end) break;
+      DSGD_SEG(B, C, A); tile += stride; if (tile >= t_end) break;
+      DSGD_SEG(C, D, B); tile += stride; if (tile >= t_end) break;
+      DSGD_SEG(D, A, C); tile += stride; if (tile >= t_end) break;
+    }
+#undef DSGD_SEG
+  }
+
+  if (SCATTER) {
+    __syncthreads();
+    for (int j = tid; j < hg; j += ST_THREADS) {
+      const int q = x.gl[j];
+      if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
+    }
+    active_local = wave_sum_u32(active_local);
+    if ((tid & 63) == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
+  } else {
+    c0 = wave_sum_u32(c0);
+    c1 = wave_sum_u32(c1);
+    c2 = wave_sum_u32(c2);
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&sc->counts[3], (unsigned long long)(seg.row_end - seg.row_begin));
+    if ((tid & 63) == 0) {
+      if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
+      if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
+      if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
+    }
   }
 }

@@ -336,3 +336,60 @@ def test_full_size_properties(full):
     assert c_sub == [int((pred == y).sum()), int((pred == 0).sum()), int((pred == -y).sum())]
     # (4) idempotence: evaluation does not change the weights
     np.testing.assert_array_equal(eng.get_weights(), w0)
+
+
+# ---- ragged inputs: empty rows, one-element rows, values below the Sparse epsilon ---------------------
+def ragged_data(seed, n_rows=6000):
+    base = dsgd_amd.synth.generate(n_rows, seed=seed)
+    rng = np.random.default_rng(seed)
+    row_ptr, col, val = [0], [], []
+    for i in range(n_rows):
+        b, e = int(base.row_ptr[i]), int(base.row_ptr[i + 1])
+        kind = rng.integers(0, 10)
+        if kind == 0:
+            pass  # empty row: Sparse.zeros
+        elif kind == 1:
+            col.append(base.col[b]); val.append(np.float32(1.0))  # single-element row
+        else:
+            c, v = base.col[b:e], base.val[b:e].copy()
+            if kind == 2:
+                v[0] = np.float32(1e-25)  # dropped by the Sparse constructor (math/Sparse.scala:112-114)
+            col.extend(c.tolist()); val.extend(v.tolist())
+        row_ptr.append(len(col))
+    return dsgd_amd.synth.Csr(base.dim, np.asarray(row_ptr, np.int64), np.asarray(col, np.int32),
+                              np.asarray(val, np.float32), base.label.copy())
+
+
+@pytest.mark.parametrize("flags", [0, FORCE_TILED, FORCE_ROWS])
+def test_ragged_rows_all_kernel_paths(flags):
+    data = ragged_data(21)
+    n_train = 4800
+    o, eng = make_pair(data, 1e-5, n_train, flags)
+    rng = np.random.default_rng(21)
+    with eng:
+        # index-list batches (row-wise kernels) ...
+        w_ref, flips, rows = run_sync(o, eng, batches(rng, n_train, 2, 300, 10), 0.5)
+        # ... then whole contiguous ranges (streaming kernels when flags == FORCE_TILED), lr scaled to the batch
+        lr = 0.5 * 100 / 2400
+        for step in range(4):
+            st = eng.sync_step_ranges([(0, 2400), (2400, 4800)], lr)
+            o.sync_step(w_ref, [np.arange(0, 2400), np.arange(2400, 4800)], lr)
+            assert st["n_samples"] == 4800
+            if st["n_active"] != o.last_stats["n_active"]:
+                assert o.last_stats["min_abs_margin"] < GATE_EPS
+                eng.set_weights(w_ref.astype(np.float32))
+                continue
+            w = eng.get_weights().astype(np.float64)
+            assert np.abs(w - w_ref).max() <= tol(w_ref) * 4  # sums of 2400 rows per coordinate
+        for lo, hi in ((0, n_train), (n_train, data.n_rows), (100, 4700)):
+            loss, acc, counts = eng.loss_acc(lo, hi)
+            loss_ref, acc_ref, counts_ref, mam = o.loss_acc(eng.get_weights().astype(np.float64), lo, hi)
+            assert sum(counts) == hi - lo
+            if mam >= GATE_EPS:
+                assert counts == counts_ref
+        # an all-zero weight vector: every row (also the empty ones) is active, predictions are 0
+        eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+        st = eng.sync_step_ranges([(0, n_train)], 0.0)
+        assert st["n_active"] == n_train
+        _, _, counts = eng.loss_acc(0, n_train)
+        assert counts == [0, n_train, 0]
