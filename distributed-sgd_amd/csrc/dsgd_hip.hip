@@ -150,11 +150,23 @@ struct dsgd_ctx {
   int hw_se = DSGD_LDS_FLOATS - ST_FIXED_FLOATS;                     // ... of the streaming evaluation kernel
   bool stream_ranges = true;
   bool pf_early = false;
-  int stream_mode = 2;  // 1: LDS-staged products (dsgd_stream_kernel), 2: register segmented scan (dsgd_seg_kernel)
+  int stream_mode = 3;  // 1: LDS-staged products (dsgd_stream_kernel), 2: workgroup tiles + register segmented scan
+                        // (dsgd_seg_kernel), 3: wave tiles, no workgroup barriers (dsgd_wseg_kernel)
+  // wave tiles of mode 3
+  WTile* d_wtiles = nullptr;
+  unsigned int* d_wmeta = nullptr;
+  long long n_wtiles = 0;
+  std::vector<int> h_wtile_r0;          // first row of every wave tile (+ sentinel n_rows)
+  std::vector<long long> wlong_rows;    // rows with more than WS_MAXNNZ non-zeros: row-per-group kernels
+  int* d_wlong_idx = nullptr;           // staging of the long rows of the current call
+  long long wlong_cap = 0;
+  std::vector<int> wlong_last;
+  int hw_w = 8192, hg_w = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 8192;  // LDS tiles of the wseg gradient kernel
+  int hw_we = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE;                     // ... of the wseg evaluation kernel
   unsigned short* d_tile_meta = nullptr;  // n_tiles x 1024 lane descriptors of the seg kernels
   int hw_g = 6144, hg_g = DSGD_LDS_FLOATS - SG_LDS_FIXED - 6144 - 2;  // LDS tiles of the seg gradient kernel
   int hw_ge = DSGD_LDS_FLOATS - SG_LDS_FIXED - 2;                     // ... of the seg evaluation kernel
-  int hg_cold() const { return stream_mode == 2 ? hg_g : hg_s; }
+  int hg_cold() const { return stream_mode == 3 ? hg_w : (stream_mode == 2 ? hg_g : hg_s); }
   // cold columns (rank >= hg_s): transposed (row, value) lists + per-row gate coefficients
   unsigned int* d_cold_ptr = nullptr;  // n_cold + 1
   int* d_cold_row = nullptr;
@@ -281,8 +293,12 @@ static int reset_counters(dsgd_ctx* c) {
   return DSGD_OK;
 }
 static int check_err_flag(dsgd_ctx* c) {
-  if (c->h_sc->err) {
+  const int err = c->h_sc->err;
+  if (err) {
     HIP_TRY(hipMemsetAsync(&c->d_sc->err, 0, sizeof(int), c->stream));
+    if (err & 2)
+      return fail(DSGD_ESTATE, "fixed-point gradient accumulator left its safe band; the step is invalid "
+                               "(rerun with DSGD_STREAM=0 to use the fp32 row-wise kernels)");
     return fail(DSGD_ERANGE, "sample index / key outside the loaded data");
   }
   return DSGD_OK;
@@ -623,6 +639,83 @@ static int finish_stream(dsgd_ctx* c, int n_workers) {
   return DSGD_OK;
 }
 
+// mode 3: wave tiles.  segs carry ROW ranges; tile ranges are recomputed for the wave tiling.
+template <bool SCATTER>
+static int launch_wseg(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
+  const int n_workers = (int)row_segs.size();
+  std::vector<StreamSeg> segs(row_segs);
+  const std::vector<int>& wr0 = c->h_wtile_r0;  // n_wtiles + 1 entries (sentinel n_rows)
+  long long max_tiles = 1;
+  std::vector<int> long_idx;
+  std::vector<WorkSeg> long_segs(n_workers);
+  for (int k = 0; k < n_workers; ++k) {
+    StreamSeg& s = segs[k];
+    // first tile whose rows reach row_begin: the last tile with r0 <= row_begin (it may end before row_begin when a
+    // long row sits in between -- then all its rows are masked) ... one past the last tile with r0 < row_end
+    long long tb = (std::upper_bound(wr0.begin(), wr0.end() - 1, (int)s.row_begin) - wr0.begin()) - 1;
+    if (tb < 0) tb = 0;
+    long long te = std::lower_bound(wr0.begin(), wr0.end() - 1, (int)s.row_end) - wr0.begin();
+    if (te < tb) te = tb;
+    s.tile_begin = tb;
+    s.tile_end = te;
+    max_tiles = std::max(max_tiles, te - tb);
+    long_segs[k].begin = (long long)long_idx.size();
+    auto lo = std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), s.row_begin);
+    auto hi = std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), s.row_end);
+    for (auto it = lo; it != hi; ++it) long_idx.push_back((int)*it);
+    long_segs[k].end = (long long)long_idx.size();
+  }
+  DSGD_TRY(upload_ssegs(c, segs));
+  long long bx = std::max<long long>(1, c->n_cu / n_workers);
+  bx = std::min(bx, (max_tiles + 15) / 16);
+  dim3 grid((unsigned)std::max<long long>(1, bx), n_workers);
+  const int hw = SCATTER ? c->hw_w : c->hw_we;
+  const int hg = SCATTER ? c->hg_w : 0;
+  const size_t lds = sizeof(float) * (size_t)(16 * WS_COEF_STRIDE + hw + hg);
+  CsrView m = view(c);
+  WTables wt;
+  wt.tiles = c->d_wtiles;
+  wt.meta = c->d_wmeta;
+  hipLaunchKernelGGL(dsgd_wseg_kernel<SCATTER>, grid, dim3(1024), lds, c->stream, m, wt, c->d_w, c->d_g64, (long long)c->dp,
+                     c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8);
+  HIP_TRY(hipGetLastError());
+  if (SCATTER) c->last_grad_kernel = "dsgd_wseg_kernel<true>";
+  if (!long_idx.empty()) {
+    // the few rows longer than a wave tile: row-per-group kernels on an explicit list
+    if ((long long)long_idx.size() > c->wlong_cap) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      hipFree(c->d_wlong_idx);
+      c->d_wlong_idx = nullptr;
+      c->wlong_cap = std::max<long long>((long long)long_idx.size(), 2 * c->wlong_cap);
+      HIP_TRY(hipMalloc(&c->d_wlong_idx, sizeof(int) * (size_t)c->wlong_cap));
+    }
+    if (c->wlong_last != long_idx) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipMemcpy(c->d_wlong_idx, long_idx.data(), sizeof(int) * long_idx.size(), hipMemcpyHostToDevice));
+      c->wlong_last = long_idx;
+    }
+    if (SCATTER) {
+      DSGD_TRY(upload_segs(c, long_segs));
+      long long mx = 0;
+      for (const auto& s : long_segs) mx = std::max(mx, s.end - s.begin);
+      const size_t lds2 = sizeof(float) * (size_t)(c->hw + c->hg);
+      const int G = 64;  // long rows: a whole wave per row
+      const long long groups_per_block = 1024 / G;
+      long long b2 = std::max<long long>(1, std::min<long long>(c->n_cu / n_workers, (mx + groups_per_block - 1) / groups_per_block));
+      hipLaunchKernelGGL(dsgd_grad_tiled_kernel<64>, dim3((unsigned)b2, n_workers), dim3(1024), lds2, c->stream, m, c->d_w,
+                         c->d_g, (long long)c->dp, c->d_wlong_idx, c->d_segs, c->d_sc, c->hw, c->hg);
+      HIP_TRY(hipGetLastError());
+    } else {
+      const long long n = (long long)long_idx.size();
+      const int blocks = (int)std::max<long long>(1, std::min<long long>((n + 3) / 4, (long long)c->n_cu * 4));
+      hipLaunchKernelGGL(dsgd_eval_idx_kernel<64>, dim3(blocks), dim3(256), 0, c->stream, m, c->d_w, c->d_wlong_idx, n,
+                         c->d_sc);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  return finish_stream<SCATTER>(c, n_workers);
+}
+
 template <bool SCATTER>
 static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
   DSGD_TRY(upload_ssegs(c, segs));
@@ -633,6 +726,7 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
   bx = std::min(bx, max_tiles);
   dim3 grid((unsigned)bx, n_workers);
   CsrView m = view(c);
+  if (c->stream_mode == 3) return launch_wseg<SCATTER>(c, segs);
   if (c->stream_mode == 2) {
     const int hw = SCATTER ? c->hw_g : c->hw_ge;
     const int hg = SCATTER ? c->hg_g : 0;
@@ -642,7 +736,8 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
     st.tile_pos = c->d_tile_pos;
     st.tile_meta = c->d_tile_meta;
     hipLaunchKernelGGL(dsgd_seg_kernel<SCATTER>, grid, dim3(ST_THREADS), lds, c->stream, m, st, c->d_w, c->d_g64,
-                       (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8);
+                       (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8,
+                       getenv("DSGD_DBG") ? atoi(getenv("DSGD_DBG")) : 0);
     HIP_TRY(hipGetLastError());
     if (SCATTER) c->last_grad_kernel = "dsgd_seg_kernel<true>";
     return finish_stream<SCATTER>(c, n_workers);
@@ -756,10 +851,17 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_HG_S")) c->hg_s = atoi(e);
   if (const char* e = getenv("DSGD_STREAM")) {
     c->stream_ranges = atoi(e) != 0;
-    if (atoi(e) == 1 || atoi(e) == 2) c->stream_mode = atoi(e);
+    if (atoi(e) >= 1 && atoi(e) <= 3) c->stream_mode = atoi(e);
   }
   if (const char* e = getenv("DSGD_HW_G")) c->hw_g = atoi(e);
   if (const char* e = getenv("DSGD_HG_G")) c->hg_g = atoi(e);
+  if (const char* e = getenv("DSGD_HW_W")) c->hw_w = atoi(e);
+  if (const char* e = getenv("DSGD_HG_W")) c->hg_w = atoi(e);
+  c->hw_w = std::max(0, std::min(c->hw_w, c->dp));
+  c->hg_w = std::max(0, std::min(c->hg_w, c->dp));
+  c->hw_we = std::min(c->hw_we, c->dp);
+  if (c->hw_w + c->hg_w > DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE)
+    return bail(fail(DSGD_EINVAL, "DSGD_HW_W + DSGD_HG_W exceed %d floats of LDS", DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE));
   c->hw_g = std::max(0, std::min(c->hw_g, c->dp));
   c->hg_g = std::max(0, std::min(c->hg_g, c->dp));
   c->hw_ge = std::min(c->hw_ge, c->dp);
@@ -790,6 +892,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR((dsgd_stream_kernel<16, false, false>));
   DSGD_ATTR((dsgd_stream_kernel<8, true, false>));
   DSGD_ATTR((dsgd_stream_kernel<8, false, false>));
+  DSGD_ATTR(dsgd_wseg_kernel<true>);
+  DSGD_ATTR(dsgd_wseg_kernel<false>);
   DSGD_ATTR(dsgd_seg_kernel<true>);
   DSGD_ATTR(dsgd_seg_kernel<false>);
 #undef DSGD_ATTR
@@ -834,6 +938,9 @@ int dsgd_destroy(dsgd_ctx* c) {
   hipFree(c->d_cold_val);
   hipFree(c->d_coef8);
   hipFree(c->d_tile_meta);
+  hipFree(c->d_wtiles);
+  hipFree(c->d_wmeta);
+  hipFree(c->d_wlong_idx);
   if (c->h_sc) hipHostFree(c->h_sc);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -1029,6 +1136,80 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr_in, const 
       c->d_tile_meta = nullptr;
       HIP_TRY(hipMalloc(&c->d_tile_meta, sizeof(unsigned short) * std::max<size_t>(meta.size(), 1)));
       HIP_TRY(hipMemcpy(c->d_tile_meta, meta.data(), sizeof(unsigned short) * meta.size(), hipMemcpyHostToDevice));
+    }
+    // wave tiles of the wseg kernels: whole rows, <= WS_MAXNNZ non-zeros, <= WS_MAXROWS rows; longer rows are
+    // listed in wlong_rows.  Lane l owns slots [4l, 4l+4) and [256+4l, 256+4l+4) of the window at pos0.
+    // Descriptor of a 4-slot group: local row of its first slot (8 bits) | row-start bits << 8 | label sign of
+    // the row ENDING at each start << 12.
+    {
+      std::vector<WTile> wt;
+      std::vector<int>& wr0 = c->h_wtile_r0;
+      wr0.clear();
+      c->wlong_rows.clear();
+      int64_t start = -1;  // first row of the open tile
+      auto close = [&](int64_t end_row) {
+        if (start < 0) return;
+        WTile t;
+        t.pos0 = row_ptr[start] & ~3LL;
+        t.r0 = (int)start;
+        t.nrows = (int)(end_row - start);
+        wt.push_back(t);
+        wr0.push_back((int)start);
+        start = -1;
+      };
+      for (int64_t i = 0; i < n_rows; ++i) {
+        const int64_t len = row_ptr[i + 1] - row_ptr[i];
+        if (len > WS_MAXNNZ) {
+          close(i);
+          c->wlong_rows.push_back(i);
+          continue;
+        }
+        if (start >= 0 && (row_ptr[i + 1] - (row_ptr[start] & ~3LL) > WS_SLOTS - 1 || i - start >= WS_MAXROWS)) close(i);
+        if (start < 0) start = i;
+      }
+      close(n_rows);
+      wr0.push_back((int)n_rows);
+      c->n_wtiles = (long long)wt.size();
+      std::vector<unsigned int> wm((size_t)std::max<long long>(c->n_wtiles, 1) * 64, 0u);
+      for (long long t = 0; t < c->n_wtiles; ++t) {
+        const WTile& T = wt[(size_t)t];
+        unsigned short desc[128];
+        int cur_row = 0, next = 0;
+        for (int grp = 0; grp < 128; ++grp) {  // groups 0..63: first half (lane = grp), 64..127: second half
+          int bits = 0, ys = 0, first_row = 0;
+          for (int k = 0; k < 4; ++k) {
+            const long long slot = 4LL * grp + k;
+            bool st = false;
+            if (next < T.nrows && row_ptr[T.r0 + next] - T.pos0 == slot) st = true;
+            else if (next == T.nrows && row_ptr[T.r0 + T.nrows] - T.pos0 == slot) st = true;  // end mark
+            if (st) {
+              bits |= 1 << k;
+              // the row that ends here is local row cur_row (1-based); rows 0 = leading padding
+              if (cur_row >= 1 && label[T.r0 + cur_row - 1] > 0) ys |= 1 << k;
+              ++cur_row;
+              ++next;
+            }
+            if (k == 0) first_row = cur_row;
+          }
+          desc[grp] = (unsigned short)(first_row | (bits << 8) | (ys << 12));
+        }
+        for (int l = 0; l < 64; ++l) wm[(size_t)t * 64 + l] = (unsigned int)desc[l] | ((unsigned int)desc[64 + l] << 16);
+      }
+      hipFree(c->d_wtiles);
+      hipFree(c->d_wmeta);
+      c->d_wtiles = nullptr;
+      c->d_wmeta = nullptr;
+      if (wt.empty()) {
+        WTile t;
+        t.pos0 = 0;
+        t.r0 = 0;
+        t.nrows = -1;
+        wt.push_back(t);
+      }
+      HIP_TRY(hipMalloc(&c->d_wtiles, sizeof(WTile) * wt.size()));
+      HIP_TRY(hipMalloc(&c->d_wmeta, sizeof(unsigned int) * wm.size()));
+      HIP_TRY(hipMemcpy(c->d_wtiles, wt.data(), sizeof(WTile) * wt.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(c->d_wmeta, wm.data(), sizeof(unsigned int) * wm.size(), hipMemcpyHostToDevice));
     }
     hipFree(c->d_tile_row);
     hipFree(c->d_tile_pos);
@@ -1283,7 +1464,7 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
   DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_g(c, n_workers));
   DSGD_TRY(ensure_s(c));
-  if (c->stream_ranges && tot >= c->tiled_min && !any_long_row(c, row_begin, row_end, n_workers)) {
+  if (c->stream_ranges && tot >= c->tiled_min && (c->stream_mode == 3 || !any_long_row(c, row_begin, row_end, n_workers))) {
     // whole contiguous ranges: the nnz-streaming kernel (coalesced 16-byte loads, no per-row latency chain)
     std::vector<StreamSeg> ssegs(n_workers);
     for (int k = 0; k < n_workers; ++k) ssegs[k] = make_sseg(c, row_begin[k], row_end[k]);
@@ -1331,6 +1512,9 @@ int dsgd_synchronize(dsgd_ctx* c, dsgd_batch_stats* stats) {
   const long long act = (long long)c->h_sc->n_active;
   const int err = c->h_sc->err;
   DSGD_TRY(reset_counters(c));
+  if (err & 2)
+    return fail(DSGD_ESTATE, "fixed-point gradient accumulator left its safe band; the steps since the last "
+                             "synchronize are invalid (rerun with DSGD_STREAM=0)");
   if (err) return fail(DSGD_ERANGE, "sample index / key outside the loaded data");
   if (stats) {
     stats->n_active = act;
@@ -1464,7 +1648,7 @@ int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_en
   if (w) DSGD_TRY(set_weights_locked(c, w));
   DSGD_TRY(ensure_s(c));  // also refreshes |w|^2
   DSGD_TRY(reset_counters(c));
-  if (c->stream_ranges && row_end - row_begin >= 4096 && !any_long_row(c, &row_begin, &row_end, 1)) {
+  if (c->stream_ranges && row_end - row_begin >= 4096 && (c->stream_mode == 3 || !any_long_row(c, &row_begin, &row_end, 1))) {
     std::vector<StreamSeg> ssegs(1, make_sseg(c, row_begin, row_end));
     DSGD_TRY(launch_stream<false>(c, ssegs));
   } else {

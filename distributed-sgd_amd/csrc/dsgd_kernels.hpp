@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) dsgd_grad_rows_kernel(CsrView m, const fl
   for (long long t = seg.begin + group; t < seg.end; t += n_groups) {
     const long long row = idx ? (long long)idx[t] : t;
     if (row < 0 || row >= m.n_rows) {
-      if (sub == 0) atomicExch(&sc->err, 1);
+      if (sub == 0) atomicOr(&sc->err, 1);
       continue;
     }
     const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(1024) dsgd_grad_tiled_kernel(CsrView m, const 
   for (long long t = seg.begin + group; t < seg.end; t += n_groups) {
     const long long row = idx ? (long long)idx[t] : t;
     if (row < 0 || row >= m.n_rows) {
-      if (sub == 0) atomicExch(&sc->err, 1);
+      if (sub == 0) atomicOr(&sc->err, 1);
       continue;
     }
     const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
@@ -368,7 +368,7 @@ __global__ void dsgd_update_grad_kernel(float* w, const int* __restrict__ perm, 
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
     const int k = key[i];
     if (k < 0 || k >= dp) {
-      atomicExch(&sc->err, 1);
+      atomicOr(&sc->err, 1);
       continue;
     }
     atomicAdd(&w[perm[k]], -dv[i]);
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(256) dsgd_forward_kernel(CsrView m, const floa
   for (long long t = group; t < n; t += n_groups) {
     const long long row = idx[t];
     if (row < 0 || row >= m.n_rows) {
-      if (sub == 0) atomicExch(&sc->err, 1);
+      if (sub == 0) atomicOr(&sc->err, 1);
       continue;
     }
     RowRegs<G, UNR> r;
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(1024) dsgd_colcount_kernel(const int* __restri
     const int c = col[p];
     if (!(fabsf(val[p]) > DSGD_EPS)) continue;
     if (c < 0 || c >= dp) {
-      atomicExch(&sc->err, 1);
+      atomicOr(&sc->err, 1);
       continue;
     }
     if (c < hcnt) atomicAdd(&lcnt[c], 1u);
@@ -991,6 +991,7 @@ struct SegCtx {
   long long row_begin, row_end;
   int hw, hg;
   float fix_scale;
+  int dbg;  // ablation switches for tuning runs (0 in production)
 };
 
 template <bool SCATTER>
@@ -1014,7 +1015,7 @@ __device__ __forceinline__ void seg_tile(const CsrView& m, const SegTables& tt, 
   for (int k = 0; k < 4; ++k) {
     const bool hot = cc[k] < x.hw;
     typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
-    const float a = ((lds_cvfloat*)x.wl)[hot ? cc[k] : 0];
+    const float a = (x.dbg & 16) ? 1.0f : ((lds_cvfloat*)x.wl)[hot ? cc[k] : 0];
     pk[k] = filt(vv[k] * (hot ? a : cur.gw[k]));  // ref: math/Sparse.scala:46 (product map, filtered)
   }
   if (tid < nrows) x.yl[tid + 1] = cur.y;
@@ -1028,14 +1029,14 @@ __device__ __forceinline__ void seg_tile(const CsrView& m, const SegTables& tt, 
   }
   float s = trail;
   int f = bits != 0;
-  wave_seg_scan(s, f);
+  if (!(x.dbg & 8)) wave_seg_scan(s, f);
   float incoming = dpp_get_f<0x138, 0xf>(s);  // wave_shr:1 -> running sum of the row entering this lane
   const int head_before = dpp_get_i<0x138, 0xf>(f);
   if (lane == 63) {
     x.wc_v[wave] = s;
     x.wc_f[wave] = f;
   }
-  __syncthreads();
+  if (!(x.dbg & 4)) __syncthreads();
   if (SCATTER && tid == 0) {  // (after the barrier: every lane is done with the previous tile's coefficients)
     x.coefl[0] = 0.0f;                          // padding before the tile's first row
     x.coefl[nrows < 0 ? 1 : nrows + 1] = 0.0f;  // ... and after its last row
@@ -1044,16 +1045,16 @@ __device__ __forceinline__ void seg_tile(const CsrView& m, const SegTables& tt, 
     // carry of the row entering this wave: sums of the preceding waves back to the last one holding a
     // row start (wave 0 always holds one: the tile's first row starts in its lane 0), ascending order
     float carry = 0.0f;
-    int j0 = wave;
+    int j0 = (x.dbg & 8) ? 0 : wave;
     while (j0 > 0 && !x.wc_f[j0 - 1]) --j0;
     if (j0 > 0) --j0;
-    if (wave > 0)
+    if (wave > 0 && !(x.dbg & 8))
       for (int j = j0; j < wave; ++j) carry += x.wc_v[j];
     if (!head_before) incoming += carry;
   }
 
   // rows that END in this lane are finalised here (the lane holding the start of the next row)
-  {
+  if (!(x.dbg & 1)) {
     float run = incoming;
     int r = rf - (bits & 1);
 #pragma unroll
@@ -1082,8 +1083,8 @@ __device__ __forceinline__ void seg_tile(const CsrView& m, const SegTables& tt, 
       run += pk[k];
     }
   }
-  __syncthreads();  // coefficients visible; yl / carries may be overwritten by the next tile
-  if (SCATTER) {
+  if (!(x.dbg & 4)) __syncthreads();  // coefficients visible; yl / carries may be overwritten by the next tile
+  if (SCATTER && !(x.dbg & 2)) {
     if (rows_acc + (nrows < 0 ? 0 : nrows) > FIX_ROWS_PER_SCAN) {
       for (int j = tid; j < x.hg; j += ST_THREADS) {
         const int q = x.gl[j];
@@ -1117,9 +1118,10 @@ template <bool SCATTER>
 __global__ void __launch_bounds__(ST_THREADS) dsgd_seg_kernel(CsrView m, SegTables tt, const float* __restrict__ w,
                                                              long long* g64_base, long long g_stride,
                                                              const StreamSeg* __restrict__ segs, DevScalars* sc, int hw,
-                                                             int hg, float fix_scale, signed char* coef8) {
+                                                             int hg, float fix_scale, signed char* coef8, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   SegCtx x;
+  x.dbg = dbg;
   x.coef8 = coef8;
   x.yl = lds;
   x.coefl = lds + (ST_MAXROWS + 2);
@@ -1181,5 +1183,326 @@ __global__ void __launch_bounds__(ST_THREADS) dsgd_seg_kernel(CsrView m, SegTabl
       if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
       if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
     }
+  }
+}
+
+// ======================================================================================================
+// K1e / K5d: WAVE-independent streaming kernels ("wseg"): no workgroup barrier inside the stream loop
+// ======================================================================================================
+// The ablation of dsgd_seg_kernel on MI355X (tools/ablate.py) showed that with one 1024-lane workgroup
+// per CU (needed for the 160 KiB of LDS tiles) the two barriers per tile put all 16 waves in lockstep:
+// HBM, VALU and the LDS atomics are used one after the other instead of at the same time (51-70 % of
+// the wave cycles are SQ_WAIT_ANY).  Here every WAVE owns its own tiles of 512 slots made of WHOLE rows,
+// so a wave never needs data from another wave: the 16 waves of the workgroup drift apart and overlap
+// each other's memory waits, DPP scans and LDS atomics like ordinary independent waves, while still
+// sharing the workgroup's LDS weight tile and LDS gradient tile.
+//   * lane l owns slots [4l, 4l+4) and [256+4l, 256+4l+4) of the tile window: two fully coalesced
+//     16-byte loads per lane and array;
+//   * one 16-bit descriptor per 4-slot group: local row of the first slot (8 bits, rows are 1-based,
+//     0 / nrows+1 = padding), row-start bits (4), label sign of the row that ENDS at each start (4) --
+//     labels travel inside the descriptor, no per-row loads at all;
+//   * row sums: in-register fragments + DPP segmented scan per half, the second half continues the
+//     first; gate coefficients go through a per-wave LDS strip (same wave writes and reads: no barrier);
+//   * rows longer than WS_MAXNNZ non-zeros are left to the row-per-group kernel (3 % of the RCV1-like
+//     non-zeros).
+// Gradient accumulation: ds_add_rtn_u32 fixed point (FIX_SHIFT).  Without a workgroup-wide quiet point
+// the overflow control is local: the lane that brings an entry to |q| >= 2^28 swaps it out
+// (ds_wrxchg) into the 64-bit global accumulator.  Should an entry ever be seen at |q| >= 2^30 the
+// kernel raises DevScalars::err bit 2 and the host rejects the step (any wrap-around must pass
+// through that band because one contribution is at most 2^21).
+constexpr int WS_SLOTS = 512;
+constexpr int WS_MAXNNZ = WS_SLOTS - 4;
+constexpr int WS_MAXROWS = 254;
+constexpr int WS_SPILL_AT = 1 << 28;
+constexpr int WS_PANIC_AT = 1 << 30;
+constexpr int WS_COEF_STRIDE = 256;
+
+struct WTile {       // 16 bytes, read with one scalar load
+  long long pos0;    // first slot of the window (multiple of 4)
+  int r0;            // global row of local row 1
+  int nrows;         // rows in the tile (-1: unused entry)
+};
+
+struct WTables {
+  const WTile* __restrict__ tiles;
+  const unsigned int* __restrict__ meta;  // n_tiles x 64: lane descriptor pair (lo 16 bits: first half, hi: second)
+};
+
+struct WRegs {
+  int4 c0, c1;
+  float4 v0, v1;
+  float gw[8];
+  unsigned int meta;
+  int r0, nrows;
+};
+
+__device__ __forceinline__ void w_issue(const CsrView& m, const WTables& tt, long long t, long long t_end, int lane,
+                                        long long nnz_pad4, WRegs& r) {
+  const bool live = t < t_end;
+  const WTile wt = tt.tiles[live ? t : t_end - 1];
+  r.r0 = wt.r0;
+  r.nrows = live ? wt.nrows : -1;
+  long long p0 = wt.pos0 + 4 * lane;
+  long long p1 = p0 + 256;
+  p0 = p0 < nnz_pad4 ? p0 : nnz_pad4;
+  p1 = p1 < nnz_pad4 ? p1 : nnz_pad4;
+  r.c0 = *reinterpret_cast<const int4*>(m.col + p0);
+  r.c1 = *reinterpret_cast<const int4*>(m.col + p1);
+  r.v0 = *reinterpret_cast<const float4*>(m.val + p0);
+  r.v1 = *reinterpret_cast<const float4*>(m.val + p1);
+  r.meta = tt.meta[(live ? t : t_end - 1) * 64 + lane];
+}
+
+__device__ __forceinline__ void w_gather(const float* __restrict__ w, int hw, WRegs& r) {
+  r.gw[0] = w[r.c0.x < hw ? 0 : r.c0.x];
+  r.gw[1] = w[r.c0.y < hw ? 0 : r.c0.y];
+  r.gw[2] = w[r.c0.z < hw ? 0 : r.c0.z];
+  r.gw[3] = w[r.c0.w < hw ? 0 : r.c0.w];
+  r.gw[4] = w[r.c1.x < hw ? 0 : r.c1.x];
+  r.gw[5] = w[r.c1.y < hw ? 0 : r.c1.y];
+  r.gw[6] = w[r.c1.z < hw ? 0 : r.c1.z];
+  r.gw[7] = w[r.c1.w < hw ? 0 : r.c1.w];
+}
+
+struct WCtx {
+  signed char* coef8;
+  float* coefw;   // this wave's strip of WS_COEF_STRIDE floats
+  int* gl;
+  float* wl;
+  long long* g64;
+  DevScalars* sc;
+  int rb_lo, rb_hi;  // (set per tile) local-row window of the worker's batch
+  long long row_begin, row_end;
+  int hw, hg;
+  float fix_scale;
+};
+
+// one half (256 slots, 4 per lane) of a wave tile: products, fragments, segmented scan.
+// carry: running sum of the row entering the half at its lane 0 (0 for the first half).
+// Returns the lane's products in pk, its incoming sum in `incoming`, and the half's carry-out.
+__device__ __forceinline__ void w_half_scan(const float (&pk)[4], int bits, float carry, float& incoming, float& carry_out,
+                                            int& any_head) {
+  float trail = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if ((bits >> k) & 1) trail = 0.0f;
+    trail += pk[k];
+  }
+  float s = trail;
+  int f = bits != 0;
+  wave_seg_scan(s, f);
+  incoming = dpp_get_f<0x138, 0xf>(s);                 // wave_shr:1
+  const int head_before = dpp_get_i<0x138, 0xf>(f);
+  if (!head_before) incoming += carry;
+  const float s63 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
+  any_head = __builtin_amdgcn_readlane(f, 63);
+  carry_out = any_head ? s63 : carry + s63;
+}
+
+template <bool SCATTER>
+__device__ __forceinline__ void w_half_finalize(const WCtx& x, const float (&pk)[4], int desc, float incoming, int r0,
+                                                int nrows, unsigned int& active_local, unsigned int& c0,
+                                                unsigned int& c1, unsigned int& c2) {
+  const int rf = desc & 255, bits = (desc >> 8) & 15, ys = (desc >> 12) & 15;
+  float run = incoming;
+  int r = rf - (bits & 1);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if ((bits >> k) & 1) {
+      if (r >= 1 && r <= nrows) {
+        const float d = run;                                  // x . w
+        const float y = ((ys >> k) & 1) ? 1.0f : -1.0f;
+        const bool in_range = r >= x.rb_lo && r < x.rb_hi;
+        if (SCATTER) {
+          const bool active = in_range && !(y * d < 0.0f);   // ref: core/ml/SparseSVM.scala:27-28
+          x.coefw[r] = active ? y : 0.0f;
+          if (in_range) x.coef8[(long long)r0 + r - 1] = (signed char)(active ? (int)y : 0);
+          if (active) active_local++;
+        } else if (in_range) {
+          const float yd = y * d;                             // ref: core/ml/SparseSVM.scala:14,16
+          if (yd < 0.0f) c0++;
+          else if (yd > 0.0f) c2++;
+          else c1++;
+        }
+      }
+      run = 0.0f;
+      ++r;
+    }
+    run += pk[k];
+  }
+}
+
+__device__ __forceinline__ void w_half_scatter(const WCtx& x, const int (&cc)[4], const float (&vv)[4], int desc) {
+  const int rf = desc & 255, bits = (desc >> 8) & 15;
+  int r = rf;
+  float coef = x.coefw[r];
+  int q[4], old[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k > 0 && ((bits >> k) & 1)) {
+      ++r;
+      coef = x.coefw[r];
+    }
+    const float xv = filt(vv[k] * coef);  // x * y (ref: SparseSVM.scala:28); coef is 0 on inactive rows / padding
+    q[k] = (xv != 0.0f && cc[k] < x.hg) ? __float2int_rn(xv * x.fix_scale) : 0;
+    old[k] = 0;
+    if (q[k] != 0) old[k] = atomicAdd(&x.gl[cc[k]], q[k]);  // ds_add_rtn_u32
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (q[k] != 0) {
+      const int nw = old[k] + q[k];
+      if (old[k] >= WS_PANIC_AT || old[k] <= -WS_PANIC_AT) atomicOr(&x.sc->err, 2);
+      if (nw >= WS_SPILL_AT || nw <= -WS_SPILL_AT) {
+        const int v = atomicExch(&x.gl[cc[k]], 0);
+        if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[cc[k]]), (unsigned long long)(long long)v);
+      }
+    }
+  }
+}
+
+template <bool SCATTER>
+__device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, const float* __restrict__ w, WCtx& x,
+                                       long long tile, long long stride, long long t_end, long long nnz_pad4,
+                                       WRegs& cur, WRegs& nxt, WRegs& far, unsigned int& active_local,
+                                       unsigned int& c0, unsigned int& c1, unsigned int& c2) {
+  const int lane = threadIdx.x & 63;
+  w_gather(w, x.hw, nxt);                                        // tile t+1 (its col ids landed)
+  w_issue(m, tt, tile + 2 * stride, t_end, lane, nnz_pad4, far);  // tile t+2
+
+  const int nrows = cur.nrows;
+  const int dA = nrows < 0 ? 0 : (int)(cur.meta & 0xffffu);
+  const int dB = nrows < 0 ? 0 : (int)(cur.meta >> 16);
+  const int ccA[4] = {cur.c0.x, cur.c0.y, cur.c0.z, cur.c0.w};
+  const int ccB[4] = {cur.c1.x, cur.c1.y, cur.c1.z, cur.c1.w};
+  const float vvA[4] = {cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w};
+  const float vvB[4] = {cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w};
+  float pA[4], pB[4];
+  typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool hotA = ccA[k] < x.hw, hotB = ccB[k] < x.hw;
+    const float a = ((lds_cvfloat*)x.wl)[hotA ? ccA[k] : 0];
+    const float b = ((lds_cvfloat*)x.wl)[hotB ? ccB[k] : 0];
+    pA[k] = filt(vvA[k] * (hotA ? a : cur.gw[k]));      // ref: math/Sparse.scala:46 (product map, filtered)
+    pB[k] = filt(vvB[k] * (hotB ? b : cur.gw[4 + k]));
+  }
+  // local rows of the worker's batch inside this tile (rows are 1-based here)
+  {
+    const long long lo = x.row_begin - cur.r0 + 1, hi = x.row_end - cur.r0 + 1;
+    x.rb_lo = (int)(lo < 0 ? 0 : (lo > 1024 ? 1024 : lo));
+    x.rb_hi = (int)(hi < 0 ? 0 : (hi > 1024 ? 1024 : hi));
+  }
+  float inA, inB, carryA, carryB;
+  int headA, headB;
+  w_half_scan(pA, (dA >> 8) & 15, 0.0f, inA, carryA, headA);
+  w_half_scan(pB, (dB >> 8) & 15, carryA, inB, carryB, headB);
+  w_half_finalize<SCATTER>(x, pA, dA, inA, cur.r0, nrows, active_local, c0, c1, c2);
+  w_half_finalize<SCATTER>(x, pB, dB, inB, cur.r0, nrows, active_local, c0, c1, c2);
+  if (SCATTER) {
+    if (lane == 0) {
+      x.coefw[0] = 0.0f;                          // padding rows carry a zero coefficient
+      x.coefw[nrows < 0 ? 1 : nrows + 1] = 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();  // same wave wrote the strip; LDS executes a wave's accesses in order
+    w_half_scatter(x, ccA, vvA, dA);
+    w_half_scatter(x, ccB, vvB, dB);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, WTables tt, const float* __restrict__ w,
+                                                        long long* g64_base, long long g_stride,
+                                                        const StreamSeg* __restrict__ segs, DevScalars* sc, int hw, int hg,
+                                                        float fix_scale, signed char* coef8) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WCtx x;
+  x.coef8 = coef8;
+  x.coefw = lds + wave * WS_COEF_STRIDE;                       // 16 strips
+  x.gl = reinterpret_cast<int*>(lds + 16 * WS_COEF_STRIDE);    // hg (SCATTER only)
+  x.wl = lds + 16 * WS_COEF_STRIDE + (SCATTER ? hg : 0);       // hw
+  const StreamSeg seg = segs[blockIdx.y];
+  x.g64 = g64_base + (long long)blockIdx.y * g_stride;
+  x.sc = sc;
+  x.row_begin = seg.row_begin;
+  x.row_end = seg.row_end;
+  x.rb_lo = x.rb_hi = 0;
+  x.hw = hw;
+  x.hg = hg;
+  x.fix_scale = fix_scale;
+  if (SCATTER)
+    for (int j = tid; j < hg; j += 1024) x.gl[j] = 0;
+  for (int j = tid; j < hw; j += 1024) x.wl[j] = w[j];
+  __syncthreads();
+
+  unsigned int active_local = 0, c0 = 0, c1 = 0, c2 = 0;
+  const long long nnz_pad4 = (m.row_ptr[m.n_rows] + 3) & ~3LL;
+  const long long stride = (long long)gridDim.x * 16;          // waves of this worker's grid row
+  const long long t_end = seg.tile_end;
+  long long tile = seg.tile_begin + (long long)blockIdx.x * 16 + wave;
+  if (tile < t_end) {
+    WRegs A, B, C;
+    w_issue(m, tt, tile, t_end, lane, nnz_pad4, A);
+    w_issue(m, tt, tile + stride, t_end, lane, nnz_pad4, B);
+    w_gather(w, hw, A);
+#define DSGD_WT(CUR, NXT, FAR) w_tile<SCATTER>(m, tt, w, x, tile, stride, t_end, nnz_pad4, CUR, NXT, FAR, active_local, c0, c1, c2)
+    for (;;) {
+      DSGD_WT(A, B, C); tile += stride; if (tile >= t_end) break;
+      DSGD_WT(B, C, A); tile += stride; if (tile >= t_end) break;
+      DSGD_WT(C, A, B); tile += stride; if (tile >= t_end) break;
+    }
+#undef DSGD_WT
+  }
+
+  if (SCATTER) {
+    __syncthreads();
+    for (int j = tid; j < hg; j += 1024) {
+      const int q = x.gl[j];
+      if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
+    }
+    active_local = wave_sum_u32(active_local);
+    if (lane == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
+  } else {
+    c0 = wave_sum_u32(c0);
+    c1 = wave_sum_u32(c1);
+    c2 = wave_sum_u32(c2);
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&sc->counts[3], (unsigned long long)(seg.row_end - seg.row_begin));
+    if (lane == 0) {
+      if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
+      if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
+      if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
+    }
+  }
+}
+
+// evaluation tallies of an explicit list of rows (the few rows too long for the wave tiles)
+template <int G>
+__global__ void __launch_bounds__(256) dsgd_eval_idx_kernel(CsrView m, const float* __restrict__ w,
+                                                           const int* __restrict__ idx, long long n, DevScalars* sc) {
+  constexpr int UNR = 4;
+  const int sub = threadIdx.x % G;
+  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
+  unsigned int c0 = 0, c1 = 0, c2 = 0;
+  for (long long t = group; t < n; t += n_groups) {
+    const long long row = idx[t];
+    RowRegs<G, UNR> r;
+    const float d = row_dot<G, UNR, false>(m, m.row_ptr[row], m.row_ptr[row + 1], nullptr, w, 0, sub, r);
+    const float yd = (float)m.label[row] * d;
+    if (sub == 0) {
+      if (yd < 0.0f) c0++;
+      else if (yd > 0.0f) c2++;
+      else c1++;
+    }
+  }
+  c0 = wave_sum_u32(c0);
+  c1 = wave_sum_u32(c1);
+  c2 = wave_sum_u32(c2);
+  if ((threadIdx.x & 63) == 0) {
+    if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
+    if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
+    if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
   }
 }

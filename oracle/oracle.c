@@ -77,8 +77,10 @@ double orc_dense_dot(const double* a, const double* b, int32_t dim) {
 void orc_dim_sparsity(const orc_csr* m, int64_t n_train, double* ds /* dim+1 */) {
   int32_t D = m->dim;
   double* buff = (double*)calloc((size_t)D + 1, sizeof(double));
+  /* v.map.keys: the Sparse constructor has already dropped abs(value) <= 1e-20 (math/Sparse.scala:108-118) */
   for (int64_t i = 0; i < n_train; ++i)
-    for (int64_t p = m->row_ptr[i]; p < m->row_ptr[i + 1]; ++p) buff[m->col[p] - 1] += 1.0;
+    for (int64_t p = m->row_ptr[i]; p < m->row_ptr[i + 1]; ++p)
+      if (fabs((double)m->val[p]) > ORC_EPS) buff[m->col[p] - 1] += 1.0;
   for (int32_t i = 0; i <= D; ++i) ds[i] = 0.0;
   for (int32_t i = 0; i < D; ++i)
     if (buff[i] != 0.0) ds[i] = filt(1.0 / (buff[i] + 1.0));
