@@ -161,8 +161,8 @@ struct dsgd_ctx {
   int* d_wlong_idx = nullptr;           // staging of the long rows of the current call
   long long wlong_cap = 0;
   std::vector<int> wlong_last;
-  int hw_w = 8192, hg_w = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 8192;  // LDS tiles of the wseg gradient kernel
-  int hw_we = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE;                     // ... of the wseg evaluation kernel
+  int hw_w = 8192, hg_w = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 8192 - 4;  // LDS tiles of the wseg gradient kernel
+  int hw_we = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4;                     // ... of the wseg evaluation kernel
   unsigned short* d_tile_meta = nullptr;  // n_tiles x 1024 lane descriptors of the seg kernels
   int hw_g = 6144, hg_g = DSGD_LDS_FLOATS - SG_LDS_FIXED - 6144 - 2;  // LDS tiles of the seg gradient kernel
   int hw_ge = DSGD_LDS_FLOATS - SG_LDS_FIXED - 2;                     // ... of the seg evaluation kernel
@@ -671,13 +671,13 @@ static int launch_wseg(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   dim3 grid((unsigned)std::max<long long>(1, bx), n_workers);
   const int hw = SCATTER ? c->hw_w : c->hw_we;
   const int hg = SCATTER ? c->hg_w : 0;
-  const size_t lds = sizeof(float) * (size_t)(16 * WS_COEF_STRIDE + hw + hg);
+  const size_t lds = sizeof(float) * (size_t)(16 * WS_COEF_STRIDE + hw + hg + 4);
   CsrView m = view(c);
   WTables wt;
   wt.tiles = c->d_wtiles;
   wt.meta = c->d_wmeta;
   hipLaunchKernelGGL(dsgd_wseg_kernel<SCATTER>, grid, dim3(1024), lds, c->stream, m, wt, c->d_w, c->d_g64, (long long)c->dp,
-                     c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8);
+                     c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8, c->dp);
   HIP_TRY(hipGetLastError());
   if (SCATTER) c->last_grad_kernel = "dsgd_wseg_kernel<true>";
   if (!long_idx.empty()) {
@@ -821,7 +821,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   } while (0)
   HIP_TRY_B(hipSetDevice(cfg->device));
   HIP_TRY_B(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIP_TRY_B(hipMalloc(&c->d_w, sizeof(float) * c->dp));
+  HIP_TRY_B(hipMalloc(&c->d_w, sizeof(float) * (c->dp + 1)));  // + the zero slot w[dp] of the wseg kernels
+  HIP_TRY_B(hipMemsetAsync(c->d_w + c->dp, 0, sizeof(float), c->stream));
   HIP_TRY_B(hipMalloc(&c->d_ds, sizeof(float) * c->dp));
   HIP_TRY_B(hipMalloc(&c->d_gsum, sizeof(float) * c->dp));
   HIP_TRY_B(hipMalloc(&c->d_tmp, sizeof(float) * c->dp));
@@ -860,8 +861,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   c->hw_w = std::max(0, std::min(c->hw_w, c->dp));
   c->hg_w = std::max(0, std::min(c->hg_w, c->dp));
   c->hw_we = std::min(c->hw_we, c->dp);
-  if (c->hw_w + c->hg_w > DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE)
-    return bail(fail(DSGD_EINVAL, "DSGD_HW_W + DSGD_HG_W exceed %d floats of LDS", DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE));
+  if (c->hw_w + c->hg_w > DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4)
+    return bail(fail(DSGD_EINVAL, "DSGD_HW_W + DSGD_HG_W exceed %d floats of LDS", DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4));
   c->hw_g = std::max(0, std::min(c->hw_g, c->dp));
   c->hg_g = std::max(0, std::min(c->hg_g, c->dp));
   c->hw_ge = std::min(c->hw_ge, c->dp);
@@ -1014,11 +1015,11 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr_in, const 
   c->d_label = nullptr;
   HIP_TRY(hipMalloc(&c->d_row_ptr, sizeof(long long) * (size_t)(n_rows + 1)));
   if (n_rows >= (int64_t)1 << 31) return fail(DSGD_EUNSUPPORTED, "more than 2^31-1 rows per context");
-  // +8: the streaming kernels read whole 16-byte groups, the last one may reach past nnz
-  HIP_TRY(hipMalloc(&c->d_col, sizeof(int) * (size_t)(nnz + 8)));
-  HIP_TRY(hipMalloc(&c->d_val, sizeof(float) * (size_t)(nnz + 8)));
-  HIP_TRY(hipMemset(c->d_col + nnz, 0, sizeof(int) * 8));
-  HIP_TRY(hipMemset(c->d_val + nnz, 0, sizeof(float) * 8));
+  // padding: the streaming kernels read whole windows (up to 512 slots) without clamping
+  HIP_TRY(hipMalloc(&c->d_col, sizeof(int) * (size_t)(nnz + WS_PAD)));
+  HIP_TRY(hipMalloc(&c->d_val, sizeof(float) * (size_t)(nnz + WS_PAD)));
+  HIP_TRY(hipMemset(c->d_col + nnz, 0, sizeof(int) * WS_PAD));
+  HIP_TRY(hipMemset(c->d_val + nnz, 0, sizeof(float) * WS_PAD));
   HIP_TRY(hipMalloc(&c->d_label, (size_t)n_rows));
   HIP_TRY(hipMemcpy(c->d_row_ptr, row_ptr, sizeof(long long) * (size_t)(n_rows + 1), hipMemcpyHostToDevice));
   if (nnz) {
@@ -1138,9 +1139,9 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr_in, const 
       HIP_TRY(hipMemcpy(c->d_tile_meta, meta.data(), sizeof(unsigned short) * meta.size(), hipMemcpyHostToDevice));
     }
     // wave tiles of the wseg kernels: whole rows, <= WS_MAXNNZ non-zeros, <= WS_MAXROWS rows; longer rows are
-    // listed in wlong_rows.  Lane l owns slots [4l, 4l+4) and [256+4l, 256+4l+4) of the window at pos0.
-    // Descriptor of a 4-slot group: local row of its first slot (8 bits) | row-start bits << 8 | label sign of
-    // the row ENDING at each start << 12.
+    // listed in wlong_rows.  Lane l owns the 8 contiguous slots [8l, 8l+8) of the window at pos0.
+    // Lane descriptor: local row of its first slot (8 bits) | row-start bits << 8 | label sign of the row ENDING
+    // at each start << 16.
     {
       std::vector<WTile> wt;
       std::vector<int>& wr0 = c->h_wtile_r0;
@@ -1173,27 +1174,26 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr_in, const 
       std::vector<unsigned int> wm((size_t)std::max<long long>(c->n_wtiles, 1) * 64, 0u);
       for (long long t = 0; t < c->n_wtiles; ++t) {
         const WTile& T = wt[(size_t)t];
-        unsigned short desc[128];
         int cur_row = 0, next = 0;
-        for (int grp = 0; grp < 128; ++grp) {  // groups 0..63: first half (lane = grp), 64..127: second half
-          int bits = 0, ys = 0, first_row = 0;
-          for (int k = 0; k < 4; ++k) {
-            const long long slot = 4LL * grp + k;
+        for (int l = 0; l < 64; ++l) {  // lane l owns slots [8l, 8l+8)
+          unsigned int bits = 0, ys = 0;
+          int first_row = 0;
+          for (int k = 0; k < 8; ++k) {
+            const long long slot = 8LL * l + k;
             bool st = false;
             if (next < T.nrows && row_ptr[T.r0 + next] - T.pos0 == slot) st = true;
             else if (next == T.nrows && row_ptr[T.r0 + T.nrows] - T.pos0 == slot) st = true;  // end mark
             if (st) {
-              bits |= 1 << k;
-              // the row that ends here is local row cur_row (1-based); rows 0 = leading padding
-              if (cur_row >= 1 && label[T.r0 + cur_row - 1] > 0) ys |= 1 << k;
+              bits |= 1u << k;
+              // the row that ends here is local row cur_row (1-based); row 0 = leading padding
+              if (cur_row >= 1 && label[T.r0 + cur_row - 1] > 0) ys |= 1u << k;
               ++cur_row;
               ++next;
             }
             if (k == 0) first_row = cur_row;
           }
-          desc[grp] = (unsigned short)(first_row | (bits << 8) | (ys << 12));
+          wm[(size_t)t * 64 + l] = (unsigned int)first_row | (bits << 8) | (ys << 16);
         }
-        for (int l = 0; l < 64; ++l) wm[(size_t)t * 64 + l] = (unsigned int)desc[l] | ((unsigned int)desc[64 + l] << 16);
       }
       hipFree(c->d_wtiles);
       hipFree(c->d_wmeta);

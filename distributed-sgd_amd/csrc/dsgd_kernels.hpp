@@ -1189,30 +1189,37 @@ __global__ void __launch_bounds__(ST_THREADS) dsgd_seg_kernel(CsrView m, SegTabl
 // ======================================================================================================
 // K1e / K5d: WAVE-independent streaming kernels ("wseg"): no workgroup barrier inside the stream loop
 // ======================================================================================================
-// The ablation of dsgd_seg_kernel on MI355X (tools/ablate.py) showed that with one 1024-lane workgroup
-// per CU (needed for the 160 KiB of LDS tiles) the two barriers per tile put all 16 waves in lockstep:
-// HBM, VALU and the LDS atomics are used one after the other instead of at the same time (51-70 % of
-// the wave cycles are SQ_WAIT_ANY).  Here every WAVE owns its own tiles of 512 slots made of WHOLE rows,
-// so a wave never needs data from another wave: the 16 waves of the workgroup drift apart and overlap
-// each other's memory waits, DPP scans and LDS atomics like ordinary independent waves, while still
-// sharing the workgroup's LDS weight tile and LDS gradient tile.
-//   * lane l owns slots [4l, 4l+4) and [256+4l, 256+4l+4) of the tile window: two fully coalesced
-//     16-byte loads per lane and array;
-//   * one 16-bit descriptor per 4-slot group: local row of the first slot (8 bits, rows are 1-based,
-//     0 / nrows+1 = padding), row-start bits (4), label sign of the row that ENDS at each start (4) --
-//     labels travel inside the descriptor, no per-row loads at all;
-//   * row sums: in-register fragments + DPP segmented scan per half, the second half continues the
-//     first; gate coefficients go through a per-wave LDS strip (same wave writes and reads: no barrier);
+// Two measurements on MI355X shaped this kernel:
+//  * ablation of dsgd_seg_kernel (tools/ablate.py): with one 1024-lane workgroup per CU (needed for the
+//    160 KiB of LDS tiles) two barriers per tile put all 16 waves in lockstep -- HBM, VALU and the LDS
+//    atomics are used one after the other (51-70 % of the wave cycles are SQ_WAIT_ANY);
+//  * the first barrier-free version executed ~750 instructions per 512-slot tile and was bound by VALU
+//    issue (2 wave64 instructions per clock and CU), not by memory.
+// So: every WAVE owns its own tiles of 512 slots made of WHOLE rows (no data ever crosses waves; the 16
+// waves of the workgroup drift apart and overlap each other's memory waits, DPP scans and LDS atomics
+// while sharing the LDS weight tile and the LDS gradient tile), and the per-tile instruction count is
+// kept near 240 (evaluation) / 340 (gradient):
+//   * lane l owns the 8 CONTIGUOUS slots [8l, 8l+8): two 16-byte loads per array, scalar base + 32-bit
+//     lane offset addressing, no clamping (col/val carry 520 elements of padding);
+//   * one 32-bit descriptor per lane: local row of its first slot (8 bits, rows 1-based, 0 / nrows+1 =
+//     padding), row-start bits (8), label sign of the row ENDING at each start (8): no per-row loads;
+//   * weight lookup without selects: w[dp] == 0 and wl[hw] == 0 are zero slots, so
+//     w_c = wl[min(c, hw)] + w[c < hw ? dp : c];
+//   * ONE DPP segmented scan per tile; a lane with at most one row start (the common case: rows >= 8
+//     non-zeros) finalises branch-free, the general loop runs only when some lane of the wave holds two;
+//   * gate coefficients go through a per-wave LDS strip, pre-multiplied by the fixed-point scale
+//     (same wave writes and reads: LDS executes a wave's accesses in order, no barrier);
 //   * rows longer than WS_MAXNNZ non-zeros are left to the row-per-group kernel (3 % of the RCV1-like
 //     non-zeros).
-// Gradient accumulation: ds_add_rtn_u32 fixed point (FIX_SHIFT).  Without a workgroup-wide quiet point
-// the overflow control is local: the lane that brings an entry to |q| >= 2^28 swaps it out
-// (ds_wrxchg) into the 64-bit global accumulator.  Should an entry ever be seen at |q| >= 2^30 the
-// kernel raises DevScalars::err bit 2 and the host rejects the step (any wrap-around must pass
-// through that band because one contribution is at most 2^21).
+// Gradient accumulation: ds_add_rtn_u32 fixed point (FIX_SHIFT); rounding to the fixed-point grid also
+// absorbs the reference's 1e-20 filter on y*x.  Without a workgroup-wide quiet point the overflow control
+// is local: the lane that brings an entry to |q| >= 2^28 swaps it out (ds_wrxchg) into the 64-bit global
+// accumulator.  Should an entry ever be SEEN at |q| >= 2^30 the kernel raises DevScalars::err bit 2 and
+// the host rejects the step (a wrap-around must pass through that band: one contribution is <= 2^21).
 constexpr int WS_SLOTS = 512;
-constexpr int WS_MAXNNZ = WS_SLOTS - 4;
+constexpr int WS_MAXNNZ = WS_SLOTS - 8;
 constexpr int WS_MAXROWS = 254;
+constexpr int WS_PAD = WS_SLOTS + 8;   // padding elements behind col/val
 constexpr int WS_SPILL_AT = 1 << 28;
 constexpr int WS_PANIC_AT = 1 << 30;
 constexpr int WS_COEF_STRIDE = 256;
@@ -1225,7 +1232,7 @@ struct WTile {       // 16 bytes, read with one scalar load
 
 struct WTables {
   const WTile* __restrict__ tiles;
-  const unsigned int* __restrict__ meta;  // n_tiles x 64: lane descriptor pair (lo 16 bits: first half, hi: second)
+  const unsigned int* __restrict__ meta;  // n_tiles x 64 lane descriptors: rf | bits << 8 | ys << 16
 };
 
 struct WRegs {
@@ -1237,176 +1244,184 @@ struct WRegs {
 };
 
 __device__ __forceinline__ void w_issue(const CsrView& m, const WTables& tt, long long t, long long t_end, int lane,
-                                        long long nnz_pad4, WRegs& r) {
+                                        WRegs& r) {
   const bool live = t < t_end;
-  const WTile wt = tt.tiles[live ? t : t_end - 1];
+  const long long tc = live ? t : t_end - 1;     // wave-uniform: scalar loads below
+  const WTile wt = tt.tiles[tc];
   r.r0 = wt.r0;
   r.nrows = live ? wt.nrows : -1;
-  long long p0 = wt.pos0 + 4 * lane;
-  long long p1 = p0 + 256;
-  p0 = p0 < nnz_pad4 ? p0 : nnz_pad4;
-  p1 = p1 < nnz_pad4 ? p1 : nnz_pad4;
-  r.c0 = *reinterpret_cast<const int4*>(m.col + p0);
-  r.c1 = *reinterpret_cast<const int4*>(m.col + p1);
-  r.v0 = *reinterpret_cast<const float4*>(m.val + p0);
-  r.v1 = *reinterpret_cast<const float4*>(m.val + p1);
-  r.meta = tt.meta[(live ? t : t_end - 1) * 64 + lane];
+  const int4* cp = reinterpret_cast<const int4*>(m.col + wt.pos0);
+  const float4* vp = reinterpret_cast<const float4*>(m.val + wt.pos0);
+  const unsigned int o = 2u * (unsigned int)lane;
+  r.c0 = cp[o];
+  r.c1 = cp[o + 1];
+  r.v0 = vp[o];
+  r.v1 = vp[o + 1];
+  r.meta = (tt.meta + tc * 64)[(unsigned int)lane];
 }
 
-__device__ __forceinline__ void w_gather(const float* __restrict__ w, int hw, WRegs& r) {
-  r.gw[0] = w[r.c0.x < hw ? 0 : r.c0.x];
-  r.gw[1] = w[r.c0.y < hw ? 0 : r.c0.y];
-  r.gw[2] = w[r.c0.z < hw ? 0 : r.c0.z];
-  r.gw[3] = w[r.c0.w < hw ? 0 : r.c0.w];
-  r.gw[4] = w[r.c1.x < hw ? 0 : r.c1.x];
-  r.gw[5] = w[r.c1.y < hw ? 0 : r.c1.y];
-  r.gw[6] = w[r.c1.z < hw ? 0 : r.c1.z];
-  r.gw[7] = w[r.c1.w < hw ? 0 : r.c1.w];
+// cold-weight gathers of a tile whose column ids have landed; hot lanes read the zero slot w[dp]
+__device__ __forceinline__ void w_gather(const float* __restrict__ w, int hw, unsigned int dp, WRegs& r) {
+  const int c[8] = {r.c0.x, r.c0.y, r.c0.z, r.c0.w, r.c1.x, r.c1.y, r.c1.z, r.c1.w};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r.gw[k] = w[c[k] < hw ? dp : (unsigned int)c[k]];
 }
 
 struct WCtx {
   signed char* coef8;
   float* coefw;   // this wave's strip of WS_COEF_STRIDE floats
   int* gl;
-  float* wl;
+  const float* wl;
   long long* g64;
   DevScalars* sc;
-  int rb_lo, rb_hi;  // (set per tile) local-row window of the worker's batch
   long long row_begin, row_end;
   int hw, hg;
   float fix_scale;
 };
 
-// one half (256 slots, 4 per lane) of a wave tile: products, fragments, segmented scan.
-// carry: running sum of the row entering the half at its lane 0 (0 for the first half).
-// Returns the lane's products in pk, its incoming sum in `incoming`, and the half's carry-out.
-__device__ __forceinline__ void w_half_scan(const float (&pk)[4], int bits, float carry, float& incoming, float& carry_out,
-                                            int& any_head) {
-  float trail = 0.0f;
+template <bool SCATTER>
+__device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, const float* __restrict__ w, const WCtx& x,
+                                       unsigned int dp, long long tile, long long stride, long long t_end, WRegs& cur,
+                                       WRegs& nxt, WRegs& far, unsigned int& n_all, unsigned int& n_neg,
+                                       unsigned int& n_pos) {
+  const int lane = threadIdx.x & 63;
+  w_gather(w, x.hw, dp, nxt);                          // tile t+1 (its col ids landed)
+  w_issue(m, tt, tile + 2 * stride, t_end, lane, far);  // tile t+2
+
+  const int nrows = cur.nrows;                          // wave-uniform; -1: the whole tile is padding
+  const unsigned int desc = nrows < 0 ? 0u : cur.meta;
+  const int rf = (int)(desc & 255u);
+  const unsigned int bits = (desc >> 8) & 255u;
+  const unsigned int ys = (desc >> 16) & 255u;
+  const int cc[8] = {cur.c0.x, cur.c0.y, cur.c0.z, cur.c0.w, cur.c1.x, cur.c1.y, cur.c1.z, cur.c1.w};
+  const float vv[8] = {cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w};
+  typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
+  // products and the lane's two open fragments: `head` (slots before its first row start, continues the row
+  // entering the lane) and `trail` (slots from its last row start on, continues into the next lane)
+  float pk[8];
+  float head = 0.0f, trail = 0.0f;
+  bool seen = false;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if ((bits >> k) & 1) trail = 0.0f;
+  for (int k = 0; k < 8; ++k) {
+    const float a = ((lds_cvfloat*)x.wl)[min(cc[k], x.hw)];
+    pk[k] = filt(vv[k] * (a + cur.gw[k]));   // ref: math/Sparse.scala:46 (product map, filtered)
+    const bool st = (bits >> k) & 1u;
+    seen = seen || st;
+    trail = st ? 0.0f : trail;
     trail += pk[k];
+    head += seen ? 0.0f : pk[k];
   }
   float s = trail;
-  int f = bits != 0;
+  int f = bits != 0u;
   wave_seg_scan(s, f);
-  incoming = dpp_get_f<0x138, 0xf>(s);                 // wave_shr:1
-  const int head_before = dpp_get_i<0x138, 0xf>(f);
-  if (!head_before) incoming += carry;
-  const float s63 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
-  any_head = __builtin_amdgcn_readlane(f, 63);
-  carry_out = any_head ? s63 : carry + s63;
-}
+  const float incoming = dpp_get_f<0x138, 0xf>(s);      // wave_shr:1: running sum of the row entering this lane
 
-template <bool SCATTER>
-__device__ __forceinline__ void w_half_finalize(const WCtx& x, const float (&pk)[4], int desc, float incoming, int r0,
-                                                int nrows, unsigned int& active_local, unsigned int& c0,
-                                                unsigned int& c1, unsigned int& c2) {
-  const int rf = desc & 255, bits = (desc >> 8) & 15, ys = (desc >> 12) & 15;
-  float run = incoming;
-  int r = rf - (bits & 1);
+  // rows of the worker's batch, as local rows of this tile (wave-uniform)
+  const long long lo64 = x.row_begin - cur.r0 + 1, hi64 = x.row_end - cur.r0 + 1;
+  const int r_lo = (int)(lo64 < 1 ? 1 : (lo64 > 1024 ? 1024 : lo64));
+  const int r_hi = (int)(hi64 > nrows + 1 ? nrows + 1 : (hi64 < 0 ? 0 : hi64));   // exclusive
+  const float ps = x.fix_scale, ns = -x.fix_scale;
+
+  const int nb = __popc(bits);
+  if (__builtin_amdgcn_ballot_w64(nb > 1) == 0) {
+    // common case: at most one row start per lane -> at most one row ENDS in this lane
+    const int r_end = rf - (int)(bits & 1u);            // local row that ends at the lane's row start
+    const bool fin = nb == 1 && r_end >= r_lo && r_end < r_hi;
+    const float d = incoming + head;                     // x . w of that row
+    const bool ypos = (ys & bits) != 0u;
+    const float yd = ypos ? d : -d;
+    if (SCATTER) {
+      const bool active = fin && !(yd < 0.0f);           // ref: core/ml/SparseSVM.scala:27-28
+      if (nb == 1 && r_end >= 1 && r_end <= nrows) {
+        x.coefw[r_end] = active ? (ypos ? ps : ns) : 0.0f;
+        if (fin) x.coef8[(long long)cur.r0 + r_end - 1] = (signed char)(active ? (ypos ? 1 : -1) : 0);
+      }
+      n_all += active;
+    } else {
+      n_all += fin;                                       // ref: core/ml/SparseSVM.scala:14,16
+      n_neg += fin && (yd < 0.0f);
+      n_pos += fin && (yd > 0.0f);
+    }
+  } else {
+    // general case (a lane holds two or more row starts: rows shorter than 8 non-zeros)
+    float run = incoming;
+    int r = rf - (int)(bits & 1u);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if ((bits >> k) & 1) {
-      if (r >= 1 && r <= nrows) {
-        const float d = run;                                  // x . w
-        const float y = ((ys >> k) & 1) ? 1.0f : -1.0f;
-        const bool in_range = r >= x.rb_lo && r < x.rb_hi;
-        if (SCATTER) {
-          const bool active = in_range && !(y * d < 0.0f);   // ref: core/ml/SparseSVM.scala:27-28
-          x.coefw[r] = active ? y : 0.0f;
-          if (in_range) x.coef8[(long long)r0 + r - 1] = (signed char)(active ? (int)y : 0);
-          if (active) active_local++;
-        } else if (in_range) {
-          const float yd = y * d;                             // ref: core/ml/SparseSVM.scala:14,16
-          if (yd < 0.0f) c0++;
-          else if (yd > 0.0f) c2++;
-          else c1++;
+    for (int k = 0; k < 8; ++k) {
+      if ((bits >> k) & 1u) {
+        if (r >= 1 && r <= nrows) {
+          const bool in_range = r >= r_lo && r < r_hi;
+          const bool ypos = (ys >> k) & 1u;
+          const float yd = ypos ? run : -run;
+          if (SCATTER) {
+            const bool active = in_range && !(yd < 0.0f);
+            x.coefw[r] = active ? (ypos ? ps : ns) : 0.0f;
+            if (in_range) x.coef8[(long long)cur.r0 + r - 1] = (signed char)(active ? (ypos ? 1 : -1) : 0);
+            n_all += active;
+          } else {
+            n_all += in_range;
+            n_neg += in_range && (yd < 0.0f);
+            n_pos += in_range && (yd > 0.0f);
+          }
         }
+        run = 0.0f;
+        ++r;
       }
-      run = 0.0f;
-      ++r;
-    }
-    run += pk[k];
-  }
-}
-
-__device__ __forceinline__ void w_half_scatter(const WCtx& x, const int (&cc)[4], const float (&vv)[4], int desc) {
-  const int rf = desc & 255, bits = (desc >> 8) & 15;
-  int r = rf;
-  float coef = x.coefw[r];
-  int q[4], old[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (k > 0 && ((bits >> k) & 1)) {
-      ++r;
-      coef = x.coefw[r];
-    }
-    const float xv = filt(vv[k] * coef);  // x * y (ref: SparseSVM.scala:28); coef is 0 on inactive rows / padding
-    q[k] = (xv != 0.0f && cc[k] < x.hg) ? __float2int_rn(xv * x.fix_scale) : 0;
-    old[k] = 0;
-    if (q[k] != 0) old[k] = atomicAdd(&x.gl[cc[k]], q[k]);  // ds_add_rtn_u32
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (q[k] != 0) {
-      const int nw = old[k] + q[k];
-      if (old[k] >= WS_PANIC_AT || old[k] <= -WS_PANIC_AT) atomicOr(&x.sc->err, 2);
-      if (nw >= WS_SPILL_AT || nw <= -WS_SPILL_AT) {
-        const int v = atomicExch(&x.gl[cc[k]], 0);
-        if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[cc[k]]), (unsigned long long)(long long)v);
-      }
+      run += pk[k];
     }
   }
-}
 
-template <bool SCATTER>
-__device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, const float* __restrict__ w, WCtx& x,
-                                       long long tile, long long stride, long long t_end, long long nnz_pad4,
-                                       WRegs& cur, WRegs& nxt, WRegs& far, unsigned int& active_local,
-                                       unsigned int& c0, unsigned int& c1, unsigned int& c2) {
-  const int lane = threadIdx.x & 63;
-  w_gather(w, x.hw, nxt);                                        // tile t+1 (its col ids landed)
-  w_issue(m, tt, tile + 2 * stride, t_end, lane, nnz_pad4, far);  // tile t+2
-
-  const int nrows = cur.nrows;
-  const int dA = nrows < 0 ? 0 : (int)(cur.meta & 0xffffu);
-  const int dB = nrows < 0 ? 0 : (int)(cur.meta >> 16);
-  const int ccA[4] = {cur.c0.x, cur.c0.y, cur.c0.z, cur.c0.w};
-  const int ccB[4] = {cur.c1.x, cur.c1.y, cur.c1.z, cur.c1.w};
-  const float vvA[4] = {cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w};
-  const float vvB[4] = {cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w};
-  float pA[4], pB[4];
-  typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const bool hotA = ccA[k] < x.hw, hotB = ccB[k] < x.hw;
-    const float a = ((lds_cvfloat*)x.wl)[hotA ? ccA[k] : 0];
-    const float b = ((lds_cvfloat*)x.wl)[hotB ? ccB[k] : 0];
-    pA[k] = filt(vvA[k] * (hotA ? a : cur.gw[k]));      // ref: math/Sparse.scala:46 (product map, filtered)
-    pB[k] = filt(vvB[k] * (hotB ? b : cur.gw[4 + k]));
-  }
-  // local rows of the worker's batch inside this tile (rows are 1-based here)
-  {
-    const long long lo = x.row_begin - cur.r0 + 1, hi = x.row_end - cur.r0 + 1;
-    x.rb_lo = (int)(lo < 0 ? 0 : (lo > 1024 ? 1024 : lo));
-    x.rb_hi = (int)(hi < 0 ? 0 : (hi > 1024 ? 1024 : hi));
-  }
-  float inA, inB, carryA, carryB;
-  int headA, headB;
-  w_half_scan(pA, (dA >> 8) & 15, 0.0f, inA, carryA, headA);
-  w_half_scan(pB, (dB >> 8) & 15, carryA, inB, carryB, headB);
-  w_half_finalize<SCATTER>(x, pA, dA, inA, cur.r0, nrows, active_local, c0, c1, c2);
-  w_half_finalize<SCATTER>(x, pB, dB, inB, cur.r0, nrows, active_local, c0, c1, c2);
   if (SCATTER) {
     if (lane == 0) {
       x.coefw[0] = 0.0f;                          // padding rows carry a zero coefficient
       x.coefw[nrows < 0 ? 1 : nrows + 1] = 0.0f;
     }
     __builtin_amdgcn_wave_barrier();  // same wave wrote the strip; LDS executes a wave's accesses in order
-    w_half_scatter(x, ccA, vvA, dA);
-    w_half_scatter(x, ccB, vvB, dB);
+    int q[8], old[8];
+    if (__builtin_amdgcn_ballot_w64(nb > 1) == 0) {
+      // slots before the lane's row start belong to row rf - (start at slot 0 ? 0 : ...): with one start at
+      // slot k*, slots [0, k*) are row rf (or all 8 when k* == 0 / no start), slots [k*, 8) are row rf + 1
+      const float cA = x.coefw[rf];
+      const float cB = x.coefw[rf + 1 <= WS_MAXROWS + 1 ? rf + 1 : rf];
+      const unsigned int after = (bits & 1u) ? 0u : (bits ? (0xffu & ~((bits & (0u - bits)) - 1u)) : 0u);  // slots >= k*
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float coef = ((after >> k) & 1u) ? cB : cA;
+        q[k] = cc[k] < x.hg ? __float2int_rn(vv[k] * coef) : 0;   // y * x on the fixed-point grid
+      }
+    } else {
+      int r = rf;
+      float coef = x.coefw[r];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k > 0 && ((bits >> k) & 1u)) {
+          ++r;
+          coef = x.coefw[r];
+        }
+        q[k] = cc[k] < x.hg ? __float2int_rn(vv[k] * coef) : 0;
+      }
+    }
+    int worst = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      old[k] = 0;
+      if (q[k] != 0) old[k] = atomicAdd(&x.gl[cc[k]], q[k]);   // ds_add_rtn_u32
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) worst = max(worst, abs(old[k] + q[k]));
+    if (worst >= WS_SPILL_AT) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (q[k] != 0) {
+          const int nw = old[k] + q[k];
+          if (old[k] >= WS_PANIC_AT || old[k] <= -WS_PANIC_AT) atomicOr(&x.sc->err, 2);
+          if (nw >= WS_SPILL_AT || nw <= -WS_SPILL_AT) {
+            const int v = atomicExch(&x.gl[cc[k]], 0);
+            if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[cc[k]]), (unsigned long long)(long long)v);
+          }
+        }
+      }
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -1415,39 +1430,39 @@ template <bool SCATTER>
 __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, WTables tt, const float* __restrict__ w,
                                                         long long* g64_base, long long g_stride,
                                                         const StreamSeg* __restrict__ segs, DevScalars* sc, int hw, int hg,
-                                                        float fix_scale, signed char* coef8) {
+                                                        float fix_scale, signed char* coef8, int dp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WCtx x;
   x.coef8 = coef8;
   x.coefw = lds + wave * WS_COEF_STRIDE;                       // 16 strips
   x.gl = reinterpret_cast<int*>(lds + 16 * WS_COEF_STRIDE);    // hg (SCATTER only)
-  x.wl = lds + 16 * WS_COEF_STRIDE + (SCATTER ? hg : 0);       // hw
+  float* wl = lds + 16 * WS_COEF_STRIDE + (SCATTER ? hg : 0);  // hw + 1 (zero slot at wl[hw])
+  x.wl = wl;
   const StreamSeg seg = segs[blockIdx.y];
   x.g64 = g64_base + (long long)blockIdx.y * g_stride;
   x.sc = sc;
   x.row_begin = seg.row_begin;
   x.row_end = seg.row_end;
-  x.rb_lo = x.rb_hi = 0;
   x.hw = hw;
   x.hg = hg;
   x.fix_scale = fix_scale;
   if (SCATTER)
     for (int j = tid; j < hg; j += 1024) x.gl[j] = 0;
-  for (int j = tid; j < hw; j += 1024) x.wl[j] = w[j];
+  for (int j = tid; j < hw; j += 1024) wl[j] = w[j];
+  if (tid == 0) wl[hw] = 0.0f;
   __syncthreads();
 
-  unsigned int active_local = 0, c0 = 0, c1 = 0, c2 = 0;
-  const long long nnz_pad4 = (m.row_ptr[m.n_rows] + 3) & ~3LL;
+  unsigned int n_all = 0, n_neg = 0, n_pos = 0;
   const long long stride = (long long)gridDim.x * 16;          // waves of this worker's grid row
   const long long t_end = seg.tile_end;
   long long tile = seg.tile_begin + (long long)blockIdx.x * 16 + wave;
   if (tile < t_end) {
     WRegs A, B, C;
-    w_issue(m, tt, tile, t_end, lane, nnz_pad4, A);
-    w_issue(m, tt, tile + stride, t_end, lane, nnz_pad4, B);
-    w_gather(w, hw, A);
-#define DSGD_WT(CUR, NXT, FAR) w_tile<SCATTER>(m, tt, w, x, tile, stride, t_end, nnz_pad4, CUR, NXT, FAR, active_local, c0, c1, c2)
+    w_issue(m, tt, tile, t_end, lane, A);
+    w_issue(m, tt, tile + stride, t_end, lane, B);
+    w_gather(w, hw, (unsigned int)dp, A);
+#define DSGD_WT(CUR, NXT, FAR) w_tile<SCATTER>(m, tt, w, x, (unsigned int)dp, tile, stride, t_end, CUR, NXT, FAR, n_all, n_neg, n_pos)
     for (;;) {
       DSGD_WT(A, B, C); tile += stride; if (tile >= t_end) break;
       DSGD_WT(B, C, A); tile += stride; if (tile >= t_end) break;
@@ -1462,17 +1477,17 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, WTables tt, 
       const int q = x.gl[j];
       if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
     }
-    active_local = wave_sum_u32(active_local);
-    if (lane == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
+    n_all = wave_sum_u32(n_all);
+    if (lane == 0 && n_all) atomicAdd(&sc->n_active, (unsigned long long)n_all);
   } else {
-    c0 = wave_sum_u32(c0);
-    c1 = wave_sum_u32(c1);
-    c2 = wave_sum_u32(c2);
+    n_all = wave_sum_u32(n_all);
+    n_neg = wave_sum_u32(n_neg);
+    n_pos = wave_sum_u32(n_pos);
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&sc->counts[3], (unsigned long long)(seg.row_end - seg.row_begin));
     if (lane == 0) {
-      if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
-      if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
-      if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
+      if (n_neg) atomicAdd(&sc->counts[0], (unsigned long long)n_neg);                          // pred == y
+      if (n_all - n_neg - n_pos) atomicAdd(&sc->counts[1], (unsigned long long)(n_all - n_neg - n_pos));  // pred == 0
+      if (n_pos) atomicAdd(&sc->counts[2], (unsigned long long)n_pos);                          // pred == -y
     }
   }
 }
