@@ -161,7 +161,7 @@ struct dsgd_ctx {
   int* d_wlong_idx = nullptr;           // staging of the long rows of the current call
   long long wlong_cap = 0;
   std::vector<int> wlong_last;
-  int hw_w = 8192, hg_w = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 8192 - 4;  // LDS tiles of the wseg gradient kernel
+  int hw_w = 12288, hg_w = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 12288 - 4;  // LDS tiles of the wseg gradient kernel
   int hw_we = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4;                     // ... of the wseg evaluation kernel
   unsigned short* d_tile_meta = nullptr;  // n_tiles x 1024 lane descriptors of the seg kernels
   int hw_g = 6144, hg_g = DSGD_LDS_FLOATS - SG_LDS_FIXED - 6144 - 2;  // LDS tiles of the seg gradient kernel

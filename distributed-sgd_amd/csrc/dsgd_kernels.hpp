@@ -1243,11 +1243,16 @@ struct WRegs {
   int r0, nrows;
 };
 
+// the tile record of tile t (clamped), fetched one iteration before w_issue needs it: a scalar load whose
+// result feeds the address computation would otherwise expose the scalar-cache latency once per tile
+__device__ __forceinline__ WTile w_fetch(const WTables& tt, long long t, long long t_end) {
+  return tt.tiles[t < t_end ? t : t_end - 1];
+}
+
 __device__ __forceinline__ void w_issue(const CsrView& m, const WTables& tt, long long t, long long t_end, int lane,
-                                        WRegs& r) {
+                                        const WTile& wt, WRegs& r) {
   const bool live = t < t_end;
-  const long long tc = live ? t : t_end - 1;     // wave-uniform: scalar loads below
-  const WTile wt = tt.tiles[tc];
+  const long long tc = live ? t : t_end - 1;     // wave-uniform
   r.r0 = wt.r0;
   r.nrows = live ? wt.nrows : -1;
   const int4* cp = reinterpret_cast<const int4*>(m.col + wt.pos0);
@@ -1282,11 +1287,12 @@ struct WCtx {
 template <bool SCATTER>
 __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, const float* __restrict__ w, const WCtx& x,
                                        unsigned int dp, long long tile, long long stride, long long t_end, WRegs& cur,
-                                       WRegs& nxt, WRegs& far, unsigned int& n_all, unsigned int& n_neg,
-                                       unsigned int& n_pos) {
+                                       WRegs& nxt, WRegs& far, WTile& wt_far, unsigned int& n_all,
+                                       unsigned int& n_neg, unsigned int& n_pos) {
   const int lane = threadIdx.x & 63;
-  w_gather(w, x.hw, dp, nxt);                          // tile t+1 (its col ids landed)
-  w_issue(m, tt, tile + 2 * stride, t_end, lane, far);  // tile t+2
+  w_gather(w, x.hw, dp, nxt);                                  // tile t+1 (its col ids landed)
+  w_issue(m, tt, tile + 2 * stride, t_end, lane, wt_far, far);  // tile t+2 (record fetched last iteration)
+  wt_far = w_fetch(tt, tile + 3 * stride, t_end);               // record of tile t+3, used next iteration
 
   const int nrows = cur.nrows;                          // wave-uniform; -1: the whole tile is padding
   const unsigned int desc = nrows < 0 ? 0u : cur.meta;
@@ -1459,10 +1465,13 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, WTables tt, 
   long long tile = seg.tile_begin + (long long)blockIdx.x * 16 + wave;
   if (tile < t_end) {
     WRegs A, B, C;
-    w_issue(m, tt, tile, t_end, lane, A);
-    w_issue(m, tt, tile + stride, t_end, lane, B);
+    WTile wt = w_fetch(tt, tile, t_end);
+    w_issue(m, tt, tile, t_end, lane, wt, A);
+    wt = w_fetch(tt, tile + stride, t_end);
+    w_issue(m, tt, tile + stride, t_end, lane, wt, B);
+    wt = w_fetch(tt, tile + 2 * stride, t_end);
     w_gather(w, hw, (unsigned int)dp, A);
-#define DSGD_WT(CUR, NXT, FAR) w_tile<SCATTER>(m, tt, w, x, (unsigned int)dp, tile, stride, t_end, CUR, NXT, FAR, n_all, n_neg, n_pos)
+#define DSGD_WT(CUR, NXT, FAR) w_tile<SCATTER>(m, tt, w, x, (unsigned int)dp, tile, stride, t_end, CUR, NXT, FAR, wt, n_all, n_neg, n_pos)
     for (;;) {
       DSGD_WT(A, B, C); tile += stride; if (tile >= t_end) break;
       DSGD_WT(B, C, A); tile += stride; if (tile >= t_end) break;
