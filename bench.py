@@ -41,8 +41,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=int(os.environ.get("DSGD_BENCH_ROWS", 804414)),
-                    help="rows per GPU (804414 = RCV1 full=true, DatasetTests.scala:18)")
+    ap.add_argument("--rows", type=int, default=int(os.environ.get("DSGD_BENCH_ROWS", 8388608)),
+                    help="rows per GPU.  8388608 (5.1 GB of CSR, BASELINE.md section 3) keeps the stream in HBM; "
+                         "804414 = RCV1 full=true (DatasetTests.scala:18) fits mostly in the 256 MiB Infinity Cache")
     ap.add_argument("--workers", type=int, default=1, help="virtual workers (node-count share) per GPU")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

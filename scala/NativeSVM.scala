@@ -1,0 +1,87 @@
+package epfl.distributed.core.ml
+
+import epfl.distributed.math.Vec
+import spire.math.Number
+
+/** JVM face of libdsgd_hip (include/dsgd.h) -- the binding a maintainer of zifeo/distributed-sgd adds.
+  *
+  * `SparseSVM` keeps its constructor and its six methods (core/ml/SparseSVM.scala:11-31); `HipSVM` below is a
+  * subclass whose batch-level entry points replace the bodies of `SlaveImpl.gradient` / `forward`
+  * (core/Slave.scala:129-157) and of the `Master.fit` batch closure (core/Master.scala:179-199) when
+  * `dsgd.backend = hip` (a new OPTIONAL key; every existing `dsgd { ... }` key of application.conf is untouched).
+  */
+object NativeSVM {
+  System.loadLibrary("dsgd_jni") // jni/dsgd_jni.cpp, links libdsgd_hip.so
+
+  @native def create(nFeatures: Int, lambda: Double, device: Int): Long
+  @native def destroy(ctx: Long): Unit
+  @native def loadCsr(ctx: Long, rowPtr: Array[Long], col: Array[Int], value: Array[Float], label: Array[Byte]): Unit
+  @native def buildDimSparsity(ctx: Long, nTrain: Long): Unit
+  @native def gradient(ctx: Long, w: Array[Float], idx: Array[Int], gOut: Array[Float]): Long
+  @native def forward(ctx: Long, w: Array[Float], idx: Array[Int], predOut: Array[Float]): Unit
+  @native def syncStep(ctx: Long, idxPerWorker: Array[Array[Int]], lr: Float): Long
+  @native def lossAcc(ctx: Long, w: Array[Float], rowBegin: Long, rowEnd: Long, out: Array[Double]): Unit
+  @native def asyncStep(ctx: Long, idx: Array[Int], lr: Float, deltaOut: Array[Float]): Unit
+  @native def updateGrad(ctx: Long, keys: Array[Int], values: Array[Float]): Unit
+  @native def setWeights(ctx: Long, w: Array[Float]): Unit
+  @native def getWeights(ctx: Long, wOut: Array[Float]): Unit
+}
+
+/** Dense float[D+1] indexed by KEY is the exchange format: feature ids are 1-based map keys
+  * (utils/Dataset.scala:30), dimSparsity uses 0-based keys (Main.scala:60-62), so both slot 0 and slot D exist. */
+object DenseKeys {
+  def fromVec(v: Vec): Array[Float] = {
+    val a = new Array[Float](v.size + 1)
+    v.map.foreach { case (k, n) => a(k) = n.toDouble.toFloat }
+    a
+  }
+  def toVec(a: Array[Float], size: Int): Vec =
+    Vec(a.iterator.zipWithIndex.collect { case (x, k) if x != 0f => k -> Number(x.toDouble) }.toMap, size)
+}
+
+class HipSVM(lambda: Number, dimSparsity: Vec, data: Array[(Vec, Int)], nTrain: Int, device: Int = 0)
+    extends SparseSVM(lambda, dimSparsity) {
+
+  private val dim = data(0)._1.size
+  private val ctx = NativeSVM.create(dim, lambda.toDouble, device)
+
+  {
+    // Array[(Vec, Int)] -> CSR, columns ascending (the order of the text files, utils/Dataset.scala:19-34)
+    val rowPtr = new Array[Long](data.length + 1)
+    val cols   = Array.newBuilder[Int]
+    val vals   = Array.newBuilder[Float]
+    val labels = new Array[Byte](data.length)
+    var nnz    = 0L
+    data.zipWithIndex.foreach {
+      case ((x, y), i) =>
+        x.map.toSeq.sortBy(_._1).foreach { case (k, n) => cols += k; vals += n.toDouble.toFloat; nnz += 1 }
+        rowPtr(i + 1) = nnz
+        labels(i) = y.toByte
+    }
+    NativeSVM.loadCsr(ctx, rowPtr, cols.result(), vals.result(), labels)
+    NativeSVM.buildDimSparsity(ctx, nTrain)
+  }
+
+  /** body of SlaveImpl.gradient (core/Slave.scala:142-157) */
+  def gradientBatch(w: Vec, samplesIdx: Seq[Int]): Vec = {
+    val g = new Array[Float](dim + 1)
+    NativeSVM.gradient(ctx, DenseKeys.fromVec(w), samplesIdx.toArray, g)
+    DenseKeys.toVec(g, dim)
+  }
+
+  /** body of SlaveImpl.forward (core/Slave.scala:129-140) */
+  def forwardBatch(w: Vec, samplesIdx: Seq[Int]): Seq[Number] = {
+    val p = new Array[Float](samplesIdx.size)
+    NativeSVM.forward(ctx, DenseKeys.fromVec(w), samplesIdx.toArray, p)
+    p.map(x => Number(x.toDouble))
+  }
+
+  /** Master.localLoss / localAccuracy over a row range (core/Master.scala:100-107) */
+  def lossAndAccuracy(w: Vec, rowBegin: Int, rowEnd: Int): (Number, Double) = {
+    val out = new Array[Double](2)
+    NativeSVM.lossAcc(ctx, DenseKeys.fromVec(w), rowBegin, rowEnd, out)
+    (Number(out(0)), out(1))
+  }
+
+  def close(): Unit = NativeSVM.destroy(ctx)
+}
