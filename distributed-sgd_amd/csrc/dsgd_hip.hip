@@ -196,6 +196,16 @@ struct dsgd_ctx {
   int segs_cap = 0;
   std::vector<WorkSeg> segs_last;  // what d_segs currently holds
   long long pending_samples = 0;   // rows enqueued by *_async calls since the last dsgd_synchronize
+  // persistent Hogwild engine
+  hipStream_t async_stream = nullptr;
+  hipStream_t query_stream = nullptr;
+  HogState* d_hog = nullptr;
+  HogState* h_hog = nullptr;   // pinned
+  int* h_stop = nullptr;       // host-mapped stop flag
+  float* d_gcold = nullptr;
+  long long* d_asg = nullptr;  // begin[n], end[n]
+  int hog_workers = 0;
+  bool async_running = false;
   // comm
   rccl::comm_t comm = nullptr;
   int world = 1, rank = 0;
@@ -781,6 +791,11 @@ static int require_data(dsgd_ctx* c) {
   if (!c->d_row_ptr) return fail(DSGD_ESTATE, "no data loaded (dsgd_load_csr)");
   return DSGD_OK;
 }
+// the synchronous entry points own w; they are refused while the lock-free engine is updating it
+static int require_sync_mode(dsgd_ctx* c) {
+  if (c->async_running) return fail(DSGD_ESTATE, "async computation running (dsgd_async_stop / dsgd_async_wait first)");
+  return DSGD_OK;
+}
 static int require_ds(dsgd_ctx* c) {
   if (!c->have_ds) return fail(DSGD_ESTATE, "dimSparsity not set (dsgd_set_dim_sparsity / dsgd_build_dim_sparsity)");
   return DSGD_OK;
@@ -902,6 +917,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR((dsgd_stream_kernel<16, false, false>));
   DSGD_ATTR((dsgd_stream_kernel<8, true, false>));
   DSGD_ATTR((dsgd_stream_kernel<8, false, false>));
+  DSGD_ATTR(dsgd_hogwild_kernel);
   DSGD_ATTR(dsgd_wseg_kernel<true>);
   DSGD_ATTR(dsgd_wseg_kernel<false>);
   DSGD_ATTR(dsgd_seg_kernel<true>);
@@ -951,6 +967,17 @@ int dsgd_destroy(dsgd_ctx* c) {
   hipFree(c->d_wtiles);
   hipFree(c->d_wmeta);
   hipFree(c->d_wlong_idx);
+  if (c->async_stream) {
+    if (c->h_stop) *c->h_stop = 1;
+    hipStreamSynchronize(c->async_stream);
+    hipStreamDestroy(c->async_stream);
+  }
+  if (c->query_stream) hipStreamDestroy(c->query_stream);
+  hipFree(c->d_hog);
+  hipFree(c->d_gcold);
+  hipFree(c->d_asg);
+  if (c->h_hog) hipHostFree(c->h_hog);
+  if (c->h_stop) hipHostFree(c->h_stop);
   if (c->h_sc) hipHostFree(c->h_sc);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -1323,6 +1350,7 @@ int dsgd_set_weights(dsgd_ctx* c, const float* w) {
   if (!w) return fail(DSGD_EINVAL, "null w");
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
+  DSGD_TRY(require_sync_mode(c));
   return set_weights_locked(c, w);
 }
 
@@ -1432,6 +1460,7 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
   DSGD_TRY(bind(c));
   DSGD_TRY(require_data(c));
   DSGD_TRY(require_ds(c));
+  DSGD_TRY(require_sync_mode(c));
   DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_g(c, n_workers));
   DSGD_TRY(ensure_s(c));
@@ -1457,6 +1486,7 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
   if (n_workers < 1 || !row_begin || !row_end) return fail(DSGD_EINVAL, "need at least one worker");
   DSGD_TRY(require_data(c));
   DSGD_TRY(require_ds(c));
+  DSGD_TRY(require_sync_mode(c));
   std::vector<WorkSeg> segs(n_workers);
   long long mx = 0, tot = 0;
   for (int k = 0; k < n_workers; ++k) {
@@ -1591,6 +1621,7 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
   DSGD_TRY(bind(c));
   DSGD_TRY(require_data(c));
   DSGD_TRY(require_ds(c));
+  DSGD_TRY(require_sync_mode(c));
   DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_g(c, p->n_workers));
   DSGD_TRY(ensure_s(c));
@@ -1654,7 +1685,8 @@ int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_en
   if (w) DSGD_TRY(set_weights_locked(c, w));
   DSGD_TRY(ensure_s(c));  // also refreshes |w|^2
   DSGD_TRY(reset_counters(c));
-  if (c->stream_ranges && row_end - row_begin >= 4096 && (c->stream_mode == 3 || !any_long_row(c, &row_begin, &row_end, 1))) {
+  if (!c->async_running && c->stream_ranges && row_end - row_begin >= 4096 &&
+      (c->stream_mode == 3 || !any_long_row(c, &row_begin, &row_end, 1))) {
     std::vector<StreamSeg> ssegs(1, make_sseg(c, row_begin, row_end));
     DSGD_TRY(launch_stream<false>(c, ssegs));
   } else {
@@ -1663,7 +1695,8 @@ int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_en
     const long long rows = row_end - row_begin;
     dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(c->n_cu, (rows + groups_per_block - 1) / groups_per_block)));
     // small ranges do not amortise staging 160 KiB of weights per workgroup: shrink the LDS tile
-    const int hw = rows >= 4096 ? c->hw_eval : std::min(c->hw_eval, 1024);
+    // while the Hogwild engine owns most of every CU's LDS, keep the footprint small enough to co-reside
+    const int hw = c->async_running ? std::min(c->hw_eval, 8192) : (rows >= 4096 ? c->hw_eval : std::min(c->hw_eval, 1024));
     const size_t lds = sizeof(float) * (size_t)hw;
     CsrView m = view(c);
     switch (G) {
@@ -1699,6 +1732,7 @@ int dsgd_async_step(dsgd_ctx* c, const int32_t* idx, int64_t n, float lr, float*
   DSGD_TRY(bind(c));
   DSGD_TRY(require_data(c));
   DSGD_TRY(require_ds(c));
+  DSGD_TRY(require_sync_mode(c));
   DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_s(c));
   DSGD_TRY(reset_counters(c));
@@ -1746,22 +1780,125 @@ int dsgd_update_grad(dsgd_ctx* c, const int32_t* key, const float* dv, int64_t n
   return check_err_flag(c);
 }
 
-// ---- Hogwild persistent engine: implemented in round 1 part 2 -----------------------------------
-int dsgd_async_start(dsgd_ctx* c, const int64_t*, const int64_t*, int32_t, int32_t, float, int64_t, uint64_t, int32_t) {
-  DSGD_TRY(check_ctx(c));
-  return fail(DSGD_EUNSUPPORTED, "persistent Hogwild engine not built into this library version");
+// ---- Hogwild persistent engine -------------------------------------------------------------------------
+static int async_refresh(dsgd_ctx* c) {  // copy the engine's counters to the host without touching its stream
+  HIP_TRY(hipMemcpyAsync(c->h_hog, c->d_hog, sizeof(HogState), hipMemcpyDeviceToHost, c->query_stream));
+  HIP_TRY(hipStreamSynchronize(c->query_stream));
+  return DSGD_OK;
 }
-int dsgd_async_updates(dsgd_ctx* c, int64_t*, int32_t*) {
+
+int dsgd_async_start(dsgd_ctx* c, const int64_t* assigned_begin, const int64_t* assigned_end, int32_t n_workers, int32_t batch,
+                     float lr, int64_t max_updates, uint64_t seed, int32_t positional_bug) {
   DSGD_TRY(check_ctx(c));
-  return fail(DSGD_EUNSUPPORTED, "persistent Hogwild engine not built into this library version");
+  if (!assigned_begin || !assigned_end || n_workers < 1) return fail(DSGD_EINVAL, "need at least one worker");
+  if (batch < 1 || batch > HOG_MAX_BATCH) return fail(DSGD_EINVAL, "batch %d outside [1, %d]", batch, HOG_MAX_BATCH);
+  if (max_updates < 0) return fail(DSGD_EINVAL, "negative max_updates");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(require_data(c));
+  DSGD_TRY(require_ds(c));
+  // ref: core/Slave.scala:161 "Async computation already running, can't be initialized unless stopped first"
+  if (c->async_running) return fail(DSGD_ESTATE, "async computation already running: stop it first");
+  std::vector<long long> asg(2 * (size_t)n_workers);
+  for (int k = 0; k < n_workers; ++k) {
+    const long long b = assigned_begin[k], e = assigned_end[k];
+    if (e <= b) return fail(DSGD_EINVAL, "worker %d has no assigned samples", k);
+    if (b < 0 || e > c->n_rows) return fail(DSGD_ERANGE, "worker %d range [%lld, %lld) outside the %lld loaded rows", k, b, e, c->n_rows);
+    if (batch > e - b) return fail(DSGD_EINVAL, "batch %d larger than worker %d's %lld assigned samples", batch, k, e - b);
+    if (positional_bug && e - b > c->n_rows) return fail(DSGD_ERANGE, "positional sampling outside the data");
+    asg[k] = b;
+    asg[n_workers + k] = e;
+  }
+  DSGD_TRY(prepare_layout(c));
+  DSGD_TRY(ensure_s(c));
+  if (!c->async_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->async_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->query_stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&c->d_hog, sizeof(HogState)));
+    HIP_TRY(hipHostMalloc(&c->h_hog, sizeof(HogState), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&c->h_stop, sizeof(int), hipHostMallocMapped));
+  }
+  const int hl = std::min(c->dp, 24576);
+  if (n_workers > c->hog_workers) {
+    hipFree(c->d_gcold);
+    hipFree(c->d_asg);
+    c->d_gcold = nullptr;
+    c->d_asg = nullptr;
+    HIP_TRY(hipMalloc(&c->d_gcold, sizeof(float) * (size_t)n_workers * (size_t)std::max(1, c->dp - hl)));
+    HIP_TRY(hipMalloc(&c->d_asg, sizeof(long long) * 2 * (size_t)n_workers));
+    c->hog_workers = n_workers;
+  }
+  HIP_TRY(hipMemsetAsync(c->d_gcold, 0, sizeof(float) * (size_t)n_workers * (size_t)std::max(1, c->dp - hl), c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_asg, asg.data(), sizeof(long long) * asg.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_hog, 0, sizeof(HogState), c->stream));
+  HIP_TRY(hipMemcpyAsync(&c->d_hog->s_reg, &c->d_sc->s_reg, sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // asg is a stack-lifetime host buffer; everything is in place before launch
+  *c->h_stop = 0;
+  HogArgs a;
+  a.m = view(c);
+  a.w = c->d_w;
+  a.ds = c->d_ds;
+  a.gcold = c->d_gcold;
+  a.asg_begin = c->d_asg;
+  a.asg_end = c->d_asg + n_workers;
+  a.st = c->d_hog;
+  int* dev_stop = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_stop), c->h_stop, 0));
+  a.stop = dev_stop;
+  a.max_updates = max_updates;
+  a.seed = seed;
+  a.lr = lr;
+  a.lambda = (float)c->cfg.lambda;
+  a.batch = batch;
+  a.positional_bug = positional_bug;
+  a.hl = hl;
+  a.dp = c->dp;
+  const size_t lds = sizeof(float) * (size_t)(hl + HOG_MAX_BATCH / 4 + 16 + 16);
+  hipLaunchKernelGGL(dsgd_hogwild_kernel, dim3(n_workers), dim3(HOG_THREADS), lds, c->async_stream, a);
+  HIP_TRY(hipGetLastError());
+  c->async_running = true;
+  c->s_dirty = true;
+  return DSGD_OK;
 }
-int dsgd_async_stop(dsgd_ctx* c) {
+
+int dsgd_async_updates(dsgd_ctx* c, int64_t* updates, int32_t* running) {
   DSGD_TRY(check_ctx(c));
-  return fail(DSGD_EUNSUPPORTED, "persistent Hogwild engine not built into this library version");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  if (!c->d_hog) {
+    if (updates) *updates = 0;
+    if (running) *running = 0;
+    return DSGD_OK;
+  }
+  DSGD_TRY(async_refresh(c));
+  if (updates) *updates = (int64_t)c->h_hog->updates;
+  const bool busy = c->async_running && hipStreamQuery(c->async_stream) == hipErrorNotReady;
+  if (running) *running = busy ? 1 : 0;
+  return DSGD_OK;
 }
+
+static int async_join(dsgd_ctx* c) {
+  HIP_TRY(hipStreamSynchronize(c->async_stream));
+  c->async_running = false;
+  c->s_dirty = true;  // w moved under the scalar the synchronous kernels cache
+  return DSGD_OK;
+}
+
+int dsgd_async_stop(dsgd_ctx* c) {  // ref: SlaveImpl.stopAsync, core/Slave.scala:187-195
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  if (!c->async_running) return DSGD_OK;
+  *c->h_stop = 1;
+  return async_join(c);
+}
+
 int dsgd_async_wait(dsgd_ctx* c) {
   DSGD_TRY(check_ctx(c));
-  return fail(DSGD_EUNSUPPORTED, "persistent Hogwild engine not built into this library version");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  if (!c->async_running) return DSGD_OK;
+  return async_join(c);
 }
 
 int dsgd_comm_unique_id(char* id_out) {

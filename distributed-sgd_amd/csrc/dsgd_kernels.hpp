@@ -1530,3 +1530,167 @@ __global__ void __launch_bounds__(256) dsgd_eval_idx_kernel(CsrView m, const flo
     if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
   }
 }
+
+// ======================================================================================================
+// K7: persistent lock-free ("Hogwild") engine -- Slave.asyncTask for many workers sharing ONE w
+// ======================================================================================================
+// ref: core/Slave.scala:79-111 (the loop), :177-185 / core/MasterAsync.scala:164-177 (applying updates),
+//      README.md:35 (Recht et al. 2011).
+// The reference gives every slave its own replica of w and gossips each update to every peer, who
+// subtracts it; with all workers on one GPU the replicas collapse into a single device-resident w that
+// every worker (= workgroup) reads without locks and updates with atomicAdd(w[j], -delta_j).
+// One iteration of a worker:
+//   draw `batch` rows of its assigned range (affine permutation of the range = "shuffle take batch";
+//   batch == 1: one uniform draw) -> gated sub-gradients on whatever w holds right now -> batch sum in
+//   a workgroup-private accumulator (LDS for the hot columns, a private global strip for the cold ones)
+//   -> MEAN over the batch -> support-only regulariser with s = 2*lambda*(w.ds) -> scale by lr ->
+//   atomicAdd into w.  The scalar s is kept up to date incrementally (s -= 2*lambda*sum(delta_j*ds_j))
+//   instead of re-reducing 47 K products per mini-batch as SparseSVM.regularize does.
+struct HogState {
+  unsigned long long updates;   // mini-batch updates applied (MasterAsync counts these: MasterAsync.scala:83,171)
+  unsigned long long samples;   // rows whose gradient was computed
+  unsigned long long active;    // ... of which the gate let through
+  float s_reg;                  // 2 * lambda * (w . ds), maintained incrementally
+  int done_blocks;
+};
+
+struct HogArgs {
+  CsrView m;
+  float* w;
+  const float* ds;
+  float* gcold;                 // n_workers x (dp - hl) private strips, zero between iterations
+  const long long* asg_begin;
+  const long long* asg_end;
+  HogState* st;
+  const volatile int* stop;     // host-mapped flag
+  long long max_updates;
+  unsigned long long seed;
+  float lr, lambda;
+  int batch, positional_bug, hl, dp;
+};
+
+__device__ __forceinline__ unsigned long long hog_mix(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ long long hog_gcd(long long a, long long b) {
+  while (b) {
+    const long long t = a % b;
+    a = b;
+    b = t;
+  }
+  return a;
+}
+
+constexpr int HOG_THREADS = 512;
+constexpr int HOG_G = 16;
+constexpr int HOG_MAX_BATCH = 4096;
+
+__global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* gl = lds;                                                  // hl hot accumulators
+  unsigned char* act = reinterpret_cast<unsigned char*>(lds + a.hl);  // HOG_MAX_BATCH gate flags
+  float* red = lds + a.hl + HOG_MAX_BATCH / 4;                      // 16 floats + control words
+  int* ctl = reinterpret_cast<int*>(red + 16);
+  const int tid = threadIdx.x, sub = tid % HOG_G, gidx = tid / HOG_G;
+  constexpr int NG = HOG_THREADS / HOG_G;
+  const int worker = blockIdx.x;
+  const long long begin = a.asg_begin[worker], n_k = a.asg_end[worker] - begin;
+  const long long base = a.positional_bug ? 0 : begin;   // ref: core/Slave.scala:87 indexes `data` by POSITION
+  float* gc = a.gcold + (long long)worker * (a.dp - a.hl);
+  for (int j = tid; j < a.hl; j += HOG_THREADS) gl[j] = 0.0f;
+  __syncthreads();
+  const int B = a.batch;
+  const float inv_b = 1.0f / (float)B;  // exact for the usual powers of two; Vec.mean divides (math/Vec.scala:139)
+  unsigned long long it = 0;
+  for (;;) {
+    if (tid == 0) {
+      const unsigned long long u = *reinterpret_cast<volatile unsigned long long*>(&a.st->updates);
+      ctl[0] = (*a.stop != 0) || ((long long)u >= a.max_updates);
+    }
+    __syncthreads();
+    if (ctl[0]) break;
+    const float s = *reinterpret_cast<volatile float*>(&a.st->s_reg);
+    const bool add_s = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+    // this iteration's sample: rows base + (mul * t + off) mod n_k, t = 0..B-1 (distinct rows)
+    const unsigned long long key = hog_mix(a.seed ^ hog_mix((unsigned long long)worker * 0x100000001B3ull + it));
+    long long mul = 1 + (long long)(hog_mix(key) % (unsigned long long)n_k);
+    while (hog_gcd(mul, n_k) != 1) mul = mul % n_k + 1;
+    const long long off = (long long)(hog_mix(key ^ 0xABCDEF12345ull) % (unsigned long long)n_k);
+    unsigned int n_act = 0;
+    // phase 1: gated sub-gradient sum of the batch (ref: core/Slave.scala:93-98)
+    for (int t = gidx; t < B; t += NG) {
+      const long long row = base + (long long)(((unsigned long long)mul * (unsigned long long)t + (unsigned long long)off) % (unsigned long long)n_k);
+      const long long start = a.m.row_ptr[row], end = a.m.row_ptr[row + 1];
+      const float y = (float)a.m.label[row];
+      float acc = 0.0f;
+      // agent-scope loads: another CU's atomics must become visible (a plain load may hit a stale L1 line forever)
+      for (long long p = start + sub; p < end; p += HOG_G)
+        acc += filt(a.m.val[p] * __hip_atomic_load(&a.w[a.m.col[p]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const float d = group_sum<HOG_G>(acc);
+      const bool active = !(y * d < 0.0f);
+      if (sub == 0) {
+        act[t] = active ? 1 : 0;
+        n_act += active;
+      }
+      if (active)
+        for (long long p = start + sub; p < end; p += HOG_G) {
+          const int c = a.m.col[p];
+          const float xv = filt(a.m.val[p] * y);
+          if (xv != 0.0f) {
+            if (c < a.hl) atomicAdd(&gl[c], xv);
+            else atomicAdd(&gc[c - a.hl], xv);
+          }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // phase 2: mean, regularise on the support, scale, subtract from the shared w (ref: Slave.scala:98-101)
+    float ds_acc = 0.0f;
+    for (int t = gidx; t < B; t += NG) {
+      if (!act[t]) continue;
+      const long long row = base + (long long)(((unsigned long long)mul * (unsigned long long)t + (unsigned long long)off) % (unsigned long long)n_k);
+      const long long start = a.m.row_ptr[row], end = a.m.row_ptr[row + 1];
+      for (long long p = start + sub; p < end; p += HOG_G) {
+        const int c = a.m.col[p];
+        // take-and-clear: the first lane to reach column c gets the whole batch sum, the others get 0
+        const float v = c < a.hl ? atomicExch(&gl[c], 0.0f) : atomicExch(&gc[c - a.hl], 0.0f);
+        if (fabsf(v) > DSGD_EPS) {
+          float g = filt(v * inv_b);
+          if (add_s) g = filt(g + s);
+          const float delta = filt(g * a.lr);
+          if (delta != 0.0f) {
+            atomicAdd(&a.w[c], -delta);   // lock-free update of the ONE weight vector
+            ds_acc += delta * a.ds[c];
+          }
+        }
+      }
+    }
+    // one atomic per workgroup for the incremental regulariser scalar and the counters
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ds_acc += __shfl_xor(ds_acc, o, 64);
+    n_act = wave_sum_u32(n_act);
+    if ((tid & 63) == 0) {
+      red[tid >> 6] = ds_acc;
+      ctl[2 + (tid >> 6)] = (int)n_act;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float tot = 0.0f;
+      int na = 0;
+      for (int i = 0; i < HOG_THREADS / 64; ++i) {
+        tot += red[i];
+        na += ctl[2 + i];
+      }
+      if (tot != 0.0f) atomicAdd(&a.st->s_reg, -2.0f * a.lambda * tot);
+      atomicAdd(&a.st->updates, 1ull);
+      atomicAdd(&a.st->samples, (unsigned long long)B);
+      atomicAdd(&a.st->active, (unsigned long long)na);
+    }
+    ++it;
+    __syncthreads();
+  }
+  if (tid == 0) atomicAdd(&a.st->done_blocks, 1);
+}

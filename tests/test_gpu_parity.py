@@ -393,3 +393,97 @@ def test_ragged_rows_all_kernel_paths(flags):
         assert st["n_active"] == n_train
         _, _, counts = eng.loss_acc(0, n_train)
         assert counts == [0, n_train, 0]
+
+
+# ---- persistent lock-free ("Hogwild") engine -----------------------------------------------------------
+M64 = (1 << 64) - 1
+
+
+def hog_mix(z):  # csrc/dsgd_kernels.hpp: hog_mix (splitmix64 finaliser)
+    z = (z + 0x9E3779B97F4A7C15) & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def hog_rows(seed, worker, it, begin, n_k, batch, positional_bug):
+    """The rows iteration `it` of worker `worker` samples (mirror of dsgd_hogwild_kernel)."""
+    import math
+    key = hog_mix(seed ^ hog_mix((worker * 0x100000001B3 + it) & M64))
+    mul = 1 + hog_mix(key) % n_k
+    while math.gcd(mul, n_k) != 1:
+        mul = mul % n_k + 1
+    off = hog_mix(key ^ 0xABCDEF12345) % n_k
+    base = 0 if positional_bug else begin
+    return np.asarray([base + (mul * t + off) % n_k for t in range(batch)], dtype=np.int32)
+
+
+def test_hogwild_single_worker_replays_the_oracle():
+    """One worker is deterministic: replay its sample lists through the oracle's async_step."""
+    data = dsgd_amd.synth.generate(6000, seed=12)
+    n_train = 4800
+    o, eng = make_pair(data, 1e-5, n_train)
+    with eng:
+        for batch, n_upd, bug in ((100, 40, False), (1, 60, False), (64, 30, True)):
+            eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+            w_ref = np.zeros(data.dim + 1)
+            begin, end = 1000, 4000
+            eng.async_start([(begin, end)], batch=batch, lr=0.5, max_updates=n_upd, seed=77, positional_bug=bug)
+            with pytest.raises(dsgd_amd.DsgdError):  # Slave.scala:161: already running
+                eng.async_start([(begin, end)], batch=batch, lr=0.5, max_updates=n_upd, seed=77)
+            eng.async_wait()
+            updates, running = eng.async_updates()
+            assert updates == n_upd and not running
+            exposed = False
+            for it in range(n_upd):
+                rows = hog_rows(77, 0, it, begin, end - begin, batch, bug)
+                assert len(set(rows.tolist())) == batch  # "shuffle take batch": distinct rows
+                if bug:
+                    assert rows.max() < end - begin  # Slave.scala:87 indexes `data` by position
+                else:
+                    assert rows.min() >= begin and rows.max() < end
+                o.async_step(w_ref, rows, 0.5)
+                exposed = exposed or o.last_stats["min_abs_margin"] < GATE_EPS
+            w = eng.get_weights().astype(np.float64)
+            if not exposed:
+                assert np.abs(w - w_ref).max() <= 4 * tol(w_ref), (batch, np.abs(w - w_ref).max())
+
+
+def test_hogwild_many_workers_statistical_parity():
+    data = dsgd_amd.synth.generate(40000, seed=13)
+    n_train = 32000
+    o, eng = make_pair(data, 1e-5, n_train)
+    k, batch, n_upd = 64, 100, 3200
+    split = [(r.start, r.stop) for r in rd.split_vanilla(n_train, k)]
+    with eng:
+        eng.async_start(split, batch=batch, lr=0.5, max_updates=n_upd, seed=5, positional_bug=False)
+        seen = []
+        while True:
+            u, running = eng.async_updates()
+            seen.append(u)
+            if not running:
+                break
+            loss, acc, counts = eng.loss_acc(n_train, data.n_rows)  # the master's loss check runs concurrently
+            assert sum(counts) == data.n_rows - n_train
+        eng.async_wait()
+        u, running = eng.async_updates()
+        assert not running and n_upd <= u <= n_upd + k  # every worker finishes its current mini-batch
+        assert seen == sorted(seen)
+        w = eng.get_weights()
+        assert np.isfinite(w).all()
+        loss, acc, _ = eng.loss_acc(n_train, data.n_rows)
+        # oracle: the same number of updates applied one after the other (instant gossip == one shared w)
+        rng = np.random.default_rng(0)
+        w_ref = np.zeros(data.dim + 1)
+        for it in range(n_upd):
+            b, e = split[it % k]
+            o.async_step(w_ref, rng.permutation(np.arange(b, e))[:batch].astype(np.int32), 0.5)
+        loss_ref, acc_ref, _, _ = o.loss_acc(w_ref, n_train, data.n_rows)
+        assert acc > 0.55 and abs(acc - acc_ref) < 0.08, (acc, acc_ref)
+        # stop() interrupts a run that would otherwise go on for a long time
+        eng.async_start(split, batch=batch, lr=0.5, max_updates=10**9, seed=6)
+        eng.async_stop()
+        u2, running = eng.async_updates()
+        assert not running and 0 <= u2 < 10**9
+        st = eng.sync_step([np.arange(100, dtype=np.int32)], 0.5)  # synchronous calls work again afterwards
+        assert st["n_samples"] == 100
