@@ -7,8 +7,8 @@
 The directory name is not an importable identifier; `import dsgd_amd` (repo root) aliases it.
 """
 
-from . import _build, _lib, synth  # noqa: F401
+from . import _build, _lib, host, synth  # noqa: F401
 from ._lib import DsgdError, DsgdIndexError, DsgdInvalidArgument  # noqa: F401
 from .engine import Engine, Plan, device_count  # noqa: F401
 
-__all__ = ["Engine", "Plan", "device_count", "synth", "DsgdError", "DsgdIndexError", "DsgdInvalidArgument"]
+__all__ = ["Engine", "Plan", "device_count", "synth", "host", "DsgdError", "DsgdIndexError", "DsgdInvalidArgument"]

@@ -1,0 +1,357 @@
+"""Host-side mirror of the reference's coordination layer for the hot path.
+
+Same names, argument meaning and stopping behaviour as the Scala classes, so that parity tests read like
+the reference.  Citations are relative to /root/reference/src/main/scala/epfl/distributed/.
+
+    Config            utils/Config.scala:3-21 + resources/application.conf:1-52 (DSGD_* overrides)
+    SplitStrategy     core/ml/SplitStrategy.scala:13-14
+    EarlyStopping     core/ml/EarlyStopping.scala:11-46
+    GradState         core/ml/GradState.scala:6-24  (`grad` holds the WEIGHTS)
+    JavaRandom        java.util.Random (the generator behind scala.util.Random, seeded 0 at Main.scala:32)
+    scala_shuffle     scala.util.Random.shuffle (2.12): the per-batch reshuffle of Master.scala:184
+    MasterSync.fit    core/Master.scala:120-218
+    MasterAsync.fit   core/MasterAsync.scala:32-62, 96-177
+
+All arithmetic happens behind a *backend* (the HIP `Engine`); this module only orchestrates.  A backend
+offers: sync_step(idx_lists, lr), gradient(idx) -> (g, stats), apply(g_mean, lr), loss_acc(lo, hi),
+get_weights(), set_weights(w), and for the asynchronous mode async_start/async_updates/async_stop.
+"""
+
+from __future__ import annotations
+
+import math
+import os
+import time
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+
+# ---- configuration --------------------------------------------------------------------------------------
+@dataclass
+class Config:
+    """utils/Config.scala:3-21; defaults are application.conf:1-52."""
+
+    data_path: str = "data"
+    host: str = "127.0.0.1"
+    port: int = 4000
+    master_host: Optional[str] = None
+    master_port: Optional[int] = None
+    batch_size: int = 100
+    learning_rate: float = 0.5
+    lambda_: float = 1e-5
+    full: bool = False
+    node_count: int = 3
+    async_: bool = False
+    record: bool = False
+    max_epochs: int = 10
+    check_every: int = 100
+    leaky_loss: float = 0.9
+    patience: int = 5
+    conv_delta: float = 0.01
+
+    # application.conf key -> (field, env override, parser)
+    _KEYS = {
+        "data-path": ("data_path", "DSGD_DATA_PATH", str),
+        "host": ("host", "DSGD_NODE_HOST", str),
+        "port": ("port", "DSGD_NODE_PORT", int),
+        "master-host": ("master_host", "DSGD_MASTER_HOST", str),
+        "master-port": ("master_port", "DSGD_MASTER_PORT", int),
+        "batch-size": ("batch_size", "DSGD_BATCH_SIZE", int),
+        "learning-rate": ("learning_rate", "DSGD_LEARNING_RATE", float),
+        "lambda": ("lambda_", "DSGD_LAMBDA", float),
+        "full": ("full", "DSGD_FULL", lambda s: str(s).lower() == "true"),
+        "node-count": ("node_count", "DSGD_NODE_COUNT", int),
+        "async": ("async_", "DSGD_ASYNC", lambda s: str(s).lower() == "true"),
+        "record": ("record", "DSGD_RECORD", lambda s: str(s).lower() == "true"),
+        "max-epochs": ("max_epochs", "DSGD_MAX_EPOCHS", int),
+        "check-every": ("check_every", "DSGD_CHECK_EVERY", int),
+        "leaky-loss": ("leaky_loss", "DSGD_LEAKY_LOSS", float),
+        "patience": ("patience", "DSGD_PATIENCE", int),
+        "conv-delta": ("conv_delta", "DSGD_CONV_DELTA", float),
+    }
+
+    @classmethod
+    def load(cls, conf_text: Optional[str] = None, env=os.environ) -> "Config":
+        """`key = value` lines of the dsgd { ... } block, then the DSGD_* environment overrides
+        (`key = ${?DSGD_X}` lines of application.conf)."""
+        cfg = cls()
+        if conf_text:
+            depth, in_dsgd = 0, False
+            for raw in conf_text.splitlines():
+                line = raw.split("#", 1)[0].strip()
+                if not line:
+                    continue
+                if line.startswith("dsgd") and line.endswith("{"):
+                    in_dsgd, depth = True, 1
+                    continue
+                if in_dsgd:
+                    depth += line.count("{") - line.count("}")
+                    if depth <= 0:
+                        in_dsgd = False
+                        continue
+                    if "=" in line:
+                        k, v = (t.strip() for t in line.split("=", 1))
+                        if k in cls._KEYS and not v.startswith("${"):
+                            name, _, parse = cls._KEYS[k]
+                            setattr(cfg, name, parse(v.strip('"')))
+        for k, (name, var, parse) in cls._KEYS.items():
+            if var in env and env[var] != "":
+                setattr(cfg, name, parse(env[var]))
+        return cfg
+
+    def role(self) -> str:
+        """Main.scala:122-159: master-host/port equal to own -> master; set but different -> slave; unset -> dev."""
+        if self.master_host is not None and self.master_port is not None:
+            return "master" if (self.master_host == self.host and self.master_port == self.port) else "slave"
+        return "dev"
+
+
+# ---- split / stopping / state -----------------------------------------------------------------------------
+def split_vanilla(n: int, n_slaves: int) -> List[range]:
+    """SplitStrategy.vanilla: indices.grouped(ceil(n / K)); may yield fewer than K groups."""
+    size = int(math.ceil(n / float(n_slaves)))
+    return [range(b, min(n, b + size)) for b in range(0, n, size)]
+
+
+class EarlyStopping:
+    @staticmethod
+    def target(target: float) -> Callable[[Sequence[float]], bool]:
+        return lambda losses: bool(losses) and losses[0] <= target  # EarlyStopping.scala:11
+
+    @staticmethod
+    def no_improvement(patience: int = 5, min_delta: float = 1e-3, min_steps: Optional[int] = None):
+        """EarlyStopping.scala:13-46 over a NEWEST-FIRST list."""
+
+        def crit(losses: Sequence[float]) -> bool:
+            abs_min_delta = abs(min_delta)
+
+            def check() -> bool:
+                mn, idx_min = 1.7976931348623157e308, -1
+                for index, num in enumerate(losses):
+                    if (num - mn) <= abs_min_delta:
+                        mn, idx_min = num, index
+                return False if idx_min == 0 else idx_min >= patience
+
+            if not losses:
+                return False
+            if min_steps is None:
+                return check()
+            return False if min_steps < len(losses) else check()
+
+        return crit
+
+
+@dataclass
+class GradState:
+    """GradState.scala:6-24 -- `grad` is the weight vector."""
+
+    grad: np.ndarray
+    loss: Optional[float] = None
+    start: float = field(default_factory=time.time)
+    updates: int = 0
+    end: Optional[float] = None
+
+    def replace_grad(self, new_grad) -> "GradState":
+        return GradState(new_grad, self.loss, self.start, self.updates + 1, self.end)
+
+    def finish(self, final_loss) -> "GradState":
+        return GradState(self.grad, final_loss, self.start, self.updates, time.time())
+
+
+# ---- the reference's random stream ---------------------------------------------------------------------------
+class JavaRandom:
+    """java.util.Random: 48-bit LCG; scala.util.Random delegates to it (seed 0 at Main.scala:32)."""
+
+    def __init__(self, seed: int = 0):
+        self.seed = (seed ^ 0x5DEECE66D) & ((1 << 48) - 1)
+
+    def _next(self, bits: int) -> int:
+        self.seed = (self.seed * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
+        v = self.seed >> (48 - bits)
+        return v - (1 << 32) if (bits == 32 and v >= (1 << 31)) else v  # (int) cast of the Java original
+
+    def next_int(self, bound: Optional[int] = None) -> int:
+        if bound is None:
+            return self._next(32)
+        if bound <= 0:
+            raise ValueError("bound must be positive")
+        r = self._next(31)
+        m = bound - 1
+        if (bound & m) == 0:
+            return (bound * r) >> 31
+        u = r
+        while True:
+            r = u % bound
+            if u - r + m < (1 << 31):
+                return r
+            u = self._next(31)
+
+
+def scala_shuffle(xs: Sequence[int], rnd: JavaRandom) -> List[int]:
+    """scala.util.Random.shuffle (2.12): for n <- len to 2 by -1: swap(n - 1, nextInt(n))."""
+    buf = list(xs)
+    for n in range(len(buf), 1, -1):
+        k = rnd.next_int(n)
+        buf[n - 1], buf[k] = buf[k], buf[n - 1]
+    return buf
+
+
+# ---- distributed aggregate owned by the host (alternative to the in-library RCCL all-reduce) -----------------
+class HostAllReduceBackend:
+    """Mean over world_size x hosted workers with the collective owned by the host (`torch.distributed`,
+    gloo on CPU / nccl on GPU).  core/Master.scala:190-197: every rank computes the regularised sums of its
+    own workers, the sums are all-reduced, every rank applies the identical update."""
+
+    def __init__(self, local, dist_module, n_rows_local_train: int):
+        self.local, self.dist = local, dist_module
+        self.world = dist_module.get_world_size()
+        self.n_train = n_rows_local_train
+
+    def sync_step(self, idx_lists, lr):
+        import torch
+
+        total = None
+        stats = {"n_samples": 0, "n_active": 0}
+        for idx in idx_lists:
+            g, st = self.local.gradient(idx)
+            total = g.astype(np.float64) if total is None else total + g
+            stats["n_samples"] += st["n_samples"]
+            stats["n_active"] += st["n_active"]
+        t = torch.from_numpy(np.ascontiguousarray(total))
+        self.dist.all_reduce(t)  # sum over ranks
+        k_total = len(idx_lists) * self.world
+        self.local.apply((t.numpy() / k_total).astype(np.float32), lr)  # Vec.mean then w - lr * grad
+        return stats
+
+    def loss_acc(self, lo, hi):
+        import torch
+
+        _, _, counts = self.local.loss_acc(lo, hi)
+        t = torch.tensor(list(counts) + [hi - lo], dtype=torch.int64)
+        self.dist.all_reduce(t)
+        c0, c1, c2, n = (int(x) for x in t)
+        w = self.local.get_weights().astype(np.float64)
+        lam = getattr(self.local, "lam")
+        return lam * float((w * w).sum()) + (c1 + 2.0 * c2) / n, c0 / n, [c0, c1, c2]
+
+    def get_weights(self):
+        return self.local.get_weights()
+
+    def set_weights(self, w):
+        self.local.set_weights(w)
+
+
+# ---- Master.fit (synchronous) ---------------------------------------------------------------------------------
+class MasterSync:
+    """core/Master.scala:120-218 for the workers hosted behind one backend.
+
+    data layout: rows [0, n_train) are the train set, [n_train, n_rows) the test set (Main.scala:52)."""
+
+    def __init__(self, backend, n_train: int, n_rows: int, node_count: int, rnd: Optional[JavaRandom] = None, log=None):
+        self.backend, self.n_train, self.n_rows, self.node_count = backend, n_train, n_rows, node_count
+        self.rnd = rnd or JavaRandom(0)
+        self.log = log or (lambda *a: None)
+        self.losses: List[float] = []
+        self.accs: List[float] = []
+        self.test_losses: List[float] = []
+        self.test_accs: List[float] = []
+
+    def local_loss(self, test: bool = False):  # Master.scala:104-106
+        lo, hi = (self.n_train, self.n_rows) if test else (0, self.n_train)
+        return self.backend.loss_acc(lo, hi)[0]
+
+    def local_accuracy(self, test: bool = False):  # Master.scala:100-102
+        lo, hi = (self.n_train, self.n_rows) if test else (0, self.n_train)
+        return self.backend.loss_acc(lo, hi)[1]
+
+    def fit(self, initial_weights, max_epochs: int, batch_size: int, learning_rate: float,
+            stopping_criterion: Callable[[Sequence[float]], bool]) -> GradState:
+        split = split_vanilla(self.n_train, self.node_count)  # Master.scala:136
+        max_samples = max(len(r) for r in split)              # :138
+        self.backend.set_weights(np.asarray(initial_weights, dtype=np.float32))
+        state = GradState(np.asarray(initial_weights, dtype=np.float32))
+        epoch = 0
+        while True:
+            if self.losses:
+                self.log("loss after epoch %d: %s" % (epoch, self.losses[0]))
+                self.log("acc after epoch %d: %s" % (epoch, self.accs[0]))
+            if epoch >= max_epochs:                             # :154
+                self.log("Reached max number of epochs: stopping computation")
+                return state.finish(self.losses[0] if self.losses else None)
+            if stopping_criterion(self.test_losses):            # :166
+                self.log("Converged to target: stopping computation")
+                return state.finish(self.losses[0] if self.losses else None)
+            for batch in range(0, max_samples, batch_size):    # :179
+                # :184 -- every worker's split is reshuffled for EVERY batch, then sliced
+                lists = []
+                for r in split:
+                    shuffled = scala_shuffle(list(r), self.rnd)
+                    lists.append(np.asarray(shuffled[batch:batch + batch_size], dtype=np.int32))
+                # a slice past the end of a short last split is empty: Vec.sum would throw in the slave
+                self.backend.sync_step(lists, learning_rate)     # :186-197
+            w = self.backend.get_weights()
+            state = state.replace_grad(w)
+            # :206-209 -- four full passes per epoch; newest first
+            l, a, _ = self.backend.loss_acc(0, self.n_train)
+            tl, ta, _ = self.backend.loss_acc(self.n_train, self.n_rows)
+            self.losses.insert(0, l)
+            self.accs.insert(0, a)
+            self.test_losses.insert(0, tl)
+            self.test_accs.insert(0, ta)
+            epoch += 1
+
+
+# ---- MasterAsync.fit ------------------------------------------------------------------------------------------------
+class MasterAsync:
+    """core/MasterAsync.scala:32-177 on top of the lock-free engine: start the workers, check the test loss
+    every `check_every` updates with a leaky average, keep the best weights, stop on the criterion or at
+    maxSteps = n_train * max_epochs updates (MasterAsync.scala:83)."""
+
+    def __init__(self, backend, n_train: int, n_rows: int, node_count: int, log=None, poll_s: float = 0.0):
+        self.backend, self.n_train, self.n_rows, self.node_count = backend, n_train, n_rows, node_count
+        self.log = log or (lambda *a: None)
+        self.poll_s = poll_s
+        self.test_losses: List[float] = []
+        self.test_accs: List[float] = []
+
+    def fit(self, initial_weights, max_epoch: int, batch_size: int, learning_rate: float,
+            stopping_criterion: Callable[[Sequence[float]], bool], check_every: int, leak_loss_coef: float,
+            seed: int = 0, positional_bug: bool = True, max_steps: Optional[int] = None) -> GradState:
+        if not (0 <= leak_loss_coef <= 1):
+            raise ValueError("leaking coefficient must be between 0 and 1")  # MasterAsync.scala:97
+        split = [(r.start, r.stop) for r in split_vanilla(self.n_train, self.node_count)]
+        steps = self.n_train * max_epoch if max_steps is None else max_steps
+        self.backend.set_weights(np.asarray(initial_weights, dtype=np.float32))
+        self.backend.async_start(split, batch=batch_size, lr=learning_rate, max_updates=steps, seed=seed,
+                                 positional_bug=positional_bug)
+        best_w, best_loss = np.asarray(initial_weights, dtype=np.float32), float("inf")
+        last_step = -check_every
+        state = GradState(best_w)
+        try:
+            while True:
+                updates, running = self.backend.async_updates()
+                if updates - last_step >= check_every or not running:
+                    computed_loss, computed_acc, _ = self.backend.loss_acc(self.n_train, self.n_rows)
+                    prev_l = self.test_losses[0] if self.test_losses else computed_loss
+                    prev_a = self.test_accs[0] if self.test_accs else computed_acc
+                    loss = leak_loss_coef * computed_loss + (1 - leak_loss_coef) * prev_l   # :122-125
+                    acc = leak_loss_coef * computed_acc + (1 - leak_loss_coef) * prev_a
+                    if best_loss > loss:                                                     # :132-138
+                        best_loss, best_w = loss, self.backend.get_weights()
+                    self.test_losses.insert(0, loss)
+                    self.test_accs.insert(0, acc)
+                    last_step = updates
+                    if stopping_criterion(self.test_losses):                                # :146
+                        self.log("converged to target: stopping computation")
+                        break
+                if not running:
+                    break
+                if self.poll_s:
+                    time.sleep(self.poll_s)
+        finally:
+            self.backend.async_stop()                                                        # endComputation :87-94
+        updates, _ = self.backend.async_updates()
+        state = GradState(best_w, updates=int(updates)).finish(best_loss)
+        return state

@@ -1,0 +1,132 @@
+"""CPU tests of the host-side mirror (distributed-sgd_amd/host.py) and of the N > 1 orchestration with
+world_size 2 over gloo."""
+
+import os
+
+import numpy as np
+import pytest
+
+import dsgd_amd
+from dsgd_amd import host
+from oracle import oracle as orc
+from oracle_backend import OracleBackend
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_java_random_known_answers():
+    r = host.JavaRandom(0)
+    assert [r.next_int() for _ in range(3)] == [-1155484576, -723955400, 1033096058]  # new java.util.Random(0)
+    r = host.JavaRandom(0)
+    assert [r.next_int(10) for _ in range(10)] == [0, 8, 9, 7, 5, 3, 1, 1, 9, 4]
+    r = host.JavaRandom(42)
+    assert r.next_int() == -1170105035
+
+
+def test_scala_shuffle_is_a_seeded_permutation():
+    a = host.scala_shuffle(list(range(20)), host.JavaRandom(0))
+    b = host.scala_shuffle(list(range(20)), host.JavaRandom(0))
+    assert a == b and sorted(a) == list(range(20)) and a != list(range(20))
+    # the last element is decided first: swap(n - 1, nextInt(n)) with nextInt(20) of seed 0
+    assert a[19] == host.JavaRandom(0).next_int(20)
+
+
+def test_config_defaults_env_and_roles():
+    text = open(os.path.join(HERE, "golden", "application.conf")).read()
+    c = host.Config.load(text, env={})
+    assert (c.batch_size, c.learning_rate, c.lambda_, c.node_count, c.max_epochs) == (100, 0.5, 1e-5, 3, 10)
+    assert (c.check_every, c.leaky_loss, c.patience, c.conv_delta, c.full, c.async_) == (100, 0.9, 5, 0.01, False, False)
+    assert c.role() == "dev" and c.port == 4000 and c.host == "127.0.0.1"
+    # kube/config-sync.yaml:8-20 overrides
+    env = {"DSGD_BATCH_SIZE": "200", "DSGD_NODE_COUNT": "4", "DSGD_CONV_DELTA": "0.001", "DSGD_ASYNC": "true",
+           "DSGD_MASTER_HOST": "10.0.0.1", "DSGD_MASTER_PORT": "46746", "DSGD_NODE_PORT": "46746"}
+    c = host.Config.load(text, env=env)
+    assert (c.batch_size, c.node_count, c.conv_delta, c.async_) == (200, 4, 0.001, True)
+    assert c.role() == "slave"
+    env["DSGD_NODE_HOST"] = "10.0.0.1"
+    assert host.Config.load(text, env=env).role() == "master"
+
+
+def test_early_stopping_and_split():
+    crit = host.EarlyStopping.no_improvement(patience=2, min_delta=0.01)
+    assert not crit([]) and not crit([0.4, 0.5]) and not crit([0.45, 0.4, 0.5]) and crit([0.46, 0.45, 0.4, 0.5])
+    assert host.EarlyStopping.target(0.3)([0.29, 0.5]) and not host.EarlyStopping.target(0.3)([0.31])
+    assert [len(r) for r in host.split_vanilla(18519, 3)] == [6173, 6173, 6173]
+    assert len(host.split_vanilla(9, 4)) == 3  # SplitStrategy.scala:14 can yield fewer groups than workers
+
+
+def small_problem(n_rows=3000, seed=31):
+    data = dsgd_amd.synth.generate(n_rows, seed=seed)
+    n_train = int(n_rows * 0.8)
+    o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, 1e-5)
+    o.set_dim_sparsity(o.dim_sparsity(n_train))
+    return data, n_train, o
+
+
+def test_master_sync_fit_loop():
+    data, n_train, o = small_problem()
+    be = OracleBackend(o)
+    m = host.MasterSync(be, n_train, data.n_rows, node_count=3, rnd=host.JavaRandom(0))
+    state = m.fit(np.zeros(data.dim + 1), max_epochs=2, batch_size=100, learning_rate=0.5,
+                  stopping_criterion=host.EarlyStopping.no_improvement(5, 0.01))
+    per_epoch = -(-len(host.split_vanilla(n_train, 3)[0]) // 100)  # ceil(800 / 100) batches per epoch
+    assert len(be.steps) == 2 * per_epoch and all(s == [100, 100, 100] for s in be.steps)
+    assert len(m.losses) == 2 and len(m.test_losses) == 2 and state.updates == 2 and state.end is not None
+    assert m.accs[0] > 0.5
+    # replaying the same random stream gives the same weights (Main.scala:32 seeds the global Random with 0)
+    be2 = OracleBackend(o)
+    m2 = host.MasterSync(be2, n_train, data.n_rows, node_count=3, rnd=host.JavaRandom(0))
+    state2 = m2.fit(np.zeros(data.dim + 1), 2, 100, 0.5, host.EarlyStopping.no_improvement(5, 0.01))
+    np.testing.assert_array_equal(state.grad, state2.grad)
+    # a criterion that fires immediately stops after the first epoch's evaluation
+    be3 = OracleBackend(o)
+    m3 = host.MasterSync(be3, n_train, data.n_rows, node_count=3)
+    m3.fit(np.zeros(data.dim + 1), 10, 100, 0.5, lambda losses: len(losses) >= 1)
+    assert len(be3.steps) == per_epoch
+
+
+# ---- world_size 2 over gloo: host-owned all-reduce == one process hosting all workers ---------------------------
+def _rank_main(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data, n_train, o = small_problem()
+    local = OracleBackend(o)
+    be = host.HostAllReduceBackend(local, dist, n_train)
+    # four workers in total, two per rank; rank r hosts workers 2r and 2r+1 (contiguous ranges of the train rows)
+    split = host.split_vanilla(n_train, 2 * world)
+    rng = np.random.default_rng(123)
+    for step in range(5):
+        lists = [rng.permutation(np.asarray(r))[:100].astype(np.int32) for r in split]  # same stream on every rank
+        be.sync_step(lists[2 * rank:2 * rank + 2], 0.5)
+    loss, acc, counts = be.loss_acc(n_train + rank * 100, n_train + rank * 100 + 100)   # disjoint eval shards
+    np.save(os.path.join(out_dir, "w%d.npy" % rank), local.w)
+    np.save(os.path.join(out_dir, "e%d.npy" % rank), np.asarray([loss, acc] + counts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    w0, w1 = np.load(tmp_path / "w0.npy"), np.load(tmp_path / "w1.npy")
+    np.testing.assert_array_equal(w0, w1)  # replicas apply the identical update
+    data, n_train, o = small_problem()
+    ref = OracleBackend(o)
+    split = host.split_vanilla(n_train, 4)
+    rng = np.random.default_rng(123)
+    for step in range(5):
+        lists = [rng.permutation(np.asarray(r))[:100].astype(np.int32) for r in split]
+        ref.sync_step(lists, 0.5)  # mean over 4 workers in one process (Master.scala:194)
+    np.testing.assert_allclose(w0, ref.w, rtol=0, atol=1e-6)  # the host path rounds g_mean to fp32 at the ABI
+    e0, e1 = np.load(tmp_path / "e0.npy"), np.load(tmp_path / "e1.npy")
+    np.testing.assert_array_equal(e0, e1)  # tallies are summed over ranks
+    ref.w = w0.copy()
+    c = np.zeros(3)
+    for r in range(2):
+        c += np.asarray(ref.loss_acc(n_train + r * 100, n_train + r * 100 + 100)[2])
+    assert list(e0[2:]) == list(c) and abs(e0[1] - c[0] / 200) < 1e-12
