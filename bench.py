@@ -210,6 +210,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_sweep:
         out["sweep"] = sweep(eng, n_train, bytes_per_row)
 
+    # ---- the other configurations of BASELINE.json, reported beside the headline (N=1 only) --------------------
+    if rank == 0 and world == 1 and not args.no_sweep:
+        out["eval_pass"] = eval_pass(eng, n_train, bytes_per_row)
+        out["hogwild"] = hogwild(eng, n_train)
+
     # ---- CPU baseline on this box's host cores (rank 0, N=1 only) --------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["cpu_literal"] = cpu_baseline(data, n_train, args.cpu_seconds)
@@ -243,6 +248,34 @@ def sweep(eng, n_train, bytes_per_row):
         res.append({"batch": b, "steps": steps, "examples_per_s": b * steps / dt, "us_per_step": 1e6 * dt / steps,
                     "frac_hbm_peak": b * steps / dt * bytes_per_row / HBM_PEAK})
     return res
+
+
+def eval_pass(eng, n_train, bytes_per_row):
+    """Master.localLoss/localAccuracy over the train rows (core/Master.scala:100-107): examples/s of one pass."""
+    eng.loss_acc(0, n_train)
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        eng.loss_acc(0, n_train)
+    dt = (time.perf_counter() - t0) / reps
+    return {"rows": n_train, "examples_per_s": n_train / dt, "ms": 1e3 * dt,
+            "frac_hbm_peak": n_train / dt * bytes_per_row / HBM_PEAK, "note": "wall time incl. launch + readback"}
+
+
+def hogwild(eng, n_train, workers=256, batch=100, updates=20000):
+    """BASELINE.json configs[3]: asynchronous mode, one workgroup per worker, lock-free atomicAdd into ONE
+    device-resident w (core/Slave.scala:79-111); reference defaults batch-size 100, learning-rate 0.5."""
+    from dsgd_amd import host
+
+    eng.set_weights(np.zeros(eng.dp, dtype=np.float32))
+    split = [(r.start, r.stop) for r in host.split_vanilla(n_train, workers)]
+    t0 = time.perf_counter()
+    eng.async_start(split, batch=batch, lr=LR0, max_updates=updates, seed=1, positional_bug=False)
+    eng.async_wait()
+    dt = time.perf_counter() - t0
+    u, _ = eng.async_updates()
+    return {"workers": len(split), "batch": batch, "updates": int(u), "examples_per_s": u * batch / dt,
+            "updates_per_s": u / dt, "ms": 1e3 * dt}
 
 
 def cpu_baseline(data, n_train, budget_s):

@@ -399,8 +399,8 @@ static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
   const float k_total = (float)n_workers * (float)c->world;
   if (n_workers == 1 && !c->comm) {
     // one hosted worker, no peers: regularise + "mean" over one worker + update in a single pass
-    hipLaunchKernelGGL(dsgd_apply_kernel<true>, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_g, c->d_g, (long long)dp,
-                       1, dp, c->d_ds, 1.0f, lr, (float)c->cfg.lambda, c->d_sc);
+    hipLaunchKernelGGL(dsgd_apply_mb_kernel<true>, dim3(std::min(64, blocks)), dim3(1024), 0, c->stream, c->d_w, c->d_g,
+                       c->d_g, (long long)dp, 1, dp, c->d_ds, 1.0f, lr, (float)c->cfg.lambda, c->d_sc);
     HIP_TRY(hipGetLastError());
     c->s_dirty = false;
     return DSGD_OK;
@@ -416,8 +416,8 @@ static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
     // all-reduce of D+1 floats over xGMI, ordered on the same stream as the kernels around it
     RCCL_TRY(rccl::AllReduce(c->d_gsum, c->d_gsum, (size_t)dp, rccl::kFloat32, rccl::kSum, c->comm, c->stream));
   }
-  hipLaunchKernelGGL(dsgd_apply_kernel<false>, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_gsum, c->d_g,
-                     (long long)dp, n_workers, dp, c->d_ds, k_total, lr, (float)c->cfg.lambda, c->d_sc);
+  hipLaunchKernelGGL(dsgd_apply_mb_kernel<false>, dim3(std::min(64, blocks)), dim3(1024), 0, c->stream, c->d_w, c->d_gsum,
+                     c->d_g, (long long)dp, n_workers, dp, c->d_ds, k_total, lr, (float)c->cfg.lambda, c->d_sc);
   HIP_TRY(hipGetLastError());
   c->s_dirty = false;
   return DSGD_OK;
@@ -689,7 +689,8 @@ static int launch_wseg(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   size_t slot = 0;
   if (SCATTER) DSGD_TRY(prof_begin(c, &slot));
   hipLaunchKernelGGL(dsgd_wseg_kernel<SCATTER>, grid, dim3(1024), lds, c->stream, m, wt, c->d_w, c->d_g64, (long long)c->dp,
-                     c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8, c->dp);
+                     c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8, c->dp,
+                     getenv("DSGD_DBG") ? atoi(getenv("DSGD_DBG")) : 0);
   HIP_TRY(hipGetLastError());
   if (SCATTER) DSGD_TRY(prof_end(c, slot));
   if (SCATTER) c->last_grad_kernel = "dsgd_wseg_kernel<true>";

@@ -29,6 +29,12 @@ struct DevScalars {
   unsigned long long n_active;   // rows with y*(x.w) >= 0
   unsigned long long n_samples;  // rows processed
   unsigned long long counts[4];  // eval tallies {pred==y, pred==0, pred==-y, rows}
+  // multi-workgroup apply: per-workgroup partial sums of w.ds and |w|^2, combined in a fixed order by the
+  // last workgroup to arrive (ticket)
+  float part_dot[64];
+  float part_nsq[64];
+  unsigned int ticket;
+  unsigned int pad2;
 };
 
 // one unit of gradient work: worker k processes items [begin, end) -- positions in the resident
@@ -313,6 +319,60 @@ __global__ void __launch_bounds__(1024) dsgd_apply_kernel(float* w, const float*
   if (threadIdx.x == 0) {
     sc->s_reg = lambda * 2.0f * dsum;
     sc->wnorm2 = nsum;
+  }
+}
+
+// Multi-workgroup form of K3 (the single-workgroup kernel above takes ~23 us for D+1 = 47,237 on MI355X,
+// half of a batch-size-100 step): up to 64 workgroups own contiguous slices; the two dot products are
+// combined by the last workgroup to arrive, in slice order, so the scalars stay reproducible.
+template <bool REG>
+__global__ void __launch_bounds__(1024) dsgd_apply_mb_kernel(float* w, const float* gsum, float* zero_base,
+                                                            long long zero_stride, int n_zero, int dp,
+                                                            const float* __restrict__ ds, float n_workers_total, float lr,
+                                                            float lambda, DevScalars* sc) {
+  __shared__ float red[16];
+  __shared__ int is_last;
+  const float s = sc->s_reg;
+  const bool add = REG && (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+  const int per = (dp + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = min(dp, lo + per);
+  float dot = 0.0f, nsq = 0.0f;
+  for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+    float gv = gsum[j];
+    if (REG) {
+      gv = filt(gv);
+      if (add && gv != 0.0f) gv = filt(gv + s);
+    }
+    const float mean = filt(gv / n_workers_total);
+    const float upd = filt(mean * lr);
+    const float wn = filt(w[j] - upd);
+    w[j] = wn;
+    dot += filt(wn * ds[j]);
+    nsq += wn * wn;
+  }
+  __syncthreads();  // all reads of gsum done before it is zeroed (gsum may alias zero_base)
+  for (int k = 0; k < n_zero; ++k)
+    for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) zero_base[(long long)k * zero_stride + j] = 0.0f;
+  const float dsum = block_sum_1024(dot, red);
+  const float nsum = block_sum_1024(nsq, red);
+  if (threadIdx.x == 0) {
+    sc->part_dot[blockIdx.x] = dsum;
+    sc->part_nsq[blockIdx.x] = nsum;
+    __threadfence();                                   // publish the partials before taking a ticket
+    const unsigned int t = atomicAdd(&sc->ticket, 1u);
+    is_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (is_last && threadIdx.x == 0) {
+    __threadfence();                                   // acquire: the other workgroups' partials
+    float d = 0.0f, q = 0.0f;
+    for (unsigned int b = 0; b < gridDim.x; ++b) {
+      d += __hip_atomic_load(&sc->part_dot[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      q += __hip_atomic_load(&sc->part_nsq[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    sc->s_reg = lambda * 2.0f * d;
+    sc->wnorm2 = q;
+    sc->ticket = 0;
   }
 }
 
@@ -1265,11 +1325,20 @@ __device__ __forceinline__ void w_issue(const CsrView& m, const WTables& tt, lon
   r.meta = (tt.meta + tc * 64)[(unsigned int)lane];
 }
 
-// cold-weight gathers of a tile whose column ids have landed; hot lanes read the zero slot w[dp]
-__device__ __forceinline__ void w_gather(const float* __restrict__ w, int hw, unsigned int dp, WRegs& r) {
+// cold-weight gathers of a tile whose column ids have landed.  Buffer loads: a hot lane gets an offset
+// beyond num_records, which the texture addresser answers with 0 WITHOUT touching the cache -- the
+// instruction stays unconditional (countable by vmcnt) and only the cold lanes cost memory traffic.
+__device__ __forceinline__ void w_gather(__amdgpu_buffer_rsrc_t wrs, int hw, WRegs& r) {
   const int c[8] = {r.c0.x, r.c0.y, r.c0.z, r.c0.w, r.c1.x, r.c1.y, r.c1.z, r.c1.w};
 #pragma unroll
-  for (int k = 0; k < 8; ++k) r.gw[k] = w[c[k] < hw ? dp : (unsigned int)c[k]];
+  for (int k = 0; k < 8; ++k) {
+    const unsigned int off = c[k] < hw ? 0xFFFFFFF0u : (unsigned int)c[k] * 4u;
+    r.gw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, off, 0, 0));
+  }
+}
+__device__ __forceinline__ void w_gather_off(WRegs& r) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r.gw[k] = 0.25f;
 }
 
 struct WCtx {
@@ -1282,15 +1351,17 @@ struct WCtx {
   long long row_begin, row_end;
   int hw, hg;
   float fix_scale;
+  int dbg;  // ablation switches for tuning runs (0 in production)
 };
 
 template <bool SCATTER>
-__device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, const float* __restrict__ w, const WCtx& x,
+__device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __amdgpu_buffer_rsrc_t wrs, const WCtx& x,
                                        unsigned int dp, long long tile, long long stride, long long t_end, WRegs& cur,
                                        WRegs& nxt, WRegs& far, WTile& wt_far, unsigned int& n_all,
                                        unsigned int& n_neg, unsigned int& n_pos) {
   const int lane = threadIdx.x & 63;
-  w_gather(w, x.hw, dp, nxt);                                  // tile t+1 (its col ids landed)
+  if (x.dbg & 32) w_gather_off(nxt);
+  else w_gather(wrs, x.hw, nxt);                               // tile t+1 (its col ids landed)
   w_issue(m, tt, tile + 2 * stride, t_end, lane, wt_far, far);  // tile t+2 (record fetched last iteration)
   wt_far = w_fetch(tt, tile + 3 * stride, t_end);               // record of tile t+3, used next iteration
 
@@ -1309,7 +1380,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, cons
   bool seen = false;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const float a = ((lds_cvfloat*)x.wl)[min(cc[k], x.hw)];
+    const float a = (x.dbg & 16) ? 0.5f : ((lds_cvfloat*)x.wl)[min(cc[k], x.hw)];
     pk[k] = filt(vv[k] * (a + cur.gw[k]));   // ref: math/Sparse.scala:46 (product map, filtered)
     const bool st = (bits >> k) & 1u;
     seen = seen || st;
@@ -1319,7 +1390,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, cons
   }
   float s = trail;
   int f = bits != 0u;
-  wave_seg_scan(s, f);
+  if (!(x.dbg & 8)) wave_seg_scan(s, f);
   const float incoming = dpp_get_f<0x138, 0xf>(s);      // wave_shr:1: running sum of the row entering this lane
 
   // rows of the worker's batch, as local rows of this tile (wave-uniform)
@@ -1329,7 +1400,8 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, cons
   const float ps = x.fix_scale, ns = -x.fix_scale;
 
   const int nb = __popc(bits);
-  if (__builtin_amdgcn_ballot_w64(nb > 1) == 0) {
+  if (x.dbg & 1) {
+  } else if (__builtin_amdgcn_ballot_w64(nb > 1) == 0) {
     // common case: at most one row start per lane -> at most one row ENDS in this lane
     const int r_end = rf - (int)(bits & 1u);            // local row that ends at the lane's row start
     const bool fin = nb == 1 && r_end >= r_lo && r_end < r_hi;
@@ -1377,7 +1449,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, cons
     }
   }
 
-  if (SCATTER) {
+  if (SCATTER && !(x.dbg & 2)) {
     if (lane == 0) {
       x.coefw[0] = 0.0f;                          // padding rows carry a zero coefficient
       x.coefw[nrows < 0 ? 1 : nrows + 1] = 0.0f;
@@ -1411,7 +1483,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, cons
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       old[k] = 0;
-      if (q[k] != 0) old[k] = atomicAdd(&x.gl[cc[k]], q[k]);   // ds_add_rtn_u32
+      if (q[k] != 0 && !(x.dbg & 4)) old[k] = atomicAdd(&x.gl[cc[k]], q[k]);   // ds_add_rtn_u32
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) worst = max(worst, abs(old[k] + q[k]));
@@ -1436,10 +1508,11 @@ template <bool SCATTER>
 __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, WTables tt, const float* __restrict__ w,
                                                         long long* g64_base, long long g_stride,
                                                         const StreamSeg* __restrict__ segs, DevScalars* sc, int hw, int hg,
-                                                        float fix_scale, signed char* coef8, int dp) {
+                                                        float fix_scale, signed char* coef8, int dp, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WCtx x;
+  x.dbg = dbg;
   x.coef8 = coef8;
   x.coefw = lds + wave * WS_COEF_STRIDE;                       // 16 strips
   x.gl = reinterpret_cast<int*>(lds + 16 * WS_COEF_STRIDE);    // hg (SCATTER only)
@@ -1460,6 +1533,8 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, WTables tt, 
   __syncthreads();
 
   unsigned int n_all = 0, n_neg = 0, n_pos = 0;
+  // raw buffer over w[0 .. dp): word 3 = 0x00020000 (gfx9 family: 32-bit data, no swizzle)
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, dp * 4, 0x00020000);
   const long long stride = (long long)gridDim.x * 16;          // waves of this worker's grid row
   const long long t_end = seg.tile_end;
   long long tile = seg.tile_begin + (long long)blockIdx.x * 16 + wave;
@@ -1470,8 +1545,8 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, WTables tt, 
     wt = w_fetch(tt, tile + stride, t_end);
     w_issue(m, tt, tile + stride, t_end, lane, wt, B);
     wt = w_fetch(tt, tile + 2 * stride, t_end);
-    w_gather(w, hw, (unsigned int)dp, A);
-#define DSGD_WT(CUR, NXT, FAR) w_tile<SCATTER>(m, tt, w, x, (unsigned int)dp, tile, stride, t_end, CUR, NXT, FAR, wt, n_all, n_neg, n_pos)
+    w_gather(wrs, hw, A);
+#define DSGD_WT(CUR, NXT, FAR) w_tile<SCATTER>(m, tt, wrs, x, (unsigned int)dp, tile, stride, t_end, CUR, NXT, FAR, wt, n_all, n_neg, n_pos)
     for (;;) {
       DSGD_WT(A, B, C); tile += stride; if (tile >= t_end) break;
       DSGD_WT(B, C, A); tile += stride; if (tile >= t_end) break;

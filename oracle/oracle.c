@@ -253,7 +253,14 @@ int orc_gradient_range_omp(const orc_csr* m, const double* w, const double* ds, 
   if (row_end <= row_begin || row_begin < 0 || row_end > m->n_rows) return -1;
   int32_t D = m->dim;
   int nt = orc_num_threads();
-  double* priv = (double*)calloc((size_t)nt * ((size_t)D + 1), sizeof(double));
+  static double* priv = NULL; /* per-thread dense accumulators, kept between calls (bench loop) */
+  static size_t priv_len = 0;
+  size_t need = (size_t)nt * ((size_t)D + 1);
+  if (priv_len < need) {
+    free(priv);
+    priv = (double*)malloc(need * sizeof(double));
+    priv_len = need;
+  }
   int64_t n_active = 0;
 #pragma omp parallel reduction(+ : n_active)
   {
@@ -263,6 +270,7 @@ int orc_gradient_range_omp(const orc_csr* m, const double* w, const double* ds, 
     int tid = 0;
 #endif
     double* g = priv + (size_t)tid * ((size_t)D + 1);
+    memset(g, 0, ((size_t)D + 1) * sizeof(double));
 #pragma omp for schedule(dynamic, 1024)
     for (int64_t i = row_begin; i < row_end; ++i) {
       double d = orc_row_dot(m, i, w);
@@ -271,13 +279,14 @@ int orc_gradient_range_omp(const orc_csr* m, const double* w, const double* ds, 
       n_active++;
       for (int64_t p = m->row_ptr[i]; p < m->row_ptr[i + 1]; ++p) g[m->col[p]] += (double)m->val[p] * y;
     }
+    /* implicit barrier above; every thread reduces a slice of the coordinates over all accumulators */
+#pragma omp for schedule(static)
+    for (int32_t j = 0; j <= D; ++j) {
+      double a = 0.0;
+      for (int t = 0; t < nt; ++t) a += priv[(size_t)t * ((size_t)D + 1) + j];
+      g_out[j] = filt(a);
+    }
   }
-  for (int32_t j = 0; j <= D; ++j) {
-    double a = 0.0;
-    for (int t = 0; t < nt; ++t) a += priv[(size_t)t * ((size_t)D + 1) + j];
-    g_out[j] = filt(a);
-  }
-  free(priv);
   regularize_inplace(g_out, w, ds, lambda, D);
   if (n_active_out) *n_active_out = n_active;
   return 0;

@@ -12,7 +12,7 @@ eng.build_dim_sparsity(n_train)
 lr = 0.5 * 100 / n_train
 for _ in range(8): eng.sync_step_ranges([(0, n_train)], lr)
 w = eng.get_weights()
-for dbg in [0, 1, 2, 3, 4, 7, 8, 15, 16, 31]:
+for dbg in [0, 32, 1]:
     os.environ["DSGD_DBG"] = str(dbg)
     eng.set_weights(w)
     eng.prof_enable(True); eng.prof_read(reset=True)
