@@ -640,9 +640,8 @@ static int finish_stream(dsgd_ctx* c, int n_workers) {
                      c->d_g, (long long)c->dp, c->dp, 1.0 / (double)c->fix_scale);
   HIP_TRY(hipGetLastError());
   if (c->n_cold > 0 && c->cold_nnz > 0) {
-    const int cg = 16;
-    const int blocks = std::max(1, std::min((c->n_cold * cg + 255) / 256, c->n_cu * 8 / n_workers + 1));
-    hipLaunchKernelGGL(dsgd_cold_scatter_kernel<16>, dim3(blocks, n_workers), dim3(256), 0, c->stream, c->d_cold_ptr,
+    const int blocks = std::max(1, std::min((c->n_cold + 3) / 4, c->n_cu * 8 / n_workers + 1));  // 4 waves = 4 columns per block
+    hipLaunchKernelGGL(dsgd_cold_scatter_kernel, dim3(blocks, n_workers), dim3(256), 0, c->stream, c->d_cold_ptr,
                        c->d_cold_row, c->d_cold_val, c->d_coef8, c->n_cold, c->hg_cold(), c->d_g, (long long)c->dp, c->d_ssegs);
     HIP_TRY(hipGetLastError());
   }
@@ -708,24 +707,16 @@ static int launch_wseg(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
       HIP_TRY(hipMemcpy(c->d_wlong_idx, long_idx.data(), sizeof(int) * long_idx.size(), hipMemcpyHostToDevice));
       c->wlong_last = long_idx;
     }
-    if (SCATTER) {
-      DSGD_TRY(upload_segs(c, long_segs));
-      long long mx = 0;
-      for (const auto& s : long_segs) mx = std::max(mx, s.end - s.begin);
-      const size_t lds2 = sizeof(float) * (size_t)(c->hw + c->hg);
-      const int G = 64;  // long rows: a whole wave per row
-      const long long groups_per_block = 1024 / G;
-      long long b2 = std::max<long long>(1, std::min<long long>(c->n_cu / n_workers, (mx + groups_per_block - 1) / groups_per_block));
-      hipLaunchKernelGGL(dsgd_grad_tiled_kernel<64>, dim3((unsigned)b2, n_workers), dim3(1024), lds2, c->stream, m, c->d_w,
-                         c->d_g, (long long)c->dp, c->d_wlong_idx, c->d_segs, c->d_sc, c->hw, c->hg);
-      HIP_TRY(hipGetLastError());
-    } else {
-      const long long n = (long long)long_idx.size();
-      const int blocks = (int)std::max<long long>(1, std::min<long long>((n + 3) / 4, (long long)c->n_cu * 4));
-      hipLaunchKernelGGL(dsgd_eval_idx_kernel<64>, dim3(blocks), dim3(256), 0, c->stream, m, c->d_w, c->d_wlong_idx, n,
-                         c->d_sc);
-      HIP_TRY(hipGetLastError());
-    }
+    DSGD_TRY(upload_segs(c, long_segs));
+    long long mx = 0;
+    for (const auto& s : long_segs) mx = std::max(mx, s.end - s.begin);
+    const long long b2 = std::max<long long>(1, std::min<long long>(c->n_cu / n_workers, (mx + 15) / 16));
+    // same LDS tiles and fixed-point accumulators as the wave-tile kernel (the cold columns of these rows
+    // reach the gradient through coef8 and the cold lists as well)
+    const size_t lds2 = sizeof(float) * (size_t)(hw + hg + 4);
+    hipLaunchKernelGGL(dsgd_wlong_kernel<SCATTER>, dim3((unsigned)b2, n_workers), dim3(1024), lds2, c->stream, m, c->d_w,
+                       c->d_g64, (long long)c->dp, c->d_wlong_idx, c->d_segs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8);
+    HIP_TRY(hipGetLastError());
   }
   return finish_stream<SCATTER>(c, n_workers);
 }
@@ -919,6 +910,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR((dsgd_stream_kernel<8, true, false>));
   DSGD_ATTR((dsgd_stream_kernel<8, false, false>));
   DSGD_ATTR(dsgd_hogwild_kernel);
+  DSGD_ATTR(dsgd_wlong_kernel<true>);
+  DSGD_ATTR(dsgd_wlong_kernel<false>);
   DSGD_ATTR(dsgd_wseg_kernel<true>);
   DSGD_ATTR(dsgd_wseg_kernel<false>);
   DSGD_ATTR(dsgd_seg_kernel<true>);

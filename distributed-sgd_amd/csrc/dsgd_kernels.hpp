@@ -928,9 +928,10 @@ __device__ __forceinline__ unsigned int lower_bound_rows(const int* __restrict__
 }
 
 // g_k[hg + j] = sum over the entries of cold column j whose row lies in worker k's batch of
-// coef[row] * value, in list order (rows ascending): no atomics, reproducible.
+// coef[row] * value, in a fixed order: no atomics, reproducible.
 // ref: core/Slave.scala:147-153 restricted to the cold columns.
-template <int G>
+// One WAVE per column, eight independent 64-entry chunks in flight per iteration (the first version, 16
+// lanes per column and one chunk at a time, was latency-bound at 0.6 TB/s and cost 25 % of a step).
 __global__ void __launch_bounds__(256) dsgd_cold_scatter_kernel(const unsigned int* __restrict__ cold_ptr,
                                                                const int* __restrict__ cold_row,
                                                                const float* __restrict__ cold_val,
@@ -939,18 +940,31 @@ __global__ void __launch_bounds__(256) dsgd_cold_scatter_kernel(const unsigned i
                                                                const StreamSeg* __restrict__ segs) {
   const StreamSeg seg = segs[blockIdx.y];
   float* g = g_base + (long long)blockIdx.y * g_stride;
-  const int sub = threadIdx.x % G;
-  const int group = (blockIdx.x * blockDim.x + threadIdx.x) / G;
-  const int n_groups = gridDim.x * blockDim.x / G;
-  for (int j = group; j < n_cold; j += n_groups) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (int j = wave; j < n_cold; j += n_waves) {
     unsigned int b = cold_ptr[j], e = cold_ptr[j + 1];
     if (b == e) continue;
     if ((long long)cold_row[b] < seg.row_begin) b = lower_bound_rows(cold_row, b, e, seg.row_begin);
     if (b < e && (long long)cold_row[e - 1] >= seg.row_end) e = lower_bound_rows(cold_row, b, e, seg.row_end);
-    float acc = 0.0f;
-    for (unsigned int q = b + sub; q < e; q += G) acc += filt(cold_val[q] * (float)coef8[cold_row[q]]);
-    acc = group_sum<G>(acc);
-    if (sub == 0 && acc != 0.0f) g[hg + j] += acc;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unsigned int q = b + lane;
+    for (; q + 448 < e; q += 512) {   // eight independent 64-entry chunks in flight
+      int r[8];
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        r[k] = cold_row[q + 64 * k];
+        v[k] = cold_val[q + 64 * k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += filt(v[k] * (float)coef8[r[k]]);
+    }
+    for (; q < e; q += 64) a[0] += filt(cold_val[q] * (float)coef8[cold_row[q]]);
+    float acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    acc = group_sum<64>(acc);
+    if (lane == 0 && acc != 0.0f) g[hg + j] += acc;
   }
 }
 
@@ -1768,4 +1782,98 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     __syncthreads();
   }
   if (tid == 0) atomicAdd(&a.st->done_blocks, 1);
+}
+
+// ---- rows longer than a wave tile: one wave per row, four 64-element chunks in flight -------------------------
+// Same LDS tiles, fixed-point accumulation and cold-column convention as dsgd_wseg_kernel (rows of 500+
+// non-zeros are 0.5 % of the RCV1-like rows but 3 % of the non-zeros).
+__device__ __forceinline__ void fix_add_lds(int* gl, long long* g64, DevScalars* sc, int c, int q) {
+  const int old = atomicAdd(&gl[c], q);   // ds_add_rtn_u32
+  const int nw = old + q;
+  if (nw >= WS_SPILL_AT || nw <= -WS_SPILL_AT) {
+    if (old >= WS_PANIC_AT || old <= -WS_PANIC_AT) atomicOr(&sc->err, 2);
+    const int v = atomicExch(&gl[c], 0);
+    if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[c]), (unsigned long long)(long long)v);
+  }
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(1024) dsgd_wlong_kernel(CsrView m, const float* __restrict__ w, long long* g64_base,
+                                                         long long g_stride, const int* __restrict__ idx,
+                                                         const WorkSeg* __restrict__ segs, DevScalars* sc, int hw, int hg,
+                                                         float fix_scale, signed char* coef8) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int* gl = reinterpret_cast<int*>(lds);             // hg (SCATTER only)
+  float* wl = lds + (SCATTER ? hg : 0);              // hw
+  const int tid = threadIdx.x, lane = tid & 63;
+  const WorkSeg seg = segs[blockIdx.y];
+  long long* g64 = g64_base + (long long)blockIdx.y * g_stride;
+  if (SCATTER)
+    for (int j = tid; j < hg; j += 1024) gl[j] = 0;
+  for (int j = tid; j < hw; j += 1024) wl[j] = w[j];
+  __syncthreads();
+  unsigned int n_all = 0, n_neg = 0, n_pos = 0;
+  const long long wave_g = (long long)blockIdx.x * 16 + (tid >> 6), n_waves = (long long)gridDim.x * 16;
+  for (long long t = seg.begin + wave_g; t < seg.end; t += n_waves) {
+    const long long row = idx[t];
+    const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
+    const float y = (float)m.label[row];
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long p = start + lane; p < end; p += 256) {
+      int c[4];
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool in = p + 64 * k < end;
+        c[k] = in ? m.col[p + 64 * k] : 0;
+        v[k] = in ? m.val[p + 64 * k] : 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float wv = c[k] < hw ? wl[c[k]] : w[c[k]];
+        a[k] += filt(v[k] * wv);   // ref: math/Sparse.scala:46
+      }
+    }
+    const float d = group_sum<64>((a[0] + a[1]) + (a[2] + a[3]));
+    const float yd = y * d;
+    if (SCATTER) {
+      const bool active = !(yd < 0.0f);     // ref: core/ml/SparseSVM.scala:27-28
+      if (lane == 0) {
+        coef8[row] = (signed char)(active ? (int)y : 0);
+        n_all += active;
+      }
+      if (active) {
+        const float cs = y * fix_scale;
+        for (long long p = start + lane; p < end; p += 64) {
+          const int c = m.col[p];
+          if (c < hg) {
+            const int q = __float2int_rn(m.val[p] * cs);
+            if (q != 0) fix_add_lds(gl, g64, sc, c, q);
+          }
+        }
+      }
+    } else if (lane == 0) {
+      n_all += 1;
+      n_neg += yd < 0.0f;
+      n_pos += yd > 0.0f;
+    }
+  }
+  if (SCATTER) {
+    __syncthreads();
+    for (int j = tid; j < hg; j += 1024) {
+      const int q = gl[j];
+      if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[j]), (unsigned long long)(long long)q);
+    }
+    n_all = wave_sum_u32(n_all);
+    if (lane == 0 && n_all) atomicAdd(&sc->n_active, (unsigned long long)n_all);
+  } else {
+    n_all = wave_sum_u32(n_all);
+    n_neg = wave_sum_u32(n_neg);
+    n_pos = wave_sum_u32(n_pos);
+    if (lane == 0) {
+      if (n_neg) atomicAdd(&sc->counts[0], (unsigned long long)n_neg);
+      if (n_all - n_neg - n_pos) atomicAdd(&sc->counts[1], (unsigned long long)(n_all - n_neg - n_pos));
+      if (n_pos) atomicAdd(&sc->counts[2], (unsigned long long)n_pos);
+    }
+  }
 }
