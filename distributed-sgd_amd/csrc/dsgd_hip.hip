@@ -172,6 +172,7 @@ struct dsgd_ctx {
   int* d_cold_row = nullptr;
   float* d_cold_val = nullptr;
   signed char* d_coef8 = nullptr;  // n_rows
+  unsigned int* d_coefp = nullptr; // n_rows / 16: 2-bit packing of coef8 for the cold lists
   int n_cold = 0;
   long long cold_nnz = 0;
   const char* last_grad_kernel = "";
@@ -461,6 +462,8 @@ static int build_cold_lists(dsgd_ctx* c) {
   hipFree(c->d_cold_row);
   hipFree(c->d_cold_val);
   hipFree(c->d_coef8);
+  hipFree(c->d_coefp);
+  c->d_coefp = nullptr;
   c->d_cold_ptr = nullptr;
   c->d_cold_row = nullptr;
   c->d_cold_val = nullptr;
@@ -469,6 +472,8 @@ static int build_cold_lists(dsgd_ctx* c) {
   c->cold_nnz = 0;
   HIP_TRY(hipMalloc(&c->d_coef8, (size_t)std::max<long long>(c->n_rows, 1)));
   HIP_TRY(hipMemset(c->d_coef8, 0, (size_t)std::max<long long>(c->n_rows, 1)));
+  HIP_TRY(hipMalloc(&c->d_coefp, sizeof(unsigned int) * (size_t)((c->n_rows + 15) / 16 + 1)));
+  HIP_TRY(hipMemset(c->d_coefp, 0, sizeof(unsigned int) * (size_t)((c->n_rows + 15) / 16 + 1)));
   if (!c->stream_ranges || c->n_cold == 0 || c->nnz == 0) {
     c->n_cold = 0;
     return DSGD_OK;
@@ -640,9 +645,13 @@ static int finish_stream(dsgd_ctx* c, int n_workers) {
                      c->d_g, (long long)c->dp, c->dp, 1.0 / (double)c->fix_scale);
   HIP_TRY(hipGetLastError());
   if (c->n_cold > 0 && c->cold_nnz > 0) {
+    const long long n_words = (c->n_rows + 15) / 16;
+    hipLaunchKernelGGL(dsgd_pack_coef_kernel, dim3((unsigned)std::min<long long>((n_words + 255) / 256, (long long)c->n_cu * 8)),
+                       dim3(256), 0, c->stream, c->d_coef8, c->d_coefp, c->n_rows);
+    HIP_TRY(hipGetLastError());
     const int blocks = std::max(1, std::min((c->n_cold + 3) / 4, c->n_cu * 8 / n_workers + 1));  // 4 waves = 4 columns per block
     hipLaunchKernelGGL(dsgd_cold_scatter_kernel, dim3(blocks, n_workers), dim3(256), 0, c->stream, c->d_cold_ptr,
-                       c->d_cold_row, c->d_cold_val, c->d_coef8, c->n_cold, c->hg_cold(), c->d_g, (long long)c->dp, c->d_ssegs);
+                       c->d_cold_row, c->d_cold_val, c->d_coefp, c->n_cold, c->hg_cold(), c->d_g, (long long)c->dp, c->d_ssegs);
     HIP_TRY(hipGetLastError());
   }
   return DSGD_OK;
@@ -957,6 +966,7 @@ int dsgd_destroy(dsgd_ctx* c) {
   hipFree(c->d_cold_row);
   hipFree(c->d_cold_val);
   hipFree(c->d_coef8);
+  hipFree(c->d_coefp);
   hipFree(c->d_tile_meta);
   hipFree(c->d_wtiles);
   hipFree(c->d_wmeta);

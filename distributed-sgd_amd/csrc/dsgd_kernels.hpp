@@ -932,10 +932,32 @@ __device__ __forceinline__ unsigned int lower_bound_rows(const int* __restrict__
 // ref: core/Slave.scala:147-153 restricted to the cold columns.
 // One WAVE per column, eight independent 64-entry chunks in flight per iteration (the first version, 16
 // lanes per column and one chunk at a time, was latency-bound at 0.6 TB/s and cost 25 % of a step).
+// The per-row coefficients are read through a 2-bit packing (16 rows per word, 2.1 MB for 8.4 M rows): the
+// byte array (one 64-byte line fetched per random 1-byte read, 6.7 MB > one XCD's 4 MiB L2) made this
+// kernel line-traffic bound.
+__global__ void dsgd_pack_coef_kernel(const signed char* __restrict__ coef8, unsigned int* __restrict__ packed,
+                                      long long n_rows) {
+  const long long n_words = (n_rows + 15) / 16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (long long)gridDim.x * blockDim.x) {
+    unsigned int word = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const long long r = i * 16 + k;
+      const int cf = r < n_rows ? (int)coef8[r] : 0;
+      word |= ((unsigned int)cf & 3u) << (2 * k);   // 0 -> 0, +1 -> 1, -1 -> 3
+    }
+    packed[i] = word;
+  }
+}
+__device__ __forceinline__ float coef_unpack(const unsigned int* __restrict__ packed, int r) {
+  const unsigned int code = (packed[r >> 4] >> ((r & 15) * 2)) & 3u;
+  return code == 1u ? 1.0f : (code == 3u ? -1.0f : 0.0f);
+}
+
 __global__ void __launch_bounds__(256) dsgd_cold_scatter_kernel(const unsigned int* __restrict__ cold_ptr,
                                                                const int* __restrict__ cold_row,
                                                                const float* __restrict__ cold_val,
-                                                               const signed char* __restrict__ coef8, int n_cold, int hg,
+                                                               const unsigned int* __restrict__ coefp, int n_cold, int hg,
                                                                float* g_base, long long g_stride,
                                                                const StreamSeg* __restrict__ segs) {
   const StreamSeg seg = segs[blockIdx.y];
@@ -959,9 +981,9 @@ __global__ void __launch_bounds__(256) dsgd_cold_scatter_kernel(const unsigned i
         v[k] = cold_val[q + 64 * k];
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) a[k] += filt(v[k] * (float)coef8[r[k]]);
+      for (int k = 0; k < 8; ++k) a[k] += filt(v[k] * coef_unpack(coefp, r[k]));
     }
-    for (; q < e; q += 64) a[0] += filt(cold_val[q] * (float)coef8[cold_row[q]]);
+    for (; q < e; q += 64) a[0] += filt(cold_val[q] * coef_unpack(coefp, cold_row[q]));
     float acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     acc = group_sum<64>(acc);
     if (lane == 0 && acc != 0.0f) g[hg + j] += acc;
