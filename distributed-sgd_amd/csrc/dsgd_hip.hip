@@ -161,7 +161,10 @@ struct dsgd_ctx {
   int* d_wlong_idx = nullptr;           // staging of the long rows of the current call
   long long wlong_cap = 0;
   std::vector<int> wlong_last;
-  int hw_w = 12288, hg_w = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 12288 - 4;  // LDS tiles of the wseg gradient kernel
+  // LDS tiles of the wseg gradient kernel.  Cost model from tools/microbench4.hip and the profiles: a cold weight
+  // costs ~3 clk of a CU's texture path per distinct cache line, a cold gradient entry ~8 B of list traffic;
+  // 16384 / 20476 balances the two for RCV1-like column statistics.
+  int hw_w = 16384, hg_w = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 16384 - 4;
   int hw_we = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4;                     // ... of the wseg evaluation kernel
   unsigned short* d_tile_meta = nullptr;  // n_tiles x 1024 lane descriptors of the seg kernels
   int hw_g = 6144, hg_g = DSGD_LDS_FLOATS - SG_LDS_FIXED - 6144 - 2;  // LDS tiles of the seg gradient kernel

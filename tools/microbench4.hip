@@ -10,12 +10,12 @@ constexpr int DP = 47237;
 template <int MODE>
 __global__ void __launch_bounds__(1024) k(const float* __restrict__ w, const int* __restrict__ idx, float* out, int iters) {
   const int lane = threadIdx.x & 63;
-  const int* my = idx + ((blockIdx.x * 1024 + threadIdx.x) & 0xFFFFF);
+  const unsigned base = (blockIdx.x * 1024 + threadIdx.x);
   float acc = 0.f;
   for (int i = 0; i < iters; ++i) {
     int c[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) c[j] = my[(i * 8 + j) * 4099 & 0xFFFFF];
+    for (int j = 0; j < 8; ++j) c[j] = idx[(base + (unsigned)(i * 8 + j) * 4099u) & 0xFFFFFu];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (MODE == 0) acc += w[c[j]];
