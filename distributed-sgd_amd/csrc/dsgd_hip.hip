@@ -157,14 +157,18 @@ struct dsgd_ctx {
   unsigned int* d_wmeta = nullptr;
   long long n_wtiles = 0;
   std::vector<int> h_wtile_r0;          // first row of every wave tile (+ sentinel n_rows)
-  std::vector<long long> wlong_rows;    // rows with more than WS_MAXNNZ non-zeros: row-per-group kernels
-  int* d_wlong_idx = nullptr;           // staging of the long rows of the current call
-  long long wlong_cap = 0;
-  std::vector<int> wlong_last;
+  std::vector<long long> wlong_rows;    // rows with more than WS_MAXNNZ non-zeros (sorted): one wave per row
+  int* d_wlong_rows = nullptr;          // the same list on the device
+  int* d_part = nullptr;                // per-workgroup partial sums of the wseg gradient kernel: part_wgs x part_stride
+  long long part_wgs = 0;
+  int part_stride = 0;
+  bool use_part = true;                 // DSGD_EPI=0: 64-bit atomics into g64 instead
+  int pf_depth = 4;                     // DSGD_PF=3|4: tiles in flight per wave (register sets of the wseg kernels)
+  int dbg = 0;                          // DSGD_DBG: ablation switches of the streaming kernels (tuning runs only)
   // LDS tiles of the wseg gradient kernel.  Cost model from tools/microbench4.hip and the profiles: a cold weight
   // costs ~3 clk of a CU's texture path per distinct cache line, a cold gradient entry ~8 B of list traffic;
   // 16384 / 20476 balances the two for RCV1-like column statistics.
-  int hw_w = 16384, hg_w = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 16384 - 4;
+  int hw_w = 16384, hg_w = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 16384 - 4 - 64;
   int hw_we = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4;                     // ... of the wseg evaluation kernel
   unsigned short* d_tile_meta = nullptr;  // n_tiles x 1024 lane descriptors of the seg kernels
   int hw_g = 6144, hg_g = DSGD_LDS_FLOATS - SG_LDS_FIXED - 6144 - 2;  // LDS tiles of the seg gradient kernel
@@ -633,7 +637,7 @@ static int upload_ssegs(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
 }
 static StreamSeg make_sseg(dsgd_ctx* c, long long rb, long long re) {
   const std::vector<int>& tr = c->h_tile_row;
-  StreamSeg s;
+  StreamSeg s{};
   s.row_begin = rb;
   s.row_end = re;
   s.tile_begin = (std::upper_bound(tr.begin(), tr.end(), (int)rb) - tr.begin()) - 1;  // tile containing rb
@@ -642,10 +646,15 @@ static StreamSeg make_sseg(dsgd_ctx* c, long long rb, long long re) {
 }
 // after a streaming gradient kernel: fixed point -> fp32, then the cold columns from their transposed lists
 template <bool SCATTER>
-static int finish_stream(dsgd_ctx* c, int n_workers) {
+static int finish_stream(dsgd_ctx* c, int n_workers, int part_wg_per_worker = 0, int part_hg = 0) {
   if (!SCATTER) return DSGD_OK;
-  hipLaunchKernelGGL(dsgd_fix_finalize_kernel, dim3((c->dp + 1023) / 1024, n_workers), dim3(1024), 0, c->stream, c->d_g64,
-                     c->d_g, (long long)c->dp, c->dp, 1.0 / (double)c->fix_scale);
+  if (part_wg_per_worker > 0)
+    hipLaunchKernelGGL(dsgd_fix_reduce_kernel, dim3((c->dp + 63) / 64, n_workers), dim3(1024), 0, c->stream, c->d_g64, c->d_g,
+                       (long long)c->dp, c->dp, part_hg, c->d_part, c->part_stride, part_wg_per_worker,
+                       1.0 / (double)c->fix_scale);
+  else
+    hipLaunchKernelGGL(dsgd_fix_finalize_kernel, dim3((c->dp + 1023) / 1024, n_workers), dim3(1024), 0, c->stream, c->d_g64,
+                       c->d_g, (long long)c->dp, c->dp, 1.0 / (double)c->fix_scale);
   HIP_TRY(hipGetLastError());
   if (c->n_cold > 0 && c->cold_nnz > 0) {
     const long long n_words = (c->n_rows + 15) / 16;
@@ -666,9 +675,7 @@ static int launch_wseg(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   const int n_workers = (int)row_segs.size();
   std::vector<StreamSeg> segs(row_segs);
   const std::vector<int>& wr0 = c->h_wtile_r0;  // n_wtiles + 1 entries (sentinel n_rows)
-  long long max_tiles = 1;
-  std::vector<int> long_idx;
-  std::vector<WorkSeg> long_segs(n_workers);
+  long long max_tiles = 1, max_long = 0;
   for (int k = 0; k < n_workers; ++k) {
     StreamSeg& s = segs[k];
     // first tile whose rows reach row_begin: the last tile with r0 <= row_begin (it may end before row_begin when a
@@ -680,57 +687,46 @@ static int launch_wseg(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
     s.tile_begin = tb;
     s.tile_end = te;
     max_tiles = std::max(max_tiles, te - tb);
-    long_segs[k].begin = (long long)long_idx.size();
-    auto lo = std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), s.row_begin);
-    auto hi = std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), s.row_end);
-    for (auto it = lo; it != hi; ++it) long_idx.push_back((int)*it);
-    long_segs[k].end = (long long)long_idx.size();
+    // the rows that fit no tile: a range of the sorted long-row list, handled by the same kernel (one wave per row)
+    s.long_begin = std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), s.row_begin) - c->wlong_rows.begin();
+    s.long_end = std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), s.row_end) - c->wlong_rows.begin();
+    max_long = std::max(max_long, s.long_end - s.long_begin);
   }
   DSGD_TRY(upload_ssegs(c, segs));
   long long bx = std::max<long long>(1, c->n_cu / n_workers);
-  bx = std::min(bx, (max_tiles + 15) / 16);
+  bx = std::min(bx, std::max((max_tiles + 15) / 16, (max_long + 15) / 16));
   dim3 grid((unsigned)std::max<long long>(1, bx), n_workers);
   const int hw = SCATTER ? c->hw_w : c->hw_we;
   const int hg = SCATTER ? c->hg_w : 0;
-  const size_t lds = sizeof(float) * (size_t)(16 * WS_COEF_STRIDE + hw + hg + 4);
+  const size_t lds = sizeof(float) * (size_t)(16 * WS_COEF_STRIDE + hw + hg + (SCATTER ? 64 : 0) + 4);
+  const bool part = SCATTER && c->use_part;
+  if (part && ((long long)grid.x * grid.y > c->part_wgs || hg > c->part_stride)) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipFree(c->d_part);
+    c->d_part = nullptr;
+    c->part_wgs = std::max<long long>((long long)grid.x * grid.y, c->n_cu);
+    c->part_stride = (hg + 63) / 64 * 64;
+    HIP_TRY(hipMalloc(&c->d_part, sizeof(int) * (size_t)c->part_wgs * (size_t)c->part_stride));
+  }
   CsrView m = view(c);
   WTables wt;
   wt.tiles = c->d_wtiles;
   wt.meta = c->d_wmeta;
   size_t slot = 0;
   if (SCATTER) DSGD_TRY(prof_begin(c, &slot));
-  hipLaunchKernelGGL(dsgd_wseg_kernel<SCATTER>, grid, dim3(1024), lds, c->stream, m, wt, c->d_w, c->d_g64, (long long)c->dp,
-                     c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8, c->dp,
-                     getenv("DSGD_DBG") ? atoi(getenv("DSGD_DBG")) : 0);
+#define DSGD_LAUNCH_WSEG(ABL, DEPTH)                                                                                   \
+  hipLaunchKernelGGL((dsgd_wseg_kernel<SCATTER, ABL, DEPTH>), grid, dim3(1024), lds, c->stream, m, wt.tiles, wt.meta,    \
+                     c->d_w, c->d_g64,                                                                                \
+                     (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8, c->dp, c->dbg,            \
+                     c->d_wlong_rows, part ? c->d_part : nullptr, c->part_stride)
+  if (c->dbg) DSGD_LAUNCH_WSEG(true, 3);   // ablation build of the same kernel (DSGD_DBG, tuning runs only)
+  else if (c->pf_depth == 4) DSGD_LAUNCH_WSEG(false, 4);
+  else DSGD_LAUNCH_WSEG(false, 3);
+#undef DSGD_LAUNCH_WSEG
   HIP_TRY(hipGetLastError());
   if (SCATTER) DSGD_TRY(prof_end(c, slot));
-  if (SCATTER) c->last_grad_kernel = "dsgd_wseg_kernel<true>";
-  if (!long_idx.empty()) {
-    // the few rows longer than a wave tile: row-per-group kernels on an explicit list
-    if ((long long)long_idx.size() > c->wlong_cap) {
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      hipFree(c->d_wlong_idx);
-      c->d_wlong_idx = nullptr;
-      c->wlong_cap = std::max<long long>((long long)long_idx.size(), 2 * c->wlong_cap);
-      HIP_TRY(hipMalloc(&c->d_wlong_idx, sizeof(int) * (size_t)c->wlong_cap));
-    }
-    if (c->wlong_last != long_idx) {
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      HIP_TRY(hipMemcpy(c->d_wlong_idx, long_idx.data(), sizeof(int) * long_idx.size(), hipMemcpyHostToDevice));
-      c->wlong_last = long_idx;
-    }
-    DSGD_TRY(upload_segs(c, long_segs));
-    long long mx = 0;
-    for (const auto& s : long_segs) mx = std::max(mx, s.end - s.begin);
-    const long long b2 = std::max<long long>(1, std::min<long long>(c->n_cu / n_workers, (mx + 15) / 16));
-    // same LDS tiles and fixed-point accumulators as the wave-tile kernel (the cold columns of these rows
-    // reach the gradient through coef8 and the cold lists as well)
-    const size_t lds2 = sizeof(float) * (size_t)(hw + hg + 4);
-    hipLaunchKernelGGL(dsgd_wlong_kernel<SCATTER>, dim3((unsigned)b2, n_workers), dim3(1024), lds2, c->stream, m, c->d_w,
-                       c->d_g64, (long long)c->dp, c->d_wlong_idx, c->d_segs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8);
-    HIP_TRY(hipGetLastError());
-  }
-  return finish_stream<SCATTER>(c, n_workers);
+  if (SCATTER) c->last_grad_kernel = c->dbg ? "dsgd_wseg_kernel<true, true, 3>" : (c->pf_depth == 4 ? "dsgd_wseg_kernel<true, false, 4>" : "dsgd_wseg_kernel<true, false, 3>");
+  return finish_stream<SCATTER>(c, n_workers, part ? (int)grid.x : 0, hg);
 }
 
 template <bool SCATTER>
@@ -755,8 +751,7 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
     size_t slot = 0;
     if (SCATTER) DSGD_TRY(prof_begin(c, &slot));
     hipLaunchKernelGGL(dsgd_seg_kernel<SCATTER>, grid, dim3(ST_THREADS), lds, c->stream, m, st, c->d_w, c->d_g64,
-                       (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8,
-                       getenv("DSGD_DBG") ? atoi(getenv("DSGD_DBG")) : 0);
+                       (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8, c->dbg);
     HIP_TRY(hipGetLastError());
     if (SCATTER) DSGD_TRY(prof_end(c, slot));
     if (SCATTER) c->last_grad_kernel = "dsgd_seg_kernel<true>";
@@ -882,6 +877,9 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
     c->stream_ranges = atoi(e) != 0;
     if (atoi(e) >= 1 && atoi(e) <= 3) c->stream_mode = atoi(e);
   }
+  if (const char* e = getenv("DSGD_EPI")) c->use_part = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_DBG")) c->dbg = atoi(e);
+  if (const char* e = getenv("DSGD_PF")) c->pf_depth = atoi(e) == 3 ? 3 : 4;
   if (const char* e = getenv("DSGD_HW_G")) c->hw_g = atoi(e);
   if (const char* e = getenv("DSGD_HG_G")) c->hg_g = atoi(e);
   if (const char* e = getenv("DSGD_HW_W")) c->hw_w = atoi(e);
@@ -889,8 +887,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   c->hw_w = std::max(0, std::min(c->hw_w, c->dp));
   c->hg_w = std::max(0, std::min(c->hg_w, c->dp));
   c->hw_we = std::min(c->hw_we, c->dp);
-  if (c->hw_w + c->hg_w > DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4)
-    return bail(fail(DSGD_EINVAL, "DSGD_HW_W + DSGD_HG_W exceed %d floats of LDS", DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4));
+  if (c->hw_w + c->hg_w > DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64)
+    return bail(fail(DSGD_EINVAL, "DSGD_HW_W + DSGD_HG_W exceed %d floats of LDS", DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64));
   c->hw_g = std::max(0, std::min(c->hw_g, c->dp));
   c->hg_g = std::max(0, std::min(c->hg_g, c->dp));
   c->hw_ge = std::min(c->hw_ge, c->dp);
@@ -922,10 +920,12 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR((dsgd_stream_kernel<8, true, false>));
   DSGD_ATTR((dsgd_stream_kernel<8, false, false>));
   DSGD_ATTR(dsgd_hogwild_kernel);
-  DSGD_ATTR(dsgd_wlong_kernel<true>);
-  DSGD_ATTR(dsgd_wlong_kernel<false>);
-  DSGD_ATTR(dsgd_wseg_kernel<true>);
-  DSGD_ATTR(dsgd_wseg_kernel<false>);
+  DSGD_ATTR((dsgd_wseg_kernel<true, false, 3>));
+  DSGD_ATTR((dsgd_wseg_kernel<true, false, 4>));
+  DSGD_ATTR((dsgd_wseg_kernel<true, true, 3>));
+  DSGD_ATTR((dsgd_wseg_kernel<false, false, 3>));
+  DSGD_ATTR((dsgd_wseg_kernel<false, false, 4>));
+  DSGD_ATTR((dsgd_wseg_kernel<false, true, 3>));
   DSGD_ATTR(dsgd_seg_kernel<true>);
   DSGD_ATTR(dsgd_seg_kernel<false>);
 #undef DSGD_ATTR
@@ -973,7 +973,8 @@ int dsgd_destroy(dsgd_ctx* c) {
   hipFree(c->d_tile_meta);
   hipFree(c->d_wtiles);
   hipFree(c->d_wmeta);
-  hipFree(c->d_wlong_idx);
+  hipFree(c->d_wlong_rows);
+  hipFree(c->d_part);
   if (c->async_stream) {
     if (c->h_stop) *c->h_stop = 1;
     hipStreamSynchronize(c->async_stream);
@@ -1253,6 +1254,12 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr_in, const 
       HIP_TRY(hipMalloc(&c->d_wmeta, sizeof(unsigned int) * wm.size()));
       HIP_TRY(hipMemcpy(c->d_wtiles, wt.data(), sizeof(WTile) * wt.size(), hipMemcpyHostToDevice));
       HIP_TRY(hipMemcpy(c->d_wmeta, wm.data(), sizeof(unsigned int) * wm.size(), hipMemcpyHostToDevice));
+      hipFree(c->d_wlong_rows);
+      c->d_wlong_rows = nullptr;
+      std::vector<int> lr(c->wlong_rows.begin(), c->wlong_rows.end());
+      lr.push_back(0);
+      HIP_TRY(hipMalloc(&c->d_wlong_rows, sizeof(int) * lr.size()));
+      HIP_TRY(hipMemcpy(c->d_wlong_rows, lr.data(), sizeof(int) * lr.size(), hipMemcpyHostToDevice));
     }
     hipFree(c->d_tile_row);
     hipFree(c->d_tile_pos);

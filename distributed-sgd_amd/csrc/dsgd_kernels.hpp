@@ -591,6 +591,7 @@ constexpr int FIX_SPILL_AT = 1 << 29;
 struct StreamSeg {
   long long row_begin, row_end;    // rows of this worker's batch
   long long tile_begin, tile_end;  // tiles intersecting [row_begin, row_end)
+  long long long_begin, long_end;  // wave-tile mode: range of the long-row list (rows that fit no tile)
 };
 
 // tile tables built at load time (dsgd_hip.hip: build_tiles)
@@ -893,6 +894,33 @@ __global__ void __launch_bounds__(1024) dsgd_fix_finalize_kernel(long long* g64_
       g[j] += (float)((double)q * inv_scale);
       g64[j] = 0;
     }
+  }
+}
+
+// the same with per-workgroup partial sums (dsgd_wseg_kernel with `part`): worker k owns workgroups
+// [k * n_wg, (k + 1) * n_wg); g[j] += (float)((g64[j] + sum_wg part[wg][j]) * inv_scale) for j < hg, and the plain
+// conversion of g64 for hg <= j < dp.  Block = 64 columns x 16 workgroup phases.
+__global__ void __launch_bounds__(1024) dsgd_fix_reduce_kernel(long long* g64_base, float* g_base, long long g_stride,
+                                                              int dp, int hg, const int* __restrict__ part,
+                                                              int part_stride, int n_wg, double inv_scale) {
+  __shared__ long long red[16][64];
+  long long* g64 = g64_base + (long long)blockIdx.y * g_stride;
+  float* g = g_base + (long long)blockIdx.y * g_stride;
+  const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cx;
+  long long q = 0;
+  if (j < hg) {
+    const int* p = part + (long long)blockIdx.y * n_wg * part_stride + j;
+    for (int b = ph; b < n_wg; b += 16) q += (long long)p[(long long)b * part_stride];
+  }
+  red[ph][cx] = q;
+  __syncthreads();
+  if (ph == 0 && j < dp) {
+    long long tot = g64[j];
+    if (tot != 0) g64[j] = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += red[k][cx];
+    if (tot != 0) g[j] += (float)((double)tot * inv_scale);
   }
 }
 
@@ -1336,29 +1364,39 @@ struct WRegs {
   float4 v0, v1;
   float gw[8];
   unsigned int meta;
-  int r0, nrows;
+  long long pos0, tc;  // wave-uniform (scalar registers): window start, clamped tile index
+  int r0, nrows;       // wave-uniform
 };
 
-// the tile record of tile t (clamped), fetched one iteration before w_issue needs it: a scalar load whose
-// result feeds the address computation would otherwise expose the scalar-cache latency once per tile
+// the tile record of tile t (clamped), fetched one iteration before w_issue_cols needs it: a load whose
+// result feeds the address computation would otherwise expose its latency once per tile
+// (a scalar s_load -- counted by lgkmcnt, not queued behind the stream loads in vmcnt -- as long as the kernel
+// passes the table as a __restrict__ parameter of its own)
 __device__ __forceinline__ WTile w_fetch(const WTables& tt, long long t, long long t_end) {
   return tt.tiles[t < t_end ? t : t_end - 1];
 }
 
-__device__ __forceinline__ void w_issue(const CsrView& m, const WTables& tt, long long t, long long t_end, int lane,
-                                        const WTile& wt, WRegs& r) {
+// the two halves of a tile's stream: column ids first (the cold-weight gathers of the tile wait for them), values
+// and lane descriptors one iteration later when DEPTH = 4 (they are not needed before the tile is processed) --
+// this keeps four column sets but only three value sets live
+__device__ __forceinline__ void w_issue_cols(const CsrView& m, long long t, long long t_end, int lane, const WTile& wt,
+                                             WRegs& r) {
   const bool live = t < t_end;
-  const long long tc = live ? t : t_end - 1;     // wave-uniform
+  r.tc = live ? t : t_end - 1;     // wave-uniform
   r.r0 = wt.r0;
   r.nrows = live ? wt.nrows : -1;
+  r.pos0 = wt.pos0;
   const int4* cp = reinterpret_cast<const int4*>(m.col + wt.pos0);
-  const float4* vp = reinterpret_cast<const float4*>(m.val + wt.pos0);
   const unsigned int o = 2u * (unsigned int)lane;
   r.c0 = cp[o];
   r.c1 = cp[o + 1];
+}
+__device__ __forceinline__ void w_issue_vals(const CsrView& m, const WTables& tt, int lane, WRegs& r) {
+  const float4* vp = reinterpret_cast<const float4*>(m.val + r.pos0);
+  const unsigned int o = 2u * (unsigned int)lane;
   r.v0 = vp[o];
   r.v1 = vp[o + 1];
-  r.meta = (tt.meta + tc * 64)[(unsigned int)lane];
+  r.meta = (tt.meta + r.tc * 64)[(unsigned int)lane];
 }
 
 // cold-weight gathers of a tile whose column ids have landed.  Buffer loads: a hot lane gets an offset
@@ -1390,16 +1428,58 @@ struct WCtx {
   int dbg;  // ablation switches for tuning runs (0 in production)
 };
 
-template <bool SCATTER>
+// fixed-point scatter of a lane's eight contributions into the LDS gradient tile.  Every lane issues all eight
+// ds_add_rtn_u32 unconditionally (no exec-mask branches, one wait for the eight returns): a slot with nothing
+// to add (q == 0: cold column, inactive row, padding) targets the lane's private always-zero word gl[hg + lane].
+// Overflow control without a quiet point: whoever SEES an entry at |old| >= 2^28 swaps it out into the 64-bit
+// global accumulator; an entry seen at |old| >= 2^30 raises the error bit (a contribution is <= 2^21 and at most
+// 16 waves x 8 adds are in flight, so a wrap would have to pass through that band unseen).
+template <bool ABL>
+__device__ __forceinline__ void w_scatter(const WCtx& x, const int (&cc)[8], const int (&q)[8], int lane, int dbg) {
+  int old[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int slot = q[k] != 0 ? cc[k] : x.hg + lane;
+    old[k] = (ABL && (dbg & 4)) ? 0 : atomicAdd(&x.gl[slot], q[k]);   // ds_add_rtn_u32
+  }
+  int hi = max(max(old[0], old[1]), old[2]), lo = min(min(old[0], old[1]), old[2]);   // v_max3 / v_min3
+  hi = max(max(hi, old[3]), old[4]);
+  lo = min(min(lo, old[3]), old[4]);
+  hi = max(max(hi, old[5]), old[6]);
+  lo = min(min(lo, old[5]), old[6]);
+  hi = max(hi, old[7]);
+  lo = min(lo, old[7]);
+  if (hi >= WS_SPILL_AT || lo <= -WS_SPILL_AT) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (old[k] >= WS_SPILL_AT || old[k] <= -WS_SPILL_AT) {
+        if (old[k] >= WS_PANIC_AT || old[k] <= -WS_PANIC_AT) atomicOr(&x.sc->err, 2);
+        const int v = atomicExch(&x.gl[cc[k]], 0);
+        if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[cc[k]]), (unsigned long long)(long long)v);
+      }
+    }
+  }
+}
+
+// One tile of one wave.  `cur` = tile t (everything landed), `nxt` = tile t+1 (column ids landed: its cold weights
+// are gathered now), `far` = the register set that receives the column ids of tile t+DEPTH-1; with DEPTH = 4
+// `mid` = tile t+2, whose column ids are in flight and whose values are requested now.  The stream loads are issued FIRST so that they are already on their way while the
+// wave waits (counted vmcnt) for the column ids of t+1.
+template <bool SCATTER, bool ABL, int DEPTH>
 __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __amdgpu_buffer_rsrc_t wrs, const WCtx& x,
                                        unsigned int dp, long long tile, long long stride, long long t_end, WRegs& cur,
-                                       WRegs& nxt, WRegs& far, WTile& wt_far, unsigned int& n_all,
+                                       WRegs& nxt, WRegs& mid, WRegs& far, WTile& wt_far, unsigned int& n_all,
                                        unsigned int& n_neg, unsigned int& n_pos) {
   const int lane = threadIdx.x & 63;
-  if (x.dbg & 32) w_gather_off(nxt);
-  else w_gather(wrs, x.hw, nxt);                               // tile t+1 (its col ids landed)
-  w_issue(m, tt, tile + 2 * stride, t_end, lane, wt_far, far);  // tile t+2 (record fetched last iteration)
-  wt_far = w_fetch(tt, tile + 3 * stride, t_end);               // record of tile t+3, used next iteration
+  const int dbg = ABL ? x.dbg : 0;   // ablation switches exist only in the ABL instantiation (tuning runs)
+  // the record load goes out BEFORE this iteration's stream loads: vmcnt retires in order, so next iteration's
+  // wait for it does not drain the stream loads issued behind it
+  const WTile wt_now = wt_far;                                              // record fetched last iteration
+  wt_far = w_fetch(tt, tile + DEPTH * stride, t_end);                       // record used next iteration
+  w_issue_cols(m, tile + (DEPTH - 1) * stride, t_end, lane, wt_now, far);
+  w_issue_vals(m, tt, lane, DEPTH == 4 ? mid : far);                        // tile t+2
+  if (dbg & 32) w_gather_off(nxt);
+  else w_gather(wrs, x.hw, nxt);                                           // tile t+1
 
   const int nrows = cur.nrows;                          // wave-uniform; -1: the whole tile is padding
   const unsigned int desc = nrows < 0 ? 0u : cur.meta;
@@ -1408,102 +1488,130 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
   const unsigned int ys = (desc >> 16) & 255u;
   const int cc[8] = {cur.c0.x, cur.c0.y, cur.c0.z, cur.c0.w, cur.c1.x, cur.c1.y, cur.c1.z, cur.c1.w};
   const float vv[8] = {cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w};
-  typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
-  // products and the lane's two open fragments: `head` (slots before its first row start, continues the row
-  // entering the lane) and `trail` (slots from its last row start on, continues into the next lane)
-  float pk[8];
-  float head = 0.0f, trail = 0.0f;
-  bool seen = false;
+  typedef __attribute__((address_space(3))) const float lds_cfloat;
+  lds_cfloat* wl3 = (lds_cfloat*)x.wl;
+  // hot weights: eight LDS reads back to back (cold columns read the zero slot wl[hw]); products filtered as
+  // the reference's product map is.  ref: math/Sparse.scala:46
+  float a[8], pk[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float a = (x.dbg & 16) ? 0.5f : ((lds_cvfloat*)x.wl)[min(cc[k], x.hw)];
-    pk[k] = filt(vv[k] * (a + cur.gw[k]));   // ref: math/Sparse.scala:46 (product map, filtered)
-    const bool st = (bits >> k) & 1u;
-    seen = seen || st;
-    trail = st ? 0.0f : trail;
-    trail += pk[k];
-    head += seen ? 0.0f : pk[k];
-  }
-  float s = trail;
-  int f = bits != 0u;
-  if (!(x.dbg & 8)) wave_seg_scan(s, f);
-  const float incoming = dpp_get_f<0x138, 0xf>(s);      // wave_shr:1: running sum of the row entering this lane
+  for (int k = 0; k < 8; ++k) a[k] = (dbg & 16) ? 0.5f : wl3[min(cc[k], x.hw)];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pk[k] = filt(vv[k] * (a[k] + cur.gw[k]));
 
-  // rows of the worker's batch, as local rows of this tile (wave-uniform)
+  // rows of the worker's batch, as local rows of this tile (wave-uniform, scalar registers)
   const long long lo64 = x.row_begin - cur.r0 + 1, hi64 = x.row_end - cur.r0 + 1;
   const int r_lo = (int)(lo64 < 1 ? 1 : (lo64 > 1024 ? 1024 : lo64));
   const int r_hi = (int)(hi64 > nrows + 1 ? nrows + 1 : (hi64 < 0 ? 0 : hi64));   // exclusive
   const float ps = x.fix_scale, ns = -x.fix_scale;
+  signed char* const coef8_tile = x.coef8 + ((long long)cur.r0 - 1);   // [local row] -> global row's gate
 
   const int nb = __popc(bits);
-  if (x.dbg & 1) {
-  } else if (__builtin_amdgcn_ballot_w64(nb > 1) == 0) {
-    // common case: at most one row start per lane -> at most one row ENDS in this lane
-    const int r_end = rf - (int)(bits & 1u);            // local row that ends at the lane's row start
-    const bool fin = nb == 1 && r_end >= r_lo && r_end < r_hi;
-    const float d = incoming + head;                     // x . w of that row
-    const bool ypos = (ys & bits) != 0u;
-    const float yd = ypos ? d : -d;
-    if (SCATTER) {
-      const bool active = fin && !(yd < 0.0f);           // ref: core/ml/SparseSVM.scala:27-28
-      if (nb == 1 && r_end >= 1 && r_end <= nrows) {
-        x.coefw[r_end] = active ? (ypos ? ps : ns) : 0.0f;
-        if (fin) x.coef8[(long long)cur.r0 + r_end - 1] = (signed char)(active ? (ypos ? 1 : -1) : 0);
-      }
-      n_all += active;
-    } else {
-      n_all += fin;                                       // ref: core/ml/SparseSVM.scala:14,16
-      n_neg += fin && (yd < 0.0f);
-      n_pos += fin && (yd > 0.0f);
-    }
-  } else {
-    // general case (a lane holds two or more row starts: rows shorter than 8 non-zeros)
-    float run = incoming;
-    int r = rf - (int)(bits & 1u);
+  int q[8];
+  if (__builtin_amdgcn_ballot_w64(nb > 1) == 0) {
+    // ---- common case: at most one row start per lane -> at most one row ENDS in this lane ----
+    // T = slots from the lane's row start on (all eight when no row starts here): they continue into the next
+    // lane (`trail`); the slots before the start close the row entering the lane (`head`)
+    const unsigned int low = bits & (0u - bits);
+    const unsigned int T = bits ? (0xffu & ~(low - 1u)) : 0xffu;
+    bool in_t[8];
+    float head = 0.0f, trail = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      if ((bits >> k) & 1u) {
-        if (r >= 1 && r <= nrows) {
-          const bool in_range = r >= r_lo && r < r_hi;
-          const bool ypos = (ys >> k) & 1u;
-          const float yd = ypos ? run : -run;
-          if (SCATTER) {
-            const bool active = in_range && !(yd < 0.0f);
-            x.coefw[r] = active ? (ypos ? ps : ns) : 0.0f;
-            if (in_range) x.coef8[(long long)cur.r0 + r - 1] = (signed char)(active ? (ypos ? 1 : -1) : 0);
-            n_all += active;
-          } else {
-            n_all += in_range;
-            n_neg += in_range && (yd < 0.0f);
-            n_pos += in_range && (yd > 0.0f);
-          }
+      in_t[k] = (T >> k) & 1u;
+      trail += in_t[k] ? pk[k] : 0.0f;
+      head += in_t[k] ? 0.0f : pk[k];
+    }
+    float s = trail;
+    int f = bits != 0u;
+    if (!(dbg & 8)) wave_seg_scan(s, f);
+    const float incoming = dpp_get_f<0x138, 0xf>(s);      // wave_shr:1: running sum of the row entering this lane
+    const int r_end = rf - (int)(bits & 1u);              // local row that ends at the lane's row start
+    if (!(dbg & 1)) {
+      const bool fin = nb == 1 && r_end >= r_lo && r_end < r_hi;
+      const float d = incoming + head;                     // x . w of that row
+      const bool ypos = (ys & bits) != 0u;
+      const float yd = ypos ? d : -d;
+      if (SCATTER) {
+        const bool active = fin && !(yd < 0.0f);           // ref: core/ml/SparseSVM.scala:27-28
+        if (nb == 1 && r_end >= 1 && r_end <= nrows) {
+          x.coefw[r_end] = active ? (ypos ? ps : ns) : 0.0f;
+          if (fin) coef8_tile[(unsigned int)r_end] = (signed char)(active ? (ypos ? 1 : -1) : 0);
         }
-        run = 0.0f;
-        ++r;
+        n_all += active;
+      } else {
+        n_all += fin;                                       // ref: core/ml/SparseSVM.scala:14,16
+        n_neg += fin && (yd < 0.0f);
+        n_pos += fin && (yd > 0.0f);
       }
-      run += pk[k];
     }
-  }
-
-  if (SCATTER && !(x.dbg & 2)) {
-    if (lane == 0) {
-      x.coefw[0] = 0.0f;                          // padding rows carry a zero coefficient
-      x.coefw[nrows < 0 ? 1 : nrows + 1] = 0.0f;
-    }
-    __builtin_amdgcn_wave_barrier();  // same wave wrote the strip; LDS executes a wave's accesses in order
-    int q[8], old[8];
-    if (__builtin_amdgcn_ballot_w64(nb > 1) == 0) {
-      // slots before the lane's row start belong to row rf - (start at slot 0 ? 0 : ...): with one start at
-      // slot k*, slots [0, k*) are row rf (or all 8 when k* == 0 / no start), slots [k*, 8) are row rf + 1
+    if (SCATTER && !(dbg & 2)) {
+      if (lane == 0) {
+        x.coefw[0] = 0.0f;                          // padding rows carry a zero coefficient
+        x.coefw[nrows < 0 ? 1 : nrows + 1] = 0.0f;
+      }
+      __builtin_amdgcn_wave_barrier();  // same wave wrote the strip; LDS executes a wave's accesses in order
+      // slots before the lane's row start belong to local row rf, the slots from it on to row rf + 1 -- unless
+      // the start sits at slot 0 (then rf already names the new row) or there is no start at all
       const float cA = x.coefw[rf];
       const float cB = x.coefw[rf + 1 <= WS_MAXROWS + 1 ? rf + 1 : rf];
-      const unsigned int after = (bits & 1u) ? 0u : (bits ? (0xffu & ~((bits & (0u - bits)) - 1u)) : 0u);  // slots >= k*
+      const float cT = (bits != 0u && !(bits & 1u)) ? cB : cA;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float coef = ((after >> k) & 1u) ? cB : cA;
+        const float coef = in_t[k] ? cT : cA;
         q[k] = cc[k] < x.hg ? __float2int_rn(vv[k] * coef) : 0;   // y * x on the fixed-point grid
       }
-    } else {
+      w_scatter<ABL>(x, cc, q, lane, dbg);
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    // ---- general case (some lane holds two or more row starts: rows shorter than 8 non-zeros) ----
+    float head = 0.0f, trail = 0.0f;
+    bool seen = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool st = (bits >> k) & 1u;
+      seen = seen || st;
+      trail = st ? 0.0f : trail;
+      trail += pk[k];
+      head += seen ? 0.0f : pk[k];
+    }
+    float s = trail;
+    int f = bits != 0u;
+    if (!(dbg & 8)) wave_seg_scan(s, f);
+    const float incoming = dpp_get_f<0x138, 0xf>(s);
+    if (!(dbg & 1)) {
+      float run = incoming;
+      int r = rf - (int)(bits & 1u);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if ((bits >> k) & 1u) {
+          if (r >= 1 && r <= nrows) {
+            const bool in_range = r >= r_lo && r < r_hi;
+            const bool ypos = (ys >> k) & 1u;
+            const float yd = ypos ? run : -run;
+            if (SCATTER) {
+              const bool active = in_range && !(yd < 0.0f);
+              x.coefw[r] = active ? (ypos ? ps : ns) : 0.0f;
+              if (in_range) coef8_tile[(unsigned int)r] = (signed char)(active ? (ypos ? 1 : -1) : 0);
+              n_all += active;
+            } else {
+              n_all += in_range;
+              n_neg += in_range && (yd < 0.0f);
+              n_pos += in_range && (yd > 0.0f);
+            }
+          }
+          run = 0.0f;
+          ++r;
+        }
+        run += pk[k];
+      }
+    }
+    if (SCATTER && !(dbg & 2)) {
+      if (lane == 0) {
+        x.coefw[0] = 0.0f;
+        x.coefw[nrows < 0 ? 1 : nrows + 1] = 0.0f;
+      }
+      __builtin_amdgcn_wave_barrier();
       int r = rf;
       float coef = x.coefw[r];
 #pragma unroll
@@ -1514,45 +1622,96 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
         }
         q[k] = cc[k] < x.hg ? __float2int_rn(vv[k] * coef) : 0;
       }
+      w_scatter<ABL>(x, cc, q, lane, dbg);
+      __builtin_amdgcn_wave_barrier();
     }
-    int worst = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      old[k] = 0;
-      if (q[k] != 0 && !(x.dbg & 4)) old[k] = atomicAdd(&x.gl[cc[k]], q[k]);   // ds_add_rtn_u32
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) worst = max(worst, abs(old[k] + q[k]));
-    if (worst >= WS_SPILL_AT) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (q[k] != 0) {
-          const int nw = old[k] + q[k];
-          if (old[k] >= WS_PANIC_AT || old[k] <= -WS_PANIC_AT) atomicOr(&x.sc->err, 2);
-          if (nw >= WS_SPILL_AT || nw <= -WS_SPILL_AT) {
-            const int v = atomicExch(&x.gl[cc[k]], 0);
-            if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[cc[k]]), (unsigned long long)(long long)v);
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- rows longer than a wave tile: one wave per row, four 64-element chunks in flight -------------------------
+// Run by the waves of dsgd_wseg_kernel after their tiles (same LDS weight tile, fixed-point accumulators and
+// cold-column convention); rows of 500+ non-zeros are 0.5 % of the RCV1-like rows but 3 % of the non-zeros.
+__device__ __forceinline__ void fix_add_lds(int* gl, long long* g64, DevScalars* sc, int c, int q) {
+  const int old = atomicAdd(&gl[c], q);   // ds_add_rtn_u32
+  const int nw = old + q;
+  if (nw >= WS_SPILL_AT || nw <= -WS_SPILL_AT) {
+    if (old >= WS_PANIC_AT || old <= -WS_PANIC_AT) atomicOr(&sc->err, 2);
+    const int v = atomicExch(&gl[c], 0);
+    if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[c]), (unsigned long long)(long long)v);
   }
 }
 
 template <bool SCATTER>
-__global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, WTables tt, const float* __restrict__ w,
-                                                        long long* g64_base, long long g_stride,
-                                                        const StreamSeg* __restrict__ segs, DevScalars* sc, int hw, int hg,
-                                                        float fix_scale, signed char* coef8, int dp, int dbg) {
+__device__ __forceinline__ void w_long_row(const CsrView& m, const float* __restrict__ w, const WCtx& x, long long row,
+                                           unsigned int& n_all, unsigned int& n_neg, unsigned int& n_pos) {
+  typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
+  const int lane = threadIdx.x & 63;
+  const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
+  const float y = (float)m.label[row];
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long long p = start + lane; p < end; p += 256) {
+    int c[4];
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool in = p + 64 * k < end;
+      c[k] = in ? m.col[p + 64 * k] : 0;
+      v[k] = in ? m.val[p + 64 * k] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float wv = c[k] < x.hw ? ((lds_cvfloat*)x.wl)[c[k]] : w[c[k]];
+      a[k] += filt(v[k] * wv);   // ref: math/Sparse.scala:46
+    }
+  }
+  const float d = group_sum<64>((a[0] + a[1]) + (a[2] + a[3]));
+  const float yd = y * d;
+  if (SCATTER) {
+    const bool active = !(yd < 0.0f);     // ref: core/ml/SparseSVM.scala:27-28
+    if (lane == 0) {
+      x.coef8[row] = (signed char)(active ? (int)y : 0);
+      n_all += active;
+    }
+    if (active) {
+      const float cs = y * x.fix_scale;
+      for (long long p = start + lane; p < end; p += 64) {
+        const int c = m.col[p];
+        if (c < x.hg) {
+          const int q = __float2int_rn(m.val[p] * cs);
+          if (q != 0) fix_add_lds(x.gl, x.g64, x.sc, c, q);
+        }
+      }
+    }
+  } else if (lane == 0) {
+    n_all += 1;
+    n_neg += yd < 0.0f;
+    n_pos += yd > 0.0f;
+  }
+}
+
+template <bool SCATTER, bool ABL, int DEPTH>
+__global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, const WTile* __restrict__ tiles,
+                                                        const unsigned int* __restrict__ meta,
+                                                        const float* __restrict__ w, long long* __restrict__ g64_base,
+                                                        long long g_stride, const StreamSeg* __restrict__ segs,
+                                                        DevScalars* __restrict__ sc, int hw, int hg, float fix_scale,
+                                                        signed char* __restrict__ coef8, int dp, int dbg,
+                                                        const int* __restrict__ long_rows, int* __restrict__ part,
+                                                        int part_stride) {
+  // (the tables are direct __restrict__ parameters: only then can the compiler prove that the stores of this kernel
+  // do not clobber them and select scalar loads for the wave-uniform tile records)
+  WTables tt;
+  tt.tiles = tiles;
+  tt.meta = meta;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile records, bases and row ranges stay in SGPRs
   WCtx x;
   x.dbg = dbg;
   x.coef8 = coef8;
   x.coefw = lds + wave * WS_COEF_STRIDE;                       // 16 strips
-  x.gl = reinterpret_cast<int*>(lds + 16 * WS_COEF_STRIDE);    // hg (SCATTER only)
-  float* wl = lds + 16 * WS_COEF_STRIDE + (SCATTER ? hg : 0);  // hw + 1 (zero slot at wl[hw])
+  x.gl = reinterpret_cast<int*>(lds + 16 * WS_COEF_STRIDE);    // hg + 64 always-zero words (SCATTER only)
+  float* wl = lds + 16 * WS_COEF_STRIDE + (SCATTER ? hg + 64 : 0);  // hw + 1 (zero slot at wl[hw])
   x.wl = wl;
   const StreamSeg seg = segs[blockIdx.y];
   x.g64 = g64_base + (long long)blockIdx.y * g_stride;
@@ -1563,7 +1722,7 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, WTables tt, 
   x.hg = hg;
   x.fix_scale = fix_scale;
   if (SCATTER)
-    for (int j = tid; j < hg; j += 1024) x.gl[j] = 0;
+    for (int j = tid; j < hg + 64; j += 1024) x.gl[j] = 0;
   for (int j = tid; j < hw; j += 1024) wl[j] = w[j];
   if (tid == 0) wl[hw] = 0.0f;
   __syncthreads();
@@ -1575,27 +1734,54 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, WTables tt, 
   const long long t_end = seg.tile_end;
   long long tile = seg.tile_begin + (long long)blockIdx.x * 16 + wave;
   if (tile < t_end) {
-    WRegs A, B, C;
+    WRegs A, B, C, D;
     WTile wt = w_fetch(tt, tile, t_end);
-    w_issue(m, tt, tile, t_end, lane, wt, A);
+    w_issue_cols(m, tile, t_end, lane, wt, A);
+    w_issue_vals(m, tt, lane, A);
     wt = w_fetch(tt, tile + stride, t_end);
-    w_issue(m, tt, tile + stride, t_end, lane, wt, B);
+    w_issue_cols(m, tile + stride, t_end, lane, wt, B);
+    w_issue_vals(m, tt, lane, B);
     wt = w_fetch(tt, tile + 2 * stride, t_end);
+    if (DEPTH == 4) {
+      w_issue_cols(m, tile + 2 * stride, t_end, lane, wt, C);
+      wt = w_fetch(tt, tile + 3 * stride, t_end);
+    }
     w_gather(wrs, hw, A);
-#define DSGD_WT(CUR, NXT, FAR) w_tile<SCATTER>(m, tt, wrs, x, (unsigned int)dp, tile, stride, t_end, CUR, NXT, FAR, wt, n_all, n_neg, n_pos)
-    for (;;) {
-      DSGD_WT(A, B, C); tile += stride; if (tile >= t_end) break;
-      DSGD_WT(B, C, A); tile += stride; if (tile >= t_end) break;
-      DSGD_WT(C, A, B); tile += stride; if (tile >= t_end) break;
+#define DSGD_WT(CUR, NXT, MID, FAR)                                                                                  \
+  w_tile<SCATTER, ABL, DEPTH>(m, tt, wrs, x, (unsigned int)dp, tile, stride, t_end, CUR, NXT, MID, FAR, wt, n_all, \
+                              n_neg, n_pos)
+    if (DEPTH == 4) {
+      for (;;) {
+        DSGD_WT(A, B, C, D); tile += stride; if (tile >= t_end) break;
+        DSGD_WT(B, C, D, A); tile += stride; if (tile >= t_end) break;
+        DSGD_WT(C, D, A, B); tile += stride; if (tile >= t_end) break;
+        DSGD_WT(D, A, B, C); tile += stride; if (tile >= t_end) break;
+      }
+    } else {
+      for (;;) {
+        DSGD_WT(A, B, C, C); tile += stride; if (tile >= t_end) break;
+        DSGD_WT(B, C, A, A); tile += stride; if (tile >= t_end) break;
+        DSGD_WT(C, A, B, B); tile += stride; if (tile >= t_end) break;
+      }
     }
 #undef DSGD_WT
   }
+  // rows that fit no tile: one wave per row
+  for (long long t = seg.long_begin + (long long)blockIdx.x * 16 + wave; t < seg.long_end; t += stride)
+    w_long_row<SCATTER>(m, w, x, (long long)long_rows[t], n_all, n_neg, n_pos);
 
   if (SCATTER) {
     __syncthreads();
-    for (int j = tid; j < hg; j += 1024) {
-      const int q = x.gl[j];
-      if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
+    if (part) {
+      // this workgroup's exact partial sums, written whole (zeros included): dsgd_fix_reduce_kernel adds the
+      // partials of a worker in a fixed order -- no atomics, and 256 workgroups do not meet on one address
+      int* mine = part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * part_stride;
+      for (int j = tid; j < hg; j += 1024) mine[j] = x.gl[j];
+    } else {
+      for (int j = tid; j < hg; j += 1024) {
+        const int q = x.gl[j];
+        if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
+      }
     }
     n_all = wave_sum_u32(n_all);
     if (lane == 0 && n_all) atomicAdd(&sc->n_active, (unsigned long long)n_all);
@@ -1806,96 +1992,3 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   if (tid == 0) atomicAdd(&a.st->done_blocks, 1);
 }
 
-// ---- rows longer than a wave tile: one wave per row, four 64-element chunks in flight -------------------------
-// Same LDS tiles, fixed-point accumulation and cold-column convention as dsgd_wseg_kernel (rows of 500+
-// non-zeros are 0.5 % of the RCV1-like rows but 3 % of the non-zeros).
-__device__ __forceinline__ void fix_add_lds(int* gl, long long* g64, DevScalars* sc, int c, int q) {
-  const int old = atomicAdd(&gl[c], q);   // ds_add_rtn_u32
-  const int nw = old + q;
-  if (nw >= WS_SPILL_AT || nw <= -WS_SPILL_AT) {
-    if (old >= WS_PANIC_AT || old <= -WS_PANIC_AT) atomicOr(&sc->err, 2);
-    const int v = atomicExch(&gl[c], 0);
-    if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[c]), (unsigned long long)(long long)v);
-  }
-}
-
-template <bool SCATTER>
-__global__ void __launch_bounds__(1024) dsgd_wlong_kernel(CsrView m, const float* __restrict__ w, long long* g64_base,
-                                                         long long g_stride, const int* __restrict__ idx,
-                                                         const WorkSeg* __restrict__ segs, DevScalars* sc, int hw, int hg,
-                                                         float fix_scale, signed char* coef8) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int* gl = reinterpret_cast<int*>(lds);             // hg (SCATTER only)
-  float* wl = lds + (SCATTER ? hg : 0);              // hw
-  const int tid = threadIdx.x, lane = tid & 63;
-  const WorkSeg seg = segs[blockIdx.y];
-  long long* g64 = g64_base + (long long)blockIdx.y * g_stride;
-  if (SCATTER)
-    for (int j = tid; j < hg; j += 1024) gl[j] = 0;
-  for (int j = tid; j < hw; j += 1024) wl[j] = w[j];
-  __syncthreads();
-  unsigned int n_all = 0, n_neg = 0, n_pos = 0;
-  const long long wave_g = (long long)blockIdx.x * 16 + (tid >> 6), n_waves = (long long)gridDim.x * 16;
-  for (long long t = seg.begin + wave_g; t < seg.end; t += n_waves) {
-    const long long row = idx[t];
-    const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
-    const float y = (float)m.label[row];
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long long p = start + lane; p < end; p += 256) {
-      int c[4];
-      float v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool in = p + 64 * k < end;
-        c[k] = in ? m.col[p + 64 * k] : 0;
-        v[k] = in ? m.val[p + 64 * k] : 0.0f;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float wv = c[k] < hw ? wl[c[k]] : w[c[k]];
-        a[k] += filt(v[k] * wv);   // ref: math/Sparse.scala:46
-      }
-    }
-    const float d = group_sum<64>((a[0] + a[1]) + (a[2] + a[3]));
-    const float yd = y * d;
-    if (SCATTER) {
-      const bool active = !(yd < 0.0f);     // ref: core/ml/SparseSVM.scala:27-28
-      if (lane == 0) {
-        coef8[row] = (signed char)(active ? (int)y : 0);
-        n_all += active;
-      }
-      if (active) {
-        const float cs = y * fix_scale;
-        for (long long p = start + lane; p < end; p += 64) {
-          const int c = m.col[p];
-          if (c < hg) {
-            const int q = __float2int_rn(m.val[p] * cs);
-            if (q != 0) fix_add_lds(gl, g64, sc, c, q);
-          }
-        }
-      }
-    } else if (lane == 0) {
-      n_all += 1;
-      n_neg += yd < 0.0f;
-      n_pos += yd > 0.0f;
-    }
-  }
-  if (SCATTER) {
-    __syncthreads();
-    for (int j = tid; j < hg; j += 1024) {
-      const int q = gl[j];
-      if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[j]), (unsigned long long)(long long)q);
-    }
-    n_all = wave_sum_u32(n_all);
-    if (lane == 0 && n_all) atomicAdd(&sc->n_active, (unsigned long long)n_all);
-  } else {
-    n_all = wave_sum_u32(n_all);
-    n_neg = wave_sum_u32(n_neg);
-    n_pos = wave_sum_u32(n_pos);
-    if (lane == 0) {
-      if (n_neg) atomicAdd(&sc->counts[0], (unsigned long long)n_neg);
-      if (n_all - n_neg - n_pos) atomicAdd(&sc->counts[1], (unsigned long long)(n_all - n_neg - n_pos));
-      if (n_pos) atomicAdd(&sc->counts[2], (unsigned long long)n_pos);
-    }
-  }
-}
