@@ -132,49 +132,54 @@ struct dsgd_ctx {
   int hw = 8192, hg = 32768;  // LDS tile sizes (floats) of the tiled gradient kernel; hw + hg <= 40960
   int hw_eval = DSGD_LDS_FLOATS;
   long long tiled_min = 8192;  // batches with at least this many rows use the tiled kernel
-  // nnz-streaming kernels (contiguous row ranges): tiles of consecutive rows
-  std::vector<int> h_tile_row;       // n_tiles + 1
-  std::vector<long long> long_rows;  // rows with more than ST_MAXNNZ non-zeros (own tile, handled row-wise)
-  int* d_tile_row = nullptr;
-  long long* d_tile_pos = nullptr;
-  long long* d_tile_vptr = nullptr;
-  int* d_tile_rp = nullptr;
-  long long n_tile_rp = 0;
-  int* d_vrow = nullptr;
-  long long n_vrow = 0;
-  long long n_tiles = 0;
+  // nnz-streaming kernels (contiguous row ranges)
   StreamSeg* d_ssegs = nullptr;
   int ssegs_cap = 0;
   std::vector<StreamSeg> ssegs_last;
-  int hw_s = 4096, hg_s = DSGD_LDS_FLOATS - ST_FIXED_FLOATS - 4096;  // LDS tiles of the streaming gradient kernel
-  int hw_se = DSGD_LDS_FLOATS - ST_FIXED_FLOATS;                     // ... of the streaming evaluation kernel
   bool stream_ranges = true;
-  bool pf_early = false;
-  int stream_mode = 3;  // 1: LDS-staged products (dsgd_stream_kernel), 2: workgroup tiles + register segmented scan
-                        // (dsgd_seg_kernel), 3: wave tiles, no workgroup barriers (dsgd_wseg_kernel)
-  // wave tiles of mode 3
+  // stream_mode 3: wave tiles over the whole ranked CSR, cold weights gathered, cold gradient columns through
+  //                transposed lists;
+  // stream_mode 4: the matrix is SPLIT by column rank into a hot stream (rank < hsplit: wave tiles, weights and
+  //                gradient in LDS, no gathers) and a cold stream (col - hsplit, val, row) handled by two small
+  //                kernels whose LDS holds the cold weights / the cold gradient.
+  int stream_mode = 4;
+  std::vector<long long> h_row_ptr;     // host copy of the internal row_ptr (tile building at layout time)
+  std::vector<long long> h_crow_ptr;    // mode 4: row offsets of the cold stream
+  std::vector<signed char> h_label;
+  // wave tiles (mode 3: over d_col/d_val; mode 4: over d_hcol/d_hval)
   WTile* d_wtiles = nullptr;
   unsigned int* d_wmeta = nullptr;
   long long n_wtiles = 0;
   std::vector<int> h_wtile_r0;          // first row of every wave tile (+ sentinel n_rows)
-  std::vector<long long> wlong_rows;    // rows with more than WS_MAXNNZ non-zeros (sorted): one wave per row
+  std::vector<long long> wlong_rows;    // rows that fit no wave tile (sorted): one wave per row, from the whole CSR
   int* d_wlong_rows = nullptr;          // the same list on the device
   int* d_part = nullptr;                // per-workgroup partial sums of the wseg gradient kernel: part_wgs x part_stride
   long long part_wgs = 0;
   int part_stride = 0;
-  bool use_part = true;                 // DSGD_EPI=0: 64-bit atomics into g64 instead
-  int pf_depth = 4;                     // DSGD_PF=3|4: tiles in flight per wave (register sets of the wseg kernels)
+  bool use_part = true;                 // DSGD_EPI=0 (mode 3 only): 64-bit atomics into g64 instead
+  int pf_depth = 4;                     // DSGD_PF=3|4 (mode 3): tiles in flight per wave
   int dbg = 0;                          // DSGD_DBG: ablation switches of the streaming kernels (tuning runs only)
-  // LDS tiles of the wseg gradient kernel.  Cost model from tools/microbench4.hip and the profiles: a cold weight
-  // costs ~3 clk of a CU's texture path per distinct cache line, a cold gradient entry ~8 B of list traffic;
-  // 16384 / 20476 balances the two for RCV1-like column statistics.
+  // mode 3 LDS tiles.  Cost model from tools/microbench4.hip and the profiles: a cold weight costs ~3 clk of a CU's
+  // texture path per distinct cache line, a cold gradient entry ~8 B of list traffic.
   int hw_w = 16384, hg_w = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 16384 - 4 - 64;
-  int hw_we = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4;                     // ... of the wseg evaluation kernel
-  unsigned short* d_tile_meta = nullptr;  // n_tiles x 1024 lane descriptors of the seg kernels
-  int hw_g = 6144, hg_g = DSGD_LDS_FLOATS - SG_LDS_FIXED - 6144 - 2;  // LDS tiles of the seg gradient kernel
-  int hw_ge = DSGD_LDS_FLOATS - SG_LDS_FIXED - 2;                     // ... of the seg evaluation kernel
-  int hg_cold() const { return stream_mode == 3 ? hg_w : (stream_mode == 2 ? hg_g : hg_s); }
-  // cold columns (rank >= hg_s): transposed (row, value) lists + per-row gate coefficients
+  int hw_we = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4;                     // ... of the mode-3 evaluation kernel
+  // mode 4
+  int hsplit = (DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64) / 2;         // hot ranks: 2 * hsplit words of LDS
+  int* d_hcol = nullptr;                // hot stream (ranks < hsplit), WS_PAD elements of padding
+  float* d_hval = nullptr;
+  long long* d_hrow_ptr = nullptr;      // n_rows + 1 (rows of the long list: empty)
+  long long hot_nnz = 0;
+  int* d_ccol = nullptr;                // cold stream in row order: rank - hsplit, value, row
+  float* d_cval = nullptr;
+  int* d_crow = nullptr;
+  long long* d_crow_ptr = nullptr;      // n_rows + 1
+  long long coldm_nnz = 0;
+  float* d_dcold = nullptr;             // n_rows: cold part of x.w (rows without cold entries stay 0)
+  int* d_partc = nullptr;               // per-workgroup cold gradient partials: partc_wgs x partc_stride
+  long long partc_wgs = 0;
+  int partc_stride = 0;
+  int hg_cold() const { return hg_w; }
+  // mode 3 cold columns (rank >= hg_w): transposed (row, value) lists + per-row gate coefficients
   unsigned int* d_cold_ptr = nullptr;  // n_cold + 1
   int* d_cold_row = nullptr;
   float* d_cold_val = nullptr;
@@ -561,6 +566,172 @@ static int build_cold_lists(dsgd_ctx* c) {
   return DSGD_OK;
 }
 
+// ---- wave tiles ------------------------------------------------------------------------------------------
+// Tiles of WHOLE rows with <= WS_MAXNNZ non-zeros and <= WS_MAXROWS rows.  Lane l owns the 8 contiguous slots
+// [8l, 8l+8) of the 512-slot window at pos0 (a multiple of 4 elements).  Lane descriptor: local row of its first
+// slot (8 bits, rows 1-based) | row-start bits << 8 | label sign of the row ENDING at each start << 16.
+// Rows longer than WS_MAXNNZ go to `long_rows` (if given); rows of length 0 are skipped (they are on that list
+// already -- the caller emptied them).
+struct HostTiles {
+  std::vector<WTile> wt;
+  std::vector<int> r0;              // first row of every tile + sentinel n_rows
+  std::vector<unsigned int> meta;   // n_tiles x 64
+};
+static void build_wave_tiles(const long long* row_ptr, long long n_rows, const signed char* label, HostTiles& out,
+                             std::vector<long long>* long_rows) {
+  std::vector<WTile>& wt = out.wt;
+  std::vector<int>& wr0 = out.r0;
+  wt.clear();
+  wr0.clear();
+  long long start = -1;  // first row of the open tile
+  auto close = [&](long long end_row) {
+    if (start < 0) return;
+    WTile t;
+    t.pos0 = row_ptr[start] & ~3LL;
+    t.r0 = (int)start;
+    t.nrows = (int)(end_row - start);
+    wt.push_back(t);
+    wr0.push_back((int)start);
+    start = -1;
+  };
+  for (long long i = 0; i < n_rows; ++i) {
+    const long long len = row_ptr[i + 1] - row_ptr[i];
+    if (len > WS_MAXNNZ || len == 0) {
+      close(i);
+      if (long_rows && len > WS_MAXNNZ) long_rows->push_back(i);
+      continue;
+    }
+    if (start >= 0 && (row_ptr[i + 1] - (row_ptr[start] & ~3LL) > WS_SLOTS - 1 || i - start >= WS_MAXROWS)) close(i);
+    if (start < 0) start = i;
+  }
+  close(n_rows);
+  wr0.push_back((int)n_rows);
+  const long long n_tiles = (long long)wt.size();
+  out.meta.assign((size_t)std::max<long long>(n_tiles, 1) * 64, 0u);
+  for (long long t = 0; t < n_tiles; ++t) {
+    const WTile& T = wt[(size_t)t];
+    int cur_row = 0, next = 0;
+    for (int l = 0; l < 64; ++l) {  // lane l owns slots [8l, 8l+8)
+      unsigned int bits = 0, ys = 0;
+      int first_row = 0;
+      for (int k = 0; k < 8; ++k) {
+        const long long slot = 8LL * l + k;
+        bool st = false;
+        if (next < T.nrows && row_ptr[T.r0 + next] - T.pos0 == slot) st = true;
+        else if (next == T.nrows && row_ptr[T.r0 + T.nrows] - T.pos0 == slot) st = true;  // end mark
+        if (st) {
+          bits |= 1u << k;
+          // the row that ends here is local row cur_row (1-based); row 0 = leading padding
+          if (cur_row >= 1 && label[T.r0 + cur_row - 1] > 0) ys |= 1u << k;
+          ++cur_row;
+          ++next;
+        }
+        if (k == 0) first_row = cur_row;
+      }
+      out.meta[(size_t)t * 64 + l] = (unsigned int)first_row | (bits << 8) | (ys << 16);
+    }
+  }
+  if (wt.empty()) {
+    WTile t;
+    t.pos0 = 0;
+    t.r0 = 0;
+    t.nrows = -1;
+    wt.push_back(t);
+  }
+}
+static int upload_wave_tiles(dsgd_ctx* c, HostTiles& ht) {
+  hipFree(c->d_wtiles);
+  hipFree(c->d_wmeta);
+  hipFree(c->d_wlong_rows);
+  c->d_wtiles = nullptr;
+  c->d_wmeta = nullptr;
+  c->d_wlong_rows = nullptr;
+  c->n_wtiles = (long long)ht.r0.size() - 1;
+  c->h_wtile_r0.swap(ht.r0);
+  HIP_TRY(hipMalloc(&c->d_wtiles, sizeof(WTile) * ht.wt.size()));
+  HIP_TRY(hipMalloc(&c->d_wmeta, sizeof(unsigned int) * ht.meta.size()));
+  HIP_TRY(hipMemcpy(c->d_wtiles, ht.wt.data(), sizeof(WTile) * ht.wt.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_wmeta, ht.meta.data(), sizeof(unsigned int) * ht.meta.size(), hipMemcpyHostToDevice));
+  std::vector<int> lr(c->wlong_rows.begin(), c->wlong_rows.end());
+  lr.push_back(0);
+  HIP_TRY(hipMalloc(&c->d_wlong_rows, sizeof(int) * lr.size()));
+  HIP_TRY(hipMemcpy(c->d_wlong_rows, lr.data(), sizeof(int) * lr.size(), hipMemcpyHostToDevice));
+  c->ssegs_last.clear();
+  return DSGD_OK;
+}
+
+// mode 4: split the ranked CSR into the hot stream (rank < hsplit; wave tiles) and the cold stream
+// (rank - hsplit, value, row); rows whose hot part exceeds a wave tile stay on the long-row list and in neither.
+static int build_split(dsgd_ctx* c) {
+  hipFree(c->d_hcol); hipFree(c->d_hval); hipFree(c->d_hrow_ptr);
+  hipFree(c->d_ccol); hipFree(c->d_cval); hipFree(c->d_crow); hipFree(c->d_crow_ptr);
+  hipFree(c->d_dcold); hipFree(c->d_coef8);
+  c->d_hcol = nullptr; c->d_hval = nullptr; c->d_hrow_ptr = nullptr;
+  c->d_ccol = nullptr; c->d_cval = nullptr; c->d_crow = nullptr; c->d_crow_ptr = nullptr;
+  c->d_dcold = nullptr; c->d_coef8 = nullptr;
+  const long long n_rows = c->n_rows;
+  const int H = std::min(c->hsplit, c->dp);
+  HIP_TRY(hipMalloc(&c->d_coef8, (size_t)std::max<long long>(n_rows, 1)));
+  HIP_TRY(hipMemset(c->d_coef8, 0, (size_t)std::max<long long>(n_rows, 1)));
+  HIP_TRY(hipMalloc(&c->d_dcold, sizeof(float) * (size_t)std::max<long long>(n_rows, 1)));
+  HIP_TRY(hipMemset(c->d_dcold, 0, sizeof(float) * (size_t)std::max<long long>(n_rows, 1)));
+  // cold entries per row
+  int* d_cnt = nullptr;
+  HIP_TRY(hipMalloc(&d_cnt, sizeof(int) * (size_t)n_rows));
+  CsrView m = view(c);
+  {
+    const int blocks = (int)std::max<long long>(1, std::min<long long>((n_rows + 15) / 16, (long long)c->n_cu * 16));
+    hipLaunchKernelGGL(dsgd_split_count_kernel<16>, dim3(blocks), dim3(256), 0, c->stream, m, H, d_cnt);
+  }
+  std::vector<int> cnt((size_t)n_rows);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * (size_t)n_rows, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_cnt);
+  if (e != hipSuccess) return fail(DSGD_EHIP, "split counts: %s", hipGetErrorString(e));
+  std::vector<long long> hrp((size_t)n_rows + 1), &crp = c->h_crow_ptr;
+  crp.assign((size_t)n_rows + 1, 0);
+  c->wlong_rows.clear();
+  hrp[0] = 0;
+  const std::vector<long long>& rp = c->h_row_ptr;
+  for (long long i = 0; i < n_rows; ++i) {
+    const long long len = rp[i + 1] - rp[i], cold = cnt[(size_t)i], hot = len - cold;
+    if (hot > WS_MAXNNZ) {   // served whole from the ranked CSR, one wave per row
+      c->wlong_rows.push_back(i);
+      hrp[i + 1] = hrp[i];
+      crp[i + 1] = crp[i];
+    } else {
+      hrp[i + 1] = hrp[i] + std::max<long long>(hot, 1);
+      crp[i + 1] = crp[i] + cold;
+    }
+  }
+  c->hot_nnz = hrp[n_rows];
+  c->coldm_nnz = crp[n_rows];
+  HIP_TRY(hipMalloc(&c->d_hcol, sizeof(int) * (size_t)(c->hot_nnz + WS_PAD)));
+  HIP_TRY(hipMalloc(&c->d_hval, sizeof(float) * (size_t)(c->hot_nnz + WS_PAD)));
+  HIP_TRY(hipMemset(c->d_hcol + c->hot_nnz, 0, sizeof(int) * WS_PAD));
+  HIP_TRY(hipMemset(c->d_hval + c->hot_nnz, 0, sizeof(float) * WS_PAD));
+  HIP_TRY(hipMalloc(&c->d_hrow_ptr, sizeof(long long) * hrp.size()));
+  HIP_TRY(hipMemcpy(c->d_hrow_ptr, hrp.data(), sizeof(long long) * hrp.size(), hipMemcpyHostToDevice));
+  const size_t nc = (size_t)std::max<long long>(c->coldm_nnz, 1);
+  HIP_TRY(hipMalloc(&c->d_ccol, sizeof(int) * nc));
+  HIP_TRY(hipMalloc(&c->d_cval, sizeof(float) * nc));
+  HIP_TRY(hipMalloc(&c->d_crow, sizeof(int) * nc));
+  HIP_TRY(hipMalloc(&c->d_crow_ptr, sizeof(long long) * crp.size()));
+  HIP_TRY(hipMemcpy(c->d_crow_ptr, crp.data(), sizeof(long long) * crp.size(), hipMemcpyHostToDevice));
+  {
+    const int blocks = (int)std::max<long long>(1, std::min<long long>((n_rows + 3) / 4, (long long)c->n_cu * 16));
+    hipLaunchKernelGGL(dsgd_split_fill_kernel, dim3(blocks), dim3(256), 0, c->stream, m, H, c->d_hrow_ptr, c->d_crow_ptr,
+                       c->d_hcol, c->d_hval, c->d_ccol, c->d_cval, c->d_crow);
+    HIP_TRY(hipGetLastError());
+  }
+  HostTiles ht;
+  build_wave_tiles(hrp.data(), n_rows, c->h_label.data(), ht, nullptr);
+  DSGD_TRY(upload_wave_tiles(c, ht));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DSGD_OK;
+}
+
 // Rank the columns by how often they occur in the loaded rows (summed over ranks when a
 // communicator is attached, so every replica uses the same order) and relabel the CSR columns.
 // Runs once, lazily, at the first compute call after dsgd_load_csr.
@@ -598,7 +769,8 @@ static int prepare_layout(dsgd_ctx* c) {
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
-  DSGD_TRY(build_cold_lists(c));
+  if (c->stream_mode == 4 && c->stream_ranges) DSGD_TRY(build_split(c));
+  else DSGD_TRY(build_cold_lists(c));
   c->layout_ready = true;
   c->s_dirty = true;
   return DSGD_OK;
@@ -635,23 +807,50 @@ static int upload_ssegs(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
   c->ssegs_last = segs;
   return DSGD_OK;
 }
-static StreamSeg make_sseg(dsgd_ctx* c, long long rb, long long re) {
-  const std::vector<int>& tr = c->h_tile_row;
+static StreamSeg make_sseg(long long rb, long long re) {
   StreamSeg s{};
   s.row_begin = rb;
   s.row_end = re;
-  s.tile_begin = (std::upper_bound(tr.begin(), tr.end(), (int)rb) - tr.begin()) - 1;  // tile containing rb
-  s.tile_end = std::lower_bound(tr.begin(), tr.end(), (int)re) - tr.begin();          // one past the tile of re-1
   return s;
 }
-// after a streaming gradient kernel: fixed point -> fp32, then the cold columns from their transposed lists
-template <bool SCATTER>
-static int finish_stream(dsgd_ctx* c, int n_workers, int part_wg_per_worker = 0, int part_hg = 0) {
-  if (!SCATTER) return DSGD_OK;
+// tile and long-row ranges of every worker's row range (wave tiles of whatever stream the mode uses)
+static void locate_segs(dsgd_ctx* c, std::vector<StreamSeg>& segs, long long* max_tiles, long long* max_long) {
+  const std::vector<int>& wr0 = c->h_wtile_r0;  // n_wtiles + 1 entries (sentinel n_rows)
+  *max_tiles = 1;
+  *max_long = 0;
+  for (StreamSeg& s : segs) {
+    // first tile whose rows reach row_begin: the last tile with r0 <= row_begin (it may end before row_begin when a
+    // long row sits in between -- then all its rows are masked) ... one past the last tile with r0 < row_end
+    long long tb = (std::upper_bound(wr0.begin(), wr0.end() - 1, (int)s.row_begin) - wr0.begin()) - 1;
+    if (tb < 0) tb = 0;
+    long long te = std::lower_bound(wr0.begin(), wr0.end() - 1, (int)s.row_end) - wr0.begin();
+    if (te < tb) te = tb;
+    s.tile_begin = tb;
+    s.tile_end = te;
+    *max_tiles = std::max(*max_tiles, te - tb);
+    // the rows that fit no tile: a range of the sorted long-row list, handled by the same kernel (one wave per row)
+    s.long_begin = std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), s.row_begin) - c->wlong_rows.begin();
+    s.long_end = std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), s.row_end) - c->wlong_rows.begin();
+    *max_long = std::max(*max_long, s.long_end - s.long_begin);
+  }
+}
+static int ensure_part(dsgd_ctx* c, int** buf, long long* wgs, int* stride, long long need_wgs, int need_cols) {
+  if (need_wgs <= *wgs && need_cols <= *stride) return DSGD_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  hipFree(*buf);
+  *buf = nullptr;
+  *wgs = std::max<long long>(need_wgs, c->n_cu);
+  *stride = std::max(*stride, (need_cols + 63) / 64 * 64);
+  HIP_TRY(hipMalloc(buf, sizeof(int) * (size_t)*wgs * (size_t)*stride));
+  return DSGD_OK;
+}
+
+// mode 3 -- after the gradient kernel: fixed point -> fp32, then the cold columns from their transposed lists
+static int finish_mode3(dsgd_ctx* c, int n_workers, int part_wg_per_worker, int part_hg) {
   if (part_wg_per_worker > 0)
     hipLaunchKernelGGL(dsgd_fix_reduce_kernel, dim3((c->dp + 63) / 64, n_workers), dim3(1024), 0, c->stream, c->d_g64, c->d_g,
-                       (long long)c->dp, c->dp, part_hg, c->d_part, c->part_stride, part_wg_per_worker,
-                       1.0 / (double)c->fix_scale);
+                       (long long)c->dp, c->dp, part_hg, c->d_part, c->part_stride, part_wg_per_worker, 0, 0,
+                       (const int*)nullptr, 0, 0, 1.0 / (double)c->fix_scale);
   else
     hipLaunchKernelGGL(dsgd_fix_finalize_kernel, dim3((c->dp + 1023) / 1024, n_workers), dim3(1024), 0, c->stream, c->d_g64,
                        c->d_g, (long long)c->dp, c->dp, 1.0 / (double)c->fix_scale);
@@ -669,29 +868,13 @@ static int finish_stream(dsgd_ctx* c, int n_workers, int part_wg_per_worker = 0,
   return DSGD_OK;
 }
 
-// mode 3: wave tiles.  segs carry ROW ranges; tile ranges are recomputed for the wave tiling.
+// mode 3: wave tiles over the whole ranked CSR
 template <bool SCATTER>
 static int launch_wseg(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   const int n_workers = (int)row_segs.size();
   std::vector<StreamSeg> segs(row_segs);
-  const std::vector<int>& wr0 = c->h_wtile_r0;  // n_wtiles + 1 entries (sentinel n_rows)
-  long long max_tiles = 1, max_long = 0;
-  for (int k = 0; k < n_workers; ++k) {
-    StreamSeg& s = segs[k];
-    // first tile whose rows reach row_begin: the last tile with r0 <= row_begin (it may end before row_begin when a
-    // long row sits in between -- then all its rows are masked) ... one past the last tile with r0 < row_end
-    long long tb = (std::upper_bound(wr0.begin(), wr0.end() - 1, (int)s.row_begin) - wr0.begin()) - 1;
-    if (tb < 0) tb = 0;
-    long long te = std::lower_bound(wr0.begin(), wr0.end() - 1, (int)s.row_end) - wr0.begin();
-    if (te < tb) te = tb;
-    s.tile_begin = tb;
-    s.tile_end = te;
-    max_tiles = std::max(max_tiles, te - tb);
-    // the rows that fit no tile: a range of the sorted long-row list, handled by the same kernel (one wave per row)
-    s.long_begin = std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), s.row_begin) - c->wlong_rows.begin();
-    s.long_end = std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), s.row_end) - c->wlong_rows.begin();
-    max_long = std::max(max_long, s.long_end - s.long_begin);
-  }
+  long long max_tiles, max_long;
+  locate_segs(c, segs, &max_tiles, &max_long);
   DSGD_TRY(upload_ssegs(c, segs));
   long long bx = std::max<long long>(1, c->n_cu / n_workers);
   bx = std::min(bx, std::max((max_tiles + 15) / 16, (max_long + 15) / 16));
@@ -700,90 +883,85 @@ static int launch_wseg(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   const int hg = SCATTER ? c->hg_w : 0;
   const size_t lds = sizeof(float) * (size_t)(16 * WS_COEF_STRIDE + hw + hg + (SCATTER ? 64 : 0) + 4);
   const bool part = SCATTER && c->use_part;
-  if (part && ((long long)grid.x * grid.y > c->part_wgs || hg > c->part_stride)) {
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    hipFree(c->d_part);
-    c->d_part = nullptr;
-    c->part_wgs = std::max<long long>((long long)grid.x * grid.y, c->n_cu);
-    c->part_stride = (hg + 63) / 64 * 64;
-    HIP_TRY(hipMalloc(&c->d_part, sizeof(int) * (size_t)c->part_wgs * (size_t)c->part_stride));
-  }
+  if (part) DSGD_TRY(ensure_part(c, &c->d_part, &c->part_wgs, &c->part_stride, (long long)grid.x * grid.y, hg));
   CsrView m = view(c);
-  WTables wt;
-  wt.tiles = c->d_wtiles;
-  wt.meta = c->d_wmeta;
   size_t slot = 0;
   if (SCATTER) DSGD_TRY(prof_begin(c, &slot));
-#define DSGD_LAUNCH_WSEG(ABL, DEPTH)                                                                                   \
-  hipLaunchKernelGGL((dsgd_wseg_kernel<SCATTER, ABL, DEPTH>), grid, dim3(1024), lds, c->stream, m, wt.tiles, wt.meta,    \
-                     c->d_w, c->d_g64,                                                                                \
-                     (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8, c->dp, c->dbg,            \
-                     c->d_wlong_rows, part ? c->d_part : nullptr, c->part_stride)
-  if (c->dbg) DSGD_LAUNCH_WSEG(true, 3);   // ablation build of the same kernel (DSGD_DBG, tuning runs only)
-  else if (c->pf_depth == 4) DSGD_LAUNCH_WSEG(false, 4);
-  else DSGD_LAUNCH_WSEG(false, 3);
+#define DSGD_LAUNCH_WSEG(ABL)                                                                                          \
+  hipLaunchKernelGGL((dsgd_wseg_kernel<SCATTER, ABL, 4, false>), grid, dim3(1024), lds, c->stream, m, m, c->d_wtiles,   \
+                     c->d_wmeta, c->d_w, c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, c->fix_scale,      \
+                     c->d_coef8, c->dp, c->dbg, c->d_wlong_rows, part ? c->d_part : nullptr, c->part_stride,         \
+                     (const float*)nullptr)
+  if (c->dbg) DSGD_LAUNCH_WSEG(true);   // ablation build of the same kernel (DSGD_DBG, tuning runs only)
+  else DSGD_LAUNCH_WSEG(false);
 #undef DSGD_LAUNCH_WSEG
   HIP_TRY(hipGetLastError());
   if (SCATTER) DSGD_TRY(prof_end(c, slot));
-  if (SCATTER) c->last_grad_kernel = c->dbg ? "dsgd_wseg_kernel<true, true, 3>" : (c->pf_depth == 4 ? "dsgd_wseg_kernel<true, false, 4>" : "dsgd_wseg_kernel<true, false, 3>");
-  return finish_stream<SCATTER>(c, n_workers, part ? (int)grid.x : 0, hg);
+  if (SCATTER) c->last_grad_kernel = c->dbg ? "dsgd_wseg_kernel<true, true, 4, false>" : "dsgd_wseg_kernel<true, false, 4, false>";
+  if (!SCATTER) return DSGD_OK;
+  return finish_mode3(c, n_workers, part ? (int)grid.x : 0, hg);
+}
+
+// mode 4: hot stream in wave tiles, cold stream before (x.w) and after (gradient) it
+template <bool SCATTER>
+static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
+  const int n_workers = (int)row_segs.size();
+  std::vector<StreamSeg> segs(row_segs);
+  long long max_tiles, max_long;
+  locate_segs(c, segs, &max_tiles, &max_long);
+  DSGD_TRY(upload_ssegs(c, segs));
+  const int H = std::min(c->hsplit, c->dp);
+  const int nc = c->dp - H;                                     // cold columns
+  const int nc_lds = std::min(nc, DSGD_LDS_FLOATS - 64);        // ... of which in the LDS tile of the cold kernels
+  long long max_cold = 0;
+  for (const StreamSeg& sg : segs) max_cold = std::max(max_cold, c->h_crow_ptr[sg.row_end] - c->h_crow_ptr[sg.row_begin]);
+  const long long per_worker = std::max<long long>(1, c->n_cu / n_workers);
+  dim3 gridc((unsigned)std::max<long long>(1, std::min(per_worker, (max_cold + 16383) / 16384)), n_workers);
+  const bool cold = nc > 0 && max_cold > 0;
+  if (cold) {
+    hipLaunchKernelGGL(dsgd_cdot_kernel, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, c->d_ccol,
+                       c->d_cval, c->d_crow, c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds);
+    HIP_TRY(hipGetLastError());
+  }
+  long long bx = std::min(per_worker, std::max((max_tiles + 15) / 16, (max_long + 15) / 16));
+  dim3 grid((unsigned)std::max<long long>(1, bx), n_workers);
+  const int hw = H, hg = SCATTER ? H : 0;
+  const size_t lds = sizeof(float) * (size_t)(16 * WS_COEF_STRIDE + hw + hg + (SCATTER ? 64 : 0) + 4);
+  if (SCATTER) {
+    DSGD_TRY(ensure_part(c, &c->d_part, &c->part_wgs, &c->part_stride, (long long)grid.x * grid.y, hg));
+    if (cold) DSGD_TRY(ensure_part(c, &c->d_partc, &c->partc_wgs, &c->partc_stride, (long long)gridc.x * gridc.y, nc_lds));
+  }
+  CsrView mh = view(c);
+  mh.row_ptr = c->d_hrow_ptr;
+  mh.col = c->d_hcol;
+  mh.val = c->d_hval;
+  CsrView mf = view(c);
+  size_t slot = 0;
+  if (SCATTER) DSGD_TRY(prof_begin(c, &slot));
+  hipLaunchKernelGGL((dsgd_wseg_kernel<SCATTER, false, 4, true>), grid, dim3(1024), lds, c->stream, mh, mf, c->d_wtiles,
+                     c->d_wmeta, c->d_w, c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8,
+                     c->dp, 0, c->d_wlong_rows, SCATTER ? c->d_part : nullptr, c->part_stride, c->d_dcold);
+  HIP_TRY(hipGetLastError());
+  if (SCATTER) DSGD_TRY(prof_end(c, slot));
+  if (!SCATTER) return DSGD_OK;
+  c->last_grad_kernel = "dsgd_wseg_kernel<true, false, 4, true>";
+  if (cold) {
+    hipLaunchKernelGGL(dsgd_cgrad_kernel, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, c->d_ccol,
+                       c->d_cval, c->d_crow, c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H,
+                       nc_lds, c->fix_scale, c->d_partc, c->partc_stride);
+    HIP_TRY(hipGetLastError());
+  }
+  hipLaunchKernelGGL(dsgd_fix_reduce_kernel, dim3((c->dp + 63) / 64, n_workers), dim3(1024), 0, c->stream, c->d_g64, c->d_g,
+                     (long long)c->dp, c->dp, hg, c->d_part, c->part_stride, (int)grid.x, H, cold ? nc_lds : 0, c->d_partc,
+                     c->partc_stride, (int)gridc.x, 1.0 / (double)c->fix_scale);
+  HIP_TRY(hipGetLastError());
+  return DSGD_OK;
 }
 
 template <bool SCATTER>
 static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
-  DSGD_TRY(upload_ssegs(c, segs));
-  long long max_tiles = 1;
-  for (const auto& s : segs) max_tiles = std::max(max_tiles, s.tile_end - s.tile_begin);
-  const int n_workers = (int)segs.size();
-  long long bx = std::max<long long>(1, c->n_cu / n_workers);
-  bx = std::min(bx, max_tiles);
-  dim3 grid((unsigned)bx, n_workers);
-  CsrView m = view(c);
-  if (c->stream_mode == 3) return launch_wseg<SCATTER>(c, segs);
-  if (c->stream_mode == 2) {
-    const int hw = SCATTER ? c->hw_g : c->hw_ge;
-    const int hg = SCATTER ? c->hg_g : 0;
-    const size_t lds = sizeof(float) * (size_t)(SG_LDS_FIXED + hw + hg + 2);
-    SegTables st;
-    st.tile_row = c->d_tile_row;
-    st.tile_pos = c->d_tile_pos;
-    st.tile_meta = c->d_tile_meta;
-    size_t slot = 0;
-    if (SCATTER) DSGD_TRY(prof_begin(c, &slot));
-    hipLaunchKernelGGL(dsgd_seg_kernel<SCATTER>, grid, dim3(ST_THREADS), lds, c->stream, m, st, c->d_w, c->d_g64,
-                       (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8, c->dbg);
-    HIP_TRY(hipGetLastError());
-    if (SCATTER) DSGD_TRY(prof_end(c, slot));
-    if (SCATTER) c->last_grad_kernel = "dsgd_seg_kernel<true>";
-    return finish_stream<SCATTER>(c, n_workers);
-  }
-  const int hw = SCATTER ? c->hw_s : c->hw_se;
-  const int hg = SCATTER ? c->hg_s : 0;
-  const size_t lds = sizeof(float) * (size_t)(ST_FIXED_FLOATS + hw + hg);
-  TileTables tt;
-  tt.tile_row = c->d_tile_row;
-  tt.tile_pos = c->d_tile_pos;
-  tt.tile_vptr = c->d_tile_vptr;
-  tt.vrow = c->d_vrow;
-  tt.n_vrow = c->n_vrow;
-  tt.tile_rp = c->d_tile_rp;
-  tt.n_tile_rp = c->n_tile_rp;
-  const float scale = c->fix_scale;
-  size_t slot1 = 0;
-  if (SCATTER) DSGD_TRY(prof_begin(c, &slot1));
-#define DSGD_LAUNCH_STREAM(GG)                                                                                       \
-  hipLaunchKernelGGL((dsgd_stream_kernel<GG, SCATTER, false>), grid, dim3(ST_THREADS), lds, c->stream, m, tt, c->d_w,  \
-                     c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, scale, c->d_coef8)
-  switch (c->group) {
-    case 64: DSGD_LAUNCH_STREAM(64); if (SCATTER) c->last_grad_kernel = "dsgd_stream_kernel<64, true"; break;
-    case 32: DSGD_LAUNCH_STREAM(32); if (SCATTER) c->last_grad_kernel = "dsgd_stream_kernel<32, true"; break;
-    case 16: DSGD_LAUNCH_STREAM(16); if (SCATTER) c->last_grad_kernel = "dsgd_stream_kernel<16, true"; break;
-    default: DSGD_LAUNCH_STREAM(8); if (SCATTER) c->last_grad_kernel = "dsgd_stream_kernel<8, true"; break;
-  }
-#undef DSGD_LAUNCH_STREAM
-  HIP_TRY(hipGetLastError());
-  if (SCATTER) DSGD_TRY(prof_end(c, slot1));
-  return finish_stream<SCATTER>(c, n_workers);
+  if (c->stream_mode == 4) return launch_split<SCATTER>(c, segs);
+  return launch_wseg<SCATTER>(c, segs);
 }
 
 static int require_data(dsgd_ctx* c) {
@@ -871,17 +1049,13 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   c->hg = std::max(0, std::min(c->hg, c->dp));
   if (c->hw + c->hg > DSGD_LDS_FLOATS) return bail(fail(DSGD_EINVAL, "DSGD_HW + DSGD_HG exceed %d floats of LDS", DSGD_LDS_FLOATS));
   c->hw_eval = std::min(c->dp, DSGD_LDS_FLOATS);
-  if (const char* e = getenv("DSGD_HW_S")) c->hw_s = atoi(e);
-  if (const char* e = getenv("DSGD_HG_S")) c->hg_s = atoi(e);
-  if (const char* e = getenv("DSGD_STREAM")) {
+  if (const char* e = getenv("DSGD_STREAM")) {   // 0: row-wise kernels only, 3: wave tiles + gathers, 4: split matrix
     c->stream_ranges = atoi(e) != 0;
-    if (atoi(e) >= 1 && atoi(e) <= 3) c->stream_mode = atoi(e);
+    if (atoi(e) == 3 || atoi(e) == 4) c->stream_mode = atoi(e);
   }
   if (const char* e = getenv("DSGD_EPI")) c->use_part = atoi(e) != 0;
   if (const char* e = getenv("DSGD_DBG")) c->dbg = atoi(e);
-  if (const char* e = getenv("DSGD_PF")) c->pf_depth = atoi(e) == 3 ? 3 : 4;
-  if (const char* e = getenv("DSGD_HW_G")) c->hw_g = atoi(e);
-  if (const char* e = getenv("DSGD_HG_G")) c->hg_g = atoi(e);
+  if (c->dbg) c->stream_mode = 3;   // the ablation build exists for the mode-3 kernel
   if (const char* e = getenv("DSGD_HW_W")) c->hw_w = atoi(e);
   if (const char* e = getenv("DSGD_HG_W")) c->hg_w = atoi(e);
   c->hw_w = std::max(0, std::min(c->hw_w, c->dp));
@@ -889,17 +1063,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   c->hw_we = std::min(c->hw_we, c->dp);
   if (c->hw_w + c->hg_w > DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64)
     return bail(fail(DSGD_EINVAL, "DSGD_HW_W + DSGD_HG_W exceed %d floats of LDS", DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64));
-  c->hw_g = std::max(0, std::min(c->hw_g, c->dp));
-  c->hg_g = std::max(0, std::min(c->hg_g, c->dp));
-  c->hw_ge = std::min(c->hw_ge, c->dp);
-  if (c->hw_g + c->hg_g > DSGD_LDS_FLOATS - SG_LDS_FIXED)
-    return bail(fail(DSGD_EINVAL, "DSGD_HW_G + DSGD_HG_G exceed %d floats of LDS", DSGD_LDS_FLOATS - SG_LDS_FIXED));
-  if (const char* e = getenv("DSGD_PF_EARLY")) c->pf_early = atoi(e) != 0;
-  c->hw_s = std::max(0, std::min(c->hw_s, c->dp));
-  c->hg_s = std::max(0, std::min(c->hg_s, c->dp));
-  c->hw_se = std::min(c->hw_se, c->dp);
-  if (c->hw_s + c->hg_s > DSGD_LDS_FLOATS - ST_FIXED_FLOATS)
-    return bail(fail(DSGD_EINVAL, "DSGD_HW_S + DSGD_HG_S exceed %d floats of LDS", DSGD_LDS_FLOATS - ST_FIXED_FLOATS));
+  if (const char* e = getenv("DSGD_HSPLIT")) c->hsplit = atoi(e);
+  c->hsplit = std::max(1, std::min(c->hsplit, (DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64) / 2));
   const int lds_max = DSGD_LDS_FLOATS * (int)sizeof(float);
 #define DSGD_ATTR(fn) HIP_TRY_B(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max))
   DSGD_ATTR(dsgd_grad_tiled_kernel<64>);
@@ -911,23 +1076,15 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_eval_kernel<16>);
   DSGD_ATTR(dsgd_eval_kernel<8>);
   DSGD_ATTR(dsgd_colcount_kernel);
-  DSGD_ATTR((dsgd_stream_kernel<64, true, false>));
-  DSGD_ATTR((dsgd_stream_kernel<64, false, false>));
-  DSGD_ATTR((dsgd_stream_kernel<32, true, false>));
-  DSGD_ATTR((dsgd_stream_kernel<32, false, false>));
-  DSGD_ATTR((dsgd_stream_kernel<16, true, false>));
-  DSGD_ATTR((dsgd_stream_kernel<16, false, false>));
-  DSGD_ATTR((dsgd_stream_kernel<8, true, false>));
-  DSGD_ATTR((dsgd_stream_kernel<8, false, false>));
   DSGD_ATTR(dsgd_hogwild_kernel);
-  DSGD_ATTR((dsgd_wseg_kernel<true, false, 3>));
-  DSGD_ATTR((dsgd_wseg_kernel<true, false, 4>));
-  DSGD_ATTR((dsgd_wseg_kernel<true, true, 3>));
-  DSGD_ATTR((dsgd_wseg_kernel<false, false, 3>));
-  DSGD_ATTR((dsgd_wseg_kernel<false, false, 4>));
-  DSGD_ATTR((dsgd_wseg_kernel<false, true, 3>));
-  DSGD_ATTR(dsgd_seg_kernel<true>);
-  DSGD_ATTR(dsgd_seg_kernel<false>);
+  DSGD_ATTR((dsgd_wseg_kernel<true, false, 4, false>));
+  DSGD_ATTR((dsgd_wseg_kernel<true, true, 4, false>));
+  DSGD_ATTR((dsgd_wseg_kernel<false, false, 4, false>));
+  DSGD_ATTR((dsgd_wseg_kernel<false, true, 4, false>));
+  DSGD_ATTR((dsgd_wseg_kernel<true, false, 4, true>));
+  DSGD_ATTR((dsgd_wseg_kernel<false, false, 4, true>));
+  DSGD_ATTR(dsgd_cdot_kernel);
+  DSGD_ATTR(dsgd_cgrad_kernel);
 #undef DSGD_ATTR
   HIP_TRY_B(hipStreamSynchronize(c->stream));
 #undef HIP_TRY_B
@@ -959,22 +1116,25 @@ int dsgd_destroy(dsgd_ctx* c) {
   hipFree(c->d_sc);
   hipFree(c->d_idx);
   hipFree(c->d_segs);
-  hipFree(c->d_tile_row);
-  hipFree(c->d_tile_pos);
-  hipFree(c->d_tile_vptr);
-  hipFree(c->d_tile_rp);
-  hipFree(c->d_vrow);
   hipFree(c->d_ssegs);
   hipFree(c->d_cold_ptr);
   hipFree(c->d_cold_row);
   hipFree(c->d_cold_val);
   hipFree(c->d_coef8);
   hipFree(c->d_coefp);
-  hipFree(c->d_tile_meta);
   hipFree(c->d_wtiles);
   hipFree(c->d_wmeta);
   hipFree(c->d_wlong_rows);
   hipFree(c->d_part);
+  hipFree(c->d_partc);
+  hipFree(c->d_hcol);
+  hipFree(c->d_hval);
+  hipFree(c->d_hrow_ptr);
+  hipFree(c->d_ccol);
+  hipFree(c->d_cval);
+  hipFree(c->d_crow);
+  hipFree(c->d_crow_ptr);
+  hipFree(c->d_dcold);
   if (c->async_stream) {
     if (c->h_stop) *c->h_stop = 1;
     hipStreamSynchronize(c->async_stream);
@@ -1079,205 +1239,15 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr_in, const 
     if (vmax > 0.0f && std::ldexp(1.0f, e - 1) == vmax) e -= 1;  // vmax itself a power of two
     c->fix_scale = std::ldexp(1.0f, FIX_SHIFT - e);
   }
-  {
-    // tiles of consecutive rows with <= ST_MAXNNZ non-zeros and <= ST_MAXROWS rows (greedy)
-    std::vector<int>& tr = c->h_tile_row;
-    std::vector<long long> tp;
-    tr.clear();
-    c->long_rows.clear();
-    tr.push_back(0);
-    tp.push_back(0);
-    int64_t start = 0;
-    for (int64_t i = 0; i < n_rows; ++i) {
-      const int64_t len = row_ptr[i + 1] - row_ptr[i];
-      if (len > ST_MAXNNZ) {  // over-long row: its own tile, skipped by the streaming kernels
-        if (i > start) {
-          tr.push_back((int)i);
-          tp.push_back(row_ptr[i]);
-        }
-        tr.push_back((int)(i + 1));
-        tp.push_back(row_ptr[i + 1]);
-        c->long_rows.push_back(i);
-        start = i + 1;
-        continue;
-      }
-      if (row_ptr[i + 1] - row_ptr[start] > ST_MAXNNZ || i - start >= ST_MAXROWS) {
-        tr.push_back((int)i);
-        tp.push_back(row_ptr[i]);
-        start = i;
-      }
-    }
-    if (tr.back() != (int)n_rows) {
-      tr.push_back((int)n_rows);
-      tp.push_back(row_ptr[n_rows]);
-    }
-    c->n_tiles = (long long)tr.size() - 1;
-    // virtual rows: every row is cut into chunks of <= ST_VCHUNK non-zeros; entry = (local row << 16) |
-    // (chunk index << 1) | last-chunk flag.  An empty row still gets one (empty, last) chunk.
-    std::vector<long long> vptr(tr.size());
-    std::vector<int> vrow;
-    vrow.reserve((size_t)(nnz / ST_VCHUNK + n_rows + 16));
-    for (size_t t = 0; t + 1 < tr.size(); ++t) {
-      vptr[t] = (long long)vrow.size();
-      if (tp[t + 1] - tp[t] > ST_MAXNNZ) continue;  // over-long row: no virtual rows, skipped by the kernel
-      for (int r = tr[t]; r < tr[t + 1]; ++r) {
-        const int64_t len = row_ptr[r + 1] - row_ptr[r];
-        const int nch = (int)std::max<int64_t>(1, (len + ST_VCHUNK - 1) / ST_VCHUNK);
-        for (int k = 0; k < nch; ++k) vrow.push_back(((r - tr[t]) << 16) | (k << 1) | (k == nch - 1 ? 1 : 0));
-      }
-      if ((long long)vrow.size() - vptr[t] > ST_MAXV) return fail(DSGD_EINVAL, "internal: tile with too many virtual rows");
-    }
-    vptr[tr.size() - 1] = (long long)vrow.size();
-    if (vrow.empty()) vrow.push_back(1);
-    c->n_vrow = (long long)vrow.size();
-    // per-tile row offsets relative to the tile's 16-byte aligned window start (int32: 4 B/row of traffic)
-    std::vector<int> trp((size_t)n_rows + tr.size() - 1);
-    for (size_t t = 0; t + 1 < tr.size(); ++t) {
-      const long long pos0 = tp[t] & ~3LL;
-      const size_t base = (size_t)tr[t] + t;
-      for (int r = tr[t]; r <= tr[t + 1]; ++r) trp[base + (size_t)(r - tr[t])] = (int)std::min<long long>(row_ptr[r] - pos0, 1 << 30);
-    }
-    c->n_tile_rp = (long long)trp.size();
-    hipFree(c->d_tile_rp);
-    c->d_tile_rp = nullptr;
-    HIP_TRY(hipMalloc(&c->d_tile_rp, sizeof(int) * trp.size()));
-    HIP_TRY(hipMemcpy(c->d_tile_rp, trp.data(), sizeof(int) * trp.size(), hipMemcpyHostToDevice));
-    // lane descriptors of the seg kernels: lane l of tile t owns slots [4l, 4l+4) of the window at pos0;
-    // descriptor = (row-start bits of its 4 slots) << 9 | local row of slot 4l.  Local rows are 1-based:
-    // 0 = padding before the tile's first non-zero, nrows + 1 = padding after its last one.
-    {
-      std::vector<unsigned short> meta((size_t)c->n_tiles * ST_THREADS, 0);
-      for (size_t t = 0; t + 1 < tr.size(); ++t) {
-        unsigned short* mt = meta.data() + t * ST_THREADS;
-        if (tp[t + 1] - tp[t] > ST_MAXNNZ) continue;  // over-long row: the kernel treats the tile as padding
-        const long long pos0 = tp[t] & ~3LL;
-        const int nr = tr[t + 1] - tr[t];
-        // row starts (slot index relative to pos0), plus the end mark that starts the trailing padding
-        int lane = 0;
-        int cur_row = 0;  // local row of the slot being visited
-        int next = 0;     // next row to start (0-based within the tile)
-        for (lane = 0; lane < ST_THREADS; ++lane) {
-          int bits = 0, first_row = -1;
-          for (int k = 0; k < 4; ++k) {
-            const long long slot = 4LL * lane + k;
-            bool start = false;
-            if (next < nr && row_ptr[tr[t] + next] - pos0 == slot) {
-              start = true;
-              ++next;
-            } else if (next == nr && row_ptr[tr[t + 1]] - pos0 == slot) {
-              start = true;  // end mark
-              ++next;
-            }
-            if (start) {
-              bits |= 1 << k;
-              ++cur_row;
-            }
-            if (k == 0) first_row = cur_row;
-          }
-          mt[lane] = (unsigned short)((bits << 9) | first_row);
-        }
-      }
-      hipFree(c->d_tile_meta);
-      c->d_tile_meta = nullptr;
-      HIP_TRY(hipMalloc(&c->d_tile_meta, sizeof(unsigned short) * std::max<size_t>(meta.size(), 1)));
-      HIP_TRY(hipMemcpy(c->d_tile_meta, meta.data(), sizeof(unsigned short) * meta.size(), hipMemcpyHostToDevice));
-    }
-    // wave tiles of the wseg kernels: whole rows, <= WS_MAXNNZ non-zeros, <= WS_MAXROWS rows; longer rows are
-    // listed in wlong_rows.  Lane l owns the 8 contiguous slots [8l, 8l+8) of the window at pos0.
-    // Lane descriptor: local row of its first slot (8 bits) | row-start bits << 8 | label sign of the row ENDING
-    // at each start << 16.
-    {
-      std::vector<WTile> wt;
-      std::vector<int>& wr0 = c->h_wtile_r0;
-      wr0.clear();
-      c->wlong_rows.clear();
-      int64_t start = -1;  // first row of the open tile
-      auto close = [&](int64_t end_row) {
-        if (start < 0) return;
-        WTile t;
-        t.pos0 = row_ptr[start] & ~3LL;
-        t.r0 = (int)start;
-        t.nrows = (int)(end_row - start);
-        wt.push_back(t);
-        wr0.push_back((int)start);
-        start = -1;
-      };
-      for (int64_t i = 0; i < n_rows; ++i) {
-        const int64_t len = row_ptr[i + 1] - row_ptr[i];
-        if (len > WS_MAXNNZ) {
-          close(i);
-          c->wlong_rows.push_back(i);
-          continue;
-        }
-        if (start >= 0 && (row_ptr[i + 1] - (row_ptr[start] & ~3LL) > WS_SLOTS - 1 || i - start >= WS_MAXROWS)) close(i);
-        if (start < 0) start = i;
-      }
-      close(n_rows);
-      wr0.push_back((int)n_rows);
-      c->n_wtiles = (long long)wt.size();
-      std::vector<unsigned int> wm((size_t)std::max<long long>(c->n_wtiles, 1) * 64, 0u);
-      for (long long t = 0; t < c->n_wtiles; ++t) {
-        const WTile& T = wt[(size_t)t];
-        int cur_row = 0, next = 0;
-        for (int l = 0; l < 64; ++l) {  // lane l owns slots [8l, 8l+8)
-          unsigned int bits = 0, ys = 0;
-          int first_row = 0;
-          for (int k = 0; k < 8; ++k) {
-            const long long slot = 8LL * l + k;
-            bool st = false;
-            if (next < T.nrows && row_ptr[T.r0 + next] - T.pos0 == slot) st = true;
-            else if (next == T.nrows && row_ptr[T.r0 + T.nrows] - T.pos0 == slot) st = true;  // end mark
-            if (st) {
-              bits |= 1u << k;
-              // the row that ends here is local row cur_row (1-based); row 0 = leading padding
-              if (cur_row >= 1 && label[T.r0 + cur_row - 1] > 0) ys |= 1u << k;
-              ++cur_row;
-              ++next;
-            }
-            if (k == 0) first_row = cur_row;
-          }
-          wm[(size_t)t * 64 + l] = (unsigned int)first_row | (bits << 8) | (ys << 16);
-        }
-      }
-      hipFree(c->d_wtiles);
-      hipFree(c->d_wmeta);
-      c->d_wtiles = nullptr;
-      c->d_wmeta = nullptr;
-      if (wt.empty()) {
-        WTile t;
-        t.pos0 = 0;
-        t.r0 = 0;
-        t.nrows = -1;
-        wt.push_back(t);
-      }
-      HIP_TRY(hipMalloc(&c->d_wtiles, sizeof(WTile) * wt.size()));
-      HIP_TRY(hipMalloc(&c->d_wmeta, sizeof(unsigned int) * wm.size()));
-      HIP_TRY(hipMemcpy(c->d_wtiles, wt.data(), sizeof(WTile) * wt.size(), hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(c->d_wmeta, wm.data(), sizeof(unsigned int) * wm.size(), hipMemcpyHostToDevice));
-      hipFree(c->d_wlong_rows);
-      c->d_wlong_rows = nullptr;
-      std::vector<int> lr(c->wlong_rows.begin(), c->wlong_rows.end());
-      lr.push_back(0);
-      HIP_TRY(hipMalloc(&c->d_wlong_rows, sizeof(int) * lr.size()));
-      HIP_TRY(hipMemcpy(c->d_wlong_rows, lr.data(), sizeof(int) * lr.size(), hipMemcpyHostToDevice));
-    }
-    hipFree(c->d_tile_row);
-    hipFree(c->d_tile_pos);
-    hipFree(c->d_tile_vptr);
-    hipFree(c->d_vrow);
-    c->d_tile_row = nullptr;
-    c->d_tile_pos = nullptr;
-    c->d_tile_vptr = nullptr;
-    c->d_vrow = nullptr;
-    HIP_TRY(hipMalloc(&c->d_tile_vptr, sizeof(long long) * vptr.size()));
-    HIP_TRY(hipMalloc(&c->d_vrow, sizeof(int) * vrow.size()));
-    HIP_TRY(hipMemcpy(c->d_tile_vptr, vptr.data(), sizeof(long long) * vptr.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_vrow, vrow.data(), sizeof(int) * vrow.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&c->d_tile_row, sizeof(int) * tr.size()));
-    HIP_TRY(hipMalloc(&c->d_tile_pos, sizeof(long long) * tp.size()));
-    HIP_TRY(hipMemcpy(c->d_tile_row, tr.data(), sizeof(int) * tr.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_tile_pos, tp.data(), sizeof(long long) * tp.size(), hipMemcpyHostToDevice));
-    c->ssegs_last.clear();
+  c->h_row_ptr.assign(row_ptr, row_ptr + n_rows + 1);
+  c->h_label.assign(label, label + n_rows);
+  c->ssegs_last.clear();
+  // mode 3 tiles cover the CSR as loaded; mode 4 tiles cover the hot stream and are built with the layout
+  if (c->stream_mode == 3) {
+    HostTiles ht;
+    c->wlong_rows.clear();
+    build_wave_tiles(c->h_row_ptr.data(), n_rows, c->h_label.data(), ht, &c->wlong_rows);
+    DSGD_TRY(upload_wave_tiles(c, ht));
   }
   const double mean = (double)nnz / (double)n_rows;
   c->group = mean > 192.0 ? 64 : (mean > 96.0 ? 32 : (mean > 12.0 ? 16 : 8));
@@ -1486,15 +1456,6 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
   return finish_stats(c, stats, tot);
 }
 
-static bool any_long_row(dsgd_ctx* c, const int64_t* row_begin, const int64_t* row_end, int n) {
-  if (c->long_rows.empty()) return false;
-  for (int k = 0; k < n; ++k) {
-    auto it = std::lower_bound(c->long_rows.begin(), c->long_rows.end(), (long long)row_begin[k]);
-    if (it != c->long_rows.end() && *it < row_end[k]) return true;
-  }
-  return false;
-}
-
 static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* row_end, int n_workers, float lr,
                           long long* total) {
   if (n_workers < 1 || !row_begin || !row_end) return fail(DSGD_EINVAL, "need at least one worker");
@@ -1517,10 +1478,10 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
   DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_g(c, n_workers));
   DSGD_TRY(ensure_s(c));
-  if (c->stream_ranges && tot >= c->tiled_min && (c->stream_mode == 3 || !any_long_row(c, row_begin, row_end, n_workers))) {
+  if (c->stream_ranges && tot >= c->tiled_min) {
     // whole contiguous ranges: the nnz-streaming kernel (coalesced 16-byte loads, no per-row latency chain)
     std::vector<StreamSeg> ssegs(n_workers);
-    for (int k = 0; k < n_workers; ++k) ssegs[k] = make_sseg(c, row_begin[k], row_end[k]);
+    for (int k = 0; k < n_workers; ++k) ssegs[k] = make_sseg(row_begin[k], row_end[k]);
     DSGD_TRY(launch_stream<true>(c, ssegs));  // (the profiling events bracket the main kernel only)
   } else {
     DSGD_TRY(upload_segs(c, segs));
@@ -1699,9 +1660,8 @@ int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_en
   if (w) DSGD_TRY(set_weights_locked(c, w));
   DSGD_TRY(ensure_s(c));  // also refreshes |w|^2
   DSGD_TRY(reset_counters(c));
-  if (!c->async_running && c->stream_ranges && row_end - row_begin >= 4096 &&
-      (c->stream_mode == 3 || !any_long_row(c, &row_begin, &row_end, 1))) {
-    std::vector<StreamSeg> ssegs(1, make_sseg(c, row_begin, row_end));
+  if (!c->async_running && c->stream_ranges && row_end - row_begin >= 4096) {
+    std::vector<StreamSeg> ssegs(1, make_sseg(row_begin, row_end));
     DSGD_TRY(launch_stream<false>(c, ssegs));
   } else {
     const int G = c->group;

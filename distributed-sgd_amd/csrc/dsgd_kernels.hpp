@@ -550,338 +550,28 @@ __global__ void dsgd_ds_kernel(const unsigned int* __restrict__ cnt, const int* 
 }
 
 // ======================================================================================================
-// K1c / K5b: nnz-STREAMING kernels for contiguous row ranges (whole-shard batches, evaluation passes)
+// K1c / K5b: nnz-STREAMING kernels for contiguous row ranges -- shared pieces
 // ======================================================================================================
-// The row-per-group kernels above chain two dependent memory round trips per row (row_ptr -> col/val)
-// and top out near 1.2 TB/s on MI355X.  Here the HBM stream is decoupled from the row structure:
-//   * at load time the rows are cut into TILES of consecutive rows with <= ST_MAXNNZ non-zeros;
-//   * a 1024-lane workgroup reads a tile's col/val with one 16-byte load per lane and array
-//     (lane l owns non-zeros [pos0 + 4l, pos0 + 4l + 4), pos0 16-byte aligned) -- addresses depend
-//     only on tile_pos[], so the NEXT tile's loads are issued before the current tile is processed;
-//   * products v * w[c] go to LDS; rows are reduced from LDS by groups of G lanes (fixed order, so
-//     x.w is reproducible); the gate coefficient y*[y(x.w) >= 0] is written back over the row's
-//     products; each lane then scatters its own four non-zeros (still in registers) into the LDS
-//     gradient tile (ds_add_f32) or, for the cold tail, into L2.
-// LDS per workgroup (floats): 2*4096 products (double buffer) + 1028 row offsets + 1024 labels
-//                             + hg gradient tile + hw weight tile  <= 40960.
-constexpr int ST_THREADS = 1024;
-constexpr int ST_TILE = 4096;             // non-zeros per tile slot (4 per lane)
-constexpr int ST_MAXNNZ = ST_TILE - 4;    // pos0 is rounded down to a multiple of 4; slot 4095 stays free for the end mark
-constexpr int ST_MAXROWS = 496;           // rows per tile (<= FIX_ROWS_PER_SCAN, one lane stages one row offset)
-constexpr int ST_VCHUNK = 64;             // non-zeros per virtual row (a row is cut into chunks of <= 64)
-constexpr int ST_MAXV = ST_MAXROWS + ST_TILE / ST_VCHUNK + 16;  // virtual rows per tile, padded to 576
-// double-buffered small arrays: row offsets, labels, virtual-row entries, virtual-row partial sums
-constexpr int ST_SMALL = (ST_MAXROWS + 4) + ST_MAXROWS + ST_MAXV + ST_MAXV;
-constexpr int ST_FIXED_FLOATS = 2 * ST_TILE + 2 * ST_SMALL + ST_MAXROWS;
+// The row-per-group kernels above chain two dependent memory round trips per row (row_ptr -> col/val) and top
+// out near 1.2 TB/s on MI355X.  The streaming kernels decouple the HBM stream from the row structure: rows are
+// cut at load time into tiles whose addresses are known without row_ptr, so tiles are prefetched while earlier
+// ones are processed.  (Two earlier generations -- LDS-staged products, then workgroup tiles with a register
+// segmented scan -- are in the git history; profiles/README.md keeps their measurements.)
 
 // Fixed-point gradient accumulation.  Measured on MI355X (tools/microbench3.hip): ds_add_f32 retires
 // 0.31 lanes/clk/CU (188 Gnnz/s chip-wide) while ds_add_u32 runs at the HBM streaming rate
 // (671 Gnnz/s).  The scatter therefore accumulates round(y*x * 2^21 / vmax2) as 32-bit integers in
-// LDS (vmax2 = max|x| rounded up to a power of two, so the scaling is exact).  Overflow control: a
-// column receives at most one contribution per row and |contribution| <= 2^21; every <= 700 rows the
-// workgroup scans its tile and moves only the entries with |q| >= 2^29 to the 64-bit global
-// accumulators, so an entry never exceeds 2^29 + 700 * 2^21 < 2^31.  Only truly hot columns are
-// ever moved; everything else leaves LDS once, at the end of the kernel.  Integer addition is
+// LDS (vmax2 = max|x| rounded up to a power of two, so the scaling is exact; overflow control of the
+// 32-bit accumulators: see w_scatter).  Integer addition is
 // associative: the gradient of a whole-shard batch is bit-reproducible run to run, and exact up to
 // the 2^-22 * vmax2 rounding of each contribution (fp32 atomics round at the ulp of the RUNNING sum).
 constexpr int FIX_SHIFT = 21;
-constexpr int FIX_ROWS_PER_SCAN = 700;
-constexpr int FIX_SPILL_AT = 1 << 29;
 
 struct StreamSeg {
   long long row_begin, row_end;    // rows of this worker's batch
   long long tile_begin, tile_end;  // tiles intersecting [row_begin, row_end)
   long long long_begin, long_end;  // wave-tile mode: range of the long-row list (rows that fit no tile)
 };
-
-// tile tables built at load time (dsgd_hip.hip: build_tiles)
-struct TileTables {
-  const int* __restrict__ tile_row;        // n_tiles + 1: first row of each tile
-  const long long* __restrict__ tile_pos;  // n_tiles + 1: row_ptr[tile_row[t]]
-  const long long* __restrict__ tile_vptr; // n_tiles + 1: offsets into vrow
-  const int* __restrict__ tile_rp;         // n_rows + n_tiles: per tile nrows+1 row offsets relative to pos0,
-                                           //   tile t's block starts at tile_row[t] + t
-  const int* __restrict__ vrow;            // virtual rows: (local row << 16) | (chunk index << 1) | last-chunk flag
-  long long n_vrow;
-  long long n_tile_rp;
-};
-
-struct TileRegs {
-  int4 c;
-  float4 v;
-  float gw[4];    // weights of the tile's COLD columns (gathered one tile ahead of their use)
-  int rp;         // offset of row r0 + lane relative to pos0 (lanes <= nrows)
-  float y;        // label of row r0 + lane (lanes < nrows)
-  int ve;         // virtual-row entry of lane (lanes < nv)
-  int lo_rel, hi_rel;  // the tile's non-zeros are slots [lo_rel, hi_rel) of the 4096-slot window at pos0
-  int r0, nrows, nv;
-};
-
-// Issue the loads of tile t.  Every load is UNCONDITIONAL (tile index and addresses are clamped,
-// results are masked later): with a branch around a VMEM instruction hipcc can no longer count its
-// s_waitcnt vmcnt(N) and falls back to vmcnt(0) in the middle of the tile.
-__device__ __forceinline__ void stream_issue(const CsrView& m, const TileTables& tt, long long t, long long t_end,
-                                             int tid, long long nnz_pad4, TileRegs& r) {
-  const bool live = t < t_end;
-  const long long tc = live ? t : t_end - 1;
-  const long long lo = tt.tile_pos[tc];
-  const long long hi = tt.tile_pos[tc + 1];
-  const long long pos0 = lo & ~3LL;
-  r.r0 = tt.tile_row[tc];
-  r.nrows = tt.tile_row[tc + 1] - r.r0;
-  const long long v0 = tt.tile_vptr[tc];
-  r.nv = (int)(tt.tile_vptr[tc + 1] - v0);
-  r.lo_rel = (int)(lo - pos0);
-  r.hi_rel = (int)(hi - pos0);
-  if (!live || hi - lo > ST_MAXNNZ) {  // past the end, or a single over-long row (handled row-wise elsewhere)
-    r.hi_rel = r.lo_rel;
-    r.nrows = 0;
-    r.nv = 0;
-  }
-  long long p = pos0 + 4 * tid;
-  p = p < nnz_pad4 ? p : nnz_pad4;  // col/val carry 8 elements of padding: 16-byte reads stay in bounds
-  r.c = *reinterpret_cast<const int4*>(m.col + p);
-  r.v = *reinterpret_cast<const float4*>(m.val + p);
-  const long long rp0 = (long long)r.r0 + tc;  // this tile's block of relative row offsets
-  long long ri = rp0 + tid;
-  ri = ri < tt.n_tile_rp ? ri : tt.n_tile_rp - 1;
-  r.rp = tt.tile_rp[ri];
-  long long rr = (long long)r.r0 + tid;
-  r.y = (float)m.label[rr < m.n_rows ? rr : m.n_rows - 1];
-  long long vi = v0 + tid;
-  vi = vi < tt.n_vrow ? vi : tt.n_vrow - 1;
-  r.ve = tt.vrow[vi];
-}
-
-// cold-weight gathers of a tile whose column ids have landed (hot lanes read w[0]: one cache line)
-__device__ __forceinline__ void stream_gather(const float* __restrict__ w, int hw, TileRegs& r) {
-  r.gw[0] = w[r.c.x < hw ? 0 : r.c.x];
-  r.gw[1] = w[r.c.y < hw ? 0 : r.c.y];
-  r.gw[2] = w[r.c.z < hw ? 0 : r.c.z];
-  r.gw[3] = w[r.c.w < hw ? 0 : r.c.w];
-}
-
-struct StreamCtx {
-  signed char* coef8;  // per-row gate coefficient y*[active] for the cold-column pass
-  float* prods;   // 2 x ST_TILE
-  float* small;   // 2 x ST_SMALL
-  float* coefl;   // ST_MAXROWS
-  int* gl;
-  float* wl;
-  long long* g64;
-  long long row_begin, row_end;
-  int hw, hg;
-  float fix_scale;
-};
-
-// One tile.  `cur` holds the tile (col/val/cold weights landed), `nxt` is the next tile (col/val
-// landed): its cold-weight gathers are issued here; tile t+2 is in flight and tile t+3 is issued
-// into `far`, so two tiles (64 KiB per CU) of HBM reads stay in flight while this tile's LDS
-// phases run.  vmcnt completes in order: gathers are issued BEFORE the far tile so that the one
-// wait per tile is a counted vmcnt that leaves the far tile outstanding.  The four register sets
-// rotate by unrolling, never by copying (a v_mov of a register with a pending load would wait).
-//   S2  products v * w[c] -> LDS (16-byte store per lane)                         | barrier
-//   A   every VIRTUAL ROW (<= 64 consecutive non-zeros of one row) is summed by G lanes: balanced
-//       work whatever the row-length distribution (one 1200-non-zero row no longer stalls the tile) | barrier
-//   B   the lane owning a row's last chunk adds the row's partial sums in order -> x.w, gate/tally
-//   (gradient only)                                                                | barrier
-//   C   the gate coefficient y*[y(x.w) >= 0] is written over the row's products    | barrier
-//   S5  each lane scatters its own four non-zeros (still in registers) with ds_add_u32
-template <int G, bool SCATTER>
-__device__ __forceinline__ void stream_tile(const CsrView& m, const TileTables& tt, const float* __restrict__ w,
-                                            const StreamCtx& x, long long tile, long long stride, long long t_end,
-                                            long long nnz_pad4, int buf, TileRegs& cur, TileRegs& nxt, TileRegs& far,
-                                            int& rows_acc, unsigned int& active_local, unsigned int& c0,
-                                            unsigned int& c1, unsigned int& c2) {
-  constexpr int NG = ST_THREADS / G;
-  constexpr int IT = ST_VCHUNK / G;
-  const int tid = threadIdx.x;
-  const int sub = tid % G, gidx = tid / G;
-  stream_gather(w, x.hw, nxt);                                          // tile t+1 (its col ids landed)
-  stream_issue(m, tt, tile + 3 * stride, t_end, tid, nnz_pad4, far);     // tile t+3 (t+2 is still in flight)
-
-  float* pr = x.prods + buf * ST_TILE;
-  float* sm = x.small + buf * ST_SMALL;
-  int* rp = reinterpret_cast<int*>(sm);                               // ST_MAXROWS + 4
-  float* yl = sm + (ST_MAXROWS + 4);                                  // ST_MAXROWS
-  int* ve = reinterpret_cast<int*>(sm + (ST_MAXROWS + 4) + ST_MAXROWS);  // ST_MAXV
-  float* vpart = sm + (ST_MAXROWS + 4) + ST_MAXROWS + ST_MAXV;        // ST_MAXV
-  const int p = 4 * tid;
-  const int cc[4] = {cur.c.x, cur.c.y, cur.c.z, cur.c.w};
-  const float vv[4] = {cur.v.x, cur.v.y, cur.v.z, cur.v.w};
-  float pk[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const bool valid = (p + k >= cur.lo_rel) && (p + k < cur.hi_rel);
-    const bool hot = cc[k] < x.hw;
-    typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
-    const float a = ((lds_cvfloat*)x.wl)[(valid && hot) ? cc[k] : 0];
-    const float wv = hot ? a : cur.gw[k];
-    pk[k] = valid ? filt(vv[k] * wv) : 0.0f;  // ref: math/Sparse.scala:46 (product map, filtered)
-  }
-  *reinterpret_cast<float4*>(pr + 4 * tid) = make_float4(pk[0], pk[1], pk[2], pk[3]);
-  if (tid <= cur.nrows) rp[tid] = cur.rp;
-  if (tid < cur.nrows) yl[tid] = cur.y;
-  if (tid < cur.nv) ve[tid] = cur.ve;
-  __syncthreads();
-
-  // A: partial sums of the virtual rows, G lanes each, fixed order
-  for (int v = gidx; v < cur.nv; v += NG) {
-    const int e = ve[v];
-    const int r = e >> 16, k = (e >> 1) & 0x7fff;
-    const int s = rp[r] + k * ST_VCHUNK;
-    const int eend = min(s + ST_VCHUNK, rp[r + 1]);
-    float acc = 0.0f;
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int q = s + sub + i * G;
-      acc += (q < eend) ? pr[q] : 0.0f;
-    }
-    acc = group_sum<G>(acc);
-    if (sub == 0) vpart[v] = acc;
-  }
-  __syncthreads();
-
-  // B: x.w of every row = its partial sums added first chunk first; gate or tally
-  if (tid < cur.nv) {
-    const int e = cur.ve;
-    if (e & 1) {
-      const int r = e >> 16, k = (e >> 1) & 0x7fff;
-      float d = 0.0f;
-      for (int j = k; j >= 0; --j) d += vpart[tid - j];
-      const float y = yl[r];
-      const long long row = (long long)cur.r0 + r;
-      const bool in_range = row >= x.row_begin && row < x.row_end;
-      if (SCATTER) {
-        const bool active = in_range && !(y * d < 0.0f);  // ref: core/ml/SparseSVM.scala:27-28
-        x.coefl[r] = active ? y : 0.0f;
-        if (in_range) x.coef8[row] = (signed char)(active ? (int)y : 0);
-        if (active) active_local++;
-      } else if (in_range) {
-        const float yd = y * d;  // ref: core/ml/SparseSVM.scala:14,16
-        if (yd < 0.0f) c0++;
-        else if (yd > 0.0f) c2++;
-        else c1++;
-      }
-    }
-  }
-  if (SCATTER) {
-    __syncthreads();
-    // C: coefficient of the row over the row's products
-    for (int v = gidx; v < cur.nv; v += NG) {
-      const int e = ve[v];
-      const int r = e >> 16, k = (e >> 1) & 0x7fff;
-      const int s = rp[r] + k * ST_VCHUNK;
-      const int eend = min(s + ST_VCHUNK, rp[r + 1]);
-      const float coef = x.coefl[r];
-#pragma unroll
-      for (int i = 0; i < IT; ++i) {
-        const int q = s + sub + i * G;
-        if (q < eend) pr[q] = coef;
-      }
-    }
-    __syncthreads();
-    if (rows_acc + cur.nrows > FIX_ROWS_PER_SCAN) {
-      // move the entries that could overflow within the next FIX_ROWS_PER_SCAN rows to the 64-bit
-      // global accumulators; every lane has passed barriers since the previous tile's scatter, so
-      // gl is quiescent
-      for (int j = tid; j < x.hg; j += ST_THREADS) {
-        const int q = x.gl[j];
-        if (q >= FIX_SPILL_AT || q <= -FIX_SPILL_AT) {
-          atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
-          x.gl[j] = 0;
-        }
-      }
-      rows_acc = 0;
-      __syncthreads();
-    }
-    rows_acc += cur.nrows;
-    const float4 cf4 = *reinterpret_cast<const float4*>(pr + 4 * tid);
-    const float cf[4] = {cf4.x, cf4.y, cf4.z, cf4.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (cf[k] != 0.0f) {
-        const float xv = filt(vv[k] * cf[k]);  // x * y (ref: SparseSVM.scala:28)
-        const int c = cc[k];
-        if (xv != 0.0f) {
-          // columns >= hg are COLD: scattered L2 atomics top out near 16 G/s on MI355X, so their
-          // gradient comes from the transposed cold-column lists instead (dsgd_cold_scatter_kernel)
-          if (c < x.hg) atomicAdd(&x.gl[c], __float2int_rn(xv * x.fix_scale));  // ds_add_u32: wrap-around is exact
-        }
-      }
-    }
-  }
-}
-
-template <int G, bool SCATTER, bool PF_EARLY>
-__global__ void __launch_bounds__(ST_THREADS) dsgd_stream_kernel(CsrView m, TileTables tt, const float* __restrict__ w,
-                                                                long long* g64_base, long long g_stride,
-                                                                const StreamSeg* __restrict__ segs, DevScalars* sc,
-                                                                int hw, int hg, float fix_scale, signed char* coef8) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  StreamCtx x;
-  x.coef8 = coef8;
-  x.prods = lds;                                               // 2 x ST_TILE
-  x.small = lds + 2 * ST_TILE;                                 // 2 x ST_SMALL
-  x.coefl = x.small + 2 * ST_SMALL;                            // ST_MAXROWS
-  x.gl = reinterpret_cast<int*>(x.coefl + ST_MAXROWS);         // hg fixed-point accumulators (SCATTER only)
-  x.wl = x.coefl + ST_MAXROWS + (SCATTER ? hg : 0);            // hw
-  const int tid = threadIdx.x;
-  const StreamSeg seg = segs[blockIdx.y];
-  x.g64 = g64_base + (long long)blockIdx.y * g_stride;
-  x.row_begin = seg.row_begin;
-  x.row_end = seg.row_end;
-  x.hw = hw;
-  x.hg = hg;
-  x.fix_scale = fix_scale;
-  int rows_acc = 0;  // rows scattered into gl since it was last drained (uniform across the workgroup)
-  if (SCATTER)
-    for (int j = tid; j < hg; j += ST_THREADS) x.gl[j] = 0;
-  for (int j = tid; j < hw; j += ST_THREADS) x.wl[j] = w[j];
-  __syncthreads();
-
-  unsigned int active_local = 0, c0 = 0, c1 = 0, c2 = 0;
-  const long long nnz_pad4 = (m.row_ptr[m.n_rows] + 3) & ~3LL;  // last in-bounds 16-byte group start
-  const long long stride = gridDim.x;
-  const long long t_end = seg.tile_end;
-  long long tile = seg.tile_begin + blockIdx.x;
-  if (tile < t_end) {
-    TileRegs A, B, C, D;
-    stream_issue(m, tt, tile, t_end, tid, nnz_pad4, A);
-    stream_issue(m, tt, tile + stride, t_end, tid, nnz_pad4, B);
-    stream_issue(m, tt, tile + 2 * stride, t_end, tid, nnz_pad4, C);
-    stream_gather(w, hw, A);
-#define DSGD_TILE(CUR, NXT, FAR, BUF) \
-  stream_tile<G, SCATTER>(m, tt, w, x, tile, stride, t_end, nnz_pad4, BUF, CUR, NXT, FAR, rows_acc, active_local, c0, c1, c2)
-    for (;;) {  // period 4 = lcm(4 register sets, 2 LDS buffers)
-      DSGD_TILE(A, B, D, 0); tile += stride; if (tile >= t_end) break;
-      DSGD_TILE(B, C, A, 1); tile += stride; if (tile >= t_end) break;
-      DSGD_TILE(C, D, B, 0); tile += stride; if (tile >= t_end) break;
-      DSGD_TILE(D, A, C, 1); tile += stride; if (tile >= t_end) break;
-    }
-#undef DSGD_TILE
-  }
-
-  if (SCATTER) {
-    __syncthreads();
-    for (int j = tid; j < hg; j += ST_THREADS) {
-      const int q = x.gl[j];
-      if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
-    }
-    active_local = wave_sum_u32(active_local);
-    if ((tid & 63) == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
-  } else {
-    c0 = wave_sum_u32(c0);
-    c1 = wave_sum_u32(c1);
-    c2 = wave_sum_u32(c2);
-    if (blockIdx.x == 0 && tid == 0) atomicAdd(&sc->counts[3], (unsigned long long)(seg.row_end - seg.row_begin));
-    if ((tid & 63) == 0) {
-      if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
-      if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
-      if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
-    }
-  }
-}
 
 // fixed point -> fp32: g[j] += (float)(g64[j] * inv_scale); g64[j] = 0   (one rounding of the exact sum)
 __global__ void __launch_bounds__(1024) dsgd_fix_finalize_kernel(long long* g64_base, float* g_base, long long g_stride,
@@ -897,12 +587,15 @@ __global__ void __launch_bounds__(1024) dsgd_fix_finalize_kernel(long long* g64_
   }
 }
 
-// the same with per-workgroup partial sums (dsgd_wseg_kernel with `part`): worker k owns workgroups
-// [k * n_wg, (k + 1) * n_wg); g[j] += (float)((g64[j] + sum_wg part[wg][j]) * inv_scale) for j < hg, and the plain
-// conversion of g64 for hg <= j < dp.  Block = 64 columns x 16 workgroup phases.
+// the same with per-workgroup partial sums: worker k owns workgroups [k * n_wg, (k + 1) * n_wg) of `part` (main
+// kernel, columns [0, hg)) and [k * n_wgc, (k + 1) * n_wgc) of `partc` (dsgd_cgrad_kernel, columns [hc, hc + nc));
+// g[j] += (float)((g64[j] + sum of the partials of column j) * inv_scale), g64[j] = 0.  Fixed order, no atomics.
+// Block = 64 columns x 16 workgroup phases.
 __global__ void __launch_bounds__(1024) dsgd_fix_reduce_kernel(long long* g64_base, float* g_base, long long g_stride,
                                                               int dp, int hg, const int* __restrict__ part,
-                                                              int part_stride, int n_wg, double inv_scale) {
+                                                              int part_stride, int n_wg, int hc, int nc,
+                                                              const int* __restrict__ partc, int partc_stride,
+                                                              int n_wgc, double inv_scale) {
   __shared__ long long red[16][64];
   long long* g64 = g64_base + (long long)blockIdx.y * g_stride;
   float* g = g_base + (long long)blockIdx.y * g_stride;
@@ -912,6 +605,9 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_kernel(long long* g64_ba
   if (j < hg) {
     const int* p = part + (long long)blockIdx.y * n_wg * part_stride + j;
     for (int b = ph; b < n_wg; b += 16) q += (long long)p[(long long)b * part_stride];
+  } else if (j >= hc && j < hc + nc) {
+    const int* p = partc + (long long)blockIdx.y * n_wgc * partc_stride + (j - hc);
+    for (int b = ph; b < n_wgc; b += 16) q += (long long)p[(long long)b * partc_stride];
   }
   red[ph][cx] = q;
   __syncthreads();
@@ -1018,64 +714,7 @@ __global__ void __launch_bounds__(256) dsgd_cold_scatter_kernel(const unsigned i
   }
 }
 
-// ======================================================================================================
-// K1d / K5c: nnz-streaming kernels, register-level segmented reduction ("seg" kernels)
-// ======================================================================================================
-// Same HBM stream as dsgd_stream_kernel (one 16-byte col and val load per lane and tile, two tiles in
-// flight), but the row sums never touch LDS:
-//   * at load time every lane of every tile gets a 16-bit descriptor: the local row (1-based; 0 and
-//     nrows+1 are the padding before/after the tile's own non-zeros) of its first element and one
-//     bit per element "a row starts here";
-//   * a lane adds up its (<= 4) row fragments in registers; the fragment that continues into the next
-//     lane enters a wave-wide SEGMENTED SCAN built from DPP row_shr / row_bcast steps (VALU only);
-//   * waves exchange one carry through LDS (barrier 1); the lane holding the start of the NEXT row
-//     finalises a row: x.w, gate, tally / coefficient (LDS, 1 float per row; barrier 2);
-//   * each lane scatters its own non-zeros with ds_add_u32 (fixed point, see FIX_SHIFT).
-// LDS per workgroup: labels + coefficients + wave carries (~4 KiB); everything else is the weight
-// tile and the gradient tile: hw + hg <= 39,900 floats instead of 27,976.
-// Requires: no empty rows inside the internal CSR (dsgd_load_csr pads them with one explicit zero).
-constexpr int SG_LDS_FIXED = (ST_MAXROWS + 2) * 2 + 32 + 2;  // yl, coefl, wave carries
-
-struct SegTables {
-  const int* __restrict__ tile_row;               // n_tiles + 1
-  const long long* __restrict__ tile_pos;         // n_tiles + 1
-  const unsigned short* __restrict__ tile_meta;   // n_tiles x 1024 lane descriptors
-};
-
-struct SegRegs {
-  int4 c;
-  float4 v;
-  float gw[4];
-  float y;     // label of row r0 + lane (lanes < nrows)
-  int meta;    // (row-start bits b0..b3) << 9 | local row of element 0
-  int r0, nrows;
-};
-
-__device__ __forceinline__ void seg_issue(const CsrView& m, const SegTables& tt, long long t, long long t_end, int tid,
-                                          long long nnz_pad4, SegRegs& r) {
-  const bool live = t < t_end;
-  const long long tc = live ? t : t_end - 1;
-  const long long lo = tt.tile_pos[tc];
-  const long long hi = tt.tile_pos[tc + 1];
-  r.r0 = tt.tile_row[tc];
-  r.nrows = tt.tile_row[tc + 1] - r.r0;
-  if (!live || hi - lo > ST_MAXNNZ) r.nrows = -1;  // past the end / over-long row: every lane is padding
-  long long p = (lo & ~3LL) + 4 * tid;
-  p = p < nnz_pad4 ? p : nnz_pad4;
-  r.c = *reinterpret_cast<const int4*>(m.col + p);
-  r.v = *reinterpret_cast<const float4*>(m.val + p);
-  r.meta = tt.tile_meta[tc * ST_THREADS + tid];
-  const long long rr = (long long)r.r0 + tid;
-  r.y = (float)m.label[rr < m.n_rows ? rr : m.n_rows - 1];
-}
-
-__device__ __forceinline__ void seg_gather(const float* __restrict__ w, int hw, SegRegs& r) {
-  r.gw[0] = w[r.c.x < hw ? 0 : r.c.x];
-  r.gw[1] = w[r.c.y < hw ? 0 : r.c.y];
-  r.gw[2] = w[r.c.z < hw ? 0 : r.c.z];
-  r.gw[3] = w[r.c.w < hw ? 0 : r.c.w];
-}
-
+// segmented scan over the 64 lanes of a wave, DPP only (no LDS round trip)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_get_f(float src) {  // lanes without a source (or masked rows) read 0
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
@@ -1101,213 +740,6 @@ __device__ __forceinline__ void wave_seg_scan(float& v, int& f) {
   seg_scan_step<0x118, 0xf>(v, f);  // row_shr:8
   seg_scan_step<0x142, 0xa>(v, f);  // row_bcast:15 -> rows 1 and 3
   seg_scan_step<0x143, 0xc>(v, f);  // row_bcast:31 -> rows 2 and 3
-}
-
-struct SegCtx {
-  signed char* coef8;
-  float* yl;      // ST_MAXROWS + 2 (local rows are 1-based)
-  float* coefl;   // ST_MAXROWS + 2
-  float* wc_v;    // 16 wave carries
-  int* wc_f;      // 16
-  int* gl;
-  float* wl;
-  long long* g64;
-  long long row_begin, row_end;
-  int hw, hg;
-  float fix_scale;
-  int dbg;  // ablation switches for tuning runs (0 in production)
-};
-
-template <bool SCATTER>
-__device__ __forceinline__ void seg_tile(const CsrView& m, const SegTables& tt, const float* __restrict__ w,
-                                         const SegCtx& x, long long tile, long long stride, long long t_end,
-                                         long long nnz_pad4, SegRegs& cur, SegRegs& nxt, SegRegs& far, int& rows_acc,
-                                         unsigned int& active_local, unsigned int& c0, unsigned int& c1,
-                                         unsigned int& c2) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  seg_gather(w, x.hw, nxt);                                       // tile t+1 (its col ids landed)
-  seg_issue(m, tt, tile + 3 * stride, t_end, tid, nnz_pad4, far);  // tile t+3 (t+2 is still in flight)
-
-  const int nrows = cur.nrows;                    // -1: nothing to do in this tile (all padding)
-  const int rf = nrows < 0 ? 0 : (cur.meta & 511);
-  const int bits = nrows < 0 ? 0 : (cur.meta >> 9);
-  const int cc[4] = {cur.c.x, cur.c.y, cur.c.z, cur.c.w};
-  const float vv[4] = {cur.v.x, cur.v.y, cur.v.z, cur.v.w};
-  float pk[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const bool hot = cc[k] < x.hw;
-    typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
-    const float a = (x.dbg & 16) ? 1.0f : ((lds_cvfloat*)x.wl)[hot ? cc[k] : 0];
-    pk[k] = filt(vv[k] * (hot ? a : cur.gw[k]));  // ref: math/Sparse.scala:46 (product map, filtered)
-  }
-  if (tid < nrows) x.yl[tid + 1] = cur.y;
-
-  // fragment that continues into the next lane, and whether a row starts inside this lane
-  float trail = 0.0f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if ((bits >> k) & 1) trail = 0.0f;
-    trail += pk[k];
-  }
-  float s = trail;
-  int f = bits != 0;
-  if (!(x.dbg & 8)) wave_seg_scan(s, f);
-  float incoming = dpp_get_f<0x138, 0xf>(s);  // wave_shr:1 -> running sum of the row entering this lane
-  const int head_before = dpp_get_i<0x138, 0xf>(f);
-  if (lane == 63) {
-    x.wc_v[wave] = s;
-    x.wc_f[wave] = f;
-  }
-  if (!(x.dbg & 4)) __syncthreads();
-  if (SCATTER && tid == 0) {  // (after the barrier: every lane is done with the previous tile's coefficients)
-    x.coefl[0] = 0.0f;                          // padding before the tile's first row
-    x.coefl[nrows < 0 ? 1 : nrows + 1] = 0.0f;  // ... and after its last row
-  }
-  {
-    // carry of the row entering this wave: sums of the preceding waves back to the last one holding a
-    // row start (wave 0 always holds one: the tile's first row starts in its lane 0), ascending order
-    float carry = 0.0f;
-    int j0 = (x.dbg & 8) ? 0 : wave;
-    while (j0 > 0 && !x.wc_f[j0 - 1]) --j0;
-    if (j0 > 0) --j0;
-    if (wave > 0 && !(x.dbg & 8))
-      for (int j = j0; j < wave; ++j) carry += x.wc_v[j];
-    if (!head_before) incoming += carry;
-  }
-
-  // rows that END in this lane are finalised here (the lane holding the start of the next row)
-  if (!(x.dbg & 1)) {
-    float run = incoming;
-    int r = rf - (bits & 1);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if ((bits >> k) & 1) {
-        if (r >= 1 && r <= nrows) {
-          const float d = run;  // x . w
-          const float y = x.yl[r];
-          const long long row = (long long)cur.r0 + r - 1;
-          const bool in_range = row >= x.row_begin && row < x.row_end;
-          if (SCATTER) {
-            const bool active = in_range && !(y * d < 0.0f);  // ref: core/ml/SparseSVM.scala:27-28
-            x.coefl[r] = active ? y : 0.0f;
-            if (in_range) x.coef8[row] = (signed char)(active ? (int)y : 0);
-            if (active) active_local++;
-          } else if (in_range) {
-            const float yd = y * d;  // ref: core/ml/SparseSVM.scala:14,16
-            if (yd < 0.0f) c0++;
-            else if (yd > 0.0f) c2++;
-            else c1++;
-          }
-        }
-        run = 0.0f;
-        ++r;
-      }
-      run += pk[k];
-    }
-  }
-  if (!(x.dbg & 4)) __syncthreads();  // coefficients visible; yl / carries may be overwritten by the next tile
-  if (SCATTER && !(x.dbg & 2)) {
-    if (rows_acc + (nrows < 0 ? 0 : nrows) > FIX_ROWS_PER_SCAN) {
-      for (int j = tid; j < x.hg; j += ST_THREADS) {
-        const int q = x.gl[j];
-        if (q >= FIX_SPILL_AT || q <= -FIX_SPILL_AT) {
-          atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
-          x.gl[j] = 0;
-        }
-      }
-      rows_acc = 0;
-      __syncthreads();
-    }
-    rows_acc += nrows < 0 ? 0 : nrows;
-    int r = rf;
-    float coef = x.coefl[r];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k > 0 && ((bits >> k) & 1)) {
-        ++r;
-        coef = x.coefl[r];
-      }
-      if (coef != 0.0f) {
-        const float xv = filt(vv[k] * coef);  // x * y (ref: SparseSVM.scala:28)
-        const int c = cc[k];
-        if (xv != 0.0f && c < x.hg) atomicAdd(&x.gl[c], __float2int_rn(xv * x.fix_scale));
-      }
-    }
-  }
-}
-
-template <bool SCATTER>
-__global__ void __launch_bounds__(ST_THREADS) dsgd_seg_kernel(CsrView m, SegTables tt, const float* __restrict__ w,
-                                                             long long* g64_base, long long g_stride,
-                                                             const StreamSeg* __restrict__ segs, DevScalars* sc, int hw,
-                                                             int hg, float fix_scale, signed char* coef8, int dbg) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  SegCtx x;
-  x.dbg = dbg;
-  x.coef8 = coef8;
-  x.yl = lds;
-  x.coefl = lds + (ST_MAXROWS + 2);
-  x.wc_v = lds + 2 * (ST_MAXROWS + 2);
-  x.wc_f = reinterpret_cast<int*>(x.wc_v + 16);
-  x.gl = reinterpret_cast<int*>(lds + SG_LDS_FIXED);
-  x.wl = lds + SG_LDS_FIXED + (SCATTER ? hg : 0);
-  const int tid = threadIdx.x;
-  const StreamSeg seg = segs[blockIdx.y];
-  x.g64 = g64_base + (long long)blockIdx.y * g_stride;
-  x.row_begin = seg.row_begin;
-  x.row_end = seg.row_end;
-  x.hw = hw;
-  x.hg = hg;
-  x.fix_scale = fix_scale;
-  int rows_acc = 0;
-  if (SCATTER)
-    for (int j = tid; j < hg; j += ST_THREADS) x.gl[j] = 0;
-  for (int j = tid; j < hw; j += ST_THREADS) x.wl[j] = w[j];
-  __syncthreads();
-
-  unsigned int active_local = 0, c0 = 0, c1 = 0, c2 = 0;
-  const long long nnz_pad4 = (m.row_ptr[m.n_rows] + 3) & ~3LL;
-  const long long stride = gridDim.x;
-  const long long t_end = seg.tile_end;
-  long long tile = seg.tile_begin + blockIdx.x;
-  if (tile < t_end) {
-    SegRegs A, B, C, D;
-    seg_issue(m, tt, tile, t_end, tid, nnz_pad4, A);
-    seg_issue(m, tt, tile + stride, t_end, tid, nnz_pad4, B);
-    seg_issue(m, tt, tile + 2 * stride, t_end, tid, nnz_pad4, C);
-    seg_gather(w, hw, A);
-#define DSGD_SEG(CUR, NXT, FAR) \
-  seg_tile<SCATTER>(m, tt, w, x, tile, stride, t_end, nnz_pad4, CUR, NXT, FAR, rows_acc, active_local, c0, c1, c2)
-    for (;;) {
-      DSGD_SEG(A, B, D); tile += stride; if (tile >= t_end) break;
-      DSGD_SEG(B, C, A); tile += stride; if (tile >= t_end) break;
-      DSGD_SEG(C, D, B); tile += stride; if (tile >= t_end) break;
-      DSGD_SEG(D, A, C); tile += stride; if (tile >= t_end) break;
-    }
-#undef DSGD_SEG
-  }
-
-  if (SCATTER) {
-    __syncthreads();
-    for (int j = tid; j < hg; j += ST_THREADS) {
-      const int q = x.gl[j];
-      if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
-    }
-    active_local = wave_sum_u32(active_local);
-    if ((tid & 63) == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
-  } else {
-    c0 = wave_sum_u32(c0);
-    c1 = wave_sum_u32(c1);
-    c2 = wave_sum_u32(c2);
-    if (blockIdx.x == 0 && tid == 0) atomicAdd(&sc->counts[3], (unsigned long long)(seg.row_end - seg.row_begin));
-    if ((tid & 63) == 0) {
-      if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
-      if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
-      if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
-    }
-  }
 }
 
 // ======================================================================================================
@@ -1363,6 +795,7 @@ struct WRegs {
   int4 c0, c1;
   float4 v0, v1;
   float gw[8];
+  float dc;            // SPLIT: cold part of x.w of the row that ends in this lane
   unsigned int meta;
   long long pos0, tc;  // wave-uniform (scalar registers): window start, clamped tile index
   int r0, nrows;       // wave-uniform
@@ -1422,11 +855,23 @@ struct WCtx {
   const float* wl;
   long long* g64;
   DevScalars* sc;
+  const float* dcold;   // SPLIT: per-row cold part of x.w, written by dsgd_cdot_kernel
   long long row_begin, row_end;
   int hw, hg;
   float fix_scale;
   int dbg;  // ablation switches for tuning runs (0 in production)
 };
+
+// SPLIT: cold part of x.w of the row that ends in this lane (the lane's first row start closes it); lanes
+// without a row end read row r0 and ignore the value
+__device__ __forceinline__ void w_load_dc(const WCtx& x, WRegs& r) {
+  const unsigned int dn = r.nrows < 0 ? 0u : r.meta;
+  const unsigned int bn = (dn >> 8) & 255u;
+  const int re_n = (int)(dn & 255u) - (int)(bn & 1u);
+  const bool ok = bn != 0u && re_n >= 1 && re_n <= r.nrows;
+  r.dc = (x.dcold + r.r0)[ok ? (unsigned int)(re_n - 1) : 0u];
+}
+
 
 // fixed-point scatter of a lane's eight contributions into the LDS gradient tile.  Every lane issues all eight
 // ds_add_rtn_u32 unconditionally (no exec-mask branches, one wait for the eight returns): a slot with nothing
@@ -1465,7 +910,9 @@ __device__ __forceinline__ void w_scatter(const WCtx& x, const int (&cc)[8], con
 // are gathered now), `far` = the register set that receives the column ids of tile t+DEPTH-1; with DEPTH = 4
 // `mid` = tile t+2, whose column ids are in flight and whose values are requested now.  The stream loads are issued FIRST so that they are already on their way while the
 // wave waits (counted vmcnt) for the column ids of t+1.
-template <bool SCATTER, bool ABL, int DEPTH>
+// SPLIT (stream_mode 4): the tiles hold the HOT part of the matrix only (every column id < hw = hg), the cold
+// part of each row's x.w comes from x.dcold -- no gathers, no clamps, no cold checks.
+template <bool SCATTER, bool ABL, int DEPTH, bool SPLIT>
 __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __amdgpu_buffer_rsrc_t wrs, const WCtx& x,
                                        unsigned int dp, long long tile, long long stride, long long t_end, WRegs& cur,
                                        WRegs& nxt, WRegs& mid, WRegs& far, WTile& wt_far, unsigned int& n_all,
@@ -1478,7 +925,8 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
   wt_far = w_fetch(tt, tile + DEPTH * stride, t_end);                       // record used next iteration
   w_issue_cols(m, tile + (DEPTH - 1) * stride, t_end, lane, wt_now, far);
   w_issue_vals(m, tt, lane, DEPTH == 4 ? mid : far);                        // tile t+2
-  if (dbg & 32) w_gather_off(nxt);
+  if (SPLIT) w_load_dc(x, nxt);   // tile t+1 (descriptor landed): one load instead of eight gathers
+  else if (dbg & 32) w_gather_off(nxt);
   else w_gather(wrs, x.hw, nxt);                                           // tile t+1
 
   const int nrows = cur.nrows;                          // wave-uniform; -1: the whole tile is padding
@@ -1494,9 +942,9 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
   // the reference's product map is.  ref: math/Sparse.scala:46
   float a[8], pk[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) a[k] = (dbg & 16) ? 0.5f : wl3[min(cc[k], x.hw)];
+  for (int k = 0; k < 8; ++k) a[k] = (dbg & 16) ? 0.5f : wl3[SPLIT ? cc[k] : min(cc[k], x.hw)];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) pk[k] = filt(vv[k] * (a[k] + cur.gw[k]));
+  for (int k = 0; k < 8; ++k) pk[k] = filt(vv[k] * (SPLIT ? a[k] : a[k] + cur.gw[k]));
 
   // rows of the worker's batch, as local rows of this tile (wave-uniform, scalar registers)
   const long long lo64 = x.row_begin - cur.r0 + 1, hi64 = x.row_end - cur.r0 + 1;
@@ -1528,7 +976,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
     const int r_end = rf - (int)(bits & 1u);              // local row that ends at the lane's row start
     if (!(dbg & 1)) {
       const bool fin = nb == 1 && r_end >= r_lo && r_end < r_hi;
-      const float d = incoming + head;                     // x . w of that row
+      const float d = SPLIT ? (incoming + head) + cur.dc : incoming + head;   // x . w of that row
       const bool ypos = (ys & bits) != 0u;
       const float yd = ypos ? d : -d;
       if (SCATTER) {
@@ -1558,7 +1006,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float coef = in_t[k] ? cT : cA;
-        q[k] = cc[k] < x.hg ? __float2int_rn(vv[k] * coef) : 0;   // y * x on the fixed-point grid
+        q[k] = (SPLIT || cc[k] < x.hg) ? __float2int_rn(vv[k] * coef) : 0;   // y * x on the fixed-point grid
       }
       w_scatter<ABL>(x, cc, q, lane, dbg);
       __builtin_amdgcn_wave_barrier();
@@ -1588,7 +1036,8 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
           if (r >= 1 && r <= nrows) {
             const bool in_range = r >= r_lo && r < r_hi;
             const bool ypos = (ys >> k) & 1u;
-            const float yd = ypos ? run : -run;
+            const float dfull = SPLIT ? run + (x.dcold + cur.r0)[(unsigned int)(r - 1)] : run;
+            const float yd = ypos ? dfull : -dfull;
             if (SCATTER) {
               const bool active = in_range && !(yd < 0.0f);
               x.coefw[r] = active ? (ypos ? ps : ns) : 0.0f;
@@ -1620,7 +1069,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
           ++r;
           coef = x.coefw[r];
         }
-        q[k] = cc[k] < x.hg ? __float2int_rn(vv[k] * coef) : 0;
+        q[k] = (SPLIT || cc[k] < x.hg) ? __float2int_rn(vv[k] * coef) : 0;
       }
       w_scatter<ABL>(x, cc, q, lane, dbg);
       __builtin_amdgcn_wave_barrier();
@@ -1641,7 +1090,7 @@ __device__ __forceinline__ void fix_add_lds(int* gl, long long* g64, DevScalars*
   }
 }
 
-template <bool SCATTER>
+template <bool SCATTER, bool SPLIT>
 __device__ __forceinline__ void w_long_row(const CsrView& m, const float* __restrict__ w, const WCtx& x, long long row,
                                            unsigned int& n_all, unsigned int& n_neg, unsigned int& n_pos) {
   typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
@@ -1679,6 +1128,9 @@ __device__ __forceinline__ void w_long_row(const CsrView& m, const float* __rest
         if (c < x.hg) {
           const int q = __float2int_rn(m.val[p] * cs);
           if (q != 0) fix_add_lds(x.gl, x.g64, x.sc, c, q);
+        } else if (SPLIT) {   // no cold lists in the split layout: straight to the 64-bit accumulator
+          const int q = __float2int_rn(m.val[p] * cs);
+          if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[c]), (unsigned long long)(long long)q);
         }
       }
     }
@@ -1689,15 +1141,15 @@ __device__ __forceinline__ void w_long_row(const CsrView& m, const float* __rest
   }
 }
 
-template <bool SCATTER, bool ABL, int DEPTH>
-__global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, const WTile* __restrict__ tiles,
+template <bool SCATTER, bool ABL, int DEPTH, bool SPLIT>
+__global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mfull, const WTile* __restrict__ tiles,
                                                         const unsigned int* __restrict__ meta,
                                                         const float* __restrict__ w, long long* __restrict__ g64_base,
                                                         long long g_stride, const StreamSeg* __restrict__ segs,
                                                         DevScalars* __restrict__ sc, int hw, int hg, float fix_scale,
                                                         signed char* __restrict__ coef8, int dp, int dbg,
                                                         const int* __restrict__ long_rows, int* __restrict__ part,
-                                                        int part_stride) {
+                                                        int part_stride, const float* __restrict__ dcold) {
   // (the tables are direct __restrict__ parameters: only then can the compiler prove that the stores of this kernel
   // do not clobber them and select scalar loads for the wave-uniform tile records)
   WTables tt;
@@ -1716,6 +1168,7 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, const WTile*
   const StreamSeg seg = segs[blockIdx.y];
   x.g64 = g64_base + (long long)blockIdx.y * g_stride;
   x.sc = sc;
+  x.dcold = dcold;
   x.row_begin = seg.row_begin;
   x.row_end = seg.row_end;
   x.hw = hw;
@@ -1746,10 +1199,11 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, const WTile*
       w_issue_cols(m, tile + 2 * stride, t_end, lane, wt, C);
       wt = w_fetch(tt, tile + 3 * stride, t_end);
     }
-    w_gather(wrs, hw, A);
+    if (SPLIT) w_load_dc(x, A);
+    else w_gather(wrs, hw, A);
 #define DSGD_WT(CUR, NXT, MID, FAR)                                                                                  \
-  w_tile<SCATTER, ABL, DEPTH>(m, tt, wrs, x, (unsigned int)dp, tile, stride, t_end, CUR, NXT, MID, FAR, wt, n_all, \
-                              n_neg, n_pos)
+  w_tile<SCATTER, ABL, DEPTH, SPLIT>(m, tt, wrs, x, (unsigned int)dp, tile, stride, t_end, CUR, NXT, MID, FAR, wt, \
+                                     n_all, n_neg, n_pos)
     if (DEPTH == 4) {
       for (;;) {
         DSGD_WT(A, B, C, D); tile += stride; if (tile >= t_end) break;
@@ -1768,7 +1222,7 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, const WTile*
   }
   // rows that fit no tile: one wave per row
   for (long long t = seg.long_begin + (long long)blockIdx.x * 16 + wave; t < seg.long_end; t += stride)
-    w_long_row<SCATTER>(m, w, x, (long long)long_rows[t], n_all, n_neg, n_pos);
+    w_long_row<SCATTER, SPLIT>(mfull, w, x, (long long)long_rows[t], n_all, n_neg, n_pos);
 
   if (SCATTER) {
     __syncthreads();
@@ -1796,6 +1250,217 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, const WTile*
       if (n_pos) atomicAdd(&sc->counts[2], (unsigned long long)n_pos);                          // pred == -y
     }
   }
+}
+
+// ======================================================================================================
+// stream_mode 4: the matrix split by column rank -- layout kernels and the two cold-stream kernels
+// ======================================================================================================
+// Measured on MI355X (profiles/README.md): with 9 % of the non-zeros outside the LDS weight tile the eight
+// per-lane gathers of a tile keep a CU's texture addresser busy 60 % of the time (20 % without them), and the
+// transposed cold lists pay one scattered coefficient lookup per cold entry.  Both disappear when the cold
+// entries leave the main stream: they form their own row-ordered stream (rank - hsplit, value, row) that two
+// small kernels read linearly -- dsgd_cdot_kernel with the cold WEIGHTS in LDS (cold part of x.w per row, before
+// the main kernel), dsgd_cgrad_kernel with the cold GRADIENT in LDS (after it, coefficients read by row).
+
+// cold entries per row (ranked column ids; G lanes per row)
+template <int G>
+__global__ void __launch_bounds__(256) dsgd_split_count_kernel(CsrView m, int hsplit, int* __restrict__ cnt_cold) {
+  const int sub = threadIdx.x % G;
+  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
+  for (long long row = group; row < m.n_rows; row += n_groups) {
+    const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
+    int n = 0;
+    for (long long p = start + sub; p < end; p += G) n += m.col[p] >= hsplit;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) n += __shfl_xor(n, o, G);
+    if (sub == 0) cnt_cold[row] = n;
+  }
+}
+
+// one wave per row: stable partition of the row into the hot and the cold stream.  A row whose hot range is empty
+// in hrow_ptr belongs to the long-row list and is left out of both streams; a row without any hot entry gets one
+// explicit zero on rank 0 so that every tiled row owns a slot.
+__global__ void __launch_bounds__(256) dsgd_split_fill_kernel(CsrView m, int hsplit,
+                                                             const long long* __restrict__ hrow_ptr,
+                                                             const long long* __restrict__ crow_ptr,
+                                                             int* __restrict__ hcol, float* __restrict__ hval,
+                                                             int* __restrict__ ccol, float* __restrict__ cval,
+                                                             int* __restrict__ crow) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long row = wave; row < m.n_rows; row += n_waves) {
+    long long hp = hrow_ptr[row];
+    if (hrow_ptr[row + 1] == hp) continue;   // long row
+    long long cp = crow_ptr[row];
+    const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
+    bool any_hot = false;
+    for (long long p0 = start; p0 < end; p0 += 64) {
+      const long long p = p0 + lane;
+      const bool in = p < end;
+      const int c = in ? m.col[p] : 0;
+      const float v = in ? m.val[p] : 0.0f;
+      const bool hot = in && c < hsplit, cold = in && c >= hsplit;
+      const unsigned long long mh = __builtin_amdgcn_ballot_w64(hot), mc = __builtin_amdgcn_ballot_w64(cold);
+      const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+      if (hot) {
+        const long long o = hp + __popcll(mh & below);
+        hcol[o] = c;
+        hval[o] = v;
+      }
+      if (cold) {
+        const long long o = cp + __popcll(mc & below);
+        ccol[o] = c - hsplit;
+        cval[o] = v;
+        crow[o] = (int)row;
+      }
+      hp += __popcll(mh);
+      cp += __popcll(mc);
+      any_hot = any_hot || mh != 0ull;
+    }
+    if (!any_hot && lane == 0) {
+      hcol[hp] = 0;
+      hval[hp] = 0.0f;
+    }
+  }
+}
+
+// first element index e' >= e of the cold stream at which a new row starts (e_lo and e_hi are row starts)
+__device__ __forceinline__ long long cold_row_start(const int* __restrict__ crow, long long e, long long e_lo,
+                                                    long long e_hi, int lane) {
+  if (e <= e_lo) return e_lo;
+  while (e < e_hi) {
+    const long long i = e + lane;
+    const bool st = i < e_hi && crow[i] != crow[i - 1];
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(st);
+    if (mk) return e + __builtin_ctzll(mk);
+    e += 64;
+  }
+  return e_hi;
+}
+
+constexpr int CD_UNR = 4;   // 64-element chunks in flight per wave
+
+// dcold[row] = sum over the cold entries of the row of filt(value * w[hsplit + col]) for the rows of each
+// worker's range.  Every wave owns a contiguous, ROW-ALIGNED piece of the cold stream: no atomics, fixed order.
+// ref: math/Sparse.scala:46 restricted to the cold columns.
+__global__ void __launch_bounds__(1024) dsgd_cdot_kernel(const int* __restrict__ ccol, const float* __restrict__ cval,
+                                                        const int* __restrict__ crow,
+                                                        const long long* __restrict__ crow_ptr,
+                                                        const float* __restrict__ w, float* __restrict__ dcold,
+                                                        const StreamSeg* __restrict__ segs, int hsplit, int nc_lds) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef __attribute__((address_space(3))) const float lds_cfloat;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int j = tid; j < nc_lds; j += 1024) lds[j] = w[hsplit + j];
+  __syncthreads();
+  const StreamSeg seg = segs[blockIdx.y];
+  const long long e_lo = crow_ptr[seg.row_begin], e_hi = crow_ptr[seg.row_end];
+  const long long n = e_hi - e_lo;
+  const long long n_waves = (long long)gridDim.x * 16, me = (long long)blockIdx.x * 16 + wave;
+  // nominal pieces in units of 64 elements, then moved forward to the next row start
+  const long long chunks = (n + 63) / 64;
+  const long long b0 = e_lo + 64 * (chunks * me / n_waves), b1 = e_lo + 64 * (chunks * (me + 1) / n_waves);
+  const long long s = cold_row_start(crow, b0, e_lo, e_hi, lane);
+  const long long t = me + 1 == n_waves ? e_hi : cold_row_start(crow, b1 < e_hi ? b1 : e_hi, e_lo, e_hi, lane);
+  float carry_sum = 0.0f;
+  int carry_row = -1;
+  lds_cfloat* wc = (lds_cfloat*)lds;
+  for (long long e = s; e < t; e += 64 * CD_UNR) {
+    int c[CD_UNR], r[CD_UNR];
+    float v[CD_UNR];
+#pragma unroll
+    for (int k = 0; k < CD_UNR; ++k) {
+      const long long i = e + 64 * k + lane;
+      const bool in = i < t;
+      c[k] = in ? ccol[i] : 0;
+      v[k] = in ? cval[i] : 0.0f;
+      r[k] = in ? crow[i] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < CD_UNR; ++k) {
+      const float wv = c[k] < nc_lds ? wc[c[k]] : w[hsplit + c[k]];
+      float p = filt(v[k] * wv);
+      // the row carried in from the previous chunk: continues in lane 0 or is complete
+      if (lane == 0) {
+        if (r[k] == carry_row) p += carry_sum;
+        else if (carry_row >= 0) dcold[carry_row] = carry_sum;
+      }
+      const int prev = dpp_get_i<0x138, 0xf>(r[k]);          // wave_shr:1 (lane 0 reads 0: it never continues a lane)
+      int f = lane == 0 ? 1 : (r[k] != prev);
+      float sum = p;
+      wave_seg_scan(sum, f);
+      const int next = __builtin_amdgcn_update_dpp(-1, r[k], 0x130, 0xf, 0xf, false);   // wave_shl:1 (lane 63: -1)
+      if (lane < 63 && r[k] >= 0 && next != r[k]) dcold[r[k]] = sum;
+      carry_sum = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sum), 63));
+      carry_row = __builtin_amdgcn_readlane(r[k], 63);
+    }
+  }
+  if (lane == 0 && carry_row >= 0) dcold[carry_row] = carry_sum;
+}
+
+// cold gradient columns of each worker's range: q = round(value * coef[row] * scale) accumulated in an LDS tile of
+// 32-bit integers (same fixed-point grid and overflow rule as the main kernel), flushed once per workgroup into
+// partc[workgroup][col]; dsgd_fix_reduce_kernel adds the partials in a fixed order.
+// ref: core/Slave.scala:147-153 restricted to the cold columns.
+__global__ void __launch_bounds__(1024) dsgd_cgrad_kernel(const int* __restrict__ ccol, const float* __restrict__ cval,
+                                                         const int* __restrict__ crow,
+                                                         const long long* __restrict__ crow_ptr,
+                                                         const signed char* __restrict__ coef8,
+                                                         long long* __restrict__ g64_base, long long g_stride,
+                                                         DevScalars* __restrict__ sc,
+                                                         const StreamSeg* __restrict__ segs, int hsplit, int nc_lds,
+                                                         float fix_scale, int* __restrict__ partc, int partc_stride) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int* gc = reinterpret_cast<int*>(lds);   // nc_lds accumulators + 64 always-zero words
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int j = tid; j < nc_lds + 64; j += 1024) gc[j] = 0;
+  __syncthreads();
+  const StreamSeg seg = segs[blockIdx.y];
+  long long* g64 = g64_base + (long long)blockIdx.y * g_stride;
+  const long long e_lo = crow_ptr[seg.row_begin], e_hi = crow_ptr[seg.row_end];
+  const long long chunks = (e_hi - e_lo + 63) / 64;
+  const long long n_waves = (long long)gridDim.x * 16, me = (long long)blockIdx.x * 16 + wave;
+  const long long s = e_lo + 64 * (chunks * me / n_waves);
+  long long t = e_lo + 64 * (chunks * (me + 1) / n_waves);
+  if (t > e_hi) t = e_hi;
+  for (long long e = s; e < t; e += 64 * CD_UNR) {
+    int c[CD_UNR], r[CD_UNR], q[CD_UNR], old[CD_UNR];
+    float v[CD_UNR];
+#pragma unroll
+    for (int k = 0; k < CD_UNR; ++k) {
+      const long long i = e + 64 * k + lane;
+      const bool in = i < t;
+      c[k] = in ? ccol[i] : 0;
+      v[k] = in ? cval[i] : 0.0f;
+      r[k] = in ? crow[i] : (int)seg.row_begin;
+    }
+#pragma unroll
+    for (int k = 0; k < CD_UNR; ++k) {
+      const float coef = (float)coef8[r[k]] * fix_scale;
+      q[k] = __float2int_rn(v[k] * coef);   // y * x on the fixed-point grid (0 for inactive rows and padding)
+      if (c[k] >= nc_lds) {                 // beyond the LDS tile (very wide models): 64-bit global accumulator
+        if (q[k] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[hsplit + c[k]]), (unsigned long long)(long long)q[k]);
+        q[k] = 0;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CD_UNR; ++k) old[k] = atomicAdd(&gc[q[k] != 0 ? c[k] : nc_lds + lane], q[k]);
+#pragma unroll
+    for (int k = 0; k < CD_UNR; ++k) {
+      if (old[k] >= WS_SPILL_AT || old[k] <= -WS_SPILL_AT) {
+        if (old[k] >= WS_PANIC_AT || old[k] <= -WS_PANIC_AT) atomicOr(&sc->err, 2);
+        const int x = atomicExch(&gc[c[k]], 0);
+        if (x != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[hsplit + c[k]]), (unsigned long long)(long long)x);
+      }
+    }
+  }
+  __syncthreads();
+  int* mine = partc + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * partc_stride;
+  for (int j = tid; j < nc_lds; j += 1024) mine[j] = gc[j];
 }
 
 // evaluation tallies of an explicit list of rows (the few rows too long for the wave tiles)

@@ -338,6 +338,48 @@ def test_full_size_properties(full):
     np.testing.assert_array_equal(eng.get_weights(), w0)
 
 
+# ---- the two streaming layouts (DSGD_STREAM=3: gathers + cold lists, =4: split matrix) and a wide model ----------
+@pytest.mark.parametrize("mode,dim,hsplit", [("4", dsgd_amd.synth.RCV1_DIM, None), ("3", dsgd_amd.synth.RCV1_DIM, None),
+                                             ("4", 70000, None),      # cold columns beyond the cold kernels' LDS tile
+                                             ("4", dsgd_amd.synth.RCV1_DIM, "3000"),   # short hot part, long cold rows
+                                             ("4", 3000, None)])       # no cold stream at all
+def test_streaming_layouts_match_oracle(monkeypatch, mode, dim, hsplit):
+    monkeypatch.setenv("DSGD_STREAM", mode)
+    if hsplit:
+        monkeypatch.setenv("DSGD_HSPLIT", hsplit)
+    n_rows = 120000
+    data = dsgd_amd.synth.generate(n_rows, seed=5, dim=dim)
+    n_train = 100000
+    o, eng = make_pair(data, 1e-5, n_train)
+    with eng:
+        w_ref = np.zeros(data.dim + 1)
+        lr = 0.5 * 100 / n_train
+        for step in range(4):
+            ranges = [(0, n_train)] if step % 2 == 0 else [(0, 30001), (30001, 64000), (64000, n_train)]
+            st = eng.sync_step_ranges(ranges, lr * len(ranges))
+            o.sync_step(w_ref, [np.arange(a, b) for a, b in ranges], lr * len(ranges))
+            assert st["n_samples"] == n_train
+            if st["n_active"] != o.last_stats["n_active"]:
+                assert o.last_stats["min_abs_margin"] < GATE_EPS
+                eng.set_weights(w_ref.astype(np.float32))
+                continue
+            w = eng.get_weights().astype(np.float64)
+            assert np.abs(w - w_ref).max() <= 2e-4 * max(1.0, np.abs(w_ref).max())
+        for lo, hi in ((n_train, n_rows), (0, n_train), (777, 99001)):
+            loss, acc, counts = eng.loss_acc(lo, hi)
+            _, _, counts_ref, mam = o.loss_acc(eng.get_weights().astype(np.float64), lo, hi)
+            assert sum(counts) == hi - lo
+            if mam >= GATE_EPS:
+                assert counts == counts_ref
+        # bit-reproducible: the same step from the same weights twice
+        w0 = eng.get_weights()
+        eng.sync_step_ranges([(0, n_train)], lr)
+        w1 = eng.get_weights()
+        eng.set_weights(w0)
+        eng.sync_step_ranges([(0, n_train)], lr)
+        np.testing.assert_array_equal(eng.get_weights(), w1)
+
+
 # ---- ragged inputs: empty rows, one-element rows, values below the Sparse epsilon ---------------------
 def ragged_data(seed, n_rows=6000):
     base = dsgd_amd.synth.generate(n_rows, seed=seed)
