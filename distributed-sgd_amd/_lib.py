@@ -25,7 +25,8 @@ SYMBOLS = [
     "dsgd_plan_destroy", "dsgd_plan_run", "dsgd_sync_step_ranges_async", "dsgd_synchronize", "dsgd_forward",
     "dsgd_loss_acc", "dsgd_async_step", "dsgd_update_grad", "dsgd_async_start", "dsgd_async_updates",
     "dsgd_async_stop", "dsgd_async_wait", "dsgd_comm_unique_id", "dsgd_comm_init", "dsgd_comm_destroy",
-    "dsgd_prof_enable", "dsgd_prof_read", "dsgd_grad_kernel_name", "dsgd_device_ptrs",
+    "dsgd_prof_enable", "dsgd_prof_read", "dsgd_prof_read_kinds", "dsgd_range_nnz", "dsgd_grad_kernel_name",
+    "dsgd_device_ptrs",
 ]
 
 

@@ -169,9 +169,11 @@ struct dsgd_ctx {
   float* d_hval = nullptr;
   long long* d_hrow_ptr = nullptr;      // n_rows + 1 (rows of the long list: empty)
   long long hot_nnz = 0;
-  int* d_ccol = nullptr;                // cold stream in row order: rank - hsplit, value, row
+  unsigned int* d_ckey = nullptr;       // cold stream in row order (ColdView): key, value, [row], [block base rows]
   float* d_cval = nullptr;
   int* d_crow = nullptr;
+  int* d_cbase = nullptr;
+  bool cold_packed = false;
   long long* d_crow_ptr = nullptr;      // n_rows + 1
   long long coldm_nnz = 0;
   float* d_dcold = nullptr;             // n_rows: cold part of x.w (rows without cold entries stay 0)
@@ -226,8 +228,9 @@ struct dsgd_ctx {
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
   size_t prof_used = 0;
-  double prof_ms = 0.0;
-  long long prof_n = 0;
+  std::vector<int> prof_kind;
+  double prof_kms[3] = {0.0, 0.0, 0.0};
+  long long prof_kn[3] = {0, 0, 0};
   int n_cu = 256;
 };
 
@@ -334,15 +337,18 @@ static int grid_for(dsgd_ctx* c, long long items, int group) {
   return (int)std::max<long long>(1, std::min(blocks, cap));
 }
 
-static int prof_begin(dsgd_ctx* c, size_t* slot) {
+// kind 0: the main gradient kernel, 1: dsgd_cdot_kernel, 2: dsgd_cgrad_kernel (split layout)
+static int prof_begin(dsgd_ctx* c, size_t* slot, int kind = 0) {
   if (!c->prof) return DSGD_OK;
   if (c->prof_used == c->prof_ev.size()) {
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
     c->prof_ev.emplace_back(a, b);
+    c->prof_kind.push_back(0);
   }
   *slot = c->prof_used++;
+  c->prof_kind[*slot] = kind;
   HIP_TRY(hipEventRecord(c->prof_ev[*slot].first, c->stream));
   return DSGD_OK;
 }
@@ -355,8 +361,9 @@ static int prof_collect(dsgd_ctx* c) {  // stream must be idle
   for (size_t i = 0; i < c->prof_used; ++i) {
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, c->prof_ev[i].first, c->prof_ev[i].second));
-    c->prof_ms += ms;
-    c->prof_n++;
+    const int k = c->prof_kind[i];
+    c->prof_kms[k] += ms;
+    c->prof_kn[k]++;
   }
   c->prof_used = 0;
   return DSGD_OK;
@@ -664,10 +671,10 @@ static int upload_wave_tiles(dsgd_ctx* c, HostTiles& ht) {
 // (rank - hsplit, value, row); rows whose hot part exceeds a wave tile stay on the long-row list and in neither.
 static int build_split(dsgd_ctx* c) {
   hipFree(c->d_hcol); hipFree(c->d_hval); hipFree(c->d_hrow_ptr);
-  hipFree(c->d_ccol); hipFree(c->d_cval); hipFree(c->d_crow); hipFree(c->d_crow_ptr);
+  hipFree(c->d_ckey); hipFree(c->d_cval); hipFree(c->d_crow); hipFree(c->d_cbase); hipFree(c->d_crow_ptr);
   hipFree(c->d_dcold); hipFree(c->d_coef8);
   c->d_hcol = nullptr; c->d_hval = nullptr; c->d_hrow_ptr = nullptr;
-  c->d_ccol = nullptr; c->d_cval = nullptr; c->d_crow = nullptr; c->d_crow_ptr = nullptr;
+  c->d_ckey = nullptr; c->d_cval = nullptr; c->d_crow = nullptr; c->d_cbase = nullptr; c->d_crow_ptr = nullptr;
   c->d_dcold = nullptr; c->d_coef8 = nullptr;
   const long long n_rows = c->n_rows;
   const int H = std::min(c->hsplit, c->dp);
@@ -714,15 +721,35 @@ static int build_split(dsgd_ctx* c) {
   HIP_TRY(hipMalloc(&c->d_hrow_ptr, sizeof(long long) * hrp.size()));
   HIP_TRY(hipMemcpy(c->d_hrow_ptr, hrp.data(), sizeof(long long) * hrp.size(), hipMemcpyHostToDevice));
   const size_t nc = (size_t)std::max<long long>(c->coldm_nnz, 1);
-  HIP_TRY(hipMalloc(&c->d_ccol, sizeof(int) * nc));
+  // first row of every block of 256 cold entries; the packed form needs 16-bit column ids and row offsets
+  std::vector<int> cbase((size_t)((c->coldm_nnz + 255) / 256) + 1, 0);
+  bool packed = c->dp - H <= 65536 && !getenv("DSGD_COLD_UNPACKED");
+  {
+    size_t b = 0;
+    for (long long i = 0; i < n_rows; ++i)          // row i is the base of every block that starts inside it
+      for (; (long long)b * 256 < crp[i + 1]; ++b) cbase[b] = (int)i;
+    for (long long i = 0; i < n_rows && packed; ++i) {
+      if (crp[i + 1] == crp[i]) continue;
+      for (long long bb = crp[i] / 256; bb <= (crp[i + 1] - 1) / 256; ++bb)   // blocks holding entries of row i
+        if (i - (long long)cbase[(size_t)bb] > 65535) packed = false;
+    }
+  }
+  c->cold_packed = packed;
+  HIP_TRY(hipMalloc(&c->d_ckey, sizeof(unsigned int) * nc));
   HIP_TRY(hipMalloc(&c->d_cval, sizeof(float) * nc));
-  HIP_TRY(hipMalloc(&c->d_crow, sizeof(int) * nc));
+  if (!packed) HIP_TRY(hipMalloc(&c->d_crow, sizeof(int) * nc));
+  HIP_TRY(hipMalloc(&c->d_cbase, sizeof(int) * cbase.size()));
+  HIP_TRY(hipMemcpy(c->d_cbase, cbase.data(), sizeof(int) * cbase.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&c->d_crow_ptr, sizeof(long long) * crp.size()));
   HIP_TRY(hipMemcpy(c->d_crow_ptr, crp.data(), sizeof(long long) * crp.size(), hipMemcpyHostToDevice));
   {
     const int blocks = (int)std::max<long long>(1, std::min<long long>((n_rows + 3) / 4, (long long)c->n_cu * 16));
-    hipLaunchKernelGGL(dsgd_split_fill_kernel, dim3(blocks), dim3(256), 0, c->stream, m, H, c->d_hrow_ptr, c->d_crow_ptr,
-                       c->d_hcol, c->d_hval, c->d_ccol, c->d_cval, c->d_crow);
+    if (packed)
+      hipLaunchKernelGGL(dsgd_split_fill_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, m, H, c->d_hrow_ptr,
+                         c->d_crow_ptr, c->d_hcol, c->d_hval, c->d_ckey, c->d_cval, c->d_crow, c->d_cbase);
+    else
+      hipLaunchKernelGGL(dsgd_split_fill_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, m, H, c->d_hrow_ptr,
+                         c->d_crow_ptr, c->d_hcol, c->d_hval, c->d_ckey, c->d_cval, c->d_crow, c->d_cbase);
     HIP_TRY(hipGetLastError());
   }
   HostTiles ht;
@@ -918,10 +945,22 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   const long long per_worker = std::max<long long>(1, c->n_cu / n_workers);
   dim3 gridc((unsigned)std::max<long long>(1, std::min(per_worker, (max_cold + 16383) / 16384)), n_workers);
   const bool cold = nc > 0 && max_cold > 0;
+  ColdView cv;
+  cv.key = c->d_ckey;
+  cv.val = c->d_cval;
+  cv.row = c->d_crow;
+  cv.base = c->d_cbase;
   if (cold) {
-    hipLaunchKernelGGL(dsgd_cdot_kernel, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, c->d_ccol,
-                       c->d_cval, c->d_crow, c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds);
+    size_t slot_c = 0;
+    DSGD_TRY(prof_begin(c, &slot_c, 1));
+    if (c->cold_packed)
+      hipLaunchKernelGGL(dsgd_cdot_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
+                         c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds);
+    else
+      hipLaunchKernelGGL(dsgd_cdot_kernel<false>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
+                         c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds);
     HIP_TRY(hipGetLastError());
+    DSGD_TRY(prof_end(c, slot_c));
   }
   long long bx = std::min(per_worker, std::max((max_tiles + 15) / 16, (max_long + 15) / 16));
   dim3 grid((unsigned)std::max<long long>(1, bx), n_workers);
@@ -946,10 +985,18 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   if (!SCATTER) return DSGD_OK;
   c->last_grad_kernel = "dsgd_wseg_kernel<true, false, 4, true>";
   if (cold) {
-    hipLaunchKernelGGL(dsgd_cgrad_kernel, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, c->d_ccol,
-                       c->d_cval, c->d_crow, c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H,
-                       nc_lds, c->fix_scale, c->d_partc, c->partc_stride);
+    size_t slot_g = 0;
+    DSGD_TRY(prof_begin(c, &slot_g, 2));
+    if (c->cold_packed)
+      hipLaunchKernelGGL(dsgd_cgrad_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, cv,
+                         c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H, nc_lds, c->fix_scale,
+                         c->d_partc, c->partc_stride);
+    else
+      hipLaunchKernelGGL(dsgd_cgrad_kernel<false>, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, cv,
+                         c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H, nc_lds, c->fix_scale,
+                         c->d_partc, c->partc_stride);
     HIP_TRY(hipGetLastError());
+    DSGD_TRY(prof_end(c, slot_g));
   }
   hipLaunchKernelGGL(dsgd_fix_reduce_kernel, dim3((c->dp + 63) / 64, n_workers), dim3(1024), 0, c->stream, c->d_g64, c->d_g,
                      (long long)c->dp, c->dp, hg, c->d_part, c->part_stride, (int)grid.x, H, cold ? nc_lds : 0, c->d_partc,
@@ -1083,8 +1130,10 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR((dsgd_wseg_kernel<false, true, 4, false>));
   DSGD_ATTR((dsgd_wseg_kernel<true, false, 4, true>));
   DSGD_ATTR((dsgd_wseg_kernel<false, false, 4, true>));
-  DSGD_ATTR(dsgd_cdot_kernel);
-  DSGD_ATTR(dsgd_cgrad_kernel);
+  DSGD_ATTR(dsgd_cdot_kernel<true>);
+  DSGD_ATTR(dsgd_cdot_kernel<false>);
+  DSGD_ATTR(dsgd_cgrad_kernel<true>);
+  DSGD_ATTR(dsgd_cgrad_kernel<false>);
 #undef DSGD_ATTR
   HIP_TRY_B(hipStreamSynchronize(c->stream));
 #undef HIP_TRY_B
@@ -1130,9 +1179,10 @@ int dsgd_destroy(dsgd_ctx* c) {
   hipFree(c->d_hcol);
   hipFree(c->d_hval);
   hipFree(c->d_hrow_ptr);
-  hipFree(c->d_ccol);
+  hipFree(c->d_ckey);
   hipFree(c->d_cval);
   hipFree(c->d_crow);
+  hipFree(c->d_cbase);
   hipFree(c->d_crow_ptr);
   hipFree(c->d_dcold);
   if (c->async_stream) {
@@ -1928,11 +1978,41 @@ int dsgd_prof_read(dsgd_ctx* c, double* ms_avg, int64_t* n_launches, int32_t res
   DSGD_TRY(bind(c));
   HIP_TRY(hipStreamSynchronize(c->stream));
   DSGD_TRY(prof_collect(c));
-  if (ms_avg) *ms_avg = c->prof_n ? c->prof_ms / (double)c->prof_n : 0.0;
-  if (n_launches) *n_launches = c->prof_n;
+  if (ms_avg) *ms_avg = c->prof_kn[0] ? c->prof_kms[0] / (double)c->prof_kn[0] : 0.0;
+  if (n_launches) *n_launches = c->prof_kn[0];
   if (reset) {
-    c->prof_ms = 0.0;
-    c->prof_n = 0;
+    for (int k = 0; k < 3; ++k) {
+      c->prof_kms[k] = 0.0;
+      c->prof_kn[k] = 0;
+    }
+  }
+  return DSGD_OK;
+}
+
+int dsgd_prof_read_kinds(dsgd_ctx* c, double* ms_avg3, int64_t* n_launches3) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  DSGD_TRY(prof_collect(c));
+  for (int k = 0; k < 3; ++k) {
+    if (ms_avg3) ms_avg3[k] = c->prof_kn[k] ? c->prof_kms[k] / (double)c->prof_kn[k] : 0.0;
+    if (n_launches3) n_launches3[k] = c->prof_kn[k];
+  }
+  return DSGD_OK;
+}
+
+int dsgd_range_nnz(dsgd_ctx* c, int64_t row_begin, int64_t row_end, int64_t* nnz, int64_t* cold_nnz) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(require_data(c));
+  if (row_begin < 0 || row_end < row_begin || row_end > c->n_rows) return fail(DSGD_ERANGE, "row range [%lld, %lld) outside [0, %lld)", (long long)row_begin, (long long)row_end, c->n_rows);
+  DSGD_TRY(prepare_layout(c));
+  if (nnz) *nnz = c->h_row_ptr[(size_t)row_end] - c->h_row_ptr[(size_t)row_begin];
+  if (cold_nnz) {
+    const bool split = c->stream_mode == 4 && c->stream_ranges && c->h_crow_ptr.size() == (size_t)c->n_rows + 1;
+    *cold_nnz = split ? c->h_crow_ptr[(size_t)row_end] - c->h_crow_ptr[(size_t)row_begin] : 0;
   }
   return DSGD_OK;
 }

@@ -1262,6 +1262,32 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
 // small kernels read linearly -- dsgd_cdot_kernel with the cold WEIGHTS in LDS (cold part of x.w per row, before
 // the main kernel), dsgd_cgrad_kernel with the cold GRADIENT in LDS (after it, coefficients read by row).
 
+// The cold stream in row order.  Packed form (8 bytes per entry): key = col | (row - base[i >> 8]) << 16 with one
+// base row per 256 entries -- used whenever there are at most 65536 cold columns and no 256-entry block spans
+// more than 65535 rows; otherwise (12 bytes per entry) key = col and the row has its own array.
+struct ColdView {
+  const unsigned int* __restrict__ key;
+  const float* __restrict__ val;
+  const int* __restrict__ row;    // unpacked form only
+  const int* __restrict__ base;   // packed form only: first row of every 256-entry block
+};
+template <bool PACKED>
+__device__ __forceinline__ void cold_get(const ColdView& cv, long long i, int& col, int& row) {
+  const unsigned int k = cv.key[i];
+  if (PACKED) {
+    col = (int)(k & 0xffffu);
+    row = cv.base[i >> 8] + (int)(k >> 16);
+  } else {
+    col = (int)k;
+    row = cv.row[i];
+  }
+}
+template <bool PACKED>
+__device__ __forceinline__ int cold_row_at(const ColdView& cv, long long i) {
+  if (PACKED) return cv.base[i >> 8] + (int)(cv.key[i] >> 16);
+  return cv.row[i];
+}
+
 // cold entries per row (ranked column ids; G lanes per row)
 template <int G>
 __global__ void __launch_bounds__(256) dsgd_split_count_kernel(CsrView m, int hsplit, int* __restrict__ cnt_cold) {
@@ -1281,12 +1307,13 @@ __global__ void __launch_bounds__(256) dsgd_split_count_kernel(CsrView m, int hs
 // one wave per row: stable partition of the row into the hot and the cold stream.  A row whose hot range is empty
 // in hrow_ptr belongs to the long-row list and is left out of both streams; a row without any hot entry gets one
 // explicit zero on rank 0 so that every tiled row owns a slot.
+template <bool PACKED>
 __global__ void __launch_bounds__(256) dsgd_split_fill_kernel(CsrView m, int hsplit,
                                                              const long long* __restrict__ hrow_ptr,
                                                              const long long* __restrict__ crow_ptr,
                                                              int* __restrict__ hcol, float* __restrict__ hval,
-                                                             int* __restrict__ ccol, float* __restrict__ cval,
-                                                             int* __restrict__ crow) {
+                                                             unsigned int* __restrict__ ckey, float* __restrict__ cval,
+                                                             int* __restrict__ crow, const int* __restrict__ cbase) {
   const int lane = threadIdx.x & 63;
   const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
@@ -1311,9 +1338,13 @@ __global__ void __launch_bounds__(256) dsgd_split_fill_kernel(CsrView m, int hsp
       }
       if (cold) {
         const long long o = cp + __popcll(mc & below);
-        ccol[o] = c - hsplit;
+        if (PACKED) {
+          ckey[o] = (unsigned int)(c - hsplit) | ((unsigned int)((int)row - cbase[o >> 8]) << 16);
+        } else {
+          ckey[o] = (unsigned int)(c - hsplit);
+          crow[o] = (int)row;
+        }
         cval[o] = v;
-        crow[o] = (int)row;
       }
       hp += __popcll(mh);
       cp += __popcll(mc);
@@ -1327,12 +1358,13 @@ __global__ void __launch_bounds__(256) dsgd_split_fill_kernel(CsrView m, int hsp
 }
 
 // first element index e' >= e of the cold stream at which a new row starts (e_lo and e_hi are row starts)
-__device__ __forceinline__ long long cold_row_start(const int* __restrict__ crow, long long e, long long e_lo,
-                                                    long long e_hi, int lane) {
+template <bool PACKED>
+__device__ __forceinline__ long long cold_row_start(const ColdView& cv, long long e, long long e_lo, long long e_hi,
+                                                    int lane) {
   if (e <= e_lo) return e_lo;
   while (e < e_hi) {
     const long long i = e + lane;
-    const bool st = i < e_hi && crow[i] != crow[i - 1];
+    const bool st = i < e_hi && cold_row_at<PACKED>(cv, i) != cold_row_at<PACKED>(cv, i - 1);
     const unsigned long long mk = __builtin_amdgcn_ballot_w64(st);
     if (mk) return e + __builtin_ctzll(mk);
     e += 64;
@@ -1345,9 +1377,8 @@ constexpr int CD_UNR = 4;   // 64-element chunks in flight per wave
 // dcold[row] = sum over the cold entries of the row of filt(value * w[hsplit + col]) for the rows of each
 // worker's range.  Every wave owns a contiguous, ROW-ALIGNED piece of the cold stream: no atomics, fixed order.
 // ref: math/Sparse.scala:46 restricted to the cold columns.
-__global__ void __launch_bounds__(1024) dsgd_cdot_kernel(const int* __restrict__ ccol, const float* __restrict__ cval,
-                                                        const int* __restrict__ crow,
-                                                        const long long* __restrict__ crow_ptr,
+template <bool PACKED>
+__global__ void __launch_bounds__(1024) dsgd_cdot_kernel(ColdView cv, const long long* __restrict__ crow_ptr,
                                                         const float* __restrict__ w, float* __restrict__ dcold,
                                                         const StreamSeg* __restrict__ segs, int hsplit, int nc_lds) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1363,8 +1394,8 @@ __global__ void __launch_bounds__(1024) dsgd_cdot_kernel(const int* __restrict__
   // nominal pieces in units of 64 elements, then moved forward to the next row start
   const long long chunks = (n + 63) / 64;
   const long long b0 = e_lo + 64 * (chunks * me / n_waves), b1 = e_lo + 64 * (chunks * (me + 1) / n_waves);
-  const long long s = cold_row_start(crow, b0, e_lo, e_hi, lane);
-  const long long t = me + 1 == n_waves ? e_hi : cold_row_start(crow, b1 < e_hi ? b1 : e_hi, e_lo, e_hi, lane);
+  const long long s = cold_row_start<PACKED>(cv, b0, e_lo, e_hi, lane);
+  const long long t = me + 1 == n_waves ? e_hi : cold_row_start<PACKED>(cv, b1 < e_hi ? b1 : e_hi, e_lo, e_hi, lane);
   float carry_sum = 0.0f;
   int carry_row = -1;
   lds_cfloat* wc = (lds_cfloat*)lds;
@@ -1375,9 +1406,12 @@ __global__ void __launch_bounds__(1024) dsgd_cdot_kernel(const int* __restrict__
     for (int k = 0; k < CD_UNR; ++k) {
       const long long i = e + 64 * k + lane;
       const bool in = i < t;
-      c[k] = in ? ccol[i] : 0;
-      v[k] = in ? cval[i] : 0.0f;
-      r[k] = in ? crow[i] : -1;
+      const long long ic = in ? i : t - 1;   // unconditional (clamped) loads keep the vmcnt waits counted
+      cold_get<PACKED>(cv, ic, c[k], r[k]);
+      const float vl = cv.val[ic];
+      v[k] = in ? vl : 0.0f;
+      c[k] = in ? c[k] : 0;
+      r[k] = in ? r[k] : -1;
     }
 #pragma unroll
     for (int k = 0; k < CD_UNR; ++k) {
@@ -1405,9 +1439,8 @@ __global__ void __launch_bounds__(1024) dsgd_cdot_kernel(const int* __restrict__
 // 32-bit integers (same fixed-point grid and overflow rule as the main kernel), flushed once per workgroup into
 // partc[workgroup][col]; dsgd_fix_reduce_kernel adds the partials in a fixed order.
 // ref: core/Slave.scala:147-153 restricted to the cold columns.
-__global__ void __launch_bounds__(1024) dsgd_cgrad_kernel(const int* __restrict__ ccol, const float* __restrict__ cval,
-                                                         const int* __restrict__ crow,
-                                                         const long long* __restrict__ crow_ptr,
+template <bool PACKED>
+__global__ void __launch_bounds__(1024) dsgd_cgrad_kernel(ColdView cv, const long long* __restrict__ crow_ptr,
                                                          const signed char* __restrict__ coef8,
                                                          long long* __restrict__ g64_base, long long g_stride,
                                                          DevScalars* __restrict__ sc,
@@ -1434,9 +1467,10 @@ __global__ void __launch_bounds__(1024) dsgd_cgrad_kernel(const int* __restrict_
     for (int k = 0; k < CD_UNR; ++k) {
       const long long i = e + 64 * k + lane;
       const bool in = i < t;
-      c[k] = in ? ccol[i] : 0;
-      v[k] = in ? cval[i] : 0.0f;
-      r[k] = in ? crow[i] : (int)seg.row_begin;
+      const long long ic = in ? i : t - 1;
+      cold_get<PACKED>(cv, ic, c[k], r[k]);
+      const float vl = cv.val[ic];
+      v[k] = in ? vl : 0.0f;   // (a clamped lane re-reads an entry of the range: its q is 0)
     }
 #pragma unroll
     for (int k = 0; k < CD_UNR; ++k) {

@@ -215,6 +215,19 @@ class Engine:
         check(self._lib.dsgd_prof_read(self._ctx, C.byref(ms), C.byref(n), C.c_int32(1 if reset else 0)))
         return ms.value, n.value
 
+    def prof_read_kinds(self):
+        """{kind: (avg ms, launches)} of the main / cold x.w / cold gradient kernels of the split layout."""
+        ms = (C.c_double * 3)()
+        n = (C.c_int64 * 3)()
+        check(self._lib.dsgd_prof_read_kinds(self._ctx, ms, n))
+        return {k: (ms[i], n[i]) for i, k in enumerate(("main", "cdot", "cgrad"))}
+
+    def range_nnz(self, row_begin, row_end):
+        """(non-zeros, of which in the cold stream) of rows [row_begin, row_end) as held internally."""
+        a, b = C.c_int64(), C.c_int64()
+        check(self._lib.dsgd_range_nnz(self._ctx, C.c_int64(row_begin), C.c_int64(row_end), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def grad_kernel_name(self):
         return self._lib.dsgd_grad_kernel_name(self._ctx).decode()
 

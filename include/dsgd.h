@@ -193,6 +193,15 @@ int dsgd_comm_destroy(dsgd_ctx* ctx);
  * reset, measured with HIP events on the launch stream; n_launches may be NULL.               */
 int dsgd_prof_enable(dsgd_ctx* ctx, int32_t on);
 int dsgd_prof_read(dsgd_ctx* ctx, double* grad_kernel_ms_avg, int64_t* n_launches, int32_t reset);
+/* Split layout only: average duration (ms) and launch count of {main gradient kernel, cold x.w kernel, cold
+ * gradient kernel} since the last reset of dsgd_prof_read.  Measurement aid; nothing in the reference. */
+int dsgd_prof_read_kinds(dsgd_ctx* ctx, double* ms_avg3, int64_t* n_launches3);
+
+/* Non-zeros of rows [row_begin, row_end) as held internally (empty rows count one explicit zero), and how many of
+ * them live in the cold stream of the split layout (0 in the other layouts).  Used by bench.py to attribute the
+ * algorithmic bytes of a step to the kernel that reads them.  Nothing in the reference. */
+int dsgd_range_nnz(dsgd_ctx* ctx, int64_t row_begin, int64_t row_end, int64_t* nnz, int64_t* cold_nnz);
+
 /* name of the gradient kernel variant in use (for matching rocprofv3 kernel-trace rows)        */
 const char* dsgd_grad_kernel_name(dsgd_ctx* ctx);
 /* raw device pointers (float[D+1]) for hosts that own the collective (e.g. torch.distributed)  */

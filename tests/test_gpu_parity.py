@@ -341,10 +341,14 @@ def test_full_size_properties(full):
 # ---- the two streaming layouts (DSGD_STREAM=3: gathers + cold lists, =4: split matrix) and a wide model ----------
 @pytest.mark.parametrize("mode,dim,hsplit", [("4", dsgd_amd.synth.RCV1_DIM, None), ("3", dsgd_amd.synth.RCV1_DIM, None),
                                              ("4", 70000, None),      # cold columns beyond the cold kernels' LDS tile
+                                             ("4", 90000, None),      # more than 65536 cold columns: unpacked cold stream
+                                             ("4u", dsgd_amd.synth.RCV1_DIM, None),    # unpacked cold stream, forced
                                              ("4", dsgd_amd.synth.RCV1_DIM, "3000"),   # short hot part, long cold rows
                                              ("4", 3000, None)])       # no cold stream at all
 def test_streaming_layouts_match_oracle(monkeypatch, mode, dim, hsplit):
-    monkeypatch.setenv("DSGD_STREAM", mode)
+    monkeypatch.setenv("DSGD_STREAM", mode[0])
+    if mode.endswith("u"):
+        monkeypatch.setenv("DSGD_COLD_UNPACKED", "1")
     if hsplit:
         monkeypatch.setenv("DSGD_HSPLIT", hsplit)
     n_rows = 120000
