@@ -955,10 +955,10 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
     DSGD_TRY(prof_begin(c, &slot_c, 1));
     if (c->cold_packed)
       hipLaunchKernelGGL(dsgd_cdot_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
-                         c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds);
+                         c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds, nc > nc_lds ? 1 : 0);
     else
       hipLaunchKernelGGL(dsgd_cdot_kernel<false>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
-                         c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds);
+                         c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds, nc > nc_lds ? 1 : 0);
     HIP_TRY(hipGetLastError());
     DSGD_TRY(prof_end(c, slot_c));
   }
@@ -990,11 +990,11 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
     if (c->cold_packed)
       hipLaunchKernelGGL(dsgd_cgrad_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, cv,
                          c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H, nc_lds, c->fix_scale,
-                         c->d_partc, c->partc_stride);
+                         c->d_partc, c->partc_stride, nc > nc_lds ? 1 : 0);
     else
       hipLaunchKernelGGL(dsgd_cgrad_kernel<false>, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, cv,
                          c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H, nc_lds, c->fix_scale,
-                         c->d_partc, c->partc_stride);
+                         c->d_partc, c->partc_stride, nc > nc_lds ? 1 : 0);
     HIP_TRY(hipGetLastError());
     DSGD_TRY(prof_end(c, slot_g));
   }

@@ -1372,7 +1372,7 @@ __device__ __forceinline__ long long cold_row_start(const ColdView& cv, long lon
   return e_hi;
 }
 
-constexpr int CD_UNR = 4;   // 64-element chunks in flight per wave
+constexpr int CD_UNR = 16;   // 64-element chunks in flight per wave (the cold kernels are latency-bound: 16 waves per CU)
 
 // dcold[row] = sum over the cold entries of the row of filt(value * w[hsplit + col]) for the rows of each
 // worker's range.  Every wave owns a contiguous, ROW-ALIGNED piece of the cold stream: no atomics, fixed order.
@@ -1380,7 +1380,8 @@ constexpr int CD_UNR = 4;   // 64-element chunks in flight per wave
 template <bool PACKED>
 __global__ void __launch_bounds__(1024) dsgd_cdot_kernel(ColdView cv, const long long* __restrict__ crow_ptr,
                                                         const float* __restrict__ w, float* __restrict__ dcold,
-                                                        const StreamSeg* __restrict__ segs, int hsplit, int nc_lds) {
+                                                        const StreamSeg* __restrict__ segs, int hsplit, int nc_lds,
+                                                        int wide) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   typedef __attribute__((address_space(3))) const float lds_cfloat;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1413,10 +1414,17 @@ __global__ void __launch_bounds__(1024) dsgd_cdot_kernel(ColdView cv, const long
       c[k] = in ? c[k] : 0;
       r[k] = in ? r[k] : -1;
     }
+    float wv[CD_UNR];
+#pragma unroll
+    for (int k = 0; k < CD_UNR; ++k) wv[k] = wc[min(c[k], nc_lds - 1)];
+    if (wide) {   // wave-uniform: cold columns beyond the LDS tile exist (very wide models only)
+#pragma unroll
+      for (int k = 0; k < CD_UNR; ++k)
+        if (c[k] >= nc_lds) wv[k] = w[hsplit + c[k]];
+    }
 #pragma unroll
     for (int k = 0; k < CD_UNR; ++k) {
-      const float wv = c[k] < nc_lds ? wc[c[k]] : w[hsplit + c[k]];
-      float p = filt(v[k] * wv);
+      float p = filt(v[k] * wv[k]);
       // the row carried in from the previous chunk: continues in lane 0 or is complete
       if (lane == 0) {
         if (r[k] == carry_row) p += carry_sum;
@@ -1445,7 +1453,8 @@ __global__ void __launch_bounds__(1024) dsgd_cgrad_kernel(ColdView cv, const lon
                                                          long long* __restrict__ g64_base, long long g_stride,
                                                          DevScalars* __restrict__ sc,
                                                          const StreamSeg* __restrict__ segs, int hsplit, int nc_lds,
-                                                         float fix_scale, int* __restrict__ partc, int partc_stride) {
+                                                         float fix_scale, int* __restrict__ partc, int partc_stride,
+                                                         int wide) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int* gc = reinterpret_cast<int*>(lds);   // nc_lds accumulators + 64 always-zero words
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1472,13 +1481,20 @@ __global__ void __launch_bounds__(1024) dsgd_cgrad_kernel(ColdView cv, const lon
       const float vl = cv.val[ic];
       v[k] = in ? vl : 0.0f;   // (a clamped lane re-reads an entry of the range: its q is 0)
     }
+    signed char cf[CD_UNR];
 #pragma unroll
-    for (int k = 0; k < CD_UNR; ++k) {
-      const float coef = (float)coef8[r[k]] * fix_scale;
-      q[k] = __float2int_rn(v[k] * coef);   // y * x on the fixed-point grid (0 for inactive rows and padding)
-      if (c[k] >= nc_lds) {                 // beyond the LDS tile (very wide models): 64-bit global accumulator
-        if (q[k] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[hsplit + c[k]]), (unsigned long long)(long long)q[k]);
-        q[k] = 0;
+    for (int k = 0; k < CD_UNR; ++k) cf[k] = coef8[r[k]];   // all the gate coefficients of the set in flight at once
+#pragma unroll
+    for (int k = 0; k < CD_UNR; ++k)
+      q[k] = __float2int_rn(v[k] * ((float)cf[k] * fix_scale));   // y * x on the fixed-point grid (0: inactive row, padding)
+    if (wide) {   // wave-uniform: columns beyond the LDS tile (very wide models) go to the 64-bit global accumulator
+#pragma unroll
+      for (int k = 0; k < CD_UNR; ++k) {
+        if (c[k] >= nc_lds) {
+          if (q[k] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[hsplit + c[k]]), (unsigned long long)(long long)q[k]);
+          q[k] = 0;
+          c[k] = 0;
+        }
       }
     }
 #pragma unroll

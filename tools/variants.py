@@ -20,13 +20,14 @@ def child(rows):
     for _ in range(n): eng.sync_step_ranges([(0, n_train)], lr)
     eng.synchronize()
     step = (time.perf_counter() - t0) / n * 1e3
+    kinds = eng.prof_read_kinds()
     ms, cnt = eng.prof_read(reset=True)
     eng.loss_acc(0, n_train)
     t0 = time.perf_counter()
     for _ in range(5): loss, acc, _t = eng.loss_acc(0, n_train)
     ev = (time.perf_counter() - t0) / 5 * 1e3
-    print("kernel %.3f ms %5.0f GB/s | step %.3f ms %.3f Gex/s | eval %.3f ms %5.0f GB/s | loss %.6f acc %.4f | %s" % (
-        ms, alg / ms / 1e6, step, n_train / step / 1e6, ev, alg / ev / 1e6, loss, acc, eng.grad_kernel_name()), flush=True)
+    print("cdot %.3f cgrad %.3f | kernel %.3f ms %5.0f GB/s | step %.3f ms %.3f Gex/s | eval %.3f ms %5.0f GB/s | loss %.6f acc %.4f | %s" % (
+        kinds["cdot"][0], kinds["cgrad"][0], ms, alg / ms / 1e6, step, n_train / step / 1e6, ev, alg / ev / 1e6, loss, acc, eng.grad_kernel_name()), flush=True)
 
 if __name__ == "__main__":
     args = sys.argv[1:]
