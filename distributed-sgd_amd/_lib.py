@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB = os.path.join(HERE, "lib", "libdsgd_hip.so")
+HIP_LIB = os.environ.get("DSGD_LIB_PATH") or os.path.join(HERE, "lib", "libdsgd_hip.so")  # (override: A/B runs of two builds)
 
 OK, EINVAL, ERANGE, ESTATE, EHIP, ERCCL, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
 UNIQUE_ID_BYTES = 128

@@ -596,7 +596,7 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
     WTile t;
     t.pos0 = row_ptr[start] & ~3LL;
     t.r0 = (int)start;
-    t.nrows = (int)(end_row - start);
+    t.info = (int)(((end_row - start) & 0xffff) | ((row_ptr[end_row] - t.pos0) << 16));
     wt.push_back(t);
     wr0.push_back((int)start);
     start = -1;
@@ -617,6 +617,7 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
   out.meta.assign((size_t)std::max<long long>(n_tiles, 1) * 64, 0u);
   for (long long t = 0; t < n_tiles; ++t) {
     const WTile& T = wt[(size_t)t];
+    const int t_nrows = (int)(short)(T.info & 0xffff);
     int cur_row = 0, next = 0;
     for (int l = 0; l < 64; ++l) {  // lane l owns slots [8l, 8l+8)
       unsigned int bits = 0, ys = 0;
@@ -624,8 +625,8 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
       for (int k = 0; k < 8; ++k) {
         const long long slot = 8LL * l + k;
         bool st = false;
-        if (next < T.nrows && row_ptr[T.r0 + next] - T.pos0 == slot) st = true;
-        else if (next == T.nrows && row_ptr[T.r0 + T.nrows] - T.pos0 == slot) st = true;  // end mark
+        if (next < t_nrows && row_ptr[T.r0 + next] - T.pos0 == slot) st = true;
+        else if (next == t_nrows && row_ptr[T.r0 + t_nrows] - T.pos0 == slot) st = true;  // end mark
         if (st) {
           bits |= 1u << k;
           // the row that ends here is local row cur_row (1-based); row 0 = leading padding
@@ -642,7 +643,7 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
     WTile t;
     t.pos0 = 0;
     t.r0 = 0;
-    t.nrows = -1;
+    t.info = 0xffff;   // -1 rows, 0 slots
     wt.push_back(t);
   }
 }

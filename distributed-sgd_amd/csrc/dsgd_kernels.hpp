@@ -783,7 +783,7 @@ constexpr int WS_COEF_STRIDE = 256;
 struct WTile {       // 16 bytes, read with one scalar load
   long long pos0;    // first slot of the window (multiple of 4)
   int r0;            // global row of local row 1
-  int nrows;         // rows in the tile (-1: unused entry)
+  int info;          // rows in the tile (low 16 bits, signed; -1: unused entry) | slots holding its non-zeros << 16
 };
 
 struct WTables {
@@ -798,7 +798,7 @@ struct WRegs {
   float dc;            // SPLIT: cold part of x.w of the row that ends in this lane
   unsigned int meta;
   long long pos0, tc;  // wave-uniform (scalar registers): window start, clamped tile index
-  int r0, nrows;       // wave-uniform
+  int r0, nrows, nb;   // wave-uniform: first row, rows, bytes of the window that belong to the tile
 };
 
 // the tile record of tile t (clamped), fetched one iteration before w_issue_cols needs it: a load whose
@@ -817,18 +817,31 @@ __device__ __forceinline__ void w_issue_cols(const CsrView& m, long long t, long
   const bool live = t < t_end;
   r.tc = live ? t : t_end - 1;     // wave-uniform
   r.r0 = wt.r0;
-  r.nrows = live ? wt.nrows : -1;
+  r.nrows = live ? (int)(short)(wt.info & 0xffff) : -1;
   r.pos0 = wt.pos0;
-  const int4* cp = reinterpret_cast<const int4*>(m.col + wt.pos0);
-  const unsigned int o = 2u * (unsigned int)lane;
-  r.c0 = cp[o];
-  r.c1 = cp[o + 1];
+  // Raw buffer over exactly the tile's own slots (rounded up to 16 bytes): lanes past the end get zeros WITHOUT a
+  // memory access.  Reading the whole 512-slot window would fetch the first ~50 slots of the next tile a second
+  // time -- with three tiles in flight per wave those lines have left the caches again (rocprofv3 FETCH_SIZE was
+  // 1.2 x the algorithmic bytes).
+  r.nb = (int)(((unsigned int)wt.info >> 16) + 3u & ~3u) * 4;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(m.col + wt.pos0), 0, r.nb, 0x00020000);
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 a = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane, 0, 0));
+  const i32x4 b = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane + 16, 0, 0));
+  r.c0 = make_int4(a.x, a.y, a.z, a.w);
+  r.c1 = make_int4(b.x, b.y, b.z, b.w);
 }
 __device__ __forceinline__ void w_issue_vals(const CsrView& m, const WTables& tt, int lane, WRegs& r) {
-  const float4* vp = reinterpret_cast<const float4*>(m.val + r.pos0);
-  const unsigned int o = 2u * (unsigned int)lane;
-  r.v0 = vp[o];
-  r.v1 = vp[o + 1];
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m.val + r.pos0), 0, r.nb, 0x00020000);
+  // (whole-vector bit casts: an element-wise __builtin_bit_cast(float, a.x) of the returned vector is folded to
+  //  component 0 for all four elements by this compiler)
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane, 0, 0));
+  const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane + 16, 0, 0));
+  r.v0 = make_float4(a.x, a.y, a.z, a.w);
+  r.v1 = make_float4(b.x, b.y, b.z, b.w);
   r.meta = (tt.meta + r.tc * 64)[(unsigned int)lane];
 }
 
@@ -924,7 +937,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
   const WTile wt_now = wt_far;                                              // record fetched last iteration
   wt_far = w_fetch(tt, tile + DEPTH * stride, t_end);                       // record used next iteration
   w_issue_cols(m, tile + (DEPTH - 1) * stride, t_end, lane, wt_now, far);
-  w_issue_vals(m, tt, lane, DEPTH == 4 ? mid : far);                        // tile t+2
+  w_issue_vals(m, tt, lane, far);   // (values with the column ids: the window descriptor stays in scalar registers)
   if (SPLIT) w_load_dc(x, nxt);   // tile t+1 (descriptor landed): one load instead of eight gathers
   else if (dbg & 32) w_gather_off(nxt);
   else w_gather(wrs, x.hw, nxt);                                           // tile t+1
@@ -959,16 +972,18 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
     // ---- common case: at most one row start per lane -> at most one row ENDS in this lane ----
     // T = slots from the lane's row start on (all eight when no row starts here): they continue into the next
     // lane (`trail`); the slots before the start close the row entering the lane (`head`)
-    const unsigned int low = bits & (0u - bits);
-    const unsigned int T = bits ? (0xffu & ~(low - 1u)) : 0xffu;
+    const unsigned int kstar = bits ? (unsigned int)__builtin_ctz(bits) : 0u;   // first slot of T
     bool in_t[8];
-    float head = 0.0f, trail = 0.0f;
+    float mk[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      in_t[k] = (T >> k) & 1u;
-      trail += in_t[k] ? pk[k] : 0.0f;
-      head += in_t[k] ? 0.0f : pk[k];
+      in_t[k] = (unsigned int)k >= kstar;
+      mk[k] = in_t[k] ? pk[k] : 0.0f;
     }
+    // pairwise trees (packed adds); head = total - trail is exact when the lane holds no start or starts at slot 0
+    const float total = ((pk[0] + pk[1]) + (pk[2] + pk[3])) + ((pk[4] + pk[5]) + (pk[6] + pk[7]));
+    const float trail = ((mk[0] + mk[1]) + (mk[2] + mk[3])) + ((mk[4] + mk[5]) + (mk[6] + mk[7]));
+    const float head = total - trail;
     float s = trail;
     int f = bits != 0u;
     if (!(dbg & 8)) wave_seg_scan(s, f);
@@ -1006,7 +1021,10 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float coef = in_t[k] ? cT : cA;
-        q[k] = (SPLIT || cc[k] < x.hg) ? __float2int_rn(vv[k] * coef) : 0;   // y * x on the fixed-point grid
+        // y * x on the fixed-point grid: |v * coef| <= 2^21, so v * coef + 1.5 * 2^23 rounds (once, to nearest even)
+        // to an fp32 whose low mantissa bits are the integer
+        const int qi = __float_as_int(fmaf(vv[k], coef, 12582912.0f)) - 0x4B400000;
+        q[k] = (SPLIT || cc[k] < x.hg) ? qi : 0;
       }
       w_scatter<ABL>(x, cc, q, lane, dbg);
       __builtin_amdgcn_wave_barrier();
@@ -1197,6 +1215,7 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
     wt = w_fetch(tt, tile + 2 * stride, t_end);
     if (DEPTH == 4) {
       w_issue_cols(m, tile + 2 * stride, t_end, lane, wt, C);
+      w_issue_vals(m, tt, lane, C);
       wt = w_fetch(tt, tile + 3 * stride, t_end);
     }
     if (SPLIT) w_load_dc(x, A);
