@@ -140,6 +140,7 @@ def main():
     sync_all(eng)
     barrier()
     dt = time.perf_counter() - t0
+    last = eng.sync_step_ranges(ranges, 0.0)   # (outside the clock) gate statistics of the state the timed steps ended in
     kinds = eng.prof_read_kinds()
     kernel_ms, n_launch = eng.prof_read(reset=True)
     eng.prof_enable(False)
@@ -174,6 +175,7 @@ def main():
             "parallelism": "dp%d (row-partitioned, RCCL all-reduce of the %d-float gradient)" % (world, data.dim + 1),
             "seed": args.seed,
         },
+        "active_fraction_after": last["n_active"] / max(1, last["n_samples"]),
         "test_loss_after": loss,
         "test_acc_after": acc,
         "setup_s": {"generate": round(t_gen, 2), "upload": round(t_up, 2)},
@@ -380,9 +382,11 @@ def epochs_to_target(dsgd_amd, device):
     # the hinge part of the loss moves in steps of 1/n_test (predictions are -1/0/+1): allow one test row of slack
     slack = 1.0 / (n_rows - n_train)
     reached = next((i + 1 for i, l in enumerate(curve) if l <= target + slack), None)
+    reached_ref = next((i + 1 for i, l in enumerate(ref_curve) if l <= target + slack), None)
     return {"config": "23149 rows, 3 workers x batch 100, lr 0.5, lambda 1e-5, 10 epochs", "target_test_loss": target,
             "slack": slack,
-            "engine_epochs": reached, "oracle_epochs": epochs, "engine_test_loss": curve, "oracle_test_loss": ref_curve,
+            "max_epochs": epochs, "engine_epochs": reached, "oracle_epochs": reached_ref,
+            "engine_test_loss": curve, "oracle_test_loss": ref_curve,
             "engine_s": t_eng, "oracle_s": t_ref, "steps_per_epoch": len(lists[0])}
 
 

@@ -892,13 +892,17 @@ __device__ __forceinline__ void w_load_dc(const WCtx& x, WRegs& r) {
 // Overflow control without a quiet point: whoever SEES an entry at |old| >= 2^28 swaps it out into the 64-bit
 // global accumulator; an entry seen at |old| >= 2^30 raises the error bit (a contribution is <= 2^21 and at most
 // 16 waves x 8 adds are in flight, so a wrap would have to pass through that band unseen).
-template <bool ABL>
+template <bool ABL, bool SPLIT>
 __device__ __forceinline__ void w_scatter(const WCtx& x, const int (&cc)[8], const int (&q)[8], int lane, int dbg) {
   int old[8];
+  const int esh = SPLIT ? 0 : 2;             // split layout: cc[] are byte offsets already
+  const int dummy = (x.hg + lane) << 2;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int slot = q[k] != 0 ? cc[k] : x.hg + lane;
-    old[k] = (ABL && (dbg & 4)) ? 0 : atomicAdd(&x.gl[slot], q[k]);   // ds_add_rtn_u32
+    // (measured: adding the zeros to their real columns instead costs +33 % kernel time in LDS bank conflicts)
+    const int off = q[k] != 0 ? (cc[k] << esh) : dummy;
+    int* slot = reinterpret_cast<int*>(reinterpret_cast<char*>(x.gl) + off);
+    old[k] = (ABL && (dbg & 4)) ? 0 : atomicAdd(slot, q[k]);   // ds_add_rtn_u32
   }
   int hi = max(max(old[0], old[1]), old[2]), lo = min(min(old[0], old[1]), old[2]);   // v_max3 / v_min3
   hi = max(max(hi, old[3]), old[4]);
@@ -912,8 +916,9 @@ __device__ __forceinline__ void w_scatter(const WCtx& x, const int (&cc)[8], con
     for (int k = 0; k < 8; ++k) {
       if (old[k] >= WS_SPILL_AT || old[k] <= -WS_SPILL_AT) {
         if (old[k] >= WS_PANIC_AT || old[k] <= -WS_PANIC_AT) atomicOr(&x.sc->err, 2);
-        const int v = atomicExch(&x.gl[cc[k]], 0);
-        if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[cc[k]]), (unsigned long long)(long long)v);
+        const int col = SPLIT ? cc[k] >> 2 : cc[k];
+        const int v = atomicExch(&x.gl[col], 0);
+        if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[col]), (unsigned long long)(long long)v);
       }
     }
   }
@@ -955,7 +960,10 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
   // the reference's product map is.  ref: math/Sparse.scala:46
   float a[8], pk[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) a[k] = (dbg & 16) ? 0.5f : wl3[SPLIT ? cc[k] : min(cc[k], x.hw)];
+  for (int k = 0; k < 8; ++k) {
+    if (SPLIT) a[k] = *(lds_cfloat*)((__attribute__((address_space(3))) const char*)wl3 + cc[k]);   // byte offset, wl at LDS 0
+    else a[k] = (dbg & 16) ? 0.5f : wl3[min(cc[k], x.hw)];
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) pk[k] = filt(vv[k] * (SPLIT ? a[k] : a[k] + cur.gw[k]));
 
@@ -1026,7 +1034,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
         const int qi = __float_as_int(fmaf(vv[k], coef, 12582912.0f)) - 0x4B400000;
         q[k] = (SPLIT || cc[k] < x.hg) ? qi : 0;
       }
-      w_scatter<ABL>(x, cc, q, lane, dbg);
+      w_scatter<ABL, SPLIT>(x, cc, q, lane, dbg);
       __builtin_amdgcn_wave_barrier();
     }
   } else {
@@ -1089,7 +1097,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
         }
         q[k] = (SPLIT || cc[k] < x.hg) ? __float2int_rn(vv[k] * coef) : 0;
       }
-      w_scatter<ABL>(x, cc, q, lane, dbg);
+      w_scatter<ABL, SPLIT>(x, cc, q, lane, dbg);
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -1179,9 +1187,12 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
   WCtx x;
   x.dbg = dbg;
   x.coef8 = coef8;
-  x.coefw = lds + wave * WS_COEF_STRIDE;                       // 16 strips
-  x.gl = reinterpret_cast<int*>(lds + 16 * WS_COEF_STRIDE);    // hg + 64 always-zero words (SCATTER only)
-  float* wl = lds + 16 * WS_COEF_STRIDE + (SCATTER ? hg + 64 : 0);  // hw + 1 (zero slot at wl[hw])
+  // LDS: 16 coefficient strips, hg + 64 gradient words (SCATTER only; the last 64 stay zero), hw + 1 weights (zero
+  // slot at wl[hw]).  The split layout puts the weights FIRST: its column ids are byte offsets from LDS address 0.
+  float* wl = SPLIT ? lds : lds + 16 * WS_COEF_STRIDE + (SCATTER ? hg + 64 : 0);
+  float* strips = SPLIT ? lds + ((hw + 4) & ~3) : lds;
+  x.coefw = strips + wave * WS_COEF_STRIDE;
+  x.gl = reinterpret_cast<int*>(strips + 16 * WS_COEF_STRIDE);
   x.wl = wl;
   const StreamSeg seg = segs[blockIdx.y];
   x.g64 = g64_base + (long long)blockIdx.y * g_stride;
@@ -1352,7 +1363,7 @@ __global__ void __launch_bounds__(256) dsgd_split_fill_kernel(CsrView m, int hsp
       const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
       if (hot) {
         const long long o = hp + __popcll(mh & below);
-        hcol[o] = c;
+        hcol[o] = c * 4;   // the hot stream carries BYTE offsets into the LDS tiles (no shift in the kernel)
         hval[o] = v;
       }
       if (cold) {
