@@ -140,10 +140,10 @@ def main():
     sync_all(eng)
     barrier()
     dt = time.perf_counter() - t0
-    last = eng.sync_step_ranges(ranges, 0.0)   # (outside the clock) gate statistics of the state the timed steps ended in
     kinds = eng.prof_read_kinds()
     kernel_ms, n_launch = eng.prof_read(reset=True)
     eng.prof_enable(False)
+    last = eng.sync_step_ranges(ranges, 0.0)   # (outside the clock) gate statistics of the state the timed steps ended in
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -196,6 +196,9 @@ struct dsgd_ctx {
   float* d_g = nullptr;  // g_cap x dp
   long long* d_g64 = nullptr;  // g_cap x dp fixed-point accumulators of the streaming kernel (zero between steps)
   float fix_scale = 4194304.0f;  // 2^FIX_SHIFT / vmax2
+  int vexp = 0;                  // vmax2 = 2^vexp >= max |value|
+  int last_shift = FIX_SHIFT;    // shift of the last split-layout gradient launch
+  int max_shift = FIX_SHIFT;     // DSGD_FIX_SHIFT: cap of the per-launch fixed-point shift of the split layout
   int g_cap = 0;
   float* d_gsum = nullptr;  // dp (all-reduce buffer / sum over hosted workers)
   float* d_tmp = nullptr;   // dp scratch (ranked order)
@@ -877,8 +880,8 @@ static int ensure_part(dsgd_ctx* c, int** buf, long long* wgs, int* stride, long
 static int finish_mode3(dsgd_ctx* c, int n_workers, int part_wg_per_worker, int part_hg) {
   if (part_wg_per_worker > 0)
     hipLaunchKernelGGL(dsgd_fix_reduce_kernel, dim3((c->dp + 63) / 64, n_workers), dim3(1024), 0, c->stream, c->d_g64, c->d_g,
-                       (long long)c->dp, c->dp, part_hg, c->d_part, c->part_stride, part_wg_per_worker, 0, 0,
-                       (const int*)nullptr, 0, 0, 1.0 / (double)c->fix_scale);
+                       (long long)c->dp, c->dp, part_hg, c->d_part, c->part_stride, part_wg_per_worker, c->dp, 0,
+                       (const int*)nullptr, 0, 0, 1.0 / (double)c->fix_scale, 1.0 / (double)c->fix_scale);
   else
     hipLaunchKernelGGL(dsgd_fix_finalize_kernel, dim3((c->dp + 1023) / 1024, n_workers), dim3(1024), 0, c->stream, c->d_g64,
                        c->d_g, (long long)c->dp, c->dp, 1.0 / (double)c->fix_scale);
@@ -919,7 +922,7 @@ static int launch_wseg(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   hipLaunchKernelGGL((dsgd_wseg_kernel<SCATTER, ABL, 4, false>), grid, dim3(1024), lds, c->stream, m, m, c->d_wtiles,   \
                      c->d_wmeta, c->d_w, c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, c->fix_scale,      \
                      c->d_coef8, c->dp, c->dbg, c->d_wlong_rows, part ? c->d_part : nullptr, c->part_stride,         \
-                     (const float*)nullptr)
+                     (const float*)nullptr, c->fix_scale)
   if (c->dbg) DSGD_LAUNCH_WSEG(true);   // ablation build of the same kernel (DSGD_DBG, tuning runs only)
   else DSGD_LAUNCH_WSEG(false);
 #undef DSGD_LAUNCH_WSEG
@@ -971,6 +974,32 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
     DSGD_TRY(ensure_part(c, &c->d_part, &c->part_wgs, &c->part_stride, (long long)grid.x * grid.y, hg));
     if (cold) DSGD_TRY(ensure_part(c, &c->d_partc, &c->partc_wgs, &c->partc_stride, (long long)gridc.x * gridc.y, nc_lds));
   }
+  // Fixed-point scale of THIS launch: a column receives at most one contribution per row, |contribution| <= 2^shift,
+  // and workgroup b of a worker owns the 16-tile groups b, b + grid.x, ... of its tile range (plus its share of the
+  // long rows): with rows(b) <= 2^bits, shift = 30 - bits keeps every 32-bit LDS sum below 2^30.  (Rows between the
+  // first rows of two tiles bound the rows of a tile from above.)
+  float main_scale = c->fix_scale;
+  if (SCATTER) {
+    const std::vector<int>& wr0 = c->h_wtile_r0;
+    long long worst = 1;
+    std::vector<long long> rows_of((size_t)grid.x);
+    for (const StreamSeg& sg : segs) {
+      std::fill(rows_of.begin(), rows_of.end(), 0);
+      long long g = 0;
+      for (long long t = sg.tile_begin; t < sg.tile_end; t += 16, ++g) {
+        const long long t1 = std::min<long long>(t + 16, sg.tile_end);
+        rows_of[(size_t)(g % grid.x)] += (long long)wr0[(size_t)t1] - (long long)wr0[(size_t)t];
+      }
+      const long long n_long = sg.long_end - sg.long_begin;
+      const long long long_share = (n_long + 16LL * grid.x - 1) / (16LL * grid.x) * 16;
+      for (long long v : rows_of) worst = std::max(worst, v + long_share);
+    }
+    int bits = 0;
+    while ((1LL << bits) < worst) ++bits;
+    const int shift = std::max(1, std::min(c->max_shift, 30 - bits));
+    main_scale = std::ldexp(1.0f, shift - c->vexp);
+    c->last_shift = shift;
+  }
   CsrView mh = view(c);
   mh.row_ptr = c->d_hrow_ptr;
   mh.col = c->d_hcol;
@@ -979,8 +1008,8 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   size_t slot = 0;
   if (SCATTER) DSGD_TRY(prof_begin(c, &slot));
   hipLaunchKernelGGL((dsgd_wseg_kernel<SCATTER, false, 4, true>), grid, dim3(1024), lds, c->stream, mh, mf, c->d_wtiles,
-                     c->d_wmeta, c->d_w, c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, c->fix_scale, c->d_coef8,
-                     c->dp, 0, c->d_wlong_rows, SCATTER ? c->d_part : nullptr, c->part_stride, c->d_dcold);
+                     c->d_wmeta, c->d_w, c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, main_scale, c->d_coef8,
+                     c->dp, 0, c->d_wlong_rows, SCATTER ? c->d_part : nullptr, c->part_stride, c->d_dcold, c->fix_scale);
   HIP_TRY(hipGetLastError());
   if (SCATTER) DSGD_TRY(prof_end(c, slot));
   if (!SCATTER) return DSGD_OK;
@@ -1001,7 +1030,7 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   }
   hipLaunchKernelGGL(dsgd_fix_reduce_kernel, dim3((c->dp + 63) / 64, n_workers), dim3(1024), 0, c->stream, c->d_g64, c->d_g,
                      (long long)c->dp, c->dp, hg, c->d_part, c->part_stride, (int)grid.x, H, cold ? nc_lds : 0, c->d_partc,
-                     c->partc_stride, (int)gridc.x, 1.0 / (double)c->fix_scale);
+                     c->partc_stride, (int)gridc.x, 1.0 / (double)main_scale, 1.0 / (double)c->fix_scale);
   HIP_TRY(hipGetLastError());
   return DSGD_OK;
 }
@@ -1103,6 +1132,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   }
   if (const char* e = getenv("DSGD_EPI")) c->use_part = atoi(e) != 0;
   if (const char* e = getenv("DSGD_DBG")) c->dbg = atoi(e);
+  if (const char* e = getenv("DSGD_FIX_SHIFT")) c->max_shift = std::max(8, std::min(FIX_SHIFT, atoi(e)));
   if (c->dbg) c->stream_mode = 3;   // the ablation build exists for the mode-3 kernel
   if (const char* e = getenv("DSGD_HW_W")) c->hw_w = atoi(e);
   if (const char* e = getenv("DSGD_HG_W")) c->hg_w = atoi(e);
@@ -1288,6 +1318,7 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr_in, const 
     int e = 0;
     std::frexp(vmax > 0.0f ? vmax : 1.0f, &e);  // vmax = f * 2^e, f in [0.5, 1)  ->  vmax2 = 2^e >= vmax
     if (vmax > 0.0f && std::ldexp(1.0f, e - 1) == vmax) e -= 1;  // vmax itself a power of two
+    c->vexp = e;   // vmax2 = 2^e
     c->fix_scale = std::ldexp(1.0f, FIX_SHIFT - e);
   }
   c->h_row_ptr.assign(row_ptr, row_ptr + n_rows + 1);

@@ -11,7 +11,7 @@ def child(rows):
     eng = dsgd_amd.Engine(data.dim, 1e-5)
     eng.load_csr(data.row_ptr, data.col, data.val, data.label)
     eng.build_dim_sparsity(n_train)
-    lr = 0.5 * 100 / n_train
+    lr = 0.0 if os.environ.get("VAR_ALL_ACTIVE") else 0.5 * 100 / n_train   # lr 0: w stays 0, every row active
     for _ in range(6): eng.sync_step_ranges([(0, n_train)], lr)
     eng.synchronize()
     eng.prof_enable(True); eng.prof_read(reset=True)
