@@ -2,6 +2,7 @@
 
     libdsgd_hip.so    hipcc --offload-arch=gfx950   csrc/dsgd_hip.hip   (the product)
     libdsgd_synth.so  gcc -fopenmp                  csrc/synth.c        (synthetic RCV1-like data)
+    libdsgd_rcv1.so   gcc                           csrc/rcv1.c         (RCV1-v2 text files -> CSR, Dataset.rcv1 semantics)
 
 hipcc cross-compiles gfx950 without a GPU, so this runs in the build container too.
 
@@ -29,6 +30,8 @@ HIP_SRC = os.path.join(CSRC, "dsgd_hip.hip")
 HIP_LIB = os.path.join(LIBDIR, "libdsgd_hip.so")
 SYNTH_SRC = os.path.join(CSRC, "synth.c")
 SYNTH_LIB = os.path.join(LIBDIR, "libdsgd_synth.so")
+RCV1_SRC = os.path.join(CSRC, "rcv1.c")
+RCV1_LIB = os.path.join(LIBDIR, "libdsgd_rcv1.so")
 
 
 def _stale(target: str, *sources: str) -> bool:
@@ -97,8 +100,16 @@ def build_synth(force: bool = False) -> str:
     return SYNTH_LIB
 
 
+def build_rcv1(force: bool = False) -> str:
+    if not force and not _stale(RCV1_LIB, RCV1_SRC, __file__):
+        return RCV1_LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    _run(["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-Wall", RCV1_SRC, "-o", RCV1_LIB])
+    return RCV1_LIB
+
+
 def build_all(force: bool = False) -> dict:
-    return {"hip": build_hip(force), "synth": build_synth(force)}
+    return {"hip": build_hip(force), "synth": build_synth(force), "rcv1": build_rcv1(force)}
 
 
 if __name__ == "__main__":
