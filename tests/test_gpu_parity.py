@@ -384,6 +384,36 @@ def test_streaming_layouts_match_oracle(monkeypatch, mode, dim, hsplit):
         np.testing.assert_array_equal(eng.get_weights(), w1)
 
 
+# ---- the in-library RCCL path with a communicator of size one (the N>1 code path on a 1-GPU box) --------------------
+def test_communicator_of_size_one_changes_nothing():
+    """dsgd_comm_init(world=1): column counts, dimSparsity counts, the gradient and the evaluation tallies all go
+    through ncclAllReduce over one rank -- results must equal the no-communicator engine bit for bit."""
+    n_rows, n_train = 60000, 50000
+    data = dsgd_amd.synth.generate(n_rows, seed=9)
+    lr = 0.5 * 100 / n_train
+    rng = np.random.default_rng(9)
+    lists = [[rng.permutation(n_train)[:100].astype(np.int32) for _ in range(3)] for _ in range(5)]
+    out = []
+    for with_comm in (False, True):
+        with dsgd_amd.Engine(data.dim, 1e-5) as eng:
+            eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+            if with_comm:
+                eng.comm_init(dsgd_amd.Engine.comm_unique_id(), 1, 0)
+            ds = eng.build_dim_sparsity(n_train)
+            stats = [eng.sync_step_ranges([(0, n_train)], lr), eng.sync_step_ranges([(0, 20000), (20000, n_train)], 2 * lr)]
+            w_stream = eng.get_weights()
+            for step in lists:
+                stats.append(eng.sync_step(step, 0.5))
+            out.append((ds, w_stream, eng.get_weights(), eng.loss_acc(n_train, n_rows), stats))
+    (ds0, ws0, w0, la0, st0), (ds1, ws1, w1, la1, st1) = out
+    np.testing.assert_array_equal(ds0, ds1)
+    np.testing.assert_array_equal(ws0, ws1)          # whole-range steps: integer sums, bit-identical
+    assert st0 == st1
+    assert la0[2] == la1[2]                          # tallies
+    # index-list steps accumulate with fp32 L2 atomics: equal to rounding only
+    assert np.abs(w0 - w1).max() <= 1e-5 * max(1.0, np.abs(w0).max())
+
+
 # ---- ragged inputs: empty rows, one-element rows, values below the Sparse epsilon ---------------------
 def ragged_data(seed, n_rows=6000):
     base = dsgd_amd.synth.generate(n_rows, seed=seed)
