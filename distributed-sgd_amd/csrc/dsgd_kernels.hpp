@@ -746,33 +746,29 @@ __device__ __forceinline__ void wave_seg_scan(float& v, int& f) {
 // ======================================================================================================
 // K1e / K5d: WAVE-independent streaming kernels ("wseg"): no workgroup barrier inside the stream loop
 // ======================================================================================================
-// Two measurements on MI355X shaped this kernel:
-//  * ablation of dsgd_seg_kernel (tools/ablate.py): with one 1024-lane workgroup per CU (needed for the
-//    160 KiB of LDS tiles) two barriers per tile put all 16 waves in lockstep -- HBM, VALU and the LDS
-//    atomics are used one after the other (51-70 % of the wave cycles are SQ_WAIT_ANY);
-//  * the first barrier-free version executed ~750 instructions per 512-slot tile and was bound by VALU
-//    issue (2 wave64 instructions per clock and CU), not by memory.
-// So: every WAVE owns its own tiles of 512 slots made of WHOLE rows (no data ever crosses waves; the 16
-// waves of the workgroup drift apart and overlap each other's memory waits, DPP scans and LDS atomics
-// while sharing the LDS weight tile and the LDS gradient tile), and the per-tile instruction count is
-// kept near 240 (evaluation) / 340 (gradient):
-//   * lane l owns the 8 CONTIGUOUS slots [8l, 8l+8): two 16-byte loads per array, scalar base + 32-bit
-//     lane offset addressing, no clamping (col/val carry 520 elements of padding);
+// Measurements on MI355X that shaped this kernel (profiles/README.md):
+//  * with one 1024-lane workgroup per CU (needed for the 160 KiB of LDS tiles) two barriers per tile put all 16
+//    waves in lockstep -- HBM, VALU and the LDS atomics were used one after the other (51-70 % SQ_WAIT_ANY);
+//  * the first barrier-free version executed ~750 instructions per 512-slot tile and was bound by VALU issue;
+//  * trimming it to ~250 changed nothing once the memory pipeline was the limiter: what helped next was taking
+//    the cold columns out of the stream (split layout), exact-size windows, and atomics that never overflow.
+// So: every WAVE owns its own tiles of 512 slots made of WHOLE rows (no data ever crosses waves; the 16 waves of the
+// workgroup drift apart and overlap each other's memory waits, DPP scans and LDS atomics while sharing the LDS
+// weight tile and the LDS gradient tile):
+//   * lane l owns the 8 CONTIGUOUS slots [8l, 8l+8): two 16-byte buffer loads per array through a resource that
+//     covers exactly the tile's own bytes, four register sets rotated by unrolling (three tiles in flight);
 //   * one 32-bit descriptor per lane: local row of its first slot (8 bits, rows 1-based, 0 / nrows+1 =
 //     padding), row-start bits (8), label sign of the row ENDING at each start (8): no per-row loads;
-//   * weight lookup without selects: w[dp] == 0 and wl[hw] == 0 are zero slots, so
-//     w_c = wl[min(c, hw)] + w[c < hw ? dp : c];
 //   * ONE DPP segmented scan per tile; a lane with at most one row start (the common case: rows >= 8
 //     non-zeros) finalises branch-free, the general loop runs only when some lane of the wave holds two;
 //   * gate coefficients go through a per-wave LDS strip, pre-multiplied by the fixed-point scale
 //     (same wave writes and reads: LDS executes a wave's accesses in order, no barrier);
-//   * rows longer than WS_MAXNNZ non-zeros are left to the row-per-group kernel (3 % of the RCV1-like
-//     non-zeros).
-// Gradient accumulation: ds_add_rtn_u32 fixed point (FIX_SHIFT); rounding to the fixed-point grid also
-// absorbs the reference's 1e-20 filter on y*x.  Without a workgroup-wide quiet point the overflow control
-// is local: the lane that brings an entry to |q| >= 2^28 swaps it out (ds_wrxchg) into the 64-bit global
-// accumulator.  Should an entry ever be SEEN at |q| >= 2^30 the kernel raises DevScalars::err bit 2 and
-// the host rejects the step (a wrap-around must pass through that band: one contribution is <= 2^21).
+//   * rows longer than WS_MAXNNZ non-zeros are processed after the tiles, one wave per row.
+// Two variants of the column handling (template SPLIT): the split layout (hot columns only, cold part of x.w from
+// dcold, plain ds_add_u32 with a per-launch scale) and the older mode 3 (all columns: cold weights gathered with
+// out-of-range buffer loads -- w[dp] == 0 and wl[hw] == 0 are zero slots, so w_c = wl[min(c, hw)] + gathered --
+// cold gradient columns left to the transposed lists, ds_add_rtn_u32 with the spill rule described at w_scatter).
+// Rounding to the fixed-point grid also absorbs the reference's 1e-20 filter on y*x.
 constexpr int WS_SLOTS = 512;
 constexpr int WS_MAXNNZ = WS_SLOTS - 8;
 constexpr int WS_MAXROWS = 254;
