@@ -11,6 +11,8 @@ the reference.  Citations are relative to /root/reference/src/main/scala/epfl/di
     scala_shuffle     scala.util.Random.shuffle (2.12): the per-batch reshuffle of Master.scala:184
     MasterSync.fit    core/Master.scala:120-218
     MasterAsync.fit   core/MasterAsync.scala:32-62, 96-177
+    Metrics           the Kamon instruments of the path, same names (core/Slave.scala:90-181, core/Master.scala:150-183)
+    format_final_weights   the `final weights: idx:val ...` log line (Main.scala:114)
 
 All arithmetic happens behind a *backend* (the HIP `Engine`); this module only orchestrates.  A backend
 offers: sync_step(idx_lists, lr), gradient(idx) -> (g, stats), apply(g_mean, lr), loss_acc(lo, hi),
@@ -26,6 +28,70 @@ from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
 
 import numpy as np
+
+
+SPARSE_EPSILON = 1e-20  # math/Sparse.scala:104: entries with abs(v) <= epsilon are not stored
+
+
+# ---- instruments (Kamon names, so dashboards such as kube/monitor.yaml keep working) ----------------------
+class Metrics:
+    """Counters / histograms / timers under the reference's instrument names:
+    counters `slave.sync.forward`, `slave.sync.backward` (one increment per SAMPLE, core/Slave.scala:131-150),
+    `slave.async.backward` (per sample, :90-95), `slave.async.batch` (:107), `slave.async.grad.update` (:181),
+    `master.async.loss` (MasterAsync.scala:126); histograms `master.sync.loss`, `master.sync.acc`
+    (Master.scala:150-151 record `losses.head.toLong` and `100 * accs.head.toLong`: the values are TRUNCATED to
+    integers before they are recorded -- kept); timer `master.sync.batch.duration` (:183)."""
+
+    def __init__(self):
+        import threading
+
+        self._lock = threading.Lock()
+        self.counters: dict = {}
+        self.histograms: dict = {}
+
+    def counter(self, name: str, times: int = 1):
+        with self._lock:
+            self.counters[name] = self.counters.get(name, 0) + int(times)
+
+    def histogram(self, name: str, value):
+        with self._lock:
+            self.histograms.setdefault(name, []).append(int(value))  # .toLong
+
+    def timer(self, name: str):
+        metrics = self
+
+        class _T:
+            def __enter__(self):
+                self.t0 = time.perf_counter_ns()
+                return self
+
+            def __exit__(self, *exc):
+                with metrics._lock:
+                    metrics.histograms.setdefault(name, []).append(time.perf_counter_ns() - self.t0)
+
+        return _T()
+
+    def snapshot(self) -> dict:
+        with self._lock:
+            return {"counters": dict(self.counters), "histograms": {k: list(v) for k, v in self.histograms.items()}}
+
+    def influx_lines(self, tags: str = "") -> List[str]:
+        """InfluxDB line protocol (the reference reports through kamon-influxdb, Main.scala:42)."""
+        snap, t = self.snapshot(), time.time_ns()
+        tag = ("," + tags) if tags else ""
+        out = ["%s%s count=%di %d" % (k, tag, v, t) for k, v in sorted(snap["counters"].items())]
+        for k, v in sorted(snap["histograms"].items()):
+            if v:
+                out.append("%s%s count=%di,sum=%di,min=%di,max=%di %d" % (k, tag, len(v), sum(v), min(v), max(v), t))
+        return out
+
+
+def format_final_weights(w, eps: float = SPARSE_EPSILON) -> str:
+    """Main.scala:114: `w1.map.map { case (idx, n) => s"$idx:$n" }.mkString(" ")` -- the stored (non-zero) entries as
+    `idx:value`.  The reference iterates an immutable HashMap (unspecified order) and prints fp64; here ascending keys
+    and the shortest decimal that round-trips the engine's fp32 value."""
+    arr = np.asarray(w)
+    return " ".join("%d:%s" % (int(k), repr(float(np.float32(arr[k])))) for k in np.flatnonzero(np.abs(arr) > eps))
 
 
 # ---- configuration --------------------------------------------------------------------------------------
@@ -249,8 +315,10 @@ class MasterSync:
 
     data layout: rows [0, n_train) are the train set, [n_train, n_rows) the test set (Main.scala:52)."""
 
-    def __init__(self, backend, n_train: int, n_rows: int, node_count: int, rnd: Optional[JavaRandom] = None, log=None):
+    def __init__(self, backend, n_train: int, n_rows: int, node_count: int, rnd: Optional[JavaRandom] = None, log=None,
+                 metrics: Optional[Metrics] = None):
         self.backend, self.n_train, self.n_rows, self.node_count = backend, n_train, n_rows, node_count
+        self.metrics = metrics or Metrics()
         self.rnd = rnd or JavaRandom(0)
         self.log = log or (lambda *a: None)
         self.losses: List[float] = []
@@ -277,6 +345,8 @@ class MasterSync:
             if self.losses:
                 self.log("loss after epoch %d: %s" % (epoch, self.losses[0]))
                 self.log("acc after epoch %d: %s" % (epoch, self.accs[0]))
+                self.metrics.histogram("master.sync.loss", self.losses[0])       # Master.scala:150 (.toLong)
+                self.metrics.histogram("master.sync.acc", 100 * int(self.accs[0]))  # :151: 100 * accs.head.toLong
             if epoch >= max_epochs:                             # :154
                 self.log("Reached max number of epochs: stopping computation")
                 return state.finish(self.losses[0] if self.losses else None)
@@ -290,7 +360,10 @@ class MasterSync:
                     shuffled = scala_shuffle(list(r), self.rnd)
                     lists.append(np.asarray(shuffled[batch:batch + batch_size], dtype=np.int32))
                 # a slice past the end of a short last split is empty: Vec.sum would throw in the slave
-                self.backend.sync_step(lists, learning_rate)     # :186-197
+                with self.metrics.timer("master.sync.batch.duration"):   # :183
+                    st = self.backend.sync_step(lists, learning_rate)    # :186-197
+                if st:
+                    self.metrics.counter("slave.sync.backward", st.get("n_samples", 0))  # Slave.scala:145-150
             w = self.backend.get_weights()
             state = state.replace_grad(w)
             # :206-209 -- four full passes per epoch; newest first

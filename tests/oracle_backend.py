@@ -1,6 +1,8 @@
 """Test helper: the CPU oracle behind the backend interface of distributed-sgd_amd/host.py, so that the
 host-side orchestration (Master.fit mirror, host-owned all-reduce) can be exercised without a GPU."""
 
+import threading
+
 import numpy as np
 
 
@@ -10,10 +12,32 @@ class OracleBackend:
         self.lam = oracle.lam
         self.w = np.zeros(oracle.dim + 1)
         self.steps = []
+        self.mu = threading.Lock()  # the engine serialises calls on a context; handlers arrive from 8 pool threads
 
-    def gradient(self, idx):
-        g = self.o.gradient(self.w, idx)
+    def gradient(self, idx, w=None):
+        wv = self.w if w is None else np.asarray(w, dtype=np.float64)
+        g = self.o.gradient(wv, idx)
         return g, {"n_samples": len(idx), "n_active": self.o.last_stats["n_active"]}
+
+    def forward(self, idx, w=None):
+        return self.o.forward(self.w if w is None else np.asarray(w, dtype=np.float64), idx)
+
+    def async_step(self, idx, lr, want_delta=False):
+        with self.mu:
+            w = np.ascontiguousarray(self.w, dtype=np.float64).copy()
+            delta = self.o.async_step(w, idx, lr, want_delta=want_delta)
+            self.w = w
+            return delta, {"n_samples": len(idx), "n_active": self.o.last_stats["n_active"]}
+
+    def update_grad(self, keys, values):
+        with self.mu:
+            w = self.w.copy()
+            np.subtract.at(w, np.asarray(keys, dtype=np.int64), np.asarray(values, dtype=np.float64))
+            self.w = w
+
+    @property
+    def dp(self):
+        return self.o.dim + 1
 
     def apply(self, g_mean, lr):
         self.w = self.w - lr * np.asarray(g_mean, dtype=np.float64)

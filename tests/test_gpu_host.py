@@ -52,3 +52,42 @@ def test_master_async_fit_runs_and_stops():
         # the best weights are a snapshot the engine really produced
         loss, acc, _ = eng.loss_acc(n_train, n_rows, w=st.grad)
         assert acc > 0.5
+
+
+def test_wire_worker_serves_the_engine():
+    """The reference's Slave protocol in front of the HIP engine: Gradient / Forward replies equal the direct calls and
+    the oracle within the fp32 tolerance; UpdateGrad applies w - delta."""
+    grpc = pytest.importorskip("grpc")
+    from dsgd_amd import wire
+
+    n_rows = 4000
+    data = dsgd_amd.synth.generate(n_rows, seed=43)
+    o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, 1e-5)
+    o.set_dim_sparsity(o.dim_sparsity(n_rows))
+    rng = np.random.default_rng(43)
+    w = np.zeros(data.dim + 1, dtype=np.float32)
+    w[rng.choice(np.arange(1, data.dim + 1), 5000, replace=False)] = rng.normal(scale=0.1, size=5000).astype(np.float32)
+    idx = rng.permutation(n_rows)[:200].astype(np.int32)
+    with dsgd_amd.Engine(data.dim, 1e-5) as eng:
+        eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+        eng.build_dim_sparsity(n_rows)
+        worker = wire.SlaveWorker(eng, data.dim, asynchronous=True).start()
+        try:
+            stub = wire.Stub(wire.new_channel("127.0.0.1", worker.port), "Slave")
+            M = wire.messages()
+            reply = stub.Gradient(M["GradientRequest"](weights=wire.to_sparse(w, data.dim), samples=idx.tolist()))
+            got = np.zeros(data.dim + 1)
+            for k, v in reply.gradUpdate.map.items():
+                got[k] = v
+            g_ref = o.gradient(w.astype(np.float64), idx)
+            assert np.abs(got - g_ref).max() <= 1e-5 * max(1.0, np.abs(g_ref).max())
+            assert set(reply.gradUpdate.map) == set(np.flatnonzero(g_ref).tolist())
+            pred = stub.Forward(M["ForwardRequest"](samples=idx.tolist(), weights=wire.to_sparse(w, data.dim)))
+            np.testing.assert_array_equal(np.asarray(pred.predictions), o.forward(w.astype(np.float64), idx))
+            eng.set_weights(w)
+            delta = np.zeros(data.dim + 1, dtype=np.float32)
+            delta[[3, 77]] = [0.25, -0.5]
+            stub.UpdateGrad(M["GradUpdate"](gradUpdate=wire.to_sparse(delta, data.dim)))
+            np.testing.assert_array_equal(eng.get_weights(), w - delta)
+        finally:
+            worker.stop()
