@@ -52,7 +52,7 @@ enum {
 
 /* dsgd_config.flags */
 #define DSGD_F_DEFAULT 0u
-#define DSGD_F_NO_GRAPH 1u /* never capture step chains into hipGraphs (debugging)               */
+#define DSGD_F_NO_GRAPH 1u /* reserved: small-batch steps measured execution-bound, no graphs used  */
 #define DSGD_F_FORCE_TILED 2u /* always use the LDS-tiled gradient kernel (tests / tuning)        */
 #define DSGD_F_FORCE_ROWS 4u  /* always use the direct-to-L2 gradient kernel (tests / tuning)      */
 
