@@ -1,4 +1,5 @@
-"""Small-batch steps through resident plans, with and without hipGraph replay (DSGD_F_NO_GRAPH = 1)."""
+"""Time per small-batch step through resident plans (dsgd_plan_run).  (The `flags` loop dates from the hipGraph
+experiment recorded in profiles/README.md: DSGD_F_NO_GRAPH is a reserved flag now, both passes run the same code.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
