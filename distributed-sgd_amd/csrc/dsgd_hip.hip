@@ -1256,6 +1256,22 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr_in, const 
   }
   for (int64_t i = 0; i < n_rows; ++i)
     if (label[i] != 1 && label[i] != -1) return fail(DSGD_EINVAL, "label[%lld] = %d, expected +1/-1", (long long)i, label[i]);
+  // A row is a Map[Int, Number] in the reference (math/Sparse.scala:11): a key occurs once.  The fixed-point bound of
+  // the streaming kernels ("one contribution per row and column") relies on it, so duplicates are rejected here
+  // (ascending rows -- the RCV1 files -- take the cheap path).
+  {
+    std::vector<int32_t> keys;
+    for (int64_t i = 0; i < n_rows; ++i) {
+      const int64_t b = row_ptr[i], e = row_ptr[i + 1];
+      bool ascending = true;
+      for (int64_t p = b + 1; p < e && ascending; ++p) ascending = col[p] > col[p - 1];
+      if (ascending) continue;
+      keys.assign(col + b, col + e);
+      std::sort(keys.begin(), keys.end());
+      if (std::adjacent_find(keys.begin(), keys.end()) != keys.end())
+        return fail(DSGD_EINVAL, "row %lld holds a key twice (a Sparse vector is a map: one value per key)", (long long)i);
+    }
+  }
   // Internal CSR: an empty row (Sparse.zeros) gets ONE explicit zero on key 0.  x.w, the gate and the
   // gradient are unchanged (the product and y*x are 0 and every counting kernel skips abs(v) <= 1e-20),
   // and the streaming kernels can rely on "every row owns at least one slot".

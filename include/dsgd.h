@@ -83,8 +83,9 @@ int dsgd_device_count(void);
 int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out);
 int dsgd_destroy(dsgd_ctx* ctx);
 
-/* data: Array[(Vec, Int)] (utils/Dataset.scala:11) as CSR.  col ids 1-based ascending per row,
- * label +1/-1.  Copied to HBM once; resident afterwards.  Indices in later calls refer to it,
+/* data: Array[(Vec, Int)] (utils/Dataset.scala:11) as CSR.  col ids are the reference's keys (1-based feature ids),
+ * each at most once per row in any order (a row is a Map: DSGD_EINVAL for a repeated key), label +1/-1.
+ * Copied to HBM once; resident afterwards.  Indices in later calls refer to it,
  * exactly as GradientRequest.samples / ForwardRequest.samples index Slave.data
  * (core/Slave.scala:134,149; proto.proto:51-63). */
 int dsgd_load_csr(dsgd_ctx* ctx, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_1based, const float* val,

@@ -265,6 +265,15 @@ def test_error_behaviour():
         # the engine is still usable after errors
         st = eng.sync_step([[0, 1, 2]], 0.5)
         assert st["n_samples"] == 3 and st["n_active"] == 3  # w = 0: every row is active (0 >= 0)
+    dup = data.col.copy()
+    dup[1] = dup[0]  # the same key twice in row 0: not a Map (math/Sparse.scala:11)
+    with dsgd_amd.Engine(data.dim, 1e-5) as eng:
+        with pytest.raises(ValueError):
+            eng.load_csr(data.row_ptr, dup, data.val, data.label)
+        perm = data.col.copy()  # an unsorted row is fine
+        b, e = int(data.row_ptr[0]), int(data.row_ptr[1])
+        perm[b:e] = perm[b:e][::-1]
+        eng.load_csr(data.row_ptr, perm, data.val, data.label)
     bad = data.col.copy()
     bad[0] = data.dim + 1
     with dsgd_amd.Engine(data.dim, 1e-5) as eng:
