@@ -161,3 +161,55 @@ def test_empty_batch_raises_like_vec_sum():  # math/Vec.scala:129
         o.gradient(np.zeros(7), [])
     with pytest.raises(ValueError):
         rd.vec_sum([])
+
+
+# ---- the committed fixtures (tests/golden/*.json) against BOTH restatements --------------------------------------
+def _golden(name):
+    import json
+    import os
+
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)))
+
+
+def test_fixture_vectests_json():
+    g = _golden("vectests.json")
+    d = g["dense_14_21"]
+    v = rd.Sparse({i: x for i, x in enumerate(d["v"])}, 3)
+    assert (v + v) == rd.Sparse({i: x for i, x in enumerate(d["v_plus_v"])}, 3)
+    assert v.dot(v) == d["v_dot_v"] and v.norm() == math.sqrt(d["norm_squared"])
+    assert v * 2 == rd.Sparse({i: x for i, x in enumerate(d["v_times_2"])}, 3)
+    assert 3 * v == rd.Sparse({i: x for i, x in enumerate(d["3_times_v"])}, 3)
+    s = g["sparse_add_26_29"]
+    a, b = (rd.Sparse({int(k): x for k, x in s[n].items()}, s["size"]) for n in ("a", "b"))
+    assert a + b == rd.Sparse({int(k): x for k, x in s["sum"].items()}, s["size"])
+    sp = g["sparsity_38_40"]
+    assert rd.Sparse({int(k): x for k, x in sp["map"].items()}, sp["size"]).sparsity() == sp["sparsity"]
+
+
+def test_fixture_kat_json_dict_and_c():
+    import sys
+    import os
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import check_fixtures
+
+    kat = _golden("kat.json")
+    assert check_fixtures.check(kat)            # dict-based restatement
+    rows = [({int(k): v for k, v in m.items()}, y) for m, y in kat["rows"]]
+    assert rows == KAT_ROWS                     # the inline copy used by the GPU tests is the same data
+    # C oracle: the whole KAT-1 trajectory
+    k1 = kat["kat1"]
+    data = dsgd_amd.synth.from_rows(6, rows)
+    o = orc.Oracle(6, data.row_ptr, data.col, data.val, data.label, k1["lambda"])
+    ds = o.dim_sparsity(6)
+    np.testing.assert_allclose(ds, [k1["ds"].get(str(j), 0.0) for j in range(7)], rtol=0, atol=1e-12)
+    o.set_dim_sparsity(ds)
+    w = np.zeros(7)
+    for st in k1["steps"]:
+        for idx, name in zip(k1["batches"], ("g0", "g1")):
+            g = o.gradient(w, np.asarray(idx, dtype=np.int32))
+            np.testing.assert_allclose(g, [st[name].get(str(j), 0.0) for j in range(7)], rtol=0, atol=2e-7)  # float32 inputs
+        o.sync_step(w, [np.asarray(i, dtype=np.int32) for i in k1["batches"]], k1["lr"])
+        np.testing.assert_allclose(w, [st["w"].get(str(j), 0.0) for j in range(7)], rtol=0, atol=2e-7)
+        loss, acc, _, _ = o.loss_acc(w, 0, 6)
+        assert abs(loss - st["loss"]) < 1e-6 and abs(acc - st["acc"]) < 1e-12
