@@ -366,3 +366,57 @@ class MasterService:
         if self.on_update is not None:
             self.on_update(dict(request.gradUpdate.map))
         return messages()["Ack"]()
+
+
+# ---- the master's side of the synchronous protocol, for JVM-free deployments ------------------------------------------
+class WireBackend:
+    """`host.MasterSync(WireBackend(...), ...)` is the reference's synchronous master over the wire: one `Gradient` RPC
+    per worker and batch (`core/Master.scala:184-190`), `Vec.mean`, `w - lr * mean` (:192-197) on the master's own
+    copy of the weights; loss and accuracy through `Forward` RPCs fanned out over the slaves
+    (`predict` / `distributedLoss` / `distributedAccuracy`, `core/Master.scala:60-98`) -- the master needs the labels
+    only.  Worker k of a batch is served by slave k (zip of splits and slaves, :184)."""
+
+    def __init__(self, slaves: Sequence[Stub], n_features: int, lam: float, labels):
+        self.slaves, self.size, self.dp, self.lam = list(slaves), n_features, n_features + 1, lam
+        self.labels = np.asarray(labels, dtype=np.float64)
+        self.w = np.zeros(self.dp, dtype=np.float64)
+
+    def set_weights(self, w):
+        self.w = np.asarray(w, dtype=np.float64).copy()
+
+    def get_weights(self):
+        return self.w.copy()
+
+    def _dense(self, sparse) -> np.ndarray:
+        g = np.zeros(self.dp, dtype=np.float64)
+        for k, v in sparse.map.items():
+            g[k] = v
+        return g
+
+    def sync_step(self, idx_lists, lr):
+        M = messages()
+        if len(idx_lists) > len(self.slaves):
+            raise ValueError("%d workers in the batch but %d slaves registered" % (len(idx_lists), len(self.slaves)))
+        weights = to_sparse(self.w, self.size)
+        calls = [stub.Gradient.future(M["GradientRequest"](weights=weights, samples=[int(i) for i in idx]))
+                 for stub, idx in zip(self.slaves, idx_lists)]
+        total = np.zeros(self.dp, dtype=np.float64)
+        for c in calls:                      # Future.sequence: a failed RPC fails the batch
+            total += self._dense(c.result().gradUpdate)
+        self.w = self.w - lr * (total / len(idx_lists))   # Vec.mean, then weights - learningRate * grad
+        return {"n_samples": sum(len(i) for i in idx_lists), "n_active": None}
+
+    def loss_acc(self, lo, hi):
+        M = messages()
+        rows = np.arange(lo, hi)
+        if len(rows) == 0:
+            raise ValueError("requirement failed: empty row range")
+        parts = [p for p in np.array_split(rows, len(self.slaves)) if len(p)]
+        weights = to_sparse(self.w, self.size)
+        calls = [stub.Forward.future(M["ForwardRequest"](samples=[int(i) for i in p], weights=weights))
+                 for stub, p in zip(self.slaves, parts)]
+        pred = np.concatenate([np.asarray(c.result().predictions, dtype=np.float64) for c in calls])
+        y = self.labels[lo:hi]
+        hinge = np.maximum(0.0, 1.0 - y * pred)                     # core/ml/SparseSVM.scala:16
+        counts = [int((pred == y).sum()), int((pred == 0).sum()), int((pred == -y).sum())]
+        return self.lam * float(self.w @ self.w) + float(hinge.mean()), counts[0] / len(rows), counts

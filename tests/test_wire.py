@@ -156,3 +156,29 @@ def test_metrics_and_final_weights_line():
     w = np.zeros(6, dtype=np.float32)
     w[[1, 4]] = [0.1, -2.5]
     assert host.format_final_weights(w) == "1:0.10000000149011612 4:-2.5"   # Main.scala:114 (fp32 values printed as doubles)
+
+
+def test_master_fit_over_the_wire_equals_the_in_process_fit():
+    """core/Master.scala:120-218 with the slaves behind gRPC: same java.util.Random stream, same batches, same result as
+    the mirror driving one backend directly (up to the fp32 weights the workers compute from)."""
+    data, o, direct = make_backend(91, n_rows=900)
+    n_train, n_rows, k = 720, 900, 3
+    master = wire.MasterService(expected_nodes=k).start()
+    workers = [wire.SlaveWorker(make_backend(91, n_rows=900)[2], data.dim, master=("127.0.0.1", master.port)).start() for _ in range(k)]
+    try:
+        assert master.ready.wait(5)
+        stubs = [wire.Stub(wire.new_channel("127.0.0.1", w.port), "Slave") for w in workers]
+        over_wire = host.MasterSync(wire.WireBackend(stubs, data.dim, 1e-5, data.label), n_train, n_rows, node_count=k, rnd=host.JavaRandom(0))
+        s_wire = over_wire.fit(np.zeros(data.dim + 1), 2, 100, 0.5, host.EarlyStopping.no_improvement(5, 0.01))
+        in_proc = host.MasterSync(direct, n_train, n_rows, node_count=k, rnd=host.JavaRandom(0))
+        s_ref = in_proc.fit(np.zeros(data.dim + 1), 2, 100, 0.5, host.EarlyStopping.no_improvement(5, 0.01))
+        assert s_wire.updates == s_ref.updates == 2
+        np.testing.assert_allclose(s_wire.grad, s_ref.grad, rtol=0, atol=2e-5 * max(1.0, np.abs(s_ref.grad).max()))
+        np.testing.assert_allclose(over_wire.test_losses, in_proc.test_losses, rtol=0, atol=5e-3)
+        np.testing.assert_allclose(over_wire.test_accs, in_proc.test_accs, rtol=0, atol=5e-3)
+        # 2 epochs x 3 batches (240 rows per worker, batch 100) x 3 workers: one Gradient RPC each, per sample counted
+        assert sum(w.metrics.snapshot()["counters"]["slave.sync.backward"] for w in workers) == 2 * 720
+    finally:
+        for w in workers:
+            w.stop()
+        master.stop()
