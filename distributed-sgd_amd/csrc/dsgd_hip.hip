@@ -480,11 +480,11 @@ static int count_columns(dsgd_ctx* c, long long nnz, unsigned int* d_cnt) {
 // Transposed lists of the cold columns (rank >= hg_s) of the rows held by THIS context, sorted by
 // row: the streaming gradient kernel leaves those columns to dsgd_cold_scatter_kernel.
 static int build_cold_lists(dsgd_ctx* c) {
-  hipFree(c->d_cold_ptr);
-  hipFree(c->d_cold_row);
-  hipFree(c->d_cold_val);
-  hipFree(c->d_coef8);
-  hipFree(c->d_coefp);
+  (void)hipFree(c->d_cold_ptr);
+  (void)hipFree(c->d_cold_row);
+  (void)hipFree(c->d_cold_val);
+  (void)hipFree(c->d_coef8);
+  (void)hipFree(c->d_coefp);
   c->d_coefp = nullptr;
   c->d_cold_ptr = nullptr;
   c->d_cold_row = nullptr;
@@ -510,7 +510,7 @@ static int build_cold_lists(dsgd_ctx* c) {
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = fail(DSGD_EHIP, "cold counts: %s", hipGetErrorString(e));
   }
-  hipFree(d_cnt);
+  (void)hipFree(d_cnt);
   DSGD_TRY(rc);
   std::vector<unsigned int> ptr((size_t)c->n_cold + 1, 0u);
   unsigned long long tot = 0;
@@ -533,10 +533,10 @@ static int build_cold_lists(dsgd_ctx* c) {
   float* d_val_tmp = nullptr;
   void* d_temp = nullptr;
   auto cleanup = [&]() {
-    hipFree(d_cursor);
-    hipFree(d_row_tmp);
-    hipFree(d_val_tmp);
-    hipFree(d_temp);
+    (void)hipFree(d_cursor);
+    (void)hipFree(d_row_tmp);
+    (void)hipFree(d_val_tmp);
+    (void)hipFree(d_temp);
   };
 #define HIP_TRY_C(expr)                                                                     \
   do {                                                                                      \
@@ -651,9 +651,9 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
   }
 }
 static int upload_wave_tiles(dsgd_ctx* c, HostTiles& ht) {
-  hipFree(c->d_wtiles);
-  hipFree(c->d_wmeta);
-  hipFree(c->d_wlong_rows);
+  (void)hipFree(c->d_wtiles);
+  (void)hipFree(c->d_wmeta);
+  (void)hipFree(c->d_wlong_rows);
   c->d_wtiles = nullptr;
   c->d_wmeta = nullptr;
   c->d_wlong_rows = nullptr;
@@ -674,9 +674,9 @@ static int upload_wave_tiles(dsgd_ctx* c, HostTiles& ht) {
 // mode 4: split the ranked CSR into the hot stream (rank < hsplit; wave tiles) and the cold stream
 // (rank - hsplit, value, row); rows whose hot part exceeds a wave tile stay on the long-row list and in neither.
 static int build_split(dsgd_ctx* c) {
-  hipFree(c->d_hcol); hipFree(c->d_hval); hipFree(c->d_hrow_ptr);
-  hipFree(c->d_ckey); hipFree(c->d_cval); hipFree(c->d_crow); hipFree(c->d_cbase); hipFree(c->d_crow_ptr);
-  hipFree(c->d_dcold); hipFree(c->d_coef8);
+  (void)hipFree(c->d_hcol); (void)hipFree(c->d_hval); (void)hipFree(c->d_hrow_ptr);
+  (void)hipFree(c->d_ckey); (void)hipFree(c->d_cval); (void)hipFree(c->d_crow); (void)hipFree(c->d_cbase); (void)hipFree(c->d_crow_ptr);
+  (void)hipFree(c->d_dcold); (void)hipFree(c->d_coef8);
   c->d_hcol = nullptr; c->d_hval = nullptr; c->d_hrow_ptr = nullptr;
   c->d_ckey = nullptr; c->d_cval = nullptr; c->d_crow = nullptr; c->d_cbase = nullptr; c->d_crow_ptr = nullptr;
   c->d_dcold = nullptr; c->d_coef8 = nullptr;
@@ -698,7 +698,7 @@ static int build_split(dsgd_ctx* c) {
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * (size_t)n_rows, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(d_cnt);
+  (void)hipFree(d_cnt);
   if (e != hipSuccess) return fail(DSGD_EHIP, "split counts: %s", hipGetErrorString(e));
   std::vector<long long> hrp((size_t)n_rows + 1), &crp = c->h_crow_ptr;
   crp.assign((size_t)n_rows + 1, 0);
@@ -781,7 +781,7 @@ static int prepare_layout(dsgd_ctx* c) {
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = fail(DSGD_EHIP, "column counts: %s", hipGetErrorString(e));
   }
-  hipFree(d_cnt);
+  (void)hipFree(d_cnt);
   DSGD_TRY(rc);
   std::vector<int> order(c->dp);
   for (int j = 0; j < c->dp; ++j) order[j] = j;
@@ -826,7 +826,7 @@ static int upload_ssegs(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
   const int n = (int)segs.size();
   if (n > c->ssegs_cap) {
     HIP_TRY(hipStreamSynchronize(c->stream));
-    hipFree(c->d_ssegs);
+    (void)hipFree(c->d_ssegs);
     c->d_ssegs = nullptr;
     HIP_TRY(hipMalloc(&c->d_ssegs, sizeof(StreamSeg) * (size_t)n));
     c->ssegs_cap = n;
@@ -868,7 +868,7 @@ static void locate_segs(dsgd_ctx* c, std::vector<StreamSeg>& segs, long long* ma
 static int ensure_part(dsgd_ctx* c, int** buf, long long* wgs, int* stride, long long need_wgs, int need_cols) {
   if (need_wgs <= *wgs && need_cols <= *stride) return DSGD_OK;
   HIP_TRY(hipStreamSynchronize(c->stream));
-  hipFree(*buf);
+  (void)hipFree(*buf);
   *buf = nullptr;
   *wgs = std::max<long long>(need_wgs, c->n_cu);
   *stride = std::max(*stride, (need_cols + 63) / 64 * 64);
@@ -1174,61 +1174,61 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
 
 int dsgd_destroy(dsgd_ctx* c) {
   if (!c) return DSGD_OK;
-  hipSetDevice(c->cfg.device);
-  if (c->stream) hipStreamSynchronize(c->stream);
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm && rccl::available()) rccl::CommDestroy(c->comm);
   for (auto& e : c->prof_ev) {
-    hipEventDestroy(e.first);
-    hipEventDestroy(e.second);
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
   }
-  hipFree(c->d_row_ptr);
-  hipFree(c->d_col);
-  hipFree(c->d_val);
-  hipFree(c->d_label);
-  hipFree(c->d_w);
-  hipFree(c->d_ds);
-  hipFree(c->d_g);
-  hipFree(c->d_g64);
-  hipFree(c->d_gsum);
-  hipFree(c->d_tmp);
-  hipFree(c->d_io);
-  hipFree(c->d_perm);
-  hipFree(c->d_sc);
-  hipFree(c->d_idx);
-  hipFree(c->d_segs);
-  hipFree(c->d_ssegs);
-  hipFree(c->d_cold_ptr);
-  hipFree(c->d_cold_row);
-  hipFree(c->d_cold_val);
-  hipFree(c->d_coef8);
-  hipFree(c->d_coefp);
-  hipFree(c->d_wtiles);
-  hipFree(c->d_wmeta);
-  hipFree(c->d_wlong_rows);
-  hipFree(c->d_part);
-  hipFree(c->d_partc);
-  hipFree(c->d_hcol);
-  hipFree(c->d_hval);
-  hipFree(c->d_hrow_ptr);
-  hipFree(c->d_ckey);
-  hipFree(c->d_cval);
-  hipFree(c->d_crow);
-  hipFree(c->d_cbase);
-  hipFree(c->d_crow_ptr);
-  hipFree(c->d_dcold);
+  (void)hipFree(c->d_row_ptr);
+  (void)hipFree(c->d_col);
+  (void)hipFree(c->d_val);
+  (void)hipFree(c->d_label);
+  (void)hipFree(c->d_w);
+  (void)hipFree(c->d_ds);
+  (void)hipFree(c->d_g);
+  (void)hipFree(c->d_g64);
+  (void)hipFree(c->d_gsum);
+  (void)hipFree(c->d_tmp);
+  (void)hipFree(c->d_io);
+  (void)hipFree(c->d_perm);
+  (void)hipFree(c->d_sc);
+  (void)hipFree(c->d_idx);
+  (void)hipFree(c->d_segs);
+  (void)hipFree(c->d_ssegs);
+  (void)hipFree(c->d_cold_ptr);
+  (void)hipFree(c->d_cold_row);
+  (void)hipFree(c->d_cold_val);
+  (void)hipFree(c->d_coef8);
+  (void)hipFree(c->d_coefp);
+  (void)hipFree(c->d_wtiles);
+  (void)hipFree(c->d_wmeta);
+  (void)hipFree(c->d_wlong_rows);
+  (void)hipFree(c->d_part);
+  (void)hipFree(c->d_partc);
+  (void)hipFree(c->d_hcol);
+  (void)hipFree(c->d_hval);
+  (void)hipFree(c->d_hrow_ptr);
+  (void)hipFree(c->d_ckey);
+  (void)hipFree(c->d_cval);
+  (void)hipFree(c->d_crow);
+  (void)hipFree(c->d_cbase);
+  (void)hipFree(c->d_crow_ptr);
+  (void)hipFree(c->d_dcold);
   if (c->async_stream) {
     if (c->h_stop) *c->h_stop = 1;
-    hipStreamSynchronize(c->async_stream);
-    hipStreamDestroy(c->async_stream);
+    (void)hipStreamSynchronize(c->async_stream);
+    (void)hipStreamDestroy(c->async_stream);
   }
-  if (c->query_stream) hipStreamDestroy(c->query_stream);
-  hipFree(c->d_hog);
-  hipFree(c->d_gcold);
-  hipFree(c->d_asg);
-  if (c->h_hog) hipHostFree(c->h_hog);
-  if (c->h_stop) hipHostFree(c->h_stop);
-  if (c->h_sc) hipHostFree(c->h_sc);
-  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->query_stream) (void)hipStreamDestroy(c->query_stream);
+  (void)hipFree(c->d_hog);
+  (void)hipFree(c->d_gcold);
+  (void)hipFree(c->d_asg);
+  if (c->h_hog) (void)hipHostFree(c->h_hog);
+  if (c->h_stop) (void)hipHostFree(c->h_stop);
+  if (c->h_sc) (void)hipHostFree(c->h_sc);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return DSGD_OK;
 }
@@ -1306,10 +1306,10 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr_in, const 
   DSGD_TRY(bind(c));
   HIP_TRY(hipStreamSynchronize(c->stream));
   DSGD_TRY(reset_layout(c));
-  hipFree(c->d_row_ptr);
-  hipFree(c->d_col);
-  hipFree(c->d_val);
-  hipFree(c->d_label);
+  (void)hipFree(c->d_row_ptr);
+  (void)hipFree(c->d_col);
+  (void)hipFree(c->d_val);
+  (void)hipFree(c->d_label);
   c->d_row_ptr = nullptr;
   c->d_col = nullptr;
   c->d_val = nullptr;
@@ -1405,7 +1405,7 @@ int dsgd_build_dim_sparsity(dsgd_ctx* c, int64_t n_train, float* ds_out) {
     if (le != hipSuccess) rc = fail(DSGD_EHIP, "dimSparsity kernels: %s", hipGetErrorString(le));
   }
   if (!rc) rc = read_scalars(c);
-  hipFree(d_cnt);
+  (void)hipFree(d_cnt);
   DSGD_TRY(rc);
   DSGD_TRY(check_err_flag(c));
   if (cnt_key0) return fail(DSGD_ERANGE, "feature id 0 cannot be counted by Main.scala:60 (buff(idx - 1))");
@@ -1663,8 +1663,8 @@ int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, in
   if (e == hipSuccess) e = hipMemcpy(p->d_idx, idx, sizeof(int) * (size_t)offsets[n_lists], hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p->d_segs, segs.data(), sizeof(WorkSeg) * (size_t)n_lists, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
-    hipFree(p->d_idx);
-    hipFree(p->d_segs);
+    (void)hipFree(p->d_idx);
+    (void)hipFree(p->d_segs);
     delete p;
     return fail(DSGD_EHIP, "plan upload: %s", hipGetErrorString(e));
   }
@@ -1678,8 +1678,8 @@ int dsgd_plan_destroy(dsgd_ctx* c, dsgd_plan* p) {
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  hipFree(p->d_idx);
-  hipFree(p->d_segs);
+  (void)hipFree(p->d_idx);
+  (void)hipFree(p->d_segs);
   delete p;
   return DSGD_OK;
 }
@@ -1737,7 +1737,7 @@ int dsgd_forward(dsgd_ctx* c, const float* w, const int32_t* idx, int64_t n, flo
   hipError_t le = hipGetLastError();
   if (le == hipSuccess) le = hipMemcpyAsync(pred_out, d_pred, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
   int rc = read_scalars(c);
-  hipFree(d_pred);
+  (void)hipFree(d_pred);
   if (le != hipSuccess) return fail(DSGD_EHIP, "forward: %s", hipGetErrorString(le));
   DSGD_TRY(rc);
   return check_err_flag(c);
@@ -1844,8 +1844,8 @@ int dsgd_update_grad(dsgd_ctx* c, const int32_t* key, const float* dv, int64_t n
     e = hipGetLastError();
   }
   int rc = read_scalars(c);
-  hipFree(d_key);
-  hipFree(d_dv);
+  (void)hipFree(d_key);
+  (void)hipFree(d_dv);
   c->s_dirty = true;
   if (e != hipSuccess) return fail(DSGD_EHIP, "update_grad: %s", hipGetErrorString(e));
   DSGD_TRY(rc);
@@ -1892,8 +1892,8 @@ int dsgd_async_start(dsgd_ctx* c, const int64_t* assigned_begin, const int64_t* 
   }
   const int hl = std::min(c->dp, 24576);
   if (n_workers > c->hog_workers) {
-    hipFree(c->d_gcold);
-    hipFree(c->d_asg);
+    (void)hipFree(c->d_gcold);
+    (void)hipFree(c->d_asg);
     c->d_gcold = nullptr;
     c->d_asg = nullptr;
     HIP_TRY(hipMalloc(&c->d_gcold, sizeof(float) * (size_t)n_workers * (size_t)std::max(1, c->dp - hl)));

@@ -1048,15 +1048,12 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
     }
   } else {
     // ---- general case (some lane holds two or more row starts: rows shorter than 8 non-zeros) ----
-    float head = 0.0f, trail = 0.0f;
-    bool seen = false;
+    float trail = 0.0f;   // the fragment after the lane's LAST row start continues into the next lane
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const bool st = (bits >> k) & 1u;
-      seen = seen || st;
       trail = st ? 0.0f : trail;
       trail += pk[k];
-      head += seen ? 0.0f : pk[k];
     }
     float s = trail;
     int f = bits != 0u;
