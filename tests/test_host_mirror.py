@@ -32,7 +32,17 @@ def test_scala_shuffle_is_a_seeded_permutation():
 
 
 def test_config_defaults_env_and_roles():
-    text = open(os.path.join(HERE, "golden", "application.conf")).read()
+    # the HOCON text a deployment would hold, synthesised from the key table of tests/golden/config_keys.json
+    import json
+
+    keys = json.load(open(os.path.join(HERE, "golden", "config_keys.json")))["keys"]
+    lines = ["dsgd {"]
+    for k, (default, env_var) in keys.items():
+        if default is not None:
+            lines.append("  %s = %s" % (k, default))
+        lines.append("  %s = ${?%s}   # environment override" % (k, env_var))
+    text = "\n".join(lines + ["}", "kamon { metric { tick-interval = 1 seconds } }"])
+    assert set(keys) == set(host.Config._KEYS) and all(host.Config._KEYS[k][1] == v[1] for k, v in keys.items())
     c = host.Config.load(text, env={})
     assert (c.batch_size, c.learning_rate, c.lambda_, c.node_count, c.max_epochs) == (100, 0.5, 1e-5, 3, 10)
     assert (c.check_every, c.leaky_loss, c.patience, c.conv_delta, c.full, c.async_) == (100, 0.9, 5, 0.01, False, False)
