@@ -5,11 +5,16 @@
 // Column space: inside the library every dense vector (w, g, ds) and the CSR column array use
 // FREQUENCY-RANKED column ids (rank 0 = the most frequent feature).  RCV1-like data is Zipfian,
 // so the first H ranks cover most non-zeros; a workgroup stages those H weights in LDS and
-// accumulates those H gradient coordinates in LDS (ds_add_f32) instead of going to L2 for every
-// non-zero.  Measured on MI355X (tools/microbench.hip, 90 M non-zeros): scattered device-scope
-// fp32 atomics top out at ~5-14 G/s, the LDS-privatised scatter at 130-540 Gnnz/s, and an
-// LDS-staged gather at 667 Gnnz/s vs 216-349 Gnnz/s through L1/L2.  The API (include/dsgd.h)
-// speaks original keys; dsgd_hip.hip permutes at the boundary.
+// accumulates those H gradient coordinates in LDS instead of going to L2 for every non-zero.
+// Measured on MI355X (tools/microbench*.hip, 90 M non-zeros): scattered device-scope fp32 atomics top
+// out at ~5-14 G/s, an LDS-staged gather runs at 667 Gnnz/s vs 216-349 Gnnz/s through L1/L2, and
+// ds_add_u32 at the streaming rate where ds_add_f32 manages 188 Gnnz/s (hence fixed point).  The
+// API (include/dsgd.h) speaks original keys; dsgd_hip.hip permutes at the boundary.
+//
+// Kernel families, in file order: row-per-group kernels for index-list batches (K1a/K1b), finish kernels
+// (regularise, sum, apply), layout kernels, fixed-point helpers, the transposed cold lists of stream mode 3,
+// the wave-tile streaming kernel (both layouts), the split-matrix layout kernels and the two cold-stream
+// kernels, the Hogwild engine.  DESIGN.md section 3 describes each with its roofline.
 #pragma once
 
 #include <hip/hip_runtime.h>
