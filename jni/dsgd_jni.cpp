@@ -1,15 +1,32 @@
 // JNI shim between the reference's Scala classes and libdsgd_hip (include/dsgd.h).
-// Source only: this image has no JDK (no jni.h); build on a box that has one with
-//   g++ -std=c++17 -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../include \
-//       dsgd_jni.cpp -o libdsgd_jni.so -L../distributed-sgd_amd/lib -ldsgd_hip
-// The Scala side is scala/NativeSVM.scala (package epfl.distributed.core.ml).
+//
+// Build on a box with a JDK:
+//   g++ -std=c++17 -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../include
+//       dsgd_jni.cpp -o libdsgd_jni.so -L../distributed-sgd_amd/lib -ldsgd_hip        (one command line)
+// This image has no JDK; tests/test_jni_shim.py compiles this file against tests/jni_stub/jni.h (a stand-in that
+// declares the slice of the JNI API used here), checks the exported symbol set against the @native declarations of
+// scala/NativeSVM.scala and drives the entry points with a recording fake JNIEnv.
+//
+// Symbol names.  The natives are declared in `object NativeSVM` (scala/NativeSVM.scala), i.e. on the JVM class
+// `epfl.distributed.core.ml.NativeSVM$`; JNI mangles '$' as `_00024`, and a method of a Scala object is an INSTANCE
+// method of the module singleton, so every entry point takes (JNIEnv*, jobject self, ...).
+//
+// Array passing.  Arrays are taken with Get<Type>ArrayElements / Release<Type>ArrayElements (which may pin or copy
+// and put no restriction on what runs in between), never with GetPrimitiveArrayCritical: every dsgd_* call below
+// takes the context mutex and blocks on the GPU, which is exactly what a JNI critical region must not do (the
+// reference calls its model from an 8-thread pool, utils/Pool.scala:13 -- a thread parked inside a critical region
+// stalls every collector).  Array lengths are read before any array is taken.
 //
 // Error mapping (include/dsgd.h): DSGD_EINVAL -> IllegalArgumentException (what `require` throws at
 // math/Vec.scala:129 and math/Sparse.scala:16), DSGD_ERANGE -> IndexOutOfBoundsException
 // (math/Sparse.scala:63), everything else -> RuntimeException.
 #include <jni.h>
 
+#include <vector>
+
 #include "dsgd.h"
+
+#define NATIVE(name) Java_epfl_distributed_core_ml_NativeSVM_00024_##name
 
 namespace {
 jint raise(JNIEnv* env, int rc) {
@@ -21,24 +38,32 @@ jint raise(JNIEnv* env, int rc) {
 }
 inline dsgd_ctx* ctx(jlong h) { return reinterpret_cast<dsgd_ctx*>(h); }
 
-// RAII view of a primitive array; the engine copies, so the critical section is short
-template <class T>
-struct Crit {
-  JNIEnv* env;
-  jarray arr;
-  T* p;
-  Crit(JNIEnv* e, jarray a) : env(e), arr(a), p(a ? static_cast<T*>(e->GetPrimitiveArrayCritical(a, nullptr)) : nullptr) {}
-  ~Crit() {
-    if (p) env->ReleasePrimitiveArrayCritical(arr, p, 0);
-  }
-};
+// RAII views of primitive arrays.  `mode` 0 copies changes back (outputs), JNI_ABORT discards them (inputs).
+#define DSGD_ELEMS(Name, T)                                                                          \
+  struct Name##Elems {                                                                               \
+    JNIEnv* env;                                                                                     \
+    jarray arr;                                                                                      \
+    T* p;                                                                                            \
+    jint mode;                                                                                       \
+    Name##Elems(JNIEnv* e, jarray a, jint m)                                                         \
+        : env(e), arr(a), p(a ? e->Get##Name##ArrayElements(a, nullptr) : nullptr), mode(m) {}       \
+    ~Name##Elems() {                                                                                 \
+      if (p) env->Release##Name##ArrayElements(arr, p, mode);                                        \
+    }                                                                                                \
+    Name##Elems(const Name##Elems&) = delete;                                                        \
+    Name##Elems& operator=(const Name##Elems&) = delete;                                             \
+  };
+DSGD_ELEMS(Long, jlong)
+DSGD_ELEMS(Int, jint)
+DSGD_ELEMS(Float, jfloat)
+DSGD_ELEMS(Byte, jbyte)
+#undef DSGD_ELEMS
 }  // namespace
 
 extern "C" {
 
 // new SparseSVM(lambda, dimSparsity) + the data array given to `new Slave(...)` (Main.scala:68,138,148)
-JNIEXPORT jlong JNICALL Java_epfl_distributed_core_ml_NativeSVM_create(JNIEnv* env, jclass, jint nFeatures, jdouble lambda,
-                                                                      jint device) {
+JNIEXPORT jlong JNICALL NATIVE(create)(JNIEnv* env, jobject, jint nFeatures, jdouble lambda, jint device) {
   dsgd_config cfg{};
   cfg.n_features = nFeatures;
   cfg.device = device;
@@ -52,18 +77,18 @@ JNIEXPORT jlong JNICALL Java_epfl_distributed_core_ml_NativeSVM_create(JNIEnv* e
   return reinterpret_cast<jlong>(c);
 }
 
-JNIEXPORT void JNICALL Java_epfl_distributed_core_ml_NativeSVM_destroy(JNIEnv*, jclass, jlong h) { dsgd_destroy(ctx(h)); }
+JNIEXPORT void JNICALL NATIVE(destroy)(JNIEnv*, jobject, jlong h) { dsgd_destroy(ctx(h)); }
 
 // Array[(Vec, Int)] flattened by the Scala side to CSR (utils/Dataset.scala:11)
-JNIEXPORT void JNICALL Java_epfl_distributed_core_ml_NativeSVM_loadCsr(JNIEnv* env, jclass, jlong h, jlongArray rowPtr,
-                                                                      jintArray col, jfloatArray val, jbyteArray label) {
+JNIEXPORT void JNICALL NATIVE(loadCsr)(JNIEnv* env, jobject, jlong h, jlongArray rowPtr, jintArray col, jfloatArray val,
+                                       jbyteArray label) {
   const jsize nRows = env->GetArrayLength(label);
   int rc;
   {
-    Crit<jlong> rp(env, rowPtr);
-    Crit<jint> c(env, col);
-    Crit<jfloat> v(env, val);
-    Crit<jbyte> y(env, label);
+    LongElems rp(env, rowPtr, JNI_ABORT);
+    IntElems c(env, col, JNI_ABORT);
+    FloatElems v(env, val, JNI_ABORT);
+    ByteElems y(env, label, JNI_ABORT);
     rc = dsgd_load_csr(ctx(h), nRows, reinterpret_cast<const int64_t*>(rp.p), reinterpret_cast<const int32_t*>(c.p), v.p,
                        reinterpret_cast<const int8_t*>(y.p));
   }
@@ -71,69 +96,89 @@ JNIEXPORT void JNICALL Java_epfl_distributed_core_ml_NativeSVM_loadCsr(JNIEnv* e
 }
 
 // Main.scala:54-65 on the device
-JNIEXPORT void JNICALL Java_epfl_distributed_core_ml_NativeSVM_buildDimSparsity(JNIEnv* env, jclass, jlong h, jlong nTrain) {
+JNIEXPORT void JNICALL NATIVE(buildDimSparsity)(JNIEnv* env, jobject, jlong h, jlong nTrain) {
   int rc = dsgd_build_dim_sparsity(ctx(h), nTrain, nullptr);
   if (rc) raise(env, rc);
 }
 
 // SlaveImpl.gradient (core/Slave.scala:142-157); w may be null = use the resident weights.
 // Returns the number of active samples so that the caller can counter.increment(n) (Slave.scala:145,150).
-JNIEXPORT jlong JNICALL Java_epfl_distributed_core_ml_NativeSVM_gradient(JNIEnv* env, jclass, jlong h, jfloatArray w,
-                                                                        jintArray idx, jfloatArray gOut) {
+JNIEXPORT jlong JNICALL NATIVE(gradient)(JNIEnv* env, jobject, jlong h, jfloatArray w, jintArray idx, jfloatArray gOut) {
   dsgd_batch_stats st{};
+  const jsize n = env->GetArrayLength(idx);
   int rc;
   {
-    Crit<jfloat> wv(env, w);
-    Crit<jint> iv(env, idx);
-    Crit<jfloat> gv(env, gOut);
-    rc = dsgd_gradient(ctx(h), wv.p, reinterpret_cast<const int32_t*>(iv.p), env->GetArrayLength(idx), gv.p, &st);
+    FloatElems wv(env, w, JNI_ABORT);
+    IntElems iv(env, idx, JNI_ABORT);
+    FloatElems gv(env, gOut, 0);
+    rc = dsgd_gradient(ctx(h), wv.p, reinterpret_cast<const int32_t*>(iv.p), n, gv.p, &st);
   }
   if (rc) raise(env, rc);
   return st.n_active;
 }
 
 // SlaveImpl.forward (core/Slave.scala:129-140)
-JNIEXPORT void JNICALL Java_epfl_distributed_core_ml_NativeSVM_forward(JNIEnv* env, jclass, jlong h, jfloatArray w,
-                                                                      jintArray idx, jfloatArray predOut) {
+JNIEXPORT void JNICALL NATIVE(forward)(JNIEnv* env, jobject, jlong h, jfloatArray w, jintArray idx, jfloatArray predOut) {
+  const jsize n = env->GetArrayLength(idx);
   int rc;
   {
-    Crit<jfloat> wv(env, w);
-    Crit<jint> iv(env, idx);
-    Crit<jfloat> pv(env, predOut);
-    rc = dsgd_forward(ctx(h), wv.p, reinterpret_cast<const int32_t*>(iv.p), env->GetArrayLength(idx), pv.p);
+    FloatElems wv(env, w, JNI_ABORT);
+    IntElems iv(env, idx, JNI_ABORT);
+    FloatElems pv(env, predOut, 0);
+    rc = dsgd_forward(ctx(h), wv.p, reinterpret_cast<const int32_t*>(iv.p), n, pv.p);
   }
   if (rc) raise(env, rc);
 }
 
 // Master.fit batch closure (core/Master.scala:184-197) for the workers hosted by this process
-JNIEXPORT jlong JNICALL Java_epfl_distributed_core_ml_NativeSVM_syncStep(JNIEnv* env, jclass, jlong h, jobjectArray idxPerWorker,
-                                                                        jfloat lr) {
+JNIEXPORT jlong JNICALL NATIVE(syncStep)(JNIEnv* env, jobject, jlong h, jobjectArray idxPerWorker, jfloat lr) {
   const jsize k = env->GetArrayLength(idxPerWorker);
-  // index lists are small (batch-size entries): copy them out instead of nesting critical sections
-  int32_t** lists = new int32_t*[k];
-  int64_t* ns = new int64_t[k];
+  // index lists are small (batch-size entries): copied out with GetIntArrayRegion
+  std::vector<std::vector<int32_t>> lists(static_cast<size_t>(k));
+  std::vector<const int32_t*> ptrs(static_cast<size_t>(k));
+  std::vector<int64_t> ns(static_cast<size_t>(k));
   for (jsize i = 0; i < k; ++i) {
     jintArray a = static_cast<jintArray>(env->GetObjectArrayElement(idxPerWorker, i));
-    ns[i] = env->GetArrayLength(a);
-    lists[i] = new int32_t[ns[i] > 0 ? ns[i] : 1];
-    env->GetIntArrayRegion(a, 0, static_cast<jsize>(ns[i]), reinterpret_cast<jint*>(lists[i]));
+    const jsize n = a ? env->GetArrayLength(a) : 0;
+    lists[i].resize(n > 0 ? n : 1);
+    if (n > 0) env->GetIntArrayRegion(a, 0, n, reinterpret_cast<jint*>(lists[i].data()));
+    ptrs[i] = lists[i].data();
+    ns[i] = n;
+    if (a) env->DeleteLocalRef(a);
   }
   dsgd_batch_stats st{};
-  int rc = dsgd_sync_step(ctx(h), lists, ns, k, lr, &st);
-  for (jsize i = 0; i < k; ++i) delete[] lists[i];
-  delete[] lists;
-  delete[] ns;
+  int rc = dsgd_sync_step(ctx(h), ptrs.data(), ns.data(), k, lr, &st);
+  if (rc) raise(env, rc);
+  return st.n_active;
+}
+
+// the same closure when every worker's batch is its whole split (batch-size >= split size): contiguous row ranges
+JNIEXPORT jlong JNICALL NATIVE(syncStepRanges)(JNIEnv* env, jobject, jlong h, jlongArray rowBegin, jlongArray rowEnd,
+                                              jfloat lr) {
+  const jsize k = env->GetArrayLength(rowBegin);
+  if (env->GetArrayLength(rowEnd) != k) {
+    env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "rowBegin / rowEnd length mismatch");
+    return 0;
+  }
+  dsgd_batch_stats st{};
+  int rc;
+  {
+    LongElems rb(env, rowBegin, JNI_ABORT);
+    LongElems re(env, rowEnd, JNI_ABORT);
+    rc = dsgd_sync_step_ranges(ctx(h), reinterpret_cast<const int64_t*>(rb.p), reinterpret_cast<const int64_t*>(re.p), k,
+                               lr, &st);
+  }
   if (rc) raise(env, rc);
   return st.n_active;
 }
 
 // Master.localLoss / localAccuracy (core/Master.scala:100-107): out = {loss, accuracy}
-JNIEXPORT void JNICALL Java_epfl_distributed_core_ml_NativeSVM_lossAcc(JNIEnv* env, jclass, jlong h, jfloatArray w, jlong rowBegin,
-                                                                      jlong rowEnd, jdoubleArray out) {
+JNIEXPORT void JNICALL NATIVE(lossAcc)(JNIEnv* env, jobject, jlong h, jfloatArray w, jlong rowBegin, jlong rowEnd,
+                                       jdoubleArray out) {
   double la[2] = {0, 0};
   int rc;
   {
-    Crit<jfloat> wv(env, w);
+    FloatElems wv(env, w, JNI_ABORT);
     rc = dsgd_loss_acc(ctx(h), wv.p, rowBegin, rowEnd, &la[0], &la[1], nullptr);
   }
   if (rc) {
@@ -144,42 +189,84 @@ JNIEXPORT void JNICALL Java_epfl_distributed_core_ml_NativeSVM_lossAcc(JNIEnv* e
 }
 
 // Slave.asyncTask body (core/Slave.scala:92-101); deltaOut receives what Slave.scala:103-105 gossips
-JNIEXPORT void JNICALL Java_epfl_distributed_core_ml_NativeSVM_asyncStep(JNIEnv* env, jclass, jlong h, jintArray idx, jfloat lr,
-                                                                        jfloatArray deltaOut) {
+JNIEXPORT void JNICALL NATIVE(asyncStep)(JNIEnv* env, jobject, jlong h, jintArray idx, jfloat lr, jfloatArray deltaOut) {
+  const jsize n = env->GetArrayLength(idx);
   int rc;
   {
-    Crit<jint> iv(env, idx);
-    Crit<jfloat> dv(env, deltaOut);
-    rc = dsgd_async_step(ctx(h), reinterpret_cast<const int32_t*>(iv.p), env->GetArrayLength(idx), lr, dv.p, nullptr);
+    IntElems iv(env, idx, JNI_ABORT);
+    FloatElems dv(env, deltaOut, 0);
+    rc = dsgd_async_step(ctx(h), reinterpret_cast<const int32_t*>(iv.p), n, lr, dv.p, nullptr);
   }
   if (rc) raise(env, rc);
 }
 
 // SlaveImpl.updateGrad / MasterAsync.updateGrad (core/Slave.scala:177-185, core/MasterAsync.scala:164-177)
-JNIEXPORT void JNICALL Java_epfl_distributed_core_ml_NativeSVM_updateGrad(JNIEnv* env, jclass, jlong h, jintArray keys,
-                                                                         jfloatArray values) {
+JNIEXPORT void JNICALL NATIVE(updateGrad)(JNIEnv* env, jobject, jlong h, jintArray keys, jfloatArray values) {
+  const jsize n = env->GetArrayLength(keys);
+  if (env->GetArrayLength(values) != n) {
+    env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "keys / values length mismatch");
+    return;
+  }
   int rc;
   {
-    Crit<jint> kv(env, keys);
-    Crit<jfloat> vv(env, values);
-    rc = dsgd_update_grad(ctx(h), reinterpret_cast<const int32_t*>(kv.p), vv.p, env->GetArrayLength(keys));
+    IntElems kv(env, keys, JNI_ABORT);
+    FloatElems vv(env, values, JNI_ABORT);
+    rc = dsgd_update_grad(ctx(h), reinterpret_cast<const int32_t*>(kv.p), vv.p, n);
   }
   if (rc) raise(env, rc);
 }
 
-JNIEXPORT void JNICALL Java_epfl_distributed_core_ml_NativeSVM_setWeights(JNIEnv* env, jclass, jlong h, jfloatArray w) {
+// SlaveImpl.startAsync (core/Slave.scala:159-175): the persistent lock-free engine on ONE device-resident w
+JNIEXPORT void JNICALL NATIVE(asyncStart)(JNIEnv* env, jobject, jlong h, jlongArray assignedBegin, jlongArray assignedEnd,
+                                          jint batch, jfloat lr, jlong maxUpdates, jlong seed, jboolean positionalBug) {
+  const jsize k = env->GetArrayLength(assignedBegin);
+  if (env->GetArrayLength(assignedEnd) != k) {
+    env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "assignedBegin / assignedEnd length mismatch");
+    return;
+  }
   int rc;
   {
-    Crit<jfloat> wv(env, w);
+    LongElems ab(env, assignedBegin, JNI_ABORT);
+    LongElems ae(env, assignedEnd, JNI_ABORT);
+    rc = dsgd_async_start(ctx(h), reinterpret_cast<const int64_t*>(ab.p), reinterpret_cast<const int64_t*>(ae.p), k, batch,
+                          lr, maxUpdates, static_cast<uint64_t>(seed), positionalBug ? 1 : 0);
+  }
+  if (rc) raise(env, rc);
+}
+
+// mini-batch updates applied so far (MasterAsync counts these: core/MasterAsync.scala:83,171)
+JNIEXPORT jlong JNICALL NATIVE(asyncUpdates)(JNIEnv* env, jobject, jlong h) {
+  int64_t u = 0;
+  int32_t running = 0;
+  int rc = dsgd_async_updates(ctx(h), &u, &running);
+  if (rc) raise(env, rc);
+  return u;
+}
+
+// SlaveImpl.stopAsync (core/Slave.scala:187-195)
+JNIEXPORT void JNICALL NATIVE(asyncStop)(JNIEnv* env, jobject, jlong h) {
+  int rc = dsgd_async_stop(ctx(h));
+  if (rc) raise(env, rc);
+}
+
+JNIEXPORT void JNICALL NATIVE(asyncWait)(JNIEnv* env, jobject, jlong h) {
+  int rc = dsgd_async_wait(ctx(h));
+  if (rc) raise(env, rc);
+}
+
+JNIEXPORT void JNICALL NATIVE(setWeights)(JNIEnv* env, jobject, jlong h, jfloatArray w) {
+  int rc;
+  {
+    FloatElems wv(env, w, JNI_ABORT);
     rc = dsgd_set_weights(ctx(h), wv.p);
   }
   if (rc) raise(env, rc);
 }
 
-JNIEXPORT void JNICALL Java_epfl_distributed_core_ml_NativeSVM_getWeights(JNIEnv* env, jclass, jlong h, jfloatArray wOut) {
+JNIEXPORT void JNICALL NATIVE(getWeights)(JNIEnv* env, jobject, jlong h, jfloatArray wOut) {
   int rc;
   {
-    Crit<jfloat> wv(env, wOut);
+    FloatElems wv(env, wOut, 0);
     rc = dsgd_get_weights(ctx(h), wv.p);
   }
   if (rc) raise(env, rc);

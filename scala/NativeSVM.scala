@@ -11,6 +11,9 @@ import spire.math.Number
   * `dsgd.backend = hip` (a new OPTIONAL key; every existing `dsgd { ... }` key of application.conf is untouched).
   */
 object NativeSVM {
+  // The natives live on the module class `NativeSVM$`: their JNI names are
+  // Java_epfl_distributed_core_ml_NativeSVM_00024_<name>(JNIEnv*, jobject self, ...) -- jni/dsgd_jni.cpp exports
+  // exactly these (tests/test_jni_shim.py compares the two lists).
   System.loadLibrary("dsgd_jni") // jni/dsgd_jni.cpp, links libdsgd_hip.so
 
   @native def create(nFeatures: Int, lambda: Double, device: Int): Long
@@ -20,9 +23,15 @@ object NativeSVM {
   @native def gradient(ctx: Long, w: Array[Float], idx: Array[Int], gOut: Array[Float]): Long
   @native def forward(ctx: Long, w: Array[Float], idx: Array[Int], predOut: Array[Float]): Unit
   @native def syncStep(ctx: Long, idxPerWorker: Array[Array[Int]], lr: Float): Long
+  @native def syncStepRanges(ctx: Long, rowBegin: Array[Long], rowEnd: Array[Long], lr: Float): Long
   @native def lossAcc(ctx: Long, w: Array[Float], rowBegin: Long, rowEnd: Long, out: Array[Double]): Unit
   @native def asyncStep(ctx: Long, idx: Array[Int], lr: Float, deltaOut: Array[Float]): Unit
   @native def updateGrad(ctx: Long, keys: Array[Int], values: Array[Float]): Unit
+  @native def asyncStart(ctx: Long, assignedBegin: Array[Long], assignedEnd: Array[Long], batch: Int, lr: Float,
+                         maxUpdates: Long, seed: Long, positionalBug: Boolean): Unit
+  @native def asyncUpdates(ctx: Long): Long
+  @native def asyncStop(ctx: Long): Unit
+  @native def asyncWait(ctx: Long): Unit
   @native def setWeights(ctx: Long, w: Array[Float]): Unit
   @native def getWeights(ctx: Long, wOut: Array[Float]): Unit
 }
