@@ -112,6 +112,7 @@ struct dsgd_plan {
   long long n_steps = 0;
   int n_workers = 0;
   long long max_items = 0;  // largest single list
+  long long max_step_rows = 0;  // largest step (all workers together)
 };
 
 struct dsgd_ctx {
@@ -165,7 +166,7 @@ struct dsgd_ctx {
   int hw_we = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4;                     // ... of the mode-3 evaluation kernel
   // mode 4
   int hsplit = (DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64) / 2;         // hot ranks: 2 * hsplit words of LDS
-  int* d_hcol = nullptr;                // hot stream (ranks < hsplit), WS_PAD elements of padding
+  unsigned short* d_hcol = nullptr;     // hot stream (16-bit ranks < hsplit), WS_PAD elements of padding
   float* d_hval = nullptr;
   long long* d_hrow_ptr = nullptr;      // n_rows + 1 (rows of the long list: empty)
   long long hot_nnz = 0;
@@ -198,7 +199,12 @@ struct dsgd_ctx {
   float fix_scale = 4194304.0f;  // 2^FIX_SHIFT / vmax2
   int vexp = 0;                  // vmax2 = 2^vexp >= max |value|
   int last_shift = FIX_SHIFT;    // shift of the last split-layout gradient launch
+  std::vector<StreamSeg> bound_segs;   // split layout: the (ranges, grid) configuration bound_shift was measured for
+  unsigned bound_grid = 0;
+  int bound_shift = 0;
+  unsigned int* d_bound = nullptr;
   int max_shift = FIX_SHIFT;     // DSGD_FIX_SHIFT: cap of the per-launch fixed-point shift of the split layout
+  bool fix_bound = true;         // DSGD_FIX_BOUND=0: keep the data-independent bound (rows per workgroup x largest value)
   int g_cap = 0;
   float* d_gsum = nullptr;  // dp (all-reduce buffer / sum over hosted workers)
   float* d_tmp = nullptr;   // dp scratch (ranked order)
@@ -206,6 +212,7 @@ struct dsgd_ctx {
   DevScalars* d_sc = nullptr;
   DevScalars* h_sc = nullptr;  // pinned
   bool s_dirty = true;
+  bool nsq_dirty = false;   // |w|^2 stale although s is current (after dsgd_plan_kernel)
   bool have_ds = false;
   // staging for host-provided index lists
   int* d_idx = nullptr;
@@ -219,10 +226,22 @@ struct dsgd_ctx {
   hipStream_t query_stream = nullptr;
   HogState* d_hog = nullptr;
   HogState* h_hog = nullptr;   // pinned
-  int* h_stop = nullptr;       // host-mapped stop flag
   float* d_gcold = nullptr;
   long long* d_asg = nullptr;  // begin[n], end[n]
-  int hog_workers = 0;
+  unsigned long long* d_hog_it = nullptr;   // per worker: iterations done (continues across exchange rounds)
+  int* h_one = nullptr;        // pinned constant 1: source of the stop-flag copy
+  // small-batch plan kernel (one persistent workgroup): cold strip and the multi-worker sum buffer
+  float* d_plan_gcold = nullptr;
+  float* d_plan_upd = nullptr;
+  bool plan_kernel = true;     // DSGD_PLAN_KERNEL=0: the multi-launch small-batch path
+  long long plan_max_rows = 2048;   // steps with more rows in total use the multi-workgroup kernels
+  int hog_workers = 0;      // capacity of the per-worker buffers
+  int hog_n = 0, hog_batch = 0, hog_bug = 0;   // the running configuration
+  float hog_lr = 0.0f;
+  unsigned long long hog_seed = 0;
+  long long exchange_every = 0;   // dsgd_async_set_exchange: cross-GPU exchange period in local updates (0 = none)
+  float* d_wprev = nullptr;       // weights at the last exchange
+  float* d_wdelta = nullptr;      // 2 x dp: all-reduced updates, this replica's own part
   bool async_running = false;
   // comm
   rccl::comm_t comm = nullptr;
@@ -303,6 +322,7 @@ static int upload_segs(dsgd_ctx* c, const std::vector<WorkSeg>& segs) {
 
 static int ensure_s(dsgd_ctx* c) {  // s = 2*lambda*(w.ds) must match the resident w
   if (!c->s_dirty) return DSGD_OK;
+  c->nsq_dirty = false;
   hipLaunchKernelGGL(dsgd_wstats_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_ds, c->dp,
                      (float)c->cfg.lambda, c->d_sc);
   HIP_TRY(hipGetLastError());
@@ -585,10 +605,15 @@ static int build_cold_lists(dsgd_ctx* c) {
 struct HostTiles {
   std::vector<WTile> wt;
   std::vector<int> r0;              // first row of every tile + sentinel n_rows
-  std::vector<unsigned int> meta;   // n_tiles x 64
+  std::vector<unsigned int> meta;   // n_tiles x 64 (mode 3: first row | start bits << 8 | label signs << 16)
+  std::vector<unsigned short> meta16;   // n_tiles x 64 (split layout: start bits | label signs << 8)
 };
+// `split`: the hot stream of the split layout -- windows start at a multiple of 8 slots (one 16-byte load of eight
+// 16-bit column ranks per lane) and the lane descriptors are the 16-bit form (the kernel derives each lane's first
+// row with a wave prefix sum over the start bits).
 static void build_wave_tiles(const long long* row_ptr, long long n_rows, const signed char* label, HostTiles& out,
-                             std::vector<long long>* long_rows) {
+                             std::vector<long long>* long_rows, bool split) {
+  const long long amask = split ? ~7LL : ~3LL;
   std::vector<WTile>& wt = out.wt;
   std::vector<int>& wr0 = out.r0;
   wt.clear();
@@ -597,7 +622,7 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
   auto close = [&](long long end_row) {
     if (start < 0) return;
     WTile t;
-    t.pos0 = row_ptr[start] & ~3LL;
+    t.pos0 = row_ptr[start] & amask;
     t.r0 = (int)start;
     t.info = (int)(((end_row - start) & 0xffff) | ((row_ptr[end_row] - t.pos0) << 16));
     wt.push_back(t);
@@ -611,13 +636,14 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
       if (long_rows && len > WS_MAXNNZ) long_rows->push_back(i);
       continue;
     }
-    if (start >= 0 && (row_ptr[i + 1] - (row_ptr[start] & ~3LL) > WS_SLOTS - 1 || i - start >= WS_MAXROWS)) close(i);
+    if (start >= 0 && (row_ptr[i + 1] - (row_ptr[start] & amask) > WS_SLOTS - 1 || i - start >= WS_MAXROWS)) close(i);
     if (start < 0) start = i;
   }
   close(n_rows);
   wr0.push_back((int)n_rows);
   const long long n_tiles = (long long)wt.size();
-  out.meta.assign((size_t)std::max<long long>(n_tiles, 1) * 64, 0u);
+  if (split) out.meta16.assign((size_t)std::max<long long>(n_tiles, 1) * 64, (unsigned short)0);
+  else out.meta.assign((size_t)std::max<long long>(n_tiles, 1) * 64, 0u);
   for (long long t = 0; t < n_tiles; ++t) {
     const WTile& T = wt[(size_t)t];
     const int t_nrows = (int)(short)(T.info & 0xffff);
@@ -639,7 +665,8 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
         }
         if (k == 0) first_row = cur_row;
       }
-      out.meta[(size_t)t * 64 + l] = (unsigned int)first_row | (bits << 8) | (ys << 16);
+      if (split) out.meta16[(size_t)t * 64 + l] = (unsigned short)(bits | (ys << 8));
+      else out.meta[(size_t)t * 64 + l] = (unsigned int)first_row | (bits << 8) | (ys << 16);
     }
   }
   if (wt.empty()) {
@@ -660,9 +687,13 @@ static int upload_wave_tiles(dsgd_ctx* c, HostTiles& ht) {
   c->n_wtiles = (long long)ht.r0.size() - 1;
   c->h_wtile_r0.swap(ht.r0);
   HIP_TRY(hipMalloc(&c->d_wtiles, sizeof(WTile) * ht.wt.size()));
-  HIP_TRY(hipMalloc(&c->d_wmeta, sizeof(unsigned int) * ht.meta.size()));
+  // (the split layout's 16-bit descriptors live in the same buffer; the kernel reinterprets the pointer)
+  const void* meta_src = ht.meta16.empty() ? (const void*)ht.meta.data() : (const void*)ht.meta16.data();
+  const size_t meta_bytes = ht.meta16.empty() ? sizeof(unsigned int) * ht.meta.size() : sizeof(unsigned short) * ht.meta16.size();
+  HIP_TRY(hipMalloc(&c->d_wmeta, meta_bytes));
   HIP_TRY(hipMemcpy(c->d_wtiles, ht.wt.data(), sizeof(WTile) * ht.wt.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c->d_wmeta, ht.meta.data(), sizeof(unsigned int) * ht.meta.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_wmeta, meta_src, meta_bytes, hipMemcpyHostToDevice));
+  c->bound_segs.clear();
   std::vector<int> lr(c->wlong_rows.begin(), c->wlong_rows.end());
   lr.push_back(0);
   HIP_TRY(hipMalloc(&c->d_wlong_rows, sizeof(int) * lr.size()));
@@ -718,9 +749,9 @@ static int build_split(dsgd_ctx* c) {
   }
   c->hot_nnz = hrp[n_rows];
   c->coldm_nnz = crp[n_rows];
-  HIP_TRY(hipMalloc(&c->d_hcol, sizeof(int) * (size_t)(c->hot_nnz + WS_PAD)));
+  HIP_TRY(hipMalloc(&c->d_hcol, sizeof(unsigned short) * (size_t)(c->hot_nnz + WS_PAD)));
   HIP_TRY(hipMalloc(&c->d_hval, sizeof(float) * (size_t)(c->hot_nnz + WS_PAD)));
-  HIP_TRY(hipMemset(c->d_hcol + c->hot_nnz, 0, sizeof(int) * WS_PAD));
+  HIP_TRY(hipMemset(c->d_hcol + c->hot_nnz, 0, sizeof(unsigned short) * WS_PAD));
   HIP_TRY(hipMemset(c->d_hval + c->hot_nnz, 0, sizeof(float) * WS_PAD));
   HIP_TRY(hipMalloc(&c->d_hrow_ptr, sizeof(long long) * hrp.size()));
   HIP_TRY(hipMemcpy(c->d_hrow_ptr, hrp.data(), sizeof(long long) * hrp.size(), hipMemcpyHostToDevice));
@@ -757,7 +788,7 @@ static int build_split(dsgd_ctx* c) {
     HIP_TRY(hipGetLastError());
   }
   HostTiles ht;
-  build_wave_tiles(hrp.data(), n_rows, c->h_label.data(), ht, nullptr);
+  build_wave_tiles(hrp.data(), n_rows, c->h_label.data(), ht, nullptr, true);
   DSGD_TRY(upload_wave_tiles(c, ht));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return DSGD_OK;
@@ -996,13 +1027,37 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
     }
     int bits = 0;
     while ((1LL << bits) < worst) ++bits;
-    const int shift = std::max(1, std::min(c->max_shift, 30 - bits));
+    const int shift0 = std::max(1, std::min(c->max_shift, 30 - bits));   // safe for ANY data: rows x largest value
+    int shift = shift0;
+    if (c->fix_bound && shift0 < c->max_shift) {
+      // data-dependent refinement (dsgd_wseg_bound_kernel): measured once per (ranges, grid) configuration
+      const bool hit = c->bound_grid == grid.x && c->bound_segs.size() == segs.size() &&
+                       memcmp(c->bound_segs.data(), segs.data(), sizeof(StreamSeg) * segs.size()) == 0;
+      if (!hit) {
+        if (!c->d_bound) HIP_TRY(hipMalloc(&c->d_bound, sizeof(unsigned int)));
+        HIP_TRY(hipMemsetAsync(c->d_bound, 0, sizeof(unsigned int), c->stream));
+        hipLaunchKernelGGL(dsgd_wseg_bound_kernel, grid, dim3(1024), sizeof(unsigned int) * (size_t)hg, c->stream,
+                           c->d_hrow_ptr, c->d_hcol, c->d_hval, c->d_wtiles, c->n_wtiles, c->n_rows, view(c),
+                           c->d_wlong_rows, c->d_ssegs, hg, std::ldexp(1.0f, shift0 - c->vexp), c->d_bound);
+        HIP_TRY(hipGetLastError());
+        unsigned int amax = 0;
+        HIP_TRY(hipMemcpyAsync(&amax, c->d_bound, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        int s2 = shift0;
+        const double room = (double)(1LL << 30) - (double)worst;
+        while (s2 < c->max_shift && std::ldexp((double)amax, s2 + 1 - shift0) <= room) ++s2;
+        c->bound_segs = segs;
+        c->bound_grid = grid.x;
+        c->bound_shift = s2;
+      }
+      shift = c->bound_shift;
+    }
     main_scale = std::ldexp(1.0f, shift - c->vexp);
     c->last_shift = shift;
   }
   CsrView mh = view(c);
   mh.row_ptr = c->d_hrow_ptr;
-  mh.col = c->d_hcol;
+  mh.col = reinterpret_cast<const int*>(c->d_hcol);   // 16-bit ranks; the split kernel reinterprets the pointer
   mh.val = c->d_hval;
   CsrView mf = view(c);
   size_t slot = 0;
@@ -1039,6 +1094,61 @@ template <bool SCATTER>
 static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
   if (c->stream_mode == 4) return launch_split<SCATTER>(c, segs);
   return launch_wseg<SCATTER>(c, segs);
+}
+
+static int hog_raise_stop(dsgd_ctx* c);
+
+// small-batch steps as ONE persistent workgroup (dsgd_plan_kernel): eligible when no collective sits between the
+// gradient and the update and a step is small enough for one CU
+static bool plan_kernel_ok(const dsgd_ctx* c, long long step_rows) {
+  return c->plan_kernel && !c->comm && step_rows <= c->plan_max_rows &&
+         !(c->cfg.flags & (DSGD_F_FORCE_TILED | DSGD_F_FORCE_ROWS));
+}
+static int launch_plan_kernel(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int n_workers, long long step_begin,
+                              long long step_end, float lr) {
+  const int hl = std::min(c->dp, 32768);
+  if (!c->d_plan_gcold) {
+    const size_t strip = (size_t)std::max(1, c->dp - hl);
+    HIP_TRY(hipMalloc(&c->d_plan_gcold, sizeof(float) * strip));
+    HIP_TRY(hipMalloc(&c->d_plan_upd, sizeof(float) * c->dp));
+    HIP_TRY(hipMemsetAsync(c->d_plan_gcold, 0, sizeof(float) * strip, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_plan_upd, 0, sizeof(float) * c->dp, c->stream));
+  }
+  PlanArgs a;
+  a.m = view(c);
+  a.w = c->d_w;
+  a.ds = c->d_ds;
+  a.gcold = c->d_plan_gcold;
+  a.upd = c->d_plan_upd;
+  a.idx = d_idx;
+  a.segs = d_segs;
+  a.sc = c->d_sc;
+  a.step_begin = step_begin;
+  a.step_end = step_end;
+  a.k_total = (float)n_workers;
+  a.lr = lr;
+  a.lambda = (float)c->cfg.lambda;
+  a.inv_vmax2 = std::ldexp(1.0f, -c->vexp);
+  a.vexp = c->vexp;
+  a.n_workers = n_workers;
+  a.hl = hl;
+  a.dp = c->dp;
+  const int n_cw = (c->dp - hl + 31) / 32, n_uw = n_workers > 1 ? (c->dp + 31) / 32 : 0;
+  const size_t lds = sizeof(float) * (size_t)(((hl + n_cw + n_uw + 1) & ~1) + 32 + 8);
+  size_t slot = 0;
+  DSGD_TRY(prof_begin(c, &slot));
+  if (n_workers > 1) {
+    hipLaunchKernelGGL(dsgd_plan_kernel<true>, dim3(1), dim3(PLAN_THREADS), lds, c->stream, a);
+    c->last_grad_kernel = "dsgd_plan_kernel<true>";
+  } else {
+    hipLaunchKernelGGL(dsgd_plan_kernel<false>, dim3(1), dim3(PLAN_THREADS), lds, c->stream, a);
+    c->last_grad_kernel = "dsgd_plan_kernel<false>";
+  }
+  HIP_TRY(hipGetLastError());
+  DSGD_TRY(prof_end(c, slot));
+  c->s_dirty = false;     // the kernel leaves s = 2*lambda*(w . ds) of the weights it ends with ...
+  c->nsq_dirty = true;    // ... but not |w|^2 (needed only by dsgd_loss_acc)
+  return DSGD_OK;
 }
 
 static int require_data(dsgd_ctx* c) {
@@ -1133,6 +1243,9 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_EPI")) c->use_part = atoi(e) != 0;
   if (const char* e = getenv("DSGD_DBG")) c->dbg = atoi(e);
   if (const char* e = getenv("DSGD_FIX_SHIFT")) c->max_shift = std::max(8, std::min(FIX_SHIFT, atoi(e)));
+  if (const char* e = getenv("DSGD_FIX_BOUND")) c->fix_bound = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_PLAN_MAX_ROWS")) c->plan_max_rows = std::max(1LL, atoll(e));
   if (c->dbg) c->stream_mode = 3;   // the ablation build exists for the mode-3 kernel
   if (const char* e = getenv("DSGD_HW_W")) c->hw_w = atoi(e);
   if (const char* e = getenv("DSGD_HG_W")) c->hg_w = atoi(e);
@@ -1142,7 +1255,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (c->hw_w + c->hg_w > DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64)
     return bail(fail(DSGD_EINVAL, "DSGD_HW_W + DSGD_HG_W exceed %d floats of LDS", DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64));
   if (const char* e = getenv("DSGD_HSPLIT")) c->hsplit = atoi(e);
-  c->hsplit = std::max(1, std::min(c->hsplit, (DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64) / 2));
+  c->hsplit = std::max(1, std::min(c->hsplit, (DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64) / 2));   // (< 65536: 16-bit ranks)
   const int lds_max = DSGD_LDS_FLOATS * (int)sizeof(float);
 #define DSGD_ATTR(fn) HIP_TRY_B(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max))
   DSGD_ATTR(dsgd_grad_tiled_kernel<64>);
@@ -1155,12 +1268,15 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_eval_kernel<8>);
   DSGD_ATTR(dsgd_colcount_kernel);
   DSGD_ATTR(dsgd_hogwild_kernel);
+  DSGD_ATTR(dsgd_plan_kernel<true>);
+  DSGD_ATTR(dsgd_plan_kernel<false>);
   DSGD_ATTR((dsgd_wseg_kernel<true, false, 4, false>));
   DSGD_ATTR((dsgd_wseg_kernel<true, true, 4, false>));
   DSGD_ATTR((dsgd_wseg_kernel<false, false, 4, false>));
   DSGD_ATTR((dsgd_wseg_kernel<false, true, 4, false>));
   DSGD_ATTR((dsgd_wseg_kernel<true, false, 4, true>));
   DSGD_ATTR((dsgd_wseg_kernel<false, false, 4, true>));
+  DSGD_ATTR(dsgd_wseg_bound_kernel);
   DSGD_ATTR(dsgd_cdot_kernel<true>);
   DSGD_ATTR(dsgd_cdot_kernel<false>);
   DSGD_ATTR(dsgd_cgrad_kernel<true>);
@@ -1174,7 +1290,15 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
 
 int dsgd_destroy(dsgd_ctx* c) {
   if (!c) return DSGD_OK;
+  c->mu.lock();   // a call still running on another thread finishes first
   (void)hipSetDevice(c->cfg.device);
+  // The persistent Hogwild kernel only exits on its stop flag: raise it and wait BEFORE any hipFree (hipFree
+  // synchronises the device -- it would wait forever on that kernel, or free memory the kernel still reads).
+  if (c->async_stream) {
+    (void)hog_raise_stop(c);
+    (void)hipStreamSynchronize(c->async_stream);
+    c->async_running = false;
+  }
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm && rccl::available()) rccl::CommDestroy(c->comm);
   for (auto& e : c->prof_ev) {
@@ -1216,19 +1340,22 @@ int dsgd_destroy(dsgd_ctx* c) {
   (void)hipFree(c->d_cbase);
   (void)hipFree(c->d_crow_ptr);
   (void)hipFree(c->d_dcold);
-  if (c->async_stream) {
-    if (c->h_stop) *c->h_stop = 1;
-    (void)hipStreamSynchronize(c->async_stream);
-    (void)hipStreamDestroy(c->async_stream);
-  }
+  (void)hipFree(c->d_bound);
+  if (c->async_stream) (void)hipStreamDestroy(c->async_stream);
   if (c->query_stream) (void)hipStreamDestroy(c->query_stream);
   (void)hipFree(c->d_hog);
   (void)hipFree(c->d_gcold);
   (void)hipFree(c->d_asg);
   if (c->h_hog) (void)hipHostFree(c->h_hog);
-  if (c->h_stop) (void)hipHostFree(c->h_stop);
+  if (c->h_one) (void)hipHostFree(c->h_one);
+  (void)hipFree(c->d_hog_it);
+  (void)hipFree(c->d_wprev);
+  (void)hipFree(c->d_wdelta);
+  (void)hipFree(c->d_plan_gcold);
+  (void)hipFree(c->d_plan_upd);
   if (c->h_sc) (void)hipHostFree(c->h_sc);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  c->mu.unlock();
   delete c;
   return DSGD_OK;
 }
@@ -1304,6 +1431,7 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr_in, const 
   }
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
+  DSGD_TRY(require_sync_mode(c));   // the persistent engine reads the matrix that would be freed here
   HIP_TRY(hipStreamSynchronize(c->stream));
   DSGD_TRY(reset_layout(c));
   (void)hipFree(c->d_row_ptr);
@@ -1344,7 +1472,7 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr_in, const 
   if (c->stream_mode == 3) {
     HostTiles ht;
     c->wlong_rows.clear();
-    build_wave_tiles(c->h_row_ptr.data(), n_rows, c->h_label.data(), ht, &c->wlong_rows);
+    build_wave_tiles(c->h_row_ptr.data(), n_rows, c->h_label.data(), ht, &c->wlong_rows, false);
     DSGD_TRY(upload_wave_tiles(c, ht));
   }
   const double mean = (double)nnz / (double)n_rows;
@@ -1364,6 +1492,7 @@ int dsgd_set_dim_sparsity(dsgd_ctx* c, const float* ds) {
   if (!ds) return fail(DSGD_EINVAL, "null ds");
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
+  DSGD_TRY(require_sync_mode(c));
   HIP_TRY(hipMemcpyAsync(c->d_io, ds, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
   DSGD_TRY(launch_permute_in(c, c->d_io, c->d_ds));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1377,6 +1506,7 @@ int dsgd_build_dim_sparsity(dsgd_ctx* c, int64_t n_train, float* ds_out) {
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
   DSGD_TRY(require_data(c));
+  DSGD_TRY(require_sync_mode(c));
   if (n_train < 1 || n_train > c->n_rows) return fail(DSGD_EINVAL, "n_train %lld outside [1, %lld]", (long long)n_train, c->n_rows);
   DSGD_TRY(prepare_layout(c));
   long long nnz_train = 0;
@@ -1483,6 +1613,7 @@ int dsgd_gradient(dsgd_ctx* c, const float* w, const int32_t* idx, int64_t n, fl
   DSGD_TRY(bind(c));
   DSGD_TRY(require_data(c));
   DSGD_TRY(require_ds(c));
+  DSGD_TRY(require_sync_mode(c));   // g accumulators, s and (with w != NULL) the weights belong to the running engine
   DSGD_TRY(prepare_layout(c));
   if (w) DSGD_TRY(set_weights_locked(c, w));
   DSGD_TRY(ensure_s(c));
@@ -1513,6 +1644,7 @@ int dsgd_apply(dsgd_ctx* c, const float* g_mean, float lr) {
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
   DSGD_TRY(require_ds(c));
+  DSGD_TRY(require_sync_mode(c));
   HIP_TRY(hipMemcpyAsync(c->d_io, g_mean, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
   DSGD_TRY(launch_permute_in(c, c->d_io, c->d_gsum));
   hipLaunchKernelGGL(dsgd_apply_kernel<false>, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_gsum, c->d_gsum,
@@ -1544,10 +1676,20 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
   DSGD_TRY(require_ds(c));
   DSGD_TRY(require_sync_mode(c));
   DSGD_TRY(prepare_layout(c));
+  long long mx = 0, tot = 0;
+  {
+    long long t = 0;
+    for (int k = 0; k < n_workers; ++k) t += std::max<long long>(0, n_per_worker[k]);
+    if (plan_kernel_ok(c, t)) {   // the reference's batch sizes: one persistent workgroup does the whole closure
+      DSGD_TRY(reset_counters(c));
+      DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
+      DSGD_TRY(launch_plan_kernel(c, c->d_idx, c->d_segs, n_workers, 0, 1, lr));
+      return finish_stats(c, stats, tot);
+    }
+  }
   DSGD_TRY(ensure_g(c, n_workers));
   DSGD_TRY(ensure_s(c));
   DSGD_TRY(reset_counters(c));
-  long long mx = 0, tot = 0;
   DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
   DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, n_workers, mx, tot));
   DSGD_TRY(launch_finish_sync(c, n_workers, lr));
@@ -1653,6 +1795,8 @@ int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, in
   p->n_workers = n_workers;
   p->max_items = mx;
   p->offsets.assign(offsets, offsets + n_lists + 1);
+  for (int64_t st = 0; st < n_steps; ++st)
+    p->max_step_rows = std::max<long long>(p->max_step_rows, offsets[(st + 1) * n_workers] - offsets[st * n_workers]);
   std::vector<WorkSeg> segs((size_t)n_lists);
   for (int64_t i = 0; i < n_lists; ++i) {
     segs[i].begin = offsets[i];
@@ -1696,6 +1840,11 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
   DSGD_TRY(require_ds(c));
   DSGD_TRY(require_sync_mode(c));
   DSGD_TRY(prepare_layout(c));
+  if (plan_kernel_ok(c, p->max_step_rows)) {
+    if (step_end > step_begin) DSGD_TRY(launch_plan_kernel(c, p->d_idx, p->d_segs, p->n_workers, step_begin, step_end, lr));
+    c->pending_samples += p->offsets[step_end * p->n_workers] - p->offsets[step_begin * p->n_workers];
+    return DSGD_OK;
+  }
   DSGD_TRY(ensure_g(c, p->n_workers));
   DSGD_TRY(ensure_s(c));
   for (int64_t s = step_begin; s < step_end; ++s) {
@@ -1717,6 +1866,7 @@ int dsgd_forward(dsgd_ctx* c, const float* w, const int32_t* idx, int64_t n, flo
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
   DSGD_TRY(require_data(c));
+  if (w) DSGD_TRY(require_sync_mode(c));   // replacing the weights under the lock-free engine is refused
   DSGD_TRY(prepare_layout(c));
   if (w) DSGD_TRY(set_weights_locked(c, w));
   if (n == 0) return DSGD_OK;  // samplesIdx.map over an empty Seq is an empty reply (ref: core/Slave.scala:133)
@@ -1754,9 +1904,15 @@ int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_en
     return fail(DSGD_EINVAL, "empty row range: reduce on an empty sample list");
   if (row_begin < 0 || row_end > c->n_rows)
     return fail(DSGD_ERANGE, "rows [%lld, %lld) outside the %lld loaded rows", (long long)row_begin, (long long)row_end, c->n_rows);
+  if (w) DSGD_TRY(require_sync_mode(c));
   DSGD_TRY(prepare_layout(c));
   if (w) DSGD_TRY(set_weights_locked(c, w));
+  // |w|^2 of the loss: cached with s while the synchronous kernels own w; while the lock-free engine runs w moves
+  // under the cache, so every check recomputes it (MasterAsync's leaky loss check, core/MasterAsync.scala:96-162,
+  // compares successive losses).  The engine keeps its own s (HogState), so refreshing d_sc here disturbs nothing.
+  if (c->async_running || c->nsq_dirty) c->s_dirty = true;
   DSGD_TRY(ensure_s(c));  // also refreshes |w|^2
+  if (c->async_running) c->s_dirty = true;
   DSGD_TRY(reset_counters(c));
   if (!c->async_running && c->stream_ranges && row_end - row_begin >= 4096) {
     std::vector<StreamSeg> ssegs(1, make_sseg(row_begin, row_end));
@@ -1840,7 +1996,9 @@ int dsgd_update_grad(dsgd_ctx* c, const int32_t* key, const float* dv, int64_t n
     int blocks = (int)std::min<long long>((nnz + 255) / 256, 2048);
     hipLaunchKernelGGL(dsgd_update_grad_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_w, c->d_perm, d_key, d_dv,
                        (long long)nnz, c->dp, c->d_sc);
-    hipLaunchKernelGGL(dsgd_filter_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, c->d_w, c->dp);
+    // the Sparse filter pass rewrites every w[j] non-atomically: skipped while the lock-free engine is adding to w
+    if (!c->async_running)
+      hipLaunchKernelGGL(dsgd_filter_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, c->d_w, c->dp);
     e = hipGetLastError();
   }
   int rc = read_scalars(c);
@@ -1859,6 +2017,36 @@ static int async_refresh(dsgd_ctx* c) {  // copy the engine's counters to the ho
   return DSGD_OK;
 }
 
+// one launch of the persistent kernel on async_stream: workers run until the TOTAL update count reaches max_updates
+static int hog_launch(dsgd_ctx* c, long long max_updates) {
+  HogArgs a;
+  a.m = view(c);
+  a.w = c->d_w;
+  a.ds = c->d_ds;
+  a.gcold = c->d_gcold;
+  a.asg_begin = c->d_asg;
+  a.asg_end = c->d_asg + c->hog_n;
+  a.it = c->d_hog_it;
+  a.st = c->d_hog;
+  a.max_updates = max_updates;
+  a.seed = c->hog_seed;
+  a.lr = c->hog_lr;
+  a.lambda = (float)c->cfg.lambda;
+  int bits = 0;
+  while ((1 << bits) < c->hog_batch) ++bits;
+  const int shift = std::min(23, 30 - bits);   // at most one contribution per row and column: sums stay below 2^30
+  a.qscale = std::ldexp(1.0f, shift - c->vexp);
+  a.inv_qscale = std::ldexp(1.0f, c->vexp - shift);
+  a.batch = c->hog_batch;
+  a.positional_bug = c->hog_bug;
+  a.hl = std::min(c->dp, HOG_HL);
+  a.dp = c->dp;
+  const size_t lds = sizeof(float) * (size_t)(a.hl + (c->dp - a.hl + 31) / 32 + 16 + 8);
+  hipLaunchKernelGGL(dsgd_hogwild_kernel, dim3(c->hog_n), dim3(HOG_THREADS), lds, c->async_stream, a);
+  HIP_TRY(hipGetLastError());
+  return DSGD_OK;
+}
+
 int dsgd_async_start(dsgd_ctx* c, const int64_t* assigned_begin, const int64_t* assigned_end, int32_t n_workers, int32_t batch,
                      float lr, int64_t max_updates, uint64_t seed, int32_t positional_bug) {
   DSGD_TRY(check_ctx(c));
@@ -1871,6 +2059,8 @@ int dsgd_async_start(dsgd_ctx* c, const int64_t* assigned_begin, const int64_t* 
   DSGD_TRY(require_ds(c));
   // ref: core/Slave.scala:161 "Async computation already running, can't be initialized unless stopped first"
   if (c->async_running) return fail(DSGD_ESTATE, "async computation already running: stop it first");
+  if (n_workers > c->n_cu)   // every worker is a resident workgroup (they never yield): one per CU at most
+    return fail(DSGD_EINVAL, "%d workers on a device with %d compute units", n_workers, c->n_cu);
   std::vector<long long> asg(2 * (size_t)n_workers);
   for (int k = 0; k < n_workers; ++k) {
     const long long b = assigned_begin[k], e = assigned_end[k];
@@ -1881,6 +2071,17 @@ int dsgd_async_start(dsgd_ctx* c, const int64_t* assigned_begin, const int64_t* 
     asg[k] = b;
     asg[n_workers + k] = e;
   }
+  const bool exchange = c->comm && c->exchange_every > 0;
+  long long n_rounds = 1;
+  if (exchange) {
+    // ref: core/Slave.scala:103-105 gossips every update to every peer; across GPUs the replicas exchange the SUM of
+    // their updates every `exchange_every` local updates (dsgd_async_set_exchange) -- all ranks must enqueue the same
+    // number of collectives, so the update budget has to be finite and identical on every rank.
+    n_rounds = (max_updates + c->exchange_every - 1) / c->exchange_every;
+    if (n_rounds < 1) n_rounds = 1;
+    if (n_rounds > 65536)
+      return fail(DSGD_EINVAL, "max_updates / exchange_every = %lld rounds: more than 65536 (give a finite update budget)", n_rounds);
+  }
   DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_s(c));
   if (!c->async_stream) {
@@ -1888,48 +2089,68 @@ int dsgd_async_start(dsgd_ctx* c, const int64_t* assigned_begin, const int64_t* 
     HIP_TRY(hipStreamCreateWithFlags(&c->query_stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&c->d_hog, sizeof(HogState)));
     HIP_TRY(hipHostMalloc(&c->h_hog, sizeof(HogState), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(&c->h_stop, sizeof(int), hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc(&c->h_one, sizeof(int), hipHostMallocDefault));
+    *c->h_one = 1;
   }
-  const int hl = std::min(c->dp, 24576);
+  const int hl = std::min(c->dp, HOG_HL);
+  const size_t strip = (size_t)std::max(1, c->dp - hl);
   if (n_workers > c->hog_workers) {
     (void)hipFree(c->d_gcold);
     (void)hipFree(c->d_asg);
+    (void)hipFree(c->d_hog_it);
     c->d_gcold = nullptr;
     c->d_asg = nullptr;
-    HIP_TRY(hipMalloc(&c->d_gcold, sizeof(float) * (size_t)n_workers * (size_t)std::max(1, c->dp - hl)));
+    c->d_hog_it = nullptr;
+    HIP_TRY(hipMalloc(&c->d_gcold, sizeof(float) * (size_t)n_workers * strip));
     HIP_TRY(hipMalloc(&c->d_asg, sizeof(long long) * 2 * (size_t)n_workers));
+    HIP_TRY(hipMalloc(&c->d_hog_it, sizeof(unsigned long long) * (size_t)n_workers));
     c->hog_workers = n_workers;
   }
-  HIP_TRY(hipMemsetAsync(c->d_gcold, 0, sizeof(float) * (size_t)n_workers * (size_t)std::max(1, c->dp - hl), c->stream));
+  if (exchange && !c->d_wprev) {
+    HIP_TRY(hipMalloc(&c->d_wprev, sizeof(float) * c->dp));
+    HIP_TRY(hipMalloc(&c->d_wdelta, sizeof(float) * 2 * c->dp));
+  }
+  HIP_TRY(hipMemsetAsync(c->d_gcold, 0, sizeof(float) * (size_t)n_workers * strip, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_hog_it, 0, sizeof(unsigned long long) * (size_t)n_workers, c->stream));
   HIP_TRY(hipMemcpyAsync(c->d_asg, asg.data(), sizeof(long long) * asg.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_hog, 0, sizeof(HogState), c->stream));
   HIP_TRY(hipMemcpyAsync(&c->d_hog->s_reg, &c->d_sc->s_reg, sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  if (exchange) HIP_TRY(hipMemcpyAsync(c->d_wprev, c->d_w, sizeof(float) * c->dp, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));  // asg is a stack-lifetime host buffer; everything is in place before launch
-  *c->h_stop = 0;
-  HogArgs a;
-  a.m = view(c);
-  a.w = c->d_w;
-  a.ds = c->d_ds;
-  a.gcold = c->d_gcold;
-  a.asg_begin = c->d_asg;
-  a.asg_end = c->d_asg + n_workers;
-  a.st = c->d_hog;
-  int* dev_stop = nullptr;
-  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_stop), c->h_stop, 0));
-  a.stop = dev_stop;
-  a.max_updates = max_updates;
-  a.seed = seed;
-  a.lr = lr;
-  a.lambda = (float)c->cfg.lambda;
-  a.batch = batch;
-  a.positional_bug = positional_bug;
-  a.hl = hl;
-  a.dp = c->dp;
-  const size_t lds = sizeof(float) * (size_t)(hl + HOG_MAX_BATCH / 4 + 16 + 16);
-  hipLaunchKernelGGL(dsgd_hogwild_kernel, dim3(n_workers), dim3(HOG_THREADS), lds, c->async_stream, a);
-  HIP_TRY(hipGetLastError());
+  c->hog_n = n_workers;
+  c->hog_batch = batch;
+  c->hog_lr = lr;
+  c->hog_seed = seed;
+  c->hog_bug = positional_bug;
+  if (!exchange) {
+    DSGD_TRY(hog_launch(c, max_updates));
+  } else {
+    const int blocks = (c->dp + 1023) / 1024;
+    for (long long r = 0; r < n_rounds; ++r) {
+      DSGD_TRY(hog_launch(c, std::min<long long>(max_updates, (r + 1) * c->exchange_every)));
+      // d_local = w_prev - w (what this replica subtracted since the last exchange); all-reduce; the peers' part
+      // d_sum - d_local is subtracted on top (a replica applies its own updates as it goes and its peers' updates
+      // when they arrive: core/Slave.scala:99-105,177-185).  With one rank the peers' part is exactly zero.
+      hipLaunchKernelGGL(dsgd_exchange_delta_kernel, dim3(blocks), dim3(1024), 0, c->async_stream, c->d_w, c->d_wprev,
+                         c->d_wdelta, c->d_wdelta + c->dp, c->dp);
+      HIP_TRY(hipGetLastError());
+      RCCL_TRY(rccl::AllReduce(c->d_wdelta, c->d_wdelta, (size_t)c->dp, rccl::kFloat32, rccl::kSum, c->comm, c->async_stream));
+      hipLaunchKernelGGL(dsgd_exchange_apply_kernel, dim3(1), dim3(1024), 0, c->async_stream, c->d_w, c->d_wprev,
+                         c->d_wdelta, c->d_wdelta + c->dp, c->d_ds, c->dp, (float)c->cfg.lambda, c->d_hog);
+      HIP_TRY(hipGetLastError());
+    }
+  }
   c->async_running = true;
   c->s_dirty = true;
+  return DSGD_OK;
+}
+
+int dsgd_async_set_exchange(dsgd_ctx* c, int64_t every_updates) {
+  DSGD_TRY(check_ctx(c));
+  if (every_updates < 0) return fail(DSGD_EINVAL, "negative exchange period");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (c->async_running) return fail(DSGD_ESTATE, "async computation running");
+  c->exchange_every = every_updates;
   return DSGD_OK;
 }
 
@@ -1949,10 +2170,20 @@ int dsgd_async_updates(dsgd_ctx* c, int64_t* updates, int32_t* running) {
   return DSGD_OK;
 }
 
+// raise the engine's stop flag: a 4-byte copy on the side stream (the kernel polls device memory, not the PCIe bus)
+static int hog_raise_stop(dsgd_ctx* c) {
+  if (!c->d_hog || !c->h_one) return DSGD_OK;
+  HIP_TRY(hipMemcpyAsync(&c->d_hog->stop, c->h_one, sizeof(int), hipMemcpyHostToDevice, c->query_stream));
+  HIP_TRY(hipStreamSynchronize(c->query_stream));
+  return DSGD_OK;
+}
+
 static int async_join(dsgd_ctx* c) {
   HIP_TRY(hipStreamSynchronize(c->async_stream));
   c->async_running = false;
   c->s_dirty = true;  // w moved under the scalar the synchronous kernels cache
+  DSGD_TRY(async_refresh(c));
+  if (c->h_hog->err) return fail(DSGD_ERANGE, "the lock-free engine sampled a row outside the loaded data");
   return DSGD_OK;
 }
 
@@ -1961,7 +2192,7 @@ int dsgd_async_stop(dsgd_ctx* c) {  // ref: SlaveImpl.stopAsync, core/Slave.scal
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
   if (!c->async_running) return DSGD_OK;
-  *c->h_stop = 1;
+  DSGD_TRY(hog_raise_stop(c));
   return async_join(c);
 }
 
@@ -2062,6 +2293,16 @@ int dsgd_range_nnz(dsgd_ctx* c, int64_t row_begin, int64_t row_end, int64_t* nnz
     const bool split = c->stream_mode == 4 && c->stream_ranges && c->h_crow_ptr.size() == (size_t)c->n_rows + 1;
     *cold_nnz = split ? c->h_crow_ptr[(size_t)row_end] - c->h_crow_ptr[(size_t)row_begin] : 0;
   }
+  return DSGD_OK;
+}
+
+int dsgd_tuning_info(dsgd_ctx* c, int32_t* vals, int32_t n) {
+  DSGD_TRY(check_ctx(c));
+  if (!vals || n < 0 || n > 6) return fail(DSGD_EINVAL, "bad tuning_info arguments");
+  std::lock_guard<std::mutex> lk(c->mu);
+  const int32_t all[6] = {c->stream_ranges ? c->stream_mode : 0, std::min(c->hsplit, c->dp), c->last_shift,
+                          c->cold_packed ? 1 : 0, c->plan_kernel ? 1 : 0, c->fix_bound ? 1 : 0};
+  for (int i = 0; i < n; ++i) vals[i] = all[i];
   return DSGD_OK;
 }
 

@@ -798,6 +798,7 @@ struct WRegs {
   float4 v0, v1;
   float gw[8];
   float dc;            // SPLIT: cold part of x.w of the row that ends in this lane
+  int rf;              // SPLIT: local row of the lane's first slot (wave prefix sum over the row-start bits)
   unsigned int meta;
   long long pos0, tc;  // wave-uniform (scalar registers): window start, clamped tile index
   int r0, nrows, nb;   // wave-uniform: first row, rows, bytes of the window that belong to the tile
@@ -814,6 +815,7 @@ __device__ __forceinline__ WTile w_fetch(const WTables& tt, long long t, long lo
 // the two halves of a tile's stream: column ids first (the cold-weight gathers of the tile wait for them), values
 // and lane descriptors one iteration later when DEPTH = 4 (they are not needed before the tile is processed) --
 // this keeps four column sets but only three value sets live
+template <bool SPLIT>
 __device__ __forceinline__ void w_issue_cols(const CsrView& m, long long t, long long t_end, int lane, const WTile& wt,
                                              WRegs& r) {
   const bool live = t < t_end;
@@ -826,14 +828,28 @@ __device__ __forceinline__ void w_issue_cols(const CsrView& m, long long t, long
   // time -- with three tiles in flight per wave those lines have left the caches again (rocprofv3 FETCH_SIZE was
   // 1.2 x the algorithmic bytes).
   r.nb = (int)(((unsigned int)wt.info >> 16) + 3u & ~3u) * 4;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  if (SPLIT) {
+    // Split layout: the hot stream carries 16-BIT column ranks (hot ranks < hsplit <= 65536 always: LDS caps hsplit
+    // near 18 K), eight per lane in ONE 16-byte load -- 6 bytes per non-zero instead of 8.  The kernel was moving
+    // 5.6 TB/s of physical traffic (89 % of the 6.29 TB/s copy ceiling) at 0.62 of the ALGORITHMIC roofline: bytes,
+    // not latency, were the lever.  Windows start at a multiple of 8 slots (16-byte aligned in this array).
+    const unsigned short* col16 = reinterpret_cast<const unsigned short*>(m.col);
+    const int nb16 = (int)(((unsigned int)wt.info >> 16) + 7u & ~7u) * 2;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(col16 + wt.pos0), 0, nb16, 0x00020000);
+    const i32x4 a = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0));
+    r.c0 = make_int4(a.x, a.y, a.z, a.w);
+    return;
+  }
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(m.col + wt.pos0), 0, r.nb, 0x00020000);
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
   const i32x4 a = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane, 0, 0));
   const i32x4 b = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane + 16, 0, 0));
   r.c0 = make_int4(a.x, a.y, a.z, a.w);
   r.c1 = make_int4(b.x, b.y, b.z, b.w);
 }
+template <bool SPLIT>
 __device__ __forceinline__ void w_issue_vals(const CsrView& m, const WTables& tt, int lane, WRegs& r) {
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m.val + r.pos0), 0, r.nb, 0x00020000);
@@ -844,7 +860,10 @@ __device__ __forceinline__ void w_issue_vals(const CsrView& m, const WTables& tt
   const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane + 16, 0, 0));
   r.v0 = make_float4(a.x, a.y, a.z, a.w);
   r.v1 = make_float4(b.x, b.y, b.z, b.w);
-  r.meta = (tt.meta + r.tc * 64)[(unsigned int)lane];
+  // lane descriptor.  Split layout: 16 bits (row-start bits | label signs << 8); the local row of the lane's first
+  // slot is a wave prefix sum over the start bits (w_load_dc) instead of a stored field -- half the descriptor bytes
+  if (SPLIT) r.meta = (reinterpret_cast<const unsigned short*>(tt.meta) + r.tc * 64)[(unsigned int)lane];
+  else r.meta = (tt.meta + r.tc * 64)[(unsigned int)lane];
 }
 
 // cold-weight gathers of a tile whose column ids have landed.  Buffer loads: a hot lane gets an offset
@@ -882,8 +901,19 @@ struct WCtx {
 // without a row end read row r0 and ignore the value
 __device__ __forceinline__ void w_load_dc(const WCtx& x, WRegs& r) {
   const unsigned int dn = r.nrows < 0 ? 0u : r.meta;
-  const unsigned int bn = (dn >> 8) & 255u;
-  const int re_n = (int)(dn & 255u) - (int)(bn & 1u);
+  const unsigned int bn = dn & 255u;
+  // row starts in the lanes below this one = the local row that ENDS at this lane's first start (rows are 1-based,
+  // the end mark of the tile's last row counts as a start): inclusive DPP scan of the popcounts minus the lane's own
+  const int pc = __popc(bn);
+  int v = pc;
+  v += dpp_get_i<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_get_i<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_get_i<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_get_i<0x118, 0xf>(v);   // row_shr:8
+  v += dpp_get_i<0x142, 0xa>(v);   // row_bcast:15 -> rows 1 and 3
+  v += dpp_get_i<0x143, 0xc>(v);   // row_bcast:31 -> rows 2 and 3
+  const int re_n = v - pc;
+  r.rf = re_n + (int)(bn & 1u);    // a start at slot 0 makes the lane's first slot the NEW row
   const bool ok = bn != 0u && re_n >= 1 && re_n <= r.nrows;
   r.dc = (x.dcold + r.r0)[ok ? (unsigned int)(re_n - 1) : 0u];
 }
@@ -955,18 +985,30 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
   // wait for it does not drain the stream loads issued behind it
   const WTile wt_now = wt_far;                                              // record fetched last iteration
   wt_far = w_fetch(tt, tile + DEPTH * stride, t_end);                       // record used next iteration
-  w_issue_cols(m, tile + (DEPTH - 1) * stride, t_end, lane, wt_now, far);
-  w_issue_vals(m, tt, lane, far);   // (values with the column ids: the window descriptor stays in scalar registers)
+  w_issue_cols<SPLIT>(m, tile + (DEPTH - 1) * stride, t_end, lane, wt_now, far);
+  w_issue_vals<SPLIT>(m, tt, lane, far);   // (values with the column ids: the window descriptor stays in scalar registers)
   if (SPLIT) w_load_dc(x, nxt);   // tile t+1 (descriptor landed): one load instead of eight gathers
   else if (dbg & 32) w_gather_off(nxt);
   else w_gather(wrs, x.hw, nxt);                                           // tile t+1
 
   const int nrows = cur.nrows;                          // wave-uniform; -1: the whole tile is padding
   const unsigned int desc = nrows < 0 ? 0u : cur.meta;
-  const int rf = (int)(desc & 255u);
-  const unsigned int bits = (desc >> 8) & 255u;
-  const unsigned int ys = (desc >> 16) & 255u;
-  const int cc[8] = {cur.c0.x, cur.c0.y, cur.c0.z, cur.c0.w, cur.c1.x, cur.c1.y, cur.c1.z, cur.c1.w};
+  const int rf = SPLIT ? cur.rf : (int)(desc & 255u);
+  const unsigned int bits = SPLIT ? desc & 255u : (desc >> 8) & 255u;
+  const unsigned int ys = SPLIT ? (desc >> 8) & 255u : (desc >> 16) & 255u;
+  int cc[8];
+  if (SPLIT) {
+    // 16-bit ranks -> LDS byte offsets 4 * rank (two VALU per id; the weights sit at LDS address 0)
+    const unsigned int cw[4] = {(unsigned int)cur.c0.x, (unsigned int)cur.c0.y, (unsigned int)cur.c0.z, (unsigned int)cur.c0.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      cc[2 * k] = (int)((cw[k] & 0xffffu) << 2);
+      cc[2 * k + 1] = (int)((cw[k] >> 14) & 0x3fffcu);
+    }
+  } else {
+    cc[0] = cur.c0.x; cc[1] = cur.c0.y; cc[2] = cur.c0.z; cc[3] = cur.c0.w;
+    cc[4] = cur.c1.x; cc[5] = cur.c1.y; cc[6] = cur.c1.z; cc[7] = cur.c1.w;
+  }
   const float vv[8] = {cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w};
   typedef __attribute__((address_space(3))) const float lds_cfloat;
   lds_cfloat* wl3 = (lds_cfloat*)x.wl;
@@ -1234,15 +1276,15 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
   if (tile < t_end) {
     WRegs A, B, C, D;
     WTile wt = w_fetch(tt, tile, t_end);
-    w_issue_cols(m, tile, t_end, lane, wt, A);
-    w_issue_vals(m, tt, lane, A);
+    w_issue_cols<SPLIT>(m, tile, t_end, lane, wt, A);
+    w_issue_vals<SPLIT>(m, tt, lane, A);
     wt = w_fetch(tt, tile + stride, t_end);
-    w_issue_cols(m, tile + stride, t_end, lane, wt, B);
-    w_issue_vals(m, tt, lane, B);
+    w_issue_cols<SPLIT>(m, tile + stride, t_end, lane, wt, B);
+    w_issue_vals<SPLIT>(m, tt, lane, B);
     wt = w_fetch(tt, tile + 2 * stride, t_end);
     if (DEPTH == 4) {
-      w_issue_cols(m, tile + 2 * stride, t_end, lane, wt, C);
-      w_issue_vals(m, tt, lane, C);
+      w_issue_cols<SPLIT>(m, tile + 2 * stride, t_end, lane, wt, C);
+      w_issue_vals<SPLIT>(m, tt, lane, C);
       wt = w_fetch(tt, tile + 3 * stride, t_end);
     }
     if (SPLIT) w_load_dc(x, A);
@@ -1295,6 +1337,59 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
       if (n_all - n_neg - n_pos) atomicAdd(&sc->counts[1], (unsigned long long)(n_all - n_neg - n_pos));  // pred == 0
       if (n_pos) atomicAdd(&sc->counts[2], (unsigned long long)n_pos);                          // pred == -y
     }
+  }
+}
+
+// ---- split layout: a data-dependent bound for the fixed-point scale of the hot gradient tile -------------------
+// The LDS accumulators of dsgd_wseg_kernel are 32-bit; a column's sum over the rows ONE workgroup sees must stay
+// below 2^30.  "rows per workgroup x largest value" (26 K rows -> shift 15) is a crude bound for L2-normalised rows:
+// what actually limits the sum is A = max_column sum_rows |x|.  This kernel runs the launch's own tile -> workgroup
+// assignment once per (ranges, grid) configuration, accumulates ceil(|x| * 2^s0 / vmax2) per column in LDS at the
+// crude-but-safe shift s0 and returns the largest column sum; the host then picks the finest shift s <= 21 with
+// 2^(s - s0) * A + rows <= 2^30 (the `+ rows` covers the half-unit rounding of every contribution).  Whatever
+// subset of rows is active and whatever their signs, no accumulator can pass that bound.
+__global__ void __launch_bounds__(1024) dsgd_wseg_bound_kernel(const long long* __restrict__ hrow_ptr,
+                                                              const unsigned short* __restrict__ hcol16,
+                                                              const float* __restrict__ hval,
+                                                              const WTile* __restrict__ tiles, long long n_tiles,
+                                                              long long n_rows, CsrView mfull,
+                                                              const int* __restrict__ long_rows,
+                                                              const StreamSeg* __restrict__ segs, int hg, float scale0,
+                                                              unsigned int* __restrict__ out_max) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int bl[];
+  __shared__ unsigned int red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int j = tid; j < hg; j += 1024) bl[j] = 0u;
+  __syncthreads();
+  const StreamSeg seg = segs[blockIdx.y];
+  for (long long t = seg.tile_begin + (long long)blockIdx.x * 16; t < seg.tile_end; t += (long long)gridDim.x * 16) {
+    const long long t1 = t + 16 < seg.tile_end ? t + 16 : seg.tile_end;
+    const long long ra = tiles[t].r0, rb = t1 < n_tiles ? (long long)tiles[t1].r0 : n_rows;
+    const long long e0 = hrow_ptr[ra], e1 = hrow_ptr[rb];
+    for (long long e = e0 + tid; e < e1; e += 1024) {
+      const unsigned int q = (unsigned int)ceilf(fabsf(hval[e]) * scale0);
+      if (q) atomicAdd(&bl[hcol16[e]], q);
+    }
+  }
+  // the rows that fit no tile are shared out one wave per row, exactly as the gradient kernel does
+  for (long long t = seg.long_begin + (long long)blockIdx.x * 16 + wave; t < seg.long_end; t += (long long)gridDim.x * 16) {
+    const long long row = long_rows[t];
+    for (long long p = mfull.row_ptr[row] + lane; p < mfull.row_ptr[row + 1]; p += 64) {
+      const int c = mfull.col[p];
+      const unsigned int q = (unsigned int)ceilf(fabsf(mfull.val[p]) * scale0);
+      if (c < hg && q) atomicAdd(&bl[c], q);
+    }
+  }
+  __syncthreads();
+  unsigned int m = 0u;
+  for (int j = tid; j < hg; j += 1024) m = max(m, bl[j]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, off, 64));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < 16; ++i) m = max(m, red[i]);
+    atomicMax(out_max, m);
   }
 }
 
@@ -1357,7 +1452,7 @@ template <bool PACKED>
 __global__ void __launch_bounds__(256) dsgd_split_fill_kernel(CsrView m, int hsplit,
                                                              const long long* __restrict__ hrow_ptr,
                                                              const long long* __restrict__ crow_ptr,
-                                                             int* __restrict__ hcol, float* __restrict__ hval,
+                                                             unsigned short* __restrict__ hcol, float* __restrict__ hval,
                                                              unsigned int* __restrict__ ckey, float* __restrict__ cval,
                                                              int* __restrict__ crow, const int* __restrict__ cbase) {
   const int lane = threadIdx.x & 63;
@@ -1379,7 +1474,7 @@ __global__ void __launch_bounds__(256) dsgd_split_fill_kernel(CsrView m, int hsp
       const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
       if (hot) {
         const long long o = hp + __popcll(mh & below);
-        hcol[o] = c * 4;   // the hot stream carries BYTE offsets into the LDS tiles (no shift in the kernel)
+        hcol[o] = (unsigned short)c;   // the hot stream carries 16-bit ranks (6 bytes per non-zero)
         hval[o] = v;
       }
       if (cold) {
@@ -1590,6 +1685,119 @@ __global__ void __launch_bounds__(256) dsgd_eval_idx_kernel(CsrView m, const flo
 }
 
 // ======================================================================================================
+// Mini-batch engine: ONE workgroup computes a whole mini-batch (gather-dot, gate, batch sum, regularise, update)
+// ======================================================================================================
+// Shared by the persistent lock-free ("Hogwild") kernel and by the small-batch plan kernel (dsgd_plan_kernel): both
+// are LATENCY problems (a batch of 100 rows is 60 KB of CSR), so the work is arranged to put every load of a batch
+// in flight at once and never to touch a row twice:
+//   phase 1  groups of 16 lanes take R rows each; row_ptr/label of all R rows, then the first UNR x 16 non-zeros of
+//            all R rows, then their weights are requested back to back (three dependent round trips per BATCH, not
+//            per row); DPP butterfly, gate; the contributions y*x of active rows -- still in registers -- go to a
+//            fixed-point LDS accumulator (ranks < hl: ds_add_u32, exact, order-independent) or to the workgroup's
+//            private global strip plus an LDS bitmap (the few ranks >= hl);
+//   phase 2  a dense sweep over the LDS accumulators (consecutive lanes = consecutive ranks, so the global updates of
+//            the dense hot head coalesce) and a bitmap walk over the cold strip turn the batch sum into the update.
+//            No second pass over the CSR, no per-row flags.
+// Fixed point: q = round(y*x * 2^shift / vmax2), shift = min(23, 30 - ceil(log2 batch)): a column receives at most
+// one contribution per row, so no 32-bit word can pass 2^30; contributions below half a grid unit vanish (this
+// absorbs the reference's 1e-20 filter on y*x, math/Vec.scala:42 -> math/Sparse.scala:108-118).
+constexpr int BT_G = 16;   // lanes per row
+
+struct BtLds {
+  int* acc;              // hl fixed-point accumulators, zero between batches
+  unsigned int* cbits;   // one bit per rank >= hl: the strip entry was touched by this batch
+  int hl;
+};
+
+// contribution of one non-zero of an active row
+__device__ __forceinline__ void bt_add(const BtLds& L, float* __restrict__ gcold, int c, float xv, float qscale) {
+  if (c < L.hl) {
+    const int q = __float2int_rn(xv * qscale);
+    if (q != 0) atomicAdd(&L.acc[c], q);   // ds_add_u32
+  } else {
+    const float f = filt(xv);
+    if (f != 0.0f) {
+      atomicAdd(&gcold[c - L.hl], f);
+      atomicOr(&L.cbits[(unsigned int)(c - L.hl) >> 5], 1u << ((c - L.hl) & 31));
+    }
+  }
+}
+
+// Phase 1 over the rows row_of(0 .. B-1).  AGENT: weights are read with agent-scope loads (other workgroups update
+// them concurrently: a plain load could be served by a stale L1 line forever).  Returns, on lanes with sub == 0, the
+// number of active rows of the lane's group.  Rows outside [0, n_rows) raise `*bad` and are skipped.
+template <int THREADS, int R, int UNR, bool AGENT, class RowOf>
+__device__ __forceinline__ unsigned int bt_phase1(const CsrView& m, const float* w, const BtLds& L,
+                                                  float* __restrict__ gcold, int B, RowOf row_of, float qscale,
+                                                  int* bad) {
+  constexpr int NG = THREADS / BT_G;
+  const int sub = threadIdx.x % BT_G, gidx = threadIdx.x / BT_G;
+  unsigned int n_act = 0;
+  for (int t0 = 0; t0 < B; t0 += NG * R) {
+    long long st[R], en[R];
+    float y[R];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int t = t0 + r * NG + gidx;
+      ok[r] = t < B;
+      const long long row = ok[r] ? row_of(t) : 0;
+      if (row < 0 || row >= m.n_rows) {
+        if (sub == 0) atomicOr(bad, 1);
+        ok[r] = false;
+      }
+      const long long rr = ok[r] ? row : 0;
+      st[r] = m.row_ptr[rr];
+      en[r] = ok[r] ? m.row_ptr[rr + 1] : st[r];
+      y[r] = (float)m.label[rr];
+    }
+    int c[R][UNR];
+    float v[R][UNR], acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+        const long long p = st[r] + sub + k * BT_G;
+        const bool in = p < en[r];
+        c[r][k] = in ? m.col[p] : -1;
+        v[r][k] = in ? m.val[p] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      acc[r] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+        const int cc = c[r][k] >= 0 ? c[r][k] : 0;
+        const float wv = AGENT ? __hip_atomic_load(const_cast<float*>(&w[cc]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : w[cc];
+        acc[r] += filt(v[r][k] * wv);   // ref: math/Sparse.scala:46 (padding lanes: v == 0)
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {   // rows longer than UNR x 16 non-zeros
+      for (long long p = st[r] + sub + UNR * BT_G; p < en[r]; p += BT_G) {
+        const int cc = m.col[p];
+        const float wv = AGENT ? __hip_atomic_load(const_cast<float*>(&w[cc]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : w[cc];
+        acc[r] += filt(m.val[p] * wv);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float d = group_sum<BT_G>(acc[r]);
+      const bool active = ok[r] && !(y[r] * d < 0.0f);   // ref: core/ml/SparseSVM.scala:27-28
+      if (sub == 0) n_act += active;
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < UNR; ++k)
+          if (c[r][k] >= 0) bt_add(L, gcold, c[r][k], v[r][k] * y[r], qscale);
+        for (long long p = st[r] + sub + UNR * BT_G; p < en[r]; p += BT_G) bt_add(L, gcold, m.col[p], m.val[p] * y[r], qscale);
+      }
+    }
+  }
+  return n_act;
+}
+
+// ======================================================================================================
 // K7: persistent lock-free ("Hogwild") engine -- Slave.asyncTask for many workers sharing ONE w
 // ======================================================================================================
 // ref: core/Slave.scala:79-111 (the loop), :177-185 / core/MasterAsync.scala:164-177 (applying updates),
@@ -1598,18 +1806,25 @@ __global__ void __launch_bounds__(256) dsgd_eval_idx_kernel(CsrView m, const flo
 // subtracts it; with all workers on one GPU the replicas collapse into a single device-resident w that
 // every worker (= workgroup) reads without locks and updates with atomicAdd(w[j], -delta_j).
 // One iteration of a worker:
-//   draw `batch` rows of its assigned range (affine permutation of the range = "shuffle take batch";
-//   batch == 1: one uniform draw) -> gated sub-gradients on whatever w holds right now -> batch sum in
-//   a workgroup-private accumulator (LDS for the hot columns, a private global strip for the cold ones)
-//   -> MEAN over the batch -> support-only regulariser with s = 2*lambda*(w.ds) -> scale by lr ->
-//   atomicAdd into w.  The scalar s is kept up to date incrementally (s -= 2*lambda*sum(delta_j*ds_j))
+//   draw `batch` rows of its assigned range -> gated sub-gradients on whatever w holds right now -> batch sum
+//   (mini-batch engine above) -> MEAN over the batch -> support-only regulariser with s = 2*lambda*(w.ds) -> scale
+//   by lr -> atomicAdd into w.  The scalar s is kept up to date incrementally (s -= 2*lambda*sum(delta_j*ds_j))
 //   instead of re-reducing 47 K products per mini-batch as SparseSVM.regularize does.
+// SAMPLING (deliberate deviation): Slave.scala:87 draws `Random.shuffle(indices) take B`; a
+// device-side Fisher-Yates of a 20,000-row range per mini-batch would cost more than the mini-batch.  The engine
+// draws the affine progression rows (mul * t + off) mod n, t = 0..B-1 with gcd(mul, n) = 1 from a counter-based
+// generator keyed by (seed, worker, iteration): B DISTINCT rows of the range, every row equally likely, replayable
+// on the host (tests/test_gpu_parity.py hog_rows) -- but not the JVM's stream and not a uniform B-subset.
+// batch == 1 is a single uniform draw, as Slave.scala:84.  The wire-level worker (wire.SlaveWorker) replays the JVM
+// generator exactly for hosts that need it.
 struct HogState {
   unsigned long long updates;   // mini-batch updates applied (MasterAsync counts these: MasterAsync.scala:83,171)
   unsigned long long samples;   // rows whose gradient was computed
   unsigned long long active;    // ... of which the gate let through
   float s_reg;                  // 2 * lambda * (w . ds), maintained incrementally
   int done_blocks;
+  int stop;                     // raised by the host (copy on a side stream): workers exit after their mini-batch
+  int err;                      // a sampled row fell outside the data
 };
 
 struct HogArgs {
@@ -1619,11 +1834,12 @@ struct HogArgs {
   float* gcold;                 // n_workers x (dp - hl) private strips, zero between iterations
   const long long* asg_begin;
   const long long* asg_end;
+  unsigned long long* it;       // per worker: iterations done so far (continues across exchange rounds)
   HogState* st;
-  const volatile int* stop;     // host-mapped flag
   long long max_updates;
   unsigned long long seed;
   float lr, lambda;
+  float qscale, inv_qscale;     // 2^shift / vmax2 and its inverse
   int batch, positional_bug, hl, dp;
 };
 
@@ -1633,123 +1849,356 @@ __device__ __forceinline__ unsigned long long hog_mix(unsigned long long z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-__device__ __forceinline__ long long hog_gcd(long long a, long long b) {
+__device__ __forceinline__ unsigned int hog_gcd32(unsigned int a, unsigned int b) {
   while (b) {
-    const long long t = a % b;
+    const unsigned int t = a % b;
     a = b;
     b = t;
   }
   return a;
 }
 
-constexpr int HOG_THREADS = 512;
-constexpr int HOG_G = 16;
+constexpr int HOG_THREADS = 512;   // 2 waves per SIMD: leaves registers and LDS for the master's concurrent loss check
 constexpr int HOG_MAX_BATCH = 4096;
+constexpr int HOG_HL = 24576;      // ranks with an LDS accumulator (96 KiB; + 32 KiB of dsgd_eval_kernel still fit a CU)
+
+struct HogCtl {
+  int stop;
+  unsigned int mul, off;
+  float s;
+};
 
 __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* gl = lds;                                                  // hl hot accumulators
-  unsigned char* act = reinterpret_cast<unsigned char*>(lds + a.hl);  // HOG_MAX_BATCH gate flags
-  float* red = lds + a.hl + HOG_MAX_BATCH / 4;                      // 16 floats + control words
-  int* ctl = reinterpret_cast<int*>(red + 16);
-  const int tid = threadIdx.x, sub = tid % HOG_G, gidx = tid / HOG_G;
-  constexpr int NG = HOG_THREADS / HOG_G;
+  BtLds L;
+  L.hl = a.hl;
+  L.acc = reinterpret_cast<int*>(lds);
+  const int n_cw = (a.dp - a.hl + 31) / 32;                  // bitmap words of the cold strip (0 when dp <= hl)
+  L.cbits = reinterpret_cast<unsigned int*>(lds + a.hl);
+  float* red = lds + a.hl + n_cw;                            // 8 floats + 8 ints + control
+  unsigned int* redn = reinterpret_cast<unsigned int*>(red + 8);
+  HogCtl* ctl = reinterpret_cast<HogCtl*>(red + 16);
+  const int tid = threadIdx.x;
   const int worker = blockIdx.x;
-  const long long begin = a.asg_begin[worker], n_k = a.asg_end[worker] - begin;
+  const long long begin = a.asg_begin[worker];
+  const unsigned int n_k = (unsigned int)(a.asg_end[worker] - begin);   // < 2^31 rows per context
   const long long base = a.positional_bug ? 0 : begin;   // ref: core/Slave.scala:87 indexes `data` by POSITION
-  float* gc = a.gcold + (long long)worker * (a.dp - a.hl);
-  for (int j = tid; j < a.hl; j += HOG_THREADS) gl[j] = 0.0f;
-  __syncthreads();
+  const double inv_n = 1.0 / (double)n_k;
+  float* gc = a.gcold + (long long)worker * (a.dp > a.hl ? a.dp - a.hl : 1);
+  for (int j = tid; j < a.hl + n_cw; j += HOG_THREADS) L.acc[j] = 0;   // accumulators and bitmap
   const int B = a.batch;
-  const float inv_b = 1.0f / (float)B;  // exact for the usual powers of two; Vec.mean divides (math/Vec.scala:139)
-  unsigned long long it = 0;
+  const float fB = (float)B;
+  unsigned long long it = a.it[worker];
+  // thread 0 carries the shared scalars between iterations: what its own returning atomics saw
+  unsigned long long u = 0;
+  float s = 0.0f;
+  int stop = 0;
+  if (tid == 0) {
+    u = __hip_atomic_load(&a.st->updates, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s = __hip_atomic_load(&a.st->s_reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stop = __hip_atomic_load(&a.st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   for (;;) {
     if (tid == 0) {
-      const unsigned long long u = *reinterpret_cast<volatile unsigned long long*>(&a.st->updates);
-      ctl[0] = (*a.stop != 0) || ((long long)u >= a.max_updates);
+      ctl->stop = stop != 0 || (long long)u >= a.max_updates;
+      // this iteration's sample: rows base + (mul * t + off) mod n_k, t = 0..B-1 (distinct rows)
+      const unsigned long long key = hog_mix(a.seed ^ hog_mix((unsigned long long)worker * 0x100000001B3ull + it));
+      unsigned int mul = 1u + (unsigned int)(hog_mix(key) % (unsigned long long)n_k);
+      while (hog_gcd32(mul, n_k) != 1u) mul = mul % n_k + 1u;
+      ctl->mul = mul;
+      ctl->off = (unsigned int)(hog_mix(key ^ 0xABCDEF12345ull) % (unsigned long long)n_k);
+      ctl->s = s;
     }
     __syncthreads();
-    if (ctl[0]) break;
-    const float s = *reinterpret_cast<volatile float*>(&a.st->s_reg);
-    const bool add_s = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
-    // this iteration's sample: rows base + (mul * t + off) mod n_k, t = 0..B-1 (distinct rows)
-    const unsigned long long key = hog_mix(a.seed ^ hog_mix((unsigned long long)worker * 0x100000001B3ull + it));
-    long long mul = 1 + (long long)(hog_mix(key) % (unsigned long long)n_k);
-    while (hog_gcd(mul, n_k) != 1) mul = mul % n_k + 1;
-    const long long off = (long long)(hog_mix(key ^ 0xABCDEF12345ull) % (unsigned long long)n_k);
-    unsigned int n_act = 0;
+    if (ctl->stop) break;
+    const unsigned long long mul = ctl->mul, off = ctl->off;
+    const float s_it = ctl->s;
+    const bool add_s = (s_it != 0.0f) && (fabsf(s_it) > DSGD_EPS);
     // phase 1: gated sub-gradient sum of the batch (ref: core/Slave.scala:93-98)
-    for (int t = gidx; t < B; t += NG) {
-      const long long row = base + (long long)(((unsigned long long)mul * (unsigned long long)t + (unsigned long long)off) % (unsigned long long)n_k);
-      const long long start = a.m.row_ptr[row], end = a.m.row_ptr[row + 1];
-      const float y = (float)a.m.label[row];
-      float acc = 0.0f;
-      // agent-scope loads: another CU's atomics must become visible (a plain load may hit a stale L1 line forever)
-      for (long long p = start + sub; p < end; p += HOG_G)
-        acc += filt(a.m.val[p] * __hip_atomic_load(&a.w[a.m.col[p]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      const float d = group_sum<HOG_G>(acc);
-      const bool active = !(y * d < 0.0f);
-      if (sub == 0) {
-        act[t] = active ? 1 : 0;
-        n_act += active;
-      }
-      if (active)
-        for (long long p = start + sub; p < end; p += HOG_G) {
-          const int c = a.m.col[p];
-          const float xv = filt(a.m.val[p] * y);
-          if (xv != 0.0f) {
-            if (c < a.hl) atomicAdd(&gl[c], xv);
-            else atomicAdd(&gc[c - a.hl], xv);
-          }
-        }
-    }
-    __threadfence_block();
+    auto row_of = [&](int t) -> long long {
+      const unsigned long long x = mul * (unsigned long long)t + off;          // < 2^44: exact in a double
+      long long r = (long long)x - (long long)((unsigned long long)((double)x * inv_n)) * (long long)n_k;
+      if (r < 0) r += n_k;
+      if (r >= (long long)n_k) r -= n_k;
+      return base + r;
+    };
+    unsigned int n_act = bt_phase1<HOG_THREADS, 4, 6, true>(a.m, a.w, L, gc, B, row_of, a.qscale, &a.st->err);
     __syncthreads();
     // phase 2: mean, regularise on the support, scale, subtract from the shared w (ref: Slave.scala:98-101)
     float ds_acc = 0.0f;
-    for (int t = gidx; t < B; t += NG) {
-      if (!act[t]) continue;
-      const long long row = base + (long long)(((unsigned long long)mul * (unsigned long long)t + (unsigned long long)off) % (unsigned long long)n_k);
-      const long long start = a.m.row_ptr[row], end = a.m.row_ptr[row + 1];
-      for (long long p = start + sub; p < end; p += HOG_G) {
-        const int c = a.m.col[p];
-        // take-and-clear: the first lane to reach column c gets the whole batch sum, the others get 0
-        const float v = c < a.hl ? atomicExch(&gl[c], 0.0f) : atomicExch(&gc[c - a.hl], 0.0f);
-        if (fabsf(v) > DSGD_EPS) {
-          float g = filt(v * inv_b);
-          if (add_s) g = filt(g + s);
-          const float delta = filt(g * a.lr);
-          if (delta != 0.0f) {
-            atomicAdd(&a.w[c], -delta);   // lock-free update of the ONE weight vector
-            ds_acc += delta * a.ds[c];
-          }
+    for (int j0 = 0; j0 < a.hl; j0 += HOG_THREADS * 4) {
+      int q[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = j0 + e * HOG_THREADS + tid;
+        q[e] = j < a.hl ? L.acc[j] : 0;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (q[e] == 0) continue;
+        const int j = j0 + e * HOG_THREADS + tid;
+        L.acc[j] = 0;
+        float g = filt(((float)q[e] * a.inv_qscale) / fB);   // Vec.mean divides (ref: math/Vec.scala:139)
+        if (g == 0.0f) continue;
+        if (add_s) g = filt(g + s_it);
+        const float delta = filt(g * a.lr);
+        if (delta != 0.0f) {
+          atomicAdd(&a.w[j], -delta);   // lock-free update of the ONE weight vector
+          ds_acc += delta * a.ds[j];
         }
       }
     }
-    // one atomic per workgroup for the incremental regulariser scalar and the counters
+    for (int wd = tid; wd < n_cw; wd += HOG_THREADS) {
+      unsigned int bits = L.cbits[wd];
+      if (!bits) continue;
+      L.cbits[wd] = 0u;
+      while (bits) {
+        const int b = __builtin_ctz(bits);
+        bits &= bits - 1u;
+        const int jc = wd * 32 + b;
+        const float v = atomicExch(&gc[jc], 0.0f);   // take-and-clear the private strip entry
+        float g = filt(v / fB);
+        if (g == 0.0f) continue;
+        if (add_s) g = filt(g + s_it);
+        const float delta = filt(g * a.lr);
+        if (delta != 0.0f) {
+          atomicAdd(&a.w[a.hl + jc], -delta);
+          ds_acc += delta * a.ds[a.hl + jc];
+        }
+      }
+    }
+    // one returning atomic per workgroup for the incremental regulariser scalar and the update counter: thread 0
+    // continues with what they saw (no separate loads of the shared scalars in the next iteration)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) ds_acc += __shfl_xor(ds_acc, o, 64);
     n_act = wave_sum_u32(n_act);
     if ((tid & 63) == 0) {
       red[tid >> 6] = ds_acc;
-      ctl[2 + (tid >> 6)] = (int)n_act;
+      redn[tid >> 6] = n_act;
     }
     __syncthreads();
     if (tid == 0) {
       float tot = 0.0f;
-      int na = 0;
+      unsigned int na = 0;
       for (int i = 0; i < HOG_THREADS / 64; ++i) {
         tot += red[i];
-        na += ctl[2 + i];
+        na += redn[i];
       }
-      if (tot != 0.0f) atomicAdd(&a.st->s_reg, -2.0f * a.lambda * tot);
-      atomicAdd(&a.st->updates, 1ull);
+      const float ds_term = -2.0f * a.lambda * tot;
+      s = atomicAdd(&a.st->s_reg, ds_term) + ds_term;
+      u = atomicAdd(&a.st->updates, 1ull) + 1ull;
       atomicAdd(&a.st->samples, (unsigned long long)B);
       atomicAdd(&a.st->active, (unsigned long long)na);
+      stop = __hip_atomic_load(&a.st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     ++it;
-    __syncthreads();
   }
-  if (tid == 0) atomicAdd(&a.st->done_blocks, 1);
+  if (tid == 0) {
+    a.it[worker] = it;
+    atomicAdd(&a.st->done_blocks, 1);
+  }
 }
 
+// ---- cross-GPU asynchronous mode: replicas + periodic exchange of the summed updates ---------------------------
+// ref: core/Slave.scala:103-105 (every update is gossiped to every peer), :177-185 (a peer subtracts it),
+// core/MasterAsync.scala:164-177.  One single-w engine per GPU; every `exchange_every` local updates the replicas
+// all-reduce what each subtracted since the last exchange and subtract the PEERS' part on top of their own.
+__global__ void __launch_bounds__(1024) dsgd_exchange_delta_kernel(const float* __restrict__ w,
+                                                                  const float* __restrict__ wprev,
+                                                                  float* __restrict__ dsum, float* __restrict__ dlocal,
+                                                                  int dp) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) {
+    const float d = wprev[j] - w[j];
+    dsum[j] = d;     // all-reduced in place by the caller
+    dlocal[j] = d;
+  }
+}
+// w <- w - (dsum - dlocal); s <- s - 2*lambda*sum((dsum - dlocal) * ds); wprev <- w.  One workgroup (fixed-order sum).
+__global__ void __launch_bounds__(1024) dsgd_exchange_apply_kernel(float* __restrict__ w, float* __restrict__ wprev,
+                                                                  const float* __restrict__ dsum,
+                                                                  const float* __restrict__ dlocal,
+                                                                  const float* __restrict__ ds, int dp, float lambda,
+                                                                  HogState* st) {
+  __shared__ float red[16];
+  float acc = 0.0f;
+  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
+    const float o = dsum[j] - dlocal[j];   // exactly 0 with a single rank: the replica keeps its own weights bit for bit
+    float wn = w[j];
+    if (o != 0.0f) {
+      wn = filt(wn - o);
+      w[j] = wn;
+      acc += o * ds[j];
+    }
+    wprev[j] = wn;
+  }
+  const float tot = block_sum_1024(acc, red);
+  if (threadIdx.x == 0 && tot != 0.0f) st->s_reg += -2.0f * lambda * tot;
+}
+
+// ======================================================================================================
+// K1p: small-batch synchronous steps (the reference's batch-size 100-200) as ONE persistent workgroup
+// ======================================================================================================
+// ref: core/Master.scala:179-199 (the batch closure), core/Slave.scala:142-157, application.conf:15 (batch-size 100).
+// A B = 100 step is 60 KB of CSR: as separate launches (gradient rows -> regularise -> sum -> ticketed apply) it
+// took 31-41 us, all of it dependent-launch and cross-workgroup latency (profiles/README.md: a hipGraph of the same
+// chain changed nothing).  Here ONE 1024-lane workgroup runs the steps [step_begin, step_end) of a resident plan
+// back to back with nothing but workgroup barriers in between:
+//   per worker k:  mini-batch engine phase 1 on the worker's index list (snapshot of w), then the sweep turns the
+//                  fixed-point batch sum into g_k = regularize(sum, w) on its support (SparseSVM.scala:31) and either
+//                  applies it (one hosted worker) or adds it to `upd` in worker order (Vec.sum folds left);
+//   then           w <- w - lr * (upd / K) on the union of the supports (Vec.mean, Master.scala:194-197).
+// The regulariser scalar s = 2*lambda*(w . ds) is computed exactly (fp64, all D+1 products) when the launch starts
+// and then carried in fp64 through the updates of the touched coordinates -- closer to the fp64 reference than the
+// fp32 re-reduction of the multi-launch path, and no 47 K-element pass per step.
+// The gradient is deterministic: integer accumulation, fixed sweep order (the multi-launch path used fp32 L2
+// atomics in arrival order).
+struct PlanArgs {
+  CsrView m;
+  float* w;
+  const float* ds;
+  float* gcold;              // dp - hl floats, zero between batches
+  float* upd;                // MULTI: dp floats, zero between steps
+  const int* idx;
+  const WorkSeg* segs;       // n_steps x n_workers
+  DevScalars* sc;
+  long long step_begin, step_end;
+  float k_total, lr, lambda;
+  float inv_vmax2;           // 2^-vexp
+  int vexp, n_workers, hl, dp;
+};
+
+constexpr int PLAN_THREADS = 1024;
+constexpr int PLAN_HD = 4096;    // MULTI: ranks below this are swept densely in the final apply, the rest via a bitmap
+
+__device__ __forceinline__ double block_sum_f64(double v, double* red /* 16 doubles of LDS */) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+  return t;
+}
+
+template <bool MULTI>
+__global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  BtLds L;
+  L.hl = a.hl;
+  L.acc = reinterpret_cast<int*>(lds);
+  const int n_cw = (a.dp - a.hl + 31) / 32;
+  const int n_uw = MULTI ? (a.dp + 31) / 32 : 0;
+  L.cbits = reinterpret_cast<unsigned int*>(lds + a.hl);
+  unsigned int* ubits = L.cbits + n_cw;                                  // MULTI: touched coordinates of `upd`
+  double* red = reinterpret_cast<double*>(lds + ((a.hl + n_cw + n_uw + 1) & ~1));   // 16 doubles
+  const int tid = threadIdx.x;
+  for (int j = tid; j < a.hl + n_cw + n_uw; j += PLAN_THREADS) L.acc[j] = 0;
+  // exact w . ds of the weights this launch starts from
+  double dot_part = 0.0;
+  for (int j = tid; j < a.dp; j += PLAN_THREADS) dot_part += (double)a.w[j] * (double)a.ds[j];
+  double dot = block_sum_f64(dot_part, red);   // (also the barrier behind the LDS zeroing)
+  unsigned long long n_act_total = 0;
+
+  // w[j] <- w[j] - lr * (gsum / K); returns the change of w[j] * ds[j]
+  auto apply = [&](int j, float gsum) -> double {
+    const float mean = filt(gsum / a.k_total);   // Vec.mean (ref: math/Vec.scala:139)
+    const float updv = filt(mean * a.lr);        // learningRate * grad (ref: core/Master.scala:197)
+    if (updv == 0.0f) return 0.0;
+    const float wo = a.w[j];
+    const float wn = filt(wo - updv);
+    a.w[j] = wn;
+    return ((double)wn - (double)wo) * (double)a.ds[j];
+  };
+
+  for (long long step = a.step_begin; step < a.step_end; ++step) {
+    const float s = (float)(2.0 * (double)a.lambda * dot);   // thread-uniform: every thread carries the same dot
+    const bool add_s = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+    double ddot = 0.0;
+    unsigned int n_act = 0;
+    for (int k = 0; k < a.n_workers; ++k) {
+      const WorkSeg seg = a.segs[step * a.n_workers + k];
+      const int B = (int)(seg.end - seg.begin);
+      int bits = 0;
+      while ((1 << bits) < B) ++bits;
+      const int shift = min(23, 30 - bits);
+      const float qscale = ldexpf(1.0f, shift - a.vexp), inv_qscale = ldexpf(1.0f, a.vexp - shift);
+      const int* __restrict__ list = a.idx + seg.begin;
+      auto row_of = [&](int t) -> long long { return (long long)list[t]; };
+      n_act += bt_phase1<PLAN_THREADS, 2, 8, false>(a.m, a.w, L, a.gcold, B, row_of, qscale, &a.sc->err);
+      __syncthreads();
+      // sweep: this worker's regularised sum on its support
+      for (int j0 = 0; j0 < a.hl; j0 += PLAN_THREADS * 4) {
+        int q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = j0 + e * PLAN_THREADS + tid;
+          q[e] = j < a.hl ? L.acc[j] : 0;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (q[e] == 0) continue;
+          const int j = j0 + e * PLAN_THREADS + tid;
+          L.acc[j] = 0;
+          float g = filt((float)q[e] * inv_qscale);            // Vec.sum of the batch (ref: core/Slave.scala:153)
+          if (g == 0.0f) continue;
+          if (add_s) g = filt(g + s);                          // ref: core/ml/SparseSVM.scala:31, math/Vec.scala:65-75
+          if (MULTI) {
+            a.upd[j] = filt(a.upd[j] + g);
+            if (j >= PLAN_HD) atomicOr(&ubits[j >> 5], 1u << (j & 31));
+          } else {
+            ddot += apply(j, g);
+          }
+        }
+      }
+      for (int wd = tid; wd < n_cw; wd += PLAN_THREADS) {
+        unsigned int cb = L.cbits[wd];
+        if (!cb) continue;
+        L.cbits[wd] = 0u;
+        while (cb) {
+          const int b = __builtin_ctz(cb);
+          cb &= cb - 1u;
+          const int jc = wd * 32 + b, j = a.hl + jc;
+          float g = filt(atomicExch(&a.gcold[jc], 0.0f));   // (written with L2 atomics: read it there, not through L1)
+          if (g == 0.0f) continue;
+          if (add_s) g = filt(g + s);
+          if (MULTI) {
+            a.upd[j] = filt(a.upd[j] + g);
+            atomicOr(&ubits[j >> 5], 1u << (j & 31));
+          } else {
+            ddot += apply(j, g);
+          }
+        }
+      }
+      __syncthreads();   // accumulators are clean (and, MULTI, upd is written) before the next worker's phase 1
+    }
+    if (MULTI) {
+      // mean over the workers and the update, on the union of the supports
+      for (int j = tid; j < min(PLAN_HD, a.dp); j += PLAN_THREADS) {
+        const float u = a.upd[j];
+        if (u != 0.0f) {
+          a.upd[j] = 0.0f;
+          ddot += apply(j, u);
+        }
+      }
+      for (int wd = PLAN_HD / 32 + tid; wd < n_uw; wd += PLAN_THREADS) {
+        unsigned int ub = ubits[wd];
+        if (!ub) continue;
+        ubits[wd] = 0u;
+        while (ub) {
+          const int j = wd * 32 + __builtin_ctz(ub);
+          ub &= ub - 1u;
+          const float u = a.upd[j];
+          a.upd[j] = 0.0f;
+          ddot += apply(j, u);
+        }
+      }
+    }
+    dot += block_sum_f64(ddot, red);   // every thread adds the same total: `dot` stays thread-uniform
+    n_act_total += n_act;
+    // (block_sum_f64's barriers also order this step's writes of w before the next step's reads)
+  }
+  n_act_total = (unsigned long long)wave_sum_u32((unsigned int)n_act_total);
+  if ((tid & 63) == 0 && n_act_total) atomicAdd(&a.sc->n_active, n_act_total);
+  if (tid == 0) a.sc->s_reg = (float)(2.0 * (double)a.lambda * dot);
+}

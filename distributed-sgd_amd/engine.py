@@ -180,6 +180,10 @@ class Engine:
         check(self._lib.dsgd_async_start(self._ctx, rb, re_, C.c_int32(k), C.c_int32(batch), C.c_float(lr),
                                          C.c_int64(max_updates), C.c_uint64(seed), C.c_int32(1 if positional_bug else 0)))
 
+    def async_set_exchange(self, every_updates):
+        """Cross-GPU asynchronous mode: exchange the summed updates every `every_updates` local updates (0 = off)."""
+        check(self._lib.dsgd_async_set_exchange(self._ctx, C.c_int64(every_updates)))
+
     def async_updates(self):
         n, running = C.c_int64(0), C.c_int32(0)
         check(self._lib.dsgd_async_updates(self._ctx, C.byref(n), C.byref(running)))
@@ -227,6 +231,11 @@ class Engine:
         a, b = C.c_int64(), C.c_int64()
         check(self._lib.dsgd_range_nnz(self._ctx, C.c_int64(row_begin), C.c_int64(row_end), C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def tuning_info(self):
+        v = (C.c_int32 * 6)()
+        check(self._lib.dsgd_tuning_info(self._ctx, v, C.c_int32(6)))
+        return dict(zip(("stream_mode", "hsplit", "fix_shift", "cold_packed", "plan_kernel", "fix_bound"), [int(x) for x in v]))
 
     def grad_kernel_name(self):
         return self._lib.dsgd_grad_kernel_name(self._ctx).decode()

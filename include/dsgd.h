@@ -52,7 +52,6 @@ enum {
 
 /* dsgd_config.flags */
 #define DSGD_F_DEFAULT 0u
-#define DSGD_F_NO_GRAPH 1u /* reserved: small-batch steps measured execution-bound, no graphs used  */
 #define DSGD_F_FORCE_TILED 2u /* always use the LDS-tiled gradient kernel (tests / tuning)        */
 #define DSGD_F_FORCE_ROWS 4u  /* always use the direct-to-L2 gradient kernel (tests / tuning)      */
 
@@ -176,6 +175,13 @@ int dsgd_update_grad(dsgd_ctx* ctx, const int32_t* key, const float* dv, int64_t
 int dsgd_async_start(dsgd_ctx* ctx, const int64_t* assigned_begin, const int64_t* assigned_end, int32_t n_workers,
                      int32_t batch, float lr, int64_t max_updates, uint64_t seed, int32_t positional_bug);
 int dsgd_async_updates(dsgd_ctx* ctx, int64_t* updates, int32_t* running);
+/* Asynchronous mode ACROSS GPUs: with a communicator attached, every context runs its own
+ * single-w engine on its own rows and the replicas exchange updates every `every_updates` LOCAL mini-batch updates:
+ * one all-reduce of what each replica subtracted since the last exchange, after which every replica subtracts its
+ * peers' part -- the batched form of the reference's gossip (core/Slave.scala:103-105 sends every update to every
+ * peer, :177-185 / core/MasterAsync.scala:164-177 subtract it).  0 (default) = no exchange.  Every rank must use
+ * the same period and the same finite max_updates (the ranks enqueue the same number of collectives).            */
+int dsgd_async_set_exchange(dsgd_ctx* ctx, int64_t every_updates);
 int dsgd_async_stop(dsgd_ctx* ctx); /* SlaveImpl.stopAsync, core/Slave.scala:187-195 */
 int dsgd_async_wait(dsgd_ctx* ctx); /* block until max_updates reached */
 
@@ -202,6 +208,12 @@ int dsgd_prof_read_kinds(dsgd_ctx* ctx, double* ms_avg3, int64_t* n_launches3);
  * them live in the cold stream of the split layout (0 in the other layouts).  Used by bench.py to attribute the
  * algorithmic bytes of a step to the kernel that reads them.  Nothing in the reference. */
 int dsgd_range_nnz(dsgd_ctx* ctx, int64_t row_begin, int64_t row_end, int64_t* nnz, int64_t* cold_nnz);
+
+/* Tuning state that changes numerics or layout, for benchmark records: vals[0] = streaming layout (DSGD_STREAM),
+ * [1] = hot/cold split rank, [2] = fixed-point shift of the last whole-range gradient launch, [3] = 1 if the cold
+ * stream is packed, [4] = 1 if small batches run in the persistent plan kernel, [5] = 1 if the data-dependent
+ * fixed-point bound is enabled.  n = number of slots the caller provides (<= 6).                                  */
+int dsgd_tuning_info(dsgd_ctx* ctx, int32_t* vals, int32_t n);
 
 /* name of the gradient kernel variant in use (for matching rocprofv3 kernel-trace rows)        */
 const char* dsgd_grad_kernel_name(dsgd_ctx* ctx);

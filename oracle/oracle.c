@@ -292,6 +292,29 @@ int orc_gradient_range_omp(const orc_csr* m, const double* w, const double* ds, 
   return 0;
 }
 
+/* Gate profile of a row range for the derived parity bound of the whole-shard tests: rows whose fp64 margin is
+ * within eps of zero (but not exactly zero: an exact zero -- e.g. w = 0, or no common key -- is exactly zero in
+ * fp32 too) may be gated differently by an fp32 implementation.  near_l1[j] = sum over those rows of |x_j|: the
+ * most coordinate j of the gated sum (core/Slave.scala:147-153) can move if every one of them flips. */
+int orc_range_gate_profile(const orc_csr* m, const double* w, int64_t row_begin, int64_t row_end, double eps,
+                           int64_t* n_near_out, double* near_l1 /* dim+1, accumulated into */) {
+  if (row_end <= row_begin || row_begin < 0 || row_end > m->n_rows) return -1;
+  int64_t n_near = 0;
+#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : n_near)
+  for (int64_t i = row_begin; i < row_end; ++i) {
+    double d = orc_row_dot(m, i, w);
+    if (d != 0.0 && fabs(d) < eps) {
+      n_near++;
+      for (int64_t p = m->row_ptr[i]; p < m->row_ptr[i + 1]; ++p) {
+#pragma omp atomic
+        near_l1[m->col[p]] += fabs((double)m->val[p]);
+      }
+    }
+  }
+  if (n_near_out) *n_near_out = n_near;
+  return 0;
+}
+
 /* one whole-shard synchronous step with K=1 worker on all cores (bench cpu_baseline leg) */
 int orc_sync_step_range_omp(const orc_csr* m, double* w, const double* ds, double lambda, int64_t row_begin,
                             int64_t row_end, double lr, int64_t* n_active_out) {

@@ -131,6 +131,15 @@ class Oracle:
         _check(rc)
         return n_active.value
 
+    def gate_profile(self, w, row_begin, row_end, eps=1e-5):
+        """(rows with 0 < |x.w| < eps, per-coordinate sum of |x_j| over those rows): see orc_range_gate_profile."""
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        near = np.zeros(self.dim + 1, dtype=np.float64)
+        n = C.c_int64(0)
+        _check(lib().orc_range_gate_profile(C.byref(self._csr), _p(w), C.c_int64(row_begin), C.c_int64(row_end),
+                                            C.c_double(eps), C.byref(n), _p(near)))
+        return n.value, near
+
     def gradient_range_omp(self, w, row_begin, row_end):
         w = np.ascontiguousarray(w, dtype=np.float64)
         g = np.zeros(self.dim + 1, dtype=np.float64)

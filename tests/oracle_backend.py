@@ -12,6 +12,8 @@ class OracleBackend:
         self.lam = oracle.lam
         self.w = np.zeros(oracle.dim + 1)
         self.steps = []
+        self.min_margins = []
+        self.actives = []
         self.mu = threading.Lock()  # the engine serialises calls on a context; handlers arrive from 8 pool threads
 
     def gradient(self, idx, w=None):
@@ -45,6 +47,10 @@ class OracleBackend:
     def sync_step(self, lists, lr):
         self.steps.append([len(a) for a in lists])
         self.o.sync_step(self.w, lists, lr)
+        # flip accounting for engine-vs-oracle runs: a step is "exposed" when some row's fp64 margin is within fp32
+        # round-off of the gate (core/ml/SparseSVM.scala:27-28) -- only then may an fp32 engine gate a row differently
+        self.min_margins.append(self.o.last_stats["min_abs_margin"])
+        self.actives.append(self.o.last_stats["n_active"])
         return {"n_samples": sum(len(a) for a in lists), "n_active": self.o.last_stats["n_active"]}
 
     def loss_acc(self, lo, hi):

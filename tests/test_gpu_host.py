@@ -13,27 +13,58 @@ from oracle_backend import OracleBackend
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="no gfx950 device")]
 
 
+class CountingEngine:
+    """The engine behind the backend interface, recording the active-row count of every step."""
+
+    def __init__(self, eng):
+        self.eng, self.actives = eng, []
+
+    def sync_step(self, lists, lr):
+        st = self.eng.sync_step(lists, lr)
+        self.actives.append(st["n_active"])
+        return st
+
+    def __getattr__(self, name):
+        return getattr(self.eng, name)
+
+
 def test_master_sync_fit_engine_vs_oracle():
+    """host.MasterSync.fit (epochs, per-batch reshuffle with the java.util.Random stream, evaluation, early stopping)
+    over the HIP engine against the same mirror over the oracle.  Flip accounting as in test_gpu_parity.run_sync: the
+    tight bound is waived only for a run in which the ORACLE saw a margin within 1e-5 of the gate; otherwise the
+    active-row count of every step and the final weights must agree."""
     n_rows = 5000
     data = dsgd_amd.synth.generate(n_rows, seed=41)
     n_train = int(n_rows * 0.8)
     o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, 1e-5)
     o.set_dim_sparsity(o.dim_sparsity(n_train))
-    ref = host.MasterSync(OracleBackend(o), n_train, n_rows, node_count=3, rnd=host.JavaRandom(0))
+    ob = OracleBackend(o)
+    ref = host.MasterSync(ob, n_train, n_rows, node_count=3, rnd=host.JavaRandom(0))
     s_ref = ref.fit(np.zeros(data.dim + 1), 2, 100, 0.5, host.EarlyStopping.no_improvement(5, 0.01))
     with dsgd_amd.Engine(data.dim, 1e-5) as eng:
         eng.load_csr(data.row_ptr, data.col, data.val, data.label)
         eng.build_dim_sparsity(n_train)
-        m = host.MasterSync(eng, n_train, n_rows, node_count=3, rnd=host.JavaRandom(0))
+        ce = CountingEngine(eng)
+        m = host.MasterSync(ce, n_train, n_rows, node_count=3, rnd=host.JavaRandom(0))
         s = m.fit(np.zeros(data.dim + 1), 2, 100, 0.5, host.EarlyStopping.no_improvement(5, 0.01))
     assert s.updates == s_ref.updates == 2
+    assert len(ce.actives) == len(ob.actives) == 28  # 2 epochs x ceil(ceil(4000/3)/100) batches of 3 x 100
+    exposed = [i for i, mm in enumerate(ob.min_margins) if mm < 1e-5]
+    first_diff = next((i for i, (a, b) in enumerate(zip(ce.actives, ob.actives)) if a != b), None)
+    if first_diff is not None:
+        # a differing gate decision is legitimate only at (or after) a step the oracle flagged
+        assert exposed and exposed[0] <= first_diff, (first_diff, exposed, ce.actives, ob.actives)
     scale = max(1.0, np.abs(s_ref.grad).max())
     err = np.abs(s.grad.astype(np.float64) - s_ref.grad).max()
-    # 28 steps of batch 3 x 100; a gate flip (|x.w| within fp32 round-off of 0) would show as an O(lr) difference
-    assert err <= 1e-4 * scale or err > 1e-2, err
-    if err <= 1e-4 * scale:
-        assert abs(m.test_accs[0] - ref.test_accs[0]) < 5e-3
-        assert abs(m.test_losses[0] - ref.test_losses[0]) < 5e-3
+    if not exposed:
+        assert ce.actives == ob.actives
+        assert err <= 1e-5 * scale, err            # the stated tolerance (test_gpu_parity.py), 28 steps
+        assert abs(m.test_accs[0] - ref.test_accs[0]) <= 1.0 / (n_rows - n_train) + 1e-12
+        assert abs(m.test_losses[0] - ref.test_losses[0]) <= 2.0 / (n_rows - n_train) + 1e-6
+    else:
+        # a flipped row moves the weights by lr * y * x / K once; the runs stay close but not within round-off
+        assert err <= 0.5 * len(exposed) + 1e-5 * scale, (err, exposed)
+        assert abs(m.test_accs[0] - ref.test_accs[0]) < 2e-2
 
 
 def test_master_async_fit_runs_and_stops():

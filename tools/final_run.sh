@@ -9,11 +9,11 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 { nproc; lscpu | grep -E "Model name|Socket|Thread|Core"; rocm-smi --showproductname 2>/dev/null | head -8; } > $OUT/env.txt 2>&1
 echo "== pytest -m gpu"
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -6 | tee $OUT/pytest_gpu.txt
+timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -40 | tee $OUT/pytest_gpu.txt
 echo "== bench (default flags)"
 timeout 900 python bench.py 2> $OUT/bench.err > $OUT/bench.json; tail -3 $OUT/bench.err; cut -c1-400 $OUT/bench.json
 echo "== rocprofv3 kernel trace"
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sweep > $OUT/bench_prof.json 2> $OUT/bench_prof.err )
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sweep --no-parity-gate > $OUT/bench_prof.json 2> $OUT/bench_prof.err )
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv && head -8 "$f" | cut -c1-160
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE"; do
