@@ -231,6 +231,7 @@ struct dsgd_ctx {
   unsigned long long* d_hog_it = nullptr;   // per worker: iterations done (continues across exchange rounds)
   int* h_one = nullptr;        // pinned constant 1: source of the stop-flag copy
   // small-batch plan kernel (one persistent workgroup): cold strip and the multi-worker sum buffer
+  unsigned long long* d_tprof = nullptr;   // DSGD_PLAN_PROF=1: phase cycle counters of dsgd_plan_kernel (tuning runs)
   float* d_plan_gcold = nullptr;
   float* d_plan_upd = nullptr;
   bool plan_kernel = true;     // DSGD_PLAN_KERNEL=0: the multi-launch small-batch path
@@ -1036,7 +1037,7 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
       if (!hit) {
         if (!c->d_bound) HIP_TRY(hipMalloc(&c->d_bound, sizeof(unsigned int)));
         HIP_TRY(hipMemsetAsync(c->d_bound, 0, sizeof(unsigned int), c->stream));
-        hipLaunchKernelGGL(dsgd_wseg_bound_kernel, grid, dim3(1024), sizeof(unsigned int) * (size_t)hg, c->stream,
+        hipLaunchKernelGGL(dsgd_wseg_bound_kernel, grid, dim3(1024), sizeof(unsigned int) * (size_t)(hg + 16), c->stream,
                            c->d_hrow_ptr, c->d_hcol, c->d_hval, c->d_wtiles, c->n_wtiles, c->n_rows, view(c),
                            c->d_wlong_rows, c->d_ssegs, hg, std::ldexp(1.0f, shift0 - c->vexp), c->d_bound);
         HIP_TRY(hipGetLastError());
@@ -1106,7 +1107,7 @@ static bool plan_kernel_ok(const dsgd_ctx* c, long long step_rows) {
 }
 static int launch_plan_kernel(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int n_workers, long long step_begin,
                               long long step_end, float lr) {
-  const int hl = std::min(c->dp, 32768);
+  const int hl = std::min(c->dp, PLAN_HL);
   if (!c->d_plan_gcold) {
     const size_t strip = (size_t)std::max(1, c->dp - hl);
     HIP_TRY(hipMalloc(&c->d_plan_gcold, sizeof(float) * strip));
@@ -1128,13 +1129,12 @@ static int launch_plan_kernel(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_se
   a.k_total = (float)n_workers;
   a.lr = lr;
   a.lambda = (float)c->cfg.lambda;
-  a.inv_vmax2 = std::ldexp(1.0f, -c->vexp);
+  a.tprof = c->d_tprof;
   a.vexp = c->vexp;
   a.n_workers = n_workers;
   a.hl = hl;
   a.dp = c->dp;
-  const int n_cw = (c->dp - hl + 31) / 32, n_uw = n_workers > 1 ? (c->dp + 31) / 32 : 0;
-  const size_t lds = sizeof(float) * (size_t)(((hl + n_cw + n_uw + 1) & ~1) + 32 + 8);
+  const size_t lds = sizeof(float) * (size_t)plan_lds_words(hl, c->dp, n_workers > 1);
   size_t slot = 0;
   DSGD_TRY(prof_begin(c, &slot));
   if (n_workers > 1) {
@@ -1246,6 +1246,10 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_FIX_BOUND")) c->fix_bound = atoi(e) != 0;
   if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;
   if (const char* e = getenv("DSGD_PLAN_MAX_ROWS")) c->plan_max_rows = std::max(1LL, atoll(e));
+  if (getenv("DSGD_PLAN_PROF") && atoi(getenv("DSGD_PLAN_PROF"))) {
+    HIP_TRY_B(hipMalloc(&c->d_tprof, sizeof(unsigned long long) * 8));
+    HIP_TRY_B(hipMemsetAsync(c->d_tprof, 0, sizeof(unsigned long long) * 8, c->stream));
+  }
   if (c->dbg) c->stream_mode = 3;   // the ablation build exists for the mode-3 kernel
   if (const char* e = getenv("DSGD_HW_W")) c->hw_w = atoi(e);
   if (const char* e = getenv("DSGD_HG_W")) c->hg_w = atoi(e);
@@ -1351,6 +1355,7 @@ int dsgd_destroy(dsgd_ctx* c) {
   (void)hipFree(c->d_hog_it);
   (void)hipFree(c->d_wprev);
   (void)hipFree(c->d_wdelta);
+  (void)hipFree(c->d_tprof);
   (void)hipFree(c->d_plan_gcold);
   (void)hipFree(c->d_plan_upd);
   if (c->h_sc) (void)hipHostFree(c->h_sc);
@@ -2034,14 +2039,14 @@ static int hog_launch(dsgd_ctx* c, long long max_updates) {
   a.lambda = (float)c->cfg.lambda;
   int bits = 0;
   while ((1 << bits) < c->hog_batch) ++bits;
-  const int shift = std::min(23, 30 - bits);   // at most one contribution per row and column: sums stay below 2^30
+  const int shift = 30 - bits;   // at most one contribution per row and column: sums stay below 2^30
   a.qscale = std::ldexp(1.0f, shift - c->vexp);
   a.inv_qscale = std::ldexp(1.0f, c->vexp - shift);
   a.batch = c->hog_batch;
   a.positional_bug = c->hog_bug;
   a.hl = std::min(c->dp, HOG_HL);
   a.dp = c->dp;
-  const size_t lds = sizeof(float) * (size_t)(a.hl + (c->dp - a.hl + 31) / 32 + 16 + 8);
+  const size_t lds = sizeof(float) * (size_t)hog_lds_words(a.hl, c->dp);
   hipLaunchKernelGGL(dsgd_hogwild_kernel, dim3(c->hog_n), dim3(HOG_THREADS), lds, c->async_stream, a);
   HIP_TRY(hipGetLastError());
   return DSGD_OK;
@@ -2293,6 +2298,19 @@ int dsgd_range_nnz(dsgd_ctx* c, int64_t row_begin, int64_t row_end, int64_t* nnz
     const bool split = c->stream_mode == 4 && c->stream_ranges && c->h_crow_ptr.size() == (size_t)c->n_rows + 1;
     *cold_nnz = split ? c->h_crow_ptr[(size_t)row_end] - c->h_crow_ptr[(size_t)row_begin] : 0;
   }
+  return DSGD_OK;
+}
+
+int dsgd_debug_cycles(dsgd_ctx* c, uint64_t* out8, int32_t reset) {
+  DSGD_TRY(check_ctx(c));
+  if (!out8) return fail(DSGD_EINVAL, "null out8");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
+  if (!c->d_tprof) return DSGD_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(out8, c->d_tprof, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost));
+  if (reset) HIP_TRY(hipMemset(c->d_tprof, 0, sizeof(unsigned long long) * 8));
   return DSGD_OK;
 }
 

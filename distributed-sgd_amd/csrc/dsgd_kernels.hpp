@@ -1356,8 +1356,8 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_bound_kernel(const long long* 
                                                               const int* __restrict__ long_rows,
                                                               const StreamSeg* __restrict__ segs, int hg, float scale0,
                                                               unsigned int* __restrict__ out_max) {
-  extern __shared__ __attribute__((aligned(16))) unsigned int bl[];
-  __shared__ unsigned int red[16];
+  extern __shared__ __attribute__((aligned(16))) unsigned int bl[];   // hg column sums + 16 words
+  unsigned int* red = bl + hg;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int j = tid; j < hg; j += 1024) bl[j] = 0u;
   __syncthreads();
@@ -1688,26 +1688,49 @@ __global__ void __launch_bounds__(256) dsgd_eval_idx_kernel(CsrView m, const flo
 // Mini-batch engine: ONE workgroup computes a whole mini-batch (gather-dot, gate, batch sum, regularise, update)
 // ======================================================================================================
 // Shared by the persistent lock-free ("Hogwild") kernel and by the small-batch plan kernel (dsgd_plan_kernel): both
-// are LATENCY problems (a batch of 100 rows is 60 KB of CSR), so the work is arranged to put every load of a batch
-// in flight at once and never to touch a row twice:
-//   phase 1  groups of 16 lanes take R rows each; row_ptr/label of all R rows, then the first UNR x 16 non-zeros of
-//            all R rows, then their weights are requested back to back (three dependent round trips per BATCH, not
-//            per row); DPP butterfly, gate; the contributions y*x of active rows -- still in registers -- go to a
-//            fixed-point LDS accumulator (ranks < hl: ds_add_u32, exact, order-independent) or to the workgroup's
-//            private global strip plus an LDS bitmap (the few ranks >= hl);
-//   phase 2  a dense sweep over the LDS accumulators (consecutive lanes = consecutive ranks, so the global updates of
-//            the dense hot head coalesce) and a bitmap walk over the cold strip turn the batch sum into the update.
-//            No second pass over the CSR, no per-row flags.
-// Fixed point: q = round(y*x * 2^shift / vmax2), shift = min(23, 30 - ceil(log2 batch)): a column receives at most
-// one contribution per row, so no 32-bit word can pass 2^30; contributions below half a grid unit vanish (this
+// are LATENCY problems (a batch of 100 rows is 60 KB of CSR scattered over gigabytes), so the work is arranged as
+// a fixed number of dependent memory round trips per BATCH, whatever the row lengths:
+//   A  one thread per row: row_ptr / label -> row records in LDS, chunks of 128 non-zeros per row
+//   B  workgroup scan over the chunk counts -> a table of WORK ITEMS (row, chunk); as many rows as fit the
+//      NG x R item slots form a sub-batch (a batch of 100 RCV1-like rows is ~118 items: one sub-batch)
+//   C  a group of 16 lanes per item, R items per group in flight: 8 + 8 loads per lane (col, val), then the 8
+//      weights, DPP butterfly -> partial x.w of the item in LDS
+//   D  one thread per row adds the row's partials in chunk order (fixed order: x.w is reproducible), gates
+//      (core/ml/SparseSVM.scala:27-28) and leaves y or 0 as the row's coefficient
+//   E  every item -- its non-zeros are STILL IN REGISTERS -- adds coefficient * x to a fixed-point LDS accumulator
+//      (ranks < hl: ds_add_u32, exact, order-independent) or to the workgroup's private global strip plus an LDS
+//      bitmap (the few ranks >= hl)
+// and the caller's sweep over the accumulators turns the batch sum into the update.  No second pass over the CSR.
+// Fixed point: q = round(y*x * 2^shift / vmax2), shift = 30 - ceil(log2 batch): a column receives at most one
+// contribution per row, so no 32-bit word can pass 2^30; contributions below half a grid unit vanish (this
 // absorbs the reference's 1e-20 filter on y*x, math/Vec.scala:42 -> math/Sparse.scala:108-118).
-constexpr int BT_G = 16;   // lanes per row
+constexpr int BT_G = 16;     // lanes per work item
+constexpr int BT_K = 8;      // non-zeros per lane and item
+constexpr int BT_CH = BT_G * BT_K;   // 128 non-zeros per item
 
 struct BtLds {
   int* acc;              // hl fixed-point accumulators, zero between batches
   unsigned int* cbits;   // one bit per rank >= hl: the strip entry was touched by this batch
   int hl;
+  // sub-batch tables: cap = item slots (NG x R) = most rows of a sub-batch
+  long long* rst;        // [cap] first non-zero of the row
+  int* rlen;             // [cap] its length
+  float* rcoef;          // [cap] label, then (after the gate) label or 0
+  int* ifirst;           // [cap] first work item of the row
+  int* item_row;         // [cap]
+  float* pdot;           // [cap] partial x.w per item
+  int* misc;             // [40]: 16 wave sums, 16 wave counts, item total, scratch
 };
+__host__ __device__ constexpr int bt_lds_words(int cap) { return 2 * cap + 5 * cap + 40; }
+__device__ __forceinline__ void bt_carve(BtLds& L, int* base, int cap) {
+  L.rst = reinterpret_cast<long long*>(base);   // (base is 8-byte aligned)
+  L.rlen = base + 2 * cap;
+  L.rcoef = reinterpret_cast<float*>(base + 3 * cap);
+  L.ifirst = base + 4 * cap;
+  L.item_row = base + 5 * cap;
+  L.pdot = reinterpret_cast<float*>(base + 6 * cap);
+  L.misc = base + 7 * cap;
+}
 
 // contribution of one non-zero of an active row
 __device__ __forceinline__ void bt_add(const BtLds& L, float* __restrict__ gcold, int c, float xv, float qscale) {
@@ -1723,76 +1746,152 @@ __device__ __forceinline__ void bt_add(const BtLds& L, float* __restrict__ gcold
   }
 }
 
-// Phase 1 over the rows row_of(0 .. B-1).  AGENT: weights are read with agent-scope loads (other workgroups update
-// them concurrently: a plain load could be served by a stale L1 line forever).  Returns, on lanes with sub == 0, the
-// number of active rows of the lane's group.  Rows outside [0, n_rows) raise `*bad` and are skipped.
-template <int THREADS, int R, int UNR, bool AGENT, class RowOf>
-__device__ __forceinline__ unsigned int bt_phase1(const CsrView& m, const float* w, const BtLds& L,
-                                                  float* __restrict__ gcold, int B, RowOf row_of, float qscale,
-                                                  int* bad) {
-  constexpr int NG = THREADS / BT_G;
-  const int sub = threadIdx.x % BT_G, gidx = threadIdx.x / BT_G;
+template <bool AGENT>
+__device__ __forceinline__ float bt_load_w(const float* w, int c) {
+  // AGENT: other workgroups update w concurrently -- a plain load could be served by a stale L1 line forever
+  return AGENT ? __hip_atomic_load(const_cast<float*>(&w[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : w[c];
+}
+
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+  v += dpp_get_i<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_get_i<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_get_i<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_get_i<0x118, 0xf>(v);   // row_shr:8
+  v += dpp_get_i<0x142, 0xa>(v);   // row_bcast:15 -> rows 1 and 3
+  v += dpp_get_i<0x143, 0xc>(v);   // row_bcast:31 -> rows 2 and 3
+  return v;
+}
+
+// The gated batch sum of the rows row_of(0 .. B-1) into the accumulators.  Returns this thread's share of the
+// active-row count.  Rows outside [0, n_rows) raise `*bad` and are skipped.  All threads of the workgroup call it
+// (workgroup barriers inside); the caller synchronises before sweeping the accumulators.
+template <int THREADS, int R, bool AGENT, class RowOf>
+__device__ __forceinline__ unsigned int bt_batch(const CsrView& m, const float* w, const BtLds& L, float* __restrict__ gcold,
+                                                 int B, RowOf row_of, float qscale, int* bad) {
+  constexpr int NG = THREADS / BT_G, CAP = NG * R;
+  static_assert(CAP <= THREADS, "one thread per row of a sub-batch");
+  const int tid = threadIdx.x, sub = tid % BT_G, gidx = tid / BT_G, lane = tid & 63, wave = tid >> 6;
   unsigned int n_act = 0;
-  for (int t0 = 0; t0 < B; t0 += NG * R) {
-    long long st[R], en[R];
-    float y[R];
-    bool ok[R];
+  int b0 = 0;
+  while (b0 < B) {   // workgroup-uniform
+    const int nb = min(CAP, B - b0);
+    // ---- A: row records ----
+    long long st = 0;
+    int len = 0, nch = 0;
+    float y = 0.0f;
+    if (tid < nb) {
+      long long row = row_of(b0 + tid);
+      const bool ok = row >= 0 && row < m.n_rows;
+      if (!ok) {
+        atomicOr(bad, 1);
+        row = 0;
+      }
+      st = m.row_ptr[row];
+      len = ok ? (int)(m.row_ptr[row + 1] - st) : 0;
+      y = (float)m.label[row];
+      nch = (len + BT_CH - 1) / BT_CH;   // (a skipped row has no items)
+    }
+    // ---- B: scan of the chunk counts, rows that fit the item slots ----
+    const int incl = wave_incl_scan_i32(nch);
+    if (lane == 63) L.misc[wave] = incl;
+    if (tid == 0) L.misc[32] = 0;
+    __syncthreads();
+    int first = incl - nch;
+    for (int i = 0; i < wave; ++i) first += L.misc[i];
+    const bool fits = tid < nb && first + nch <= CAP;   // monotone in tid: the fitting rows are a prefix
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(fits);
+    if (lane == 0) L.misc[16 + wave] = __popcll(bal);
+    if (fits) {
+      L.rst[tid] = st;
+      L.rlen[tid] = len;
+      L.rcoef[tid] = y;
+      L.ifirst[tid] = first;
+      for (int c = 0; c < nch; ++c) L.item_row[first + c] = tid;
+      if (nch) atomicMax(&L.misc[32], first + nch);
+    } else if (tid == 0) {   // the first row alone exceeds the item slots: whole-workgroup path below
+      L.rst[0] = st;
+      L.rlen[0] = len;
+      L.rcoef[0] = y;
+    }
+    __syncthreads();
+    int nbf = 0;
+    for (int i = 0; i < THREADS / 64; ++i) nbf += L.misc[16 + i];
+    const int n_items = L.misc[32];
+    if (nbf == 0) {
+      // ---- a single row longer than CAP x 128 non-zeros: all threads share it (never the case for RCV1) ----
+      const long long s0 = L.rst[0];
+      const int ln = L.rlen[0];
+      const float yy = L.rcoef[0];
+      float part = 0.0f;
+      for (int p = tid; p < ln; p += THREADS) part += filt(m.val[s0 + p] * bt_load_w<AGENT>(w, m.col[s0 + p]));
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+      __syncthreads();
+      if (lane == 0) L.pdot[wave] = part;
+      __syncthreads();
+      float d = 0.0f;
+      for (int i = 0; i < THREADS / 64; ++i) d += L.pdot[i];
+      if (!(yy * d < 0.0f)) {
+        if (tid == 0) n_act++;
+        for (int p = tid; p < ln; p += THREADS) bt_add(L, gcold, m.col[s0 + p], m.val[s0 + p] * yy, qscale);
+      }
+      b0 += 1;
+      __syncthreads();
+      continue;
+    }
+    // ---- C: one group per item, R items per group in flight ----
+    int c[R][BT_K];
+    float v[R][BT_K];
+    int irow[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int t = t0 + r * NG + gidx;
-      ok[r] = t < B;
-      const long long row = ok[r] ? row_of(t) : 0;
-      if (row < 0 || row >= m.n_rows) {
-        if (sub == 0) atomicOr(bad, 1);
-        ok[r] = false;
-      }
-      const long long rr = ok[r] ? row : 0;
-      st[r] = m.row_ptr[rr];
-      en[r] = ok[r] ? m.row_ptr[rr + 1] : st[r];
-      y[r] = (float)m.label[rr];
-    }
-    int c[R][UNR];
-    float v[R][UNR], acc[R];
+      const int i = r * NG + gidx;
+      const bool valid = i < n_items;
+      irow[r] = valid ? L.item_row[i] : -1;
+      const int row = valid ? irow[r] : 0;
+      const int ch = valid ? i - L.ifirst[row] : 0;
+      const long long p0 = L.rst[row] + (long long)ch * BT_CH;
+      const int cnt = valid ? min(BT_CH, L.rlen[row] - ch * BT_CH) : 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-#pragma unroll
-      for (int k = 0; k < UNR; ++k) {
-        const long long p = st[r] + sub + k * BT_G;
-        const bool in = p < en[r];
-        c[r][k] = in ? m.col[p] : -1;
-        v[r][k] = in ? m.val[p] : 0.0f;
+      for (int k = 0; k < BT_K; ++k) {
+        const int e = sub + k * BT_G;
+        const bool in = e < cnt;
+        c[r][k] = in ? m.col[p0 + e] : -1;
+        v[r][k] = in ? m.val[p0 + e] : 0.0f;
       }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      acc[r] = 0.0f;
+      float acc = 0.0f;
 #pragma unroll
-      for (int k = 0; k < UNR; ++k) {
-        const int cc = c[r][k] >= 0 ? c[r][k] : 0;
-        const float wv = AGENT ? __hip_atomic_load(const_cast<float*>(&w[cc]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : w[cc];
-        acc[r] += filt(v[r][k] * wv);   // ref: math/Sparse.scala:46 (padding lanes: v == 0)
-      }
+      for (int k = 0; k < BT_K; ++k) acc += filt(v[r][k] * bt_load_w<AGENT>(w, c[r][k] >= 0 ? c[r][k] : 0));   // ref: math/Sparse.scala:46
+      acc = group_sum<BT_G>(acc);
+      if (sub == 0 && irow[r] >= 0) L.pdot[r * NG + gidx] = acc;
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {   // rows longer than UNR x 16 non-zeros
-      for (long long p = st[r] + sub + UNR * BT_G; p < en[r]; p += BT_G) {
-        const int cc = m.col[p];
-        const float wv = AGENT ? __hip_atomic_load(const_cast<float*>(&w[cc]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : w[cc];
-        acc[r] += filt(m.val[p] * wv);
-      }
+    __syncthreads();
+    // ---- D: x.w per row in chunk order, gate ----
+    if (tid < nbf) {
+      const int f0 = L.ifirst[tid], n = (L.rlen[tid] + BT_CH - 1) / BT_CH;
+      float d = 0.0f;
+      for (int i = 0; i < n; ++i) d += L.pdot[f0 + i];
+      const float yy = L.rcoef[tid];
+      const bool active = L.rlen[tid] > 0 && !(yy * d < 0.0f);   // ref: core/ml/SparseSVM.scala:27-28
+      L.rcoef[tid] = active ? yy : 0.0f;
+      n_act += active;
     }
+    __syncthreads();
+    // ---- E: contributions of the active rows, from registers ----
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float d = group_sum<BT_G>(acc[r]);
-      const bool active = ok[r] && !(y[r] * d < 0.0f);   // ref: core/ml/SparseSVM.scala:27-28
-      if (sub == 0) n_act += active;
-      if (active) {
+      const float coef = irow[r] >= 0 ? L.rcoef[irow[r]] : 0.0f;
+      if (coef != 0.0f) {
 #pragma unroll
-        for (int k = 0; k < UNR; ++k)
-          if (c[r][k] >= 0) bt_add(L, gcold, c[r][k], v[r][k] * y[r], qscale);
-        for (long long p = st[r] + sub + UNR * BT_G; p < en[r]; p += BT_G) bt_add(L, gcold, m.col[p], m.val[p] * y[r], qscale);
+        for (int k = 0; k < BT_K; ++k)
+          if (c[r][k] >= 0) bt_add(L, gcold, c[r][k], v[r][k] * coef, qscale);
       }
     }
+    b0 += nbf;
+    // (the next sub-batch writes only misc[] before its first barrier; nothing above reads misc[] after the last one)
   }
   return n_act;
 }
@@ -1859,14 +1958,21 @@ __device__ __forceinline__ unsigned int hog_gcd32(unsigned int a, unsigned int b
 }
 
 constexpr int HOG_THREADS = 512;   // 2 waves per SIMD: leaves registers and LDS for the master's concurrent loss check
+constexpr int HOG_R = 4;           // work items in flight per group: 32 groups x 4 = 128 item slots per sub-batch
+constexpr int HOG_CAP = HOG_THREADS / BT_G * HOG_R;
 constexpr int HOG_MAX_BATCH = 4096;
 constexpr int HOG_HL = 24576;      // ranks with an LDS accumulator (96 KiB; + 32 KiB of dsgd_eval_kernel still fit a CU)
+constexpr int HOG_SW = 8;          // accumulator slots per thread and sweep pass
 
 struct HogCtl {
   int stop;
   unsigned int mul, off;
   float s;
 };
+
+__host__ __device__ constexpr int hog_lds_words(int hl, int dp) {
+  return ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8;
+}
 
 __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1875,7 +1981,9 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   L.acc = reinterpret_cast<int*>(lds);
   const int n_cw = (a.dp - a.hl + 31) / 32;                  // bitmap words of the cold strip (0 when dp <= hl)
   L.cbits = reinterpret_cast<unsigned int*>(lds + a.hl);
-  float* red = lds + a.hl + n_cw;                            // 8 floats + 8 ints + control
+  int* tables = reinterpret_cast<int*>(lds) + ((a.hl + n_cw + 1) & ~1);
+  bt_carve(L, tables, HOG_CAP);
+  float* red = reinterpret_cast<float*>(tables + bt_lds_words(HOG_CAP));   // 8 floats + 8 counters + control
   unsigned int* redn = reinterpret_cast<unsigned int*>(red + 8);
   HogCtl* ctl = reinterpret_cast<HogCtl*>(red + 16);
   const int tid = threadIdx.x;
@@ -1922,19 +2030,27 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       if (r >= (long long)n_k) r -= n_k;
       return base + r;
     };
-    unsigned int n_act = bt_phase1<HOG_THREADS, 4, 6, true>(a.m, a.w, L, gc, B, row_of, a.qscale, &a.st->err);
+    unsigned int n_act = bt_batch<HOG_THREADS, HOG_R, true>(a.m, a.w, L, gc, B, row_of, a.qscale, &a.st->err);
     __syncthreads();
-    // phase 2: mean, regularise on the support, scale, subtract from the shared w (ref: Slave.scala:98-101)
+    // phase 2: mean, regularise on the support, scale, subtract from the shared w (ref: Slave.scala:98-101).
+    // Dense sweep, consecutive lanes = consecutive ranks (the updates of the dense hot head coalesce); the dimSparsity
+    // values of a pass are requested together, under the mask of the non-zero accumulators, before any is used.
     float ds_acc = 0.0f;
-    for (int j0 = 0; j0 < a.hl; j0 += HOG_THREADS * 4) {
-      int q[4];
+    for (int j0 = 0; j0 < a.hl; j0 += HOG_THREADS * HOG_SW) {
+      int q[HOG_SW];
+      float dsv[HOG_SW];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < HOG_SW; ++e) {
         const int j = j0 + e * HOG_THREADS + tid;
         q[e] = j < a.hl ? L.acc[j] : 0;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < HOG_SW; ++e) {
+        dsv[e] = 0.0f;
+        if (q[e] != 0) dsv[e] = a.ds[j0 + e * HOG_THREADS + tid];
+      }
+#pragma unroll
+      for (int e = 0; e < HOG_SW; ++e) {
         if (q[e] == 0) continue;
         const int j = j0 + e * HOG_THREADS + tid;
         L.acc[j] = 0;
@@ -1944,7 +2060,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         const float delta = filt(g * a.lr);
         if (delta != 0.0f) {
           atomicAdd(&a.w[j], -delta);   // lock-free update of the ONE weight vector
-          ds_acc += delta * a.ds[j];
+          ds_acc += delta * dsv[e];
         }
       }
     }
@@ -1956,6 +2072,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         const int b = __builtin_ctz(bits);
         bits &= bits - 1u;
         const int jc = wd * 32 + b;
+        const float dsj = a.ds[a.hl + jc];
         const float v = atomicExch(&gc[jc], 0.0f);   // take-and-clear the private strip entry
         float g = filt(v / fB);
         if (g == 0.0f) continue;
@@ -1963,7 +2080,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         const float delta = filt(g * a.lr);
         if (delta != 0.0f) {
           atomicAdd(&a.w[a.hl + jc], -delta);
-          ds_acc += delta * a.ds[a.hl + jc];
+          ds_acc += delta * dsj;
         }
       }
     }
@@ -2061,14 +2178,22 @@ struct PlanArgs {
   const int* idx;
   const WorkSeg* segs;       // n_steps x n_workers
   DevScalars* sc;
+  unsigned long long* tprof; // optional (tuning runs): shader-clock cycles of thread 0 in {gradient, sweep, reduce}, steps
   long long step_begin, step_end;
   float k_total, lr, lambda;
-  float inv_vmax2;           // 2^-vexp
   int vexp, n_workers, hl, dp;
 };
 
 constexpr int PLAN_THREADS = 1024;
+constexpr int PLAN_R = 3;        // 64 groups x 3 = 192 item slots per sub-batch
+constexpr int PLAN_CAP = PLAN_THREADS / BT_G * PLAN_R;
+constexpr int PLAN_HL = 24576;   // ranks with an LDS accumulator: one sweep pass of 24 slots per thread
+constexpr int PLAN_SW = 8;       // accumulator slots per thread and sweep pass (3 passes over PLAN_HL)
 constexpr int PLAN_HD = 4096;    // MULTI: ranks below this are swept densely in the final apply, the rest via a bitmap
+
+__host__ __device__ constexpr int plan_lds_words(int hl, int dp, bool multi) {
+  return ((hl + (dp - hl + 31) / 32 + (multi ? (dp + 31) / 32 : 0) + 1) & ~1) + bt_lds_words(PLAN_CAP) + 32 + 8;
+}
 
 __device__ __forceinline__ double block_sum_f64(double v, double* red /* 16 doubles of LDS */) {
 #pragma unroll
@@ -2091,7 +2216,9 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
   const int n_uw = MULTI ? (a.dp + 31) / 32 : 0;
   L.cbits = reinterpret_cast<unsigned int*>(lds + a.hl);
   unsigned int* ubits = L.cbits + n_cw;                                  // MULTI: touched coordinates of `upd`
-  double* red = reinterpret_cast<double*>(lds + ((a.hl + n_cw + n_uw + 1) & ~1));   // 16 doubles
+  int* tables = reinterpret_cast<int*>(lds) + ((a.hl + n_cw + n_uw + 1) & ~1);
+  bt_carve(L, tables, PLAN_CAP);
+  double* red = reinterpret_cast<double*>(tables + bt_lds_words(PLAN_CAP));   // 16 doubles
   const int tid = threadIdx.x;
   for (int j = tid; j < a.hl + n_cw + n_uw; j += PLAN_THREADS) L.acc[j] = 0;
   // exact w . ds of the weights this launch starts from
@@ -2099,16 +2226,16 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
   for (int j = tid; j < a.dp; j += PLAN_THREADS) dot_part += (double)a.w[j] * (double)a.ds[j];
   double dot = block_sum_f64(dot_part, red);   // (also the barrier behind the LDS zeroing)
   unsigned long long n_act_total = 0;
+  unsigned long long tp[3] = {0, 0, 0};
 
-  // w[j] <- w[j] - lr * (gsum / K); returns the change of w[j] * ds[j]
-  auto apply = [&](int j, float gsum) -> double {
+  // w[j] <- w[j] - lr * (gsum / K) given the old weight and ds[j]; returns the change of w[j] * ds[j]
+  auto apply = [&](int j, float gsum, float wo, float dsj) -> double {
     const float mean = filt(gsum / a.k_total);   // Vec.mean (ref: math/Vec.scala:139)
     const float updv = filt(mean * a.lr);        // learningRate * grad (ref: core/Master.scala:197)
     if (updv == 0.0f) return 0.0;
-    const float wo = a.w[j];
     const float wn = filt(wo - updv);
     a.w[j] = wn;
-    return ((double)wn - (double)wo) * (double)a.ds[j];
+    return ((double)wn - (double)wo) * (double)dsj;
   };
 
   for (long long step = a.step_begin; step < a.step_end; ++step) {
@@ -2117,26 +2244,41 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     double ddot = 0.0;
     unsigned int n_act = 0;
     for (int k = 0; k < a.n_workers; ++k) {
+      const unsigned long long t0 = a.tprof ? __builtin_readcyclecounter() : 0ull;
       const WorkSeg seg = a.segs[step * a.n_workers + k];
       const int B = (int)(seg.end - seg.begin);
       int bits = 0;
       while ((1 << bits) < B) ++bits;
-      const int shift = min(23, 30 - bits);
+      const int shift = 30 - bits;   // at most one contribution per row and column: sums stay below 2^30
       const float qscale = ldexpf(1.0f, shift - a.vexp), inv_qscale = ldexpf(1.0f, a.vexp - shift);
       const int* __restrict__ list = a.idx + seg.begin;
       auto row_of = [&](int t) -> long long { return (long long)list[t]; };
-      n_act += bt_phase1<PLAN_THREADS, 2, 8, false>(a.m, a.w, L, a.gcold, B, row_of, qscale, &a.sc->err);
+      // (the multi-worker instantiation carries the `upd` bookkeeping: 2 items per group keep it out of scratch)
+      n_act += bt_batch<PLAN_THREADS, MULTI ? 2 : PLAN_R, false>(a.m, a.w, L, a.gcold, B, row_of, qscale, &a.sc->err);
       __syncthreads();
-      // sweep: this worker's regularised sum on its support
-      for (int j0 = 0; j0 < a.hl; j0 += PLAN_THREADS * 4) {
-        int q[4];
+      const unsigned long long t1 = a.tprof ? __builtin_readcyclecounter() : 0ull;
+      // sweep: this worker's regularised sum on its support.  Per pass: 8 accumulators of the thread, then (under
+      // the mask of the non-zero ones) every weight / dimSparsity value they need, then the arithmetic.
+      for (int j0 = 0; j0 < a.hl; j0 += PLAN_THREADS * PLAN_SW) {
+        int q[PLAN_SW];
+        float wo[PLAN_SW], dsv[PLAN_SW];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < PLAN_SW; ++e) {
           const int j = j0 + e * PLAN_THREADS + tid;
           q[e] = j < a.hl ? L.acc[j] : 0;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < PLAN_SW; ++e) {
+          wo[e] = 0.0f;
+          dsv[e] = 0.0f;
+          if (q[e] != 0) {
+            const int j = j0 + e * PLAN_THREADS + tid;
+            wo[e] = MULTI ? a.upd[j] : a.w[j];
+            if (!MULTI) dsv[e] = a.ds[j];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < PLAN_SW; ++e) {
           if (q[e] == 0) continue;
           const int j = j0 + e * PLAN_THREADS + tid;
           L.acc[j] = 0;
@@ -2144,10 +2286,10 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
           if (g == 0.0f) continue;
           if (add_s) g = filt(g + s);                          // ref: core/ml/SparseSVM.scala:31, math/Vec.scala:65-75
           if (MULTI) {
-            a.upd[j] = filt(a.upd[j] + g);
+            a.upd[j] = filt(wo[e] + g);                        // Vec.sum over the workers folds left
             if (j >= PLAN_HD) atomicOr(&ubits[j >> 5], 1u << (j & 31));
           } else {
-            ddot += apply(j, g);
+            ddot += apply(j, g, wo[e], dsv[e]);
           }
         }
       }
@@ -2159,26 +2301,51 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
           const int b = __builtin_ctz(cb);
           cb &= cb - 1u;
           const int jc = wd * 32 + b, j = a.hl + jc;
+          const float old = MULTI ? a.upd[j] : a.w[j];
+          const float dsj = MULTI ? 0.0f : a.ds[j];
           float g = filt(atomicExch(&a.gcold[jc], 0.0f));   // (written with L2 atomics: read it there, not through L1)
           if (g == 0.0f) continue;
           if (add_s) g = filt(g + s);
           if (MULTI) {
-            a.upd[j] = filt(a.upd[j] + g);
+            a.upd[j] = filt(old + g);
             atomicOr(&ubits[j >> 5], 1u << (j & 31));
           } else {
-            ddot += apply(j, g);
+            ddot += apply(j, g, old, dsj);
           }
         }
       }
       __syncthreads();   // accumulators are clean (and, MULTI, upd is written) before the next worker's phase 1
+      if (a.tprof) {
+        tp[0] += t1 - t0;
+        tp[1] += __builtin_readcyclecounter() - t1;
+      }
     }
+    const unsigned long long t2 = a.tprof ? __builtin_readcyclecounter() : 0ull;
     if (MULTI) {
       // mean over the workers and the update, on the union of the supports
-      for (int j = tid; j < min(PLAN_HD, a.dp); j += PLAN_THREADS) {
-        const float u = a.upd[j];
-        if (u != 0.0f) {
+      {
+        constexpr int ND = PLAN_HD / PLAN_THREADS;
+        float u[ND], wo[ND], dsv[ND];
+#pragma unroll
+        for (int e = 0; e < ND; ++e) {
+          const int j = e * PLAN_THREADS + tid;
+          u[e] = j < a.dp ? a.upd[j] : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < ND; ++e) {
+          wo[e] = 0.0f;
+          dsv[e] = 0.0f;
+          if (u[e] != 0.0f) {
+            wo[e] = a.w[e * PLAN_THREADS + tid];
+            dsv[e] = a.ds[e * PLAN_THREADS + tid];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < ND; ++e) {
+          if (u[e] == 0.0f) continue;
+          const int j = e * PLAN_THREADS + tid;
           a.upd[j] = 0.0f;
-          ddot += apply(j, u);
+          ddot += apply(j, u[e], wo[e], dsv[e]);
         }
       }
       for (int wd = PLAN_HD / 32 + tid; wd < n_uw; wd += PLAN_THREADS) {
@@ -2188,17 +2355,26 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
         while (ub) {
           const int j = wd * 32 + __builtin_ctz(ub);
           ub &= ub - 1u;
-          const float u = a.upd[j];
+          const float u = a.upd[j], wo = a.w[j], dsj = a.ds[j];
           a.upd[j] = 0.0f;
-          ddot += apply(j, u);
+          ddot += apply(j, u, wo, dsj);
         }
       }
     }
     dot += block_sum_f64(ddot, red);   // every thread adds the same total: `dot` stays thread-uniform
     n_act_total += n_act;
+    if (a.tprof) tp[2] += __builtin_readcyclecounter() - t2;
     // (block_sum_f64's barriers also order this step's writes of w before the next step's reads)
   }
   n_act_total = (unsigned long long)wave_sum_u32((unsigned int)n_act_total);
   if ((tid & 63) == 0 && n_act_total) atomicAdd(&a.sc->n_active, n_act_total);
-  if (tid == 0) a.sc->s_reg = (float)(2.0 * (double)a.lambda * dot);
+  if (tid == 0) {
+    a.sc->s_reg = (float)(2.0 * (double)a.lambda * dot);
+    if (a.tprof) {
+      a.tprof[0] += tp[0];
+      a.tprof[1] += tp[1];
+      a.tprof[2] += tp[2];
+      a.tprof[3] += (unsigned long long)(a.step_end - a.step_begin);
+    }
+  }
 }

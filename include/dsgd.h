@@ -215,6 +215,11 @@ int dsgd_range_nnz(dsgd_ctx* ctx, int64_t row_begin, int64_t row_end, int64_t* n
  * fixed-point bound is enabled.  n = number of slots the caller provides (<= 6).                                  */
 int dsgd_tuning_info(dsgd_ctx* ctx, int32_t* vals, int32_t n);
 
+/* Tuning aid (DSGD_PLAN_PROF=1 in the environment at dsgd_create): shader-clock cycles thread 0 of the small-batch
+ * plan kernel spent in {gradient phase, sweep, reduce} and the number of steps, accumulated since the last reset;
+ * all zeros when the aid is off.                                                                                */
+int dsgd_debug_cycles(dsgd_ctx* ctx, uint64_t* out8, int32_t reset);
+
 /* name of the gradient kernel variant in use (for matching rocprofv3 kernel-trace rows)        */
 const char* dsgd_grad_kernel_name(dsgd_ctx* ctx);
 /* raw device pointers (float[D+1]) for hosts that own the collective (e.g. torch.distributed)  */

@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 { nproc; lscpu | grep -E "Model name|Socket|Thread|Core"; rocm-smi --showproductname 2>/dev/null | head -8; } > $OUT/env.txt 2>&1
 echo "== pytest -m gpu"
-timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -40 | tee $OUT/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -q --timeout 300 2>&1 | tail -80 | tee $OUT/pytest_gpu.txt
 echo "== bench (default flags)"
 timeout 900 python bench.py 2> $OUT/bench.err > $OUT/bench.json; tail -3 $OUT/bench.err; cut -c1-400 $OUT/bench.json
 echo "== rocprofv3 kernel trace"
