@@ -58,7 +58,8 @@ def hipcc_path() -> str:
 
 def build_hip(force: bool = False) -> str:
     header = os.path.join(HERE, "..", "include", "dsgd.h")
-    if not force and not _stale(HIP_LIB, HIP_SRC, os.path.join(CSRC, "dsgd_kernels.hpp"), header, __file__):
+    if not force and not _stale(HIP_LIB, HIP_SRC, os.path.join(CSRC, "dsgd_kernels.hpp"), os.path.join(CSRC, "dsgd_batch.hpp"),
+                              header, __file__):
         return HIP_LIB
     os.makedirs(LIBDIR, exist_ok=True)
     stub_dir = tempfile.mkdtemp(prefix="dsgd_stub_")

@@ -1,0 +1,851 @@
+// Device code of libdsgd_hip, part 2 (gfx950 only): the MINI-BATCH engine and the two persistent kernels built on
+// it -- the lock-free "Hogwild" engine (BASELINE.json configs[3]) and the small-batch plan kernel (the reference's
+// batch-size 100-200).  Included by dsgd_hip.hip after dsgd_kernels.hpp.
+//
+// Citations "ref:" are relative to /root/reference/src/main/scala/epfl/distributed/.
+#pragma once
+
+// ======================================================================================================
+// Mini-batch engine: ONE workgroup computes a whole mini-batch (gather-dot, gate, batch sum)
+// ======================================================================================================
+// Both users are LATENCY problems (a batch of 100 rows is 60 KB of CSR scattered over gigabytes), so the work is a
+// fixed number of dependent memory round trips per BATCH, whatever the row lengths, and every stage is a separate
+// function so that the callers can put the NEXT batch's round trips under the current batch's update sweep:
+//   bt_rows_issue   one thread per row: row_ptr / label requested (registers; nothing waits)
+//   bt_build        workgroup scan over the rows' chunk counts (128 non-zeros per chunk) -> a table of WORK ITEMS
+//                   (row, chunk) in LDS; as many rows as fit the NG x R item slots form a sub-batch (100 RCV1-like
+//                   rows are ~118 items)
+//   bt_items_issue  a group of 16 lanes per item, R items per group: 8 + 8 loads per lane (col, val) requested
+//   bt_items_dot    the 8 weights per lane and item, products, DPP butterfly -> partial x.w of the item in LDS
+//   bt_gate         one thread per row adds the row's partials in chunk order (fixed order: x.w is reproducible),
+//                   gates (core/ml/SparseSVM.scala:27-28) and leaves y or 0 as the row's coefficient
+//   bt_scatter      every item -- its non-zeros are STILL IN REGISTERS -- adds coefficient * x to a fixed-point LDS
+//                   accumulator (ranks < hl: ds_add_u32, exact, order-independent) or to the workgroup's private
+//                   global strip plus an LDS bitmap (the few ranks >= hl)
+// The caller's sweep over the accumulators turns the batch sum into the update.  No second pass over the CSR.
+// Fixed point: q = round(y*x * 2^shift / vmax2), shift = 30 - ceil(log2 batch): a column receives at most one
+// contribution per row, so no 32-bit word can pass 2^30; contributions below half a grid unit vanish (this
+// absorbs the reference's 1e-20 filter on y*x, math/Vec.scala:42 -> math/Sparse.scala:108-118).
+constexpr int BT_G = 16;     // lanes per work item
+constexpr int BT_K = 8;      // non-zeros per lane and item
+constexpr int BT_CH = BT_G * BT_K;   // 128 non-zeros per item
+
+struct BtLds {
+  int* acc;              // hl fixed-point accumulators, zero between batches
+  unsigned int* cbits;   // one bit per rank >= hl: the strip entry was touched by this batch
+  int hl;
+  // sub-batch tables: cap = item slots (NG x R) = most rows of a sub-batch
+  long long* rst;        // [cap] first non-zero of the row
+  int* rlen;             // [cap] its length
+  float* rcoef;          // [cap] label, then (after the gate) label or 0
+  int* ifirst;           // [cap] first work item of the row
+  int* item_row;         // [cap]
+  float* pdot;           // [cap] partial x.w per item
+  int* misc;             // [40]: 16 wave sums, 16 wave counts, item total, scratch
+};
+__host__ __device__ constexpr int bt_lds_words(int cap) { return 7 * cap + 40; }
+__device__ __forceinline__ void bt_carve(BtLds& L, int* base, int cap) {
+  L.rst = reinterpret_cast<long long*>(base);   // (base is 8-byte aligned)
+  L.rlen = base + 2 * cap;
+  L.rcoef = reinterpret_cast<float*>(base + 3 * cap);
+  L.ifirst = base + 4 * cap;
+  L.item_row = base + 5 * cap;
+  L.pdot = reinterpret_cast<float*>(base + 6 * cap);
+  L.misc = base + 7 * cap;
+}
+
+template <int R>
+struct BtItems {
+  int c[R][BT_K];
+  float v[R][BT_K];
+  int irow[R];   // row of the sub-batch (-1: unused slot)
+};
+struct BtRow {
+  long long st;
+  int len;
+  float y;
+};
+
+// contribution of one non-zero of an active row.  WGSCOPE: the strip is private to a workgroup that is alone with
+// its data (plan kernel): workgroup-scope atomics stay in this XCD's L2.
+template <bool WGSCOPE>
+__device__ __forceinline__ void bt_add(const BtLds& L, float* __restrict__ gcold, int c, float xv, float qscale) {
+  if (c < L.hl) {
+    const int q = __float2int_rn(xv * qscale);
+    if (q != 0) atomicAdd(&L.acc[c], q);   // ds_add_u32
+  } else {
+    const float f = filt(xv);
+    if (f != 0.0f) {
+      if (WGSCOPE) __hip_atomic_fetch_add(&gcold[c - L.hl], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else atomicAdd(&gcold[c - L.hl], f);
+      atomicOr(&L.cbits[(unsigned int)(c - L.hl) >> 5], 1u << ((c - L.hl) & 31));
+    }
+  }
+}
+
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+  v += dpp_get_i<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_get_i<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_get_i<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_get_i<0x118, 0xf>(v);   // row_shr:8
+  v += dpp_get_i<0x142, 0xa>(v);   // row_bcast:15 -> rows 1 and 3
+  v += dpp_get_i<0x143, 0xc>(v);   // row_bcast:31 -> rows 2 and 3
+  return v;
+}
+
+// row records of the rows row_of(b0 .. b0 + min(CAP, B - b0) - 1), one per thread; loads only
+template <int CAP, class RowOf>
+__device__ __forceinline__ BtRow bt_rows_issue(const CsrView& m, int B, int b0, RowOf row_of, int* bad) {
+  BtRow r;
+  r.st = 0;
+  r.len = 0;
+  r.y = 0.0f;
+  const int tid = threadIdx.x;
+  if (tid < min(CAP, B - b0)) {
+    long long row = row_of(b0 + tid);
+    const bool ok = row >= 0 && row < m.n_rows;
+    if (!ok) {
+      atomicOr(bad, 1);
+      row = 0;
+    }
+    r.st = m.row_ptr[row];
+    r.len = ok ? (int)(m.row_ptr[row + 1] - r.st) : 0;   // (a skipped row has no items)
+    r.y = (float)m.label[row];
+  }
+  return r;
+}
+
+// tables of the sub-batch: returns {rows that fit the item slots (a prefix), work items}.  Two workgroup barriers.
+template <int THREADS, int CAP>
+__device__ __forceinline__ int2 bt_build(const BtLds& L, int B, int b0, const BtRow& row) {
+  static_assert(CAP <= THREADS, "one thread per row of a sub-batch");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = min(CAP, B - b0);
+  const int nch = tid < nb ? (row.len + BT_CH - 1) / BT_CH : 0;
+  const int incl = wave_incl_scan_i32(nch);
+  if (lane == 63) L.misc[wave] = incl;
+  if (tid == 0) L.misc[32] = 0;
+  __syncthreads();
+  int first = incl - nch;
+  for (int i = 0; i < wave; ++i) first += L.misc[i];
+  const bool fits = tid < nb && first + nch <= CAP;   // monotone in tid: the fitting rows are a prefix
+  const unsigned long long bal = __builtin_amdgcn_ballot_w64(fits);
+  if (lane == 0) L.misc[16 + wave] = __popcll(bal);
+  if (fits) {
+    L.rst[tid] = row.st;
+    L.rlen[tid] = row.len;
+    L.rcoef[tid] = row.y;
+    L.ifirst[tid] = first;
+    for (int c = 0; c < nch; ++c) L.item_row[first + c] = tid;
+    if (nch) atomicMax(&L.misc[32], first + nch);
+  } else if (tid == 0) {   // the first row alone exceeds the item slots: bt_giant_row
+    L.rst[0] = row.st;
+    L.rlen[0] = row.len;
+    L.rcoef[0] = row.y;
+  }
+  __syncthreads();
+  int nbf = 0;
+  for (int i = 0; i < THREADS / 64; ++i) nbf += L.misc[16 + i];
+  return make_int2(nbf, L.misc[32]);
+}
+
+template <int THREADS, int R>
+__device__ __forceinline__ void bt_items_issue(const CsrView& m, const BtLds& L, int n_items, BtItems<R>& it) {
+  constexpr int NG = THREADS / BT_G;
+  const int sub = threadIdx.x % BT_G, gidx = threadIdx.x / BT_G;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = r * NG + gidx;
+    const bool valid = i < n_items;
+    const int row = valid ? L.item_row[i] : 0;
+    it.irow[r] = valid ? row : -1;
+    const int ch = valid ? i - L.ifirst[row] : 0;
+    const long long p0 = L.rst[row] + (long long)ch * BT_CH;
+    const int cnt = valid ? min(BT_CH, L.rlen[row] - ch * BT_CH) : 0;
+#pragma unroll
+    for (int k = 0; k < BT_K; ++k) {
+      const int e = sub + k * BT_G;
+      const bool in = e < cnt;
+      it.c[r][k] = in ? m.col[p0 + e] : -1;
+      it.v[r][k] = in ? m.val[p0 + e] : 0.0f;
+    }
+  }
+}
+
+// partial x.w of every item -> L.pdot; `wload(c)` returns the weight of rank c
+template <int THREADS, int R, class WLoad>
+__device__ __forceinline__ void bt_items_dot(const BtLds& L, const BtItems<R>& it, WLoad wload) {
+  constexpr int NG = THREADS / BT_G;
+  const int sub = threadIdx.x % BT_G, gidx = threadIdx.x / BT_G;
+  float wv[R][BT_K];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int k = 0; k < BT_K; ++k) wv[r][k] = wload(it.c[r][k] >= 0 ? it.c[r][k] : 0);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < BT_K; ++k) acc += filt(it.v[r][k] * wv[r][k]);   // ref: math/Sparse.scala:46 (padding: v == 0)
+    acc = group_sum<BT_G>(acc);
+    if (sub == 0 && it.irow[r] >= 0) L.pdot[r * NG + gidx] = acc;
+  }
+}
+
+// x.w per row in chunk order, gate; returns this thread's count of active rows (0 or 1)
+__device__ __forceinline__ unsigned int bt_gate(const BtLds& L, int nbf) {
+  const int tid = threadIdx.x;
+  if (tid >= nbf) return 0u;
+  const int f0 = L.ifirst[tid], n = (L.rlen[tid] + BT_CH - 1) / BT_CH;
+  float d = 0.0f;
+  for (int i = 0; i < n; ++i) d += L.pdot[f0 + i];
+  const float yy = L.rcoef[tid];
+  const bool active = L.rlen[tid] > 0 && !(yy * d < 0.0f);   // ref: core/ml/SparseSVM.scala:27-28
+  L.rcoef[tid] = active ? yy : 0.0f;
+  return active ? 1u : 0u;
+}
+
+template <int R, bool WGSCOPE>
+__device__ __forceinline__ void bt_scatter(const BtLds& L, float* __restrict__ gcold, const BtItems<R>& it, float qscale) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float coef = it.irow[r] >= 0 ? L.rcoef[it.irow[r]] : 0.0f;
+    if (coef != 0.0f) {
+#pragma unroll
+      for (int k = 0; k < BT_K; ++k)
+        if (it.c[r][k] >= 0) bt_add<WGSCOPE>(L, gcold, it.c[r][k], it.v[r][k] * coef, qscale);
+    }
+  }
+}
+
+// a single row longer than CAP x 128 non-zeros (never the case for RCV1): all threads share it.  The row record was
+// left in slot 0 by bt_build.  Three workgroup barriers.
+template <int THREADS, bool WGSCOPE, class WLoad>
+__device__ __forceinline__ unsigned int bt_giant_row(const CsrView& m, const BtLds& L, float* __restrict__ gcold,
+                                                     WLoad wload, float qscale) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long s0 = L.rst[0];
+  const int ln = L.rlen[0];
+  const float yy = L.rcoef[0];
+  float part = 0.0f;
+  for (int p = tid; p < ln; p += THREADS) part += filt(m.val[s0 + p] * wload(m.col[s0 + p]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+  __syncthreads();
+  if (lane == 0) L.pdot[wave] = part;
+  __syncthreads();
+  float d = 0.0f;
+  for (int i = 0; i < THREADS / 64; ++i) d += L.pdot[i];
+  unsigned int n_act = 0;
+  if (!(yy * d < 0.0f)) {
+    n_act = tid == 0 ? 1u : 0u;
+    for (int p = tid; p < ln; p += THREADS) bt_add<WGSCOPE>(L, gcold, m.col[s0 + p], m.val[s0 + p] * yy, qscale);
+  }
+  __syncthreads();
+  return n_act;
+}
+
+// The gated batch sum of the rows row_of(b0 .. B-1), stage after stage (nothing overlapped): the general path for
+// whatever a pipelined caller could not stage ahead.  Returns this thread's share of the active-row count.
+template <int THREADS, int R, bool WGSCOPE, class RowOf, class WLoad>
+__device__ __forceinline__ unsigned int bt_batch(const CsrView& m, const BtLds& L, float* __restrict__ gcold, int B, int b0,
+                                                 RowOf row_of, WLoad wload, float qscale, int* bad) {
+  constexpr int CAP = THREADS / BT_G * R;
+  unsigned int n_act = 0;
+  while (b0 < B) {   // workgroup-uniform
+    const BtRow row = bt_rows_issue<CAP>(m, B, b0, row_of, bad);
+    const int2 bd = bt_build<THREADS, CAP>(L, B, b0, row);
+    if (bd.x == 0) {
+      n_act += bt_giant_row<THREADS, WGSCOPE>(m, L, gcold, wload, qscale);
+      b0 += 1;
+      continue;
+    }
+    BtItems<R> it;
+    bt_items_issue<THREADS, R>(m, L, bd.y, it);
+    bt_items_dot<THREADS, R>(L, it, wload);
+    __syncthreads();
+    n_act += bt_gate(L, bd.x);
+    __syncthreads();
+    bt_scatter<R, WGSCOPE>(L, gcold, it, qscale);
+    b0 += bd.x;
+    // (bt_build writes only misc[] before its first barrier; nothing above reads misc[] after the last barrier)
+  }
+  return n_act;
+}
+
+// ======================================================================================================
+// K7: persistent lock-free ("Hogwild") engine -- Slave.asyncTask for many workers sharing ONE w
+// ======================================================================================================
+// ref: core/Slave.scala:79-111 (the loop), :177-185 / core/MasterAsync.scala:164-177 (applying updates),
+//      README.md:35 (Recht et al. 2011).
+// The reference gives every slave its own replica of w and gossips each update to every peer, who
+// subtracts it; with all workers on one GPU the replicas collapse into a single device-resident w that
+// every worker (= workgroup) reads without locks and updates with atomicAdd(w[j], -delta_j).
+// One iteration of a worker:
+//   draw `batch` rows of its assigned range -> gated sub-gradients on whatever w holds right now -> batch sum
+//   (mini-batch engine above) -> MEAN over the batch -> support-only regulariser with s = 2*lambda*(w.ds) -> scale
+//   by lr -> atomicAdd into w.  The scalar s is kept up to date incrementally (s -= 2*lambda*sum(delta_j*ds_j))
+//   instead of re-reducing 47 K products per mini-batch as SparseSVM.regularize does.
+// The sample of iteration i+1 does not depend on w: its row records and its non-zeros are requested while
+// iteration i's update sweep runs (only the weight gather and everything after it wait for the sweep).
+// SAMPLING (deliberate deviation): Slave.scala:87 draws `Random.shuffle(indices) take B`; a
+// device-side Fisher-Yates of a 20,000-row range per mini-batch would cost more than the mini-batch.  The engine
+// draws the affine progression rows (mul * t + off) mod n, t = 0..B-1 with gcd(mul, n) = 1 from a counter-based
+// generator keyed by (seed, worker, iteration): B DISTINCT rows of the range, every row equally likely, replayable
+// on the host (tests/test_gpu_parity.py hog_rows) -- but not the JVM's stream and not a uniform B-subset.
+// batch == 1 is a single uniform draw, as Slave.scala:84.  The wire-level worker (wire.SlaveWorker) replays the JVM
+// generator exactly for hosts that need it.
+struct HogState {
+  unsigned long long updates;   // mini-batch updates applied (MasterAsync counts these: MasterAsync.scala:83,171)
+  unsigned long long samples;   // rows whose gradient was computed
+  unsigned long long active;    // ... of which the gate let through
+  float s_reg;                  // 2 * lambda * (w . ds), maintained incrementally
+  int done_blocks;
+  int stop;                     // raised by the host (copy on a side stream): workers exit after their mini-batch
+  int err;                      // a sampled row fell outside the data
+};
+
+struct HogArgs {
+  CsrView m;
+  float* w;
+  const float* ds;
+  float* gcold;                 // n_workers x (dp - hl) private strips, zero between iterations
+  const long long* asg_begin;
+  const long long* asg_end;
+  unsigned long long* it;       // per worker: iterations done so far (continues across exchange rounds)
+  HogState* st;
+  long long max_updates;
+  unsigned long long seed;
+  float lr, lambda;
+  float qscale, inv_qscale;     // 2^shift / vmax2 and its inverse
+  int batch, positional_bug, hl, dp;
+};
+
+__device__ __forceinline__ unsigned long long hog_mix(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned int hog_gcd32(unsigned int a, unsigned int b) {
+  while (b) {
+    const unsigned int t = a % b;
+    a = b;
+    b = t;
+  }
+  return a;
+}
+
+constexpr int HOG_THREADS = 512;   // 2 waves per SIMD: leaves registers and LDS for the master's concurrent loss check
+constexpr int HOG_R = 4;           // work items in flight per group: 32 groups x 4 = 128 item slots per sub-batch
+constexpr int HOG_CAP = HOG_THREADS / BT_G * HOG_R;
+constexpr int HOG_MAX_BATCH = 4096;
+constexpr int HOG_HL = 24576;      // ranks with an LDS accumulator (96 KiB; + 32 KiB of dsgd_eval_kernel still fit a CU)
+constexpr int HOG_SW = 8;          // accumulator slots per thread and sweep pass
+
+struct HogCtl {   // per iteration parity
+  unsigned int mul, off;
+  float s;
+  int stop;
+};
+
+__host__ __device__ constexpr int hog_lds_words(int hl, int dp) {
+  return ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8;
+}
+
+// the sampler of iteration `it`: rows base + (mul * t + off) mod n_k, t = 0..B-1 (distinct rows)
+__device__ __forceinline__ void hog_sampler(const HogArgs& a, int worker, unsigned long long it, unsigned int n_k,
+                                            HogCtl* out) {
+  const unsigned long long key = hog_mix(a.seed ^ hog_mix((unsigned long long)worker * 0x100000001B3ull + it));
+  unsigned int mul = 1u + (unsigned int)(hog_mix(key) % (unsigned long long)n_k);
+  while (hog_gcd32(mul, n_k) != 1u) mul = mul % n_k + 1u;
+  out->mul = mul;
+  out->off = (unsigned int)(hog_mix(key ^ 0xABCDEF12345ull) % (unsigned long long)n_k);
+}
+
+// Registers: the master's loss check (dsgd_eval_kernel, launched with 256-lane blocks while this engine runs: one wave
+// of 40 VGPRs per SIMD) must stay co-resident with the two waves per SIMD of this kernel (225 VGPRs -> 232 allocated):
+// 2 x 232 + 40 <= 512.  tests/test_abi.py checks both numbers in the code object's metadata.
+__global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  BtLds L;
+  L.hl = a.hl;
+  L.acc = reinterpret_cast<int*>(lds);
+  const int n_cw = (a.dp - a.hl + 31) / 32;                  // bitmap words of the cold strip (0 when dp <= hl)
+  L.cbits = reinterpret_cast<unsigned int*>(lds + a.hl);
+  int* tables = reinterpret_cast<int*>(lds) + ((a.hl + n_cw + 1) & ~1);
+  bt_carve(L, tables, HOG_CAP);
+  float* red = reinterpret_cast<float*>(tables + bt_lds_words(HOG_CAP));   // 8 floats + 8 counters
+  unsigned int* redn = reinterpret_cast<unsigned int*>(red + 8);
+  HogCtl* ctl = reinterpret_cast<HogCtl*>(red + 16);                       // 2 slots (iteration parity)
+  const int tid = threadIdx.x;
+  const int worker = blockIdx.x;
+  const long long begin = a.asg_begin[worker];
+  const unsigned int n_k = (unsigned int)(a.asg_end[worker] - begin);   // < 2^31 rows per context
+  const long long base = a.positional_bug ? 0 : begin;   // ref: core/Slave.scala:87 indexes `data` by POSITION
+  const double inv_n = 1.0 / (double)n_k;
+  float* gc = a.gcold + (long long)worker * (a.dp > a.hl ? a.dp - a.hl : 1);
+  for (int j = tid; j < a.hl + n_cw; j += HOG_THREADS) L.acc[j] = 0;   // accumulators and bitmap
+  const int B = a.batch;
+  const float fB = (float)B;
+  unsigned long long it = a.it[worker];
+  // thread 0 carries the shared scalars between iterations: what its own returning atomics saw
+  unsigned long long u = 0;
+  float s = 0.0f;
+  if (tid == 0) {
+    u = __hip_atomic_load(&a.st->updates, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s = __hip_atomic_load(&a.st->s_reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int stop = __hip_atomic_load(&a.st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    HogCtl* c0 = &ctl[it & 1];
+    hog_sampler(a, worker, it, n_k, c0);
+    c0->s = s;
+    c0->stop = stop != 0 || (long long)u >= a.max_updates;
+    hog_sampler(a, worker, it + 1, n_k, &ctl[(it + 1) & 1]);
+  }
+  __syncthreads();
+  auto wload = [&](int c) -> float {
+    // agent scope: other workgroups update w concurrently -- a plain load could be served by a stale L1 line forever
+    return __hip_atomic_load(&a.w[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto row_at = [&](unsigned long long mul, unsigned long long off, int t) -> long long {
+    const unsigned long long x = mul * (unsigned long long)t + off;          // < 2^44: exact in a double
+    long long r = (long long)x - (long long)((unsigned long long)((double)x * inv_n)) * (long long)n_k;
+    if (r < 0) r += n_k;
+    if (r >= (long long)n_k) r -= n_k;
+    return base + r;
+  };
+  if (ctl[it & 1].stop) {
+    if (tid == 0) atomicAdd(&a.st->done_blocks, 1);
+    return;
+  }
+  // prologue: stage the first iteration's sub-batch
+  BtItems<HOG_R> items;
+  int2 bd;
+  {
+    const unsigned long long mul = ctl[it & 1].mul, off = ctl[it & 1].off;
+    const BtRow row = bt_rows_issue<HOG_CAP>(a.m, B, 0, [&](int t) { return row_at(mul, off, t); }, &a.st->err);
+    bd = bt_build<HOG_THREADS, HOG_CAP>(L, B, 0, row);
+    if (bd.x > 0) bt_items_issue<HOG_THREADS, HOG_R>(a.m, L, bd.y, items);
+  }
+  for (;;) {
+    const HogCtl cur = ctl[it & 1];
+    const unsigned long long mul = cur.mul, off = cur.off;
+    const float s_it = cur.s;
+    const bool add_s = (s_it != 0.0f) && (fabsf(s_it) > DSGD_EPS);
+    auto row_of = [&](int t) { return row_at(mul, off, t); };
+    // phase 1: gated sub-gradient sum of the batch (ref: core/Slave.scala:93-98): the staged sub-batch ...
+    unsigned int n_act = 0;
+    int done = 0;
+    if (bd.x > 0) {
+      bt_items_dot<HOG_THREADS, HOG_R>(L, items, wload);
+      __syncthreads();
+      n_act += bt_gate(L, bd.x);
+      __syncthreads();
+      bt_scatter<HOG_R, false>(L, gc, items, a.qscale);
+      done = bd.x;
+    }
+    // ... and whatever did not fit its item slots (long rows, batches beyond 128 rows)
+    if (done < B) n_act += bt_batch<HOG_THREADS, HOG_R, false>(a.m, L, gc, B, done, row_of, wload, a.qscale, &a.st->err);
+    // the next iteration's sample does not depend on w: request its row records now
+    const HogCtl nxt = ctl[(it + 1) & 1];
+    const BtRow row_n = bt_rows_issue<HOG_CAP>(a.m, B, 0, [&](int t) { return row_at(nxt.mul, nxt.off, t); }, &a.st->err);
+    __syncthreads();
+    // phase 2: mean, regularise on the support, scale, subtract from the shared w (ref: Slave.scala:98-101).
+    // Dense sweep, consecutive lanes = consecutive ranks (the updates of the dense hot head coalesce); the dimSparsity
+    // values of a pass are requested together, under the mask of the non-zero accumulators, before any is used.
+    float ds_acc = 0.0f;
+    int2 bd_n = make_int2(0, 0);
+    for (int j0 = 0, pass = 0; j0 < a.hl; j0 += HOG_THREADS * HOG_SW, ++pass) {
+      int q[HOG_SW];
+      float dsv[HOG_SW];
+#pragma unroll
+      for (int e = 0; e < HOG_SW; ++e) {
+        const int j = j0 + e * HOG_THREADS + tid;
+        q[e] = j < a.hl ? L.acc[j] : 0;
+      }
+#pragma unroll
+      for (int e = 0; e < HOG_SW; ++e) {
+        dsv[e] = 0.0f;
+        if (q[e] != 0) dsv[e] = a.ds[j0 + e * HOG_THREADS + tid];
+      }
+      if (pass == 0) {
+        // the row records have landed behind the first pass's loads: tables and the non-zeros of the next sub-batch
+        // (the tables of this iteration are no longer needed: every scatter is behind the barrier above)
+        bd_n = bt_build<HOG_THREADS, HOG_CAP>(L, B, 0, row_n);
+        if (bd_n.x > 0) bt_items_issue<HOG_THREADS, HOG_R>(a.m, L, bd_n.y, items);
+      }
+#pragma unroll
+      for (int e = 0; e < HOG_SW; ++e) {
+        if (q[e] == 0) continue;
+        const int j = j0 + e * HOG_THREADS + tid;
+        L.acc[j] = 0;
+        float g = filt(((float)q[e] * a.inv_qscale) / fB);   // Vec.mean divides (ref: math/Vec.scala:139)
+        if (g == 0.0f) continue;
+        if (add_s) g = filt(g + s_it);
+        const float delta = filt(g * a.lr);
+        if (delta != 0.0f) {
+          atomicAdd(&a.w[j], -delta);   // lock-free update of the ONE weight vector
+          ds_acc += delta * dsv[e];
+        }
+      }
+    }
+    for (int wd = tid; wd < n_cw; wd += HOG_THREADS) {
+      unsigned int bits = L.cbits[wd];
+      if (!bits) continue;
+      L.cbits[wd] = 0u;
+      while (bits) {
+        const int b = __builtin_ctz(bits);
+        bits &= bits - 1u;
+        const int jc = wd * 32 + b;
+        const float dsj = a.ds[a.hl + jc];
+        const float v = atomicExch(&gc[jc], 0.0f);   // take-and-clear the private strip entry
+        float g = filt(v / fB);
+        if (g == 0.0f) continue;
+        if (add_s) g = filt(g + s_it);
+        const float delta = filt(g * a.lr);
+        if (delta != 0.0f) {
+          atomicAdd(&a.w[a.hl + jc], -delta);
+          ds_acc += delta * dsj;
+        }
+      }
+    }
+    // one returning atomic per workgroup for the incremental regulariser scalar and the update counter: thread 0
+    // continues with what they saw (no separate loads of the shared scalars in the next iteration)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ds_acc += __shfl_xor(ds_acc, o, 64);
+    n_act = wave_sum_u32(n_act);
+    if ((tid & 63) == 0) {
+      red[tid >> 6] = ds_acc;
+      redn[tid >> 6] = n_act;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float tot = 0.0f;
+      unsigned int na = 0;
+      for (int i = 0; i < HOG_THREADS / 64; ++i) {
+        tot += red[i];
+        na += redn[i];
+      }
+      const float ds_term = -2.0f * a.lambda * tot;
+      s = atomicAdd(&a.st->s_reg, ds_term) + ds_term;
+      u = atomicAdd(&a.st->updates, 1ull) + 1ull;
+      atomicAdd(&a.st->samples, (unsigned long long)B);
+      atomicAdd(&a.st->active, (unsigned long long)na);
+      const int stop = __hip_atomic_load(&a.st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      HogCtl* cn = &ctl[(it + 1) & 1];
+      cn->s = s;
+      cn->stop = stop != 0 || (long long)u >= a.max_updates;
+      hog_sampler(a, worker, it + 2, n_k, &ctl[it & 1]);   // (this iteration's slot is free: its fields are in registers)
+    }
+    __syncthreads();
+    ++it;
+    bd = bd_n;
+    if (ctl[it & 1].stop) break;
+  }
+  if (tid == 0) {
+    a.it[worker] = it;
+    atomicAdd(&a.st->done_blocks, 1);
+  }
+}
+
+// ---- cross-GPU asynchronous mode: replicas + periodic exchange of the summed updates ---------------------------
+// ref: core/Slave.scala:103-105 (every update is gossiped to every peer), :177-185 (a peer subtracts it),
+// core/MasterAsync.scala:164-177.  One single-w engine per GPU; every `exchange_every` local updates the replicas
+// all-reduce what each subtracted since the last exchange and subtract the PEERS' part on top of their own.
+__global__ void __launch_bounds__(1024) dsgd_exchange_delta_kernel(const float* __restrict__ w,
+                                                                  const float* __restrict__ wprev,
+                                                                  float* __restrict__ dsum, float* __restrict__ dlocal,
+                                                                  int dp) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) {
+    const float d = wprev[j] - w[j];
+    dsum[j] = d;     // all-reduced in place by the caller
+    dlocal[j] = d;
+  }
+}
+// w <- w - (dsum - dlocal); s <- s - 2*lambda*sum((dsum - dlocal) * ds); wprev <- w.  One workgroup (fixed-order sum).
+__global__ void __launch_bounds__(1024) dsgd_exchange_apply_kernel(float* __restrict__ w, float* __restrict__ wprev,
+                                                                  const float* __restrict__ dsum,
+                                                                  const float* __restrict__ dlocal,
+                                                                  const float* __restrict__ ds, int dp, float lambda,
+                                                                  HogState* st) {
+  __shared__ float red[16];
+  float acc = 0.0f;
+  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
+    const float o = dsum[j] - dlocal[j];   // exactly 0 with a single rank: the replica keeps its own weights bit for bit
+    float wn = w[j];
+    if (o != 0.0f) {
+      wn = filt(wn - o);
+      w[j] = wn;
+      acc += o * ds[j];
+    }
+    wprev[j] = wn;
+  }
+  const float tot = block_sum_1024(acc, red);
+  if (threadIdx.x == 0 && tot != 0.0f) st->s_reg += -2.0f * lambda * tot;
+}
+
+// ======================================================================================================
+// K1p: small-batch synchronous steps (the reference's batch-size 100-200) as ONE persistent workgroup
+// ======================================================================================================
+// ref: core/Master.scala:179-199 (the batch closure), core/Slave.scala:142-157, application.conf:15 (batch-size 100).
+// A B = 100 step is 60 KB of CSR: as separate launches (gradient rows -> regularise -> sum -> ticketed apply) it
+// took 31-41 us, all of it dependent-launch and cross-workgroup latency (profiles/README.md: a hipGraph of the same
+// chain changed nothing).  Here ONE 1024-lane workgroup owns the weights for the steps [step_begin, step_end) of a
+// resident plan and runs them back to back with nothing but workgroup barriers in between:
+//   * the hl hottest weights, their dimSparsity values and (several workers) the per-step sum `upd` live in LDS next
+//     to the fixed-point accumulators: the weight gather of ~88 % of the non-zeros and the whole update sweep of
+//     those ranks never leave the CU (global w is written through, never read back for them);
+//   * per worker k: mini-batch engine on the worker's index list (snapshot of w), then the sweep turns the batch
+//     sum into g_k = regularize(sum, w) on its support (SparseSVM.scala:31) and either applies it (one hosted worker)
+//     or adds it to `upd` in worker order (Vec.sum folds left); then w <- w - lr * (upd / K) on the union of the
+//     supports (Vec.mean, Master.scala:194-197);
+//   * the NEXT batch's index list, row records and non-zeros are requested while the current batch is swept -- only
+//     the weight gather and the gate wait for the update (the reference's synchronous semantics are kept exactly:
+//     every gradient of a step sees the weights of the previous step);
+//   * the regulariser scalar s = 2*lambda*(w . ds) is computed exactly (fp64, all D+1 products) when the launch
+//     starts and then carried in fp64 through the updates of the touched coordinates -- closer to the fp64 reference
+//     than the fp32 re-reduction of the multi-launch path, and no 47 K-element pass per step.
+// The gradient is deterministic: integer accumulation, fixed sweep order (the multi-launch path used fp32 L2
+// atomics in arrival order).
+struct PlanArgs {
+  CsrView m;
+  float* w;
+  const float* ds;
+  float* gcold;              // dp - hl floats, zero between batches
+  float* upd;                // MULTI: dp floats (ranks >= hl used), zero between steps
+  const int* idx;
+  const WorkSeg* segs;       // n_steps x n_workers
+  DevScalars* sc;
+  unsigned long long* tprof; // optional (tuning runs): shader-clock cycles of thread 0 in {gradient, sweep + staging, reduce}, steps
+  long long step_begin, step_end;
+  float k_total, lr, lambda;
+  int vexp, n_workers, dp;
+};
+
+constexpr int PLAN_THREADS = 1024;
+constexpr int PLAN_R = 2;        // 64 groups x 2 = 128 item slots per sub-batch
+constexpr int PLAN_CAP = PLAN_THREADS / BT_G * PLAN_R;
+constexpr int PLAN_HL1 = 11264;  // one hosted worker: LDS-resident ranks (accumulator + weight + dimSparsity: 12 bytes each)
+constexpr int PLAN_HLM = 8192;   // several workers: + the per-step sum (16 bytes each)
+__host__ __device__ constexpr int plan_hl(bool multi, int dp) { return (multi ? PLAN_HLM : PLAN_HL1) < dp ? (multi ? PLAN_HLM : PLAN_HL1) : dp; }
+__host__ __device__ constexpr int plan_lds_words(int dp, bool multi) {
+  const int hl = plan_hl(multi, dp);
+  const int n_cw = (dp - hl + 31) / 32;
+  return (((multi ? 4 : 3) * hl + (multi ? 2 : 1) * n_cw + 1) & ~1) + bt_lds_words(PLAN_CAP) + 32 + 8;
+}
+
+__device__ __forceinline__ double block_sum_f64(double v, double* red /* 16 doubles of LDS */) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+  return t;
+}
+
+template <bool MULTI>
+__global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int hl = plan_hl(MULTI, a.dp);
+  const int n_cw = (a.dp - hl + 31) / 32;
+  BtLds L;
+  L.hl = hl;
+  L.acc = reinterpret_cast<int*>(lds);
+  float* wl = lds + hl;                       // hot weights
+  float* dsl = lds + 2 * hl;                  // hot dimSparsity
+  float* updl = lds + 3 * hl;                 // MULTI: hot part of the per-step sum over the workers
+  L.cbits = reinterpret_cast<unsigned int*>(lds + (MULTI ? 4 : 3) * hl);
+  unsigned int* ubits = L.cbits + n_cw;       // MULTI: touched cold coordinates of `upd`
+  int* tables = reinterpret_cast<int*>(lds) + (((MULTI ? 4 : 3) * hl + (MULTI ? 2 : 1) * n_cw + 1) & ~1);
+  bt_carve(L, tables, PLAN_CAP);
+  double* red = reinterpret_cast<double*>(tables + bt_lds_words(PLAN_CAP));   // 16 doubles
+  const int tid = threadIdx.x;
+  for (int j = tid; j < hl; j += PLAN_THREADS) {
+    L.acc[j] = 0;
+    wl[j] = a.w[j];
+    dsl[j] = a.ds[j];
+    if (MULTI) updl[j] = 0.0f;
+  }
+  for (int j = tid; j < (MULTI ? 2 : 1) * n_cw; j += PLAN_THREADS) L.cbits[j] = 0u;
+  // exact w . ds of the weights this launch starts from
+  double dot_part = 0.0;
+  for (int j = tid; j < a.dp; j += PLAN_THREADS) dot_part += (double)a.w[j] * (double)a.ds[j];
+  double dot = block_sum_f64(dot_part, red);   // (also the barrier behind the LDS initialisation)
+  unsigned long long n_act_total = 0;
+  unsigned long long tp[3] = {0, 0, 0};
+
+  typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
+  auto wload = [&](int c) -> float {   // hot ranks from LDS, the tail from L1/L2 (two loads + a select of VALUES: w_at)
+    const bool hot = c < hl;
+    float v = ((lds_cvfloat*)wl)[hot ? c : 0];
+    if (!hot) v = a.w[c];
+    return v;
+  };
+  // new weight of coordinate j given the summed gradient; returns the change of w[j] * ds[j]
+  auto step_w = [&](float gsum, float wo, float dsj, float& wn) -> double {
+    const float mean = filt(gsum / a.k_total);   // Vec.mean (ref: math/Vec.scala:139)
+    const float updv = filt(mean * a.lr);        // learningRate * grad (ref: core/Master.scala:197)
+    wn = filt(wo - updv);
+    return ((double)wn - (double)wo) * (double)dsj;
+  };
+
+  const int K = a.n_workers;
+  const long long n_batches = (a.step_end - a.step_begin) * K;
+  const WorkSeg* segs = a.segs + a.step_begin * K;
+  // staging pipeline: row ids of batch n+1 are in `rid_next` while batch n is computed
+  auto load_rid = [&](long long n) -> int {
+    if (n >= n_batches) return -1;
+    const WorkSeg sg = segs[n];
+    return tid < min((long long)PLAN_CAP, sg.end - sg.begin) ? a.idx[sg.begin + tid] : -1;
+  };
+  int rid_cur = load_rid(0), rid_next = load_rid(1);
+  BtItems<PLAN_R> items;
+  int2 bd = make_int2(0, 0);
+  if (n_batches > 0) {
+    const int B0 = (int)(segs[0].end - segs[0].begin);
+    const BtRow row = bt_rows_issue<PLAN_CAP>(a.m, B0, 0, [&](int) { return (long long)rid_cur; }, &a.sc->err);
+    bd = bt_build<PLAN_THREADS, PLAN_CAP>(L, B0, 0, row);
+    if (bd.x > 0) bt_items_issue<PLAN_THREADS, PLAN_R>(a.m, L, bd.y, items);
+  }
+  float s = 0.0f;
+  bool add_s = false;
+  double ddot = 0.0;
+  unsigned int n_act = 0;
+  for (long long n = 0; n < n_batches; ++n) {
+    const int k = (int)(n % K);
+    if (k == 0) {
+      s = (float)(2.0 * (double)a.lambda * dot);   // thread-uniform: every thread carries the same dot
+      add_s = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+      ddot = 0.0;
+      n_act = 0;
+    }
+    const unsigned long long t0 = a.tprof ? __builtin_readcyclecounter() : 0ull;
+    const WorkSeg seg = segs[n];
+    const int B = (int)(seg.end - seg.begin);
+    int bits = 0;
+    while ((1 << bits) < B) ++bits;
+    const int shift = 30 - bits;   // at most one contribution per row and column: sums stay below 2^30
+    const float qscale = ldexpf(1.0f, shift - a.vexp), inv_qscale = ldexpf(1.0f, a.vexp - shift);
+    const int* __restrict__ list = a.idx + seg.begin;
+    // ---- gradient of worker k on the weights of the previous step: the staged sub-batch, then any leftovers ----
+    int done = 0;
+    if (bd.x > 0) {
+      bt_items_dot<PLAN_THREADS, PLAN_R>(L, items, wload);
+      __syncthreads();
+      n_act += bt_gate(L, bd.x);
+      __syncthreads();
+      bt_scatter<PLAN_R, true>(L, a.gcold, items, qscale);
+      done = bd.x;
+    }
+    if (done < B)
+      n_act += bt_batch<PLAN_THREADS, PLAN_R, true>(a.m, L, a.gcold, B, done, [&](int t) { return (long long)list[t]; }, wload,
+                                                   qscale, &a.sc->err);
+    // ---- the next batch does not depend on w until its weight gather: request its row records, and the row ids of
+    // the batch after it ----
+    const int Bn = n + 1 < n_batches ? (int)(segs[n + 1].end - segs[n + 1].begin) : 0;
+    const int rid_n = rid_next;
+    const BtRow row_n = bt_rows_issue<PLAN_CAP>(a.m, Bn, 0, [&](int) { return (long long)rid_n; }, &a.sc->err);
+    rid_next = load_rid(n + 2);
+    __syncthreads();   // every contribution of this batch is in the accumulators
+    const unsigned long long t1 = a.tprof ? __builtin_readcyclecounter() : 0ull;
+    // ---- sweep: this worker's regularised sum on its support; the hot ranks never leave LDS ----
+    for (int j = tid; j < hl; j += PLAN_THREADS) {
+      const int q = L.acc[j];
+      if (q == 0) continue;
+      L.acc[j] = 0;
+      float g = filt((float)q * inv_qscale);            // Vec.sum of the batch (ref: core/Slave.scala:153)
+      if (g == 0.0f) continue;
+      if (add_s) g = filt(g + s);                       // ref: core/ml/SparseSVM.scala:31, math/Vec.scala:65-75
+      if (MULTI) {
+        updl[j] = filt(updl[j] + g);                    // Vec.sum over the workers folds left
+      } else {
+        float wn;
+        ddot += step_w(g, wl[j], dsl[j], wn);
+        wl[j] = wn;
+        a.w[j] = wn;                                    // written through; never read back for a hot rank
+      }
+    }
+    for (int wd = tid; wd < n_cw; wd += PLAN_THREADS) {
+      unsigned int cb = L.cbits[wd];
+      if (!cb) continue;
+      L.cbits[wd] = 0u;
+      while (cb) {
+        const int b = __builtin_ctz(cb);
+        cb &= cb - 1u;
+        const int jc = wd * 32 + b, j = hl + jc;
+        const float old = MULTI ? a.upd[j] : a.w[j];
+        const float dsj = MULTI ? 0.0f : a.ds[j];
+        // (written with L2 atomics of this workgroup: read it there, not through L1)
+        float g = filt(__hip_atomic_exchange(&a.gcold[jc], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (g == 0.0f) continue;
+        if (add_s) g = filt(g + s);
+        if (MULTI) {
+          a.upd[j] = filt(old + g);
+          atomicOr(&ubits[jc >> 5], 1u << (jc & 31));
+        } else {
+          float wn;
+          ddot += step_w(g, old, dsj, wn);
+          a.w[j] = wn;
+        }
+      }
+    }
+    if (MULTI && k == K - 1) {
+      __syncthreads();   // the bitmap walk below crosses threads
+      // mean over the workers and the update, on the union of the supports
+      for (int j = tid; j < hl; j += PLAN_THREADS) {
+        const float u = updl[j];
+        if (u == 0.0f) continue;
+        updl[j] = 0.0f;
+        float wn;
+        ddot += step_w(u, wl[j], dsl[j], wn);
+        wl[j] = wn;
+        a.w[j] = wn;
+      }
+      for (int wd = tid; wd < n_cw; wd += PLAN_THREADS) {
+        unsigned int ub = ubits[wd];
+        if (!ub) continue;
+        ubits[wd] = 0u;
+        while (ub) {
+          const int j = hl + wd * 32 + __builtin_ctz(ub);
+          ub &= ub - 1u;
+          const float u = a.upd[j], wo = a.w[j], dsj = a.ds[j];
+          a.upd[j] = 0.0f;
+          float wn;
+          ddot += step_w(u, wo, dsj, wn);
+          a.w[j] = wn;
+        }
+      }
+    }
+    // ---- tables and non-zeros of the next batch (its row records have landed behind the sweep); the two barriers
+    // inside also order this sweep's writes of the weights before the next gather ----
+    bd = make_int2(0, 0);
+    if (Bn > 0) {
+      bd = bt_build<PLAN_THREADS, PLAN_CAP>(L, Bn, 0, row_n);
+      if (bd.x > 0) bt_items_issue<PLAN_THREADS, PLAN_R>(a.m, L, bd.y, items);
+    }
+    const unsigned long long t2 = a.tprof ? __builtin_readcyclecounter() : 0ull;
+    if (k == K - 1) {
+      dot += block_sum_f64(ddot, red);   // every thread adds the same total: `dot` stays thread-uniform
+      n_act_total += n_act;
+    }
+    if (a.tprof) {
+      tp[0] += t1 - t0;
+      tp[1] += t2 - t1;
+      tp[2] += __builtin_readcyclecounter() - t2;
+    }
+  }
+  n_act_total = (unsigned long long)wave_sum_u32((unsigned int)n_act_total);
+  if ((tid & 63) == 0 && n_act_total) atomicAdd(&a.sc->n_active, n_act_total);
+  if (tid == 0) {
+    a.sc->s_reg = (float)(2.0 * (double)a.lambda * dot);
+    if (a.tprof) {
+      a.tprof[0] += tp[0];
+      a.tprof[1] += tp[1];
+      a.tprof[2] += tp[2];
+      a.tprof[3] += (unsigned long long)(a.step_end - a.step_begin);
+    }
+  }
+}

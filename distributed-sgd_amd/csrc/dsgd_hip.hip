@@ -101,6 +101,7 @@ static bool available() {
   } while (0)
 
 #include "dsgd_kernels.hpp"
+#include "dsgd_batch.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -113,6 +114,11 @@ struct dsgd_plan {
   int n_workers = 0;
   long long max_items = 0;  // largest single list
   long long max_step_rows = 0;  // largest step (all workers together)
+};
+
+struct FusedArgs {
+  int hg, n_wg, hc, nc, n_wgc;
+  double inv_scale, inv_scale_cold;
 };
 
 struct dsgd_ctx {
@@ -204,6 +210,11 @@ struct dsgd_ctx {
   int bound_shift = 0;
   unsigned int* d_bound = nullptr;
   int max_shift = FIX_SHIFT;     // DSGD_FIX_SHIFT: cap of the per-launch fixed-point shift of the split layout
+  bool fuse_apply = true;        // DSGD_FUSE_APPLY=0: separate dsgd_fix_reduce_kernel + dsgd_apply_mb_kernel launches
+  bool fused_apply_pending = false;
+  FusedArgs fused_args{};
+  float* d_redpart = nullptr;    // per-block partial sums of w.ds and |w|^2 of the fused reduce + apply kernel
+  int redpart_cap = 0;
   bool fix_bound = true;         // DSGD_FIX_BOUND=0: keep the data-independent bound (rows per workgroup x largest value)
   int g_cap = 0;
   float* d_gsum = nullptr;  // dp (all-reduce buffer / sum over hosted workers)
@@ -249,6 +260,7 @@ struct dsgd_ctx {
   int world = 1, rank = 0;
   // profiling of the gradient kernel
   bool prof = false;
+  bool prof_main_only = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
   size_t prof_used = 0;
   std::vector<int> prof_kind;
@@ -363,7 +375,10 @@ static int grid_for(dsgd_ctx* c, long long items, int group) {
 
 // kind 0: the main gradient kernel, 1: dsgd_cdot_kernel, 2: dsgd_cgrad_kernel (split layout)
 static int prof_begin(dsgd_ctx* c, size_t* slot, int kind = 0) {
-  if (!c->prof) return DSGD_OK;
+  if (!c->prof || (kind != 0 && c->prof_main_only)) {   // (a skipped bracket: prof_end ignores the slot)
+    *slot = (size_t)-1;
+    return DSGD_OK;
+  }
   if (c->prof_used == c->prof_ev.size()) {
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
@@ -377,7 +392,7 @@ static int prof_begin(dsgd_ctx* c, size_t* slot, int kind = 0) {
   return DSGD_OK;
 }
 static int prof_end(dsgd_ctx* c, size_t slot) {
-  if (!c->prof) return DSGD_OK;
+  if (!c->prof || slot == (size_t)-1) return DSGD_OK;
   HIP_TRY(hipEventRecord(c->prof_ev[slot].second, c->stream));
   return DSGD_OK;
 }
@@ -441,6 +456,16 @@ static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
   const int dp = c->dp;
   const int blocks = (dp + 1023) / 1024;
   const float k_total = (float)n_workers * (float)c->world;
+  if (c->fused_apply_pending) {
+    c->fused_apply_pending = false;
+    const FusedArgs& f = c->fused_args;
+    hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel, dim3((dp + 63) / 64), dim3(1024), 0, c->stream, c->d_g64, c->d_w, c->d_ds,
+                       dp, f.hg, c->d_part, c->part_stride, f.n_wg, f.hc, f.nc, c->d_partc, c->partc_stride, f.n_wgc,
+                       f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart);
+    HIP_TRY(hipGetLastError());
+    c->s_dirty = false;
+    return DSGD_OK;
+  }
   if (n_workers == 1 && !c->comm) {
     // one hosted worker, no peers: regularise + "mean" over one worker + update in a single pass
     hipLaunchKernelGGL(dsgd_apply_mb_kernel<true>, dim3(std::min(64, blocks)), dim3(1024), 0, c->stream, c->d_w, c->d_g,
@@ -1084,6 +1109,21 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
     HIP_TRY(hipGetLastError());
     DSGD_TRY(prof_end(c, slot_g));
   }
+  c->fused_apply_pending = false;
+  if (n_workers == 1 && !c->comm && c->fuse_apply) {
+    // one hosted worker, no peers: the exact column sums go straight into regularise + update + next s (one launch
+    // instead of dsgd_fix_reduce_kernel + dsgd_apply_mb_kernel; g itself is never materialised)
+    const int blocks = (c->dp + 63) / 64;
+    if (blocks > c->redpart_cap) {
+      (void)hipFree(c->d_redpart);
+      c->d_redpart = nullptr;
+      HIP_TRY(hipMalloc(&c->d_redpart, sizeof(float) * 2 * (size_t)blocks));
+      c->redpart_cap = blocks;
+    }
+    c->fused_args = {hg, (int)grid.x, H, cold ? nc_lds : 0, (int)gridc.x, 1.0 / (double)main_scale, 1.0 / (double)c->fix_scale};
+    c->fused_apply_pending = true;   // launched by launch_finish_sync, which knows lr
+    return DSGD_OK;
+  }
   hipLaunchKernelGGL(dsgd_fix_reduce_kernel, dim3((c->dp + 63) / 64, n_workers), dim3(1024), 0, c->stream, c->d_g64, c->d_g,
                      (long long)c->dp, c->dp, hg, c->d_part, c->part_stride, (int)grid.x, H, cold ? nc_lds : 0, c->d_partc,
                      c->partc_stride, (int)gridc.x, 1.0 / (double)main_scale, 1.0 / (double)c->fix_scale);
@@ -1107,9 +1147,8 @@ static bool plan_kernel_ok(const dsgd_ctx* c, long long step_rows) {
 }
 static int launch_plan_kernel(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int n_workers, long long step_begin,
                               long long step_end, float lr) {
-  const int hl = std::min(c->dp, PLAN_HL);
   if (!c->d_plan_gcold) {
-    const size_t strip = (size_t)std::max(1, c->dp - hl);
+    const size_t strip = (size_t)std::max(1, c->dp - plan_hl(true, c->dp));   // (the longer of the two strips)
     HIP_TRY(hipMalloc(&c->d_plan_gcold, sizeof(float) * strip));
     HIP_TRY(hipMalloc(&c->d_plan_upd, sizeof(float) * c->dp));
     HIP_TRY(hipMemsetAsync(c->d_plan_gcold, 0, sizeof(float) * strip, c->stream));
@@ -1132,9 +1171,8 @@ static int launch_plan_kernel(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_se
   a.tprof = c->d_tprof;
   a.vexp = c->vexp;
   a.n_workers = n_workers;
-  a.hl = hl;
   a.dp = c->dp;
-  const size_t lds = sizeof(float) * (size_t)plan_lds_words(hl, c->dp, n_workers > 1);
+  const size_t lds = sizeof(float) * (size_t)plan_lds_words(c->dp, n_workers > 1);
   size_t slot = 0;
   DSGD_TRY(prof_begin(c, &slot));
   if (n_workers > 1) {
@@ -1244,6 +1282,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_DBG")) c->dbg = atoi(e);
   if (const char* e = getenv("DSGD_FIX_SHIFT")) c->max_shift = std::max(8, std::min(FIX_SHIFT, atoi(e)));
   if (const char* e = getenv("DSGD_FIX_BOUND")) c->fix_bound = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_FUSE_APPLY")) c->fuse_apply = atoi(e) != 0;
   if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;
   if (const char* e = getenv("DSGD_PLAN_MAX_ROWS")) c->plan_max_rows = std::max(1LL, atoll(e));
   if (getenv("DSGD_PLAN_PROF") && atoi(getenv("DSGD_PLAN_PROF"))) {
@@ -1345,6 +1384,7 @@ int dsgd_destroy(dsgd_ctx* c) {
   (void)hipFree(c->d_crow_ptr);
   (void)hipFree(c->d_dcold);
   (void)hipFree(c->d_bound);
+  (void)hipFree(c->d_redpart);
   if (c->async_stream) (void)hipStreamDestroy(c->async_stream);
   if (c->query_stream) (void)hipStreamDestroy(c->query_stream);
   (void)hipFree(c->d_hog);
@@ -2253,6 +2293,7 @@ int dsgd_prof_enable(dsgd_ctx* c, int32_t on) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   DSGD_TRY(prof_collect(c));
   c->prof = on != 0;
+  c->prof_main_only = on == 2;   // 2: bracket only the dominant gradient kernel (two event records per step, not six)
   return DSGD_OK;
 }
 

@@ -626,6 +626,84 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_kernel(long long* g64_ba
   }
 }
 
+// The same reduction fused with K2 + K3 for ONE hosted worker without peers (the benchmark's whole-shard step): the
+// exact column sum becomes g[j] in a register, gets the support-only regulariser (ref: core/ml/SparseSVM.scala:31),
+// the "mean" over one worker and the update (ref: core/Master.scala:194-197) -- g is never written.  The two dot
+// products of the new weights are combined by the last block to arrive, in block order (reproducible).  Every block
+// reads the old s before it takes its ticket, so the last block's write of the new s cannot be seen by any of them.
+__global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* __restrict__ g64, float* __restrict__ w,
+                                                                    const float* __restrict__ ds, int dp, int hg,
+                                                                    const int* __restrict__ part, int part_stride,
+                                                                    int n_wg, int hc, int nc,
+                                                                    const int* __restrict__ partc, int partc_stride,
+                                                                    int n_wgc, double inv_scale, double inv_scale_cold,
+                                                                    float lr, float lambda, DevScalars* sc,
+                                                                    float* __restrict__ redpart) {
+  __shared__ long long red[16][64];
+  __shared__ int is_last;
+  const float s = sc->s_reg;
+  const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+  const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cx;
+  long long q = 0;
+  if (j < hg) {
+    const int* p = part + j;
+    for (int b = ph; b < n_wg; b += 16) q += (long long)p[(long long)b * part_stride];
+  } else if (j >= hc && j < hc + nc) {
+    const int* p = partc + (j - hc);
+    for (int b = ph; b < n_wgc; b += 16) q += (long long)p[(long long)b * partc_stride];
+  }
+  red[ph][cx] = q;
+  __syncthreads();
+  if (ph == 0) {   // one wave: the 64 columns of the block
+    float dot = 0.0f, nsq = 0.0f;
+    if (j < dp) {
+      long long tot = g64[j];
+      if (tot != 0) g64[j] = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot += red[k][cx];
+      float gv = filt((float)((double)tot * (j >= hc ? inv_scale_cold : inv_scale)));   // one rounding of the exact sum
+      if (add && gv != 0.0f) gv = filt(gv + s);
+      const float upd = filt(filt(gv / 1.0f) * lr);   // Vec.mean over ONE worker, then learningRate * grad
+      const float wn = filt(w[j] - upd);
+      w[j] = wn;
+      dot = filt(wn * ds[j]);
+      nsq = wn * wn;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      dot += __shfl_xor(dot, off, 64);
+      nsq += __shfl_xor(nsq, off, 64);
+    }
+    if (cx == 0) {
+      __hip_atomic_store(&redpart[2 * blockIdx.x], dot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&redpart[2 * blockIdx.x + 1], nsq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();                                   // publish the partials before taking a ticket
+      const unsigned int t = atomicAdd(&sc->ticket, 1u);
+      is_last = (t == gridDim.x - 1);
+    }
+  }
+  __syncthreads();
+  if (is_last && ph == 0) {
+    __threadfence();                                     // acquire: the other blocks' partials
+    float d = 0.0f, qq = 0.0f;
+    for (unsigned int b = cx; b < gridDim.x; b += 64) {   // fixed assignment and order: reproducible
+      d += __hip_atomic_load(&redpart[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      qq += __hip_atomic_load(&redpart[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      d += __shfl_xor(d, off, 64);
+      qq += __shfl_xor(qq, off, 64);
+    }
+    if (cx == 0) {
+      sc->s_reg = lambda * 2.0f * d;
+      sc->wnorm2 = qq;
+      sc->ticket = 0;
+    }
+  }
+}
+
 // ---- cold columns (rank >= hg): transposed lists built once at layout time ------------------------------
 // fill: every non-zero of a cold column appends (row, value) to the column's list
 template <int G>
@@ -1681,700 +1759,5 @@ __global__ void __launch_bounds__(256) dsgd_eval_idx_kernel(CsrView m, const flo
     if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
     if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
     if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
-  }
-}
-
-// ======================================================================================================
-// Mini-batch engine: ONE workgroup computes a whole mini-batch (gather-dot, gate, batch sum, regularise, update)
-// ======================================================================================================
-// Shared by the persistent lock-free ("Hogwild") kernel and by the small-batch plan kernel (dsgd_plan_kernel): both
-// are LATENCY problems (a batch of 100 rows is 60 KB of CSR scattered over gigabytes), so the work is arranged as
-// a fixed number of dependent memory round trips per BATCH, whatever the row lengths:
-//   A  one thread per row: row_ptr / label -> row records in LDS, chunks of 128 non-zeros per row
-//   B  workgroup scan over the chunk counts -> a table of WORK ITEMS (row, chunk); as many rows as fit the
-//      NG x R item slots form a sub-batch (a batch of 100 RCV1-like rows is ~118 items: one sub-batch)
-//   C  a group of 16 lanes per item, R items per group in flight: 8 + 8 loads per lane (col, val), then the 8
-//      weights, DPP butterfly -> partial x.w of the item in LDS
-//   D  one thread per row adds the row's partials in chunk order (fixed order: x.w is reproducible), gates
-//      (core/ml/SparseSVM.scala:27-28) and leaves y or 0 as the row's coefficient
-//   E  every item -- its non-zeros are STILL IN REGISTERS -- adds coefficient * x to a fixed-point LDS accumulator
-//      (ranks < hl: ds_add_u32, exact, order-independent) or to the workgroup's private global strip plus an LDS
-//      bitmap (the few ranks >= hl)
-// and the caller's sweep over the accumulators turns the batch sum into the update.  No second pass over the CSR.
-// Fixed point: q = round(y*x * 2^shift / vmax2), shift = 30 - ceil(log2 batch): a column receives at most one
-// contribution per row, so no 32-bit word can pass 2^30; contributions below half a grid unit vanish (this
-// absorbs the reference's 1e-20 filter on y*x, math/Vec.scala:42 -> math/Sparse.scala:108-118).
-constexpr int BT_G = 16;     // lanes per work item
-constexpr int BT_K = 8;      // non-zeros per lane and item
-constexpr int BT_CH = BT_G * BT_K;   // 128 non-zeros per item
-
-struct BtLds {
-  int* acc;              // hl fixed-point accumulators, zero between batches
-  unsigned int* cbits;   // one bit per rank >= hl: the strip entry was touched by this batch
-  int hl;
-  // sub-batch tables: cap = item slots (NG x R) = most rows of a sub-batch
-  long long* rst;        // [cap] first non-zero of the row
-  int* rlen;             // [cap] its length
-  float* rcoef;          // [cap] label, then (after the gate) label or 0
-  int* ifirst;           // [cap] first work item of the row
-  int* item_row;         // [cap]
-  float* pdot;           // [cap] partial x.w per item
-  int* misc;             // [40]: 16 wave sums, 16 wave counts, item total, scratch
-};
-__host__ __device__ constexpr int bt_lds_words(int cap) { return 2 * cap + 5 * cap + 40; }
-__device__ __forceinline__ void bt_carve(BtLds& L, int* base, int cap) {
-  L.rst = reinterpret_cast<long long*>(base);   // (base is 8-byte aligned)
-  L.rlen = base + 2 * cap;
-  L.rcoef = reinterpret_cast<float*>(base + 3 * cap);
-  L.ifirst = base + 4 * cap;
-  L.item_row = base + 5 * cap;
-  L.pdot = reinterpret_cast<float*>(base + 6 * cap);
-  L.misc = base + 7 * cap;
-}
-
-// contribution of one non-zero of an active row
-__device__ __forceinline__ void bt_add(const BtLds& L, float* __restrict__ gcold, int c, float xv, float qscale) {
-  if (c < L.hl) {
-    const int q = __float2int_rn(xv * qscale);
-    if (q != 0) atomicAdd(&L.acc[c], q);   // ds_add_u32
-  } else {
-    const float f = filt(xv);
-    if (f != 0.0f) {
-      atomicAdd(&gcold[c - L.hl], f);
-      atomicOr(&L.cbits[(unsigned int)(c - L.hl) >> 5], 1u << ((c - L.hl) & 31));
-    }
-  }
-}
-
-template <bool AGENT>
-__device__ __forceinline__ float bt_load_w(const float* w, int c) {
-  // AGENT: other workgroups update w concurrently -- a plain load could be served by a stale L1 line forever
-  return AGENT ? __hip_atomic_load(const_cast<float*>(&w[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : w[c];
-}
-
-__device__ __forceinline__ int wave_incl_scan_i32(int v) {
-  v += dpp_get_i<0x111, 0xf>(v);   // row_shr:1
-  v += dpp_get_i<0x112, 0xf>(v);   // row_shr:2
-  v += dpp_get_i<0x114, 0xf>(v);   // row_shr:4
-  v += dpp_get_i<0x118, 0xf>(v);   // row_shr:8
-  v += dpp_get_i<0x142, 0xa>(v);   // row_bcast:15 -> rows 1 and 3
-  v += dpp_get_i<0x143, 0xc>(v);   // row_bcast:31 -> rows 2 and 3
-  return v;
-}
-
-// The gated batch sum of the rows row_of(0 .. B-1) into the accumulators.  Returns this thread's share of the
-// active-row count.  Rows outside [0, n_rows) raise `*bad` and are skipped.  All threads of the workgroup call it
-// (workgroup barriers inside); the caller synchronises before sweeping the accumulators.
-template <int THREADS, int R, bool AGENT, class RowOf>
-__device__ __forceinline__ unsigned int bt_batch(const CsrView& m, const float* w, const BtLds& L, float* __restrict__ gcold,
-                                                 int B, RowOf row_of, float qscale, int* bad) {
-  constexpr int NG = THREADS / BT_G, CAP = NG * R;
-  static_assert(CAP <= THREADS, "one thread per row of a sub-batch");
-  const int tid = threadIdx.x, sub = tid % BT_G, gidx = tid / BT_G, lane = tid & 63, wave = tid >> 6;
-  unsigned int n_act = 0;
-  int b0 = 0;
-  while (b0 < B) {   // workgroup-uniform
-    const int nb = min(CAP, B - b0);
-    // ---- A: row records ----
-    long long st = 0;
-    int len = 0, nch = 0;
-    float y = 0.0f;
-    if (tid < nb) {
-      long long row = row_of(b0 + tid);
-      const bool ok = row >= 0 && row < m.n_rows;
-      if (!ok) {
-        atomicOr(bad, 1);
-        row = 0;
-      }
-      st = m.row_ptr[row];
-      len = ok ? (int)(m.row_ptr[row + 1] - st) : 0;
-      y = (float)m.label[row];
-      nch = (len + BT_CH - 1) / BT_CH;   // (a skipped row has no items)
-    }
-    // ---- B: scan of the chunk counts, rows that fit the item slots ----
-    const int incl = wave_incl_scan_i32(nch);
-    if (lane == 63) L.misc[wave] = incl;
-    if (tid == 0) L.misc[32] = 0;
-    __syncthreads();
-    int first = incl - nch;
-    for (int i = 0; i < wave; ++i) first += L.misc[i];
-    const bool fits = tid < nb && first + nch <= CAP;   // monotone in tid: the fitting rows are a prefix
-    const unsigned long long bal = __builtin_amdgcn_ballot_w64(fits);
-    if (lane == 0) L.misc[16 + wave] = __popcll(bal);
-    if (fits) {
-      L.rst[tid] = st;
-      L.rlen[tid] = len;
-      L.rcoef[tid] = y;
-      L.ifirst[tid] = first;
-      for (int c = 0; c < nch; ++c) L.item_row[first + c] = tid;
-      if (nch) atomicMax(&L.misc[32], first + nch);
-    } else if (tid == 0) {   // the first row alone exceeds the item slots: whole-workgroup path below
-      L.rst[0] = st;
-      L.rlen[0] = len;
-      L.rcoef[0] = y;
-    }
-    __syncthreads();
-    int nbf = 0;
-    for (int i = 0; i < THREADS / 64; ++i) nbf += L.misc[16 + i];
-    const int n_items = L.misc[32];
-    if (nbf == 0) {
-      // ---- a single row longer than CAP x 128 non-zeros: all threads share it (never the case for RCV1) ----
-      const long long s0 = L.rst[0];
-      const int ln = L.rlen[0];
-      const float yy = L.rcoef[0];
-      float part = 0.0f;
-      for (int p = tid; p < ln; p += THREADS) part += filt(m.val[s0 + p] * bt_load_w<AGENT>(w, m.col[s0 + p]));
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
-      __syncthreads();
-      if (lane == 0) L.pdot[wave] = part;
-      __syncthreads();
-      float d = 0.0f;
-      for (int i = 0; i < THREADS / 64; ++i) d += L.pdot[i];
-      if (!(yy * d < 0.0f)) {
-        if (tid == 0) n_act++;
-        for (int p = tid; p < ln; p += THREADS) bt_add(L, gcold, m.col[s0 + p], m.val[s0 + p] * yy, qscale);
-      }
-      b0 += 1;
-      __syncthreads();
-      continue;
-    }
-    // ---- C: one group per item, R items per group in flight ----
-    int c[R][BT_K];
-    float v[R][BT_K];
-    int irow[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = r * NG + gidx;
-      const bool valid = i < n_items;
-      irow[r] = valid ? L.item_row[i] : -1;
-      const int row = valid ? irow[r] : 0;
-      const int ch = valid ? i - L.ifirst[row] : 0;
-      const long long p0 = L.rst[row] + (long long)ch * BT_CH;
-      const int cnt = valid ? min(BT_CH, L.rlen[row] - ch * BT_CH) : 0;
-#pragma unroll
-      for (int k = 0; k < BT_K; ++k) {
-        const int e = sub + k * BT_G;
-        const bool in = e < cnt;
-        c[r][k] = in ? m.col[p0 + e] : -1;
-        v[r][k] = in ? m.val[p0 + e] : 0.0f;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float acc = 0.0f;
-#pragma unroll
-      for (int k = 0; k < BT_K; ++k) acc += filt(v[r][k] * bt_load_w<AGENT>(w, c[r][k] >= 0 ? c[r][k] : 0));   // ref: math/Sparse.scala:46
-      acc = group_sum<BT_G>(acc);
-      if (sub == 0 && irow[r] >= 0) L.pdot[r * NG + gidx] = acc;
-    }
-    __syncthreads();
-    // ---- D: x.w per row in chunk order, gate ----
-    if (tid < nbf) {
-      const int f0 = L.ifirst[tid], n = (L.rlen[tid] + BT_CH - 1) / BT_CH;
-      float d = 0.0f;
-      for (int i = 0; i < n; ++i) d += L.pdot[f0 + i];
-      const float yy = L.rcoef[tid];
-      const bool active = L.rlen[tid] > 0 && !(yy * d < 0.0f);   // ref: core/ml/SparseSVM.scala:27-28
-      L.rcoef[tid] = active ? yy : 0.0f;
-      n_act += active;
-    }
-    __syncthreads();
-    // ---- E: contributions of the active rows, from registers ----
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float coef = irow[r] >= 0 ? L.rcoef[irow[r]] : 0.0f;
-      if (coef != 0.0f) {
-#pragma unroll
-        for (int k = 0; k < BT_K; ++k)
-          if (c[r][k] >= 0) bt_add(L, gcold, c[r][k], v[r][k] * coef, qscale);
-      }
-    }
-    b0 += nbf;
-    // (the next sub-batch writes only misc[] before its first barrier; nothing above reads misc[] after the last one)
-  }
-  return n_act;
-}
-
-// ======================================================================================================
-// K7: persistent lock-free ("Hogwild") engine -- Slave.asyncTask for many workers sharing ONE w
-// ======================================================================================================
-// ref: core/Slave.scala:79-111 (the loop), :177-185 / core/MasterAsync.scala:164-177 (applying updates),
-//      README.md:35 (Recht et al. 2011).
-// The reference gives every slave its own replica of w and gossips each update to every peer, who
-// subtracts it; with all workers on one GPU the replicas collapse into a single device-resident w that
-// every worker (= workgroup) reads without locks and updates with atomicAdd(w[j], -delta_j).
-// One iteration of a worker:
-//   draw `batch` rows of its assigned range -> gated sub-gradients on whatever w holds right now -> batch sum
-//   (mini-batch engine above) -> MEAN over the batch -> support-only regulariser with s = 2*lambda*(w.ds) -> scale
-//   by lr -> atomicAdd into w.  The scalar s is kept up to date incrementally (s -= 2*lambda*sum(delta_j*ds_j))
-//   instead of re-reducing 47 K products per mini-batch as SparseSVM.regularize does.
-// SAMPLING (deliberate deviation): Slave.scala:87 draws `Random.shuffle(indices) take B`; a
-// device-side Fisher-Yates of a 20,000-row range per mini-batch would cost more than the mini-batch.  The engine
-// draws the affine progression rows (mul * t + off) mod n, t = 0..B-1 with gcd(mul, n) = 1 from a counter-based
-// generator keyed by (seed, worker, iteration): B DISTINCT rows of the range, every row equally likely, replayable
-// on the host (tests/test_gpu_parity.py hog_rows) -- but not the JVM's stream and not a uniform B-subset.
-// batch == 1 is a single uniform draw, as Slave.scala:84.  The wire-level worker (wire.SlaveWorker) replays the JVM
-// generator exactly for hosts that need it.
-struct HogState {
-  unsigned long long updates;   // mini-batch updates applied (MasterAsync counts these: MasterAsync.scala:83,171)
-  unsigned long long samples;   // rows whose gradient was computed
-  unsigned long long active;    // ... of which the gate let through
-  float s_reg;                  // 2 * lambda * (w . ds), maintained incrementally
-  int done_blocks;
-  int stop;                     // raised by the host (copy on a side stream): workers exit after their mini-batch
-  int err;                      // a sampled row fell outside the data
-};
-
-struct HogArgs {
-  CsrView m;
-  float* w;
-  const float* ds;
-  float* gcold;                 // n_workers x (dp - hl) private strips, zero between iterations
-  const long long* asg_begin;
-  const long long* asg_end;
-  unsigned long long* it;       // per worker: iterations done so far (continues across exchange rounds)
-  HogState* st;
-  long long max_updates;
-  unsigned long long seed;
-  float lr, lambda;
-  float qscale, inv_qscale;     // 2^shift / vmax2 and its inverse
-  int batch, positional_bug, hl, dp;
-};
-
-__device__ __forceinline__ unsigned long long hog_mix(unsigned long long z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-__device__ __forceinline__ unsigned int hog_gcd32(unsigned int a, unsigned int b) {
-  while (b) {
-    const unsigned int t = a % b;
-    a = b;
-    b = t;
-  }
-  return a;
-}
-
-constexpr int HOG_THREADS = 512;   // 2 waves per SIMD: leaves registers and LDS for the master's concurrent loss check
-constexpr int HOG_R = 4;           // work items in flight per group: 32 groups x 4 = 128 item slots per sub-batch
-constexpr int HOG_CAP = HOG_THREADS / BT_G * HOG_R;
-constexpr int HOG_MAX_BATCH = 4096;
-constexpr int HOG_HL = 24576;      // ranks with an LDS accumulator (96 KiB; + 32 KiB of dsgd_eval_kernel still fit a CU)
-constexpr int HOG_SW = 8;          // accumulator slots per thread and sweep pass
-
-struct HogCtl {
-  int stop;
-  unsigned int mul, off;
-  float s;
-};
-
-__host__ __device__ constexpr int hog_lds_words(int hl, int dp) {
-  return ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8;
-}
-
-__global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  BtLds L;
-  L.hl = a.hl;
-  L.acc = reinterpret_cast<int*>(lds);
-  const int n_cw = (a.dp - a.hl + 31) / 32;                  // bitmap words of the cold strip (0 when dp <= hl)
-  L.cbits = reinterpret_cast<unsigned int*>(lds + a.hl);
-  int* tables = reinterpret_cast<int*>(lds) + ((a.hl + n_cw + 1) & ~1);
-  bt_carve(L, tables, HOG_CAP);
-  float* red = reinterpret_cast<float*>(tables + bt_lds_words(HOG_CAP));   // 8 floats + 8 counters + control
-  unsigned int* redn = reinterpret_cast<unsigned int*>(red + 8);
-  HogCtl* ctl = reinterpret_cast<HogCtl*>(red + 16);
-  const int tid = threadIdx.x;
-  const int worker = blockIdx.x;
-  const long long begin = a.asg_begin[worker];
-  const unsigned int n_k = (unsigned int)(a.asg_end[worker] - begin);   // < 2^31 rows per context
-  const long long base = a.positional_bug ? 0 : begin;   // ref: core/Slave.scala:87 indexes `data` by POSITION
-  const double inv_n = 1.0 / (double)n_k;
-  float* gc = a.gcold + (long long)worker * (a.dp > a.hl ? a.dp - a.hl : 1);
-  for (int j = tid; j < a.hl + n_cw; j += HOG_THREADS) L.acc[j] = 0;   // accumulators and bitmap
-  const int B = a.batch;
-  const float fB = (float)B;
-  unsigned long long it = a.it[worker];
-  // thread 0 carries the shared scalars between iterations: what its own returning atomics saw
-  unsigned long long u = 0;
-  float s = 0.0f;
-  int stop = 0;
-  if (tid == 0) {
-    u = __hip_atomic_load(&a.st->updates, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s = __hip_atomic_load(&a.st->s_reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    stop = __hip_atomic_load(&a.st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  for (;;) {
-    if (tid == 0) {
-      ctl->stop = stop != 0 || (long long)u >= a.max_updates;
-      // this iteration's sample: rows base + (mul * t + off) mod n_k, t = 0..B-1 (distinct rows)
-      const unsigned long long key = hog_mix(a.seed ^ hog_mix((unsigned long long)worker * 0x100000001B3ull + it));
-      unsigned int mul = 1u + (unsigned int)(hog_mix(key) % (unsigned long long)n_k);
-      while (hog_gcd32(mul, n_k) != 1u) mul = mul % n_k + 1u;
-      ctl->mul = mul;
-      ctl->off = (unsigned int)(hog_mix(key ^ 0xABCDEF12345ull) % (unsigned long long)n_k);
-      ctl->s = s;
-    }
-    __syncthreads();
-    if (ctl->stop) break;
-    const unsigned long long mul = ctl->mul, off = ctl->off;
-    const float s_it = ctl->s;
-    const bool add_s = (s_it != 0.0f) && (fabsf(s_it) > DSGD_EPS);
-    // phase 1: gated sub-gradient sum of the batch (ref: core/Slave.scala:93-98)
-    auto row_of = [&](int t) -> long long {
-      const unsigned long long x = mul * (unsigned long long)t + off;          // < 2^44: exact in a double
-      long long r = (long long)x - (long long)((unsigned long long)((double)x * inv_n)) * (long long)n_k;
-      if (r < 0) r += n_k;
-      if (r >= (long long)n_k) r -= n_k;
-      return base + r;
-    };
-    unsigned int n_act = bt_batch<HOG_THREADS, HOG_R, true>(a.m, a.w, L, gc, B, row_of, a.qscale, &a.st->err);
-    __syncthreads();
-    // phase 2: mean, regularise on the support, scale, subtract from the shared w (ref: Slave.scala:98-101).
-    // Dense sweep, consecutive lanes = consecutive ranks (the updates of the dense hot head coalesce); the dimSparsity
-    // values of a pass are requested together, under the mask of the non-zero accumulators, before any is used.
-    float ds_acc = 0.0f;
-    for (int j0 = 0; j0 < a.hl; j0 += HOG_THREADS * HOG_SW) {
-      int q[HOG_SW];
-      float dsv[HOG_SW];
-#pragma unroll
-      for (int e = 0; e < HOG_SW; ++e) {
-        const int j = j0 + e * HOG_THREADS + tid;
-        q[e] = j < a.hl ? L.acc[j] : 0;
-      }
-#pragma unroll
-      for (int e = 0; e < HOG_SW; ++e) {
-        dsv[e] = 0.0f;
-        if (q[e] != 0) dsv[e] = a.ds[j0 + e * HOG_THREADS + tid];
-      }
-#pragma unroll
-      for (int e = 0; e < HOG_SW; ++e) {
-        if (q[e] == 0) continue;
-        const int j = j0 + e * HOG_THREADS + tid;
-        L.acc[j] = 0;
-        float g = filt(((float)q[e] * a.inv_qscale) / fB);   // Vec.mean divides (ref: math/Vec.scala:139)
-        if (g == 0.0f) continue;
-        if (add_s) g = filt(g + s_it);
-        const float delta = filt(g * a.lr);
-        if (delta != 0.0f) {
-          atomicAdd(&a.w[j], -delta);   // lock-free update of the ONE weight vector
-          ds_acc += delta * dsv[e];
-        }
-      }
-    }
-    for (int wd = tid; wd < n_cw; wd += HOG_THREADS) {
-      unsigned int bits = L.cbits[wd];
-      if (!bits) continue;
-      L.cbits[wd] = 0u;
-      while (bits) {
-        const int b = __builtin_ctz(bits);
-        bits &= bits - 1u;
-        const int jc = wd * 32 + b;
-        const float dsj = a.ds[a.hl + jc];
-        const float v = atomicExch(&gc[jc], 0.0f);   // take-and-clear the private strip entry
-        float g = filt(v / fB);
-        if (g == 0.0f) continue;
-        if (add_s) g = filt(g + s_it);
-        const float delta = filt(g * a.lr);
-        if (delta != 0.0f) {
-          atomicAdd(&a.w[a.hl + jc], -delta);
-          ds_acc += delta * dsj;
-        }
-      }
-    }
-    // one returning atomic per workgroup for the incremental regulariser scalar and the update counter: thread 0
-    // continues with what they saw (no separate loads of the shared scalars in the next iteration)
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) ds_acc += __shfl_xor(ds_acc, o, 64);
-    n_act = wave_sum_u32(n_act);
-    if ((tid & 63) == 0) {
-      red[tid >> 6] = ds_acc;
-      redn[tid >> 6] = n_act;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      float tot = 0.0f;
-      unsigned int na = 0;
-      for (int i = 0; i < HOG_THREADS / 64; ++i) {
-        tot += red[i];
-        na += redn[i];
-      }
-      const float ds_term = -2.0f * a.lambda * tot;
-      s = atomicAdd(&a.st->s_reg, ds_term) + ds_term;
-      u = atomicAdd(&a.st->updates, 1ull) + 1ull;
-      atomicAdd(&a.st->samples, (unsigned long long)B);
-      atomicAdd(&a.st->active, (unsigned long long)na);
-      stop = __hip_atomic_load(&a.st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    ++it;
-  }
-  if (tid == 0) {
-    a.it[worker] = it;
-    atomicAdd(&a.st->done_blocks, 1);
-  }
-}
-
-// ---- cross-GPU asynchronous mode: replicas + periodic exchange of the summed updates ---------------------------
-// ref: core/Slave.scala:103-105 (every update is gossiped to every peer), :177-185 (a peer subtracts it),
-// core/MasterAsync.scala:164-177.  One single-w engine per GPU; every `exchange_every` local updates the replicas
-// all-reduce what each subtracted since the last exchange and subtract the PEERS' part on top of their own.
-__global__ void __launch_bounds__(1024) dsgd_exchange_delta_kernel(const float* __restrict__ w,
-                                                                  const float* __restrict__ wprev,
-                                                                  float* __restrict__ dsum, float* __restrict__ dlocal,
-                                                                  int dp) {
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) {
-    const float d = wprev[j] - w[j];
-    dsum[j] = d;     // all-reduced in place by the caller
-    dlocal[j] = d;
-  }
-}
-// w <- w - (dsum - dlocal); s <- s - 2*lambda*sum((dsum - dlocal) * ds); wprev <- w.  One workgroup (fixed-order sum).
-__global__ void __launch_bounds__(1024) dsgd_exchange_apply_kernel(float* __restrict__ w, float* __restrict__ wprev,
-                                                                  const float* __restrict__ dsum,
-                                                                  const float* __restrict__ dlocal,
-                                                                  const float* __restrict__ ds, int dp, float lambda,
-                                                                  HogState* st) {
-  __shared__ float red[16];
-  float acc = 0.0f;
-  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
-    const float o = dsum[j] - dlocal[j];   // exactly 0 with a single rank: the replica keeps its own weights bit for bit
-    float wn = w[j];
-    if (o != 0.0f) {
-      wn = filt(wn - o);
-      w[j] = wn;
-      acc += o * ds[j];
-    }
-    wprev[j] = wn;
-  }
-  const float tot = block_sum_1024(acc, red);
-  if (threadIdx.x == 0 && tot != 0.0f) st->s_reg += -2.0f * lambda * tot;
-}
-
-// ======================================================================================================
-// K1p: small-batch synchronous steps (the reference's batch-size 100-200) as ONE persistent workgroup
-// ======================================================================================================
-// ref: core/Master.scala:179-199 (the batch closure), core/Slave.scala:142-157, application.conf:15 (batch-size 100).
-// A B = 100 step is 60 KB of CSR: as separate launches (gradient rows -> regularise -> sum -> ticketed apply) it
-// took 31-41 us, all of it dependent-launch and cross-workgroup latency (profiles/README.md: a hipGraph of the same
-// chain changed nothing).  Here ONE 1024-lane workgroup runs the steps [step_begin, step_end) of a resident plan
-// back to back with nothing but workgroup barriers in between:
-//   per worker k:  mini-batch engine phase 1 on the worker's index list (snapshot of w), then the sweep turns the
-//                  fixed-point batch sum into g_k = regularize(sum, w) on its support (SparseSVM.scala:31) and either
-//                  applies it (one hosted worker) or adds it to `upd` in worker order (Vec.sum folds left);
-//   then           w <- w - lr * (upd / K) on the union of the supports (Vec.mean, Master.scala:194-197).
-// The regulariser scalar s = 2*lambda*(w . ds) is computed exactly (fp64, all D+1 products) when the launch starts
-// and then carried in fp64 through the updates of the touched coordinates -- closer to the fp64 reference than the
-// fp32 re-reduction of the multi-launch path, and no 47 K-element pass per step.
-// The gradient is deterministic: integer accumulation, fixed sweep order (the multi-launch path used fp32 L2
-// atomics in arrival order).
-struct PlanArgs {
-  CsrView m;
-  float* w;
-  const float* ds;
-  float* gcold;              // dp - hl floats, zero between batches
-  float* upd;                // MULTI: dp floats, zero between steps
-  const int* idx;
-  const WorkSeg* segs;       // n_steps x n_workers
-  DevScalars* sc;
-  unsigned long long* tprof; // optional (tuning runs): shader-clock cycles of thread 0 in {gradient, sweep, reduce}, steps
-  long long step_begin, step_end;
-  float k_total, lr, lambda;
-  int vexp, n_workers, hl, dp;
-};
-
-constexpr int PLAN_THREADS = 1024;
-constexpr int PLAN_R = 3;        // 64 groups x 3 = 192 item slots per sub-batch
-constexpr int PLAN_CAP = PLAN_THREADS / BT_G * PLAN_R;
-constexpr int PLAN_HL = 24576;   // ranks with an LDS accumulator: one sweep pass of 24 slots per thread
-constexpr int PLAN_SW = 8;       // accumulator slots per thread and sweep pass (3 passes over PLAN_HL)
-constexpr int PLAN_HD = 4096;    // MULTI: ranks below this are swept densely in the final apply, the rest via a bitmap
-
-__host__ __device__ constexpr int plan_lds_words(int hl, int dp, bool multi) {
-  return ((hl + (dp - hl + 31) / 32 + (multi ? (dp + 31) / 32 : 0) + 1) & ~1) + bt_lds_words(PLAN_CAP) + 32 + 8;
-}
-
-__device__ __forceinline__ double block_sum_f64(double v, double* red /* 16 doubles of LDS */) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double t = 0.0;
-  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
-  return t;
-}
-
-template <bool MULTI>
-__global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  BtLds L;
-  L.hl = a.hl;
-  L.acc = reinterpret_cast<int*>(lds);
-  const int n_cw = (a.dp - a.hl + 31) / 32;
-  const int n_uw = MULTI ? (a.dp + 31) / 32 : 0;
-  L.cbits = reinterpret_cast<unsigned int*>(lds + a.hl);
-  unsigned int* ubits = L.cbits + n_cw;                                  // MULTI: touched coordinates of `upd`
-  int* tables = reinterpret_cast<int*>(lds) + ((a.hl + n_cw + n_uw + 1) & ~1);
-  bt_carve(L, tables, PLAN_CAP);
-  double* red = reinterpret_cast<double*>(tables + bt_lds_words(PLAN_CAP));   // 16 doubles
-  const int tid = threadIdx.x;
-  for (int j = tid; j < a.hl + n_cw + n_uw; j += PLAN_THREADS) L.acc[j] = 0;
-  // exact w . ds of the weights this launch starts from
-  double dot_part = 0.0;
-  for (int j = tid; j < a.dp; j += PLAN_THREADS) dot_part += (double)a.w[j] * (double)a.ds[j];
-  double dot = block_sum_f64(dot_part, red);   // (also the barrier behind the LDS zeroing)
-  unsigned long long n_act_total = 0;
-  unsigned long long tp[3] = {0, 0, 0};
-
-  // w[j] <- w[j] - lr * (gsum / K) given the old weight and ds[j]; returns the change of w[j] * ds[j]
-  auto apply = [&](int j, float gsum, float wo, float dsj) -> double {
-    const float mean = filt(gsum / a.k_total);   // Vec.mean (ref: math/Vec.scala:139)
-    const float updv = filt(mean * a.lr);        // learningRate * grad (ref: core/Master.scala:197)
-    if (updv == 0.0f) return 0.0;
-    const float wn = filt(wo - updv);
-    a.w[j] = wn;
-    return ((double)wn - (double)wo) * (double)dsj;
-  };
-
-  for (long long step = a.step_begin; step < a.step_end; ++step) {
-    const float s = (float)(2.0 * (double)a.lambda * dot);   // thread-uniform: every thread carries the same dot
-    const bool add_s = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
-    double ddot = 0.0;
-    unsigned int n_act = 0;
-    for (int k = 0; k < a.n_workers; ++k) {
-      const unsigned long long t0 = a.tprof ? __builtin_readcyclecounter() : 0ull;
-      const WorkSeg seg = a.segs[step * a.n_workers + k];
-      const int B = (int)(seg.end - seg.begin);
-      int bits = 0;
-      while ((1 << bits) < B) ++bits;
-      const int shift = 30 - bits;   // at most one contribution per row and column: sums stay below 2^30
-      const float qscale = ldexpf(1.0f, shift - a.vexp), inv_qscale = ldexpf(1.0f, a.vexp - shift);
-      const int* __restrict__ list = a.idx + seg.begin;
-      auto row_of = [&](int t) -> long long { return (long long)list[t]; };
-      // (the multi-worker instantiation carries the `upd` bookkeeping: 2 items per group keep it out of scratch)
-      n_act += bt_batch<PLAN_THREADS, MULTI ? 2 : PLAN_R, false>(a.m, a.w, L, a.gcold, B, row_of, qscale, &a.sc->err);
-      __syncthreads();
-      const unsigned long long t1 = a.tprof ? __builtin_readcyclecounter() : 0ull;
-      // sweep: this worker's regularised sum on its support.  Per pass: 8 accumulators of the thread, then (under
-      // the mask of the non-zero ones) every weight / dimSparsity value they need, then the arithmetic.
-      for (int j0 = 0; j0 < a.hl; j0 += PLAN_THREADS * PLAN_SW) {
-        int q[PLAN_SW];
-        float wo[PLAN_SW], dsv[PLAN_SW];
-#pragma unroll
-        for (int e = 0; e < PLAN_SW; ++e) {
-          const int j = j0 + e * PLAN_THREADS + tid;
-          q[e] = j < a.hl ? L.acc[j] : 0;
-        }
-#pragma unroll
-        for (int e = 0; e < PLAN_SW; ++e) {
-          wo[e] = 0.0f;
-          dsv[e] = 0.0f;
-          if (q[e] != 0) {
-            const int j = j0 + e * PLAN_THREADS + tid;
-            wo[e] = MULTI ? a.upd[j] : a.w[j];
-            if (!MULTI) dsv[e] = a.ds[j];
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < PLAN_SW; ++e) {
-          if (q[e] == 0) continue;
-          const int j = j0 + e * PLAN_THREADS + tid;
-          L.acc[j] = 0;
-          float g = filt((float)q[e] * inv_qscale);            // Vec.sum of the batch (ref: core/Slave.scala:153)
-          if (g == 0.0f) continue;
-          if (add_s) g = filt(g + s);                          // ref: core/ml/SparseSVM.scala:31, math/Vec.scala:65-75
-          if (MULTI) {
-            a.upd[j] = filt(wo[e] + g);                        // Vec.sum over the workers folds left
-            if (j >= PLAN_HD) atomicOr(&ubits[j >> 5], 1u << (j & 31));
-          } else {
-            ddot += apply(j, g, wo[e], dsv[e]);
-          }
-        }
-      }
-      for (int wd = tid; wd < n_cw; wd += PLAN_THREADS) {
-        unsigned int cb = L.cbits[wd];
-        if (!cb) continue;
-        L.cbits[wd] = 0u;
-        while (cb) {
-          const int b = __builtin_ctz(cb);
-          cb &= cb - 1u;
-          const int jc = wd * 32 + b, j = a.hl + jc;
-          const float old = MULTI ? a.upd[j] : a.w[j];
-          const float dsj = MULTI ? 0.0f : a.ds[j];
-          float g = filt(atomicExch(&a.gcold[jc], 0.0f));   // (written with L2 atomics: read it there, not through L1)
-          if (g == 0.0f) continue;
-          if (add_s) g = filt(g + s);
-          if (MULTI) {
-            a.upd[j] = filt(old + g);
-            atomicOr(&ubits[j >> 5], 1u << (j & 31));
-          } else {
-            ddot += apply(j, g, old, dsj);
-          }
-        }
-      }
-      __syncthreads();   // accumulators are clean (and, MULTI, upd is written) before the next worker's phase 1
-      if (a.tprof) {
-        tp[0] += t1 - t0;
-        tp[1] += __builtin_readcyclecounter() - t1;
-      }
-    }
-    const unsigned long long t2 = a.tprof ? __builtin_readcyclecounter() : 0ull;
-    if (MULTI) {
-      // mean over the workers and the update, on the union of the supports
-      {
-        constexpr int ND = PLAN_HD / PLAN_THREADS;
-        float u[ND], wo[ND], dsv[ND];
-#pragma unroll
-        for (int e = 0; e < ND; ++e) {
-          const int j = e * PLAN_THREADS + tid;
-          u[e] = j < a.dp ? a.upd[j] : 0.0f;
-        }
-#pragma unroll
-        for (int e = 0; e < ND; ++e) {
-          wo[e] = 0.0f;
-          dsv[e] = 0.0f;
-          if (u[e] != 0.0f) {
-            wo[e] = a.w[e * PLAN_THREADS + tid];
-            dsv[e] = a.ds[e * PLAN_THREADS + tid];
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < ND; ++e) {
-          if (u[e] == 0.0f) continue;
-          const int j = e * PLAN_THREADS + tid;
-          a.upd[j] = 0.0f;
-          ddot += apply(j, u[e], wo[e], dsv[e]);
-        }
-      }
-      for (int wd = PLAN_HD / 32 + tid; wd < n_uw; wd += PLAN_THREADS) {
-        unsigned int ub = ubits[wd];
-        if (!ub) continue;
-        ubits[wd] = 0u;
-        while (ub) {
-          const int j = wd * 32 + __builtin_ctz(ub);
-          ub &= ub - 1u;
-          const float u = a.upd[j], wo = a.w[j], dsj = a.ds[j];
-          a.upd[j] = 0.0f;
-          ddot += apply(j, u, wo, dsj);
-        }
-      }
-    }
-    dot += block_sum_f64(ddot, red);   // every thread adds the same total: `dot` stays thread-uniform
-    n_act_total += n_act;
-    if (a.tprof) tp[2] += __builtin_readcyclecounter() - t2;
-    // (block_sum_f64's barriers also order this step's writes of w before the next step's reads)
-  }
-  n_act_total = (unsigned long long)wave_sum_u32((unsigned int)n_act_total);
-  if ((tid & 63) == 0 && n_act_total) atomicAdd(&a.sc->n_active, n_act_total);
-  if (tid == 0) {
-    a.sc->s_reg = (float)(2.0 * (double)a.lambda * dot);
-    if (a.tprof) {
-      a.tprof[0] += tp[0];
-      a.tprof[1] += tp[1];
-      a.tprof[2] += tp[2];
-      a.tprof[3] += (unsigned long long)(a.step_end - a.step_begin);
-    }
   }
 }

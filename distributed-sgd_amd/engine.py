@@ -212,7 +212,8 @@ class Engine:
 
     # -- profiling ---------------------------------------------------------------------------------
     def prof_enable(self, on=True):
-        check(self._lib.dsgd_prof_enable(self._ctx, C.c_int32(1 if on else 0)))
+        """0 / False: off; 1 / True: bracket every profiled kernel; 2: the dominant gradient kernel only."""
+        check(self._lib.dsgd_prof_enable(self._ctx, C.c_int32(int(on))))
 
     def prof_read(self, reset=True):
         ms, n = C.c_double(0), C.c_int64(0)

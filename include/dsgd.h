@@ -198,7 +198,7 @@ int dsgd_comm_destroy(dsgd_ctx* ctx);
 /* ---- introspection for benchmarks ---------------------------------------------------------
  * average device time (ms) of the dominant gradient kernel over its launches since the last
  * reset, measured with HIP events on the launch stream; n_launches may be NULL.               */
-int dsgd_prof_enable(dsgd_ctx* ctx, int32_t on);
+int dsgd_prof_enable(dsgd_ctx* ctx, int32_t on /* 0 off, 1 all profiled kernels, 2 the dominant kernel only */);
 int dsgd_prof_read(dsgd_ctx* ctx, double* grad_kernel_ms_avg, int64_t* n_launches, int32_t reset);
 /* Split layout only: average duration (ms) and launch count of {main gradient kernel, cold x.w kernel, cold
  * gradient kernel} since the last reset of dsgd_prof_read.  Measurement aid; nothing in the reference. */
