@@ -366,7 +366,7 @@ __device__ __forceinline__ void hog_sampler(const HogArgs& a, int worker, unsign
 
 // Registers: the master's loss check (dsgd_eval_kernel, launched with 256-lane blocks while this engine runs: one wave
 // of 40 VGPRs per SIMD) must stay co-resident with the two waves per SIMD of this kernel (225 VGPRs -> 232 allocated):
-// 2 x 232 + 40 <= 512.  tests/test_abi.py checks both numbers in the code object's metadata.
+// 2 x 232 + 40 <= 512.
 __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   BtLds L;

@@ -1964,19 +1964,21 @@ int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_en
     DSGD_TRY(launch_stream<false>(c, ssegs));
   } else {
     const int G = c->group;
-    const long long groups_per_block = 1024 / G;
+    // beside the persistent Hogwild engine (2 waves x 232 VGPRs per SIMD, 103 KB of LDS) only ONE more wave per SIMD
+    // and 32 KB of LDS fit a CU: 256-lane blocks with a small weight tile, one per CU
+    const int bs = c->async_running ? 256 : 1024;
+    const long long groups_per_block = bs / G;
     const long long rows = row_end - row_begin;
     dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(c->n_cu, (rows + groups_per_block - 1) / groups_per_block)));
     // small ranges do not amortise staging 160 KiB of weights per workgroup: shrink the LDS tile
-    // while the Hogwild engine owns most of every CU's LDS, keep the footprint small enough to co-reside
     const int hw = c->async_running ? std::min(c->hw_eval, 8192) : (rows >= 4096 ? c->hw_eval : std::min(c->hw_eval, 1024));
     const size_t lds = sizeof(float) * (size_t)hw;
     CsrView m = view(c);
     switch (G) {
-      case 64: hipLaunchKernelGGL(dsgd_eval_kernel<64>, grid, dim3(1024), lds, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc, hw); break;
-      case 32: hipLaunchKernelGGL(dsgd_eval_kernel<32>, grid, dim3(1024), lds, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc, hw); break;
-      case 16: hipLaunchKernelGGL(dsgd_eval_kernel<16>, grid, dim3(1024), lds, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc, hw); break;
-      default: hipLaunchKernelGGL(dsgd_eval_kernel<8>, grid, dim3(1024), lds, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc, hw); break;
+      case 64: hipLaunchKernelGGL(dsgd_eval_kernel<64>, grid, dim3(bs), lds, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc, hw); break;
+      case 32: hipLaunchKernelGGL(dsgd_eval_kernel<32>, grid, dim3(bs), lds, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc, hw); break;
+      case 16: hipLaunchKernelGGL(dsgd_eval_kernel<16>, grid, dim3(bs), lds, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc, hw); break;
+      default: hipLaunchKernelGGL(dsgd_eval_kernel<8>, grid, dim3(bs), lds, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc, hw); break;
     }
     HIP_TRY(hipGetLastError());
   }

@@ -474,11 +474,11 @@ __global__ void __launch_bounds__(1024) dsgd_eval_kernel(CsrView m, const float*
   constexpr int UNR = 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* wl = lds;
-  for (int j = threadIdx.x; j < hw; j += 1024) wl[j] = w[j];
+  for (int j = threadIdx.x; j < hw; j += blockDim.x) wl[j] = w[j];
   __syncthreads();
   const int sub = threadIdx.x % G;
-  const long long group = ((long long)blockIdx.x * 1024 + threadIdx.x) / G;
-  const long long n_groups = (long long)gridDim.x * 1024 / G;
+  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const long long n_groups = (long long)gridDim.x * blockDim.x / G;   // (256-lane blocks beside the Hogwild engine, 1024 otherwise)
   unsigned int c0 = 0, c1 = 0, c2 = 0;
   for (long long row = row_begin + group; row < row_end; row += n_groups) {
     RowRegs<G, UNR> r;
