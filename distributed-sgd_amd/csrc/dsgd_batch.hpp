@@ -115,20 +115,31 @@ __device__ __forceinline__ BtRow bt_rows_issue(const CsrView& m, int B, int b0, 
   return r;
 }
 
-// tables of the sub-batch: returns {rows that fit the item slots (a prefix), work items}.  Two workgroup barriers.
+// tables of the sub-batch in three parts around two workgroup barriers (a caller with barriers of its own in the
+// right places shares them): p1 ... barrier ... p2 ... barrier ... p3 returns {rows that fit the item slots (a
+// prefix), work items}.  p1/p2 write L.misc and (p2) the tables of L; nothing else.
+struct BtScan {
+  int nch, incl;
+};
 template <int THREADS, int CAP>
-__device__ __forceinline__ int2 bt_build(const BtLds& L, int B, int b0, const BtRow& row) {
+__device__ __forceinline__ BtScan bt_build_p1(const BtLds& L, int B, int b0, const BtRow& row) {
   static_assert(CAP <= THREADS, "one thread per row of a sub-batch");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = min(CAP, B - b0);
-  const int nch = tid < nb ? (row.len + BT_CH - 1) / BT_CH : 0;
-  const int incl = wave_incl_scan_i32(nch);
-  if (lane == 63) L.misc[wave] = incl;
+  BtScan sc;
+  sc.nch = tid < nb ? (row.len + BT_CH - 1) / BT_CH : 0;
+  sc.incl = wave_incl_scan_i32(sc.nch);
+  if (lane == 63) L.misc[wave] = sc.incl;
   if (tid == 0) L.misc[32] = 0;
-  __syncthreads();
-  int first = incl - nch;
+  return sc;
+}
+template <int THREADS, int CAP>
+__device__ __forceinline__ void bt_build_p2(const BtLds& L, int B, int b0, const BtRow& row, const BtScan& sc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = min(CAP, B - b0);
+  int first = sc.incl - sc.nch;
   for (int i = 0; i < wave; ++i) first += L.misc[i];
-  const bool fits = tid < nb && first + nch <= CAP;   // monotone in tid: the fitting rows are a prefix
+  const bool fits = tid < nb && first + sc.nch <= CAP;   // monotone in tid: the fitting rows are a prefix
   const unsigned long long bal = __builtin_amdgcn_ballot_w64(fits);
   if (lane == 0) L.misc[16 + wave] = __popcll(bal);
   if (fits) {
@@ -136,17 +147,27 @@ __device__ __forceinline__ int2 bt_build(const BtLds& L, int B, int b0, const Bt
     L.rlen[tid] = row.len;
     L.rcoef[tid] = row.y;
     L.ifirst[tid] = first;
-    for (int c = 0; c < nch; ++c) L.item_row[first + c] = tid;
-    if (nch) atomicMax(&L.misc[32], first + nch);
+    for (int c = 0; c < sc.nch; ++c) L.item_row[first + c] = tid;
+    if (sc.nch) atomicMax(&L.misc[32], first + sc.nch);
   } else if (tid == 0) {   // the first row alone exceeds the item slots: bt_giant_row
     L.rst[0] = row.st;
     L.rlen[0] = row.len;
     L.rcoef[0] = row.y;
   }
-  __syncthreads();
+}
+template <int THREADS>
+__device__ __forceinline__ int2 bt_build_p3(const BtLds& L) {
   int nbf = 0;
   for (int i = 0; i < THREADS / 64; ++i) nbf += L.misc[16 + i];
   return make_int2(nbf, L.misc[32]);
+}
+template <int THREADS, int CAP>
+__device__ __forceinline__ int2 bt_build(const BtLds& L, int B, int b0, const BtRow& row) {
+  const BtScan sc = bt_build_p1<THREADS, CAP>(L, B, b0, row);
+  __syncthreads();
+  bt_build_p2<THREADS, CAP>(L, B, b0, row, sc);
+  __syncthreads();
+  return bt_build_p3<THREADS>(L);
 }
 
 template <int THREADS, int R>
@@ -632,18 +653,43 @@ __host__ __device__ constexpr int plan_hl(bool multi, int dp) { return (multi ? 
 __host__ __device__ constexpr int plan_lds_words(int dp, bool multi) {
   const int hl = plan_hl(multi, dp);
   const int n_cw = (dp - hl + 31) / 32;
-  return (((multi ? 4 : 3) * hl + (multi ? 2 : 1) * n_cw + 1) & ~1) + bt_lds_words(PLAN_CAP) + 32 + 8;
+  return (((multi ? 4 : 3) * hl + (multi ? 2 : 1) * n_cw + 1) & ~1) + 2 * bt_lds_words(PLAN_CAP) + 32 + 8;
 }
 
-__device__ __forceinline__ double block_sum_f64(double v, double* red /* 16 doubles of LDS */) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
+// sum over the 64 lanes of a wave, valid in lane 63; DPP moves of the two halves (a __shfl_xor of a double is two
+// ds_bpermute round trips per step: 1,500 cycles per reduction, measured as "reduce" in the phase counters)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_get_f64(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)b, CTRL, ROW_MASK, 0xf, false);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);   // (lanes without a source read +0.0)
+}
+__device__ __forceinline__ double wave_sum_f64_lane63(double v) {
+  v += dpp_get_f64<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_get_f64<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_get_f64<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_get_f64<0x118, 0xf>(v);   // row_shr:8
+  v += dpp_get_f64<0x142, 0xa>(v);   // row_bcast:15 -> rows 1 and 3
+  v += dpp_get_f64<0x143, 0xc>(v);   // row_bcast:31 -> rows 2 and 3
+  return v;
+}
+// workgroup sum in two halves so that the barriers of other code in between can be shared:
+// publish (every wave leaves its partial in LDS) ... any workgroup barrier ... collect (fixed order: reproducible)
+__device__ __forceinline__ void block_sum_f64_publish(double v, double* red /* 16 doubles of LDS */) {
+  v = wave_sum_f64_lane63(v);
+  if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = v;
+}
+__device__ __forceinline__ double block_sum_f64_collect(const double* red) {
   double t = 0.0;
   for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
   return t;
+}
+__device__ __forceinline__ double block_sum_f64(double v, double* red) {
+  __syncthreads();
+  block_sum_f64_publish(v, red);
+  __syncthreads();
+  return block_sum_f64_collect(red);
 }
 
 template <bool MULTI>
@@ -660,8 +706,12 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
   L.cbits = reinterpret_cast<unsigned int*>(lds + (MULTI ? 4 : 3) * hl);
   unsigned int* ubits = L.cbits + n_cw;       // MULTI: touched cold coordinates of `upd`
   int* tables = reinterpret_cast<int*>(lds) + (((MULTI ? 4 : 3) * hl + (MULTI ? 2 : 1) * n_cw + 1) & ~1);
+  // two sets of sub-batch tables (batch parity): the next batch's tables are built while the current one's are in use
+  BtLds L2 = L;
   bt_carve(L, tables, PLAN_CAP);
-  double* red = reinterpret_cast<double*>(tables + bt_lds_words(PLAN_CAP));   // 16 doubles
+  bt_carve(L2, tables + bt_lds_words(PLAN_CAP), PLAN_CAP);
+  L2.misc = L.misc;   // (one scratch area: a build is over before the next one starts)
+  double* red = reinterpret_cast<double*>(tables + 2 * bt_lds_words(PLAN_CAP));   // 16 doubles
   const int tid = threadIdx.x;
   for (int j = tid; j < hl; j += PLAN_THREADS) {
     L.acc[j] = 0;
@@ -695,26 +745,74 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
   const int K = a.n_workers;
   const long long n_batches = (a.step_end - a.step_begin) * K;
   const WorkSeg* segs = a.segs + a.step_begin * K;
-  // staging pipeline: row ids of batch n+1 are in `rid_next` while batch n is computed
-  auto load_rid = [&](long long n) -> int {
-    if (n >= n_batches) return -1;
-    const WorkSeg sg = segs[n];
-    return tid < min((long long)PLAN_CAP, sg.end - sg.begin) ? a.idx[sg.begin + tid] : -1;
+  // The list descriptors of the batches n .. n+3 live in registers (a sliding window); the descriptor of batch n+4 is
+  // requested at the top of iteration n with a VECTOR load: a scalar load would share lgkmcnt with the LDS traffic
+  // of the whole iteration and stall the first LDS wait behind it for a memory round trip -- four such loads per
+  // batch were ~3 us of the 15 us step (phase counters, profiles/README.md).
+  auto seg_load = [&](long long n, long long& beg, int& len) {
+    beg = 0;
+    len = 0;
+    if (n < n_batches) {
+      const WorkSeg* p = segs + n;
+      asm volatile("" : "+v"(p));   // keep the address in vector registers: global_load, counted by vmcnt
+      const WorkSeg sg = *p;
+      beg = sg.begin;
+      len = (int)(sg.end - sg.begin);
+    }
   };
-  int rid_cur = load_rid(0), rid_next = load_rid(1);
+  // ... and back to scalar registers once the load has landed (the values are workgroup-uniform)
+  auto to_scalar = [&](long long& beg, int& len) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)beg);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)beg >> 32));
+    beg = (long long)(((unsigned long long)hi << 32) | lo);
+    len = __builtin_amdgcn_readfirstlane(len);
+  };
+  long long sb[4];
+  int sl[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    seg_load(i, sb[i], sl[i]);
+    to_scalar(sb[i], sl[i]);
+  }
+  // row ids of a batch whose descriptor is (beg, len)
+  auto load_rid = [&](long long beg, int len) -> int { return tid < min(PLAN_CAP, len) ? a.idx[beg + tid] : -1; };
+  // Software pipeline over the batches n = 0, 1, ... (a batch = one worker's list of one step):
+  //   iteration n:  dot(n) | build part 1 (n+1)            -- the non-zeros of batch n were requested an iteration ago
+  //                 barrier
+  //                 gate(n) | build part 2 (n+1)            -- into the OTHER table set
+  //                 barrier
+  //                 scatter(n); leftovers(n); request the non-zeros of batch n+1 and the row records of batch n+2
+  //                 barrier
+  //                 sweep(n) (the update); publish the change of w . ds
+  //                 barrier
+  // Four barriers per batch; every global round trip of batch n+1 / n+2 runs under batch n's arithmetic.  Only the
+  // weight gather (LDS for the hot ranks) and what follows it wait for the update -- the reference's synchronous
+  // semantics are untouched.
+  auto rows_of = [&](int len, int rid) -> BtRow {
+    return bt_rows_issue<PLAN_CAP>(a.m, len, 0, [&](int) { return (long long)rid; }, &a.sc->err);
+  };
   BtItems<PLAN_R> items;
   int2 bd = make_int2(0, 0);
-  if (n_batches > 0) {
-    const int B0 = (int)(segs[0].end - segs[0].begin);
-    const BtRow row = bt_rows_issue<PLAN_CAP>(a.m, B0, 0, [&](int) { return (long long)rid_cur; }, &a.sc->err);
-    bd = bt_build<PLAN_THREADS, PLAN_CAP>(L, B0, 0, row);
-    if (bd.x > 0) bt_items_issue<PLAN_THREADS, PLAN_R>(a.m, L, bd.y, items);
+  BtRow row_next;          // row records of batch n+1 (requested during iteration n-1)
+  int rid_next2;           // row ids of batch n+2
+  {
+    const int rid0 = load_rid(sb[0], sl[0]);
+    const int rid1 = load_rid(sb[1], sl[1]);
+    rid_next2 = load_rid(sb[2], sl[2]);
+    const BtRow row0 = rows_of(sl[0], rid0);
+    row_next = rows_of(sl[1], rid1);
+    if (n_batches > 0) {
+      bd = bt_build<PLAN_THREADS, PLAN_CAP>(L, sl[0], 0, row0);
+      if (bd.x > 0) bt_items_issue<PLAN_THREADS, PLAN_R>(a.m, L, bd.y, items);
+    }
   }
   float s = 0.0f;
   bool add_s = false;
   double ddot = 0.0;
   unsigned int n_act = 0;
   for (long long n = 0; n < n_batches; ++n) {
+    const BtLds& Lc = (n & 1) ? L2 : L;     // tables of batch n
+    const BtLds& Ln = (n & 1) ? L : L2;     // tables of batch n+1
     const int k = (int)(n % K);
     if (k == 0) {
       s = (float)(2.0 * (double)a.lambda * dot);   // thread-uniform: every thread carries the same dot
@@ -723,32 +821,33 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
       n_act = 0;
     }
     const unsigned long long t0 = a.tprof ? __builtin_readcyclecounter() : 0ull;
-    const WorkSeg seg = segs[n];
-    const int B = (int)(seg.end - seg.begin);
+    long long sb4;
+    int sl4;
+    seg_load(n + 4, sb4, sl4);   // (used when the window shifts at the end of the iteration)
+    const int B = sl[0], Bn = sl[1];
     int bits = 0;
     while ((1 << bits) < B) ++bits;
     const int shift = 30 - bits;   // at most one contribution per row and column: sums stay below 2^30
     const float qscale = ldexpf(1.0f, shift - a.vexp), inv_qscale = ldexpf(1.0f, a.vexp - shift);
-    const int* __restrict__ list = a.idx + seg.begin;
-    // ---- gradient of worker k on the weights of the previous step: the staged sub-batch, then any leftovers ----
-    int done = 0;
-    if (bd.x > 0) {
-      bt_items_dot<PLAN_THREADS, PLAN_R>(L, items, wload);
-      __syncthreads();
-      n_act += bt_gate(L, bd.x);
-      __syncthreads();
-      bt_scatter<PLAN_R, true>(L, a.gcold, items, qscale);
-      done = bd.x;
-    }
-    if (done < B)
-      n_act += bt_batch<PLAN_THREADS, PLAN_R, true>(a.m, L, a.gcold, B, done, [&](int t) { return (long long)list[t]; }, wload,
+    const int* __restrict__ list = a.idx + sb[0];
+    // ---- gradient of worker k on the weights of the previous step, interleaved with the tables of batch n+1 ----
+    if (bd.x > 0) bt_items_dot<PLAN_THREADS, PLAN_R>(Lc, items, wload);
+    const BtScan scn = bt_build_p1<PLAN_THREADS, PLAN_CAP>(Ln, Bn, 0, row_next);
+    __syncthreads();
+    if (bd.x > 0) n_act += bt_gate(Lc, bd.x);
+    bt_build_p2<PLAN_THREADS, PLAN_CAP>(Ln, Bn, 0, row_next, scn);
+    __syncthreads();
+    if (bd.x > 0) bt_scatter<PLAN_R, true>(Lc, a.gcold, items, qscale);
+    const int2 bd_n = bt_build_p3<PLAN_THREADS>(Ln);
+    if (bd.x < B) {   // whatever did not fit the staged sub-batch (long rows, lists beyond 128 rows): stage by stage
+      __syncthreads();   // (its table build reuses the scratch words part 3 above has just read)
+      n_act += bt_batch<PLAN_THREADS, PLAN_R, true>(a.m, Lc, a.gcold, B, bd.x, [&](int t) { return (long long)list[t]; }, wload,
                                                    qscale, &a.sc->err);
-    // ---- the next batch does not depend on w until its weight gather: request its row records, and the row ids of
-    // the batch after it ----
-    const int Bn = n + 1 < n_batches ? (int)(segs[n + 1].end - segs[n + 1].begin) : 0;
-    const int rid_n = rid_next;
-    const BtRow row_n = bt_rows_issue<PLAN_CAP>(a.m, Bn, 0, [&](int) { return (long long)rid_n; }, &a.sc->err);
-    rid_next = load_rid(n + 2);
+    }
+    // ---- nothing of batch n+1 / n+2 depends on w until the weight gather: request it all now ----
+    if (Bn > 0 && bd_n.x > 0) bt_items_issue<PLAN_THREADS, PLAN_R>(a.m, Ln, bd_n.y, items);
+    row_next = rows_of(sl[2], rid_next2);
+    rid_next2 = load_rid(sb[3], sl[3]);
     __syncthreads();   // every contribution of this batch is in the accumulators
     const unsigned long long t1 = a.tprof ? __builtin_readcyclecounter() : 0ull;
     // ---- sweep: this worker's regularised sum on its support; the hot ranks never leave LDS ----
@@ -773,28 +872,46 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
       if (!cb) continue;
       L.cbits[wd] = 0u;
       while (cb) {
-        const int b = __builtin_ctz(cb);
-        cb &= cb - 1u;
-        const int jc = wd * 32 + b, j = hl + jc;
-        const float old = MULTI ? a.upd[j] : a.w[j];
-        const float dsj = MULTI ? 0.0f : a.ds[j];
-        // (written with L2 atomics of this workgroup: read it there, not through L1)
-        float g = filt(__hip_atomic_exchange(&a.gcold[jc], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if (g == 0.0f) continue;
-        if (add_s) g = filt(g + s);
-        if (MULTI) {
-          a.upd[j] = filt(old + g);
-          atomicOr(&ubits[jc >> 5], 1u << (jc & 31));
-        } else {
-          float wn;
-          ddot += step_w(g, old, dsj, wn);
-          a.w[j] = wn;
+        // up to four touched ranks of the word per round: their loads are in flight together (a batch of 100 rows
+        // touches ~900 cold ranks over ~1,100 words: one round for nearly every thread)
+        int jc[4];
+        float old[4], dsj[4], gs[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          jc[e] = cb ? wd * 32 + __builtin_ctz(cb) : -1;
+          cb &= cb - 1u;   // (0 stays 0)
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          old[e] = dsj[e] = gs[e] = 0.0f;
+          if (jc[e] >= 0) {
+            old[e] = MULTI ? a.upd[hl + jc[e]] : a.w[hl + jc[e]];
+            if (!MULTI) dsj[e] = a.ds[hl + jc[e]];
+            // (written with L2 atomics of this workgroup: read it there, not through L1)
+            gs[e] = __hip_atomic_exchange(&a.gcold[jc[e]], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (jc[e] < 0) continue;
+          const int j = hl + jc[e];
+          float g = filt(gs[e]);
+          if (g == 0.0f) continue;
+          if (add_s) g = filt(g + s);
+          if (MULTI) {
+            a.upd[j] = filt(old[e] + g);
+            atomicOr(&ubits[jc[e] >> 5], 1u << (jc[e] & 31));
+          } else {
+            float wn;
+            ddot += step_w(g, old[e], dsj[e], wn);
+            a.w[j] = wn;
+          }
         }
       }
     }
     if (MULTI && k == K - 1) {
-      __syncthreads();   // the bitmap walk below crosses threads
-      // mean over the workers and the update, on the union of the supports
+      // mean over the workers and the update, on the union of the supports (every coordinate of `upd` is owned by
+      // the thread that wrote it: no barrier needed in between)
       for (int j = tid; j < hl; j += PLAN_THREADS) {
         const float u = updl[j];
         if (u == 0.0f) continue;
@@ -819,18 +936,24 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
         }
       }
     }
-    // ---- tables and non-zeros of the next batch (its row records have landed behind the sweep); the two barriers
-    // inside also order this sweep's writes of the weights before the next gather ----
-    bd = make_int2(0, 0);
-    if (Bn > 0) {
-      bd = bt_build<PLAN_THREADS, PLAN_CAP>(L, Bn, 0, row_n);
-      if (bd.x > 0) bt_items_issue<PLAN_THREADS, PLAN_R>(a.m, L, bd.y, items);
-    }
+    // (`red` is free: the previous collect is behind three barriers)
+    if (k == K - 1) block_sum_f64_publish(ddot, red);
     const unsigned long long t2 = a.tprof ? __builtin_readcyclecounter() : 0ull;
+    __syncthreads();   // the weights of the next gather are written; the wave partials are visible
     if (k == K - 1) {
-      dot += block_sum_f64(ddot, red);   // every thread adds the same total: `dot` stays thread-uniform
+      dot += block_sum_f64_collect(red);   // every thread adds the same total: `dot` stays thread-uniform
       n_act_total += n_act;
     }
+    bd = bd_n;
+    if (Bn == 0) bd = make_int2(0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      sb[i] = sb[i + 1];
+      sl[i] = sl[i + 1];
+    }
+    to_scalar(sb4, sl4);
+    sb[3] = sb4;
+    sl[3] = sl4;
     if (a.tprof) {
       tp[0] += t1 - t0;
       tp[1] += t2 - t1;

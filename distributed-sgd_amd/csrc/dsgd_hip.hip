@@ -210,6 +210,8 @@ struct dsgd_ctx {
   int bound_shift = 0;
   unsigned int* d_bound = nullptr;
   int max_shift = FIX_SHIFT;     // DSGD_FIX_SHIFT: cap of the per-launch fixed-point shift of the split layout
+  int cold8 = 1;                 // DSGD_COLD8 bit 0: dsgd_cdot8_kernel, bit 1: dsgd_cgrad8_kernel (measured: cdot8 85 vs
+                                 // 93 us, cgrad8 75 vs 73 us per 0.30 GB -- both are start-up bound, profiles/README.md)
   bool fuse_apply = true;        // DSGD_FUSE_APPLY=0: separate dsgd_fix_reduce_kernel + dsgd_apply_mb_kernel launches
   bool fused_apply_pending = false;
   FusedArgs fused_args{};
@@ -796,9 +798,16 @@ static int build_split(dsgd_ctx* c) {
     }
   }
   c->cold_packed = packed;
-  HIP_TRY(hipMalloc(&c->d_ckey, sizeof(unsigned int) * nc));
-  HIP_TRY(hipMalloc(&c->d_cval, sizeof(float) * nc));
-  if (!packed) HIP_TRY(hipMalloc(&c->d_crow, sizeof(int) * nc));
+  // (+ COLD_PAD entries: the second-generation cold kernels read whole 512-entry tiles, masked by index)
+  HIP_TRY(hipMalloc(&c->d_ckey, sizeof(unsigned int) * (nc + COLD_PAD)));
+  HIP_TRY(hipMalloc(&c->d_cval, sizeof(float) * (nc + COLD_PAD)));
+  HIP_TRY(hipMemset(c->d_ckey + nc, 0, sizeof(unsigned int) * COLD_PAD));
+  HIP_TRY(hipMemset(c->d_cval + nc, 0, sizeof(float) * COLD_PAD));
+  if (!packed) {
+    HIP_TRY(hipMalloc(&c->d_crow, sizeof(int) * (nc + COLD_PAD)));
+    HIP_TRY(hipMemset(c->d_crow + nc, 0, sizeof(int) * COLD_PAD));
+  }
+  cbase.resize(cbase.size() + COLD_PAD / 256 + 2, cbase.empty() ? 0 : cbase.back());
   HIP_TRY(hipMalloc(&c->d_cbase, sizeof(int) * cbase.size()));
   HIP_TRY(hipMemcpy(c->d_cbase, cbase.data(), sizeof(int) * cbase.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&c->d_crow_ptr, sizeof(long long) * crp.size()));
@@ -1014,7 +1023,13 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   if (cold) {
     size_t slot_c = 0;
     DSGD_TRY(prof_begin(c, &slot_c, 1));
-    if (c->cold_packed)
+    if ((c->cold8 & 1) && c->cold_packed)
+      hipLaunchKernelGGL(dsgd_cdot8_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
+                         c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds, nc > nc_lds ? 1 : 0);
+    else if (c->cold8 & 1)
+      hipLaunchKernelGGL(dsgd_cdot8_kernel<false>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
+                         c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds, nc > nc_lds ? 1 : 0);
+    else if (c->cold_packed)
       hipLaunchKernelGGL(dsgd_cdot_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
                          c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds, nc > nc_lds ? 1 : 0);
     else
@@ -1098,7 +1113,15 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   if (cold) {
     size_t slot_g = 0;
     DSGD_TRY(prof_begin(c, &slot_g, 2));
-    if (c->cold_packed)
+    if ((c->cold8 & 2) && c->cold_packed)
+      hipLaunchKernelGGL(dsgd_cgrad8_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, cv,
+                         c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H, nc_lds, c->fix_scale,
+                         c->d_partc, c->partc_stride, nc > nc_lds ? 1 : 0);
+    else if (c->cold8 & 2)
+      hipLaunchKernelGGL(dsgd_cgrad8_kernel<false>, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, cv,
+                         c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H, nc_lds, c->fix_scale,
+                         c->d_partc, c->partc_stride, nc > nc_lds ? 1 : 0);
+    else if (c->cold_packed)
       hipLaunchKernelGGL(dsgd_cgrad_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, cv,
                          c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H, nc_lds, c->fix_scale,
                          c->d_partc, c->partc_stride, nc > nc_lds ? 1 : 0);
@@ -1283,6 +1306,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_FIX_SHIFT")) c->max_shift = std::max(8, std::min(FIX_SHIFT, atoi(e)));
   if (const char* e = getenv("DSGD_FIX_BOUND")) c->fix_bound = atoi(e) != 0;
   if (const char* e = getenv("DSGD_FUSE_APPLY")) c->fuse_apply = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_COLD8")) c->cold8 = atoi(e);
   if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;
   if (const char* e = getenv("DSGD_PLAN_MAX_ROWS")) c->plan_max_rows = std::max(1LL, atoll(e));
   if (getenv("DSGD_PLAN_PROF") && atoi(getenv("DSGD_PLAN_PROF"))) {
@@ -1324,6 +1348,10 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_cdot_kernel<false>);
   DSGD_ATTR(dsgd_cgrad_kernel<true>);
   DSGD_ATTR(dsgd_cgrad_kernel<false>);
+  DSGD_ATTR(dsgd_cdot8_kernel<true>);
+  DSGD_ATTR(dsgd_cdot8_kernel<false>);
+  DSGD_ATTR(dsgd_cgrad8_kernel<true>);
+  DSGD_ATTR(dsgd_cgrad8_kernel<false>);
 #undef DSGD_ATTR
   HIP_TRY_B(hipStreamSynchronize(c->stream));
 #undef HIP_TRY_B

@@ -1761,3 +1761,207 @@ __global__ void __launch_bounds__(256) dsgd_eval_idx_kernel(CsrView m, const flo
     if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
   }
 }
+
+// ======================================================================================================
+// Cold-stream kernels, second generation: EIGHT CONTIGUOUS entries per lane
+// ======================================================================================================
+// The first generation (dsgd_cdot_kernel / dsgd_cgrad_kernel above) gave every lane one entry of a 64-entry chunk:
+// 16 dword loads per array in flight per lane, one DPP segmented scan plus two readlanes per 64 entries (cdot: 70
+// VALU instructions per chunk, 3.2 TB/s) -- VMEM-issue and VALU bound on a 0.3 GB stream.  Here lane l owns the
+// entries [tb + 8l, tb + 8l + 8) of a 512-entry tile (tb a multiple of 8): two 16-byte loads per array, rows that
+// begin and end inside the lane (cold rows hold ~5 entries) are summed sequentially and written straight away, and
+// ONE segmented scan per tile joins the fragments that cross lanes.  Two tiles in flight per wave.
+struct ColdTile8 {
+  unsigned int k[8];
+  float v[8];
+  int r[8];      // unpacked form: rows; packed form: r[0] holds the block base row
+};
+constexpr int COLD_PAD = 1024;   // entries the cold arrays are padded with (whole tiles are read)
+
+template <bool PACKED>
+__device__ __forceinline__ void cold_tile_issue(const ColdView& cv, long long tb, int lane, ColdTile8& T) {
+  const long long i0 = tb + 8 * lane;
+  const uint4 a = *reinterpret_cast<const uint4*>(cv.key + i0), b = *reinterpret_cast<const uint4*>(cv.key + i0 + 4);
+  const float4 x = *reinterpret_cast<const float4*>(cv.val + i0), y = *reinterpret_cast<const float4*>(cv.val + i0 + 4);
+  T.k[0] = a.x; T.k[1] = a.y; T.k[2] = a.z; T.k[3] = a.w; T.k[4] = b.x; T.k[5] = b.y; T.k[6] = b.z; T.k[7] = b.w;
+  T.v[0] = x.x; T.v[1] = x.y; T.v[2] = x.z; T.v[3] = x.w; T.v[4] = y.x; T.v[5] = y.y; T.v[6] = y.z; T.v[7] = y.w;
+  if (PACKED) {
+    T.r[0] = cv.base[i0 >> 8];   // (8 | 256: the lane's entries share one block)
+  } else {
+    const int4 p = *reinterpret_cast<const int4*>(cv.row + i0), q = *reinterpret_cast<const int4*>(cv.row + i0 + 4);
+    T.r[0] = p.x; T.r[1] = p.y; T.r[2] = p.z; T.r[3] = p.w; T.r[4] = q.x; T.r[5] = q.y; T.r[6] = q.z; T.r[7] = q.w;
+  }
+}
+// columns and rows of the lane's entries; entries outside [s, t) become (col 0, value 0, row -1)
+template <bool PACKED>
+__device__ __forceinline__ void cold_tile_decode(ColdTile8& T, long long tb, int lane, long long s, long long t, int (&col)[8]) {
+  const long long i0 = tb + 8 * lane;
+  const int base = T.r[0];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const bool in = i0 + k >= s && i0 + k < t;
+    const int rr = PACKED ? base + (int)(T.k[k] >> 16) : T.r[k];
+    col[k] = in ? (int)(PACKED ? T.k[k] & 0xffffu : T.k[k]) : 0;
+    T.r[k] = in ? rr : -1;
+    T.v[k] = in ? T.v[k] : 0.0f;
+  }
+}
+
+// dcold[row] = sum over the cold entries of the row of filt(value * w[hsplit + col]); same contract as
+// dsgd_cdot_kernel (row-aligned pieces per wave: no atomics, fixed order).  ref: math/Sparse.scala:46.
+template <bool PACKED>
+__global__ void __launch_bounds__(1024) dsgd_cdot8_kernel(ColdView cv, const long long* __restrict__ crow_ptr,
+                                                         const float* __restrict__ w, float* __restrict__ dcold,
+                                                         const StreamSeg* __restrict__ segs, int hsplit, int nc_lds,
+                                                         int wide) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef __attribute__((address_space(3))) const float lds_cfloat;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int j = tid; j < nc_lds; j += 1024) lds[j] = w[hsplit + j];
+  __syncthreads();
+  const StreamSeg seg = segs[blockIdx.y];
+  const long long e_lo = crow_ptr[seg.row_begin], e_hi = crow_ptr[seg.row_end];
+  const long long n = e_hi - e_lo;
+  const long long n_waves = (long long)gridDim.x * 16, me = (long long)blockIdx.x * 16 + wave;
+  const long long chunks = (n + 63) / 64;
+  const long long b0 = e_lo + 64 * (chunks * me / n_waves), b1 = e_lo + 64 * (chunks * (me + 1) / n_waves);
+  const long long s = cold_row_start<PACKED>(cv, b0, e_lo, e_hi, lane);
+  const long long t = me + 1 == n_waves ? e_hi : cold_row_start<PACKED>(cv, b1 < e_hi ? b1 : e_hi, e_lo, e_hi, lane);
+  if (s >= t) return;
+  lds_cfloat* wc = (lds_cfloat*)lds;
+  float carry_sum = 0.0f;
+  int carry_row = -1;
+  auto process = [&](ColdTile8& T, long long tb) {
+    int col[8];
+    cold_tile_decode<PACKED>(T, tb, lane, s, t, col);
+    float p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = wc[min(col[k], nc_lds - 1)];
+    if (wide) {   // wave-uniform: cold columns beyond the LDS tile exist (very wide models only)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (col[k] >= nc_lds) p[k] = w[hsplit + col[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = filt(T.v[k] * p[k]);
+    // the row of the element before this lane: the previous lane's last row, or the row carried in from the last tile
+    int rprev = __builtin_amdgcn_update_dpp(0, T.r[7], 0x138, 0xf, 0xf, false);   // wave_shr:1
+    if (lane == 0) rprev = carry_row;
+    const bool b_first = T.r[0] != rprev;
+    if (lane == 0 && !b_first) p[0] += carry_sum;   // the carried row continues: its running sum joins this lane's
+    // sequential pass: `head` closes the row entering the lane, rows inside the lane are complete, `run` stays open
+    float run = 0.0f, head = 0.0f;
+    bool seen = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool bnd = k == 0 ? b_first : T.r[k] != T.r[k - 1];
+      if (bnd) {
+        if (!seen) {
+          head = run;
+          seen = true;
+        } else if (T.r[k - (k > 0)] >= 0) {
+          dcold[T.r[k - (k > 0)]] = run;   // (k > 0 here: a second boundary cannot sit at slot 0)
+        }
+        run = 0.0f;
+      }
+      run += p[k];
+    }
+    float S = run;
+    int f = seen ? 1 : 0;
+    wave_seg_scan(S, f);
+    float incoming = dpp_get_f<0x138, 0xf>(S);   // wave_shr:1: running sum of the row entering this lane
+    if (lane == 0) incoming = b_first ? carry_sum : 0.0f;
+    const int rclose = b_first ? rprev : T.r[0];   // the row the lane's FIRST boundary closes
+    if (seen && rclose >= 0) dcold[rclose] = incoming + head;
+    carry_sum = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S), 63));
+    carry_row = __builtin_amdgcn_readlane(T.r[7], 63);
+  };
+  long long tb = s & ~7LL;
+  ColdTile8 A, B;
+  cold_tile_issue<PACKED>(cv, tb, lane, A);
+  for (;;) {
+    if (tb + 512 < t) cold_tile_issue<PACKED>(cv, tb + 512, lane, B);
+    process(A, tb);
+    tb += 512;
+    if (tb >= t) break;
+    if (tb + 512 < t) cold_tile_issue<PACKED>(cv, tb + 512, lane, A);
+    process(B, tb);
+    tb += 512;
+    if (tb >= t) break;
+  }
+  if (lane == 0 && carry_row >= 0) dcold[carry_row] = carry_sum;
+}
+
+// cold gradient columns, same contract as dsgd_cgrad_kernel (fixed-point LDS accumulators, shift 21, spill rule of
+// w_scatter, per-workgroup partials).  ref: core/Slave.scala:147-153 restricted to the cold columns.
+template <bool PACKED>
+__global__ void __launch_bounds__(1024) dsgd_cgrad8_kernel(ColdView cv, const long long* __restrict__ crow_ptr,
+                                                          const signed char* __restrict__ coef8,
+                                                          long long* __restrict__ g64_base, long long g_stride,
+                                                          DevScalars* __restrict__ sc,
+                                                          const StreamSeg* __restrict__ segs, int hsplit, int nc_lds,
+                                                          float fix_scale, int* __restrict__ partc, int partc_stride,
+                                                          int wide) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int* gc = reinterpret_cast<int*>(lds);   // nc_lds accumulators + 64 always-zero words
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int j = tid; j < nc_lds + 64; j += 1024) gc[j] = 0;
+  __syncthreads();
+  const StreamSeg seg = segs[blockIdx.y];
+  long long* g64 = g64_base + (long long)blockIdx.y * g_stride;
+  const long long e_lo = crow_ptr[seg.row_begin], e_hi = crow_ptr[seg.row_end];
+  const long long chunks = (e_hi - e_lo + 63) / 64;
+  const long long n_waves = (long long)gridDim.x * 16, me = (long long)blockIdx.x * 16 + wave;
+  const long long s = e_lo + 64 * (chunks * me / n_waves);
+  long long t = e_lo + 64 * (chunks * (me + 1) / n_waves);
+  if (t > e_hi) t = e_hi;
+  if (s < t) {
+    auto process = [&](ColdTile8& T, long long tb) {
+      int col[8], q[8], old[8];
+      cold_tile_decode<PACKED>(T, tb, lane, s, t, col);
+      signed char cf[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cf[k] = coef8[T.r[k] >= 0 ? T.r[k] : (int)seg.row_begin];   // (neighbouring entries share rows)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) q[k] = __float2int_rn(T.v[k] * ((float)cf[k] * fix_scale));   // 0: inactive row, padding
+      if (wide) {   // wave-uniform: columns beyond the LDS tile (very wide models) go to the 64-bit global accumulator
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (col[k] >= nc_lds) {
+            if (q[k] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[hsplit + col[k]]), (unsigned long long)(long long)q[k]);
+            q[k] = 0;
+            col[k] = 0;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) old[k] = atomicAdd(&gc[q[k] != 0 ? col[k] : nc_lds + lane], q[k]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (old[k] >= WS_SPILL_AT || old[k] <= -WS_SPILL_AT) {
+          if (old[k] >= WS_PANIC_AT || old[k] <= -WS_PANIC_AT) atomicOr(&sc->err, 2);
+          const int x = atomicExch(&gc[col[k]], 0);
+          if (x != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[hsplit + col[k]]), (unsigned long long)(long long)x);
+        }
+      }
+    };
+    long long tb = s & ~7LL;
+    ColdTile8 A, B;
+    cold_tile_issue<PACKED>(cv, tb, lane, A);
+    for (;;) {
+      if (tb + 512 < t) cold_tile_issue<PACKED>(cv, tb + 512, lane, B);
+      process(A, tb);
+      tb += 512;
+      if (tb >= t) break;
+      if (tb + 512 < t) cold_tile_issue<PACKED>(cv, tb + 512, lane, A);
+      process(B, tb);
+      tb += 512;
+      if (tb >= t) break;
+    }
+  }
+  __syncthreads();
+  int* mine = partc + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * partc_stride;
+  for (int j = tid; j < nc_lds; j += 1024) mine[j] = gc[j];
+}

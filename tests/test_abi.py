@@ -75,3 +75,35 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".c", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not pat.search(text), (dirpath, f, pat.search(text).group(0))
+
+
+def test_register_budget_of_the_async_engine_and_the_concurrent_loss_check(tmp_path):
+    """MasterAsync checks the loss WHILE the persistent lock-free engine runs (core/MasterAsync.scala:96-162): the
+    evaluation kernel must become resident beside workgroups that never leave their CU.  Per SIMD the engine holds
+    2 waves, the check 1 wave (256-lane blocks, csrc/dsgd_hip.hip dsgd_loss_acc): their ALLOCATED VGPRs (granule 8)
+    must fit the 512-register file, and their LDS the 160 KiB of a CU."""
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", _lib.HIP_LIB, fat])
+    subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    notes = subprocess.run([llvm + "/llvm-readelf", "--notes", co], stdout=subprocess.PIPE, text=True, check=True).stdout
+    vg = {}
+    name = None
+    for line in notes.splitlines():
+        m = re.search(r"\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"\.vgpr_count:\s+(\d+)", line)
+        if m and name:
+            vg[name] = int(m.group(1))
+    alloc = lambda n: -(-n // 8) * 8
+    hog = [v for k, v in vg.items() if "dsgd_hogwild_kernel" in k]
+    evals = [v for k, v in vg.items() if "dsgd_eval_kernel" in k]
+    assert len(hog) == 1 and len(evals) == 4
+    assert 2 * alloc(hog[0]) + alloc(max(evals)) <= 512, (hog, evals)
+    for k, v in vg.items():   # 1024-lane workgroups: 4 waves per SIMD
+        if "dsgd_plan_kernel" in k or "dsgd_wseg_kernel" in k:
+            assert v <= 128, (k, v)

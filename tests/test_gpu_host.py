@@ -122,3 +122,39 @@ def test_wire_worker_serves_the_engine():
             np.testing.assert_array_equal(eng.get_weights(), w - delta)
         finally:
             worker.stop()
+
+
+def test_lyrl2004_text_to_csr_to_one_epoch_on_the_gpu():
+    """f2 end to end: the committed LYRL2004-formatted sample through the product's native parser (csrc/rcv1.c) into the
+    engine, one epoch of Master.fit (3 workers, batch 4) -- against the oracle fed the CSR of the INDEPENDENT loader
+    restatement (oracle/ref_loader.py, utils/Dataset.scala:19-58)."""
+    import os
+
+    from dsgd_amd import rcv1
+    from oracle import ref_loader
+
+    sample = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lyrl2004_sample")
+    rp, col, val, lab, ids = ref_loader.rcv1(sample, full=True)
+    dim = rcv1.RCV1_DIM
+    n_rows, n_train = len(lab), 19   # Main.scala:52: 80 / 20 split of 24 documents
+    o = orc.Oracle(dim, rp, col, val.astype(np.float32), lab, 1e-5)
+    o.set_dim_sparsity(o.dim_sparsity(n_train))
+    ob = OracleBackend(o)
+    ref = host.MasterSync(ob, n_train, n_rows, node_count=3, rnd=host.JavaRandom(0))
+    s_ref = ref.fit(np.zeros(dim + 1), 1, 4, 0.5, host.EarlyStopping.no_improvement(5, 0.01))
+    data = rcv1.load(sample, full=True)
+    with dsgd_amd.Engine(dim, 1e-5) as eng:
+        eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+        ds = eng.build_dim_sparsity(n_train)
+        np.testing.assert_array_equal(ds, o.ds.astype(np.float32))
+        ce = CountingEngine(eng)
+        m = host.MasterSync(ce, n_train, n_rows, node_count=3, rnd=host.JavaRandom(0))
+        s = m.fit(np.zeros(dim + 1), 1, 4, 0.5, host.EarlyStopping.no_improvement(5, 0.01))
+    assert len(ce.actives) == len(ob.actives) == 2   # ceil(ceil(19 / 3) / 4) batches
+    if min(ob.min_margins) >= 1e-5:
+        assert ce.actives == ob.actives
+        err = np.abs(s.grad.astype(np.float64) - s_ref.grad).max()
+        assert err <= 1e-5 * max(1.0, np.abs(s_ref.grad).max()), err
+        assert set(np.flatnonzero(s.grad)) == set(np.flatnonzero(s_ref.grad))
+        assert m.test_accs[0] == ref.test_accs[0]
+        assert abs(m.test_losses[0] - ref.test_losses[0]) <= 1e-6

@@ -78,3 +78,68 @@ def test_full_needs_all_five_files(tmp_path):
     assert rcv1.load(str(tmp_path), full=False).n_rows == 1
     with pytest.raises(ValueError):
         rcv1.load(str(tmp_path), full=True)
+
+
+# ---- the product parser against the INDEPENDENT restatement (oracle/ref_loader.py) on LYRL2004-formatted text --------
+SAMPLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lyrl2004_sample")
+
+
+def canon(row_ptr, col, val):
+    """rows as sorted (column, fp32 value) lists: a row is a Map in the reference, its iteration order is unspecified"""
+    return [sorted(zip(col[row_ptr[i]:row_ptr[i + 1]].tolist(), np.asarray(val[row_ptr[i]:row_ptr[i + 1]], np.float32).tolist()))
+            for i in range(len(row_ptr) - 1)]
+
+
+@pytest.mark.parametrize("full", [True, False])
+def test_native_parser_equals_the_independent_restatement_on_the_lyrl2004_sample(full):
+    from oracle import ref_loader
+
+    rp, col, val, lab, ids = ref_loader.rcv1(SAMPLE, full=full)
+    d, d_ids = rcv1.load(SAMPLE, full=full, with_ids=True)
+    assert d.n_rows == (24 if full else 8) == len(lab)
+    np.testing.assert_array_equal(d_ids, ids)
+    np.testing.assert_array_equal(d.label, lab)
+    np.testing.assert_array_equal(d.row_ptr, rp)
+    assert canon(d.row_ptr, d.col, d.val) == canon(rp, col, val)
+    if full:
+        # pinned by hand from the committed files: ids ascend from 2286 across the five files in order; a document is
+        # +1 only when CCAT is the LAST of its qrels lines (codes are listed in code order: C15 < CCAT < E12 ...)
+        assert ids[0] == 2286 and (np.diff(ids) > 0).all() and int(rp[-1]) == 857
+        qrels = {}
+        for line in open(os.path.join(SAMPLE, rcv1.QRELS)):
+            code, did, _ = line.split()
+            qrels.setdefault(int(did), []).append(code)
+        assert lab.tolist() == [1 if qrels[int(i)][-1] == "CCAT" else -1 for i in ids]
+        assert any("CCAT" in qrels[int(i)] and qrels[int(i)][-1] != "CCAT" for i in ids)   # the quirk is exercised
+        assert 0 < (lab > 0).sum() < len(lab)
+        # cosine-normalised rows, 16 significant digits in the text: fp32 after parsing
+        norms = [float(np.sqrt((np.asarray(d.val[d.row_ptr[i]:d.row_ptr[i + 1]], np.float64) ** 2).sum())) for i in range(24)]
+        assert max(abs(x - 1.0) for x in norms) < 1e-6
+
+
+def test_native_parser_equals_the_restatement_on_the_quirk_lines(tmp_path):
+    from oracle import ref_loader
+
+    files = {rcv1.FILES[0]: ("10  3:0.5 7:0.25\n11 9:1.0 4:0.5 6:0.125\n12  5:1 5:2 2:3\n13  8:1e-25 1:0.5:junk\n14  \n"
+                             "15  2:1.5 \n16  4:2  6:3\n")}   # trailing space; a doubled space inside the features
+    qrels = "CCAT 10 1\nCCAT 11 1\nGCAT 11 1\nMCAT 12 1\nCCAT 12 1\nECAT 13 1\nCCAT 14 1\nCCAT 15 1\nCCAT 16 1\n"
+    write(str(tmp_path), files, qrels)
+    try:
+        ref = ref_loader.rcv1(str(tmp_path), full=False)
+    except (ValueError, IndexError, KeyError) as e:
+        ref = e
+    try:
+        d, ids = rcv1.load(str(tmp_path), full=False, with_ids=True)
+    except ValueError as e:
+        d = e
+    # `16  4:2  6:3`: the doubled space yields an empty token, "".split(':')(0).toInt throws in the reference
+    assert isinstance(ref, Exception) == isinstance(d, Exception)
+    if isinstance(ref, Exception):
+        files[rcv1.FILES[0]] = files[rcv1.FILES[0]].replace("16  4:2  6:3\n", "16  4:2 6:3\n")
+        write(str(tmp_path), files, qrels)
+        ref = ref_loader.rcv1(str(tmp_path), full=False)
+        d, ids = rcv1.load(str(tmp_path), full=False, with_ids=True)
+    rp, col, val, lab, rids = ref
+    np.testing.assert_array_equal(ids, rids)
+    np.testing.assert_array_equal(d.label, lab)
+    assert canon(d.row_ptr, d.col, d.val) == canon(rp, col, val)
