@@ -322,6 +322,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_sweep:
         out["eval_pass"] = eval_pass(eng, n_train, bytes_per_row)
         out["hogwild"] = hogwild(eng, n_train)
+        out["dense_logistic"] = dense_logistic(dsgd_amd, local_rank)
 
     # ---- CPU baseline on this box's host cores (rank 0, N=1 only) --------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -396,6 +397,38 @@ def hogwild(eng, n_train, workers=256, batch=100, updates=60000):
     return {"workers": len(split), "batch": batch, "updates": int(u), "examples_per_s": u * batch / dt,
             "updates_per_s": u / dt, "ms": 1e3 * dt, "test_loss_after": loss, "test_acc_after": acc,
             "note": "one lock-free workgroup per worker on ONE device-resident w; wall time incl. launch and join"}
+
+
+def dense_logistic(dsgd_amd, device, rows=1250000, dim=4096):
+    """BASELINE.json configs[4] on ONE GPU's share: 10 M x 4096 over 8 GPUs = 1.25 M rows (20.5 GB) per GPU, generated
+    on the device; mini-batch steps of contiguous 4,096 / 65,536-row slices.  No reference counterpart (the optional
+    dense variant of north_star); roofline 16,388 B per example."""
+    res = {"rows": rows, "dim": dim, "bytes_per_example": 4 * dim + 4, "batches": [],
+           "note": "dsgd_dense_step_kernel: row block read once, forward and gradient products from registers (v_fma: an fp32 "
+                   "GEMV fills 1/16 of an MFMA at the vector rate -- csrc/dsgd_dense.hpp); no reference counterpart"}
+    with dsgd_amd.DenseLogistic(dim, device=device) as eng:
+        t0 = time.perf_counter()
+        eng.generate(rows, seed=device)
+        res["generate_s"] = round(time.perf_counter() - t0, 2)
+        for b, steps in ((65536, 40), (4096, 200)):
+            starts = [(i * b) % (rows - b) for i in range(steps + 5)]
+            for st in starts[:5]:
+                eng.step(st, st + b, 1.0)
+            eng.synchronize()
+            eng.prof(True)
+            t0 = time.perf_counter()
+            for st in starts[5:]:
+                eng.step(st, st + b, 1.0)
+            eng.synchronize()
+            dt = time.perf_counter() - t0
+            kms, kn = eng.prof(False)
+            ex = b * steps / dt
+            res["batches"].append({"batch": b, "steps": steps, "examples_per_s": ex, "us_per_step": 1e6 * dt / steps,
+                                   "frac_hbm_peak": ex * (4 * dim + 4) / HBM_PEAK, "kernel_ms_avg": kms,
+                                   "kernel_frac_hbm_peak": (b * (4 * dim + 4) / (kms * 1e-3) / HBM_PEAK) if kms > 0 else None})
+        loss, acc = eng.loss(rows - 65536, rows)
+        res["loss_after"], res["acc_after"] = loss, acc
+    return res
 
 
 def cpu_baseline(data, n_train, budget_s):

@@ -58,7 +58,7 @@ def hipcc_path() -> str:
 
 def build_hip(force: bool = False) -> str:
     header = os.path.join(HERE, "..", "include", "dsgd.h")
-    if not force and not _stale(HIP_LIB, HIP_SRC, os.path.join(CSRC, "dsgd_kernels.hpp"), os.path.join(CSRC, "dsgd_batch.hpp"),
+    if not force and not _stale(HIP_LIB, HIP_SRC, os.path.join(CSRC, "dsgd_kernels.hpp"), os.path.join(CSRC, "dsgd_batch.hpp"), os.path.join(CSRC, "dsgd_dense.hpp"),
                               header, __file__):
         return HIP_LIB
     os.makedirs(LIBDIR, exist_ok=True)

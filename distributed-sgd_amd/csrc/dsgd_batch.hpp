@@ -638,7 +638,7 @@ struct PlanArgs {
   const int* idx;
   const WorkSeg* segs;       // n_steps x n_workers
   DevScalars* sc;
-  unsigned long long* tprof; // optional (tuning runs): shader-clock cycles of thread 0 in {gradient, sweep + staging, reduce}, steps
+  unsigned long long* tprof; // optional (tuning runs): 16 words -- shader-clock cycles of thread 0 in nine phases of a batch, [15] = steps
   long long step_begin, step_end;
   float k_total, lr, lambda;
   int vexp, n_workers, dp;
@@ -725,7 +725,14 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
   for (int j = tid; j < a.dp; j += PLAN_THREADS) dot_part += (double)a.w[j] * (double)a.ds[j];
   double dot = block_sum_f64(dot_part, red);   // (also the barrier behind the LDS initialisation)
   unsigned long long n_act_total = 0;
-  unsigned long long tp[3] = {0, 0, 0};
+  unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int i, unsigned long long& last) {   // tuning runs only: cycles since the previous stamp -> tp[i]
+    if (a.tprof) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      tp[i] += now - last;
+      last = now;
+    }
+  };
 
   typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
   auto wload = [&](int c) -> float {   // hot ranks from LDS, the tail from L1/L2 (two loads + a select of VALUES: w_at)
@@ -820,10 +827,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
       ddot = 0.0;
       n_act = 0;
     }
-    const unsigned long long t0 = a.tprof ? __builtin_readcyclecounter() : 0ull;
-    long long sb4;
-    int sl4;
-    seg_load(n + 4, sb4, sl4);   // (used when the window shifts at the end of the iteration)
+    unsigned long long tl = a.tprof ? __builtin_readcyclecounter() : 0ull;
     const int B = sl[0], Bn = sl[1];
     int bits = 0;
     while ((1 << bits) < B) ++bits;
@@ -833,10 +837,18 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     // ---- gradient of worker k on the weights of the previous step, interleaved with the tables of batch n+1 ----
     if (bd.x > 0) bt_items_dot<PLAN_THREADS, PLAN_R>(Lc, items, wload);
     const BtScan scn = bt_build_p1<PLAN_THREADS, PLAN_CAP>(Ln, Bn, 0, row_next);
+    // (requested behind the gather's wait for its non-zeros: a request in front of it would be waited for as well)
+    long long sb4;
+    int sl4;
+    seg_load(n + 4, sb4, sl4);   // used when the window shifts at the end of the iteration
+    stamp(0, tl);
     __syncthreads();
+    stamp(1, tl);
     if (bd.x > 0) n_act += bt_gate(Lc, bd.x);
     bt_build_p2<PLAN_THREADS, PLAN_CAP>(Ln, Bn, 0, row_next, scn);
+    stamp(2, tl);
     __syncthreads();
+    stamp(3, tl);
     if (bd.x > 0) bt_scatter<PLAN_R, true>(Lc, a.gcold, items, qscale);
     const int2 bd_n = bt_build_p3<PLAN_THREADS>(Ln);
     if (bd.x < B) {   // whatever did not fit the staged sub-batch (long rows, lists beyond 128 rows): stage by stage
@@ -846,10 +858,12 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     }
     // ---- nothing of batch n+1 / n+2 depends on w until the weight gather: request it all now ----
     if (Bn > 0 && bd_n.x > 0) bt_items_issue<PLAN_THREADS, PLAN_R>(a.m, Ln, bd_n.y, items);
+    stamp(4, tl);
     row_next = rows_of(sl[2], rid_next2);
     rid_next2 = load_rid(sb[3], sl[3]);
+    stamp(5, tl);
     __syncthreads();   // every contribution of this batch is in the accumulators
-    const unsigned long long t1 = a.tprof ? __builtin_readcyclecounter() : 0ull;
+    stamp(6, tl);
     // ---- sweep: this worker's regularised sum on its support; the hot ranks never leave LDS ----
     for (int j = tid; j < hl; j += PLAN_THREADS) {
       const int q = L.acc[j];
@@ -938,7 +952,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     }
     // (`red` is free: the previous collect is behind three barriers)
     if (k == K - 1) block_sum_f64_publish(ddot, red);
-    const unsigned long long t2 = a.tprof ? __builtin_readcyclecounter() : 0ull;
+    stamp(7, tl);
     __syncthreads();   // the weights of the next gather are written; the wave partials are visible
     if (k == K - 1) {
       dot += block_sum_f64_collect(red);   // every thread adds the same total: `dot` stays thread-uniform
@@ -954,21 +968,15 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     to_scalar(sb4, sl4);
     sb[3] = sb4;
     sl[3] = sl4;
-    if (a.tprof) {
-      tp[0] += t1 - t0;
-      tp[1] += t2 - t1;
-      tp[2] += __builtin_readcyclecounter() - t2;
-    }
+    stamp(8, tl);
   }
   n_act_total = (unsigned long long)wave_sum_u32((unsigned int)n_act_total);
   if ((tid & 63) == 0 && n_act_total) atomicAdd(&a.sc->n_active, n_act_total);
   if (tid == 0) {
     a.sc->s_reg = (float)(2.0 * (double)a.lambda * dot);
     if (a.tprof) {
-      a.tprof[0] += tp[0];
-      a.tprof[1] += tp[1];
-      a.tprof[2] += tp[2];
-      a.tprof[3] += (unsigned long long)(a.step_end - a.step_begin);
+      for (int i = 0; i < 9; ++i) a.tprof[i] += tp[i];
+      a.tprof[15] += (unsigned long long)(a.step_end - a.step_begin);
     }
   }
 }

@@ -1,0 +1,168 @@
+// Device code of libdsgd_hip, part 3 (gfx950 only): K8, the DENSE logistic mini-batch step of BASELINE.json
+// configs[4] ("Synthetic dense 10M x 4096 logistic, mini-batch GEMV").  Included by dsgd_hip.hip.
+//
+// NO REFERENCE COUNTERPART: zifeo/distributed-sgd has exactly one model, the sparse hinge "SVM"
+// (core/ml/SparseSVM.scala:11; Main.scala:67 "could use another model").  This kernel family is the optional variant
+// north_star names; its oracle (oracle/dense_ref.py) restates textbook logistic regression in fp64 and is pinned by
+// finite differences, not by anything in the reference: PARITY UNPINNED by construction.
+//
+//   z = X w,  p = sigmoid(z),  loss = mean(softplus(z) - y z),  g = X^T (p - y) / B,  w <- w - lr * g
+//
+// Roofline: one fp32 row of D = 4096 features is 16,388 bytes for 4 D flops: 1 flop per byte, far
+// left of the ridge -- HBM-bound.  The row block is read ONCE: it stays in registers between the forward product and
+// the gradient product.
+//
+// Why not MFMA (measured reasoning, MI355X_MICROARCH.md "Matrix cores"): with fp32 INPUTS the matrix pipe runs at
+// the fp32 VECTOR rate (v_mfma_f32_32x32x2_f32: 64 flop/clk/SIMD), and a matrix-VECTOR product fills one column of
+// the N dimension: 1/32 (32x32x2) or 1/16 (16x16x4) of every instruction's multiply-adds are useful.  At 1/16 the
+// two products of a step would need ~45 % of the matrix pipe's cycles to keep up with HBM and the operand layout
+// (rows across lanes) forces 64-byte load segments; v_fma on a lane-owns-columns layout needs 5 % of the VALU and
+// loads 1 KB per wave instruction.  The matrix cores have nothing to offer a single fp32 GEMV.
+#pragma once
+
+constexpr int DN_ROWS = 8;          // rows per block and workgroup iteration
+constexpr int DN_COLS = 8;          // columns per lane: two float4 (D / 2 apart)
+
+struct DenseArgs {
+  const float* __restrict__ X;      // n_rows x D, row-major
+  const float* __restrict__ y;      // n_rows labels in {0, 1}
+  const float* __restrict__ w;      // D
+  float* __restrict__ gpart;        // gridDim.x x D per-workgroup sums of (p - y) * x  (null: evaluation only)
+  double* __restrict__ lpart;       // gridDim.x x 2: sum of losses, correct predictions
+  long long row_begin, row_end;
+  int D;
+};
+
+// One workgroup of D / 8 lanes per row block: lane t owns columns [4t, 4t+4) and [D/2 + 4t, D/2 + 4t + 4) of every
+// row (each wave-level load is 1 KB of one row).  Two workgroups share a CU (<= 128 VGPRs each): one computes while
+// the other's loads are in flight.
+__global__ void __launch_bounds__(1024) dsgd_dense_step_kernel(DenseArgs a) {
+  __shared__ float zpart[16][DN_ROWS];
+  __shared__ float rl[DN_ROWS];
+  __shared__ double lred[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+  const int c0 = 4 * tid, c1 = a.D / 2 + 4 * tid;
+  const float4 w0 = *reinterpret_cast<const float4*>(a.w + c0), w1 = *reinterpret_cast<const float4*>(a.w + c1);
+  float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+  double loss_acc = 0.0, corr_acc = 0.0;   // (thread r < DN_ROWS accumulates row r of every block)
+  const long long n_blocks = (a.row_end - a.row_begin + DN_ROWS - 1) / DN_ROWS;
+  for (long long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const long long r0 = a.row_begin + blk * DN_ROWS;
+    float4 x0[DN_ROWS], x1[DN_ROWS];
+#pragma unroll
+    for (int i = 0; i < DN_ROWS; ++i) {
+      const bool in = r0 + i < a.row_end;
+      const float* row = a.X + (in ? r0 + i : a.row_begin) * (long long)a.D;
+      x0[i] = *reinterpret_cast<const float4*>(row + c0);
+      x1[i] = *reinterpret_cast<const float4*>(row + c1);
+    }
+    // forward: partial z per lane, wave sums, workgroup sums
+#pragma unroll
+    for (int i = 0; i < DN_ROWS; ++i) {
+      float p = x0[i].x * w0.x;
+      p = fmaf(x0[i].y, w0.y, p);
+      p = fmaf(x0[i].z, w0.z, p);
+      p = fmaf(x0[i].w, w0.w, p);
+      p = fmaf(x1[i].x, w1.x, p);
+      p = fmaf(x1[i].y, w1.y, p);
+      p = fmaf(x1[i].z, w1.z, p);
+      p = fmaf(x1[i].w, w1.w, p);
+      p = group_sum<64>(p);
+      if (lane == 0) zpart[wave][i] = p;
+    }
+    __syncthreads();
+    if (tid < DN_ROWS) {
+      float z = 0.0f;
+      for (int wv = 0; wv < n_waves; ++wv) z += zpart[wv][tid];
+      const bool in = r0 + tid < a.row_end;
+      const float yy = in ? a.y[r0 + tid] : 0.0f;
+      const float p = 1.0f / (1.0f + __expf(-z));
+      rl[tid] = in ? p - yy : 0.0f;
+      if (in) {
+        // softplus(z) - y z, evaluated without overflow: max(z, 0) + log1p(exp(-|z|)) - y z
+        loss_acc += (double)(fmaxf(z, 0.0f) + log1pf(__expf(-fabsf(z))) - yy * z);
+        corr_acc += ((z > 0.0f) == (yy > 0.5f)) ? 1.0 : 0.0;
+      }
+    }
+    __syncthreads();
+    // gradient: the same registers
+    if (a.gpart) {
+#pragma unroll
+      for (int i = 0; i < DN_ROWS; ++i) {
+        const float r = rl[i];
+        g0.x = fmaf(r, x0[i].x, g0.x);
+        g0.y = fmaf(r, x0[i].y, g0.y);
+        g0.z = fmaf(r, x0[i].z, g0.z);
+        g0.w = fmaf(r, x0[i].w, g0.w);
+        g1.x = fmaf(r, x1[i].x, g1.x);
+        g1.y = fmaf(r, x1[i].y, g1.y);
+        g1.z = fmaf(r, x1[i].z, g1.z);
+        g1.w = fmaf(r, x1[i].w, g1.w);
+      }
+    }
+  }
+  if (a.gpart) {
+    float* mine = a.gpart + (long long)blockIdx.x * a.D;
+    *reinterpret_cast<float4*>(mine + c0) = g0;
+    *reinterpret_cast<float4*>(mine + c1) = g1;
+  }
+  if (tid == 0) lred[0] = lred[1] = 0.0;
+  __syncthreads();
+  if (tid < DN_ROWS) {
+    atomicAdd(&lred[0], loss_acc);
+    atomicAdd(&lred[1], corr_acc);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    a.lpart[2 * blockIdx.x] = lred[0];
+    a.lpart[2 * blockIdx.x + 1] = lred[1];
+  }
+}
+
+// g = sum of the per-workgroup partials (fixed order); with a communicator the caller all-reduces g before
+// dsgd_dense_apply_kernel.  One thread per column.
+__global__ void __launch_bounds__(256) dsgd_dense_reduce_kernel(const float* __restrict__ gpart, int n_part, int D,
+                                                               float* __restrict__ g) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= D) return;
+  float s = 0.0f;
+  for (int b = 0; b < n_part; ++b) s += gpart[(long long)b * D + j];
+  g[j] = s;
+}
+__global__ void __launch_bounds__(256) dsgd_dense_apply_kernel(float* __restrict__ w, const float* __restrict__ g, int D,
+                                                              float scale /* lr / global batch */) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < D) w[j] -= scale * g[j];
+}
+
+// synthetic data on the device (configs[4]: "X generated on-device per shard (seed = rank)"): x ~ N(0, 1) / sqrt(D)
+// from a counter-based generator (splitmix64 of the element index), y = [x . w* + 0.1 N(0,1) > 0] with planted
+// w* ~ N(0, 1).  Two passes: rows, then labels.
+__device__ __forceinline__ float dn_normal(unsigned long long key) {
+  const unsigned long long a = hog_mix(key), b = hog_mix(key ^ 0x5851F42D4C957F2Dull);
+  const float u1 = ((float)(a >> 40) + 1.0f) * (1.0f / 16777217.0f);   // (0, 1)
+  const float u2 = (float)(b >> 40) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
+}
+__global__ void __launch_bounds__(256) dsgd_dense_generate_kernel(float* __restrict__ X, float* __restrict__ y,
+                                                                 long long n_rows, int D, unsigned long long seed) {
+  __shared__ float red[4];
+  const float inv = rsqrtf((float)D);
+  for (long long row = blockIdx.x; row < n_rows; row += gridDim.x) {
+    float dot = 0.0f;
+    for (int j = threadIdx.x; j < D; j += blockDim.x) {
+      const float x = dn_normal(seed * 0x9E3779B97F4A7C15ull + (unsigned long long)row * (unsigned long long)D + j) * inv;
+      const float ws = dn_normal(0xD1B54A32D192ED03ull * (seed + 1) + j);   // planted separator (same for every row)
+      X[row * (long long)D + j] = x;
+      dot = fmaf(x, ws, dot);
+    }
+    dot = group_sum<64>(dot);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float z = red[0] + red[1] + red[2] + red[3] + 0.1f * dn_normal(~seed * 0xA0761D6478BD642Full + (unsigned long long)row);
+      y[row] = z > 0.0f ? 1.0f : 0.0f;
+    }
+  }
+}

@@ -102,6 +102,7 @@ static bool available() {
 
 #include "dsgd_kernels.hpp"
 #include "dsgd_batch.hpp"
+#include "dsgd_dense.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1310,8 +1311,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;
   if (const char* e = getenv("DSGD_PLAN_MAX_ROWS")) c->plan_max_rows = std::max(1LL, atoll(e));
   if (getenv("DSGD_PLAN_PROF") && atoi(getenv("DSGD_PLAN_PROF"))) {
-    HIP_TRY_B(hipMalloc(&c->d_tprof, sizeof(unsigned long long) * 8));
-    HIP_TRY_B(hipMemsetAsync(c->d_tprof, 0, sizeof(unsigned long long) * 8, c->stream));
+    HIP_TRY_B(hipMalloc(&c->d_tprof, sizeof(unsigned long long) * 16));
+    HIP_TRY_B(hipMemsetAsync(c->d_tprof, 0, sizeof(unsigned long long) * 16, c->stream));
   }
   if (c->dbg) c->stream_mode = 3;   // the ablation build exists for the mode-3 kernel
   if (const char* e = getenv("DSGD_HW_W")) c->hw_w = atoi(e);
@@ -2377,11 +2378,11 @@ int dsgd_debug_cycles(dsgd_ctx* c, uint64_t* out8, int32_t reset) {
   if (!out8) return fail(DSGD_EINVAL, "null out8");
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
-  for (int i = 0; i < 8; ++i) out8[i] = 0;
+  for (int i = 0; i < 16; ++i) out8[i] = 0;
   if (!c->d_tprof) return DSGD_OK;
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipMemcpy(out8, c->d_tprof, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost));
-  if (reset) HIP_TRY(hipMemset(c->d_tprof, 0, sizeof(unsigned long long) * 8));
+  HIP_TRY(hipMemcpy(out8, c->d_tprof, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+  if (reset) HIP_TRY(hipMemset(c->d_tprof, 0, sizeof(unsigned long long) * 16));
   return DSGD_OK;
 }
 
@@ -2405,6 +2406,255 @@ int dsgd_device_ptrs(dsgd_ctx* c, void** w_dev, void** g_dev, void** stream) {
   if (w_dev) *w_dev = c->d_w;
   if (g_dev) *g_dev = c->d_gsum;
   if (stream) *stream = c->stream;
+  return DSGD_OK;
+}
+
+// ---- K8: dense logistic mini-batch step (no reference counterpart; include/dsgd.h) ------------------------------
+struct dsgd_dense {
+  int D = 0, device = 0, n_cu = 256;
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  long long n_rows = 0;
+  float* d_X = nullptr;
+  float* d_y = nullptr;
+  float* d_w = nullptr;
+  float* d_g = nullptr;
+  float* d_gpart = nullptr;   // n_wg x D
+  double* d_lpart = nullptr;  // n_wg x 2
+  double* h_lpart = nullptr;  // pinned
+  int n_wg = 0;
+  rccl::comm_t comm = nullptr;
+  int world = 1;
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  size_t ev_used = 0;
+  double ms_sum = 0.0;
+  long long ms_n = 0;
+};
+static int dn_bind(dsgd_dense* d) {
+  if (!d) return fail(DSGD_EINVAL, "null dense object");
+  HIP_TRY(hipSetDevice(d->device));
+  return DSGD_OK;
+}
+static int dn_collect(dsgd_dense* d) {
+  for (size_t i = 0; i < d->ev_used; ++i) {
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, d->ev[i].first, d->ev[i].second));
+    d->ms_sum += ms;
+    d->ms_n++;
+  }
+  d->ev_used = 0;
+  return DSGD_OK;
+}
+static int dn_launch(dsgd_dense* d, long long rb, long long re, bool grad) {
+  DenseArgs a;
+  a.X = d->d_X;
+  a.y = d->d_y;
+  a.w = d->d_w;
+  a.gpart = grad ? d->d_gpart : nullptr;
+  a.lpart = d->d_lpart;
+  a.row_begin = rb;
+  a.row_end = re;
+  a.D = d->D;
+  const long long n_blocks = (re - rb + DN_ROWS - 1) / DN_ROWS;
+  const int grid = (int)std::max<long long>(1, std::min<long long>(d->n_wg, n_blocks));
+  size_t slot = (size_t)-1;
+  if (d->prof && grad) {
+    if (d->ev_used == d->ev.size()) {
+      hipEvent_t x, y;
+      HIP_TRY(hipEventCreate(&x));
+      HIP_TRY(hipEventCreate(&y));
+      d->ev.emplace_back(x, y);
+    }
+    slot = d->ev_used++;
+    HIP_TRY(hipEventRecord(d->ev[slot].first, d->stream));
+  }
+  hipLaunchKernelGGL(dsgd_dense_step_kernel, dim3(grid), dim3(d->D / DN_COLS), 0, d->stream, a);
+  HIP_TRY(hipGetLastError());
+  if (slot != (size_t)-1) HIP_TRY(hipEventRecord(d->ev[slot].second, d->stream));
+  return grid;
+}
+
+int dsgd_dense_create(int32_t n_features, int32_t device, dsgd_dense** out) {
+  if (!out) return fail(DSGD_EINVAL, "null argument");
+  if (n_features < 512 || n_features > 8192 || n_features % 512)
+    return fail(DSGD_EINVAL, "n_features must be a multiple of 512 in [512, 8192] (one lane owns 8 columns)");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    return fail(DSGD_EUNSUPPORTED, "no HIP device visible: libdsgd_hip has no CPU fallback");
+  if (device < 0 || device >= n) return fail(DSGD_EINVAL, "device %d out of range (%d devices)", device, n);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(DSGD_EUNSUPPORTED, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  dsgd_dense* d = new (std::nothrow) dsgd_dense();
+  if (!d) return fail(DSGD_ENOMEM, "out of host memory");
+  d->D = n_features;
+  d->device = device;
+  d->n_cu = prop.multiProcessorCount;
+  d->n_wg = 2 * d->n_cu;   // two workgroups per CU: one computes while the other's loads are in flight
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&d->d_w, sizeof(float) * d->D);
+  if (e == hipSuccess) e = hipMalloc(&d->d_g, sizeof(float) * d->D);
+  if (e == hipSuccess) e = hipMalloc(&d->d_gpart, sizeof(float) * (size_t)d->n_wg * d->D);
+  if (e == hipSuccess) e = hipMalloc(&d->d_lpart, sizeof(double) * 2 * d->n_wg);
+  if (e == hipSuccess) e = hipHostMalloc(&d->h_lpart, sizeof(double) * 2 * d->n_wg, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMemset(d->d_w, 0, sizeof(float) * d->D);
+  if (e != hipSuccess) {
+    dsgd_dense_destroy(d);
+    return fail(DSGD_EHIP, "dense create: %s", hipGetErrorString(e));
+  }
+  *out = d;
+  return DSGD_OK;
+}
+
+int dsgd_dense_destroy(dsgd_dense* d) {
+  if (!d) return DSGD_OK;
+  (void)hipSetDevice(d->device);
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
+  if (d->comm && rccl::available()) rccl::CommDestroy(d->comm);
+  for (auto& e : d->ev) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  (void)hipFree(d->d_X);
+  (void)hipFree(d->d_y);
+  (void)hipFree(d->d_w);
+  (void)hipFree(d->d_g);
+  (void)hipFree(d->d_gpart);
+  (void)hipFree(d->d_lpart);
+  if (d->h_lpart) (void)hipHostFree(d->h_lpart);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+  return DSGD_OK;
+}
+
+static int dn_alloc_rows(dsgd_dense* d, long long n_rows) {
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  (void)hipFree(d->d_X);
+  (void)hipFree(d->d_y);
+  d->d_X = nullptr;
+  d->d_y = nullptr;
+  d->n_rows = 0;
+  HIP_TRY(hipMalloc(&d->d_X, sizeof(float) * (size_t)n_rows * (size_t)d->D));
+  HIP_TRY(hipMalloc(&d->d_y, sizeof(float) * (size_t)n_rows));
+  d->n_rows = n_rows;
+  return DSGD_OK;
+}
+
+int dsgd_dense_generate(dsgd_dense* d, int64_t n_rows, uint64_t seed) {
+  DSGD_TRY(dn_bind(d));
+  if (n_rows < 1) return fail(DSGD_EINVAL, "n_rows must be >= 1");
+  std::lock_guard<std::mutex> lk(d->mu);
+  DSGD_TRY(dn_alloc_rows(d, n_rows));
+  hipLaunchKernelGGL(dsgd_dense_generate_kernel, dim3((unsigned)std::min<long long>(n_rows, (long long)d->n_cu * 8)), dim3(256), 0,
+                     d->stream, d->d_X, d->d_y, (long long)n_rows, d->D, (unsigned long long)seed);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return DSGD_OK;
+}
+
+int dsgd_dense_load(dsgd_dense* d, int64_t n_rows, const float* X, const float* y) {
+  DSGD_TRY(dn_bind(d));
+  if (n_rows < 1 || !X || !y) return fail(DSGD_EINVAL, "n_rows must be >= 1 and arrays non-null");
+  for (int64_t i = 0; i < n_rows; ++i)
+    if (y[i] != 0.0f && y[i] != 1.0f) return fail(DSGD_EINVAL, "label[%lld] = %g, expected 0 or 1", (long long)i, (double)y[i]);
+  std::lock_guard<std::mutex> lk(d->mu);
+  DSGD_TRY(dn_alloc_rows(d, n_rows));
+  HIP_TRY(hipMemcpy(d->d_X, X, sizeof(float) * (size_t)n_rows * (size_t)d->D, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d->d_y, y, sizeof(float) * (size_t)n_rows, hipMemcpyHostToDevice));
+  return DSGD_OK;
+}
+
+int dsgd_dense_set_weights(dsgd_dense* d, const float* w) {
+  DSGD_TRY(dn_bind(d));
+  if (!w) return fail(DSGD_EINVAL, "null w");
+  std::lock_guard<std::mutex> lk(d->mu);
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  HIP_TRY(hipMemcpy(d->d_w, w, sizeof(float) * d->D, hipMemcpyHostToDevice));
+  return DSGD_OK;
+}
+int dsgd_dense_get_weights(dsgd_dense* d, float* w_out) {
+  DSGD_TRY(dn_bind(d));
+  if (!w_out) return fail(DSGD_EINVAL, "null w_out");
+  std::lock_guard<std::mutex> lk(d->mu);
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  HIP_TRY(hipMemcpy(w_out, d->d_w, sizeof(float) * d->D, hipMemcpyDeviceToHost));
+  return DSGD_OK;
+}
+
+static int dn_check_range(dsgd_dense* d, long long rb, long long re) {
+  if (!d->d_X) return fail(DSGD_ESTATE, "no data (dsgd_dense_generate / dsgd_dense_load)");
+  if (re <= rb) return fail(DSGD_EINVAL, "empty row range");
+  if (rb < 0 || re > d->n_rows) return fail(DSGD_ERANGE, "rows [%lld, %lld) outside the %lld resident rows", rb, re, d->n_rows);
+  return DSGD_OK;
+}
+
+int dsgd_dense_step(dsgd_dense* d, int64_t row_begin, int64_t row_end, float lr) {
+  DSGD_TRY(dn_bind(d));
+  std::lock_guard<std::mutex> lk(d->mu);
+  DSGD_TRY(dn_check_range(d, row_begin, row_end));
+  const int grid = dn_launch(d, row_begin, row_end, true);
+  if (grid < 0) return grid;
+  hipLaunchKernelGGL(dsgd_dense_reduce_kernel, dim3((d->D + 255) / 256), dim3(256), 0, d->stream, d->d_gpart, grid, d->D, d->d_g);
+  HIP_TRY(hipGetLastError());
+  if (d->comm) RCCL_TRY(rccl::AllReduce(d->d_g, d->d_g, (size_t)d->D, rccl::kFloat32, rccl::kSum, d->comm, d->stream));
+  const float scale = lr / ((float)(row_end - row_begin) * (float)d->world);   // every rank contributes an equal batch
+  hipLaunchKernelGGL(dsgd_dense_apply_kernel, dim3((d->D + 255) / 256), dim3(256), 0, d->stream, d->d_w, d->d_g, d->D, scale);
+  HIP_TRY(hipGetLastError());
+  return DSGD_OK;
+}
+
+int dsgd_dense_synchronize(dsgd_dense* d) {
+  DSGD_TRY(dn_bind(d));
+  std::lock_guard<std::mutex> lk(d->mu);
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return dn_collect(d);
+}
+
+int dsgd_dense_loss(dsgd_dense* d, int64_t row_begin, int64_t row_end, double* loss, double* acc) {
+  DSGD_TRY(dn_bind(d));
+  std::lock_guard<std::mutex> lk(d->mu);
+  DSGD_TRY(dn_check_range(d, row_begin, row_end));
+  const int grid = dn_launch(d, row_begin, row_end, false);
+  if (grid < 0) return grid;
+  HIP_TRY(hipMemcpyAsync(d->h_lpart, d->d_lpart, sizeof(double) * 2 * grid, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  double l = 0.0, c = 0.0;
+  for (int b = 0; b < grid; ++b) {
+    l += d->h_lpart[2 * b];
+    c += d->h_lpart[2 * b + 1];
+  }
+  const double n = (double)(row_end - row_begin);
+  if (loss) *loss = l / n;
+  if (acc) *acc = c / n;
+  return DSGD_OK;
+}
+
+int dsgd_dense_comm_init(dsgd_dense* d, const char* unique_id, int32_t world_size, int32_t rank) {
+  DSGD_TRY(dn_bind(d));
+  if (!unique_id || world_size < 1 || rank < 0 || rank >= world_size) return fail(DSGD_EINVAL, "bad communicator arguments");
+  if (!rccl::available()) return fail(DSGD_ERCCL, "librccl could not be loaded");
+  std::lock_guard<std::mutex> lk(d->mu);
+  if (d->comm) return fail(DSGD_ESTATE, "communicator already attached");
+  rccl::unique_id_t id;
+  memcpy(id.internal, unique_id, DSGD_UNIQUE_ID_BYTES);
+  RCCL_TRY(rccl::CommInitRank(&d->comm, world_size, id, rank));
+  d->world = world_size;
+  return DSGD_OK;
+}
+
+int dsgd_dense_prof(dsgd_dense* d, int32_t enable, double* kernel_ms_avg, int64_t* n_launches) {
+  DSGD_TRY(dn_bind(d));
+  std::lock_guard<std::mutex> lk(d->mu);
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  DSGD_TRY(dn_collect(d));
+  if (kernel_ms_avg) *kernel_ms_avg = d->ms_n ? d->ms_sum / (double)d->ms_n : 0.0;
+  if (n_launches) *n_launches = d->ms_n;
+  d->ms_sum = 0.0;
+  d->ms_n = 0;
+  d->prof = enable != 0;
   return DSGD_OK;
 }
 

@@ -239,7 +239,7 @@ class Engine:
         return dict(zip(("stream_mode", "hsplit", "fix_shift", "cold_packed", "plan_kernel", "fix_bound"), [int(x) for x in v]))
 
     def debug_cycles(self, reset=True):
-        v = (C.c_uint64 * 8)()
+        v = (C.c_uint64 * 16)()
         check(self._lib.dsgd_debug_cycles(self._ctx, v, C.c_int32(1 if reset else 0)))
         return [int(x) for x in v]
 

@@ -216,14 +216,41 @@ int dsgd_range_nnz(dsgd_ctx* ctx, int64_t row_begin, int64_t row_end, int64_t* n
 int dsgd_tuning_info(dsgd_ctx* ctx, int32_t* vals, int32_t n);
 
 /* Tuning aid (DSGD_PLAN_PROF=1 in the environment at dsgd_create): shader-clock cycles thread 0 of the small-batch
- * plan kernel spent in {gradient phase, sweep, reduce} and the number of steps, accumulated since the last reset;
- * all zeros when the aid is off.                                                                                */
-int dsgd_debug_cycles(dsgd_ctx* ctx, uint64_t* out8, int32_t reset);
+ * plan kernel spent in the nine phases of a batch ([0..8]: gather+dot, barrier, gate+tables, barrier, scatter,
+ * requests, barrier, sweep, barrier+collect) and the number of steps ([15]), accumulated since the last reset;
+ * 16 words, all zeros when the aid is off.                                                                       */
+int dsgd_debug_cycles(dsgd_ctx* ctx, uint64_t* out16, int32_t reset);
 
 /* name of the gradient kernel variant in use (for matching rocprofv3 kernel-trace rows)        */
 const char* dsgd_grad_kernel_name(dsgd_ctx* ctx);
 /* raw device pointers (float[D+1]) for hosts that own the collective (e.g. torch.distributed)  */
 int dsgd_device_ptrs(dsgd_ctx* ctx, void** w_dev, void** g_dev, void** stream);
+
+/* ---- K8: dense logistic mini-batch step (BASELINE.json configs[4]) ------------------------------------------
+ * NO REFERENCE COUNTERPART: the reference has one model, the sparse hinge "SVM" (core/ml/SparseSVM.scala:11;
+ * Main.scala:67 "could use another model").  This is the optional dense variant north_star names: a second, small
+ * object next to dsgd_ctx.  X is n_rows x D fp32 row-major in HBM (D a multiple of 512, <= 8192), labels in {0, 1}:
+ *   z = X w, p = sigmoid(z), loss = mean(softplus(z) - y z), g = X^T (p - y) / B, w <- w - lr g
+ * over the contiguous rows [row_begin, row_end) of the (pre-shuffled) shard -- one mini-batch.  With a communicator
+ * the gradient sums are all-reduced and B is the global batch.  Oracle: oracle/dense_ref.py (fp64, pinned by finite
+ * differences -- parity unpinned by construction).                                                                */
+typedef struct dsgd_dense dsgd_dense;
+int dsgd_dense_create(int32_t n_features, int32_t device, dsgd_dense** out);
+int dsgd_dense_destroy(dsgd_dense* d);
+/* synthetic shard generated on the device: x ~ N(0,1)/sqrt(D), y = [x . w* + noise > 0] (planted w*), seed = rank   */
+int dsgd_dense_generate(dsgd_dense* d, int64_t n_rows, uint64_t seed);
+/* host-provided data (tests): X n_rows x D row-major, y n_rows                                                    */
+int dsgd_dense_load(dsgd_dense* d, int64_t n_rows, const float* X, const float* y);
+int dsgd_dense_set_weights(dsgd_dense* d, const float* w /* D */);
+int dsgd_dense_get_weights(dsgd_dense* d, float* w_out /* D */);
+/* one mini-batch step, enqueued on the object's stream (dsgd_dense_synchronize collects)                          */
+int dsgd_dense_step(dsgd_dense* d, int64_t row_begin, int64_t row_end, float lr);
+int dsgd_dense_synchronize(dsgd_dense* d);
+/* mean logistic loss and accuracy of the resident weights over rows [row_begin, row_end) (no update)               */
+int dsgd_dense_loss(dsgd_dense* d, int64_t row_begin, int64_t row_end, double* loss, double* acc);
+int dsgd_dense_comm_init(dsgd_dense* d, const char* unique_id, int32_t world_size, int32_t rank);
+/* average device time (ms) of the step kernel since the last reset (HIP events on the object's stream)             */
+int dsgd_dense_prof(dsgd_dense* d, int32_t enable, double* kernel_ms_avg, int64_t* n_launches);
 
 #ifdef __cplusplus
 }

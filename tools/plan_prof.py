@@ -40,10 +40,11 @@ with dsgd_amd.Engine(data.dim, 1e-5) as eng:
         dt = time.perf_counter() - t0
         cyc = eng.debug_cycles(reset=True)
         plan.destroy()
-        n = max(1, cyc[3])
+        n = max(1, cyc[15])
+        names = ("gather_dot", "barrier1", "gate_tables", "barrier2", "scatter", "requests", "barrier3", "sweep", "barrier4_collect")
         out["plan"].append({"workers": k, "batch": b, "steps": steps, "us_per_step": 1e6 * dt / steps,
                             "kernel": eng.grad_kernel_name(),
-                            "cycles_per_step": {"gradient": cyc[0] / n, "sweep": cyc[1] / n, "reduce": cyc[2] / n}})
+                            "cycles_per_step": {nm: cyc[i] / n for i, nm in enumerate(names)}})
     for workers, updates in ((1, 2000), (16, 8000), (64, 20000), (256, 40000)):
         eng.set_weights(np.zeros(eng.dp, dtype=np.float32))
         split = [(r.start, r.stop) for r in host.split_vanilla(n_train, workers)]
