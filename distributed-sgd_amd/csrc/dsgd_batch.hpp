@@ -41,9 +41,9 @@ struct BtLds {
   int* ifirst;           // [cap] first work item of the row
   int* item_row;         // [cap]
   float* pdot;           // [cap] partial x.w per item
-  int* misc;             // [40]: 16 wave sums, 16 wave counts, item total, scratch
+  int* misc;             // [56]: 16 wave sums, 16 wave counts of fitting rows, 16 wave item totals, scratch
 };
-__host__ __device__ constexpr int bt_lds_words(int cap) { return 7 * cap + 40; }
+__host__ __device__ constexpr int bt_lds_words(int cap) { return 7 * cap + 56; }
 __device__ __forceinline__ void bt_carve(BtLds& L, int* base, int cap) {
   L.rst = reinterpret_cast<long long*>(base);   // (base is 8-byte aligned)
   L.rlen = base + 2 * cap;
@@ -130,7 +130,6 @@ __device__ __forceinline__ BtScan bt_build_p1(const BtLds& L, int B, int b0, con
   sc.nch = tid < nb ? (row.len + BT_CH - 1) / BT_CH : 0;
   sc.incl = wave_incl_scan_i32(sc.nch);
   if (lane == 63) L.misc[wave] = sc.incl;
-  if (tid == 0) L.misc[32] = 0;
   return sc;
 }
 template <int THREADS, int CAP>
@@ -141,14 +140,20 @@ __device__ __forceinline__ void bt_build_p2(const BtLds& L, int B, int b0, const
   for (int i = 0; i < wave; ++i) first += L.misc[i];
   const bool fits = tid < nb && first + sc.nch <= CAP;   // monotone in tid: the fitting rows are a prefix
   const unsigned long long bal = __builtin_amdgcn_ballot_w64(fits);
-  if (lane == 0) L.misc[16 + wave] = __popcll(bal);
+  // items of the sub-batch = end of the LAST fitting row (the prefix sums are monotone).  (A shared-word atomicMax by
+  // every row's thread was a 64-way LDS conflict: 4,500 of 33,500 cycles per batch in the phase counters.)
+  const int last = bal ? 63 - __builtin_clzll(bal) : 0;
+  const int wave_items = bal ? __builtin_amdgcn_readlane(first + sc.nch, last) : 0;
+  if (lane == 0) {
+    L.misc[16 + wave] = __popcll(bal);
+    L.misc[32 + wave] = wave_items;
+  }
   if (fits) {
     L.rst[tid] = row.st;
     L.rlen[tid] = row.len;
     L.rcoef[tid] = row.y;
     L.ifirst[tid] = first;
     for (int c = 0; c < sc.nch; ++c) L.item_row[first + c] = tid;
-    if (sc.nch) atomicMax(&L.misc[32], first + sc.nch);
   } else if (tid == 0) {   // the first row alone exceeds the item slots: bt_giant_row
     L.rst[0] = row.st;
     L.rlen[0] = row.len;
@@ -157,9 +162,12 @@ __device__ __forceinline__ void bt_build_p2(const BtLds& L, int B, int b0, const
 }
 template <int THREADS>
 __device__ __forceinline__ int2 bt_build_p3(const BtLds& L) {
-  int nbf = 0;
-  for (int i = 0; i < THREADS / 64; ++i) nbf += L.misc[16 + i];
-  return make_int2(nbf, L.misc[32]);
+  int nbf = 0, items = 0;
+  for (int i = 0; i < THREADS / 64; ++i) {
+    nbf += L.misc[16 + i];
+    items = max(items, L.misc[32 + i]);
+  }
+  return make_int2(nbf, items);
 }
 template <int THREADS, int CAP>
 __device__ __forceinline__ int2 bt_build(const BtLds& L, int B, int b0, const BtRow& row) {
@@ -181,14 +189,23 @@ __device__ __forceinline__ void bt_items_issue(const CsrView& m, const BtLds& L,
     const int row = valid ? L.item_row[i] : 0;
     it.irow[r] = valid ? row : -1;
     const int ch = valid ? i - L.ifirst[row] : 0;
-    const long long p0 = L.rst[row] + (long long)ch * BT_CH;
-    const int cnt = valid ? min(BT_CH, L.rlen[row] - ch * BT_CH) : 0;
+    const long long p0 = L.rst[row] + (long long)ch * BT_CH + sub * BT_K;
+    const int cnt = (valid ? min(BT_CH, L.rlen[row] - ch * BT_CH) : 0) - sub * BT_K;   // of this lane's eight slots
+    // lane `sub` owns EIGHT CONTIGUOUS non-zeros: two 16-byte loads per array (dword-aligned: rows start anywhere)
+    // instead of eight 4-byte ones -- the request phase was bound by the number of load instructions (512 per batch
+    // through one CU's texture addresser).  Slots past the row's end read the next row (or the arrays' padding) and
+    // are masked.
+    typedef int i32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const i32x4u ca = *reinterpret_cast<const i32x4u*>(m.col + p0), cb = *reinterpret_cast<const i32x4u*>(m.col + p0 + 4);
+    const f32x4u va = *reinterpret_cast<const f32x4u*>(m.val + p0), vb = *reinterpret_cast<const f32x4u*>(m.val + p0 + 4);
+    const int cs[BT_K] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+    const float vs[BT_K] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
     for (int k = 0; k < BT_K; ++k) {
-      const int e = sub + k * BT_G;
-      const bool in = e < cnt;
-      it.c[r][k] = in ? m.col[p0 + e] : -1;
-      it.v[r][k] = in ? m.val[p0 + e] : 0.0f;
+      const bool in = k < cnt;
+      it.c[r][k] = in ? cs[k] : -1;
+      it.v[r][k] = in ? vs[k] : 0.0f;
     }
   }
 }
@@ -741,12 +758,15 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     if (!hot) v = a.w[c];
     return v;
   };
-  // new weight of coordinate j given the summed gradient; returns the change of w[j] * ds[j]
-  auto step_w = [&](float gsum, float wo, float dsj, float& wn) -> double {
-    const float mean = filt(gsum / a.k_total);   // Vec.mean (ref: math/Vec.scala:139)
+  // new weight of coordinate j given the summed gradient; returns the change of w[j] * ds[j] (fp32 per thread -- a
+  // thread adds at most a dozen such terms per step -- and fp64 from the workgroup reduction on: the fp64 form cost
+  // five half-rate instructions per slot of the sweep, which is issue-bound)
+  const bool one_worker = a.k_total == 1.0f;
+  auto step_w = [&](float gsum, float wo, float dsj, float& wn) -> float {
+    const float mean = one_worker ? gsum : filt(gsum / a.k_total);   // Vec.mean (ref: math/Vec.scala:139); x / 1 == x
     const float updv = filt(mean * a.lr);        // learningRate * grad (ref: core/Master.scala:197)
     wn = filt(wo - updv);
-    return ((double)wn - (double)wo) * (double)dsj;
+    return (wn - wo) * dsj;
   };
 
   const int K = a.n_workers;
@@ -815,7 +835,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
   }
   float s = 0.0f;
   bool add_s = false;
-  double ddot = 0.0;
+  float ddot = 0.0f;
   unsigned int n_act = 0;
   for (long long n = 0; n < n_batches; ++n) {
     const BtLds& Lc = (n & 1) ? L2 : L;     // tables of batch n
@@ -824,7 +844,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     if (k == 0) {
       s = (float)(2.0 * (double)a.lambda * dot);   // thread-uniform: every thread carries the same dot
       add_s = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
-      ddot = 0.0;
+      ddot = 0.0f;
       n_act = 0;
     }
     unsigned long long tl = a.tprof ? __builtin_readcyclecounter() : 0ull;
@@ -837,10 +857,6 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     // ---- gradient of worker k on the weights of the previous step, interleaved with the tables of batch n+1 ----
     if (bd.x > 0) bt_items_dot<PLAN_THREADS, PLAN_R>(Lc, items, wload);
     const BtScan scn = bt_build_p1<PLAN_THREADS, PLAN_CAP>(Ln, Bn, 0, row_next);
-    // (requested behind the gather's wait for its non-zeros: a request in front of it would be waited for as well)
-    long long sb4;
-    int sl4;
-    seg_load(n + 4, sb4, sl4);   // used when the window shifts at the end of the iteration
     stamp(0, tl);
     __syncthreads();
     stamp(1, tl);
@@ -856,11 +872,18 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
       n_act += bt_batch<PLAN_THREADS, PLAN_R, true>(a.m, Lc, a.gcold, B, bd.x, [&](int t) { return (long long)list[t]; }, wload,
                                                    qscale, &a.sc->err);
     }
-    // ---- nothing of batch n+1 / n+2 depends on w until the weight gather: request it all now ----
-    if (Bn > 0 && bd_n.x > 0) bt_items_issue<PLAN_THREADS, PLAN_R>(a.m, Ln, bd_n.y, items);
+    // ---- nothing of batch n+1 / n+2 depends on w until the weight gather: request it all now.  ORDER MATTERS: the
+    // compiler cannot count outstanding loads across the loop, so the first use of an old load drains everything
+    // issued before it -- what consumes last iteration's loads (the row ids) goes first, the fresh requests last,
+    // and nothing below waits for them (measured with the phase counters: 6,500 of 33,500 cycles per batch were such
+    // waits when the descriptor / non-zero requests sat in front of these consumers) ----
     stamp(4, tl);
     row_next = rows_of(sl[2], rid_next2);
     rid_next2 = load_rid(sb[3], sl[3]);
+    long long sb4;
+    int sl4;
+    seg_load(n + 4, sb4, sl4);   // used when the window shifts at the end of the iteration
+    if (Bn > 0 && bd_n.x > 0) bt_items_issue<PLAN_THREADS, PLAN_R>(a.m, Ln, bd_n.y, items);
     stamp(5, tl);
     __syncthreads();   // every contribution of this batch is in the accumulators
     stamp(6, tl);
@@ -951,7 +974,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
       }
     }
     // (`red` is free: the previous collect is behind three barriers)
-    if (k == K - 1) block_sum_f64_publish(ddot, red);
+    if (k == K - 1) block_sum_f64_publish((double)ddot, red);
     stamp(7, tl);
     __syncthreads();   // the weights of the next gather are written; the wave partials are visible
     if (k == K - 1) {

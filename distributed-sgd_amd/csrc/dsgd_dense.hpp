@@ -119,15 +119,27 @@ __global__ void __launch_bounds__(1024) dsgd_dense_step_kernel(DenseArgs a) {
   }
 }
 
-// g = sum of the per-workgroup partials (fixed order); with a communicator the caller all-reduces g before
-// dsgd_dense_apply_kernel.  One thread per column.
-__global__ void __launch_bounds__(256) dsgd_dense_reduce_kernel(const float* __restrict__ gpart, int n_part, int D,
-                                                               float* __restrict__ g) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= D) return;
+// g = sum of the per-workgroup partials (fixed order: reproducible) and, without a communicator, the update in the
+// same pass.  Block = 64 columns x 16 phases over the partials (one thread per column summing 512 partials
+// one after the other took ~100 us -- more than the step kernel itself at batch 4,096).
+__global__ void __launch_bounds__(1024) dsgd_dense_reduce_kernel(const float* __restrict__ gpart, int n_part, int D,
+                                                                float* __restrict__ g, float* __restrict__ w,
+                                                                float scale /* lr / batch; w == nullptr: no update */) {
+  __shared__ float red[16][64];
+  const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cx;
   float s = 0.0f;
-  for (int b = 0; b < n_part; ++b) s += gpart[(long long)b * D + j];
-  g[j] = s;
+  if (j < D)
+    for (int b = ph; b < n_part; b += 16) s += gpart[(long long)b * D + j];
+  red[ph][cx] = s;
+  __syncthreads();
+  if (ph == 0 && j < D) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cx];
+    g[j] = t;
+    if (w) w[j] -= scale * t;
+  }
 }
 __global__ void __launch_bounds__(256) dsgd_dense_apply_kernel(float* __restrict__ w, const float* __restrict__ g, int D,
                                                               float scale /* lr / global batch */) {

