@@ -54,16 +54,22 @@ __device__ __forceinline__ void bt_carve(BtLds& L, int* base, int cap) {
   L.misc = base + 7 * cap;
 }
 
+// Requested data is kept RAW until its consumer runs: any arithmetic on a loaded value (a length = end - start, a
+// masked select) makes the compiler wait for the load on the spot, which is exactly what staging a batch ahead must
+// not do (the phase counters showed the "request" phase of the plan kernel waiting out a full HBM round trip until the
+// masks and differences moved into the consumers).
 template <int R>
 struct BtItems {
-  int c[R][BT_K];
+  int c[R][BT_K];     // as loaded: slots k >= cnt[r] hold whatever follows the row
   float v[R][BT_K];
-  int irow[R];   // row of the sub-batch (-1: unused slot)
+  int cnt[R];         // valid slots of this lane (<= 0: none)
+  int irow[R];        // row of the sub-batch (-1: unused slot)
 };
 struct BtRow {
-  long long st;
-  int len;
-  float y;
+  long long st, en;   // row_ptr[row], row_ptr[row + 1] as loaded
+  signed char lab;    // label as loaded
+  bool ok;            // the row id was valid (known without any load)
+  __device__ __forceinline__ int len() const { return ok ? (int)(en - st) : 0; }   // (a skipped row has no items)
 };
 
 // contribution of one non-zero of an active row.  WGSCOPE: the strip is private to a workgroup that is alone with
@@ -98,19 +104,20 @@ template <int CAP, class RowOf>
 __device__ __forceinline__ BtRow bt_rows_issue(const CsrView& m, int B, int b0, RowOf row_of, int* bad) {
   BtRow r;
   r.st = 0;
-  r.len = 0;
-  r.y = 0.0f;
+  r.en = 0;
+  r.lab = 0;
+  r.ok = false;
   const int tid = threadIdx.x;
   if (tid < min(CAP, B - b0)) {
     long long row = row_of(b0 + tid);
-    const bool ok = row >= 0 && row < m.n_rows;
-    if (!ok) {
+    r.ok = row >= 0 && row < m.n_rows;
+    if (!r.ok) {
       atomicOr(bad, 1);
       row = 0;
     }
     r.st = m.row_ptr[row];
-    r.len = ok ? (int)(m.row_ptr[row + 1] - r.st) : 0;   // (a skipped row has no items)
-    r.y = (float)m.label[row];
+    r.en = m.row_ptr[row + 1];
+    r.lab = m.label[row];
   }
   return r;
 }
@@ -127,7 +134,7 @@ __device__ __forceinline__ BtScan bt_build_p1(const BtLds& L, int B, int b0, con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = min(CAP, B - b0);
   BtScan sc;
-  sc.nch = tid < nb ? (row.len + BT_CH - 1) / BT_CH : 0;
+  sc.nch = tid < nb ? (row.len() + BT_CH - 1) / BT_CH : 0;
   sc.incl = wave_incl_scan_i32(sc.nch);
   if (lane == 63) L.misc[wave] = sc.incl;
   return sc;
@@ -150,14 +157,14 @@ __device__ __forceinline__ void bt_build_p2(const BtLds& L, int B, int b0, const
   }
   if (fits) {
     L.rst[tid] = row.st;
-    L.rlen[tid] = row.len;
-    L.rcoef[tid] = row.y;
+    L.rlen[tid] = row.len();
+    L.rcoef[tid] = (float)row.lab;
     L.ifirst[tid] = first;
     for (int c = 0; c < sc.nch; ++c) L.item_row[first + c] = tid;
   } else if (tid == 0) {   // the first row alone exceeds the item slots: bt_giant_row
     L.rst[0] = row.st;
-    L.rlen[0] = row.len;
-    L.rcoef[0] = row.y;
+    L.rlen[0] = row.len();
+    L.rcoef[0] = (float)row.lab;
   }
 }
 template <int THREADS>
@@ -199,14 +206,11 @@ __device__ __forceinline__ void bt_items_issue(const CsrView& m, const BtLds& L,
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     const i32x4u ca = *reinterpret_cast<const i32x4u*>(m.col + p0), cb = *reinterpret_cast<const i32x4u*>(m.col + p0 + 4);
     const f32x4u va = *reinterpret_cast<const f32x4u*>(m.val + p0), vb = *reinterpret_cast<const f32x4u*>(m.val + p0 + 4);
-    const int cs[BT_K] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
-    const float vs[BT_K] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-#pragma unroll
-    for (int k = 0; k < BT_K; ++k) {
-      const bool in = k < cnt;
-      it.c[r][k] = in ? cs[k] : -1;
-      it.v[r][k] = in ? vs[k] : 0.0f;
-    }
+    it.cnt[r] = cnt;
+    it.c[r][0] = ca.x; it.c[r][1] = ca.y; it.c[r][2] = ca.z; it.c[r][3] = ca.w;
+    it.c[r][4] = cb.x; it.c[r][5] = cb.y; it.c[r][6] = cb.z; it.c[r][7] = cb.w;
+    it.v[r][0] = va.x; it.v[r][1] = va.y; it.v[r][2] = va.z; it.v[r][3] = va.w;
+    it.v[r][4] = vb.x; it.v[r][5] = vb.y; it.v[r][6] = vb.z; it.v[r][7] = vb.w;
   }
 }
 
@@ -219,13 +223,13 @@ __device__ __forceinline__ void bt_items_dot(const BtLds& L, const BtItems<R>& i
 #pragma unroll
   for (int r = 0; r < R; ++r) {
 #pragma unroll
-    for (int k = 0; k < BT_K; ++k) wv[r][k] = wload(it.c[r][k] >= 0 ? it.c[r][k] : 0);
+    for (int k = 0; k < BT_K; ++k) wv[r][k] = wload(k < it.cnt[r] ? it.c[r][k] : 0);
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     float acc = 0.0f;
 #pragma unroll
-    for (int k = 0; k < BT_K; ++k) acc += filt(it.v[r][k] * wv[r][k]);   // ref: math/Sparse.scala:46 (padding: v == 0)
+    for (int k = 0; k < BT_K; ++k) acc += k < it.cnt[r] ? filt(it.v[r][k] * wv[r][k]) : 0.0f;   // ref: math/Sparse.scala:46
     acc = group_sum<BT_G>(acc);
     if (sub == 0 && it.irow[r] >= 0) L.pdot[r * NG + gidx] = acc;
   }
@@ -252,7 +256,7 @@ __device__ __forceinline__ void bt_scatter(const BtLds& L, float* __restrict__ g
     if (coef != 0.0f) {
 #pragma unroll
       for (int k = 0; k < BT_K; ++k)
-        if (it.c[r][k] >= 0) bt_add<WGSCOPE>(L, gcold, it.c[r][k], it.v[r][k] * coef, qscale);
+        if (k < it.cnt[r]) bt_add<WGSCOPE>(L, gcold, it.c[r][k], it.v[r][k] * coef, qscale);
     }
   }
 }
@@ -662,7 +666,7 @@ struct PlanArgs {
 };
 
 constexpr int PLAN_THREADS = 1024;
-constexpr int PLAN_R = 2;        // 64 groups x 2 = 128 item slots per sub-batch
+constexpr int PLAN_R = 3;        // 64 groups x 3 = 192 item slots per sub-batch (100 RCV1-like rows: 118 +- 6 items)
 constexpr int PLAN_CAP = PLAN_THREADS / BT_G * PLAN_R;
 constexpr int PLAN_HL1 = 11264;  // one hosted worker: LDS-resident ranks (accumulator + weight + dimSparsity: 12 bytes each)
 constexpr int PLAN_HLM = 8192;   // several workers: + the per-step sum (16 bytes each)
@@ -709,6 +713,9 @@ __device__ __forceinline__ double block_sum_f64(double v, double* red) {
   return block_sum_f64_collect(red);
 }
 
+// Every list of the launch fits the staged sub-batch (at most PLAN_CAP rows and PLAN_CAP work items): the host knows
+// the row lengths and sends anything else down the multi-workgroup path (measured: the stage-by-stage general path
+// inlined here cost 80+ spilled registers in the main loop and ran B = 200..1000 slower than the multi-launch kernels).
 template <bool MULTI>
 __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -776,30 +783,34 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
   // requested at the top of iteration n with a VECTOR load: a scalar load would share lgkmcnt with the LDS traffic
   // of the whole iteration and stall the first LDS wait behind it for a memory round trip -- four such loads per
   // batch were ~3 us of the 15 us step (phase counters, profiles/README.md).
-  auto seg_load = [&](long long n, long long& beg, int& len) {
+  auto seg_load = [&](long long n, long long& beg, long long& end) {   // raw: no arithmetic on the loaded words here
     beg = 0;
-    len = 0;
+    end = 0;
     if (n < n_batches) {
       const WorkSeg* p = segs + n;
       asm volatile("" : "+v"(p));   // keep the address in vector registers: global_load, counted by vmcnt
       const WorkSeg sg = *p;
       beg = sg.begin;
-      len = (int)(sg.end - sg.begin);
+      end = sg.end;
     }
   };
   // ... and back to scalar registers once the load has landed (the values are workgroup-uniform)
-  auto to_scalar = [&](long long& beg, int& len) {
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)beg);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)beg >> 32));
-    beg = (long long)(((unsigned long long)hi << 32) | lo);
-    len = __builtin_amdgcn_readfirstlane(len);
+  auto to_scalar = [&](long long vbeg, long long vend, long long& beg, int& len) {
+    auto rfl = [](long long v) -> long long {
+      const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)v);
+      const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)v >> 32));
+      return (long long)(((unsigned long long)hi << 32) | lo);
+    };
+    beg = rfl(vbeg);
+    len = (int)(rfl(vend) - beg);
   };
   long long sb[4];
   int sl[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    seg_load(i, sb[i], sl[i]);
-    to_scalar(sb[i], sl[i]);
+    long long vb, ve;
+    seg_load(i, vb, ve);
+    to_scalar(vb, ve, sb[i], sl[i]);
   }
   // row ids of a batch whose descriptor is (beg, len)
   auto load_rid = [&](long long beg, int len) -> int { return tid < min(PLAN_CAP, len) ? a.idx[beg + tid] : -1; };
@@ -853,7 +864,6 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     while ((1 << bits) < B) ++bits;
     const int shift = 30 - bits;   // at most one contribution per row and column: sums stay below 2^30
     const float qscale = ldexpf(1.0f, shift - a.vexp), inv_qscale = ldexpf(1.0f, a.vexp - shift);
-    const int* __restrict__ list = a.idx + sb[0];
     // ---- gradient of worker k on the weights of the previous step, interleaved with the tables of batch n+1 ----
     if (bd.x > 0) bt_items_dot<PLAN_THREADS, PLAN_R>(Lc, items, wload);
     const BtScan scn = bt_build_p1<PLAN_THREADS, PLAN_CAP>(Ln, Bn, 0, row_next);
@@ -867,25 +877,20 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     stamp(3, tl);
     if (bd.x > 0) bt_scatter<PLAN_R, true>(Lc, a.gcold, items, qscale);
     const int2 bd_n = bt_build_p3<PLAN_THREADS>(Ln);
-    if (bd.x < B) {   // whatever did not fit the staged sub-batch (long rows, lists beyond 128 rows): stage by stage
-      __syncthreads();   // (its table build reuses the scratch words part 3 above has just read)
-      n_act += bt_batch<PLAN_THREADS, PLAN_R, true>(a.m, Lc, a.gcold, B, bd.x, [&](int t) { return (long long)list[t]; }, wload,
-                                                   qscale, &a.sc->err);
-    }
-    // ---- nothing of batch n+1 / n+2 depends on w until the weight gather: request it all now.  ORDER MATTERS: the
-    // compiler cannot count outstanding loads across the loop, so the first use of an old load drains everything
-    // issued before it -- what consumes last iteration's loads (the row ids) goes first, the fresh requests last,
-    // and nothing below waits for them (measured with the phase counters: 6,500 of 33,500 cycles per batch were such
-    // waits when the descriptor / non-zero requests sat in front of these consumers) ----
+    if (bd.x < B && tid == 0) atomicOr(&a.sc->err, 4);   // the host's fit check and the device disagree: the step is invalid
     stamp(4, tl);
+    __syncthreads();   // every contribution of this batch is in the accumulators (and the strip's atomics are performed)
+    stamp(5, tl);
+    // ---- nothing of batch n+1 / n+2 depends on w until the weight gather: request it all now, UNDER the sweep.
+    // (__syncthreads() drains every outstanding memory operation of the wave -- it is a workgroup-scope fence -- so
+    // requests placed in front of the barrier above were waited for on the spot: the phase counters showed 9,000
+    // cycles there.  Behind it they have the whole sweep to land before the next barrier.)  What consumes last
+    // iteration's loads (the row ids) goes first, the fresh requests last.
     row_next = rows_of(sl[2], rid_next2);
     rid_next2 = load_rid(sb[3], sl[3]);
-    long long sb4;
-    int sl4;
-    seg_load(n + 4, sb4, sl4);   // used when the window shifts at the end of the iteration
+    long long vb4, ve4;
+    seg_load(n + 4, vb4, ve4);   // used when the window shifts at the end of the iteration
     if (Bn > 0 && bd_n.x > 0) bt_items_issue<PLAN_THREADS, PLAN_R>(a.m, Ln, bd_n.y, items);
-    stamp(5, tl);
-    __syncthreads();   // every contribution of this batch is in the accumulators
     stamp(6, tl);
     // ---- sweep: this worker's regularised sum on its support; the hot ranks never leave LDS ----
     for (int j = tid; j < hl; j += PLAN_THREADS) {
@@ -988,9 +993,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
       sb[i] = sb[i + 1];
       sl[i] = sl[i + 1];
     }
-    to_scalar(sb4, sl4);
-    sb[3] = sb4;
-    sl[3] = sl4;
+    to_scalar(vb4, ve4, sb[3], sl[3]);
     stamp(8, tl);
   }
   n_act_total = (unsigned long long)wave_sum_u32((unsigned int)n_act_total);

@@ -115,6 +115,8 @@ struct dsgd_plan {
   int n_workers = 0;
   long long max_items = 0;  // largest single list
   long long max_step_rows = 0;  // largest step (all workers together)
+  bool fits = false;            // every list fits the staged sub-batch of dsgd_plan_kernel (rows and work items)
+  long long fits_rows = -1;     // ... of the data set with this many rows (the one loaded at plan creation)
 };
 
 struct FusedArgs {
@@ -364,6 +366,9 @@ static int check_err_flag(dsgd_ctx* c) {
     if (err & 2)
       return fail(DSGD_ESTATE, "fixed-point gradient accumulator left its safe band; the step is invalid "
                                "(rerun with DSGD_STREAM=0 to use the fp32 row-wise kernels)");
+    if (err & 4)
+      return fail(DSGD_ESTATE, "a small-batch plan was created for other data than is loaded now (its lists no longer fit "
+                               "the staged sub-batch): create the plan again");
     return fail(DSGD_ERANGE, "sample index / key outside the loaded data");
   }
   return DSGD_OK;
@@ -1165,6 +1170,18 @@ static int hog_raise_stop(dsgd_ctx* c);
 
 // small-batch steps as ONE persistent workgroup (dsgd_plan_kernel): eligible when no collective sits between the
 // gradient and the update and a step is small enough for one CU
+// does the list fit the staged sub-batch of dsgd_plan_kernel (at most PLAN_CAP rows and PLAN_CAP work items of 128
+// non-zeros)?  Row lengths from the host copy of the internal row pointers.
+static bool list_fits_staged(const dsgd_ctx* c, const int32_t* idx, long long n) {
+  if (n > PLAN_CAP || c->h_row_ptr.size() != (size_t)c->n_rows + 1) return false;
+  long long items = 0;
+  for (long long t = 0; t < n; ++t) {
+    const long long r = idx[t];
+    if (r < 0 || r >= c->n_rows) return false;
+    items += (c->h_row_ptr[(size_t)r + 1] - c->h_row_ptr[(size_t)r] + BT_CH - 1) / BT_CH;
+  }
+  return items <= PLAN_CAP;
+}
 static bool plan_kernel_ok(const dsgd_ctx* c, long long step_rows) {
   return c->plan_kernel && !c->comm && step_rows <= c->plan_max_rows &&
          !(c->cfg.flags & (DSGD_F_FORCE_TILED | DSGD_F_FORCE_ROWS));
@@ -1199,6 +1216,7 @@ static int launch_plan_kernel(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_se
   const size_t lds = sizeof(float) * (size_t)plan_lds_words(c->dp, n_workers > 1);
   size_t slot = 0;
   DSGD_TRY(prof_begin(c, &slot));
+  // (every list fits the staged sub-batch: the callers checked the row lengths)
   if (n_workers > 1) {
     hipLaunchKernelGGL(dsgd_plan_kernel<true>, dim3(1), dim3(PLAN_THREADS), lds, c->stream, a);
     c->last_grad_kernel = "dsgd_plan_kernel<true>";
@@ -1754,7 +1772,10 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
   {
     long long t = 0;
     for (int k = 0; k < n_workers; ++k) t += std::max<long long>(0, n_per_worker[k]);
-    if (plan_kernel_ok(c, t)) {   // the reference's batch sizes: one persistent workgroup does the whole closure
+    bool fits = plan_kernel_ok(c, t);
+    for (int k = 0; k < n_workers && fits; ++k)
+      fits = idx_per_worker[k] && list_fits_staged(c, idx_per_worker[k], n_per_worker[k]);
+    if (fits) {   // the reference's batch sizes: one persistent workgroup does the whole closure
       DSGD_TRY(reset_counters(c));
       DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
       DSGD_TRY(launch_plan_kernel(c, c->d_idx, c->d_segs, n_workers, 0, 1, lr));
@@ -1871,6 +1892,9 @@ int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, in
   p->offsets.assign(offsets, offsets + n_lists + 1);
   for (int64_t st = 0; st < n_steps; ++st)
     p->max_step_rows = std::max<long long>(p->max_step_rows, offsets[(st + 1) * n_workers] - offsets[st * n_workers]);
+  p->fits = true;
+  p->fits_rows = c->n_rows;
+  for (int64_t i = 0; i < n_lists && p->fits; ++i) p->fits = list_fits_staged(c, idx + offsets[i], offsets[i + 1] - offsets[i]);
   std::vector<WorkSeg> segs((size_t)n_lists);
   for (int64_t i = 0; i < n_lists; ++i) {
     segs[i].begin = offsets[i];
@@ -1914,7 +1938,7 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
   DSGD_TRY(require_ds(c));
   DSGD_TRY(require_sync_mode(c));
   DSGD_TRY(prepare_layout(c));
-  if (plan_kernel_ok(c, p->max_step_rows)) {
+  if (plan_kernel_ok(c, p->max_step_rows) && p->fits && p->fits_rows == c->n_rows) {
     if (step_end > step_begin) DSGD_TRY(launch_plan_kernel(c, p->d_idx, p->d_segs, p->n_workers, step_begin, step_end, lr));
     c->pending_samples += p->offsets[step_end * p->n_workers] - p->offsets[step_begin * p->n_workers];
     return DSGD_OK;

@@ -217,7 +217,7 @@ int dsgd_tuning_info(dsgd_ctx* ctx, int32_t* vals, int32_t n);
 
 /* Tuning aid (DSGD_PLAN_PROF=1 in the environment at dsgd_create): shader-clock cycles thread 0 of the small-batch
  * plan kernel spent in the nine phases of a batch ([0..8]: gather+dot, barrier, gate+tables, barrier, scatter,
- * requests, barrier, sweep, barrier+collect) and the number of steps ([15]), accumulated since the last reset;
+ * barrier, requests, sweep, barrier+collect) and the number of steps ([15]), accumulated since the last reset;
  * 16 words, all zeros when the aid is off.                                                                       */
 int dsgd_debug_cycles(dsgd_ctx* ctx, uint64_t* out16, int32_t reset);
 

@@ -213,3 +213,35 @@ def test_fixture_kat_json_dict_and_c():
         np.testing.assert_allclose(w, [st["w"].get(str(j), 0.0) for j in range(7)], rtol=0, atol=2e-7)
         loss, acc, _, _ = o.loss_acc(w, 0, 6)
         assert abs(loss - st["loss"]) < 1e-6 and abs(acc - st["acc"]) < 1e-12
+
+
+def test_committed_jvm_expectation_is_what_the_oracle_produces_today():
+    """tests/golden/jvm_expected/: the Main.scala scenario on a small exported workload, as the JVM should log it
+    (see tests/golden/make_jvm_expected.py).  Regenerated here and compared with the committed file, so that whoever
+    diffs the JVM's log against it diffs against the oracle the parity tests actually use."""
+    import json
+    import os
+    import sys
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, golden)
+    try:
+        import make_jvm_expected as mk
+    finally:
+        sys.path.remove(golden)
+    now = mk.compute()
+    exp = json.load(open(os.path.join(golden, "jvm_expected", "expected.json")))
+    assert now["config"] == exp["config"] and now["batches"] == exp["batches"] == 6
+    for key in ("initial_loss", "initial_accuracy", "final_test_loss", "final_test_accuracy"):
+        assert abs(now[key] - exp[key]) <= 1e-12 * max(1.0, abs(exp[key])), key
+    assert now["final_weights"].keys() == exp["final_weights"].keys()
+    assert max(abs(now["final_weights"][k] - exp["final_weights"][k]) for k in exp["final_weights"]) <= 1e-12
+    assert exp["initial_loss"] == 1.0 and exp["initial_accuracy"] == 0.0   # w = 0: every prediction is 0 (SparseSVM.scala:14-18)
+    # the exported text loads back to exactly the rows the expectation was computed on
+    import dsgd_amd
+    from dsgd_amd import rcv1
+
+    back = rcv1.load(os.path.join(golden, "jvm_expected", "data"), full=False)
+    data = dsgd_amd.synth.generate(mk.ROWS, seed=0)
+    assert back.n_rows == mk.ROWS and (back.col == data.col).all() and (back.label == data.label).all()
+    assert np.abs(back.val - data.val).max() == 0.0

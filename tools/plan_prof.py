@@ -41,7 +41,7 @@ with dsgd_amd.Engine(data.dim, 1e-5) as eng:
         cyc = eng.debug_cycles(reset=True)
         plan.destroy()
         n = max(1, cyc[15])
-        names = ("gather_dot", "barrier1", "gate_tables", "barrier2", "scatter", "requests", "barrier3", "sweep", "barrier4_collect")
+        names = ("gather_dot", "barrier1", "gate_tables", "barrier2", "scatter", "barrier3", "requests", "sweep", "barrier4_collect")
         out["plan"].append({"workers": k, "batch": b, "steps": steps, "us_per_step": 1e6 * dt / steps,
                             "kernel": eng.grad_kernel_name(),
                             "cycles_per_step": {nm: cyc[i] / n for i, nm in enumerate(names)}})
