@@ -428,6 +428,30 @@ def dense_logistic(dsgd_amd, device, rows=1250000, dim=4096):
                                    "kernel_frac_hbm_peak": (b * (4 * dim + 4) / (kms * 1e-3) / HBM_PEAK) if kms > 0 else None})
         loss, acc = eng.loss(rows - 65536, rows)
         res["loss_after"], res["acc_after"] = loss, acc
+    # the variant with the forward product on the matrix cores (configs[4]: "mini-batch GEMV via MFMA"), same data
+    os.environ["DSGD_DENSE_MFMA"] = "1"
+    try:
+        with dsgd_amd.DenseLogistic(dim, device=device) as eng:
+            eng.generate(rows, seed=device)
+            b, steps = 65536, 40
+            starts = [(i * b) % (rows - b) for i in range(steps + 5)]
+            for st in starts[:5]:
+                eng.step(st, st + b, 1.0)
+            eng.synchronize()
+            eng.prof(True)
+            t0 = time.perf_counter()
+            for st in starts[5:]:
+                eng.step(st, st + b, 1.0)
+            eng.synchronize()
+            dt = time.perf_counter() - t0
+            kms, _ = eng.prof(False)
+            res["mfma_variant"] = {"batch": b, "steps": steps, "examples_per_s": b * steps / dt, "us_per_step": 1e6 * dt / steps,
+                                   "kernel_ms_avg": kms,
+                                   "kernel_frac_hbm_peak": (b * (4 * dim + 4) / (kms * 1e-3) / HBM_PEAK) if kms > 0 else None,
+                                   "note": "dsgd_dense_step_mfma_kernel: v_mfma_f32_16x16x4_f32 forward product (1/16 of each "
+                                           "instruction useful for a matrix-vector product), gradient product on the VALU"}
+    finally:
+        del os.environ["DSGD_DENSE_MFMA"]
     return res
 
 

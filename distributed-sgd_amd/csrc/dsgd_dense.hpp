@@ -119,6 +119,95 @@ __global__ void __launch_bounds__(1024) dsgd_dense_step_kernel(DenseArgs a) {
   }
 }
 
+// ---- the MFMA variant north_star names ("mini-batch GEMV via MFMA"), selectable with DSGD_DENSE_MFMA=1 -----------
+// Forward product on the matrix cores: v_mfma_f32_16x16x4_f32 with A = a 16-row x 4-column tile of X (lane l: row
+// l % 16, column group l / 16) and B = the four weights of those columns broadcast over the N dimension, so every
+// column of D holds the same partial z and lane (j, q) register r carries z of row 4q + r.  A matrix-VECTOR product
+// uses 1/16 of the instruction's multiply-adds and the fp32 matrix rate equals the vector rate, so this cannot beat
+// v_fma (header comment): the variant exists to be MEASURED next to it (bench.py dense_logistic.mfma_variant).
+// One workgroup of D / 4 lanes per 16-row block: wave v owns columns [256v, 256v + 256); lane (i, q) loads, for each
+// of 16 macro-steps m, the float4 X[row i][256v + 16m + 4q ..]: 64 VGPRs hold the tile for both products.  The
+// gradient product stays on the VALU: r_i * x summed over the 16 rows with the DPP butterfly of group_sum<16>, lane i
+// keeping the four sums of macro-step m == i.
+typedef float dn_f32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(1024) dsgd_dense_step_mfma_kernel(DenseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // D weights
+  __shared__ float zpart[16][16];
+  __shared__ float rl[16];
+  __shared__ double lred[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  for (int j = tid * 4; j < a.D; j += blockDim.x * 4) *reinterpret_cast<float4*>(wl + j) = *reinterpret_cast<const float4*>(a.w + j);
+  __syncthreads();
+  const int cw = 256 * wave;
+  float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);   // columns cw + 16 i + 4 q .. + 3
+  double loss_acc = 0.0, corr_acc = 0.0;
+  const long long n_blocks = (a.row_end - a.row_begin + 15) / 16;
+  for (long long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const long long r0 = a.row_begin + blk * 16;
+    const bool in_i = r0 + i < a.row_end;
+    const float* row = a.X + (in_i ? r0 + i : a.row_begin) * (long long)a.D + cw + 4 * q;
+    float4 x[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x[m] = *reinterpret_cast<const float4*>(row + 16 * m);
+    dn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const float4 wv = *reinterpret_cast<const float4*>(wl + cw + 16 * m + 4 * q);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[m].x, wv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[m].y, wv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[m].z, wv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[m].w, wv.w, acc, 0, 0, 0);
+    }
+    if (i == 0) {   // D[4q + r][j] is the same for every j: one lane per column group writes its four rows
+      zpart[wave][4 * q + 0] = acc[0];
+      zpart[wave][4 * q + 1] = acc[1];
+      zpart[wave][4 * q + 2] = acc[2];
+      zpart[wave][4 * q + 3] = acc[3];
+    }
+    __syncthreads();
+    if (tid < 16) {
+      float z = 0.0f;
+      for (int wv = 0; wv < n_waves; ++wv) z += zpart[wv][tid];
+      const bool in = r0 + tid < a.row_end;
+      const float yy = in ? a.y[r0 + tid] : 0.0f;
+      const float p = 1.0f / (1.0f + __expf(-z));
+      rl[tid] = in ? p - yy : 0.0f;
+      if (in) {
+        loss_acc += (double)(fmaxf(z, 0.0f) + log1pf(__expf(-fabsf(z))) - yy * z);
+        corr_acc += ((z > 0.0f) == (yy > 0.5f)) ? 1.0 : 0.0;
+      }
+    }
+    __syncthreads();
+    if (a.gpart) {
+      const float r = rl[i];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const float sx = group_sum<16>(r * x[m].x), sy = group_sum<16>(r * x[m].y);
+        const float sz = group_sum<16>(r * x[m].z), sw = group_sum<16>(r * x[m].w);
+        if (m == i) {
+          g4.x += sx;
+          g4.y += sy;
+          g4.z += sz;
+          g4.w += sw;
+        }
+      }
+    }
+  }
+  if (a.gpart) *reinterpret_cast<float4*>(a.gpart + (long long)blockIdx.x * a.D + cw + 16 * i + 4 * q) = g4;
+  if (tid == 0) lred[0] = lred[1] = 0.0;
+  __syncthreads();
+  if (tid < 16) {
+    atomicAdd(&lred[0], loss_acc);
+    atomicAdd(&lred[1], corr_acc);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    a.lpart[2 * blockIdx.x] = lred[0];
+    a.lpart[2 * blockIdx.x + 1] = lred[1];
+  }
+}
+
 // g = sum of the per-workgroup partials (fixed order: reproducible) and, without a communicator, the update in the
 // same pass.  Block = 64 columns x 16 phases over the partials (one thread per column summing 512 partials
 // one after the other took ~100 us -- more than the step kernel itself at batch 4,096).

@@ -467,7 +467,7 @@ static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
   if (c->fused_apply_pending) {
     c->fused_apply_pending = false;
     const FusedArgs& f = c->fused_args;
-    hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel, dim3((dp + 63) / 64), dim3(1024), 0, c->stream, c->d_g64, c->d_w, c->d_ds,
+    hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel, dim3((dp + 64 * FRA_GROUPS - 1) / (64 * FRA_GROUPS)), dim3(1024), 0, c->stream, c->d_g64, c->d_w, c->d_ds,
                        dp, f.hg, c->d_part, c->part_stride, f.n_wg, f.hc, f.nc, c->d_partc, c->partc_stride, f.n_wgc,
                        f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart);
     HIP_TRY(hipGetLastError());
@@ -2447,6 +2447,7 @@ struct dsgd_dense {
   double* d_lpart = nullptr;  // n_wg x 2
   double* h_lpart = nullptr;  // pinned
   int n_wg = 0;
+  bool mfma = false;          // DSGD_DENSE_MFMA=1: forward product with v_mfma_f32_16x16x4_f32 (D a multiple of 256, <= 4096)
   rccl::comm_t comm = nullptr;
   int world = 1;
   bool prof = false;
@@ -2480,8 +2481,9 @@ static int dn_launch(dsgd_dense* d, long long rb, long long re, bool grad) {
   a.row_begin = rb;
   a.row_end = re;
   a.D = d->D;
-  const long long n_blocks = (re - rb + DN_ROWS - 1) / DN_ROWS;
-  const int grid = (int)std::max<long long>(1, std::min<long long>(d->n_wg, n_blocks));
+  const int rows_per_block = d->mfma ? 16 : DN_ROWS;
+  const long long n_blocks = (re - rb + rows_per_block - 1) / rows_per_block;
+  const int grid = (int)std::max<long long>(1, std::min<long long>(d->mfma ? d->n_cu : d->n_wg, n_blocks));
   size_t slot = (size_t)-1;
   if (d->prof && grad) {
     if (d->ev_used == d->ev.size()) {
@@ -2493,7 +2495,10 @@ static int dn_launch(dsgd_dense* d, long long rb, long long re, bool grad) {
     slot = d->ev_used++;
     HIP_TRY(hipEventRecord(d->ev[slot].first, d->stream));
   }
-  hipLaunchKernelGGL(dsgd_dense_step_kernel, dim3(grid), dim3(d->D / DN_COLS), 0, d->stream, a);
+  if (d->mfma)   // the variant on the matrix cores (forward product only; csrc/dsgd_dense.hpp)
+    hipLaunchKernelGGL(dsgd_dense_step_mfma_kernel, dim3(grid), dim3(d->D / 4), sizeof(float) * (size_t)d->D, d->stream, a);
+  else
+    hipLaunchKernelGGL(dsgd_dense_step_kernel, dim3(grid), dim3(d->D / DN_COLS), 0, d->stream, a);
   HIP_TRY(hipGetLastError());
   if (slot != (size_t)-1) HIP_TRY(hipEventRecord(d->ev[slot].second, d->stream));
   return grid;
@@ -2517,6 +2522,11 @@ int dsgd_dense_create(int32_t n_features, int32_t device, dsgd_dense** out) {
   d->device = device;
   d->n_cu = prop.multiProcessorCount;
   d->n_wg = 2 * d->n_cu;   // two workgroups per CU: one computes while the other's loads are in flight
+  if (const char* e = getenv("DSGD_DENSE_MFMA")) d->mfma = atoi(e) != 0;
+  if (d->mfma && n_features > 4096) {
+    delete d;
+    return fail(DSGD_EUNSUPPORTED, "the MFMA variant handles at most 4096 features (one wave per 256 columns)");
+  }
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&d->d_w, sizeof(float) * d->D);

@@ -631,6 +631,7 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_kernel(long long* g64_ba
 // the "mean" over one worker and the update (ref: core/Master.scala:194-197) -- g is never written.  The two dot
 // products of the new weights are combined by the last block to arrive, in block order (reproducible).  Every block
 // reads the old s before it takes its ticket, so the last block's write of the new s cannot be seen by any of them.
+constexpr int FRA_GROUPS = 4;   // 64-column groups per block: a quarter of the ticket atomics (739 on ONE word cost ~10 us)
 __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* __restrict__ g64, float* __restrict__ w,
                                                                     const float* __restrict__ ds, int dp, int hg,
                                                                     const int* __restrict__ part, int part_stride,
@@ -644,20 +645,21 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
   const float s = sc->s_reg;
   const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
   const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + cx;
-  long long q = 0;
-  if (j < hg) {
-    const int* p = part + j;
-    for (int b = ph; b < n_wg; b += 16) q += (long long)p[(long long)b * part_stride];
-  } else if (j >= hc && j < hc + nc) {
-    const int* p = partc + (j - hc);
-    for (int b = ph; b < n_wgc; b += 16) q += (long long)p[(long long)b * partc_stride];
-  }
-  red[ph][cx] = q;
-  __syncthreads();
-  if (ph == 0) {   // one wave: the 64 columns of the block
-    float dot = 0.0f, nsq = 0.0f;
-    if (j < dp) {
+  float dot = 0.0f, nsq = 0.0f;   // (wave 0 only)
+  for (int grp = 0; grp < FRA_GROUPS; ++grp) {
+    const int j = (blockIdx.x * FRA_GROUPS + grp) * 64 + cx;
+    long long q = 0;
+    if (j < hg) {
+      const int* p = part + j;
+      for (int b = ph; b < n_wg; b += 16) q += (long long)p[(long long)b * part_stride];
+    } else if (j >= hc && j < hc + nc) {
+      const int* p = partc + (j - hc);
+      for (int b = ph; b < n_wgc; b += 16) q += (long long)p[(long long)b * partc_stride];
+    }
+    if (grp) __syncthreads();   // the previous group's sums have been read
+    red[ph][cx] = q;
+    __syncthreads();
+    if (ph == 0 && j < dp) {   // one wave: the 64 columns of the group
       long long tot = g64[j];
       if (tot != 0) g64[j] = 0;
 #pragma unroll
@@ -667,9 +669,11 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
       const float upd = filt(filt(gv / 1.0f) * lr);   // Vec.mean over ONE worker, then learningRate * grad
       const float wn = filt(w[j] - upd);
       w[j] = wn;
-      dot = filt(wn * ds[j]);
-      nsq = wn * wn;
+      dot += filt(wn * ds[j]);
+      nsq += wn * wn;
     }
+  }
+  if (ph == 0) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       dot += __shfl_xor(dot, off, 64);

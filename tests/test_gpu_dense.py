@@ -21,8 +21,12 @@ def make(n, d, seed):
     return X, y
 
 
-@pytest.mark.parametrize("n,d,batch", [(1000, 512, 100), (4099, 1024, 1024), (2048, 4096, 777), (300, 8192, 300)])
-def test_steps_match_the_oracle(n, d, batch):
+@pytest.mark.parametrize("n,d,batch,mfma", [(1000, 512, 100, 0), (4099, 1024, 1024, 0), (2048, 4096, 777, 0), (300, 8192, 300, 0),
+                                            (1000, 512, 100, 1), (4099, 1024, 1024, 1), (2048, 4096, 777, 1)])
+def test_steps_match_the_oracle(monkeypatch, n, d, batch, mfma):
+    """mfma = 1: the forward product on the matrix cores (v_mfma_f32_16x16x4_f32, DSGD_DENSE_MFMA=1) -- the variant
+    BASELINE.json configs[4] names; same oracle, same tolerance."""
+    monkeypatch.setenv("DSGD_DENSE_MFMA", str(mfma))
     X, y = make(n, d, n + d)
     with dsgd_amd.DenseLogistic(d) as eng:
         eng.load(X, y)
