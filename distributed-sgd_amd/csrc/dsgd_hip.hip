@@ -1342,6 +1342,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
     return bail(fail(DSGD_EINVAL, "DSGD_HW_W + DSGD_HG_W exceed %d floats of LDS", DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64));
   if (const char* e = getenv("DSGD_HSPLIT")) c->hsplit = atoi(e);
   c->hsplit = std::max(1, std::min(c->hsplit, (DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64) / 2));   // (< 65536: 16-bit ranks)
+  if (c->hsplit >= 8) c->hsplit &= ~3;   // 16-byte aligned tile boundaries: the LDS tiles are staged / written back in 16-byte pieces
   const int lds_max = DSGD_LDS_FLOATS * (int)sizeof(float);
 #define DSGD_ATTR(fn) HIP_TRY_B(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max))
   DSGD_ATTR(dsgd_grad_tiled_kernel<64>);

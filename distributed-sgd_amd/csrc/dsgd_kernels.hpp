@@ -25,6 +25,29 @@
 // Sparse(...) constructor filter: entries with abs(v) <= 1e-20 vanish (ref: math/Sparse.scala:108-118)
 __device__ __forceinline__ float filt(float v) { return fabsf(v) > DSGD_EPS ? v : 0.0f; }
 
+// Workgroup-wide bulk moves between global memory and LDS tiles in 16-byte pieces (the 4-byte loops they replace were
+// 18-28 dependent iterations per thread in the prologue / epilogue of every persistent workgroup: the cold-stream
+// kernels stage or clear 115 KB each and run for only ~70 us).  Both pointers 16-byte aligned when n >= 4 is used
+// with aligned bases; the tail (n % 4) goes element-wise.
+__device__ __forceinline__ void wg_copy_in(float* lds_dst, const float* __restrict__ src, int n, int tid, int nthreads,
+                                           bool aligned) {
+  const int n4 = aligned ? n >> 2 : 0;
+  for (int j = tid; j < n4; j += nthreads) reinterpret_cast<float4*>(lds_dst)[j] = reinterpret_cast<const float4*>(src)[j];
+  for (int j = 4 * n4 + tid; j < n; j += nthreads) lds_dst[j] = src[j];
+}
+__device__ __forceinline__ void wg_zero(int* lds_dst, int n, int tid, int nthreads) {   // lds_dst 16-byte aligned
+  const int n4 = n >> 2;
+  for (int j = tid; j < n4; j += nthreads) reinterpret_cast<int4*>(lds_dst)[j] = make_int4(0, 0, 0, 0);
+  for (int j = 4 * n4 + tid; j < n; j += nthreads) lds_dst[j] = 0;
+}
+__device__ __forceinline__ void wg_copy_out(int* __restrict__ dst, const int* lds_src, int n, int tid, int nthreads,
+                                            bool aligned) {
+  const int n4 = aligned ? n >> 2 : 0;
+  for (int j = tid; j < n4; j += nthreads) reinterpret_cast<int4*>(dst)[j] = reinterpret_cast<const int4*>(lds_src)[j];
+  for (int j = 4 * n4 + tid; j < n; j += nthreads) dst[j] = lds_src[j];
+}
+__device__ __forceinline__ bool is_aligned16(const void* p) { return (reinterpret_cast<unsigned long long>(p) & 15ull) == 0; }
+
 // device scalars shared by the kernels of one context
 struct DevScalars {
   float s_reg;   // 2 * lambda * (w . ds)            (ref: core/ml/SparseSVM.scala:31)
@@ -631,7 +654,7 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_kernel(long long* g64_ba
 // the "mean" over one worker and the update (ref: core/Master.scala:194-197) -- g is never written.  The two dot
 // products of the new weights are combined by the last block to arrive, in block order (reproducible).  Every block
 // reads the old s before it takes its ticket, so the last block's write of the new s cannot be seen by any of them.
-constexpr int FRA_GROUPS = 4;   // 64-column groups per block: a quarter of the ticket atomics (739 on ONE word cost ~10 us)
+constexpr int FRA_GROUPS = 1;   // 64-column groups per block (4 measured slower: 41-46 vs 34.5 us -- fewer blocks in flight)
 __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* __restrict__ g64, float* __restrict__ w,
                                                                     const float* __restrict__ ds, int dp, int hg,
                                                                     const int* __restrict__ part, int part_stride,
@@ -682,14 +705,15 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
     if (cx == 0) {
       __hip_atomic_store(&redpart[2 * blockIdx.x], dot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&redpart[2 * blockIdx.x + 1], nsq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence();                                   // publish the partials before taking a ticket
+      // the two partials are write-through stores: once they are acknowledged the ticket may be taken (a full
+      // __threadfence() here writes back the L2's dirty lines -- this block's weights -- ~3.5 us per block)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned int t = atomicAdd(&sc->ticket, 1u);
       is_last = (t == gridDim.x - 1);
     }
   }
   __syncthreads();
-  if (is_last && ph == 0) {
-    __threadfence();                                     // acquire: the other blocks' partials
+  if (is_last && ph == 0) {   // (agent-scope loads below: served past this CU's L1)
     float d = 0.0f, qq = 0.0f;
     for (unsigned int b = cx; b < gridDim.x; b += 64) {   // fixed assignment and order: reproducible
       d += __hip_atomic_load(&redpart[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1343,9 +1367,12 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
   x.hg = hg;
   x.fix_scale = fix_scale;
   x.cold_scale = cold_scale;
-  if (SCATTER)
-    for (int j = tid; j < hg + 64; j += 1024) x.gl[j] = 0;
-  for (int j = tid; j < hw; j += 1024) wl[j] = w[j];
+  if (SCATTER) {
+    if (is_aligned16(x.gl)) wg_zero(x.gl, hg + 64, tid, 1024);
+    else
+      for (int j = tid; j < hg + 64; j += 1024) x.gl[j] = 0;
+  }
+  wg_copy_in(wl, w, hw, tid, 1024, is_aligned16(wl) && is_aligned16(w));
   if (tid == 0) wl[hw] = 0.0f;
   __syncthreads();
 
@@ -1400,7 +1427,7 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
       // this workgroup's exact partial sums, written whole (zeros included): dsgd_fix_reduce_kernel adds the
       // partials of a worker in a fixed order -- no atomics, and 256 workgroups do not meet on one address
       int* mine = part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * part_stride;
-      for (int j = tid; j < hg; j += 1024) mine[j] = x.gl[j];
+      wg_copy_out(mine, x.gl, hg, tid, 1024, is_aligned16(mine) && is_aligned16(x.gl));
     } else {
       for (int j = tid; j < hg; j += 1024) {
         const int q = x.gl[j];
@@ -1682,7 +1709,7 @@ __global__ void __launch_bounds__(1024) dsgd_cgrad_kernel(ColdView cv, const lon
   int* gc = reinterpret_cast<int*>(lds);   // nc_lds accumulators + 64 always-zero words
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int j = tid; j < nc_lds + 64; j += 1024) gc[j] = 0;
+  wg_zero(gc, nc_lds + 64, tid, 1024);
   __syncthreads();
   const StreamSeg seg = segs[blockIdx.y];
   long long* g64 = g64_base + (long long)blockIdx.y * g_stride;
@@ -1733,7 +1760,7 @@ __global__ void __launch_bounds__(1024) dsgd_cgrad_kernel(ColdView cv, const lon
   }
   __syncthreads();
   int* mine = partc + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * partc_stride;
-  for (int j = tid; j < nc_lds; j += 1024) mine[j] = gc[j];
+  wg_copy_out(mine, gc, nc_lds, tid, 1024, is_aligned16(mine));
 }
 
 // evaluation tallies of an explicit list of rows (the few rows too long for the wave tiles)
@@ -1822,7 +1849,7 @@ __global__ void __launch_bounds__(1024) dsgd_cdot8_kernel(ColdView cv, const lon
   typedef __attribute__((address_space(3))) const float lds_cfloat;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int j = tid; j < nc_lds; j += 1024) lds[j] = w[hsplit + j];
+  wg_copy_in(lds, w + hsplit, nc_lds, tid, 1024, is_aligned16(w + hsplit));
   __syncthreads();
   const StreamSeg seg = segs[blockIdx.y];
   const long long e_lo = crow_ptr[seg.row_begin], e_hi = crow_ptr[seg.row_end];
