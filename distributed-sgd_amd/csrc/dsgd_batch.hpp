@@ -33,6 +33,7 @@ constexpr int BT_CH = BT_G * BT_K;   // 128 non-zeros per item
 struct BtLds {
   int* acc;              // hl fixed-point accumulators, zero between batches
   unsigned int* cbits;   // one bit per rank >= hl: the strip entry was touched by this batch
+  long long* g64;        // COLD = 2: 64-bit fixed-point global accumulators of the ranks >= hl (indexed by rank)
   int hl;
   // sub-batch tables: cap = item slots (NG x R) = most rows of a sub-batch
   long long* rst;        // [cap] first non-zero of the row
@@ -72,17 +73,24 @@ struct BtRow {
   __device__ __forceinline__ int len() const { return ok ? (int)(en - st) : 0; }   // (a skipped row has no items)
 };
 
-// contribution of one non-zero of an active row.  WGSCOPE: the strip is private to a workgroup that is alone with
-// its data (plan kernel): workgroup-scope atomics stay in this XCD's L2.
-template <bool WGSCOPE>
+// contribution of one non-zero of an active row.  COLD says where the few ranks beyond the LDS accumulators go:
+//   0  the workgroup's private fp32 strip + LDS bitmap, device-scope atomics (Hogwild: the strip is swept right away)
+//   1  the same with workgroup-scope atomics (plan kernel: the workgroup is alone with its data -- they stay in this
+//      XCD's L2)
+//   2  64-bit fixed-point global accumulators on the same grid as the LDS ones (mid-size batches spread over many
+//      workgroups: dsgd_fix_reduce_* adds them to the partial sums exactly)
+template <int COLD>
 __device__ __forceinline__ void bt_add(const BtLds& L, float* __restrict__ gcold, int c, float xv, float qscale) {
   if (c < L.hl) {
     const int q = __float2int_rn(xv * qscale);
     if (q != 0) atomicAdd(&L.acc[c], q);   // ds_add_u32
+  } else if (COLD == 2) {
+    const int q = __float2int_rn(xv * qscale);
+    if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&L.g64[c]), (unsigned long long)(long long)q);
   } else {
     const float f = filt(xv);
     if (f != 0.0f) {
-      if (WGSCOPE) __hip_atomic_fetch_add(&gcold[c - L.hl], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (COLD == 1) __hip_atomic_fetch_add(&gcold[c - L.hl], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       else atomicAdd(&gcold[c - L.hl], f);
       atomicOr(&L.cbits[(unsigned int)(c - L.hl) >> 5], 1u << ((c - L.hl) & 31));
     }
@@ -248,7 +256,7 @@ __device__ __forceinline__ unsigned int bt_gate(const BtLds& L, int nbf) {
   return active ? 1u : 0u;
 }
 
-template <int R, bool WGSCOPE>
+template <int R, int COLD>
 __device__ __forceinline__ void bt_scatter(const BtLds& L, float* __restrict__ gcold, const BtItems<R>& it, float qscale) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -256,14 +264,14 @@ __device__ __forceinline__ void bt_scatter(const BtLds& L, float* __restrict__ g
     if (coef != 0.0f) {
 #pragma unroll
       for (int k = 0; k < BT_K; ++k)
-        if (k < it.cnt[r]) bt_add<WGSCOPE>(L, gcold, it.c[r][k], it.v[r][k] * coef, qscale);
+        if (k < it.cnt[r]) bt_add<COLD>(L, gcold, it.c[r][k], it.v[r][k] * coef, qscale);
     }
   }
 }
 
 // a single row longer than CAP x 128 non-zeros (never the case for RCV1): all threads share it.  The row record was
 // left in slot 0 by bt_build.  Three workgroup barriers.
-template <int THREADS, bool WGSCOPE, class WLoad>
+template <int THREADS, int COLD, class WLoad>
 __device__ __forceinline__ unsigned int bt_giant_row(const CsrView& m, const BtLds& L, float* __restrict__ gcold,
                                                      WLoad wload, float qscale) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -282,7 +290,7 @@ __device__ __forceinline__ unsigned int bt_giant_row(const CsrView& m, const BtL
   unsigned int n_act = 0;
   if (!(yy * d < 0.0f)) {
     n_act = tid == 0 ? 1u : 0u;
-    for (int p = tid; p < ln; p += THREADS) bt_add<WGSCOPE>(L, gcold, m.col[s0 + p], m.val[s0 + p] * yy, qscale);
+    for (int p = tid; p < ln; p += THREADS) bt_add<COLD>(L, gcold, m.col[s0 + p], m.val[s0 + p] * yy, qscale);
   }
   __syncthreads();
   return n_act;
@@ -290,7 +298,7 @@ __device__ __forceinline__ unsigned int bt_giant_row(const CsrView& m, const BtL
 
 // The gated batch sum of the rows row_of(b0 .. B-1), stage after stage (nothing overlapped): the general path for
 // whatever a pipelined caller could not stage ahead.  Returns this thread's share of the active-row count.
-template <int THREADS, int R, bool WGSCOPE, class RowOf, class WLoad>
+template <int THREADS, int R, int COLD, class RowOf, class WLoad>
 __device__ __forceinline__ unsigned int bt_batch(const CsrView& m, const BtLds& L, float* __restrict__ gcold, int B, int b0,
                                                  RowOf row_of, WLoad wload, float qscale, int* bad) {
   constexpr int CAP = THREADS / BT_G * R;
@@ -299,7 +307,7 @@ __device__ __forceinline__ unsigned int bt_batch(const CsrView& m, const BtLds& 
     const BtRow row = bt_rows_issue<CAP>(m, B, b0, row_of, bad);
     const int2 bd = bt_build<THREADS, CAP>(L, B, b0, row);
     if (bd.x == 0) {
-      n_act += bt_giant_row<THREADS, WGSCOPE>(m, L, gcold, wload, qscale);
+      n_act += bt_giant_row<THREADS, COLD>(m, L, gcold, wload, qscale);
       b0 += 1;
       continue;
     }
@@ -309,11 +317,66 @@ __device__ __forceinline__ unsigned int bt_batch(const CsrView& m, const BtLds& 
     __syncthreads();
     n_act += bt_gate(L, bd.x);
     __syncthreads();
-    bt_scatter<R, WGSCOPE>(L, gcold, it, qscale);
+    bt_scatter<R, COLD>(L, gcold, it, qscale);
     b0 += bd.x;
     // (bt_build writes only misc[] before its first barrier; nothing above reads misc[] after the last barrier)
   }
   return n_act;
+}
+
+// ======================================================================================================
+// K1m: index-list batches too large for one workgroup (hundreds to 10^5 rows): the batch spread over workgroups
+// ======================================================================================================
+// ref: core/Slave.scala:147-153 (Vec.sum of the gated sub-gradients of a batch).  Round 1 scattered y*x with fp32
+// atomics straight into L2 (dsgd_grad_rows_kernel / dsgd_grad_tiled_kernel: 307 K atomics for 4,096 rows at ~5 G/s:
+// 126 us per step, in arrival order).  Here every workgroup takes `rows_per_wg` rows of one worker's list through
+// the mini-batch engine into its own fixed-point LDS accumulators and writes them out as one partial
+// (part[worker][workgroup][rank]); the ranks beyond LDS go to 64-bit fixed-point global accumulators on the same
+// grid.  dsgd_fix_reduce_kernel / dsgd_fix_reduce_apply_kernel -- the finish of the streaming path -- add the
+// partials exactly, in a fixed order, with ONE rounding: the gradient is bit-reproducible.
+struct MbArgs {
+  CsrView m;
+  const float* w;
+  const int* idx;           // null: the list positions are the row numbers themselves
+  const WorkSeg* segs;      // one list per worker (blockIdx.y)
+  int* part;
+  long long* g64_base;      // per worker: stride g_stride
+  long long g_stride;
+  DevScalars* sc;
+  float qscale;
+  int part_stride, rows_per_wg, hl;
+};
+constexpr int MB_THREADS = 1024;
+constexpr int MB_R = 2;
+constexpr int MB_CAP = MB_THREADS / BT_G * MB_R;
+constexpr int MB_HL = 24576;   // ranks with an LDS accumulator per workgroup
+
+__global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  BtLds L;
+  L.hl = a.hl;
+  L.acc = reinterpret_cast<int*>(lds);
+  L.cbits = nullptr;
+  L.g64 = a.g64_base + (long long)blockIdx.y * a.g_stride;
+  bt_carve(L, reinterpret_cast<int*>(lds) + ((a.hl + 3) & ~3), MB_CAP);
+  const int tid = threadIdx.x;
+  wg_zero(L.acc, a.hl, tid, MB_THREADS);
+  __syncthreads();
+  const WorkSeg seg = a.segs[blockIdx.y];
+  const long long b = seg.begin + (long long)blockIdx.x * a.rows_per_wg;
+  const long long e = b + a.rows_per_wg < seg.end ? b + a.rows_per_wg : seg.end;
+  const int* __restrict__ idx = a.idx;
+  unsigned int n_act = 0;
+  if (b < e) {
+    auto row_of = [&](int t) -> long long { return idx ? (long long)idx[b + t] : b + t; };
+    auto wload = [&](int c) -> float { return a.w[c]; };
+    n_act = bt_batch<MB_THREADS, MB_R, 2>(a.m, L, nullptr, (int)(e - b), 0, row_of, wload, a.qscale, &a.sc->err);
+  }
+  __syncthreads();
+  int* mine = a.part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * a.part_stride;
+  wg_copy_out(mine, L.acc, a.hl, tid, MB_THREADS, is_aligned16(mine));
+  n_act = wave_sum_u32(n_act);
+  if ((tid & 63) == 0 && n_act) atomicAdd(&a.sc->n_active, (unsigned long long)n_act);
 }
 
 // ======================================================================================================
@@ -413,6 +476,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   BtLds L;
   L.hl = a.hl;
+  L.g64 = nullptr;
   L.acc = reinterpret_cast<int*>(lds);
   const int n_cw = (a.dp - a.hl + 31) / 32;                  // bitmap words of the cold strip (0 when dp <= hl)
   L.cbits = reinterpret_cast<unsigned int*>(lds + a.hl);
@@ -484,11 +548,11 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       __syncthreads();
       n_act += bt_gate(L, bd.x);
       __syncthreads();
-      bt_scatter<HOG_R, false>(L, gc, items, a.qscale);
+      bt_scatter<HOG_R, 0>(L, gc, items, a.qscale);
       done = bd.x;
     }
     // ... and whatever did not fit its item slots (long rows, batches beyond 128 rows)
-    if (done < B) n_act += bt_batch<HOG_THREADS, HOG_R, false>(a.m, L, gc, B, done, row_of, wload, a.qscale, &a.st->err);
+    if (done < B) n_act += bt_batch<HOG_THREADS, HOG_R, 0>(a.m, L, gc, B, done, row_of, wload, a.qscale, &a.st->err);
     // the next iteration's sample does not depend on w: request its row records now
     const HogCtl nxt = ctl[(it + 1) & 1];
     const BtRow row_n = bt_rows_issue<HOG_CAP>(a.m, B, 0, [&](int t) { return row_at(nxt.mul, nxt.off, t); }, &a.st->err);
@@ -635,13 +699,13 @@ __global__ void __launch_bounds__(1024) dsgd_exchange_apply_kernel(float* __rest
 // took 31-41 us, all of it dependent-launch and cross-workgroup latency (profiles/README.md: a hipGraph of the same
 // chain changed nothing).  Here ONE 1024-lane workgroup owns the weights for the steps [step_begin, step_end) of a
 // resident plan and runs them back to back with nothing but workgroup barriers in between:
-//   * the hl hottest weights, their dimSparsity values and (several workers) the per-step sum `upd` live in LDS next
-//     to the fixed-point accumulators: the weight gather of ~88 % of the non-zeros and the whole update sweep of
-//     those ranks never leave the CU (global w is written through, never read back for them);
-//   * per worker k: mini-batch engine on the worker's index list (snapshot of w), then the sweep turns the batch
-//     sum into g_k = regularize(sum, w) on its support (SparseSVM.scala:31) and either applies it (one hosted worker)
-//     or adds it to `upd` in worker order (Vec.sum folds left); then w <- w - lr * (upd / K) on the union of the
-//     supports (Vec.mean, Master.scala:194-197);
+//   * the hl hottest weights and their dimSparsity values live in LDS next to the fixed-point accumulators: the
+//     weight gather of ~88 % of the non-zeros and the whole update sweep of those ranks never leave the CU (global w
+//     is written through, never read back for them);
+//   * per step: mini-batch engine on the worker's index list (snapshot of w), then the sweep turns the batch sum into
+//     g = regularize(sum, w) on its support (SparseSVM.scala:31) and applies w <- w - lr * g there (the mean over one
+//     worker, Master.scala:194-197).  Steps with several hosted workers are not run here: their batches would queue
+//     up in the one workgroup (3 x 100 rows: 44 us) while dsgd_mb_grad_kernel gives every worker its own workgroups;
 //   * the NEXT batch's index list, row records and non-zeros are requested while the current batch is swept -- only
 //     the weight gather and the gate wait for the update (the reference's synchronous semantics are kept exactly:
 //     every gradient of a step sees the weights of the previous step);
@@ -655,26 +719,24 @@ struct PlanArgs {
   float* w;
   const float* ds;
   float* gcold;              // dp - hl floats, zero between batches
-  float* upd;                // MULTI: dp floats (ranks >= hl used), zero between steps
   const int* idx;
-  const WorkSeg* segs;       // n_steps x n_workers
+  const WorkSeg* segs;       // one per step
   DevScalars* sc;
   unsigned long long* tprof; // optional (tuning runs): 16 words -- shader-clock cycles of thread 0 in nine phases of a batch, [15] = steps
   long long step_begin, step_end;
-  float k_total, lr, lambda;
-  int vexp, n_workers, dp;
+  float lr, lambda;
+  int vexp, dp;
 };
 
 constexpr int PLAN_THREADS = 1024;
 constexpr int PLAN_R = 3;        // 64 groups x 3 = 192 item slots per sub-batch (100 RCV1-like rows: 118 +- 6 items)
 constexpr int PLAN_CAP = PLAN_THREADS / BT_G * PLAN_R;
-constexpr int PLAN_HL1 = 11264;  // one hosted worker: LDS-resident ranks (accumulator + weight + dimSparsity: 12 bytes each)
-constexpr int PLAN_HLM = 8192;   // several workers: + the per-step sum (16 bytes each)
-__host__ __device__ constexpr int plan_hl(bool multi, int dp) { return (multi ? PLAN_HLM : PLAN_HL1) < dp ? (multi ? PLAN_HLM : PLAN_HL1) : dp; }
-__host__ __device__ constexpr int plan_lds_words(int dp, bool multi) {
-  const int hl = plan_hl(multi, dp);
+constexpr int PLAN_HL = 11264;   // LDS-resident ranks (accumulator + weight + dimSparsity: 12 bytes each)
+__host__ __device__ constexpr int plan_hl(int dp) { return PLAN_HL < dp ? PLAN_HL : dp; }
+__host__ __device__ constexpr int plan_lds_words(int dp) {
+  const int hl = plan_hl(dp);
   const int n_cw = (dp - hl + 31) / 32;
-  return (((multi ? 4 : 3) * hl + (multi ? 2 : 1) * n_cw + 1) & ~1) + 2 * bt_lds_words(PLAN_CAP) + 32 + 8;
+  return ((3 * hl + n_cw + 1) & ~1) + 2 * bt_lds_words(PLAN_CAP) + 32 + 8;
 }
 
 // sum over the 64 lanes of a wave, valid in lane 63; DPP moves of the two halves (a __shfl_xor of a double is two
@@ -716,20 +778,18 @@ __device__ __forceinline__ double block_sum_f64(double v, double* red) {
 // Every list of the launch fits the staged sub-batch (at most PLAN_CAP rows and PLAN_CAP work items): the host knows
 // the row lengths and sends anything else down the multi-workgroup path (measured: the stage-by-stage general path
 // inlined here cost 80+ spilled registers in the main loop and ran B = 200..1000 slower than the multi-launch kernels).
-template <bool MULTI>
 __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int hl = plan_hl(MULTI, a.dp);
+  const int hl = plan_hl(a.dp);
   const int n_cw = (a.dp - hl + 31) / 32;
   BtLds L;
   L.hl = hl;
+  L.g64 = nullptr;
   L.acc = reinterpret_cast<int*>(lds);
   float* wl = lds + hl;                       // hot weights
   float* dsl = lds + 2 * hl;                  // hot dimSparsity
-  float* updl = lds + 3 * hl;                 // MULTI: hot part of the per-step sum over the workers
-  L.cbits = reinterpret_cast<unsigned int*>(lds + (MULTI ? 4 : 3) * hl);
-  unsigned int* ubits = L.cbits + n_cw;       // MULTI: touched cold coordinates of `upd`
-  int* tables = reinterpret_cast<int*>(lds) + (((MULTI ? 4 : 3) * hl + (MULTI ? 2 : 1) * n_cw + 1) & ~1);
+  L.cbits = reinterpret_cast<unsigned int*>(lds + 3 * hl);
+  int* tables = reinterpret_cast<int*>(lds) + ((3 * hl + n_cw + 1) & ~1);
   // two sets of sub-batch tables (batch parity): the next batch's tables are built while the current one's are in use
   BtLds L2 = L;
   bt_carve(L, tables, PLAN_CAP);
@@ -741,9 +801,8 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     L.acc[j] = 0;
     wl[j] = a.w[j];
     dsl[j] = a.ds[j];
-    if (MULTI) updl[j] = 0.0f;
   }
-  for (int j = tid; j < (MULTI ? 2 : 1) * n_cw; j += PLAN_THREADS) L.cbits[j] = 0u;
+  for (int j = tid; j < n_cw; j += PLAN_THREADS) L.cbits[j] = 0u;
   // exact w . ds of the weights this launch starts from
   double dot_part = 0.0;
   for (int j = tid; j < a.dp; j += PLAN_THREADS) dot_part += (double)a.w[j] * (double)a.ds[j];
@@ -768,17 +827,14 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
   // new weight of coordinate j given the summed gradient; returns the change of w[j] * ds[j] (fp32 per thread -- a
   // thread adds at most a dozen such terms per step -- and fp64 from the workgroup reduction on: the fp64 form cost
   // five half-rate instructions per slot of the sweep, which is issue-bound)
-  const bool one_worker = a.k_total == 1.0f;
-  auto step_w = [&](float gsum, float wo, float dsj, float& wn) -> float {
-    const float mean = one_worker ? gsum : filt(gsum / a.k_total);   // Vec.mean (ref: math/Vec.scala:139); x / 1 == x
-    const float updv = filt(mean * a.lr);        // learningRate * grad (ref: core/Master.scala:197)
+  auto step_w = [&](float g, float wo, float dsj, float& wn) -> float {
+    const float updv = filt(g * a.lr);           // Vec.mean over one worker is the identity (ref: math/Vec.scala:139); learningRate * grad (ref: core/Master.scala:197)
     wn = filt(wo - updv);
     return (wn - wo) * dsj;
   };
 
-  const int K = a.n_workers;
-  const long long n_batches = (a.step_end - a.step_begin) * K;
-  const WorkSeg* segs = a.segs + a.step_begin * K;
+  const long long n_batches = a.step_end - a.step_begin;
+  const WorkSeg* segs = a.segs + a.step_begin;
   // The list descriptors of the batches n .. n+3 live in registers (a sliding window); the descriptor of batch n+4 is
   // requested at the top of iteration n with a VECTOR load: a scalar load would share lgkmcnt with the LDS traffic
   // of the whole iteration and stall the first LDS wait behind it for a memory round trip -- four such loads per
@@ -814,7 +870,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
   }
   // row ids of a batch whose descriptor is (beg, len)
   auto load_rid = [&](long long beg, int len) -> int { return tid < min(PLAN_CAP, len) ? a.idx[beg + tid] : -1; };
-  // Software pipeline over the batches n = 0, 1, ... (a batch = one worker's list of one step):
+  // Software pipeline over the batches n = 0, 1, ... (a batch = the worker's list of one step):
   //   iteration n:  dot(n) | build part 1 (n+1)            -- the non-zeros of batch n were requested an iteration ago
   //                 barrier
   //                 gate(n) | build part 2 (n+1)            -- into the OTHER table set
@@ -844,27 +900,20 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
       if (bd.x > 0) bt_items_issue<PLAN_THREADS, PLAN_R>(a.m, L, bd.y, items);
     }
   }
-  float s = 0.0f;
-  bool add_s = false;
-  float ddot = 0.0f;
-  unsigned int n_act = 0;
   for (long long n = 0; n < n_batches; ++n) {
     const BtLds& Lc = (n & 1) ? L2 : L;     // tables of batch n
     const BtLds& Ln = (n & 1) ? L : L2;     // tables of batch n+1
-    const int k = (int)(n % K);
-    if (k == 0) {
-      s = (float)(2.0 * (double)a.lambda * dot);   // thread-uniform: every thread carries the same dot
-      add_s = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
-      ddot = 0.0f;
-      n_act = 0;
-    }
+    const float s = (float)(2.0 * (double)a.lambda * dot);   // thread-uniform: every thread carries the same dot
+    const bool add_s = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+    float ddot = 0.0f;
+    unsigned int n_act = 0;
     unsigned long long tl = a.tprof ? __builtin_readcyclecounter() : 0ull;
     const int B = sl[0], Bn = sl[1];
     int bits = 0;
     while ((1 << bits) < B) ++bits;
     const int shift = 30 - bits;   // at most one contribution per row and column: sums stay below 2^30
     const float qscale = ldexpf(1.0f, shift - a.vexp), inv_qscale = ldexpf(1.0f, a.vexp - shift);
-    // ---- gradient of worker k on the weights of the previous step, interleaved with the tables of batch n+1 ----
+    // ---- gradient on the weights of the previous step, interleaved with the tables of batch n+1 ----
     if (bd.x > 0) bt_items_dot<PLAN_THREADS, PLAN_R>(Lc, items, wload);
     const BtScan scn = bt_build_p1<PLAN_THREADS, PLAN_CAP>(Ln, Bn, 0, row_next);
     stamp(0, tl);
@@ -875,7 +924,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     stamp(2, tl);
     __syncthreads();
     stamp(3, tl);
-    if (bd.x > 0) bt_scatter<PLAN_R, true>(Lc, a.gcold, items, qscale);
+    if (bd.x > 0) bt_scatter<PLAN_R, 1>(Lc, a.gcold, items, qscale);
     const int2 bd_n = bt_build_p3<PLAN_THREADS>(Ln);
     if (bd.x < B && tid == 0) atomicOr(&a.sc->err, 4);   // the host's fit check and the device disagree: the step is invalid
     stamp(4, tl);
@@ -892,7 +941,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     seg_load(n + 4, vb4, ve4);   // used when the window shifts at the end of the iteration
     if (Bn > 0 && bd_n.x > 0) bt_items_issue<PLAN_THREADS, PLAN_R>(a.m, Ln, bd_n.y, items);
     stamp(6, tl);
-    // ---- sweep: this worker's regularised sum on its support; the hot ranks never leave LDS ----
+    // ---- sweep: the regularised sum on its support and the update; the hot ranks never leave LDS ----
     for (int j = tid; j < hl; j += PLAN_THREADS) {
       const int q = L.acc[j];
       if (q == 0) continue;
@@ -900,14 +949,10 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
       float g = filt((float)q * inv_qscale);            // Vec.sum of the batch (ref: core/Slave.scala:153)
       if (g == 0.0f) continue;
       if (add_s) g = filt(g + s);                       // ref: core/ml/SparseSVM.scala:31, math/Vec.scala:65-75
-      if (MULTI) {
-        updl[j] = filt(updl[j] + g);                    // Vec.sum over the workers folds left
-      } else {
-        float wn;
-        ddot += step_w(g, wl[j], dsl[j], wn);
-        wl[j] = wn;
-        a.w[j] = wn;                                    // written through; never read back for a hot rank
-      }
+      float wn;
+      ddot += step_w(g, wl[j], dsl[j], wn);
+      wl[j] = wn;
+      a.w[j] = wn;                                      // written through; never read back for a hot rank
     }
     for (int wd = tid; wd < n_cw; wd += PLAN_THREADS) {
       unsigned int cb = L.cbits[wd];
@@ -927,8 +972,8 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
         for (int e = 0; e < 4; ++e) {
           old[e] = dsj[e] = gs[e] = 0.0f;
           if (jc[e] >= 0) {
-            old[e] = MULTI ? a.upd[hl + jc[e]] : a.w[hl + jc[e]];
-            if (!MULTI) dsj[e] = a.ds[hl + jc[e]];
+            old[e] = a.w[hl + jc[e]];
+            dsj[e] = a.ds[hl + jc[e]];
             // (written with L2 atomics of this workgroup: read it there, not through L1)
             gs[e] = __hip_atomic_exchange(&a.gcold[jc[e]], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
@@ -940,52 +985,18 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
           float g = filt(gs[e]);
           if (g == 0.0f) continue;
           if (add_s) g = filt(g + s);
-          if (MULTI) {
-            a.upd[j] = filt(old[e] + g);
-            atomicOr(&ubits[jc[e] >> 5], 1u << (jc[e] & 31));
-          } else {
-            float wn;
-            ddot += step_w(g, old[e], dsj[e], wn);
-            a.w[j] = wn;
-          }
-        }
-      }
-    }
-    if (MULTI && k == K - 1) {
-      // mean over the workers and the update, on the union of the supports (every coordinate of `upd` is owned by
-      // the thread that wrote it: no barrier needed in between)
-      for (int j = tid; j < hl; j += PLAN_THREADS) {
-        const float u = updl[j];
-        if (u == 0.0f) continue;
-        updl[j] = 0.0f;
-        float wn;
-        ddot += step_w(u, wl[j], dsl[j], wn);
-        wl[j] = wn;
-        a.w[j] = wn;
-      }
-      for (int wd = tid; wd < n_cw; wd += PLAN_THREADS) {
-        unsigned int ub = ubits[wd];
-        if (!ub) continue;
-        ubits[wd] = 0u;
-        while (ub) {
-          const int j = hl + wd * 32 + __builtin_ctz(ub);
-          ub &= ub - 1u;
-          const float u = a.upd[j], wo = a.w[j], dsj = a.ds[j];
-          a.upd[j] = 0.0f;
           float wn;
-          ddot += step_w(u, wo, dsj, wn);
+          ddot += step_w(g, old[e], dsj[e], wn);
           a.w[j] = wn;
         }
       }
     }
     // (`red` is free: the previous collect is behind three barriers)
-    if (k == K - 1) block_sum_f64_publish((double)ddot, red);
+    block_sum_f64_publish((double)ddot, red);
     stamp(7, tl);
     __syncthreads();   // the weights of the next gather are written; the wave partials are visible
-    if (k == K - 1) {
-      dot += block_sum_f64_collect(red);   // every thread adds the same total: `dot` stays thread-uniform
-      n_act_total += n_act;
-    }
+    dot += block_sum_f64_collect(red);   // every thread adds the same total: `dot` stays thread-uniform
+    n_act_total += n_act;
     bd = bd_n;
     if (Bn == 0) bd = make_int2(0, 0);
 #pragma unroll

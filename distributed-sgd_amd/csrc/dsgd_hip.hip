@@ -249,8 +249,8 @@ struct dsgd_ctx {
   // small-batch plan kernel (one persistent workgroup): cold strip and the multi-worker sum buffer
   unsigned long long* d_tprof = nullptr;   // DSGD_PLAN_PROF=1: phase cycle counters of dsgd_plan_kernel (tuning runs)
   float* d_plan_gcold = nullptr;
-  float* d_plan_upd = nullptr;
   bool plan_kernel = true;     // DSGD_PLAN_KERNEL=0: the multi-launch small-batch path
+  bool mb_kernel = true;       // DSGD_MB_KERNEL=0: round 1's fp32-atomic kernels for index lists beyond one workgroup
   long long plan_max_rows = 2048;   // steps with more rows in total use the multi-workgroup kernels
   int hog_workers = 0;      // capacity of the per-worker buffers
   int hog_n = 0, hog_batch = 0, hog_bug = 0;   // the running configuration
@@ -416,9 +416,67 @@ static int prof_collect(dsgd_ctx* c) {  // stream must be idle
   return DSGD_OK;
 }
 
+static int ensure_part(dsgd_ctx* c, int** buf, long long* wgs, int* stride, long long need_wgs, int need_cols);
+
+// Index-list batches spread over workgroups (dsgd_mb_grad_kernel): per-workgroup fixed-point partials, then the exact
+// finish of the streaming path.  `allow_fused`: the caller goes on to launch_finish_sync (one hosted worker without
+// peers then gets regulariser + update fused into the reduction); otherwise the sums land in d_g.
+static int launch_grad_mb(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int n_workers, long long max_items,
+                          bool allow_fused) {
+  const int hl = std::min(c->dp, MB_HL);
+  const long long per_worker = std::max<long long>(1, c->n_cu / n_workers);
+  long long rows_per_wg = std::max<long long>(64, (max_items + per_worker - 1) / per_worker);
+  const long long wgs = std::max<long long>(1, (max_items + rows_per_wg - 1) / rows_per_wg);
+  DSGD_TRY(ensure_part(c, &c->d_part, &c->part_wgs, &c->part_stride, wgs * n_workers, hl));
+  int bits = 0;
+  while ((1LL << bits) < rows_per_wg) ++bits;
+  const int shift = 30 - bits;   // at most one contribution per row and column: a workgroup's sums stay below 2^30
+  MbArgs a;
+  a.m = view(c);
+  a.w = c->d_w;
+  a.idx = d_idx;
+  a.segs = d_segs;
+  a.part = c->d_part;
+  a.g64_base = c->d_g64;
+  a.g_stride = c->dp;
+  a.sc = c->d_sc;
+  a.qscale = std::ldexp(1.0f, shift - c->vexp);
+  a.part_stride = c->part_stride;
+  a.rows_per_wg = (int)rows_per_wg;
+  a.hl = hl;
+  const size_t lds = sizeof(float) * (size_t)(((hl + 3) & ~3) + bt_lds_words(MB_CAP));
+  size_t slot = 0;
+  DSGD_TRY(prof_begin(c, &slot));
+  hipLaunchKernelGGL(dsgd_mb_grad_kernel, dim3((unsigned)wgs, n_workers), dim3(MB_THREADS), lds, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  DSGD_TRY(prof_end(c, slot));
+  c->last_grad_kernel = "dsgd_mb_grad_kernel";
+  const double inv = 1.0 / (double)a.qscale;
+  c->fused_apply_pending = false;
+  if (allow_fused && !c->comm && c->fuse_apply) {
+    const int blocks = (c->dp + 63) / 64;
+    if (blocks > c->redpart_cap) {
+      (void)hipFree(c->d_redpart);
+      c->d_redpart = nullptr;
+      HIP_TRY(hipMalloc(&c->d_redpart, sizeof(float) * 2 * (size_t)blocks));
+      c->redpart_cap = blocks;
+    }
+    c->fused_args = {hl, (int)wgs, c->dp, 0, 0, inv, inv};
+    c->fused_apply_pending = true;   // launched by launch_finish_sync, which knows lr
+    return DSGD_OK;
+  }
+  hipLaunchKernelGGL(dsgd_fix_reduce_kernel, dim3((c->dp + 63) / 64, n_workers), dim3(1024), 0, c->stream, c->d_g64, c->d_g,
+                     (long long)c->dp, c->dp, hl, c->d_part, c->part_stride, (int)wgs, c->dp, 0, (const int*)nullptr, 0, 0, inv, inv);
+  HIP_TRY(hipGetLastError());
+  return DSGD_OK;
+}
+
 // launch K1 for n_workers segments living at d_segs (device); max_items = largest segment
 static int launch_grad(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int n_workers, long long max_items,
-                       long long total_items) {
+                       long long total_items, bool allow_fused = false) {
+  if (c->mb_kernel && !(c->cfg.flags & (DSGD_F_FORCE_TILED | DSGD_F_FORCE_ROWS)))
+    return launch_grad_mb(c, d_idx, d_segs, n_workers, max_items, allow_fused);
+  c->fused_apply_pending = false;
   const int G = c->group;
   size_t slot = 0;
   CsrView m = view(c);
@@ -467,8 +525,8 @@ static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
   if (c->fused_apply_pending) {
     c->fused_apply_pending = false;
     const FusedArgs& f = c->fused_args;
-    hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel, dim3((dp + 64 * FRA_GROUPS - 1) / (64 * FRA_GROUPS)), dim3(1024), 0, c->stream, c->d_g64, c->d_w, c->d_ds,
-                       dp, f.hg, c->d_part, c->part_stride, f.n_wg, f.hc, f.nc, c->d_partc, c->partc_stride, f.n_wgc,
+    hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel, dim3((dp + 63) / 64), dim3(1024), 0, c->stream, c->d_g64, (long long)dp,
+                       n_workers, c->d_w, c->d_ds, dp, f.hg, c->d_part, c->part_stride, f.n_wg, f.hc, f.nc, c->d_partc, c->partc_stride, f.n_wgc,
                        f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart);
     HIP_TRY(hipGetLastError());
     c->s_dirty = false;
@@ -1139,9 +1197,9 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
     DSGD_TRY(prof_end(c, slot_g));
   }
   c->fused_apply_pending = false;
-  if (n_workers == 1 && !c->comm && c->fuse_apply) {
-    // one hosted worker, no peers: the exact column sums go straight into regularise + update + next s (one launch
-    // instead of dsgd_fix_reduce_kernel + dsgd_apply_mb_kernel; g itself is never materialised)
+  if (!c->comm && c->fuse_apply) {
+    // no peers: the exact column sums of every hosted worker go straight into regularise + sum + mean + update + next s
+    // (one launch instead of dsgd_fix_reduce_kernel + regularise + sum + apply; g itself is never materialised)
     const int blocks = (c->dp + 63) / 64;
     if (blocks > c->redpart_cap) {
       (void)hipFree(c->d_redpart);
@@ -1182,48 +1240,40 @@ static bool list_fits_staged(const dsgd_ctx* c, const int32_t* idx, long long n)
   }
   return items <= PLAN_CAP;
 }
-static bool plan_kernel_ok(const dsgd_ctx* c, long long step_rows) {
-  return c->plan_kernel && !c->comm && step_rows <= c->plan_max_rows &&
+static bool plan_kernel_ok(const dsgd_ctx* c, long long step_rows, int n_workers) {
+  // (several hosted workers: their batches would run one after the other in the one workgroup -- 44 us for 3 x 100 --
+  //  while dsgd_mb_grad_kernel gives every worker its own workgroups: 32 us with the four-launch finish, less fused)
+  return c->plan_kernel && !c->comm && n_workers == 1 && step_rows <= c->plan_max_rows &&
          !(c->cfg.flags & (DSGD_F_FORCE_TILED | DSGD_F_FORCE_ROWS));
 }
-static int launch_plan_kernel(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int n_workers, long long step_begin,
+static int launch_plan_kernel(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, long long step_begin,
                               long long step_end, float lr) {
   if (!c->d_plan_gcold) {
-    const size_t strip = (size_t)std::max(1, c->dp - plan_hl(true, c->dp));   // (the longer of the two strips)
+    const size_t strip = (size_t)std::max(1, c->dp - plan_hl(c->dp));
     HIP_TRY(hipMalloc(&c->d_plan_gcold, sizeof(float) * strip));
-    HIP_TRY(hipMalloc(&c->d_plan_upd, sizeof(float) * c->dp));
     HIP_TRY(hipMemsetAsync(c->d_plan_gcold, 0, sizeof(float) * strip, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_plan_upd, 0, sizeof(float) * c->dp, c->stream));
   }
   PlanArgs a;
   a.m = view(c);
   a.w = c->d_w;
   a.ds = c->d_ds;
   a.gcold = c->d_plan_gcold;
-  a.upd = c->d_plan_upd;
   a.idx = d_idx;
   a.segs = d_segs;
   a.sc = c->d_sc;
   a.step_begin = step_begin;
   a.step_end = step_end;
-  a.k_total = (float)n_workers;
   a.lr = lr;
   a.lambda = (float)c->cfg.lambda;
   a.tprof = c->d_tprof;
   a.vexp = c->vexp;
-  a.n_workers = n_workers;
   a.dp = c->dp;
-  const size_t lds = sizeof(float) * (size_t)plan_lds_words(c->dp, n_workers > 1);
+  const size_t lds = sizeof(float) * (size_t)plan_lds_words(c->dp);
   size_t slot = 0;
   DSGD_TRY(prof_begin(c, &slot));
   // (every list fits the staged sub-batch: the callers checked the row lengths)
-  if (n_workers > 1) {
-    hipLaunchKernelGGL(dsgd_plan_kernel<true>, dim3(1), dim3(PLAN_THREADS), lds, c->stream, a);
-    c->last_grad_kernel = "dsgd_plan_kernel<true>";
-  } else {
-    hipLaunchKernelGGL(dsgd_plan_kernel<false>, dim3(1), dim3(PLAN_THREADS), lds, c->stream, a);
-    c->last_grad_kernel = "dsgd_plan_kernel<false>";
-  }
+  hipLaunchKernelGGL(dsgd_plan_kernel, dim3(1), dim3(PLAN_THREADS), lds, c->stream, a);
+  c->last_grad_kernel = "dsgd_plan_kernel";
   HIP_TRY(hipGetLastError());
   DSGD_TRY(prof_end(c, slot));
   c->s_dirty = false;     // the kernel leaves s = 2*lambda*(w . ds) of the weights it ends with ...
@@ -1327,6 +1377,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_FUSE_APPLY")) c->fuse_apply = atoi(e) != 0;
   if (const char* e = getenv("DSGD_COLD8")) c->cold8 = atoi(e);
   if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_MB_KERNEL")) c->mb_kernel = atoi(e) != 0;
   if (const char* e = getenv("DSGD_PLAN_MAX_ROWS")) c->plan_max_rows = std::max(1LL, atoll(e));
   if (getenv("DSGD_PLAN_PROF") && atoi(getenv("DSGD_PLAN_PROF"))) {
     HIP_TRY_B(hipMalloc(&c->d_tprof, sizeof(unsigned long long) * 16));
@@ -1355,8 +1406,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_eval_kernel<8>);
   DSGD_ATTR(dsgd_colcount_kernel);
   DSGD_ATTR(dsgd_hogwild_kernel);
-  DSGD_ATTR(dsgd_plan_kernel<true>);
-  DSGD_ATTR(dsgd_plan_kernel<false>);
+  DSGD_ATTR(dsgd_mb_grad_kernel);
+  DSGD_ATTR(dsgd_plan_kernel);
   DSGD_ATTR((dsgd_wseg_kernel<true, false, 4, false>));
   DSGD_ATTR((dsgd_wseg_kernel<true, true, 4, false>));
   DSGD_ATTR((dsgd_wseg_kernel<false, false, 4, false>));
@@ -1445,7 +1496,6 @@ int dsgd_destroy(dsgd_ctx* c) {
   (void)hipFree(c->d_wdelta);
   (void)hipFree(c->d_tprof);
   (void)hipFree(c->d_plan_gcold);
-  (void)hipFree(c->d_plan_upd);
   if (c->h_sc) (void)hipHostFree(c->h_sc);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   c->mu.unlock();
@@ -1773,13 +1823,13 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
   {
     long long t = 0;
     for (int k = 0; k < n_workers; ++k) t += std::max<long long>(0, n_per_worker[k]);
-    bool fits = plan_kernel_ok(c, t);
+    bool fits = plan_kernel_ok(c, t, n_workers);
     for (int k = 0; k < n_workers && fits; ++k)
       fits = idx_per_worker[k] && list_fits_staged(c, idx_per_worker[k], n_per_worker[k]);
     if (fits) {   // the reference's batch sizes: one persistent workgroup does the whole closure
       DSGD_TRY(reset_counters(c));
       DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
-      DSGD_TRY(launch_plan_kernel(c, c->d_idx, c->d_segs, n_workers, 0, 1, lr));
+      DSGD_TRY(launch_plan_kernel(c, c->d_idx, c->d_segs, 0, 1, lr));
       return finish_stats(c, stats, tot);
     }
   }
@@ -1787,7 +1837,7 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
   DSGD_TRY(ensure_s(c));
   DSGD_TRY(reset_counters(c));
   DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
-  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, n_workers, mx, tot));
+  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, n_workers, mx, tot, true));
   DSGD_TRY(launch_finish_sync(c, n_workers, lr));
   return finish_stats(c, stats, tot);
 }
@@ -1821,7 +1871,7 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
     DSGD_TRY(launch_stream<true>(c, ssegs));  // (the profiling events bracket the main kernel only)
   } else {
     DSGD_TRY(upload_segs(c, segs));
-    DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx, tot));
+    DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx, tot, true));
   }
   DSGD_TRY(launch_finish_sync(c, n_workers, lr));
   *total = tot;
@@ -1939,8 +1989,8 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
   DSGD_TRY(require_ds(c));
   DSGD_TRY(require_sync_mode(c));
   DSGD_TRY(prepare_layout(c));
-  if (plan_kernel_ok(c, p->max_step_rows) && p->fits && p->fits_rows == c->n_rows) {
-    if (step_end > step_begin) DSGD_TRY(launch_plan_kernel(c, p->d_idx, p->d_segs, p->n_workers, step_begin, step_end, lr));
+  if (plan_kernel_ok(c, p->max_step_rows, p->n_workers) && p->fits && p->fits_rows == c->n_rows) {
+    if (step_end > step_begin) DSGD_TRY(launch_plan_kernel(c, p->d_idx, p->d_segs, step_begin, step_end, lr));
     c->pending_samples += p->offsets[step_end * p->n_workers] - p->offsets[step_begin * p->n_workers];
     return DSGD_OK;
   }
@@ -1952,7 +2002,7 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
     for (int k = 0; k < p->n_workers; ++k)
       mx = std::max<long long>(mx, p->offsets[s * p->n_workers + k + 1] - p->offsets[s * p->n_workers + k]);
     const long long tot_s = p->offsets[(s + 1) * p->n_workers] - p->offsets[s * p->n_workers];
-    DSGD_TRY(launch_grad(c, p->d_idx, segs, p->n_workers, mx, tot_s));
+    DSGD_TRY(launch_grad(c, p->d_idx, segs, p->n_workers, mx, tot_s, true));
     DSGD_TRY(launch_finish_sync(c, p->n_workers, lr));
     c->pending_samples += p->offsets[(s + 1) * p->n_workers] - p->offsets[s * p->n_workers];
   }

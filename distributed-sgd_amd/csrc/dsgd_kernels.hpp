@@ -649,13 +649,15 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_kernel(long long* g64_ba
   }
 }
 
-// The same reduction fused with K2 + K3 for ONE hosted worker without peers (the benchmark's whole-shard step): the
-// exact column sum becomes g[j] in a register, gets the support-only regulariser (ref: core/ml/SparseSVM.scala:31),
-// the "mean" over one worker and the update (ref: core/Master.scala:194-197) -- g is never written.  The two dot
-// products of the new weights are combined by the last block to arrive, in block order (reproducible).  Every block
-// reads the old s before it takes its ticket, so the last block's write of the new s cannot be seen by any of them.
-constexpr int FRA_GROUPS = 1;   // 64-column groups per block (4 measured slower: 41-46 vs 34.5 us -- fewer blocks in flight)
-__global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* __restrict__ g64, float* __restrict__ w,
+// The same reduction fused with K2 + K3 for the workers hosted by ONE context without peers (the benchmark's
+// whole-shard step, every small / mid-size batch): per column the exact sum of every worker's partials becomes g_k[j]
+// in a register, gets the support-only regulariser (ref: core/ml/SparseSVM.scala:31), the sums are folded over the
+// workers (Vec.sum), divided by their number (Vec.mean) and applied (ref: core/Master.scala:194-197) -- g is never
+// written.  The two dot products of the new weights are combined by the last block to arrive, in block order
+// (reproducible).  Every block reads the old s before it takes its ticket, so the last block's write of the new s
+// cannot be seen by any of them.
+__global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* __restrict__ g64_base, long long g_stride,
+                                                                    int n_workers, float* __restrict__ w,
                                                                     const float* __restrict__ ds, int dp, int hg,
                                                                     const int* __restrict__ part, int part_stride,
                                                                     int n_wg, int hc, int nc,
@@ -668,35 +670,40 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
   const float s = sc->s_reg;
   const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
   const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  float dot = 0.0f, nsq = 0.0f;   // (wave 0 only)
-  for (int grp = 0; grp < FRA_GROUPS; ++grp) {
-    const int j = (blockIdx.x * FRA_GROUPS + grp) * 64 + cx;
+  const int j = blockIdx.x * 64 + cx;
+  float gsum = 0.0f;   // (wave 0) Vec.sum over the workers, folded left with the Sparse filter after every add
+  for (int k = 0; k < n_workers; ++k) {
     long long q = 0;
     if (j < hg) {
-      const int* p = part + j;
+      const int* p = part + (long long)k * n_wg * part_stride + j;
       for (int b = ph; b < n_wg; b += 16) q += (long long)p[(long long)b * part_stride];
     } else if (j >= hc && j < hc + nc) {
-      const int* p = partc + (j - hc);
+      const int* p = partc + (long long)k * n_wgc * partc_stride + (j - hc);
       for (int b = ph; b < n_wgc; b += 16) q += (long long)p[(long long)b * partc_stride];
     }
-    if (grp) __syncthreads();   // the previous group's sums have been read
+    if (k) __syncthreads();   // the previous worker's sums have been read
     red[ph][cx] = q;
     __syncthreads();
-    if (ph == 0 && j < dp) {   // one wave: the 64 columns of the group
+    if (ph == 0 && j < dp) {
+      long long* g64 = g64_base + (long long)k * g_stride;
       long long tot = g64[j];
       if (tot != 0) g64[j] = 0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) tot += red[k][cx];
+      for (int i = 0; i < 16; ++i) tot += red[i][cx];
       float gv = filt((float)((double)tot * (j >= hc ? inv_scale_cold : inv_scale)));   // one rounding of the exact sum
       if (add && gv != 0.0f) gv = filt(gv + s);
-      const float upd = filt(filt(gv / 1.0f) * lr);   // Vec.mean over ONE worker, then learningRate * grad
-      const float wn = filt(w[j] - upd);
-      w[j] = wn;
-      dot += filt(wn * ds[j]);
-      nsq += wn * wn;
+      gsum = filt(gsum + gv);
     }
   }
-  if (ph == 0) {
+  if (ph == 0) {   // one wave: the 64 columns of the block
+    float dot = 0.0f, nsq = 0.0f;
+    if (j < dp) {
+      const float upd = filt(filt(gsum / (float)n_workers) * lr);   // Vec.mean over the workers, then learningRate * grad
+      const float wn = filt(w[j] - upd);
+      w[j] = wn;
+      dot = filt(wn * ds[j]);
+      nsq = wn * wn;
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       dot += __shfl_xor(dot, off, 64);

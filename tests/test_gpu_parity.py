@@ -439,7 +439,7 @@ def test_forced_shift_15_stays_inside_the_derived_bound(monkeypatch):
 
 
 # ---- small batches: ONE persistent workgroup (dsgd_plan_kernel) vs the multi-launch path vs the oracle ---------------
-@pytest.mark.parametrize("k_workers,batch", [(1, 100), (3, 100), (4, 200), (2, 1), (1, 700)])
+@pytest.mark.parametrize("k_workers,batch", [(1, 100), (3, 100), (4, 200), (2, 1), (1, 1), (1, 700)])
 def test_plan_kernel_and_multi_launch_path_agree_with_the_oracle(monkeypatch, k_workers, batch):
     n_rows, n_train = 8192, 6553
     data = dsgd_amd.synth.generate(n_rows, seed=31)
@@ -453,9 +453,12 @@ def test_plan_kernel_and_multi_launch_path_agree_with_the_oracle(monkeypatch, k_
             assert eng.tuning_info()["plan_kernel"] == int(mode)
             w_ref, flips, rows = run_sync(o, eng, steps, 0.5)
             name = eng.grad_kernel_name()
-            # lists of up to 128 rows (and 128 work items of 128 non-zeros) take the persistent workgroup; longer ones
-            # (and DSGD_PLAN_KERNEL=0) the multi-workgroup kernels
-            assert ("dsgd_plan_kernel" in name) == (mode == "1" and batch <= 192), name   # PLAN_CAP rows per list
+            # one hosted worker with lists of up to PLAN_CAP = 192 rows (and 192 work items of 128 non-zeros) takes the
+            # persistent workgroup; longer lists, several workers per step (and DSGD_PLAN_KERNEL=0) the
+            # multi-workgroup kernel
+            assert ("dsgd_plan_kernel" in name) == (mode == "1" and k_workers == 1 and batch <= 192), name
+            if "dsgd_plan_kernel" not in name:
+                assert name == "dsgd_mb_grad_kernel"
             # the resident-plan form of the same steps: identical to the step-by-step calls bit for bit in the
             # plan kernel (integer sums, fixed sweep order)
             w_steps = eng.get_weights()
