@@ -74,9 +74,9 @@ struct BtRow {
 };
 
 // contribution of one non-zero of an active row.  COLD says where the few ranks beyond the LDS accumulators go:
-//   0  the workgroup's private fp32 strip + LDS bitmap, device-scope atomics (Hogwild: the strip is swept right away)
-//   1  the same with workgroup-scope atomics (plan kernel: the workgroup is alone with its data -- they stay in this
-//      XCD's L2)
+//   0  the workgroup's private fp32 strip + LDS bitmap, device-scope atomics
+//   1  the same with workgroup-scope atomics (plan kernel, Hogwild: only this workgroup touches its strip -- the
+//      atomics stay in this XCD's L2 instead of crossing the fabric)
 //   2  64-bit fixed-point global accumulators on the same grid as the LDS ones (mid-size batches spread over many
 //      workgroups: dsgd_fix_reduce_* adds them to the partial sums exactly)
 template <int COLD>
@@ -424,7 +424,7 @@ struct HogArgs {
   unsigned long long seed;
   float lr, lambda;
   float qscale, inv_qscale;     // 2^shift / vmax2 and its inverse
-  int batch, positional_bug, hl, dp;
+  int batch, positional_bug, hl, wl, dp;   // hl: ranks with an LDS accumulator; wl: ranks with an LDS copy of w (multiple of 256)
 };
 
 __device__ __forceinline__ unsigned long long hog_mix(unsigned long long z) {
@@ -446,7 +446,9 @@ constexpr int HOG_THREADS = 512;   // 2 waves per SIMD: leaves registers and LDS
 constexpr int HOG_R = 4;           // work items in flight per group: 32 groups x 4 = 128 item slots per sub-batch
 constexpr int HOG_CAP = HOG_THREADS / BT_G * HOG_R;
 constexpr int HOG_MAX_BATCH = 4096;
-constexpr int HOG_HL = 24576;      // ranks with an LDS accumulator (96 KiB; + 32 KiB of dsgd_eval_kernel still fit a CU)
+constexpr int HOG_HL = 20480;      // ranks with an LDS accumulator (80 KiB)
+constexpr int HOG_WL = 12288;      // ranks whose weight is gathered from an LDS copy refreshed every iteration (48 KiB;
+                                   // with the tables 136 KiB: 16 KiB of dsgd_eval_kernel still fit the CU)
 constexpr int HOG_SW = 8;          // accumulator slots per thread and sweep pass
 
 struct HogCtl {   // per iteration parity
@@ -455,9 +457,34 @@ struct HogCtl {   // per iteration parity
   int stop;
 };
 
-__host__ __device__ constexpr int hog_lds_words(int hl, int dp) {
-  return ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8;
+__host__ __device__ constexpr int hog_wl(int dp) { return (HOG_WL < dp ? HOG_WL : dp) & ~255; }   // whole 1 KiB pieces
+__host__ __device__ constexpr int hog_lds_words(int hl, int wl, int dp) {
+  return wl + ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8;
 }
+
+// Copy of w[0, wl) into LDS: each wave moves 1 KiB pieces straight from the fabric into LDS (global_load_lds_dwordx4:
+// no staging registers -- the kernel has none to spare).  sc1: past this XCD's L2, which other XCDs' updates never
+// reach.  The caller waits (hog_wcache_wait) and crosses a workgroup barrier before gathering.
+__device__ __forceinline__ void hog_wcache_issue(const float* __restrict__ w, float* wl_lds, int wl) {
+  const int lane = threadIdx.x & 63;
+  const unsigned int lds_base = (unsigned int)(unsigned long long)(__attribute__((address_space(3))) float*)wl_lds;
+  for (int piece = threadIdx.x >> 6; piece < (wl >> 8); piece += HOG_THREADS / 64) {
+    const float* src = w + piece * 256 + lane * 4;
+    // wave-uniform (M0); the lanes land at dst + lane * 16
+    const unsigned int dst = (unsigned int)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned int)piece * 1024u));
+    unsigned int keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off sc1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(dst)
+        : "memory");
+  }
+}
+__device__ __forceinline__ void hog_wcache_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // the sampler of iteration `it`: rows base + (mul * t + off) mod n_k, t = 0..B-1 (distinct rows)
 __device__ __forceinline__ void hog_sampler(const HogArgs& a, int worker, unsigned long long it, unsigned int n_k,
@@ -477,10 +504,11 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   BtLds L;
   L.hl = a.hl;
   L.g64 = nullptr;
-  L.acc = reinterpret_cast<int*>(lds);
+  float* wl = lds;                                           // copy of w[0, a.wl), 16-byte aligned
+  L.acc = reinterpret_cast<int*>(lds + a.wl);
   const int n_cw = (a.dp - a.hl + 31) / 32;                  // bitmap words of the cold strip (0 when dp <= hl)
-  L.cbits = reinterpret_cast<unsigned int*>(lds + a.hl);
-  int* tables = reinterpret_cast<int*>(lds) + ((a.hl + n_cw + 1) & ~1);
+  L.cbits = reinterpret_cast<unsigned int*>(lds + a.wl + a.hl);
+  int* tables = reinterpret_cast<int*>(lds) + a.wl + ((a.hl + n_cw + 1) & ~1);
   bt_carve(L, tables, HOG_CAP);
   float* red = reinterpret_cast<float*>(tables + bt_lds_words(HOG_CAP));   // 8 floats + 8 counters
   unsigned int* redn = reinterpret_cast<unsigned int*>(red + 8);
@@ -496,6 +524,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   const int B = a.batch;
   const float fB = (float)B;
   unsigned long long it = a.it[worker];
+  hog_wcache_issue(a.w, wl, a.wl);   // (lands under the start-up loads below; waited for in front of the first barrier)
   // thread 0 carries the shared scalars between iterations: what its own returning atomics saw
   unsigned long long u = 0;
   float s = 0.0f;
@@ -509,10 +538,21 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     c0->stop = stop != 0 || (long long)u >= a.max_updates;
     hog_sampler(a, worker, it + 1, n_k, &ctl[(it + 1) & 1]);
   }
+  hog_wcache_wait();
   __syncthreads();
+  // The weight gather: ~89 % of a batch's non-zeros have a rank below wl and read this iteration's LDS copy -- 7,600
+  // scattered coherent 4-byte loads per batch of 100 became 768 coalesced 64-byte lines + ~850 scattered ones (with
+  // 256 workers the scattered form alone held an iteration at 100 us; served from L2 -- stale, not an option -- it
+  // was 59 us: profiles/README.md).  The copy is as fresh as the gather was: taken after this workgroup's own
+  // previous update has been performed, other workers' updates as they happen to have landed.
+  typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
+  const int wl_n = a.wl;
   auto wload = [&](int c) -> float {
-    // agent scope: other workgroups update w concurrently -- a plain load could be served by a stale L1 line forever
-    return __hip_atomic_load(&a.w[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool hot = c < wl_n;
+    float v = ((lds_cvfloat*)wl)[hot ? c : 0];
+    // agent scope: other workgroups update w concurrently -- a plain load could be served by a stale L1 / L2 line forever
+    if (!hot) v = __hip_atomic_load(&a.w[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
   };
   auto row_at = [&](unsigned long long mul, unsigned long long off, int t) -> long long {
     const unsigned long long x = mul * (unsigned long long)t + off;          // < 2^44: exact in a double
@@ -548,11 +588,11 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       __syncthreads();
       n_act += bt_gate(L, bd.x);
       __syncthreads();
-      bt_scatter<HOG_R, 0>(L, gc, items, a.qscale);
+      bt_scatter<HOG_R, 1>(L, gc, items, a.qscale);
       done = bd.x;
     }
     // ... and whatever did not fit its item slots (long rows, batches beyond 128 rows)
-    if (done < B) n_act += bt_batch<HOG_THREADS, HOG_R, 0>(a.m, L, gc, B, done, row_of, wload, a.qscale, &a.st->err);
+    if (done < B) n_act += bt_batch<HOG_THREADS, HOG_R, 1>(a.m, L, gc, B, done, row_of, wload, a.qscale, &a.st->err);
     // the next iteration's sample does not depend on w: request its row records now
     const HogCtl nxt = ctl[(it + 1) & 1];
     const BtRow row_n = bt_rows_issue<HOG_CAP>(a.m, B, 0, [&](int t) { return row_at(nxt.mul, nxt.off, t); }, &a.st->err);
@@ -605,7 +645,8 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         bits &= bits - 1u;
         const int jc = wd * 32 + b;
         const float dsj = a.ds[a.hl + jc];
-        const float v = atomicExch(&gc[jc], 0.0f);   // take-and-clear the private strip entry
+        // take-and-clear the private strip entry (written with L2 atomics of this workgroup: read it there)
+        const float v = __hip_atomic_exchange(&gc[jc], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         float g = filt(v / fB);
         if (g == 0.0f) continue;
         if (add_s) g = filt(g + s_it);
@@ -625,7 +666,9 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       red[tid >> 6] = ds_acc;
       redn[tid >> 6] = n_act;
     }
-    __syncthreads();
+    __syncthreads();   // (drains this workgroup's updates of w: the barrier waits for every outstanding memory operation)
+    // next iteration's copy of the weights, requested while thread 0 exchanges the shared scalars
+    hog_wcache_issue(a.w, wl, a.wl);
     if (tid == 0) {
       float tot = 0.0f;
       unsigned int na = 0;
@@ -644,6 +687,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       cn->stop = stop != 0 || (long long)u >= a.max_updates;
       hog_sampler(a, worker, it + 2, n_k, &ctl[it & 1]);   // (this iteration's slot is free: its fields are in registers)
     }
+    hog_wcache_wait();
     __syncthreads();
     ++it;
     bd = bd_n;

@@ -2068,14 +2068,14 @@ int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_en
     DSGD_TRY(launch_stream<false>(c, ssegs));
   } else {
     const int G = c->group;
-    // beside the persistent Hogwild engine (2 waves x 232 VGPRs per SIMD, 103 KB of LDS) only ONE more wave per SIMD
-    // and 32 KB of LDS fit a CU: 256-lane blocks with a small weight tile, one per CU
+    // beside the persistent Hogwild engine (2 waves x 232 VGPRs per SIMD, 136 KB of LDS) only ONE more wave per SIMD
+    // and 16 KB of LDS fit a CU: 256-lane blocks with a small weight tile, one per CU
     const int bs = c->async_running ? 256 : 1024;
     const long long groups_per_block = bs / G;
     const long long rows = row_end - row_begin;
     dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(c->n_cu, (rows + groups_per_block - 1) / groups_per_block)));
     // small ranges do not amortise staging 160 KiB of weights per workgroup: shrink the LDS tile
-    const int hw = c->async_running ? std::min(c->hw_eval, 8192) : (rows >= 4096 ? c->hw_eval : std::min(c->hw_eval, 1024));
+    const int hw = c->async_running ? std::min(c->hw_eval, 4096) : (rows >= 4096 ? c->hw_eval : std::min(c->hw_eval, 1024));
     const size_t lds = sizeof(float) * (size_t)hw;
     CsrView m = view(c);
     switch (G) {
@@ -2168,6 +2168,9 @@ static int async_refresh(dsgd_ctx* c) {  // copy the engine's counters to the ho
   return DSGD_OK;
 }
 
+// the master's loss check must become resident beside the engine: its 16 KiB weight tile and the engine's LDS share a CU
+// (RCV1: D + 1 = 47,237)
+static_assert(sizeof(float) * ((size_t)hog_lds_words(HOG_HL, HOG_WL, 47237) + 4096 + 64) <= 160 * 1024, "Hogwild + eval LDS");
 // one launch of the persistent kernel on async_stream: workers run until the TOTAL update count reaches max_updates
 static int hog_launch(dsgd_ctx* c, long long max_updates) {
   HogArgs a;
@@ -2192,7 +2195,8 @@ static int hog_launch(dsgd_ctx* c, long long max_updates) {
   a.positional_bug = c->hog_bug;
   a.hl = std::min(c->dp, HOG_HL);
   a.dp = c->dp;
-  const size_t lds = sizeof(float) * (size_t)hog_lds_words(a.hl, c->dp);
+  a.wl = hog_wl(c->dp);
+  const size_t lds = sizeof(float) * (size_t)hog_lds_words(a.hl, a.wl, c->dp);
   hipLaunchKernelGGL(dsgd_hogwild_kernel, dim3(c->hog_n), dim3(HOG_THREADS), lds, c->async_stream, a);
   HIP_TRY(hipGetLastError());
   return DSGD_OK;
