@@ -424,7 +424,7 @@ struct HogArgs {
   unsigned long long seed;
   float lr, lambda;
   float qscale, inv_qscale;     // 2^shift / vmax2 and its inverse
-  int batch, positional_bug, hl, wl, dp;   // hl: ranks with an LDS accumulator; wl: ranks with an LDS copy of w (multiple of 256)
+  int batch, positional_bug, hl, wl, dp;   // hl: ranks with an LDS accumulator; wl: ranks with an LDS copy of w (whole 1 KiB pieces: a multiple of 256)
 };
 
 __device__ __forceinline__ unsigned long long hog_mix(unsigned long long z) {
@@ -457,7 +457,6 @@ struct HogCtl {   // per iteration parity
   int stop;
 };
 
-__host__ __device__ constexpr int hog_wl(int dp) { return (HOG_WL < dp ? HOG_WL : dp) & ~255; }   // whole 1 KiB pieces
 __host__ __device__ constexpr int hog_lds_words(int hl, int wl, int dp) {
   return wl + ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8;
 }

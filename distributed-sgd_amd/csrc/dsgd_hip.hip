@@ -250,6 +250,7 @@ struct dsgd_ctx {
   unsigned long long* d_tprof = nullptr;   // DSGD_PLAN_PROF=1: phase cycle counters of dsgd_plan_kernel (tuning runs)
   float* d_plan_gcold = nullptr;
   bool plan_kernel = true;     // DSGD_PLAN_KERNEL=0: the multi-launch small-batch path
+  int hog_hl = HOG_HL, hog_wl = HOG_WL;   // DSGD_HOG_HL / DSGD_HOG_WL (tuning runs): LDS-resident ranks of the Hogwild engine
   bool mb_kernel = true;       // DSGD_MB_KERNEL=0: round 1's fp32-atomic kernels for index lists beyond one workgroup
   long long plan_max_rows = 2048;   // steps with more rows in total use the multi-workgroup kernels
   int hog_workers = 0;      // capacity of the per-worker buffers
@@ -453,7 +454,7 @@ static int launch_grad_mb(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, 
   c->last_grad_kernel = "dsgd_mb_grad_kernel";
   const double inv = 1.0 / (double)a.qscale;
   c->fused_apply_pending = false;
-  if (allow_fused && !c->comm && c->fuse_apply) {
+  if (allow_fused && c->fuse_apply) {
     const int blocks = (c->dp + 63) / 64;
     if (blocks > c->redpart_cap) {
       (void)hipFree(c->d_redpart);
@@ -525,9 +526,24 @@ static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
   if (c->fused_apply_pending) {
     c->fused_apply_pending = false;
     const FusedArgs& f = c->fused_args;
-    hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel, dim3((dp + 63) / 64), dim3(1024), 0, c->stream, c->d_g64, (long long)dp,
+    if (!c->comm) {
+      hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel<true>, dim3((dp + FRA_COLS - 1) / FRA_COLS), dim3(1024), 0, c->stream, c->d_g64, (long long)dp,
+                         n_workers, c->d_w, c->d_ds, dp, f.hg, c->d_part, c->part_stride, f.n_wg, f.hc, f.nc, c->d_partc, c->partc_stride, f.n_wgc,
+                         f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart, (float*)nullptr);
+      HIP_TRY(hipGetLastError());
+      c->s_dirty = false;
+      return DSGD_OK;
+    }
+    // peers: exact column sums + regulariser + sum over the hosted workers in one launch, then the synchronous
+    // master's Future.sequence + Vec.mean (ref: core/Master.scala:190-194) as ONE all-reduce of D+1 floats over xGMI,
+    // ordered on the same stream as the kernels around it, then the update
+    hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel<false>, dim3((dp + FRA_COLS - 1) / FRA_COLS), dim3(1024), 0, c->stream, c->d_g64, (long long)dp,
                        n_workers, c->d_w, c->d_ds, dp, f.hg, c->d_part, c->part_stride, f.n_wg, f.hc, f.nc, c->d_partc, c->partc_stride, f.n_wgc,
-                       f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart);
+                       f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart, c->d_gsum);
+    HIP_TRY(hipGetLastError());
+    RCCL_TRY(rccl::AllReduce(c->d_gsum, c->d_gsum, (size_t)dp, rccl::kFloat32, rccl::kSum, c->comm, c->stream));
+    hipLaunchKernelGGL(dsgd_apply_cols_kernel, dim3((dp + FRA_COLS - 1) / FRA_COLS), dim3(256), 0, c->stream, c->d_w, c->d_gsum,
+                       c->d_ds, dp, k_total, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart);
     HIP_TRY(hipGetLastError());
     c->s_dirty = false;
     return DSGD_OK;
@@ -1197,9 +1213,10 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
     DSGD_TRY(prof_end(c, slot_g));
   }
   c->fused_apply_pending = false;
-  if (!c->comm && c->fuse_apply) {
-    // no peers: the exact column sums of every hosted worker go straight into regularise + sum + mean + update + next s
-    // (one launch instead of dsgd_fix_reduce_kernel + regularise + sum + apply; g itself is never materialised)
+  if (c->fuse_apply) {
+    // the exact column sums of every hosted worker go straight into regularise + sum (+ mean + update + next s when
+    // there are no peers): one launch instead of dsgd_fix_reduce_kernel + regularise + sum (+ apply); g itself is never
+    // materialised
     const int blocks = (c->dp + 63) / 64;
     if (blocks > c->redpart_cap) {
       (void)hipFree(c->d_redpart);
@@ -1378,6 +1395,12 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_COLD8")) c->cold8 = atoi(e);
   if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;
   if (const char* e = getenv("DSGD_MB_KERNEL")) c->mb_kernel = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_HOG_HL")) c->hog_hl = std::max(4, atoi(e)) & ~3;
+  if (const char* e = getenv("DSGD_HOG_WL")) c->hog_wl = std::max(0, atoi(e)) & ~255;
+  if (sizeof(float) * (size_t)(c->hog_hl + c->hog_wl + 4096) > 156 * 1024) {   // (tables, bitmap: 4 KiB)
+    c->hog_hl = HOG_HL;
+    c->hog_wl = HOG_WL;
+  }
   if (const char* e = getenv("DSGD_PLAN_MAX_ROWS")) c->plan_max_rows = std::max(1LL, atoll(e));
   if (getenv("DSGD_PLAN_PROF") && atoi(getenv("DSGD_PLAN_PROF"))) {
     HIP_TRY_B(hipMalloc(&c->d_tprof, sizeof(unsigned long long) * 16));
@@ -2193,9 +2216,9 @@ static int hog_launch(dsgd_ctx* c, long long max_updates) {
   a.inv_qscale = std::ldexp(1.0f, c->vexp - shift);
   a.batch = c->hog_batch;
   a.positional_bug = c->hog_bug;
-  a.hl = std::min(c->dp, HOG_HL);
+  a.hl = std::min(c->dp, c->hog_hl);
   a.dp = c->dp;
-  a.wl = hog_wl(c->dp);
+  a.wl = std::min(c->hog_wl, c->dp) & ~255;
   const size_t lds = sizeof(float) * (size_t)hog_lds_words(a.hl, a.wl, c->dp);
   hipLaunchKernelGGL(dsgd_hogwild_kernel, dim3(c->hog_n), dim3(HOG_THREADS), lds, c->async_stream, a);
   HIP_TRY(hipGetLastError());
@@ -2247,7 +2270,7 @@ int dsgd_async_start(dsgd_ctx* c, const int64_t* assigned_begin, const int64_t* 
     HIP_TRY(hipHostMalloc(&c->h_one, sizeof(int), hipHostMallocDefault));
     *c->h_one = 1;
   }
-  const int hl = std::min(c->dp, HOG_HL);
+  const int hl = std::min(c->dp, c->hog_hl);
   const size_t strip = (size_t)std::max(1, c->dp - hl);
   if (n_workers > c->hog_workers) {
     (void)hipFree(c->d_gcold);

@@ -649,80 +649,50 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_kernel(long long* g64_ba
   }
 }
 
-// The same reduction fused with K2 + K3 for the workers hosted by ONE context without peers (the benchmark's
-// whole-shard step, every small / mid-size batch): per column the exact sum of every worker's partials becomes g_k[j]
-// in a register, gets the support-only regulariser (ref: core/ml/SparseSVM.scala:31), the sums are folded over the
-// workers (Vec.sum), divided by their number (Vec.mean) and applied (ref: core/Master.scala:194-197) -- g is never
-// written.  The two dot products of the new weights are combined by the last block to arrive, in block order
-// (reproducible).  Every block reads the old s before it takes its ticket, so the last block's write of the new s
-// cannot be seen by any of them.
-__global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* __restrict__ g64_base, long long g_stride,
-                                                                    int n_workers, float* __restrict__ w,
-                                                                    const float* __restrict__ ds, int dp, int hg,
-                                                                    const int* __restrict__ part, int part_stride,
-                                                                    int n_wg, int hc, int nc,
-                                                                    const int* __restrict__ partc, int partc_stride,
-                                                                    int n_wgc, double inv_scale, double inv_scale_cold,
-                                                                    float lr, float lambda, DevScalars* sc,
-                                                                    float* __restrict__ redpart) {
-  __shared__ long long red[16][64];
-  __shared__ int is_last;
-  const float s = sc->s_reg;
-  const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
-  const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + cx;
-  float gsum = 0.0f;   // (wave 0) Vec.sum over the workers, folded left with the Sparse filter after every add
-  for (int k = 0; k < n_workers; ++k) {
-    long long q = 0;
-    if (j < hg) {
-      const int* p = part + (long long)k * n_wg * part_stride + j;
-      for (int b = ph; b < n_wg; b += 16) q += (long long)p[(long long)b * part_stride];
-    } else if (j >= hc && j < hc + nc) {
-      const int* p = partc + (long long)k * n_wgc * partc_stride + (j - hc);
-      for (int b = ph; b < n_wgc; b += 16) q += (long long)p[(long long)b * partc_stride];
-    }
-    if (k) __syncthreads();   // the previous worker's sums have been read
-    red[ph][cx] = q;
-    __syncthreads();
-    if (ph == 0 && j < dp) {
-      long long* g64 = g64_base + (long long)k * g_stride;
-      long long tot = g64[j];
-      if (tot != 0) g64[j] = 0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) tot += red[i][cx];
-      float gv = filt((float)((double)tot * (j >= hc ? inv_scale_cold : inv_scale)));   // one rounding of the exact sum
-      if (add && gv != 0.0f) gv = filt(gv + s);
-      gsum = filt(gsum + gv);
-    }
+constexpr int FRA_COLS = 192;
+// Tail shared by dsgd_fix_reduce_apply_kernel<true> and dsgd_apply_cols_kernel: lane tid < FRA_COLS of a block owns
+// column j = block * FRA_COLS + tid and holds the sum of the regularised gradients over the workers; mean, update, and
+// the block's share of w . ds and |w|^2 (combined by the last block to arrive, in block order: reproducible).
+__device__ __forceinline__ void fra_update_and_scalars(float gsum, float k_total, int j, int dp, float* __restrict__ w,
+                                                       const float* __restrict__ ds, float lr, float lambda,
+                                                       DevScalars* sc, float* __restrict__ redpart, float* fred,
+                                                       int* is_last) {
+  const int tid = threadIdx.x;
+  float dot = 0.0f, nsq = 0.0f;
+  if (tid < FRA_COLS && j < dp) {
+    const float upd = filt(filt(gsum / k_total) * lr);   // Vec.mean over the workers, then learningRate * grad
+    const float wn = filt(w[j] - upd);
+    w[j] = wn;
+    dot = filt(wn * ds[j]);
+    nsq = wn * wn;
   }
-  if (ph == 0) {   // one wave: the 64 columns of the block
-    float dot = 0.0f, nsq = 0.0f;
-    if (j < dp) {
-      const float upd = filt(filt(gsum / (float)n_workers) * lr);   // Vec.mean over the workers, then learningRate * grad
-      const float wn = filt(w[j] - upd);
-      w[j] = wn;
-      dot = filt(wn * ds[j]);
-      nsq = wn * wn;
-    }
+  if (tid < 256) {   // the finishing waves (FRA_COLS = 192 -> three of them carry data)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       dot += __shfl_xor(dot, off, 64);
       nsq += __shfl_xor(nsq, off, 64);
     }
-    if (cx == 0) {
-      __hip_atomic_store(&redpart[2 * blockIdx.x], dot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&redpart[2 * blockIdx.x + 1], nsq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // the two partials are write-through stores: once they are acknowledged the ticket may be taken (a full
-      // __threadfence() here writes back the L2's dirty lines -- this block's weights -- ~3.5 us per block)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned int t = atomicAdd(&sc->ticket, 1u);
-      is_last = (t == gridDim.x - 1);
+    if ((tid & 63) == 0) {
+      fred[tid >> 6] = dot;
+      fred[4 + (tid >> 6)] = nsq;
     }
   }
   __syncthreads();
-  if (is_last && ph == 0) {   // (agent-scope loads below: served past this CU's L1)
+  if (tid == 0) {
+    const float d = (fred[0] + fred[1]) + (fred[2] + fred[3]);
+    const float qq = (fred[4] + fred[5]) + (fred[6] + fred[7]);
+    __hip_atomic_store(&redpart[2 * blockIdx.x], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&redpart[2 * blockIdx.x + 1], qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the two partials are write-through stores: once they are acknowledged the ticket may be taken (a full
+    // __threadfence() here writes back the L2's dirty lines -- this block's weights -- ~3.5 us per block)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = atomicAdd(&sc->ticket, 1u);
+    *is_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (*is_last && tid < 64) {   // (agent-scope loads below: served past this CU's L1)
     float d = 0.0f, qq = 0.0f;
-    for (unsigned int b = cx; b < gridDim.x; b += 64) {   // fixed assignment and order: reproducible
+    for (unsigned int b = tid; b < gridDim.x; b += 64) {   // fixed assignment and order: reproducible
       d += __hip_atomic_load(&redpart[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       qq += __hip_atomic_load(&redpart[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -731,12 +701,121 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
       d += __shfl_xor(d, off, 64);
       qq += __shfl_xor(qq, off, 64);
     }
-    if (cx == 0) {
+    if (tid == 0) {
       sc->s_reg = lambda * 2.0f * d;
       sc->wnorm2 = qq;
       sc->ticket = 0;
     }
   }
+}
+
+
+// The same reduction fused with K2 + K3 for the workers hosted by ONE context (the benchmark's whole-shard step, every
+// small / mid-size batch): per column the exact sum of every worker's partials becomes g_k[j] in a register, gets the
+// support-only regulariser (ref: core/ml/SparseSVM.scala:31), the sums are folded over the workers (Vec.sum), divided
+// by their number (Vec.mean) and applied (ref: core/Master.scala:194-197) -- g is never written.  The two dot products
+// of the new weights are combined by the last block to arrive, in block order (reproducible).  Every block reads the
+// old s before it takes its ticket, so the last block's write of the new s cannot be seen by any of them.
+// APPLY = false (a communicator is attached): the regularised sum over the hosted workers is written to `gsum_out` for
+// the all-reduce across ranks, dsgd_apply_mb_kernel<false> finishes (two launches around the collective instead of
+// four).
+// Geometry: a block owns FRA_COLS = 192 columns (247 blocks for D + 1 = 47,237: one round over 256 CUs); a thread adds
+// FOUR adjacent columns of every 21st workgroup's partials with 16-byte loads (768-byte pieces per partial row; the
+// first form -- 64 columns per block, 4-byte loads, 256-byte pieces -- moved the 48 MB of partials of a whole-shard
+// step at 1.7 TB/s).
+constexpr int FRA_GROUPS = FRA_COLS / 4;          // 48 column groups
+constexpr int FRA_PHASES = 1024 / FRA_GROUPS;     // 21 phases (1008 of the 1024 lanes add partials)
+template <bool APPLY>
+__global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* __restrict__ g64_base, long long g_stride,
+                                                                    int n_workers, float* __restrict__ w,
+                                                                    const float* __restrict__ ds, int dp, int hg,
+                                                                    const int* __restrict__ part, int part_stride,
+                                                                    int n_wg, int hc, int nc,
+                                                                    const int* __restrict__ partc, int partc_stride,
+                                                                    int n_wgc, double inv_scale, double inv_scale_cold,
+                                                                    float lr, float lambda, DevScalars* sc,
+                                                                    float* __restrict__ redpart,
+                                                                    float* __restrict__ gsum_out) {
+  __shared__ __attribute__((aligned(16))) long long red[FRA_PHASES][FRA_COLS];   // 32 KB
+  __shared__ float fred[8];
+  __shared__ int is_last;
+  const float s = sc->s_reg;
+  const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+  const int tid = threadIdx.x;
+  const int cg = tid % FRA_GROUPS, ph = tid / FRA_GROUPS;   // (ph == FRA_PHASES: the 16 spare lanes)
+  const int j0 = blockIdx.x * FRA_COLS;
+  const int jg = j0 + 4 * cg;
+  // where the thread's four columns live: 1 = all in the hot partials, 2 = all in the cold partials (16-byte loads),
+  // 3 = a group across a boundary or a misaligned layout (element by element), 0 = nothing to add
+  const bool al = ((part_stride | partc_stride | hc) & 3) == 0;
+  int mode = 3;
+  if (ph >= FRA_PHASES || jg >= dp) mode = 0;
+  else if (al && jg + 3 < hg) mode = 1;
+  else if (al && jg >= hc && jg + 3 < hc + nc) mode = 2;
+  const int j = j0 + tid;   // the column a lane of the first three waves finishes
+  float gsum = 0.0f;        // Vec.sum over the workers, folded left with the Sparse filter after every add
+  for (int k = 0; k < n_workers; ++k) {
+    long long q[4] = {0, 0, 0, 0};
+    if (mode == 1 || mode == 2) {
+      const int n = mode == 1 ? n_wg : n_wgc;
+      const long long st = mode == 1 ? part_stride : partc_stride;
+      const int* p = (mode == 1 ? part + jg : partc + (jg - hc)) + (long long)k * n * st;
+#pragma unroll 4
+      for (int b = ph; b < n; b += FRA_PHASES) {
+        const int4 v = *reinterpret_cast<const int4*>(p + (long long)b * st);
+        q[0] += v.x;
+        q[1] += v.y;
+        q[2] += v.z;
+        q[3] += v.w;
+      }
+    } else if (mode == 3) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int je = jg + e;
+        if (je < hg) {
+          const int* p = part + (long long)k * n_wg * part_stride + je;
+          for (int b = ph; b < n_wg; b += FRA_PHASES) q[e] += (long long)p[(long long)b * part_stride];
+        } else if (je >= hc && je < hc + nc) {
+          const int* p = partc + (long long)k * n_wgc * partc_stride + (je - hc);
+          for (int b = ph; b < n_wgc; b += FRA_PHASES) q[e] += (long long)p[(long long)b * partc_stride];
+        }
+      }
+    }
+    if (k) __syncthreads();   // the previous worker's sums have been read
+    if (ph < FRA_PHASES) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[ph][4 * cg + e] = q[e];
+    }
+    __syncthreads();
+    if (tid < FRA_COLS && j < dp) {
+      long long* g64 = g64_base + (long long)k * g_stride;
+      long long tot = g64[j];
+      if (tot != 0) g64[j] = 0;
+#pragma unroll
+      for (int i = 0; i < FRA_PHASES; ++i) tot += red[i][tid];
+      float gv = filt((float)((double)tot * (j >= hc ? inv_scale_cold : inv_scale)));   // one rounding of the exact sum
+      if (add && gv != 0.0f) gv = filt(gv + s);
+      gsum = filt(gsum + gv);
+    }
+  }
+  if (!APPLY) {
+    if (tid < FRA_COLS && j < dp) gsum_out[j] = gsum;
+    return;
+  }
+  fra_update_and_scalars(gsum, (float)n_workers, j, dp, w, ds, lr, lambda, sc, redpart, fred, &is_last);
+}
+
+// The update after the all-reduce across ranks (a communicator is attached): the same columns per block, the same
+// arithmetic and the same summation order of the two dot products as the fused kernel above -- a communicator of size
+// one leaves exactly the weights and the regulariser scalar of the engine without one.
+__global__ void __launch_bounds__(256) dsgd_apply_cols_kernel(float* __restrict__ w, const float* __restrict__ gsum,
+                                                             const float* __restrict__ ds, int dp, float k_total, float lr,
+                                                             float lambda, DevScalars* sc, float* __restrict__ redpart) {
+  __shared__ float fred[8];
+  __shared__ int is_last;
+  const int j = blockIdx.x * FRA_COLS + threadIdx.x;
+  const float g = (threadIdx.x < FRA_COLS && j < dp) ? gsum[j] : 0.0f;
+  fra_update_and_scalars(g, k_total, j, dp, w, ds, lr, lambda, sc, redpart, fred, &is_last);
 }
 
 // ---- cold columns (rank >= hg): transposed lists built once at layout time ------------------------------

@@ -67,10 +67,50 @@ def test_master_sync_fit_engine_vs_oracle():
         assert abs(m.test_accs[0] - ref.test_accs[0]) < 2e-2
 
 
-def test_master_async_fit_runs_and_stops():
+def test_master_async_fit_one_worker_is_the_oracle_replay():
+    """host.MasterAsync.fit over the lock-free engine with ONE worker is deterministic: after `max_steps` updates the
+    engine's weights equal the oracle's async_step replay of the same sample lists (ref: core/Slave.scala:79-111), the
+    last leaky loss check (ref: core/MasterAsync.scala:122-125) is built from the ORACLE's loss of those weights, and
+    the returned state carries the smallest smoothed loss."""
+    from test_gpu_parity import GATE_EPS, hog_rows, tol
+
+    n_rows, n_train, n_upd, leak, seed = 6000, 4800, 60, 0.9, 5
+    data = dsgd_amd.synth.generate(n_rows, seed=44)
+    o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, 1e-5)
+    o.set_dim_sparsity(o.dim_sparsity(n_train))
+    with dsgd_amd.Engine(data.dim, 1e-5) as eng:
+        eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+        eng.build_dim_sparsity(n_train)
+        m = host.MasterAsync(eng, n_train, n_rows, node_count=1)
+        st = m.fit(np.zeros(data.dim + 1), max_epoch=1, batch_size=100, learning_rate=0.5,
+                   stopping_criterion=lambda losses: False, check_every=20, leak_loss_coef=leak, seed=seed,
+                   max_steps=n_upd, positional_bug=True)
+        w_end = eng.get_weights().astype(np.float64)
+    assert st.updates == n_upd and st.end is not None
+    w_ref = np.zeros(data.dim + 1)
+    exposed = False
+    for it in range(n_upd):
+        o.async_step(w_ref, hog_rows(seed, 0, it, 0, n_train, 100, True), 0.5)
+        exposed = exposed or o.last_stats["min_abs_margin"] < GATE_EPS
+    if not exposed:
+        assert np.abs(w_end - w_ref).max() <= 4 * tol(w_ref)
+        # the final check ran on the final weights: undo the leaky average and compare with the oracle's loss of w_ref
+        # (a single check -- the engine had finished before the first poll -- is its own previous value)
+        prev_l, prev_a = (m.test_losses[1], m.test_accs[1]) if len(m.test_losses) > 1 else (m.test_losses[0], m.test_accs[0])
+        raw_last = (m.test_losses[0] - (1 - leak) * prev_l) / leak
+        raw_acc = (m.test_accs[0] - (1 - leak) * prev_a) / leak
+        loss_ref, acc_ref, _, mam = o.loss_acc(w_ref, n_train, n_rows)
+        if mam >= GATE_EPS:
+            assert abs(raw_last - loss_ref) <= 1e-5, (raw_last, loss_ref)
+            assert abs(raw_acc - acc_ref) <= 1e-6
+    assert st.loss == min(m.test_losses)
+
+
+def test_master_async_fit_four_workers_learns_and_stops_at_the_budget():
     n_rows = 20000
     data = dsgd_amd.synth.generate(n_rows, seed=42)
     n_train = int(n_rows * 0.8)
+    o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, 1e-5)
     with dsgd_amd.Engine(data.dim, 1e-5) as eng:
         eng.load_csr(data.row_ptr, data.col, data.val, data.label)
         eng.build_dim_sparsity(n_train)
@@ -78,11 +118,17 @@ def test_master_async_fit_runs_and_stops():
         st = m.fit(np.zeros(data.dim + 1), max_epoch=1, batch_size=100, learning_rate=0.5,
                    stopping_criterion=host.EarlyStopping.no_improvement(5, 0.01), check_every=100, leak_loss_coef=0.9,
                    max_steps=1500, positional_bug=True)
-        assert st.end is not None and st.loss is not None and st.updates >= 100
+        # MasterAsync.scala:83,171: workers finish the mini-batch they are in when the budget is reached
+        assert st.end is not None and st.loss is not None and 100 <= st.updates <= 1500 + 3
         assert len(m.test_losses) >= 1 and np.isfinite(st.grad).all()
-        # the best weights are a snapshot the engine really produced
-        loss, acc, _ = eng.loss_acc(n_train, n_rows, w=st.grad)
-        assert acc > 0.5
+        # the best weights are a snapshot the engine really produced, they have learnt something (loss 1, accuracy 0 at
+        # w = 0: SparseSVM.scala:14-23 predicts 0 for every row), and the engine's evaluation of them is the oracle's
+        loss, acc, counts = eng.loss_acc(n_train, n_rows, w=st.grad)
+        loss_ref, acc_ref, counts_ref, mam = o.loss_acc(st.grad.astype(np.float64), n_train, n_rows)
+        assert acc > 0.6 and loss < 0.9
+        assert abs(loss - loss_ref) <= 1e-6 + 2.0 * (mam < 1e-5)
+        if mam >= 1e-5:
+            assert list(counts) == list(counts_ref)
 
 
 def test_wire_worker_serves_the_engine():
@@ -120,6 +166,16 @@ def test_wire_worker_serves_the_engine():
             delta[[3, 77]] = [0.25, -0.5]
             stub.UpdateGrad(M["GradUpdate"](gradUpdate=wire.to_sparse(delta, data.dim)))
             np.testing.assert_array_equal(eng.get_weights(), w - delta)
+            # the reference's instrument names, one increment per SAMPLE (core/Slave.scala:131-150) resp. per message
+            # (:181), counted in front of the HIP engine
+            assert worker.metrics.snapshot()["counters"] == {"slave.sync.backward": 200, "slave.sync.forward": 200,
+                                                             "slave.async.grad.update": 1}
+            # Main.scala:114 `idx:value` dump of the engine's weights: parses back to exactly the stored entries
+            line = host.format_final_weights(eng.get_weights())
+            back = {int(k): np.float32(v) for k, v in (kv.split(":") for kv in line.split())}
+            w_now = eng.get_weights()
+            assert sorted(back) == np.flatnonzero(w_now).tolist()
+            assert all(back[k] == w_now[k] for k in back)
         finally:
             worker.stop()
 

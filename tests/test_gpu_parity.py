@@ -397,8 +397,11 @@ def test_streaming_layouts_match_oracle(monkeypatch, mode, dim, hsplit):
             assert sum(counts) == hi - lo
             if mam >= GATE_EPS:
                 assert counts == counts_ref
-        # bit-reproducible: the same step from the same weights twice
+        # bit-reproducible: the same step from the same state twice.  The state is (w, s): set_weights re-derives the
+        # regulariser scalar s = 2 lambda (w . ds) with dsgd_wstats_kernel, whose fp32 summation order differs from
+        # the one the fused step leaves behind (last-bit differences in s) -- so both runs start from set_weights.
         w0 = eng.get_weights()
+        eng.set_weights(w0)
         eng.sync_step_ranges([(0, n_train)], lr)
         w1 = eng.get_weights()
         eng.set_weights(w0)
