@@ -1107,7 +1107,7 @@ __device__ __forceinline__ void w_load_dc(const WCtx& x, WRegs& r) {
   const int re_n = v - pc;
   r.rf = re_n + (int)(bn & 1u);    // a start at slot 0 makes the lane's first slot the NEW row
   const bool ok = bn != 0u && re_n >= 1 && re_n <= r.nrows;
-  r.dc = (x.dcold + r.r0)[ok ? (unsigned int)(re_n - 1) : 0u];
+  r.dc = (x.dcold + __builtin_amdgcn_readfirstlane(r.r0))[ok ? (unsigned int)(re_n - 1) : 0u];
 }
 
 
@@ -1194,7 +1194,13 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
     const unsigned int cw[4] = {(unsigned int)cur.c0.x, (unsigned int)cur.c0.y, (unsigned int)cur.c0.z, (unsigned int)cur.c0.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      cc[2 * k] = (int)((cw[k] & 0xffffu) << 2);
+      // low half: one SDWA shift of the selected 16-bit word (the compiler finds that form for the high half only and
+      // spends a shift and a mask on this one)
+      unsigned int lo4;
+      asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+          : "=v"(lo4)
+          : "v"(2u), "v"(cw[k]));
+      cc[2 * k] = (int)lo4;
       cc[2 * k + 1] = (int)((cw[k] >> 14) & 0x3fffcu);
     }
   } else {
@@ -1209,18 +1215,22 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
   float a[8], pk[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    if (SPLIT) a[k] = *(lds_cfloat*)((__attribute__((address_space(3))) const char*)wl3 + cc[k]);   // byte offset, wl at LDS 0
+    // byte offset = LDS address: the weights sit at LDS address 0 (checked when the kernel starts) -- adding the
+    // link-time base cost a v_add_u32 with literal 0 per slot
+    if (SPLIT) a[k] = *(lds_cfloat*)(unsigned int)cc[k];
     else a[k] = (dbg & 16) ? 0.5f : wl3[min(cc[k], x.hw)];
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) pk[k] = filt(vv[k] * (SPLIT ? a[k] : a[k] + cur.gw[k]));
 
-  // rows of the worker's batch, as local rows of this tile (wave-uniform, scalar registers)
-  const long long lo64 = x.row_begin - cur.r0 + 1, hi64 = x.row_end - cur.r0 + 1;
+  // rows of the worker's batch, as local rows of this tile (wave-uniform: readfirstlane keeps the 64-bit clamps and
+  // the row bases on the scalar unit -- the compiler had them in vector registers, ~20 VALU instructions per tile)
+  const int r0s = __builtin_amdgcn_readfirstlane(cur.r0);
+  const long long lo64 = x.row_begin - r0s + 1, hi64 = x.row_end - r0s + 1;
   const int r_lo = (int)(lo64 < 1 ? 1 : (lo64 > 1024 ? 1024 : lo64));
   const int r_hi = (int)(hi64 > nrows + 1 ? nrows + 1 : (hi64 < 0 ? 0 : hi64));   // exclusive
   const float ps = x.fix_scale, ns = -x.fix_scale;
-  signed char* const coef8_tile = x.coef8 + ((long long)cur.r0 - 1);   // [local row] -> global row's gate
+  signed char* const coef8_tile = x.coef8 + ((long long)r0s - 1);   // [local row] -> global row's gate
 
   const int nb = __popc(bits);
   int q[8];
@@ -1307,7 +1317,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
           if (r >= 1 && r <= nrows) {
             const bool in_range = r >= r_lo && r < r_hi;
             const bool ypos = (ys >> k) & 1u;
-            const float dfull = SPLIT ? run + (x.dcold + cur.r0)[(unsigned int)(r - 1)] : run;
+            const float dfull = SPLIT ? run + (x.dcold + r0s)[(unsigned int)(r - 1)] : run;
             const float yd = ypos ? dfull : -dfull;
             if (SCATTER) {
               const bool active = in_range && !(yd < 0.0f);
@@ -1457,6 +1467,11 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
     if (is_aligned16(x.gl)) wg_zero(x.gl, hg + 64, tid, 1024);
     else
       for (int j = tid; j < hg + 64; j += 1024) x.gl[j] = 0;
+  }
+  if (SPLIT && (unsigned int)(unsigned long long)(__attribute__((address_space(3))) float*)lds != 0u) {
+    // (w_tile turns column ranks into LDS addresses without adding a base: all LDS of this kernel is dynamic)
+    if (tid == 0) atomicOr(&sc->err, 2);
+    return;
   }
   wg_copy_in(wl, w, hw, tid, 1024, is_aligned16(wl) && is_aligned16(w));
   if (tid == 0) wl[hw] = 0.0f;
