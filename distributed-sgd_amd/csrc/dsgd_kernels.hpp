@@ -1220,8 +1220,19 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
     if (SPLIT) a[k] = *(lds_cfloat*)(unsigned int)cc[k];
     else a[k] = (dbg & 16) ? 0.5f : wl3[min(cc[k], x.hw)];
   }
+  if (SPLIT) {
+    // products two at a time (v_pk_mul_f32), then the reference's 1e-20 filter
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int k = 0; k < 8; ++k) pk[k] = filt(vv[k] * (SPLIT ? a[k] : a[k] + cur.gw[k]));
+    for (int k = 0; k < 8; k += 2) {
+      const f32x2 pr = f32x2{vv[k], vv[k + 1]} * f32x2{a[k], a[k + 1]};
+      pk[k] = filt(pr.x);
+      pk[k + 1] = filt(pr.y);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pk[k] = filt(vv[k] * (a[k] + cur.gw[k]));
+  }
 
   // rows of the worker's batch, as local rows of this tile (wave-uniform: readfirstlane keeps the 64-bit clamps and
   // the row bases on the scalar unit -- the compiler had them in vector registers, ~20 VALU instructions per tile)
@@ -1284,13 +1295,16 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
       const float cA = x.coefw[rf];
       const float cB = x.coefw[rf + 1 <= WS_MAXROWS + 1 ? rf + 1 : rf];
       const float cT = (bits != 0u && !(bits & 1u)) ? cB : cA;
+      // y * x on the fixed-point grid: |v * coef| <= 2^21, so v * coef + 1.5 * 2^23 rounds (once, to nearest even)
+      // to an fp32 whose low mantissa bits are the integer (two slots per v_pk_fma_f32)
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float coef = in_t[k] ? cT : cA;
-        // y * x on the fixed-point grid: |v * coef| <= 2^21, so v * coef + 1.5 * 2^23 rounds (once, to nearest even)
-        // to an fp32 whose low mantissa bits are the integer
-        const int qi = __float_as_int(fmaf(vv[k], coef, 12582912.0f)) - 0x4B400000;
-        q[k] = (SPLIT || cc[k] < x.hg) ? qi : 0;
+      for (int k = 0; k < 8; k += 2) {
+        const f32x2 coef = {in_t[k] ? cT : cA, in_t[k + 1] ? cT : cA};
+        const f32x2 r = __builtin_elementwise_fma(f32x2{vv[k], vv[k + 1]}, coef, f32x2{12582912.0f, 12582912.0f});
+        const int q0 = __float_as_int(r.x) - 0x4B400000, q1 = __float_as_int(r.y) - 0x4B400000;
+        q[k] = (SPLIT || cc[k] < x.hg) ? q0 : 0;
+        q[k + 1] = (SPLIT || cc[k + 1] < x.hg) ? q1 : 0;
       }
       w_scatter<ABL, SPLIT>(x, cc, q, lane, dbg);
       __builtin_amdgcn_wave_barrier();
