@@ -215,11 +215,24 @@ struct dsgd_ctx {
   int max_shift = FIX_SHIFT;     // DSGD_FIX_SHIFT: cap of the per-launch fixed-point shift of the split layout
   int cold8 = 1;                 // DSGD_COLD8 bit 0: dsgd_cdot8_kernel, bit 1: dsgd_cgrad8_kernel (measured: cdot8 85 vs
                                  // 93 us, cgrad8 75 vs 73 us per 0.30 GB -- both are start-up bound, profiles/README.md)
-  bool fuse_apply = true;        // DSGD_FUSE_APPLY=0: separate dsgd_fix_reduce_kernel + dsgd_apply_mb_kernel launches
+  bool fuse_apply = true;        // DSGD_FUSE_APPLY=0: separate dsgd_fix_reduce_kernel + dsgd_apply_cols_kernel launches
   bool fused_apply_pending = false;
   FusedArgs fused_args{};
   float* d_redpart = nullptr;    // per-block partial sums of w.ds and |w|^2 of the fused reduce + apply kernel
   int redpart_cap = 0;
+  // Pinned staging of the per-request entry points (Slave.gradient / Slave.forward hand over w and the sample indices
+  // and get a dense vector back): a copy between pageable memory and the device is staged by the runtime, blocks the
+  // calling thread and cannot overlap the kernels around it (151 us for a batch-size-100 dsgd_gradient, of which the
+  // kernels are ~35: profiles/r02_boundary_latency.json).
+  struct Pinned {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;   // the last copy FROM this buffer to the device
+    bool armed = false;
+  };
+  Pinned pin_w, pin_idx, pin_segs, pin_out;
+  float* d_pred = nullptr;     // dsgd_forward's predictions (grown on demand)
+  long long pred_cap = 0;
   bool fix_bound = true;         // DSGD_FIX_BOUND=0: keep the data-independent bound (rows per workgroup x largest value)
   int g_cap = 0;
   float* d_gsum = nullptr;  // dp (all-reduce buffer / sum over hosted workers)
@@ -293,6 +306,35 @@ static CsrView view(dsgd_ctx* c) {
   return v;
 }
 
+// host -> device through a pinned buffer of the context: wait until the previous copy out of it has executed, then the
+// caller fills it and enqueues the copy (pin_sent); device -> host: enqueue into pin_out, synchronise, copy out.
+static int pin_acquire(dsgd_ctx::Pinned& b, size_t bytes) {
+  if (b.armed) {
+    HIP_TRY(hipEventSynchronize(b.ev));
+    b.armed = false;
+  }
+  if (bytes > b.cap) {
+    if (b.p) HIP_TRY(hipHostFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t cap = std::max<size_t>(bytes, 4096);
+    HIP_TRY(hipHostMalloc(&b.p, cap, hipHostMallocDefault));
+    b.cap = cap;
+  }
+  if (!b.ev) HIP_TRY(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+  return DSGD_OK;
+}
+static int pin_sent(dsgd_ctx* c, dsgd_ctx::Pinned& b) {
+  HIP_TRY(hipEventRecord(b.ev, c->stream));
+  b.armed = true;
+  return DSGD_OK;
+}
+static void pin_free(dsgd_ctx::Pinned& b) {
+  if (b.ev) (void)hipEventDestroy(b.ev);
+  if (b.p) (void)hipHostFree(b.p);
+  b = dsgd_ctx::Pinned();
+}
+
 static int ensure_g(dsgd_ctx* c, int n_workers) {
   if (n_workers <= c->g_cap) return DSGD_OK;
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -333,17 +375,35 @@ static int upload_segs(dsgd_ctx* c, const std::vector<WorkSeg>& segs) {
   const int n = (int)segs.size();
   DSGD_TRY(ensure_segs(c, n));
   if ((int)c->segs_last.size() == n && memcmp(c->segs_last.data(), segs.data(), sizeof(WorkSeg) * n) == 0) return DSGD_OK;
-  HIP_TRY(hipStreamSynchronize(c->stream));  // earlier launches may still read d_segs
-  HIP_TRY(hipMemcpy(c->d_segs, segs.data(), sizeof(WorkSeg) * n, hipMemcpyHostToDevice));
+  // (ordered on the stream behind the launches that still read d_segs)
+  DSGD_TRY(pin_acquire(c->pin_segs, sizeof(WorkSeg) * (size_t)n));
+  memcpy(c->pin_segs.p, segs.data(), sizeof(WorkSeg) * (size_t)n);
+  HIP_TRY(hipMemcpyAsync(c->d_segs, c->pin_segs.p, sizeof(WorkSeg) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  DSGD_TRY(pin_sent(c, c->pin_segs));
   c->segs_last = segs;
+  return DSGD_OK;
+}
+
+// per-block partial sums of w.ds and |w|^2 (fra_scalars): one pair per FRA_COLS columns
+static int ensure_redpart(dsgd_ctx* c) {
+  const int blocks = (c->dp + FRA_COLS - 1) / FRA_COLS;
+  if (blocks <= c->redpart_cap) return DSGD_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->d_redpart) HIP_TRY(hipFree(c->d_redpart));
+  c->d_redpart = nullptr;
+  HIP_TRY(hipMalloc(&c->d_redpart, sizeof(float) * 2 * (size_t)blocks));
+  c->redpart_cap = blocks;
   return DSGD_OK;
 }
 
 static int ensure_s(dsgd_ctx* c) {  // s = 2*lambda*(w.ds) must match the resident w
   if (!c->s_dirty) return DSGD_OK;
   c->nsq_dirty = false;
-  hipLaunchKernelGGL(dsgd_wstats_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_ds, c->dp,
-                     (float)c->cfg.lambda, c->d_sc);
+  const int blocks = (c->dp + FRA_COLS - 1) / FRA_COLS;
+  DSGD_TRY(ensure_redpart(c));
+  // (the summation order of the fused step: equal weights give bit-equal s whichever kernel left it)
+  hipLaunchKernelGGL(dsgd_wstats_cols_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_w, c->d_ds, c->dp,
+                     (float)c->cfg.lambda, c->d_sc, c->d_redpart);
   HIP_TRY(hipGetLastError());
   c->s_dirty = false;
   return DSGD_OK;
@@ -455,13 +515,7 @@ static int launch_grad_mb(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, 
   const double inv = 1.0 / (double)a.qscale;
   c->fused_apply_pending = false;
   if (allow_fused && c->fuse_apply) {
-    const int blocks = (c->dp + 63) / 64;
-    if (blocks > c->redpart_cap) {
-      (void)hipFree(c->d_redpart);
-      c->d_redpart = nullptr;
-      HIP_TRY(hipMalloc(&c->d_redpart, sizeof(float) * 2 * (size_t)blocks));
-      c->redpart_cap = blocks;
-    }
+    DSGD_TRY(ensure_redpart(c));
     c->fused_args = {hl, (int)wgs, c->dp, 0, 0, inv, inv};
     c->fused_apply_pending = true;   // launched by launch_finish_sync, which knows lr
     return DSGD_OK;
@@ -521,7 +575,7 @@ static int launch_grad(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int
 // regularise each hosted worker's sum, aggregate (locally and across ranks), update w
 static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
   const int dp = c->dp;
-  const int blocks = (dp + 1023) / 1024;
+  const int blocks = (dp + 1023) / 1024, cblocks = (dp + FRA_COLS - 1) / FRA_COLS;
   const float k_total = (float)n_workers * (float)c->world;
   if (c->fused_apply_pending) {
     c->fused_apply_pending = false;
@@ -542,16 +596,18 @@ static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
                        f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart, c->d_gsum);
     HIP_TRY(hipGetLastError());
     RCCL_TRY(rccl::AllReduce(c->d_gsum, c->d_gsum, (size_t)dp, rccl::kFloat32, rccl::kSum, c->comm, c->stream));
-    hipLaunchKernelGGL(dsgd_apply_cols_kernel, dim3((dp + FRA_COLS - 1) / FRA_COLS), dim3(256), 0, c->stream, c->d_w, c->d_gsum,
-                       c->d_ds, dp, k_total, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart);
+    hipLaunchKernelGGL(dsgd_apply_cols_kernel<false>, dim3(cblocks), dim3(256), 0, c->stream, c->d_w, c->d_gsum, c->d_g,
+                       (long long)dp, 0 /* the per-worker sums were never materialised */, c->d_ds, dp, k_total, lr,
+                       (float)c->cfg.lambda, c->d_sc, c->d_redpart);
     HIP_TRY(hipGetLastError());
     c->s_dirty = false;
     return DSGD_OK;
   }
   if (n_workers == 1 && !c->comm) {
     // one hosted worker, no peers: regularise + "mean" over one worker + update in a single pass
-    hipLaunchKernelGGL(dsgd_apply_mb_kernel<true>, dim3(std::min(64, blocks)), dim3(1024), 0, c->stream, c->d_w, c->d_g,
-                       c->d_g, (long long)dp, 1, dp, c->d_ds, 1.0f, lr, (float)c->cfg.lambda, c->d_sc);
+    DSGD_TRY(ensure_redpart(c));
+    hipLaunchKernelGGL(dsgd_apply_cols_kernel<true>, dim3(cblocks), dim3(256), 0, c->stream, c->d_w, c->d_g, c->d_g,
+                       (long long)dp, 1, c->d_ds, dp, 1.0f, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart);
     HIP_TRY(hipGetLastError());
     c->s_dirty = false;
     return DSGD_OK;
@@ -567,8 +623,9 @@ static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
     // all-reduce of D+1 floats over xGMI, ordered on the same stream as the kernels around it
     RCCL_TRY(rccl::AllReduce(c->d_gsum, c->d_gsum, (size_t)dp, rccl::kFloat32, rccl::kSum, c->comm, c->stream));
   }
-  hipLaunchKernelGGL(dsgd_apply_mb_kernel<false>, dim3(std::min(64, blocks)), dim3(1024), 0, c->stream, c->d_w, c->d_gsum,
-                     c->d_g, (long long)dp, n_workers, dp, c->d_ds, k_total, lr, (float)c->cfg.lambda, c->d_sc);
+  DSGD_TRY(ensure_redpart(c));
+  hipLaunchKernelGGL(dsgd_apply_cols_kernel<false>, dim3(cblocks), dim3(256), 0, c->stream, c->d_w, c->d_gsum, c->d_g,
+                     (long long)dp, n_workers, c->d_ds, dp, k_total, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart);
   HIP_TRY(hipGetLastError());
   c->s_dirty = false;
   return DSGD_OK;
@@ -1217,13 +1274,7 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
     // the exact column sums of every hosted worker go straight into regularise + sum (+ mean + update + next s when
     // there are no peers): one launch instead of dsgd_fix_reduce_kernel + regularise + sum (+ apply); g itself is never
     // materialised
-    const int blocks = (c->dp + 63) / 64;
-    if (blocks > c->redpart_cap) {
-      (void)hipFree(c->d_redpart);
-      c->d_redpart = nullptr;
-      HIP_TRY(hipMalloc(&c->d_redpart, sizeof(float) * 2 * (size_t)blocks));
-      c->redpart_cap = blocks;
-    }
+    DSGD_TRY(ensure_redpart(c));
     c->fused_args = {hg, (int)grid.x, H, cold ? nc_lds : 0, (int)gridc.x, 1.0 / (double)main_scale, 1.0 / (double)c->fix_scale};
     c->fused_apply_pending = true;   // launched by launch_finish_sync, which knows lr
     return DSGD_OK;
@@ -1507,6 +1558,11 @@ int dsgd_destroy(dsgd_ctx* c) {
   (void)hipFree(c->d_dcold);
   (void)hipFree(c->d_bound);
   (void)hipFree(c->d_redpart);
+  (void)hipFree(c->d_pred);
+  pin_free(c->pin_w);
+  pin_free(c->pin_idx);
+  pin_free(c->pin_segs);
+  pin_free(c->pin_out);
   if (c->async_stream) (void)hipStreamDestroy(c->async_stream);
   if (c->query_stream) (void)hipStreamDestroy(c->query_stream);
   (void)hipFree(c->d_hog);
@@ -1716,9 +1772,12 @@ int dsgd_build_dim_sparsity(dsgd_ctx* c, int64_t n_train, float* ds_out) {
 }
 
 static int set_weights_locked(dsgd_ctx* c, const float* w) {
-  HIP_TRY(hipMemcpyAsync(c->d_io, w, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
+  const size_t bytes = sizeof(float) * (size_t)c->dp;
+  DSGD_TRY(pin_acquire(c->pin_w, bytes));
+  memcpy(c->pin_w.p, w, bytes);   // the caller may reuse w as soon as this returns
+  HIP_TRY(hipMemcpyAsync(c->d_io, c->pin_w.p, bytes, hipMemcpyHostToDevice, c->stream));
+  DSGD_TRY(pin_sent(c, c->pin_w));
   DSGD_TRY(launch_permute_in(c, c->d_io, c->d_w));
-  HIP_TRY(hipStreamSynchronize(c->stream));  // w is a pageable host buffer the caller may reuse
   c->s_dirty = true;
   return DSGD_OK;
 }
@@ -1737,9 +1796,12 @@ int dsgd_get_weights(dsgd_ctx* c, float* w_out) {
   if (!w_out) return fail(DSGD_EINVAL, "null w_out");
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
+  const size_t bytes = sizeof(float) * (size_t)c->dp;
+  DSGD_TRY(pin_acquire(c->pin_out, bytes));
   DSGD_TRY(launch_permute_out(c, c->d_w, c->d_io));
-  HIP_TRY(hipMemcpyAsync(w_out, c->d_io, sizeof(float) * c->dp, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->pin_out.p, c->d_io, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(w_out, c->pin_out.p, bytes);
   return DSGD_OK;
 }
 
@@ -1757,14 +1819,16 @@ static int stage_lists(dsgd_ctx* c, const int32_t* const* idx_per_worker, const 
   DSGD_TRY(ensure_idx(c, tot));
   std::vector<WorkSeg> segs(n_workers);
   long long off = 0;
-  // the previous step's kernels may still be reading d_idx
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  // one copy for all lists, on the stream (behind the previous step's kernels, which may still be reading d_idx)
+  DSGD_TRY(pin_acquire(c->pin_idx, sizeof(int) * (size_t)tot));
   for (int k = 0; k < n_workers; ++k) {
-    HIP_TRY(hipMemcpy(c->d_idx + off, idx_per_worker[k], sizeof(int) * (size_t)n_per_worker[k], hipMemcpyHostToDevice));
+    memcpy(static_cast<int*>(c->pin_idx.p) + off, idx_per_worker[k], sizeof(int) * (size_t)n_per_worker[k]);
     segs[k].begin = off;
     segs[k].end = off + n_per_worker[k];
     off += n_per_worker[k];
   }
+  HIP_TRY(hipMemcpyAsync(c->d_idx, c->pin_idx.p, sizeof(int) * (size_t)tot, hipMemcpyHostToDevice, c->stream));
+  DSGD_TRY(pin_sent(c, c->pin_idx));
   DSGD_TRY(upload_segs(c, segs));
   *max_items = mx;
   *total = tot;
@@ -1791,10 +1855,13 @@ int dsgd_gradient(dsgd_ctx* c, const float* w, const int32_t* idx, int64_t n, fl
   hipLaunchKernelGGL(dsgd_regularize_kernel, dim3((c->dp + 1023) / 1024, 1), dim3(1024), 0, c->stream, c->d_g,
                      (long long)c->dp, c->dp, c->d_sc);
   HIP_TRY(hipGetLastError());
+  const size_t bytes = sizeof(float) * (size_t)c->dp;
+  DSGD_TRY(pin_acquire(c->pin_out, bytes));
   DSGD_TRY(launch_permute_out(c, c->d_g, c->d_io));
-  HIP_TRY(hipMemcpyAsync(g_out, c->d_io, sizeof(float) * c->dp, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_g, 0, sizeof(float) * c->dp, c->stream));
-  DSGD_TRY(read_scalars(c));
+  HIP_TRY(hipMemcpyAsync(c->pin_out.p, c->d_io, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_g, 0, bytes, c->stream));
+  DSGD_TRY(read_scalars(c));   // the one synchronisation of the call
+  memcpy(g_out, c->pin_out.p, bytes);
   DSGD_TRY(prof_collect(c));
   DSGD_TRY(check_err_flag(c));
   if (stats) {
@@ -1813,8 +1880,10 @@ int dsgd_apply(dsgd_ctx* c, const float* g_mean, float lr) {
   DSGD_TRY(require_sync_mode(c));
   HIP_TRY(hipMemcpyAsync(c->d_io, g_mean, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
   DSGD_TRY(launch_permute_in(c, c->d_io, c->d_gsum));
-  hipLaunchKernelGGL(dsgd_apply_kernel<false>, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_gsum, c->d_gsum,
-                     (long long)c->dp, 1, c->dp, c->d_ds, 1.0f, lr, (float)c->cfg.lambda, c->d_sc);
+  DSGD_TRY(ensure_redpart(c));
+  hipLaunchKernelGGL(dsgd_apply_cols_kernel<false>, dim3((c->dp + FRA_COLS - 1) / FRA_COLS), dim3(256), 0, c->stream, c->d_w,
+                     c->d_gsum, c->d_gsum, (long long)c->dp, 1, c->d_ds, c->dp, 1.0f, lr, (float)c->cfg.lambda, c->d_sc,
+                     c->d_redpart);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->s_dirty = false;
@@ -2044,9 +2113,21 @@ int dsgd_forward(dsgd_ctx* c, const float* w, const int32_t* idx, int64_t n, flo
   if (n == 0) return DSGD_OK;  // samplesIdx.map over an empty Seq is an empty reply (ref: core/Slave.scala:133)
   DSGD_TRY(ensure_idx(c, n));
   DSGD_TRY(reset_counters(c));
-  float* d_pred = nullptr;
-  HIP_TRY(hipMalloc(&d_pred, sizeof(float) * (size_t)n));
-  HIP_TRY(hipMemcpyAsync(c->d_idx, idx, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  if (n > c->pred_cap) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_pred) HIP_TRY(hipFree(c->d_pred));
+    c->d_pred = nullptr;
+    c->pred_cap = 0;
+    const long long cap = std::max<long long>(n, 4096);
+    HIP_TRY(hipMalloc(&c->d_pred, sizeof(float) * (size_t)cap));
+    c->pred_cap = cap;
+  }
+  float* d_pred = c->d_pred;
+  DSGD_TRY(pin_acquire(c->pin_idx, sizeof(int) * (size_t)n));
+  memcpy(c->pin_idx.p, idx, sizeof(int) * (size_t)n);
+  HIP_TRY(hipMemcpyAsync(c->d_idx, c->pin_idx.p, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  DSGD_TRY(pin_sent(c, c->pin_idx));
+  DSGD_TRY(pin_acquire(c->pin_out, sizeof(float) * (size_t)n));
   const int G = c->group;
   dim3 grid(grid_for(c, n, G));
   CsrView m = view(c);
@@ -2056,12 +2137,10 @@ int dsgd_forward(dsgd_ctx* c, const float* w, const int32_t* idx, int64_t n, flo
     case 16: hipLaunchKernelGGL(dsgd_forward_kernel<16>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_idx, (long long)n, d_pred, c->d_sc); break;
     default: hipLaunchKernelGGL(dsgd_forward_kernel<8>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_idx, (long long)n, d_pred, c->d_sc); break;
   }
-  hipError_t le = hipGetLastError();
-  if (le == hipSuccess) le = hipMemcpyAsync(pred_out, d_pred, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
-  int rc = read_scalars(c);
-  (void)hipFree(d_pred);
-  if (le != hipSuccess) return fail(DSGD_EHIP, "forward: %s", hipGetErrorString(le));
-  DSGD_TRY(rc);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(c->pin_out.p, d_pred, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  DSGD_TRY(read_scalars(c));
+  memcpy(pred_out, c->pin_out.p, sizeof(float) * (size_t)n);
   return check_err_flag(c);
 }
 

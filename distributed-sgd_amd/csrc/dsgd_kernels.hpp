@@ -313,114 +313,9 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red /* 16 floats
 
 // ---- K3: mean over workers + update + next regulariser scalar ---------------------------------------------
 // w <- w - lr * (g_sum / K); g <- 0; s <- 2*lambda*(w.ds); |w|^2
-// ref: core/Master.scala:194-197 (Vec.mean then batchWeights - learningRate * grad)
-// REG: the (single hosted worker, no communicator) case folds K2 into the same pass.
-// Single workgroup: D+1 = 47,237 floats is one pass of 1024 lanes x 47 elements and the two dot
-// products need no inter-workgroup reduction.
-template <bool REG>
-__global__ void __launch_bounds__(1024) dsgd_apply_kernel(float* w, const float* gsum, float* zero_base,
-                                                         long long zero_stride, int n_zero, int dp,
-                                                         const float* __restrict__ ds, float n_workers_total, float lr,
-                                                         float lambda, DevScalars* sc) {
-  __shared__ float red[16];
-  const float s = sc->s_reg;
-  const bool add = REG && (s != 0.0f) && (fabsf(s) > DSGD_EPS);
-  float dot = 0.0f, nsq = 0.0f;
-  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
-    float gv = gsum[j];
-    if (REG) {
-      gv = filt(gv);
-      if (add && gv != 0.0f) gv = filt(gv + s);
-    }
-    const float mean = filt(gv / n_workers_total);  // Vec.mean (ref: math/Vec.scala:139)
-    const float upd = filt(mean * lr);              // learningRate * grad
-    const float wn = filt(w[j] - upd);
-    w[j] = wn;
-    dot += filt(wn * ds[j]);
-    nsq += wn * wn;
-  }
-  __syncthreads();  // all reads of gsum done before it is zeroed (gsum may alias zero_base)
-  for (int k = 0; k < n_zero; ++k)
-    for (int j = threadIdx.x; j < dp; j += blockDim.x) zero_base[(long long)k * zero_stride + j] = 0.0f;
-  const float dsum = block_sum_1024(dot, red);
-  const float nsum = block_sum_1024(nsq, red);
-  if (threadIdx.x == 0) {
-    sc->s_reg = lambda * 2.0f * dsum;
-    sc->wnorm2 = nsum;
-  }
-}
+// ref: core/Master.scala:194-197 (Vec.mean then batchWeights - learningRate * grad).
+// dsgd_apply_cols_kernel (below, next to the fused reduction whose tail it shares).
 
-// Multi-workgroup form of K3 (the single-workgroup kernel above takes ~23 us for D+1 = 47,237 on MI355X,
-// half of a batch-size-100 step): up to 64 workgroups own contiguous slices; the two dot products are
-// combined by the last workgroup to arrive, in slice order, so the scalars stay reproducible.
-template <bool REG>
-__global__ void __launch_bounds__(1024) dsgd_apply_mb_kernel(float* w, const float* gsum, float* zero_base,
-                                                            long long zero_stride, int n_zero, int dp,
-                                                            const float* __restrict__ ds, float n_workers_total, float lr,
-                                                            float lambda, DevScalars* sc) {
-  __shared__ float red[16];
-  __shared__ int is_last;
-  const float s = sc->s_reg;
-  const bool add = REG && (s != 0.0f) && (fabsf(s) > DSGD_EPS);
-  const int per = (dp + gridDim.x - 1) / gridDim.x;
-  const int lo = blockIdx.x * per, hi = min(dp, lo + per);
-  float dot = 0.0f, nsq = 0.0f;
-  for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) {
-    float gv = gsum[j];
-    if (REG) {
-      gv = filt(gv);
-      if (add && gv != 0.0f) gv = filt(gv + s);
-    }
-    const float mean = filt(gv / n_workers_total);
-    const float upd = filt(mean * lr);
-    const float wn = filt(w[j] - upd);
-    w[j] = wn;
-    dot += filt(wn * ds[j]);
-    nsq += wn * wn;
-  }
-  __syncthreads();  // all reads of gsum done before it is zeroed (gsum may alias zero_base)
-  for (int k = 0; k < n_zero; ++k)
-    for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) zero_base[(long long)k * zero_stride + j] = 0.0f;
-  const float dsum = block_sum_1024(dot, red);
-  const float nsum = block_sum_1024(nsq, red);
-  if (threadIdx.x == 0) {
-    sc->part_dot[blockIdx.x] = dsum;
-    sc->part_nsq[blockIdx.x] = nsum;
-    __threadfence();                                   // publish the partials before taking a ticket
-    const unsigned int t = atomicAdd(&sc->ticket, 1u);
-    is_last = (t == gridDim.x - 1);
-  }
-  __syncthreads();
-  if (is_last && threadIdx.x == 0) {
-    __threadfence();                                   // acquire: the other workgroups' partials
-    float d = 0.0f, q = 0.0f;
-    for (unsigned int b = 0; b < gridDim.x; ++b) {
-      d += __hip_atomic_load(&sc->part_dot[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      q += __hip_atomic_load(&sc->part_nsq[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    sc->s_reg = lambda * 2.0f * d;
-    sc->wnorm2 = q;
-    sc->ticket = 0;
-  }
-}
-
-// s = 2*lambda*(w.ds) and |w|^2 for weights that were set from outside
-__global__ void __launch_bounds__(1024) dsgd_wstats_kernel(const float* __restrict__ w, const float* __restrict__ ds,
-                                                          int dp, float lambda, DevScalars* sc) {
-  __shared__ float red[16];
-  float dot = 0.0f, nsq = 0.0f;
-  for (int j = threadIdx.x; j < dp; j += blockDim.x) {
-    const float wn = w[j];
-    dot += filt(wn * ds[j]);
-    nsq += wn * wn;
-  }
-  const float dsum = block_sum_1024(dot, red);
-  const float nsum = block_sum_1024(nsq, red);
-  if (threadIdx.x == 0) {
-    sc->s_reg = lambda * 2.0f * dsum;
-    sc->wnorm2 = nsum;
-  }
-}
 
 // ---- async iteration (host-driven form of Slave.asyncTask) -------------------------------------------------
 // grad = g_sum / n; delta = lr * regularize(grad, w); w -= delta  (ref: core/Slave.scala:93-101)
@@ -650,6 +545,8 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_kernel(long long* g64_ba
 }
 
 constexpr int FRA_COLS = 192;
+__device__ __forceinline__ void fra_scalars(float dot, float nsq, float lambda, DevScalars* sc,
+                                            float* __restrict__ redpart, float* fred, int* is_last);
 // Tail shared by dsgd_fix_reduce_apply_kernel<true> and dsgd_apply_cols_kernel: lane tid < FRA_COLS of a block owns
 // column j = block * FRA_COLS + tid and holds the sum of the regularised gradients over the workers; mean, update, and
 // the block's share of w . ds and |w|^2 (combined by the last block to arrive, in block order: reproducible).
@@ -666,6 +563,16 @@ __device__ __forceinline__ void fra_update_and_scalars(float gsum, float k_total
     dot = filt(wn * ds[j]);
     nsq = wn * wn;
   }
+  fra_scalars(dot, nsq, lambda, sc, redpart, fred, is_last);
+}
+
+// s = 2 * lambda * (w . ds) and |w|^2 from the per-column terms of a block (lanes tid < FRA_COLS; zeros elsewhere):
+// wave sums, the block's pair published write-through, the last block to arrive adds the pairs in block order.  ONE
+// summation order for every kernel that leaves these scalars (the fused step, the update behind an all-reduce,
+// dsgd_wstats_cols_kernel after dsgd_set_weights): equal weights give bit-equal scalars whichever path wrote them.
+__device__ __forceinline__ void fra_scalars(float dot, float nsq, float lambda, DevScalars* sc,
+                                            float* __restrict__ redpart, float* fred, int* is_last) {
+  const int tid = threadIdx.x;
   if (tid < 256) {   // the finishing waves (FRA_COLS = 192 -> three of them carry data)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -717,7 +624,7 @@ __device__ __forceinline__ void fra_update_and_scalars(float gsum, float k_total
 // of the new weights are combined by the last block to arrive, in block order (reproducible).  Every block reads the
 // old s before it takes its ticket, so the last block's write of the new s cannot be seen by any of them.
 // APPLY = false (a communicator is attached): the regularised sum over the hosted workers is written to `gsum_out` for
-// the all-reduce across ranks, dsgd_apply_mb_kernel<false> finishes (two launches around the collective instead of
+// the all-reduce across ranks, dsgd_apply_cols_kernel<false> finishes (two launches around the collective instead of
 // four).
 // Geometry: a block owns FRA_COLS = 192 columns (247 blocks for D + 1 = 47,237: one round over 256 CUs); a thread adds
 // FOUR adjacent columns of every 21st workgroup's partials with 16-byte loads (768-byte pieces per partial row; the
@@ -805,17 +712,47 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
   fra_update_and_scalars(gsum, (float)n_workers, j, dp, w, ds, lr, lambda, sc, redpart, fred, &is_last);
 }
 
-// The update after the all-reduce across ranks (a communicator is attached): the same columns per block, the same
+// The update outside the fused kernel: after the all-reduce across ranks (a communicator is attached), behind the
+// gather-based kernels of DSGD_STREAM=3 / DSGD_FUSE_APPLY=0, and for dsgd_apply.  The same columns per block, the same
 // arithmetic and the same summation order of the two dot products as the fused kernel above -- a communicator of size
 // one leaves exactly the weights and the regulariser scalar of the engine without one.
-__global__ void __launch_bounds__(256) dsgd_apply_cols_kernel(float* __restrict__ w, const float* __restrict__ gsum,
+// REG: `gsum` is ONE worker's raw batch sum: the support-only regulariser is applied first (ref: SparseSVM.scala:31).
+// The n_zero per-worker gradient vectors at zero_base are cleared for the next step (gsum may be one of them).
+template <bool REG>
+__global__ void __launch_bounds__(256) dsgd_apply_cols_kernel(float* __restrict__ w, const float* gsum, float* zero_base,
+                                                             long long zero_stride, int n_zero,
                                                              const float* __restrict__ ds, int dp, float k_total, float lr,
                                                              float lambda, DevScalars* sc, float* __restrict__ redpart) {
   __shared__ float fred[8];
   __shared__ int is_last;
   const int j = blockIdx.x * FRA_COLS + threadIdx.x;
-  const float g = (threadIdx.x < FRA_COLS && j < dp) ? gsum[j] : 0.0f;
+  const bool mine = threadIdx.x < FRA_COLS && j < dp;
+  float g = mine ? gsum[j] : 0.0f;
+  if (REG) {
+    const float s = sc->s_reg;   // (read before any block can have written the new one: see the fused kernel)
+    g = filt(g);
+    if ((s != 0.0f) && (fabsf(s) > DSGD_EPS) && g != 0.0f) g = filt(g + s);
+  }
+  if (mine)
+    for (int k = 0; k < n_zero; ++k) zero_base[(long long)k * zero_stride + j] = 0.0f;
   fra_update_and_scalars(g, k_total, j, dp, w, ds, lr, lambda, sc, redpart, fred, &is_last);
+}
+
+// s and |w|^2 for weights that were set from outside (dsgd_set_weights, the lock-free engine's weights at a loss
+// check): same blocks, same order as above; 247 blocks instead of one workgroup walking all D + 1 columns (17 us).
+__global__ void __launch_bounds__(256) dsgd_wstats_cols_kernel(const float* __restrict__ w, const float* __restrict__ ds,
+                                                              int dp, float lambda, DevScalars* sc,
+                                                              float* __restrict__ redpart) {
+  __shared__ float fred[8];
+  __shared__ int is_last;
+  const int j = blockIdx.x * FRA_COLS + threadIdx.x;
+  float dot = 0.0f, nsq = 0.0f;
+  if (threadIdx.x < FRA_COLS && j < dp) {
+    const float wn = w[j];
+    dot = filt(wn * ds[j]);
+    nsq = wn * wn;
+  }
+  fra_scalars(dot, nsq, lambda, sc, redpart, fred, &is_last);
 }
 
 // ---- cold columns (rank >= hg): transposed lists built once at layout time ------------------------------

@@ -397,11 +397,10 @@ def test_streaming_layouts_match_oracle(monkeypatch, mode, dim, hsplit):
             assert sum(counts) == hi - lo
             if mam >= GATE_EPS:
                 assert counts == counts_ref
-        # bit-reproducible: the same step from the same state twice.  The state is (w, s): set_weights re-derives the
-        # regulariser scalar s = 2 lambda (w . ds) with dsgd_wstats_kernel, whose fp32 summation order differs from
-        # the one the fused step leaves behind (last-bit differences in s) -- so both runs start from set_weights.
+        # bit-reproducible: the same step from the same weights twice.  The first run starts from the regulariser scalar
+        # s = 2 lambda (w . ds) the previous step left behind, the second from the one dsgd_set_weights re-derives: every
+        # kernel that writes s adds the same terms in the same order (fra_scalars), so the two are bit-equal.
         w0 = eng.get_weights()
-        eng.set_weights(w0)
         eng.sync_step_ranges([(0, n_train)], lr)
         w1 = eng.get_weights()
         eng.set_weights(w0)
