@@ -29,3 +29,36 @@ def test_launcher_environment_is_respected():
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
                           stderr=subprocess.PIPE, text=True, timeout=120)
     assert proc.returncode != 0 and "--gpus 2 but WORLD_SIZE=4" in proc.stderr
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The bench line the last GPU visit produced (profiles/r02_bench.json): the keys, types and internal arithmetic of
+    the driver's contract -- whole-job examples/s from the timed steps, the dominant kernel's roofline fraction from its
+    algorithmic bytes and its measured duration, a bounded CPU baseline, nothing quoted against a baseline that was
+    never published."""
+    import json
+
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), key
+    assert d["unit"] == "examples/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None            # BASELINE.md publishes no number for this metric
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    # value = rows per step x GPUs / time per step
+    rows = d["config"]["train_rows_per_gpu"] * d["n_gpus"]
+    assert abs(d["value"] - rows / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # achieved = algorithmic bytes per launch / measured launch duration (HIP events inside the timed region)
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    assert r["kernel_launches"] == d["steps"] * d["n_gpus"] or r["kernel_launches"] == d["steps"]
+    assert r["traffic"] is None or 0.5 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 1.5 * r["algorithmic_bytes_per_launch"]
+    assert 0.0 < r["frac"] <= 1.0 and 0.0 < r["step"]["frac"] <= r["frac"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["unit"] == "examples/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # the parity gate ran on the benchmarked configuration and stayed inside its derived bound
+    assert d["parity_gate_rows"] == d["config"]["train_rows_per_gpu"]
+    assert all(st["worst_err_over_bound"] <= 1.0 for st in d["parity_gate"]["steps"])
