@@ -309,6 +309,47 @@ class HostAllReduceBackend:
         self.local.set_weights(w)
 
 
+class HostAsyncExchange:
+    """The asynchronous mode across ranks with the collective owned by the host: the host-side twin of
+    `dsgd_async_set_exchange` (csrc/dsgd_hip.hip, RCCL inside the library), usable with gloo on CPU.
+
+    core/Slave.scala:99-105 applies every update locally and gossips it to every peer, who subtracts it when it
+    arrives (:177-185).  One replica per rank runs `every` local updates per round; between rounds the replicas
+    all-reduce what each subtracted since the last exchange (d_local = w_prev - w) and subtract their PEERS' part
+    (d_sum - d_local) on top of their own.  With one rank the peers' part is exactly zero."""
+
+    def __init__(self, local, dist_module):
+        self.local, self.dist = local, dist_module
+        self.world = dist_module.get_world_size()
+        self.w_prev = np.asarray(local.get_weights(), dtype=np.float64).copy()
+        self.rounds = 0
+
+    def run_round(self, idx_lists, lr):
+        """`idx_lists`: the sample lists of this rank's local updates of the round, in order (Slave.asyncTask draws
+        them itself; they are an input here so that a run can be replayed)."""
+        stats = {"n_samples": 0, "n_active": 0}
+        for idx in idx_lists:
+            _, st = self.local.async_step(idx, lr)
+            stats["n_samples"] += st["n_samples"]
+            stats["n_active"] += st["n_active"]
+        self.exchange()
+        return stats
+
+    def exchange(self):
+        import torch
+
+        w = np.asarray(self.local.get_weights(), dtype=np.float64)
+        d_local = self.w_prev - w
+        t = torch.from_numpy(np.ascontiguousarray(d_local.copy()))
+        self.dist.all_reduce(t)  # sum over ranks
+        others = t.numpy() - d_local   # exactly 0 with a single rank
+        if self.world > 1 or np.any(others != 0.0):
+            w = w - others
+            self.local.set_weights(w)
+        self.w_prev = w.copy()
+        self.rounds += 1
+
+
 # ---- Master.fit (synchronous) ---------------------------------------------------------------------------------
 class MasterSync:
     """core/Master.scala:120-218 for the workers hosted behind one backend.

@@ -140,3 +140,78 @@ def test_world_size_2_gloo_matches_single_process(tmp_path):
     for r in range(2):
         c += np.asarray(ref.loss_acc(n_train + r * 100, n_train + r * 100 + 100)[2])
     assert list(e0[2:]) == list(c) and abs(e0[1] - c[0] / 200) < 1e-12
+
+
+# ---- asynchronous mode across ranks: replicas + periodic exchange of the summed updates ---------------------------
+def _async_schedule(n_train, world, rounds, every):
+    """The sample lists of every rank, round and local update (the same on whoever computes them)."""
+    rng = np.random.default_rng(321)
+    split = host.split_vanilla(n_train, world)
+    return [[[rng.permutation(np.asarray(split[r]))[:50].astype(np.int32) for _ in range(every)] for _ in range(rounds)]
+            for r in range(world)]
+
+
+def _async_rank_main(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data, n_train, o = small_problem()
+    local = OracleBackend(o)
+    ex = host.HostAsyncExchange(local, dist)
+    for lists in _async_schedule(n_train, world, 4, 3)[rank]:
+        ex.run_round(lists, 0.5)
+    np.save(os.path.join(out_dir, "aw%d.npy" % rank), local.w)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+class _OneRank:
+    """torch.distributed's surface for a single rank: the peers' part of an exchange is exactly zero."""
+
+    @staticmethod
+    def get_world_size():
+        return 1
+
+    @staticmethod
+    def all_reduce(t):
+        return None
+
+
+def test_async_exchange_world_2_gloo_matches_the_in_process_simulation(tmp_path):
+    """core/Slave.scala:99-105,177-185 batched per round (the scheme of dsgd_async_set_exchange): two gloo ranks end
+    with the same replica, equal to a single-process simulation of the two replicas exchanging their summed updates."""
+    import torch.multiprocessing as mp
+
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_async_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    w0, w1 = np.load(tmp_path / "aw0.npy"), np.load(tmp_path / "aw1.npy")
+    # (w - A) - B on one rank, (w - B) - A on the other: equal up to the order of two fp64 subtractions
+    np.testing.assert_allclose(w0, w1, rtol=0, atol=1e-14)
+    data, n_train, o = small_problem()
+    reps = [OracleBackend(o), OracleBackend(o)]
+    sched = _async_schedule(n_train, 2, 4, 3)
+    w_prev = [r.w.copy() for r in reps]
+    for rnd in range(4):
+        for r in range(2):
+            for idx in sched[r][rnd]:
+                reps[r].async_step(idx, 0.5)
+        d = [w_prev[r] - reps[r].w for r in range(2)]
+        for r in range(2):
+            reps[r].w = reps[r].w - d[1 - r]   # the peer's part
+            w_prev[r] = reps[r].w.copy()
+    np.testing.assert_allclose(w0, reps[0].w, rtol=0, atol=1e-14)
+    assert np.abs(w0).max() > 0.01   # something was learnt: the comparison is not 0 == 0
+
+
+def test_async_exchange_with_one_rank_changes_nothing():
+    data, n_train, o = small_problem()
+    plain, local = OracleBackend(o), OracleBackend(o)
+    ex = host.HostAsyncExchange(local, _OneRank)
+    for lists in _async_schedule(n_train, 1, 3, 4)[0]:
+        for idx in lists:
+            plain.async_step(idx, 0.5)
+        ex.run_round(lists, 0.5)
+    np.testing.assert_array_equal(local.w, plain.w)   # bit for bit: the peers' part is exactly zero
+    assert ex.rounds == 3
