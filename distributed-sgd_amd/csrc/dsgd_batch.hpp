@@ -450,6 +450,7 @@ constexpr int HOG_HL = 20480;      // ranks with an LDS accumulator (80 KiB)
 constexpr int HOG_WL = 12288;      // ranks whose weight is gathered from an LDS copy refreshed every iteration (48 KiB;
                                    // with the tables 136 KiB: 16 KiB of dsgd_eval_kernel still fit the CU)
 constexpr int HOG_SW = 8;          // accumulator slots per thread and sweep pass
+constexpr int HOG_REDERIVE = 4096; // worker 0 re-derives s = 2 lambda (w . ds) from the weights every so many of its iterations
 
 struct HogCtl {   // per iteration parity
   unsigned int mul, off;
@@ -666,6 +667,22 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       redn[tid >> 6] = n_act;
     }
     __syncthreads();   // (drains this workgroup's updates of w: the barrier waits for every outstanding memory operation)
+    // The scalar s is kept by fp32 atomic increments (one per mini-batch, plus dsgd_update_grad's foreign updates): over
+    // 10^6+ updates the rounding of every add accumulates like a random walk.  Every HOG_REDERIVE iterations worker 0
+    // recomputes w . ds from the weights as they are now (fp64 partial sums) and adds the difference to the shared
+    // scalar: the accumulated drift is removed; what remains is the fuzz of the <= n_workers updates in flight
+    // around the recomputation, which does not accumulate.  Block-uniform condition.
+    const bool rederive = worker == 0 && ((it + 1) & (unsigned long long)(HOG_REDERIVE - 1)) == 0;
+    double* dred = reinterpret_cast<double*>(L.pdot);   // (free between the gate and the next iteration's products)
+    if (rederive) {
+      double part = 0.0;
+      for (int j = tid; j < a.dp; j += HOG_THREADS)
+        part += (double)__hip_atomic_load(&a.w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (double)a.ds[j];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+      if ((tid & 63) == 0) dred[tid >> 6] = part;
+      __syncthreads();
+    }
     // next iteration's copy of the weights, requested while thread 0 exchanges the shared scalars
     hog_wcache_issue(a.w, wl, a.wl);
     if (tid == 0) {
@@ -677,6 +694,12 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       }
       const float ds_term = -2.0f * a.lambda * tot;
       s = atomicAdd(&a.st->s_reg, ds_term) + ds_term;
+      if (rederive) {
+        double dot = 0.0;
+        for (int i = 0; i < HOG_THREADS / 64; ++i) dot += dred[i];
+        const float corr = (float)(2.0 * (double)a.lambda * dot) - s;
+        s = atomicAdd(&a.st->s_reg, corr) + corr;
+      }
       u = atomicAdd(&a.st->updates, 1ull) + 1ull;
       atomicAdd(&a.st->samples, (unsigned long long)B);
       atomicAdd(&a.st->active, (unsigned long long)na);

@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) dsgd_dense_apply_kernel(float* __restrict
 
 // synthetic data on the device (configs[4]: "X generated on-device per shard (seed = rank)"): x ~ N(0, 1) / sqrt(D)
 // from a counter-based generator (splitmix64 of the element index), y = [x . w* + 0.1 N(0,1) > 0] with planted
-// w* ~ N(0, 1).  Two passes: rows, then labels.
+// w* ~ N(0, 1) shared by all shards.
 __device__ __forceinline__ float dn_normal(unsigned long long key) {
   const unsigned long long a = hog_mix(key), b = hog_mix(key ^ 0x5851F42D4C957F2Dull);
   const float u1 = ((float)(a >> 40) + 1.0f) * (1.0f / 16777217.0f);   // (0, 1)
@@ -253,7 +253,9 @@ __global__ void __launch_bounds__(256) dsgd_dense_generate_kernel(float* __restr
     float dot = 0.0f;
     for (int j = threadIdx.x; j < D; j += blockDim.x) {
       const float x = dn_normal(seed * 0x9E3779B97F4A7C15ull + (unsigned long long)row * (unsigned long long)D + j) * inv;
-      const float ws = dn_normal(0xD1B54A32D192ED03ull * (seed + 1) + j);   // planted separator (same for every row)
+      // planted separator: ONE problem for every shard (the seed -- the rank -- varies x and the label noise only;
+      // ranks that all-reduce gradients of different separators would be training nothing)
+      const float ws = dn_normal(0xD1B54A32D192ED03ull + j);
       X[row * (long long)D + j] = x;
       dot = fmaf(x, ws, dot);
     }

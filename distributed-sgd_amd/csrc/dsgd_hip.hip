@@ -4,10 +4,10 @@
 //   * the CSR shard, w, g and dimSparsity stay resident in HBM (288 GB/GPU); w/g/ds are
 //     3 x 189 KB and live in the XCD L2s, so the only HBM stream is the CSR itself
 //     (8 B per non-zero + 12 B per row -- SURVEY.md 8(d));
-//   * gradient kernel: a group of G lanes of a 64-wide wavefront owns one row; gather-dot with
-//     an in-wave butterfly reduction, the reference's `activity >= 0` gate, then an fp32
-//     atomicAdd scatter of y*x into g (hardware global_atomic_add_f32, device scope);
-//   * regularise / aggregate / update are single-pass kernels over D+1 floats;
+//   * gradient kernels: whole row ranges stream the matrix split by column rank (hot tiles with weights and gradient
+//     in LDS, a row-ordered cold stream); index-list batches run the mini-batch engine (dsgd_batch.hpp); every sum is
+//     accumulated in fixed point (exact, order-independent) and rounded once;
+//   * exact reduce + regularise + aggregate + update are one fused kernel over D+1 columns;
 //   * the synchronous master's Vec.mean over workers is one ncclAllReduce on the same stream.
 // Citations "ref:" are relative to /root/reference/src/main/scala/epfl/distributed/.
 //
@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -25,10 +26,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
-
-// one-time segmented sort of the cold-column lists (layout time, not the hot path)
-#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include "../../include/dsgd.h"
 
@@ -75,7 +74,14 @@ static std::once_flag once;
 static bool ok = false;
 
 static void load() {
-  void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);  // reuse a copy the process already has
+  void* h = nullptr;
+  // DSGD_RCCL_LIB=<path>: use exactly this library for the collectives (tests/rccl_stub: a host-staged shim that lets
+  // two ranks share ONE device, which RCCL refuses -- the world = 2 arithmetic on a one-GPU box); no fallback
+  if (const char* forced = getenv("DSGD_RCCL_LIB")) {
+    h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+  }
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);  // reuse a copy the process already has
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -135,30 +141,25 @@ struct dsgd_ctx {
   int* d_col = nullptr;
   float* d_val = nullptr;
   signed char* d_label = nullptr;
-  int group = 16;  // lanes per row, chosen from the mean row length at load time
+  int group = 16;  // lanes per row of the row-wise prediction / evaluation kernels, from the mean row length
   // column layout: external keys <-> internal frequency ranks (identity until prepare_layout)
   int* d_perm = nullptr;   // key  -> rank
   bool layout_ready = false;
-  int hw = 8192, hg = 32768;  // LDS tile sizes (floats) of the tiled gradient kernel; hw + hg <= 40960
   int hw_eval = DSGD_LDS_FLOATS;
-  long long tiled_min = 8192;  // batches with at least this many rows use the tiled kernel
+  long long stream_min = 8192;  // row ranges with at least this many rows use the streaming kernels
   // nnz-streaming kernels (contiguous row ranges)
   StreamSeg* d_ssegs = nullptr;
   int ssegs_cap = 0;
   std::vector<StreamSeg> ssegs_last;
-  bool stream_ranges = true;
-  // stream_mode 3: wave tiles over the whole ranked CSR, cold weights gathered, cold gradient columns through
-  //                transposed lists;
-  // stream_mode 4: the matrix is SPLIT by column rank into a hot stream (rank < hsplit: wave tiles, weights and
-  //                gradient in LDS, no gathers) and a cold stream (col - hsplit, val, row) handled by two small
-  //                kernels whose LDS holds the cold weights / the cold gradient.
-  int stream_mode = 4;
+  // The matrix is SPLIT by column rank into a hot stream (rank < hsplit: wave tiles, weights and gradient in LDS, no
+  // gathers) and a cold stream (col - hsplit, val, row) handled by two small kernels whose LDS holds the cold weights /
+  // the cold gradient.
   std::vector<long long> h_row_ptr;     // host copy of the internal row_ptr (tile building at layout time)
-  std::vector<long long> h_crow_ptr;    // mode 4: row offsets of the cold stream
+  std::vector<long long> h_crow_ptr;    // row offsets of the cold stream
   std::vector<signed char> h_label;
-  // wave tiles (mode 3: over d_col/d_val; mode 4: over d_hcol/d_hval)
+  // wave tiles over d_hcol/d_hval
   WTile* d_wtiles = nullptr;
-  unsigned int* d_wmeta = nullptr;
+  unsigned short* d_wmeta = nullptr;
   long long n_wtiles = 0;
   std::vector<int> h_wtile_r0;          // first row of every wave tile (+ sentinel n_rows)
   std::vector<long long> wlong_rows;    // rows that fit no wave tile (sorted): one wave per row, from the whole CSR
@@ -166,14 +167,6 @@ struct dsgd_ctx {
   int* d_part = nullptr;                // per-workgroup partial sums of the wseg gradient kernel: part_wgs x part_stride
   long long part_wgs = 0;
   int part_stride = 0;
-  bool use_part = true;                 // DSGD_EPI=0 (mode 3 only): 64-bit atomics into g64 instead
-  int pf_depth = 4;                     // DSGD_PF=3|4 (mode 3): tiles in flight per wave
-  int dbg = 0;                          // DSGD_DBG: ablation switches of the streaming kernels (tuning runs only)
-  // mode 3 LDS tiles.  Cost model from tools/microbench4.hip and the profiles: a cold weight costs ~3 clk of a CU's
-  // texture path per distinct cache line, a cold gradient entry ~8 B of list traffic.
-  int hw_w = 16384, hg_w = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 16384 - 4 - 64;
-  int hw_we = DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4;                     // ... of the mode-3 evaluation kernel
-  // mode 4
   int hsplit = (DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64) / 2;         // hot ranks: 2 * hsplit words of LDS
   unsigned short* d_hcol = nullptr;     // hot stream (16-bit ranks < hsplit), WS_PAD elements of padding
   float* d_hval = nullptr;
@@ -190,15 +183,7 @@ struct dsgd_ctx {
   int* d_partc = nullptr;               // per-workgroup cold gradient partials: partc_wgs x partc_stride
   long long partc_wgs = 0;
   int partc_stride = 0;
-  int hg_cold() const { return hg_w; }
-  // mode 3 cold columns (rank >= hg_w): transposed (row, value) lists + per-row gate coefficients
-  unsigned int* d_cold_ptr = nullptr;  // n_cold + 1
-  int* d_cold_row = nullptr;
-  float* d_cold_val = nullptr;
-  signed char* d_coef8 = nullptr;  // n_rows
-  unsigned int* d_coefp = nullptr; // n_rows / 16: 2-bit packing of coef8 for the cold lists
-  int n_cold = 0;
-  long long cold_nnz = 0;
+  signed char* d_coef8 = nullptr;  // n_rows: gate coefficient y * [y (x . w) >= 0] of the last whole-range step
   const char* last_grad_kernel = "";
   // vectors
   float* d_w = nullptr;
@@ -207,15 +192,12 @@ struct dsgd_ctx {
   long long* d_g64 = nullptr;  // g_cap x dp fixed-point accumulators of the streaming kernel (zero between steps)
   float fix_scale = 4194304.0f;  // 2^FIX_SHIFT / vmax2
   int vexp = 0;                  // vmax2 = 2^vexp >= max |value|
-  int last_shift = FIX_SHIFT;    // shift of the last split-layout gradient launch
+  int last_shift = FIX_SHIFT;    // shift of the last gradient launch (streaming kernels or index-list kernel)
   std::vector<StreamSeg> bound_segs;   // split layout: the (ranges, grid) configuration bound_shift was measured for
   unsigned bound_grid = 0;
   int bound_shift = 0;
   unsigned int* d_bound = nullptr;
   int max_shift = FIX_SHIFT;     // DSGD_FIX_SHIFT: cap of the per-launch fixed-point shift of the split layout
-  int cold8 = 1;                 // DSGD_COLD8 bit 0: dsgd_cdot8_kernel, bit 1: dsgd_cgrad8_kernel (measured: cdot8 85 vs
-                                 // 93 us, cgrad8 75 vs 73 us per 0.30 GB -- both are start-up bound, profiles/README.md)
-  bool fuse_apply = true;        // DSGD_FUSE_APPLY=0: separate dsgd_fix_reduce_kernel + dsgd_apply_cols_kernel launches
   bool fused_apply_pending = false;
   FusedArgs fused_args{};
   float* d_redpart = nullptr;    // per-block partial sums of w.ds and |w|^2 of the fused reduce + apply kernel
@@ -230,7 +212,13 @@ struct dsgd_ctx {
     hipEvent_t ev = nullptr;   // the last copy FROM this buffer to the device
     bool armed = false;
   };
-  Pinned pin_w, pin_idx, pin_segs, pin_out;
+  Pinned pin_w, pin_idx, pin_segs, pin_out, pin_upd;
+  // dsgd_update_grad: persistent device staging (keys, values) -- no allocation per call, nothing that synchronises the
+  // device while the persistent engine is resident
+  int* d_upd_key = nullptr;
+  float* d_upd_dv = nullptr;
+  long long upd_cap = 0;
+  hipStream_t upd_stream = nullptr;
   float* d_pred = nullptr;     // dsgd_forward's predictions (grown on demand)
   long long pred_cap = 0;
   bool fix_bound = true;         // DSGD_FIX_BOUND=0: keep the data-independent bound (rows per workgroup x largest value)
@@ -263,8 +251,7 @@ struct dsgd_ctx {
   unsigned long long* d_tprof = nullptr;   // DSGD_PLAN_PROF=1: phase cycle counters of dsgd_plan_kernel (tuning runs)
   float* d_plan_gcold = nullptr;
   bool plan_kernel = true;     // DSGD_PLAN_KERNEL=0: the multi-launch small-batch path
-  int hog_hl = HOG_HL, hog_wl = HOG_WL;   // DSGD_HOG_HL / DSGD_HOG_WL (tuning runs): LDS-resident ranks of the Hogwild engine
-  bool mb_kernel = true;       // DSGD_MB_KERNEL=0: round 1's fp32-atomic kernels for index lists beyond one workgroup
+  int hog_hl = HOG_HL, hog_wl = HOG_WL;   // LDS-resident ranks of the Hogwild engine (accumulators / weight copy)
   long long plan_max_rows = 2048;   // steps with more rows in total use the multi-workgroup kernels
   int hog_workers = 0;      // capacity of the per-worker buffers
   int hog_n = 0, hog_batch = 0, hog_bug = 0;   // the running configuration
@@ -274,6 +261,12 @@ struct dsgd_ctx {
   float* d_wprev = nullptr;       // weights at the last exchange
   float* d_wdelta = nullptr;      // 2 x dp: all-reduced updates, this replica's own part
   bool async_running = false;
+  // exchange mode: the rounds (engine launch, delta, all-reduce, apply) are enqueued by a helper thread so that
+  // dsgd_async_start returns at once and dsgd_async_updates / dsgd_async_stop stay responsive
+  std::thread exch_thread;
+  std::atomic<bool> exch_done{true};
+  int exch_rc = DSGD_OK;
+  std::string exch_err;
   // comm
   rccl::comm_t comm = nullptr;
   int world = 1, rank = 0;
@@ -324,8 +317,8 @@ static int pin_acquire(dsgd_ctx::Pinned& b, size_t bytes) {
   if (!b.ev) HIP_TRY(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
   return DSGD_OK;
 }
-static int pin_sent(dsgd_ctx* c, dsgd_ctx::Pinned& b) {
-  HIP_TRY(hipEventRecord(b.ev, c->stream));
+static int pin_sent(dsgd_ctx* c, dsgd_ctx::Pinned& b, hipStream_t on = nullptr) {
+  HIP_TRY(hipEventRecord(b.ev, on ? on : c->stream));
   b.armed = true;
   return DSGD_OK;
 }
@@ -425,8 +418,7 @@ static int check_err_flag(dsgd_ctx* c) {
   if (err) {
     HIP_TRY(hipMemsetAsync(&c->d_sc->err, 0, sizeof(int), c->stream));
     if (err & 2)
-      return fail(DSGD_ESTATE, "fixed-point gradient accumulator left its safe band; the step is invalid "
-                               "(rerun with DSGD_STREAM=0 to use the fp32 row-wise kernels)");
+      return fail(DSGD_ESTATE, "fixed-point gradient accumulator left its safe band; the step is invalid");
     if (err & 4)
       return fail(DSGD_ESTATE, "a small-batch plan was created for other data than is loaded now (its lists no longer fit "
                                "the staged sub-batch): create the plan again");
@@ -492,6 +484,7 @@ static int launch_grad_mb(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, 
   int bits = 0;
   while ((1LL << bits) < rows_per_wg) ++bits;
   const int shift = 30 - bits;   // at most one contribution per row and column: a workgroup's sums stay below 2^30
+  c->last_shift = shift;
   MbArgs a;
   a.m = view(c);
   a.w = c->d_w;
@@ -514,7 +507,7 @@ static int launch_grad_mb(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, 
   c->last_grad_kernel = "dsgd_mb_grad_kernel";
   const double inv = 1.0 / (double)a.qscale;
   c->fused_apply_pending = false;
-  if (allow_fused && c->fuse_apply) {
+  if (allow_fused) {
     DSGD_TRY(ensure_redpart(c));
     c->fused_args = {hl, (int)wgs, c->dp, 0, 0, inv, inv};
     c->fused_apply_pending = true;   // launched by launch_finish_sync, which knows lr
@@ -526,106 +519,39 @@ static int launch_grad_mb(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, 
   return DSGD_OK;
 }
 
-// launch K1 for n_workers segments living at d_segs (device); max_items = largest segment
+// gradient of n_workers index lists (or row ranges too small for the streaming kernels) living at d_segs (device);
+// max_items = largest list
 static int launch_grad(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int n_workers, long long max_items,
-                       long long total_items, bool allow_fused = false) {
-  if (c->mb_kernel && !(c->cfg.flags & (DSGD_F_FORCE_TILED | DSGD_F_FORCE_ROWS)))
-    return launch_grad_mb(c, d_idx, d_segs, n_workers, max_items, allow_fused);
-  c->fused_apply_pending = false;
-  const int G = c->group;
-  size_t slot = 0;
-  CsrView m = view(c);
-  const bool tiled = total_items >= c->tiled_min;
-  DSGD_TRY(prof_begin(c, &slot));
-  if (tiled) {
-    // persistent workgroups: one 1024-lane block (all 160 KiB of LDS) per CU, shared out over the workers
-    const long long groups_per_block = 1024 / G;
-    long long bx = std::max<long long>(1, c->n_cu / n_workers);
-    bx = std::min(bx, (max_items + groups_per_block - 1) / groups_per_block);
-    dim3 grid((unsigned)std::max<long long>(1, bx), n_workers);
-    const size_t lds = sizeof(float) * (size_t)(c->hw + c->hg);
-#define DSGD_LAUNCH_TILED(GG)                                                                                        \
-  hipLaunchKernelGGL(dsgd_grad_tiled_kernel<GG>, grid, dim3(1024), lds, c->stream, m, c->d_w, c->d_g, (long long)c->dp, \
-                     d_idx, d_segs, c->d_sc, c->hw, c->hg)
-    switch (G) {
-      case 64: DSGD_LAUNCH_TILED(64); c->last_grad_kernel = "dsgd_grad_tiled_kernel<64>"; break;
-      case 32: DSGD_LAUNCH_TILED(32); c->last_grad_kernel = "dsgd_grad_tiled_kernel<32>"; break;
-      case 16: DSGD_LAUNCH_TILED(16); c->last_grad_kernel = "dsgd_grad_tiled_kernel<16>"; break;
-      default: DSGD_LAUNCH_TILED(8); c->last_grad_kernel = "dsgd_grad_tiled_kernel<8>"; break;
-    }
-#undef DSGD_LAUNCH_TILED
-  } else {
-    dim3 grid(grid_for(c, max_items, G), n_workers);
-#define DSGD_LAUNCH_ROWS(GG)                                                                                       \
-  hipLaunchKernelGGL(dsgd_grad_rows_kernel<GG>, grid, dim3(256), 0, c->stream, m, c->d_w, c->d_g, (long long)c->dp,   \
-                     d_idx, d_segs, c->d_sc)
-    switch (G) {
-      case 64: DSGD_LAUNCH_ROWS(64); c->last_grad_kernel = "dsgd_grad_rows_kernel<64>"; break;
-      case 32: DSGD_LAUNCH_ROWS(32); c->last_grad_kernel = "dsgd_grad_rows_kernel<32>"; break;
-      case 16: DSGD_LAUNCH_ROWS(16); c->last_grad_kernel = "dsgd_grad_rows_kernel<16>"; break;
-      default: DSGD_LAUNCH_ROWS(8); c->last_grad_kernel = "dsgd_grad_rows_kernel<8>"; break;
-    }
-#undef DSGD_LAUNCH_ROWS
-  }
-  HIP_TRY(hipGetLastError());
-  DSGD_TRY(prof_end(c, slot));
-  return DSGD_OK;
+                       bool allow_fused = false) {
+  return launch_grad_mb(c, d_idx, d_segs, n_workers, max_items, allow_fused);
 }
 
 // regularise each hosted worker's sum, aggregate (locally and across ranks), update w
 static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
   const int dp = c->dp;
-  const int blocks = (dp + 1023) / 1024, cblocks = (dp + FRA_COLS - 1) / FRA_COLS;
+  const int cblocks = (dp + FRA_COLS - 1) / FRA_COLS;
   const float k_total = (float)n_workers * (float)c->world;
-  if (c->fused_apply_pending) {
-    c->fused_apply_pending = false;
-    const FusedArgs& f = c->fused_args;
-    if (!c->comm) {
-      hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel<true>, dim3((dp + FRA_COLS - 1) / FRA_COLS), dim3(1024), 0, c->stream, c->d_g64, (long long)dp,
-                         n_workers, c->d_w, c->d_ds, dp, f.hg, c->d_part, c->part_stride, f.n_wg, f.hc, f.nc, c->d_partc, c->partc_stride, f.n_wgc,
-                         f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart, (float*)nullptr);
-      HIP_TRY(hipGetLastError());
-      c->s_dirty = false;
-      return DSGD_OK;
-    }
-    // peers: exact column sums + regulariser + sum over the hosted workers in one launch, then the synchronous
-    // master's Future.sequence + Vec.mean (ref: core/Master.scala:190-194) as ONE all-reduce of D+1 floats over xGMI,
-    // ordered on the same stream as the kernels around it, then the update
-    hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel<false>, dim3((dp + FRA_COLS - 1) / FRA_COLS), dim3(1024), 0, c->stream, c->d_g64, (long long)dp,
+  if (!c->fused_apply_pending) return fail(DSGD_ESTATE, "internal: no gradient partials pending");
+  c->fused_apply_pending = false;
+  const FusedArgs& f = c->fused_args;
+  if (!c->comm) {
+    hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel<true>, dim3(cblocks), dim3(1024), 0, c->stream, c->d_g64, (long long)dp,
                        n_workers, c->d_w, c->d_ds, dp, f.hg, c->d_part, c->part_stride, f.n_wg, f.hc, f.nc, c->d_partc, c->partc_stride, f.n_wgc,
-                       f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart, c->d_gsum);
-    HIP_TRY(hipGetLastError());
-    RCCL_TRY(rccl::AllReduce(c->d_gsum, c->d_gsum, (size_t)dp, rccl::kFloat32, rccl::kSum, c->comm, c->stream));
-    hipLaunchKernelGGL(dsgd_apply_cols_kernel<false>, dim3(cblocks), dim3(256), 0, c->stream, c->d_w, c->d_gsum, c->d_g,
-                       (long long)dp, 0 /* the per-worker sums were never materialised */, c->d_ds, dp, k_total, lr,
-                       (float)c->cfg.lambda, c->d_sc, c->d_redpart);
+                       f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart, (float*)nullptr);
     HIP_TRY(hipGetLastError());
     c->s_dirty = false;
     return DSGD_OK;
   }
-  if (n_workers == 1 && !c->comm) {
-    // one hosted worker, no peers: regularise + "mean" over one worker + update in a single pass
-    DSGD_TRY(ensure_redpart(c));
-    hipLaunchKernelGGL(dsgd_apply_cols_kernel<true>, dim3(cblocks), dim3(256), 0, c->stream, c->d_w, c->d_g, c->d_g,
-                       (long long)dp, 1, c->d_ds, dp, 1.0f, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart);
-    HIP_TRY(hipGetLastError());
-    c->s_dirty = false;
-    return DSGD_OK;
-  }
-  hipLaunchKernelGGL(dsgd_regularize_kernel, dim3(blocks, n_workers), dim3(1024), 0, c->stream, c->d_g, (long long)dp,
-                     dp, c->d_sc);
+  // peers: exact column sums + regulariser + sum over the hosted workers in one launch, then the synchronous
+  // master's Future.sequence + Vec.mean (ref: core/Master.scala:190-194) as ONE all-reduce of D+1 floats over xGMI,
+  // ordered on the same stream as the kernels around it, then the update
+  hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel<false>, dim3(cblocks), dim3(1024), 0, c->stream, c->d_g64, (long long)dp,
+                     n_workers, c->d_w, c->d_ds, dp, f.hg, c->d_part, c->part_stride, f.n_wg, f.hc, f.nc, c->d_partc, c->partc_stride, f.n_wgc,
+                     f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart, c->d_gsum);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(dsgd_sum_workers_kernel, dim3(blocks), dim3(1024), 0, c->stream, c->d_g, (long long)dp, n_workers,
-                     dp, c->d_gsum);
-  HIP_TRY(hipGetLastError());
-  if (c->comm) {
-    // the synchronous master's Future.sequence + Vec.mean (ref: core/Master.scala:190-194) as ONE
-    // all-reduce of D+1 floats over xGMI, ordered on the same stream as the kernels around it
-    RCCL_TRY(rccl::AllReduce(c->d_gsum, c->d_gsum, (size_t)dp, rccl::kFloat32, rccl::kSum, c->comm, c->stream));
-  }
-  DSGD_TRY(ensure_redpart(c));
-  hipLaunchKernelGGL(dsgd_apply_cols_kernel<false>, dim3(cblocks), dim3(256), 0, c->stream, c->d_w, c->d_gsum, c->d_g,
-                     (long long)dp, n_workers, c->d_ds, dp, k_total, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart);
+  RCCL_TRY(rccl::AllReduce(c->d_gsum, c->d_gsum, (size_t)dp, rccl::kFloat32, rccl::kSum, c->comm, c->stream));
+  hipLaunchKernelGGL(dsgd_apply_cols_kernel, dim3(cblocks), dim3(256), 0, c->stream, c->d_w, c->d_gsum, c->d_ds, dp, k_total, lr,
+                     (float)c->cfg.lambda, c->d_sc, c->d_redpart);
   HIP_TRY(hipGetLastError());
   c->s_dirty = false;
   return DSGD_OK;
@@ -662,123 +588,19 @@ static int count_columns(dsgd_ctx* c, long long nnz, unsigned int* d_cnt) {
   return DSGD_OK;
 }
 
-// Transposed lists of the cold columns (rank >= hg_s) of the rows held by THIS context, sorted by
-// row: the streaming gradient kernel leaves those columns to dsgd_cold_scatter_kernel.
-static int build_cold_lists(dsgd_ctx* c) {
-  (void)hipFree(c->d_cold_ptr);
-  (void)hipFree(c->d_cold_row);
-  (void)hipFree(c->d_cold_val);
-  (void)hipFree(c->d_coef8);
-  (void)hipFree(c->d_coefp);
-  c->d_coefp = nullptr;
-  c->d_cold_ptr = nullptr;
-  c->d_cold_row = nullptr;
-  c->d_cold_val = nullptr;
-  c->d_coef8 = nullptr;
-  c->n_cold = std::max(0, c->dp - c->hg_cold());
-  c->cold_nnz = 0;
-  HIP_TRY(hipMalloc(&c->d_coef8, (size_t)std::max<long long>(c->n_rows, 1)));
-  HIP_TRY(hipMemset(c->d_coef8, 0, (size_t)std::max<long long>(c->n_rows, 1)));
-  HIP_TRY(hipMalloc(&c->d_coefp, sizeof(unsigned int) * (size_t)((c->n_rows + 15) / 16 + 1)));
-  HIP_TRY(hipMemset(c->d_coefp, 0, sizeof(unsigned int) * (size_t)((c->n_rows + 15) / 16 + 1)));
-  if (!c->stream_ranges || c->n_cold == 0 || c->nnz == 0) {
-    c->n_cold = 0;
-    return DSGD_OK;
-  }
-  // local counts of the ranked columns
-  unsigned int* d_cnt = nullptr;
-  HIP_TRY(hipMalloc(&d_cnt, sizeof(unsigned int) * c->dp));
-  int rc = count_columns(c, c->nnz, d_cnt);
-  std::vector<unsigned int> cnt(c->dp);
-  if (!rc) {
-    hipError_t e = hipMemcpyAsync(cnt.data(), d_cnt, sizeof(unsigned int) * c->dp, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) rc = fail(DSGD_EHIP, "cold counts: %s", hipGetErrorString(e));
-  }
-  (void)hipFree(d_cnt);
-  DSGD_TRY(rc);
-  std::vector<unsigned int> ptr((size_t)c->n_cold + 1, 0u);
-  unsigned long long tot = 0;
-  for (int j = 0; j < c->n_cold; ++j) {
-    ptr[j] = (unsigned int)tot;
-    tot += cnt[c->hg_cold() + j];
-  }
-  if (tot >= 0xFFFFFFFFull) {  // keep 32-bit list offsets; fall back to the row-wise kernels
-    c->n_cold = 0;
-    c->stream_ranges = false;
-    return DSGD_OK;
-  }
-  ptr[c->n_cold] = (unsigned int)tot;
-  c->cold_nnz = (long long)tot;
-  HIP_TRY(hipMalloc(&c->d_cold_ptr, sizeof(unsigned int) * ptr.size()));
-  HIP_TRY(hipMemcpy(c->d_cold_ptr, ptr.data(), sizeof(unsigned int) * ptr.size(), hipMemcpyHostToDevice));
-  if (tot == 0) return DSGD_OK;
-  unsigned int* d_cursor = nullptr;
-  int* d_row_tmp = nullptr;
-  float* d_val_tmp = nullptr;
-  void* d_temp = nullptr;
-  auto cleanup = [&]() {
-    (void)hipFree(d_cursor);
-    (void)hipFree(d_row_tmp);
-    (void)hipFree(d_val_tmp);
-    (void)hipFree(d_temp);
-  };
-#define HIP_TRY_C(expr)                                                                     \
-  do {                                                                                      \
-    hipError_t e__ = (expr);                                                                \
-    if (e__ != hipSuccess) {                                                                \
-      cleanup();                                                                            \
-      return fail(DSGD_EHIP, "%s: %s", #expr, hipGetErrorString(e__));                       \
-    }                                                                                       \
-  } while (0)
-  HIP_TRY_C(hipMalloc(&d_cursor, sizeof(unsigned int) * (size_t)c->n_cold));
-  HIP_TRY_C(hipMemcpy(d_cursor, ptr.data(), sizeof(unsigned int) * (size_t)c->n_cold, hipMemcpyHostToDevice));
-  HIP_TRY_C(hipMalloc(&d_row_tmp, sizeof(int) * tot));
-  HIP_TRY_C(hipMalloc(&d_val_tmp, sizeof(float) * tot));
-  HIP_TRY_C(hipMalloc(&c->d_cold_row, sizeof(int) * tot));
-  HIP_TRY_C(hipMalloc(&c->d_cold_val, sizeof(float) * tot));
-  {
-    CsrView m = view(c);
-    const int blocks = (int)std::max<long long>(1, std::min<long long>((c->n_rows + 15) / 16, (long long)c->n_cu * 8));
-    hipLaunchKernelGGL(dsgd_cold_fill_kernel<16>, dim3(blocks), dim3(256), 0, c->stream, m, c->hg_cold(), d_cursor, d_row_tmp,
-                       d_val_tmp);
-    HIP_TRY_C(hipGetLastError());
-  }
-  // canonical order inside every list: ascending row (the fill order depends on scheduling)
-  size_t temp_bytes = 0;
-  HIP_TRY_C(rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, reinterpret_cast<unsigned int*>(d_row_tmp),
-                                                reinterpret_cast<unsigned int*>(c->d_cold_row), d_val_tmp, c->d_cold_val,
-                                                (unsigned int)tot, (unsigned int)c->n_cold, c->d_cold_ptr,
-                                                c->d_cold_ptr + 1, 0, 32, c->stream));
-  HIP_TRY_C(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)));
-  HIP_TRY_C(rocprim::segmented_radix_sort_pairs(d_temp, temp_bytes, reinterpret_cast<unsigned int*>(d_row_tmp),
-                                                reinterpret_cast<unsigned int*>(c->d_cold_row), d_val_tmp, c->d_cold_val,
-                                                (unsigned int)tot, (unsigned int)c->n_cold, c->d_cold_ptr,
-                                                c->d_cold_ptr + 1, 0, 32, c->stream));
-  HIP_TRY_C(hipStreamSynchronize(c->stream));
-#undef HIP_TRY_C
-  cleanup();
-  return DSGD_OK;
-}
-
 // ---- wave tiles ------------------------------------------------------------------------------------------
-// Tiles of WHOLE rows with <= WS_MAXNNZ non-zeros and <= WS_MAXROWS rows.  Lane l owns the 8 contiguous slots
-// [8l, 8l+8) of the 512-slot window at pos0 (a multiple of 4 elements).  Lane descriptor: local row of its first
-// slot (8 bits, rows 1-based) | row-start bits << 8 | label sign of the row ENDING at each start << 16.
-// Rows longer than WS_MAXNNZ go to `long_rows` (if given); rows of length 0 are skipped (they are on that list
-// already -- the caller emptied them).
+// Tiles of WHOLE rows of the hot stream with <= WS_MAXNNZ non-zeros and <= WS_MAXROWS rows.  Lane l owns the 8
+// contiguous slots [8l, 8l+8) of the 512-slot window at pos0 (a multiple of 8 slots: one 16-byte load of eight 16-bit
+// column ranks per lane).  Lane descriptor (16 bits): row-start bits | label sign of the row ENDING at each start << 8
+// (the kernel derives each lane's first row with a wave prefix sum over the start bits).  Rows of length 0 in
+// `row_ptr` are skipped: the caller emptied them and put them on the long-row list.
 struct HostTiles {
   std::vector<WTile> wt;
   std::vector<int> r0;              // first row of every tile + sentinel n_rows
-  std::vector<unsigned int> meta;   // n_tiles x 64 (mode 3: first row | start bits << 8 | label signs << 16)
-  std::vector<unsigned short> meta16;   // n_tiles x 64 (split layout: start bits | label signs << 8)
+  std::vector<unsigned short> meta16;   // n_tiles x 64
 };
-// `split`: the hot stream of the split layout -- windows start at a multiple of 8 slots (one 16-byte load of eight
-// 16-bit column ranks per lane) and the lane descriptors are the 16-bit form (the kernel derives each lane's first
-// row with a wave prefix sum over the start bits).
-static void build_wave_tiles(const long long* row_ptr, long long n_rows, const signed char* label, HostTiles& out,
-                             std::vector<long long>* long_rows, bool split) {
-  const long long amask = split ? ~7LL : ~3LL;
+static void build_wave_tiles(const long long* row_ptr, long long n_rows, const signed char* label, HostTiles& out) {
+  const long long amask = ~7LL;
   std::vector<WTile>& wt = out.wt;
   std::vector<int>& wr0 = out.r0;
   wt.clear();
@@ -798,7 +620,6 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
     const long long len = row_ptr[i + 1] - row_ptr[i];
     if (len > WS_MAXNNZ || len == 0) {
       close(i);
-      if (long_rows && len > WS_MAXNNZ) long_rows->push_back(i);
       continue;
     }
     if (start >= 0 && (row_ptr[i + 1] - (row_ptr[start] & amask) > WS_SLOTS - 1 || i - start >= WS_MAXROWS)) close(i);
@@ -807,15 +628,13 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
   close(n_rows);
   wr0.push_back((int)n_rows);
   const long long n_tiles = (long long)wt.size();
-  if (split) out.meta16.assign((size_t)std::max<long long>(n_tiles, 1) * 64, (unsigned short)0);
-  else out.meta.assign((size_t)std::max<long long>(n_tiles, 1) * 64, 0u);
+  out.meta16.assign((size_t)std::max<long long>(n_tiles, 1) * 64, (unsigned short)0);
   for (long long t = 0; t < n_tiles; ++t) {
     const WTile& T = wt[(size_t)t];
     const int t_nrows = (int)(short)(T.info & 0xffff);
     int cur_row = 0, next = 0;
     for (int l = 0; l < 64; ++l) {  // lane l owns slots [8l, 8l+8)
       unsigned int bits = 0, ys = 0;
-      int first_row = 0;
       for (int k = 0; k < 8; ++k) {
         const long long slot = 8LL * l + k;
         bool st = false;
@@ -828,10 +647,8 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
           ++cur_row;
           ++next;
         }
-        if (k == 0) first_row = cur_row;
       }
-      if (split) out.meta16[(size_t)t * 64 + l] = (unsigned short)(bits | (ys << 8));
-      else out.meta[(size_t)t * 64 + l] = (unsigned int)first_row | (bits << 8) | (ys << 16);
+      out.meta16[(size_t)t * 64 + l] = (unsigned short)(bits | (ys << 8));
     }
   }
   if (wt.empty()) {
@@ -852,12 +669,10 @@ static int upload_wave_tiles(dsgd_ctx* c, HostTiles& ht) {
   c->n_wtiles = (long long)ht.r0.size() - 1;
   c->h_wtile_r0.swap(ht.r0);
   HIP_TRY(hipMalloc(&c->d_wtiles, sizeof(WTile) * ht.wt.size()));
-  // (the split layout's 16-bit descriptors live in the same buffer; the kernel reinterprets the pointer)
-  const void* meta_src = ht.meta16.empty() ? (const void*)ht.meta.data() : (const void*)ht.meta16.data();
-  const size_t meta_bytes = ht.meta16.empty() ? sizeof(unsigned int) * ht.meta.size() : sizeof(unsigned short) * ht.meta16.size();
+  const size_t meta_bytes = sizeof(unsigned short) * ht.meta16.size();
   HIP_TRY(hipMalloc(&c->d_wmeta, meta_bytes));
   HIP_TRY(hipMemcpy(c->d_wtiles, ht.wt.data(), sizeof(WTile) * ht.wt.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c->d_wmeta, meta_src, meta_bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_wmeta, ht.meta16.data(), meta_bytes, hipMemcpyHostToDevice));
   c->bound_segs.clear();
   std::vector<int> lr(c->wlong_rows.begin(), c->wlong_rows.end());
   lr.push_back(0);
@@ -867,7 +682,7 @@ static int upload_wave_tiles(dsgd_ctx* c, HostTiles& ht) {
   return DSGD_OK;
 }
 
-// mode 4: split the ranked CSR into the hot stream (rank < hsplit; wave tiles) and the cold stream
+// split the ranked CSR into the hot stream (rank < hsplit; wave tiles) and the cold stream
 // (rank - hsplit, value, row); rows whose hot part exceeds a wave tile stay on the long-row list and in neither.
 static int build_split(dsgd_ctx* c) {
   (void)hipFree(c->d_hcol); (void)hipFree(c->d_hval); (void)hipFree(c->d_hrow_ptr);
@@ -960,7 +775,7 @@ static int build_split(dsgd_ctx* c) {
     HIP_TRY(hipGetLastError());
   }
   HostTiles ht;
-  build_wave_tiles(hrp.data(), n_rows, c->h_label.data(), ht, nullptr, true);
+  build_wave_tiles(hrp.data(), n_rows, c->h_label.data(), ht);
   DSGD_TRY(upload_wave_tiles(c, ht));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return DSGD_OK;
@@ -1003,8 +818,7 @@ static int prepare_layout(dsgd_ctx* c) {
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (c->stream_mode == 4 && c->stream_ranges) DSGD_TRY(build_split(c));
-  else DSGD_TRY(build_cold_lists(c));
+  DSGD_TRY(build_split(c));
   c->layout_ready = true;
   c->s_dirty = true;
   return DSGD_OK;
@@ -1079,66 +893,9 @@ static int ensure_part(dsgd_ctx* c, int** buf, long long* wgs, int* stride, long
   return DSGD_OK;
 }
 
-// mode 3 -- after the gradient kernel: fixed point -> fp32, then the cold columns from their transposed lists
-static int finish_mode3(dsgd_ctx* c, int n_workers, int part_wg_per_worker, int part_hg) {
-  if (part_wg_per_worker > 0)
-    hipLaunchKernelGGL(dsgd_fix_reduce_kernel, dim3((c->dp + 63) / 64, n_workers), dim3(1024), 0, c->stream, c->d_g64, c->d_g,
-                       (long long)c->dp, c->dp, part_hg, c->d_part, c->part_stride, part_wg_per_worker, c->dp, 0,
-                       (const int*)nullptr, 0, 0, 1.0 / (double)c->fix_scale, 1.0 / (double)c->fix_scale);
-  else
-    hipLaunchKernelGGL(dsgd_fix_finalize_kernel, dim3((c->dp + 1023) / 1024, n_workers), dim3(1024), 0, c->stream, c->d_g64,
-                       c->d_g, (long long)c->dp, c->dp, 1.0 / (double)c->fix_scale);
-  HIP_TRY(hipGetLastError());
-  if (c->n_cold > 0 && c->cold_nnz > 0) {
-    const long long n_words = (c->n_rows + 15) / 16;
-    hipLaunchKernelGGL(dsgd_pack_coef_kernel, dim3((unsigned)std::min<long long>((n_words + 255) / 256, (long long)c->n_cu * 8)),
-                       dim3(256), 0, c->stream, c->d_coef8, c->d_coefp, c->n_rows);
-    HIP_TRY(hipGetLastError());
-    const int blocks = std::max(1, std::min((c->n_cold + 3) / 4, c->n_cu * 8 / n_workers + 1));  // 4 waves = 4 columns per block
-    hipLaunchKernelGGL(dsgd_cold_scatter_kernel, dim3(blocks, n_workers), dim3(256), 0, c->stream, c->d_cold_ptr,
-                       c->d_cold_row, c->d_cold_val, c->d_coefp, c->n_cold, c->hg_cold(), c->d_g, (long long)c->dp, c->d_ssegs);
-    HIP_TRY(hipGetLastError());
-  }
-  return DSGD_OK;
-}
-
-// mode 3: wave tiles over the whole ranked CSR
+// whole row ranges: hot stream in wave tiles, cold stream before (x.w) and after (gradient) it
 template <bool SCATTER>
-static int launch_wseg(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
-  const int n_workers = (int)row_segs.size();
-  std::vector<StreamSeg> segs(row_segs);
-  long long max_tiles, max_long;
-  locate_segs(c, segs, &max_tiles, &max_long);
-  DSGD_TRY(upload_ssegs(c, segs));
-  long long bx = std::max<long long>(1, c->n_cu / n_workers);
-  bx = std::min(bx, std::max((max_tiles + 15) / 16, (max_long + 15) / 16));
-  dim3 grid((unsigned)std::max<long long>(1, bx), n_workers);
-  const int hw = SCATTER ? c->hw_w : c->hw_we;
-  const int hg = SCATTER ? c->hg_w : 0;
-  const size_t lds = sizeof(float) * (size_t)(16 * WS_COEF_STRIDE + hw + hg + (SCATTER ? 64 : 0) + 4);
-  const bool part = SCATTER && c->use_part;
-  if (part) DSGD_TRY(ensure_part(c, &c->d_part, &c->part_wgs, &c->part_stride, (long long)grid.x * grid.y, hg));
-  CsrView m = view(c);
-  size_t slot = 0;
-  if (SCATTER) DSGD_TRY(prof_begin(c, &slot));
-#define DSGD_LAUNCH_WSEG(ABL)                                                                                          \
-  hipLaunchKernelGGL((dsgd_wseg_kernel<SCATTER, ABL, 4, false>), grid, dim3(1024), lds, c->stream, m, m, c->d_wtiles,   \
-                     c->d_wmeta, c->d_w, c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, c->fix_scale,      \
-                     c->d_coef8, c->dp, c->dbg, c->d_wlong_rows, part ? c->d_part : nullptr, c->part_stride,         \
-                     (const float*)nullptr, c->fix_scale)
-  if (c->dbg) DSGD_LAUNCH_WSEG(true);   // ablation build of the same kernel (DSGD_DBG, tuning runs only)
-  else DSGD_LAUNCH_WSEG(false);
-#undef DSGD_LAUNCH_WSEG
-  HIP_TRY(hipGetLastError());
-  if (SCATTER) DSGD_TRY(prof_end(c, slot));
-  if (SCATTER) c->last_grad_kernel = c->dbg ? "dsgd_wseg_kernel<true, true, 4, false>" : "dsgd_wseg_kernel<true, false, 4, false>";
-  if (!SCATTER) return DSGD_OK;
-  return finish_mode3(c, n_workers, part ? (int)grid.x : 0, hg);
-}
-
-// mode 4: hot stream in wave tiles, cold stream before (x.w) and after (gradient) it
-template <bool SCATTER>
-static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
+static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   const int n_workers = (int)row_segs.size();
   std::vector<StreamSeg> segs(row_segs);
   long long max_tiles, max_long;
@@ -1160,17 +917,11 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   if (cold) {
     size_t slot_c = 0;
     DSGD_TRY(prof_begin(c, &slot_c, 1));
-    if ((c->cold8 & 1) && c->cold_packed)
+    if (c->cold_packed)
       hipLaunchKernelGGL(dsgd_cdot8_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
                          c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds, nc > nc_lds ? 1 : 0);
-    else if (c->cold8 & 1)
-      hipLaunchKernelGGL(dsgd_cdot8_kernel<false>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
-                         c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds, nc > nc_lds ? 1 : 0);
-    else if (c->cold_packed)
-      hipLaunchKernelGGL(dsgd_cdot_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
-                         c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds, nc > nc_lds ? 1 : 0);
     else
-      hipLaunchKernelGGL(dsgd_cdot_kernel<false>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
+      hipLaunchKernelGGL(dsgd_cdot8_kernel<false>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
                          c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds, nc > nc_lds ? 1 : 0);
     HIP_TRY(hipGetLastError());
     DSGD_TRY(prof_end(c, slot_c));
@@ -1235,30 +986,22 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   }
   CsrView mh = view(c);
   mh.row_ptr = c->d_hrow_ptr;
-  mh.col = reinterpret_cast<const int*>(c->d_hcol);   // 16-bit ranks; the split kernel reinterprets the pointer
+  mh.col = reinterpret_cast<const int*>(c->d_hcol);   // 16-bit ranks; the kernel reinterprets the pointer
   mh.val = c->d_hval;
   CsrView mf = view(c);
   size_t slot = 0;
   if (SCATTER) DSGD_TRY(prof_begin(c, &slot));
-  hipLaunchKernelGGL((dsgd_wseg_kernel<SCATTER, false, 4, true>), grid, dim3(1024), lds, c->stream, mh, mf, c->d_wtiles,
-                     c->d_wmeta, c->d_w, c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, main_scale, c->d_coef8,
-                     c->dp, 0, c->d_wlong_rows, SCATTER ? c->d_part : nullptr, c->part_stride, c->d_dcold, c->fix_scale);
+  hipLaunchKernelGGL(dsgd_wseg_kernel<SCATTER>, grid, dim3(1024), lds, c->stream, mh, mf, c->d_wtiles, c->d_wmeta, c->d_w,
+                     c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, main_scale, c->d_coef8, c->d_wlong_rows,
+                     SCATTER ? c->d_part : nullptr, c->part_stride, c->d_dcold, c->fix_scale);
   HIP_TRY(hipGetLastError());
   if (SCATTER) DSGD_TRY(prof_end(c, slot));
   if (!SCATTER) return DSGD_OK;
-  c->last_grad_kernel = "dsgd_wseg_kernel<true, false, 4, true>";
+  c->last_grad_kernel = "dsgd_wseg_kernel<true>";
   if (cold) {
     size_t slot_g = 0;
     DSGD_TRY(prof_begin(c, &slot_g, 2));
-    if ((c->cold8 & 2) && c->cold_packed)
-      hipLaunchKernelGGL(dsgd_cgrad8_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, cv,
-                         c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H, nc_lds, c->fix_scale,
-                         c->d_partc, c->partc_stride, nc > nc_lds ? 1 : 0);
-    else if (c->cold8 & 2)
-      hipLaunchKernelGGL(dsgd_cgrad8_kernel<false>, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, cv,
-                         c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H, nc_lds, c->fix_scale,
-                         c->d_partc, c->partc_stride, nc > nc_lds ? 1 : 0);
-    else if (c->cold_packed)
+    if (c->cold_packed)
       hipLaunchKernelGGL(dsgd_cgrad_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, cv,
                          c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H, nc_lds, c->fix_scale,
                          c->d_partc, c->partc_stride, nc > nc_lds ? 1 : 0);
@@ -1269,27 +1012,12 @@ static int launch_split(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
     HIP_TRY(hipGetLastError());
     DSGD_TRY(prof_end(c, slot_g));
   }
-  c->fused_apply_pending = false;
-  if (c->fuse_apply) {
-    // the exact column sums of every hosted worker go straight into regularise + sum (+ mean + update + next s when
-    // there are no peers): one launch instead of dsgd_fix_reduce_kernel + regularise + sum (+ apply); g itself is never
-    // materialised
-    DSGD_TRY(ensure_redpart(c));
-    c->fused_args = {hg, (int)grid.x, H, cold ? nc_lds : 0, (int)gridc.x, 1.0 / (double)main_scale, 1.0 / (double)c->fix_scale};
-    c->fused_apply_pending = true;   // launched by launch_finish_sync, which knows lr
-    return DSGD_OK;
-  }
-  hipLaunchKernelGGL(dsgd_fix_reduce_kernel, dim3((c->dp + 63) / 64, n_workers), dim3(1024), 0, c->stream, c->d_g64, c->d_g,
-                     (long long)c->dp, c->dp, hg, c->d_part, c->part_stride, (int)grid.x, H, cold ? nc_lds : 0, c->d_partc,
-                     c->partc_stride, (int)gridc.x, 1.0 / (double)main_scale, 1.0 / (double)c->fix_scale);
-  HIP_TRY(hipGetLastError());
+  // the exact column sums of every hosted worker go straight into regularise + sum (+ mean + update + next s when
+  // there are no peers): g itself is never materialised
+  DSGD_TRY(ensure_redpart(c));
+  c->fused_args = {hg, (int)grid.x, H, cold ? nc_lds : 0, (int)gridc.x, 1.0 / (double)main_scale, 1.0 / (double)c->fix_scale};
+  c->fused_apply_pending = true;   // launched by launch_finish_sync, which knows lr
   return DSGD_OK;
-}
-
-template <bool SCATTER>
-static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& segs) {
-  if (c->stream_mode == 4) return launch_split<SCATTER>(c, segs);
-  return launch_wseg<SCATTER>(c, segs);
 }
 
 static int hog_raise_stop(dsgd_ctx* c);
@@ -1311,8 +1039,7 @@ static bool list_fits_staged(const dsgd_ctx* c, const int32_t* idx, long long n)
 static bool plan_kernel_ok(const dsgd_ctx* c, long long step_rows, int n_workers) {
   // (several hosted workers: their batches would run one after the other in the one workgroup -- 44 us for 3 x 100 --
   //  while dsgd_mb_grad_kernel gives every worker its own workgroups: 32 us with the four-launch finish, less fused)
-  return c->plan_kernel && !c->comm && n_workers == 1 && step_rows <= c->plan_max_rows &&
-         !(c->cfg.flags & (DSGD_F_FORCE_TILED | DSGD_F_FORCE_ROWS));
+  return c->plan_kernel && !c->comm && n_workers == 1 && step_rows <= c->plan_max_rows;
 }
 static int launch_plan_kernel(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, long long step_begin,
                               long long step_end, float lr) {
@@ -1383,6 +1110,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (!cfg || !out) return fail(DSGD_EINVAL, "null argument");
   if (cfg->n_features < 1) return fail(DSGD_EINVAL, "n_features must be >= 1");
   if (!(cfg->lambda == cfg->lambda)) return fail(DSGD_EINVAL, "lambda is NaN");
+  if (cfg->flags != DSGD_F_DEFAULT) return fail(DSGD_EINVAL, "unknown flags 0x%x (none are defined)", cfg->flags);
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
     return fail(DSGD_EUNSUPPORTED, "no HIP device visible: libdsgd_hip has no CPU fallback");
@@ -1424,56 +1152,20 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (rc) return bail(rc);
   rc = set_identity_perm(c);
   if (rc) return bail(rc);
-  // LDS tile split of the tiled gradient kernel (tunable for experiments; hw + hg <= 40960 floats)
-  if (const char* e = getenv("DSGD_HW")) c->hw = atoi(e);
-  if (const char* e = getenv("DSGD_HG")) c->hg = atoi(e);
-  if (const char* e = getenv("DSGD_TILED_MIN")) c->tiled_min = atoll(e);
-  if (cfg->flags & DSGD_F_FORCE_TILED) c->tiled_min = 0;
-  if (cfg->flags & DSGD_F_FORCE_ROWS) c->tiled_min = (long long)1 << 62;
-  c->hw = std::max(0, std::min(c->hw, c->dp));
-  c->hg = std::max(0, std::min(c->hg, c->dp));
-  if (c->hw + c->hg > DSGD_LDS_FLOATS) return bail(fail(DSGD_EINVAL, "DSGD_HW + DSGD_HG exceed %d floats of LDS", DSGD_LDS_FLOATS));
   c->hw_eval = std::min(c->dp, DSGD_LDS_FLOATS);
-  if (const char* e = getenv("DSGD_STREAM")) {   // 0: row-wise kernels only, 3: wave tiles + gathers, 4: split matrix
-    c->stream_ranges = atoi(e) != 0;
-    if (atoi(e) == 3 || atoi(e) == 4) c->stream_mode = atoi(e);
-  }
-  if (const char* e = getenv("DSGD_EPI")) c->use_part = atoi(e) != 0;
-  if (const char* e = getenv("DSGD_DBG")) c->dbg = atoi(e);
-  if (const char* e = getenv("DSGD_FIX_SHIFT")) c->max_shift = std::max(8, std::min(FIX_SHIFT, atoi(e)));
-  if (const char* e = getenv("DSGD_FIX_BOUND")) c->fix_bound = atoi(e) != 0;
-  if (const char* e = getenv("DSGD_FUSE_APPLY")) c->fuse_apply = atoi(e) != 0;
-  if (const char* e = getenv("DSGD_COLD8")) c->cold8 = atoi(e);
-  if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;
-  if (const char* e = getenv("DSGD_MB_KERNEL")) c->mb_kernel = atoi(e) != 0;
-  if (const char* e = getenv("DSGD_HOG_HL")) c->hog_hl = std::max(4, atoi(e)) & ~3;
-  if (const char* e = getenv("DSGD_HOG_WL")) c->hog_wl = std::max(0, atoi(e)) & ~255;
-  if (sizeof(float) * (size_t)(c->hog_hl + c->hog_wl + 4096) > 156 * 1024) {   // (tables, bitmap: 4 KiB)
-    c->hog_hl = HOG_HL;
-    c->hog_wl = HOG_WL;
-  }
-  if (const char* e = getenv("DSGD_PLAN_MAX_ROWS")) c->plan_max_rows = std::max(1LL, atoll(e));
+  // Switches that stay: one per live decision (A/B measurements, tests that force a path), all read once here.
+  if (const char* e = getenv("DSGD_FIX_SHIFT")) c->max_shift = std::max(8, std::min(FIX_SHIFT, atoi(e)));   // cap of the fixed-point shift
+  if (const char* e = getenv("DSGD_FIX_BOUND")) c->fix_bound = atoi(e) != 0;      // 0: data-independent bound only
+  if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;  // 0: small batches through the multi-workgroup kernel
+  if (const char* e = getenv("DSGD_HSPLIT")) c->hsplit = atoi(e);                 // hot/cold split rank (tests: wide models)
   if (getenv("DSGD_PLAN_PROF") && atoi(getenv("DSGD_PLAN_PROF"))) {
     HIP_TRY_B(hipMalloc(&c->d_tprof, sizeof(unsigned long long) * 16));
     HIP_TRY_B(hipMemsetAsync(c->d_tprof, 0, sizeof(unsigned long long) * 16, c->stream));
   }
-  if (c->dbg) c->stream_mode = 3;   // the ablation build exists for the mode-3 kernel
-  if (const char* e = getenv("DSGD_HW_W")) c->hw_w = atoi(e);
-  if (const char* e = getenv("DSGD_HG_W")) c->hg_w = atoi(e);
-  c->hw_w = std::max(0, std::min(c->hw_w, c->dp));
-  c->hg_w = std::max(0, std::min(c->hg_w, c->dp));
-  c->hw_we = std::min(c->hw_we, c->dp);
-  if (c->hw_w + c->hg_w > DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64)
-    return bail(fail(DSGD_EINVAL, "DSGD_HW_W + DSGD_HG_W exceed %d floats of LDS", DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64));
-  if (const char* e = getenv("DSGD_HSPLIT")) c->hsplit = atoi(e);
   c->hsplit = std::max(1, std::min(c->hsplit, (DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64) / 2));   // (< 65536: 16-bit ranks)
   if (c->hsplit >= 8) c->hsplit &= ~3;   // 16-byte aligned tile boundaries: the LDS tiles are staged / written back in 16-byte pieces
   const int lds_max = DSGD_LDS_FLOATS * (int)sizeof(float);
 #define DSGD_ATTR(fn) HIP_TRY_B(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max))
-  DSGD_ATTR(dsgd_grad_tiled_kernel<64>);
-  DSGD_ATTR(dsgd_grad_tiled_kernel<32>);
-  DSGD_ATTR(dsgd_grad_tiled_kernel<16>);
-  DSGD_ATTR(dsgd_grad_tiled_kernel<8>);
   DSGD_ATTR(dsgd_eval_kernel<64>);
   DSGD_ATTR(dsgd_eval_kernel<32>);
   DSGD_ATTR(dsgd_eval_kernel<16>);
@@ -1482,21 +1174,13 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_hogwild_kernel);
   DSGD_ATTR(dsgd_mb_grad_kernel);
   DSGD_ATTR(dsgd_plan_kernel);
-  DSGD_ATTR((dsgd_wseg_kernel<true, false, 4, false>));
-  DSGD_ATTR((dsgd_wseg_kernel<true, true, 4, false>));
-  DSGD_ATTR((dsgd_wseg_kernel<false, false, 4, false>));
-  DSGD_ATTR((dsgd_wseg_kernel<false, true, 4, false>));
-  DSGD_ATTR((dsgd_wseg_kernel<true, false, 4, true>));
-  DSGD_ATTR((dsgd_wseg_kernel<false, false, 4, true>));
+  DSGD_ATTR(dsgd_wseg_kernel<true>);
+  DSGD_ATTR(dsgd_wseg_kernel<false>);
   DSGD_ATTR(dsgd_wseg_bound_kernel);
-  DSGD_ATTR(dsgd_cdot_kernel<true>);
-  DSGD_ATTR(dsgd_cdot_kernel<false>);
   DSGD_ATTR(dsgd_cgrad_kernel<true>);
   DSGD_ATTR(dsgd_cgrad_kernel<false>);
   DSGD_ATTR(dsgd_cdot8_kernel<true>);
   DSGD_ATTR(dsgd_cdot8_kernel<false>);
-  DSGD_ATTR(dsgd_cgrad8_kernel<true>);
-  DSGD_ATTR(dsgd_cgrad8_kernel<false>);
 #undef DSGD_ATTR
   HIP_TRY_B(hipStreamSynchronize(c->stream));
 #undef HIP_TRY_B
@@ -1512,9 +1196,11 @@ int dsgd_destroy(dsgd_ctx* c) {
   // synchronises the device -- it would wait forever on that kernel, or free memory the kernel still reads).
   if (c->async_stream) {
     (void)hog_raise_stop(c);
+    if (c->exch_thread.joinable()) c->exch_thread.join();
     (void)hipStreamSynchronize(c->async_stream);
     c->async_running = false;
   }
+  if (c->upd_stream) (void)hipStreamSynchronize(c->upd_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm && rccl::available()) rccl::CommDestroy(c->comm);
   for (auto& e : c->prof_ev) {
@@ -1537,11 +1223,7 @@ int dsgd_destroy(dsgd_ctx* c) {
   (void)hipFree(c->d_idx);
   (void)hipFree(c->d_segs);
   (void)hipFree(c->d_ssegs);
-  (void)hipFree(c->d_cold_ptr);
-  (void)hipFree(c->d_cold_row);
-  (void)hipFree(c->d_cold_val);
   (void)hipFree(c->d_coef8);
-  (void)hipFree(c->d_coefp);
   (void)hipFree(c->d_wtiles);
   (void)hipFree(c->d_wmeta);
   (void)hipFree(c->d_wlong_rows);
@@ -1563,6 +1245,10 @@ int dsgd_destroy(dsgd_ctx* c) {
   pin_free(c->pin_idx);
   pin_free(c->pin_segs);
   pin_free(c->pin_out);
+  pin_free(c->pin_upd);
+  (void)hipFree(c->d_upd_key);
+  (void)hipFree(c->d_upd_dv);
+  if (c->upd_stream) (void)hipStreamDestroy(c->upd_stream);
   if (c->async_stream) (void)hipStreamDestroy(c->async_stream);
   if (c->query_stream) (void)hipStreamDestroy(c->query_stream);
   (void)hipFree(c->d_hog);
@@ -1690,13 +1376,7 @@ int dsgd_load_csr(dsgd_ctx* c, int64_t n_rows, const int64_t* row_ptr_in, const 
   c->h_row_ptr.assign(row_ptr, row_ptr + n_rows + 1);
   c->h_label.assign(label, label + n_rows);
   c->ssegs_last.clear();
-  // mode 3 tiles cover the CSR as loaded; mode 4 tiles cover the hot stream and are built with the layout
-  if (c->stream_mode == 3) {
-    HostTiles ht;
-    c->wlong_rows.clear();
-    build_wave_tiles(c->h_row_ptr.data(), n_rows, c->h_label.data(), ht, &c->wlong_rows, false);
-    DSGD_TRY(upload_wave_tiles(c, ht));
-  }
+  // (the wave tiles cover the hot stream and are built with the layout, at the first compute call)
   const double mean = (double)nnz / (double)n_rows;
   c->group = mean > 192.0 ? 64 : (mean > 96.0 ? 32 : (mean > 12.0 ? 16 : 8));
   return DSGD_OK;
@@ -1851,7 +1531,7 @@ int dsgd_gradient(dsgd_ctx* c, const float* w, const int32_t* idx, int64_t n, fl
   long long mx = 0, tot = 0;
   const int64_t nn = n;
   DSGD_TRY(stage_lists(c, &idx, &nn, 1, &mx, &tot));
-  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, 1, mx, tot));
+  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, 1, mx));
   hipLaunchKernelGGL(dsgd_regularize_kernel, dim3((c->dp + 1023) / 1024, 1), dim3(1024), 0, c->stream, c->d_g,
                      (long long)c->dp, c->dp, c->d_sc);
   HIP_TRY(hipGetLastError());
@@ -1881,9 +1561,8 @@ int dsgd_apply(dsgd_ctx* c, const float* g_mean, float lr) {
   HIP_TRY(hipMemcpyAsync(c->d_io, g_mean, sizeof(float) * c->dp, hipMemcpyHostToDevice, c->stream));
   DSGD_TRY(launch_permute_in(c, c->d_io, c->d_gsum));
   DSGD_TRY(ensure_redpart(c));
-  hipLaunchKernelGGL(dsgd_apply_cols_kernel<false>, dim3((c->dp + FRA_COLS - 1) / FRA_COLS), dim3(256), 0, c->stream, c->d_w,
-                     c->d_gsum, c->d_gsum, (long long)c->dp, 1, c->d_ds, c->dp, 1.0f, lr, (float)c->cfg.lambda, c->d_sc,
-                     c->d_redpart);
+  hipLaunchKernelGGL(dsgd_apply_cols_kernel, dim3((c->dp + FRA_COLS - 1) / FRA_COLS), dim3(256), 0, c->stream, c->d_w,
+                     c->d_gsum, c->d_ds, c->dp, 1.0f, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->s_dirty = false;
@@ -1929,7 +1608,7 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
   DSGD_TRY(ensure_s(c));
   DSGD_TRY(reset_counters(c));
   DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
-  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, n_workers, mx, tot, true));
+  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, n_workers, mx, true));
   DSGD_TRY(launch_finish_sync(c, n_workers, lr));
   return finish_stats(c, stats, tot);
 }
@@ -1956,14 +1635,14 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
   DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_g(c, n_workers));
   DSGD_TRY(ensure_s(c));
-  if (c->stream_ranges && tot >= c->tiled_min) {
+  if (tot >= c->stream_min) {
     // whole contiguous ranges: the nnz-streaming kernel (coalesced 16-byte loads, no per-row latency chain)
     std::vector<StreamSeg> ssegs(n_workers);
     for (int k = 0; k < n_workers; ++k) ssegs[k] = make_sseg(row_begin[k], row_end[k]);
     DSGD_TRY(launch_stream<true>(c, ssegs));  // (the profiling events bracket the main kernel only)
   } else {
     DSGD_TRY(upload_segs(c, segs));
-    DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx, tot, true));
+    DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx, true));
   }
   DSGD_TRY(launch_finish_sync(c, n_workers, lr));
   *total = tot;
@@ -2003,7 +1682,7 @@ int dsgd_synchronize(dsgd_ctx* c, dsgd_batch_stats* stats) {
   DSGD_TRY(reset_counters(c));
   if (err & 2)
     return fail(DSGD_ESTATE, "fixed-point gradient accumulator left its safe band; the steps since the last "
-                             "synchronize are invalid (rerun with DSGD_STREAM=0)");
+                             "synchronize are invalid");
   if (err) return fail(DSGD_ERANGE, "sample index / key outside the loaded data");
   if (stats) {
     stats->n_active = act;
@@ -2093,8 +1772,7 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
     long long mx = 0;
     for (int k = 0; k < p->n_workers; ++k)
       mx = std::max<long long>(mx, p->offsets[s * p->n_workers + k + 1] - p->offsets[s * p->n_workers + k]);
-    const long long tot_s = p->offsets[(s + 1) * p->n_workers] - p->offsets[s * p->n_workers];
-    DSGD_TRY(launch_grad(c, p->d_idx, segs, p->n_workers, mx, tot_s, true));
+    DSGD_TRY(launch_grad(c, p->d_idx, segs, p->n_workers, mx, true));
     DSGD_TRY(launch_finish_sync(c, p->n_workers, lr));
     c->pending_samples += p->offsets[(s + 1) * p->n_workers] - p->offsets[s * p->n_workers];
   }
@@ -2165,7 +1843,7 @@ int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_en
   DSGD_TRY(ensure_s(c));  // also refreshes |w|^2
   if (c->async_running) c->s_dirty = true;
   DSGD_TRY(reset_counters(c));
-  if (!c->async_running && c->stream_ranges && row_end - row_begin >= 4096) {
+  if (!c->async_running && row_end - row_begin >= 4096) {
     std::vector<StreamSeg> ssegs(1, make_sseg(row_begin, row_end));
     DSGD_TRY(launch_stream<false>(c, ssegs));
   } else {
@@ -2220,7 +1898,7 @@ int dsgd_async_step(dsgd_ctx* c, const int32_t* idx, int64_t n, float lr, float*
   long long mx = 0, tot = 0;
   const int64_t nn = n;
   DSGD_TRY(stage_lists(c, &idx, &nn, 1, &mx, &tot));
-  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, 1, mx, tot));
+  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, 1, mx));
   hipLaunchKernelGGL(dsgd_async_finish_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_g, c->dp, c->d_ds, (float)n,
                      lr, (float)c->cfg.lambda, delta_out ? c->d_tmp : (float*)nullptr, c->d_sc);
   HIP_TRY(hipGetLastError());
@@ -2236,31 +1914,47 @@ int dsgd_update_grad(dsgd_ctx* c, const int32_t* key, const float* dv, int64_t n
   DSGD_TRY(check_ctx(c));
   if (nnz < 0 || (nnz > 0 && (!key || !dv))) return fail(DSGD_EINVAL, "bad update arguments");
   if (nnz == 0) return DSGD_OK;
+  for (int64_t i = 0; i < nnz; ++i)   // the keys are host data: validated here, no device-side error flag to wait for
+    if (key[i] < 0 || key[i] >= c->dp) return fail(DSGD_ERANGE, "key %d at position %lld outside [0, %d]", key[i], (long long)i, c->dp - 1);
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
-  int* d_key = nullptr;
-  float* d_dv = nullptr;
-  HIP_TRY(hipMalloc(&d_key, sizeof(int) * (size_t)nnz));
-  hipError_t e = hipMalloc(&d_dv, sizeof(float) * (size_t)nnz);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_key, key, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_dv, dv, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) {
-    reset_counters(c);
-    int blocks = (int)std::min<long long>((nnz + 255) / 256, 2048);
-    hipLaunchKernelGGL(dsgd_update_grad_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_w, c->d_perm, d_key, d_dv,
-                       (long long)nnz, c->dp, c->d_sc);
-    // the Sparse filter pass rewrites every w[j] non-atomically: skipped while the lock-free engine is adding to w
-    if (!c->async_running)
-      hipLaunchKernelGGL(dsgd_filter_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, c->d_w, c->dp);
-    e = hipGetLastError();
+  // The reference applies a peer's update while its own asyncTask runs (core/Slave.scala:177-185 is an RPC handler on
+  // another pool thread).  Here: pinned staging + a persistent device buffer (hipMalloc / hipFree per call -- hipFree
+  // synchronises the DEVICE, i.e. waits for the persistent engine to reach its update budget), the copy and the kernel
+  // on a side stream while the engine is resident, atomic adds to w, and the engine's incremental regulariser scalar
+  // told about the foreign update.
+  if (!c->upd_stream) HIP_TRY(hipStreamCreateWithFlags(&c->upd_stream, hipStreamNonBlocking));
+  if (!c->d_upd_key) {
+    const long long cap = std::max<long long>(c->dp, 4096);   // a Sparse delta holds at most D + 1 entries; longer inputs go in pieces
+    HIP_TRY(hipMalloc(&c->d_upd_key, sizeof(int) * (size_t)cap));
+    HIP_TRY(hipMalloc(&c->d_upd_dv, sizeof(float) * (size_t)cap));
+    c->upd_cap = cap;
   }
-  int rc = read_scalars(c);
-  (void)hipFree(d_key);
-  (void)hipFree(d_dv);
+  const bool live = c->async_running;
+  hipStream_t st = live ? c->upd_stream : c->stream;
+  for (int64_t o = 0; o < nnz; o += c->upd_cap) {
+    const long long n = std::min<long long>(c->upd_cap, nnz - o);
+    DSGD_TRY(pin_acquire(c->pin_upd, (sizeof(int) + sizeof(float)) * (size_t)n));
+    int* pk = static_cast<int*>(c->pin_upd.p);
+    float* pv = reinterpret_cast<float*>(pk + n);
+    memcpy(pk, key + o, sizeof(int) * (size_t)n);
+    memcpy(pv, dv + o, sizeof(float) * (size_t)n);
+    HIP_TRY(hipMemcpyAsync(c->d_upd_key, pk, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->d_upd_dv, pv, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
+    DSGD_TRY(pin_sent(c, c->pin_upd, st));
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 64);
+    hipLaunchKernelGGL(dsgd_update_grad_kernel, dim3(blocks), dim3(256), 0, st, c->d_w, c->d_perm, c->d_ds, c->d_upd_key,
+                       c->d_upd_dv, n, (float)c->cfg.lambda, live ? &c->d_hog->s_reg : (float*)nullptr);
+    HIP_TRY(hipGetLastError());
+  }
+  if (!live) {
+    // the Sparse filter pass rewrites every w[j] non-atomically: only while no engine is adding to w
+    hipLaunchKernelGGL(dsgd_filter_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, st, c->d_w, c->dp);
+    HIP_TRY(hipGetLastError());
+  }
   c->s_dirty = true;
-  if (e != hipSuccess) return fail(DSGD_EHIP, "update_grad: %s", hipGetErrorString(e));
-  DSGD_TRY(rc);
-  return check_err_flag(c);
+  HIP_TRY(hipStreamSynchronize(st));   // the update is applied when the call returns (the RPC's Ack, proto.proto:40)
+  return DSGD_OK;
 }
 
 // ---- Hogwild persistent engine -------------------------------------------------------------------------
@@ -2300,6 +1994,23 @@ static int hog_launch(dsgd_ctx* c, long long max_updates) {
   a.wl = std::min(c->hog_wl, c->dp) & ~255;
   const size_t lds = sizeof(float) * (size_t)hog_lds_words(a.hl, a.wl, c->dp);
   hipLaunchKernelGGL(dsgd_hogwild_kernel, dim3(c->hog_n), dim3(HOG_THREADS), lds, c->async_stream, a);
+  HIP_TRY(hipGetLastError());
+  return DSGD_OK;
+}
+
+// one round of the cross-GPU asynchronous mode on async_stream: local updates up to `upto`, then
+// d_local = w_prev - w (what this replica subtracted since the last exchange); all-reduce; the peers' part
+// d_sum - d_local is subtracted on top (a replica applies its own updates as it goes and its peers' updates when they
+// arrive: core/Slave.scala:99-105,177-185).  With one rank the peers' part is exactly zero.
+static int exchange_round(dsgd_ctx* c, long long upto) {
+  const int blocks = (c->dp + 1023) / 1024;
+  DSGD_TRY(hog_launch(c, upto));
+  hipLaunchKernelGGL(dsgd_exchange_delta_kernel, dim3(blocks), dim3(1024), 0, c->async_stream, c->d_w, c->d_wprev,
+                     c->d_wdelta, c->d_wdelta + c->dp, c->dp);
+  HIP_TRY(hipGetLastError());
+  RCCL_TRY(rccl::AllReduce(c->d_wdelta, c->d_wdelta, (size_t)c->dp, rccl::kFloat32, rccl::kSum, c->comm, c->async_stream));
+  hipLaunchKernelGGL(dsgd_exchange_apply_kernel, dim3(1), dim3(1024), 0, c->async_stream, c->d_w, c->d_wprev,
+                     c->d_wdelta, c->d_wdelta + c->dp, c->d_ds, c->dp, (float)c->cfg.lambda, c->d_hog);
   HIP_TRY(hipGetLastError());
   return DSGD_OK;
 }
@@ -2379,23 +2090,26 @@ int dsgd_async_start(dsgd_ctx* c, const int64_t* assigned_begin, const int64_t* 
   c->hog_lr = lr;
   c->hog_seed = seed;
   c->hog_bug = positional_bug;
+  c->exch_rc = DSGD_OK;
+  c->exch_err.clear();
   if (!exchange) {
     DSGD_TRY(hog_launch(c, max_updates));
   } else {
-    const int blocks = (c->dp + 1023) / 1024;
-    for (long long r = 0; r < n_rounds; ++r) {
-      DSGD_TRY(hog_launch(c, std::min<long long>(max_updates, (r + 1) * c->exchange_every)));
-      // d_local = w_prev - w (what this replica subtracted since the last exchange); all-reduce; the peers' part
-      // d_sum - d_local is subtracted on top (a replica applies its own updates as it goes and its peers' updates
-      // when they arrive: core/Slave.scala:99-105,177-185).  With one rank the peers' part is exactly zero.
-      hipLaunchKernelGGL(dsgd_exchange_delta_kernel, dim3(blocks), dim3(1024), 0, c->async_stream, c->d_w, c->d_wprev,
-                         c->d_wdelta, c->d_wdelta + c->dp, c->dp);
-      HIP_TRY(hipGetLastError());
-      RCCL_TRY(rccl::AllReduce(c->d_wdelta, c->d_wdelta, (size_t)c->dp, rccl::kFloat32, rccl::kSum, c->comm, c->async_stream));
-      hipLaunchKernelGGL(dsgd_exchange_apply_kernel, dim3(1), dim3(1024), 0, c->async_stream, c->d_w, c->d_wprev,
-                         c->d_wdelta, c->d_wdelta + c->dp, c->d_ds, c->dp, (float)c->cfg.lambda, c->d_hog);
-      HIP_TRY(hipGetLastError());
-    }
+    // The rounds are enqueued by a helper thread: a HIP queue holds a bounded number of launches (and a collective
+    // may block its caller), so enqueuing thousands of rounds here would hold the context's mutex for most of the run
+    // and make dsgd_async_updates / dsgd_async_stop wait behind it.
+    if (c->exch_thread.joinable()) c->exch_thread.join();
+    c->exch_done.store(false);
+    const long long every = c->exchange_every;
+    c->exch_thread = std::thread([c, n_rounds, max_updates, every]() {
+      int rc = hipSetDevice(c->cfg.device) == hipSuccess ? DSGD_OK : fail(DSGD_EHIP, "hipSetDevice in the exchange thread");
+      for (long long r = 0; r < n_rounds && rc == DSGD_OK; ++r) rc = exchange_round(c, std::min<long long>(max_updates, (r + 1) * every));
+      if (rc != DSGD_OK) {
+        c->exch_rc = rc;
+        c->exch_err = g_err;   // (thread-local message of THIS thread: carried to the joining caller)
+      }
+      c->exch_done.store(true);
+    });
   }
   c->async_running = true;
   c->s_dirty = true;
@@ -2422,7 +2136,7 @@ int dsgd_async_updates(dsgd_ctx* c, int64_t* updates, int32_t* running) {
   }
   DSGD_TRY(async_refresh(c));
   if (updates) *updates = (int64_t)c->h_hog->updates;
-  const bool busy = c->async_running && hipStreamQuery(c->async_stream) == hipErrorNotReady;
+  const bool busy = c->async_running && (!c->exch_done.load() || hipStreamQuery(c->async_stream) == hipErrorNotReady);
   if (running) *running = busy ? 1 : 0;
   return DSGD_OK;
 }
@@ -2436,9 +2150,12 @@ static int hog_raise_stop(dsgd_ctx* c) {
 }
 
 static int async_join(dsgd_ctx* c) {
+  if (c->exch_thread.joinable()) c->exch_thread.join();   // (it never takes the context's mutex)
   HIP_TRY(hipStreamSynchronize(c->async_stream));
+  if (c->upd_stream) HIP_TRY(hipStreamSynchronize(c->upd_stream));
   c->async_running = false;
   c->s_dirty = true;  // w moved under the scalar the synchronous kernels cache
+  if (c->exch_rc != DSGD_OK) return fail(c->exch_rc, "exchange round: %s", c->exch_err.c_str());
   DSGD_TRY(async_refresh(c));
   if (c->h_hog->err) return fail(DSGD_ERANGE, "the lock-free engine sampled a row outside the loaded data");
   return DSGD_OK;
@@ -2451,6 +2168,24 @@ int dsgd_async_stop(dsgd_ctx* c) {  // ref: SlaveImpl.stopAsync, core/Slave.scal
   if (!c->async_running) return DSGD_OK;
   DSGD_TRY(hog_raise_stop(c));
   return async_join(c);
+}
+
+int dsgd_async_regulariser(dsgd_ctx* c, double* s_engine, double* s_exact) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(require_ds(c));
+  if (!c->d_hog) return fail(DSGD_ESTATE, "the lock-free engine has never been started on this context");
+  DSGD_TRY(async_refresh(c));
+  if (s_engine) *s_engine = (double)c->h_hog->s_reg;
+  // the same summation the synchronous kernels use (fra_scalars), from the weights as they are now; the engine keeps its
+  // own scalar (HogState), so refreshing the synchronous one disturbs nothing
+  c->s_dirty = true;
+  DSGD_TRY(ensure_s(c));
+  DSGD_TRY(read_scalars(c));
+  if (c->async_running) c->s_dirty = true;
+  if (s_exact) *s_exact = (double)c->h_sc->s_reg;
+  return DSGD_OK;
 }
 
 int dsgd_async_wait(dsgd_ctx* c) {
@@ -2548,7 +2283,7 @@ int dsgd_range_nnz(dsgd_ctx* c, int64_t row_begin, int64_t row_end, int64_t* nnz
   DSGD_TRY(prepare_layout(c));
   if (nnz) *nnz = c->h_row_ptr[(size_t)row_end] - c->h_row_ptr[(size_t)row_begin];
   if (cold_nnz) {
-    const bool split = c->stream_mode == 4 && c->stream_ranges && c->h_crow_ptr.size() == (size_t)c->n_rows + 1;
+    const bool split = c->h_crow_ptr.size() == (size_t)c->n_rows + 1;
     *cold_nnz = split ? c->h_crow_ptr[(size_t)row_end] - c->h_crow_ptr[(size_t)row_begin] : 0;
   }
   return DSGD_OK;
@@ -2571,9 +2306,21 @@ int dsgd_tuning_info(dsgd_ctx* c, int32_t* vals, int32_t n) {
   DSGD_TRY(check_ctx(c));
   if (!vals || n < 0 || n > 6) return fail(DSGD_EINVAL, "bad tuning_info arguments");
   std::lock_guard<std::mutex> lk(c->mu);
-  const int32_t all[6] = {c->stream_ranges ? c->stream_mode : 0, std::min(c->hsplit, c->dp), c->last_shift,
+  const int32_t all[6] = {4 /* split layout: the only one */, std::min(c->hsplit, c->dp), c->last_shift,
                           c->cold_packed ? 1 : 0, c->plan_kernel ? 1 : 0, c->fix_bound ? 1 : 0};
   for (int i = 0; i < n; ++i) vals[i] = all[i];
+  return DSGD_OK;
+}
+
+int dsgd_column_ranks(dsgd_ctx* c, int32_t* rank_of_key) {
+  DSGD_TRY(check_ctx(c));
+  if (!rank_of_key) return fail(DSGD_EINVAL, "null rank_of_key");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(require_data(c));
+  DSGD_TRY(require_sync_mode(c));
+  DSGD_TRY(prepare_layout(c));
+  HIP_TRY(hipMemcpy(rank_of_key, c->d_perm, sizeof(int) * (size_t)c->dp, hipMemcpyDeviceToHost));
   return DSGD_OK;
 }
 

@@ -165,115 +165,6 @@ __device__ __forceinline__ float row_dot(const CsrView& m, long long start, long
   return group_sum<G>(acc);
 }
 
-// ---- K1a: gated sub-gradient sum, small batches -----------------------------------------------------
-// g_k += sum_{i in batch_k, y_i (x_i . w) >= 0} y_i x_i
-// ref: core/Slave.scala:147-153 (per-sample backward + Vec.sum), core/ml/SparseSVM.scala:26-29.
-// grid = (blocks, n_workers); a group of G lanes walks the worker's items with a grid stride.
-// Batches of a few hundred rows (the reference's batch-size 100-200) touch ~10^4 non-zeros: the
-// scatter goes straight to L2 atomics and no LDS tile is staged.
-template <int G>
-__global__ void __launch_bounds__(256) dsgd_grad_rows_kernel(CsrView m, const float* __restrict__ w, float* g_base,
-                                                            long long g_stride, const int* __restrict__ idx,
-                                                            const WorkSeg* __restrict__ segs, DevScalars* sc) {
-  constexpr int UNR = 4;
-  const int worker = blockIdx.y;
-  const WorkSeg seg = segs[worker];
-  float* g = g_base + (long long)worker * g_stride;
-  const int sub = threadIdx.x % G;
-  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
-  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
-  unsigned int active_local = 0;
-  for (long long t = seg.begin + group; t < seg.end; t += n_groups) {
-    const long long row = idx ? (long long)idx[t] : t;
-    if (row < 0 || row >= m.n_rows) {
-      if (sub == 0) atomicOr(&sc->err, 1);
-      continue;
-    }
-    const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
-    const float y = (float)m.label[row];
-    RowRegs<G, UNR> r;
-    const float d = row_dot<G, UNR, false>(m, start, end, nullptr, w, 0, sub, r);
-    if (y * d < 0.0f) continue;  // zerosLike (ref: SparseSVM.scala:28)
-    if (sub == 0) active_local++;
-#pragma unroll
-    for (int k = 0; k < UNR; ++k) {
-      const float xv = filt(r.v[k] * y);  // x * y (ref: SparseSVM.scala:28, math/Vec.scala:42)
-      if (r.c[k] >= 0 && xv != 0.0f) atomicAdd(&g[r.c[k]], xv);
-    }
-    for (long long p = start + sub + UNR * G; p < end; p += G) {
-      const float xv = filt(m.val[p] * y);
-      if (xv != 0.0f) atomicAdd(&g[m.col[p]], xv);
-    }
-  }
-  // one atomic per wave for the Kamon-style counters (ref: core/Slave.scala:145,150)
-  active_local = wave_sum_u32(active_local);
-  if ((threadIdx.x & 63) == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
-}
-
-// ---- K1b: gated sub-gradient sum, large batches (the HBM-bound configuration) ----------------------------
-// One persistent 1024-lane workgroup per CU; LDS holds gl[0..hg) (private gradient accumulator for
-// the hg hottest columns) and wl[0..hw) (the hw hottest weights).  hg + hw <= 40960 floats = 160 KiB.
-// The CSR rows are the only HBM stream; every non-zero costs one LDS read (w) and, for active
-// rows, one LDS atomic; the cold tail goes to L2.  The tile is flushed once per workgroup with
-// coalesced atomics (64 consecutive floats per wave instruction).
-template <int G>
-__global__ void __launch_bounds__(1024) dsgd_grad_tiled_kernel(CsrView m, const float* __restrict__ w, float* g_base,
-                                                              long long g_stride, const int* __restrict__ idx,
-                                                              const WorkSeg* __restrict__ segs, DevScalars* sc, int hw,
-                                                              int hg) {
-  constexpr int UNR = 4;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* gl = lds;
-  float* wl = lds + hg;
-  const int worker = blockIdx.y;
-  const WorkSeg seg = segs[worker];
-  float* g = g_base + (long long)worker * g_stride;
-  for (int j = threadIdx.x; j < hg; j += 1024) gl[j] = 0.0f;
-  for (int j = threadIdx.x; j < hw; j += 1024) wl[j] = w[j];
-  __syncthreads();
-  const int sub = threadIdx.x % G;
-  const long long group = ((long long)blockIdx.x * 1024 + threadIdx.x) / G;
-  const long long n_groups = (long long)gridDim.x * 1024 / G;
-  unsigned int active_local = 0;
-  for (long long t = seg.begin + group; t < seg.end; t += n_groups) {
-    const long long row = idx ? (long long)idx[t] : t;
-    if (row < 0 || row >= m.n_rows) {
-      if (sub == 0) atomicOr(&sc->err, 1);
-      continue;
-    }
-    const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
-    const float y = (float)m.label[row];
-    RowRegs<G, UNR> r;
-    const float d = row_dot<G, UNR, true>(m, start, end, wl, w, hw, sub, r);
-    if (y * d < 0.0f) continue;
-    if (sub == 0) active_local++;
-#pragma unroll
-    for (int k = 0; k < UNR; ++k) {
-      const float xv = filt(r.v[k] * y);
-      const int c = r.c[k];
-      if (c >= 0 && xv != 0.0f) {
-        if (c < hg) atomicAdd(&gl[c], xv);
-        else atomicAdd(&g[c], xv);
-      }
-    }
-    for (long long p = start + sub + UNR * G; p < end; p += G) {
-      const float xv = filt(m.val[p] * y);
-      const int c = m.col[p];
-      if (xv != 0.0f) {
-        if (c < hg) atomicAdd(&gl[c], xv);
-        else atomicAdd(&g[c], xv);
-      }
-    }
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < hg; j += 1024) {
-    const float v = gl[j];
-    if (v != 0.0f) atomicAdd(&g[j], v);
-  }
-  active_local = wave_sum_u32(active_local);
-  if ((threadIdx.x & 63) == 0 && active_local) atomicAdd(&sc->n_active, (unsigned long long)active_local);
-}
-
 // ---- K2: support-only scalar regulariser ------------------------------------------------------------------
 // g_k[j] += s for j in supp(g_k), s = 2*lambda*(w.ds)  (ref: SparseSVM.scala:31, math/Vec.scala:65-75)
 __global__ void __launch_bounds__(1024) dsgd_regularize_kernel(float* g_base, long long g_stride, int dp,
@@ -285,16 +176,6 @@ __global__ void __launch_bounds__(1024) dsgd_regularize_kernel(float* g_base, lo
     float v = filt(g[j]);
     if (add && v != 0.0f) v = filt(v + s);
     g[j] = v;
-  }
-}
-
-// sum of the per-worker regularised gradients hosted by this context (ref: math/Vec.scala:128-131)
-__global__ void __launch_bounds__(1024) dsgd_sum_workers_kernel(const float* g_base, long long g_stride, int n_workers,
-                                                               int dp, float* out) {
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) {
-    float a = 0.0f;
-    for (int k = 0; k < n_workers; ++k) a = filt(a + g_base[(long long)k * g_stride + j]);
-    out[j] = a;
   }
 }
 
@@ -345,16 +226,32 @@ __global__ void __launch_bounds__(1024) dsgd_async_finish_kernel(float* __restri
   }
 }
 
-// w[perm[key]] -= dv (ref: core/Slave.scala:180, core/ml/GradState.scala:8)
-__global__ void dsgd_update_grad_kernel(float* w, const int* __restrict__ perm, const int* key, const float* dv,
-                                        long long nnz, int dp, DevScalars* sc) {
+// w[perm[key]] -= dv (ref: core/Slave.scala:177-185, core/MasterAsync.scala:164-177, core/ml/GradState.scala:8).  Keys are
+// validated on the host.  Atomic adds: the update may arrive WHILE the lock-free engine is adding to the same weights
+// (the reference calls updateGrad concurrently with asyncTask by design).  s_reg != nullptr (engine running): the
+// change of the engine's incrementally kept regulariser scalar, -2 lambda sum(dv_j ds_j), is folded in with one
+// atomic per block.  256-lane blocks of a few registers: they become resident beside the engine's workgroups.
+__global__ void __launch_bounds__(256) dsgd_update_grad_kernel(float* w, const int* __restrict__ perm,
+                                                              const float* __restrict__ ds, const int* __restrict__ key,
+                                                              const float* __restrict__ dv, long long nnz, float lambda,
+                                                              float* s_reg) {
+  __shared__ float red[4];
+  float acc = 0.0f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
-    const int k = key[i];
-    if (k < 0 || k >= dp) {
-      atomicOr(&sc->err, 1);
-      continue;
-    }
-    atomicAdd(&w[perm[k]], -dv[i]);
+    const float d = dv[i];
+    if (d == 0.0f) continue;
+    const int r = perm[key[i]];
+    atomicAdd(&w[r], -d);
+    acc += d * ds[r];
+  }
+  if (!s_reg) return;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tot != 0.0f) atomicAdd(s_reg, -2.0f * lambda * tot);
   }
 }
 __global__ void dsgd_filter_kernel(float* w, int dp) {
@@ -495,20 +392,6 @@ struct StreamSeg {
   long long tile_begin, tile_end;  // tiles intersecting [row_begin, row_end)
   long long long_begin, long_end;  // wave-tile mode: range of the long-row list (rows that fit no tile)
 };
-
-// fixed point -> fp32: g[j] += (float)(g64[j] * inv_scale); g64[j] = 0   (one rounding of the exact sum)
-__global__ void __launch_bounds__(1024) dsgd_fix_finalize_kernel(long long* g64_base, float* g_base, long long g_stride,
-                                                                int dp, double inv_scale) {
-  long long* g64 = g64_base + (long long)blockIdx.y * g_stride;
-  float* g = g_base + (long long)blockIdx.y * g_stride;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < dp; j += gridDim.x * blockDim.x) {
-    const long long q = g64[j];
-    if (q != 0) {
-      g[j] += (float)((double)q * inv_scale);
-      g64[j] = 0;
-    }
-  }
-}
 
 // the same with per-workgroup partial sums: worker k owns workgroups [k * n_wg, (k + 1) * n_wg) of `part` (main
 // kernel, columns [0, hg)) and [k * n_wgc, (k + 1) * n_wgc) of `partc` (dsgd_cgrad_kernel, columns [hc, hc + nc));
@@ -712,29 +595,18 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
   fra_update_and_scalars(gsum, (float)n_workers, j, dp, w, ds, lr, lambda, sc, redpart, fred, &is_last);
 }
 
-// The update outside the fused kernel: after the all-reduce across ranks (a communicator is attached), behind the
-// gather-based kernels of DSGD_STREAM=3 / DSGD_FUSE_APPLY=0, and for dsgd_apply.  The same columns per block, the same
-// arithmetic and the same summation order of the two dot products as the fused kernel above -- a communicator of size
-// one leaves exactly the weights and the regulariser scalar of the engine without one.
-// REG: `gsum` is ONE worker's raw batch sum: the support-only regulariser is applied first (ref: SparseSVM.scala:31).
-// The n_zero per-worker gradient vectors at zero_base are cleared for the next step (gsum may be one of them).
-template <bool REG>
-__global__ void __launch_bounds__(256) dsgd_apply_cols_kernel(float* __restrict__ w, const float* gsum, float* zero_base,
-                                                             long long zero_stride, int n_zero,
+// The update outside the fused kernel: after the all-reduce across ranks (a communicator is attached) and for
+// dsgd_apply.  The same columns per block, the same arithmetic and the same summation order of the two dot products as
+// the fused kernel above -- a communicator of size one leaves exactly the weights and the regulariser scalar of the
+// engine without one.
+__global__ void __launch_bounds__(256) dsgd_apply_cols_kernel(float* __restrict__ w, const float* __restrict__ gsum,
                                                              const float* __restrict__ ds, int dp, float k_total, float lr,
                                                              float lambda, DevScalars* sc, float* __restrict__ redpart) {
   __shared__ float fred[8];
   __shared__ int is_last;
   const int j = blockIdx.x * FRA_COLS + threadIdx.x;
   const bool mine = threadIdx.x < FRA_COLS && j < dp;
-  float g = mine ? gsum[j] : 0.0f;
-  if (REG) {
-    const float s = sc->s_reg;   // (read before any block can have written the new one: see the fused kernel)
-    g = filt(g);
-    if ((s != 0.0f) && (fabsf(s) > DSGD_EPS) && g != 0.0f) g = filt(g + s);
-  }
-  if (mine)
-    for (int k = 0; k < n_zero; ++k) zero_base[(long long)k * zero_stride + j] = 0.0f;
+  const float g = mine ? gsum[j] : 0.0f;
   fra_update_and_scalars(g, k_total, j, dp, w, ds, lr, lambda, sc, redpart, fred, &is_last);
 }
 
@@ -753,100 +625,6 @@ __global__ void __launch_bounds__(256) dsgd_wstats_cols_kernel(const float* __re
     nsq = wn * wn;
   }
   fra_scalars(dot, nsq, lambda, sc, redpart, fred, &is_last);
-}
-
-// ---- cold columns (rank >= hg): transposed lists built once at layout time ------------------------------
-// fill: every non-zero of a cold column appends (row, value) to the column's list
-template <int G>
-__global__ void __launch_bounds__(256) dsgd_cold_fill_kernel(CsrView m, int hg, unsigned int* cursor, int* cold_row,
-                                                            float* cold_val) {
-  const int sub = threadIdx.x % G;
-  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
-  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
-  for (long long row = group; row < m.n_rows; row += n_groups) {
-    const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
-    for (long long p = start + sub; p < end; p += G) {
-      const int c = m.col[p];
-      if (c >= hg && fabsf(m.val[p]) > DSGD_EPS) {
-        const unsigned int pos = atomicAdd(&cursor[c - hg], 1u);
-        cold_row[pos] = (int)row;
-        cold_val[pos] = m.val[p];
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ unsigned int lower_bound_rows(const int* __restrict__ rows, unsigned int b, unsigned int e,
-                                                          long long key) {
-  while (b < e) {
-    const unsigned int mid = b + ((e - b) >> 1);
-    if ((long long)rows[mid] < key) b = mid + 1;
-    else e = mid;
-  }
-  return b;
-}
-
-// g_k[hg + j] = sum over the entries of cold column j whose row lies in worker k's batch of
-// coef[row] * value, in a fixed order: no atomics, reproducible.
-// ref: core/Slave.scala:147-153 restricted to the cold columns.
-// One WAVE per column, eight independent 64-entry chunks in flight per iteration (the first version, 16
-// lanes per column and one chunk at a time, was latency-bound at 0.6 TB/s and cost 25 % of a step).
-// The per-row coefficients are read through a 2-bit packing (16 rows per word, 2.1 MB for 8.4 M rows): the
-// byte array (one 64-byte line fetched per random 1-byte read, 6.7 MB > one XCD's 4 MiB L2) made this
-// kernel line-traffic bound.
-__global__ void dsgd_pack_coef_kernel(const signed char* __restrict__ coef8, unsigned int* __restrict__ packed,
-                                      long long n_rows) {
-  const long long n_words = (n_rows + 15) / 16;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (long long)gridDim.x * blockDim.x) {
-    unsigned int word = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const long long r = i * 16 + k;
-      const int cf = r < n_rows ? (int)coef8[r] : 0;
-      word |= ((unsigned int)cf & 3u) << (2 * k);   // 0 -> 0, +1 -> 1, -1 -> 3
-    }
-    packed[i] = word;
-  }
-}
-__device__ __forceinline__ float coef_unpack(const unsigned int* __restrict__ packed, int r) {
-  const unsigned int code = (packed[r >> 4] >> ((r & 15) * 2)) & 3u;
-  return code == 1u ? 1.0f : (code == 3u ? -1.0f : 0.0f);
-}
-
-__global__ void __launch_bounds__(256) dsgd_cold_scatter_kernel(const unsigned int* __restrict__ cold_ptr,
-                                                               const int* __restrict__ cold_row,
-                                                               const float* __restrict__ cold_val,
-                                                               const unsigned int* __restrict__ coefp, int n_cold, int hg,
-                                                               float* g_base, long long g_stride,
-                                                               const StreamSeg* __restrict__ segs) {
-  const StreamSeg seg = segs[blockIdx.y];
-  float* g = g_base + (long long)blockIdx.y * g_stride;
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int n_waves = (gridDim.x * blockDim.x) >> 6;
-  for (int j = wave; j < n_cold; j += n_waves) {
-    unsigned int b = cold_ptr[j], e = cold_ptr[j + 1];
-    if (b == e) continue;
-    if ((long long)cold_row[b] < seg.row_begin) b = lower_bound_rows(cold_row, b, e, seg.row_begin);
-    if (b < e && (long long)cold_row[e - 1] >= seg.row_end) e = lower_bound_rows(cold_row, b, e, seg.row_end);
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    unsigned int q = b + lane;
-    for (; q + 448 < e; q += 512) {   // eight independent 64-entry chunks in flight
-      int r[8];
-      float v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        r[k] = cold_row[q + 64 * k];
-        v[k] = cold_val[q + 64 * k];
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) a[k] += filt(v[k] * coef_unpack(coefp, r[k]));
-    }
-    for (; q < e; q += 64) a[0] += filt(cold_val[q] * coef_unpack(coefp, cold_row[q]));
-    float acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    acc = group_sum<64>(acc);
-    if (lane == 0 && acc != 0.0f) g[hg + j] += acc;
-  }
 }
 
 // segmented scan over the 64 lanes of a wave, DPP only (no LDS round trip)
@@ -898,16 +676,15 @@ __device__ __forceinline__ void wave_seg_scan(float& v, int& f) {
 //   * gate coefficients go through a per-wave LDS strip, pre-multiplied by the fixed-point scale
 //     (same wave writes and reads: LDS executes a wave's accesses in order, no barrier);
 //   * rows longer than WS_MAXNNZ non-zeros are processed after the tiles, one wave per row.
-// Two variants of the column handling (template SPLIT): the split layout (hot columns only, cold part of x.w from
-// dcold, plain ds_add_u32 with a per-launch scale) and the older mode 3 (all columns: cold weights gathered with
-// out-of-range buffer loads -- w[dp] == 0 and wl[hw] == 0 are zero slots, so w_c = wl[min(c, hw)] + gathered --
-// cold gradient columns left to the transposed lists, ds_add_rtn_u32 with the spill rule described at w_scatter).
+// The tiles hold the HOT columns only (split layout: 16-bit ranks, cold part of x.w from dcold, plain ds_add_u32 with
+// a per-launch scale that rules out overflow).  The first generation (all columns in one stream, cold weights
+// gathered, returning atomics with a spill rule) is in the git history; profiles/README.md keeps its numbers.
 // Rounding to the fixed-point grid also absorbs the reference's 1e-20 filter on y*x.
 constexpr int WS_SLOTS = 512;
 constexpr int WS_MAXNNZ = WS_SLOTS - 8;
 constexpr int WS_MAXROWS = 254;
 constexpr int WS_PAD = WS_SLOTS + 8;   // padding elements behind col/val
-constexpr int WS_SPILL_AT = 1 << 28;
+constexpr int WS_SPILL_AT = 1 << 28;   // cold-stream accumulators (shift 21, returning atomics): spill / panic bands
 constexpr int WS_PANIC_AT = 1 << 30;
 constexpr int WS_COEF_STRIDE = 256;
 
@@ -919,15 +696,14 @@ struct WTile {       // 16 bytes, read with one scalar load
 
 struct WTables {
   const WTile* __restrict__ tiles;
-  const unsigned int* __restrict__ meta;  // n_tiles x 64 lane descriptors: rf | bits << 8 | ys << 16
+  const unsigned short* __restrict__ meta;  // n_tiles x 64 lane descriptors: row-start bits | label signs << 8
 };
 
 struct WRegs {
-  int4 c0, c1;
+  int4 c0;             // eight 16-bit column ranks
   float4 v0, v1;
-  float gw[8];
-  float dc;            // SPLIT: cold part of x.w of the row that ends in this lane
-  int rf;              // SPLIT: local row of the lane's first slot (wave prefix sum over the row-start bits)
+  float dc;            // cold part of x.w of the row that ends in this lane
+  int rf;              // local row of the lane's first slot (wave prefix sum over the row-start bits)
   unsigned int meta;
   long long pos0, tc;  // wave-uniform (scalar registers): window start, clamped tile index
   int r0, nrows, nb;   // wave-uniform: first row, rows, bytes of the window that belong to the tile
@@ -941,10 +717,7 @@ __device__ __forceinline__ WTile w_fetch(const WTables& tt, long long t, long lo
   return tt.tiles[t < t_end ? t : t_end - 1];
 }
 
-// the two halves of a tile's stream: column ids first (the cold-weight gathers of the tile wait for them), values
-// and lane descriptors one iteration later when DEPTH = 4 (they are not needed before the tile is processed) --
-// this keeps four column sets but only three value sets live
-template <bool SPLIT>
+// the stream of a tile: eight 16-bit column ranks (one 16-byte load), eight values (two), the lane descriptor
 __device__ __forceinline__ void w_issue_cols(const CsrView& m, long long t, long long t_end, int lane, const WTile& wt,
                                              WRegs& r) {
   const bool live = t < t_end;
@@ -958,27 +731,17 @@ __device__ __forceinline__ void w_issue_cols(const CsrView& m, long long t, long
   // 1.2 x the algorithmic bytes).
   r.nb = (int)(((unsigned int)wt.info >> 16) + 3u & ~3u) * 4;
   typedef int i32x4 __attribute__((ext_vector_type(4)));
-  if (SPLIT) {
-    // Split layout: the hot stream carries 16-BIT column ranks (hot ranks < hsplit <= 65536 always: LDS caps hsplit
-    // near 18 K), eight per lane in ONE 16-byte load -- 6 bytes per non-zero instead of 8.  The kernel was moving
-    // 5.6 TB/s of physical traffic (89 % of the 6.29 TB/s copy ceiling) at 0.62 of the ALGORITHMIC roofline: bytes,
-    // not latency, were the lever.  Windows start at a multiple of 8 slots (16-byte aligned in this array).
-    const unsigned short* col16 = reinterpret_cast<const unsigned short*>(m.col);
-    const int nb16 = (int)(((unsigned int)wt.info >> 16) + 7u & ~7u) * 2;
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(col16 + wt.pos0), 0, nb16, 0x00020000);
-    const i32x4 a = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0));
-    r.c0 = make_int4(a.x, a.y, a.z, a.w);
-    return;
-  }
+  // The hot stream carries 16-BIT column ranks (hot ranks < hsplit <= 65536 always: LDS caps hsplit near 18 K), eight
+  // per lane in ONE 16-byte load -- 6 bytes per non-zero instead of 8.  The kernel was moving 5.6 TB/s of physical
+  // traffic (89 % of the 6.29 TB/s copy ceiling) at 0.62 of the ALGORITHMIC roofline: bytes, not latency, were the
+  // lever.  Windows start at a multiple of 8 slots (16-byte aligned in this array).
+  const unsigned short* col16 = reinterpret_cast<const unsigned short*>(m.col);
+  const int nb16 = (int)(((unsigned int)wt.info >> 16) + 7u & ~7u) * 2;
   const __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(m.col + wt.pos0), 0, r.nb, 0x00020000);
-  const i32x4 a = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane, 0, 0));
-  const i32x4 b = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane + 16, 0, 0));
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(col16 + wt.pos0), 0, nb16, 0x00020000);
+  const i32x4 a = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0));
   r.c0 = make_int4(a.x, a.y, a.z, a.w);
-  r.c1 = make_int4(b.x, b.y, b.z, b.w);
 }
-template <bool SPLIT>
 __device__ __forceinline__ void w_issue_vals(const CsrView& m, const WTables& tt, int lane, WRegs& r) {
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m.val + r.pos0), 0, r.nb, 0x00020000);
@@ -989,26 +752,9 @@ __device__ __forceinline__ void w_issue_vals(const CsrView& m, const WTables& tt
   const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane + 16, 0, 0));
   r.v0 = make_float4(a.x, a.y, a.z, a.w);
   r.v1 = make_float4(b.x, b.y, b.z, b.w);
-  // lane descriptor.  Split layout: 16 bits (row-start bits | label signs << 8); the local row of the lane's first
-  // slot is a wave prefix sum over the start bits (w_load_dc) instead of a stored field -- half the descriptor bytes
-  if (SPLIT) r.meta = (reinterpret_cast<const unsigned short*>(tt.meta) + r.tc * 64)[(unsigned int)lane];
-  else r.meta = (tt.meta + r.tc * 64)[(unsigned int)lane];
-}
-
-// cold-weight gathers of a tile whose column ids have landed.  Buffer loads: a hot lane gets an offset
-// beyond num_records, which the texture addresser answers with 0 WITHOUT touching the cache -- the
-// instruction stays unconditional (countable by vmcnt) and only the cold lanes cost memory traffic.
-__device__ __forceinline__ void w_gather(__amdgpu_buffer_rsrc_t wrs, int hw, WRegs& r) {
-  const int c[8] = {r.c0.x, r.c0.y, r.c0.z, r.c0.w, r.c1.x, r.c1.y, r.c1.z, r.c1.w};
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const unsigned int off = c[k] < hw ? 0xFFFFFFF0u : (unsigned int)c[k] * 4u;
-    r.gw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, off, 0, 0));
-  }
-}
-__device__ __forceinline__ void w_gather_off(WRegs& r) {
-#pragma unroll
-  for (int k = 0; k < 8; ++k) r.gw[k] = 0.25f;
+  // lane descriptor, 16 bits (row-start bits | label signs << 8); the local row of the lane's first slot is a wave
+  // prefix sum over the start bits (w_load_dc) instead of a stored field
+  r.meta = (tt.meta + r.tc * 64)[(unsigned int)lane];
 }
 
 struct WCtx {
@@ -1018,15 +764,14 @@ struct WCtx {
   const float* wl;
   long long* g64;
   DevScalars* sc;
-  const float* dcold;   // SPLIT: per-row cold part of x.w, written by dsgd_cdot_kernel
+  const float* dcold;   // per-row cold part of x.w, written by the cold-stream kernel
   long long row_begin, row_end;
   int hw, hg;
-  float fix_scale;    // fixed-point scale of the LDS gradient tile (split layout: chosen per launch)
-  float cold_scale;   // split layout: scale of the cold columns' 64-bit accumulators (2^FIX_SHIFT / vmax2)
-  int dbg;  // ablation switches for tuning runs (0 in production)
+  float fix_scale;    // fixed-point scale of the LDS gradient tile (chosen per launch)
+  float cold_scale;   // scale of the cold columns' 64-bit accumulators (2^FIX_SHIFT / vmax2)
 };
 
-// SPLIT: cold part of x.w of the row that ends in this lane (the lane's first row start closes it); lanes
+// cold part of x.w of the row that ends in this lane (the lane's first row start closes it); lanes
 // without a row end read row r0 and ignore the value
 __device__ __forceinline__ void w_load_dc(const WCtx& x, WRegs& r) {
   const unsigned int dn = r.nrows < 0 ? 0u : r.meta;
@@ -1048,85 +793,43 @@ __device__ __forceinline__ void w_load_dc(const WCtx& x, WRegs& r) {
 }
 
 
-// fixed-point scatter of a lane's eight contributions into the LDS gradient tile.  Every lane issues all eight
-// ds_add_rtn_u32 unconditionally (no exec-mask branches, one wait for the eight returns): a slot with nothing
-// to add (q == 0: cold column, inactive row, padding) targets the lane's private always-zero word gl[hg + lane].
-// Overflow control without a quiet point: whoever SEES an entry at |old| >= 2^28 swaps it out into the 64-bit
-// global accumulator; an entry seen at |old| >= 2^30 raises the error bit (a contribution is <= 2^21 and at most
-// 16 waves x 8 adds are in flight, so a wrap would have to pass through that band unseen).
-template <bool ABL, bool SPLIT>
-__device__ __forceinline__ void w_scatter(const WCtx& x, const int (&cc)[8], const int (&q)[8], int lane, int dbg) {
-  int old[8];
-  const int esh = 2;
-  const int dummy = (x.hg + lane) << 2;
-  if (SPLIT) {
-    // Split layout: the host picks the fixed-point scale of the launch so that NO sum of one workgroup can leave
-    // 32 bits (at most one contribution per row and column, |contribution| <= 2^shift, rows per workgroup known):
-    // plain ds_add_u32 under the exec mask -- no return value, no spill path, nothing to wait for.  Measured on
-    // MI355X against the returning form with dummy slots and 2^21 scaling: -18 % kernel time in the trained state
-    // (one-sided sums kept crossing the 2^28 spill threshold), identical loss to 6 digits.
+// fixed-point scatter of a lane's eight contributions into the LDS gradient tile.  The host picks the fixed-point
+// scale of the launch so that NO sum of one workgroup can leave 32 bits (at most one contribution per row and column,
+// |contribution| <= 2^shift, rows per workgroup known; dsgd_wseg_bound_kernel refines it): plain ds_add_u32 under the
+// exec mask -- no return value, no spill path, nothing to wait for.  Measured on MI355X against the returning form
+// with dummy slots and 2^21 scaling: -18 % kernel time in the trained state (one-sided sums kept crossing the 2^28
+// spill threshold), identical loss to 6 digits.  cc[] are LDS byte offsets.
+__device__ __forceinline__ void w_scatter(const WCtx& x, const int (&cc)[8], const int (&q)[8]) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (q[k] != 0) atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(x.gl) + cc[k]), q[k]);
-    return;
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    // (measured: adding the zeros to their real columns instead costs +33 % kernel time in LDS bank conflicts)
-    const int off = q[k] != 0 ? (cc[k] << esh) : dummy;
-    int* slot = reinterpret_cast<int*>(reinterpret_cast<char*>(x.gl) + off);
-    old[k] = (ABL && (dbg & 4)) ? 0 : atomicAdd(slot, q[k]);   // ds_add_rtn_u32
-  }
-  int hi = max(max(old[0], old[1]), old[2]), lo = min(min(old[0], old[1]), old[2]);   // v_max3 / v_min3
-  hi = max(max(hi, old[3]), old[4]);
-  lo = min(min(lo, old[3]), old[4]);
-  hi = max(max(hi, old[5]), old[6]);
-  lo = min(min(lo, old[5]), old[6]);
-  hi = max(hi, old[7]);
-  lo = min(lo, old[7]);
-  if (hi >= WS_SPILL_AT || lo <= -WS_SPILL_AT) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (old[k] >= WS_SPILL_AT || old[k] <= -WS_SPILL_AT) {
-        if (old[k] >= WS_PANIC_AT || old[k] <= -WS_PANIC_AT) atomicOr(&x.sc->err, 2);
-        const int col = SPLIT ? cc[k] >> 2 : cc[k];
-        const int v = atomicExch(&x.gl[col], 0);
-        if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[col]), (unsigned long long)(long long)v);
-      }
-    }
-  }
+  for (int k = 0; k < 8; ++k)
+    if (q[k] != 0) atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(x.gl) + cc[k]), q[k]);
 }
 
-// One tile of one wave.  `cur` = tile t (everything landed), `nxt` = tile t+1 (column ids landed: its cold weights
-// are gathered now), `far` = the register set that receives the column ids of tile t+DEPTH-1; with DEPTH = 4
-// `mid` = tile t+2, whose column ids are in flight and whose values are requested now.  The stream loads are issued FIRST so that they are already on their way while the
-// wave waits (counted vmcnt) for the column ids of t+1.
-// SPLIT (stream_mode 4): the tiles hold the HOT part of the matrix only (every column id < hw = hg), the cold
-// part of each row's x.w comes from x.dcold -- no gathers, no clamps, no cold checks.
-template <bool SCATTER, bool ABL, int DEPTH, bool SPLIT>
-__device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __amdgpu_buffer_rsrc_t wrs, const WCtx& x,
-                                       unsigned int dp, long long tile, long long stride, long long t_end, WRegs& cur,
-                                       WRegs& nxt, WRegs& mid, WRegs& far, WTile& wt_far, unsigned int& n_all,
-                                       unsigned int& n_neg, unsigned int& n_pos) {
+// One tile of one wave.  `cur` = tile t (everything landed), `nxt` = tile t+1 (descriptor landed: the cold part of
+// its rows' x.w is requested now), `far` = the register set that receives tile t+3.  The stream loads are issued
+// FIRST so that they are already on their way while the wave works on tile t.  The tiles hold the HOT part of the
+// matrix only (every column rank < hw = hg), the cold part of each row's x.w comes from x.dcold -- no gathers, no
+// clamps, no cold checks.
+template <bool SCATTER>
+__device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, const WCtx& x, long long tile,
+                                       long long stride, long long t_end, WRegs& cur, WRegs& nxt, WRegs& far,
+                                       WTile& wt_far, unsigned int& n_all, unsigned int& n_neg, unsigned int& n_pos) {
   const int lane = threadIdx.x & 63;
-  const int dbg = ABL ? x.dbg : 0;   // ablation switches exist only in the ABL instantiation (tuning runs)
   // the record load goes out BEFORE this iteration's stream loads: vmcnt retires in order, so next iteration's
   // wait for it does not drain the stream loads issued behind it
   const WTile wt_now = wt_far;                                              // record fetched last iteration
-  wt_far = w_fetch(tt, tile + DEPTH * stride, t_end);                       // record used next iteration
-  w_issue_cols<SPLIT>(m, tile + (DEPTH - 1) * stride, t_end, lane, wt_now, far);
-  w_issue_vals<SPLIT>(m, tt, lane, far);   // (values with the column ids: the window descriptor stays in scalar registers)
-  if (SPLIT) w_load_dc(x, nxt);   // tile t+1 (descriptor landed): one load instead of eight gathers
-  else if (dbg & 32) w_gather_off(nxt);
-  else w_gather(wrs, x.hw, nxt);                                           // tile t+1
+  wt_far = w_fetch(tt, tile + 4 * stride, t_end);                           // record used next iteration
+  w_issue_cols(m, tile + 3 * stride, t_end, lane, wt_now, far);
+  w_issue_vals(m, tt, lane, far);   // (values with the column ids: the window descriptor stays in scalar registers)
+  w_load_dc(x, nxt);                // tile t+1 (descriptor landed)
 
   const int nrows = cur.nrows;                          // wave-uniform; -1: the whole tile is padding
   const unsigned int desc = nrows < 0 ? 0u : cur.meta;
-  const int rf = SPLIT ? cur.rf : (int)(desc & 255u);
-  const unsigned int bits = SPLIT ? desc & 255u : (desc >> 8) & 255u;
-  const unsigned int ys = SPLIT ? (desc >> 8) & 255u : (desc >> 16) & 255u;
+  const int rf = cur.rf;
+  const unsigned int bits = desc & 255u;
+  const unsigned int ys = (desc >> 8) & 255u;
   int cc[8];
-  if (SPLIT) {
+  {
     // 16-bit ranks -> LDS byte offsets 4 * rank (two VALU per id; the weights sit at LDS address 0)
     const unsigned int cw[4] = {(unsigned int)cur.c0.x, (unsigned int)cur.c0.y, (unsigned int)cur.c0.z, (unsigned int)cur.c0.w};
 #pragma unroll
@@ -1140,24 +843,19 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
       cc[2 * k] = (int)lo4;
       cc[2 * k + 1] = (int)((cw[k] >> 14) & 0x3fffcu);
     }
-  } else {
-    cc[0] = cur.c0.x; cc[1] = cur.c0.y; cc[2] = cur.c0.z; cc[3] = cur.c0.w;
-    cc[4] = cur.c1.x; cc[5] = cur.c1.y; cc[6] = cur.c1.z; cc[7] = cur.c1.w;
   }
   const float vv[8] = {cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w};
   typedef __attribute__((address_space(3))) const float lds_cfloat;
-  lds_cfloat* wl3 = (lds_cfloat*)x.wl;
-  // hot weights: eight LDS reads back to back (cold columns read the zero slot wl[hw]); products filtered as
-  // the reference's product map is.  ref: math/Sparse.scala:46
+  // hot weights: eight LDS reads back to back; products filtered as the reference's product map is.
+  // ref: math/Sparse.scala:46
   float a[8], pk[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     // byte offset = LDS address: the weights sit at LDS address 0 (checked when the kernel starts) -- adding the
     // link-time base cost a v_add_u32 with literal 0 per slot
-    if (SPLIT) a[k] = *(lds_cfloat*)(unsigned int)cc[k];
-    else a[k] = (dbg & 16) ? 0.5f : wl3[min(cc[k], x.hw)];
+    a[k] = *(lds_cfloat*)(unsigned int)cc[k];
   }
-  if (SPLIT) {
+  {
     // products two at a time (v_pk_mul_f32), then the reference's 1e-20 filter
     typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -1166,9 +864,6 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
       pk[k] = filt(pr.x);
       pk[k + 1] = filt(pr.y);
     }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) pk[k] = filt(vv[k] * (a[k] + cur.gw[k]));
   }
 
   // rows of the worker's batch, as local rows of this tile (wave-uniform: readfirstlane keeps the 64-bit clamps and
@@ -1200,12 +895,12 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
     const float head = total - trail;
     float s = trail;
     int f = bits != 0u;
-    if (!(dbg & 8)) wave_seg_scan(s, f);
+    wave_seg_scan(s, f);
     const float incoming = dpp_get_f<0x138, 0xf>(s);      // wave_shr:1: running sum of the row entering this lane
     const int r_end = rf - (int)(bits & 1u);              // local row that ends at the lane's row start
-    if (!(dbg & 1)) {
+    {
       const bool fin = nb == 1 && r_end >= r_lo && r_end < r_hi;
-      const float d = SPLIT ? (incoming + head) + cur.dc : incoming + head;   // x . w of that row
+      const float d = (incoming + head) + cur.dc;          // x . w of that row
       const bool ypos = (ys & bits) != 0u;
       const float yd = ypos ? d : -d;
       if (SCATTER) {
@@ -1221,7 +916,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
         n_pos += fin && (yd > 0.0f);
       }
     }
-    if (SCATTER && !(dbg & 2)) {
+    if (SCATTER) {
       if (lane == 0) {
         x.coefw[0] = 0.0f;                          // padding rows carry a zero coefficient
         x.coefw[nrows < 0 ? 1 : nrows + 1] = 0.0f;
@@ -1239,11 +934,10 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
       for (int k = 0; k < 8; k += 2) {
         const f32x2 coef = {in_t[k] ? cT : cA, in_t[k + 1] ? cT : cA};
         const f32x2 r = __builtin_elementwise_fma(f32x2{vv[k], vv[k + 1]}, coef, f32x2{12582912.0f, 12582912.0f});
-        const int q0 = __float_as_int(r.x) - 0x4B400000, q1 = __float_as_int(r.y) - 0x4B400000;
-        q[k] = (SPLIT || cc[k] < x.hg) ? q0 : 0;
-        q[k + 1] = (SPLIT || cc[k + 1] < x.hg) ? q1 : 0;
+        q[k] = __float_as_int(r.x) - 0x4B400000;
+        q[k + 1] = __float_as_int(r.y) - 0x4B400000;
       }
-      w_scatter<ABL, SPLIT>(x, cc, q, lane, dbg);
+      w_scatter(x, cc, q);
       __builtin_amdgcn_wave_barrier();
     }
   } else {
@@ -1257,9 +951,9 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
     }
     float s = trail;
     int f = bits != 0u;
-    if (!(dbg & 8)) wave_seg_scan(s, f);
+    wave_seg_scan(s, f);
     const float incoming = dpp_get_f<0x138, 0xf>(s);
-    if (!(dbg & 1)) {
+    {
       float run = incoming;
       int r = rf - (int)(bits & 1u);
 #pragma unroll
@@ -1268,7 +962,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
           if (r >= 1 && r <= nrows) {
             const bool in_range = r >= r_lo && r < r_hi;
             const bool ypos = (ys >> k) & 1u;
-            const float dfull = SPLIT ? run + (x.dcold + r0s)[(unsigned int)(r - 1)] : run;
+            const float dfull = run + (x.dcold + r0s)[(unsigned int)(r - 1)];
             const float yd = ypos ? dfull : -dfull;
             if (SCATTER) {
               const bool active = in_range && !(yd < 0.0f);
@@ -1287,7 +981,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
         run += pk[k];
       }
     }
-    if (SCATTER && !(dbg & 2)) {
+    if (SCATTER) {
       if (lane == 0) {
         x.coefw[0] = 0.0f;
         x.coefw[nrows < 0 ? 1 : nrows + 1] = 0.0f;
@@ -1301,28 +995,19 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, __am
           ++r;
           coef = x.coefw[r];
         }
-        q[k] = (SPLIT || cc[k] < x.hg) ? __float2int_rn(vv[k] * coef) : 0;
+        q[k] = __float2int_rn(vv[k] * coef);
       }
-      w_scatter<ABL, SPLIT>(x, cc, q, lane, dbg);
+      w_scatter(x, cc, q);
       __builtin_amdgcn_wave_barrier();
     }
   }
 }
 
 // ---- rows longer than a wave tile: one wave per row, four 64-element chunks in flight -------------------------
-// Run by the waves of dsgd_wseg_kernel after their tiles (same LDS weight tile, fixed-point accumulators and
-// cold-column convention); rows of 500+ non-zeros are 0.5 % of the RCV1-like rows but 3 % of the non-zeros.
-__device__ __forceinline__ void fix_add_lds(int* gl, long long* g64, DevScalars* sc, int c, int q) {
-  const int old = atomicAdd(&gl[c], q);   // ds_add_rtn_u32
-  const int nw = old + q;
-  if (nw >= WS_SPILL_AT || nw <= -WS_SPILL_AT) {
-    if (old >= WS_PANIC_AT || old <= -WS_PANIC_AT) atomicOr(&sc->err, 2);
-    const int v = atomicExch(&gl[c], 0);
-    if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[c]), (unsigned long long)(long long)v);
-  }
-}
-
-template <bool SCATTER, bool SPLIT>
+// Run by the waves of dsgd_wseg_kernel after their tiles, from the WHOLE ranked CSR (same LDS weight tile and
+// fixed-point accumulators; cold columns straight to the 64-bit accumulators at the cold scale); rows of 500+
+// non-zeros are 0.5 % of the RCV1-like rows but 3 % of the non-zeros.
+template <bool SCATTER>
 __device__ __forceinline__ void w_long_row(const CsrView& m, const float* __restrict__ w, const WCtx& x, long long row,
                                            unsigned int& n_all, unsigned int& n_neg, unsigned int& n_pos) {
   typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
@@ -1359,11 +1044,8 @@ __device__ __forceinline__ void w_long_row(const CsrView& m, const float* __rest
         const int c = m.col[p];
         if (c < x.hg) {
           const int q = __float2int_rn(m.val[p] * cs);
-          if (q != 0) {
-            if (SPLIT) atomicAdd(&x.gl[c], q);   // (these rows are part of the launch's row bound: no overflow)
-            else fix_add_lds(x.gl, x.g64, x.sc, c, q);
-          }
-        } else if (SPLIT) {   // no cold lists in the split layout: straight to the 64-bit accumulator, cold scale
+          if (q != 0) atomicAdd(&x.gl[c], q);   // (these rows are part of the launch's row bound: no overflow)
+        } else {
           const int q = __float2int_rn(m.val[p] * (y * x.cold_scale));
           if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[c]), (unsigned long long)(long long)q);
         }
@@ -1376,13 +1058,14 @@ __device__ __forceinline__ void w_long_row(const CsrView& m, const float* __rest
   }
 }
 
-template <bool SCATTER, bool ABL, int DEPTH, bool SPLIT>
+// m: the hot stream (row_ptr = hot row offsets, col = 16-bit ranks, val); mfull: the whole ranked CSR (long rows)
+template <bool SCATTER>
 __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mfull, const WTile* __restrict__ tiles,
-                                                        const unsigned int* __restrict__ meta,
+                                                        const unsigned short* __restrict__ meta,
                                                         const float* __restrict__ w, long long* __restrict__ g64_base,
                                                         long long g_stride, const StreamSeg* __restrict__ segs,
                                                         DevScalars* __restrict__ sc, int hw, int hg, float fix_scale,
-                                                        signed char* __restrict__ coef8, int dp, int dbg,
+                                                        signed char* __restrict__ coef8,
                                                         const int* __restrict__ long_rows, int* __restrict__ part,
                                                         int part_stride, const float* __restrict__ dcold,
                                                         float cold_scale) {
@@ -1395,12 +1078,11 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile records, bases and row ranges stay in SGPRs
   WCtx x;
-  x.dbg = dbg;
   x.coef8 = coef8;
-  // LDS: 16 coefficient strips, hg + 64 gradient words (SCATTER only; the last 64 stay zero), hw + 1 weights (zero
-  // slot at wl[hw]).  The split layout puts the weights FIRST: its column ids are byte offsets from LDS address 0.
-  float* wl = SPLIT ? lds : lds + 16 * WS_COEF_STRIDE + (SCATTER ? hg + 64 : 0);
-  float* strips = SPLIT ? lds + ((hw + 4) & ~3) : lds;
+  // LDS: hw + 1 weights FIRST (the column ranks become byte offsets from LDS address 0; zero slot at wl[hw]), 16
+  // coefficient strips, hg + 64 gradient words (SCATTER only).
+  float* wl = lds;
+  float* strips = lds + ((hw + 4) & ~3);
   x.coefw = strips + wave * WS_COEF_STRIDE;
   x.gl = reinterpret_cast<int*>(strips + 16 * WS_COEF_STRIDE);
   x.wl = wl;
@@ -1419,7 +1101,7 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
     else
       for (int j = tid; j < hg + 64; j += 1024) x.gl[j] = 0;
   }
-  if (SPLIT && (unsigned int)(unsigned long long)(__attribute__((address_space(3))) float*)lds != 0u) {
+  if ((unsigned int)(unsigned long long)(__attribute__((address_space(3))) float*)lds != 0u) {
     // (w_tile turns column ranks into LDS addresses without adding a base: all LDS of this kernel is dynamic)
     if (tid == 0) atomicOr(&sc->err, 2);
     return;
@@ -1429,63 +1111,42 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
   __syncthreads();
 
   unsigned int n_all = 0, n_neg = 0, n_pos = 0;
-  // raw buffer over w[0 .. dp): word 3 = 0x00020000 (gfx9 family: 32-bit data, no swizzle)
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, dp * 4, 0x00020000);
   const long long stride = (long long)gridDim.x * 16;          // waves of this worker's grid row
   const long long t_end = seg.tile_end;
   long long tile = seg.tile_begin + (long long)blockIdx.x * 16 + wave;
   if (tile < t_end) {
+    // four register sets rotated by unrolling: three tiles in flight per wave
     WRegs A, B, C, D;
     WTile wt = w_fetch(tt, tile, t_end);
-    w_issue_cols<SPLIT>(m, tile, t_end, lane, wt, A);
-    w_issue_vals<SPLIT>(m, tt, lane, A);
+    w_issue_cols(m, tile, t_end, lane, wt, A);
+    w_issue_vals(m, tt, lane, A);
     wt = w_fetch(tt, tile + stride, t_end);
-    w_issue_cols<SPLIT>(m, tile + stride, t_end, lane, wt, B);
-    w_issue_vals<SPLIT>(m, tt, lane, B);
+    w_issue_cols(m, tile + stride, t_end, lane, wt, B);
+    w_issue_vals(m, tt, lane, B);
     wt = w_fetch(tt, tile + 2 * stride, t_end);
-    if (DEPTH == 4) {
-      w_issue_cols<SPLIT>(m, tile + 2 * stride, t_end, lane, wt, C);
-      w_issue_vals<SPLIT>(m, tt, lane, C);
-      wt = w_fetch(tt, tile + 3 * stride, t_end);
-    }
-    if (SPLIT) w_load_dc(x, A);
-    else w_gather(wrs, hw, A);
-#define DSGD_WT(CUR, NXT, MID, FAR)                                                                                  \
-  w_tile<SCATTER, ABL, DEPTH, SPLIT>(m, tt, wrs, x, (unsigned int)dp, tile, stride, t_end, CUR, NXT, MID, FAR, wt, \
-                                     n_all, n_neg, n_pos)
-    if (DEPTH == 4) {
-      for (;;) {
-        DSGD_WT(A, B, C, D); tile += stride; if (tile >= t_end) break;
-        DSGD_WT(B, C, D, A); tile += stride; if (tile >= t_end) break;
-        DSGD_WT(C, D, A, B); tile += stride; if (tile >= t_end) break;
-        DSGD_WT(D, A, B, C); tile += stride; if (tile >= t_end) break;
-      }
-    } else {
-      for (;;) {
-        DSGD_WT(A, B, C, C); tile += stride; if (tile >= t_end) break;
-        DSGD_WT(B, C, A, A); tile += stride; if (tile >= t_end) break;
-        DSGD_WT(C, A, B, B); tile += stride; if (tile >= t_end) break;
-      }
+    w_issue_cols(m, tile + 2 * stride, t_end, lane, wt, C);
+    w_issue_vals(m, tt, lane, C);
+    wt = w_fetch(tt, tile + 3 * stride, t_end);
+    w_load_dc(x, A);
+#define DSGD_WT(CUR, NXT, FAR) w_tile<SCATTER>(m, tt, x, tile, stride, t_end, CUR, NXT, FAR, wt, n_all, n_neg, n_pos)
+    for (;;) {
+      DSGD_WT(A, B, D); tile += stride; if (tile >= t_end) break;
+      DSGD_WT(B, C, A); tile += stride; if (tile >= t_end) break;
+      DSGD_WT(C, D, B); tile += stride; if (tile >= t_end) break;
+      DSGD_WT(D, A, C); tile += stride; if (tile >= t_end) break;
     }
 #undef DSGD_WT
   }
   // rows that fit no tile: one wave per row
   for (long long t = seg.long_begin + (long long)blockIdx.x * 16 + wave; t < seg.long_end; t += stride)
-    w_long_row<SCATTER, SPLIT>(mfull, w, x, (long long)long_rows[t], n_all, n_neg, n_pos);
+    w_long_row<SCATTER>(mfull, w, x, (long long)long_rows[t], n_all, n_neg, n_pos);
 
   if (SCATTER) {
     __syncthreads();
-    if (part) {
-      // this workgroup's exact partial sums, written whole (zeros included): dsgd_fix_reduce_kernel adds the
-      // partials of a worker in a fixed order -- no atomics, and 256 workgroups do not meet on one address
-      int* mine = part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * part_stride;
-      wg_copy_out(mine, x.gl, hg, tid, 1024, is_aligned16(mine) && is_aligned16(x.gl));
-    } else {
-      for (int j = tid; j < hg; j += 1024) {
-        const int q = x.gl[j];
-        if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[j]), (unsigned long long)(long long)q);
-      }
-    }
+    // this workgroup's exact partial sums, written whole (zeros included): the reduce kernels add the partials of a
+    // worker in a fixed order -- no atomics, and 256 workgroups do not meet on one address
+    int* mine = part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * part_stride;
+    wg_copy_out(mine, x.gl, hg, tid, 1024, is_aligned16(mine) && is_aligned16(x.gl));
     n_all = wave_sum_u32(n_all);
     if (lane == 0 && n_all) atomicAdd(&sc->n_active, (unsigned long long)n_all);
   } else {
@@ -1674,76 +1335,7 @@ __device__ __forceinline__ long long cold_row_start(const ColdView& cv, long lon
   return e_hi;
 }
 
-constexpr int CD_UNR = 16;   // 64-element chunks in flight per wave (the cold kernels are latency-bound: 16 waves per CU)
-
-// dcold[row] = sum over the cold entries of the row of filt(value * w[hsplit + col]) for the rows of each
-// worker's range.  Every wave owns a contiguous, ROW-ALIGNED piece of the cold stream: no atomics, fixed order.
-// ref: math/Sparse.scala:46 restricted to the cold columns.
-template <bool PACKED>
-__global__ void __launch_bounds__(1024) dsgd_cdot_kernel(ColdView cv, const long long* __restrict__ crow_ptr,
-                                                        const float* __restrict__ w, float* __restrict__ dcold,
-                                                        const StreamSeg* __restrict__ segs, int hsplit, int nc_lds,
-                                                        int wide) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  typedef __attribute__((address_space(3))) const float lds_cfloat;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int j = tid; j < nc_lds; j += 1024) lds[j] = w[hsplit + j];
-  __syncthreads();
-  const StreamSeg seg = segs[blockIdx.y];
-  const long long e_lo = crow_ptr[seg.row_begin], e_hi = crow_ptr[seg.row_end];
-  const long long n = e_hi - e_lo;
-  const long long n_waves = (long long)gridDim.x * 16, me = (long long)blockIdx.x * 16 + wave;
-  // nominal pieces in units of 64 elements, then moved forward to the next row start
-  const long long chunks = (n + 63) / 64;
-  const long long b0 = e_lo + 64 * (chunks * me / n_waves), b1 = e_lo + 64 * (chunks * (me + 1) / n_waves);
-  const long long s = cold_row_start<PACKED>(cv, b0, e_lo, e_hi, lane);
-  const long long t = me + 1 == n_waves ? e_hi : cold_row_start<PACKED>(cv, b1 < e_hi ? b1 : e_hi, e_lo, e_hi, lane);
-  float carry_sum = 0.0f;
-  int carry_row = -1;
-  lds_cfloat* wc = (lds_cfloat*)lds;
-  for (long long e = s; e < t; e += 64 * CD_UNR) {
-    int c[CD_UNR], r[CD_UNR];
-    float v[CD_UNR];
-#pragma unroll
-    for (int k = 0; k < CD_UNR; ++k) {
-      const long long i = e + 64 * k + lane;
-      const bool in = i < t;
-      const long long ic = in ? i : t - 1;   // unconditional (clamped) loads keep the vmcnt waits counted
-      cold_get<PACKED>(cv, ic, c[k], r[k]);
-      const float vl = cv.val[ic];
-      v[k] = in ? vl : 0.0f;
-      c[k] = in ? c[k] : 0;
-      r[k] = in ? r[k] : -1;
-    }
-    float wv[CD_UNR];
-#pragma unroll
-    for (int k = 0; k < CD_UNR; ++k) wv[k] = wc[min(c[k], nc_lds - 1)];
-    if (wide) {   // wave-uniform: cold columns beyond the LDS tile exist (very wide models only)
-#pragma unroll
-      for (int k = 0; k < CD_UNR; ++k)
-        if (c[k] >= nc_lds) wv[k] = w[hsplit + c[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < CD_UNR; ++k) {
-      float p = filt(v[k] * wv[k]);
-      // the row carried in from the previous chunk: continues in lane 0 or is complete
-      if (lane == 0) {
-        if (r[k] == carry_row) p += carry_sum;
-        else if (carry_row >= 0) dcold[carry_row] = carry_sum;
-      }
-      const int prev = dpp_get_i<0x138, 0xf>(r[k]);          // wave_shr:1 (lane 0 reads 0: it never continues a lane)
-      int f = lane == 0 ? 1 : (r[k] != prev);
-      float sum = p;
-      wave_seg_scan(sum, f);
-      const int next = __builtin_amdgcn_update_dpp(-1, r[k], 0x130, 0xf, 0xf, false);   // wave_shl:1 (lane 63: -1)
-      if (lane < 63 && r[k] >= 0 && next != r[k]) dcold[r[k]] = sum;
-      carry_sum = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sum), 63));
-      carry_row = __builtin_amdgcn_readlane(r[k], 63);
-    }
-  }
-  if (lane == 0 && carry_row >= 0) dcold[carry_row] = carry_sum;
-}
+constexpr int CD_UNR = 16;   // 64-element chunks in flight per wave
 
 // cold gradient columns of each worker's range: q = round(value * coef[row] * scale) accumulated in an LDS tile of
 // 32-bit integers (same fixed-point grid and overflow rule as the main kernel), flushed once per workgroup into
@@ -1974,77 +1566,4 @@ __global__ void __launch_bounds__(1024) dsgd_cdot8_kernel(ColdView cv, const lon
     if (tb >= t) break;
   }
   if (lane == 0 && carry_row >= 0) dcold[carry_row] = carry_sum;
-}
-
-// cold gradient columns, same contract as dsgd_cgrad_kernel (fixed-point LDS accumulators, shift 21, spill rule of
-// w_scatter, per-workgroup partials).  ref: core/Slave.scala:147-153 restricted to the cold columns.
-template <bool PACKED>
-__global__ void __launch_bounds__(1024) dsgd_cgrad8_kernel(ColdView cv, const long long* __restrict__ crow_ptr,
-                                                          const signed char* __restrict__ coef8,
-                                                          long long* __restrict__ g64_base, long long g_stride,
-                                                          DevScalars* __restrict__ sc,
-                                                          const StreamSeg* __restrict__ segs, int hsplit, int nc_lds,
-                                                          float fix_scale, int* __restrict__ partc, int partc_stride,
-                                                          int wide) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int* gc = reinterpret_cast<int*>(lds);   // nc_lds accumulators + 64 always-zero words
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int j = tid; j < nc_lds + 64; j += 1024) gc[j] = 0;
-  __syncthreads();
-  const StreamSeg seg = segs[blockIdx.y];
-  long long* g64 = g64_base + (long long)blockIdx.y * g_stride;
-  const long long e_lo = crow_ptr[seg.row_begin], e_hi = crow_ptr[seg.row_end];
-  const long long chunks = (e_hi - e_lo + 63) / 64;
-  const long long n_waves = (long long)gridDim.x * 16, me = (long long)blockIdx.x * 16 + wave;
-  const long long s = e_lo + 64 * (chunks * me / n_waves);
-  long long t = e_lo + 64 * (chunks * (me + 1) / n_waves);
-  if (t > e_hi) t = e_hi;
-  if (s < t) {
-    auto process = [&](ColdTile8& T, long long tb) {
-      int col[8], q[8], old[8];
-      cold_tile_decode<PACKED>(T, tb, lane, s, t, col);
-      signed char cf[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) cf[k] = coef8[T.r[k] >= 0 ? T.r[k] : (int)seg.row_begin];   // (neighbouring entries share rows)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) q[k] = __float2int_rn(T.v[k] * ((float)cf[k] * fix_scale));   // 0: inactive row, padding
-      if (wide) {   // wave-uniform: columns beyond the LDS tile (very wide models) go to the 64-bit global accumulator
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (col[k] >= nc_lds) {
-            if (q[k] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[hsplit + col[k]]), (unsigned long long)(long long)q[k]);
-            q[k] = 0;
-            col[k] = 0;
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) old[k] = atomicAdd(&gc[q[k] != 0 ? col[k] : nc_lds + lane], q[k]);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (old[k] >= WS_SPILL_AT || old[k] <= -WS_SPILL_AT) {
-          if (old[k] >= WS_PANIC_AT || old[k] <= -WS_PANIC_AT) atomicOr(&sc->err, 2);
-          const int x = atomicExch(&gc[col[k]], 0);
-          if (x != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[hsplit + col[k]]), (unsigned long long)(long long)x);
-        }
-      }
-    };
-    long long tb = s & ~7LL;
-    ColdTile8 A, B;
-    cold_tile_issue<PACKED>(cv, tb, lane, A);
-    for (;;) {
-      if (tb + 512 < t) cold_tile_issue<PACKED>(cv, tb + 512, lane, B);
-      process(A, tb);
-      tb += 512;
-      if (tb >= t) break;
-      if (tb + 512 < t) cold_tile_issue<PACKED>(cv, tb + 512, lane, A);
-      process(B, tb);
-      tb += 512;
-      if (tb >= t) break;
-    }
-  }
-  __syncthreads();
-  int* mine = partc + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * partc_stride;
-  for (int j = tid; j < nc_lds; j += 1024) mine[j] = gc[j];
 }

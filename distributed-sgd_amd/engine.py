@@ -195,6 +195,12 @@ class Engine:
     def async_wait(self):
         check(self._lib.dsgd_async_wait(self._ctx))
 
+    def async_regulariser(self):
+        """(engine's incrementally kept s = 2 lambda (w . ds), the same recomputed from the weights as they are now)."""
+        a, b = C.c_double(0), C.c_double(0)
+        check(self._lib.dsgd_async_regulariser(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     # -- multi-GPU ---------------------------------------------------------------------------------
     @staticmethod
     def comm_unique_id():
@@ -237,6 +243,12 @@ class Engine:
         v = (C.c_int32 * 6)()
         check(self._lib.dsgd_tuning_info(self._ctx, v, C.c_int32(6)))
         return dict(zip(("stream_mode", "hsplit", "fix_shift", "cold_packed", "plan_kernel", "fix_bound"), [int(x) for x in v]))
+
+    def column_ranks(self):
+        """Internal frequency rank of every key (D + 1 entries); identical on all ranks of a communicator."""
+        v = np.zeros(self.dp, dtype=np.int32)
+        check(self._lib.dsgd_column_ranks(self._ctx, ptr(v)))
+        return v
 
     def debug_cycles(self, reset=True):
         v = (C.c_uint64 * 16)()

@@ -50,10 +50,8 @@ enum {
   DSGD_EUNSUPPORTED = -7  /* no gfx950 device / feature not available                          */
 };
 
-/* dsgd_config.flags */
+/* dsgd_config.flags: none defined (must be 0) */
 #define DSGD_F_DEFAULT 0u
-#define DSGD_F_FORCE_TILED 2u /* always use the LDS-tiled gradient kernel (tests / tuning)        */
-#define DSGD_F_FORCE_ROWS 4u  /* always use the direct-to-L2 gradient kernel (tests / tuning)      */
 
 typedef struct dsgd_ctx dsgd_ctx;
 
@@ -159,7 +157,10 @@ int dsgd_async_step(dsgd_ctx* ctx, const int32_t* idx, int64_t n, float lr, floa
 
 /* SlaveImpl.updateGrad / MasterAsync.updateGrad / GradState.update
  * (core/Slave.scala:177-185, core/MasterAsync.scala:164-177, core/ml/GradState.scala:8):
- * w[key[i]] -= dv[i].  Keys as in the wire message Sparse.map (proto.proto:28-31).             */
+ * w[key[i]] -= dv[i].  Keys as in the wire message Sparse.map (proto.proto:28-31); a key outside [0, D] fails with
+ * DSGD_ERANGE before anything is applied.  May be called WHILE the lock-free engine runs (the reference's handler runs
+ * concurrently with asyncTask): the update is applied with atomic adds on a side stream and folded into the engine's
+ * regulariser scalar; the call returns when it has been applied and never waits for the engine.                    */
 int dsgd_update_grad(dsgd_ctx* ctx, const int32_t* key, const float* dv, int64_t nnz);
 
 /* SlaveImpl.startAsync (core/Slave.scala:159-175) for n_workers lock-free workers sharing ONE
@@ -183,6 +184,11 @@ int dsgd_async_updates(dsgd_ctx* ctx, int64_t* updates, int32_t* running);
  * the same period and the same finite max_updates (the ranks enqueue the same number of collectives).            */
 int dsgd_async_set_exchange(dsgd_ctx* ctx, int64_t every_updates);
 int dsgd_async_stop(dsgd_ctx* ctx); /* SlaveImpl.stopAsync, core/Slave.scala:187-195 */
+/* Measurement aid (nothing in the reference): the lock-free engine's incrementally kept regulariser scalar
+ * s = 2 lambda (w . ds) as the device holds it (kept by one atomic add per mini-batch and per dsgd_update_grad call,
+ * re-derived from the weights every few thousand iterations), and the same quantity recomputed from the weights as
+ * they are now.  While the engine runs the two differ by the updates in flight.                                   */
+int dsgd_async_regulariser(dsgd_ctx* ctx, double* s_engine, double* s_exact);
 int dsgd_async_wait(dsgd_ctx* ctx); /* block until max_updates reached */
 
 /* ---- multi-GPU (one process per GPU) ---------------------------------------
@@ -209,11 +215,17 @@ int dsgd_prof_read_kinds(dsgd_ctx* ctx, double* ms_avg3, int64_t* n_launches3);
  * algorithmic bytes of a step to the kernel that reads them.  Nothing in the reference. */
 int dsgd_range_nnz(dsgd_ctx* ctx, int64_t row_begin, int64_t row_end, int64_t* nnz, int64_t* cold_nnz);
 
-/* Tuning state that changes numerics or layout, for benchmark records: vals[0] = streaming layout (DSGD_STREAM),
- * [1] = hot/cold split rank, [2] = fixed-point shift of the last whole-range gradient launch, [3] = 1 if the cold
- * stream is packed, [4] = 1 if small batches run in the persistent plan kernel, [5] = 1 if the data-dependent
- * fixed-point bound is enabled.  n = number of slots the caller provides (<= 6).                                  */
+/* Tuning state that changes numerics or layout, for benchmark records and the derived error bound of the tests:
+ * vals[0] = layout generation (4 = matrix split by column rank, the only one), [1] = hot/cold split rank, [2] =
+ * fixed-point shift of the last gradient launch (whole ranges and index lists alike; not the one-workgroup plan
+ * kernel, which derives 30 - ceil(log2 batch) per batch), [3] = 1 if the cold stream is packed, [4] = 1 if small
+ * batches run in the persistent plan kernel, [5] = 1 if the data-dependent fixed-point bound is enabled.
+ * n = number of slots the caller provides (<= 6).                                                                 */
 int dsgd_tuning_info(dsgd_ctx* ctx, int32_t* vals, int32_t n);
+
+/* Layout introspection (tests of the multi-GPU path): the internal frequency rank of every key, D + 1 entries.  With a
+ * communicator attached the ranking is derived from the column counts summed over the ranks: identical on all of them. */
+int dsgd_column_ranks(dsgd_ctx* ctx, int32_t* rank_of_key /* D+1 */);
 
 /* Tuning aid (DSGD_PLAN_PROF=1 in the environment at dsgd_create): shader-clock cycles thread 0 of the small-batch
  * plan kernel spent in the nine phases of a batch ([0..8]: gather+dot, barrier, gate+tables, barrier, scatter,
@@ -237,7 +249,8 @@ int dsgd_device_ptrs(dsgd_ctx* ctx, void** w_dev, void** g_dev, void** stream);
 typedef struct dsgd_dense dsgd_dense;
 int dsgd_dense_create(int32_t n_features, int32_t device, dsgd_dense** out);
 int dsgd_dense_destroy(dsgd_dense* d);
-/* synthetic shard generated on the device: x ~ N(0,1)/sqrt(D), y = [x . w* + noise > 0] (planted w*), seed = rank   */
+/* synthetic shard generated on the device: x ~ N(0,1)/sqrt(D), y = [x . w* + noise > 0]; the planted w* is the same
+ * for every seed (one problem, many shards), the seed (= rank) varies the rows and the label noise                  */
 int dsgd_dense_generate(dsgd_dense* d, int64_t n_rows, uint64_t seed);
 /* host-provided data (tests): X n_rows x D row-major, y n_rows                                                    */
 int dsgd_dense_load(dsgd_dense* d, int64_t n_rows, const float* X, const float* y);

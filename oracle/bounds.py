@@ -58,3 +58,49 @@ def worst_ratio(w_engine, w_ref, tol):
     r = np.abs(np.asarray(w_engine, dtype=np.float64) - w_ref) / tol
     j = int(np.argmax(r))
     return float(r[j]), j
+
+
+def _list_profile(o, w, rows, eps):
+    """(cnt_j, near_j, rows near the gate) over the rows of an index list (numpy restatement of column_counts +
+    orc_range_gate_profile for rows that are not a contiguous range)."""
+    rows = np.asarray(rows, dtype=np.int64)
+    starts = o.row_ptr[rows]
+    lens = o.row_ptr[rows + 1] - starts
+    total = int(lens.sum())
+    if total == 0:
+        z = np.zeros(o.dim + 1)
+        return z, z.copy(), 0
+    first = np.cumsum(lens) - lens
+    flat = np.arange(total, dtype=np.int64) + np.repeat(starts - first, lens)
+    row_id = np.repeat(np.arange(len(rows), dtype=np.int64), lens)
+    cols = o.col[flat]
+    vals = o.val[flat].astype(np.float64)
+    keep = np.abs(vals) > 1e-20                       # math/Sparse.scala:108-118
+    cnt = np.bincount(cols[keep], minlength=o.dim + 1).astype(np.float64)
+    prod = vals * np.asarray(w, dtype=np.float64)[cols]
+    prod[np.abs(prod) <= 1e-20] = 0.0                 # math/Sparse.scala:46 -> :112-114
+    d = np.bincount(row_id, weights=prod, minlength=len(rows))
+    near_rows = (np.abs(d) > 0.0) & (np.abs(d) < eps)
+    mask = near_rows[row_id] & keep
+    near = np.bincount(cols[mask], weights=np.abs(vals[mask]), minlength=o.dim + 1)
+    return cnt, near, int(near_rows.sum())
+
+
+def list_bound(o, w_before, w_after_ref, lists, lr, shift, vmax2=None):
+    """step_bound for index lists (one list per worker, mean over the workers): the index-list kernels accumulate the
+    same fixed-point contributions exactly, at the shift the launch reports."""
+    if vmax2 is None:
+        vmax2 = vmax2_of(o.val)
+    k = len(lists)
+    cnt = np.zeros(o.dim + 1)
+    near = np.zeros(o.dim + 1)
+    n_near = 0
+    for rows in lists:
+        c, nr, n = _list_profile(o, w_before, rows, GATE_EPS)
+        cnt += c
+        near += nr
+        n_near += n
+    quantum = vmax2 * 2.0 ** (-(shift + 1))
+    tol = (lr / k) * (cnt * quantum + near)
+    tol += 8.0 * 2.0 ** -24 * (np.abs(w_after_ref) + np.abs(w_after_ref - w_before)) + 1e-9
+    return tol, n_near

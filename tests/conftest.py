@@ -28,3 +28,24 @@ def has_gpu():
         return dsgd_amd.device_count() > 0
     except Exception:
         return False
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Which branch of every conditional parity assertion ran (tests/waivers.py)."""
+    import json
+
+    import waivers
+
+    t = waivers.table()
+    if not t:
+        return
+    terminalreporter.write_sep("-", "conditional parity assertions: strict / waived")
+    for fam, v in t.items():
+        terminalreporter.write_line("%-58s strict %4d   waived %4d  %s" % (fam, v["strict"], v["waived"], "; ".join(v["reasons"][:3])))
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "waivers.json"), "w") as f:
+            json.dump(t, f, indent=1)
+    except OSError:
+        pass

@@ -23,6 +23,7 @@ import numpy as np
 import pytest
 
 import dsgd_amd
+import waivers
 from conftest import has_gpu
 from oracle import bounds as orb
 from oracle import oracle as orc
@@ -37,13 +38,10 @@ def tol(w_ref):
     return 1e-5 * max(1.0, float(np.abs(w_ref).max()))
 
 
-FORCE_TILED, FORCE_ROWS = 2, 4  # include/dsgd.h DSGD_F_*
-
-
-def make_pair(data, lam, n_train, flags=0):
+def make_pair(data, lam, n_train):
     o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, lam)
     o.set_dim_sparsity(o.dim_sparsity(n_train))
-    eng = dsgd_amd.Engine(data.dim, lam, flags=flags)
+    eng = dsgd_amd.Engine(data.dim, lam)
     eng.load_csr(data.row_ptr, data.col, data.val, data.label)
     ds = eng.build_dim_sparsity(n_train)
     # dimSparsity (Main.scala:54-65) built on the device == oracle's, to fp32 rounding of 1/(c+1)
@@ -51,8 +49,9 @@ def make_pair(data, lam, n_train, flags=0):
     return o, eng
 
 
-def run_sync(o, eng, lists_per_step, lr):
-    """Drive both sides through the same batches; returns (flips, rows)."""
+def run_sync(o, eng, lists_per_step, lr, family="run_sync"):
+    """Drive both sides through the same batches; returns (w_ref, flips, rows).  Every step records whether its tight
+    statement (equal active-row counts, weights within the stated tolerance) held or was waived for a near-gate row."""
     w_ref = np.zeros(o.dim + 1)
     flips = rows = 0
     for lists in lists_per_step:
@@ -63,6 +62,7 @@ def run_sync(o, eng, lists_per_step, lr):
         if st["n_active"] != o.last_stats["n_active"]:
             assert o.last_stats["min_abs_margin"] < GATE_EPS, (st, o.last_stats)
             flips += abs(st["n_active"] - o.last_stats["n_active"])
+            waivers.waived(family + ":step", "active %d vs %d, margin %.2g" % (st["n_active"], o.last_stats["n_active"], o.last_stats["min_abs_margin"]))
             eng.set_weights(w_ref.astype(np.float32))
             continue
         w = eng.get_weights().astype(np.float64)
@@ -70,7 +70,10 @@ def run_sync(o, eng, lists_per_step, lr):
         if err > tol(w_ref):
             assert o.last_stats["min_abs_margin"] < GATE_EPS, (err, tol(w_ref), o.last_stats)
             flips += 1
+            waivers.waived(family + ":step", "err %.3g, margin %.2g" % (err, o.last_stats["min_abs_margin"]))
             eng.set_weights(w_ref.astype(np.float32))
+        else:
+            waivers.strict(family + ":step")
     assert flips <= 1e-3 * rows, (flips, rows)
     return w_ref, flips, rows
 
@@ -88,6 +91,26 @@ def ranged_step(o, eng, ranges, lr):
     assert abs(st["n_active"] - o.last_stats["n_active"]) <= n_near, (st, o.last_stats, n_near)
     ratio, j = orb.worst_ratio(eng.get_weights(), w_ref, tol)
     assert ratio <= 1.0, "coordinate %d: error %.3g x its derived bound (shift %d, %d rows near the gate)" % (j, ratio, shift, n_near)
+    # (the derived bound is asserted unconditionally; what is recorded is whether it had to include near-gate rows)
+    waivers.check("ranged_step:no_near_gate_rows", n_near == 0, "%d rows near the gate" % n_near)
+    return ratio, shift, n_near
+
+
+def list_step(o, eng, lists, lr, family):
+    """One synchronous step over index lists from the ENGINE's current (non-zero) weights against the oracle under the
+    DERIVED bound (the index-list kernels accumulate integers too: oracle/bounds.py applies with the shift the launch
+    used); active-row counts may differ by at most the rows whose fp64 margin is within 1e-5 of the gate."""
+    w0 = eng.get_weights().astype(np.float64)
+    w_ref = w0.copy()
+    st = eng.sync_step(lists, lr)
+    shift = eng.tuning_info()["fix_shift"]
+    o.sync_step(w_ref, lists, lr)
+    tol_v, n_near = orb.list_bound(o, w0, w_ref, lists, lr, shift)
+    assert st["n_samples"] == sum(len(a) for a in lists)
+    assert abs(st["n_active"] - o.last_stats["n_active"]) <= n_near, (st, o.last_stats, n_near)
+    ratio, j = orb.worst_ratio(eng.get_weights(), w_ref, tol_v)
+    assert ratio <= 1.0, "coordinate %d: error %.3g x its derived bound (shift %d, %d rows near the gate)" % (j, ratio, shift, n_near)
+    waivers.check(family + ":no_near_gate_rows", n_near == 0, "%d rows near the gate" % n_near)
     return ratio, shift, n_near
 
 
@@ -143,29 +166,29 @@ def test_kat2_inactive_rows_leave_weights_untouched():
 
 
 # ---- synthetic RCV1-like data, reference default hyper-parameters ----------------------------------
-@pytest.mark.parametrize("n_rows,k_workers,batch,steps,seed,flags", [
-    (4096, 3, 100, 40, 0, 0),            # application.conf defaults: node-count 3, batch-size 100
-    (4096, 1, 100, 40, 1, 0),            # BASELINE.json configs[0]: one worker
-    (6000, 4, 200, 30, 2, 0),            # kube/config-sync.yaml: 4 nodes, batch 200
-    (3000, 2, 1, 60, 3, 0),              # ragged: single-sample batches
-    (4096, 3, 100, 40, 0, FORCE_TILED),  # same batches through the LDS-tiled kernel
-    (6000, 2, 1000, 20, 4, FORCE_TILED),
-    (6000, 2, 1000, 20, 4, FORCE_ROWS),
+@pytest.mark.parametrize("n_rows,k_workers,batch,steps,seed,dim", [
+    (4096, 3, 100, 40, 0, None),            # application.conf defaults: node-count 3, batch-size 100
+    (4096, 1, 100, 40, 1, None),            # BASELINE.json configs[0]: one worker
+    (6000, 4, 200, 30, 2, None),            # kube/config-sync.yaml: 4 nodes, batch 200
+    (3000, 2, 1, 60, 3, None),              # ragged: single-sample batches
+    (6000, 2, 1000, 20, 4, None),           # lists beyond one workgroup's sub-batch
+    (6000, 1, 2500, 12, 5, None),           # one list spread over many workgroups
+    (6000, 3, 300, 15, 6, 70000),           # wide model: ranks beyond the LDS accumulators (64-bit global ones)
 ])
-def test_sync_training_matches_oracle(n_rows, k_workers, batch, steps, seed, flags):
-    data = dsgd_amd.synth.generate(n_rows, seed=seed)
+def test_sync_training_matches_oracle(n_rows, k_workers, batch, steps, seed, dim):
+    data = dsgd_amd.synth.generate(n_rows, seed=seed, **({"dim": dim} if dim else {}))
     n_train = int(n_rows * 0.8)  # Main.scala:52
-    o, eng = make_pair(data, 1e-5, n_train, flags)
+    o, eng = make_pair(data, 1e-5, n_train)
     rng = np.random.default_rng(seed)
     with eng:
-        w_ref, flips, rows = run_sync(o, eng, batches(rng, n_train, k_workers, batch, steps), 0.5)
+        w_ref, flips, rows = run_sync(o, eng, batches(rng, n_train, k_workers, batch, steps), 0.5, "sync_training")
         w = eng.get_weights().astype(np.float64)
-        if flips == 0:
+        if waivers.check("sync_training:final_weights", flips == 0, "%d flips" % flips):
             assert np.abs(w - w_ref).max() <= tol(w_ref)
         for lo, hi in ((0, n_train), (n_train, n_rows)):
             loss, acc, counts = eng.loss_acc(lo, hi)
             loss_ref, acc_ref, counts_ref, mam = o.loss_acc(w_ref, lo, hi)
-            if mam >= GATE_EPS and flips == 0:
+            if waivers.check("sync_training:tallies", mam >= GATE_EPS and flips == 0, "margin %.2g, %d flips" % (mam, flips)):
                 assert counts == counts_ref
                 assert acc == acc_ref
                 assert abs(loss - loss_ref) <= 1e-6
@@ -182,10 +205,11 @@ def test_config0_size_two_epochs():
     rng = np.random.default_rng(0)
     steps = 2 * 62  # ceil(ceil(18519/3)/100) = 62 batches per epoch
     with eng:
-        w_ref, flips, rows = run_sync(o, eng, batches(rng, n_train, 3, 100, steps), 0.5)
+        w_ref, flips, rows = run_sync(o, eng, batches(rng, n_train, 3, 100, steps), 0.5, "config0")
         loss, acc, counts = eng.loss_acc(n_train, 23149)
         loss_ref, acc_ref, counts_ref, mam = o.loss_acc(w_ref, n_train, 23149)
-        assert sum(abs(a - b) for a, b in zip(counts, counts_ref)) <= (0 if (mam >= GATE_EPS and flips == 0) else 4)
+        exact = waivers.check("config0:tallies", mam >= GATE_EPS and flips == 0, "margin %.2g, %d flips" % (mam, flips))
+        assert sum(abs(a - b) for a, b in zip(counts, counts_ref)) <= (0 if exact else 4)
         assert acc > 0.6  # it actually learns the planted separator
 
 
@@ -200,7 +224,7 @@ def test_gradient_and_forward_against_oracle_with_given_weights():
     with eng:
         g, st = eng.gradient(idx, w=w0)  # the GradientRequest form: weights travel with the call
         g_ref = o.gradient(w0.astype(np.float64), idx)
-        if o.last_stats["min_abs_margin"] >= GATE_EPS:
+        if waivers.check("gradient_given_weights", o.last_stats["min_abs_margin"] >= GATE_EPS, "margin %.2g" % o.last_stats["min_abs_margin"]):
             assert st["n_active"] == o.last_stats["n_active"]
             np.testing.assert_allclose(g, g_ref, rtol=0, atol=1e-5 * max(1.0, np.abs(g_ref).max()))
             # support-only regulariser: identical supports (up to exact fp32 cancellations)
@@ -209,7 +233,7 @@ def test_gradient_and_forward_against_oracle_with_given_weights():
         pred = eng.forward(np.arange(4000, 5000))
         pred_ref = o.forward(w0.astype(np.float64), np.arange(4000, 5000))
         _, _, _, mam = o.loss_acc(w0.astype(np.float64), 4000, 5000)
-        if mam >= GATE_EPS:
+        if waivers.check("forward_given_weights", mam >= GATE_EPS, "margin %.2g" % mam):
             np.testing.assert_array_equal(pred, pred_ref)
         assert set(np.unique(pred)) <= {-1.0, 0.0, 1.0}
         # apply half of the batch closure: w <- w - lr * g_mean
@@ -229,8 +253,10 @@ def test_async_steps_against_oracle():
             delta, st = eng.async_step(idx, 0.5, want_delta=True)
             delta_ref = o.async_step(w_ref, idx, 0.5, want_delta=True)
             if o.last_stats["min_abs_margin"] < GATE_EPS and st["n_active"] != o.last_stats["n_active"]:
+                waivers.waived("async_steps", "margin %.2g" % o.last_stats["min_abs_margin"])
                 eng.set_weights(w_ref.astype(np.float32))
                 continue
+            waivers.strict("async_steps")
             assert st["n_active"] == o.last_stats["n_active"]
             np.testing.assert_allclose(delta, delta_ref, rtol=0, atol=1e-6)
             np.testing.assert_allclose(eng.get_weights(), w_ref, rtol=0, atol=tol(w_ref))
@@ -247,7 +273,7 @@ def test_plan_run_equals_step_by_step():
     rng = np.random.default_rng(9)
     steps = batches(rng, 3276, 3, 100, 20)
     with eng:
-        w_ref, flips, rows = run_sync(o, eng, steps, 0.5)
+        w_ref, flips, rows = run_sync(o, eng, steps, 0.5, "plan_run")
         w_a = eng.get_weights()
         eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
         plan = eng.plan(steps)
@@ -257,7 +283,7 @@ def test_plan_run_equals_step_by_step():
         assert st["n_samples"] == rows
         w_b = eng.get_weights()
         plan.destroy()
-        if flips == 0:
+        if waivers.check("plan_run:replay", flips == 0, "%d flips" % flips):
             np.testing.assert_allclose(w_b, w_a, rtol=0, atol=tol(w_ref))
 
 
@@ -330,6 +356,7 @@ def test_full_size_whole_shard_steps_match_oracle(full):
     loss_ref, acc_ref, counts_ref, mam = o.loss_acc(w_ref, n_train, data.n_rows)
     assert sum(counts) == data.n_rows - n_train
     n_near, _ = o.gate_profile(w_ref, n_train, data.n_rows)
+    waivers.check("full_size:tallies_exact", n_near == 0, "%d test rows near the gate" % n_near)
     assert sum(abs(a - b) for a, b in zip(counts, counts_ref)) <= 2 * n_near
     assert abs(loss - loss_ref) <= 1e-6 * max(1.0, abs(loss_ref)) + 2.0 * n_near / (data.n_rows - n_train)
 
@@ -349,8 +376,10 @@ def test_full_size_properties(full):
     eng.sync_step_ranges([(0, n_train)], 1.0)  # w = 0 - 1.0 * g(all)
     w = eng.get_weights()
     scale = max(1.0, float(np.abs(w).max()))
-    # engine against ITSELF (not an oracle comparison): ga / gb come from the index-list kernels, which accumulate
-    # ~3e5 terms per coordinate with fp32 L2 atomics in arrival order; the range step is exact integers
+    # engine against ITSELF (not an oracle comparison; that is test_mid_size_index_lists_match_oracle): ga / gb come
+    # from the index-list kernel (per-workgroup fixed-point sums at ITS shift, one rounding each), the range step from
+    # the streaming kernels at theirs: up to ~3e5 contributions per coordinate, each off by half a grid unit of either
+    # grid, plus the fp32 roundings of two gradients of magnitude ~scale
     assert np.abs(-(ga + gb) - w).max() <= 2e-4 * scale
     # (2) two workers on the two halves = mean of the halves (Master.scala:194)
     eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
@@ -369,16 +398,15 @@ def test_full_size_properties(full):
     np.testing.assert_array_equal(eng.get_weights(), w0)
 
 
-# ---- the two streaming layouts (DSGD_STREAM=3: gathers + cold lists, =4: split matrix) and a wide model ----------
-@pytest.mark.parametrize("mode,dim,hsplit", [("4", dsgd_amd.synth.RCV1_DIM, None), ("3", dsgd_amd.synth.RCV1_DIM, None),
-                                             ("4", 70000, None),      # cold columns beyond the cold kernels' LDS tile
-                                             ("4", 90000, None),      # more than 65536 cold columns: unpacked cold stream
-                                             ("4u", dsgd_amd.synth.RCV1_DIM, None),    # unpacked cold stream, forced
-                                             ("4", dsgd_amd.synth.RCV1_DIM, "3000"),   # short hot part, long cold rows
-                                             ("4", 3000, None)])       # no cold stream at all
+# ---- the split layout's variants: packed / unpacked cold stream, wide models, no cold stream at all -------------------
+@pytest.mark.parametrize("mode,dim,hsplit", [("p", dsgd_amd.synth.RCV1_DIM, None),
+                                             ("p", 70000, None),      # cold columns beyond the cold kernels' LDS tile
+                                             ("p", 90000, None),      # more than 65536 cold columns: unpacked cold stream
+                                             ("u", dsgd_amd.synth.RCV1_DIM, None),    # unpacked cold stream, forced
+                                             ("p", dsgd_amd.synth.RCV1_DIM, "3000"),   # short hot part, long cold rows
+                                             ("p", 3000, None)])       # no cold stream at all
 def test_streaming_layouts_match_oracle(monkeypatch, mode, dim, hsplit):
-    monkeypatch.setenv("DSGD_STREAM", mode[0])
-    if mode.endswith("u"):
+    if mode == "u":
         monkeypatch.setenv("DSGD_COLD_UNPACKED", "1")
     if hsplit:
         monkeypatch.setenv("DSGD_HSPLIT", hsplit)
@@ -395,7 +423,7 @@ def test_streaming_layouts_match_oracle(monkeypatch, mode, dim, hsplit):
             loss, acc, counts = eng.loss_acc(lo, hi)
             _, _, counts_ref, mam = o.loss_acc(eng.get_weights().astype(np.float64), lo, hi)
             assert sum(counts) == hi - lo
-            if mam >= GATE_EPS:
+            if waivers.check("streaming_layouts:tallies", mam >= GATE_EPS, "margin %.2g" % mam):
                 assert counts == counts_ref
         # bit-reproducible: the same step from the same weights twice.  The first run starts from the regulariser scalar
         # s = 2 lambda (w . ds) the previous step left behind, the second from the one dsgd_set_weights re-derives: every
@@ -453,7 +481,7 @@ def test_plan_kernel_and_multi_launch_path_agree_with_the_oracle(monkeypatch, k_
         o, eng = make_pair(data, 1e-5, n_train)
         with eng:
             assert eng.tuning_info()["plan_kernel"] == int(mode)
-            w_ref, flips, rows = run_sync(o, eng, steps, 0.5)
+            w_ref, flips, rows = run_sync(o, eng, steps, 0.5, "plan_vs_multi")
             name = eng.grad_kernel_name()
             # one hosted worker with lists of up to PLAN_CAP = 192 rows (and 192 work items of 128 non-zeros) takes the
             # persistent workgroup; longer lists, several workers per step (and DSGD_PLAN_KERNEL=0) the
@@ -464,7 +492,7 @@ def test_plan_kernel_and_multi_launch_path_agree_with_the_oracle(monkeypatch, k_
             # the resident-plan form of the same steps: identical to the step-by-step calls bit for bit in the
             # plan kernel (integer sums, fixed sweep order)
             w_steps = eng.get_weights()
-            if flips == 0:
+            if waivers.check("plan_vs_multi:replay", flips == 0, "%d flips" % flips):
                 eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
                 plan = eng.plan(steps)
                 eng.plan_run(plan, 0, 7, 0.5)
@@ -479,9 +507,11 @@ def test_plan_kernel_and_multi_launch_path_agree_with_the_oracle(monkeypatch, k_
                     np.testing.assert_allclose(eng.get_weights(), w_steps, rtol=0, atol=tol(w_ref))
                 loss, acc, counts = eng.loss_acc(n_train, n_rows)   # |w|^2 is refreshed after a plan launch
                 loss_ref, acc_ref, counts_ref, mam = o.loss_acc(eng.get_weights().astype(np.float64), n_train, n_rows)
-                assert abs(loss - loss_ref) <= 1e-6 and (mam < GATE_EPS or counts == counts_ref)
+                assert abs(loss - loss_ref) <= 1e-6
+                if waivers.check("plan_vs_multi:tallies", mam >= GATE_EPS, "margin %.2g" % mam):
+                    assert counts == counts_ref
             ws[mode] = (w_steps, flips)
-    if ws["1"][1] == 0 and ws["0"][1] == 0:
+    if waivers.check("plan_vs_multi:both_paths", ws["1"][1] == 0 and ws["0"][1] == 0, "flips %d / %d" % (ws["1"][1], ws["0"][1])):
         assert np.abs(ws["1"][0] - ws["0"][0]).max() <= 2 * tol(ws["1"][0])
 
 
@@ -511,8 +541,8 @@ def test_communicator_of_size_one_changes_nothing():
     np.testing.assert_array_equal(ws0, ws1)          # whole-range steps: integer sums, bit-identical
     assert st0 == st1
     assert la0[2] == la1[2]                          # tallies
-    # index-list steps accumulate with fp32 L2 atomics: equal to rounding only
-    assert np.abs(w0 - w1).max() <= 1e-5 * max(1.0, np.abs(w0).max())
+    # index-list steps: integer sums as well -- the same per-block arithmetic on both sides of the collective
+    np.testing.assert_array_equal(w0, w1)
 
 
 # ---- ragged inputs: empty rows, one-element rows, values below the Sparse epsilon ---------------------
@@ -537,35 +567,36 @@ def ragged_data(seed, n_rows=6000):
                               np.asarray(val, np.float32), base.label.copy())
 
 
-@pytest.mark.parametrize("flags", [0, FORCE_TILED, FORCE_ROWS])
-def test_ragged_rows_all_kernel_paths(flags):
-    data = ragged_data(21)
-    n_train = 4800
-    o, eng = make_pair(data, 1e-5, n_train, flags)
+def test_ragged_rows_all_kernel_paths():
+    data = ragged_data(21, n_rows=24000)
+    n_train = 20000
+    o, eng = make_pair(data, 1e-5, n_train)
     rng = np.random.default_rng(21)
     with eng:
-        # index-list batches (row-wise kernels) ...
-        w_ref, flips, rows = run_sync(o, eng, batches(rng, n_train, 2, 300, 10), 0.5)
-        # ... then whole contiguous ranges (streaming kernels when flags == FORCE_TILED), lr scaled to the batch
-        lr = 0.5 * 100 / 2400
-        for step in range(4):
-            if flags == FORCE_TILED:   # whole contiguous ranges go through the streaming kernels: derived bound
-                ranged_step(o, eng, [(0, 2400), (2400, 4800)], lr)
-                continue
+        # index-list batches (mini-batch engine: empty rows have no work item, 1e-25 entries vanish on the grid) ...
+        w_ref, flips, rows = run_sync(o, eng, batches(rng, n_train, 2, 300, 10), 0.5, "ragged")
+        # ... whole contiguous ranges through the streaming kernels (derived bound) ...
+        lr = 0.5 * 100 / 10000
+        for step in range(3):
+            ranged_step(o, eng, [(0, 10000), (10000, 20000)], lr)
+        # ... and ranges too small for them (the mini-batch engine walks the rows of the range itself)
+        for step in range(3):
             w_ref = eng.get_weights().astype(np.float64)
-            st = eng.sync_step_ranges([(0, 2400), (2400, 4800)], lr)
-            o.sync_step(w_ref, [np.arange(0, 2400), np.arange(2400, 4800)], lr)
+            st = eng.sync_step_ranges([(100, 2500), (2500, 4900)], 0.5 * 100 / 2400)
+            o.sync_step(w_ref, [np.arange(100, 2500), np.arange(2500, 4900)], 0.5 * 100 / 2400)
             assert st["n_samples"] == 4800
             if st["n_active"] != o.last_stats["n_active"]:
                 assert o.last_stats["min_abs_margin"] < GATE_EPS
+                waivers.waived("ragged:small_ranges", "margin %.2g" % o.last_stats["min_abs_margin"])
                 continue
+            waivers.strict("ragged:small_ranges")
             w = eng.get_weights().astype(np.float64)
-            assert np.abs(w - w_ref).max() <= tol(w_ref)  # one step of the fp32 row-wise kernels from identical weights
+            assert np.abs(w - w_ref).max() <= tol(w_ref)
         for lo, hi in ((0, n_train), (n_train, data.n_rows), (100, 4700)):
             loss, acc, counts = eng.loss_acc(lo, hi)
             loss_ref, acc_ref, counts_ref, mam = o.loss_acc(eng.get_weights().astype(np.float64), lo, hi)
             assert sum(counts) == hi - lo
-            if mam >= GATE_EPS:
+            if waivers.check("ragged:tallies", mam >= GATE_EPS, "margin %.2g" % mam):
                 assert counts == counts_ref
         # an all-zero weight vector: every row (also the empty ones) is active, predictions are 0
         eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
@@ -573,6 +604,43 @@ def test_ragged_rows_all_kernel_paths(flags):
         assert st["n_active"] == n_train
         _, _, counts = eng.loss_acc(0, n_train)
         assert counts == [0, n_train, 0]
+
+
+# ---- mid-size index lists (SURVEY.md 8(d)'s sweep: B = 4,096 and 65,536) directly against the oracle ----------------
+@pytest.fixture(scope="module")
+def mid():
+    data = dsgd_amd.synth.generate(200000, seed=3)
+    n_train = 160000
+    o, eng = make_pair(data, 1e-5, n_train)
+    yield data, n_train, o, eng
+    eng.close()
+
+
+@pytest.mark.parametrize("k_workers,batch", [(1, 4096), (1, 65536), (3, 4096), (4, 200), (3, 100)])
+def test_mid_size_index_lists_match_oracle(mid, k_workers, batch):
+    """bench.py's `sweep` sizes as index lists: ONE synchronous step each from identical NON-ZERO weights against the
+    oracle under the derived per-coordinate bound (the index-list kernel sums integers: cnt_j contributions off by at
+    most half a grid unit of the shift the launch used, plus the rows within 1e-5 of the gate), three steps in a row
+    with the engine's weights carried over; then the same step twice from the same weights is bit-identical."""
+    data, n_train, o, eng = mid
+    rng = np.random.default_rng(batch + k_workers)
+    w0 = np.zeros(data.dim + 1, dtype=np.float32)
+    hot = rng.choice(np.arange(1, data.dim + 1), size=6000, replace=False)
+    w0[hot] = rng.normal(scale=0.05, size=6000).astype(np.float32)
+    eng.set_weights(w0)
+    lr = 0.5 * 100 / batch
+    fam = "mid_size_lists"
+    for step in range(3):
+        lists = batches(rng, n_train, k_workers, batch, 1)[0]
+        ratio, shift, n_near = list_step(o, eng, lists, lr, fam)
+        assert eng.grad_kernel_name() == "dsgd_mb_grad_kernel"
+    w1 = eng.get_weights()
+    lists = batches(rng, n_train, k_workers, batch, 1)[0]
+    eng.sync_step(lists, lr)
+    w2 = eng.get_weights()
+    eng.set_weights(w1)
+    eng.sync_step(lists, lr)
+    np.testing.assert_array_equal(eng.get_weights(), w2)   # integer sums, fixed order: bit-reproducible
 
 
 # ---- persistent lock-free ("Hogwild") engine -----------------------------------------------------------
@@ -625,60 +693,71 @@ def test_hogwild_single_worker_replays_the_oracle():
                 o.async_step(w_ref, rows, 0.5)
                 exposed = exposed or o.last_stats["min_abs_margin"] < GATE_EPS
             w = eng.get_weights().astype(np.float64)
-            if not exposed:
+            if waivers.check("hogwild_single_worker", not exposed, "a replayed row within 1e-5 of the gate"):
                 assert np.abs(w - w_ref).max() <= 4 * tol(w_ref), (batch, np.abs(w - w_ref).max())
 
 
-def stale_round_oracle(o, split, batch, n_upd, lr, dim, seed=0):
-    """Bracket for the lock-free engine: rounds in which ALL workers read the same snapshot (maximal staleness)."""
-    rng = np.random.default_rng(seed)
-    w = np.zeros(dim + 1)
-    k = len(split)
-    for _ in range(n_upd // k):
-        snap = w.copy()
-        for b, e in split:
-            tmp = snap.copy()
-            w -= o.async_step(tmp, rng.permutation(np.arange(b, e))[:batch].astype(np.int32), lr, want_delta=True)
-    return w
-
-
-@pytest.mark.parametrize("k", [4, 64])
-def test_hogwild_many_workers_statistical_parity(k):
-    """The reference deploys 4 slaves (kube/dsgd.yaml:95); 64 workers show the staleness of a wide machine.
-    The engine must land inside the band spanned by the two orderings a lock-free run interpolates between:
-    updates applied one after the other (fresh reads) and rounds where every worker reads the same snapshot."""
-    data = dsgd_amd.synth.generate(40000, seed=13)
-    n_train = 32000
-    o, eng = make_pair(data, 1e-5, n_train)
-    batch, n_upd = 100, 3200
-    split = [(r.start, r.stop) for r in rd.split_vanilla(n_train, k)]
-    with eng:
-        eng.async_start(split, batch=batch, lr=0.5, max_updates=n_upd, seed=5, positional_bug=False)
-        seen = []
-        while True:
-            u, running = eng.async_updates()
-            seen.append(u)
-            if not running:
-                break
-            loss, acc, counts = eng.loss_acc(n_train, data.n_rows)  # the master's loss check runs concurrently
-            assert sum(counts) == data.n_rows - n_train
+def engine_hogwild_curve(eng, split, batch, lr, checkpoints, eval_range, seed, poll_first_segment=False):
+    """The lock-free engine run in segments ending at the checkpoints (every segment a fresh dsgd_async_start with its
+    own sampling seed); returns ([(updates, loss, acc)], final weights, per-segment update counts)."""
+    curve, counts, total, prev = [], [], 0, 0
+    for c, target in enumerate(checkpoints):
+        eng.async_start(split, batch=batch, lr=lr, max_updates=target - prev, seed=seed + 7919 * c, positional_bug=False)
+        if poll_first_segment and c == 0:
+            seen = []
+            while True:
+                u, running = eng.async_updates()
+                seen.append(u)
+                if not running:
+                    break
+                _, _, cnts = eng.loss_acc(*eval_range)   # the master's loss check runs concurrently (MasterAsync.scala:96-162)
+                assert sum(cnts) == eval_range[1] - eval_range[0]
+            assert seen == sorted(seen)
         eng.async_wait()
         u, running = eng.async_updates()
-        assert not running and n_upd <= u <= n_upd + k  # every worker finishes its current mini-batch
-        assert seen == sorted(seen)
-        w = eng.get_weights()
-        assert np.isfinite(w).all()
-        loss, acc, _ = eng.loss_acc(n_train, data.n_rows)
-        rng = np.random.default_rng(0)
-        w_seq = np.zeros(data.dim + 1)
-        for it in range(n_upd):
-            b, e = split[it % k]
-            o.async_step(w_seq, rng.permutation(np.arange(b, e))[:batch].astype(np.int32), 0.5)
-        acc_seq = o.loss_acc(w_seq, n_train, data.n_rows)[1]
-        acc_stale = o.loss_acc(stale_round_oracle(o, split, batch, n_upd, 0.5, data.dim), n_train, data.n_rows)[1]
-        lo, hi = min(acc_seq, acc_stale), max(acc_seq, acc_stale)
-        assert lo - 0.12 <= acc <= hi + 0.08, (acc, acc_seq, acc_stale)  # a lock-free run is not reproducible
-        assert acc > 0.55
+        assert not running and target - prev <= u <= target - prev + len(split)   # every worker finishes its mini-batch
+        counts.append(u)
+        total += u
+        prev = target
+        loss, acc, _ = eng.loss_acc(*eval_range)
+        curve.append((total, loss, acc))
+    return curve, eng.get_weights().astype(np.float64), counts
+
+
+@pytest.mark.parametrize("k,n_rows,checkpoints", [
+    (4, 40000, [800, 1600, 2400, 3200]),            # the reference deploys 4 slaves (kube/dsgd.yaml:95)
+    (64, 40000, [800, 1600, 2400, 3200]),           # the staleness of a wide machine
+    (256, 100000, [2048, 4096, 6144, 8192]),        # the benchmarked shape (bench.py hogwild: 256 workers x batch 100)
+])
+def test_hogwild_many_workers_inside_the_oracle_band(k, n_rows, checkpoints):
+    """A lock-free run is not reproducible; the ORACLE supplies the band it must land in (oracle/hogwild_band.py): the
+    reference's asynchronous iteration replayed with 5 sampling seeds in each of the two orderings a lock-free run
+    interpolates between -- sequential (fresh reads) and stale rounds (all workers read one snapshot) -- compared on
+    test loss and test accuracy averaged over the second half of the checkpoints and on |w|_2 at the end; band = the
+    oracle's own [min, max] widened by the stated margins (loss 0.06, accuracy 0.03, |w| 10 %)."""
+    from oracle import hogwild_band as hb
+
+    data = dsgd_amd.synth.generate(n_rows, seed=13)
+    n_train = int(n_rows * 0.8)
+    o, eng = make_pair(data, 1e-5, n_train)
+    batch, lr = 100, 0.5
+    split = [(r.start, r.stop) for r in rd.split_vanilla(n_train, k)]
+    ev = (n_train, data.n_rows)
+    band = hb.band(o, split, batch, checkpoints, lr, ev, n_seeds=5)
+    with eng:
+        runs = []
+        for seed in (5, 6, 7):
+            eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+            curve, w, counts = engine_hogwild_curve(eng, split, batch, lr, checkpoints, ev, seed, poll_first_segment=(seed == 5))
+            assert np.isfinite(w).all()
+            summ = hb.summarise(curve, w)
+            runs.append((summ, hb.inside(band, summ), counts))
+        print("hogwild k=%d band: loss [%.3f, %.3f] acc [%.3f, %.3f] |w| [%.2f, %.2f]; engine runs: %s" % (
+            k, band["loss"]["lo"], band["loss"]["hi"], band["acc"]["lo"], band["acc"]["hi"], band["wnorm"]["lo"],
+            band["wnorm"]["hi"], [(round(r[0]["loss"], 3), round(r[0]["acc"], 3), round(r[0]["wnorm"], 2)) for r in runs]))
+        for summ, ok, counts in runs:
+            assert all(ok.values()), (summ, ok, {q: band[q] for q in ("loss", "acc", "wnorm")}, counts)
+        assert min(r[0]["acc"] for r in runs) > 0.55
         # stop() interrupts a run that would otherwise go on for a long time
         eng.async_start(split, batch=batch, lr=0.5, max_updates=10**9, seed=6)
         eng.async_stop()
@@ -686,6 +765,62 @@ def test_hogwild_many_workers_statistical_parity(k):
         assert not running and 0 <= u2 < 10**9
         st = eng.sync_step([np.arange(100, dtype=np.int32)], 0.5)  # synchronous calls work again afterwards
         assert st["n_samples"] == 100
+
+
+def test_update_grad_arrives_while_the_engine_runs():
+    """SlaveImpl.updateGrad is an RPC handler that runs CONCURRENTLY with asyncTask (core/Slave.scala:177-185 vs
+    :79-111; the master's copy: core/MasterAsync.scala:164-177).  With the persistent engine resident every push must
+    return quickly (no allocation, nothing that synchronises the device), land exactly -- on coordinates the engine never
+    touches the weights are minus the pushed sums, bit for bit -- and be folded into the engine's incrementally kept
+    regulariser scalar."""
+    import time
+
+    data = dsgd_amd.synth.generate(40000, seed=19)
+    n_train = 32000
+    o, eng = make_pair(data, 1e-5, n_train)
+    k = 64
+    split = [(r.start, r.stop) for r in rd.split_vanilla(n_train, k)]
+    b, e = int(data.row_ptr[0]), int(data.row_ptr[n_train])
+    present = np.bincount(data.col[b:e], minlength=data.dim + 1) > 0
+    untouched = np.flatnonzero(~present)[1:]          # keys no training row holds (key 0 is never a feature id)
+    assert len(untouched) >= 500
+    rng = np.random.default_rng(19)
+    keys_u = rng.choice(untouched, size=400, replace=False).astype(np.int32)
+    keys_t = rng.choice(np.flatnonzero(present), size=200, replace=False).astype(np.int32)   # contended with the engine
+    with eng:
+        with pytest.raises(IndexError):
+            eng.update_grad(np.asarray([1, data.dim + 1], dtype=np.int32), np.ones(2, dtype=np.float32))
+        assert not eng.get_weights().any()            # a rejected update applies nothing
+        eng.async_start(split, batch=100, lr=0.5, max_updates=10**9, seed=3, positional_bug=False)
+        expect = np.zeros(len(keys_u), dtype=np.float32)
+        times = []
+        for push in range(150):
+            dv_u = rng.normal(scale=0.01, size=len(keys_u)).astype(np.float32)
+            dv_t = rng.normal(scale=1e-4, size=len(keys_t)).astype(np.float32)
+            t0 = time.perf_counter()
+            eng.update_grad(np.concatenate([keys_u, keys_t]), np.concatenate([dv_u, dv_t]))
+            times.append(time.perf_counter() - t0)
+            expect = expect - dv_u                    # fp32, in call order: what the atomic adds do to an uncontended word
+        u_mid, running = eng.async_updates()
+        assert running and u_mid > 0                  # all of it happened under a running engine
+        s_eng_run, s_exact_run = eng.async_regulariser()
+        eng.async_stop()
+        u_end, running = eng.async_updates()
+        assert not running and u_end >= u_mid
+        w = eng.get_weights()
+        np.testing.assert_array_equal(w[keys_u], expect)
+        assert np.isfinite(w).all()
+        med = float(np.median(times))
+        print("update_grad under the engine: median %.0f us, max %.0f us over %d calls; %d engine updates meanwhile; "
+              "s engine %.6g vs exact %.6g while running" % (1e6 * med, 1e6 * max(times), len(times), u_end, s_eng_run, s_exact_run))
+        assert med < 1e-3, times
+        # the engine's own scalar followed the foreign updates (and its own ~10^5+ increments): compare with the exact
+        # re-derivation from the final weights
+        s_eng, s_exact = eng.async_regulariser()
+        assert abs(s_eng - s_exact) <= 2e-3 * abs(s_exact) + 1e-9, (s_eng, s_exact)
+        # the same call in the synchronous setting still applies w - delta with the Sparse filter
+        eng.update_grad(keys_u, expect)               # w[keys_u] -= expect -> exactly 0
+        assert not eng.get_weights()[keys_u].any()
 
 
 def test_cross_gpu_exchange_with_one_rank_equals_the_plain_engine():

@@ -1,0 +1,79 @@
+"""The test-only collective shim (tests/rccl_stub) checked on its own, without a GPU: two PROCESSES attach to one
+communicator and all-reduce host buffers (DSGD_RCCL_STUB_HOSTMEM=1 makes the shim treat its buffers as host memory).
+What libdsgd_hip does with it on a real device is tests/test_gpu_world2.py."""
+
+import ctypes as C
+import multiprocessing as mp
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "rccl_stub", "rccl_stub.cpp")
+LIB = os.path.join(HERE, "rccl_stub", "librccl_stub.so")
+
+
+def build_stub():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", SRC, "-o", LIB, "-ldl", "-lpthread", "-lrt"])
+    return LIB
+
+
+class Uid(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+def _rank(rank, world, uid_bytes, q):
+    os.environ["DSGD_RCCL_STUB_HOSTMEM"] = "1"
+    lib = C.CDLL(LIB)
+    uid = Uid()
+    C.memmove(C.byref(uid), uid_bytes, 128)
+    comm = C.c_void_p()
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+    lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    assert lib.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+    out = {}
+    rng = np.random.default_rng(rank)
+    for it in range(20):   # many collectives back to back: the two barriers per call keep the slots consistent
+        a = rng.normal(size=47237).astype(np.float32)
+        r = np.empty_like(a)
+        assert lib.ncclAllReduce(a.ctypes.data, r.ctypes.data, a.size, 7, 0, comm, None) == 0
+        out["f%d" % it] = (a, r)
+    u = (np.arange(1000, dtype=np.uint32) * (rank + 1)).copy()
+    assert lib.ncclAllReduce(u.ctypes.data, u.ctypes.data, u.size, 3, 0, comm, None) == 0   # in place
+    t = np.asarray([1, 2, 3, 10 ** 12 * (rank + 1)], dtype=np.int64)
+    assert lib.ncclAllReduce(t.ctypes.data, t.ctypes.data, 4, 4, 0, comm, None) == 0
+    big = np.zeros(300000, dtype=np.float32)
+    assert lib.ncclAllReduce(big.ctypes.data, big.ctypes.data, big.size, 7, 0, comm, None) != 0   # beyond the slot: an error, not a hang
+    lib.ncclGetErrorString.restype = C.c_char_p
+    assert b"slot" in lib.ncclGetErrorString(2)
+    assert lib.ncclCommDestroy(comm) == 0
+    q.put((rank, {k: v for k, v in out.items()}, u, t))
+
+
+def test_two_processes_allreduce_through_the_shim():
+    build_stub()
+    lib = C.CDLL(LIB)
+    uid = Uid()
+    assert lib.ncclGetUniqueId(C.byref(uid)) == 0
+    uid_bytes = bytes(uid)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rank, args=(r, 2, uid_bytes, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in ps:
+        rank, out, u, t = q.get(timeout=120)
+        res[rank] = (out, u, t)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for it in range(20):
+        a0, r0 = res[0][0]["f%d" % it]
+        a1, r1 = res[1][0]["f%d" % it]
+        np.testing.assert_array_equal(r0, r1)          # every rank receives the identical sum ...
+        np.testing.assert_array_equal(r0, a0 + a1)     # ... added in rank order
+    np.testing.assert_array_equal(res[0][1], np.arange(1000, dtype=np.uint32) * 3)
+    np.testing.assert_array_equal(res[1][2], np.asarray([2, 4, 6, 3 * 10 ** 12], dtype=np.int64))

@@ -1,5 +1,5 @@
 """A/B runs of the whole-shard gradient step under different environment knobs, one subprocess per variant.
-usage: python tools/variants.py [--rows N] "DSGD_PF=3" "DSGD_PF=4 DSGD_EPI=0" ...   ("" = defaults)"""
+usage: python tools/variants.py [--rows N] "" "DSGD_FIX_BOUND=0" "DSGD_HSPLIT=16384 DSGD_FIX_SHIFT=18" ...   ("" = defaults)"""
 import os, subprocess, sys, time
 
 def child(rows):
