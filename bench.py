@@ -68,7 +68,15 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # poll all ranks: a rank that dies before the rendezvous would leave the others waiting for it forever
     rc = 0
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            time.sleep(5.0)   # let the survivors report, then end exactly the processes started here
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+        time.sleep(0.2)
     for p in procs:
         rc = max(rc, abs(p.wait()))
     return rc

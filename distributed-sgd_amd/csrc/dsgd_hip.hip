@@ -2390,6 +2390,10 @@ static int dn_launch(dsgd_dense* d, long long rb, long long re, bool grad) {
   const int grid = (int)std::max<long long>(1, std::min<long long>(d->mfma ? d->n_cu : d->n_wg, n_blocks));
   size_t slot = (size_t)-1;
   if (d->prof && grad) {
+    if (d->ev_used == d->ev.size() && d->ev.size() >= 4096) {   // bounded pool: collect what has completed so far
+      HIP_TRY(hipStreamSynchronize(d->stream));
+      DSGD_TRY(dn_collect(d));
+    }
     if (d->ev_used == d->ev.size()) {
       hipEvent_t x, y;
       HIP_TRY(hipEventCreate(&x));

@@ -346,6 +346,10 @@ class HostAsyncExchange:
         if self.world > 1 or np.any(others != 0.0):
             w = w - others
             self.local.set_weights(w)
+            # what the backend really holds now: an fp32 engine rounds on store, and a w_prev that kept the fp64 value
+            # would gossip that rounding residue to the peers as if it were an update (the device kernel sets its
+            # w_prev to the rounded value too)
+            w = np.asarray(self.local.get_weights(), dtype=np.float64)
         self.w_prev = w.copy()
         self.rounds += 1
 

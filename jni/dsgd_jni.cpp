@@ -39,13 +39,15 @@ jint raise(JNIEnv* env, int rc) {
 inline dsgd_ctx* ctx(jlong h) { return reinterpret_cast<dsgd_ctx*>(h); }
 
 // RAII views of primitive arrays.  `mode` 0 copies changes back (outputs), JNI_ABORT discards them (inputs).
-#define DSGD_ELEMS(Name, T)                                                                          \
+// (each view keeps its TYPED array reference: in the JDK's jni.h jlongArray, jintArray, ... are distinct classes derived
+// from _jarray, and Get/Release<Type>ArrayElements take exactly their own)
+#define DSGD_ELEMS(Name, T, A)                                                                       \
   struct Name##Elems {                                                                               \
     JNIEnv* env;                                                                                     \
-    jarray arr;                                                                                      \
+    A arr;                                                                                           \
     T* p;                                                                                            \
     jint mode;                                                                                       \
-    Name##Elems(JNIEnv* e, jarray a, jint m)                                                         \
+    Name##Elems(JNIEnv* e, A a, jint m)                                                              \
         : env(e), arr(a), p(a ? e->Get##Name##ArrayElements(a, nullptr) : nullptr), mode(m) {}       \
     ~Name##Elems() {                                                                                 \
       if (p) env->Release##Name##ArrayElements(arr, p, mode);                                        \
@@ -53,10 +55,10 @@ inline dsgd_ctx* ctx(jlong h) { return reinterpret_cast<dsgd_ctx*>(h); }
     Name##Elems(const Name##Elems&) = delete;                                                        \
     Name##Elems& operator=(const Name##Elems&) = delete;                                             \
   };
-DSGD_ELEMS(Long, jlong)
-DSGD_ELEMS(Int, jint)
-DSGD_ELEMS(Float, jfloat)
-DSGD_ELEMS(Byte, jbyte)
+DSGD_ELEMS(Long, jlong, jlongArray)
+DSGD_ELEMS(Int, jint, jintArray)
+DSGD_ELEMS(Float, jfloat, jfloatArray)
+DSGD_ELEMS(Byte, jbyte, jbyteArray)
 #undef DSGD_ELEMS
 }  // namespace
 

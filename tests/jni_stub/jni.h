@@ -25,22 +25,35 @@ typedef float jfloat;
 typedef double jdouble;
 typedef jint jsize;
 
-/* a fake array object: the tests build these through ctypes (length, element size, data pointer) */
-struct _jobject {
+/* a fake array object: the tests build these through ctypes (length, element size, data pointer).  The reference
+ * types mirror the REAL header's C++ class hierarchy (JNI specification, chapter 3: `class _jarray : public _jobject`,
+ * `class _jlongArray : public _jarray`, ...): a plain jarray does NOT convert to jlongArray implicitly, and code that
+ * relies on such a conversion must fail to compile here exactly as it would against a JDK. */
+class _jobject {
+ public:
   jsize length;
   jint elem_size;
   void* data;
 };
+class _jclass : public _jobject {};
+class _jthrowable : public _jobject {};
+class _jarray : public _jobject {};
+class _jlongArray : public _jarray {};
+class _jintArray : public _jarray {};
+class _jfloatArray : public _jarray {};
+class _jdoubleArray : public _jarray {};
+class _jbyteArray : public _jarray {};
+class _jobjectArray : public _jarray {};
 typedef _jobject* jobject;
-typedef jobject jclass;
-typedef jobject jthrowable;
-typedef jobject jarray;
-typedef jarray jlongArray;
-typedef jarray jintArray;
-typedef jarray jfloatArray;
-typedef jarray jdoubleArray;
-typedef jarray jbyteArray;
-typedef jarray jobjectArray;
+typedef _jclass* jclass;
+typedef _jthrowable* jthrowable;
+typedef _jarray* jarray;
+typedef _jlongArray* jlongArray;
+typedef _jintArray* jintArray;
+typedef _jfloatArray* jfloatArray;
+typedef _jdoubleArray* jdoubleArray;
+typedef _jbyteArray* jbyteArray;
+typedef _jobjectArray* jobjectArray;
 
 /* what the fake environment records (read back by the tests) */
 struct JniStubLog {
@@ -71,24 +84,24 @@ struct JNIEnv_ {
   }
   void ReleasePrimitiveArrayCritical(jarray, void*, jint) {}
 
-#define DSGD_STUB_ARRAY(T, Name)                                                            \
-  T* Get##Name##ArrayElements(jarray a, jboolean* is_copy) {                                \
+#define DSGD_STUB_ARRAY(T, Name, A)                                                         \
+  T* Get##Name##ArrayElements(A a, jboolean* is_copy) {                                     \
     if (is_copy) *is_copy = 0;                                                              \
     log.n_get++;                                                                            \
     return static_cast<T*>(a->data);                                                        \
   }                                                                                         \
-  void Release##Name##ArrayElements(jarray, T*, jint) { log.n_release++; }                  \
-  void Get##Name##ArrayRegion(jarray a, jsize start, jsize len, T* buf) {                   \
+  void Release##Name##ArrayElements(A, T*, jint) { log.n_release++; }                       \
+  void Get##Name##ArrayRegion(A a, jsize start, jsize len, T* buf) {                        \
     memcpy(buf, static_cast<T*>(a->data) + start, sizeof(T) * static_cast<size_t>(len));    \
   }                                                                                         \
-  void Set##Name##ArrayRegion(jarray a, jsize start, jsize len, const T* buf) {             \
+  void Set##Name##ArrayRegion(A a, jsize start, jsize len, const T* buf) {                  \
     memcpy(static_cast<T*>(a->data) + start, buf, sizeof(T) * static_cast<size_t>(len));    \
   }
-  DSGD_STUB_ARRAY(jlong, Long)
-  DSGD_STUB_ARRAY(jint, Int)
-  DSGD_STUB_ARRAY(jfloat, Float)
-  DSGD_STUB_ARRAY(jdouble, Double)
-  DSGD_STUB_ARRAY(jbyte, Byte)
+  DSGD_STUB_ARRAY(jlong, Long, jlongArray)
+  DSGD_STUB_ARRAY(jint, Int, jintArray)
+  DSGD_STUB_ARRAY(jfloat, Float, jfloatArray)
+  DSGD_STUB_ARRAY(jdouble, Double, jdoubleArray)
+  DSGD_STUB_ARRAY(jbyte, Byte, jbyteArray)
 #undef DSGD_STUB_ARRAY
 };
 typedef JNIEnv_ JNIEnv;

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Tuning aid for index-list batches beyond one workgroup (dsgd_mb_grad_kernel + the fused reduce): wall time per step
+from resident plans for SURVEY.md 8(d)'s sweep sizes and the reference's multi-worker defaults, with the algorithmic
+bytes (8 B per non-zero + 12 B per row) each step reads.  Run plain, or under `rocprofv3 --kernel-trace --stats` /
+`--pmc` (tools/r03_visit.sh) for the per-kernel view.
+
+    python tools/mb_prof.py [rows] [--quick]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dsgd_amd  # noqa: E402
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2000000
+quick = "--quick" in sys.argv
+data = dsgd_amd.synth.generate(rows, seed=0)
+n_train = int(rows * 0.8)
+out = {"rows": rows, "steps": []}
+with dsgd_amd.Engine(data.dim, 1e-5) as eng:
+    eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+    eng.build_dim_sparsity(n_train)
+    rng = np.random.default_rng(1)
+    cases = ((1, 65536, 40), (1, 4096, 100), (3, 100, 200), (4, 200, 200), (1, 1000, 100), (1, 16384, 60), (8, 4096, 40))
+    for k, b, steps in cases[:2] if quick else cases:
+        size = -(-n_train // k)
+        lists = []
+        for _ in range(steps):
+            lists.append([(a + rng.permutation(min(size, n_train - a))[:b]).astype(np.int32) for a in range(0, n_train, size)][:k])
+        nnz = float(np.mean([sum(int((data.row_ptr[l + 1] - data.row_ptr[l]).sum()) for l in st) for st in lists[:8]]))
+        eng.set_weights(np.zeros(eng.dp, dtype=np.float32))
+        plan = eng.plan(lists)
+        eng.plan_run(plan, 0, min(10, steps), 0.5 * 100 / b)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        eng.plan_run(plan, 0, steps, 0.5 * 100 / b)
+        eng.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        plan.destroy()
+        alg = 8.0 * nnz + 12.0 * k * b
+        out["steps"].append({"workers": k, "batch": b, "us_per_step": 1e6 * dt, "kernel": eng.grad_kernel_name(),
+                             "algorithmic_bytes": alg, "GBps": alg / dt / 1e9, "frac_of_8TBps": alg / dt / 8e12,
+                             "examples_per_s": k * b / dt, "fix_shift": eng.tuning_info()["fix_shift"]})
+print(json.dumps(out, indent=1))
