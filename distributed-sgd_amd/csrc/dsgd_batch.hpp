@@ -325,15 +325,30 @@ __device__ __forceinline__ unsigned int bt_batch(const CsrView& m, const BtLds& 
 }
 
 // ======================================================================================================
-// K1m: index-list batches too large for one workgroup (hundreds to 10^5 rows): the batch spread over workgroups
+// K1m: index-list batches spread over workgroups (several hosted workers, hundreds to 10^5 rows per list)
 // ======================================================================================================
-// ref: core/Slave.scala:147-153 (Vec.sum of the gated sub-gradients of a batch).  Round 1 scattered y*x with fp32
-// atomics straight into L2 (dsgd_grad_rows_kernel / dsgd_grad_tiled_kernel: 307 K atomics for 4,096 rows at ~5 G/s:
-// 126 us per step, in arrival order).  Here every workgroup takes `rows_per_wg` rows of one worker's list through
-// the mini-batch engine into its own fixed-point LDS accumulators and writes them out as one partial
+// ref: core/Slave.scala:147-153 (Vec.sum of the gated sub-gradients of a batch).  Every workgroup takes `rows_per_wg`
+// rows of one worker's list into its own fixed-point LDS accumulators and writes them out as one partial
 // (part[worker][workgroup][rank]); the ranks beyond LDS go to 64-bit fixed-point global accumulators on the same
 // grid.  dsgd_fix_reduce_kernel / dsgd_fix_reduce_apply_kernel -- the finish of the streaming path -- add the
 // partials exactly, in a fixed order, with ONE rounding: the gradient is bit-reproducible.
+//
+// Round 3: WAVE-AUTONOMOUS.  Round 2's form ran the workgroup-wide staged engine above over the slice -- a table of
+// work items built by a workgroup scan, three workgroup barriers and four dependent memory round trips per 128-item
+// sub-batch (B = 65,536: three sub-batches per workgroup, 69 us per step = 0.07 of the HBM roofline; B = 4,096:
+// 26 us).  Here every WAVE owns a contiguous piece of the slice and needs no barrier and no shared table:
+//   * one lane per row requests the row record (index -> row_ptr, label): two dependent round trips for up to 64 rows;
+//   * rows are classed by length: SHORT (<= 128 non-zeros, 86 % of RCV1-like rows) take one 16-lane group each, eight
+//     rows per pass; MEDIUM (129..512) take a whole wave slot -- four groups, one 128-chunk each -- two rows per pass;
+//     GIANT (> 512, 0.3 %) are walked by the whole wave.  All chunks of a row sit in ONE pass, so x.w is a DPP
+//     butterfly over 16 or 64 lanes, the gate follows at once and the non-zeros -- still in registers -- go straight
+//     into the accumulators;
+//   * the row records of a class are compacted into a per-wave LDS strip (short rows from the front, medium rows
+//     from the back), passes are software-pipelined two deep (the loads of pass q+1 are issued before pass q is
+//     processed), every lane reads EIGHT CONTIGUOUS non-zeros with 16-byte loads;
+//   * the workgroup's only shared state: the fixed-point accumulators (ds_add_u32) and a copy of the MB_WL hottest
+//     weights fetched straight into LDS (global_load_lds) while the row records are in flight -- ~85 % of the weight
+//     gathers never reach the texture path.
 struct MbArgs {
   CsrView m;
   const float* w;
@@ -344,39 +359,236 @@ struct MbArgs {
   long long g_stride;
   DevScalars* sc;
   float qscale;
-  int part_stride, rows_per_wg, hl;
+  int part_stride, rows_per_wg, hl, wl, dp;   // hl: ranks with an LDS accumulator; wl: ranks with an LDS copy of w (multiple of 256)
 };
-constexpr int MB_THREADS = 1024;
-constexpr int MB_R = 2;
-constexpr int MB_CAP = MB_THREADS / BT_G * MB_R;
-constexpr int MB_HL = 24576;   // ranks with an LDS accumulator per workgroup
+constexpr int MB_THREADS = 768;    // 12 waves: 170 VGPRs each (the two-deep pass pipeline does not fit the 128 of a 1024-lane workgroup)
+constexpr int MB_R = 2;          // item slots per 16-lane group and pass: 8 short rows or 2 medium rows per pass
+constexpr int MB_HL = 24576;     // ranks with an LDS accumulator per workgroup (96 KiB)
+constexpr int MB_WL = 11264;     // ranks with an LDS copy of their weight (44 KiB)
+constexpr int MB_SHORT = BT_CH;          // 128
+constexpr int MB_MEDIUM = 4 * BT_CH;     // 512
+struct __attribute__((aligned(16))) MbRec {   // one row of a wave's batch, as the passes need it
+  long long st;    // first non-zero
+  int len;
+  float y;         // label (+1 / -1)
+};
+__host__ __device__ constexpr int mb_lds_words(int hl, int wl) { return ((hl + 3) & ~3) + wl + (MB_THREADS / 64) * 64 * 4; }
+
+template <int R>
+struct MbPass {   // the non-zeros of a pass, as loaded (which slots are valid is re-derived from the strip: registers are scarce)
+  int c[R][BT_K];
+  float v[R][BT_K];
+};
+// slot (r, g) of pass q: its row record (len <= 0: empty slot) and this lane's offset into the row
+struct MbSlot {
+  MbRec rec;
+  int off;
+};
+template <int R>
+__device__ __forceinline__ MbSlot mb_slot(const MbRec* recs, int n_short, int n_medium, int n_sp, int q, int r, int g, int sub) {
+  const bool shortp = q < n_sp;
+  const int i = shortp ? q * 4 * R + r * 4 + g : (q - n_sp) * R + r;
+  const bool valid = shortp ? i < n_short : i < n_medium;
+  MbSlot s;
+  s.rec = recs[valid ? (shortp ? i : 63 - i) : 0];
+  s.off = (shortp ? 0 : g * BT_CH) + sub * BT_K;
+  if (!valid) {
+    s.rec.st = 0;
+    s.rec.len = 0;
+    s.rec.y = 0.0f;
+  }
+  return s;
+}
+
+// 16-byte loads of eight contiguous non-zeros from position p0 (dword-aligned: rows start anywhere; slots past the
+// row's end read what follows -- the arrays are padded -- and are masked by cnt)
+__device__ __forceinline__ void mb_load8(const CsrView& m, long long p0, int (&c)[BT_K], float (&v)[BT_K]) {
+  typedef int i32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  const i32x4u ca = *reinterpret_cast<const i32x4u*>(m.col + p0), cb = *reinterpret_cast<const i32x4u*>(m.col + p0 + 4);
+  const f32x4u va = *reinterpret_cast<const f32x4u*>(m.val + p0), vb = *reinterpret_cast<const f32x4u*>(m.val + p0 + 4);
+  c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w; c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w;
+  v[0] = va.x; v[1] = va.y; v[2] = va.z; v[3] = va.w; v[4] = vb.x; v[5] = vb.y; v[6] = vb.z; v[7] = vb.w;
+}
+
+// pass q of a wave's batch: q < n_sp short passes (slot (r, g) = short row q*4R + r*4 + g, chunk 0), then the medium
+// passes (slot r = medium row (q - n_sp)*R + r from the BACK of the strip, group g = its chunk g).  Loads only.
+template <int R>
+__device__ __forceinline__ void mb_issue(const CsrView& m, const MbRec* recs, int n_short, int n_medium, int n_sp, int q,
+                                         int g, int sub, MbPass<R>& P) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const MbSlot s = mb_slot<R>(recs, n_short, n_medium, n_sp, q, r, g, sub);
+    mb_load8(m, s.rec.len > 0 ? s.rec.st + s.off : 0, P.c[r], P.v[r]);
+  }
+}
+
+// x.w of every slot's row, the gate, the scatter of the active rows' non-zeros (still in registers)
+template <int R, class WLoad>
+__device__ __forceinline__ unsigned int mb_process(const BtLds& L, const MbRec* recs, int n_short, int n_medium, int n_sp,
+                                                   int q, int g, const MbPass<R>& P, int sub, int lane, WLoad wload,
+                                                   float qscale) {
+  const bool shortp = q < n_sp;
+  unsigned int n_act = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const MbSlot s = mb_slot<R>(recs, n_short, n_medium, n_sp, q, r, g, sub);
+    const int cnt = s.rec.len - s.off;   // valid slots of this lane (<= 0: none)
+    float wv[BT_K];
+#pragma unroll
+    for (int k = 0; k < BT_K; ++k) wv[k] = wload(k < cnt ? P.c[r][k] : 0);
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < BT_K; ++k) acc += k < cnt ? filt(P.v[r][k] * wv[k]) : 0.0f;   // ref: math/Sparse.scala:46
+    // fixed reduction trees: every lane of the row holds the bitwise-identical sum (they must agree on the gate)
+    const float d = shortp ? group_sum<BT_G>(acc) : group_sum<64>(acc);
+    const float y = s.rec.y;
+    const bool active = y != 0.0f && !(y * d < 0.0f);   // ref: core/ml/SparseSVM.scala:27-28
+    n_act += (active && (shortp ? sub == 0 : lane == 0)) ? 1u : 0u;
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < BT_K; ++k)
+        if (k < cnt) bt_add<2>(L, nullptr, P.c[r][k], P.v[r][k] * y, qscale);
+    }
+  }
+  return n_act;
+}
+
+// a row longer than a wave slot (> 512 non-zeros): the whole wave walks it twice (x.w, then the scatter)
+template <class WLoad>
+__device__ __forceinline__ unsigned int mb_giant(const CsrView& m, const BtLds& L, long long st, int len, float y, int lane,
+                                                 WLoad wload, float qscale) {
+  float acc = 0.0f;
+  for (int off = lane * BT_K; off < len; off += 64 * BT_K) {
+    int c[BT_K];
+    float v[BT_K];
+    mb_load8(m, st + off, c, v);
+#pragma unroll
+    for (int k = 0; k < BT_K; ++k)
+      if (off + k < len) acc += filt(v[k] * wload(c[k]));
+  }
+  const float d = group_sum<64>(acc);
+  if (y * d < 0.0f) return 0u;
+  for (int off = lane * BT_K; off < len; off += 64 * BT_K) {
+    int c[BT_K];
+    float v[BT_K];
+    mb_load8(m, st + off, c, v);
+#pragma unroll
+    for (int k = 0; k < BT_K; ++k)
+      if (off + k < len) bt_add<2>(L, nullptr, c[k], v[k] * y, qscale);
+  }
+  return lane == 0 ? 1u : 0u;
+}
+
+// copy of w[0, wl) into LDS, 1 KiB pieces straight from L2 (no staging registers); wl a multiple of 256
+__device__ __forceinline__ void mb_wcache_issue(const float* __restrict__ w, float* wl_lds, int wl) {
+  const int lane = threadIdx.x & 63;
+  const unsigned int lds_base = (unsigned int)(unsigned long long)(__attribute__((address_space(3))) float*)wl_lds;
+  for (int piece = threadIdx.x >> 6; piece < (wl >> 8); piece += MB_THREADS / 64) {
+    const float* src = w + piece * 256 + lane * 4;
+    const unsigned int dst = (unsigned int)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned int)piece * 1024u));
+    unsigned int keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(dst)
+        : "memory");
+  }
+}
 
 __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, sub = tid & (BT_G - 1), g = (tid >> 4) & 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   BtLds L;
   L.hl = a.hl;
   L.acc = reinterpret_cast<int*>(lds);
   L.cbits = nullptr;
   L.g64 = a.g64_base + (long long)blockIdx.y * a.g_stride;
-  bt_carve(L, reinterpret_cast<int*>(lds) + ((a.hl + 3) & ~3), MB_CAP);
-  const int tid = threadIdx.x;
-  wg_zero(L.acc, a.hl, tid, MB_THREADS);
-  __syncthreads();
+  float* wl = lds + ((a.hl + 3) & ~3);
+  MbRec* recs = reinterpret_cast<MbRec*>(wl + a.wl) + wave * 64;   // this wave's strip
   const WorkSeg seg = a.segs[blockIdx.y];
   const long long b = seg.begin + (long long)blockIdx.x * a.rows_per_wg;
   const long long e = b + a.rows_per_wg < seg.end ? b + a.rows_per_wg : seg.end;
+  const long long n = e > b ? e - b : 0;
+  const long long rpw = (n + MB_THREADS / 64 - 1) / (MB_THREADS / 64);   // rows per wave: a contiguous piece each
+  const long long wb = b + wave * rpw, we = wb + rpw < e ? wb + rpw : e;
   const int* __restrict__ idx = a.idx;
+  const int wl_n = a.wl;
+  typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
+  auto wload = [&](int c) -> float {   // hot ranks from the LDS copy, the tail from L1/L2
+    const bool hot = c < wl_n;
+    float v = ((lds_cvfloat*)wl)[hot ? c : 0];
+    if (!hot) v = a.w[c];
+    return v;
+  };
+  // the row ids of the wave's first batch go out first; the weight copy and the clearing of the accumulators run
+  // under that round trip
+  auto row_id = [&](long long t) -> long long { return t < we ? (idx ? (long long)idx[t] : t) : -1; };
+  long long row = row_id(wb + lane);
+  mb_wcache_issue(a.w, wl, a.wl);
+  wg_zero(L.acc, a.hl, tid, MB_THREADS);
   unsigned int n_act = 0;
-  if (b < e) {
-    auto row_of = [&](int t) -> long long { return idx ? (long long)idx[b + t] : b + t; };
-    auto wload = [&](int c) -> float { return a.w[c]; };
-    n_act = bt_batch<MB_THREADS, MB_R, 2>(a.m, L, nullptr, (int)(e - b), 0, row_of, wload, a.qscale, &a.sc->err);
+  bool first = true;
+  for (long long t0 = wb; first || t0 < we; t0 += 64) {   // (every wave runs the first round: it holds the barrier)
+    if (!first) row = row_id(t0 + lane);
+    const bool ok = row >= 0 && row < a.m.n_rows;
+    if (t0 + lane < we && !ok) atomicOr(&a.sc->err, 1);
+    long long st = 0, en = 0;
+    float y = 0.0f;
+    if (ok) {
+      st = a.m.row_ptr[row];
+      en = a.m.row_ptr[row + 1];
+      y = (float)a.m.label[row];
+    }
+    const int len = (int)(en - st);
+    const bool is_s = ok && len > 0 && len <= MB_SHORT, is_m = ok && len > MB_SHORT && len <= MB_MEDIUM;
+    const bool is_g = ok && len > MB_MEDIUM;
+    const unsigned long long ms = __builtin_amdgcn_ballot_w64(is_s), mm = __builtin_amdgcn_ballot_w64(is_m);
+    const unsigned long long mg = __builtin_amdgcn_ballot_w64(is_g);
+    const int n_short = __popcll(ms), n_medium = __popcll(mm), n_giant = __popcll(mg);
+    __builtin_amdgcn_wave_barrier();   // (the previous round's reads of the strip are behind us: same wave, in order)
+    if (is_s || is_m || is_g) {
+      // short rows from the front, giant rows behind them, medium rows from the back: the classes never meet
+      const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+      MbRec rec;
+      rec.st = st;
+      rec.len = len;
+      rec.y = y;
+      recs[is_s ? __popcll(ms & below) : (is_g ? n_short + __popcll(mg & below) : 63 - __popcll(mm & below))] = rec;
+    }
+    __builtin_amdgcn_wave_barrier();   // same wave writes and reads the strip; LDS executes a wave's accesses in order
+    const int n_sp = (n_short + 4 * MB_R - 1) / (4 * MB_R), n_q = n_sp + (n_medium + MB_R - 1) / MB_R;
+    MbPass<MB_R> A, B;
+    if (n_q > 0) mb_issue<MB_R>(a.m, recs, n_short, n_medium, n_sp, 0, g, sub, A);
+    if (first) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the weight copy have landed ...
+      __syncthreads();                                    // ... and everybody's; the accumulators are clear
+      first = false;
+    }
+    int q = 0;
+    while (q < n_q) {   // wave-uniform
+      if (q + 1 < n_q) mb_issue<MB_R>(a.m, recs, n_short, n_medium, n_sp, q + 1, g, sub, B);
+      n_act += mb_process<MB_R>(L, recs, n_short, n_medium, n_sp, q, g, A, sub, lane, wload, a.qscale);
+      if (++q >= n_q) break;
+      if (q + 1 < n_q) mb_issue<MB_R>(a.m, recs, n_short, n_medium, n_sp, q + 1, g, sub, A);
+      n_act += mb_process<MB_R>(L, recs, n_short, n_medium, n_sp, q, g, B, sub, lane, wload, a.qscale);
+      ++q;
+    }
+    for (int j = 0; j < n_giant; ++j) {   // wave-uniform
+      const MbRec rec = recs[n_short + j];
+      n_act += mb_giant(a.m, L, rec.st, rec.len, rec.y, lane, wload, a.qscale);
+    }
   }
   __syncthreads();
   int* mine = a.part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * a.part_stride;
   wg_copy_out(mine, L.acc, a.hl, tid, MB_THREADS, is_aligned16(mine));
   n_act = wave_sum_u32(n_act);
-  if ((tid & 63) == 0 && n_act) atomicAdd(&a.sc->n_active, (unsigned long long)n_act);
+  if (lane == 0 && n_act) atomicAdd(&a.sc->n_active, (unsigned long long)n_act);
 }
 
 // ======================================================================================================
@@ -735,21 +947,36 @@ __global__ void __launch_bounds__(1024) dsgd_exchange_delta_kernel(const float* 
     dlocal[j] = d;
   }
 }
-// w <- w - (dsum - dlocal); s <- s - 2*lambda*sum((dsum - dlocal) * ds); wprev <- w.  One workgroup (fixed-order sum).
+// The peers' part dsum - dlocal is subtracted from this replica's weights; s follows; wprev <- w.  One workgroup
+// (fixed-order sum).  With several ranks the new weights are formed as wprev - dsum: the same number as
+// w - (dsum - dlocal) up to rounding (w = wprev - dlocal, the engine is quiescent between the delta kernel and this
+// one), but built from two vectors that are bit-identical on every rank (wprev by induction, dsum from the
+// all-reduce) -- the replicas leave every exchange BIT-IDENTICAL instead of drifting apart by an ulp per round
+// (found by executing world = 2: tests/test_gpu_world2.py).  With a single rank the peers' part is exactly zero and
+// the replica keeps its own weights bit for bit.
 __global__ void __launch_bounds__(1024) dsgd_exchange_apply_kernel(float* __restrict__ w, float* __restrict__ wprev,
                                                                   const float* __restrict__ dsum,
                                                                   const float* __restrict__ dlocal,
                                                                   const float* __restrict__ ds, int dp, float lambda,
-                                                                  HogState* st) {
+                                                                  HogState* st, int world) {
   __shared__ float red[16];
   float acc = 0.0f;
   for (int j = threadIdx.x; j < dp; j += blockDim.x) {
-    const float o = dsum[j] - dlocal[j];   // exactly 0 with a single rank: the replica keeps its own weights bit for bit
     float wn = w[j];
-    if (o != 0.0f) {
-      wn = filt(wn - o);
-      w[j] = wn;
-      acc += o * ds[j];
+    if (world > 1) {
+      const float wo = wn;
+      wn = filt(wprev[j] - dsum[j]);
+      if (wn != wo) {
+        w[j] = wn;
+        acc += (wo - wn) * ds[j];
+      }
+    } else {
+      const float o = dsum[j] - dlocal[j];   // exactly 0 with a single rank
+      if (o != 0.0f) {
+        wn = filt(wn - o);
+        w[j] = wn;
+        acc += o * ds[j];
+      }
     }
     wprev[j] = wn;
   }

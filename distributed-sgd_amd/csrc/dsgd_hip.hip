@@ -498,7 +498,9 @@ static int launch_grad_mb(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, 
   a.part_stride = c->part_stride;
   a.rows_per_wg = (int)rows_per_wg;
   a.hl = hl;
-  const size_t lds = sizeof(float) * (size_t)(((hl + 3) & ~3) + bt_lds_words(MB_CAP));
+  a.wl = std::min(MB_WL, c->dp) & ~255;   // whole 1 KiB pieces
+  a.dp = c->dp;
+  const size_t lds = sizeof(float) * (size_t)mb_lds_words(hl, a.wl);
   size_t slot = 0;
   DSGD_TRY(prof_begin(c, &slot));
   hipLaunchKernelGGL(dsgd_mb_grad_kernel, dim3((unsigned)wgs, n_workers), dim3(MB_THREADS), lds, c->stream, a);
@@ -2010,7 +2012,7 @@ static int exchange_round(dsgd_ctx* c, long long upto) {
   HIP_TRY(hipGetLastError());
   RCCL_TRY(rccl::AllReduce(c->d_wdelta, c->d_wdelta, (size_t)c->dp, rccl::kFloat32, rccl::kSum, c->comm, c->async_stream));
   hipLaunchKernelGGL(dsgd_exchange_apply_kernel, dim3(1), dim3(1024), 0, c->async_stream, c->d_w, c->d_wprev,
-                     c->d_wdelta, c->d_wdelta + c->dp, c->d_ds, c->dp, (float)c->cfg.lambda, c->d_hog);
+                     c->d_wdelta, c->d_wdelta + c->dp, c->d_ds, c->dp, (float)c->cfg.lambda, c->d_hog, c->world);
   HIP_TRY(hipGetLastError());
   return DSGD_OK;
 }

@@ -34,7 +34,7 @@ def column_counts(o, lo, hi):
     return np.bincount(o.col[b:e][keep], minlength=o.dim + 1).astype(np.float64)
 
 
-def step_bound(o, w_before, w_after_ref, ranges, lr, shift, vmax2=None):
+def step_bound(o, w_before, w_after_ref, ranges, lr, shift, vmax2=None, parts=False):
     """Per-coordinate bound on |w_engine - w_after_ref| after ONE synchronous step over `ranges` (one range per worker,
     mean over the workers) starting from w_before on both sides.  Returns (tol vector, rows near the gate)."""
     if vmax2 is None:
@@ -51,6 +51,8 @@ def step_bound(o, w_before, w_after_ref, ranges, lr, shift, vmax2=None):
     quantum = vmax2 * 2.0 ** (-(shift + 1))
     tol = (lr / k) * (cnt * quantum + near)
     tol += 8.0 * 2.0 ** -24 * (np.abs(w_after_ref) + np.abs(w_after_ref - w_before)) + 1e-9
+    if parts:
+        return tol, n_near, (lr / k) * near   # (tol - this = the bound with every near-gate row gated as the oracle does)
     return tol, n_near
 
 
@@ -86,7 +88,7 @@ def _list_profile(o, w, rows, eps):
     return cnt, near, int(near_rows.sum())
 
 
-def list_bound(o, w_before, w_after_ref, lists, lr, shift, vmax2=None):
+def list_bound(o, w_before, w_after_ref, lists, lr, shift, vmax2=None, parts=False):
     """step_bound for index lists (one list per worker, mean over the workers): the index-list kernels accumulate the
     same fixed-point contributions exactly, at the shift the launch reports."""
     if vmax2 is None:
@@ -103,4 +105,6 @@ def list_bound(o, w_before, w_after_ref, lists, lr, shift, vmax2=None):
     quantum = vmax2 * 2.0 ** (-(shift + 1))
     tol = (lr / k) * (cnt * quantum + near)
     tol += 8.0 * 2.0 ** -24 * (np.abs(w_after_ref) + np.abs(w_after_ref - w_before)) + 1e-9
+    if parts:
+        return tol, n_near, (lr / k) * near
     return tol, n_near

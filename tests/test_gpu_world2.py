@@ -116,15 +116,16 @@ def test_sync_steps_replicas_identical_and_equal_to_the_oracle_with_k_workers_ti
             o.sync_step(w_ref, lists, lr)                                    # K = len(workers) = hosted workers x world
             shift = int(min(ranks[0]["shifts"][i], ranks[1]["shifts"][i]))
             if kind == "range":
-                tol_v, n_near = orb.step_bound(o, w0, w_ref, workers, lr, shift)
+                tol_v, n_near, near_part = orb.step_bound(o, w0, w_ref, workers, lr, shift, parts=True)
             else:
-                tol_v, n_near = orb.list_bound(o, w0, w_ref, lists, lr, shift)
+                tol_v, n_near, near_part = orb.list_bound(o, w0, w_ref, lists, lr, shift, parts=True)
             ratio, j = orb.worst_ratio(w_ranks, w_ref, tol_v)
             assert ratio <= 1.0, "step %d (%s): two ranks vs oracle: coordinate %d at %.3g x its bound" % (i, kind, j, ratio)
             n_act = int(ranks[0]["stats"][i][1] + ranks[1]["stats"][i][1])
             assert abs(n_act - o.last_stats["n_active"]) <= n_near
             assert int(ranks[0]["stats"][i][0] + ranks[1]["stats"][i][0]) == sum(len(l) for l in lists)
-            waivers.check("world2:no_near_gate_rows", n_near == 0, "%d rows near the gate" % n_near)
+            tight = n_act == o.last_stats["n_active"] and orb.worst_ratio(w_ranks, w_ref, tol_v - near_part)[0] <= 1.0
+            waivers.tight("world2:gates_as_the_oracle", tight, n_near > 0, "%d rows near the gate" % n_near)
             # the single process hosting ALL the workers, from the same weights: the same bound at its own shift
             single.set_weights(w_prev)
             st = single.sync_step_ranges(workers, lr) if kind == "range" else single.sync_step(workers, lr)
@@ -146,9 +147,8 @@ def test_eval_tallies_are_the_sum_over_the_shards(ranks, problem):
         loss_ref, acc_ref, counts_ref, mam = o.loss_acc(w, lo, hi)
         counts = [int(x) for x in ev[off + 2:off + 5]]
         assert sum(counts) == hi - lo
-        if waivers.check("world2:tallies", mam >= 1e-5, "margin %.2g" % mam):
-            assert counts == counts_ref
-            assert abs(ev[off] - loss_ref) <= 1e-6 and ev[off + 1] == acc_ref
+        waivers.tight("world2:tallies", counts == counts_ref and abs(ev[off] - loss_ref) <= 1e-6 and ev[off + 1] == acc_ref,
+                      mam < 1e-5, "margin %.2g" % mam)
 
 
 def test_async_exchange_of_two_replicas_equals_the_simulation(ranks, problem):
@@ -183,8 +183,8 @@ def test_async_exchange_of_two_replicas_equals_the_simulation(ranks, problem):
     assert np.abs(w[0] - w[1]).max() <= 1e-12          # after an exchange the simulated replicas agree
     np.testing.assert_array_equal(ranks[0]["w_async"], ranks[1]["w_async"])   # ... and the real ones bit for bit
     assert np.abs(ranks[0]["w_async"]).max() > 0
-    if waivers.check("world2:async_exchange", not exposed, "a replayed row within 1e-5 of the gate"):
-        assert np.abs(ranks[0]["w_async"].astype(np.float64) - w[0]).max() <= 4 * tol(w[0])
+    err = np.abs(ranks[0]["w_async"].astype(np.float64) - w[0]).max()
+    waivers.tight("world2:async_exchange", err <= 4 * tol(w[0]), exposed, "a replayed row within 1e-5 of the gate, err %.3g" % err)
     # dsgd_async_start returned at once (the rounds are enqueued by a helper thread) and stayed pollable
     for r in range(WORLD):
         assert ranks[r]["async_meta"][0] < 0.5, ranks[r]["async_meta"]

@@ -36,5 +36,17 @@ def check(family, is_strict, why=""):
     return strict(family) if is_strict else waived(family, why)
 
 
+def tight(family, ok_tight, exposed, why=""):
+    """The standard shape of a conditional parity assertion: the TIGHT statement is evaluated first and recorded as
+    strict when it holds; when it does not, that is acceptable only if the oracle reported a row within 1e-5 of the
+    gate (`exposed`) -- recorded as waived with the reason -- and an assertion failure otherwise.  Returns ok_tight."""
+    if ok_tight:
+        strict(family)
+        return True
+    assert exposed, "%s: tight statement failed without a near-gate row to explain it (%s)" % (family, why)
+    waived(family, why)
+    return False
+
+
 def table():
     return {k: {"strict": v[0], "waived": v[1], "reasons": v[2]} for k, v in COUNTS.items()}

@@ -28,7 +28,13 @@ test)
   timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -x 2>&1 | tail -40 | tee $OUT/pytest_gpu.txt ;;
 testall)
   echo "== pytest -m gpu (no -x)"
-  timeout 2400 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -60 | tee $OUT/pytest_gpu.txt ;;
+  timeout 2400 python -m pytest tests -m gpu -q --timeout 900 --tb=short -rf > $OUT/pytest_gpu_full.txt 2>&1
+  grep -E "^(E  |FAILED|ERROR|tests/.*(Error|assert))|passed|failed" $OUT/pytest_gpu_full.txt | cut -c1-400 | head -80
+  tail -45 $OUT/pytest_gpu_full.txt | cut -c1-300 | tee $OUT/pytest_gpu.txt ;;
+testsel)
+  echo "== pytest -m gpu -k \"$TESTSEL\""
+  timeout 1800 python -m pytest tests -m gpu -q --timeout 900 --tb=short -rf -s -k "$TESTSEL" > $OUT/pytest_sel.txt 2>&1
+  grep -vE "^(RCCL|HIP|ROCm|Hostname|Librccl)" $OUT/pytest_sel.txt | cut -c1-600 | tail -120 ;;
 mb)
   echo "== index-list batches (tools/mb_prof.py)"
   timeout 600 python tools/mb_prof.py 2000000 > $OUT/mb_prof.json 2> $OUT/mb_prof.err; tail -3 $OUT/mb_prof.err; python -c "
