@@ -340,9 +340,11 @@ __device__ __forceinline__ unsigned int bt_batch(const CsrView& m, const BtLds& 
 //   * one lane per row requests the row record (index -> row_ptr, label): two dependent round trips for up to 64 rows;
 //   * rows are classed by length: SHORT (<= 128 non-zeros, 86 % of RCV1-like rows) take one 16-lane group each, eight
 //     rows per pass; MEDIUM (129..512) take a whole wave slot -- four groups, one 128-chunk each -- two rows per pass;
-//     GIANT (> 512, 0.3 %) are walked by the whole wave.  All chunks of a row sit in ONE pass, so x.w is a DPP
+//     WIDE (513..1024, 0.3 %) take both slots of a pass.  All chunks of a row sit in ONE pass, so x.w is a DPP
 //     butterfly over 16 or 64 lanes, the gate follows at once and the non-zeros -- still in registers -- go straight
-//     into the accumulators;
+//     into the accumulators.  (The first form of this kernel walked rows beyond 512 non-zeros chunk by chunk: one such
+//     row per ~370 left one wave six dependent round trips behind, and a launch is as slow as its slowest wave --
+//     B = 65,536 took 74 us instead of 47.)  Rows up to 2048 non-zeros are held by both register sets at once;
 //   * the row records of a class are compacted into a per-wave LDS strip (short rows from the front, medium rows
 //     from the back), passes are software-pipelined two deep (the loads of pass q+1 are issued before pass q is
 //     processed), every lane reads EIGHT CONTIGUOUS non-zeros with 16-byte loads;
@@ -367,6 +369,7 @@ constexpr int MB_HL = 24576;     // ranks with an LDS accumulator per workgroup 
 constexpr int MB_WL = 11264;     // ranks with an LDS copy of their weight (44 KiB)
 constexpr int MB_SHORT = BT_CH;          // 128
 constexpr int MB_MEDIUM = 4 * BT_CH;     // 512
+constexpr int MB_WIDE = 4 * BT_CH * MB_R;  // 1024: one row over both slots of a pass
 struct __attribute__((aligned(16))) MbRec {   // one row of a wave's batch, as the passes need it
   long long st;    // first non-zero
   int len;
@@ -379,19 +382,43 @@ struct MbPass {   // the non-zeros of a pass, as loaded (which slots are valid i
   int c[R][BT_K];
   float v[R][BT_K];
 };
-// slot (r, g) of pass q: its row record (len <= 0: empty slot) and this lane's offset into the row
+// The passes of a wave's batch, in order: n_sp SHORT passes (8 rows each: slot (r, g) = short row q*4R + r*4 + g,
+// chunk 0), n_mp MEDIUM passes (slot r = medium row (q - n_sp)*R + r from the BACK of the strip, group g = its chunk g),
+// then one WIDE pass per wide row (513 .. 1024 non-zeros: both slots, slot r group g = chunk 4r + g).
+struct MbPlan {
+  int n_short, n_medium, n_wide, n_sp, n_mp;
+  __device__ __forceinline__ int kind(int q) const { return q < n_sp ? 0 : (q < n_sp + n_mp ? 1 : 2); }
+  __device__ __forceinline__ int passes() const { return n_sp + n_mp + n_wide; }
+};
+// slot (r, g) of pass q: its row record (len 0: empty slot) and this lane's offset into the row
 struct MbSlot {
   MbRec rec;
   int off;
 };
 template <int R>
-__device__ __forceinline__ MbSlot mb_slot(const MbRec* recs, int n_short, int n_medium, int n_sp, int q, int r, int g, int sub) {
-  const bool shortp = q < n_sp;
-  const int i = shortp ? q * 4 * R + r * 4 + g : (q - n_sp) * R + r;
-  const bool valid = shortp ? i < n_short : i < n_medium;
+__device__ __forceinline__ MbSlot mb_slot(const MbRec* recs, const MbPlan& pl, int q, int r, int g, int sub) {
+  const int kind = pl.kind(q);
+  int i, at, chunk;
+  bool valid;
+  if (kind == 0) {
+    i = q * 4 * R + r * 4 + g;
+    valid = i < pl.n_short;
+    at = i;
+    chunk = 0;
+  } else if (kind == 1) {
+    i = (q - pl.n_sp) * R + r;
+    valid = i < pl.n_medium;
+    at = 63 - i;
+    chunk = g;
+  } else {
+    i = q - pl.n_sp - pl.n_mp;
+    valid = true;
+    at = pl.n_short + i;
+    chunk = 4 * r + g;
+  }
   MbSlot s;
-  s.rec = recs[valid ? (shortp ? i : 63 - i) : 0];
-  s.off = (shortp ? 0 : g * BT_CH) + sub * BT_K;
+  s.rec = recs[valid ? at : 0];
+  s.off = chunk * BT_CH + sub * BT_K;
   if (!valid) {
     s.rec.st = 0;
     s.rec.len = 0;
@@ -401,7 +428,7 @@ __device__ __forceinline__ MbSlot mb_slot(const MbRec* recs, int n_short, int n_
 }
 
 // 16-byte loads of eight contiguous non-zeros from position p0 (dword-aligned: rows start anywhere; slots past the
-// row's end read what follows -- the arrays are padded -- and are masked by cnt)
+// row's end read what follows -- the arrays are padded -- and are masked by the row length)
 __device__ __forceinline__ void mb_load8(const CsrView& m, long long p0, int (&c)[BT_K], float (&v)[BT_K]) {
   typedef int i32x4u __attribute__((ext_vector_type(4), aligned(4)));
   typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -411,50 +438,108 @@ __device__ __forceinline__ void mb_load8(const CsrView& m, long long p0, int (&c
   v[0] = va.x; v[1] = va.y; v[2] = va.z; v[3] = va.w; v[4] = vb.x; v[5] = vb.y; v[6] = vb.z; v[7] = vb.w;
 }
 
-// pass q of a wave's batch: q < n_sp short passes (slot (r, g) = short row q*4R + r*4 + g, chunk 0), then the medium
-// passes (slot r = medium row (q - n_sp)*R + r from the BACK of the strip, group g = its chunk g).  Loads only.
+// loads of pass q (nothing waits here)
 template <int R>
-__device__ __forceinline__ void mb_issue(const CsrView& m, const MbRec* recs, int n_short, int n_medium, int n_sp, int q,
-                                         int g, int sub, MbPass<R>& P) {
+__device__ __forceinline__ void mb_issue(const CsrView& m, const MbRec* recs, const MbPlan& pl, int q, int g, int sub,
+                                         MbPass<R>& P) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const MbSlot s = mb_slot<R>(recs, n_short, n_medium, n_sp, q, r, g, sub);
-    mb_load8(m, s.rec.len > 0 ? s.rec.st + s.off : 0, P.c[r], P.v[r]);
+    const MbSlot s = mb_slot<R>(recs, pl, q, r, g, sub);
+    mb_load8(m, s.off < s.rec.len ? s.rec.st + s.off : 0, P.c[r], P.v[r]);
   }
 }
 
 // x.w of every slot's row, the gate, the scatter of the active rows' non-zeros (still in registers)
 template <int R, class WLoad>
-__device__ __forceinline__ unsigned int mb_process(const BtLds& L, const MbRec* recs, int n_short, int n_medium, int n_sp,
-                                                   int q, int g, const MbPass<R>& P, int sub, int lane, WLoad wload,
-                                                   float qscale) {
-  const bool shortp = q < n_sp;
+__device__ __forceinline__ unsigned int mb_process(const BtLds& L, const MbRec* recs, const MbPlan& pl, int q, int g,
+                                                   const MbPass<R>& P, int sub, int lane, WLoad wload, float qscale) {
+  const int kind = pl.kind(q);
   unsigned int n_act = 0;
+  float acc[R], y[R];
+  int cnt[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const MbSlot s = mb_slot<R>(recs, n_short, n_medium, n_sp, q, r, g, sub);
-    const int cnt = s.rec.len - s.off;   // valid slots of this lane (<= 0: none)
+    const MbSlot s = mb_slot<R>(recs, pl, q, r, g, sub);
+    cnt[r] = s.rec.len - s.off;   // valid slots of this lane (<= 0: none)
+    y[r] = s.rec.y;
     float wv[BT_K];
 #pragma unroll
-    for (int k = 0; k < BT_K; ++k) wv[k] = wload(k < cnt ? P.c[r][k] : 0);
-    float acc = 0.0f;
+    for (int k = 0; k < BT_K; ++k) wv[k] = wload(k < cnt[r] ? P.c[r][k] : 0);
+    float a = 0.0f;
 #pragma unroll
-    for (int k = 0; k < BT_K; ++k) acc += k < cnt ? filt(P.v[r][k] * wv[k]) : 0.0f;   // ref: math/Sparse.scala:46
-    // fixed reduction trees: every lane of the row holds the bitwise-identical sum (they must agree on the gate)
-    const float d = shortp ? group_sum<BT_G>(acc) : group_sum<64>(acc);
-    const float y = s.rec.y;
-    const bool active = y != 0.0f && !(y * d < 0.0f);   // ref: core/ml/SparseSVM.scala:27-28
-    n_act += (active && (shortp ? sub == 0 : lane == 0)) ? 1u : 0u;
+    for (int k = 0; k < BT_K; ++k) a += k < cnt[r] ? filt(P.v[r][k] * wv[k]) : 0.0f;   // ref: math/Sparse.scala:46
+    acc[r] = a;
+  }
+  // fixed reduction trees: every lane of a row holds the bitwise-identical sum (they must agree on the gate)
+  if (kind == 2) {   // one row over all the slots
+    float t = acc[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) t += acc[r];
+    t = group_sum<64>(t);
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = t;
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = kind == 0 ? group_sum<BT_G>(acc[r]) : group_sum<64>(acc[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool active = y[r] != 0.0f && !(y[r] * acc[r] < 0.0f);   // ref: core/ml/SparseSVM.scala:27-28
+    const bool counts = kind == 0 ? sub == 0 : (kind == 1 ? lane == 0 : (lane == 0 && r == 0));
+    n_act += (active && counts) ? 1u : 0u;
     if (active) {
 #pragma unroll
       for (int k = 0; k < BT_K; ++k)
-        if (k < cnt) bt_add<2>(L, nullptr, P.c[r][k], P.v[r][k] * y, qscale);
+        if (k < cnt[r]) bt_add<2>(L, nullptr, P.c[r][k], P.v[r][k] * y[r], qscale);
     }
   }
   return n_act;
 }
 
-// a row longer than a wave slot (> 512 non-zeros): the whole wave walks it twice (x.w, then the scatter)
+// a HUGE row (1025 .. 2048 non-zeros, 0.01 % of RCV1-like rows): both register sets of the pass pipeline hold it at
+// once -- one round trip for the whole row instead of a chunk-by-chunk walk that would leave one wave (and with it
+// the whole launch) several dependent round trips behind the others
+template <int R, class WLoad>
+__device__ __forceinline__ unsigned int mb_huge(const CsrView& m, const BtLds& L, const MbRec& rec, int g, int sub, int lane,
+                                                MbPass<R>& A, MbPass<R>& B, WLoad wload, float qscale) {
+  float t = 0.0f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    MbPass<R>& P = h ? B : A;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int off = ((h * R + r) * 4 + g) * BT_CH + sub * BT_K;
+      mb_load8(m, off < rec.len ? rec.st + off : 0, P.c[r], P.v[r]);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const MbPass<R>& P = h ? B : A;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int cnt = rec.len - (((h * R + r) * 4 + g) * BT_CH + sub * BT_K);
+#pragma unroll
+      for (int k = 0; k < BT_K; ++k)
+        if (k < cnt) t += filt(P.v[r][k] * wload(P.c[r][k]));
+    }
+  }
+  const float d = group_sum<64>(t);
+  if (rec.y * d < 0.0f) return 0u;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const MbPass<R>& P = h ? B : A;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int cnt = rec.len - (((h * R + r) * 4 + g) * BT_CH + sub * BT_K);
+#pragma unroll
+      for (int k = 0; k < BT_K; ++k)
+        if (k < cnt) bt_add<2>(L, nullptr, P.c[r][k], P.v[r][k] * rec.y, qscale);
+    }
+  }
+  return lane == 0 ? 1u : 0u;
+}
+
+// a row beyond that (never the case for RCV1): the whole wave walks it twice (x.w, then the scatter)
 template <class WLoad>
 __device__ __forceinline__ unsigned int mb_giant(const CsrView& m, const BtLds& L, long long st, int len, float y, int lane,
                                                  WLoad wload, float qscale) {
@@ -547,24 +632,33 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
     }
     const int len = (int)(en - st);
     const bool is_s = ok && len > 0 && len <= MB_SHORT, is_m = ok && len > MB_SHORT && len <= MB_MEDIUM;
-    const bool is_g = ok && len > MB_MEDIUM;
+    const bool is_w = ok && len > MB_MEDIUM && len <= MB_WIDE, is_g = ok && len > MB_WIDE;
     const unsigned long long ms = __builtin_amdgcn_ballot_w64(is_s), mm = __builtin_amdgcn_ballot_w64(is_m);
-    const unsigned long long mg = __builtin_amdgcn_ballot_w64(is_g);
-    const int n_short = __popcll(ms), n_medium = __popcll(mm), n_giant = __popcll(mg);
+    const unsigned long long mw = __builtin_amdgcn_ballot_w64(is_w), mg = __builtin_amdgcn_ballot_w64(is_g);
+    MbPlan pl;
+    pl.n_short = __popcll(ms);
+    pl.n_medium = __popcll(mm);
+    pl.n_wide = __popcll(mw);
+    pl.n_sp = (pl.n_short + 4 * MB_R - 1) / (4 * MB_R);
+    pl.n_mp = (pl.n_medium + MB_R - 1) / MB_R;
+    const int n_giant = __popcll(mg);
     __builtin_amdgcn_wave_barrier();   // (the previous round's reads of the strip are behind us: same wave, in order)
-    if (is_s || is_m || is_g) {
-      // short rows from the front, giant rows behind them, medium rows from the back: the classes never meet
+    if (ok && len > 0) {
+      // short rows from the front, wide rows behind them, then the giants; medium rows from the back: never meeting
       const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
       MbRec rec;
       rec.st = st;
       rec.len = len;
       rec.y = y;
-      recs[is_s ? __popcll(ms & below) : (is_g ? n_short + __popcll(mg & below) : 63 - __popcll(mm & below))] = rec;
+      const int at = is_s ? __popcll(ms & below)
+                          : (is_m ? 63 - __popcll(mm & below)
+                                  : (is_w ? pl.n_short + __popcll(mw & below) : pl.n_short + pl.n_wide + __popcll(mg & below)));
+      recs[at] = rec;
     }
     __builtin_amdgcn_wave_barrier();   // same wave writes and reads the strip; LDS executes a wave's accesses in order
-    const int n_sp = (n_short + 4 * MB_R - 1) / (4 * MB_R), n_q = n_sp + (n_medium + MB_R - 1) / MB_R;
+    const int n_q = pl.passes();
     MbPass<MB_R> A, B;
-    if (n_q > 0) mb_issue<MB_R>(a.m, recs, n_short, n_medium, n_sp, 0, g, sub, A);
+    if (n_q > 0) mb_issue<MB_R>(a.m, recs, pl, 0, g, sub, A);
     if (first) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the weight copy have landed ...
       __syncthreads();                                    // ... and everybody's; the accumulators are clear
@@ -572,16 +666,17 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
     }
     int q = 0;
     while (q < n_q) {   // wave-uniform
-      if (q + 1 < n_q) mb_issue<MB_R>(a.m, recs, n_short, n_medium, n_sp, q + 1, g, sub, B);
-      n_act += mb_process<MB_R>(L, recs, n_short, n_medium, n_sp, q, g, A, sub, lane, wload, a.qscale);
+      if (q + 1 < n_q) mb_issue<MB_R>(a.m, recs, pl, q + 1, g, sub, B);
+      n_act += mb_process<MB_R>(L, recs, pl, q, g, A, sub, lane, wload, a.qscale);
       if (++q >= n_q) break;
-      if (q + 1 < n_q) mb_issue<MB_R>(a.m, recs, n_short, n_medium, n_sp, q + 1, g, sub, A);
-      n_act += mb_process<MB_R>(L, recs, n_short, n_medium, n_sp, q, g, B, sub, lane, wload, a.qscale);
+      if (q + 1 < n_q) mb_issue<MB_R>(a.m, recs, pl, q + 1, g, sub, A);
+      n_act += mb_process<MB_R>(L, recs, pl, q, g, B, sub, lane, wload, a.qscale);
       ++q;
     }
     for (int j = 0; j < n_giant; ++j) {   // wave-uniform
-      const MbRec rec = recs[n_short + j];
-      n_act += mb_giant(a.m, L, rec.st, rec.len, rec.y, lane, wload, a.qscale);
+      const MbRec rec = recs[pl.n_short + pl.n_wide + j];
+      if (rec.len <= 2 * MB_WIDE) n_act += mb_huge<MB_R>(a.m, L, rec, g, sub, lane, A, B, wload, a.qscale);
+      else n_act += mb_giant(a.m, L, rec.st, rec.len, rec.y, lane, wload, a.qscale);
     }
   }
   __syncthreads();

@@ -726,9 +726,9 @@ def engine_hogwild_curve(eng, split, batch, lr, checkpoints, eval_range, seed, p
 ])
 def test_hogwild_many_workers_inside_the_oracle_band(k, n_rows, checkpoints):
     """A lock-free run is not reproducible; the ORACLE supplies the band it must land in (oracle/hogwild_band.py): the
-    reference's asynchronous iteration replayed with 5 sampling seeds in each of the two orderings a lock-free run
-    interpolates between -- sequential (fresh reads) and stale rounds (all workers read one snapshot) -- compared on
-    test loss and test accuracy averaged over the second half of the checkpoints and on |w|_2 at the end; band = the
+    reference's asynchronous iteration replayed with 5 sampling seeds in each of the orderings k lock-free workers can
+    realise -- sequential (fresh reads), stale rounds (all workers read one snapshot), constant delay k - 1 -- compared
+    on test loss and test accuracy averaged over the second half of the checkpoints and on |w|_2 at the end; band = the
     oracle's own [min, max] widened by the stated margins (loss 0.06, accuracy 0.03, |w| 10 %)."""
     from oracle import hogwild_band as hb
 
@@ -778,9 +778,9 @@ def test_update_grad_arrives_while_the_engine_runs():
     b, e = int(data.row_ptr[0]), int(data.row_ptr[n_train])
     present = np.bincount(data.col[b:e], minlength=data.dim + 1) > 0
     untouched = np.flatnonzero(~present)[1:]          # keys no training row holds (key 0 is never a feature id)
-    assert len(untouched) >= 500
+    assert len(untouched) >= 100
     rng = np.random.default_rng(19)
-    keys_u = rng.choice(untouched, size=400, replace=False).astype(np.int32)
+    keys_u = rng.choice(untouched, size=100, replace=False).astype(np.int32)
     keys_t = rng.choice(np.flatnonzero(present), size=200, replace=False).astype(np.int32)   # contended with the engine
     with eng:
         with pytest.raises(IndexError):
