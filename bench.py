@@ -305,6 +305,10 @@ def main():
         "frac_of_measured_copy_peak": achieved / HBM_MEASURED,
         "traffic": traffic,
         "traffic_source": traffic_source,
+        # the PHYSICAL fraction: HBM bytes the kernel really moved (rocprofv3 FETCH_SIZE pass) / its duration / peak --
+        # below the algorithmic one because 16-bit column ranks make the stream smaller than 8 B per non-zero
+        "physical_frac": (traffic / (kernel_ms * 1e-3) / HBM_PEAK) if (traffic and kernel_ms > 0) else None,
+        "physical_frac_of_measured_copy_peak": (traffic / (kernel_ms * 1e-3) / HBM_MEASURED) if (traffic and kernel_ms > 0) else None,
         "algorithmic_bytes_per_launch": alg_bytes,
         "algorithmic_bytes_per_example": bytes_per_row,
         "kernel_ms_avg": kernel_ms,
@@ -324,12 +328,14 @@ def main():
 
     # ---- batch sweep incl. the reference's default batch-size (N=1 only) ------------------------------
     if rank == 0 and world == 1 and not args.no_sweep:
-        out["sweep"] = sweep(eng, n_train, bytes_per_row)
+        out["sweep"] = sweep(eng, data, n_train, bytes_per_row, with_parity=not args.no_parity_gate)
 
     # ---- the other configurations of BASELINE.json, reported beside the headline (N=1 only) --------------------
     if rank == 0 and world == 1 and not args.no_sweep:
         out["eval_pass"] = eval_pass(eng, n_train, bytes_per_row)
         out["hogwild"] = hogwild(eng, n_train)
+        if not args.no_parity_gate:
+            out["hogwild"]["oracle_band"] = hogwild_band(dsgd_amd, local_rank)
         out["dense_logistic"] = dense_logistic(dsgd_amd, local_rank)
 
     # ---- CPU baseline on this box's host cores (rank 0, N=1 only) --------------------------------------
@@ -349,26 +355,63 @@ def main():
         print(json.dumps(out))
 
 
-def sweep(eng, n_train, bytes_per_row):
+def sweep(eng, data, n_train, bytes_per_row, with_parity=True):
+    """examples/s for index-list batches from resident plans: the reference's real defaults (3 workers x batch 100,
+    application.conf:15,27; 4 x 200, kube/config-sync.yaml) and SURVEY.md 8(d)'s sweep B in {100, 200, 4096, 65536}.
+    Every row carries `parity`: ONE step of that shape from non-zero weights against the fp64 oracle under the derived
+    per-coordinate bound of oracle/bounds.py (outside the timed loop; the oracle is the checker, never the thing timed)."""
     LR = LR0
-    """examples/s for index-list batches B in {100, 4096, 65536} (1 worker), resident plans."""
     res = []
     rng = np.random.default_rng(123)
-    for b, steps in ((100, 300), (4096, 100), (65536, 20)):
-        if b > n_train:
+    o = None
+    if with_parity:
+        from oracle import bounds as orb  # checker only
+        from oracle import oracle as orc
+
+        o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, LAMBDA)
+        o.set_dim_sparsity(o.dim_sparsity(n_train))
+        w_nz = np.zeros(eng.dp, dtype=np.float32)
+        hot = rng.choice(np.arange(1, data.dim + 1), size=6000, replace=False)
+        w_nz[hot] = rng.normal(scale=0.05, size=6000).astype(np.float32)
+    for k, b, steps in ((1, 100, 300), (3, 100, 300), (4, 200, 200), (1, 200, 200), (1, 4096, 100), (1, 65536, 20)):
+        if k * b > n_train:
             continue
+        size = -(-n_train // k)
+        split = [(a, min(n_train, a + size)) for a in range(0, n_train, size)]   # SplitStrategy.vanilla
+        lists = [[(lo + rng.permutation(hi - lo)[:b]).astype(np.int32) for lo, hi in split] for _ in range(steps)]
+        lr = LR * 100.0 / b   # the reference sums the batch (core/Slave.scala:153): keep the per-sample step of the defaults
+        entry = {"workers": k, "batch": b, "steps": steps}
+        if o is not None:
+            eng.set_weights(w_nz)
+            w0 = w_nz.astype(np.float64)
+            w_ref = w0.copy()
+            st = eng.sync_step(lists[0], lr)
+            # (one hosted worker with lists of up to 192 rows runs the persistent one-workgroup kernel, which derives
+            # its fixed-point shift per batch: 30 - ceil(log2 B); everything else reports the shift of its launch)
+            kern = eng.grad_kernel_name()
+            shift = 30 - int(np.ceil(np.log2(b))) if "plan_kernel" in kern else eng.tuning_info()["fix_shift"]
+            o.sync_step(w_ref, lists[0], lr)
+            tol, n_near = orb.list_bound(o, w0, w_ref, lists[0], lr, shift)
+            ratio, j = orb.worst_ratio(eng.get_weights(), w_ref, tol)
+            entry["parity"] = {"worst_err_over_bound": ratio, "fix_shift": shift, "rows_near_gate": int(n_near),
+                               "n_active_engine": st["n_active"], "n_active_oracle": int(o.last_stats["n_active"]),
+                               "max_abs_err": float(np.abs(eng.get_weights() - w_ref).max()), "kernel": kern}
+            if not ratio <= 1.0 or abs(st["n_active"] - o.last_stats["n_active"]) > n_near:
+                raise SystemExit("sweep parity failed for %d x %d: %r" % (k, b, entry["parity"]))
         eng.set_weights(np.zeros(eng.dp, dtype=np.float32))
-        lists = [[rng.permutation(n_train)[:b].astype(np.int32)] for _ in range(steps)]
         plan = eng.plan(lists)
-        eng.plan_run(plan, 0, min(10, steps), LR)
+        eng.plan_run(plan, 0, min(10, steps), lr)
         eng.synchronize()
         t0 = time.perf_counter()
-        eng.plan_run(plan, 0, steps, LR)
+        eng.plan_run(plan, 0, steps, lr)
         eng.synchronize()
         dt = time.perf_counter() - t0
         plan.destroy()
-        res.append({"batch": b, "steps": steps, "examples_per_s": b * steps / dt, "us_per_step": 1e6 * dt / steps,
-                    "frac_hbm_peak": b * steps / dt * bytes_per_row / HBM_PEAK})
+        nnz = float(np.mean([sum(int((data.row_ptr[l + 1] - data.row_ptr[l]).sum()) for l in st_) for st_ in lists[:8]]))
+        alg = 8.0 * nnz + 12.0 * k * b
+        entry.update({"examples_per_s": k * b * steps / dt, "us_per_step": 1e6 * dt / steps, "kernel": eng.grad_kernel_name(),
+                      "algorithmic_bytes_per_step": alg, "frac_hbm_peak": alg * steps / dt / HBM_PEAK})
+        res.append(entry)
     return res
 
 
@@ -400,11 +443,62 @@ def hogwild(eng, n_train, workers=256, batch=100, updates=60000):
     eng.async_start(split, batch=batch, lr=LR0, max_updates=updates, seed=1, positional_bug=False)
     eng.async_wait()
     dt = time.perf_counter() - t0
-    u, _ = eng.async_updates()
+    st = eng.async_stats()
+    u = st["updates"]
     loss, acc, _ = eng.loss_acc(n_train, eng.n_rows)
     return {"workers": len(split), "batch": batch, "updates": int(u), "examples_per_s": u * batch / dt,
             "updates_per_s": u / dt, "ms": 1e3 * dt, "test_loss_after": loss, "test_acc_after": acc,
-            "note": "one lock-free workgroup per worker on ONE device-resident w; wall time incl. launch and join"}
+            # lane-level atomicAdd(w[j], -delta_j) counted on the device (the coordinates the updates
+            # really moved); the memory system sees them coalesced per 128-byte line: profiles/ (TCP_TCC_ATOMIC_*)
+            "atomics_per_s": st["atomics"] / dt, "atomics_per_update": st["atomics"] / max(1, u),
+            "active_fraction": st["active"] / max(1, st["samples"]),
+            "note": "one lock-free workgroup per worker on ONE device-resident w; wall time incl. launch and join; a single "
+                    "end-of-run evaluation of a constant-step lock-free run fluctuates by several points (see oracle_band)"}
+
+
+def hogwild_band(dsgd_amd, device, workers=256, batch=100, rows=100000, checkpoints=(2048, 4096, 6144, 8192), n_seeds=3):
+    """Parity evidence for the BENCHMARKED Hogwild shape (256 workers x batch 100) on a shard small enough for the
+    oracle: the band comes from the ORACLE (oracle/hogwild_band.py: sequential / stale-round / constant-delay replays of
+    core/Slave.scala:92-101, several sampling seeds each; test loss and accuracy averaged over the second half of the
+    checkpoints, |w| at the end); the engine runs in segments ending at the same checkpoints, three seeds."""
+    from dsgd_amd import host
+    from oracle import hogwild_band as hb  # checker only
+    from oracle import oracle as orc
+
+    data = dsgd_amd.synth.generate(rows, seed=13)
+    n_train = int(rows * 0.8)
+    o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, LAMBDA)
+    o.set_dim_sparsity(o.dim_sparsity(n_train))
+    split = [(r.start, r.stop) for r in host.split_vanilla(n_train, workers)]
+    ev = (n_train, data.n_rows)
+    t0 = time.perf_counter()
+    band = hb.band(o, split, batch, list(checkpoints), LR0, ev, n_seeds=n_seeds)
+    t_oracle = time.perf_counter() - t0
+    runs = []
+    with dsgd_amd.Engine(data.dim, LAMBDA, device=device) as eng:
+        eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+        eng.build_dim_sparsity(n_train)
+        for seed in (5, 6, 7):
+            eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+            curve, prev, total = [], 0, 0
+            for c, target in enumerate(checkpoints):
+                eng.async_start(split, batch=batch, lr=LR0, max_updates=target - prev, seed=seed + 7919 * c, positional_bug=False)
+                eng.async_wait()
+                total += eng.async_updates()[0]
+                prev = target
+                loss, acc, _ = eng.loss_acc(*ev)
+                curve.append((total, loss, acc))
+            summ = hb.summarise(curve, eng.get_weights().astype(np.float64))
+            summ.update(inside=hb.inside(band, summ), updates=total, end_acc=curve[-1][2], end_loss=curve[-1][1])
+            runs.append(summ)
+    ok = all(all(r["inside"].values()) for r in runs)
+    out = {"rows": rows, "workers": workers, "batch": batch, "checkpoints": list(checkpoints), "oracle_seconds": round(t_oracle, 1),
+           "band": {q: {k: band[q][k] for k in ("lo", "hi", "oracle_min", "oracle_max", "by_mode")} for q in ("loss", "acc", "wnorm")},
+           "margin": band["margin"], "oracle_end_of_run_acc_spread": band["end_of_run_acc_spread"],
+           "engine_runs": runs, "inside": ok}
+    if not ok:
+        raise SystemExit("Hogwild parity failed: an engine run left the oracle's band: %r" % out)
+    return out
 
 
 def dense_logistic(dsgd_amd, device, rows=1250000, dim=4096):
@@ -463,13 +557,33 @@ def dense_logistic(dsgd_amd, device, rows=1250000, dim=4096):
     return res
 
 
+def l3_bytes():
+    """Total L3 of the host (all sockets), from sysfs; None if unknown."""
+    try:
+        seen, total = set(), 0
+        base = "/sys/devices/system/cpu"
+        for cpu in os.listdir(base):
+            p = os.path.join(base, cpu, "cache", "index3")
+            if not os.path.isdir(p):
+                continue
+            key = open(os.path.join(p, "shared_cpu_list")).read().strip()
+            if key in seen:
+                continue
+            seen.add(key)
+            sz = open(os.path.join(p, "size")).read().strip()
+            total += int(sz[:-1]) * (1024 if sz.endswith("K") else 1024 * 1024) if sz[-1] in "KM" else int(sz)
+        return total or None
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(data, n_train, budget_s):
     LR = LR0
     """The oracle timed on the host cores: (B) OpenMP CSR restatement on all cores, same whole-shard
     step on a bounded sample; (A) literal per-sample sparse-map restatement, one thread, B=100."""
     from oracle import oracle as orc
 
-    n_s = min(n_train, 200000)
+    n_s = min(n_train, 2000000)   # 1.2 GB of CSR: beyond the host's L3 (the 200,000-row sample of round 2 was cache-resident)
     sub = data.rows(0, n_s)
     o = orc.Oracle(sub.dim, sub.row_ptr, sub.col, sub.val, sub.label, LAMBDA)
     o.set_dim_sparsity(o.dim_sparsity(n_s))
@@ -488,6 +602,9 @@ def cpu_baseline(data, n_train, budget_s):
         "sample": "OpenMP CSR fp64 restatement (oracle.c orc_sync_step_range_omp): %d whole-shard steps over the "
                   "first %d train rows of the same workload, %.1f s" % (steps, n_s, dt),
         "host_cpus": os.cpu_count(),
+        "sample_bytes": int(8 * sub.nnz + 12 * n_s),
+        "sample_exceeds_l3": bool(8 * sub.nnz + 12 * n_s > l3_bytes()) if l3_bytes() else None,
+        "host_l3_bytes": l3_bytes(),
     }
     # literal: Slave.gradient as one single-threaded request of 100 samples (core/Slave.scala:142)
     rng = np.random.default_rng(5)
@@ -545,13 +662,19 @@ def epochs_to_target(dsgd_amd, device):
                 eng.sync_step(step, lr)
             curve.append(eng.loss_acc(n_train, n_rows)[0])
         t_eng = time.perf_counter() - t0
-    target = ref_curve[-1]
-    # the hinge part of the loss moves in steps of 1/n_test (predictions are -1/0/+1): allow one test row of slack
+    # Target: the BEST test loss the oracle reaches within max-epochs (the curve of a constant-step run is noisy: its
+    # last-epoch loss is worse than its epoch-2 loss, which made "epochs to the last-epoch loss" trivially 2 for both
+    # sides in round 2).  The hinge part moves in steps of 1/n_test (predictions are -1/0/+1): one test row of slack.
+    target = min(ref_curve)
     slack = 1.0 / (n_rows - n_train)
     reached = next((i + 1 for i, l in enumerate(curve) if l <= target + slack), None)
     reached_ref = next((i + 1 for i, l in enumerate(ref_curve) if l <= target + slack), None)
+    half = 0.5 * 1.0   # loss at w = 0 is exactly 1 (every prediction is 0): first epoch at or below half of it
     return {"config": "23149 rows, 3 workers x batch 100, lr 0.5, lambda 1e-5, 10 epochs", "target_test_loss": target,
-            "slack": slack,
+            "target": "min over the oracle's epochs", "slack": slack,
+            "epochs_to_half_initial_loss": {"engine": next((i + 1 for i, l in enumerate(curve) if l <= half), None),
+                                            "oracle": next((i + 1 for i, l in enumerate(ref_curve) if l <= half), None)},
+            "max_curve_difference": float(np.abs(np.asarray(curve) - np.asarray(ref_curve)).max()),
             "max_epochs": epochs, "engine_epochs": reached, "oracle_epochs": reached_ref,
             "engine_test_loss": curve, "oracle_test_loss": ref_curve,
             "engine_s": t_eng, "oracle_s": t_ref, "steps_per_epoch": len(lists[0])}

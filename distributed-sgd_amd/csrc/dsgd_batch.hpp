@@ -449,10 +449,71 @@ __device__ __forceinline__ void mb_issue(const CsrView& m, const MbRec* recs, co
   }
 }
 
+// weights of the ranks c: the LDS copy for c < wl_n, global memory beyond
+struct MbWeights {
+  const float* wl;   // LDS
+  const float* __restrict__ w;
+  int wl_n;
+  // the global half: requests only (the results stay untouched until `finish`: any arithmetic on them here would make
+  // the compiler wait on the spot)
+  template <int R>
+  __device__ __forceinline__ void request(const int (&c)[R][BT_K], const int (&cnt)[R], float (&u)[R][BT_K]) const {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < BT_K; ++k) {
+        const int cc = k < cnt[r] ? c[r][k] : 0;
+        u[r][k] = w[cc < wl_n ? 0 : cc];
+      }
+  }
+  // the LDS half and the select of values
+  template <int R>
+  __device__ __forceinline__ void finish(const int (&c)[R][BT_K], const int (&cnt)[R], float (&u)[R][BT_K]) const {
+    typedef __attribute__((address_space(3))) const float lds_cfloat;
+    float v[R][BT_K];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < BT_K; ++k) {
+        const int cc = k < cnt[r] ? c[r][k] : 0;
+        v[r][k] = ((lds_cfloat*)wl)[cc < wl_n ? cc : 0];
+      }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < BT_K; ++k) {
+        const int cc = k < cnt[r] ? c[r][k] : 0;
+        u[r][k] = cc < wl_n ? v[r][k] : u[r][k];
+      }
+  }
+  __device__ __forceinline__ float operator()(int c) const {   // (the rare long-row paths)
+    typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
+    const bool hot = c < wl_n;
+    const float v = ((lds_cvfloat*)wl)[hot ? c : 0];
+    const float u = w[hot ? 0 : c];
+    return hot ? v : u;
+  }
+};
+
+// the weight gathers of pass q (its column ids have landed): requested BEFORE the loads of pass q+1 go out, so that
+// the counted wait for them (vmcnt retires in order) does not also wait for that younger, slower HBM request
+template <int R, class WLoad>
+__device__ __forceinline__ void mb_gather(const MbRec* recs, const MbPlan& pl, int q, int g, const MbPass<R>& P, int sub,
+                                          WLoad wload, float (&wv)[R][BT_K]) {
+  int cnt[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const MbSlot s = mb_slot<R>(recs, pl, q, r, g, sub);
+    cnt[r] = s.rec.len - s.off;
+  }
+  wload.request(P.c, cnt, wv);
+}
+
 // x.w of every slot's row, the gate, the scatter of the active rows' non-zeros (still in registers)
 template <int R, class WLoad>
 __device__ __forceinline__ unsigned int mb_process(const BtLds& L, const MbRec* recs, const MbPlan& pl, int q, int g,
-                                                   const MbPass<R>& P, int sub, int lane, WLoad wload, float qscale) {
+                                                   const MbPass<R>& P, float (&wv)[R][BT_K], int sub, int lane,
+                                                   WLoad wload, float qscale) {
   const int kind = pl.kind(q);
   unsigned int n_act = 0;
   float acc[R], y[R];
@@ -462,12 +523,13 @@ __device__ __forceinline__ unsigned int mb_process(const BtLds& L, const MbRec* 
     const MbSlot s = mb_slot<R>(recs, pl, q, r, g, sub);
     cnt[r] = s.rec.len - s.off;   // valid slots of this lane (<= 0: none)
     y[r] = s.rec.y;
-    float wv[BT_K];
+  }
+  wload.finish(P.c, cnt, wv);
 #pragma unroll
-    for (int k = 0; k < BT_K; ++k) wv[k] = wload(k < cnt[r] ? P.c[r][k] : 0);
+  for (int r = 0; r < R; ++r) {
     float a = 0.0f;
 #pragma unroll
-    for (int k = 0; k < BT_K; ++k) a += k < cnt[r] ? filt(P.v[r][k] * wv[k]) : 0.0f;   // ref: math/Sparse.scala:46
+    for (int k = 0; k < BT_K; ++k) a += k < cnt[r] ? filt(P.v[r][k] * wv[r][k]) : 0.0f;   // ref: math/Sparse.scala:46
     acc[r] = a;
   }
   // fixed reduction trees: every lane of a row holds the bitwise-identical sum (they must agree on the gate)
@@ -604,13 +666,11 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
   const long long wb = b + wave * rpw, we = wb + rpw < e ? wb + rpw : e;
   const int* __restrict__ idx = a.idx;
   const int wl_n = a.wl;
-  typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
-  auto wload = [&](int c) -> float {   // hot ranks from the LDS copy, the tail from L1/L2
-    const bool hot = c < wl_n;
-    float v = ((lds_cvfloat*)wl)[hot ? c : 0];
-    if (!hot) v = a.w[c];
-    return v;
-  };
+  // hot ranks from the LDS copy, the tail from L1/L2 -- with UNCONDITIONAL global loads (the hot lanes all read w[0],
+  // one cache line), all of a pass issued back to back before the first is used: a branch around each load made the
+  // compiler wait for every one of a pass's 16 loads inside its own branch, i.e. 16 dependent L2 round trips per pass
+  // (measured: B = 65,536 took 86 us that way, more than round 2's kernel)
+  const MbWeights wload{wl, a.w, wl_n};
   // the row ids of the wave's first batch go out first; the weight copy and the clearing of the accumulators run
   // under that round trip
   auto row_id = [&](long long t) -> long long { return t < we ? (idx ? (long long)idx[t] : t) : -1; };
@@ -665,12 +725,15 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
       first = false;
     }
     int q = 0;
+    float wv[MB_R][BT_K];
     while (q < n_q) {   // wave-uniform
+      mb_gather<MB_R>(recs, pl, q, g, A, sub, wload, wv);
       if (q + 1 < n_q) mb_issue<MB_R>(a.m, recs, pl, q + 1, g, sub, B);
-      n_act += mb_process<MB_R>(L, recs, pl, q, g, A, sub, lane, wload, a.qscale);
+      n_act += mb_process<MB_R>(L, recs, pl, q, g, A, wv, sub, lane, wload, a.qscale);
       if (++q >= n_q) break;
+      mb_gather<MB_R>(recs, pl, q, g, B, sub, wload, wv);
       if (q + 1 < n_q) mb_issue<MB_R>(a.m, recs, pl, q + 1, g, sub, A);
-      n_act += mb_process<MB_R>(L, recs, pl, q, g, B, sub, lane, wload, a.qscale);
+      n_act += mb_process<MB_R>(L, recs, pl, q, g, B, wv, sub, lane, wload, a.qscale);
       ++q;
     }
     for (int j = 0; j < n_giant; ++j) {   // wave-uniform
@@ -716,6 +779,7 @@ struct HogState {
   int done_blocks;
   int stop;                     // raised by the host (copy on a side stream): workers exit after their mini-batch
   int err;                      // a sampled row fell outside the data
+  unsigned long long atomics;   // lane-level atomicAdd(w[j], -delta_j) performed: the coordinates the updates really moved
 };
 
 struct HogArgs {
@@ -757,6 +821,7 @@ constexpr int HOG_HL = 20480;      // ranks with an LDS accumulator (80 KiB)
 constexpr int HOG_WL = 12288;      // ranks whose weight is gathered from an LDS copy refreshed every iteration (48 KiB;
                                    // with the tables 136 KiB: 16 KiB of dsgd_eval_kernel still fit the CU)
 constexpr int HOG_SW = 8;          // accumulator slots per thread and sweep pass
+constexpr unsigned int HOG_ATOMIC_ONE = 1u << 13;   // active rows of a mini-batch (<= 4096) in the low 13 bits, weight atomics above
 constexpr int HOG_REDERIVE = 4096; // worker 0 re-derives s = 2 lambda (w . ds) from the weights every so many of its iterations
 
 struct HogCtl {   // per iteration parity
@@ -940,6 +1005,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         if (delta != 0.0f) {
           atomicAdd(&a.w[j], -delta);   // lock-free update of the ONE weight vector
           ds_acc += delta * dsv[e];
+          n_act += HOG_ATOMIC_ONE;      // (counted in the upper bits of the active-row counter: no register to spare)
         }
       }
     }
@@ -961,6 +1027,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         if (delta != 0.0f) {
           atomicAdd(&a.w[a.hl + jc], -delta);
           ds_acc += delta * dsj;
+          n_act += HOG_ATOMIC_ONE;
         }
       }
     }
@@ -1009,7 +1076,8 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       }
       u = atomicAdd(&a.st->updates, 1ull) + 1ull;
       atomicAdd(&a.st->samples, (unsigned long long)B);
-      atomicAdd(&a.st->active, (unsigned long long)na);
+      atomicAdd(&a.st->active, (unsigned long long)(na & (HOG_ATOMIC_ONE - 1u)));
+      atomicAdd(&a.st->atomics, (unsigned long long)(na >> 13));
       const int stop = __hip_atomic_load(&a.st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       HogCtl* cn = &ctl[(it + 1) & 1];
       cn->s = s;

@@ -2172,21 +2172,29 @@ int dsgd_async_stop(dsgd_ctx* c) {  // ref: SlaveImpl.stopAsync, core/Slave.scal
   return async_join(c);
 }
 
-int dsgd_async_regulariser(dsgd_ctx* c, double* s_engine, double* s_exact) {
+int dsgd_async_stats(dsgd_ctx* c, int64_t* counters, double* s_engine, double* s_exact) {
   DSGD_TRY(check_ctx(c));
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
-  DSGD_TRY(require_ds(c));
   if (!c->d_hog) return fail(DSGD_ESTATE, "the lock-free engine has never been started on this context");
   DSGD_TRY(async_refresh(c));
+  if (counters) {
+    counters[0] = (int64_t)c->h_hog->updates;
+    counters[1] = (int64_t)c->h_hog->samples;
+    counters[2] = (int64_t)c->h_hog->active;
+    counters[3] = (int64_t)c->h_hog->atomics;
+  }
   if (s_engine) *s_engine = (double)c->h_hog->s_reg;
-  // the same summation the synchronous kernels use (fra_scalars), from the weights as they are now; the engine keeps its
-  // own scalar (HogState), so refreshing the synchronous one disturbs nothing
-  c->s_dirty = true;
-  DSGD_TRY(ensure_s(c));
-  DSGD_TRY(read_scalars(c));
-  if (c->async_running) c->s_dirty = true;
-  if (s_exact) *s_exact = (double)c->h_sc->s_reg;
+  if (s_exact) {
+    // the same summation the synchronous kernels use (fra_scalars), from the weights as they are now; the engine keeps
+    // its own scalar (HogState), so refreshing the synchronous one disturbs nothing
+    DSGD_TRY(require_ds(c));
+    c->s_dirty = true;
+    DSGD_TRY(ensure_s(c));
+    DSGD_TRY(read_scalars(c));
+    if (c->async_running) c->s_dirty = true;
+    *s_exact = (double)c->h_sc->s_reg;
+  }
   return DSGD_OK;
 }
 

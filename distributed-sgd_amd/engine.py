@@ -195,11 +195,13 @@ class Engine:
     def async_wait(self):
         check(self._lib.dsgd_async_wait(self._ctx))
 
-    def async_regulariser(self):
-        """(engine's incrementally kept s = 2 lambda (w . ds), the same recomputed from the weights as they are now)."""
+    def async_stats(self):
+        """Counters of the lock-free engine (updates, samples, active rows, lane-level weight atomics) and its regulariser
+        scalar s = 2 lambda (w . ds): as kept incrementally on the device / recomputed from the weights as they are now."""
+        cnt = (C.c_int64 * 4)()
         a, b = C.c_double(0), C.c_double(0)
-        check(self._lib.dsgd_async_regulariser(self._ctx, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        check(self._lib.dsgd_async_stats(self._ctx, cnt, C.byref(a), C.byref(b)))
+        return {"updates": cnt[0], "samples": cnt[1], "active": cnt[2], "atomics": cnt[3], "s_engine": a.value, "s_exact": b.value}
 
     # -- multi-GPU ---------------------------------------------------------------------------------
     @staticmethod

@@ -184,11 +184,13 @@ int dsgd_async_updates(dsgd_ctx* ctx, int64_t* updates, int32_t* running);
  * the same period and the same finite max_updates (the ranks enqueue the same number of collectives).            */
 int dsgd_async_set_exchange(dsgd_ctx* ctx, int64_t every_updates);
 int dsgd_async_stop(dsgd_ctx* ctx); /* SlaveImpl.stopAsync, core/Slave.scala:187-195 */
-/* Measurement aid (nothing in the reference): the lock-free engine's incrementally kept regulariser scalar
- * s = 2 lambda (w . ds) as the device holds it (kept by one atomic add per mini-batch and per dsgd_update_grad call,
- * re-derived from the weights every few thousand iterations), and the same quantity recomputed from the weights as
- * they are now.  While the engine runs the two differ by the updates in flight.                                   */
-int dsgd_async_regulariser(dsgd_ctx* ctx, double* s_engine, double* s_exact);
+/* Measurement aid (nothing in the reference).  counters (4, may be NULL): mini-batch updates applied, rows whose
+ * gradient was computed, rows the gate let through, lane-level atomicAdd(w[j], -delta_j) performed (SURVEY.md 8(d):
+ * "additionally report atomics/s").  s_engine / s_exact (may be NULL): the engine's incrementally kept regulariser scalar
+ * s = 2 lambda (w . ds) as the device holds it (one atomic add per mini-batch and per dsgd_update_grad call, re-derived
+ * from the weights every few thousand iterations), and the same quantity recomputed from the weights as they are now.
+ * While the engine runs the two differ by the updates in flight.                                                  */
+int dsgd_async_stats(dsgd_ctx* ctx, int64_t* counters, double* s_engine, double* s_exact);
 int dsgd_async_wait(dsgd_ctx* ctx); /* block until max_updates reached */
 
 /* ---- multi-GPU (one process per GPU) ---------------------------------------

@@ -798,7 +798,8 @@ def test_update_grad_arrives_while_the_engine_runs():
             expect = expect - dv_u                    # fp32, in call order: what the atomic adds do to an uncontended word
         u_mid, running = eng.async_updates()
         assert running and u_mid > 0                  # all of it happened under a running engine
-        s_eng_run, s_exact_run = eng.async_regulariser()
+        st_run = eng.async_stats()
+        s_eng_run, s_exact_run = st_run["s_engine"], st_run["s_exact"]
         eng.async_stop()
         u_end, running = eng.async_updates()
         assert not running and u_end >= u_mid
@@ -811,8 +812,12 @@ def test_update_grad_arrives_while_the_engine_runs():
         assert med < 1e-3, times
         # the engine's own scalar followed the foreign updates (and its own ~10^5+ increments): compare with the exact
         # re-derivation from the final weights
-        s_eng, s_exact = eng.async_regulariser()
+        st_end = eng.async_stats()
+        s_eng, s_exact = st_end["s_engine"], st_end["s_exact"]
         assert abs(s_eng - s_exact) <= 2e-3 * abs(s_exact) + 1e-9, (s_eng, s_exact)
+        # counters: every update computed 100 rows; an update moves at most the union of its rows' coordinates
+        assert st_end["updates"] == u_end and st_end["samples"] == 100 * u_end and 0 < st_end["active"] <= st_end["samples"]
+        assert st_end["updates"] <= st_end["atomics"] <= st_end["updates"] * 100 * 1200
         # the same call in the synchronous setting still applies w - delta with the Sparse filter
         eng.update_grad(keys_u, expect)               # w[keys_u] -= expect -> exactly 0
         assert not eng.get_weights()[keys_u].any()

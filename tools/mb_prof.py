@@ -19,6 +19,7 @@ import dsgd_amd  # noqa: E402
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2000000
 quick = "--quick" in sys.argv
+only = [tuple(int(x) for x in a.split("=")[1].split("x")) for a in sys.argv if a.startswith("--only=")]   # e.g. --only=1x65536
 data = dsgd_amd.synth.generate(rows, seed=0)
 n_train = int(rows * 0.8)
 out = {"rows": rows, "steps": []}
@@ -27,6 +28,8 @@ with dsgd_amd.Engine(data.dim, 1e-5) as eng:
     eng.build_dim_sparsity(n_train)
     rng = np.random.default_rng(1)
     cases = ((1, 65536, 40), (1, 4096, 100), (3, 100, 200), (4, 200, 200), (1, 1000, 100), (1, 16384, 60), (8, 4096, 40))
+    if only:
+        cases = tuple(c for c in cases if (c[0], c[1]) in only)
     for k, b, steps in cases[:2] if quick else cases:
         size = -(-n_train // k)
         lists = []

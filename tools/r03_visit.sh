@@ -40,6 +40,14 @@ mb)
   timeout 600 python tools/mb_prof.py 2000000 > $OUT/mb_prof.json 2> $OUT/mb_prof.err; tail -3 $OUT/mb_prof.err; python -c "
 import json; d=json.load(open('$OUT/mb_prof.json'))
 for s in d['steps']: print('%d x %6d: %7.1f us/step %7.1f GB/s (%.3f of 8 TB/s) %s shift %d' % (s['workers'], s['batch'], s['us_per_step'], s['GBps'], s['frac_of_8TBps'], s['kernel'], s['fix_shift']))" ;;
+mbtrace)
+  echo "== rocprofv3 kernel trace of the index-list kernels, one batch size per run"
+  for C in 1x65536 1x4096 3x100; do
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mbtrace -o mb -- python $REPO/tools/mb_prof.py 2000000 --only=$C > /dev/null 2> $OUT/mbtrace.err )
+    f=$(find $OUT/mbtrace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && { echo "-- $C"; trace_summary "$f" | grep -E "mb_grad|fix_reduce"; } | tee -a $OUT/mb_dispatch_durations.txt
+    f=$(find $OUT/mbtrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { echo "-- $C"; grep -E "Name|mb_grad|fix_reduce" "$f" | cut -c1-200; } >> $OUT/mb_kernel_stats.csv
+    rm -rf $OUT/mbtrace
+  done ;;
 mbprof)
   echo "== rocprofv3 kernel trace + PMC of the index-list kernels"
   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mbtrace -o mb -- python $REPO/tools/mb_prof.py 2000000 --quick > /dev/null 2> $OUT/mbtrace.err )
