@@ -362,6 +362,7 @@ struct MbArgs {
   DevScalars* sc;
   float qscale;
   int part_stride, rows_per_wg, hl, wl, dp;   // hl: ranks with an LDS accumulator; wl: ranks with an LDS copy of w (multiple of 256)
+  unsigned long long* tprof;   // optional (tuning runs, DSGD_PLAN_PROF=1): cycles of wave 0 of workgroup 0 by phase, [15] = launches
 };
 constexpr int MB_THREADS = 768;    // 12 waves: 170 VGPRs each (the two-deep pass pipeline does not fit the 128 of a 1024-lane workgroup)
 constexpr int MB_R = 2;          // item slots per 16-lane group and pass: 8 short rows or 2 medium rows per pass
@@ -674,9 +675,19 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
   // the row ids of the wave's first batch go out first; the weight copy and the clearing of the accumulators run
   // under that round trip
   auto row_id = [&](long long t) -> long long { return t < we ? (idx ? (long long)idx[t] : t) : -1; };
+  const bool prof = a.tprof != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
+  unsigned long long tl = prof ? __builtin_readcyclecounter() : 0ull, tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int i) {   // cycles since the previous stamp -> tp[i]
+    if (prof) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      tp[i] += now - tl;
+      tl = now;
+    }
+  };
   long long row = row_id(wb + lane);
   mb_wcache_issue(a.w, wl, a.wl);
   wg_zero(L.acc, a.hl, tid, MB_THREADS);
+  stamp(0);   // issue of the row ids, the weight copy, clearing
   unsigned int n_act = 0;
   bool first = true;
   for (long long t0 = wb; first || t0 < we; t0 += 64) {   // (every wave runs the first round: it holds the barrier)
@@ -691,6 +702,10 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
       y = (float)a.m.label[row];
     }
     const int len = (int)(en - st);
+    if (prof) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(1);   // row ids + row records landed (two dependent round trips)
+    }
     const bool is_s = ok && len > 0 && len <= MB_SHORT, is_m = ok && len > MB_SHORT && len <= MB_MEDIUM;
     const bool is_w = ok && len > MB_MEDIUM && len <= MB_WIDE, is_g = ok && len > MB_WIDE;
     const unsigned long long ms = __builtin_amdgcn_ballot_w64(is_s), mm = __builtin_amdgcn_ballot_w64(is_m);
@@ -721,7 +736,9 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
     if (n_q > 0) mb_issue<MB_R>(a.m, recs, pl, 0, g, sub, A);
     if (first) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the weight copy have landed ...
+      stamp(2);                                           // (first pass's non-zeros landed)
       __syncthreads();                                    // ... and everybody's; the accumulators are clear
+      stamp(3);                                           // (waiting for the other waves)
       first = false;
     }
     int q = 0;
@@ -729,11 +746,15 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
     while (q < n_q) {   // wave-uniform
       mb_gather<MB_R>(recs, pl, q, g, A, sub, wload, wv);
       if (q + 1 < n_q) mb_issue<MB_R>(a.m, recs, pl, q + 1, g, sub, B);
+      stamp(4);   // waiting for this pass's column ids, requests
       n_act += mb_process<MB_R>(L, recs, pl, q, g, A, wv, sub, lane, wload, a.qscale);
+      stamp(5);   // weights landed, products, gate, scatter
       if (++q >= n_q) break;
       mb_gather<MB_R>(recs, pl, q, g, B, sub, wload, wv);
       if (q + 1 < n_q) mb_issue<MB_R>(a.m, recs, pl, q + 1, g, sub, A);
+      stamp(4);
       n_act += mb_process<MB_R>(L, recs, pl, q, g, B, wv, sub, lane, wload, a.qscale);
+      stamp(5);
       ++q;
     }
     for (int j = 0; j < n_giant; ++j) {   // wave-uniform
@@ -742,11 +763,20 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
       else n_act += mb_giant(a.m, L, rec.st, rec.len, rec.y, lane, wload, a.qscale);
     }
   }
+  stamp(6);   // long rows, loop ends
   __syncthreads();
+  stamp(7);   // waiting for the other waves
   int* mine = a.part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * a.part_stride;
   wg_copy_out(mine, L.acc, a.hl, tid, MB_THREADS, is_aligned16(mine));
   n_act = wave_sum_u32(n_act);
   if (lane == 0 && n_act) atomicAdd(&a.sc->n_active, (unsigned long long)n_act);
+  if (prof && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long now = __builtin_readcyclecounter();
+    for (int i = 0; i < 8; ++i) a.tprof[i] += tp[i];
+    a.tprof[8] += now - tl;   // writing the partial out
+    a.tprof[15] += 1;
+  }
 }
 
 // ======================================================================================================

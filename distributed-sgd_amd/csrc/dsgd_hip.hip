@@ -500,6 +500,7 @@ static int launch_grad_mb(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, 
   a.hl = hl;
   a.wl = std::min(MB_WL, c->dp) & ~255;   // whole 1 KiB pieces
   a.dp = c->dp;
+  a.tprof = c->d_tprof;
   const size_t lds = sizeof(float) * (size_t)mb_lds_words(hl, a.wl);
   size_t slot = 0;
   DSGD_TRY(prof_begin(c, &slot));

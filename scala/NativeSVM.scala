@@ -7,8 +7,11 @@ import spire.math.Number
   *
   * `SparseSVM` keeps its constructor and its six methods (core/ml/SparseSVM.scala:11-31); `HipSVM` below is a
   * subclass whose batch-level entry points replace the bodies of `SlaveImpl.gradient` / `forward`
-  * (core/Slave.scala:129-157) and of the `Master.fit` batch closure (core/Master.scala:179-199) when
-  * `dsgd.backend = hip` (a new OPTIONAL key; every existing `dsgd { ... }` key of application.conf is untouched).
+  * (core/Slave.scala:129-157), of the `Slave.asyncTask` iteration and `updateGrad` (core/Slave.scala:79-111,177-185), of
+  * `Master.localLoss` / `localAccuracy` (core/Master.scala:100-107) and of the `Master.fit` batch closure
+  * (core/Master.scala:179-199) when `dsgd.backend = hip` (a new OPTIONAL key; every existing `dsgd { ... }` key of
+  * application.conf is untouched).  scala/patch/dsgd-hip-backend.diff is the patch that wires it in (it adds this file
+  * as src/main/scala/epfl/distributed/core/ml/NativeSVM.scala).
   */
 object NativeSVM {
   // The natives live on the module class `NativeSVM$`: their JNI names are
@@ -92,5 +95,57 @@ class HipSVM(lambda: Number, dimSparsity: Vec, data: Array[(Vec, Int)], nTrain: 
     (Number(out(0)), out(1))
   }
 
+  /** dev mode (Main.scala "launch: master + slaves"): master and slaves live in ONE JVM and share this object, i.e. ONE
+    * device context holds every row and the weights can stay on the device between batches / iterations. */
+  @volatile var resident: Boolean = false
+
+  def setWeights(w: Vec): Unit = NativeSVM.setWeights(ctx, DenseKeys.fromVec(w))
+
+  def weights(): Vec = {
+    val a = new Array[Float](dim + 1)
+    NativeSVM.getWeights(ctx, a)
+    DenseKeys.toVec(a, dim)
+  }
+
+  /** the whole batch closure of Master.fit (core/Master.scala:184-197) for the workers hosted by this context: per-worker
+    * regularised sums, mean over the workers, w <- w - learningRate * mean.  An empty list fails as Vec.sum does. */
+  def syncStep(idxPerWorker: Seq[Seq[Int]], learningRate: Double): Long =
+    NativeSVM.syncStep(ctx, idxPerWorker.map(_.toArray).toArray, learningRate.toFloat)
+
+  /** one iteration of Slave.asyncTask (core/Slave.scala:92-101) on the device-resident weights; returns the update that
+    * is gossiped (core/Slave.scala:103-105) */
+  def asyncStepBatch(samplesIdx: Seq[Int], learningRate: Double): Vec = {
+    val d = new Array[Float](dim + 1)
+    NativeSVM.asyncStep(ctx, samplesIdx.toArray, learningRate.toFloat, d)
+    DenseKeys.toVec(d, dim)
+  }
+
+  /** SlaveImpl.updateGrad / MasterAsync.updateGrad (core/Slave.scala:177-185): w <- w - delta; may arrive while the
+    * lock-free engine runs */
+  def updateGrad(delta: Vec): Unit = {
+    val entries = delta.map.toSeq
+    NativeSVM.updateGrad(ctx, entries.map(_._1).toArray, entries.map(_._2.toDouble.toFloat).toArray)
+  }
+
+  /** the persistent lock-free engine: `assigned` = one contiguous row range per worker (SplitStrategy.vanilla), all of
+    * them updating ONE device-resident weight vector (BASELINE configs[3]); maxUpdates as MasterAsync counts them
+    * (core/MasterAsync.scala:83,171) */
+  def asyncStart(assigned: Seq[(Int, Int)], batchSize: Int, learningRate: Double, maxUpdates: Long, seed: Long): Unit =
+    NativeSVM.asyncStart(ctx, assigned.map(_._1.toLong).toArray, assigned.map(_._2.toLong).toArray, batchSize,
+                         learningRate.toFloat, maxUpdates, seed, false)
+
+  def asyncUpdates(): Long = NativeSVM.asyncUpdates(ctx)
+
+  def asyncStop(): Unit = NativeSVM.asyncStop(ctx)
+
+  def asyncWait(): Unit = NativeSVM.asyncWait(ctx)
+
   def close(): Unit = NativeSVM.destroy(ctx)
+}
+
+object HipSVM {
+  def isResident(model: SparseSVM): Boolean = model match {
+    case h: HipSVM => h.resident
+    case _         => false
+  }
 }

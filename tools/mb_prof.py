@@ -40,13 +40,19 @@ with dsgd_amd.Engine(data.dim, 1e-5) as eng:
         plan = eng.plan(lists)
         eng.plan_run(plan, 0, min(10, steps), 0.5 * 100 / b)
         eng.synchronize()
+        eng.debug_cycles(reset=True)
         t0 = time.perf_counter()
         eng.plan_run(plan, 0, steps, 0.5 * 100 / b)
         eng.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        cyc = eng.debug_cycles(reset=True)
         plan.destroy()
         alg = 8.0 * nnz + 12.0 * k * b
         out["steps"].append({"workers": k, "batch": b, "us_per_step": 1e6 * dt, "kernel": eng.grad_kernel_name(),
                              "algorithmic_bytes": alg, "GBps": alg / dt / 1e9, "frac_of_8TBps": alg / dt / 8e12,
                              "examples_per_s": k * b / dt, "fix_shift": eng.tuning_info()["fix_shift"]})
+        if cyc[15]:   # DSGD_PLAN_PROF=1: cycles of wave 0 of workgroup 0 per launch, by phase
+            names = ("issue_ids_copy_clear", "row_records", "first_items", "barrier_in", "pass_wait_cols", "pass_process",
+                     "long_rows", "barrier_out", "write_partial")
+            out["steps"][-1]["wave0_cycles_per_launch"] = {nm: cyc[i] / cyc[15] for i, nm in enumerate(names)}
 print(json.dumps(out, indent=1))
