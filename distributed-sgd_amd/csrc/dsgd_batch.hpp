@@ -650,6 +650,9 @@ __device__ __forceinline__ void mb_wcache_issue(const float* __restrict__ w, flo
 
 __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ unsigned int wg_active;   // active rows of the workgroup: ONE global atomic per workgroup at the end (one per
+                                       // wave -- 3,072 same-address atomics for B = 65,536 -- queued up behind each other
+                                       // for 20 us: the phase counters showed the last phase growing with the wave count)
   const int tid = threadIdx.x, lane = tid & 63, sub = tid & (BT_G - 1), g = (tid >> 4) & 3;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   BtLds L;
@@ -687,6 +690,7 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
   long long row = row_id(wb + lane);
   mb_wcache_issue(a.w, wl, a.wl);
   wg_zero(L.acc, a.hl, tid, MB_THREADS);
+  if (tid == 0) wg_active = 0u;
   stamp(0);   // issue of the row ids, the weight copy, clearing
   unsigned int n_act = 0;
   bool first = true;
@@ -764,12 +768,13 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
     }
   }
   stamp(6);   // long rows, loop ends
+  n_act = wave_sum_u32(n_act);
+  if (lane == 0 && n_act) atomicAdd(&wg_active, n_act);
   __syncthreads();
   stamp(7);   // waiting for the other waves
   int* mine = a.part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * a.part_stride;
   wg_copy_out(mine, L.acc, a.hl, tid, MB_THREADS, is_aligned16(mine));
-  n_act = wave_sum_u32(n_act);
-  if (lane == 0 && n_act) atomicAdd(&a.sc->n_active, (unsigned long long)n_act);
+  if (tid == 0 && wg_active) atomicAdd(&a.sc->n_active, (unsigned long long)wg_active);
   if (prof && lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long now = __builtin_readcyclecounter();

@@ -512,7 +512,9 @@ static int launch_grad_mb(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, 
   c->fused_apply_pending = false;
   if (allow_fused) {
     DSGD_TRY(ensure_redpart(c));
-    c->fused_args = {hl, (int)wgs, c->dp, 0, 0, inv, inv};
+    // (no cold partials here: nc = 0, and hc only has to lie at or beyond D + 1 -- a multiple of 4 keeps the reduce on
+    //  its 16-byte loads; with hc = D + 1 = 47,237 it fell back to 4-byte loads: 21.5 us for 25 MB of partials)
+    c->fused_args = {hl, (int)wgs, (c->dp + 3) & ~3, 0, 0, inv, inv};
     c->fused_apply_pending = true;   // launched by launch_finish_sync, which knows lr
     return DSGD_OK;
   }
