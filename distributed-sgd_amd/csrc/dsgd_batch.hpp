@@ -376,7 +376,7 @@ struct __attribute__((aligned(16))) MbRec {   // one row of a wave's batch, as t
   int len;
   float y;         // label (+1 / -1)
 };
-__host__ __device__ constexpr int mb_lds_words(int hl, int wl) { return ((hl + 3) & ~3) + wl + (MB_THREADS / 64) * 64 * 4; }
+__host__ __device__ constexpr int mb_lds_words(int hl, int wl) { return ((hl + 3) & ~3) + wl + (MB_THREADS / 64) * 64 * 4 + 4; }
 
 template <int R>
 struct MbPass {   // the non-zeros of a pass, as loaded (which slots are valid is re-derived from the strip: registers are scarce)
@@ -650,9 +650,6 @@ __device__ __forceinline__ void mb_wcache_issue(const float* __restrict__ w, flo
 
 __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ unsigned int wg_active;   // active rows of the workgroup: ONE global atomic per workgroup at the end (one per
-                                       // wave -- 3,072 same-address atomics for B = 65,536 -- queued up behind each other
-                                       // for 20 us: the phase counters showed the last phase growing with the wave count)
   const int tid = threadIdx.x, lane = tid & 63, sub = tid & (BT_G - 1), g = (tid >> 4) & 3;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   BtLds L;
@@ -662,6 +659,10 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
   L.g64 = a.g64_base + (long long)blockIdx.y * a.g_stride;
   float* wl = lds + ((a.hl + 3) & ~3);
   MbRec* recs = reinterpret_cast<MbRec*>(wl + a.wl) + wave * 64;   // this wave's strip
+  // active rows of the workgroup: ONE global atomic per workgroup at the end (one per wave -- 3,072 same-address atomics
+  // for B = 65,536 -- queued up behind each other: the phase counters showed the last phase growing with the wave count).
+  // (In the dynamic allocation: a static __shared__ on top of 160 KiB of dynamic LDS is refused at launch set-up.)
+  unsigned int& wg_active = *reinterpret_cast<unsigned int*>(wl + a.wl + (MB_THREADS / 64) * 64 * 4);
   const WorkSeg seg = a.segs[blockIdx.y];
   const long long b = seg.begin + (long long)blockIdx.x * a.rows_per_wg;
   const long long e = b + a.rows_per_wg < seg.end ? b + a.rows_per_wg : seg.end;
