@@ -364,7 +364,7 @@ struct MbArgs {
   int part_stride, rows_per_wg, hl, wl, dp;   // hl: ranks with an LDS accumulator; wl: ranks with an LDS copy of w (multiple of 256)
   unsigned long long* tprof;   // optional (tuning runs, DSGD_PLAN_PROF=1): cycles of wave 0 of workgroup 0 by phase, [15] = launches
 };
-constexpr int MB_THREADS = 768;    // 12 waves: 170 VGPRs each (the two-deep pass pipeline does not fit the 128 of a 1024-lane workgroup)
+constexpr int MB_THREADS = 512;    // 8 waves of up to 256 VGPRs: three register sets of a pass pipeline per wave
 constexpr int MB_R = 2;          // item slots per 16-lane group and pass: 8 short rows or 2 medium rows per pass
 constexpr int MB_HL = 24576;     // ranks with an LDS accumulator per workgroup (96 KiB)
 constexpr int MB_WL = 11264;     // ranks with an LDS copy of their weight (44 KiB)
@@ -401,7 +401,11 @@ __device__ __forceinline__ MbSlot mb_slot(const MbRec* recs, const MbPlan& pl, i
   const int kind = pl.kind(q);
   int i, at, chunk;
   bool valid;
-  if (kind == 0) {
+  if (q >= pl.passes()) {   // a prefetch beyond the last pass: an empty slot
+    valid = false;
+    at = 0;
+    chunk = 0;
+  } else if (kind == 0) {
     i = q * 4 * R + r * 4 + g;
     valid = i < pl.n_short;
     at = i;
@@ -737,8 +741,15 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
     }
     __builtin_amdgcn_wave_barrier();   // same wave writes and reads the strip; LDS executes a wave's accesses in order
     const int n_q = pl.passes();
-    MbPass<MB_R> A, B;
-    if (n_q > 0) mb_issue<MB_R>(a.m, recs, pl, 0, g, sub, A);
+    // Three register sets, rotated by unrolling: while pass q is processed the weights of pass q+1 and the non-zeros of
+    // pass q+2 are in flight.  EVERY request below is unconditional (a pass beyond the last one reads address 0 and is
+    // masked): behind a conditional load the compiler no longer knows how many younger loads are outstanding and falls
+    // back to s_waitcnt vmcnt(0) -- which waits for the prefetches too and puts both round trips back on every pass
+    // (the first form of this loop: 3,400 + 2,000 cycles per pass in the phase counters).
+    MbPass<MB_R> A, B, C;
+    float ua[MB_R][BT_K], ub[MB_R][BT_K], uc[MB_R][BT_K];
+    mb_issue<MB_R>(a.m, recs, pl, 0, g, sub, A);
+    mb_issue<MB_R>(a.m, recs, pl, 1, g, sub, B);
     if (first) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the weight copy have landed ...
       stamp(2);                                           // (first pass's non-zeros landed)
@@ -747,21 +758,20 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
       first = false;
     }
     int q = 0;
-    float wv[MB_R][BT_K];
+    mb_gather<MB_R>(recs, pl, 0, g, A, sub, wload, ua);
+#define MB_STEP(PC, UC, PN, UN, PF)                                                                      \
+  mb_issue<MB_R>(a.m, recs, pl, q + 2, g, sub, PF);       /* non-zeros of pass q+2 */                      \
+  mb_gather<MB_R>(recs, pl, q + 1, g, PN, sub, wload, UN); /* weights of pass q+1 (its column ids landed) */ \
+  stamp(4);                                                                                              \
+  n_act += mb_process<MB_R>(L, recs, pl, q, g, PC, UC, sub, lane, wload, a.qscale);                       \
+  stamp(5);                                                                                              \
+  if (++q >= n_q) break;
     while (q < n_q) {   // wave-uniform
-      mb_gather<MB_R>(recs, pl, q, g, A, sub, wload, wv);
-      if (q + 1 < n_q) mb_issue<MB_R>(a.m, recs, pl, q + 1, g, sub, B);
-      stamp(4);   // waiting for this pass's column ids, requests
-      n_act += mb_process<MB_R>(L, recs, pl, q, g, A, wv, sub, lane, wload, a.qscale);
-      stamp(5);   // weights landed, products, gate, scatter
-      if (++q >= n_q) break;
-      mb_gather<MB_R>(recs, pl, q, g, B, sub, wload, wv);
-      if (q + 1 < n_q) mb_issue<MB_R>(a.m, recs, pl, q + 1, g, sub, A);
-      stamp(4);
-      n_act += mb_process<MB_R>(L, recs, pl, q, g, B, wv, sub, lane, wload, a.qscale);
-      stamp(5);
-      ++q;
+      MB_STEP(A, ua, B, ub, C)
+      MB_STEP(B, ub, C, uc, A)
+      MB_STEP(C, uc, A, ua, B)
     }
+#undef MB_STEP
     for (int j = 0; j < n_giant; ++j) {   // wave-uniform
       const MbRec rec = recs[pl.n_short + pl.n_wide + j];
       if (rec.len <= 2 * MB_WIDE) n_act += mb_huge<MB_R>(a.m, L, rec, g, sub, lane, A, B, wload, a.qscale);
