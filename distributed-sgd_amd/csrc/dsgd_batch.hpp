@@ -515,10 +515,10 @@ __device__ __forceinline__ void mb_gather(const MbRec* recs, const MbPlan& pl, i
 }
 
 // x.w of every slot's row, the gate, the scatter of the active rows' non-zeros (still in registers)
-template <int R, class WLoad>
+template <int R, class WLoad, class Stamp>
 __device__ __forceinline__ unsigned int mb_process(const BtLds& L, const MbRec* recs, const MbPlan& pl, int q, int g,
                                                    const MbPass<R>& P, float (&wv)[R][BT_K], int sub, int lane,
-                                                   WLoad wload, float qscale) {
+                                                   WLoad wload, float qscale, Stamp stamp) {
   const int kind = pl.kind(q);
   unsigned int n_act = 0;
   float acc[R], y[R];
@@ -549,6 +549,7 @@ __device__ __forceinline__ unsigned int mb_process(const BtLds& L, const MbRec* 
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = kind == 0 ? group_sum<BT_G>(acc[r]) : group_sum<64>(acc[r]);
   }
+  stamp(5);   // (tuning runs) weights landed, products, reduction
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const bool active = y[r] != 0.0f && !(y[r] * acc[r] < 0.0f);   // ref: core/ml/SparseSVM.scala:27-28
@@ -763,8 +764,8 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
   mb_issue<MB_R>(a.m, recs, pl, q + 2, g, sub, PF);       /* non-zeros of pass q+2 */                      \
   mb_gather<MB_R>(recs, pl, q + 1, g, PN, sub, wload, UN); /* weights of pass q+1 (its column ids landed) */ \
   stamp(4);                                                                                              \
-  n_act += mb_process<MB_R>(L, recs, pl, q, g, PC, UC, sub, lane, wload, a.qscale);                       \
-  stamp(5);                                                                                              \
+  n_act += mb_process<MB_R>(L, recs, pl, q, g, PC, UC, sub, lane, wload, a.qscale, stamp);                \
+  stamp(6);   /* gate + scatter (LDS atomics, 64-bit global atomics of the tail) */                       \
   if (++q >= n_q) break;
     while (q < n_q) {   // wave-uniform
       MB_STEP(A, ua, B, ub, C)
@@ -778,7 +779,6 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
       else n_act += mb_giant(a.m, L, rec.st, rec.len, rec.y, lane, wload, a.qscale);
     }
   }
-  stamp(6);   // long rows, loop ends
   n_act = wave_sum_u32(n_act);
   if (lane == 0 && n_act) atomicAdd(&wg_active, n_act);
   __syncthreads();

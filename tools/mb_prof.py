@@ -52,7 +52,7 @@ with dsgd_amd.Engine(data.dim, 1e-5) as eng:
                              "algorithmic_bytes": alg, "GBps": alg / dt / 1e9, "frac_of_8TBps": alg / dt / 8e12,
                              "examples_per_s": k * b / dt, "fix_shift": eng.tuning_info()["fix_shift"]})
         if cyc[15]:   # DSGD_PLAN_PROF=1: cycles of wave 0 of workgroup 0 per launch, by phase
-            names = ("issue_ids_copy_clear", "row_records", "first_items", "barrier_in", "pass_wait_cols", "pass_process",
-                     "long_rows", "barrier_out", "write_partial")
+            names = ("issue_ids_copy_clear", "row_records", "first_items", "barrier_in", "pass_requests", "pass_dot",
+                     "pass_scatter", "barrier_out", "write_partial")
             out["steps"][-1]["wave0_cycles_per_launch"] = {nm: cyc[i] / cyc[15] for i, nm in enumerate(names)}
 print(json.dumps(out, indent=1))
