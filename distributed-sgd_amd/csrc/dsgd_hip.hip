@@ -172,13 +172,17 @@ struct dsgd_ctx {
   float* d_hval = nullptr;
   long long* d_hrow_ptr = nullptr;      // n_rows + 1 (rows of the long list: empty)
   long long hot_nnz = 0;
-  unsigned int* d_ckey = nullptr;       // cold stream in row order (ColdView): key, value, [row], [block base rows]
-  float* d_cval = nullptr;
-  int* d_crow = nullptr;
-  int* d_cbase = nullptr;
-  bool cold_packed = false;
-  long long* d_crow_ptr = nullptr;      // n_rows + 1
-  long long coldm_nnz = 0;
+  void* d_ccol = nullptr;               // cold stream in row order: rank - hsplit (16-bit words, or 32-bit when there
+  float* d_cval = nullptr;              // are more than 65536 cold columns), value; WS_PAD elements of padding
+  bool cold_col16 = false;
+  bool hot_nt = false;                  // DSGD_HOT_NT=1: non-temporal hint on the hot stream's loads (A/B)
+  int cold_rev = 1;                     // DSGD_COLD_REV=0: the dot kernel walks its tiles first to last (A/B)
+  long long* d_ctp = nullptr;           // n_rows + 1: slot offsets of the cold stream (a tiled row owns >= 1 slot)
+  long long coldm_nnz = 0;              // slots of the cold stream
+  WTile* d_ctiles = nullptr;            // wave tiles over d_ccol/d_cval (same records and lane descriptors as the hot ones)
+  unsigned short* d_cmeta = nullptr;
+  long long n_ctiles = 0;
+  std::vector<int> h_ctile_r0;          // first row of every cold tile (+ sentinel n_rows)
   float* d_dcold = nullptr;             // n_rows: cold part of x.w (rows without cold entries stay 0)
   int* d_partc = nullptr;               // per-workgroup cold gradient partials: partc_wgs x partc_stride
   long long partc_wgs = 0;
@@ -604,7 +608,8 @@ struct HostTiles {
   std::vector<int> r0;              // first row of every tile + sentinel n_rows
   std::vector<unsigned short> meta16;   // n_tiles x 64
 };
-static void build_wave_tiles(const long long* row_ptr, long long n_rows, const signed char* label, HostTiles& out) {
+static void build_wave_tiles(const long long* row_ptr, long long n_rows, const signed char* label, HostTiles& out,
+                             int max_rows = WS_MAXROWS) {
   const long long amask = ~7LL;
   std::vector<WTile>& wt = out.wt;
   std::vector<int>& wr0 = out.r0;
@@ -627,7 +632,7 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
       close(i);
       continue;
     }
-    if (start >= 0 && (row_ptr[i + 1] - (row_ptr[start] & amask) > WS_SLOTS - 1 || i - start >= WS_MAXROWS)) close(i);
+    if (start >= 0 && (row_ptr[i + 1] - (row_ptr[start] & amask) > WS_SLOTS - 1 || i - start >= max_rows)) close(i);
     if (start < 0) start = i;
   }
   close(n_rows);
@@ -687,14 +692,14 @@ static int upload_wave_tiles(dsgd_ctx* c, HostTiles& ht) {
   return DSGD_OK;
 }
 
-// split the ranked CSR into the hot stream (rank < hsplit; wave tiles) and the cold stream
-// (rank - hsplit, value, row); rows whose hot part exceeds a wave tile stay on the long-row list and in neither.
+// split the ranked CSR into the hot stream (rank < hsplit) and the cold stream (rank - hsplit), both in row order with
+// wave tiles of whole rows; rows whose hot or cold part exceeds a wave tile stay on the long-row list and in neither.
 static int build_split(dsgd_ctx* c) {
   (void)hipFree(c->d_hcol); (void)hipFree(c->d_hval); (void)hipFree(c->d_hrow_ptr);
-  (void)hipFree(c->d_ckey); (void)hipFree(c->d_cval); (void)hipFree(c->d_crow); (void)hipFree(c->d_cbase); (void)hipFree(c->d_crow_ptr);
+  (void)hipFree(c->d_ccol); (void)hipFree(c->d_cval); (void)hipFree(c->d_ctp); (void)hipFree(c->d_ctiles); (void)hipFree(c->d_cmeta);
   (void)hipFree(c->d_dcold); (void)hipFree(c->d_coef8);
   c->d_hcol = nullptr; c->d_hval = nullptr; c->d_hrow_ptr = nullptr;
-  c->d_ckey = nullptr; c->d_cval = nullptr; c->d_crow = nullptr; c->d_cbase = nullptr; c->d_crow_ptr = nullptr;
+  c->d_ccol = nullptr; c->d_cval = nullptr; c->d_ctp = nullptr; c->d_ctiles = nullptr; c->d_cmeta = nullptr;
   c->d_dcold = nullptr; c->d_coef8 = nullptr;
   const long long n_rows = c->n_rows;
   const int H = std::min(c->hsplit, c->dp);
@@ -704,7 +709,7 @@ static int build_split(dsgd_ctx* c) {
   HIP_TRY(hipMemset(c->d_dcold, 0, sizeof(float) * (size_t)std::max<long long>(n_rows, 1)));
   // cold entries per row
   int* d_cnt = nullptr;
-  HIP_TRY(hipMalloc(&d_cnt, sizeof(int) * (size_t)n_rows));
+  HIP_TRY(hipMalloc(&d_cnt, sizeof(int) * (size_t)std::max<long long>(n_rows, 1)));
   CsrView m = view(c);
   {
     const int blocks = (int)std::max<long long>(1, std::min<long long>((n_rows + 15) / 16, (long long)c->n_cu * 16));
@@ -716,72 +721,67 @@ static int build_split(dsgd_ctx* c) {
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(d_cnt);
   if (e != hipSuccess) return fail(DSGD_EHIP, "split counts: %s", hipGetErrorString(e));
-  std::vector<long long> hrp((size_t)n_rows + 1), &crp = c->h_crow_ptr;
+  // hrp / ctp: slot offsets of the two streams (a tiled row owns at least one slot in each: an explicit zero when it
+  // has no entry there); crp: the cold ENTRIES before each row (what dsgd_range_nnz reports)
+  std::vector<long long> hrp((size_t)n_rows + 1), ctp((size_t)n_rows + 1), &crp = c->h_crow_ptr;
   crp.assign((size_t)n_rows + 1, 0);
   c->wlong_rows.clear();
   hrp[0] = 0;
+  ctp[0] = 0;
   const std::vector<long long>& rp = c->h_row_ptr;
+  const bool has_cold = c->dp > H;
   for (long long i = 0; i < n_rows; ++i) {
     const long long len = rp[i + 1] - rp[i], cold = cnt[(size_t)i], hot = len - cold;
-    if (hot > WS_MAXNNZ) {   // served whole from the ranked CSR, one wave per row
+    if (hot > WS_MAXNNZ || cold > WS_MAXNNZ) {   // served whole from the ranked CSR, one wave per row
       c->wlong_rows.push_back(i);
       hrp[i + 1] = hrp[i];
+      ctp[i + 1] = ctp[i];
       crp[i + 1] = crp[i];
     } else {
       hrp[i + 1] = hrp[i] + std::max<long long>(hot, 1);
+      ctp[i + 1] = ctp[i] + (has_cold ? std::max<long long>(cold, 1) : 0);
       crp[i + 1] = crp[i] + cold;
     }
   }
   c->hot_nnz = hrp[n_rows];
-  c->coldm_nnz = crp[n_rows];
+  c->coldm_nnz = ctp[n_rows];
   HIP_TRY(hipMalloc(&c->d_hcol, sizeof(unsigned short) * (size_t)(c->hot_nnz + WS_PAD)));
   HIP_TRY(hipMalloc(&c->d_hval, sizeof(float) * (size_t)(c->hot_nnz + WS_PAD)));
   HIP_TRY(hipMemset(c->d_hcol + c->hot_nnz, 0, sizeof(unsigned short) * WS_PAD));
   HIP_TRY(hipMemset(c->d_hval + c->hot_nnz, 0, sizeof(float) * WS_PAD));
   HIP_TRY(hipMalloc(&c->d_hrow_ptr, sizeof(long long) * hrp.size()));
   HIP_TRY(hipMemcpy(c->d_hrow_ptr, hrp.data(), sizeof(long long) * hrp.size(), hipMemcpyHostToDevice));
-  const size_t nc = (size_t)std::max<long long>(c->coldm_nnz, 1);
-  // first row of every block of 256 cold entries; the packed form needs 16-bit column ids and row offsets
-  std::vector<int> cbase((size_t)((c->coldm_nnz + 255) / 256) + 1, 0);
-  bool packed = c->dp - H <= 65536 && !getenv("DSGD_COLD_UNPACKED");
-  {
-    size_t b = 0;
-    for (long long i = 0; i < n_rows; ++i)          // row i is the base of every block that starts inside it
-      for (; (long long)b * 256 < crp[i + 1]; ++b) cbase[b] = (int)i;
-    for (long long i = 0; i < n_rows && packed; ++i) {
-      if (crp[i + 1] == crp[i]) continue;
-      for (long long bb = crp[i] / 256; bb <= (crp[i + 1] - 1) / 256; ++bb)   // blocks holding entries of row i
-        if (i - (long long)cbase[(size_t)bb] > 65535) packed = false;
-    }
-  }
-  c->cold_packed = packed;
-  // (+ COLD_PAD entries: the second-generation cold kernels read whole 512-entry tiles, masked by index)
-  HIP_TRY(hipMalloc(&c->d_ckey, sizeof(unsigned int) * (nc + COLD_PAD)));
-  HIP_TRY(hipMalloc(&c->d_cval, sizeof(float) * (nc + COLD_PAD)));
-  HIP_TRY(hipMemset(c->d_ckey + nc, 0, sizeof(unsigned int) * COLD_PAD));
-  HIP_TRY(hipMemset(c->d_cval + nc, 0, sizeof(float) * COLD_PAD));
-  if (!packed) {
-    HIP_TRY(hipMalloc(&c->d_crow, sizeof(int) * (nc + COLD_PAD)));
-    HIP_TRY(hipMemset(c->d_crow + nc, 0, sizeof(int) * COLD_PAD));
-  }
-  cbase.resize(cbase.size() + COLD_PAD / 256 + 2, cbase.empty() ? 0 : cbase.back());
-  HIP_TRY(hipMalloc(&c->d_cbase, sizeof(int) * cbase.size()));
-  HIP_TRY(hipMemcpy(c->d_cbase, cbase.data(), sizeof(int) * cbase.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&c->d_crow_ptr, sizeof(long long) * crp.size()));
-  HIP_TRY(hipMemcpy(c->d_crow_ptr, crp.data(), sizeof(long long) * crp.size(), hipMemcpyHostToDevice));
+  // 16-bit cold ids whenever there are at most 65536 cold columns (DSGD_COLD_UNPACKED=1 forces the 32-bit form: tests)
+  c->cold_col16 = c->dp - H <= 65536 && !getenv("DSGD_COLD_UNPACKED");
+  const size_t csz = c->cold_col16 ? sizeof(unsigned short) : sizeof(unsigned int);
+  HIP_TRY(hipMalloc(&c->d_ccol, csz * (size_t)(c->coldm_nnz + WS_PAD)));
+  HIP_TRY(hipMalloc(&c->d_cval, sizeof(float) * (size_t)(c->coldm_nnz + WS_PAD)));
+  HIP_TRY(hipMemset((char*)c->d_ccol + csz * (size_t)c->coldm_nnz, 0, csz * WS_PAD));
+  HIP_TRY(hipMemset(c->d_cval + c->coldm_nnz, 0, sizeof(float) * WS_PAD));
+  HIP_TRY(hipMalloc(&c->d_ctp, sizeof(long long) * ctp.size()));
+  HIP_TRY(hipMemcpy(c->d_ctp, ctp.data(), sizeof(long long) * ctp.size(), hipMemcpyHostToDevice));
   {
     const int blocks = (int)std::max<long long>(1, std::min<long long>((n_rows + 3) / 4, (long long)c->n_cu * 16));
-    if (packed)
-      hipLaunchKernelGGL(dsgd_split_fill_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, m, H, c->d_hrow_ptr,
-                         c->d_crow_ptr, c->d_hcol, c->d_hval, c->d_ckey, c->d_cval, c->d_crow, c->d_cbase);
+    if (c->cold_col16)
+      hipLaunchKernelGGL(dsgd_split_fill_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, m, H, c->d_hrow_ptr, c->d_ctp,
+                         c->d_hcol, c->d_hval, c->d_ccol, c->d_cval);
     else
-      hipLaunchKernelGGL(dsgd_split_fill_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, m, H, c->d_hrow_ptr,
-                         c->d_crow_ptr, c->d_hcol, c->d_hval, c->d_ckey, c->d_cval, c->d_crow, c->d_cbase);
+      hipLaunchKernelGGL(dsgd_split_fill_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, m, H, c->d_hrow_ptr, c->d_ctp,
+                         c->d_hcol, c->d_hval, c->d_ccol, c->d_cval);
     HIP_TRY(hipGetLastError());
   }
   HostTiles ht;
   build_wave_tiles(hrp.data(), n_rows, c->h_label.data(), ht);
   DSGD_TRY(upload_wave_tiles(c, ht));
+  // the cold stream's own tiles (label signs unused there)
+  HostTiles hc;
+  build_wave_tiles(ctp.data(), n_rows, c->h_label.data(), hc, CT_MAXROWS);
+  c->n_ctiles = (long long)hc.r0.size() - 1;
+  c->h_ctile_r0.swap(hc.r0);
+  HIP_TRY(hipMalloc(&c->d_ctiles, sizeof(WTile) * hc.wt.size()));
+  HIP_TRY(hipMalloc(&c->d_cmeta, sizeof(unsigned short) * hc.meta16.size()));
+  HIP_TRY(hipMemcpy(c->d_ctiles, hc.wt.data(), sizeof(WTile) * hc.wt.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_cmeta, hc.meta16.data(), sizeof(unsigned short) * hc.meta16.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return DSGD_OK;
 }
@@ -867,10 +867,12 @@ static StreamSeg make_sseg(long long rb, long long re) {
   return s;
 }
 // tile and long-row ranges of every worker's row range (wave tiles of whatever stream the mode uses)
-static void locate_segs(dsgd_ctx* c, std::vector<StreamSeg>& segs, long long* max_tiles, long long* max_long) {
+static void locate_segs(dsgd_ctx* c, std::vector<StreamSeg>& segs, long long* max_tiles, long long* max_long,
+                        long long* max_ctiles = nullptr) {
   const std::vector<int>& wr0 = c->h_wtile_r0;  // n_wtiles + 1 entries (sentinel n_rows)
   *max_tiles = 1;
   *max_long = 0;
+  if (max_ctiles) *max_ctiles = 0;
   for (StreamSeg& s : segs) {
     // first tile whose rows reach row_begin: the last tile with r0 <= row_begin (it may end before row_begin when a
     // long row sits in between -- then all its rows are masked) ... one past the last tile with r0 < row_end
@@ -885,6 +887,18 @@ static void locate_segs(dsgd_ctx* c, std::vector<StreamSeg>& segs, long long* ma
     s.long_begin = std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), s.row_begin) - c->wlong_rows.begin();
     s.long_end = std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), s.row_end) - c->wlong_rows.begin();
     *max_long = std::max(*max_long, s.long_end - s.long_begin);
+    // the cold stream's tiles of the range, located the same way
+    const std::vector<int>& cr0 = c->h_ctile_r0;   // n_ctiles + 1 entries (sentinel n_rows)
+    s.ctile_begin = s.ctile_end = 0;
+    if (cr0.size() > 1) {
+      long long cb = (std::upper_bound(cr0.begin(), cr0.end() - 1, (int)s.row_begin) - cr0.begin()) - 1;
+      if (cb < 0) cb = 0;
+      long long ce = std::lower_bound(cr0.begin(), cr0.end() - 1, (int)s.row_end) - cr0.begin();
+      if (ce < cb) ce = cb;
+      s.ctile_begin = cb;
+      s.ctile_end = ce;
+    }
+    if (max_ctiles) *max_ctiles = std::max(*max_ctiles, s.ctile_end - s.ctile_begin);
   }
 }
 static int ensure_part(dsgd_ctx* c, int** buf, long long* wgs, int* stride, long long need_wgs, int need_cols) {
@@ -903,31 +917,36 @@ template <bool SCATTER>
 static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   const int n_workers = (int)row_segs.size();
   std::vector<StreamSeg> segs(row_segs);
-  long long max_tiles, max_long;
-  locate_segs(c, segs, &max_tiles, &max_long);
+  long long max_tiles, max_long, max_ctiles;
+  locate_segs(c, segs, &max_tiles, &max_long, &max_ctiles);
   DSGD_TRY(upload_ssegs(c, segs));
   const int H = std::min(c->hsplit, c->dp);
   const int nc = c->dp - H;                                     // cold columns
-  const int nc_lds = std::min(nc, DSGD_LDS_FLOATS - 64);        // ... of which in the LDS tile of the cold kernels
-  long long max_cold = 0;
-  for (const StreamSeg& sg : segs) max_cold = std::max(max_cold, c->h_crow_ptr[sg.row_end] - c->h_crow_ptr[sg.row_begin]);
+  // ... of which in the LDS tile of the cold kernels (next to 16 strips and the gradient kernel's 64 dummy words)
+  const int nc_lds = std::min(nc, DSGD_LDS_FLOATS - 16 * CT_STRIP - 64 - 4);
   const long long per_worker = std::max<long long>(1, c->n_cu / n_workers);
-  dim3 gridc((unsigned)std::max<long long>(1, std::min(per_worker, (max_cold + 16383) / 16384)), n_workers);
-  const bool cold = nc > 0 && max_cold > 0;
-  ColdView cv;
-  cv.key = c->d_ckey;
-  cv.val = c->d_cval;
-  cv.row = c->d_crow;
-  cv.base = c->d_cbase;
+  dim3 gridc((unsigned)std::max<long long>(1, std::min(per_worker, (max_ctiles + 15) / 16)), n_workers);
+  const bool cold = nc > 0 && max_ctiles > 0;
+  const bool wide = nc > nc_lds;
+  const size_t lds_cdot = sizeof(float) * (size_t)(((nc_lds + 3) & ~3) + 16 * CT_STRIP);
+  const size_t lds_cgrad = sizeof(float) * (size_t)(((nc_lds + 64 + 3) & ~3) + 16 * CT_STRIP);
   if (cold) {
     size_t slot_c = 0;
     DSGD_TRY(prof_begin(c, &slot_c, 1));
-    if (c->cold_packed)
-      hipLaunchKernelGGL(dsgd_cdot8_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
-                         c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds, nc > nc_lds ? 1 : 0);
-    else
-      hipLaunchKernelGGL(dsgd_cdot8_kernel<false>, gridc, dim3(1024), sizeof(float) * (size_t)std::max(nc_lds, 1), c->stream, cv,
-                         c->d_crow_ptr, c->d_w, c->d_dcold, c->d_ssegs, H, nc_lds, nc > nc_lds ? 1 : 0);
+    // (the dot kernel walks the tiles from the last to the first: it runs right behind the gradient kernel of the
+    //  previous step, whose last tiles are the ones still on the die)
+#define DSGD_COLD_LAUNCH(C16, GR, WD, LDS, REV)                                                                          \
+  hipLaunchKernelGGL((dsgd_cold_kernel<C16, GR, WD>), gridc, dim3(1024), LDS, c->stream, c->d_ctiles, c->d_cmeta,      \
+                     c->d_ccol, c->d_cval, c->d_ssegs, c->d_w, c->d_dcold, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, \
+                     H, nc_lds, c->fix_scale, c->d_partc, c->partc_stride, REV)
+#define DSGD_COLD_DISPATCH(GR, LDS, REV)                                       \
+  do {                                                                         \
+    if (c->cold_col16 && !wide) DSGD_COLD_LAUNCH(true, GR, false, LDS, REV);   \
+    else if (c->cold_col16) DSGD_COLD_LAUNCH(true, GR, true, LDS, REV);        \
+    else if (!wide) DSGD_COLD_LAUNCH(false, GR, false, LDS, REV);              \
+    else DSGD_COLD_LAUNCH(false, GR, true, LDS, REV);                          \
+  } while (0)
+    DSGD_COLD_DISPATCH(false, lds_cdot, c->cold_rev);
     HIP_TRY(hipGetLastError());
     DSGD_TRY(prof_end(c, slot_c));
   }
@@ -996,7 +1015,12 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   CsrView mf = view(c);
   size_t slot = 0;
   if (SCATTER) DSGD_TRY(prof_begin(c, &slot));
-  hipLaunchKernelGGL(dsgd_wseg_kernel<SCATTER>, grid, dim3(1024), lds, c->stream, mh, mf, c->d_wtiles, c->d_wmeta, c->d_w,
+  if (c->hot_nt)
+    hipLaunchKernelGGL((dsgd_wseg_kernel<SCATTER, true>), grid, dim3(1024), lds, c->stream, mh, mf, c->d_wtiles, c->d_wmeta, c->d_w,
+                     c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, main_scale, c->d_coef8, c->d_wlong_rows,
+                     SCATTER ? c->d_part : nullptr, c->part_stride, c->d_dcold, c->fix_scale);
+  else
+    hipLaunchKernelGGL((dsgd_wseg_kernel<SCATTER, false>), grid, dim3(1024), lds, c->stream, mh, mf, c->d_wtiles, c->d_wmeta, c->d_w,
                      c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, main_scale, c->d_coef8, c->d_wlong_rows,
                      SCATTER ? c->d_part : nullptr, c->part_stride, c->d_dcold, c->fix_scale);
   HIP_TRY(hipGetLastError());
@@ -1006,14 +1030,7 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   if (cold) {
     size_t slot_g = 0;
     DSGD_TRY(prof_begin(c, &slot_g, 2));
-    if (c->cold_packed)
-      hipLaunchKernelGGL(dsgd_cgrad_kernel<true>, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, cv,
-                         c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H, nc_lds, c->fix_scale,
-                         c->d_partc, c->partc_stride, nc > nc_lds ? 1 : 0);
-    else
-      hipLaunchKernelGGL(dsgd_cgrad_kernel<false>, gridc, dim3(1024), sizeof(float) * (size_t)(nc_lds + 64), c->stream, cv,
-                         c->d_crow_ptr, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, c->d_ssegs, H, nc_lds, c->fix_scale,
-                         c->d_partc, c->partc_stride, nc > nc_lds ? 1 : 0);
+    DSGD_COLD_DISPATCH(true, lds_cgrad, 0);
     HIP_TRY(hipGetLastError());
     DSGD_TRY(prof_end(c, slot_g));
   }
@@ -1162,6 +1179,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_FIX_SHIFT")) c->max_shift = std::max(8, std::min(FIX_SHIFT, atoi(e)));   // cap of the fixed-point shift
   if (const char* e = getenv("DSGD_FIX_BOUND")) c->fix_bound = atoi(e) != 0;      // 0: data-independent bound only
   if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;  // 0: small batches through the multi-workgroup kernel
+  if (const char* e = getenv("DSGD_HOT_NT")) c->hot_nt = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_COLD_REV")) c->cold_rev = atoi(e) != 0;        // 0: cold dot kernel first tile to last
   if (const char* e = getenv("DSGD_HSPLIT")) c->hsplit = atoi(e);                 // hot/cold split rank (tests: wide models)
   if (getenv("DSGD_PLAN_PROF") && atoi(getenv("DSGD_PLAN_PROF"))) {
     HIP_TRY_B(hipMalloc(&c->d_tprof, sizeof(unsigned long long) * 16));
@@ -1179,13 +1198,19 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_hogwild_kernel);
   DSGD_ATTR(dsgd_mb_grad_kernel);
   DSGD_ATTR(dsgd_plan_kernel);
-  DSGD_ATTR(dsgd_wseg_kernel<true>);
-  DSGD_ATTR(dsgd_wseg_kernel<false>);
+  DSGD_ATTR((dsgd_wseg_kernel<true, false>));
+  DSGD_ATTR((dsgd_wseg_kernel<false, false>));
+  DSGD_ATTR((dsgd_wseg_kernel<true, true>));
+  DSGD_ATTR((dsgd_wseg_kernel<false, true>));
   DSGD_ATTR(dsgd_wseg_bound_kernel);
-  DSGD_ATTR(dsgd_cgrad_kernel<true>);
-  DSGD_ATTR(dsgd_cgrad_kernel<false>);
-  DSGD_ATTR(dsgd_cdot8_kernel<true>);
-  DSGD_ATTR(dsgd_cdot8_kernel<false>);
+  DSGD_ATTR((dsgd_cold_kernel<true, false, false>));
+  DSGD_ATTR((dsgd_cold_kernel<true, false, true>));
+  DSGD_ATTR((dsgd_cold_kernel<false, false, false>));
+  DSGD_ATTR((dsgd_cold_kernel<false, false, true>));
+  DSGD_ATTR((dsgd_cold_kernel<true, true, false>));
+  DSGD_ATTR((dsgd_cold_kernel<true, true, true>));
+  DSGD_ATTR((dsgd_cold_kernel<false, true, false>));
+  DSGD_ATTR((dsgd_cold_kernel<false, true, true>));
 #undef DSGD_ATTR
   HIP_TRY_B(hipStreamSynchronize(c->stream));
 #undef HIP_TRY_B
@@ -1237,11 +1262,11 @@ int dsgd_destroy(dsgd_ctx* c) {
   (void)hipFree(c->d_hcol);
   (void)hipFree(c->d_hval);
   (void)hipFree(c->d_hrow_ptr);
-  (void)hipFree(c->d_ckey);
+  (void)hipFree(c->d_ccol);
   (void)hipFree(c->d_cval);
-  (void)hipFree(c->d_crow);
-  (void)hipFree(c->d_cbase);
-  (void)hipFree(c->d_crow_ptr);
+  (void)hipFree(c->d_ctp);
+  (void)hipFree(c->d_ctiles);
+  (void)hipFree(c->d_cmeta);
   (void)hipFree(c->d_dcold);
   (void)hipFree(c->d_bound);
   (void)hipFree(c->d_redpart);
@@ -2320,7 +2345,7 @@ int dsgd_tuning_info(dsgd_ctx* c, int32_t* vals, int32_t n) {
   if (!vals || n < 0 || n > 6) return fail(DSGD_EINVAL, "bad tuning_info arguments");
   std::lock_guard<std::mutex> lk(c->mu);
   const int32_t all[6] = {4 /* split layout: the only one */, std::min(c->hsplit, c->dp), c->last_shift,
-                          c->cold_packed ? 1 : 0, c->plan_kernel ? 1 : 0, c->fix_bound ? 1 : 0};
+                          c->cold_col16 ? 1 : 0, c->plan_kernel ? 1 : 0, c->fix_bound ? 1 : 0};
   for (int i = 0; i < n; ++i) vals[i] = all[i];
   return DSGD_OK;
 }

@@ -11,10 +11,10 @@
 // ds_add_u32 at the streaming rate where ds_add_f32 manages 188 Gnnz/s (hence fixed point).  The
 // API (include/dsgd.h) speaks original keys; dsgd_hip.hip permutes at the boundary.
 //
-// Kernel families, in file order: row-per-group kernels for index-list batches (K1a/K1b), finish kernels
-// (regularise, sum, apply), layout kernels, fixed-point helpers, the transposed cold lists of stream mode 3,
-// the wave-tile streaming kernel (both layouts), the split-matrix layout kernels and the two cold-stream
-// kernels, the Hogwild engine.  DESIGN.md section 3 describes each with its roofline.
+// Kernel families, in file order: finish kernels (regularise, sum, apply), prediction / evaluation by row, layout
+// kernels, fixed-point helpers and the fused reduce + update, the wave-tile streaming kernel of the hot columns, the
+// split-matrix layout kernels and the two cold-stream kernels.  The mini-batch engine (index lists, Hogwild) lives in
+// dsgd_batch.hpp.  DESIGN.md section 3 describes each with its roofline.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -31,8 +31,25 @@ __device__ __forceinline__ float filt(float v) { return fabsf(v) > DSGD_EPS ? v 
 // with aligned bases; the tail (n % 4) goes element-wise.
 __device__ __forceinline__ void wg_copy_in(float* lds_dst, const float* __restrict__ src, int n, int tid, int nthreads,
                                            bool aligned) {
+  // eight 16-byte requests in flight per lane (clamped, unconditional loads; predicated LDS writes): the one-load-per-
+  // iteration loop this replaces waited out a full memory round trip seven times in a row for the 115 KB of the cold
+  // dot kernel -- a fifth of a 50 us kernel
   const int n4 = aligned ? n >> 2 : 0;
-  for (int j = tid; j < n4; j += nthreads) reinterpret_cast<float4*>(lds_dst)[j] = reinterpret_cast<const float4*>(src)[j];
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  float4* d4 = reinterpret_cast<float4*>(lds_dst);
+  for (int j0 = 0; j0 < n4; j0 += 8 * nthreads) {
+    float4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u * nthreads + tid;
+      t[u] = s4[j < n4 ? j : n4 - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u * nthreads + tid;
+      if (j < n4) d4[j] = t[u];
+    }
+  }
   for (int j = 4 * n4 + tid; j < n; j += nthreads) lds_dst[j] = src[j];
 }
 __device__ __forceinline__ void wg_zero(int* lds_dst, int n, int tid, int nthreads) {   // lds_dst 16-byte aligned
@@ -391,6 +408,7 @@ struct StreamSeg {
   long long row_begin, row_end;    // rows of this worker's batch
   long long tile_begin, tile_end;  // tiles intersecting [row_begin, row_end)
   long long long_begin, long_end;  // wave-tile mode: range of the long-row list (rows that fit no tile)
+  long long ctile_begin, ctile_end;  // cold-stream tiles intersecting [row_begin, row_end)
 };
 
 // the same with per-workgroup partial sums: worker k owns workgroups [k * n_wg, (k + 1) * n_wg) of `part` (main
@@ -718,6 +736,7 @@ __device__ __forceinline__ WTile w_fetch(const WTables& tt, long long t, long lo
 }
 
 // the stream of a tile: eight 16-bit column ranks (one 16-byte load), eight values (two), the lane descriptor
+template <bool NT>
 __device__ __forceinline__ void w_issue_cols(const CsrView& m, long long t, long long t_end, int lane, const WTile& wt,
                                              WRegs& r) {
   const bool live = t < t_end;
@@ -739,17 +758,18 @@ __device__ __forceinline__ void w_issue_cols(const CsrView& m, long long t, long
   const int nb16 = (int)(((unsigned int)wt.info >> 16) + 7u & ~7u) * 2;
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(col16 + wt.pos0), 0, nb16, 0x00020000);
-  const i32x4 a = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0));
+  const i32x4 a = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, NT ? 2 : 0));
   r.c0 = make_int4(a.x, a.y, a.z, a.w);
 }
+template <bool NT>
 __device__ __forceinline__ void w_issue_vals(const CsrView& m, const WTables& tt, int lane, WRegs& r) {
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m.val + r.pos0), 0, r.nb, 0x00020000);
   // (whole-vector bit casts: an element-wise __builtin_bit_cast(float, a.x) of the returned vector is folded to
   //  component 0 for all four elements by this compiler)
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane, 0, 0));
-  const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane + 16, 0, 0));
+  const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane, 0, NT ? 2 : 0));
+  const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane + 16, 0, NT ? 2 : 0));
   r.v0 = make_float4(a.x, a.y, a.z, a.w);
   r.v1 = make_float4(b.x, b.y, b.z, b.w);
   // lane descriptor, 16 bits (row-start bits | label signs << 8); the local row of the lane's first slot is a wave
@@ -810,7 +830,7 @@ __device__ __forceinline__ void w_scatter(const WCtx& x, const int (&cc)[8], con
 // FIRST so that they are already on their way while the wave works on tile t.  The tiles hold the HOT part of the
 // matrix only (every column rank < hw = hg), the cold part of each row's x.w comes from x.dcold -- no gathers, no
 // clamps, no cold checks.
-template <bool SCATTER>
+template <bool SCATTER, bool NT>
 __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, const WCtx& x, long long tile,
                                        long long stride, long long t_end, WRegs& cur, WRegs& nxt, WRegs& far,
                                        WTile& wt_far, unsigned int& n_all, unsigned int& n_neg, unsigned int& n_pos) {
@@ -819,8 +839,8 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, cons
   // wait for it does not drain the stream loads issued behind it
   const WTile wt_now = wt_far;                                              // record fetched last iteration
   wt_far = w_fetch(tt, tile + 4 * stride, t_end);                           // record used next iteration
-  w_issue_cols(m, tile + 3 * stride, t_end, lane, wt_now, far);
-  w_issue_vals(m, tt, lane, far);   // (values with the column ids: the window descriptor stays in scalar registers)
+  w_issue_cols<NT>(m, tile + 3 * stride, t_end, lane, wt_now, far);
+  w_issue_vals<NT>(m, tt, lane, far);   // (values with the column ids: the window descriptor stays in scalar registers)
   w_load_dc(x, nxt);                // tile t+1 (descriptor landed)
 
   const int nrows = cur.nrows;                          // wave-uniform; -1: the whole tile is padding
@@ -1059,7 +1079,7 @@ __device__ __forceinline__ void w_long_row(const CsrView& m, const float* __rest
 }
 
 // m: the hot stream (row_ptr = hot row offsets, col = 16-bit ranks, val); mfull: the whole ranked CSR (long rows)
-template <bool SCATTER>
+template <bool SCATTER, bool NT>
 __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mfull, const WTile* __restrict__ tiles,
                                                         const unsigned short* __restrict__ meta,
                                                         const float* __restrict__ w, long long* __restrict__ g64_base,
@@ -1118,17 +1138,17 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
     // four register sets rotated by unrolling: three tiles in flight per wave
     WRegs A, B, C, D;
     WTile wt = w_fetch(tt, tile, t_end);
-    w_issue_cols(m, tile, t_end, lane, wt, A);
-    w_issue_vals(m, tt, lane, A);
+    w_issue_cols<NT>(m, tile, t_end, lane, wt, A);
+    w_issue_vals<NT>(m, tt, lane, A);
     wt = w_fetch(tt, tile + stride, t_end);
-    w_issue_cols(m, tile + stride, t_end, lane, wt, B);
-    w_issue_vals(m, tt, lane, B);
+    w_issue_cols<NT>(m, tile + stride, t_end, lane, wt, B);
+    w_issue_vals<NT>(m, tt, lane, B);
     wt = w_fetch(tt, tile + 2 * stride, t_end);
-    w_issue_cols(m, tile + 2 * stride, t_end, lane, wt, C);
-    w_issue_vals(m, tt, lane, C);
+    w_issue_cols<NT>(m, tile + 2 * stride, t_end, lane, wt, C);
+    w_issue_vals<NT>(m, tt, lane, C);
     wt = w_fetch(tt, tile + 3 * stride, t_end);
     w_load_dc(x, A);
-#define DSGD_WT(CUR, NXT, FAR) w_tile<SCATTER>(m, tt, x, tile, stride, t_end, CUR, NXT, FAR, wt, n_all, n_neg, n_pos)
+#define DSGD_WT(CUR, NXT, FAR) w_tile<SCATTER, NT>(m, tt, x, tile, stride, t_end, CUR, NXT, FAR, wt, n_all, n_neg, n_pos)
     for (;;) {
       DSGD_WT(A, B, D); tile += stride; if (tile >= t_end) break;
       DSGD_WT(B, C, A); tile += stride; if (tile >= t_end) break;
@@ -1216,40 +1236,22 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_bound_kernel(const long long* 
 }
 
 // ======================================================================================================
-// stream_mode 4: the matrix split by column rank -- layout kernels and the two cold-stream kernels
+// the matrix split by column rank -- layout kernels and the two cold-stream kernels
 // ======================================================================================================
 // Measured on MI355X (profiles/README.md): with 9 % of the non-zeros outside the LDS weight tile the eight
 // per-lane gathers of a tile keep a CU's texture addresser busy 60 % of the time (20 % without them), and the
 // transposed cold lists pay one scattered coefficient lookup per cold entry.  Both disappear when the cold
-// entries leave the main stream: they form their own row-ordered stream (rank - hsplit, value, row) that two
-// small kernels read linearly -- dsgd_cdot_kernel with the cold WEIGHTS in LDS (cold part of x.w per row, before
-// the main kernel), dsgd_cgrad_kernel with the cold GRADIENT in LDS (after it, coefficients read by row).
-
-// The cold stream in row order.  Packed form (8 bytes per entry): key = col | (row - base[i >> 8]) << 16 with one
-// base row per 256 entries -- used whenever there are at most 65536 cold columns and no 256-entry block spans
-// more than 65535 rows; otherwise (12 bytes per entry) key = col and the row has its own array.
-struct ColdView {
-  const unsigned int* __restrict__ key;
-  const float* __restrict__ val;
-  const int* __restrict__ row;    // unpacked form only
-  const int* __restrict__ base;   // packed form only: first row of every 256-entry block
-};
-template <bool PACKED>
-__device__ __forceinline__ void cold_get(const ColdView& cv, long long i, int& col, int& row) {
-  const unsigned int k = cv.key[i];
-  if (PACKED) {
-    col = (int)(k & 0xffffu);
-    row = cv.base[i >> 8] + (int)(k >> 16);
-  } else {
-    col = (int)k;
-    row = cv.row[i];
-  }
-}
-template <bool PACKED>
-__device__ __forceinline__ int cold_row_at(const ColdView& cv, long long i) {
-  if (PACKED) return cv.base[i >> 8] + (int)(cv.key[i] >> 16);
-  return cv.row[i];
-}
+// entries leave the main stream: they form their own row-ordered stream that two small kernels read linearly --
+// dsgd_cdot_kernel with the cold WEIGHTS in LDS (cold part of x.w per row, before the main kernel),
+// dsgd_cgrad_kernel with the cold GRADIENT in LDS (after it, gate coefficients read by row).
+//
+// Third generation (round 3): the cold stream has the SAME form as the hot stream -- (rank - hsplit) as 16-bit words
+// (32-bit when there are more than 65536 cold columns), fp32 values, wave tiles of WHOLE rows with 16-bit lane
+// descriptors (row-start bits) -- 6 bytes per entry instead of 8 (the row of an entry used to ride in the upper half
+// of a 32-bit key), no row-start search, no carry between tiles, and the tile walk of the main kernel: exact-size
+// buffer windows, four register sets rotated by unrolling, three tiles in flight per wave.  The second generation
+// (eight contiguous entries per lane of a row-agnostic 512-entry tile, two tiles in flight; git history) measured
+// 77-83 us (dot) and 66-70 us (gradient) for 0.30 GB each.
 
 // cold entries per row (ranked column ids; G lanes per row)
 template <int G>
@@ -1268,24 +1270,25 @@ __global__ void __launch_bounds__(256) dsgd_split_count_kernel(CsrView m, int hs
 }
 
 // one wave per row: stable partition of the row into the hot and the cold stream.  A row whose hot range is empty
-// in hrow_ptr belongs to the long-row list and is left out of both streams; a row without any hot entry gets one
-// explicit zero on rank 0 so that every tiled row owns a slot.
-template <bool PACKED>
+// in hrow_ptr belongs to the long-row list and is left out of both streams; a row without any hot (cold) entry gets
+// one explicit zero on the first hot (cold) rank so that every tiled row owns a slot in both streams.
+template <bool COL16>
 __global__ void __launch_bounds__(256) dsgd_split_fill_kernel(CsrView m, int hsplit,
                                                              const long long* __restrict__ hrow_ptr,
                                                              const long long* __restrict__ crow_ptr,
                                                              unsigned short* __restrict__ hcol, float* __restrict__ hval,
-                                                             unsigned int* __restrict__ ckey, float* __restrict__ cval,
-                                                             int* __restrict__ crow, const int* __restrict__ cbase) {
+                                                             void* __restrict__ ccol, float* __restrict__ cval) {
   const int lane = threadIdx.x & 63;
   const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+  unsigned short* ccol16 = reinterpret_cast<unsigned short*>(ccol);
+  unsigned int* ccol32 = reinterpret_cast<unsigned int*>(ccol);
   for (long long row = wave; row < m.n_rows; row += n_waves) {
     long long hp = hrow_ptr[row];
     if (hrow_ptr[row + 1] == hp) continue;   // long row
     long long cp = crow_ptr[row];
     const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
-    bool any_hot = false;
+    bool any_hot = false, any_cold = false;
     for (long long p0 = start; p0 < end; p0 += 64) {
       const long long p = p0 + lane;
       const bool in = p < end;
@@ -1301,110 +1304,27 @@ __global__ void __launch_bounds__(256) dsgd_split_fill_kernel(CsrView m, int hsp
       }
       if (cold) {
         const long long o = cp + __popcll(mc & below);
-        if (PACKED) {
-          ckey[o] = (unsigned int)(c - hsplit) | ((unsigned int)((int)row - cbase[o >> 8]) << 16);
-        } else {
-          ckey[o] = (unsigned int)(c - hsplit);
-          crow[o] = (int)row;
-        }
+        if (COL16) ccol16[o] = (unsigned short)(c - hsplit);
+        else ccol32[o] = (unsigned int)(c - hsplit);
         cval[o] = v;
       }
       hp += __popcll(mh);
       cp += __popcll(mc);
       any_hot = any_hot || mh != 0ull;
+      any_cold = any_cold || mc != 0ull;
     }
-    if (!any_hot && lane == 0) {
-      hcol[hp] = 0;
-      hval[hp] = 0.0f;
-    }
-  }
-}
-
-// first element index e' >= e of the cold stream at which a new row starts (e_lo and e_hi are row starts)
-template <bool PACKED>
-__device__ __forceinline__ long long cold_row_start(const ColdView& cv, long long e, long long e_lo, long long e_hi,
-                                                    int lane) {
-  if (e <= e_lo) return e_lo;
-  while (e < e_hi) {
-    const long long i = e + lane;
-    const bool st = i < e_hi && cold_row_at<PACKED>(cv, i) != cold_row_at<PACKED>(cv, i - 1);
-    const unsigned long long mk = __builtin_amdgcn_ballot_w64(st);
-    if (mk) return e + __builtin_ctzll(mk);
-    e += 64;
-  }
-  return e_hi;
-}
-
-constexpr int CD_UNR = 16;   // 64-element chunks in flight per wave
-
-// cold gradient columns of each worker's range: q = round(value * coef[row] * scale) accumulated in an LDS tile of
-// 32-bit integers (same fixed-point grid and overflow rule as the main kernel), flushed once per workgroup into
-// partc[workgroup][col]; dsgd_fix_reduce_kernel adds the partials in a fixed order.
-// ref: core/Slave.scala:147-153 restricted to the cold columns.
-template <bool PACKED>
-__global__ void __launch_bounds__(1024) dsgd_cgrad_kernel(ColdView cv, const long long* __restrict__ crow_ptr,
-                                                         const signed char* __restrict__ coef8,
-                                                         long long* __restrict__ g64_base, long long g_stride,
-                                                         DevScalars* __restrict__ sc,
-                                                         const StreamSeg* __restrict__ segs, int hsplit, int nc_lds,
-                                                         float fix_scale, int* __restrict__ partc, int partc_stride,
-                                                         int wide) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int* gc = reinterpret_cast<int*>(lds);   // nc_lds accumulators + 64 always-zero words
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  wg_zero(gc, nc_lds + 64, tid, 1024);
-  __syncthreads();
-  const StreamSeg seg = segs[blockIdx.y];
-  long long* g64 = g64_base + (long long)blockIdx.y * g_stride;
-  const long long e_lo = crow_ptr[seg.row_begin], e_hi = crow_ptr[seg.row_end];
-  const long long chunks = (e_hi - e_lo + 63) / 64;
-  const long long n_waves = (long long)gridDim.x * 16, me = (long long)blockIdx.x * 16 + wave;
-  const long long s = e_lo + 64 * (chunks * me / n_waves);
-  long long t = e_lo + 64 * (chunks * (me + 1) / n_waves);
-  if (t > e_hi) t = e_hi;
-  for (long long e = s; e < t; e += 64 * CD_UNR) {
-    int c[CD_UNR], r[CD_UNR], q[CD_UNR], old[CD_UNR];
-    float v[CD_UNR];
-#pragma unroll
-    for (int k = 0; k < CD_UNR; ++k) {
-      const long long i = e + 64 * k + lane;
-      const bool in = i < t;
-      const long long ic = in ? i : t - 1;
-      cold_get<PACKED>(cv, ic, c[k], r[k]);
-      const float vl = cv.val[ic];
-      v[k] = in ? vl : 0.0f;   // (a clamped lane re-reads an entry of the range: its q is 0)
-    }
-    signed char cf[CD_UNR];
-#pragma unroll
-    for (int k = 0; k < CD_UNR; ++k) cf[k] = coef8[r[k]];   // all the gate coefficients of the set in flight at once
-#pragma unroll
-    for (int k = 0; k < CD_UNR; ++k)
-      q[k] = __float2int_rn(v[k] * ((float)cf[k] * fix_scale));   // y * x on the fixed-point grid (0: inactive row, padding)
-    if (wide) {   // wave-uniform: columns beyond the LDS tile (very wide models) go to the 64-bit global accumulator
-#pragma unroll
-      for (int k = 0; k < CD_UNR; ++k) {
-        if (c[k] >= nc_lds) {
-          if (q[k] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[hsplit + c[k]]), (unsigned long long)(long long)q[k]);
-          q[k] = 0;
-          c[k] = 0;
-        }
+    if (lane == 0) {
+      if (!any_hot) {
+        hcol[hp] = 0;
+        hval[hp] = 0.0f;
       }
-    }
-#pragma unroll
-    for (int k = 0; k < CD_UNR; ++k) old[k] = atomicAdd(&gc[q[k] != 0 ? c[k] : nc_lds + lane], q[k]);
-#pragma unroll
-    for (int k = 0; k < CD_UNR; ++k) {
-      if (old[k] >= WS_SPILL_AT || old[k] <= -WS_SPILL_AT) {
-        if (old[k] >= WS_PANIC_AT || old[k] <= -WS_PANIC_AT) atomicOr(&sc->err, 2);
-        const int x = atomicExch(&gc[c[k]], 0);
-        if (x != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[hsplit + c[k]]), (unsigned long long)(long long)x);
+      if (!any_cold) {
+        if (COL16) ccol16[cp] = 0;
+        else ccol32[cp] = 0u;
+        cval[cp] = 0.0f;
       }
     }
   }
-  __syncthreads();
-  int* mine = partc + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * partc_stride;
-  wg_copy_out(mine, gc, nc_lds, tid, 1024, is_aligned16(mine));
 }
 
 // evaluation tallies of an explicit list of rows (the few rows too long for the wave tiles)
@@ -1437,133 +1357,324 @@ __global__ void __launch_bounds__(256) dsgd_eval_idx_kernel(CsrView m, const flo
   }
 }
 
-// ======================================================================================================
-// Cold-stream kernels, second generation: EIGHT CONTIGUOUS entries per lane
-// ======================================================================================================
-// The first generation (dsgd_cdot_kernel / dsgd_cgrad_kernel above) gave every lane one entry of a 64-entry chunk:
-// 16 dword loads per array in flight per lane, one DPP segmented scan plus two readlanes per 64 entries (cdot: 70
-// VALU instructions per chunk, 3.2 TB/s) -- VMEM-issue and VALU bound on a 0.3 GB stream.  Here lane l owns the
-// entries [tb + 8l, tb + 8l + 8) of a 512-entry tile (tb a multiple of 8): two 16-byte loads per array, rows that
-// begin and end inside the lane (cold rows hold ~5 entries) are summed sequentially and written straight away, and
-// ONE segmented scan per tile joins the fragments that cross lanes.  Two tiles in flight per wave.
-struct ColdTile8 {
-  unsigned int k[8];
-  float v[8];
-  int r[8];      // unpacked form: rows; packed form: r[0] holds the block base row
+// ---- the cold tile walk ------------------------------------------------------------------------------------
+// Cold tiles: WTile records and 16-bit lane descriptors exactly as the hot stream's (build_wave_tiles on the cold row
+// offsets), at most CT_MAXROWS rows per tile: cold rows hold ~6 entries, a 512-slot tile ~90 rows, and the gradient
+// kernel keeps a tile's gate coefficients as two bytes per lane.
+constexpr int CT_MAXROWS = 128;
+constexpr int CT_STRIP = 256;        // floats per wave: [0, CT_MAXROWS + 2) by local row, [192, 256) per-lane dummy slots
+constexpr int CT_DUMMY = 192;
+
+template <bool COL16>
+struct CRegs {
+  int4 c0, c1;         // COL16: eight 16-bit ids in c0; otherwise eight 32-bit ids
+  float4 v0, v1;
+  unsigned int meta;   // row-start bits of the lane's eight slots
+  int cf0, cf1;        // gradient kernel: gate coefficients of local rows lane + 1 and lane + 65 (0 outside the range)
+  long long pos0;      // wave-uniform from here on
+  int r0, nrows;
 };
-constexpr int COLD_PAD = 1024;   // entries the cold arrays are padded with (whole tiles are read)
 
-template <bool PACKED>
-__device__ __forceinline__ void cold_tile_issue(const ColdView& cv, long long tb, int lane, ColdTile8& T) {
-  const long long i0 = tb + 8 * lane;
-  const uint4 a = *reinterpret_cast<const uint4*>(cv.key + i0), b = *reinterpret_cast<const uint4*>(cv.key + i0 + 4);
-  const float4 x = *reinterpret_cast<const float4*>(cv.val + i0), y = *reinterpret_cast<const float4*>(cv.val + i0 + 4);
-  T.k[0] = a.x; T.k[1] = a.y; T.k[2] = a.z; T.k[3] = a.w; T.k[4] = b.x; T.k[5] = b.y; T.k[6] = b.z; T.k[7] = b.w;
-  T.v[0] = x.x; T.v[1] = x.y; T.v[2] = x.z; T.v[3] = x.w; T.v[4] = y.x; T.v[5] = y.y; T.v[6] = y.z; T.v[7] = y.w;
-  if (PACKED) {
-    T.r[0] = cv.base[i0 >> 8];   // (8 | 256: the lane's entries share one block)
+struct CTabs {
+  const WTile* __restrict__ tiles;
+  const unsigned short* __restrict__ meta;
+  const void* __restrict__ col;
+  const float* __restrict__ val;
+  const signed char* __restrict__ coef8;   // gradient kernel only
+  long long row_begin, row_end;            // the worker's rows (gradient kernel: rows outside contribute nothing)
+  long long t_lo, t_hi;                    // its tiles
+  int rev;                                 // walk the tiles from the last to the first
+};
+
+__device__ __forceinline__ long long c_map(const CTabs& tt, long long t) {   // logical tile -> tile record (clamped)
+  const long long tc = t < tt.t_hi ? t : tt.t_hi - 1;
+  return tt.rev ? tt.t_lo + (tt.t_hi - 1 - tc) : tc;
+}
+
+template <bool COL16, bool GRAD>
+__device__ __forceinline__ void c_issue(const CTabs& tt, long long t, int lane, const WTile& wt, CRegs<COL16>& r) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const bool live = t < tt.t_hi;
+  const long long tc = c_map(tt, t);
+  r.r0 = wt.r0;
+  r.nrows = live ? (int)(short)(wt.info & 0xffff) : -1;
+  r.pos0 = wt.pos0;
+  const unsigned int slots = live ? (unsigned int)wt.info >> 16 : 0u;
+  // raw buffers over exactly the tile's own slots: lanes past the end get zeros without a memory access
+  const int nb = (int)((slots + 3u) & ~3u) * 4;
+  if (COL16) {
+    const unsigned short* col16 = reinterpret_cast<const unsigned short*>(tt.col);
+    const int nb16 = (int)((slots + 7u) & ~7u) * 2;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(col16 + wt.pos0), 0, nb16, 0x00020000);
+    const i32x4 a = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0));
+    r.c0 = make_int4(a.x, a.y, a.z, a.w);
   } else {
-    const int4 p = *reinterpret_cast<const int4*>(cv.row + i0), q = *reinterpret_cast<const int4*>(cv.row + i0 + 4);
-    T.r[0] = p.x; T.r[1] = p.y; T.r[2] = p.z; T.r[3] = p.w; T.r[4] = q.x; T.r[5] = q.y; T.r[6] = q.z; T.r[7] = q.w;
+    const int* col32 = reinterpret_cast<const int*>(tt.col);
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(col32 + wt.pos0), 0, nb, 0x00020000);
+    const i32x4 a = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane, 0, 0));
+    const i32x4 b = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane + 16, 0, 0));
+    r.c0 = make_int4(a.x, a.y, a.z, a.w);
+    r.c1 = make_int4(b.x, b.y, b.z, b.w);
   }
-}
-// columns and rows of the lane's entries; entries outside [s, t) become (col 0, value 0, row -1)
-template <bool PACKED>
-__device__ __forceinline__ void cold_tile_decode(ColdTile8& T, long long tb, int lane, long long s, long long t, int (&col)[8]) {
-  const long long i0 = tb + 8 * lane;
-  const int base = T.r[0];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const bool in = i0 + k >= s && i0 + k < t;
-    const int rr = PACKED ? base + (int)(T.k[k] >> 16) : T.r[k];
-    col[k] = in ? (int)(PACKED ? T.k[k] & 0xffffu : T.k[k]) : 0;
-    T.r[k] = in ? rr : -1;
-    T.v[k] = in ? T.v[k] : 0.0f;
+  {
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tt.val + wt.pos0), 0, nb, 0x00020000);
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane, 0, 0));
+    const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane + 16, 0, 0));
+    r.v0 = make_float4(a.x, a.y, a.z, a.w);
+    r.v1 = make_float4(b.x, b.y, b.z, b.w);
+  }
+  r.meta = (tt.meta + tc * 64)[(unsigned int)lane];
+  if (GRAD) {
+    // gate coefficients of the tile's rows, one byte per row (written by the main kernel): local row l + 1 is global
+    // row r0 + l.  The window is clamped to the worker's rows -- whatever coef8 holds outside them is stale --
+    // and lanes outside the window read 0 (an offset below the window wraps to a huge unsigned one).
+    const long long lo = tt.row_begin > (long long)wt.r0 ? tt.row_begin : (long long)wt.r0;
+    long long hi = (long long)wt.r0 + (r.nrows > 0 ? r.nrows : 0);
+    if (hi > tt.row_end) hi = tt.row_end;
+    const int n = hi > lo ? (int)(hi - lo) : 0;
+    const int shift = (int)(lo - (long long)wt.r0);   // 0 .. nrows
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<signed char*>(tt.coef8 + lo), 0, n, 0x00020000);
+    r.cf0 = (int)(signed char)__builtin_amdgcn_raw_buffer_load_b8(rs, lane - shift, 0, 0);
+    r.cf1 = (int)(signed char)__builtin_amdgcn_raw_buffer_load_b8(rs, lane + 64 - shift, 0, 0);
   }
 }
 
-// dcold[row] = sum over the cold entries of the row of filt(value * w[hsplit + col]); same contract as
-// dsgd_cdot_kernel (row-aligned pieces per wave: no atomics, fixed order).  ref: math/Sparse.scala:46.
-template <bool PACKED>
-__global__ void __launch_bounds__(1024) dsgd_cdot8_kernel(ColdView cv, const long long* __restrict__ crow_ptr,
-                                                         const float* __restrict__ w, float* __restrict__ dcold,
-                                                         const StreamSeg* __restrict__ segs, int hsplit, int nc_lds,
-                                                         int wide) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  typedef __attribute__((address_space(3))) const float lds_cfloat;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  wg_copy_in(lds, w + hsplit, nc_lds, tid, 1024, is_aligned16(w + hsplit));
-  __syncthreads();
-  const StreamSeg seg = segs[blockIdx.y];
-  const long long e_lo = crow_ptr[seg.row_begin], e_hi = crow_ptr[seg.row_end];
-  const long long n = e_hi - e_lo;
-  const long long n_waves = (long long)gridDim.x * 16, me = (long long)blockIdx.x * 16 + wave;
-  const long long chunks = (n + 63) / 64;
-  const long long b0 = e_lo + 64 * (chunks * me / n_waves), b1 = e_lo + 64 * (chunks * (me + 1) / n_waves);
-  const long long s = cold_row_start<PACKED>(cv, b0, e_lo, e_hi, lane);
-  const long long t = me + 1 == n_waves ? e_hi : cold_row_start<PACKED>(cv, b1 < e_hi ? b1 : e_hi, e_lo, e_hi, lane);
-  if (s >= t) return;
-  lds_cfloat* wc = (lds_cfloat*)lds;
-  float carry_sum = 0.0f;
-  int carry_row = -1;
-  auto process = [&](ColdTile8& T, long long tb) {
-    int col[8];
-    cold_tile_decode<PACKED>(T, tb, lane, s, t, col);
-    float p[8];
+// byte offsets 4 * id of a lane's eight entries (the LDS tile sits at LDS address 0)
+template <bool COL16>
+__device__ __forceinline__ void c_offsets(const CRegs<COL16>& r, int (&cc)[8]) {
+  if (COL16) {
+    const unsigned int cw[4] = {(unsigned int)r.c0.x, (unsigned int)r.c0.y, (unsigned int)r.c0.z, (unsigned int)r.c0.w};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = wc[min(col[k], nc_lds - 1)];
-    if (wide) {   // wave-uniform: cold columns beyond the LDS tile exist (very wide models only)
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (col[k] >= nc_lds) p[k] = w[hsplit + col[k]];
+    for (int k = 0; k < 4; ++k) {
+      unsigned int lo4;
+      asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+          : "=v"(lo4)
+          : "v"(2u), "v"(cw[k]));
+      cc[2 * k] = (int)lo4;
+      cc[2 * k + 1] = (int)((cw[k] >> 14) & 0x3fffcu);
     }
+  } else {
+    const int c[8] = {r.c0.x, r.c0.y, r.c0.z, r.c0.w, r.c1.x, r.c1.y, r.c1.z, r.c1.w};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = filt(T.v[k] * p[k]);
-    // the row of the element before this lane: the previous lane's last row, or the row carried in from the last tile
-    int rprev = __builtin_amdgcn_update_dpp(0, T.r[7], 0x138, 0xf, 0xf, false);   // wave_shr:1
-    if (lane == 0) rprev = carry_row;
-    const bool b_first = T.r[0] != rprev;
-    if (lane == 0 && !b_first) p[0] += carry_sum;   // the carried row continues: its running sum joins this lane's
-    // sequential pass: `head` closes the row entering the lane, rows inside the lane are complete, `run` stays open
-    float run = 0.0f, head = 0.0f;
-    bool seen = false;
+    for (int k = 0; k < 8; ++k) cc[k] = c[k] << 2;
+  }
+}
+
+// local row closed by the lane's first row start = row starts in the lanes below (rows are 1-based; row 0 is the
+// padding in front of the tile's first row): inclusive DPP scan of the popcounts minus the lane's own
+__device__ __forceinline__ int c_rows_below(unsigned int bits) {
+  const int pc = __popc(bits);
+  int v = pc;
+  v += dpp_get_i<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_get_i<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_get_i<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_get_i<0x118, 0xf>(v);   // row_shr:8
+  v += dpp_get_i<0x142, 0xa>(v);   // row_bcast:15 -> rows 1 and 3
+  v += dpp_get_i<0x143, 0xc>(v);   // row_bcast:31 -> rows 2 and 3
+  return v - pc;
+}
+
+// dcold[row] = sum over the cold entries of the row of filt(value * w[hsplit + col]): eight LDS reads, a sequential
+// pass over the lane's slots (rows that begin and end inside the lane are complete there), ONE segmented scan for the
+// fragments that cross lanes, the sums of the tile's rows meet in the wave's LDS strip and leave as coalesced stores.
+// Every row of a tile is written, fixed order, no atomics.  ref: math/Vec.scala:58, math/Sparse.scala:46.
+template <bool COL16, bool WIDE>
+__device__ __forceinline__ void cd_tile(const CRegs<COL16>& cur, float* strip, float* __restrict__ dcold,
+                                        const float* __restrict__ wcold, int nc_lds) {
+  typedef __attribute__((address_space(3))) const float lds_cfloat;
+  const int lane = threadIdx.x & 63;
+  const int nrows = cur.nrows;                                  // wave-uniform; -1: padding tile
+  const unsigned int bits = nrows < 0 ? 0u : (cur.meta & 255u);
+  const int re_n = c_rows_below(bits);
+  int cc[8];
+  c_offsets<COL16>(cur, cc);
+  const float vv[8] = {cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w};
+  float a[8], pk[8];
+  if (!WIDE) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = *(lds_cfloat*)(unsigned int)cc[k];
+  } else {   // cold columns beyond the LDS tile exist (very wide models only; a kernel of its own: a conditional load
+             // in the tile loop costs every tile its counted waits)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const bool bnd = k == 0 ? b_first : T.r[k] != T.r[k - 1];
-      if (bnd) {
-        if (!seen) {
-          head = run;
-          seen = true;
-        } else if (T.r[k - (k > 0)] >= 0) {
-          dcold[T.r[k - (k > 0)]] = run;   // (k > 0 here: a second boundary cannot sit at slot 0)
-        }
-        run = 0.0f;
-      }
-      run += p[k];
+      const int lim = (nc_lds - 1) << 2;
+      a[k] = *(lds_cfloat*)(unsigned int)(cc[k] < lim ? cc[k] : lim);
+      if ((cc[k] >> 2) >= nc_lds) a[k] = wcold[cc[k] >> 2];
     }
-    float S = run;
-    int f = seen ? 1 : 0;
-    wave_seg_scan(S, f);
-    float incoming = dpp_get_f<0x138, 0xf>(S);   // wave_shr:1: running sum of the row entering this lane
-    if (lane == 0) incoming = b_first ? carry_sum : 0.0f;
-    const int rclose = b_first ? rprev : T.r[0];   // the row the lane's FIRST boundary closes
-    if (seen && rclose >= 0) dcold[rclose] = incoming + head;
-    carry_sum = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S), 63));
-    carry_row = __builtin_amdgcn_readlane(T.r[7], 63);
-  };
-  long long tb = s & ~7LL;
-  ColdTile8 A, B;
-  cold_tile_issue<PACKED>(cv, tb, lane, A);
-  for (;;) {
-    if (tb + 512 < t) cold_tile_issue<PACKED>(cv, tb + 512, lane, B);
-    process(A, tb);
-    tb += 512;
-    if (tb >= t) break;
-    if (tb + 512 < t) cold_tile_issue<PACKED>(cv, tb + 512, lane, A);
-    process(B, tb);
-    tb += 512;
-    if (tb >= t) break;
   }
-  if (lane == 0 && carry_row >= 0) dcold[carry_row] = carry_sum;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pk[k] = filt(vv[k] * a[k]);
+  float run = 0.0f, head = 0.0f;
+  bool seen = false;
+  int r = re_n;                                                 // the row the lane's next start closes
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const bool st = (bits >> k) & 1u;
+    // a start that is not the lane's first closes a row that began in this lane: complete (per-lane dummy slot otherwise)
+    strip[(st && seen) ? r : CT_DUMMY + lane] = run;
+    head = (st && !seen) ? run : head;
+    r += st ? 1 : 0;
+    seen = seen || st;
+    run = st ? 0.0f : run;
+    run += pk[k];
+  }
+  float S = run;
+  int f = bits != 0u;
+  wave_seg_scan(S, f);
+  const float incoming = dpp_get_f<0x138, 0xf>(S);              // wave_shr:1 (lane 0 reads 0)
+  strip[bits != 0u ? re_n : CT_DUMMY + lane] = incoming + head;   // the row entering the lane ends at its first start
+  __builtin_amdgcn_wave_barrier();                              // same wave writes and reads: LDS keeps a wave's order
+  if (nrows > 0) {
+    // A buffer over exactly the tile's rows: lanes past the last row are dropped by the bounds check.  The
+    // wave-uniform branch is deliberate: with a straight-line tile body the compiler sinks the NEXT tiles' stream
+    // requests (issued in front of this function) down the chain of exit checks to the iteration that consumes them
+    // -- a block with two predecessors stops that.
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(dcold + cur.r0, 0, 4 * nrows, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(strip[lane + 1]), rs, 4 * lane, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(strip[lane + 65]), rs, 4 * lane + 256, 0, 0);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// cold gradient columns: q = round(value * coef[row] * scale) accumulated in the LDS tile of 32-bit integers at the
+// cold scale (shift 21) with returning atomics: whoever SEES |old| >= 2^28 moves the word into the 64-bit global
+// accumulator, |old| >= 2^30 raises DevScalars::err.  ref: core/Slave.scala:147-153 restricted to the
+// cold columns.
+template <bool COL16, bool WIDE>
+__device__ __forceinline__ void cg_tile(const CRegs<COL16>& cur, float* strip, int* gc, long long* __restrict__ g64cold,
+                                        DevScalars* __restrict__ sc, float fix_scale, int nc_lds) {
+  const int lane = threadIdx.x & 63;
+  const int nrows = cur.nrows;
+  const unsigned int bits = nrows < 0 ? 0u : (cur.meta & 255u);
+  const int re_n = c_rows_below(bits);
+  // coefficients of the tile's rows by local row (0 for padding row 0, for the row behind the last and outside the range)
+  strip[lane + 1] = (float)cur.cf0 * fix_scale;
+  strip[lane + 65] = (float)cur.cf1 * fix_scale;
+  if (lane == 0) strip[0] = 0.0f;
+  if (lane == 1) strip[CT_MAXROWS + 1] = 0.0f;
+  __builtin_amdgcn_wave_barrier();
+  int cc[8];
+  c_offsets<COL16>(cur, cc);
+  const float vv[8] = {cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w};
+  float coef[8];
+  int r = re_n;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    r += (bits >> k) & 1u;                 // a start at slot k opens the next row
+    coef[k] = strip[r <= CT_MAXROWS + 1 ? r : CT_MAXROWS + 1];
+  }
+  int q[8], old[8];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    // |v * coef| <= 2^21: v * coef + 1.5 * 2^23 rounds once (to nearest even) to an fp32 whose low mantissa bits are q
+    const f32x2 rr = __builtin_elementwise_fma(f32x2{vv[k], vv[k + 1]}, f32x2{coef[k], coef[k + 1]},
+                                               f32x2{12582912.0f, 12582912.0f});
+    q[k] = __float_as_int(rr.x) - 0x4B400000;
+    q[k + 1] = __float_as_int(rr.y) - 0x4B400000;
+  }
+  if (WIDE) {   // columns beyond the LDS tile go to the 64-bit global accumulator
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if ((cc[k] >> 2) >= nc_lds) {
+        if (q[k] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64cold[cc[k] >> 2]), (unsigned long long)(long long)q[k]);
+        q[k] = 0;
+      }
+    }
+  }
+  char* gcb = reinterpret_cast<char*>(gc);
+  const int dummy = (nc_lds + lane) << 2;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) old[k] = atomicAdd(reinterpret_cast<int*>(gcb + (q[k] != 0 ? cc[k] : dummy)), q[k]);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (old[k] >= WS_SPILL_AT || old[k] <= -WS_SPILL_AT) {
+      if (old[k] >= WS_PANIC_AT || old[k] <= -WS_PANIC_AT) atomicOr(&sc->err, 2);
+      const int x = atomicExch(reinterpret_cast<int*>(gcb + cc[k]), 0);
+      if (x != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64cold[cc[k] >> 2]), (unsigned long long)(long long)x);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// GRAD = false: dsgd_cdot_kernel  (LDS: nc_lds cold weights at address 0, 16 strips)
+// GRAD = true:  dsgd_cgrad_kernel (LDS: nc_lds + 64 gradient words at address 0, 16 strips; partials out)
+template <bool COL16, bool GRAD, bool WIDE>
+__global__ void __launch_bounds__(1024) dsgd_cold_kernel(const WTile* __restrict__ tiles,
+                                                        const unsigned short* __restrict__ meta,
+                                                        const void* __restrict__ col, const float* __restrict__ val,
+                                                        const StreamSeg* __restrict__ segs, const float* __restrict__ w,
+                                                        float* __restrict__ dcold, const signed char* __restrict__ coef8,
+                                                        long long* __restrict__ g64_base, long long g_stride,
+                                                        DevScalars* __restrict__ sc, int hsplit, int nc_lds,
+                                                        float fix_scale, int* __restrict__ partc, int partc_stride,
+                                                        int rev) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_tile = GRAD ? nc_lds + 64 : nc_lds;
+  float* strip = lds + ((n_tile + 3) & ~3) + wave * CT_STRIP;
+  if ((unsigned int)(unsigned long long)(__attribute__((address_space(3))) float*)lds != 0u) {
+    if (tid == 0) atomicOr(&sc->err, 2);   // (ids become LDS addresses without a base: all LDS of this kernel is dynamic)
+    return;
+  }
+  if (GRAD) wg_zero(reinterpret_cast<int*>(lds), n_tile, tid, 1024);
+  else wg_copy_in(lds, w + hsplit, nc_lds, tid, 1024, is_aligned16(w + hsplit));
+  __syncthreads();
+  const StreamSeg seg = segs[blockIdx.y];
+  CTabs tt;
+  tt.tiles = tiles;
+  tt.meta = meta;
+  tt.col = col;
+  tt.val = val;
+  tt.coef8 = coef8;
+  tt.row_begin = seg.row_begin;
+  tt.row_end = seg.row_end;
+  tt.t_lo = seg.ctile_begin;
+  tt.t_hi = seg.ctile_end;
+  tt.rev = rev;
+  long long* g64cold = GRAD ? g64_base + (long long)blockIdx.y * g_stride + hsplit : nullptr;
+  const long long stride = (long long)gridDim.x * 16;
+  long long tile = tt.t_lo + (long long)blockIdx.x * 16 + wave;
+  if (tile < tt.t_hi) {
+    CRegs<COL16> A, B, C, D;
+    WTile wt = tiles[c_map(tt, tile)];
+    // (scheduling barriers: the requests of a tile stay together and in tile order -- vmcnt retires in order, and the
+    //  loop's first wait is the merge of this path and the back edge)
+    c_issue<COL16, GRAD>(tt, tile, lane, wt, A);
+    __builtin_amdgcn_sched_barrier(0);
+    wt = tiles[c_map(tt, tile + stride)];
+    c_issue<COL16, GRAD>(tt, tile + stride, lane, wt, B);
+    __builtin_amdgcn_sched_barrier(0);
+    wt = tiles[c_map(tt, tile + 2 * stride)];
+    c_issue<COL16, GRAD>(tt, tile + 2 * stride, lane, wt, C);
+    __builtin_amdgcn_sched_barrier(0);
+    wt = tiles[c_map(tt, tile + 3 * stride)];
+#define DSGD_CT(CUR, FAR)                                                                          \
+  {                                                                                                \
+    const WTile wt_now = wt;                                                                       \
+    wt = tiles[c_map(tt, tile + 4 * stride)];                                                      \
+    c_issue<COL16, GRAD>(tt, tile + 3 * stride, lane, wt_now, FAR);                                \
+    if (GRAD) cg_tile<COL16, WIDE>(CUR, strip, reinterpret_cast<int*>(lds), g64cold, sc, fix_scale, nc_lds); \
+    else cd_tile<COL16, WIDE>(CUR, strip, dcold, w + hsplit, nc_lds);                              \
+  }
+    for (;;) {
+      DSGD_CT(A, D); tile += stride; if (tile >= tt.t_hi) break;
+      DSGD_CT(B, A); tile += stride; if (tile >= tt.t_hi) break;
+      DSGD_CT(C, B); tile += stride; if (tile >= tt.t_hi) break;
+      DSGD_CT(D, C); tile += stride; if (tile >= tt.t_hi) break;
+    }
+#undef DSGD_CT
+  }
+  if (GRAD) {
+    __syncthreads();
+    int* mine = partc + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * partc_stride;
+    wg_copy_out(mine, reinterpret_cast<int*>(lds), nc_lds, tid, 1024, is_aligned16(mine));
+  }
 }
