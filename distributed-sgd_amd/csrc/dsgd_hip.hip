@@ -175,8 +175,6 @@ struct dsgd_ctx {
   void* d_ccol = nullptr;               // cold stream in row order: rank - hsplit (16-bit words, or 32-bit when there
   float* d_cval = nullptr;              // are more than 65536 cold columns), value; WS_PAD elements of padding
   bool cold_col16 = false;
-  bool hot_nt = false;                  // DSGD_HOT_NT=1: non-temporal hint on the hot stream's loads (A/B)
-  int cold_rev = 1;                     // DSGD_COLD_REV=0: the dot kernel walks its tiles first to last (A/B)
   long long* d_ctp = nullptr;           // n_rows + 1: slot offsets of the cold stream (a tiled row owns >= 1 slot)
   long long coldm_nnz = 0;              // slots of the cold stream
   WTile* d_ctiles = nullptr;            // wave tiles over d_ccol/d_cval (same records and lane descriptors as the hot ones)
@@ -933,20 +931,18 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   if (cold) {
     size_t slot_c = 0;
     DSGD_TRY(prof_begin(c, &slot_c, 1));
-    // (the dot kernel walks the tiles from the last to the first: it runs right behind the gradient kernel of the
-    //  previous step, whose last tiles are the ones still on the die)
-#define DSGD_COLD_LAUNCH(C16, GR, WD, LDS, REV)                                                                          \
+#define DSGD_COLD_LAUNCH(C16, GR, WD, LDS)                                                                               \
   hipLaunchKernelGGL((dsgd_cold_kernel<C16, GR, WD>), gridc, dim3(1024), LDS, c->stream, c->d_ctiles, c->d_cmeta,      \
                      c->d_ccol, c->d_cval, c->d_ssegs, c->d_w, c->d_dcold, c->d_coef8, c->d_g64, (long long)c->dp, c->d_sc, \
-                     H, nc_lds, c->fix_scale, c->d_partc, c->partc_stride, REV)
-#define DSGD_COLD_DISPATCH(GR, LDS, REV)                                       \
-  do {                                                                         \
-    if (c->cold_col16 && !wide) DSGD_COLD_LAUNCH(true, GR, false, LDS, REV);   \
-    else if (c->cold_col16) DSGD_COLD_LAUNCH(true, GR, true, LDS, REV);        \
-    else if (!wide) DSGD_COLD_LAUNCH(false, GR, false, LDS, REV);              \
-    else DSGD_COLD_LAUNCH(false, GR, true, LDS, REV);                          \
+                     H, nc_lds, c->fix_scale, c->d_partc, c->partc_stride)
+#define DSGD_COLD_DISPATCH(GR, LDS)                                       \
+  do {                                                                    \
+    if (c->cold_col16 && !wide) DSGD_COLD_LAUNCH(true, GR, false, LDS);   \
+    else if (c->cold_col16) DSGD_COLD_LAUNCH(true, GR, true, LDS);        \
+    else if (!wide) DSGD_COLD_LAUNCH(false, GR, false, LDS);              \
+    else DSGD_COLD_LAUNCH(false, GR, true, LDS);                          \
   } while (0)
-    DSGD_COLD_DISPATCH(false, lds_cdot, c->cold_rev);
+    DSGD_COLD_DISPATCH(false, lds_cdot);
     HIP_TRY(hipGetLastError());
     DSGD_TRY(prof_end(c, slot_c));
   }
@@ -1015,12 +1011,7 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   CsrView mf = view(c);
   size_t slot = 0;
   if (SCATTER) DSGD_TRY(prof_begin(c, &slot));
-  if (c->hot_nt)
-    hipLaunchKernelGGL((dsgd_wseg_kernel<SCATTER, true>), grid, dim3(1024), lds, c->stream, mh, mf, c->d_wtiles, c->d_wmeta, c->d_w,
-                     c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, main_scale, c->d_coef8, c->d_wlong_rows,
-                     SCATTER ? c->d_part : nullptr, c->part_stride, c->d_dcold, c->fix_scale);
-  else
-    hipLaunchKernelGGL((dsgd_wseg_kernel<SCATTER, false>), grid, dim3(1024), lds, c->stream, mh, mf, c->d_wtiles, c->d_wmeta, c->d_w,
+  hipLaunchKernelGGL(dsgd_wseg_kernel<SCATTER>, grid, dim3(1024), lds, c->stream, mh, mf, c->d_wtiles, c->d_wmeta, c->d_w,
                      c->d_g64, (long long)c->dp, c->d_ssegs, c->d_sc, hw, hg, main_scale, c->d_coef8, c->d_wlong_rows,
                      SCATTER ? c->d_part : nullptr, c->part_stride, c->d_dcold, c->fix_scale);
   HIP_TRY(hipGetLastError());
@@ -1030,7 +1021,7 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   if (cold) {
     size_t slot_g = 0;
     DSGD_TRY(prof_begin(c, &slot_g, 2));
-    DSGD_COLD_DISPATCH(true, lds_cgrad, 0);
+    DSGD_COLD_DISPATCH(true, lds_cgrad);
     HIP_TRY(hipGetLastError());
     DSGD_TRY(prof_end(c, slot_g));
   }
@@ -1179,8 +1170,6 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_FIX_SHIFT")) c->max_shift = std::max(8, std::min(FIX_SHIFT, atoi(e)));   // cap of the fixed-point shift
   if (const char* e = getenv("DSGD_FIX_BOUND")) c->fix_bound = atoi(e) != 0;      // 0: data-independent bound only
   if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;  // 0: small batches through the multi-workgroup kernel
-  if (const char* e = getenv("DSGD_HOT_NT")) c->hot_nt = atoi(e) != 0;
-  if (const char* e = getenv("DSGD_COLD_REV")) c->cold_rev = atoi(e) != 0;        // 0: cold dot kernel first tile to last
   if (const char* e = getenv("DSGD_HSPLIT")) c->hsplit = atoi(e);                 // hot/cold split rank (tests: wide models)
   if (getenv("DSGD_PLAN_PROF") && atoi(getenv("DSGD_PLAN_PROF"))) {
     HIP_TRY_B(hipMalloc(&c->d_tprof, sizeof(unsigned long long) * 16));
@@ -1198,10 +1187,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_hogwild_kernel);
   DSGD_ATTR(dsgd_mb_grad_kernel);
   DSGD_ATTR(dsgd_plan_kernel);
-  DSGD_ATTR((dsgd_wseg_kernel<true, false>));
-  DSGD_ATTR((dsgd_wseg_kernel<false, false>));
-  DSGD_ATTR((dsgd_wseg_kernel<true, true>));
-  DSGD_ATTR((dsgd_wseg_kernel<false, true>));
+  DSGD_ATTR(dsgd_wseg_kernel<true>);
+  DSGD_ATTR(dsgd_wseg_kernel<false>);
   DSGD_ATTR(dsgd_wseg_bound_kernel);
   DSGD_ATTR((dsgd_cold_kernel<true, false, false>));
   DSGD_ATTR((dsgd_cold_kernel<true, false, true>));

@@ -720,10 +720,10 @@ struct WTables {
 struct WRegs {
   int4 c0;             // eight 16-bit column ranks
   float4 v0, v1;
-  float dc;            // cold part of x.w of the row that ends in this lane
-  int rf;              // local row of the lane's first slot (wave prefix sum over the row-start bits)
+  float dcv;           // cold part of x.w of the tile's local row lane + 1 (0 beyond the tile's rows)
   unsigned int meta;
-  long long pos0, tc;  // wave-uniform (scalar registers): window start, clamped tile index
+  long long pos0;      // wave-uniform (scalar registers): window start
+  int tc;              // ... clamped tile index
   int r0, nrows, nb;   // wave-uniform: first row, rows, bytes of the window that belong to the tile
 };
 
@@ -731,13 +731,15 @@ struct WRegs {
 // result feeds the address computation would otherwise expose its latency once per tile
 // (a scalar s_load -- counted by lgkmcnt, not queued behind the stream loads in vmcnt -- as long as the kernel
 // passes the table as a __restrict__ parameter of its own)
-__device__ __forceinline__ WTile w_fetch(const WTables& tt, long long t, long long t_end) {
+// (tile indices are 32-bit: a 64-bit `t < t_end` is a VALU compare whose operands the register allocator parks in
+//  whatever vector registers are dead -- e.g. half of a register set with a stream load still in flight, and the
+//  write-after-write hazard made the loop head wait for EVERY outstanding load (s_waitcnt vmcnt(0)) once per round)
+__device__ __forceinline__ WTile w_fetch(const WTables& tt, int t, int t_end) {
   return tt.tiles[t < t_end ? t : t_end - 1];
 }
 
 // the stream of a tile: eight 16-bit column ranks (one 16-byte load), eight values (two), the lane descriptor
-template <bool NT>
-__device__ __forceinline__ void w_issue_cols(const CsrView& m, long long t, long long t_end, int lane, const WTile& wt,
+__device__ __forceinline__ void w_issue_cols(const CsrView& m, int t, int t_end, int lane, const WTile& wt,
                                              WRegs& r) {
   const bool live = t < t_end;
   r.tc = live ? t : t_end - 1;     // wave-uniform
@@ -758,23 +760,32 @@ __device__ __forceinline__ void w_issue_cols(const CsrView& m, long long t, long
   const int nb16 = (int)(((unsigned int)wt.info >> 16) + 7u & ~7u) * 2;
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(col16 + wt.pos0), 0, nb16, 0x00020000);
-  const i32x4 a = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, NT ? 2 : 0));
+  const i32x4 a = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0));
   r.c0 = make_int4(a.x, a.y, a.z, a.w);
 }
-template <bool NT>
-__device__ __forceinline__ void w_issue_vals(const CsrView& m, const WTables& tt, int lane, WRegs& r) {
+__device__ __forceinline__ void w_issue_vals(const CsrView& m, const WTables& tt, const float* __restrict__ dcold, int lane,
+                                             WRegs& r) {
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m.val + r.pos0), 0, r.nb, 0x00020000);
   // (whole-vector bit casts: an element-wise __builtin_bit_cast(float, a.x) of the returned vector is folded to
   //  component 0 for all four elements by this compiler)
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane, 0, NT ? 2 : 0));
-  const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane + 16, 0, NT ? 2 : 0));
+  const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane, 0, 0));
+  const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane + 16, 0, 0));
   r.v0 = make_float4(a.x, a.y, a.z, a.w);
   r.v1 = make_float4(b.x, b.y, b.z, b.w);
   // lane descriptor, 16 bits (row-start bits | label signs << 8); the local row of the lane's first slot is a wave
-  // prefix sum over the start bits (w_load_dc) instead of a stored field
-  r.meta = (tt.meta + r.tc * 64)[(unsigned int)lane];
+  // prefix sum over the start bits (w_rows_below) instead of a stored field
+  r.meta = (tt.meta + (long long)r.tc * 64)[(unsigned int)lane];
+  // The cold part of x.w of the tile's rows, by local row: ONE coalesced load whose address needs the tile record
+  // only.  Before round 3 every lane fetched dcold[row ending in this lane] one tile ahead -- an address that needs the
+  // lane descriptors, i.e. a load that depends on a load: issued behind the stream requests of the two tiles after it,
+  // and vmcnt retires in order, so waiting for it also waited for those (one tile in flight during the arithmetic
+  // instead of three).  Tiles of more than 64 rows (rows shorter than 8 non-zeros) fetch the rest when they are
+  // processed (w_tile).
+  const __amdgpu_buffer_rsrc_t rd =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dcold + r.r0), 0, r.nrows > 0 ? 4 * r.nrows : 0, 0x00020000);
+  r.dcv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, 4 * lane, 0, 0));
 }
 
 struct WCtx {
@@ -785,20 +796,16 @@ struct WCtx {
   long long* g64;
   DevScalars* sc;
   const float* dcold;   // per-row cold part of x.w, written by the cold-stream kernel
-  long long row_begin, row_end;
+  int row_begin, row_end;   // (rows are 32-bit throughout the tile records)
   int hw, hg;
   float fix_scale;    // fixed-point scale of the LDS gradient tile (chosen per launch)
   float cold_scale;   // scale of the cold columns' 64-bit accumulators (2^FIX_SHIFT / vmax2)
 };
 
-// cold part of x.w of the row that ends in this lane (the lane's first row start closes it); lanes
-// without a row end read row r0 and ignore the value
-__device__ __forceinline__ void w_load_dc(const WCtx& x, WRegs& r) {
-  const unsigned int dn = r.nrows < 0 ? 0u : r.meta;
-  const unsigned int bn = dn & 255u;
-  // row starts in the lanes below this one = the local row that ENDS at this lane's first start (rows are 1-based,
-  // the end mark of the tile's last row counts as a start): inclusive DPP scan of the popcounts minus the lane's own
-  const int pc = __popc(bn);
+// row starts in the lanes below this one = the local row that ENDS at this lane's first start (rows are 1-based, the
+// end mark of the tile's last row counts as a start): inclusive DPP scan of the popcounts minus the lane's own
+__device__ __forceinline__ int w_rows_below(unsigned int bits) {
+  const int pc = __popc(bits);
   int v = pc;
   v += dpp_get_i<0x111, 0xf>(v);   // row_shr:1
   v += dpp_get_i<0x112, 0xf>(v);   // row_shr:2
@@ -806,10 +813,7 @@ __device__ __forceinline__ void w_load_dc(const WCtx& x, WRegs& r) {
   v += dpp_get_i<0x118, 0xf>(v);   // row_shr:8
   v += dpp_get_i<0x142, 0xa>(v);   // row_bcast:15 -> rows 1 and 3
   v += dpp_get_i<0x143, 0xc>(v);   // row_bcast:31 -> rows 2 and 3
-  const int re_n = v - pc;
-  r.rf = re_n + (int)(bn & 1u);    // a start at slot 0 makes the lane's first slot the NEW row
-  const bool ok = bn != 0u && re_n >= 1 && re_n <= r.nrows;
-  r.dc = (x.dcold + __builtin_amdgcn_readfirstlane(r.r0))[ok ? (unsigned int)(re_n - 1) : 0u];
+  return v - pc;
 }
 
 
@@ -825,28 +829,35 @@ __device__ __forceinline__ void w_scatter(const WCtx& x, const int (&cc)[8], con
     if (q[k] != 0) atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(x.gl) + cc[k]), q[k]);
 }
 
-// One tile of one wave.  `cur` = tile t (everything landed), `nxt` = tile t+1 (descriptor landed: the cold part of
-// its rows' x.w is requested now), `far` = the register set that receives tile t+3.  The stream loads are issued
-// FIRST so that they are already on their way while the wave works on tile t.  The tiles hold the HOT part of the
-// matrix only (every column rank < hw = hg), the cold part of each row's x.w comes from x.dcold -- no gathers, no
-// clamps, no cold checks.
-template <bool SCATTER, bool NT>
-__device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, const WCtx& x, long long tile,
-                                       long long stride, long long t_end, WRegs& cur, WRegs& nxt, WRegs& far,
+// One tile of one wave.  `cur` = tile t (everything landed), `far` = the register set that receives tile t+3.  The
+// requests of a tile -- column ranks, values, lane descriptors, the cold parts of its rows' x.w -- need the tile record
+// only and are issued FIRST, so that three tiles are on their way while the wave works on tile t.  The tiles hold the
+// HOT part of the matrix only (every column rank < hw = hg): no gathers, no clamps, no cold checks.
+template <bool SCATTER>
+__device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, const WCtx& x, int tile,
+                                       int stride, int t_end, WRegs& cur, WRegs& far,
                                        WTile& wt_far, unsigned int& n_all, unsigned int& n_neg, unsigned int& n_pos) {
   const int lane = threadIdx.x & 63;
   // the record load goes out BEFORE this iteration's stream loads: vmcnt retires in order, so next iteration's
   // wait for it does not drain the stream loads issued behind it
   const WTile wt_now = wt_far;                                              // record fetched last iteration
   wt_far = w_fetch(tt, tile + 4 * stride, t_end);                           // record used next iteration
-  w_issue_cols<NT>(m, tile + 3 * stride, t_end, lane, wt_now, far);
-  w_issue_vals<NT>(m, tt, lane, far);   // (values with the column ids: the window descriptor stays in scalar registers)
-  w_load_dc(x, nxt);                // tile t+1 (descriptor landed)
+  w_issue_cols(m, tile + 3 * stride, t_end, lane, wt_now, far);
+  w_issue_vals(m, tt, x.dcold, lane, far);   // (values with the column ids: the window descriptor stays in scalar registers)
 
   const int nrows = cur.nrows;                          // wave-uniform; -1: the whole tile is padding
   const unsigned int desc = nrows < 0 ? 0u : cur.meta;
-  const int rf = cur.rf;
   const unsigned int bits = desc & 255u;
+  const int re_n = w_rows_below(bits);          // local row that ends at the lane's first start
+  const int rf = re_n + (int)(bits & 1u);       // local row of the lane's first slot (a start at slot 0 opens the NEW row)
+  // the cold parts of the tile's rows go through the wave's coefficient strip: slot r holds dcold of local row r until the
+  // lane that closes row r has read it -- the same lane then overwrites it with the row's gate coefficient (LDS executes a
+  // wave's accesses in order; every other lane reads coefficients only behind the wave barrier further down)
+  x.coefw[lane + 1] = cur.dcv;
+  if (nrows > 64) {   // wave-uniform, rare: rows shorter than 8 non-zeros
+    for (int i = 64 + lane; i < nrows; i += 64) x.coefw[i + 1] = (x.dcold + __builtin_amdgcn_readfirstlane(cur.r0))[i];
+  }
+  __builtin_amdgcn_wave_barrier();
   const unsigned int ys = (desc >> 8) & 255u;
   int cc[8];
   {
@@ -889,9 +900,9 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, cons
   // rows of the worker's batch, as local rows of this tile (wave-uniform: readfirstlane keeps the 64-bit clamps and
   // the row bases on the scalar unit -- the compiler had them in vector registers, ~20 VALU instructions per tile)
   const int r0s = __builtin_amdgcn_readfirstlane(cur.r0);
-  const long long lo64 = x.row_begin - r0s + 1, hi64 = x.row_end - r0s + 1;
-  const int r_lo = (int)(lo64 < 1 ? 1 : (lo64 > 1024 ? 1024 : lo64));
-  const int r_hi = (int)(hi64 > nrows + 1 ? nrows + 1 : (hi64 < 0 ? 0 : hi64));   // exclusive
+  const int lo = x.row_begin - r0s + 1, hi = x.row_end - r0s + 1;   // (both operands in [0, 2^31): no overflow)
+  const int r_lo = lo < 1 ? 1 : (lo > 1024 ? 1024 : lo);
+  const int r_hi = hi > nrows + 1 ? nrows + 1 : (hi < 0 ? 0 : hi);   // exclusive
   const float ps = x.fix_scale, ns = -x.fix_scale;
   signed char* const coef8_tile = x.coef8 + ((long long)r0s - 1);   // [local row] -> global row's gate
 
@@ -920,7 +931,8 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, cons
     const int r_end = rf - (int)(bits & 1u);              // local row that ends at the lane's row start
     {
       const bool fin = nb == 1 && r_end >= r_lo && r_end < r_hi;
-      const float d = (incoming + head) + cur.dc;          // x . w of that row
+      const float dc = x.coefw[(nb == 1 && r_end >= 1 && r_end <= nrows) ? r_end : 0];
+      const float d = (incoming + head) + dc;              // x . w of that row
       const bool ypos = (ys & bits) != 0u;
       const float yd = ypos ? d : -d;
       if (SCATTER) {
@@ -982,7 +994,7 @@ __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, cons
           if (r >= 1 && r <= nrows) {
             const bool in_range = r >= r_lo && r < r_hi;
             const bool ypos = (ys >> k) & 1u;
-            const float dfull = run + (x.dcold + r0s)[(unsigned int)(r - 1)];
+            const float dfull = run + x.coefw[r];
             const float yd = ypos ? dfull : -dfull;
             if (SCATTER) {
               const bool active = in_range && !(yd < 0.0f);
@@ -1079,7 +1091,7 @@ __device__ __forceinline__ void w_long_row(const CsrView& m, const float* __rest
 }
 
 // m: the hot stream (row_ptr = hot row offsets, col = 16-bit ranks, val); mfull: the whole ranked CSR (long rows)
-template <bool SCATTER, bool NT>
+template <bool SCATTER>
 __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mfull, const WTile* __restrict__ tiles,
                                                         const unsigned short* __restrict__ meta,
                                                         const float* __restrict__ w, long long* __restrict__ g64_base,
@@ -1110,8 +1122,8 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
   x.g64 = g64_base + (long long)blockIdx.y * g_stride;
   x.sc = sc;
   x.dcold = dcold;
-  x.row_begin = seg.row_begin;
-  x.row_end = seg.row_end;
+  x.row_begin = (int)seg.row_begin;
+  x.row_end = (int)seg.row_end;
   x.hw = hw;
   x.hg = hg;
   x.fix_scale = fix_scale;
@@ -1131,34 +1143,37 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
   __syncthreads();
 
   unsigned int n_all = 0, n_neg = 0, n_pos = 0;
-  const long long stride = (long long)gridDim.x * 16;          // waves of this worker's grid row
-  const long long t_end = seg.tile_end;
-  long long tile = seg.tile_begin + (long long)blockIdx.x * 16 + wave;
+  const int stride = (int)gridDim.x * 16;          // waves of this worker's grid row
+  const int t_end = (int)seg.tile_end;
+  int tile = (int)seg.tile_begin + (int)blockIdx.x * 16 + wave;
   if (tile < t_end) {
     // four register sets rotated by unrolling: three tiles in flight per wave
     WRegs A, B, C, D;
     WTile wt = w_fetch(tt, tile, t_end);
-    w_issue_cols<NT>(m, tile, t_end, lane, wt, A);
-    w_issue_vals<NT>(m, tt, lane, A);
+    w_issue_cols(m, tile, t_end, lane, wt, A);
+    w_issue_vals(m, tt, x.dcold, lane, A);
+    __builtin_amdgcn_sched_barrier(0);   // (a tile's requests stay together and in tile order: vmcnt retires in order,
+                                         //  and the loop's first wait merges this path with the back edge)
     wt = w_fetch(tt, tile + stride, t_end);
-    w_issue_cols<NT>(m, tile + stride, t_end, lane, wt, B);
-    w_issue_vals<NT>(m, tt, lane, B);
+    w_issue_cols(m, tile + stride, t_end, lane, wt, B);
+    w_issue_vals(m, tt, x.dcold, lane, B);
+    __builtin_amdgcn_sched_barrier(0);
     wt = w_fetch(tt, tile + 2 * stride, t_end);
-    w_issue_cols<NT>(m, tile + 2 * stride, t_end, lane, wt, C);
-    w_issue_vals<NT>(m, tt, lane, C);
+    w_issue_cols(m, tile + 2 * stride, t_end, lane, wt, C);
+    w_issue_vals(m, tt, x.dcold, lane, C);
+    __builtin_amdgcn_sched_barrier(0);
     wt = w_fetch(tt, tile + 3 * stride, t_end);
-    w_load_dc(x, A);
-#define DSGD_WT(CUR, NXT, FAR) w_tile<SCATTER, NT>(m, tt, x, tile, stride, t_end, CUR, NXT, FAR, wt, n_all, n_neg, n_pos)
+#define DSGD_WT(CUR, FAR) w_tile<SCATTER>(m, tt, x, tile, stride, t_end, CUR, FAR, wt, n_all, n_neg, n_pos)
     for (;;) {
-      DSGD_WT(A, B, D); tile += stride; if (tile >= t_end) break;
-      DSGD_WT(B, C, A); tile += stride; if (tile >= t_end) break;
-      DSGD_WT(C, D, B); tile += stride; if (tile >= t_end) break;
-      DSGD_WT(D, A, C); tile += stride; if (tile >= t_end) break;
+      DSGD_WT(A, D); tile += stride; if (tile >= t_end) break;
+      DSGD_WT(B, A); tile += stride; if (tile >= t_end) break;
+      DSGD_WT(C, B); tile += stride; if (tile >= t_end) break;
+      DSGD_WT(D, C); tile += stride; if (tile >= t_end) break;
     }
 #undef DSGD_WT
   }
   // rows that fit no tile: one wave per row
-  for (long long t = seg.long_begin + (long long)blockIdx.x * 16 + wave; t < seg.long_end; t += stride)
+  for (long long t = seg.long_begin + (long long)blockIdx.x * 16 + wave; t < seg.long_end; t += (long long)stride)
     w_long_row<SCATTER>(mfull, w, x, (long long)long_rows[t], n_all, n_neg, n_pos);
 
   if (SCATTER) {
@@ -1381,22 +1396,20 @@ struct CTabs {
   const void* __restrict__ col;
   const float* __restrict__ val;
   const signed char* __restrict__ coef8;   // gradient kernel only
-  long long row_begin, row_end;            // the worker's rows (gradient kernel: rows outside contribute nothing)
-  long long t_lo, t_hi;                    // its tiles
-  int rev;                                 // walk the tiles from the last to the first
+  int row_begin, row_end;                  // the worker's rows (gradient kernel: rows outside contribute nothing)
+  int t_lo, t_hi;                          // its tiles (32-bit: see w_fetch)
 };
 
-__device__ __forceinline__ long long c_map(const CTabs& tt, long long t) {   // logical tile -> tile record (clamped)
-  const long long tc = t < tt.t_hi ? t : tt.t_hi - 1;
-  return tt.rev ? tt.t_lo + (tt.t_hi - 1 - tc) : tc;
+__device__ __forceinline__ int c_map(const CTabs& tt, int t) {   // logical tile -> tile record (clamped)
+  return t < tt.t_hi ? t : tt.t_hi - 1;
 }
 
 template <bool COL16, bool GRAD>
-__device__ __forceinline__ void c_issue(const CTabs& tt, long long t, int lane, const WTile& wt, CRegs<COL16>& r) {
+__device__ __forceinline__ void c_issue(const CTabs& tt, int t, int lane, const WTile& wt, CRegs<COL16>& r) {
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const bool live = t < tt.t_hi;
-  const long long tc = c_map(tt, t);
+  const int tc = c_map(tt, t);
   r.r0 = wt.r0;
   r.nrows = live ? (int)(short)(wt.info & 0xffff) : -1;
   r.pos0 = wt.pos0;
@@ -1427,16 +1440,16 @@ __device__ __forceinline__ void c_issue(const CTabs& tt, long long t, int lane, 
     r.v0 = make_float4(a.x, a.y, a.z, a.w);
     r.v1 = make_float4(b.x, b.y, b.z, b.w);
   }
-  r.meta = (tt.meta + tc * 64)[(unsigned int)lane];
+  r.meta = (tt.meta + (long long)tc * 64)[(unsigned int)lane];
   if (GRAD) {
     // gate coefficients of the tile's rows, one byte per row (written by the main kernel): local row l + 1 is global
     // row r0 + l.  The window is clamped to the worker's rows -- whatever coef8 holds outside them is stale --
     // and lanes outside the window read 0 (an offset below the window wraps to a huge unsigned one).
-    const long long lo = tt.row_begin > (long long)wt.r0 ? tt.row_begin : (long long)wt.r0;
-    long long hi = (long long)wt.r0 + (r.nrows > 0 ? r.nrows : 0);
+    const int lo = tt.row_begin > wt.r0 ? tt.row_begin : wt.r0;
+    int hi = wt.r0 + (r.nrows > 0 ? r.nrows : 0);
     if (hi > tt.row_end) hi = tt.row_end;
-    const int n = hi > lo ? (int)(hi - lo) : 0;
-    const int shift = (int)(lo - (long long)wt.r0);   // 0 .. nrows
+    const int n = hi > lo ? hi - lo : 0;
+    const int shift = lo - wt.r0;   // 0 .. nrows
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<signed char*>(tt.coef8 + lo), 0, n, 0x00020000);
     r.cf0 = (int)(signed char)__builtin_amdgcn_raw_buffer_load_b8(rs, lane - shift, 0, 0);
@@ -1613,8 +1626,7 @@ __global__ void __launch_bounds__(1024) dsgd_cold_kernel(const WTile* __restrict
                                                         float* __restrict__ dcold, const signed char* __restrict__ coef8,
                                                         long long* __restrict__ g64_base, long long g_stride,
                                                         DevScalars* __restrict__ sc, int hsplit, int nc_lds,
-                                                        float fix_scale, int* __restrict__ partc, int partc_stride,
-                                                        int rev) {
+                                                        float fix_scale, int* __restrict__ partc, int partc_stride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1634,14 +1646,13 @@ __global__ void __launch_bounds__(1024) dsgd_cold_kernel(const WTile* __restrict
   tt.col = col;
   tt.val = val;
   tt.coef8 = coef8;
-  tt.row_begin = seg.row_begin;
-  tt.row_end = seg.row_end;
-  tt.t_lo = seg.ctile_begin;
-  tt.t_hi = seg.ctile_end;
-  tt.rev = rev;
+  tt.row_begin = (int)seg.row_begin;
+  tt.row_end = (int)seg.row_end;
+  tt.t_lo = (int)seg.ctile_begin;
+  tt.t_hi = (int)seg.ctile_end;
   long long* g64cold = GRAD ? g64_base + (long long)blockIdx.y * g_stride + hsplit : nullptr;
-  const long long stride = (long long)gridDim.x * 16;
-  long long tile = tt.t_lo + (long long)blockIdx.x * 16 + wave;
+  const int stride = (int)gridDim.x * 16;
+  int tile = tt.t_lo + (int)blockIdx.x * 16 + wave;
   if (tile < tt.t_hi) {
     CRegs<COL16> A, B, C, D;
     WTile wt = tiles[c_map(tt, tile)];

@@ -37,7 +37,7 @@ for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   echo "== pmc pass $i: $P" | tee -a $OUT/pmc_summary.txt
   ( cd /tmp && timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc$i -o pmc -- python $REPO/tools/pmc_step.py 8388608 3 > $OUT/pmc$i.out 2> $OUT/pmc$i.err )
   f=$(find $OUT/pmc$i -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python tools/pmc_summary.py "$f" "dsgd_" | grep -E "wseg_kernel<true|cdot|cgrad|reduce|apply|bound" | tee -a $OUT/pmc_summary.txt
+  [ -n "$f" ] && python tools/pmc_summary.py "$f" "dsgd_" | grep -E "wseg_kernel<true|cdot|cgrad|cold|reduce|apply|bound" | tee -a $OUT/pmc_summary.txt
   rm -rf $OUT/pmc$i $OUT/pmc$i.out $OUT/pmc$i.err
 done
 echo "== small-batch phase counters and Hogwild by worker count"
