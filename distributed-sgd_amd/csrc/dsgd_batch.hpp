@@ -796,6 +796,198 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
 }
 
 // ======================================================================================================
+// K1v: index-list batches as VIRTUAL TILES over the split streams (round 3)
+// ======================================================================================================
+// ref: core/Slave.scala:147-153 (Vec.sum of the gated sub-gradients of a batch), the same contract as
+// dsgd_mb_grad_kernel: per-workgroup fixed-point partials of the hot ranks, 64-bit fixed-point global accumulators
+// for the cold ones, the exact reduce + regularise + update behind it.
+//
+// dsgd_mb_grad_kernel walks the whole ranked CSR row by row: 32-bit ids, half of the weights gathered from global
+// memory, every slot masked in four places -- ~1,500 instructions per pass of 1,024 slots, 40 us for B = 65,536
+// (0.1 of the HBM roofline), the worst fraction in the repository.  The streaming kernel next door spends ~180 per
+// 512-slot tile because its tiles are laid out for it.  Here the HOST lays a batch out the same way when a plan is
+// created: every row of a list gets ceil(hot entries / 8) consecutive lanes of a 64-lane "virtual tile", each lane a
+// 16-byte descriptor {position of its 8 slots in the hot stream, valid slots, first / last lane of the row, label
+// sign, local row, position of ONE cold entry}.  A wave then runs a three-stage pipeline over its tiles --
+// descriptors -> stream requests (16-bit ranks + values of the hot stream from wherever the row lives, one cold
+// entry) -> cold weight gather -> arithmetic -- with all hot weights and the hot gradient in LDS exactly as in
+// dsgd_wseg_kernel (no gathers, no rank checks), one segmented scan per tile (a lane belongs to ONE row: no head /
+// trail fragments), the gate on the row's last lane, coefficients through the wave's strip.
+struct VtLane {          // 16 bytes, one per lane of a virtual tile (written by the host: vt_build)
+  unsigned int hp;       // first of the lane's <= 8 slots in the hot stream
+  unsigned int info;     // valid slots (bits 0-3) | first lane of its row (4) | last lane (5) | label > 0 (6) |
+                         // has a cold entry (8) | local row of the tile (bits 16-21)
+  unsigned int cp;       // the lane's cold entry in the cold stream
+  unsigned int row;      // global row (bookkeeping)
+};
+constexpr unsigned int VT_START = 1u << 4, VT_LAST = 1u << 5, VT_YPOS = 1u << 6, VT_COLD = 1u << 8;
+
+struct VtArgs {
+  const unsigned short* hcol;   // hot stream: 16-bit ranks, values
+  const float* hval;
+  const unsigned short* ccol;   // cold stream (16-bit form): rank - hsplit, values
+  const float* cval;
+  const float* w;
+  const VtLane* lanes;          // 64 per tile
+  const WorkSeg* tsegs;         // tile range of every worker's list of this step (blockIdx.y)
+  int* part;
+  long long* g64_base;
+  long long g_stride;
+  DevScalars* sc;
+  float qscale, cold_scale;     // fixed-point scales of the LDS tile (per launch) and of the 64-bit accumulators
+  int part_stride, hsplit;
+};
+
+struct VtRegs {
+  uint4 d;                // the lane's descriptor (raw: a select on it at request time would wait for the load on the spot)
+  int live;               // wave-uniform: the tile exists (a tile beyond the wave's last one is requested and masked)
+  unsigned int c[5];      // 20 bytes from the dword below the lane's first rank (ranks sit at any 2-byte offset)
+  float4 v0, v1;
+  unsigned int cc;        // cold rank
+  float cv, cw;           // cold value, cold weight
+};
+
+// stage D: the descriptors of tile t (a tile beyond the wave's last one reads the list's first tile and is masked)
+__device__ __forceinline__ void vt_issue_desc(const VtArgs& a, int t, int t_end, int lane, VtRegs& r) {
+  const int tc = t < t_end ? t : t_end - 1;
+  r.d = reinterpret_cast<const uint4*>(a.lanes)[(long long)tc * 64 + lane];
+  r.live = t < t_end;
+}
+// stage S: the lane's slots of the hot stream and its cold entry
+__device__ __forceinline__ void vt_issue_stream(const VtArgs& a, VtRegs& r) {
+  typedef unsigned int u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  const unsigned int hp = r.d.x;
+  const unsigned int* cb = reinterpret_cast<const unsigned int*>(a.hcol) + (hp >> 1);   // the dword holding rank hp
+  const u32x4u ca = *reinterpret_cast<const u32x4u*>(cb);
+  r.c[0] = ca.x; r.c[1] = ca.y; r.c[2] = ca.z; r.c[3] = ca.w;
+  r.c[4] = cb[4];
+  const f32x4u va = *reinterpret_cast<const f32x4u*>(a.hval + hp), vb = *reinterpret_cast<const f32x4u*>(a.hval + hp + 4);
+  r.v0 = make_float4(va.x, va.y, va.z, va.w);
+  r.v1 = make_float4(vb.x, vb.y, vb.z, vb.w);
+  const unsigned int cp = (r.d.y & VT_COLD) ? r.d.z : 0u;
+  r.cc = a.ccol[cp];
+  r.cv = a.cval[cp];
+}
+// stage G: the weight of the lane's cold rank (its id has landed)
+__device__ __forceinline__ void vt_issue_gather(const VtArgs& a, VtRegs& r) {
+  r.cw = a.w[a.hsplit + (int)r.cc];
+}
+
+// stage P
+__device__ __forceinline__ unsigned int vt_process(const VtArgs& a, const VtRegs& r, float* strip, int* gl,
+                                                   long long* __restrict__ g64) {
+  typedef __attribute__((address_space(3))) const float lds_cfloat;
+  const unsigned int info = r.live ? r.d.y : 0u;   // (masked tile: no valid slot, no row end, no cold entry)
+  const unsigned int cnt = info & 15u;
+  const unsigned int lrow = (info >> 16) & 63u;
+  // eight 16-bit ranks from the five dwords: funnel shift by 0 or 16 bits
+  const unsigned int sh = (r.d.x & 1u) << 4;
+  unsigned int cw[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cw[k] = __builtin_amdgcn_alignbit(r.c[k + 1], r.c[k], sh);
+  int cc[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    cc[2 * k] = (int)((cw[k] & 0xffffu) << 2);
+    cc[2 * k + 1] = (int)((cw[k] >> 14) & 0x3fffcu);
+  }
+  // slots past the row's end (the row's last lane) hold the NEXT row's entries: their values become 0 -- the products
+  // and the fixed-point contributions follow; the ranks stay valid LDS addresses (< hsplit) whatever they are
+  float vv[8] = {r.v0.x, r.v0.y, r.v0.z, r.v0.w, r.v1.x, r.v1.y, r.v1.z, r.v1.w};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) vv[k] = (unsigned int)k < cnt ? vv[k] : 0.0f;
+  float p[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) p[k] = filt(vv[k] * *(lds_cfloat*)(unsigned int)cc[k]);   // ref: math/Sparse.scala:46
+  const bool hasc = (info & VT_COLD) != 0u;
+  const float cv = hasc ? r.cv : 0.0f;
+  float t = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+  t += filt(cv * r.cw);
+  // a lane belongs to ONE row: an inclusive segmented scan over the lanes leaves x.w on the row's last lane
+  int f = (info & VT_START) != 0u;
+  wave_seg_scan(t, f);
+  const bool last = (info & VT_LAST) != 0u;
+  const bool ypos = (info & VT_YPOS) != 0u;
+  const float yd = ypos ? t : -t;
+  const bool active = last && !(yd < 0.0f);                   // ref: core/ml/SparseSVM.scala:27-28
+  if (last) strip[lrow] = active ? (ypos ? a.qscale : -a.qscale) : 0.0f;
+  __builtin_amdgcn_wave_barrier();   // same wave writes and reads the strip: LDS keeps a wave's order
+  const float coef = cnt != 0u || hasc ? strip[lrow] : 0.0f;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  int q[8];
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    // |v * coef| <= 2^shift <= 2^22: v * coef + 1.5 * 2^23 rounds once to an fp32 whose low mantissa bits are q
+    const f32x2 rr = __builtin_elementwise_fma(f32x2{vv[k], vv[k + 1]}, f32x2{coef, coef}, f32x2{12582912.0f, 12582912.0f});
+    q[k] = __float_as_int(rr.x) - 0x4B400000;
+    q[k + 1] = __float_as_int(rr.y) - 0x4B400000;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (q[k] != 0) atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(gl) + cc[k]), q[k]);
+  if (hasc && coef != 0.0f) {   // the cold entry of an active row: 64-bit global accumulator at the cold scale
+    const int qc = __float2int_rn(cv * (coef > 0.0f ? a.cold_scale : -a.cold_scale));
+    if (qc != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[a.hsplit + (int)r.cc]), (unsigned long long)(long long)qc);
+  }
+  __builtin_amdgcn_wave_barrier();
+  return active ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(1024) dsgd_vt_grad_kernel(VtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.hsplit;
+  // LDS as in dsgd_wseg_kernel: H + 1 weights at address 0 (ranks become byte offsets), 16 strips, H + 64 gradient words
+  float* wl = lds;
+  float* strips = lds + ((H + 4) & ~3);
+  float* strip = strips + wave * 64;
+  int* gl = reinterpret_cast<int*>(strips + 16 * 64);
+  const WorkSeg seg = a.tsegs[blockIdx.y];
+  long long* g64 = a.g64_base + (long long)blockIdx.y * a.g_stride;
+  const int stride = (int)gridDim.x * 16, t_end = (int)seg.end;
+  int tile = (int)seg.begin + (int)blockIdx.x * 16 + wave;
+  VtRegs A, B, C, D;
+  // the first descriptors and stream requests go out before the LDS tiles are set up (they need neither)
+  vt_issue_desc(a, tile, t_end, lane, A);
+  vt_issue_desc(a, tile + stride, t_end, lane, B);
+  vt_issue_desc(a, tile + 2 * stride, t_end, lane, C);
+  if ((unsigned int)(unsigned long long)(__attribute__((address_space(3))) float*)lds != 0u) {
+    if (tid == 0) atomicOr(&a.sc->err, 2);
+    return;
+  }
+  wg_zero(gl, H + 64, tid, 1024);
+  vt_issue_stream(a, A);
+  vt_issue_stream(a, B);
+  wg_copy_in(wl, a.w, H, tid, 1024, is_aligned16(a.w));
+  if (tid == 0) wl[H] = 0.0f;
+  vt_issue_gather(a, A);
+  __syncthreads();
+  unsigned int n_act = 0;
+  if (tile < t_end) {
+    // iteration i: descriptors of tile i+3, stream of i+2 (its descriptors landed), cold weight of i+1, arithmetic of i
+#define DSGD_VT(CUR, N1, N2, N3)                           \
+  vt_issue_desc(a, tile + 3 * stride, t_end, lane, N3);    \
+  vt_issue_stream(a, N2);                                  \
+  vt_issue_gather(a, N1);                                  \
+  n_act += vt_process(a, CUR, strip, gl, g64);
+    for (;;) {
+      DSGD_VT(A, B, C, D) tile += stride; if (tile >= t_end) break;
+      DSGD_VT(B, C, D, A) tile += stride; if (tile >= t_end) break;
+      DSGD_VT(C, D, A, B) tile += stride; if (tile >= t_end) break;
+      DSGD_VT(D, A, B, C) tile += stride; if (tile >= t_end) break;
+    }
+#undef DSGD_VT
+  }
+  __syncthreads();
+  int* mine = a.part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * a.part_stride;
+  wg_copy_out(mine, gl, H, tid, 1024, is_aligned16(mine) && is_aligned16(gl));
+  n_act = wave_sum_u32(n_act);
+  if (lane == 0 && n_act) atomicAdd(&a.sc->n_active, (unsigned long long)n_act);
+}
+
+// ======================================================================================================
 // K7: persistent lock-free ("Hogwild") engine -- Slave.asyncTask for many workers sharing ONE w
 // ======================================================================================================
 // ref: core/Slave.scala:79-111 (the loop), :177-185 / core/MasterAsync.scala:164-177 (applying updates),

@@ -123,6 +123,14 @@ struct dsgd_plan {
   long long max_step_rows = 0;  // largest step (all workers together)
   bool fits = false;            // every list fits the staged sub-batch of dsgd_plan_kernel (rows and work items)
   long long fits_rows = -1;     // ... of the data set with this many rows (the one loaded at plan creation)
+  // virtual tiles (dsgd_vt_grad_kernel): the lists laid out over the split streams, built at the first run that needs them
+  std::vector<int> h_idx;       // host copy of the lists
+  VtLane* d_vt_lanes = nullptr; // 64 descriptors per tile
+  WorkSeg* d_vt_segs = nullptr; // tile range of every list
+  std::vector<long long> vt_off;       // n_lists + 1 tile offsets
+  std::vector<int> vt_grid, vt_shift;  // per step: workgroups per worker, fixed-point shift (rows per workgroup)
+  long long vt_layout = -1;     // the layout generation the tiles were built for (-1: not built)
+  bool vt_ok = false;           // every row of every list sits in the tiled streams
 };
 
 struct FusedArgs {
@@ -155,7 +163,11 @@ struct dsgd_ctx {
   // gathers) and a cold stream (col - hsplit, val, row) handled by two small kernels whose LDS holds the cold weights /
   // the cold gradient.
   std::vector<long long> h_row_ptr;     // host copy of the internal row_ptr (tile building at layout time)
-  std::vector<long long> h_crow_ptr;    // row offsets of the cold stream
+  std::vector<long long> h_crow_ptr;    // cold ENTRIES before each row
+  std::vector<long long> h_hrp, h_ctp;  // slot offsets of the hot / cold stream (virtual tiles are built from them)
+  long long layout_gen = 0;             // bumped whenever the split streams are rebuilt
+  bool vt_enable = true;                // DSGD_VT=0: index-list steps of resident plans through dsgd_mb_grad_kernel
+  int vt_tpw = 2;                       // DSGD_VT_TPW: virtual tiles per wave the grid is sized for
   std::vector<signed char> h_label;
   // wave tiles over d_hcol/d_hval
   WTile* d_wtiles = nullptr;
@@ -526,6 +538,131 @@ static int launch_grad_mb(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, 
   return DSGD_OK;
 }
 
+// ---- virtual tiles (dsgd_vt_grad_kernel) ---------------------------------------------------------------------
+// Lay the lists of a plan out over the split streams: a row gets max(ceil(hot slots / 8), cold entries, 1) consecutive
+// lanes of a 64-lane tile (whole rows per tile, every list starts a tile).  Not possible (vt_ok = false, the plan keeps
+// using dsgd_mb_grad_kernel) when a row sits on the long-row list, holds more than 64 cold entries, or the streams are
+// not in their 16-bit / 32-bit-addressable form.
+static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
+  p->vt_layout = c->layout_gen;
+  p->vt_ok = false;
+  (void)hipFree(p->d_vt_lanes);
+  (void)hipFree(p->d_vt_segs);
+  p->d_vt_lanes = nullptr;
+  p->d_vt_segs = nullptr;
+  const int H = std::min(c->hsplit, c->dp);
+  const long long n_lists = (long long)p->n_steps * p->n_workers;
+  if (!c->cold_col16 || c->dp <= H || c->hot_nnz + WS_PAD >= (1LL << 32) || c->coldm_nnz + WS_PAD >= (1LL << 32)) return DSGD_OK;
+  if (c->h_hrp.size() != (size_t)c->n_rows + 1 || (long long)p->h_idx.size() != p->offsets[n_lists]) return DSGD_OK;
+  const std::vector<long long>&hrp = c->h_hrp, &ctp = c->h_ctp, &crp = c->h_crow_ptr;
+  std::vector<VtLane> lanes;
+  lanes.reserve((size_t)p->offsets[n_lists] * 10);
+  std::vector<int> tile_rows;
+  p->vt_off.assign((size_t)n_lists + 1, 0);
+  const VtLane empty{0u, 0u, 0u, 0u};
+  for (long long li = 0; li < n_lists; ++li) {
+    int used = 0, rows = 0;   // lanes and rows of the open tile
+    for (long long t = p->offsets[li]; t < p->offsets[li + 1]; ++t) {
+      const long long r = p->h_idx[(size_t)t];
+      if (r < 0 || r >= c->n_rows) return DSGD_OK;       // (the mb kernel reports the bad index)
+      const long long hot = hrp[r + 1] - hrp[r], cold = crp[r + 1] - crp[r];
+      if (hot <= 0 || cold > 64) return DSGD_OK;          // long-row list / too many cold entries for one tile
+      const int nl = (int)std::max<long long>(std::max<long long>((hot + 7) / 8, cold), 1);
+      if (used + nl > 64) {                               // close the tile
+        lanes.resize(lanes.size() + (size_t)(64 - used), empty);
+        tile_rows.push_back(rows);
+        used = 0;
+        rows = 0;
+      }
+      const unsigned int ypos = c->h_label[(size_t)r] > 0 ? VT_YPOS : 0u;
+      for (int j = 0; j < nl; ++j) {
+        VtLane L;
+        const long long left = hot - 8LL * j;
+        const unsigned int cnt = (unsigned int)std::max<long long>(0, std::min<long long>(8, left));
+        L.hp = cnt ? (unsigned int)(hrp[r] + 8LL * j) : 0u;
+        L.info = cnt | (j == 0 ? VT_START : 0u) | (j == nl - 1 ? VT_LAST : 0u) | ypos | (j < cold ? VT_COLD : 0u) |
+                 ((unsigned int)rows << 16);
+        L.cp = j < cold ? (unsigned int)(ctp[r] + j) : 0u;
+        L.row = (unsigned int)r;
+        lanes.push_back(L);
+      }
+      used += nl;
+      ++rows;
+    }
+    lanes.resize(lanes.size() + (size_t)(64 - used), empty);   // (a list is never empty: its last tile is open)
+    tile_rows.push_back(rows);
+    p->vt_off[(size_t)li + 1] = (long long)tile_rows.size();
+  }
+  // per step: the grid (workgroups per worker) and the fixed-point shift from the rows ONE workgroup can meet
+  p->vt_grid.assign((size_t)p->n_steps, 1);
+  p->vt_shift.assign((size_t)p->n_steps, 21);
+  const long long per_worker = std::max<long long>(1, c->n_cu / p->n_workers);
+  std::vector<WorkSeg> segs((size_t)n_lists);
+  for (long long s = 0; s < p->n_steps; ++s) {
+    long long max_t = 1;
+    for (int k = 0; k < p->n_workers; ++k) {
+      const long long li = s * p->n_workers + k;
+      segs[(size_t)li].begin = p->vt_off[(size_t)li];
+      segs[(size_t)li].end = p->vt_off[(size_t)li + 1];
+      max_t = std::max(max_t, segs[(size_t)li].end - segs[(size_t)li].begin);
+    }
+    const long long gx = std::max<long long>(1, std::min(per_worker, (max_t + 16LL * c->vt_tpw - 1) / (16LL * c->vt_tpw)));
+    long long worst = 1;
+    std::vector<long long> rows_of((size_t)gx);
+    for (int k = 0; k < p->n_workers; ++k) {
+      const WorkSeg& sg = segs[(size_t)(s * p->n_workers + k)];
+      std::fill(rows_of.begin(), rows_of.end(), 0);
+      for (long long t = sg.begin; t < sg.end; ++t) rows_of[(size_t)(((t - sg.begin) / 16) % gx)] += tile_rows[(size_t)t];
+      for (long long v : rows_of) worst = std::max(worst, v);
+    }
+    int bits = 0;
+    while ((1LL << bits) < worst) ++bits;
+    p->vt_grid[(size_t)s] = (int)gx;
+    p->vt_shift[(size_t)s] = std::min(21, 30 - bits);   // (<= 21: the fixed-point conversion is one fma against 1.5 * 2^23)
+  }
+  HIP_TRY(hipMalloc(&p->d_vt_lanes, sizeof(VtLane) * std::max<size_t>(lanes.size(), 64)));
+  HIP_TRY(hipMalloc(&p->d_vt_segs, sizeof(WorkSeg) * (size_t)n_lists));
+  HIP_TRY(hipMemcpy(p->d_vt_lanes, lanes.data(), sizeof(VtLane) * lanes.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->d_vt_segs, segs.data(), sizeof(WorkSeg) * (size_t)n_lists, hipMemcpyHostToDevice));
+  p->vt_ok = true;
+  return DSGD_OK;
+}
+
+static int launch_grad_vt(dsgd_ctx* c, dsgd_plan* p, long long step) {
+  const int H = std::min(c->hsplit, c->dp);
+  const int gx = p->vt_grid[(size_t)step], shift = p->vt_shift[(size_t)step];
+  DSGD_TRY(ensure_part(c, &c->d_part, &c->part_wgs, &c->part_stride, (long long)gx * p->n_workers, H));
+  c->last_shift = shift;
+  VtArgs a;
+  a.hcol = c->d_hcol;
+  a.hval = c->d_hval;
+  a.ccol = reinterpret_cast<const unsigned short*>(c->d_ccol);
+  a.cval = c->d_cval;
+  a.w = c->d_w;
+  a.lanes = p->d_vt_lanes;
+  a.tsegs = p->d_vt_segs + step * p->n_workers;
+  a.part = c->d_part;
+  a.g64_base = c->d_g64;
+  a.g_stride = c->dp;
+  a.sc = c->d_sc;
+  a.qscale = std::ldexp(1.0f, shift - c->vexp);
+  a.cold_scale = c->fix_scale;
+  a.part_stride = c->part_stride;
+  a.hsplit = H;
+  const size_t lds = sizeof(float) * (size_t)(((H + 4) & ~3) + 16 * 64 + H + 64);
+  size_t slot = 0;
+  DSGD_TRY(prof_begin(c, &slot));
+  hipLaunchKernelGGL(dsgd_vt_grad_kernel, dim3((unsigned)gx, p->n_workers), dim3(1024), lds, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  DSGD_TRY(prof_end(c, slot));
+  c->last_grad_kernel = "dsgd_vt_grad_kernel";
+  DSGD_TRY(ensure_redpart(c));
+  // hot ranks: the workgroups' partials at this launch's scale; cold ranks: the 64-bit accumulators at the cold scale
+  c->fused_args = {H, gx, H, 0, 0, 1.0 / (double)a.qscale, 1.0 / (double)c->fix_scale};
+  c->fused_apply_pending = true;
+  return DSGD_OK;
+}
+
 // gradient of n_workers index lists (or row ranges too small for the streaming kernels) living at d_segs (device);
 // max_items = largest list
 static int launch_grad(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int n_workers, long long max_items,
@@ -721,7 +858,10 @@ static int build_split(dsgd_ctx* c) {
   if (e != hipSuccess) return fail(DSGD_EHIP, "split counts: %s", hipGetErrorString(e));
   // hrp / ctp: slot offsets of the two streams (a tiled row owns at least one slot in each: an explicit zero when it
   // has no entry there); crp: the cold ENTRIES before each row (what dsgd_range_nnz reports)
-  std::vector<long long> hrp((size_t)n_rows + 1), ctp((size_t)n_rows + 1), &crp = c->h_crow_ptr;
+  std::vector<long long>&hrp = c->h_hrp, &ctp = c->h_ctp, &crp = c->h_crow_ptr;
+  hrp.assign((size_t)n_rows + 1, 0);
+  ctp.assign((size_t)n_rows + 1, 0);
+  ++c->layout_gen;
   crp.assign((size_t)n_rows + 1, 0);
   c->wlong_rows.clear();
   hrp[0] = 0;
@@ -1170,6 +1310,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_FIX_SHIFT")) c->max_shift = std::max(8, std::min(FIX_SHIFT, atoi(e)));   // cap of the fixed-point shift
   if (const char* e = getenv("DSGD_FIX_BOUND")) c->fix_bound = atoi(e) != 0;      // 0: data-independent bound only
   if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;  // 0: small batches through the multi-workgroup kernel
+  if (const char* e = getenv("DSGD_VT")) c->vt_enable = atoi(e) != 0;             // 0: plans' index lists through dsgd_mb_grad_kernel
+  if (const char* e = getenv("DSGD_VT_TPW")) c->vt_tpw = std::max(1, atoi(e));
   if (const char* e = getenv("DSGD_HSPLIT")) c->hsplit = atoi(e);                 // hot/cold split rank (tests: wide models)
   if (getenv("DSGD_PLAN_PROF") && atoi(getenv("DSGD_PLAN_PROF"))) {
     HIP_TRY_B(hipMalloc(&c->d_tprof, sizeof(unsigned long long) * 16));
@@ -1186,6 +1328,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_colcount_kernel);
   DSGD_ATTR(dsgd_hogwild_kernel);
   DSGD_ATTR(dsgd_mb_grad_kernel);
+  DSGD_ATTR(dsgd_vt_grad_kernel);
   DSGD_ATTR(dsgd_plan_kernel);
   DSGD_ATTR(dsgd_wseg_kernel<true>);
   DSGD_ATTR(dsgd_wseg_kernel<false>);
@@ -1729,6 +1872,7 @@ int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, in
   p->n_workers = n_workers;
   p->max_items = mx;
   p->offsets.assign(offsets, offsets + n_lists + 1);
+  p->h_idx.assign(idx, idx + offsets[n_lists]);
   for (int64_t st = 0; st < n_steps; ++st)
     p->max_step_rows = std::max<long long>(p->max_step_rows, offsets[(st + 1) * n_workers] - offsets[st * n_workers]);
   p->fits = true;
@@ -1761,6 +1905,8 @@ int dsgd_plan_destroy(dsgd_ctx* c, dsgd_plan* p) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   (void)hipFree(p->d_idx);
   (void)hipFree(p->d_segs);
+  (void)hipFree(p->d_vt_lanes);
+  (void)hipFree(p->d_vt_segs);
   delete p;
   return DSGD_OK;
 }
@@ -1784,7 +1930,15 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
   }
   DSGD_TRY(ensure_g(c, p->n_workers));
   DSGD_TRY(ensure_s(c));
+  if (c->vt_enable && p->vt_layout != c->layout_gen) DSGD_TRY(vt_build(c, p));
+  const bool vt = c->vt_enable && p->vt_ok && p->vt_layout == c->layout_gen;
   for (int64_t s = step_begin; s < step_end; ++s) {
+    if (vt) {   // the lists as virtual tiles over the split streams
+      DSGD_TRY(launch_grad_vt(c, p, s));
+      DSGD_TRY(launch_finish_sync(c, p->n_workers, lr));
+      c->pending_samples += p->offsets[(s + 1) * p->n_workers] - p->offsets[s * p->n_workers];
+      continue;
+    }
     const WorkSeg* segs = p->d_segs + s * p->n_workers;
     long long mx = 0;
     for (int k = 0; k < p->n_workers; ++k)

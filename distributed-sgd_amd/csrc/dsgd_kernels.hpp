@@ -44,6 +44,10 @@ __device__ __forceinline__ void wg_copy_in(float* lds_dst, const float* __restri
       const int j = j0 + u * nthreads + tid;
       t[u] = s4[j < n4 ? j : n4 - 1];
     }
+    // (the values are "used" here: otherwise the compiler sinks every load into the predicated block of its store and
+    //  the eight round trips run one after the other again)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(t[u].x), "+v"(t[u].y), "+v"(t[u].z), "+v"(t[u].w));
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int j = j0 + u * nthreads + tid;
@@ -451,17 +455,19 @@ __device__ __forceinline__ void fra_scalars(float dot, float nsq, float lambda, 
 // Tail shared by dsgd_fix_reduce_apply_kernel<true> and dsgd_apply_cols_kernel: lane tid < FRA_COLS of a block owns
 // column j = block * FRA_COLS + tid and holds the sum of the regularised gradients over the workers; mean, update, and
 // the block's share of w . ds and |w|^2 (combined by the last block to arrive, in block order: reproducible).
+// (wj, dsj: w[j] and ds[j], requested by the caller when the kernel starts -- behind the last workgroup barrier their
+//  round trip would be paid once more; the step's tail is a chain of dependent round trips as it is)
 __device__ __forceinline__ void fra_update_and_scalars(float gsum, float k_total, int j, int dp, float* __restrict__ w,
-                                                       const float* __restrict__ ds, float lr, float lambda,
+                                                       float wj, float dsj, float lr, float lambda,
                                                        DevScalars* sc, float* __restrict__ redpart, float* fred,
                                                        int* is_last) {
   const int tid = threadIdx.x;
   float dot = 0.0f, nsq = 0.0f;
   if (tid < FRA_COLS && j < dp) {
     const float upd = filt(filt(gsum / k_total) * lr);   // Vec.mean over the workers, then learningRate * grad
-    const float wn = filt(w[j] - upd);
+    const float wn = filt(wj - upd);
     w[j] = wn;
-    dot = filt(wn * ds[j]);
+    dot = filt(wn * dsj);
     nsq = wn * wn;
   }
   fra_scalars(dot, nsq, lambda, sc, redpart, fred, is_last);
@@ -561,6 +567,11 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
   else if (al && jg + 3 < hg) mode = 1;
   else if (al && jg >= hc && jg + 3 < hc + nc) mode = 2;
   const int j = j0 + tid;   // the column a lane of the first three waves finishes
+  // everything the finishing lanes need that does not depend on the partials is requested NOW, next to the partials
+  // (their round trips overlap): the column's weight and dimSparsity value, the first worker's 64-bit accumulator
+  const bool fin = tid < FRA_COLS && j < dp;
+  const float wj = (APPLY && fin) ? w[j] : 0.0f, dsj = (APPLY && fin) ? ds[j] : 0.0f;
+  long long tot_next = fin ? g64_base[j] : 0;
   float gsum = 0.0f;        // Vec.sum over the workers, folded left with the Sparse filter after every add
   for (int k = 0; k < n_workers; ++k) {
     long long q[4] = {0, 0, 0, 0};
@@ -595,9 +606,10 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
       for (int e = 0; e < 4; ++e) red[ph][4 * cg + e] = q[e];
     }
     __syncthreads();
-    if (tid < FRA_COLS && j < dp) {
+    long long tot = tot_next;
+    if (fin && k + 1 < n_workers) tot_next = (g64_base + (long long)(k + 1) * g_stride)[j];   // (under the barrier below)
+    if (fin) {
       long long* g64 = g64_base + (long long)k * g_stride;
-      long long tot = g64[j];
       if (tot != 0) g64[j] = 0;
 #pragma unroll
       for (int i = 0; i < FRA_PHASES; ++i) tot += red[i][tid];
@@ -610,7 +622,7 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
     if (tid < FRA_COLS && j < dp) gsum_out[j] = gsum;
     return;
   }
-  fra_update_and_scalars(gsum, (float)n_workers, j, dp, w, ds, lr, lambda, sc, redpart, fred, &is_last);
+  fra_update_and_scalars(gsum, (float)n_workers, j, dp, w, wj, dsj, lr, lambda, sc, redpart, fred, &is_last);
 }
 
 // The update outside the fused kernel: after the all-reduce across ranks (a communicator is attached) and for
@@ -625,7 +637,8 @@ __global__ void __launch_bounds__(256) dsgd_apply_cols_kernel(float* __restrict_
   const int j = blockIdx.x * FRA_COLS + threadIdx.x;
   const bool mine = threadIdx.x < FRA_COLS && j < dp;
   const float g = mine ? gsum[j] : 0.0f;
-  fra_update_and_scalars(g, k_total, j, dp, w, ds, lr, lambda, sc, redpart, fred, &is_last);
+  const float wj = mine ? w[j] : 0.0f, dsj = mine ? ds[j] : 0.0f;
+  fra_update_and_scalars(g, k_total, j, dp, w, wj, dsj, lr, lambda, sc, redpart, fred, &is_last);
 }
 
 // s and |w|^2 for weights that were set from outside (dsgd_set_weights, the lock-free engine's weights at a loss
