@@ -808,17 +808,25 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
 // 512-slot tile because its tiles are laid out for it.  Here the HOST lays a batch out the same way when a plan is
 // created: every row of a list gets ceil(hot entries / 8) consecutive lanes of a 64-lane "virtual tile", each lane a
 // 16-byte descriptor {position of its 8 slots in the hot stream, valid slots, first / last lane of the row, label
-// sign, local row, position of ONE cold entry}.  A wave then runs a three-stage pipeline over its tiles --
-// descriptors -> stream requests (16-bit ranks + values of the hot stream from wherever the row lives, one cold
-// entry) -> cold weight gather -> arithmetic -- with all hot weights and the hot gradient in LDS exactly as in
-// dsgd_wseg_kernel (no gathers, no rank checks), one segmented scan per tile (a lane belongs to ONE row: no head /
+// sign, local row, position AND rank of ONE cold entry}.  All hot weights and the hot gradient sit in LDS exactly as
+// in dsgd_wseg_kernel (no gathers, no rank checks), one segmented scan per tile (a lane belongs to ONE row: no head /
 // trail fragments), the gate on the row's last lane, coefficients through the wave's strip.
+//
+// A step of this size is latency, not bytes (the waves of the first form waited 73 % of their cycles with 650 VALU
+// instructions each: profiles/r03_vt_pmc_and_ablation.txt), so a wave requests the descriptors of up to FOUR tiles at
+// once, then everything they point to at once -- the cold entry's weight included: the host knows its rank and stores
+// it in the descriptor -- and only then computes: two round trips per group of four tiles (the grid is sized for two
+// tiles per wave).  The rows outside the tiled streams get workgroups of their own (vt_long_row: record -> whole row
+// in registers -> cold weights), running beside the tile workgroups instead of behind them.  What an ablation then
+// found under all of it: 55 of the 67 us went to 4,096 waves finishing together and adding their active-row counts
+// to ONE address -- one atomic per workgroup: 24.6 us for B = 65,536 (dsgd_mb_grad_kernel: 40), 15.7 for 4,096 (18.4),
+// 12.3 for 3 x 100 (15.4).
 struct VtLane {          // 16 bytes, one per lane of a virtual tile (written by the host: vt_build)
   unsigned int hp;       // first of the lane's <= 8 slots in the hot stream
   unsigned int info;     // valid slots (bits 0-3) | first lane of its row (4) | last lane (5) | label > 0 (6) |
                          // has a cold entry (8) | local row of the tile (bits 16-21)
   unsigned int cp;       // the lane's cold entry in the cold stream
-  unsigned int row;      // global row (bookkeeping)
+  unsigned int crank;    // ... and its rank - hsplit (the host keeps a copy of the cold ranks: no load depends on a load)
 };
 constexpr unsigned int VT_START = 1u << 4, VT_LAST = 1u << 5, VT_YPOS = 1u << 6, VT_COLD = 1u << 8;
 
@@ -830,12 +838,15 @@ struct VtArgs {
   const float* w;
   const VtLane* lanes;          // 64 per tile
   const WorkSeg* tsegs;         // tile range of every worker's list of this step (blockIdx.y)
+  const WorkSeg* lsegs;         // ... and its range of `long_recs`: rows outside the tiled streams (more than 504 hot or
+  const MbRec* long_recs;       //     64 cold entries), one wave per row from the whole ranked CSR (vt_long_row)
+  CsrView mfull;
   int* part;
   long long* g64_base;
   long long g_stride;
   DevScalars* sc;
   float qscale, cold_scale;     // fixed-point scales of the LDS tile (per launch) and of the 64-bit accumulators
-  int part_stride, hsplit;
+  int part_stride, hsplit, gx_tiles;   // gx_tiles: workgroups per worker that walk tiles (the rest take the long rows)
 };
 
 struct VtRegs {
@@ -843,20 +854,22 @@ struct VtRegs {
   int live;               // wave-uniform: the tile exists (a tile beyond the wave's last one is requested and masked)
   unsigned int c[5];      // 20 bytes from the dword below the lane's first rank (ranks sit at any 2-byte offset)
   float4 v0, v1;
-  unsigned int cc;        // cold rank
   float cv, cw;           // cold value, cold weight
 };
 
 // stage D: the descriptors of tile t (a tile beyond the wave's last one reads the list's first tile and is masked)
 __device__ __forceinline__ void vt_issue_desc(const VtArgs& a, int t, int t_end, int lane, VtRegs& r) {
-  const int tc = t < t_end ? t : t_end - 1;
-  r.d = reinterpret_cast<const uint4*>(a.lanes)[(long long)tc * 64 + lane];
   r.live = t < t_end;
+  r.d = make_uint4(0u, 0u, 0u, 0u);
+  // (wave-uniform branch: thousands of waves re-reading the list's last tile -- what a clamped index does -- meet on
+  //  one L2 channel)
+  if (r.live) r.d = reinterpret_cast<const uint4*>(a.lanes)[(long long)t * 64 + lane];
 }
 // stage S: the lane's slots of the hot stream and its cold entry
 __device__ __forceinline__ void vt_issue_stream(const VtArgs& a, VtRegs& r) {
   typedef unsigned int u32x4u __attribute__((ext_vector_type(4), aligned(4)));
   typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  if (!r.live) return;   // (wave-uniform; vt_process masks the set)
   const unsigned int hp = r.d.x;
   const unsigned int* cb = reinterpret_cast<const unsigned int*>(a.hcol) + (hp >> 1);   // the dword holding rank hp
   const u32x4u ca = *reinterpret_cast<const u32x4u*>(cb);
@@ -865,13 +878,9 @@ __device__ __forceinline__ void vt_issue_stream(const VtArgs& a, VtRegs& r) {
   const f32x4u va = *reinterpret_cast<const f32x4u*>(a.hval + hp), vb = *reinterpret_cast<const f32x4u*>(a.hval + hp + 4);
   r.v0 = make_float4(va.x, va.y, va.z, va.w);
   r.v1 = make_float4(vb.x, vb.y, vb.z, vb.w);
-  const unsigned int cp = (r.d.y & VT_COLD) ? r.d.z : 0u;
-  r.cc = a.ccol[cp];
-  r.cv = a.cval[cp];
-}
-// stage G: the weight of the lane's cold rank (its id has landed)
-__device__ __forceinline__ void vt_issue_gather(const VtArgs& a, VtRegs& r) {
-  r.cw = a.w[a.hsplit + (int)r.cc];
+  const bool hasc = (r.d.y & VT_COLD) != 0u;
+  r.cv = a.cval[hasc ? r.d.z : 0u];
+  r.cw = a.w[a.hsplit + (hasc ? (int)r.d.w : 0)];
 }
 
 // stage P
@@ -926,12 +935,73 @@ __device__ __forceinline__ unsigned int vt_process(const VtArgs& a, const VtRegs
 #pragma unroll
   for (int k = 0; k < 8; ++k)
     if (q[k] != 0) atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(gl) + cc[k]), q[k]);
-  if (hasc && coef != 0.0f) {   // the cold entry of an active row: 64-bit global accumulator at the cold scale
+  if (hasc && coef != 0.0f && a.cold_scale != 0.0f) {   // the cold entry of an active row: 64-bit global accumulator at the cold scale
     const int qc = __float2int_rn(cv * (coef > 0.0f ? a.cold_scale : -a.cold_scale));
-    if (qc != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[a.hsplit + (int)r.cc]), (unsigned long long)(long long)qc);
+    if (qc != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[a.hsplit + (int)r.d.w]), (unsigned long long)(long long)qc);
   }
   __builtin_amdgcn_wave_barrier();
   return active ? 1u : 0u;
+}
+
+// A row outside the tiled streams (0.5 % of RCV1-like rows, 3 % of the non-zeros), one wave per row from the whole
+// ranked CSR.  The launch is as slow as its slowest wave and a batch of 65,536 rows holds ~330 of them, so the row is
+// NOT walked chunk by chunk (dsgd_wseg_kernel's w_long_row chains two dependent loads per 64 entries -- invisible
+// inside a 600 us kernel, 40 us on the critical path here): up to 2,048 non-zeros sit in registers at once (four sets
+// of eight contiguous entries per lane, sixteen 16-byte requests in flight), the cold weights are gathered in one more
+// round trip, the non-zeros stay in registers for the scatter.  The row record {first non-zero, length, label} comes
+// from the plan (no row_ptr round trip).  Longer rows (never the case for RCV1) take the chunked walk.
+struct VtLong {
+  int c[4][BT_K];
+  float v[4][BT_K];
+};
+__device__ __forceinline__ void vt_long_issue(const VtArgs& a, const MbRec& rec, int lane, VtLong& R) {
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const int off = (h * 64 + lane) * BT_K;
+    mb_load8(a.mfull, off < rec.len ? rec.st + off : rec.st, R.c[h], R.v[h]);
+  }
+}
+__device__ __forceinline__ unsigned int vt_long_finish(const VtArgs& a, const MbRec& rec, VtLong& R, const float* wl, int* gl,
+                                                       long long* __restrict__ g64, int lane) {
+  typedef __attribute__((address_space(3))) const float lds_cfloat;
+  const int H = a.hsplit;
+  int (&c)[4][BT_K] = R.c;
+  float (&v)[4][BT_K] = R.v;
+  float u[4][BT_K];
+  // cold weights: unconditional requests (hot lanes read w[0]), all of them before the first is used
+#pragma unroll
+  for (int h = 0; h < 4; ++h)
+#pragma unroll
+    for (int k = 0; k < BT_K; ++k) {
+      const bool in = (h * 64 + lane) * BT_K + k < rec.len;
+      c[h][k] = in ? c[h][k] : 0;
+      v[h][k] = in ? v[h][k] : 0.0f;
+      u[h][k] = a.w[c[h][k] < H ? 0 : c[h][k]];
+    }
+  float t = 0.0f;
+#pragma unroll
+  for (int h = 0; h < 4; ++h)
+#pragma unroll
+    for (int k = 0; k < BT_K; ++k) {
+      const float wh = *(lds_cfloat*)(unsigned int)((c[h][k] < H ? c[h][k] : 0) << 2);
+      t += filt(v[h][k] * (c[h][k] < H ? wh : u[h][k]));   // ref: math/Sparse.scala:46
+    }
+  const float d = group_sum<64>(t);
+  if (rec.y * d < 0.0f) return 0u;                          // ref: core/ml/SparseSVM.scala:27-28
+  const float ch = rec.y * a.qscale, cc = rec.y * a.cold_scale;
+#pragma unroll
+  for (int h = 0; h < 4; ++h)
+#pragma unroll
+    for (int k = 0; k < BT_K; ++k) {
+      if (c[h][k] < H) {
+        const int q = __float2int_rn(v[h][k] * ch);
+        if (q != 0) atomicAdd(&gl[c[h][k]], q);
+      } else {
+        const int q = __float2int_rn(v[h][k] * cc);
+        if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[c[h][k]]), (unsigned long long)(long long)q);
+      }
+    }
+  return lane == 0 ? 1u : 0u;
 }
 
 __global__ void __launch_bounds__(1024) dsgd_vt_grad_kernel(VtArgs a) {
@@ -945,46 +1015,118 @@ __global__ void __launch_bounds__(1024) dsgd_vt_grad_kernel(VtArgs a) {
   float* strip = strips + wave * 64;
   int* gl = reinterpret_cast<int*>(strips + 16 * 64);
   const WorkSeg seg = a.tsegs[blockIdx.y];
+  const WorkSeg ls = a.lsegs[blockIdx.y];
   long long* g64 = a.g64_base + (long long)blockIdx.y * a.g_stride;
-  const int stride = (int)gridDim.x * 16, t_end = (int)seg.end;
+  // the first gx_t workgroups of a worker walk its tiles, the others (gridDim.x - gx_t, when the list holds rows outside
+  // the tiled streams) take those rows, one wave per row
+  const int gx_t = a.gx_tiles;
+  const bool tile_wg = (int)blockIdx.x < gx_t;
+  const int stride = gx_t * 16, t_end = (int)seg.end;
   int tile = (int)seg.begin + (int)blockIdx.x * 16 + wave;
-  VtRegs A, B, C, D;
-  // the first descriptors and stream requests go out before the LDS tiles are set up (they need neither)
-  vt_issue_desc(a, tile, t_end, lane, A);
-  vt_issue_desc(a, tile + stride, t_end, lane, B);
-  vt_issue_desc(a, tile + 2 * stride, t_end, lane, C);
+  const long long l_stride = (long long)((int)gridDim.x - gx_t) * 16;
+  long long lt = ls.begin + (long long)((int)blockIdx.x - gx_t) * 16 + wave;
   if ((unsigned int)(unsigned long long)(__attribute__((address_space(3))) float*)lds != 0u) {
     if (tid == 0) atomicOr(&a.sc->err, 2);
     return;
   }
-  wg_zero(gl, H + 64, tid, 1024);
-  vt_issue_stream(a, A);
-  vt_issue_stream(a, B);
-  wg_copy_in(wl, a.w, H, tid, 1024, is_aligned16(a.w));
-  if (tid == 0) wl[H] = 0.0f;
-  vt_issue_gather(a, A);
-  __syncthreads();
   unsigned int n_act = 0;
-  if (tile < t_end) {
-    // iteration i: descriptors of tile i+3, stream of i+2 (its descriptors landed), cold weight of i+1, arithmetic of i
-#define DSGD_VT(CUR, N1, N2, N3)                           \
-  vt_issue_desc(a, tile + 3 * stride, t_end, lane, N3);    \
-  vt_issue_stream(a, N2);                                  \
-  vt_issue_gather(a, N1);                                  \
-  n_act += vt_process(a, CUR, strip, gl, g64);
-    for (;;) {
-      DSGD_VT(A, B, C, D) tile += stride; if (tile >= t_end) break;
-      DSGD_VT(B, C, D, A) tile += stride; if (tile >= t_end) break;
-      DSGD_VT(C, D, A, B) tile += stride; if (tile >= t_end) break;
-      DSGD_VT(D, A, B, C) tile += stride; if (tile >= t_end) break;
+  // (the two kinds of workgroup share no code between their requests and their arithmetic: with the LDS set-up in a
+  //  common stretch both register files -- four tile sets, a whole long row -- were live across it and spilled)
+  if (tile_wg) {
+    VtRegs A, B, C, D;
+    // round trip 1: the descriptors of the wave's first four tiles; the accumulators are cleared under it
+    vt_issue_desc(a, tile, t_end, lane, A);
+    vt_issue_desc(a, tile + stride, t_end, lane, B);
+    vt_issue_desc(a, tile + 2 * stride, t_end, lane, C);
+    vt_issue_desc(a, tile + 3 * stride, t_end, lane, D);
+    wg_zero(gl, H + 64, tid, 1024);
+    // round trip 2: everything the descriptors point to, and the weight tile
+    vt_issue_stream(a, A);
+    vt_issue_stream(a, B);
+    vt_issue_stream(a, C);
+    vt_issue_stream(a, D);
+    wg_copy_in(wl, a.w, H, tid, 1024, is_aligned16(a.w));
+    if (tid == 0) wl[H] = 0.0f;
+    __syncthreads();
+    for (;;) {   // (wave-uniform) groups of four tiles: two round trips each
+      n_act += vt_process(a, A, strip, gl, g64);
+      n_act += vt_process(a, B, strip, gl, g64);
+      n_act += vt_process(a, C, strip, gl, g64);
+      n_act += vt_process(a, D, strip, gl, g64);
+      tile += 4 * stride;
+      if (tile >= t_end) break;
+      vt_issue_desc(a, tile, t_end, lane, A);
+      vt_issue_desc(a, tile + stride, t_end, lane, B);
+      vt_issue_desc(a, tile + 2 * stride, t_end, lane, C);
+      vt_issue_desc(a, tile + 3 * stride, t_end, lane, D);
+      vt_issue_stream(a, A);
+      vt_issue_stream(a, B);
+      vt_issue_stream(a, C);
+      vt_issue_stream(a, D);
     }
-#undef DSGD_VT
+  } else {
+    VtLong LR;
+    MbRec lrec;
+    lrec.st = 0;
+    lrec.len = 0;
+    lrec.y = 0.0f;
+    if (lt < ls.end) lrec = a.long_recs[lt];                                        // round trip 1
+    wg_zero(gl, H + 64, tid, 1024);
+    if (lrec.len != 0 && lrec.len <= 4 * 64 * BT_K) vt_long_issue(a, lrec, lane, LR);   // round trip 2
+    wg_copy_in(wl, a.w, H, tid, 1024, is_aligned16(a.w));
+    if (tid == 0) wl[H] = 0.0f;
+    __syncthreads();
+    for (; lt < ls.end; lt += l_stride) {   // (wave-uniform)
+      const bool first = lrec.len != 0;   // (wave-uniform) the row requested before the barrier
+      const MbRec rec = first ? lrec : a.long_recs[lt];
+      lrec.len = 0;
+      if (rec.len <= 4 * 64 * BT_K) {
+        if (!first) vt_long_issue(a, rec, lane, LR);
+        n_act += vt_long_finish(a, rec, LR, wl, gl, g64, lane);
+      } else {   // beyond the register sets (never the case for RCV1): dsgd_mb_grad_kernel's chunked walk
+        BtLds L;
+        L.hl = H;
+        L.acc = gl;
+        L.cbits = nullptr;
+        L.g64 = g64;
+        const MbWeights wload{wl, a.w, H};
+        float acc = 0.0f;
+        for (int off = lane * BT_K; off < rec.len; off += 64 * BT_K) {
+          int c[BT_K];
+          float v[BT_K];
+          mb_load8(a.mfull, rec.st + off, c, v);
+#pragma unroll
+          for (int k = 0; k < BT_K; ++k)
+            if (off + k < rec.len) acc += filt(v[k] * wload(c[k]));
+        }
+        const float d = group_sum<64>(acc);
+        if (!(rec.y * d < 0.0f)) {
+          for (int off = lane * BT_K; off < rec.len; off += 64 * BT_K) {
+            int c[BT_K];
+            float v[BT_K];
+            mb_load8(a.mfull, rec.st + off, c, v);
+#pragma unroll
+            for (int k = 0; k < BT_K; ++k)   // (hot ranks at the launch's scale, cold ranks at the cold one)
+              if (off + k < rec.len) bt_add<2>(L, nullptr, c[k], v[k] * rec.y, c[k] < H ? a.qscale : a.cold_scale);
+          }
+          n_act += lane == 0 ? 1u : 0u;
+        }
+      }
+    }
   }
+  // active rows: ONE global atomic per workgroup.  (One per wave -- 4,096 atomics on one address when the waves of a
+  // short launch all finish together -- queued up for 40 us: an ablation with every request and all the arithmetic
+  // switched off still took 55 of this kernel's first 67 us.)
+  n_act = wave_sum_u32(n_act);
+  if (lane == 0) reinterpret_cast<unsigned int*>(strip)[0] = n_act;   // (the strips are free: the tiles are done)
   __syncthreads();
   int* mine = a.part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * a.part_stride;
   wg_copy_out(mine, gl, H, tid, 1024, is_aligned16(mine) && is_aligned16(gl));
-  n_act = wave_sum_u32(n_act);
-  if (lane == 0 && n_act) atomicAdd(&a.sc->n_active, (unsigned long long)n_act);
+  if (tid == 0) {
+    unsigned int tot = 0;
+    for (int i = 0; i < 16; ++i) tot += reinterpret_cast<const unsigned int*>(strips + i * 64)[0];
+    if (tot) atomicAdd(&a.sc->n_active, (unsigned long long)tot);
+  }
 }
 
 // ======================================================================================================

@@ -126,9 +126,10 @@ struct dsgd_plan {
   // virtual tiles (dsgd_vt_grad_kernel): the lists laid out over the split streams, built at the first run that needs them
   std::vector<int> h_idx;       // host copy of the lists
   VtLane* d_vt_lanes = nullptr; // 64 descriptors per tile
-  WorkSeg* d_vt_segs = nullptr; // tile range of every list
+  WorkSeg* d_vt_segs = nullptr; // tile range of every list, then (n_lists further entries) its range of d_vt_long
+  MbRec* d_vt_long = nullptr;   // rows of the lists that sit in no tile (long-row list, more than 64 cold entries)
   std::vector<long long> vt_off;       // n_lists + 1 tile offsets
-  std::vector<int> vt_grid, vt_shift;  // per step: workgroups per worker, fixed-point shift (rows per workgroup)
+  std::vector<int> vt_grid, vt_gxt, vt_shift;  // per step: workgroups per worker, those of them that walk tiles, shift
   long long vt_layout = -1;     // the layout generation the tiles were built for (-1: not built)
   bool vt_ok = false;           // every row of every list sits in the tiled streams
 };
@@ -165,6 +166,7 @@ struct dsgd_ctx {
   std::vector<long long> h_row_ptr;     // host copy of the internal row_ptr (tile building at layout time)
   std::vector<long long> h_crow_ptr;    // cold ENTRIES before each row
   std::vector<long long> h_hrp, h_ctp;  // slot offsets of the hot / cold stream (virtual tiles are built from them)
+  std::vector<unsigned short> h_ccol;   // host copy of the 16-bit cold ranks (a virtual tile's descriptor carries its cold rank)
   long long layout_gen = 0;             // bumped whenever the split streams are rebuilt
   bool vt_enable = true;                // DSGD_VT=0: index-list steps of resident plans through dsgd_mb_grad_kernel
   int vt_tpw = 2;                       // DSGD_VT_TPW: virtual tiles per wave the grid is sized for
@@ -548,16 +550,21 @@ static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
   p->vt_ok = false;
   (void)hipFree(p->d_vt_lanes);
   (void)hipFree(p->d_vt_segs);
+  (void)hipFree(p->d_vt_long);
   p->d_vt_lanes = nullptr;
   p->d_vt_segs = nullptr;
+  p->d_vt_long = nullptr;
   const int H = std::min(c->hsplit, c->dp);
   const long long n_lists = (long long)p->n_steps * p->n_workers;
   if (!c->cold_col16 || c->dp <= H || c->hot_nnz + WS_PAD >= (1LL << 32) || c->coldm_nnz + WS_PAD >= (1LL << 32)) return DSGD_OK;
   if (c->h_hrp.size() != (size_t)c->n_rows + 1 || (long long)p->h_idx.size() != p->offsets[n_lists]) return DSGD_OK;
+  if ((long long)c->h_ccol.size() != c->coldm_nnz) return DSGD_OK;
   const std::vector<long long>&hrp = c->h_hrp, &ctp = c->h_ctp, &crp = c->h_crow_ptr;
   std::vector<VtLane> lanes;
   lanes.reserve((size_t)p->offsets[n_lists] * 10);
   std::vector<int> tile_rows;
+  std::vector<MbRec> long_rows;
+  std::vector<long long> long_off((size_t)n_lists + 1, 0);
   p->vt_off.assign((size_t)n_lists + 1, 0);
   const VtLane empty{0u, 0u, 0u, 0u};
   for (long long li = 0; li < n_lists; ++li) {
@@ -566,7 +573,14 @@ static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
       const long long r = p->h_idx[(size_t)t];
       if (r < 0 || r >= c->n_rows) return DSGD_OK;       // (the mb kernel reports the bad index)
       const long long hot = hrp[r + 1] - hrp[r], cold = crp[r + 1] - crp[r];
-      if (hot <= 0 || cold > 64) return DSGD_OK;          // long-row list / too many cold entries for one tile
+      if (hot <= 0 || cold > 64) {   // long-row list / too many cold entries for a tile: one wave per row, whole CSR
+        MbRec lr;
+        lr.st = c->h_row_ptr[(size_t)r];
+        lr.len = (int)(c->h_row_ptr[(size_t)r + 1] - c->h_row_ptr[(size_t)r]);
+        lr.y = (float)c->h_label[(size_t)r];
+        long_rows.push_back(lr);
+        continue;
+      }
       const int nl = (int)std::max<long long>(std::max<long long>((hot + 7) / 8, cold), 1);
       if (used + nl > 64) {                               // close the tile
         lanes.resize(lanes.size() + (size_t)(64 - used), empty);
@@ -583,7 +597,7 @@ static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
         L.info = cnt | (j == 0 ? VT_START : 0u) | (j == nl - 1 ? VT_LAST : 0u) | ypos | (j < cold ? VT_COLD : 0u) |
                  ((unsigned int)rows << 16);
         L.cp = j < cold ? (unsigned int)(ctp[r] + j) : 0u;
-        L.row = (unsigned int)r;
+        L.crank = j < cold ? (unsigned int)c->h_ccol[(size_t)(ctp[r] + j)] : 0u;
         lanes.push_back(L);
       }
       used += nl;
@@ -592,12 +606,18 @@ static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
     lanes.resize(lanes.size() + (size_t)(64 - used), empty);   // (a list is never empty: its last tile is open)
     tile_rows.push_back(rows);
     p->vt_off[(size_t)li + 1] = (long long)tile_rows.size();
+    long_off[(size_t)li + 1] = (long long)long_rows.size();
   }
   // per step: the grid (workgroups per worker) and the fixed-point shift from the rows ONE workgroup can meet
   p->vt_grid.assign((size_t)p->n_steps, 1);
+  p->vt_gxt.assign((size_t)p->n_steps, 1);
   p->vt_shift.assign((size_t)p->n_steps, 21);
   const long long per_worker = std::max<long long>(1, c->n_cu / p->n_workers);
-  std::vector<WorkSeg> segs((size_t)n_lists);
+  std::vector<WorkSeg> segs((size_t)n_lists * 2);
+  for (long long li = 0; li < n_lists; ++li) {
+    segs[(size_t)(n_lists + li)].begin = long_off[(size_t)li];
+    segs[(size_t)(n_lists + li)].end = long_off[(size_t)li + 1];
+  }
   for (long long s = 0; s < p->n_steps; ++s) {
     long long max_t = 1;
     for (int k = 0; k < p->n_workers; ++k) {
@@ -606,7 +626,12 @@ static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
       segs[(size_t)li].end = p->vt_off[(size_t)li + 1];
       max_t = std::max(max_t, segs[(size_t)li].end - segs[(size_t)li].begin);
     }
-    const long long gx = std::max<long long>(1, std::min(per_worker, (max_t + 16LL * c->vt_tpw - 1) / (16LL * c->vt_tpw)));
+    long long max_long = 0;
+    for (int k = 0; k < p->n_workers; ++k)
+      max_long = std::max(max_long, long_off[(size_t)(s * p->n_workers + k) + 1] - long_off[(size_t)(s * p->n_workers + k)]);
+    // workgroups of their own for the rows outside the tiled streams (one wave per row), beside the tile workgroups
+    const long long gl = max_long ? std::max<long long>(1, std::min<long long>((max_long + 15) / 16, std::max<long long>(1, per_worker / 8))) : 0;
+    const long long gx = std::max<long long>(1, std::min(per_worker - gl, (max_t + 16LL * c->vt_tpw - 1) / (16LL * c->vt_tpw)));
     long long worst = 1;
     std::vector<long long> rows_of((size_t)gx);
     for (int k = 0; k < p->n_workers; ++k) {
@@ -615,15 +640,20 @@ static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
       for (long long t = sg.begin; t < sg.end; ++t) rows_of[(size_t)(((t - sg.begin) / 16) % gx)] += tile_rows[(size_t)t];
       for (long long v : rows_of) worst = std::max(worst, v);
     }
+    if (gl) worst = std::max(worst, (max_long + 16 * gl - 1) / (16 * gl) * 16);   // rows one long-row workgroup can meet
     int bits = 0;
     while ((1LL << bits) < worst) ++bits;
-    p->vt_grid[(size_t)s] = (int)gx;
+    p->vt_gxt[(size_t)s] = (int)gx;
+    p->vt_grid[(size_t)s] = (int)(gx + gl);
     p->vt_shift[(size_t)s] = std::min(21, 30 - bits);   // (<= 21: the fixed-point conversion is one fma against 1.5 * 2^23)
   }
   HIP_TRY(hipMalloc(&p->d_vt_lanes, sizeof(VtLane) * std::max<size_t>(lanes.size(), 64)));
-  HIP_TRY(hipMalloc(&p->d_vt_segs, sizeof(WorkSeg) * (size_t)n_lists));
+  HIP_TRY(hipMalloc(&p->d_vt_segs, sizeof(WorkSeg) * segs.size()));
+  HIP_TRY(hipMalloc(&p->d_vt_long, sizeof(MbRec) * std::max<size_t>(long_rows.size(), 1)));
   HIP_TRY(hipMemcpy(p->d_vt_lanes, lanes.data(), sizeof(VtLane) * lanes.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(p->d_vt_segs, segs.data(), sizeof(WorkSeg) * (size_t)n_lists, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->d_vt_segs, segs.data(), sizeof(WorkSeg) * segs.size(), hipMemcpyHostToDevice));
+  if (!long_rows.empty())
+    HIP_TRY(hipMemcpy(p->d_vt_long, long_rows.data(), sizeof(MbRec) * long_rows.size(), hipMemcpyHostToDevice));
   p->vt_ok = true;
   return DSGD_OK;
 }
@@ -641,6 +671,9 @@ static int launch_grad_vt(dsgd_ctx* c, dsgd_plan* p, long long step) {
   a.w = c->d_w;
   a.lanes = p->d_vt_lanes;
   a.tsegs = p->d_vt_segs + step * p->n_workers;
+  a.lsegs = p->d_vt_segs + ((long long)p->n_steps + step) * p->n_workers;
+  a.long_recs = p->d_vt_long;
+  a.mfull = view(c);
   a.part = c->d_part;
   a.g64_base = c->d_g64;
   a.g_stride = c->dp;
@@ -649,6 +682,7 @@ static int launch_grad_vt(dsgd_ctx* c, dsgd_plan* p, long long step) {
   a.cold_scale = c->fix_scale;
   a.part_stride = c->part_stride;
   a.hsplit = H;
+  a.gx_tiles = p->vt_gxt[(size_t)step];
   const size_t lds = sizeof(float) * (size_t)(((H + 4) & ~3) + 16 * 64 + H + 64);
   size_t slot = 0;
   DSGD_TRY(prof_begin(c, &slot));
@@ -907,6 +941,11 @@ static int build_split(dsgd_ctx* c) {
       hipLaunchKernelGGL(dsgd_split_fill_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, m, H, c->d_hrow_ptr, c->d_ctp,
                          c->d_hcol, c->d_hval, c->d_ccol, c->d_cval);
     HIP_TRY(hipGetLastError());
+  }
+  c->h_ccol.clear();
+  if (c->cold_col16 && c->vt_enable && c->coldm_nnz > 0) {   // (75 MB for the 8.4 M-row shard)
+    c->h_ccol.resize((size_t)c->coldm_nnz);
+    HIP_TRY(hipMemcpyAsync(c->h_ccol.data(), c->d_ccol, sizeof(unsigned short) * (size_t)c->coldm_nnz, hipMemcpyDeviceToHost, c->stream));
   }
   HostTiles ht;
   build_wave_tiles(hrp.data(), n_rows, c->h_label.data(), ht);
@@ -1907,6 +1946,7 @@ int dsgd_plan_destroy(dsgd_ctx* c, dsgd_plan* p) {
   (void)hipFree(p->d_segs);
   (void)hipFree(p->d_vt_lanes);
   (void)hipFree(p->d_vt_segs);
+  (void)hipFree(p->d_vt_long);
   delete p;
   return DSGD_OK;
 }

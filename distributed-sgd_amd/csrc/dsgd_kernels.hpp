@@ -1189,23 +1189,41 @@ __global__ void __launch_bounds__(1024) dsgd_wseg_kernel(CsrView m, CsrView mful
   for (long long t = seg.long_begin + (long long)blockIdx.x * 16 + wave; t < seg.long_end; t += (long long)stride)
     w_long_row<SCATTER>(mfull, w, x, (long long)long_rows[t], n_all, n_neg, n_pos);
 
+  // Tallies: ONE global atomic per workgroup and counter.  (One per wave put 4,096 atomics on one address at the end
+  // of the launch, when every wave arrives together: they are served one after the other -- measured on the
+  // index-list kernel, where that queue was 40 of 67 us.)  The strips are free now: every wave's tiles are done.
+  n_all = wave_sum_u32(n_all);
+  n_neg = wave_sum_u32(n_neg);
+  n_pos = wave_sum_u32(n_pos);
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    unsigned int* mine3 = reinterpret_cast<unsigned int*>(x.coefw);
+    mine3[0] = n_all;
+    mine3[1] = n_neg;
+    mine3[2] = n_pos;
+  }
+  __syncthreads();
+  unsigned int t_all = 0, t_neg = 0, t_pos = 0;
+  if (tid == 0) {
+    for (int i = 0; i < 16; ++i) {
+      const unsigned int* s3 = reinterpret_cast<const unsigned int*>(strips + i * WS_COEF_STRIDE);
+      t_all += s3[0];
+      t_neg += s3[1];
+      t_pos += s3[2];
+    }
+  }
   if (SCATTER) {
-    __syncthreads();
     // this workgroup's exact partial sums, written whole (zeros included): the reduce kernels add the partials of a
     // worker in a fixed order -- no atomics, and 256 workgroups do not meet on one address
     int* mine = part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * part_stride;
     wg_copy_out(mine, x.gl, hg, tid, 1024, is_aligned16(mine) && is_aligned16(x.gl));
-    n_all = wave_sum_u32(n_all);
-    if (lane == 0 && n_all) atomicAdd(&sc->n_active, (unsigned long long)n_all);
+    if (tid == 0 && t_all) atomicAdd(&sc->n_active, (unsigned long long)t_all);
   } else {
-    n_all = wave_sum_u32(n_all);
-    n_neg = wave_sum_u32(n_neg);
-    n_pos = wave_sum_u32(n_pos);
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&sc->counts[3], (unsigned long long)(seg.row_end - seg.row_begin));
-    if (lane == 0) {
-      if (n_neg) atomicAdd(&sc->counts[0], (unsigned long long)n_neg);                          // pred == y
-      if (n_all - n_neg - n_pos) atomicAdd(&sc->counts[1], (unsigned long long)(n_all - n_neg - n_pos));  // pred == 0
-      if (n_pos) atomicAdd(&sc->counts[2], (unsigned long long)n_pos);                          // pred == -y
+    if (tid == 0) {
+      if (t_neg) atomicAdd(&sc->counts[0], (unsigned long long)t_neg);                          // pred == y
+      if (t_all - t_neg - t_pos) atomicAdd(&sc->counts[1], (unsigned long long)(t_all - t_neg - t_pos));  // pred == 0
+      if (t_pos) atomicAdd(&sc->counts[2], (unsigned long long)t_pos);                          // pred == -y
     }
   }
 }

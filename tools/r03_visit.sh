@@ -49,15 +49,15 @@ mbtrace)
   echo "== rocprofv3 kernel trace of the index-list kernels, one batch size per run"
   for C in 1x65536 1x4096 3x100; do
     ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mbtrace -o mb -- python $REPO/tools/mb_prof.py 2000000 --only=$C > /dev/null 2> $OUT/mbtrace.err )
-    f=$(find $OUT/mbtrace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && { echo "-- $C"; trace_summary "$f" | grep -E "mb_grad|fix_reduce"; } | tee -a $OUT/mb_dispatch_durations.txt
-    f=$(find $OUT/mbtrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { echo "-- $C"; grep -E "Name|mb_grad|fix_reduce" "$f" | cut -c1-200; } >> $OUT/mb_kernel_stats.csv
+    f=$(find $OUT/mbtrace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && { echo "-- $C"; trace_summary "$f" | grep -E "mb_grad|vt_grad|fix_reduce"; } | tee -a $OUT/mb_dispatch_durations.txt
+    f=$(find $OUT/mbtrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { echo "-- $C"; grep -E "Name|mb_grad|vt_grad|fix_reduce" "$f" | cut -c1-200; } >> $OUT/mb_kernel_stats.csv
     rm -rf $OUT/mbtrace
   done ;;
 mbprof)
   echo "== rocprofv3 kernel trace + PMC of the index-list kernels"
   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mbtrace -o mb -- python $REPO/tools/mb_prof.py 2000000 --quick > /dev/null 2> $OUT/mbtrace.err )
-  f=$(find $OUT/mbtrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "Name|mb_grad|fix_reduce|plan_kernel" "$f" | cut -c1-220 | tee $OUT/mb_kernel_stats.csv
-  f=$(find $OUT/mbtrace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && trace_summary "$f" | grep -E "per-kernel|mb_grad|fix_reduce" | tee $OUT/mb_dispatch_durations.txt
+  f=$(find $OUT/mbtrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "Name|mb_grad|vt_grad|fix_reduce|plan_kernel" "$f" | cut -c1-220 | tee $OUT/mb_kernel_stats.csv
+  f=$(find $OUT/mbtrace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && trace_summary "$f" | grep -E "per-kernel|mb_grad|vt_grad|fix_reduce" | tee $OUT/mb_dispatch_durations.txt
   rm -rf $OUT/mbtrace
   i=0
   for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TA_BUSY_avr"; do
@@ -65,7 +65,7 @@ mbprof)
     echo "== mb pmc pass $i: $P" | tee -a $OUT/mb_pmc_summary.txt
     ( cd /tmp && timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/mbpmc$i -o pmc -- python $REPO/tools/mb_prof.py 2000000 --quick > /dev/null 2> $OUT/mbpmc$i.err )
     f=$(find $OUT/mbpmc$i -name "*counter_collection.csv" | head -1)
-    if [ -n "$f" ]; then python tools/pmc_summary.py "$f" "dsgd_" | grep -E "mb_grad|fix_reduce" | tee -a $OUT/mb_pmc_summary.txt; else tail -3 $OUT/mbpmc$i.err; fi
+    if [ -n "$f" ]; then python tools/pmc_summary.py "$f" "dsgd_" | grep -E "mb_grad|vt_grad|fix_reduce" | tee -a $OUT/mb_pmc_summary.txt; else tail -3 $OUT/mbpmc$i.err; fi
     rm -rf $OUT/mbpmc$i $OUT/mbpmc$i.err
   done ;;
 bench)
