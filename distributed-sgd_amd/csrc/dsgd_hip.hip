@@ -245,6 +245,8 @@ struct dsgd_ctx {
   DevScalars* d_sc = nullptr;
   DevScalars* h_sc = nullptr;  // pinned
   bool s_dirty = true;
+  bool s_lazy = false;      // s and |w|^2 of the resident w are still per-block pairs in d_redpart[red_par] (fra_scalars)
+  int red_par = 0;          // the half of d_redpart the last scalar-writing kernel wrote
   bool nsq_dirty = false;   // |w|^2 stale although s is current (after dsgd_plan_kernel)
   bool have_ds = false;
   // staging for host-provided index lists
@@ -400,21 +402,38 @@ static int ensure_redpart(dsgd_ctx* c) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->d_redpart) HIP_TRY(hipFree(c->d_redpart));
   c->d_redpart = nullptr;
-  HIP_TRY(hipMalloc(&c->d_redpart, sizeof(float) * 2 * (size_t)blocks));
+  HIP_TRY(hipMalloc(&c->d_redpart, sizeof(float) * 4 * (size_t)blocks));   // two halves: see red_out
   c->redpart_cap = blocks;
   return DSGD_OK;
 }
 
-static int ensure_s(dsgd_ctx* c) {  // s = 2*lambda*(w.ds) must match the resident w
-  if (!c->s_dirty) return DSGD_OK;
-  c->nsq_dirty = false;
+// The per-block pairs (w . ds, |w|^2) live in one of two halves of d_redpart: a kernel that writes new pairs takes
+// the half the previous one did not (a lazy consumer may still be reading the old pairs in the same launch).
+static float* red_cur(dsgd_ctx* c) { return c->d_redpart + (size_t)c->red_par * 2 * (size_t)c->redpart_cap; }
+static float* red_out(dsgd_ctx* c) { return c->d_redpart + (size_t)(1 - c->red_par) * 2 * (size_t)c->redpart_cap; }
+
+// s = 2*lambda*(w.ds) must match the resident w.  allow_lazy: the caller goes on to the fused reduce + update, which
+// adds the pairs itself; everybody else gets the scalars finalised in DevScalars.
+static int ensure_s(dsgd_ctx* c, bool allow_lazy = false) {
   const int blocks = (c->dp + FRA_COLS - 1) / FRA_COLS;
-  DSGD_TRY(ensure_redpart(c));
-  // (the summation order of the fused step: equal weights give bit-equal s whichever kernel left it)
-  hipLaunchKernelGGL(dsgd_wstats_cols_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_w, c->d_ds, c->dp,
-                     (float)c->cfg.lambda, c->d_sc, c->d_redpart);
-  HIP_TRY(hipGetLastError());
-  c->s_dirty = false;
+  if (c->s_dirty) {
+    c->nsq_dirty = false;
+    DSGD_TRY(ensure_redpart(c));
+    // (the summation order of the fused step: equal weights give bit-equal s whichever kernel left it)
+    hipLaunchKernelGGL(dsgd_wstats_cols_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_w, c->d_ds, c->dp,
+                       (float)c->cfg.lambda, c->d_sc, red_out(c));
+    HIP_TRY(hipGetLastError());
+    c->red_par ^= 1;
+    c->s_dirty = false;
+    c->s_lazy = false;
+    return DSGD_OK;
+  }
+  if (c->s_lazy && !allow_lazy) {
+    hipLaunchKernelGGL(dsgd_scalars_finalize_kernel, dim3(1), dim3(64), 0, c->stream, red_cur(c), (unsigned int)blocks,
+                       (float)c->cfg.lambda, c->d_sc);
+    HIP_TRY(hipGetLastError());
+    c->s_lazy = false;
+  }
   return DSGD_OK;
 }
 
@@ -712,11 +731,15 @@ static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
   if (!c->fused_apply_pending) return fail(DSGD_ESTATE, "internal: no gradient partials pending");
   c->fused_apply_pending = false;
   const FusedArgs& f = c->fused_args;
+  if (c->s_dirty) return fail(DSGD_ESTATE, "internal: regulariser scalar not prepared");
   if (!c->comm) {
     hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel<true>, dim3(cblocks), dim3(1024), 0, c->stream, c->d_g64, (long long)dp,
                        n_workers, c->d_w, c->d_ds, dp, f.hg, c->d_part, c->part_stride, f.n_wg, f.hc, f.nc, c->d_partc, c->partc_stride, f.n_wgc,
-                       f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart, (float*)nullptr);
+                       f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, red_out(c), (float*)nullptr,
+                       (const float*)red_cur(c), c->s_lazy ? 1 : 0);
     HIP_TRY(hipGetLastError());
+    c->red_par ^= 1;
+    c->s_lazy = true;   // the new pairs stay in d_redpart: the next step adds them itself, anyone else asks ensure_s
     c->s_dirty = false;
     return DSGD_OK;
   }
@@ -725,12 +748,15 @@ static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr) {
   // ordered on the same stream as the kernels around it, then the update
   hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel<false>, dim3(cblocks), dim3(1024), 0, c->stream, c->d_g64, (long long)dp,
                      n_workers, c->d_w, c->d_ds, dp, f.hg, c->d_part, c->part_stride, f.n_wg, f.hc, f.nc, c->d_partc, c->partc_stride, f.n_wgc,
-                     f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart, c->d_gsum);
+                     f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, red_out(c), c->d_gsum,
+                     (const float*)red_cur(c), c->s_lazy ? 1 : 0);
   HIP_TRY(hipGetLastError());
   RCCL_TRY(rccl::AllReduce(c->d_gsum, c->d_gsum, (size_t)dp, rccl::kFloat32, rccl::kSum, c->comm, c->stream));
   hipLaunchKernelGGL(dsgd_apply_cols_kernel, dim3(cblocks), dim3(256), 0, c->stream, c->d_w, c->d_gsum, c->d_ds, dp, k_total, lr,
-                     (float)c->cfg.lambda, c->d_sc, c->d_redpart);
+                     (float)c->cfg.lambda, c->d_sc, red_out(c), 0);
   HIP_TRY(hipGetLastError());
+  c->red_par ^= 1;
+  c->s_lazy = true;
   c->s_dirty = false;
   return DSGD_OK;
 }
@@ -1263,6 +1289,7 @@ static int launch_plan_kernel(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_se
   c->last_grad_kernel = "dsgd_plan_kernel";
   HIP_TRY(hipGetLastError());
   DSGD_TRY(prof_end(c, slot));
+  c->s_lazy = false;
   c->s_dirty = false;     // the kernel leaves s = 2*lambda*(w . ds) of the weights it ends with ...
   c->nsq_dirty = true;    // ... but not |w|^2 (needed only by dsgd_loss_acc)
   return DSGD_OK;
@@ -1761,9 +1788,11 @@ int dsgd_apply(dsgd_ctx* c, const float* g_mean, float lr) {
   DSGD_TRY(launch_permute_in(c, c->d_io, c->d_gsum));
   DSGD_TRY(ensure_redpart(c));
   hipLaunchKernelGGL(dsgd_apply_cols_kernel, dim3((c->dp + FRA_COLS - 1) / FRA_COLS), dim3(256), 0, c->stream, c->d_w,
-                     c->d_gsum, c->d_ds, c->dp, 1.0f, lr, (float)c->cfg.lambda, c->d_sc, c->d_redpart);
+                     c->d_gsum, c->d_ds, c->dp, 1.0f, lr, (float)c->cfg.lambda, c->d_sc, red_out(c), 1);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
+  c->red_par ^= 1;
+  c->s_lazy = false;
   c->s_dirty = false;
   return DSGD_OK;
 }
@@ -1804,7 +1833,7 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
     }
   }
   DSGD_TRY(ensure_g(c, n_workers));
-  DSGD_TRY(ensure_s(c));
+  DSGD_TRY(ensure_s(c, true));
   DSGD_TRY(reset_counters(c));
   DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
   DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, n_workers, mx, true));
@@ -1833,7 +1862,7 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
   }
   DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_g(c, n_workers));
-  DSGD_TRY(ensure_s(c));
+  DSGD_TRY(ensure_s(c, true));
   if (tot >= c->stream_min) {
     // whole contiguous ranges: the nnz-streaming kernel (coalesced 16-byte loads, no per-row latency chain)
     std::vector<StreamSeg> ssegs(n_workers);
@@ -1969,7 +1998,7 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
     return DSGD_OK;
   }
   DSGD_TRY(ensure_g(c, p->n_workers));
-  DSGD_TRY(ensure_s(c));
+  DSGD_TRY(ensure_s(c, true));
   if (c->vt_enable && p->vt_layout != c->layout_gen) DSGD_TRY(vt_build(c, p));
   const bool vt = c->vt_enable && p->vt_ok && p->vt_layout == c->layout_gen;
   for (int64_t s = step_begin; s < step_end; ++s) {

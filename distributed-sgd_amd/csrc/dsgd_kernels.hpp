@@ -451,7 +451,39 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_kernel(long long* g64_ba
 
 constexpr int FRA_COLS = 192;
 __device__ __forceinline__ void fra_scalars(float dot, float nsq, float lambda, DevScalars* sc,
-                                            float* __restrict__ redpart, float* fred, int* is_last);
+                                            float* __restrict__ redpart, float* fred, int* is_last, bool finalize);
+// the per-block pairs (w . ds, |w|^2) added in block order by the first wave of a workgroup: lanes take blocks
+// lane, lane + 64, ..., then a butterfly -- THE summation order of s and |w|^2, whoever runs it
+__device__ __forceinline__ void fra_sum_pairs(const float* __restrict__ redpart, unsigned int n_blocks, int lane, float& d,
+                                              float& qq) {
+  d = 0.0f;
+  qq = 0.0f;
+  for (unsigned int b0 = 0; b0 < n_blocks; b0 += 256) {   // (D + 1 = 47,237: 247 blocks, one round)
+    // eight requests in flight, then the adds in block order (a loop of load + add pays one round trip per iteration)
+    float x[4], y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned int b = b0 + 64u * i + lane;
+      const unsigned int bc = b < n_blocks ? b : n_blocks - 1;
+      // (agent-scope loads: served past this CU's L1)
+      x[i] = __hip_atomic_load(&redpart[2 * bc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      y[i] = __hip_atomic_load(&redpart[2 * bc + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned int b = b0 + 64u * i + lane;
+      if (b < n_blocks) {
+        d += x[i];
+        qq += y[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    d += __shfl_xor(d, off, 64);
+    qq += __shfl_xor(qq, off, 64);
+  }
+}
 // Tail shared by dsgd_fix_reduce_apply_kernel<true> and dsgd_apply_cols_kernel: lane tid < FRA_COLS of a block owns
 // column j = block * FRA_COLS + tid and holds the sum of the regularised gradients over the workers; mean, update, and
 // the block's share of w . ds and |w|^2 (combined by the last block to arrive, in block order: reproducible).
@@ -460,7 +492,7 @@ __device__ __forceinline__ void fra_scalars(float dot, float nsq, float lambda, 
 __device__ __forceinline__ void fra_update_and_scalars(float gsum, float k_total, int j, int dp, float* __restrict__ w,
                                                        float wj, float dsj, float lr, float lambda,
                                                        DevScalars* sc, float* __restrict__ redpart, float* fred,
-                                                       int* is_last) {
+                                                       int* is_last, bool finalize) {
   const int tid = threadIdx.x;
   float dot = 0.0f, nsq = 0.0f;
   if (tid < FRA_COLS && j < dp) {
@@ -470,15 +502,21 @@ __device__ __forceinline__ void fra_update_and_scalars(float gsum, float k_total
     dot = filt(wn * dsj);
     nsq = wn * wn;
   }
-  fra_scalars(dot, nsq, lambda, sc, redpart, fred, is_last);
+  fra_scalars(dot, nsq, lambda, sc, redpart, fred, is_last, finalize);
 }
 
 // s = 2 * lambda * (w . ds) and |w|^2 from the per-column terms of a block (lanes tid < FRA_COLS; zeros elsewhere):
-// wave sums, the block's pair published write-through, the last block to arrive adds the pairs in block order.  ONE
-// summation order for every kernel that leaves these scalars (the fused step, the update behind an all-reduce,
-// dsgd_wstats_cols_kernel after dsgd_set_weights): equal weights give bit-equal scalars whichever path wrote them.
+// wave sums, the block's pair published, and -- `finalize` -- the last block to arrive adds the pairs in block order
+// (fra_sum_pairs).  ONE summation order for every kernel that leaves these scalars (the fused step, the update behind an
+// all-reduce, dsgd_wstats_cols_kernel after dsgd_set_weights): equal weights give bit-equal scalars whichever path
+// wrote them.
+// finalize = false (round 3, the steps of the synchronous path): the pairs are left in `redpart` and whoever needs
+// the scalars next adds them itself -- the next step's fused kernel in every block's first wave, anything else through
+// dsgd_scalars_finalize_kernel.  The finalising tail is a chain of dependent round trips at the end of every step:
+// store acknowledgement -> 247 returning atomics on ONE address (served one after the other) -> the last block's
+// loads -> its store; 3-4 of the kernel's 9-10 us on a small batch.
 __device__ __forceinline__ void fra_scalars(float dot, float nsq, float lambda, DevScalars* sc,
-                                            float* __restrict__ redpart, float* fred, int* is_last) {
+                                            float* __restrict__ redpart, float* fred, int* is_last, bool finalize) {
   const int tid = threadIdx.x;
   if (tid < 256) {   // the finishing waves (FRA_COLS = 192 -> three of them carry data)
 #pragma unroll
@@ -497,29 +535,35 @@ __device__ __forceinline__ void fra_scalars(float dot, float nsq, float lambda, 
     const float qq = (fred[4] + fred[5]) + (fred[6] + fred[7]);
     __hip_atomic_store(&redpart[2 * blockIdx.x], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&redpart[2 * blockIdx.x + 1], qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // the two partials are write-through stores: once they are acknowledged the ticket may be taken (a full
-    // __threadfence() here writes back the L2's dirty lines -- this block's weights -- ~3.5 us per block)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int t = atomicAdd(&sc->ticket, 1u);
-    *is_last = (t == gridDim.x - 1);
+    if (finalize) {
+      // the two partials are write-through stores: once they are acknowledged the ticket may be taken (a full
+      // __threadfence() here writes back the L2's dirty lines -- this block's weights -- ~3.5 us per block)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned int t = atomicAdd(&sc->ticket, 1u);
+      *is_last = (t == gridDim.x - 1);
+    }
   }
+  if (!finalize) return;
   __syncthreads();
-  if (*is_last && tid < 64) {   // (agent-scope loads below: served past this CU's L1)
-    float d = 0.0f, qq = 0.0f;
-    for (unsigned int b = tid; b < gridDim.x; b += 64) {   // fixed assignment and order: reproducible
-      d += __hip_atomic_load(&redpart[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      qq += __hip_atomic_load(&redpart[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      d += __shfl_xor(d, off, 64);
-      qq += __shfl_xor(qq, off, 64);
-    }
+  if (*is_last && tid < 64) {
+    float d, qq;
+    fra_sum_pairs(redpart, gridDim.x, tid, d, qq);
     if (tid == 0) {
       sc->s_reg = lambda * 2.0f * d;
       sc->wnorm2 = qq;
       sc->ticket = 0;
     }
+  }
+}
+
+// the scalars from the pairs a finalize = false kernel left behind (one wave; dsgd_hip.hip: ensure_s)
+__global__ void __launch_bounds__(64) dsgd_scalars_finalize_kernel(const float* __restrict__ redpart, unsigned int n_blocks,
+                                                                  float lambda, DevScalars* sc) {
+  float d, qq;
+  fra_sum_pairs(redpart, n_blocks, threadIdx.x, d, qq);
+  if (threadIdx.x == 0) {
+    sc->s_reg = lambda * 2.0f * d;
+    sc->wnorm2 = qq;
   }
 }
 
@@ -549,14 +593,28 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
                                                                     int n_wgc, double inv_scale, double inv_scale_cold,
                                                                     float lr, float lambda, DevScalars* sc,
                                                                     float* __restrict__ redpart,
-                                                                    float* __restrict__ gsum_out) {
+                                                                    float* __restrict__ gsum_out,
+                                                                    const float* __restrict__ redpart_in, int s_lazy) {
   __shared__ __attribute__((aligned(16))) long long red[FRA_PHASES][FRA_COLS];   // 32 KB
   __shared__ float fred[8];
   __shared__ int is_last;
-  const float s = sc->s_reg;
-  const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+  __shared__ float s_sh;
   const int tid = threadIdx.x;
+  // s of the weights this step starts from: final in DevScalars, or (s_lazy) still the previous step's per-block pairs
+  // (redpart_in: the OTHER half of the pair buffer -- a fast block of this launch publishes its new pair while a slow
+  // one still reads the old ones)
+  if (s_lazy) {
+    if (tid < 64) {
+      float d, qq;
+      fra_sum_pairs(redpart_in, gridDim.x, tid, d, qq);
+      if (tid == 0) s_sh = lambda * 2.0f * d;
+    }
+  } else if (tid == 0) {
+    s_sh = sc->s_reg;
+  }
   const int cg = tid % FRA_GROUPS, ph = tid / FRA_GROUPS;   // (ph == FRA_PHASES: the 16 spare lanes)
+  float s = 0.0f;
+  bool add = false;
   const int j0 = blockIdx.x * FRA_COLS;
   const int jg = j0 + 4 * cg;
   // where the thread's four columns live: 1 = all in the hot partials, 2 = all in the cold partials (16-byte loads),
@@ -570,8 +628,17 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
   // everything the finishing lanes need that does not depend on the partials is requested NOW, next to the partials
   // (their round trips overlap): the column's weight and dimSparsity value, the first worker's 64-bit accumulator
   const bool fin = tid < FRA_COLS && j < dp;
-  const float wj = (APPLY && fin) ? w[j] : 0.0f, dsj = (APPLY && fin) ? ds[j] : 0.0f;
-  long long tot_next = fin ? g64_base[j] : 0;
+  // (relaxed ATOMIC loads: a plain load is sunk by the compiler behind the barriers, to where its result is consumed,
+  //  and its round trip is paid a second time there; an atomic one stays where it is written)
+  float wj = 0.0f, dsj = 0.0f;
+  long long tot_next = 0;
+  if (fin) {
+    if (APPLY) {
+      wj = __hip_atomic_load(&w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dsj = __hip_atomic_load(&ds[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    tot_next = __hip_atomic_load(&g64_base[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   float gsum = 0.0f;        // Vec.sum over the workers, folded left with the Sparse filter after every add
   for (int k = 0; k < n_workers; ++k) {
     long long q[4] = {0, 0, 0, 0};
@@ -606,8 +673,13 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
       for (int e = 0; e < 4; ++e) red[ph][4 * cg + e] = q[e];
     }
     __syncthreads();
+    if (k == 0) {
+      s = s_sh;
+      add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+    }
     long long tot = tot_next;
-    if (fin && k + 1 < n_workers) tot_next = (g64_base + (long long)(k + 1) * g_stride)[j];   // (under the barrier below)
+    if (fin && k + 1 < n_workers)   // (under the barrier below)
+      tot_next = __hip_atomic_load(&(g64_base + (long long)(k + 1) * g_stride)[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (fin) {
       long long* g64 = g64_base + (long long)k * g_stride;
       if (tot != 0) g64[j] = 0;
@@ -622,7 +694,7 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
     if (tid < FRA_COLS && j < dp) gsum_out[j] = gsum;
     return;
   }
-  fra_update_and_scalars(gsum, (float)n_workers, j, dp, w, wj, dsj, lr, lambda, sc, redpart, fred, &is_last);
+  fra_update_and_scalars(gsum, (float)n_workers, j, dp, w, wj, dsj, lr, lambda, sc, redpart, fred, &is_last, false);
 }
 
 // The update outside the fused kernel: after the all-reduce across ranks (a communicator is attached) and for
@@ -631,14 +703,15 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
 // engine without one.
 __global__ void __launch_bounds__(256) dsgd_apply_cols_kernel(float* __restrict__ w, const float* __restrict__ gsum,
                                                              const float* __restrict__ ds, int dp, float k_total, float lr,
-                                                             float lambda, DevScalars* sc, float* __restrict__ redpart) {
+                                                             float lambda, DevScalars* sc, float* __restrict__ redpart,
+                                                             int finalize) {
   __shared__ float fred[8];
   __shared__ int is_last;
   const int j = blockIdx.x * FRA_COLS + threadIdx.x;
   const bool mine = threadIdx.x < FRA_COLS && j < dp;
   const float g = mine ? gsum[j] : 0.0f;
   const float wj = mine ? w[j] : 0.0f, dsj = mine ? ds[j] : 0.0f;
-  fra_update_and_scalars(g, k_total, j, dp, w, wj, dsj, lr, lambda, sc, redpart, fred, &is_last);
+  fra_update_and_scalars(g, k_total, j, dp, w, wj, dsj, lr, lambda, sc, redpart, fred, &is_last, finalize != 0);
 }
 
 // s and |w|^2 for weights that were set from outside (dsgd_set_weights, the lock-free engine's weights at a loss
@@ -655,7 +728,7 @@ __global__ void __launch_bounds__(256) dsgd_wstats_cols_kernel(const float* __re
     dot = filt(wn * ds[j]);
     nsq = wn * wn;
   }
-  fra_scalars(dot, nsq, lambda, sc, redpart, fred, &is_last);
+  fra_scalars(dot, nsq, lambda, sc, redpart, fred, &is_last, true);
 }
 
 // segmented scan over the 64 lanes of a wave, DPP only (no LDS round trip)
