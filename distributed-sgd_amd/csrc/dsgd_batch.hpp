@@ -815,8 +815,9 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
 // A step of this size is latency, not bytes (the waves of the first form waited 73 % of their cycles with 650 VALU
 // instructions each: profiles/r03_vt_pmc_and_ablation.txt), so a wave requests the descriptors of up to FOUR tiles at
 // once, then everything they point to at once -- the cold entry's weight included: the host knows its rank and stores
-// it in the descriptor -- and only then computes: two round trips per group of four tiles (the grid is sized for two
-// tiles per wave).  The rows outside the tiled streams get workgroups of their own (vt_long_row: record -> whole row
+// it in the descriptor -- and only then computes: two round trips per group of four tiles (the grid is sized for one
+// tile per wave; two to three at B = 65,536, where the 256 CUs cap it).  The rows outside the tiled streams get
+// workgroups of their own (vt_long_row: record -> whole row
 // in registers -> cold weights), running beside the tile workgroups instead of behind them.  What an ablation then
 // found under all of it: 55 of the 67 us went to 4,096 waves finishing together and adding their active-row counts
 // to ONE address -- one atomic per workgroup: 24.6 us for B = 65,536 (dsgd_mb_grad_kernel: 40), 15.7 for 4,096 (18.4),

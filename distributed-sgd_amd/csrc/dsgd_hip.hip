@@ -169,7 +169,7 @@ struct dsgd_ctx {
   std::vector<unsigned short> h_ccol;   // host copy of the 16-bit cold ranks (a virtual tile's descriptor carries its cold rank)
   long long layout_gen = 0;             // bumped whenever the split streams are rebuilt
   bool vt_enable = true;                // DSGD_VT=0: index-list steps of resident plans through dsgd_mb_grad_kernel
-  int vt_tpw = 2;                       // DSGD_VT_TPW: virtual tiles per wave the grid is sized for
+  int vt_tpw = 1;                       // DSGD_VT_TPW: virtual tiles per wave the grid is sized for (measured: 1 beats 2-4 up to B = 65,536)
   std::vector<signed char> h_label;
   // wave tiles over d_hcol/d_hval
   WTile* d_wtiles = nullptr;
