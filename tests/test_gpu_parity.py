@@ -638,6 +638,78 @@ def test_mid_size_index_lists_match_oracle(mid, k_workers, batch):
     np.testing.assert_array_equal(eng.get_weights(), w2)   # integer sums, fixed order: bit-reproducible
 
 
+def plan_step(o, eng, lists, lr, family):
+    """list_step through a RESIDENT PLAN of one step (dsgd_plan_run: index lists as virtual tiles over the split streams
+    unless the plan kernel takes them): the same derived bound, with the shift that launch used."""
+    w0 = eng.get_weights().astype(np.float64)
+    w_ref = w0.copy()
+    plan = eng.plan([lists])
+    eng.synchronize()   # (the counters of whatever ran before)
+    eng.plan_run(plan, 0, 1, lr)
+    st = eng.synchronize()
+    plan.destroy()
+    shift = eng.tuning_info()["fix_shift"]
+    o.sync_step(w_ref, lists, lr)
+    tol_v, n_near, near_part = orb.list_bound(o, w0, w_ref, lists, lr, shift, parts=True)
+    assert st["n_samples"] == sum(len(a) for a in lists)
+    assert abs(st["n_active"] - o.last_stats["n_active"]) <= n_near, (st, o.last_stats, n_near)
+    w = eng.get_weights()
+    ratio, j = orb.worst_ratio(w, w_ref, tol_v)
+    assert ratio <= 1.0, "coordinate %d: error %.3g x its derived bound (shift %d, %d rows near the gate)" % (j, ratio, shift, n_near)
+    tight = st["n_active"] == o.last_stats["n_active"] and orb.worst_ratio(w, w_ref, tol_v - near_part)[0] <= 1.0
+    waivers.tight(family + ":gates_as_the_oracle", tight, n_near > 0, "%d rows near the gate" % n_near)
+    return ratio, shift, n_near
+
+
+@pytest.mark.parametrize("k_workers,batch", [(1, 4096), (1, 65536), (3, 4096), (4, 200), (3, 100), (2, 1)])
+def test_virtual_tiles_match_oracle(mid, k_workers, batch):
+    """The index lists of resident plans run as virtual tiles over the split streams (dsgd_vt_grad_kernel): one step
+    each from identical NON-ZERO weights against the oracle under the derived bound, three steps with the engine's
+    weights carried over (lists of 160,000-row data hold rows outside the tiled streams too: their own workgroups);
+    a plan of several steps equals its steps one plan at a time bit for bit; DSGD_VT=0 is covered by the per-request
+    tests above (same kernel as dsgd_sync_step)."""
+    data, n_train, o, eng = mid
+    rng = np.random.default_rng(7 * batch + k_workers)
+    w0 = np.zeros(data.dim + 1, dtype=np.float32)
+    hot = rng.choice(np.arange(1, data.dim + 1), size=6000, replace=False)
+    w0[hot] = rng.normal(scale=0.05, size=6000).astype(np.float32)
+    eng.set_weights(w0)
+    lr = 0.5 * 100 / batch
+    steps = batches(rng, n_train, k_workers, batch, 3)
+    for lists in steps:
+        plan_step(o, eng, lists, lr, "virtual_tiles")
+        assert eng.grad_kernel_name() == "dsgd_vt_grad_kernel"
+    w_one_by_one = eng.get_weights()
+    eng.set_weights(w0)
+    plan = eng.plan(steps)
+    eng.plan_run(plan, 0, 2, lr)
+    eng.plan_run(plan, 2, 3, lr)
+    eng.synchronize()
+    plan.destroy()
+    np.testing.assert_array_equal(eng.get_weights(), w_one_by_one)   # integer sums, fixed order: bit-reproducible
+
+
+@pytest.mark.parametrize("hsplit", [None, "3000"])
+def test_virtual_tiles_on_ragged_rows(monkeypatch, hsplit):
+    """Empty rows, one-element rows, values below the Sparse epsilon, and (DSGD_HSPLIT=3000) rows whose cold part is
+    longer than their hot part or than a tile can give lanes to (more than 64 cold entries: the long-row workgroups)."""
+    if hsplit:
+        monkeypatch.setenv("DSGD_HSPLIT", hsplit)
+    data = ragged_data(23)
+    n_train = 5000
+    o, eng = make_pair(data, 1e-5, n_train)
+    rng = np.random.default_rng(23)
+    with eng:
+        w0 = np.zeros(data.dim + 1, dtype=np.float32)
+        hot = rng.choice(np.arange(1, data.dim + 1), size=4000, replace=False)
+        w0[hot] = rng.normal(scale=0.05, size=4000).astype(np.float32)
+        eng.set_weights(w0)
+        for k_workers, batch in ((2, 700), (3, 100), (1, 3000)):
+            for lists in batches(rng, n_train, k_workers, batch, 2):
+                plan_step(o, eng, lists, 0.5 * 100 / batch, "virtual_tiles_ragged")
+                assert eng.grad_kernel_name() == "dsgd_vt_grad_kernel"
+
+
 # ---- persistent lock-free ("Hogwild") engine -----------------------------------------------------------
 M64 = (1 << 64) - 1
 
