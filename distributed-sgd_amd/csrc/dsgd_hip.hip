@@ -469,7 +469,7 @@ static int grid_for(dsgd_ctx* c, long long items, int group) {
   return (int)std::max<long long>(1, std::min(blocks, cap));
 }
 
-// kind 0: the main gradient kernel, 1: dsgd_cdot_kernel, 2: dsgd_cgrad_kernel (split layout)
+// kind 0: the main gradient kernel, 1 / 2: the cold stream's dot / gradient pass (dsgd_cold_kernel)
 static int prof_begin(dsgd_ctx* c, size_t* slot, int kind = 0) {
   if (!c->prof || (kind != 0 && c->prof_main_only)) {   // (a skipped bracket: prof_end ignores the slot)
     *slot = (size_t)-1;
