@@ -771,14 +771,18 @@ __device__ __forceinline__ void wave_seg_scan(float& v, int& f) {
 // So: every WAVE owns its own tiles of 512 slots made of WHOLE rows (no data ever crosses waves; the 16 waves of the
 // workgroup drift apart and overlap each other's memory waits, DPP scans and LDS atomics while sharing the LDS
 // weight tile and the LDS gradient tile):
-//   * lane l owns the 8 CONTIGUOUS slots [8l, 8l+8): two 16-byte buffer loads per array through a resource that
-//     covers exactly the tile's own bytes, four register sets rotated by unrolling (three tiles in flight);
-//   * one 32-bit descriptor per lane: local row of its first slot (8 bits, rows 1-based, 0 / nrows+1 =
-//     padding), row-start bits (8), label sign of the row ENDING at each start (8): no per-row loads;
+//   * lane l owns the 8 CONTIGUOUS slots [8l, 8l+8): one 16-byte buffer load of eight 16-bit ranks and two of eight
+//     values through resources that cover exactly the tile's own bytes, four register sets rotated by unrolling
+//     (three tiles in flight); every request of a tile -- ranks, values, lane descriptors, the cold parts of its
+//     rows' x.w -- needs the tile record only (no load depends on a load), all indices are 32-bit (scalar unit);
+//   * one 16-bit descriptor per lane: row-start bits (8), label sign of the row ENDING at each start (8); the
+//     local row of the lane's first slot (rows 1-based, 0 / nrows+1 = padding) is a DPP prefix sum over the start
+//     bits: no per-row loads;
 //   * ONE DPP segmented scan per tile; a lane with at most one row start (the common case: rows >= 8
 //     non-zeros) finalises branch-free, the general loop runs only when some lane of the wave holds two;
-//   * gate coefficients go through a per-wave LDS strip, pre-multiplied by the fixed-point scale
-//     (same wave writes and reads: LDS executes a wave's accesses in order, no barrier);
+//   * the cold parts of the rows' x.w come in and the gate coefficients go out through a per-wave LDS strip (slot r:
+//     row r's cold part until the lane that closes row r has read it, then its coefficient, pre-multiplied by the
+//     fixed-point scale; same wave writes and reads: LDS executes a wave's accesses in order, no barrier);
 //   * rows longer than WS_MAXNNZ non-zeros are processed after the tiles, one wave per row.
 // The tiles hold the HOT columns only (split layout: 16-bit ranks, cold part of x.w from dcold, plain ds_add_u32 with
 // a per-launch scale that rules out overflow).  The first generation (all columns in one stream, cold weights
