@@ -640,7 +640,53 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
     tot_next = __hip_atomic_load(&g64_base[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   float gsum = 0.0f;        // Vec.sum over the workers, folded left with the Sparse filter after every add
-  for (int k = 0; k < n_workers; ++k) {
+  // Small steps (the reference's 3 x 100 and 4 x 200: a few workgroups per worker, no cold partials): every
+  // (worker, workgroup) pair is ONE phase of a single pass -- one round trip and one pair of barriers for all workers
+  // instead of one per worker; the finishing lanes then walk the workers exactly as the loop below does (each worker's
+  // exact sum rounded once, regularised, folded in worker order).
+  const bool flat = n_workers > 1 && n_workers <= 4 && n_workers * n_wg <= FRA_PHASES && nc == 0;
+  if (flat) {
+    long long q[4] = {0, 0, 0, 0};
+    if (ph < n_workers * n_wg) {
+      if (mode == 1) {
+        const int4 v = *reinterpret_cast<const int4*>(part + (long long)ph * part_stride + jg);   // ph = k * n_wg + b
+        q[0] = v.x;
+        q[1] = v.y;
+        q[2] = v.z;
+        q[3] = v.w;
+      } else if (mode == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (jg + e < hg) q[e] = part[(long long)ph * part_stride + jg + e];
+      }
+    }
+    long long tot_k[4] = {tot_next, 0, 0, 0};
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (fin && k < n_workers)
+        tot_k[k] = __hip_atomic_load(&(g64_base + (long long)k * g_stride)[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ph < FRA_PHASES) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[ph][4 * cg + e] = q[e];
+    }
+    __syncthreads();
+    s = s_sh;
+    add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+    if (fin) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < n_workers) {
+          long long tot = tot_k[k];
+          if (tot != 0) (g64_base + (long long)k * g_stride)[j] = 0;
+          for (int b = 0; b < n_wg; ++b) tot += red[k * n_wg + b][tid];
+          float gv = filt((float)((double)tot * (j >= hc ? inv_scale_cold : inv_scale)));   // one rounding of the exact sum
+          if (add && gv != 0.0f) gv = filt(gv + s);
+          gsum = filt(gsum + gv);
+        }
+      }
+    }
+  }
+  for (int k = 0; k < (flat ? 0 : n_workers); ++k) {
     long long q[4] = {0, 0, 0, 0};
     if (mode == 1 || mode == 2) {
       const int n = mode == 1 ? n_wg : n_wgc;
