@@ -838,6 +838,7 @@ struct VtArgs {
   const float* cval;
   const float* w;
   const VtLane* lanes;          // 64 per tile
+  const uint4* packed;          // PACKED plans: 4 KiB per tile -- the tile's own copy of what its descriptors point to
   const WorkSeg* tsegs;         // tile range of every worker's list of this step (blockIdx.y)
   const WorkSeg* lsegs;         // ... and its range of `long_recs`: rows outside the tiled streams (more than 504 hot or
   const MbRec* long_recs;       //     64 cold entries), one wave per row from the whole ranked CSR (vt_long_row)
@@ -882,6 +883,61 @@ __device__ __forceinline__ void vt_issue_stream(const VtArgs& a, VtRegs& r) {
   const bool hasc = (r.d.y & VT_COLD) != 0u;
   r.cv = a.cval[hasc ? r.d.z : 0u];
   r.cw = a.w[a.hsplit + (hasc ? (int)r.d.w : 0)];
+}
+
+// PACKED plans (small and mid-size plans: vt_build): the rows a tile touches are copied into the plan in tile order
+// when it is built -- four 1 KiB blocks per tile {descriptor-like words, eight ranks, values 0-3, values 4-7}, each one
+// coalesced 16-byte load per lane.  A step then makes ONE round trip into HBM instead of two dependent ones
+// (descriptors, then wherever they point) -- its data also sits where the translation caches see it again next step --
+// and the cold weights' gather (L2) goes out as soon as the first block has landed, under the other three.
+__device__ __forceinline__ void vt_issue_packed_misc(const VtArgs& a, int t, int t_end, int lane, VtRegs& r) {
+  r.live = t < t_end;
+  r.d = make_uint4(0u, 0u, 0u, 0u);
+  if (r.live) r.d = a.packed[(long long)t * 256 + lane];   // {0, info, cold value bits, cold rank}
+}
+__device__ __forceinline__ void vt_issue_packed_data(const VtArgs& a, int t, int lane, VtRegs& r) {
+  if (!r.live) return;
+  const uint4* b = a.packed + (long long)t * 256 + lane;
+  const uint4 c = b[64], x = b[128], y = b[192];
+  r.c[0] = c.x; r.c[1] = c.y; r.c[2] = c.z; r.c[3] = c.w;
+  r.c[4] = 0u;
+  r.v0 = make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+  r.v1 = make_float4(__uint_as_float(y.x), __uint_as_float(y.y), __uint_as_float(y.z), __uint_as_float(y.w));
+}
+__device__ __forceinline__ void vt_issue_packed_cw(const VtArgs& a, VtRegs& r) {   // (the first block has landed)
+  if (!r.live) return;
+  r.cv = __uint_as_float(r.d.z);
+  r.cw = a.w[a.hsplit + ((r.d.y & VT_COLD) ? (int)r.d.w : 0)];
+}
+// one wave per tile: the plan's packed copy from the descriptors and the streams (runs once, when the plan is built)
+__global__ void __launch_bounds__(256) dsgd_vt_pack_kernel(VtArgs a, long long n_tiles, uint4* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (t >= n_tiles) return;
+  VtRegs r;
+  vt_issue_desc(a, (int)t, (int)n_tiles, lane, r);
+  vt_issue_stream(a, r);
+  const unsigned int info = r.d.y, cnt = info & 15u;
+  const unsigned int sh = (r.d.x & 1u) << 4;
+  uint4 c;
+  c.x = __builtin_amdgcn_alignbit(r.c[1], r.c[0], sh);
+  c.y = __builtin_amdgcn_alignbit(r.c[2], r.c[1], sh);
+  c.z = __builtin_amdgcn_alignbit(r.c[3], r.c[2], sh);
+  c.w = __builtin_amdgcn_alignbit(r.c[4], r.c[3], sh);
+  // slots past the row's end hold the next row's entries: rank 0 / value 0 in the copy
+  const unsigned int keep[4] = {cnt >= 2u ? 0xffffffffu : (cnt == 1u ? 0xffffu : 0u), cnt >= 4u ? 0xffffffffu : (cnt == 3u ? 0xffffu : 0u),
+                                cnt >= 6u ? 0xffffffffu : (cnt == 5u ? 0xffffu : 0u), cnt >= 8u ? 0xffffffffu : (cnt == 7u ? 0xffffu : 0u)};
+  c.x &= keep[0]; c.y &= keep[1]; c.z &= keep[2]; c.w &= keep[3];
+  const float v[8] = {r.v0.x, r.v0.y, r.v0.z, r.v0.w, r.v1.x, r.v1.y, r.v1.z, r.v1.w};
+  unsigned int vb[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) vb[k] = (unsigned int)k < cnt ? __float_as_uint(v[k]) : 0u;
+  const bool hasc = (info & VT_COLD) != 0u;
+  uint4* o = out + t * 256 + lane;
+  o[0] = make_uint4(0u, info, hasc ? __float_as_uint(r.cv) : 0u, hasc ? r.d.w : 0u);
+  o[64] = c;
+  o[128] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
+  o[192] = make_uint4(vb[4], vb[5], vb[6], vb[7]);
 }
 
 // stage P
@@ -936,7 +992,7 @@ __device__ __forceinline__ unsigned int vt_process(const VtArgs& a, const VtRegs
 #pragma unroll
   for (int k = 0; k < 8; ++k)
     if (q[k] != 0) atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(gl) + cc[k]), q[k]);
-  if (hasc && coef != 0.0f && a.cold_scale != 0.0f) {   // the cold entry of an active row: 64-bit global accumulator at the cold scale
+  if (hasc && coef != 0.0f) {   // the cold entry of an active row: 64-bit global accumulator at the cold scale
     const int qc = __float2int_rn(cv * (coef > 0.0f ? a.cold_scale : -a.cold_scale));
     if (qc != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g64[a.hsplit + (int)r.d.w]), (unsigned long long)(long long)qc);
   }
@@ -1005,6 +1061,7 @@ __device__ __forceinline__ unsigned int vt_long_finish(const VtArgs& a, const Mb
   return lane == 0 ? 1u : 0u;
 }
 
+template <bool PACKED>
 __global__ void __launch_bounds__(1024) dsgd_vt_grad_kernel(VtArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1035,17 +1092,34 @@ __global__ void __launch_bounds__(1024) dsgd_vt_grad_kernel(VtArgs a) {
   //  common stretch both register files -- four tile sets, a whole long row -- were live across it and spilled)
   if (tile_wg) {
     VtRegs A, B, C, D;
-    // round trip 1: the descriptors of the wave's first four tiles; the accumulators are cleared under it
-    vt_issue_desc(a, tile, t_end, lane, A);
-    vt_issue_desc(a, tile + stride, t_end, lane, B);
-    vt_issue_desc(a, tile + 2 * stride, t_end, lane, C);
-    vt_issue_desc(a, tile + 3 * stride, t_end, lane, D);
-    wg_zero(gl, H + 64, tid, 1024);
-    // round trip 2: everything the descriptors point to, and the weight tile
-    vt_issue_stream(a, A);
-    vt_issue_stream(a, B);
-    vt_issue_stream(a, C);
-    vt_issue_stream(a, D);
+    if (PACKED) {
+      // ONE round trip: the tiles' first blocks, then their other three; the cold weights go out under those
+      vt_issue_packed_misc(a, tile, t_end, lane, A);
+      vt_issue_packed_misc(a, tile + stride, t_end, lane, B);
+      vt_issue_packed_misc(a, tile + 2 * stride, t_end, lane, C);
+      vt_issue_packed_misc(a, tile + 3 * stride, t_end, lane, D);
+      vt_issue_packed_data(a, tile, lane, A);
+      vt_issue_packed_data(a, tile + stride, lane, B);
+      vt_issue_packed_data(a, tile + 2 * stride, lane, C);
+      vt_issue_packed_data(a, tile + 3 * stride, lane, D);
+      wg_zero(gl, H + 64, tid, 1024);
+      vt_issue_packed_cw(a, A);
+      vt_issue_packed_cw(a, B);
+      vt_issue_packed_cw(a, C);
+      vt_issue_packed_cw(a, D);
+    } else {
+      // round trip 1: the descriptors of the wave's first four tiles; the accumulators are cleared under it
+      vt_issue_desc(a, tile, t_end, lane, A);
+      vt_issue_desc(a, tile + stride, t_end, lane, B);
+      vt_issue_desc(a, tile + 2 * stride, t_end, lane, C);
+      vt_issue_desc(a, tile + 3 * stride, t_end, lane, D);
+      wg_zero(gl, H + 64, tid, 1024);
+      // round trip 2: everything the descriptors point to, and the weight tile
+      vt_issue_stream(a, A);
+      vt_issue_stream(a, B);
+      vt_issue_stream(a, C);
+      vt_issue_stream(a, D);
+    }
     wg_copy_in(wl, a.w, H, tid, 1024, is_aligned16(a.w));
     if (tid == 0) wl[H] = 0.0f;
     __syncthreads();
@@ -1056,14 +1130,29 @@ __global__ void __launch_bounds__(1024) dsgd_vt_grad_kernel(VtArgs a) {
       n_act += vt_process(a, D, strip, gl, g64);
       tile += 4 * stride;
       if (tile >= t_end) break;
-      vt_issue_desc(a, tile, t_end, lane, A);
-      vt_issue_desc(a, tile + stride, t_end, lane, B);
-      vt_issue_desc(a, tile + 2 * stride, t_end, lane, C);
-      vt_issue_desc(a, tile + 3 * stride, t_end, lane, D);
-      vt_issue_stream(a, A);
-      vt_issue_stream(a, B);
-      vt_issue_stream(a, C);
-      vt_issue_stream(a, D);
+      if (PACKED) {
+        vt_issue_packed_misc(a, tile, t_end, lane, A);
+        vt_issue_packed_misc(a, tile + stride, t_end, lane, B);
+        vt_issue_packed_misc(a, tile + 2 * stride, t_end, lane, C);
+        vt_issue_packed_misc(a, tile + 3 * stride, t_end, lane, D);
+        vt_issue_packed_data(a, tile, lane, A);
+        vt_issue_packed_data(a, tile + stride, lane, B);
+        vt_issue_packed_data(a, tile + 2 * stride, lane, C);
+        vt_issue_packed_data(a, tile + 3 * stride, lane, D);
+        vt_issue_packed_cw(a, A);
+        vt_issue_packed_cw(a, B);
+        vt_issue_packed_cw(a, C);
+        vt_issue_packed_cw(a, D);
+      } else {
+        vt_issue_desc(a, tile, t_end, lane, A);
+        vt_issue_desc(a, tile + stride, t_end, lane, B);
+        vt_issue_desc(a, tile + 2 * stride, t_end, lane, C);
+        vt_issue_desc(a, tile + 3 * stride, t_end, lane, D);
+        vt_issue_stream(a, A);
+        vt_issue_stream(a, B);
+        vt_issue_stream(a, C);
+        vt_issue_stream(a, D);
+      }
     }
   } else {
     VtLong LR;

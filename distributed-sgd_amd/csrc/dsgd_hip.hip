@@ -128,6 +128,7 @@ struct dsgd_plan {
   VtLane* d_vt_lanes = nullptr; // 64 descriptors per tile
   WorkSeg* d_vt_segs = nullptr; // tile range of every list, then (n_lists further entries) its range of d_vt_long
   MbRec* d_vt_long = nullptr;   // rows of the lists that sit in no tile (long-row list, more than 64 cold entries)
+  uint4* d_vt_packed = nullptr; // plans up to vt_pack_mb: the tiles' own copy of the rows they touch (4 KiB per tile)
   std::vector<long long> vt_off;       // n_lists + 1 tile offsets
   std::vector<int> vt_grid, vt_gxt, vt_shift;  // per step: workgroups per worker, those of them that walk tiles, shift
   long long vt_layout = -1;     // the layout generation the tiles were built for (-1: not built)
@@ -169,6 +170,7 @@ struct dsgd_ctx {
   std::vector<unsigned short> h_ccol;   // host copy of the 16-bit cold ranks (a virtual tile's descriptor carries its cold rank)
   long long layout_gen = 0;             // bumped whenever the split streams are rebuilt
   bool vt_enable = true;                // DSGD_VT=0: index-list steps of resident plans through dsgd_mb_grad_kernel
+  long long vt_pack_mb = 2048;          // DSGD_VT_PACK_MB: plans whose packed copy fits get one (0: descriptors only)
   int vt_tpw = 1;                       // DSGD_VT_TPW: virtual tiles per wave the grid is sized for (measured: 1 beats 2-4 up to B = 65,536)
   std::vector<signed char> h_label;
   // wave tiles over d_hcol/d_hval
@@ -570,9 +572,11 @@ static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
   (void)hipFree(p->d_vt_lanes);
   (void)hipFree(p->d_vt_segs);
   (void)hipFree(p->d_vt_long);
+  (void)hipFree(p->d_vt_packed);
   p->d_vt_lanes = nullptr;
   p->d_vt_segs = nullptr;
   p->d_vt_long = nullptr;
+  p->d_vt_packed = nullptr;
   const int H = std::min(c->hsplit, c->dp);
   const long long n_lists = (long long)p->n_steps * p->n_workers;
   if (!c->cold_col16 || c->dp <= H || c->hot_nnz + WS_PAD >= (1LL << 32) || c->coldm_nnz + WS_PAD >= (1LL << 32)) return DSGD_OK;
@@ -673,6 +677,24 @@ static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
   HIP_TRY(hipMemcpy(p->d_vt_segs, segs.data(), sizeof(WorkSeg) * segs.size(), hipMemcpyHostToDevice));
   if (!long_rows.empty())
     HIP_TRY(hipMemcpy(p->d_vt_long, long_rows.data(), sizeof(MbRec) * long_rows.size(), hipMemcpyHostToDevice));
+  // small and mid-size plans get their own copy of the rows they touch, in tile order (dsgd_vt_pack_kernel): one
+  // coalesced round trip per step instead of descriptors -> scattered rows
+  const long long n_tiles = (long long)tile_rows.size();
+  if (n_tiles > 0 && n_tiles * 4096 <= c->vt_pack_mb * (1LL << 20)) {
+    HIP_TRY(hipMalloc(&p->d_vt_packed, (size_t)n_tiles * 4096));
+    VtArgs a{};
+    a.hcol = c->d_hcol;
+    a.hval = c->d_hval;
+    a.ccol = reinterpret_cast<const unsigned short*>(c->d_ccol);
+    a.cval = c->d_cval;
+    a.w = c->d_w;
+    a.lanes = p->d_vt_lanes;
+    a.hsplit = H;
+    const long long blocks = (n_tiles + 3) / 4;   // four tiles (waves) per block
+    hipLaunchKernelGGL(dsgd_vt_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, a, n_tiles, p->d_vt_packed);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   p->vt_ok = true;
   return DSGD_OK;
 }
@@ -689,6 +711,7 @@ static int launch_grad_vt(dsgd_ctx* c, dsgd_plan* p, long long step) {
   a.cval = c->d_cval;
   a.w = c->d_w;
   a.lanes = p->d_vt_lanes;
+  a.packed = p->d_vt_packed;
   a.tsegs = p->d_vt_segs + step * p->n_workers;
   a.lsegs = p->d_vt_segs + ((long long)p->n_steps + step) * p->n_workers;
   a.long_recs = p->d_vt_long;
@@ -705,7 +728,8 @@ static int launch_grad_vt(dsgd_ctx* c, dsgd_plan* p, long long step) {
   const size_t lds = sizeof(float) * (size_t)(((H + 4) & ~3) + 16 * 64 + H + 64);
   size_t slot = 0;
   DSGD_TRY(prof_begin(c, &slot));
-  hipLaunchKernelGGL(dsgd_vt_grad_kernel, dim3((unsigned)gx, p->n_workers), dim3(1024), lds, c->stream, a);
+  if (a.packed) hipLaunchKernelGGL(dsgd_vt_grad_kernel<true>, dim3((unsigned)gx, p->n_workers), dim3(1024), lds, c->stream, a);
+  else hipLaunchKernelGGL(dsgd_vt_grad_kernel<false>, dim3((unsigned)gx, p->n_workers), dim3(1024), lds, c->stream, a);
   HIP_TRY(hipGetLastError());
   DSGD_TRY(prof_end(c, slot));
   c->last_grad_kernel = "dsgd_vt_grad_kernel";
@@ -1378,6 +1402,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;  // 0: small batches through the multi-workgroup kernel
   if (const char* e = getenv("DSGD_VT")) c->vt_enable = atoi(e) != 0;             // 0: plans' index lists through dsgd_mb_grad_kernel
   if (const char* e = getenv("DSGD_VT_TPW")) c->vt_tpw = std::max(1, atoi(e));
+  if (const char* e = getenv("DSGD_VT_PACK_MB")) c->vt_pack_mb = std::max(0, atoi(e));
   if (const char* e = getenv("DSGD_HSPLIT")) c->hsplit = atoi(e);                 // hot/cold split rank (tests: wide models)
   if (getenv("DSGD_PLAN_PROF") && atoi(getenv("DSGD_PLAN_PROF"))) {
     HIP_TRY_B(hipMalloc(&c->d_tprof, sizeof(unsigned long long) * 16));
@@ -1394,7 +1419,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_colcount_kernel);
   DSGD_ATTR(dsgd_hogwild_kernel);
   DSGD_ATTR(dsgd_mb_grad_kernel);
-  DSGD_ATTR(dsgd_vt_grad_kernel);
+  DSGD_ATTR(dsgd_vt_grad_kernel<true>);
+  DSGD_ATTR(dsgd_vt_grad_kernel<false>);
   DSGD_ATTR(dsgd_plan_kernel);
   DSGD_ATTR(dsgd_wseg_kernel<true>);
   DSGD_ATTR(dsgd_wseg_kernel<false>);
@@ -1976,6 +2002,7 @@ int dsgd_plan_destroy(dsgd_ctx* c, dsgd_plan* p) {
   (void)hipFree(p->d_vt_lanes);
   (void)hipFree(p->d_vt_segs);
   (void)hipFree(p->d_vt_long);
+  (void)hipFree(p->d_vt_packed);
   delete p;
   return DSGD_OK;
 }

@@ -689,12 +689,16 @@ def test_virtual_tiles_match_oracle(mid, k_workers, batch):
     np.testing.assert_array_equal(eng.get_weights(), w_one_by_one)   # integer sums, fixed order: bit-reproducible
 
 
-@pytest.mark.parametrize("hsplit", [None, "3000"])
-def test_virtual_tiles_on_ragged_rows(monkeypatch, hsplit):
+@pytest.mark.parametrize("hsplit,pack_mb", [(None, None), ("3000", None), (None, "0"), ("3000", "0")])
+def test_virtual_tiles_on_ragged_rows(monkeypatch, hsplit, pack_mb):
     """Empty rows, one-element rows, values below the Sparse epsilon, and (DSGD_HSPLIT=3000) rows whose cold part is
-    longer than their hot part or than a tile can give lanes to (more than 64 cold entries: the long-row workgroups)."""
+    longer than their hot part or than a tile can give lanes to (more than 64 cold entries: the long-row workgroups);
+    with the plan's packed copy of its rows (the default for plans of this size) and with descriptors only
+    (DSGD_VT_PACK_MB=0: what a plan beyond the packing limit runs)."""
     if hsplit:
         monkeypatch.setenv("DSGD_HSPLIT", hsplit)
+    if pack_mb:
+        monkeypatch.setenv("DSGD_VT_PACK_MB", pack_mb)
     data = ragged_data(23)
     n_train = 5000
     o, eng = make_pair(data, 1e-5, n_train)
