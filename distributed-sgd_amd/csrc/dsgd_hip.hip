@@ -2122,8 +2122,9 @@ int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_en
     const long long rows = row_end - row_begin;
     dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(c->n_cu, (rows + groups_per_block - 1) / groups_per_block)));
     // small ranges do not amortise staging 160 KiB of weights per workgroup: shrink the LDS tile
-    const int hw = c->async_running ? std::min(c->hw_eval, 4096) : (rows >= 4096 ? c->hw_eval : std::min(c->hw_eval, 1024));
-    const size_t lds = sizeof(float) * (size_t)hw;
+    const int hw = std::min(c->async_running ? std::min(c->hw_eval, 4096) : (rows >= 4096 ? c->hw_eval : std::min(c->hw_eval, 1024)),
+                            DSGD_LDS_FLOATS - 4);
+    const size_t lds = sizeof(float) * (size_t)(hw + 4);   // (+ the workgroup's three tally words)
     CsrView m = view(c);
     switch (G) {
       case 64: hipLaunchKernelGGL(dsgd_eval_kernel<64>, grid, dim3(bs), lds, c->stream, m, c->d_w, (long long)row_begin, (long long)row_end, c->d_sc, hw); break;

@@ -300,6 +300,26 @@ __global__ void __launch_bounds__(256) dsgd_forward_kernel(CsrView m, const floa
   }
 }
 
+// the three evaluation tallies of a workgroup: ONE global atomic per counter and workgroup (one per wave puts thousands
+// of atomics on three addresses when the grid finishes; they are served one after the other)
+// (tally: three words of LDS the caller owns -- a static __shared__ next to a 160 KiB dynamic allocation is refused)
+__device__ __forceinline__ void block_tally3(unsigned int c0, unsigned int c1, unsigned int c2, DevScalars* sc,
+                                             unsigned int* tally) {
+  __syncthreads();   // (everybody is done with whatever the words held)
+  if (threadIdx.x < 3) tally[threadIdx.x] = 0u;
+  __syncthreads();
+  c0 = wave_sum_u32(c0);
+  c1 = wave_sum_u32(c1);
+  c2 = wave_sum_u32(c2);
+  if ((threadIdx.x & 63) == 0) {
+    if (c0) atomicAdd(&tally[0], c0);
+    if (c1) atomicAdd(&tally[1], c1);
+    if (c2) atomicAdd(&tally[2], c2);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 && tally[threadIdx.x]) atomicAdd(&sc->counts[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
+}
+
 // ---- K5: loss / accuracy tallies over a row range -------------------------------------------------------------
 // ref: core/Master.scala:100-107, core/ml/SparseSVM.scala:16-23: with p = -signum(x.w),
 //   y*p = +1 (loss 0, correct) iff y*(x.w) < 0;  p = 0 (loss 1) iff x.w == 0;  y*p = -1 (loss 2) otherwise
@@ -326,15 +346,8 @@ __global__ void __launch_bounds__(1024) dsgd_eval_kernel(CsrView m, const float*
       else c1++;
     }
   }
-  c0 = wave_sum_u32(c0);
-  c1 = wave_sum_u32(c1);
-  c2 = wave_sum_u32(c2);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&sc->counts[3], (unsigned long long)(row_end - row_begin));
-  if ((threadIdx.x & 63) == 0) {
-    if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
-    if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
-    if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
-  }
+  block_tally3(c0, c1, c2, sc, reinterpret_cast<unsigned int*>(wl + hw));   // (the launch allocates hw + 4 floats)
 }
 
 // ---- layout: column frequencies, ranking, permutations ---------------------------------------------------------
@@ -1493,36 +1506,6 @@ __global__ void __launch_bounds__(256) dsgd_split_fill_kernel(CsrView m, int hsp
         cval[cp] = 0.0f;
       }
     }
-  }
-}
-
-// evaluation tallies of an explicit list of rows (the few rows too long for the wave tiles)
-template <int G>
-__global__ void __launch_bounds__(256) dsgd_eval_idx_kernel(CsrView m, const float* __restrict__ w,
-                                                           const int* __restrict__ idx, long long n, DevScalars* sc) {
-  constexpr int UNR = 4;
-  const int sub = threadIdx.x % G;
-  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
-  const long long n_groups = (long long)gridDim.x * blockDim.x / G;
-  unsigned int c0 = 0, c1 = 0, c2 = 0;
-  for (long long t = group; t < n; t += n_groups) {
-    const long long row = idx[t];
-    RowRegs<G, UNR> r;
-    const float d = row_dot<G, UNR, false>(m, m.row_ptr[row], m.row_ptr[row + 1], nullptr, w, 0, sub, r);
-    const float yd = (float)m.label[row] * d;
-    if (sub == 0) {
-      if (yd < 0.0f) c0++;
-      else if (yd > 0.0f) c2++;
-      else c1++;
-    }
-  }
-  c0 = wave_sum_u32(c0);
-  c1 = wave_sum_u32(c1);
-  c2 = wave_sum_u32(c2);
-  if ((threadIdx.x & 63) == 0) {
-    if (c0) atomicAdd(&sc->counts[0], (unsigned long long)c0);
-    if (c1) atomicAdd(&sc->counts[1], (unsigned long long)c1);
-    if (c2) atomicAdd(&sc->counts[2], (unsigned long long)c2);
   }
 }
 
