@@ -32,13 +32,13 @@ def test_launcher_environment_is_respected():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The bench line the last GPU visit produced (profiles/r02_bench.json): the keys, types and internal arithmetic of
+    """The bench line the last GPU visit produced (profiles/r03_bench.json): the keys, types and internal arithmetic of
     the driver's contract -- whole-job examples/s from the timed steps, the dominant kernel's roofline fraction from its
     algorithmic bytes and its measured duration, a bounded CPU baseline, nothing quoted against a baseline that was
     never published."""
     import json
 
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
@@ -62,3 +62,12 @@ def test_committed_bench_line_keeps_the_contract():
     # the parity gate ran on the benchmarked configuration and stayed inside its derived bound
     assert d["parity_gate_rows"] == d["config"]["train_rows_per_gpu"]
     assert all(st["worst_err_over_bound"] <= 1.0 for st in d["parity_gate"]["steps"])
+    # every quoted configuration carries its own parity evidence: the sweep rows (one step against the oracle under the
+    # derived bound, active rows equal up to the rows near the gate) and the 256-worker lock-free run (oracle band)
+    assert {(s["workers"], s["batch"]) for s in d["sweep"]} >= {(1, 100), (3, 100), (4, 200), (1, 4096), (1, 65536)}
+    for s in d["sweep"]:
+        pz = s["parity"]
+        assert pz["worst_err_over_bound"] <= 1.0 and abs(pz["n_active_engine"] - pz["n_active_oracle"]) <= pz["rows_near_gate"]
+    hb = d["hogwild"]["oracle_band"]
+    assert hb["workers"] == d["hogwild"]["workers"] == 256 and hb["batch"] == 100 and hb["inside"] is True
+    assert d["hogwild"]["atomics_per_s"] > 0
