@@ -680,8 +680,12 @@ static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
   // small and mid-size plans get their own copy of the rows they touch, in tile order (dsgd_vt_pack_kernel): one
   // coalesced round trip per step instead of descriptors -> scattered rows
   const long long n_tiles = (long long)tile_rows.size();
-  if (n_tiles > 0 && n_tiles * 4096 <= c->vt_pack_mb * (1LL << 20)) {
-    HIP_TRY(hipMalloc(&p->d_vt_packed, (size_t)n_tiles * 4096));
+  if (n_tiles > 0 && n_tiles * 4096 <= c->vt_pack_mb * (1LL << 20) &&
+      hipMalloc(&p->d_vt_packed, (size_t)n_tiles * 4096) != hipSuccess) {
+    (void)hipGetLastError();      // (no room for the copy: the plan runs from its descriptors)
+    p->d_vt_packed = nullptr;
+  }
+  if (p->d_vt_packed) {
     VtArgs a{};
     a.hcol = c->d_hcol;
     a.hval = c->d_hval;
