@@ -95,5 +95,18 @@ variants)
   eval "timeout 900 python tools/variants.py $VARIANTS" 2>&1 | tee $OUT/variants.txt ;;
 hog)
   timeout 300 python tools/hog_prof.py 8388608 256 60000 > $OUT/hogwild_8m.json 2> $OUT/hogwild_8m.err; cat $OUT/hogwild_8m.json ;;
+hogprof)
+  echo "== Hogwild: kernel trace and PMC"
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hogtrace -o hog -- python $REPO/tools/hog_prof.py 8388608 256 60000 > /dev/null 2> $OUT/hog_trace.err )
+  f=$(find $OUT/hogtrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "Name|hogwild|eval" "$f" | cut -c1-200 | tee $OUT/hogwild_kernel_stats.csv
+  rm -rf $OUT/hogtrace
+  i=0
+  for P in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum"; do
+    i=$((i+1))
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/hpmc$i -o pmc -- python $REPO/tools/hog_prof.py 8388608 256 60000 > /dev/null 2> $OUT/hpmc$i.err )
+    f=$(find $OUT/hpmc$i -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then python tools/pmc_summary.py "$f" "dsgd_hogwild" | tee -a $OUT/hogwild_pmc_summary.txt; else tail -5 $OUT/hpmc$i.err; fi
+    rm -rf $OUT/hpmc$i $OUT/hpmc$i.err
+  done ;;
 esac
 done
