@@ -1649,6 +1649,7 @@ struct PlanArgs {
   const WorkSeg* segs;       // one per step
   DevScalars* sc;
   unsigned long long* tprof; // optional (tuning runs): 16 words -- shader-clock cycles of thread 0 in nine phases of a batch, [15] = steps
+  unsigned long long* mail;  // optional (per-request steps): host-mapped {n_active, err} written when the launch ends
   long long step_begin, step_end;
   float lr, lambda;
   int vexp, dp;
@@ -1934,8 +1935,21 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     stamp(8, tl);
   }
   n_act_total = (unsigned long long)wave_sum_u32((unsigned int)n_act_total);
-  if ((tid & 63) == 0 && n_act_total) atomicAdd(&a.sc->n_active, n_act_total);
+  // one atomic for the workgroup (`red` is free: the last collect is behind a barrier); its return value is what the
+  // host-mapped mailbox of a per-request step gets -- no copy back behind the launch
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = (double)n_act_total;
+  __threadfence();   // (this workgroup's error flags, if any, are out before thread 0 reads them)
+  __syncthreads();
   if (tid == 0) {
+    unsigned long long tot = 0;
+    for (int i = 0; i < PLAN_THREADS / 64; ++i) tot += (unsigned long long)red[i];
+    const unsigned long long old = atomicAdd(&a.sc->n_active, tot);
+    if (a.mail) {
+      __hip_atomic_store(&a.mail[0], old + tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const int err = __hip_atomic_load(&a.sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.mail[1], (unsigned long long)(unsigned int)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     a.sc->s_reg = (float)(2.0 * (double)a.lambda * dot);
     if (a.tprof) {
       for (int i = 0; i < 9; ++i) a.tprof[i] += tp[i];

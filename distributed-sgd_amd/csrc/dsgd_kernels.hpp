@@ -607,12 +607,19 @@ __global__ void __launch_bounds__(1024) dsgd_fix_reduce_apply_kernel(long long* 
                                                                     float lr, float lambda, DevScalars* sc,
                                                                     float* __restrict__ redpart,
                                                                     float* __restrict__ gsum_out,
-                                                                    const float* __restrict__ redpart_in, int s_lazy) {
+                                                                    const float* __restrict__ redpart_in, int s_lazy,
+                                                                    unsigned long long* __restrict__ mail) {
   __shared__ __attribute__((aligned(16))) long long red[FRA_PHASES][FRA_COLS];   // 32 KB
   __shared__ float fred[8];
   __shared__ int is_last;
   __shared__ float s_sh;
   const int tid = threadIdx.x;
+  // per-request steps (dsgd_sync_step): the gradient kernel's active-row count and the error flags go to a host-mapped
+  // mailbox from HERE -- the last launch of the request -- instead of through a device-to-host copy behind it
+  if (mail && blockIdx.x == 0 && tid == 0) {
+    __hip_atomic_store(&mail[0], sc->n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mail[1], (unsigned long long)(unsigned int)sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   // s of the weights this step starts from: final in DevScalars, or (s_lazy) still the previous step's per-block pairs
   // (redpart_in: the OTHER half of the pair buffer -- a fast block of this launch publishes its new pair while a slow
   // one still reads the old ones)
