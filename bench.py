@@ -541,27 +541,6 @@ def dense_logistic(dsgd_amd, device, rows=1250000, dim=4096):
                                    "kernel_frac_hbm_peak": (b * (4 * dim + 4) / (kms * 1e-3) / HBM_PEAK) if kms > 0 else None})
         loss, acc = eng.loss(rows - 65536, rows)
         res["loss_after"], res["acc_after"] = loss, acc
-    res["reduce"] = ("fused: partial sums added and the update applied in the step kernel's tail behind a grid-wide ticket "
-                     "(kernel_ms_avg covers the whole step); two_kernel_us_per_step = the same steps with DSGD_DENSE_FUSED=0")
-    os.environ["DSGD_DENSE_FUSED"] = "0"
-    try:
-        with dsgd_amd.DenseLogistic(dim, device=device) as eng:
-            eng.generate(rows, seed=device)
-            for entry in res["batches"]:
-                b, steps = entry["batch"], entry["steps"]
-                starts = [(i * b) % (rows - b) for i in range(steps + 5)]
-                for st in starts[:5]:
-                    eng.step(st, st + b, 1.0)
-                eng.synchronize()
-                eng.prof(True)   # (the same per-launch events as above: like for like)
-                t0 = time.perf_counter()
-                for st in starts[5:]:
-                    eng.step(st, st + b, 1.0)
-                eng.synchronize()
-                entry["two_kernel_us_per_step"] = 1e6 * (time.perf_counter() - t0) / steps
-                eng.prof(False)
-    finally:
-        del os.environ["DSGD_DENSE_FUSED"]
     # the variant with the forward product on the matrix cores (configs[4]: "mini-batch GEMV via MFMA"), same data
     os.environ["DSGD_DENSE_MFMA"] = "1"
     try:

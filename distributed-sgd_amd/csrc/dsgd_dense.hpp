@@ -31,108 +31,11 @@ struct DenseArgs {
   double* __restrict__ lpart;       // gridDim.x x 2: sum of losses, correct predictions
   long long row_begin, row_end;
   int D;
-  // the fused form (dsgd_dense_step_kernel<true>): the reduce of the partials and the update in the step kernel's tail
-  float* g;                         // D: the summed gradient (kept for callers that read it)
-  float* wout;                      // == w: the update (every workgroup has read `w` before it takes its ticket)
-  unsigned int* ticket;             // monotonic arrival counter of the object (never reset)
-  unsigned int target;              // its value once every workgroup of THIS launch has arrived
-  unsigned int* bail;               // host-mapped word: set when the wait gave up (dsgd_dense_synchronize reports it)
-  float scale;                      // lr / batch
 };
-
-// The tail of the fused step.  Every workgroup publishes its partial row with write-through (agent-scope) stores,
-// waits for their acknowledgement and takes a ticket.  Workgroups b >= R leave; the first R = min(grid, D / 16) wait
-// until the counter shows the whole grid, then each adds the partials of 16-column slices (64-byte pieces of every
-// partial row, requested together and staged in LDS) in dsgd_dense_reduce_kernel's order -- phase ph adds partials
-// ph, ph + 16, ... one after the other, the 16 phase sums are added in phase order -- so the fused and the two-kernel
-// form (communicator attached, MFMA variant) leave bit-identical weights.
-// Waiting is safe because the host launches this form only when the whole grid is resident at once (occupancy
-// query in dsgd_dense_create); a wait that does not end (16 M polls) sets `bail` instead of hanging the device.
-constexpr int DN_SLICE = 16;        // columns per slice
-constexpr int DN_STAGE = 8192;      // floats of LDS staging: grid * DN_SLICE <= DN_STAGE (grid <= 512)
-__device__ __forceinline__ void dn_fused_tail(const DenseArgs& a, float4 g0, float4 g1, int c0, int c1, float* stage,
-                                              float (*red)[DN_SLICE], int* flag) {
-  const int tid = threadIdx.x, grid = gridDim.x;
-  float* mine = a.gpart + (long long)blockIdx.x * a.D;
-  __hip_atomic_store(mine + c0 + 0, g0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(mine + c0 + 1, g0.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(mine + c0 + 2, g0.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(mine + c0 + 3, g0.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(mine + c1 + 0, g1.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(mine + c1 + 1, g1.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(mine + c1 + 2, g1.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(mine + c1 + 3, g1.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's stores are acknowledged ...
-  __syncthreads();                                   // ... and every lane's
-  const int n_slices = a.D / DN_SLICE;
-  const int R = grid < n_slices ? grid : n_slices;
-  if (tid == 0) {
-    __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int ok = 1;
-    if ((int)blockIdx.x < R) {
-      unsigned int polls = 0;
-      while ((int)(__hip_atomic_load(a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.target) < 0) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++polls > (1u << 24)) {
-          ok = 0;
-          __hip_atomic_store(a.bail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          break;
-        }
-      }
-    }
-    *flag = ok;
-  }
-  __syncthreads();
-  if ((int)blockIdx.x >= R || !*flag) return;
-  for (int s = blockIdx.x; s < n_slices; s += R) {
-    const int j0 = s * DN_SLICE;
-    // 64 consecutive lanes read the slice of four partial rows; 16 requests per lane in flight, then the LDS writes
-    // (a loop of load + write pays one round trip per iteration)
-    const int n = grid * DN_SLICE;
-    for (int base = 0; base < n; base += 16 * (int)blockDim.x) {
-      float v[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int idx = base + i * (int)blockDim.x + tid;
-        const int ic = idx < n ? idx : n - 1;
-        v[i] = __hip_atomic_load(a.gpart + (long long)(ic / DN_SLICE) * a.D + j0 + (ic % DN_SLICE), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int idx = base + i * (int)blockDim.x + tid;
-        if (idx < n) stage[idx] = v[i];
-      }
-    }
-    __syncthreads();
-    if (tid < 64) {   // (ph, four columns): blockDim.x >= 64 for every supported D
-      const int ph = tid >> 2, f = (tid & 3) * 4;
-      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int b = ph; b < grid; b += 16) {
-        const float4 v = *reinterpret_cast<const float4*>(stage + b * DN_SLICE + f);
-        sum.x += v.x;
-        sum.y += v.y;
-        sum.z += v.z;
-        sum.w += v.w;
-      }
-      *reinterpret_cast<float4*>(&red[ph][f]) = sum;
-    }
-    __syncthreads();
-    if (tid < DN_SLICE) {
-      float t = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) t += red[k][tid];
-      a.g[j0 + tid] = t;
-      a.wout[j0 + tid] = fmaf(-a.scale, t, a.wout[j0 + tid]);
-    }
-    __syncthreads();   // (stage and red are reused by the next slice)
-  }
-}
 
 // One workgroup of D / 8 lanes per row block: lane t owns columns [4t, 4t+4) and [D/2 + 4t, D/2 + 4t + 4) of every
 // row (each wave-level load is 1 KB of one row).  Two workgroups share a CU (<= 128 VGPRs each): one computes while
 // the other's loads are in flight.
-template <bool FUSED>
 __global__ void __launch_bounds__(1024) dsgd_dense_step_kernel(DenseArgs a) {
   __shared__ float zpart[16][DN_ROWS];
   __shared__ float rl[DN_ROWS];
@@ -198,7 +101,7 @@ __global__ void __launch_bounds__(1024) dsgd_dense_step_kernel(DenseArgs a) {
       }
     }
   }
-  if (!FUSED && a.gpart) {
+  if (a.gpart) {
     float* mine = a.gpart + (long long)blockIdx.x * a.D;
     *reinterpret_cast<float4*>(mine + c0) = g0;
     *reinterpret_cast<float4*>(mine + c1) = g1;
@@ -213,12 +116,6 @@ __global__ void __launch_bounds__(1024) dsgd_dense_step_kernel(DenseArgs a) {
   if (tid == 0) {
     a.lpart[2 * blockIdx.x] = lred[0];
     a.lpart[2 * blockIdx.x + 1] = lred[1];
-  }
-  if constexpr (FUSED) {
-    __shared__ __attribute__((aligned(16))) float stage[DN_STAGE];
-    __shared__ __attribute__((aligned(16))) float red[16][DN_SLICE];
-    __shared__ int flag;
-    dn_fused_tail(a, g0, g1, c0, c1, stage, red, &flag);
   }
 }
 
@@ -330,13 +227,13 @@ __global__ void __launch_bounds__(1024) dsgd_dense_reduce_kernel(const float* __
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][cx];
     g[j] = t;
-    if (w) w[j] = fmaf(-scale, t, w[j]);   // (one rounding: the same operation in the fused tail and the apply kernel)
+    if (w) w[j] -= scale * t;
   }
 }
 __global__ void __launch_bounds__(256) dsgd_dense_apply_kernel(float* __restrict__ w, const float* __restrict__ g, int D,
                                                               float scale /* lr / global batch */) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < D) w[j] = fmaf(-scale, g[j], w[j]);
+  if (j < D) w[j] -= scale * g[j];
 }
 
 // synthetic data on the device (configs[4]: "X generated on-device per shard (seed = rank)"): x ~ N(0, 1) / sqrt(D)

@@ -2685,12 +2685,6 @@ struct dsgd_dense {
   double* h_lpart = nullptr;  // pinned
   int n_wg = 0;
   bool mfma = false;          // DSGD_DENSE_MFMA=1: forward product with v_mfma_f32_16x16x4_f32 (D a multiple of 256, <= 4096)
-  bool fuse = true;           // DSGD_DENSE_FUSED=0: reduce + update as a second kernel even without a communicator
-  int fused_cap = 0;          // workgroups of dsgd_dense_step_kernel<true> resident at once (the fused tail waits on the grid)
-  unsigned int* d_ticket = nullptr;    // arrival counter of the fused tail (monotonic)
-  unsigned int ticket_total = 0;       // its value after the launches enqueued so far
-  unsigned int* h_bail = nullptr;      // host-mapped: a fused tail gave up waiting
-  unsigned int* d_bail = nullptr;
   rccl::comm_t comm = nullptr;
   int world = 1;
   bool prof = false;
@@ -2714,9 +2708,7 @@ static int dn_collect(dsgd_dense* d) {
   d->ev_used = 0;
   return DSGD_OK;
 }
-// grad: partials for a step.  fused_out != nullptr: the caller wants reduce + update (w -= scale * g) in the same kernel
-// when the grid allows; *fused_out says whether it was (false: the caller launches dsgd_dense_reduce_kernel).
-static int dn_launch(dsgd_dense* d, long long rb, long long re, bool grad, float scale = 0.0f, bool* fused_out = nullptr) {
+static int dn_launch(dsgd_dense* d, long long rb, long long re, bool grad) {
   DenseArgs a;
   a.X = d->d_X;
   a.y = d->d_y;
@@ -2729,19 +2721,6 @@ static int dn_launch(dsgd_dense* d, long long rb, long long re, bool grad, float
   const int rows_per_block = d->mfma ? 16 : DN_ROWS;
   const long long n_blocks = (re - rb + rows_per_block - 1) / rows_per_block;
   const int grid = (int)std::max<long long>(1, std::min<long long>(d->mfma ? d->n_cu : d->n_wg, n_blocks));
-  const bool fused = grad && fused_out && d->fuse && !d->mfma && !d->comm && grid <= d->fused_cap && grid * DN_SLICE <= DN_STAGE;
-  a.g = d->d_g;
-  a.wout = d->d_w;
-  a.ticket = d->d_ticket;
-  a.bail = d->d_bail;
-  a.target = 0;
-  a.scale = 0.0f;
-  if (fused) {
-    d->ticket_total += (unsigned int)grid;
-    a.target = d->ticket_total;
-    a.scale = scale;
-  }
-  if (fused_out) *fused_out = fused;
   size_t slot = (size_t)-1;
   if (d->prof && grad) {
     if (d->ev_used == d->ev.size() && d->ev.size() >= 4096) {   // bounded pool: collect what has completed so far
@@ -2759,10 +2738,8 @@ static int dn_launch(dsgd_dense* d, long long rb, long long re, bool grad, float
   }
   if (d->mfma)   // the variant on the matrix cores (forward product only; csrc/dsgd_dense.hpp)
     hipLaunchKernelGGL(dsgd_dense_step_mfma_kernel, dim3(grid), dim3(d->D / 4), sizeof(float) * (size_t)d->D, d->stream, a);
-  else if (fused)
-    hipLaunchKernelGGL(dsgd_dense_step_kernel<true>, dim3(grid), dim3(d->D / DN_COLS), 0, d->stream, a);
   else
-    hipLaunchKernelGGL(dsgd_dense_step_kernel<false>, dim3(grid), dim3(d->D / DN_COLS), 0, d->stream, a);
+    hipLaunchKernelGGL(dsgd_dense_step_kernel, dim3(grid), dim3(d->D / DN_COLS), 0, d->stream, a);
   HIP_TRY(hipGetLastError());
   if (slot != (size_t)-1) HIP_TRY(hipEventRecord(d->ev[slot].second, d->stream));
   return grid;
@@ -2787,7 +2764,6 @@ int dsgd_dense_create(int32_t n_features, int32_t device, dsgd_dense** out) {
   d->n_cu = prop.multiProcessorCount;
   d->n_wg = 2 * d->n_cu;   // two workgroups per CU: one computes while the other's loads are in flight
   if (const char* e = getenv("DSGD_DENSE_MFMA")) d->mfma = atoi(e) != 0;
-  if (const char* e = getenv("DSGD_DENSE_FUSED")) d->fuse = atoi(e) != 0;
   if (d->mfma && n_features > 4096) {
     delete d;
     return fail(DSGD_EUNSUPPORTED, "the MFMA variant handles at most 4096 features (one wave per 256 columns)");
@@ -2800,19 +2776,6 @@ int dsgd_dense_create(int32_t n_features, int32_t device, dsgd_dense** out) {
   if (e == hipSuccess) e = hipMalloc(&d->d_lpart, sizeof(double) * 2 * d->n_wg);
   if (e == hipSuccess) e = hipHostMalloc(&d->h_lpart, sizeof(double) * 2 * d->n_wg, hipHostMallocDefault);
   if (e == hipSuccess) e = hipMemset(d->d_w, 0, sizeof(float) * d->D);
-  if (e == hipSuccess) e = hipMalloc(&d->d_ticket, sizeof(unsigned int));
-  if (e == hipSuccess) e = hipMemset(d->d_ticket, 0, sizeof(unsigned int));
-  if (e == hipSuccess) e = hipHostMalloc(&d->h_bail, sizeof(unsigned int), hipHostMallocMapped);
-  if (e == hipSuccess) {
-    *d->h_bail = 0;
-    e = hipHostGetDevicePointer((void**)&d->d_bail, d->h_bail, 0);
-  }
-  if (e == hipSuccess) {
-    // the fused tail's wait needs every workgroup of a launch resident at once
-    int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dsgd_dense_step_kernel<true>, d->D / DN_COLS, 0);
-    d->fused_cap = per_cu * d->n_cu;
-  }
   if (e != hipSuccess) {
     dsgd_dense_destroy(d);
     return fail(DSGD_EHIP, "dense create: %s", hipGetErrorString(e));
@@ -2837,8 +2800,6 @@ int dsgd_dense_destroy(dsgd_dense* d) {
   (void)hipFree(d->d_gpart);
   (void)hipFree(d->d_lpart);
   if (d->h_lpart) (void)hipHostFree(d->h_lpart);
-  (void)hipFree(d->d_ticket);
-  if (d->h_bail) (void)hipHostFree(d->h_bail);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
   return DSGD_OK;
@@ -2909,11 +2870,9 @@ int dsgd_dense_step(dsgd_dense* d, int64_t row_begin, int64_t row_end, float lr)
   DSGD_TRY(dn_bind(d));
   std::lock_guard<std::mutex> lk(d->mu);
   DSGD_TRY(dn_check_range(d, row_begin, row_end));
-  const float scale = lr / ((float)(row_end - row_begin) * (float)d->world);   // every rank contributes an equal batch
-  bool fused = false;
-  const int grid = dn_launch(d, row_begin, row_end, true, scale, &fused);
+  const int grid = dn_launch(d, row_begin, row_end, true);
   if (grid < 0) return grid;
-  if (fused) return DSGD_OK;   // reduce + update ran in the step kernel's tail
+  const float scale = lr / ((float)(row_end - row_begin) * (float)d->world);   // every rank contributes an equal batch
   hipLaunchKernelGGL(dsgd_dense_reduce_kernel, dim3((d->D + 63) / 64), dim3(1024), 0, d->stream, d->d_gpart, grid, d->D, d->d_g,
                      d->comm ? (float*)nullptr : d->d_w, scale);
   HIP_TRY(hipGetLastError());
@@ -2929,10 +2888,6 @@ int dsgd_dense_synchronize(dsgd_dense* d) {
   DSGD_TRY(dn_bind(d));
   std::lock_guard<std::mutex> lk(d->mu);
   HIP_TRY(hipStreamSynchronize(d->stream));
-  if (*d->h_bail) {
-    *d->h_bail = 0;
-    return fail(DSGD_EHIP, "a fused dense step gave up waiting for its grid (weights not updated by that step)");
-  }
   return dn_collect(d);
 }
 

@@ -46,28 +46,6 @@ def test_steps_match_the_oracle(monkeypatch, n, d, batch, mfma):
         assert abs(acc - acc_ref) <= 2.0 / n   # rows with z within round-off of 0
 
 
-@pytest.mark.parametrize("n,d,batch", [(1000, 512, 100), (4099, 1024, 1024), (12288, 4096, 4096), (2048, 4096, 777),
-                                       (300, 8192, 300), (5000, 8192, 2500)])
-def test_fused_and_two_kernel_steps_agree_bit_for_bit(monkeypatch, n, d, batch):
-    """The step kernel's fused tail (reduce + update behind a grid-wide ticket) adds the partials in the two-kernel form's
-    order: DSGD_DENSE_FUSED=0 and the default leave identical weights and identical summed gradients.  Covers a full
-    grid (4,096 rows of 4,096 features: 512 workgroups), ragged last batches, one-wave workgroups (D = 512) and a
-    shape the fused form declines (D = 8192 with more workgroups than are resident at once)."""
-    X, y = make(n, d, 7 * n + d)
-    out = []
-    for fused in ("1", "0"):
-        monkeypatch.setenv("DSGD_DENSE_FUSED", fused)
-        with dsgd_amd.DenseLogistic(d) as eng:
-            eng.load(X, y)
-            for rep in range(2):
-                for b in range(0, n, batch):
-                    eng.step(b, min(n, b + batch), 3.0)
-            eng.synchronize()
-            out.append(eng.get_weights())
-    assert np.abs(out[0]).max() > 1e-3
-    np.testing.assert_array_equal(out[0], out[1])
-
-
 def test_generated_shard_trains_and_errors():
     with pytest.raises(ValueError):
         dsgd_amd.DenseLogistic(1000)        # D must be a multiple of 512

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""K8 tuning aid: wall time per dense mini-batch step with the reduce + update fused into the step kernel's tail
-(default) and as a second kernel (DSGD_DENSE_FUSED=0), no per-launch events.
+"""K8 tuning aid: wall time per dense mini-batch step (no per-launch events), best of three runs per batch size.
+At commit 21f3295 the library also had the reduce + update fused into the step kernel's tail (DSGD_DENSE_FUSED): this
+script produced profiles/r03_dense_fused_tail_ab.json there (fused measured slower; see profiles/README.md).
 
     python tools/dense_check.py [rows]
 """
@@ -16,8 +17,7 @@ import dsgd_amd  # noqa: E402
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1250000
 dim = 4096
 out = {"rows": rows, "dim": dim, "cases": []}
-for fused in ("1", "0"):
-    os.environ["DSGD_DENSE_FUSED"] = fused
+for fused in ("0",):
     with dsgd_amd.DenseLogistic(dim) as eng:
         eng.generate(rows, seed=0)
         for b, steps in ((4096, 400), (65536, 40), (1024, 400), (512, 400)):
