@@ -141,16 +141,6 @@ __device__ __forceinline__ float w_at(const float* wl, const float* __restrict__
   return a;
 }
 
-// Same, with an unconditional global load (hot lanes all read w[0], one cache line): no branch
-// around a VMEM instruction, so the surrounding loop keeps counted vmcnt waits.
-__device__ __forceinline__ float w_at_uncond(const float* wl, const float* __restrict__ w, int c, int hw) {
-  const bool hot = c < hw;
-  typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
-  const float a = ((lds_cvfloat*)wl)[hot ? c : 0];
-  const float b = __builtin_nontemporal_load(w + (hot ? 0 : c));
-  return hot ? a : b;
-}
-
 // A row held by a group of G lanes: the first UNR*G non-zeros stay in registers between the
 // dot product and the scatter (no second trip to memory for ~half of the rows).
 template <int G, int UNR>
