@@ -196,10 +196,16 @@ def main():
             eng.sync_step_ranges(ranges, 0.0, asynchronous=True)
         sync_all(eng)
         now = time.perf_counter()
-        g = now - t_g
+        g, elapsed = now - t_g, now - t_ramp
+        if world > 1:
+            # every step carries an all-reduce: the ranks must leave the ramp after the SAME number of steps, so they
+            # decide on the same numbers (the slowest rank's group time, the longest elapsed time)
+            t = torch.tensor([g, elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            g, elapsed = float(t[0].item()), float(t[1].item())
         settled = settled + 1 if g <= 1.015 * best else 0
         best = min(best, g)
-        if (now - t_ramp >= args.clock_ramp and settled >= 2) or now - t_ramp >= 6.0 * args.clock_ramp:
+        if (elapsed >= args.clock_ramp and settled >= 2) or elapsed >= 6.0 * args.clock_ramp:
             break
     ramp_s = time.perf_counter() - t_ramp
     eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
