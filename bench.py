@@ -82,6 +82,31 @@ def spawn_ranks(n):
     return rc
 
 
+def clock_ramp(run_group, nominal_s, world=1, dist=None):
+    """Run groups of untimed steps until two groups in a row took within 1.5 % of the fastest group seen and at least
+    `nominal_s` have passed, or 6 x `nominal_s` at the latest.  Returns the number of groups.  With more than one rank
+    every step carries an all-reduce, so the ranks must leave after the SAME number of groups: they decide on the
+    same numbers (the slowest rank's group time, the longest elapsed time), agreed through `dist`."""
+    t_ramp = time.perf_counter()
+    best, settled, groups = float("inf"), 0, 0
+    while True:
+        t_g = time.perf_counter()
+        run_group()
+        now = time.perf_counter()
+        g, elapsed = now - t_g, now - t_ramp
+        if world > 1:
+            import torch
+
+            t = torch.tensor([g, elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            g, elapsed = float(t[0].item()), float(t[1].item())
+        groups += 1
+        settled = settled + 1 if g <= 1.015 * best else 0
+        best = min(best, g)
+        if (elapsed >= nominal_s and settled >= 2) or elapsed >= 6.0 * nominal_s:
+            return groups
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -188,25 +213,13 @@ def main():
     # unchanged) for a fixed wall time bring the clocks up; the W warmup steps and the K timed steps follow unchanged.
     # (some boxes of the pool need longer than others: the ramp goes on -- up to 6x the nominal time -- until two groups
     #  of steps in a row ran within 1.5 % of the fastest group seen)
-    t_ramp = time.perf_counter()
-    best, settled = float("inf"), 0
-    while True:
-        t_g = time.perf_counter()
+    def ramp_group():
         for _ in range(8):
             eng.sync_step_ranges(ranges, 0.0, asynchronous=True)
         sync_all(eng)
-        now = time.perf_counter()
-        g, elapsed = now - t_g, now - t_ramp
-        if world > 1:
-            # every step carries an all-reduce: the ranks must leave the ramp after the SAME number of steps, so they
-            # decide on the same numbers (the slowest rank's group time, the longest elapsed time)
-            t = torch.tensor([g, elapsed], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            g, elapsed = float(t[0].item()), float(t[1].item())
-        settled = settled + 1 if g <= 1.015 * best else 0
-        best = min(best, g)
-        if (elapsed >= args.clock_ramp and settled >= 2) or elapsed >= 6.0 * args.clock_ramp:
-            break
+
+    t_ramp = time.perf_counter()
+    clock_ramp(ramp_group, args.clock_ramp, world, dist if world > 1 else None)
     ramp_s = time.perf_counter() - t_ramp
     eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
 

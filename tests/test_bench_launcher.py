@@ -31,6 +31,52 @@ def test_launcher_environment_is_respected():
     assert proc.returncode != 0 and "--gpus 2 but WORLD_SIZE=4" in proc.stderr
 
 
+_RAMP_RANK = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+import bench
+rank = int(os.environ["RANK"])
+dist.init_process_group(backend="gloo", rank=rank, world_size=2)
+n = [0]
+def group():                      # rank 1 is slower and noisier: alone it would leave the ramp at a different point
+    n[0] += 1
+    time.sleep(0.002 if rank == 0 else 0.004 + 0.003 * (n[0] % 3))
+    dist.barrier()                # stands for the all-reduce inside every step: unmatched calls would hang here
+groups = bench.clock_ramp(group, 0.15, 2, dist)
+alone = bench.clock_ramp(lambda: time.sleep(0.001), 0.02)
+dist.barrier()
+dist.destroy_process_group()
+print("RAMP", rank, groups, n[0], alone)
+"""
+
+
+def test_ranks_leave_the_clock_ramp_together(tmp_path):
+    """bench.py's clock ramp ends on a timing criterion; with N > 1 every ramp step carries an all-reduce, so ranks
+    that left after different numbers of steps would leave unmatched collectives behind (a hang at the end of the
+    run).  Two gloo ranks with different timings must report the same number of groups."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "ramp_rank.py"
+    script.write_text(_RAMP_RANK)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    lines = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+        lines.append([l for l in so.splitlines() if l.startswith("RAMP")][0].split())
+    g0, g1 = int(lines[0][2]), int(lines[1][2])
+    assert g0 == g1 and g0 == int(lines[0][3]) == int(lines[1][3]) and g0 >= 3, lines
+    assert int(lines[0][4]) >= 3    # a single rank needs no process group
+
+
 def test_committed_bench_line_keeps_the_contract():
     """The bench line the last GPU visit produced (profiles/r03_bench.json): the keys, types and internal arithmetic of
     the driver's contract -- whole-job examples/s from the timed steps, the dominant kernel's roofline fraction from its
