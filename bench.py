@@ -123,6 +123,8 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: no need to resolve the container's hostname
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
