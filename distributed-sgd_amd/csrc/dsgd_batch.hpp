@@ -1252,6 +1252,19 @@ struct HogState {
   unsigned long long atomics;   // lane-level atomicAdd(w[j], -delta_j) performed: the coordinates the updates really moved
 };
 
+// Traced runs (dsgd_async_set_trace; parity evidence for many workers, tests/test_gpu_hogwild_trace.py): the update
+// whose returning atomic on HogState::updates saw `commit - 1` leaves record [commit - 1] = {its worker, that worker's
+// iteration number (the sampler's key), the update count its weights were read at}.  `read_at` is what thread 0's
+// returning atomic of the worker's PREVIOUS commit returned (the launch's starting count for a first iteration): the
+// LDS copy of the hot weights is requested right next to that atomic, so the snapshot the gradient was computed on is
+// "the weights after update #read_at" up to the few updates in flight around it.  The oracle replays Slave.asyncTask
+// (core/Slave.scala:92-101) in commit order with exactly these staleness values (oracle/hogwild_replay.py).
+struct HogTrace {
+  int worker;
+  unsigned int it;
+  unsigned long long read_at;
+};
+
 struct HogArgs {
   CsrView m;
   float* w;
@@ -1266,6 +1279,8 @@ struct HogArgs {
   float lr, lambda;
   float qscale, inv_qscale;     // 2^shift / vmax2 and its inverse
   int batch, positional_bug, hl, wl, dp;   // hl: ranks with an LDS accumulator; wl: ranks with an LDS copy of w (whole 1 KiB pieces: a multiple of 256)
+  HogTrace* trace;              // optional (dsgd_async_set_trace): one record per mini-batch update, indexed by its commit number
+  long long trace_cap;
 };
 
 __device__ __forceinline__ unsigned long long hog_mix(unsigned long long z) {
@@ -1368,7 +1383,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   unsigned long long it = a.it[worker];
   hog_wcache_issue(a.w, wl, a.wl);   // (lands under the start-up loads below; waited for in front of the first barrier)
   // thread 0 carries the shared scalars between iterations: what its own returning atomics saw
-  unsigned long long u = 0;
+  unsigned long long u = 0;   // (between commits: the update count this iteration's weights were read at)
   float s = 0.0f;
   if (tid == 0) {
     u = __hip_atomic_load(&a.st->updates, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1544,7 +1559,15 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         const float corr = (float)(2.0 * (double)a.lambda * dot) - s;
         s = atomicAdd(&a.st->s_reg, corr) + corr;
       }
+      const unsigned long long read_at = u;
       u = atomicAdd(&a.st->updates, 1ull) + 1ull;
+      if (a.trace && (long long)u <= a.trace_cap) {   // (16 bytes, one lane, once per mini-batch)
+        HogTrace rec;
+        rec.worker = worker;
+        rec.it = (unsigned int)it;
+        rec.read_at = read_at;
+        a.trace[u - 1] = rec;
+      }
       atomicAdd(&a.st->samples, (unsigned long long)B);
       atomicAdd(&a.st->active, (unsigned long long)(na & (HOG_ATOMIC_ONE - 1u)));
       atomicAdd(&a.st->atomics, (unsigned long long)(na >> 13));

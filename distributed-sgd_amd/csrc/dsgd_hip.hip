@@ -272,6 +272,8 @@ struct dsgd_ctx {
   float* d_gcold = nullptr;
   long long* d_asg = nullptr;  // begin[n], end[n]
   unsigned long long* d_hog_it = nullptr;   // per worker: iterations done (continues across exchange rounds)
+  HogTrace* d_trace = nullptr;              // dsgd_async_set_trace: one record per update of the next engine runs
+  long long trace_cap = 0;
   int* h_one = nullptr;        // pinned constant 1: source of the stop-flag copy
   // small-batch plan kernel (one persistent workgroup): cold strip and the multi-worker sum buffer
   unsigned long long* d_tprof = nullptr;   // DSGD_PLAN_PROF=1: phase cycle counters of dsgd_plan_kernel (tuning runs)
@@ -1529,6 +1531,7 @@ int dsgd_destroy(dsgd_ctx* c) {
   if (c->h_hog) (void)hipHostFree(c->h_hog);
   if (c->h_one) (void)hipHostFree(c->h_one);
   (void)hipFree(c->d_hog_it);
+  (void)hipFree(c->d_trace);
   (void)hipFree(c->d_wprev);
   (void)hipFree(c->d_wdelta);
   (void)hipFree(c->d_tprof);
@@ -2317,6 +2320,8 @@ static int hog_launch(dsgd_ctx* c, long long max_updates) {
   a.hl = std::min(c->dp, c->hog_hl);
   a.dp = c->dp;
   a.wl = std::min(c->hog_wl, c->dp) & ~255;
+  a.trace = c->d_trace;
+  a.trace_cap = c->trace_cap;
   const size_t lds = sizeof(float) * (size_t)hog_lds_words(a.hl, a.wl, c->dp);
   hipLaunchKernelGGL(dsgd_hogwild_kernel, dim3(c->hog_n), dim3(HOG_THREADS), lds, c->async_stream, a);
   HIP_TRY(hipGetLastError());
@@ -2517,6 +2522,51 @@ int dsgd_async_stats(dsgd_ctx* c, int64_t* counters, double* s_engine, double* s
     DSGD_TRY(read_scalars(c));
     if (c->async_running) c->s_dirty = true;
     *s_exact = (double)c->h_sc->s_reg;
+  }
+  return DSGD_OK;
+}
+
+int dsgd_async_set_trace(dsgd_ctx* c, int64_t capacity) {
+  DSGD_TRY(check_ctx(c));
+  if (capacity < 0) return fail(DSGD_EINVAL, "negative trace capacity");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  if (c->async_running) return fail(DSGD_ESTATE, "async computation running");
+  if (capacity != c->trace_cap) {
+    (void)hipFree(c->d_trace);   // (no engine is resident: hipFree's device synchronisation returns)
+    c->d_trace = nullptr;
+    c->trace_cap = 0;
+    if (capacity > 0) {
+      HIP_TRY(hipMalloc(&c->d_trace, sizeof(HogTrace) * (size_t)capacity));
+      c->trace_cap = capacity;
+    }
+  }
+  return DSGD_OK;
+}
+
+int dsgd_async_read_trace(dsgd_ctx* c, int32_t* worker, uint32_t* iteration, int64_t* read_at, int64_t n, int64_t* n_out) {
+  DSGD_TRY(check_ctx(c));
+  if (n < 0 || (n > 0 && (!worker || !iteration || !read_at))) return fail(DSGD_EINVAL, "bad trace arguments");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  if (c->async_running) return fail(DSGD_ESTATE, "async computation running (dsgd_async_wait / dsgd_async_stop first)");
+  if (!c->d_trace || !c->d_hog) return fail(DSGD_ESTATE, "no traced run on this context (dsgd_async_set_trace, then dsgd_async_start)");
+  DSGD_TRY(async_refresh(c));
+  const long long have = std::min<long long>((long long)c->h_hog->updates, c->trace_cap);
+  const long long m = std::min<long long>(have, n);
+  if (n_out) *n_out = have;
+  if (m == 0) return DSGD_OK;
+  std::vector<HogTrace> recs;
+  try {
+    recs.resize((size_t)m);
+  } catch (const std::bad_alloc&) {
+    return fail(DSGD_ENOMEM, "out of host memory");
+  }
+  HIP_TRY(hipMemcpy(recs.data(), c->d_trace, sizeof(HogTrace) * (size_t)m, hipMemcpyDeviceToHost));
+  for (long long i = 0; i < m; ++i) {
+    worker[i] = recs[(size_t)i].worker;
+    iteration[i] = recs[(size_t)i].it;
+    read_at[i] = (int64_t)recs[(size_t)i].read_at;
   }
   return DSGD_OK;
 }

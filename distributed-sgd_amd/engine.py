@@ -203,6 +203,23 @@ class Engine:
         check(self._lib.dsgd_async_stats(self._ctx, cnt, C.byref(a), C.byref(b)))
         return {"updates": cnt[0], "samples": cnt[1], "active": cnt[2], "atomics": cnt[3], "s_engine": a.value, "s_exact": b.value}
 
+    def async_set_trace(self, capacity):
+        """Attach a trace of `capacity` update records to the following lock-free runs (0 detaches it)."""
+        check(self._lib.dsgd_async_set_trace(self._ctx, C.c_int64(capacity)))
+
+    def async_read_trace(self):
+        """(worker, iteration, read_at) of every recorded update of the last run, in commit order (record i = update
+        number i + 1); see dsgd_async_set_trace."""
+        n = C.c_int64(0)
+        check(self._lib.dsgd_async_read_trace(self._ctx, None, None, None, C.c_int64(0), C.byref(n)))
+        k = n.value
+        worker = np.zeros(k, dtype=np.int32)
+        it = np.zeros(k, dtype=np.uint32)
+        read_at = np.zeros(k, dtype=np.int64)
+        if k:
+            check(self._lib.dsgd_async_read_trace(self._ctx, ptr(worker), ptr(it), ptr(read_at), C.c_int64(k), None))
+        return worker, it, read_at
+
     # -- multi-GPU ---------------------------------------------------------------------------------
     @staticmethod
     def comm_unique_id():

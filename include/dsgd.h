@@ -195,6 +195,15 @@ int dsgd_async_stop(dsgd_ctx* ctx); /* SlaveImpl.stopAsync, core/Slave.scala:187
  * While the engine runs the two differ by the updates in flight.                                                  */
 int dsgd_async_stats(dsgd_ctx* ctx, int64_t* counters, double* s_engine, double* s_exact);
 int dsgd_async_wait(dsgd_ctx* ctx); /* block until max_updates reached */
+/* Parity aid for the MANY-worker lock-free engine (nothing in the reference; tests/test_gpu_hogwild_trace.py, bench.py):
+ * with a trace of `capacity` records attached (0 detaches it), every mini-batch update of the following engine runs
+ * leaves one record at index (its commit number - 1): the worker that made it, that worker's iteration number (the key
+ * of the engine's replayable sampler) and the update count its weights were read at.  The oracle
+ * replays Slave.asyncTask (core/Slave.scala:92-101) in commit order with exactly these staleness values
+ * (oracle/hogwild_replay.py) -- a many-worker parity statement that can fail.  dsgd_async_read_trace copies the first
+ * min(n, recorded) records of the LAST run out (engine joined); *n_out (may be NULL) = records available.           */
+int dsgd_async_set_trace(dsgd_ctx* ctx, int64_t capacity);
+int dsgd_async_read_trace(dsgd_ctx* ctx, int32_t* worker, uint32_t* iteration, int64_t* read_at, int64_t n, int64_t* n_out);
 
 /* ---- multi-GPU (one process per GPU) ---------------------------------------
  * The synchronous master's aggregate (core/Master.scala:190-194: Future.sequence barrier +

@@ -715,26 +715,7 @@ def test_virtual_tiles_on_ragged_rows(monkeypatch, hsplit, pack_mb):
 
 
 # ---- persistent lock-free ("Hogwild") engine -----------------------------------------------------------
-M64 = (1 << 64) - 1
-
-
-def hog_mix(z):  # csrc/dsgd_kernels.hpp: hog_mix (splitmix64 finaliser)
-    z = (z + 0x9E3779B97F4A7C15) & M64
-    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
-    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
-    return z ^ (z >> 31)
-
-
-def hog_rows(seed, worker, it, begin, n_k, batch, positional_bug):
-    """The rows iteration `it` of worker `worker` samples (mirror of dsgd_hogwild_kernel)."""
-    import math
-    key = hog_mix(seed ^ hog_mix((worker * 0x100000001B3 + it) & M64))
-    mul = 1 + hog_mix(key) % n_k
-    while math.gcd(mul, n_k) != 1:
-        mul = mul % n_k + 1
-    off = hog_mix(key ^ 0xABCDEF12345) % n_k
-    base = 0 if positional_bug else begin
-    return np.asarray([base + (mul * t + off) % n_k for t in range(batch)], dtype=np.int32)
+from oracle.hogwild_replay import hog_rows  # noqa: E402  (the host mirror of the engine's sampler)
 
 
 def test_hogwild_single_worker_replays_the_oracle():
