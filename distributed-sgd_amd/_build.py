@@ -56,12 +56,15 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (looked in %s/bin and PATH)" % ROCM)
 
 
-def build_hip(force: bool = False) -> str:
+def build_hip(force: bool = False, out: str | None = None, defines: tuple = ()) -> str:
+    """libdsgd_hip.so.  `out` / `defines`: a second build of the same sources under another name -- the tests' seam
+    build (tests/rccl_stub/libdsgd_hip_seam.so, -DDSGD_TEST_COLLECTIVE_SEAM); the product is always built without."""
     header = os.path.join(HERE, "..", "include", "dsgd.h")
-    if not force and not _stale(HIP_LIB, HIP_SRC, os.path.join(CSRC, "dsgd_kernels.hpp"), os.path.join(CSRC, "dsgd_batch.hpp"), os.path.join(CSRC, "dsgd_dense.hpp"),
+    target = out or HIP_LIB
+    if not force and not _stale(target, HIP_SRC, os.path.join(CSRC, "dsgd_kernels.hpp"), os.path.join(CSRC, "dsgd_batch.hpp"), os.path.join(CSRC, "dsgd_dense.hpp"),
                               header, __file__):
-        return HIP_LIB
-    os.makedirs(LIBDIR, exist_ok=True)
+        return target
+    os.makedirs(os.path.dirname(target), exist_ok=True)
     stub_dir = tempfile.mkdtemp(prefix="dsgd_stub_")
     stub = os.path.join(stub_dir, "libamdhip64.so")
     empty = os.path.join(stub_dir, "empty.c")
@@ -78,9 +81,10 @@ def build_hip(force: bool = False) -> str:
         "-munsafe-fp-atomics",  # fp32 atomicAdd -> global_atomic_add_f32, not a CAS loop
         "-Wall",
         "-Wno-unused-function",
+        *["-D" + d for d in defines],
         HIP_SRC,
         "-o",
-        HIP_LIB,
+        target,
         "-L" + stub_dir,
         "-Wl,-rpath," + os.path.join(ROCM, "lib"),
         "-ldl",
@@ -90,7 +94,7 @@ def build_hip(force: bool = False) -> str:
         _run(cmd)
     finally:
         shutil.rmtree(stub_dir, ignore_errors=True)
-    return HIP_LIB
+    return target
 
 
 def build_synth(force: bool = False) -> str:

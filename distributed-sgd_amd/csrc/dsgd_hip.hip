@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -75,12 +76,17 @@ static bool ok = false;
 
 static void load() {
   void* h = nullptr;
-  // DSGD_RCCL_LIB=<path>: use exactly this library for the collectives (tests/rccl_stub: a host-staged shim that lets
-  // two ranks share ONE device, which RCCL refuses -- the world = 2 arithmetic on a one-GPU box); no fallback
+#ifdef DSGD_TEST_COLLECTIVE_SEAM
+  // TEST BUILDS ONLY (tests/rccl_stub/build_seam.py compiles this file a second time with -DDSGD_TEST_COLLECTIVE_SEAM into
+  // tests/rccl_stub/libdsgd_hip_seam.so): DSGD_RCCL_LIB=<path> names the library that serves the collectives -- a
+  // host-staged shim that lets several ranks share ONE device, which RCCL refuses (the world = 2 arithmetic on a one-GPU
+  // box).  The product library (distributed-sgd_amd/lib/libdsgd_hip.so) is compiled without this block: no environment
+  // variable can put anything in RCCL's place there.
   if (const char* forced = getenv("DSGD_RCCL_LIB")) {
     h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
     if (!h) return;
   }
+#endif
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);  // reuse a copy the process already has
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
@@ -289,6 +295,8 @@ struct dsgd_ctx {
   float* d_wprev = nullptr;       // weights at the last exchange
   float* d_wdelta = nullptr;      // 2 x dp: all-reduced updates, this replica's own part
   bool async_running = false;
+  bool join_in_progress = false;            // one thread blocks on the engine (without the mutex); the others wait for it
+  std::condition_variable join_cv;
   // exchange mode: the rounds (engine launch, delta, all-reduce, apply) are enqueued by a helper thread so that
   // dsgd_async_start returns at once and dsgd_async_updates / dsgd_async_stop stay responsive
   std::thread exch_thread;
@@ -577,7 +585,16 @@ static int launch_grad_mb(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, 
 // lanes of a 64-lane tile (whole rows per tile, every list starts a tile).  Not possible (vt_ok = false, the plan keeps
 // using dsgd_mb_grad_kernel) when a row sits on the long-row list, holds more than 64 cold entries, or the streams are
 // not in their 16-bit / 32-bit-addressable form.
-static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
+// (returns 1 for a SOFT failure -- host or device memory for the layout could not be had: vt_build frees what was
+//  allocated and the plan runs from dsgd_mb_grad_kernel, exactly as for lists the layout cannot hold)
+#define VT_SOFT(expr)                 \
+  do {                                \
+    if ((expr) != hipSuccess) {       \
+      (void)hipGetLastError();        \
+      return 1;                       \
+    }                                 \
+  } while (0)
+static int vt_build_impl(dsgd_ctx* c, dsgd_plan* p) {
   p->vt_layout = c->layout_gen;
   p->vt_ok = false;
   (void)hipFree(p->d_vt_lanes);
@@ -681,9 +698,9 @@ static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
     p->vt_grid[(size_t)s] = (int)(gx + gl);
     p->vt_shift[(size_t)s] = std::min(21, 30 - bits);   // (<= 21: the fixed-point conversion is one fma against 1.5 * 2^23)
   }
-  HIP_TRY(hipMalloc(&p->d_vt_lanes, sizeof(VtLane) * std::max<size_t>(lanes.size(), 64)));
-  HIP_TRY(hipMalloc(&p->d_vt_segs, sizeof(WorkSeg) * segs.size()));
-  HIP_TRY(hipMalloc(&p->d_vt_long, sizeof(MbRec) * std::max<size_t>(long_rows.size(), 1)));
+  VT_SOFT(hipMalloc(&p->d_vt_lanes, sizeof(VtLane) * std::max<size_t>(lanes.size(), 64)));
+  VT_SOFT(hipMalloc(&p->d_vt_segs, sizeof(WorkSeg) * segs.size()));
+  VT_SOFT(hipMalloc(&p->d_vt_long, sizeof(MbRec) * std::max<size_t>(long_rows.size(), 1)));
   HIP_TRY(hipMemcpy(p->d_vt_lanes, lanes.data(), sizeof(VtLane) * lanes.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(p->d_vt_segs, segs.data(), sizeof(WorkSeg) * segs.size(), hipMemcpyHostToDevice));
   if (!long_rows.empty())
@@ -691,7 +708,14 @@ static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
   // small and mid-size plans get their own copy of the rows they touch, in tile order (dsgd_vt_pack_kernel): one
   // coalesced round trip per step instead of descriptors -> scattered rows
   const long long n_tiles = (long long)tile_rows.size();
-  if (n_tiles > 0 && n_tiles * 4096 <= c->vt_pack_mb * (1LL << 20) &&
+  // (bounded by DSGD_VT_PACK_MB and by a quarter of the device memory that is free right now: a plan's copy must not be
+  //  what makes the next allocation of the data path fail)
+  size_t mem_free = 0, mem_total = 0;
+  if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) {
+    (void)hipGetLastError();
+    mem_free = 0;
+  }
+  if (n_tiles > 0 && n_tiles * 4096 <= c->vt_pack_mb * (1LL << 20) && (size_t)n_tiles * 4096 <= mem_free / 4 &&
       hipMalloc(&p->d_vt_packed, (size_t)n_tiles * 4096) != hipSuccess) {
     (void)hipGetLastError();      // (no room for the copy: the plan runs from its descriptors)
     p->d_vt_packed = nullptr;
@@ -712,6 +736,28 @@ static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
   }
   p->vt_ok = true;
   return DSGD_OK;
+}
+#undef VT_SOFT
+static int vt_build(dsgd_ctx* c, dsgd_plan* p) {
+  int rc;
+  try {
+    rc = vt_build_impl(c, p);
+  } catch (const std::bad_alloc&) {   // (160 bytes of host memory per listed row; nothing may unwind across the C ABI)
+    rc = 1;
+  }
+  if (rc == 1) {
+    (void)hipFree(p->d_vt_lanes);
+    (void)hipFree(p->d_vt_segs);
+    (void)hipFree(p->d_vt_long);
+    (void)hipFree(p->d_vt_packed);
+    p->d_vt_lanes = nullptr;
+    p->d_vt_segs = nullptr;
+    p->d_vt_long = nullptr;
+    p->d_vt_packed = nullptr;
+    p->vt_ok = false;   // (vt_layout is stamped: the plan keeps the row-wise kernel until the layout changes)
+    return DSGD_OK;
+  }
+  return rc;
 }
 
 static int launch_grad_vt(dsgd_ctx* c, dsgd_plan* p, long long step) {
@@ -2258,7 +2304,9 @@ int dsgd_update_grad(dsgd_ctx* c, const int32_t* key, const float* dv, int64_t n
     HIP_TRY(hipMalloc(&c->d_upd_dv, sizeof(float) * (size_t)cap));
     c->upd_cap = cap;
   }
-  const bool live = c->async_running;
+  // (an engine that has reached its budget but has not been joined yet is not live: its kernel has exited, nothing adds
+  //  to w any more and nobody reads HogState::s_reg -- the update takes the plain path with the Sparse filter pass)
+  const bool live = c->async_running && !(c->exch_done.load() && hipStreamQuery(c->async_stream) == hipSuccess);
   hipStream_t st = live ? c->upd_stream : c->stream;
   for (int64_t o = 0; o < nnz; o += c->upd_cap) {
     const long long n = std::min<long long>(c->upd_cap, nnz - o);
@@ -2491,13 +2539,35 @@ static int async_join(dsgd_ctx* c) {
   return DSGD_OK;
 }
 
+// Block until the engine has left the device -- WITHOUT the context's mutex: dsgd_update_grad, dsgd_loss_acc and
+// dsgd_async_updates are RPC handlers of other pool threads in the reference (core/Slave.scala:177-185 runs while
+// asyncTask does) and must not queue up behind a waiter for as long as the update budget lasts.  One thread does the
+// blocking; a second waiter sleeps on the condition variable.
+static int async_wait_released(dsgd_ctx* c, std::unique_lock<std::mutex>& lk) {
+  if (c->join_in_progress) {
+    c->join_cv.wait(lk, [c] { return !c->join_in_progress; });
+    return DSGD_OK;   // (the joining thread reports the engine's errors)
+  }
+  c->join_in_progress = true;
+  hipStream_t st = c->async_stream;
+  lk.unlock();
+  if (c->exch_thread.joinable()) c->exch_thread.join();   // (it never takes the context's mutex)
+  const hipError_t e = hipStreamSynchronize(st);
+  lk.lock();
+  c->join_in_progress = false;
+  c->join_cv.notify_all();
+  if (e != hipSuccess) return fail(DSGD_EHIP, "hipStreamSynchronize(async stream): %s", hipGetErrorString(e));
+  if (!c->async_running) return DSGD_OK;
+  return async_join(c);   // (its own synchronisations return at once now)
+}
+
 int dsgd_async_stop(dsgd_ctx* c) {  // ref: SlaveImpl.stopAsync, core/Slave.scala:187-195
   DSGD_TRY(check_ctx(c));
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::unique_lock<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
   if (!c->async_running) return DSGD_OK;
   DSGD_TRY(hog_raise_stop(c));
-  return async_join(c);
+  return async_wait_released(c, lk);
 }
 
 int dsgd_async_stats(dsgd_ctx* c, int64_t* counters, double* s_engine, double* s_exact) {
@@ -2573,10 +2643,10 @@ int dsgd_async_read_trace(dsgd_ctx* c, int32_t* worker, uint32_t* iteration, int
 
 int dsgd_async_wait(dsgd_ctx* c) {
   DSGD_TRY(check_ctx(c));
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::unique_lock<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
   if (!c->async_running) return DSGD_OK;
-  return async_join(c);
+  return async_wait_released(c, lk);
 }
 
 int dsgd_comm_unique_id(char* id_out) {

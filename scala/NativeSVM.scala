@@ -88,10 +88,13 @@ class HipSVM(lambda: Number, dimSparsity: Vec, data: Array[(Vec, Int)], nTrain: 
     p.map(x => Number(x.toDouble))
   }
 
-  /** Master.localLoss / localAccuracy over a row range (core/Master.scala:100-107) */
+  /** Master.localLoss / localAccuracy over a row range (core/Master.scala:100-107).  In resident mode the weights on
+    * the device ARE the model's weights and are evaluated IN PLACE (a null `w`: dsgd_loss_acc then writes nothing): the
+    * `w` a caller holds is a snapshot of them, and writing it back would discard every update the slave threads applied
+    * since it was taken (MasterAsync's loss check runs while they do, core/MasterAsync.scala:96-162). */
   def lossAndAccuracy(w: Vec, rowBegin: Int, rowEnd: Int): (Number, Double) = {
     val out = new Array[Double](2)
-    NativeSVM.lossAcc(ctx, DenseKeys.fromVec(w), rowBegin, rowEnd, out)
+    NativeSVM.lossAcc(ctx, if (resident) null else DenseKeys.fromVec(w), rowBegin, rowEnd, out)
     (Number(out(0)), out(1))
   }
 

@@ -27,7 +27,7 @@ from conftest import has_gpu
 from oracle import bounds as orb
 from oracle import dense_ref
 from oracle import oracle as orc
-from test_rccl_stub import build_stub
+from test_rccl_stub import seam_env
 from world2_common import CFG, dense_problem, local_lists, shard_of
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="no gfx950 device")]
@@ -39,9 +39,7 @@ WORLD = 2
 @pytest.fixture(scope="module")
 def ranks(tmp_path_factory):
     wd = str(tmp_path_factory.mktemp("world2"))
-    env = dict(os.environ)
-    env["DSGD_RCCL_LIB"] = build_stub()
-    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env = seam_env()   # the seam build of the library (DSGD_LIB_PATH) over the shim (DSGD_RCCL_LIB)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "world2_worker.py"), str(r), str(WORLD), wd], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(WORLD)]
     outs = []

@@ -20,6 +20,40 @@ def build_stub():
     return LIB
 
 
+SEAM_LIB = os.path.join(HERE, "rccl_stub", "libdsgd_hip_seam.so")
+
+
+def build_seam():
+    """The TEST build of libdsgd_hip: the product's sources compiled a second time with -DDSGD_TEST_COLLECTIVE_SEAM, the only
+    build in which DSGD_RCCL_LIB can put the shim in RCCL's place (csrc/dsgd_hip.hip rccl::load).  Lives next to the
+    shim, never under distributed-sgd_amd/lib; a rank process selects it with DSGD_LIB_PATH."""
+    import importlib
+    import sys
+
+    root = os.path.dirname(HERE)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    pkg = importlib.import_module("distributed-sgd_amd")
+    return pkg._build.build_hip(out=SEAM_LIB, defines=("DSGD_TEST_COLLECTIVE_SEAM",))
+
+
+def seam_env(env=None):
+    """Environment of a rank process that runs the seam build over the shim."""
+    env = dict(os.environ if env is None else env)
+    env["DSGD_RCCL_LIB"] = build_stub()
+    env["DSGD_LIB_PATH"] = build_seam()
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+def test_the_product_library_has_no_collective_seam():
+    """The shipping library must not let an environment variable replace RCCL: the variable's name does not occur in it
+    -- and does in the tests' seam build."""
+    product = os.path.join(os.path.dirname(HERE), "distributed-sgd_amd", "lib", "libdsgd_hip.so")
+    assert b"DSGD_RCCL_LIB" not in open(product, "rb").read()
+    assert b"DSGD_RCCL_LIB" in open(build_seam(), "rb").read()
+
+
 class Uid(C.Structure):
     _fields_ = [("internal", C.c_char * 128)]
 

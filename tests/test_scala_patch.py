@@ -48,6 +48,9 @@ def test_patch_applies_to_the_reference_tree(tmp_path):
     assert "model.backward(w, x, y)" in slave and "model.regularize(grad, w)" in slave      # the JVM bodies are still there
     assert "h.syncStep(lists, learningRate)" in master and "worker.gradient(req)" in master
     assert "h.lossAndAccuracy(weights, lo, hi)" in master
+    # resident (dev) mode: the loss check evaluates the device weights in place -- a snapshot written back would discard
+    # the updates the slave threads applied since it was taken
+    assert "NativeSVM.lossAcc(ctx, if (resident) null else DenseKeys.fromVec(w), rowBegin, rowEnd, out)" in added
     assert "HipSVM.isResident(model)" in masync and "_.update(request.gradUpdate)" in masync
     # every method the patched code calls on HipSVM exists in the file the patch adds
     used = set(re.findall(r"\bh\.(\w+)\(", slave + master + masync + main)) | {"weights"}

@@ -1,5 +1,6 @@
 """One rank of tests/test_gpu_world2.py: a process of its own on device 0, its shard of the rows, the in-library
-collective path through the test-only shim (DSGD_RCCL_LIB = tests/rccl_stub/librccl_stub.so).
+collective path through the test-only shim (DSGD_RCCL_LIB = tests/rccl_stub/librccl_stub.so, honoured only by the
+tests' seam build of the library, DSGD_LIB_PATH = tests/rccl_stub/libdsgd_hip_seam.so).
 usage: python world2_worker.py <rank> <world> <workdir>"""
 
 import os
@@ -35,6 +36,7 @@ def exchange_uid(wd, name, rank, make):
 def main():
     rank, world, wd = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     assert os.environ.get("DSGD_RCCL_LIB"), "the worker must run with the shim selected explicitly"
+    assert os.environ.get("DSGD_LIB_PATH", "").endswith("libdsgd_hip_seam.so"), "... through the tests' seam build of the library"
     data = dsgd_amd.synth.generate(CFG["n_rows"], seed=CFG["seed"])
     sh = shard_of(data, CFG["n_train"], rank, world)
     out = {}
