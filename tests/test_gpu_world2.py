@@ -202,3 +202,35 @@ def test_dense_two_ranks_equal_one_process_over_the_union(ranks):
             dl.step(s * 2 * bsz, (s + 1) * 2 * bsz, 0.5)
         dl.synchronize()
         assert np.abs(dl.get_weights() - ranks[0]["w_dense"]).max() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("mode", ["strong", "weak"])
+def test_bench_parity_gate_with_two_ranks(mode):
+    """bench.py --gpus 2: the N > 1 parity gate EXECUTED (two ranks on the one device through the seam build + shim):
+    every rank steps over the first --gate-rows rows of its shard through the in-library all-reduce, rank 0 hosts both
+    shards in the oracle as world x workers workers and holds the update to the derived bound and the stated 1e-5
+    tolerance; then the timed steps and the replica digest.  Strong mode: ONE data set split by SplitStrategy.vanilla."""
+    import json
+
+    env = seam_env({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")})
+    env["DSGD_BENCH_ONE_DEVICE"] = "1"
+    shape = ["--scaling", "strong", "--rows-total", "60000"] if mode == "strong" else ["--rows", "30000"]
+    gate_rows = 8000 if mode == "strong" else 12000   # (below / above the row count from which ranges take the streaming kernels)
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--workers", "2", "--gate-rows", str(gate_rows),
+           "--steps", "3", "--warmup", "1", "--repeats", "2", "--clock-ramp", "0.05", "--no-cpu-baseline"] + shape
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-4000:]
+    line = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == mode and line["replicas_bit_identical"] is True
+    g = line["parity_gate"]
+    assert g["world"] == 2 and g["workers_total"] == 4 and g["rows_per_rank"] == gate_rows and len(g["steps"]) == 2
+    assert g["replicas_bit_identical_after_gate"] is True
+    for st in g["steps"]:
+        assert st["worst_err_over_bound"] <= 1.0 and st["max_rel_err"] <= 1e-5
+        assert abs(st["n_active_engine"] - st["n_active_oracle"]) <= st["rows_near_gate"]
+    if mode == "strong":
+        assert line["config"]["train_rows_job"] == 48000 and line["config"]["train_rows_per_gpu"] == 24000
+        assert abs(line["value"] - 48000 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    else:
+        assert abs(line["value"] - 2 * 24000 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    assert len(line["repeats"]["ms_per_step"]) == 2
