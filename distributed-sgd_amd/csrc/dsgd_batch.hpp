@@ -243,8 +243,9 @@ __device__ __forceinline__ void bt_items_dot(const BtLds& L, const BtItems<R>& i
   }
 }
 
-// x.w per row in chunk order, gate; returns this thread's count of active rows (0 or 1)
-__device__ __forceinline__ unsigned int bt_gate(const BtLds& L, int nbf) {
+// x.w per row in chunk order, gate; returns this thread's count of active rows (0 or 1).
+// gmask (LDS, may be null; traced runs of the lock-free engine): bit b0 + row of the mini-batch set for an active row.
+__device__ __forceinline__ unsigned int bt_gate(const BtLds& L, int nbf, unsigned int* gmask = nullptr, int b0 = 0) {
   const int tid = threadIdx.x;
   if (tid >= nbf) return 0u;
   const int f0 = L.ifirst[tid], n = (L.rlen[tid] + BT_CH - 1) / BT_CH;
@@ -253,6 +254,7 @@ __device__ __forceinline__ unsigned int bt_gate(const BtLds& L, int nbf) {
   const float yy = L.rcoef[tid];
   const bool active = L.rlen[tid] > 0 && !(yy * d < 0.0f);   // ref: core/ml/SparseSVM.scala:27-28
   L.rcoef[tid] = active ? yy : 0.0f;
+  if (gmask && active) atomicOr(&gmask[(unsigned int)(b0 + tid) >> 5], 1u << ((b0 + tid) & 31));
   return active ? 1u : 0u;
 }
 
@@ -273,7 +275,7 @@ __device__ __forceinline__ void bt_scatter(const BtLds& L, float* __restrict__ g
 // left in slot 0 by bt_build.  Three workgroup barriers.
 template <int THREADS, int COLD, class WLoad>
 __device__ __forceinline__ unsigned int bt_giant_row(const CsrView& m, const BtLds& L, float* __restrict__ gcold,
-                                                     WLoad wload, float qscale) {
+                                                     WLoad wload, float qscale, unsigned int* gmask = nullptr, int b0 = 0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long s0 = L.rst[0];
   const int ln = L.rlen[0];
@@ -290,6 +292,7 @@ __device__ __forceinline__ unsigned int bt_giant_row(const CsrView& m, const BtL
   unsigned int n_act = 0;
   if (!(yy * d < 0.0f)) {
     n_act = tid == 0 ? 1u : 0u;
+    if (gmask && tid == 0) atomicOr(&gmask[(unsigned int)b0 >> 5], 1u << (b0 & 31));
     for (int p = tid; p < ln; p += THREADS) bt_add<COLD>(L, gcold, m.col[s0 + p], m.val[s0 + p] * yy, qscale);
   }
   __syncthreads();
@@ -300,14 +303,15 @@ __device__ __forceinline__ unsigned int bt_giant_row(const CsrView& m, const BtL
 // whatever a pipelined caller could not stage ahead.  Returns this thread's share of the active-row count.
 template <int THREADS, int R, int COLD, class RowOf, class WLoad>
 __device__ __forceinline__ unsigned int bt_batch(const CsrView& m, const BtLds& L, float* __restrict__ gcold, int B, int b0,
-                                                 RowOf row_of, WLoad wload, float qscale, int* bad) {
+                                                 RowOf row_of, WLoad wload, float qscale, int* bad,
+                                                 unsigned int* gmask = nullptr) {
   constexpr int CAP = THREADS / BT_G * R;
   unsigned int n_act = 0;
   while (b0 < B) {   // workgroup-uniform
     const BtRow row = bt_rows_issue<CAP>(m, B, b0, row_of, bad);
     const int2 bd = bt_build<THREADS, CAP>(L, B, b0, row);
     if (bd.x == 0) {
-      n_act += bt_giant_row<THREADS, COLD>(m, L, gcold, wload, qscale);
+      n_act += bt_giant_row<THREADS, COLD>(m, L, gcold, wload, qscale, gmask, b0);
       b0 += 1;
       continue;
     }
@@ -315,7 +319,7 @@ __device__ __forceinline__ unsigned int bt_batch(const CsrView& m, const BtLds& 
     bt_items_issue<THREADS, R>(m, L, bd.y, it);
     bt_items_dot<THREADS, R>(L, it, wload);
     __syncthreads();
-    n_act += bt_gate(L, bd.x);
+    n_act += bt_gate(L, bd.x, gmask, b0);
     __syncthreads();
     bt_scatter<R, COLD>(L, gcold, it, qscale);
     b0 += bd.x;
@@ -1253,17 +1257,20 @@ struct HogState {
 };
 
 // Traced runs (dsgd_async_set_trace; parity evidence for many workers, tests/test_gpu_hogwild_trace.py): the update
-// whose returning atomic on HogState::updates saw `commit - 1` leaves record [commit - 1] = {its worker, that worker's
-// iteration number (the sampler's key), the update count its weights were read at}.  `read_at` is what thread 0's
-// returning atomic of the worker's PREVIOUS commit returned (the launch's starting count for a first iteration): the
-// LDS copy of the hot weights is requested right next to that atomic, so the snapshot the gradient was computed on is
-// "the weights after update #read_at" up to the few updates in flight around it.  The oracle replays Slave.asyncTask
-// (core/Slave.scala:92-101) in commit order with exactly these staleness values (oracle/hogwild_replay.py).
-struct HogTrace {
-  int worker;
-  unsigned int it;
-  unsigned long long read_at;
-};
+// whose returning atomic on HogState::updates saw `commit - 1` leaves record [commit - 1] of HOG_TRACE_HDR + ceil(B / 32)
+// 32-bit words:
+//   [0] its worker   [1] that worker's iteration number (the sampler's key)
+//   [2..3] read_at: the update count its weights were read at -- what thread 0's returning atomic of the worker's PREVIOUS
+//          commit returned (the launch's starting count for a first iteration); the LDS copy of the hot weights is
+//          requested right next to that atomic
+//   [4] the regulariser scalar s = 2 lambda (w . ds) the iteration used (fp32 bits)   [5] its active rows
+//   [6..] the GATE DECISIONS of its mini-batch: bit t = row t of the sample was active (core/ml/SparseSVM.scala:27-28).
+// A constant-step run from w = 0 is chaotic (a 1e-7 perturbation of the initial weights moves the test loss by 0.1 after 400
+// updates: every margin starts AT the gate), so no replay that re-decides the gates can follow the engine.  With the
+// engine's own decisions and scalar on record the oracle recomputes every update EXACTLY (oracle/hogwild_replay.py):
+// the final weights must then agree to rounding -- every update applied once, with the reference's rule -- and the
+// recorded decisions are checked against the margins of the replayed weights at `read_at`.
+constexpr int HOG_TRACE_HDR = 6;
 
 struct HogArgs {
   CsrView m;
@@ -1279,8 +1286,8 @@ struct HogArgs {
   float lr, lambda;
   float qscale, inv_qscale;     // 2^shift / vmax2 and its inverse
   int batch, positional_bug, hl, wl, dp;   // hl: ranks with an LDS accumulator; wl: ranks with an LDS copy of w (whole 1 KiB pieces: a multiple of 256)
-  HogTrace* trace;              // optional (dsgd_async_set_trace): one record per mini-batch update, indexed by its commit number
-  long long trace_cap;
+  unsigned int* trace;          // optional (dsgd_async_set_trace): one record per mini-batch update, indexed by its commit number
+  long long trace_cap;          // ... records of HOG_TRACE_HDR + (batch + 31) / 32 words
 };
 
 __device__ __forceinline__ unsigned long long hog_mix(unsigned long long z) {
@@ -1316,7 +1323,7 @@ struct HogCtl {   // per iteration parity
 };
 
 __host__ __device__ constexpr int hog_lds_words(int hl, int wl, int dp) {
-  return wl + ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8;
+  return wl + ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8 + HOG_MAX_BATCH / 32;
 }
 
 // Copy of w[0, wl) into LDS: each wave moves 1 KiB pieces straight from the fabric into LDS (global_load_lds_dwordx4:
@@ -1370,8 +1377,11 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   float* red = reinterpret_cast<float*>(tables + bt_lds_words(HOG_CAP));   // 8 floats + 8 counters
   unsigned int* redn = reinterpret_cast<unsigned int*>(red + 8);
   HogCtl* ctl = reinterpret_cast<HogCtl*>(red + 16);                       // 2 slots (iteration parity)
+  unsigned int* gmask = reinterpret_cast<unsigned int*>(red + 24);         // traced runs: gate decisions of the mini-batch
   const int tid = threadIdx.x;
   const int worker = blockIdx.x;
+  if (tid < HOG_MAX_BATCH / 32) gmask[tid] = 0u;
+  unsigned int* const gm = a.trace ? gmask : nullptr;
   const long long begin = a.asg_begin[worker];
   const unsigned int n_k = (unsigned int)(a.asg_end[worker] - begin);   // < 2^31 rows per context
   const long long base = a.positional_bug ? 0 : begin;   // ref: core/Slave.scala:87 indexes `data` by POSITION
@@ -1443,13 +1453,13 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     if (bd.x > 0) {
       bt_items_dot<HOG_THREADS, HOG_R>(L, items, wload);
       __syncthreads();
-      n_act += bt_gate(L, bd.x);
+      n_act += bt_gate(L, bd.x, gm, 0);
       __syncthreads();
       bt_scatter<HOG_R, 1>(L, gc, items, a.qscale);
       done = bd.x;
     }
     // ... and whatever did not fit its item slots (long rows, batches beyond 128 rows)
-    if (done < B) n_act += bt_batch<HOG_THREADS, HOG_R, 1>(a.m, L, gc, B, done, row_of, wload, a.qscale, &a.st->err);
+    if (done < B) n_act += bt_batch<HOG_THREADS, HOG_R, 1>(a.m, L, gc, B, done, row_of, wload, a.qscale, &a.st->err, gm);
     // the next iteration's sample does not depend on w: request its row records now
     const HogCtl nxt = ctl[(it + 1) & 1];
     const BtRow row_n = bt_rows_issue<HOG_CAP>(a.m, B, 0, [&](int t) { return row_at(nxt.mul, nxt.off, t); }, &a.st->err);
@@ -1561,12 +1571,19 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       }
       const unsigned long long read_at = u;
       u = atomicAdd(&a.st->updates, 1ull) + 1ull;
-      if (a.trace && (long long)u <= a.trace_cap) {   // (16 bytes, one lane, once per mini-batch)
-        HogTrace rec;
-        rec.worker = worker;
-        rec.it = (unsigned int)it;
-        rec.read_at = read_at;
-        a.trace[u - 1] = rec;
+      if (a.trace) {   // (one lane, once per mini-batch; the decisions were taken several barriers ago)
+        const int mw = (B + 31) >> 5;
+        if ((long long)u <= a.trace_cap) {
+          unsigned int* rec = a.trace + (u - 1) * (unsigned long long)(HOG_TRACE_HDR + mw);
+          rec[0] = (unsigned int)worker;
+          rec[1] = (unsigned int)it;
+          rec[2] = (unsigned int)read_at;
+          rec[3] = (unsigned int)(read_at >> 32);
+          rec[4] = __float_as_uint(s_it);
+          rec[5] = na & (HOG_ATOMIC_ONE - 1u);
+          for (int i = 0; i < mw; ++i) rec[HOG_TRACE_HDR + i] = gmask[i];
+        }
+        for (int i = 0; i < mw; ++i) gmask[i] = 0u;   // (the next gate is behind the barriers below)
       }
       atomicAdd(&a.st->samples, (unsigned long long)B);
       atomicAdd(&a.st->active, (unsigned long long)(na & (HOG_ATOMIC_ONE - 1u)));

@@ -278,8 +278,10 @@ struct dsgd_ctx {
   float* d_gcold = nullptr;
   long long* d_asg = nullptr;  // begin[n], end[n]
   unsigned long long* d_hog_it = nullptr;   // per worker: iterations done (continues across exchange rounds)
-  HogTrace* d_trace = nullptr;              // dsgd_async_set_trace: one record per update of the next engine runs
-  long long trace_cap = 0;
+  unsigned int* d_trace = nullptr;          // dsgd_async_set_trace: one record per update of the next engine runs
+  long long trace_cap = 0;                  // records asked for
+  long long trace_words = 0;                // words allocated at d_trace
+  int trace_mw = 0;                         // mask words per record of the last traced run ((batch + 31) / 32)
   int* h_one = nullptr;        // pinned constant 1: source of the stop-flag copy
   // small-batch plan kernel (one persistent workgroup): cold strip and the multi-worker sum buffer
   unsigned long long* d_tprof = nullptr;   // DSGD_PLAN_PROF=1: phase cycle counters of dsgd_plan_kernel (tuning runs)
@@ -2368,7 +2370,7 @@ static int hog_launch(dsgd_ctx* c, long long max_updates) {
   a.hl = std::min(c->dp, c->hog_hl);
   a.dp = c->dp;
   a.wl = std::min(c->hog_wl, c->dp) & ~255;
-  a.trace = c->d_trace;
+  a.trace = c->trace_cap > 0 ? c->d_trace : nullptr;
   a.trace_cap = c->trace_cap;
   const size_t lds = sizeof(float) * (size_t)hog_lds_words(a.hl, a.wl, c->dp);
   hipLaunchKernelGGL(dsgd_hogwild_kernel, dim3(c->hog_n), dim3(HOG_THREADS), lds, c->async_stream, a);
@@ -2451,6 +2453,17 @@ int dsgd_async_start(dsgd_ctx* c, const int64_t* assigned_begin, const int64_t* 
     HIP_TRY(hipMalloc(&c->d_asg, sizeof(long long) * 2 * (size_t)n_workers));
     HIP_TRY(hipMalloc(&c->d_hog_it, sizeof(unsigned long long) * (size_t)n_workers));
     c->hog_workers = n_workers;
+  }
+  if (c->trace_cap > 0) {   // traced run: records of HOG_TRACE_HDR + ceil(batch / 32) words
+    c->trace_mw = (batch + 31) / 32;
+    const long long need = c->trace_cap * (HOG_TRACE_HDR + c->trace_mw);
+    if (need > c->trace_words) {
+      (void)hipFree(c->d_trace);
+      c->d_trace = nullptr;
+      c->trace_words = 0;
+      HIP_TRY(hipMalloc(&c->d_trace, sizeof(unsigned int) * (size_t)need));
+      c->trace_words = need;
+    }
   }
   if (exchange && !c->d_wprev) {
     HIP_TRY(hipMalloc(&c->d_wprev, sizeof(float) * c->dp));
@@ -2602,41 +2615,48 @@ int dsgd_async_set_trace(dsgd_ctx* c, int64_t capacity) {
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
   if (c->async_running) return fail(DSGD_ESTATE, "async computation running");
-  if (capacity != c->trace_cap) {
+  c->trace_cap = capacity;   // (the buffer is sized at dsgd_async_start: a record's length depends on the batch size)
+  if (capacity == 0) {
     (void)hipFree(c->d_trace);   // (no engine is resident: hipFree's device synchronisation returns)
     c->d_trace = nullptr;
-    c->trace_cap = 0;
-    if (capacity > 0) {
-      HIP_TRY(hipMalloc(&c->d_trace, sizeof(HogTrace) * (size_t)capacity));
-      c->trace_cap = capacity;
-    }
+    c->trace_words = 0;
+    c->trace_mw = 0;
   }
   return DSGD_OK;
 }
 
-int dsgd_async_read_trace(dsgd_ctx* c, int32_t* worker, uint32_t* iteration, int64_t* read_at, int64_t n, int64_t* n_out) {
+int dsgd_async_read_trace(dsgd_ctx* c, int32_t* worker, uint32_t* iteration, int64_t* read_at, float* s_used,
+                          int32_t* n_active, uint32_t* gate_mask, int64_t n, int64_t* n_out, int32_t* mask_words_out) {
   DSGD_TRY(check_ctx(c));
-  if (n < 0 || (n > 0 && (!worker || !iteration || !read_at))) return fail(DSGD_EINVAL, "bad trace arguments");
+  if (n < 0 || (n > 0 && (!worker || !iteration || !read_at || !s_used || !n_active || !gate_mask)))
+    return fail(DSGD_EINVAL, "bad trace arguments");
   std::lock_guard<std::mutex> lk(c->mu);
   DSGD_TRY(bind(c));
   if (c->async_running) return fail(DSGD_ESTATE, "async computation running (dsgd_async_wait / dsgd_async_stop first)");
-  if (!c->d_trace || !c->d_hog) return fail(DSGD_ESTATE, "no traced run on this context (dsgd_async_set_trace, then dsgd_async_start)");
+  if (!c->d_trace || !c->d_hog || c->trace_mw == 0)
+    return fail(DSGD_ESTATE, "no traced run on this context (dsgd_async_set_trace, then dsgd_async_start)");
   DSGD_TRY(async_refresh(c));
   const long long have = std::min<long long>((long long)c->h_hog->updates, c->trace_cap);
   const long long m = std::min<long long>(have, n);
+  const int mw = c->trace_mw, rw = HOG_TRACE_HDR + mw;
   if (n_out) *n_out = have;
+  if (mask_words_out) *mask_words_out = mw;
   if (m == 0) return DSGD_OK;
-  std::vector<HogTrace> recs;
+  std::vector<unsigned int> recs;
   try {
-    recs.resize((size_t)m);
+    recs.resize((size_t)m * (size_t)rw);
   } catch (const std::bad_alloc&) {
     return fail(DSGD_ENOMEM, "out of host memory");
   }
-  HIP_TRY(hipMemcpy(recs.data(), c->d_trace, sizeof(HogTrace) * (size_t)m, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(recs.data(), c->d_trace, sizeof(unsigned int) * recs.size(), hipMemcpyDeviceToHost));
   for (long long i = 0; i < m; ++i) {
-    worker[i] = recs[(size_t)i].worker;
-    iteration[i] = recs[(size_t)i].it;
-    read_at[i] = (int64_t)recs[(size_t)i].read_at;
+    const unsigned int* r = recs.data() + (size_t)i * (size_t)rw;
+    worker[i] = (int32_t)r[0];
+    iteration[i] = r[1];
+    read_at[i] = (int64_t)(((unsigned long long)r[3] << 32) | r[2]);
+    memcpy(&s_used[i], &r[4], sizeof(float));
+    n_active[i] = (int32_t)r[5];
+    memcpy(gate_mask + (size_t)i * (size_t)mw, r + HOG_TRACE_HDR, sizeof(unsigned int) * (size_t)mw);
   }
   return DSGD_OK;
 }

@@ -208,17 +208,24 @@ class Engine:
         check(self._lib.dsgd_async_set_trace(self._ctx, C.c_int64(capacity)))
 
     def async_read_trace(self):
-        """(worker, iteration, read_at) of every recorded update of the last run, in commit order (record i = update
-        number i + 1); see dsgd_async_set_trace."""
-        n = C.c_int64(0)
-        check(self._lib.dsgd_async_read_trace(self._ctx, None, None, None, C.c_int64(0), C.byref(n)))
-        k = n.value
+        """The recorded updates of the last run in commit order (record i = update number i + 1) as a dict of arrays:
+        worker, it (the worker's iteration = the sampler's key), read_at (update count its weights were read at), s (the
+        regulariser scalar it used), n_active, mask (bool [n, batch]: the gate decision of every sampled row);
+        see dsgd_async_set_trace."""
+        n, mw = C.c_int64(0), C.c_int32(0)
+        check(self._lib.dsgd_async_read_trace(self._ctx, None, None, None, None, None, None, C.c_int64(0), C.byref(n), C.byref(mw)))
+        k, m = n.value, mw.value
         worker = np.zeros(k, dtype=np.int32)
         it = np.zeros(k, dtype=np.uint32)
         read_at = np.zeros(k, dtype=np.int64)
+        s = np.zeros(k, dtype=np.float32)
+        n_active = np.zeros(k, dtype=np.int32)
+        mask = np.zeros((k, m), dtype=np.uint32)
         if k:
-            check(self._lib.dsgd_async_read_trace(self._ctx, ptr(worker), ptr(it), ptr(read_at), C.c_int64(k), None))
-        return worker, it, read_at
+            check(self._lib.dsgd_async_read_trace(self._ctx, ptr(worker), ptr(it), ptr(read_at), ptr(s), ptr(n_active), ptr(mask),
+                                                  C.c_int64(k), None, None))
+        bits = ((mask[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).astype(bool).reshape(k, 32 * m)
+        return {"worker": worker, "it": it, "read_at": read_at, "s": s, "n_active": n_active, "mask": bits}
 
     # -- multi-GPU ---------------------------------------------------------------------------------
     @staticmethod

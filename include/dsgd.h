@@ -198,12 +198,17 @@ int dsgd_async_wait(dsgd_ctx* ctx); /* block until max_updates reached */
 /* Parity aid for the MANY-worker lock-free engine (nothing in the reference; tests/test_gpu_hogwild_trace.py, bench.py):
  * with a trace of `capacity` records attached (0 detaches it), every mini-batch update of the following engine runs
  * leaves one record at index (its commit number - 1): the worker that made it, that worker's iteration number (the key
- * of the engine's replayable sampler) and the update count its weights were read at.  The oracle
- * replays Slave.asyncTask (core/Slave.scala:92-101) in commit order with exactly these staleness values
- * (oracle/hogwild_replay.py) -- a many-worker parity statement that can fail.  dsgd_async_read_trace copies the first
- * min(n, recorded) records of the LAST run out (engine joined); *n_out (may be NULL) = records available.           */
+ * of the engine's replayable sampler), the update count its weights were read at, the regulariser
+ * scalar s = 2 lambda (w . ds) it used, and the GATE DECISIONS of its mini-batch (bit t of the mask = row t of the
+ * sample was active, core/ml/SparseSVM.scala:27-28).  A constant-step lock-free run is chaotic -- no replay that
+ * re-decides the gates can follow it -- but with the engine's own decisions on record the oracle recomputes every update
+ * exactly (oracle/hogwild_replay.py): the final weights must agree to rounding, and the recorded decisions are held
+ * to the margins of the replayed weights at `read_at`.  A many-worker parity statement that can fail.
+ * dsgd_async_read_trace copies the first min(n, recorded) records of the LAST run out (engine joined); gate_mask holds
+ * *mask_words_out = ceil(batch / 32) words per record; *n_out = records available (both may be NULL; n = 0 queries them). */
 int dsgd_async_set_trace(dsgd_ctx* ctx, int64_t capacity);
-int dsgd_async_read_trace(dsgd_ctx* ctx, int32_t* worker, uint32_t* iteration, int64_t* read_at, int64_t n, int64_t* n_out);
+int dsgd_async_read_trace(dsgd_ctx* ctx, int32_t* worker, uint32_t* iteration, int64_t* read_at, float* s_used,
+                          int32_t* n_active, uint32_t* gate_mask, int64_t n, int64_t* n_out, int32_t* mask_words_out);
 
 /* ---- multi-GPU (one process per GPU) ---------------------------------------
  * The synchronous master's aggregate (core/Master.scala:190-194: Future.sequence barrier +

@@ -1,25 +1,36 @@
 """ORACLE side (test infrastructure, NOT product code): replay of a TRACED lock-free ("Hogwild") run.
 
 A many-worker lock-free run is not reproducible, so round 3 held it to a band between the orderings the oracle can
-invent (oracle/hogwild_band.py) -- a band from chance to near-perfect that a broken engine would also sit in.  This
-module replaces invention by measurement: a traced run (dsgd_async_set_trace, include/dsgd.h) records, for every
-mini-batch update in COMMIT order, which worker made it, that worker's iteration number (the key of the engine's
-replayable sampler) and the update count its weights were read at.  The oracle then replays the reference's
-asynchronous iteration (core/Slave.scala:92-101 = oracle.c orc_async_step) with exactly that schedule:
+invent (oracle/hogwild_band.py) -- a band from chance to near-perfect that a broken engine would also sit in.
 
-    update c (record c - 1):  rows   = the engine's sample for (seed, worker, iteration)        -- hog_rows below
-                              W_snap = the weights after update number read_at[c]                -- a ring of snapshots
-                              delta  = lr * regularize(mean_i backward(W_snap, x_i, y_i), W_snap)   (Slave.scala:93-99)
-                              W_c    = W_{c-1} - delta                                              (Slave.scala:101,
-                                                                                                    GradState.scala:8)
+Why a plain re-simulation cannot do better: a constant-step run from w = 0 is CHAOTIC.  Every margin starts exactly
+at the gate (x . 0 = 0 is active, core/ml/SparseSVM.scala:27-28), so a perturbation of 1e-7 in the initial weights
+moves the test loss by 0.1 and the weights by a third of their norm within 400 updates (measured on this oracle;
+tests/test_hogwild_replay.py keeps the experiment).  Whatever re-decides the gates -- in fp64 instead of fp32, a few
+updates earlier or later -- leaves the engine's trajectory at once.
 
-What the replay cannot know is the handful of updates in flight while a worker's reads were being served (a worker's
-LDS copy of the hot weights is requested right next to the atomic whose return value is `read_at`), and the engine
-computes in fp32: the two trajectories separate slowly, and a constant-step run amplifies differences through gate
-flips.  They stay close enough for tolerances an order of magnitude tighter than the band (tests/
-test_gpu_hogwild_trace.py states them), and -- the point -- replays with a deliberately WRONG rule (every update applied
-twice, a third of the updates lost, the batch summed instead of averaged, half the step length, the staleness ignored)
-land far outside those tolerances: the check can fail.
+So the engine RECORDS its decisions (dsgd_async_set_trace, include/dsgd.h): for every mini-batch update, in commit
+order, {worker, the worker's iteration = the key of the engine's replayable sampler, the update count its weights were
+read at, the regulariser scalar s it used, the gate decision of every sampled row}.  With those on record the
+reference's asynchronous iteration (core/Slave.scala:92-101) is a LINEAR recurrence the oracle evaluates exactly:
+
+    update c:  rows   = the engine's sample for (seed, worker, iteration)                      -- hog_rows
+               g      = (sum over the rows the ENGINE found active of y_i x_i) / batch         (Slave.scala:93-98, Vec.mean)
+               g_j   += s_c on supp(g)                                                         (SparseSVM.scala:31; s_c as recorded)
+               W_c    = W_{c-1} - lr * g                                                       (Slave.scala:99-101, GradState.scala:8)
+
+Three statements follow, each of which fails for a broken engine:
+  (A) ACCOUNTING, to rounding: the engine's final weights equal W_n coordinate by coordinate within ACCOUNT_TOL *
+      max(1, |w|_inf) -- every update applied exactly once, the batch averaged, the step length, the sign, the
+      support-only regulariser.  (An update lost in 8,000, a doubled one, a sum instead of a mean, a missing
+      regulariser at lambda = 1e-5: all far outside.)
+  (B) GATES: the recorded decision of row i of update c must be what the reference's gate gives on the replayed weights
+      the update read, W_{read_at(c)}: y_i (x_i . W) >= 0.  What the replay cannot know is the handful of updates in
+      flight while a worker's reads were served, so rows whose margin is within MARGIN_CLEAR of zero are reported but
+      excused; on the CLEAR rows the disagreement must stay below GATE_TOL -- and the same check against the WRONG
+      snapshot (the weights at the commit instead of at the read: staleness ignored) must be visibly worse with many
+      workers, which is what shows that `read_at` means something.
+  (C) SCALAR: the recorded s_c equals 2 lambda (W_{read_at(c)} . ds) within S_TOL (relative to the run's largest |s|).
 """
 
 from __future__ import annotations
@@ -29,6 +40,12 @@ import math
 import numpy as np
 
 M64 = (1 << 64) - 1
+
+ACCOUNT_TOL = 2e-4     # (A): max_j |w_engine - W_n|_j <= ACCOUNT_TOL * max(1, |W_n|_inf)
+MARGIN_CLEAR = 0.02    # (B): rows with |x . W| above this are "clear"
+GATE_TOL = 0.01        # (B): fraction of the clear rows whose recorded decision may differ
+S_TOL = 0.05           # (C): |s_engine - s_replay| <= S_TOL * max_c |s_replay| for all but S_OUTLIERS of the updates
+S_OUTLIERS = 0.01
 
 
 def hog_mix(z):  # csrc/dsgd_batch.hpp: hog_mix (splitmix64 finaliser)
@@ -50,24 +67,70 @@ def hog_rows(seed, worker, it, begin, n_k, batch, positional_bug=False):
     return np.asarray(base + (mul * np.arange(batch, dtype=np.int64) + off) % n_k, dtype=np.int32)
 
 
-FAULTS = ("double_apply", "drop_third", "sum_not_mean", "half_step", "no_regulariser", "fresh_reads")
+def _entries(o, rows):
+    """(flat positions, row number of every entry) of the CSR rows `rows`."""
+    rows = np.asarray(rows, dtype=np.int64)
+    starts = o.row_ptr[rows]
+    lens = o.row_ptr[rows + 1] - starts
+    total = int(lens.sum())
+    first = np.cumsum(lens) - lens
+    flat = np.arange(total, dtype=np.int64) + np.repeat(starts - first, lens)
+    return flat, np.repeat(np.arange(len(rows), dtype=np.int64), lens)
 
 
-def replay_segment(o, w, split, batch, lr, seed, trace, fault=None, positional_bug=False):
-    """Replay one traced engine run (one dsgd_async_start ... dsgd_async_wait) in place on `w` (float64, D + 1).
-    trace = (worker, iteration, read_at) as Engine.async_read_trace returns them; record i is update number i + 1 and
-    read_at counts the updates of THIS run (0 = the weights the run started from).  `fault` (one of FAULTS) breaks the
-    rule on purpose: the negative controls of the tests.  Returns {updates, max_lag, mean_lag}."""
-    worker, it, read_at = (np.asarray(a) for a in trace)
+def margins(o, w, rows):
+    """x_i . w of the rows (products filtered as math/Sparse.scala:46 -> :112-114 does)."""
+    flat, rid = _entries(o, rows)
+    prod = o.val[flat].astype(np.float64) * w[o.col[flat]]
+    prod[np.abs(prod) <= 1e-20] = 0.0
+    return np.bincount(rid, weights=prod, minlength=len(rows))
+
+
+def forced_delta(o, rows, active, s, batch, lr, fault=None):
+    """lr * regularize(mean_i backward_i) with the gate decisions GIVEN (core/Slave.scala:93-99): the mean divides by
+    the batch size -- an inactive row contributes a zero vector, it is still one of the vectors (math/Vec.scala:139)."""
+    g = np.zeros(o.dim + 1)
+    act = np.asarray(rows)[np.asarray(active, dtype=bool)]
+    if len(act):
+        flat, rid = _entries(o, act)
+        yx = o.val[flat].astype(np.float64) * o.label[act].astype(np.float64)[rid]
+        yx[np.abs(yx) <= 1e-20] = 0.0               # math/Sparse.scala:108-118
+        g = np.bincount(o.col[flat], weights=yx, minlength=o.dim + 1)
+    if fault != "sum_not_mean":
+        g = g / float(batch)
+    g[np.abs(g) <= 1e-20] = 0.0
+    if fault != "no_regulariser" and s != 0.0 and abs(s) > 1e-20:   # core/ml/SparseSVM.scala:31, math/Vec.scala:65-75
+        g[g != 0.0] += s
+    step = lr * g
+    if fault == "double_apply":
+        step = 2.0 * step
+    elif fault == "half_step":
+        step = 0.5 * step
+    return step
+
+
+FAULTS = ("double_apply", "drop_one", "sum_not_mean", "half_step", "no_regulariser", "wrong_rows")
+
+
+def replay_forced(o, w, split, batch, lr, seed, trace, fault=None, positional_bug=False, check=True):
+    """Replay one traced engine run (one dsgd_async_start ... dsgd_async_wait) in place on `w` (float64, D + 1) with the
+    engine's recorded gate decisions and scalars.  trace: the dict Engine.async_read_trace returns; read_at counts the
+    updates of THIS run (0 = the weights the run started from).  `fault` (one of FAULTS) breaks the rule on purpose: the
+    negative controls.  Returns the statistics of checks (B) and (C) (module docstring) over this run."""
+    worker, it, read_at = np.asarray(trace["worker"]), np.asarray(trace["it"]), np.asarray(trace["read_at"])
+    s_rec, mask, n_act = np.asarray(trace["s"], dtype=np.float64), np.asarray(trace["mask"]), np.asarray(trace["n_active"])
     n = len(worker)
+    st = {"updates": n, "max_lag": 0, "mean_lag": 0.0, "rows": 0, "rows_clear": 0, "gate_differs": 0, "gate_differs_clear": 0,
+          "gate_differs_clear_if_fresh": 0, "rows_clear_if_fresh": 0, "s_max_abs": 0.0, "s_err": []}
     if n == 0:
-        return {"updates": 0, "max_lag": 0, "mean_lag": 0.0}
+        return st
     commit = np.arange(1, n + 1, dtype=np.int64)
     if np.any(read_at < 0) or np.any(read_at >= commit):
         raise ValueError("trace inconsistent: an update read weights from its own future")
+    if np.any(mask[:, batch:]) or np.any(mask[:, :batch].sum(axis=1) != n_act):
+        raise ValueError("trace inconsistent: gate masks and active counts disagree")
     lag = commit - 1 - read_at                      # updates applied between the read and the commit
-    if fault == "fresh_reads":
-        read_at = commit - 1
+    st["max_lag"], st["mean_lag"] = int(lag.max()), float(lag.mean())
     ring_n = 1
     while ring_n < int(lag.max()) + 2:
         ring_n *= 2
@@ -75,65 +138,73 @@ def replay_segment(o, w, split, batch, lr, seed, trace, fault=None, positional_b
         raise MemoryError("staleness of %d updates needs a %d-entry snapshot ring" % (int(lag.max()), ring_n))
     ring = np.empty((ring_n, o.dim + 1))
     ring[0] = w
-    lam = o.lam
     for c in range(1, n + 1):
         k = int(worker[c - 1])
         b, e = split[k]
         rows = hog_rows(seed, k, int(it[c - 1]), b, e - b, batch, positional_bug)
-        snap = ring[int(read_at[c - 1]) % ring_n].copy()
-        if fault == "no_regulariser":
-            o.lam = 0.0
-        try:
-            delta = o.async_step(snap, rows, lr, want_delta=True)
-        finally:
-            o.lam = lam
-        if fault == "double_apply":
-            delta = 2.0 * delta
-        elif fault == "sum_not_mean":
-            delta = float(batch) * delta
-        elif fault == "half_step":
-            delta = 0.5 * delta
-        if not (fault == "drop_third" and c % 3 == 0):
-            w -= delta
+        active = mask[c - 1, :batch]
+        if check:
+            snap = ring[int(read_at[c - 1]) % ring_n]
+            y = o.label[rows].astype(np.float64)
+            d = margins(o, snap, rows)
+            want = ~(y * d < 0.0)                   # core/ml/SparseSVM.scala:27-28
+            clear = np.abs(d) > MARGIN_CLEAR
+            st["rows"] += batch
+            st["rows_clear"] += int(clear.sum())
+            st["gate_differs"] += int((want != active).sum())
+            st["gate_differs_clear"] += int(((want != active) & clear).sum())
+            if lag[c - 1] > 0:                      # the same against the WRONG snapshot: staleness ignored
+                d2 = margins(o, w, rows)
+                clear2 = np.abs(d2) > MARGIN_CLEAR
+                st["rows_clear_if_fresh"] += int(clear2.sum())
+                st["gate_differs_clear_if_fresh"] += int(((~(y * d2 < 0.0) != active) & clear2).sum())
+            s_ref = 2.0 * o.lam * float(snap @ o.ds)
+            st["s_max_abs"] = max(st["s_max_abs"], abs(s_ref))
+            st["s_err"].append(abs(float(s_rec[c - 1]) - s_ref))
+        if fault == "wrong_rows":
+            rows = hog_rows(seed + 1, k, int(it[c - 1]), b, e - b, batch, positional_bug)
+        if not (fault == "drop_one" and c == n // 2):
+            w -= forced_delta(o, rows, active, float(s_rec[c - 1]), batch, lr, fault)
             w[np.abs(w) <= 1e-20] = 0.0             # math/Sparse.scala:108-118
         ring[c % ring_n] = w
-    return {"updates": n, "max_lag": int(lag.max()), "mean_lag": float(lag.mean())}
+    return st
 
 
-def compare(o, w_engine, w_replay, eval_range, engine_eval=None):
-    """The statistics a traced run is held to: test loss / accuracy of both weight vectors over `eval_range`
-    (core/Master.scala:100-107), |w|_2, the sum of the weights (a linear functional: a lost or doubled update moves it),
-    the relative distance and the cosine between the two vectors.  engine_eval: (loss, acc) as the ENGINE evaluated
-    its own weights, when the caller has them."""
+def merge(stats):
+    """The statistics of several consecutive runs (segments between checkpoints) as one."""
+    out = {"updates": sum(s["updates"] for s in stats), "max_lag": max(s["max_lag"] for s in stats),
+           "mean_lag": float(np.average([s["mean_lag"] for s in stats], weights=[max(1, s["updates"]) for s in stats])),
+           "s_max_abs": max(s["s_max_abs"] for s in stats), "s_err": [e for s in stats for e in s["s_err"]]}
+    for q in ("rows", "rows_clear", "gate_differs", "gate_differs_clear", "gate_differs_clear_if_fresh", "rows_clear_if_fresh"):
+        out[q] = sum(s[q] for s in stats)
+    return out
+
+
+def verdict(o, w_engine, w_replay, stats, eval_range=None):
+    """The three statements (module docstring) as numbers and booleans."""
     w_engine = np.asarray(w_engine, dtype=np.float64)
-    le, ae, _, _ = o.loss_acc(w_engine, eval_range[0], eval_range[1])
-    lr_, ar, _, _ = o.loss_acc(w_replay, eval_range[0], eval_range[1])
-    if engine_eval is not None:
-        le, ae = engine_eval
     with np.errstate(all="ignore"):   # (a negative control may have diverged to inf / nan: it then fails every comparison)
-        ne, nr = float(np.sqrt(w_engine @ w_engine)), float(np.sqrt(w_replay @ w_replay))
+        err = float(np.abs(w_engine - w_replay).max())
+        scale = max(1.0, float(np.abs(w_replay).max()))
+        nr = float(np.sqrt(w_replay @ w_replay))
         dist = float(np.sqrt(((w_engine - w_replay) ** 2).sum()) / max(nr, 1e-300))
-        cos = float((w_engine @ w_replay) / max(ne * nr, 1e-300))
-    return {
-        "loss_engine": float(le), "loss_replay": float(lr_), "acc_engine": float(ae), "acc_replay": float(ar),
-        "wnorm_engine": ne, "wnorm_replay": nr,
-        "wsum_engine": float(w_engine.sum()), "wsum_replay": float(w_replay.sum()),
-        "rel_distance": dist, "cosine": cos,
+    s_err = np.asarray(stats["s_err"]) if len(stats["s_err"]) else np.zeros(1)
+    s_bad = float((s_err > S_TOL * max(stats["s_max_abs"], 1e-300)).mean())
+    gate_clear = stats["gate_differs_clear"] / max(1, stats["rows_clear"])
+    out = {
+        "updates": stats["updates"], "max_lag": stats["max_lag"], "mean_lag": stats["mean_lag"],
+        "account_max_abs_err": err, "account_err_over_tol": err / (ACCOUNT_TOL * scale), "account_tolerance": ACCOUNT_TOL,
+        "rel_distance": dist, "wnorm_engine": float(np.sqrt(w_engine @ w_engine)), "wnorm_replay": nr,
+        "rows": stats["rows"], "rows_clear": stats["rows_clear"], "margin_clear": MARGIN_CLEAR,
+        "gate_differs_all_rows": stats["gate_differs"] / max(1, stats["rows"]),
+        "gate_differs_clear_rows": gate_clear, "gate_tolerance": GATE_TOL,
+        "gate_differs_clear_rows_if_staleness_ignored": stats["gate_differs_clear_if_fresh"] / max(1, stats["rows_clear_if_fresh"]),
+        "s_max_abs": stats["s_max_abs"], "s_err_median": float(np.median(s_err)), "s_err_max": float(s_err.max()),
+        "s_fraction_outside": s_bad, "s_tolerance": S_TOL,
     }
-
-
-# The stated tolerances of the traced parity check (tests/test_gpu_hogwild_trace.py, bench.py hogwild.traced_replay):
-# |loss_engine - loss_replay| <= LOSS, |acc_engine - acc_replay| <= ACC, |w| within WNORM_REL, relative distance of
-# the weight vectors <= REL_DISTANCE.  (Round 3's band, for comparison: loss +- 0.43, accuracy +- 0.21, |w| x 55.)
-TOL = {"loss": 0.02, "acc": 0.02, "wnorm_rel": 0.03, "rel_distance": 0.25}
-
-
-def within(cmp, tol=None):
-    """{quantity: bool} -- all True = the engine's run is the traced schedule's run within the stated tolerances."""
-    t = dict(TOL if tol is None else tol)
-    return {
-        "loss": abs(cmp["loss_engine"] - cmp["loss_replay"]) <= t["loss"],
-        "acc": abs(cmp["acc_engine"] - cmp["acc_replay"]) <= t["acc"],
-        "wnorm": abs(cmp["wnorm_engine"] - cmp["wnorm_replay"]) <= t["wnorm_rel"] * cmp["wnorm_replay"],
-        "rel_distance": cmp["rel_distance"] <= t["rel_distance"],
-    }
+    if eval_range is not None:
+        out["loss_engine"], out["acc_engine"] = o.loss_acc(w_engine, eval_range[0], eval_range[1])[:2]
+        out["loss_replay"], out["acc_replay"] = o.loss_acc(w_replay, eval_range[0], eval_range[1])[:2]
+    out["ok"] = {"accounting": bool(err <= ACCOUNT_TOL * scale), "gates": bool(gate_clear <= GATE_TOL),
+                 "scalar": bool(s_bad <= S_OUTLIERS)}
+    return out
