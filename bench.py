@@ -692,8 +692,8 @@ def hogwild_parity(dsgd_amd, device, workers=256, batch=100, rows=100000, checkp
     recomputes every update of core/Slave.scala:92-101 EXACTLY (oracle/hogwild_replay.py: a constant-step lock-free run
     is chaotic, nothing that re-decides the gates can follow it) and three statements are asserted: the final weights
     are the replayed ones to rounding (every update applied once, averaged, scaled, regularised as the reference does),
-    the recorded decisions are the reference's gate on the replayed weights at `read_at` (rows clear of zero), the
-    recorded scalar is 2 lambda (w . ds) of those weights; two deliberately broken replays (every update applied twice;
+    the recorded decisions fit the replayed weights at the read end of [read_at, commit) better than at the commit end,
+    the recorded scalar is 2 lambda (w . ds) of the weights at read_at; two deliberately broken replays (every update applied twice;
     ONE update lost) must break the first -- the check can fail.  SECONDARY: `oracle_band` -- round 3's band between
     the orderings the oracle can invent, kept as a sanity check only: it spans chance to near-perfect."""
     from oracle import hogwild_band as hb  # checker only
@@ -729,7 +729,7 @@ def hogwild_parity(dsgd_amd, device, workers=256, batch=100, rows=100000, checkp
                 if si == 0:
                     t1 = time.perf_counter()
                     trace = eng.async_read_trace()
-                    stats.append(hr.replay_forced(o, w_rep, split, batch, LR0, sseed, trace))
+                    stats.append(hr.replay_forced(o, w_rep, split, batch, LR0, sseed, trace, fractions=(0.0, 1.0)))
                     v = hr.verdict(o, eng.get_weights(), w_rep, hr.merge(stats))
                     v.update(loss_engine=loss, acc_engine=acc)
                     verdicts.append(v)

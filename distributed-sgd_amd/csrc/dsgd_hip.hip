@@ -114,6 +114,7 @@ static bool available() {
 
 #include "dsgd_kernels.hpp"
 #include "dsgd_batch.hpp"
+#include "dsgd_cs.hpp"
 #include "dsgd_dense.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -139,6 +140,16 @@ struct dsgd_plan {
   std::vector<int> vt_grid, vt_gxt, vt_shift;  // per step: workgroups per worker, those of them that walk tiles, shift
   long long vt_layout = -1;     // the layout generation the tiles were built for (-1: not built)
   bool vt_ok = false;           // every row of every list sits in the tiled streams
+  // column slices (dsgd_cs_step_kernel): the lists laid out per (slice, step), built at the first run that can use them
+  CsHdr* d_cs_hdr = nullptr;
+  unsigned int* d_cs_meta = nullptr;
+  unsigned short* d_cs_rf = nullptr;
+  unsigned short* d_cs_col = nullptr;
+  float* d_cs_val = nullptr;
+  int cs_G = 0, cs_spl = 0, cs_slot_stride = 0, cs_row_stride = 0;
+  std::vector<int> cs_shift;    // per step
+  long long cs_layout = -1;     // the layout generation (column ranking) the slices were built for
+  bool cs_ok = false;
 };
 
 struct FusedArgs {
@@ -175,6 +186,11 @@ struct dsgd_ctx {
   std::vector<long long> h_hrp, h_ctp;  // slot offsets of the hot / cold stream (virtual tiles are built from them)
   std::vector<unsigned short> h_ccol;   // host copy of the 16-bit cold ranks (a virtual tile's descriptor carries its cold rank)
   long long layout_gen = 0;             // bumped whenever the split streams are rebuilt
+  bool cs_enable = true;                // DSGD_CS=0: small steps of resident plans through the row-parallel kernels
+  int cs_g = 0;                         // DSGD_CS_G: slices (8 or 16; 0 = 8 up to four hosted workers, 16 beyond)
+  long long cs_max_mb = 1024;           // DSGD_CS_MAX_MB: largest column-slice layout of one plan
+  float* d_cs_x = nullptr;              // exchange buffer of dsgd_cs_step_kernel: [2][CS_MAX_G][CS_XSTRIDE]
+  unsigned int* d_cs_sync = nullptr;    // its arrival counter and abort word
   bool vt_enable = true;                // DSGD_VT=0: index-list steps of resident plans through dsgd_mb_grad_kernel
   long long vt_pack_mb = 2048;          // DSGD_VT_PACK_MB: plans whose packed copy fits get one (0: descriptors only)
   int vt_tpw = 1;                       // DSGD_VT_TPW: virtual tiles per wave the grid is sized for (measured: 1 beats 2-4 up to B = 65,536)
@@ -476,6 +492,9 @@ static int check_err_flag(dsgd_ctx* c) {
     HIP_TRY(hipMemsetAsync(&c->d_sc->err, 0, sizeof(int), c->stream));
     if (err & 2)
       return fail(DSGD_ESTATE, "fixed-point gradient accumulator left its safe band; the step is invalid");
+    if (err & 8)
+      return fail(DSGD_ESTATE, "the column-slice kernel's exchange between its workgroups timed out; the run is invalid "
+                               "(DSGD_CS=0 selects the row-parallel kernels)");
     if (err & 4)
       return fail(DSGD_ESTATE, "a small-batch plan was created for other data than is loaded now (its lists no longer fit "
                                "the staged sub-batch): create the plan again");
@@ -801,6 +820,227 @@ static int launch_grad_vt(dsgd_ctx* c, dsgd_plan* p, long long step) {
   // hot ranks: the workgroups' partials at this launch's scale; cold ranks: the 64-bit accumulators at the cold scale
   c->fused_args = {H, gx, H, 0, 0, 1.0 / (double)a.qscale, 1.0 / (double)c->fix_scale};
   c->fused_apply_pending = true;
+  return DSGD_OK;
+}
+
+// ---- column slices (dsgd_cs_step_kernel) ---------------------------------------------------------------------
+// Lay the lists of a plan out per (slice, step): slice b holds the entries whose rank is b (mod G), a row's entries
+// inside a slice in slots of <= CS_L.  Not possible (cs_ok = false, the plan keeps the row-parallel kernels) beyond
+// CS_MAX_K hosted workers, for steps of more than CS_MAX_SLOTS rows or slots, when the slices do not fit LDS, or when the
+// layout would exceed DSGD_CS_MAX_MB.  Returns 1 for a soft failure (memory): the caller frees and falls back.
+#define CS_SOFT(expr)                 \
+  do {                                \
+    if ((expr) != hipSuccess) {       \
+      (void)hipGetLastError();        \
+      return 1;                       \
+    }                                 \
+  } while (0)
+static void cs_free(dsgd_plan* p) {
+  (void)hipFree(p->d_cs_hdr);
+  (void)hipFree(p->d_cs_meta);
+  (void)hipFree(p->d_cs_rf);
+  (void)hipFree(p->d_cs_col);
+  (void)hipFree(p->d_cs_val);
+  p->d_cs_hdr = nullptr;
+  p->d_cs_meta = nullptr;
+  p->d_cs_rf = nullptr;
+  p->d_cs_col = nullptr;
+  p->d_cs_val = nullptr;
+  p->cs_ok = false;
+}
+static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
+  cs_free(p);
+  p->cs_layout = c->layout_gen;
+  const int K = p->n_workers;
+  const long long n_steps = p->n_steps, n_lists = n_steps * K;
+  if (K > CS_MAX_K || p->max_step_rows > CS_MAX_SLOTS) return DSGD_OK;
+  const int G = c->cs_g ? c->cs_g : (K <= 4 ? 8 : 16);
+  if (c->dp < 4 * G || cs_lds_words(c->dp, G, K) > DSGD_LDS_FLOATS) return DSGD_OK;
+  if (c->h_row_ptr.size() != (size_t)c->n_rows + 1 || (long long)p->h_idx.size() != p->offsets[n_lists]) return DSGD_OK;
+  const long long N = p->offsets[n_lists];
+  std::vector<long long> pre((size_t)N + 1);
+  pre[0] = 0;
+  for (long long t = 0; t < N; ++t) {
+    const long long r = p->h_idx[(size_t)t];
+    if (r < 0 || r >= c->n_rows) return DSGD_OK;   // (the row-wise kernel reports the bad index)
+    pre[(size_t)t + 1] = pre[(size_t)t] + (c->h_row_ptr[(size_t)r + 1] - c->h_row_ptr[(size_t)r]);
+  }
+  const long long E = pre[(size_t)N];
+  if (E > (64LL << 20)) return DSGD_OK;   // (the rows' entries pass through host memory once: 8 bytes each)
+  // the listed rows' (rank, value) pairs: the ranked CSR lives on the device only
+  std::vector<int> ecol((size_t)std::max<long long>(E, 1));
+  std::vector<float> eval((size_t)std::max<long long>(E, 1));
+  {
+    long long* d_pre = nullptr;
+    int* d_ecol = nullptr;
+    float* d_eval = nullptr;
+    auto drop = [&]() {
+      (void)hipFree(d_pre);
+      (void)hipFree(d_ecol);
+      (void)hipFree(d_eval);
+    };
+    hipError_t e = hipMalloc(&d_pre, sizeof(long long) * pre.size());
+    if (e == hipSuccess) e = hipMalloc(&d_ecol, sizeof(int) * ecol.size());
+    if (e == hipSuccess) e = hipMalloc(&d_eval, sizeof(float) * eval.size());
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pre, pre.data(), sizeof(long long) * pre.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+      const int blocks = (int)std::max<long long>(1, std::min<long long>((N + 3) / 4, (long long)c->n_cu * 8));
+      hipLaunchKernelGGL(dsgd_rows_gather_kernel, dim3(blocks), dim3(256), 0, c->stream, view(c), p->d_idx, N, d_pre, d_ecol, d_eval);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess && E > 0) e = hipMemcpyAsync(ecol.data(), d_ecol, sizeof(int) * (size_t)E, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && E > 0) e = hipMemcpyAsync(eval.data(), d_eval, sizeof(float) * (size_t)E, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    drop();
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return 1;
+    }
+  }
+  // pass 1: slots per (slice, step) -> the strides of the layout
+  long long max_slots = 1, max_rows = 1;
+  p->cs_shift.assign((size_t)n_steps, 21);
+  {
+    std::vector<int> cnt((size_t)G);
+    for (long long s = 0; s < n_steps; ++s) {
+      std::vector<long long> slots((size_t)G, 0);
+      long long worst_list = 1;
+      for (int k = 0; k < K; ++k) worst_list = std::max(worst_list, p->offsets[(size_t)(s * K + k) + 1] - p->offsets[(size_t)(s * K + k)]);
+      for (long long t = p->offsets[(size_t)(s * K)]; t < p->offsets[(size_t)((s + 1) * K)]; ++t) {
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (long long e = pre[(size_t)t]; e < pre[(size_t)t + 1]; ++e) ++cnt[(size_t)(ecol[(size_t)e] % G)];
+        for (int b = 0; b < G; ++b) slots[(size_t)b] += (cnt[(size_t)b] + CS_L - 1) / CS_L;
+      }
+      for (int b = 0; b < G; ++b) max_slots = std::max(max_slots, slots[(size_t)b]);
+      max_rows = std::max(max_rows, p->offsets[(size_t)((s + 1) * K)] - p->offsets[(size_t)(s * K)]);
+      int bits = 0;
+      while ((1LL << bits) < worst_list) ++bits;
+      p->cs_shift[(size_t)s] = 30 - bits;   // at most one contribution per row and column: a worker's sums stay below 2^30
+    }
+  }
+  if (max_slots > CS_MAX_SLOTS || max_rows > CS_MAX_SLOTS) return DSGD_OK;
+  const int slot_stride = (int)((max_slots + 63) / 64 * 64), row_stride = (int)((max_rows + 1 + 63) / 64 * 64);
+  const long long cells = (long long)G * n_steps;
+  const long long bytes = cells * ((long long)slot_stride * (4 + CS_L * 2 + CS_L * 4) + (long long)row_stride * 2 + 8);
+  if (bytes > c->cs_max_mb * (1LL << 20)) return DSGD_OK;
+  // pass 2: the layout
+  std::vector<CsHdr> hdr((size_t)cells);
+  std::vector<unsigned int> meta((size_t)(cells * slot_stride), 0u);
+  std::vector<unsigned short> rf((size_t)(cells * row_stride), (unsigned short)0);
+  std::vector<unsigned short> col((size_t)(cells * slot_stride * CS_L), (unsigned short)0);
+  std::vector<float> val((size_t)(cells * slot_stride * CS_L), 0.0f);
+  {
+    std::vector<std::vector<std::pair<unsigned short, float>>> bucket((size_t)G);
+    for (long long s = 0; s < n_steps; ++s) {
+      std::vector<int> cur((size_t)G, 0);
+      int r = 0;
+      for (int k = 0; k < K; ++k) {
+        for (long long t = p->offsets[(size_t)(s * K + k)]; t < p->offsets[(size_t)(s * K + k) + 1]; ++t, ++r) {
+          for (auto& v : bucket) v.clear();
+          for (long long e = pre[(size_t)t]; e < pre[(size_t)t + 1]; ++e) {
+            const int rank = ecol[(size_t)e];
+            bucket[(size_t)(rank % G)].emplace_back((unsigned short)(rank / G), eval[(size_t)e]);
+          }
+          const unsigned short ypos = c->h_label[(size_t)p->h_idx[(size_t)t]] > 0 ? (unsigned short)0x8000u : (unsigned short)0;
+          for (int b = 0; b < G; ++b) {
+            const long long cell = (long long)b * n_steps + s;
+            rf[(size_t)(cell * row_stride + r)] = (unsigned short)(cur[(size_t)b] | ypos);
+            const auto& bk = bucket[(size_t)b];
+            for (size_t j0 = 0; j0 < bk.size(); j0 += CS_L) {
+              const long long slot = cell * slot_stride + cur[(size_t)b];
+              meta[(size_t)slot] = (unsigned int)r | ((unsigned int)k << 16);
+              for (size_t j = j0; j < std::min(bk.size(), j0 + CS_L); ++j) {
+                col[(size_t)(slot * CS_L + (long long)(j - j0))] = bk[j].first;
+                val[(size_t)(slot * CS_L + (long long)(j - j0))] = bk[j].second;
+              }
+              ++cur[(size_t)b];
+            }
+          }
+        }
+      }
+      for (int b = 0; b < G; ++b) {
+        const long long cell = (long long)b * n_steps + s;
+        rf[(size_t)(cell * row_stride + r)] = (unsigned short)cur[(size_t)b];   // the sentinel: one past the last row's slots
+        hdr[(size_t)cell].counts = (unsigned int)cur[(size_t)b] | ((unsigned int)r << 16);
+        hdr[(size_t)cell].shift = p->cs_shift[(size_t)s];
+      }
+    }
+  }
+  CS_SOFT(hipMalloc(&p->d_cs_hdr, sizeof(CsHdr) * hdr.size()));
+  CS_SOFT(hipMalloc(&p->d_cs_meta, sizeof(unsigned int) * meta.size()));
+  CS_SOFT(hipMalloc(&p->d_cs_rf, sizeof(unsigned short) * rf.size()));
+  CS_SOFT(hipMalloc(&p->d_cs_col, sizeof(unsigned short) * col.size()));
+  CS_SOFT(hipMalloc(&p->d_cs_val, sizeof(float) * val.size()));
+  CS_SOFT(hipMemcpy(p->d_cs_hdr, hdr.data(), sizeof(CsHdr) * hdr.size(), hipMemcpyHostToDevice));
+  CS_SOFT(hipMemcpy(p->d_cs_meta, meta.data(), sizeof(unsigned int) * meta.size(), hipMemcpyHostToDevice));
+  CS_SOFT(hipMemcpy(p->d_cs_rf, rf.data(), sizeof(unsigned short) * rf.size(), hipMemcpyHostToDevice));
+  CS_SOFT(hipMemcpy(p->d_cs_col, col.data(), sizeof(unsigned short) * col.size(), hipMemcpyHostToDevice));
+  CS_SOFT(hipMemcpy(p->d_cs_val, val.data(), sizeof(float) * val.size(), hipMemcpyHostToDevice));
+  if (!c->d_cs_x) {
+    CS_SOFT(hipMalloc(&c->d_cs_x, sizeof(float) * 2 * CS_MAX_G * CS_XSTRIDE));
+    CS_SOFT(hipMalloc(&c->d_cs_sync, sizeof(unsigned int) * 2));
+  }
+  p->cs_G = G;
+  p->cs_spl = std::max(max_slots, max_rows) <= 2 * CS_THREADS ? 2 : 4;
+  p->cs_slot_stride = slot_stride;
+  p->cs_row_stride = row_stride;
+  p->cs_ok = true;
+  return DSGD_OK;
+}
+#undef CS_SOFT
+static int cs_build(dsgd_ctx* c, dsgd_plan* p) {
+  int rc;
+  try {
+    rc = cs_build_impl(c, p);
+  } catch (const std::bad_alloc&) {   // (nothing may unwind across the C ABI)
+    rc = 1;
+  }
+  if (rc == 1) {
+    cs_free(p);   // (cs_layout is stamped: the plan keeps the row-parallel kernels until the layout changes)
+    return DSGD_OK;
+  }
+  return rc;
+}
+
+// the steps [step_begin, step_end) of a plan with column slices: ONE launch
+static int launch_cs(dsgd_ctx* c, dsgd_plan* p, long long step_begin, long long step_end, float lr) {
+  CsArgs a;
+  a.hdr = p->d_cs_hdr;
+  a.slot_meta = p->d_cs_meta;
+  a.row_first = p->d_cs_rf;
+  a.col = p->d_cs_col;
+  a.val = p->d_cs_val;
+  a.w = c->d_w;
+  a.ds = c->d_ds;
+  a.xbuf = c->d_cs_x;
+  a.sync = c->d_cs_sync;
+  a.sc = c->d_sc;
+  a.n_steps_plan = p->n_steps;
+  a.step_begin = step_begin;
+  a.step_end = step_end;
+  a.slot_stride = p->cs_slot_stride;
+  a.row_stride = p->cs_row_stride;
+  a.lr = lr;
+  a.lambda = (float)c->cfg.lambda;
+  a.vexp = c->vexp;
+  a.dp = c->dp;
+  a.G = p->cs_G;
+  a.K = p->n_workers;
+  const size_t lds = sizeof(float) * (size_t)cs_lds_words(c->dp, a.G, a.K);
+  HIP_TRY(hipMemsetAsync(c->d_cs_sync, 0, sizeof(unsigned int) * 2, c->stream));   // arrivals are counted per launch
+  size_t slot = 0;
+  DSGD_TRY(prof_begin(c, &slot));
+  c->ctr_known = false;
+  if (p->cs_spl == 2) hipLaunchKernelGGL(dsgd_cs_step_kernel<2>, dim3((unsigned)a.G), dim3(CS_THREADS), lds, c->stream, a);
+  else hipLaunchKernelGGL(dsgd_cs_step_kernel<4>, dim3((unsigned)a.G), dim3(CS_THREADS), lds, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  DSGD_TRY(prof_end(c, slot));
+  c->last_grad_kernel = "dsgd_cs_step_kernel";
+  c->last_shift = p->cs_shift[(size_t)(step_end - 1)];
+  c->fused_apply_pending = false;
+  c->s_dirty = true;    // the kernel carries s = 2 lambda (w . ds) itself; whoever needs it next recomputes it from the weights
+  c->s_lazy = false;
+  c->nsq_dirty = false;
   return DSGD_OK;
 }
 
@@ -1471,6 +1711,9 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_FIX_BOUND")) c->fix_bound = atoi(e) != 0;      // 0: data-independent bound only
   if (const char* e = getenv("DSGD_PLAN_KERNEL")) c->plan_kernel = atoi(e) != 0;  // 0: small batches through the multi-workgroup kernel
   if (const char* e = getenv("DSGD_VT")) c->vt_enable = atoi(e) != 0;             // 0: plans' index lists through dsgd_mb_grad_kernel
+  if (const char* e = getenv("DSGD_CS")) c->cs_enable = atoi(e) != 0;             // 0: small plan steps through the row-parallel kernels
+  if (const char* e = getenv("DSGD_CS_G")) c->cs_g = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 0);
+  if (const char* e = getenv("DSGD_CS_MAX_MB")) c->cs_max_mb = std::max(0, atoi(e));
   if (const char* e = getenv("DSGD_VT_TPW")) c->vt_tpw = std::max(1, atoi(e));
   if (const char* e = getenv("DSGD_VT_PACK_MB")) c->vt_pack_mb = std::max(0, atoi(e));
   if (const char* e = getenv("DSGD_HSPLIT")) c->hsplit = atoi(e);                 // hot/cold split rank (tests: wide models)
@@ -1492,6 +1735,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_vt_grad_kernel<true>);
   DSGD_ATTR(dsgd_vt_grad_kernel<false>);
   DSGD_ATTR(dsgd_plan_kernel);
+  DSGD_ATTR(dsgd_cs_step_kernel<2>);
+  DSGD_ATTR(dsgd_cs_step_kernel<4>);
   DSGD_ATTR(dsgd_wseg_kernel<true>);
   DSGD_ATTR(dsgd_wseg_kernel<false>);
   DSGD_ATTR(dsgd_wseg_bound_kernel);
@@ -1584,6 +1829,8 @@ int dsgd_destroy(dsgd_ctx* c) {
   (void)hipFree(c->d_wdelta);
   (void)hipFree(c->d_tprof);
   (void)hipFree(c->d_plan_gcold);
+  (void)hipFree(c->d_cs_x);
+  (void)hipFree(c->d_cs_sync);
   if (c->h_sc) (void)hipHostFree(c->h_sc);
   if (c->h_mail) (void)hipHostFree(c->h_mail);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -2045,6 +2292,9 @@ int dsgd_synchronize(dsgd_ctx* c, dsgd_batch_stats* stats) {
   if (err & 2)
     return fail(DSGD_ESTATE, "fixed-point gradient accumulator left its safe band; the steps since the last "
                              "synchronize are invalid");
+  if (err & 8)
+    return fail(DSGD_ESTATE, "the column-slice kernel's exchange between its workgroups timed out; the steps since the last "
+                             "synchronize are invalid (DSGD_CS=0 selects the row-parallel kernels)");
   if (err) return fail(DSGD_ERANGE, "sample index / key outside the loaded data");
   if (stats) {
     stats->n_active = act;
@@ -2111,6 +2361,11 @@ int dsgd_plan_destroy(dsgd_ctx* c, dsgd_plan* p) {
   (void)hipFree(p->d_vt_segs);
   (void)hipFree(p->d_vt_long);
   (void)hipFree(p->d_vt_packed);
+  (void)hipFree(p->d_cs_hdr);
+  (void)hipFree(p->d_cs_meta);
+  (void)hipFree(p->d_cs_rf);
+  (void)hipFree(p->d_cs_col);
+  (void)hipFree(p->d_cs_val);
   delete p;
   return DSGD_OK;
 }
@@ -2127,6 +2382,15 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
   DSGD_TRY(require_ds(c));
   DSGD_TRY(require_sync_mode(c));
   DSGD_TRY(prepare_layout(c));
+  // the reference's own batch sizes: column slices, the whole range of steps in ONE launch (csrc/dsgd_cs.hpp)
+  if (c->cs_enable && !c->comm) {
+    if (p->cs_layout != c->layout_gen) DSGD_TRY(cs_build(c, p));
+    if (p->cs_ok && p->cs_layout == c->layout_gen) {
+      if (step_end > step_begin) DSGD_TRY(launch_cs(c, p, step_begin, step_end, lr));
+      c->pending_samples += p->offsets[step_end * p->n_workers] - p->offsets[step_begin * p->n_workers];
+      return DSGD_OK;
+    }
+  }
   if (plan_kernel_ok(c, p->max_step_rows, p->n_workers) && p->fits && p->fits_rows == c->n_rows) {
     if (step_end > step_begin) DSGD_TRY(launch_plan_kernel(c, p->d_idx, p->d_segs, step_begin, step_end, lr));
     c->pending_samples += p->offsets[step_end * p->n_workers] - p->offsets[step_begin * p->n_workers];

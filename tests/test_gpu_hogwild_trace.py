@@ -6,9 +6,9 @@ update count its weights were read at, the regulariser scalar it used, the gate 
 (tests/test_hogwild_replay.py keeps that experiment); with the engine's own decisions the oracle recomputes every
 update of core/Slave.scala:92-101 exactly (oracle/hogwild_replay.py) and three statements are asserted at 4, 64 and 256
 workers: (A) the engine's final weights ARE the replayed ones to rounding -- every update applied once, averaged,
-scaled, regularised as the reference does; (B) on rows whose margin is clear of zero the recorded gate decisions are
-the reference's gate on the replayed weights at `read_at` -- and visibly NOT on the weights at the commit when there are
-many workers; (C) the recorded scalar is 2 lambda (w . ds) of those weights.  Negative controls (every update applied
+scaled, regularised as the reference does; (B) with many workers the recorded gate decisions fit the replayed weights at the READ end of
+[read_at, commit) better than at the commit end (row by row they cannot be reproduced: one update in flight flips 12 % of
+the gates -- tests/test_hogwild_replay.py); (C) the recorded scalar is 2 lambda (w . ds) of the weights at read_at.  Negative controls (every update applied
 twice, ONE update lost, sum instead of mean, half the step, no regulariser, the wrong sample) must break (A).  The trace
 itself is held to exact invariants."""
 
@@ -83,26 +83,20 @@ def traced_run(k, n_rows, checkpoints, data_seed=13):
 def test_traced_run_is_the_reference_rule_applied_once_per_update(k, n_rows, checkpoints):
     o, split, ev, segs, verdicts, w_eng = traced_run(k, n_rows, checkpoints)
     for v in verdicts:
-        print("k=%d after %5d updates (lag max %d mean %.1f): accounting err %.2e (%.3f of tol)  rel.dist %.2e  gates differ "
-              "%.4f of all rows, %.5f of the clear rows (%.4f if staleness is ignored)  s err median %.1e max %.1e of |s| <= %.1e; "
-              "loss %.4f / %.4f" % (k, v["updates"], v["max_lag"], v["mean_lag"], v["account_max_abs_err"], v["account_err_over_tol"],
-                                    v["rel_distance"], v["gate_differs_all_rows"], v["gate_differs_clear_rows"],
-                                    v["gate_differs_clear_rows_if_staleness_ignored"], v["s_err_median"], v["s_err_max"],
-                                    v["s_max_abs"], v["loss_engine"], v["loss_replay"]))
+        print("k=%d after %5d updates (lag max %d mean %.1f): accounting err %.2e (%.3f of tol)  rel.dist %.2e  gates differ at "
+              "read_at + f * lag, f = %s: %s  s rel err median %.1e p90 %.1e max %.1e of |s| <= %.1e; loss %.4f / %.4f" % (
+                  k, v["updates"], v["max_lag"], v["mean_lag"], v["account_max_abs_err"], v["account_err_over_tol"], v["rel_distance"],
+                  v["gate_fractions"], ["%.4f" % x for x in v["gate_differs_at_fraction"]], v["s_rel_err_median"], v["s_rel_err_p90"],
+                  v["s_rel_err_max"], v["s_max_abs"], v["loss_engine"], v["loss_replay"]))
     for v in verdicts:
         assert all(v["ok"].values()), v
-    last = verdicts[-1]
-    if k >= 64:   # `read_at` carries information: against the weights at the commit the decisions fit visibly worse
-        assert last["gate_differs_clear_rows_if_staleness_ignored"] > 3.0 * max(last["gate_differs_clear_rows"], 1e-4), last
     # negative controls: the same records under a broken rule must break the accounting
     for fault in hr.FAULTS:
         w_bad = np.zeros(o.dim + 1)
         with np.errstate(all="ignore"):
             for seed, trace in segs:
                 hr.replay_forced(o, w_bad, split, BATCH, LR, seed, trace, fault=fault, check=False)
-            vb = hr.verdict(o, w_eng, w_bad, {"updates": 0, "max_lag": 0, "mean_lag": 0.0, "rows": 0, "rows_clear": 0, "gate_differs": 0,
-                                              "gate_differs_clear": 0, "gate_differs_clear_if_fresh": 0, "rows_clear_if_fresh": 0,
-                                              "s_max_abs": 0.0, "s_err": []})
+            vb = hr.verdict(o, w_eng, w_bad, hr.EMPTY)
         print("k=%d control %-15s accounting err %.3e = %.1f x tolerance -> %s" % (
             k, fault, vb["account_max_abs_err"], vb["account_err_over_tol"], "rejected" if not vb["ok"]["accounting"] else "NOT rejected"))
         assert not vb["ok"]["accounting"], (fault, vb)

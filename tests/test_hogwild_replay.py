@@ -63,7 +63,7 @@ def test_forced_replay_reproduces_a_modelled_schedule(k):
     assert st["updates"] == 160 and st["max_lag"] == k - 1
     # the recorded scalar is fp32: |s| ~ 1e-6, so the weights agree to ~1e-13 rather than bit for bit
     assert v["account_max_abs_err"] <= 1e-9 and all(v["ok"].values()), v
-    assert v["gate_differs_all_rows"] == 0.0 and v["s_err_max"] <= 1e-6 * max(v["s_max_abs"], 1e-12) + 1e-12
+    assert v["gate_differs_at_fraction"][0] == 0.0 and v["s_rel_err_max"] <= 1e-6
 
 
 def test_every_negative_control_breaks_the_accounting():
@@ -96,6 +96,23 @@ def test_a_resimulation_cannot_follow_a_perturbed_run():
     w0[np.random.default_rng(0).integers(1, 47000, 100)] = 1e-7
     w_b, _ = model_run(o, split, 100, 0.5, 4242, 400, w0=w0)
     assert np.sqrt(((w_a - w_b) ** 2).sum()) > 0.05 * np.sqrt((w_a ** 2).sum())
+
+
+def test_gates_are_hypersensitive_to_the_snapshot():
+    """Why statement (B) is a profile and not a row-by-row check: the recorded gates of a MODELLED 4-worker schedule held
+    against a snapshot that is off by ONE update disagree on ~12 % of the rows (two: ~24 %) -- the margins of a
+    constant-step run are as small as what one update moves them by."""
+    data, o, n_train = problem(n_rows=20000)
+    k = 4
+    split = [(r.start, r.stop) for r in host.split_vanilla(n_train, k)]
+    _, tr = model_run(o, split, 100, 0.5, 4242, 300)
+    commit = np.arange(1, 301)
+    out = {}
+    for shift in (0, 1, 2):
+        t2 = dict(tr, read_at=np.clip(tr["read_at"] + shift, 0, commit - 1))
+        st = hr.replay_forced(o, np.zeros(o.dim + 1), split, 100, 0.5, 4242, t2, fractions=(0.0,))
+        out[shift] = st["gate_differs"][0] / st["rows"]
+    assert out[0] == 0.0 and out[1] > 0.05 and out[2] > out[1], out
 
 
 def test_inconsistent_traces_are_refused():
