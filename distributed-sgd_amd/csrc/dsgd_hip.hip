@@ -854,8 +854,9 @@ static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
   const int K = p->n_workers;
   const long long n_steps = p->n_steps, n_lists = n_steps * K;
   if (K > CS_MAX_K || p->max_step_rows > CS_MAX_SLOTS) return DSGD_OK;
-  const int G = c->cs_g ? c->cs_g : (K <= 4 ? 8 : 16);
-  if (c->dp < 4 * G || cs_lds_words(c->dp, G, K) > DSGD_LDS_FLOATS) return DSGD_OK;
+  int G = c->cs_g ? c->cs_g : (K <= 4 ? 8 : 16);
+  if (!c->cs_g && G == 8 && cs_lds_words(c->dp, 8, K) > DSGD_LDS_FLOATS) G = 16;   // (a wide model: narrower slices)
+  if (c->dp < 4 * G || cs_lds_words(c->dp, G, K) > DSGD_LDS_FLOATS || (c->dp + G - 1) / G > 65536) return DSGD_OK;
   if (c->h_row_ptr.size() != (size_t)c->n_rows + 1 || (long long)p->h_idx.size() != p->offsets[n_lists]) return DSGD_OK;
   const long long N = p->offsets[n_lists];
   std::vector<long long> pre((size_t)N + 1);

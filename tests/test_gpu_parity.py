@@ -34,6 +34,22 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="no gfx9
 GATE_EPS = 1e-5
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _row_parallel_kernels_of_resident_plans():
+    """This module pins the ROW-parallel index-list kernels (the one-workgroup plan kernel, virtual tiles, the row-wise
+    kernel): the small steps of resident plans would otherwise take the column-slice kernel, which has its own module
+    (tests/test_gpu_cs.py).  DSGD_CS is read when a context is created."""
+    import os
+
+    old = os.environ.get("DSGD_CS")
+    os.environ["DSGD_CS"] = "0"
+    yield
+    if old is None:
+        del os.environ["DSGD_CS"]
+    else:
+        os.environ["DSGD_CS"] = old
+
+
 def tol(w_ref):
     return 1e-5 * max(1.0, float(np.abs(w_ref).max()))
 
