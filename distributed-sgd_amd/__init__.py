@@ -1,6 +1,7 @@
 """distributed-sgd_amd -- MI355X-native engine for the hot path of zifeo/distributed-sgd.
 
     Engine            one libdsgd_hip context (HIP kernels behind the C ABI of include/dsgd.h)
+    EngineGroup       several contexts (one per device) driven by one host thread: dsgd_*_devices
     synth             synthetic RCV1-like CSR generator
     host              host-side mirror of the reference's Master / Slave / SparseSVM surface
     rcv1              RCV1-v2 text files <-> CSR with the reference loader's semantics (Dataset.rcv1)
@@ -13,6 +14,6 @@ The directory name is not an importable identifier; `import dsgd_amd` (repo root
 from . import _build, _lib, host, rcv1, synth, wire  # noqa: F401
 from ._lib import DsgdError, DsgdIndexError, DsgdInvalidArgument  # noqa: F401
 from .dense import DenseLogistic  # noqa: F401
-from .engine import Engine, Plan, device_count  # noqa: F401
+from .engine import Engine, EngineGroup, Plan, device_count  # noqa: F401
 
-__all__ = ["Engine", "Plan", "DenseLogistic", "device_count", "synth", "host", "rcv1", "wire", "DsgdError", "DsgdIndexError", "DsgdInvalidArgument"]
+__all__ = ["Engine", "EngineGroup", "Plan", "DenseLogistic", "device_count", "synth", "host", "rcv1", "wire", "DsgdError", "DsgdIndexError", "DsgdInvalidArgument"]

@@ -70,6 +70,8 @@ static int (*GetUniqueId)(unique_id_t*) = nullptr;
 static int (*CommInitRank)(comm_t*, int, unique_id_t, int) = nullptr;
 static int (*CommDestroy)(comm_t) = nullptr;
 static int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+static int (*GroupStart)() = nullptr;
+static int (*GroupEnd)() = nullptr;
 static const char* (*GetErrorString)(int) = nullptr;
 static std::once_flag once;
 static bool ok = false;
@@ -97,8 +99,10 @@ static void load() {
   CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
   CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
   AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+  GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
+  GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
   GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
-  ok = GetUniqueId && CommInitRank && CommDestroy && AllReduce && GetErrorString;
+  ok = GetUniqueId && CommInitRank && CommDestroy && AllReduce && GroupStart && GroupEnd && GetErrorString;
 }
 static bool available() {
   std::call_once(once, load);
@@ -1052,11 +1056,17 @@ static int launch_grad(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, int
   return launch_grad_mb(c, d_idx, d_segs, n_workers, max_items, allow_fused);
 }
 
-// regularise each hosted worker's sum, aggregate (locally and across ranks), update w
-static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr, bool mail = false) {
+// regularise each hosted worker's sum, aggregate (locally and across ranks), update w -- in three parts, so that ONE host
+// thread can drive several contexts (dsgd_sync_step_devices): every context's kernels in front of the collective are
+// enqueued first, then all the all-reduces inside one ncclGroup, then the updates behind them.
+//   finish_pre         without peers: the whole fused reduce + regularise + mean + update (nothing else follows);
+//                      with peers: exact column sums + regulariser + sum over the hosted workers -> d_gsum
+//   finish_collective  the synchronous master's Future.sequence + Vec.mean (ref: core/Master.scala:190-194) as ONE all-reduce
+//                      of D+1 floats over xGMI, ordered on the same stream as the kernels around it
+//   finish_post        w <- w - lr * sum / (workers x world), the next regulariser scalar
+static int finish_pre(dsgd_ctx* c, int n_workers, float lr, bool mail) {
   const int dp = c->dp;
   const int cblocks = (dp + FRA_COLS - 1) / FRA_COLS;
-  const float k_total = (float)n_workers * (float)c->world;
   if (!c->fused_apply_pending) return fail(DSGD_ESTATE, "internal: no gradient partials pending");
   c->fused_apply_pending = false;
   const FusedArgs& f = c->fused_args;
@@ -1072,22 +1082,34 @@ static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr, bool mail = 
     c->s_dirty = false;
     return DSGD_OK;
   }
-  // peers: exact column sums + regulariser + sum over the hosted workers in one launch, then the synchronous
-  // master's Future.sequence + Vec.mean (ref: core/Master.scala:190-194) as ONE all-reduce of D+1 floats over xGMI,
-  // ordered on the same stream as the kernels around it, then the update
   hipLaunchKernelGGL(dsgd_fix_reduce_apply_kernel<false>, dim3(cblocks), dim3(1024), 0, c->stream, c->d_g64, (long long)dp,
                      n_workers, c->d_w, c->d_ds, dp, f.hg, c->d_part, c->part_stride, f.n_wg, f.hc, f.nc, c->d_partc, c->partc_stride, f.n_wgc,
                      f.inv_scale, f.inv_scale_cold, lr, (float)c->cfg.lambda, c->d_sc, red_out(c), c->d_gsum,
                      (const float*)red_cur(c), c->s_lazy ? 1 : 0, (unsigned long long*)nullptr);
   HIP_TRY(hipGetLastError());
-  RCCL_TRY(rccl::AllReduce(c->d_gsum, c->d_gsum, (size_t)dp, rccl::kFloat32, rccl::kSum, c->comm, c->stream));
-  hipLaunchKernelGGL(dsgd_apply_cols_kernel, dim3(cblocks), dim3(256), 0, c->stream, c->d_w, c->d_gsum, c->d_ds, dp, k_total, lr,
+  return DSGD_OK;
+}
+static int finish_collective(dsgd_ctx* c) {
+  if (!c->comm) return DSGD_OK;
+  RCCL_TRY(rccl::AllReduce(c->d_gsum, c->d_gsum, (size_t)c->dp, rccl::kFloat32, rccl::kSum, c->comm, c->stream));
+  return DSGD_OK;
+}
+static int finish_post(dsgd_ctx* c, int n_workers, float lr) {
+  if (!c->comm) return DSGD_OK;
+  const int cblocks = (c->dp + FRA_COLS - 1) / FRA_COLS;
+  const float k_total = (float)n_workers * (float)c->world;
+  hipLaunchKernelGGL(dsgd_apply_cols_kernel, dim3(cblocks), dim3(256), 0, c->stream, c->d_w, c->d_gsum, c->d_ds, c->dp, k_total, lr,
                      (float)c->cfg.lambda, c->d_sc, red_out(c), 0);
   HIP_TRY(hipGetLastError());
   c->red_par ^= 1;
   c->s_lazy = true;
   c->s_dirty = false;
   return DSGD_OK;
+}
+static int launch_finish_sync(dsgd_ctx* c, int n_workers, float lr, bool mail = false) {
+  DSGD_TRY(finish_pre(c, n_workers, lr, mail));
+  DSGD_TRY(finish_collective(c));
+  return finish_post(c, n_workers, lr);
 }
 
 // ---- column layout -------------------------------------------------------------------------------------
@@ -1321,17 +1343,32 @@ static int build_split(dsgd_ctx* c) {
 // Rank the columns by how often they occur in the loaded rows (summed over ranks when a
 // communicator is attached, so every replica uses the same order) and relabel the CSR columns.
 // Runs once, lazily, at the first compute call after dsgd_load_csr.
-static int prepare_layout(dsgd_ctx* c) {
+// (in three parts -- the counts, their all-reduce, the ranking and the split -- so that one host thread can prepare several
+//  contexts: dsgd_build_dim_sparsity_devices)
+static int layout_begin(dsgd_ctx* c, unsigned int** d_cnt_out) {
+  *d_cnt_out = nullptr;
   if (c->layout_ready) return DSGD_OK;
   unsigned int* d_cnt = nullptr;
   HIP_TRY(hipMalloc(&d_cnt, sizeof(unsigned int) * c->dp));
-  int rc = count_columns(c, c->nnz, d_cnt);
-  if (!rc && c->comm) {
-    int r = rccl::AllReduce(d_cnt, d_cnt, (size_t)c->dp, rccl::kUint32, rccl::kSum, c->comm, c->stream);
-    if (r) rc = fail(DSGD_ERCCL, "ncclAllReduce(column counts): %s", rccl::GetErrorString(r));
+  const int rc = count_columns(c, c->nnz, d_cnt);
+  if (rc) {
+    (void)hipFree(d_cnt);
+    return rc;
   }
+  *d_cnt_out = d_cnt;
+  return DSGD_OK;
+}
+static int layout_collective(dsgd_ctx* c, unsigned int* d_cnt) {
+  if (!d_cnt || !c->comm) return DSGD_OK;
+  int r = rccl::AllReduce(d_cnt, d_cnt, (size_t)c->dp, rccl::kUint32, rccl::kSum, c->comm, c->stream);
+  if (r) return fail(DSGD_ERCCL, "ncclAllReduce(column counts): %s", rccl::GetErrorString(r));
+  return DSGD_OK;
+}
+static int layout_finish(dsgd_ctx* c, unsigned int* d_cnt) {   // (takes ownership of d_cnt)
+  if (!d_cnt) return DSGD_OK;
   std::vector<unsigned int> cnt(c->dp);
-  if (!rc) {
+  int rc = DSGD_OK;
+  {
     hipError_t e = hipMemcpyAsync(cnt.data(), d_cnt, sizeof(unsigned int) * c->dp, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = fail(DSGD_EHIP, "column counts: %s", hipGetErrorString(e));
@@ -1359,6 +1396,17 @@ static int prepare_layout(dsgd_ctx* c) {
   c->layout_ready = true;
   c->s_dirty = true;
   return DSGD_OK;
+}
+static int prepare_layout(dsgd_ctx* c) {
+  if (c->layout_ready) return DSGD_OK;
+  unsigned int* d_cnt = nullptr;
+  DSGD_TRY(layout_begin(c, &d_cnt));
+  const int rc = layout_collective(c, d_cnt);
+  if (rc) {
+    (void)hipFree(d_cnt);
+    return rc;
+  }
+  return layout_finish(c, d_cnt);
 }
 // back to the identity layout (before new data is loaded): resident vectors return to key order
 static int reset_layout(dsgd_ctx* c) {
@@ -1975,27 +2023,33 @@ int dsgd_set_dim_sparsity(dsgd_ctx* c, const float* ds) {
   return DSGD_OK;
 }
 
-int dsgd_build_dim_sparsity(dsgd_ctx* c, int64_t n_train, float* ds_out) {
-  DSGD_TRY(check_ctx(c));
-  std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c));
-  DSGD_TRY(require_data(c));
-  DSGD_TRY(require_sync_mode(c));
-  if (n_train < 1 || n_train > c->n_rows) return fail(DSGD_EINVAL, "n_train %lld outside [1, %lld]", (long long)n_train, c->n_rows);
-  DSGD_TRY(prepare_layout(c));
+// dimSparsity in three parts around its all-reduce (one host thread, several contexts: dsgd_build_dim_sparsity_devices)
+static int ds_begin(dsgd_ctx* c, long long n_train, unsigned int** d_cnt_out) {   // (layout ready)
+  *d_cnt_out = nullptr;
   long long nnz_train = 0;
   HIP_TRY(hipMemcpy(&nnz_train, c->d_row_ptr + n_train, sizeof(long long), hipMemcpyDeviceToHost));
   unsigned int* d_cnt = nullptr;
   HIP_TRY(hipMalloc(&d_cnt, sizeof(unsigned int) * c->dp));
   int rc = reset_counters(c);
   if (!rc) rc = count_columns(c, nnz_train, d_cnt);
-  if (!rc && c->comm) {
-    // the reference counts over the WHOLE train set (Main.scala:57-60); shards sum their counts
-    int r = rccl::AllReduce(d_cnt, d_cnt, (size_t)c->dp, rccl::kUint32, rccl::kSum, c->comm, c->stream);
-    if (r) rc = fail(DSGD_ERCCL, "ncclAllReduce(feature counts): %s", rccl::GetErrorString(r));
+  if (rc) {
+    (void)hipFree(d_cnt);
+    return rc;
   }
+  *d_cnt_out = d_cnt;
+  return DSGD_OK;
+}
+static int ds_collective(dsgd_ctx* c, unsigned int* d_cnt) {
+  if (!c->comm) return DSGD_OK;
+  // the reference counts over the WHOLE train set (Main.scala:57-60); shards sum their counts
+  int r = rccl::AllReduce(d_cnt, d_cnt, (size_t)c->dp, rccl::kUint32, rccl::kSum, c->comm, c->stream);
+  if (r) return fail(DSGD_ERCCL, "ncclAllReduce(feature counts): %s", rccl::GetErrorString(r));
+  return DSGD_OK;
+}
+static int ds_finish(dsgd_ctx* c, unsigned int* d_cnt, float* ds_out) {   // (takes ownership of d_cnt)
+  int rc = DSGD_OK;
   unsigned int cnt_key0 = 0;
-  if (!rc) {
+  {
     // Main.scala:60 does buff(idx - 1): a feature id 0 in a train row would index buff(-1)
     int rank0 = 0;
     hipError_t e = hipMemcpyAsync(&rank0, c->d_perm, sizeof(int), hipMemcpyDeviceToHost, c->stream);
@@ -2021,6 +2075,28 @@ int dsgd_build_dim_sparsity(dsgd_ctx* c, int64_t n_train, float* ds_out) {
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   return DSGD_OK;
+}
+static int ds_checks(dsgd_ctx* c, long long n_train) {
+  DSGD_TRY(require_data(c));
+  DSGD_TRY(require_sync_mode(c));
+  if (n_train < 1 || n_train > c->n_rows) return fail(DSGD_EINVAL, "n_train %lld outside [1, %lld]", n_train, c->n_rows);
+  return DSGD_OK;
+}
+
+int dsgd_build_dim_sparsity(dsgd_ctx* c, int64_t n_train, float* ds_out) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(ds_checks(c, n_train));
+  DSGD_TRY(prepare_layout(c));
+  unsigned int* d_cnt = nullptr;
+  DSGD_TRY(ds_begin(c, n_train, &d_cnt));
+  const int rc = ds_collective(c, d_cnt);
+  if (rc) {
+    (void)hipFree(d_cnt);
+    return rc;
+  }
+  return ds_finish(c, d_cnt, ds_out);
 }
 
 static int set_weights_locked(dsgd_ctx* c, const float* w) {
@@ -2223,8 +2299,9 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
   return finish_mail(c, stats, tot, before);
 }
 
+// (finish = false: stop behind the gradient kernels -- the caller splits the finish around a grouped collective)
 static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* row_end, int n_workers, float lr,
-                          long long* total) {
+                          long long* total, bool finish = true) {
   if (n_workers < 1 || !row_begin || !row_end) return fail(DSGD_EINVAL, "need at least one worker");
   DSGD_TRY(require_data(c));
   DSGD_TRY(require_ds(c));
@@ -2254,7 +2331,7 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
     DSGD_TRY(upload_segs(c, segs));
     DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx, true));
   }
-  DSGD_TRY(launch_finish_sync(c, n_workers, lr));
+  if (finish) DSGD_TRY(launch_finish_sync(c, n_workers, lr));
   *total = tot;
   return DSGD_OK;
 }
@@ -2462,11 +2539,8 @@ int dsgd_forward(dsgd_ctx* c, const float* w, const int32_t* idx, int64_t n, flo
   return check_err_flag(c);
 }
 
-int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_end, double* loss, double* acc,
-                  int64_t* counts) {
-  DSGD_TRY(check_ctx(c));
-  std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c));
+// evaluation in three parts around the all-reduce of its tallies (one host thread, several contexts: dsgd_loss_acc_devices)
+static int eval_enqueue(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_end) {
   DSGD_TRY(require_data(c));
   DSGD_TRY(require_ds(c));
   if (row_end <= row_begin)  // samples.map(...).reduce on an empty collection throws (ref: SparseSVM.scala:21-23)
@@ -2507,11 +2581,16 @@ int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_en
     }
     HIP_TRY(hipGetLastError());
   }
+  return DSGD_OK;
+}
+static int eval_collective(dsgd_ctx* c) {
+  if (!c->comm) return DSGD_OK;
+  // shard-wise evaluation: three tallies + row count summed over ranks
+  RCCL_TRY(rccl::AllReduce(c->d_sc->counts, c->d_sc->counts, 4, rccl::kInt64, rccl::kSum, c->comm, c->stream));
+  return DSGD_OK;
+}
+static int eval_read(dsgd_ctx* c, double* loss, double* acc, int64_t* counts) {
   long long tallies[4] = {0, 0, 0, 0};
-  if (c->comm) {
-    // shard-wise evaluation: three tallies + row count summed over ranks
-    RCCL_TRY(rccl::AllReduce(c->d_sc->counts, c->d_sc->counts, 4, rccl::kInt64, rccl::kSum, c->comm, c->stream));
-  }
   DSGD_TRY(read_scalars(c));
   for (int i = 0; i < 4; ++i) tallies[i] = (long long)c->h_sc->counts[i];
   const double n = (double)tallies[3];
@@ -2523,6 +2602,16 @@ int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_en
     counts[2] = tallies[2];
   }
   return DSGD_OK;
+}
+
+int dsgd_loss_acc(dsgd_ctx* c, const float* w, int64_t row_begin, int64_t row_end, double* loss, double* acc,
+                  int64_t* counts) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  DSGD_TRY(eval_enqueue(c, w, row_begin, row_end));
+  DSGD_TRY(eval_collective(c));
+  return eval_read(c, loss, acc, counts);
 }
 
 int dsgd_async_step(dsgd_ctx* c, const int32_t* idx, int64_t n, float lr, float* delta_out, dsgd_batch_stats* stats) {
@@ -2968,6 +3057,230 @@ int dsgd_comm_destroy(dsgd_ctx* c) {
   c->comm = nullptr;
   c->world = 1;
   c->rank = 0;
+  return DSGD_OK;
+}
+
+// ---- ONE host thread driving several contexts -------------------------------------------------------------------------
+// The reference's dev role runs the master and every slave in ONE JVM (Main.scala:144-158): one thread of that JVM must be
+// able to step all the GPUs of a node.  A collective blocks its caller until every rank has joined, so the per-context
+// entry points above cannot be called one after the other from one thread; these take all the contexts at once: every
+// context's kernels in front of a collective are enqueued first, then all the collectives inside one
+// ncclGroupStart / ncclGroupEnd, then what follows them -- the same kernels, sums and order as N processes, one per GPU.
+}  // extern "C" (the helpers below are C++)
+namespace {
+struct MultiLock {
+  std::vector<dsgd_ctx*> held;
+  int lock(dsgd_ctx* const* ctxs, int n) {
+    if (!ctxs || n < 1) return fail(DSGD_EINVAL, "need at least one context");
+    std::vector<dsgd_ctx*> order(ctxs, ctxs + n);
+    for (dsgd_ctx* c : order)
+      if (!c) return fail(DSGD_EINVAL, "null context");
+    std::sort(order.begin(), order.end());   // one locking order for every caller
+    if (std::adjacent_find(order.begin(), order.end()) != order.end()) return fail(DSGD_EINVAL, "a context appears twice");
+    for (dsgd_ctx* c : order) {
+      c->mu.lock();
+      held.push_back(c);
+    }
+    return DSGD_OK;
+  }
+  ~MultiLock() {
+    for (auto it = held.rbegin(); it != held.rend(); ++it) (*it)->mu.unlock();
+  }
+};
+// every context of a grouped call joins the SAME collectives: communicators of one size, attached to all or to none
+int group_shape(dsgd_ctx* const* ctxs, int n) {
+  for (int i = 0; i < n; ++i) {
+    if ((ctxs[i]->comm != nullptr) != (ctxs[0]->comm != nullptr) || ctxs[i]->world != ctxs[0]->world)
+      return fail(DSGD_ESTATE, "the contexts of a grouped call must share one communicator shape (dsgd_comm_init_all)");
+    if (ctxs[i]->layout_ready != ctxs[0]->layout_ready)
+      return fail(DSGD_ESTATE, "some contexts have their column layout and some do not: load the data of all of them first");
+  }
+  if (n > 1 && !ctxs[0]->comm) return fail(DSGD_ESTATE, "several contexts without a communicator (dsgd_comm_init_all)");
+  return DSGD_OK;
+}
+// phase 2 of every grouped call: fn(context) enqueues that context's collective
+template <class Fn>
+int grouped(dsgd_ctx* const* ctxs, int n, Fn fn) {
+  if (!ctxs[0]->comm) return DSGD_OK;
+  RCCL_TRY(rccl::GroupStart());
+  int rc = DSGD_OK;
+  for (int i = 0; i < n && rc == DSGD_OK; ++i) {
+    rc = bind(ctxs[i]);
+    if (rc == DSGD_OK) rc = fn(ctxs[i], i);
+  }
+  const int re = rccl::GroupEnd();   // (always: a group that was started is ended)
+  if (rc == DSGD_OK && re != 0) rc = fail(DSGD_ERCCL, "ncclGroupEnd: %s", rccl::GetErrorString(re));
+  return rc;
+}
+}  // namespace
+extern "C" {
+
+int dsgd_comm_init_all(dsgd_ctx* const* ctxs, int32_t n_ctx) {
+  MultiLock ml;
+  DSGD_TRY(ml.lock(ctxs, n_ctx));
+  if (!rccl::available()) return fail(DSGD_ERCCL, "librccl could not be loaded");
+  for (int i = 0; i < n_ctx; ++i)
+    if (ctxs[i]->comm) return fail(DSGD_ESTATE, "communicator already attached to context %d", i);
+  rccl::unique_id_t id;
+  RCCL_TRY(rccl::GetUniqueId(&id));
+  RCCL_TRY(rccl::GroupStart());
+  int rc = DSGD_OK;
+  for (int i = 0; i < n_ctx && rc == DSGD_OK; ++i) {
+    rc = bind(ctxs[i]);
+    if (rc == DSGD_OK) {
+      const int r = rccl::CommInitRank(&ctxs[i]->comm, n_ctx, id, i);
+      if (r) rc = fail(DSGD_ERCCL, "ncclCommInitRank(rank %d of %d): %s", i, n_ctx, rccl::GetErrorString(r));
+    }
+  }
+  const int re = rccl::GroupEnd();
+  if (rc == DSGD_OK && re != 0) rc = fail(DSGD_ERCCL, "ncclGroupEnd: %s", rccl::GetErrorString(re));
+  if (rc != DSGD_OK) {
+    for (int i = 0; i < n_ctx; ++i) ctxs[i]->comm = nullptr;   // (whatever was created is abandoned: the call failed as a whole)
+    return rc;
+  }
+  for (int i = 0; i < n_ctx; ++i) {
+    ctxs[i]->world = n_ctx;
+    ctxs[i]->rank = i;
+  }
+  return DSGD_OK;
+}
+
+int dsgd_build_dim_sparsity_devices(dsgd_ctx* const* ctxs, int32_t n_ctx, const int64_t* n_train_per_ctx) {
+  MultiLock ml;
+  DSGD_TRY(ml.lock(ctxs, n_ctx));
+  if (!n_train_per_ctx) return fail(DSGD_EINVAL, "null n_train_per_ctx");
+  DSGD_TRY(group_shape(ctxs, n_ctx));
+  std::vector<unsigned int*> cnt((size_t)n_ctx, nullptr);
+  auto drop = [&]() {
+    for (auto& p : cnt) {
+      (void)hipFree(p);
+      p = nullptr;
+    }
+  };
+  int rc = DSGD_OK;
+  for (int i = 0; i < n_ctx && !rc; ++i) {
+    rc = bind(ctxs[i]);
+    if (!rc) rc = ds_checks(ctxs[i], n_train_per_ctx[i]);
+  }
+  // the column ranking: counts, their sum over the contexts, one order for all
+  for (int i = 0; i < n_ctx && !rc; ++i) {
+    rc = bind(ctxs[i]);
+    if (!rc) rc = layout_begin(ctxs[i], &cnt[(size_t)i]);
+  }
+  if (!rc) rc = grouped(ctxs, n_ctx, [&](dsgd_ctx* c, int i) { return layout_collective(c, cnt[(size_t)i]); });
+  for (int i = 0; i < n_ctx && !rc; ++i) {
+    rc = bind(ctxs[i]);
+    if (!rc) {
+      rc = layout_finish(ctxs[i], cnt[(size_t)i]);   // (takes the buffer)
+      cnt[(size_t)i] = nullptr;
+    }
+  }
+  // dimSparsity: feature counts of every context's train rows, summed (Main.scala:57-60 counts the whole train set)
+  for (int i = 0; i < n_ctx && !rc; ++i) {
+    rc = bind(ctxs[i]);
+    if (!rc) rc = ds_begin(ctxs[i], n_train_per_ctx[i], &cnt[(size_t)i]);
+  }
+  if (!rc) rc = grouped(ctxs, n_ctx, [&](dsgd_ctx* c, int i) { return ds_collective(c, cnt[(size_t)i]); });
+  for (int i = 0; i < n_ctx && !rc; ++i) {
+    rc = bind(ctxs[i]);
+    if (!rc) {
+      rc = ds_finish(ctxs[i], cnt[(size_t)i], nullptr);
+      cnt[(size_t)i] = nullptr;
+    }
+  }
+  drop();
+  return rc;
+}
+
+}  // extern "C"
+static int devices_step_checks(dsgd_ctx* const* ctxs, int n_ctx) {
+  DSGD_TRY(group_shape(ctxs, n_ctx));
+  for (int i = 0; i < n_ctx; ++i) {
+    dsgd_ctx* c = ctxs[i];
+    DSGD_TRY(bind(c));
+    DSGD_TRY(require_data(c));
+    DSGD_TRY(require_ds(c));
+    DSGD_TRY(require_sync_mode(c));
+    if (!c->layout_ready) return fail(DSGD_ESTATE, "context %d has no column layout yet (dsgd_build_dim_sparsity_devices)", i);
+  }
+  return DSGD_OK;
+}
+static int devices_step_finish(dsgd_ctx* const* ctxs, int n_ctx, int n_workers, float lr, const std::vector<long long>& totals,
+                               dsgd_batch_stats* stats) {
+  DSGD_TRY(grouped(ctxs, n_ctx, [](dsgd_ctx* c, int) { return finish_collective(c); }));
+  for (int i = 0; i < n_ctx; ++i) {
+    DSGD_TRY(bind(ctxs[i]));
+    DSGD_TRY(finish_post(ctxs[i], n_workers, lr));
+  }
+  dsgd_batch_stats sum{0, 0};
+  for (int i = 0; i < n_ctx; ++i) {
+    DSGD_TRY(bind(ctxs[i]));
+    dsgd_batch_stats one{0, 0};
+    DSGD_TRY(finish_stats(ctxs[i], &one, totals[(size_t)i]));
+    sum.n_samples += one.n_samples;
+    sum.n_active += one.n_active;
+  }
+  if (stats) *stats = sum;
+  return DSGD_OK;
+}
+extern "C" {
+
+int dsgd_sync_step_devices(dsgd_ctx* const* ctxs, int32_t n_ctx, const int32_t* const* idx_per_worker,
+                           const int64_t* n_per_worker, int32_t workers_per_ctx, float lr, dsgd_batch_stats* stats) {
+  MultiLock ml;
+  DSGD_TRY(ml.lock(ctxs, n_ctx));
+  if (workers_per_ctx < 1 || !idx_per_worker || !n_per_worker) return fail(DSGD_EINVAL, "need at least one worker per context");
+  DSGD_TRY(devices_step_checks(ctxs, n_ctx));
+  std::vector<long long> totals((size_t)n_ctx, 0);
+  for (int i = 0; i < n_ctx; ++i) {   // every context's gradient kernels and its part of the finish in front of the collective
+    dsgd_ctx* c = ctxs[i];
+    DSGD_TRY(bind(c));
+    DSGD_TRY(ensure_g(c, workers_per_ctx));
+    DSGD_TRY(ensure_s(c, true));
+    DSGD_TRY(reset_counters(c));
+    long long mx = 0;
+    DSGD_TRY(stage_lists(c, idx_per_worker + (size_t)i * workers_per_ctx, n_per_worker + (size_t)i * workers_per_ctx, workers_per_ctx,
+                         &mx, &totals[(size_t)i]));
+    DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, workers_per_ctx, mx, true));
+    DSGD_TRY(finish_pre(c, workers_per_ctx, lr, false));
+  }
+  return devices_step_finish(ctxs, n_ctx, workers_per_ctx, lr, totals, stats);
+}
+
+int dsgd_sync_step_ranges_devices(dsgd_ctx* const* ctxs, int32_t n_ctx, const int64_t* row_begin, const int64_t* row_end,
+                                  int32_t workers_per_ctx, float lr, dsgd_batch_stats* stats) {
+  MultiLock ml;
+  DSGD_TRY(ml.lock(ctxs, n_ctx));
+  if (workers_per_ctx < 1 || !row_begin || !row_end) return fail(DSGD_EINVAL, "need at least one worker per context");
+  DSGD_TRY(devices_step_checks(ctxs, n_ctx));
+  std::vector<long long> totals((size_t)n_ctx, 0);
+  for (int i = 0; i < n_ctx; ++i) {
+    dsgd_ctx* c = ctxs[i];
+    DSGD_TRY(bind(c));
+    DSGD_TRY(reset_counters(c));
+    DSGD_TRY(ranges_enqueue(c, row_begin + (size_t)i * workers_per_ctx, row_end + (size_t)i * workers_per_ctx, workers_per_ctx, lr,
+                            &totals[(size_t)i], false));
+    DSGD_TRY(finish_pre(c, workers_per_ctx, lr, false));
+  }
+  return devices_step_finish(ctxs, n_ctx, workers_per_ctx, lr, totals, stats);
+}
+
+int dsgd_loss_acc_devices(dsgd_ctx* const* ctxs, int32_t n_ctx, const int64_t* row_begin, const int64_t* row_end, double* loss,
+                          double* acc, int64_t* counts) {
+  MultiLock ml;
+  DSGD_TRY(ml.lock(ctxs, n_ctx));
+  if (!row_begin || !row_end) return fail(DSGD_EINVAL, "null row ranges");
+  DSGD_TRY(group_shape(ctxs, n_ctx));
+  for (int i = 0; i < n_ctx; ++i) {
+    DSGD_TRY(bind(ctxs[i]));
+    if (!ctxs[i]->layout_ready) return fail(DSGD_ESTATE, "context %d has no column layout yet (dsgd_build_dim_sparsity_devices)", i);
+    DSGD_TRY(eval_enqueue(ctxs[i], nullptr, row_begin[i], row_end[i]));
+  }
+  DSGD_TRY(grouped(ctxs, n_ctx, [](dsgd_ctx* c, int) { return eval_collective(c); }));
+  for (int i = n_ctx - 1; i >= 0; --i) {   // (every replica holds the summed tallies and the same weights: context 0 answers)
+    DSGD_TRY(bind(ctxs[i]));
+    DSGD_TRY(eval_read(ctxs[i], i == 0 ? loss : nullptr, i == 0 ? acc : nullptr, i == 0 ? counts : nullptr));
+  }
   return DSGD_OK;
 }
 

@@ -285,5 +285,55 @@ class Engine:
         return self._lib.dsgd_grad_kernel_name(self._ctx).decode()
 
 
+class EngineGroup:
+    """Several contexts (one per device, each with its own rows) driven by ONE host thread: the dsgd_*_devices entry
+    points of include/dsgd.h (the reference's dev role runs the master and every slave in one JVM, Main.scala:144-158).
+    Arrays over workers are context-major."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        self._lib = _lib.load()
+        self._ctxs = (C.c_void_p * len(self.engines))(*[e._ctx for e in self.engines])
+        self.n = len(self.engines)
+
+    def comm_init_all(self):
+        check(self._lib.dsgd_comm_init_all(self._ctxs, C.c_int32(self.n)))
+
+    def build_dim_sparsity(self, n_train_per_engine):
+        nt = (C.c_int64 * self.n)(*[int(v) for v in n_train_per_engine])
+        check(self._lib.dsgd_build_dim_sparsity_devices(self._ctxs, C.c_int32(self.n), nt))
+
+    def sync_step(self, lists_per_engine, lr):
+        """lists_per_engine: per engine, the index lists of its hosted workers (the same number for every engine)."""
+        k = len(lists_per_engine[0])
+        flat = [i32(a) for ls in lists_per_engine for a in ls]
+        if len(lists_per_engine) != self.n or any(len(ls) != k for ls in lists_per_engine):
+            raise ValueError("every engine needs the same number of workers")
+        ptrs = (C.c_void_p * len(flat))(*[ptr(a) for a in flat])
+        ns = (C.c_int64 * len(flat))(*[len(a) for a in flat])
+        st = BatchStats()
+        check(self._lib.dsgd_sync_step_devices(self._ctxs, C.c_int32(self.n), ptrs, ns, C.c_int32(k), C.c_float(lr), C.byref(st)))
+        return {"n_samples": st.n_samples, "n_active": st.n_active}
+
+    def sync_step_ranges(self, ranges_per_engine, lr):
+        k = len(ranges_per_engine[0])
+        if len(ranges_per_engine) != self.n or any(len(r) != k for r in ranges_per_engine):
+            raise ValueError("every engine needs the same number of workers")
+        flat = [r for rs in ranges_per_engine for r in rs]
+        rb = (C.c_int64 * len(flat))(*[int(r[0]) for r in flat])
+        re_ = (C.c_int64 * len(flat))(*[int(r[1]) for r in flat])
+        st = BatchStats()
+        check(self._lib.dsgd_sync_step_ranges_devices(self._ctxs, C.c_int32(self.n), rb, re_, C.c_int32(k), C.c_float(lr), C.byref(st)))
+        return {"n_samples": st.n_samples, "n_active": st.n_active}
+
+    def loss_acc(self, range_per_engine):
+        rb = (C.c_int64 * self.n)(*[int(r[0]) for r in range_per_engine])
+        re_ = (C.c_int64 * self.n)(*[int(r[1]) for r in range_per_engine])
+        loss, acc = C.c_double(0), C.c_double(0)
+        counts = (C.c_int64 * 3)()
+        check(self._lib.dsgd_loss_acc_devices(self._ctxs, C.c_int32(self.n), rb, re_, C.byref(loss), C.byref(acc), counts))
+        return loss.value, acc.value, list(counts)
+
+
 def device_count():
     return _lib.load().dsgd_device_count()

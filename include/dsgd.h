@@ -220,6 +220,25 @@ int dsgd_comm_unique_id(char* id_out /* DSGD_UNIQUE_ID_BYTES */);
 int dsgd_comm_init(dsgd_ctx* ctx, const char* unique_id, int32_t world_size, int32_t rank);
 int dsgd_comm_destroy(dsgd_ctx* ctx);
 
+/* ---- several GPUs driven by ONE host thread --------------------------------------------------------------------
+ * The reference's dev role runs the master and every slave in ONE JVM (Main.scala:144-158); SURVEY.md 8(b) lists the
+ * fused step as dsgd_sync_step(ctx, idx_per_dev, n_per_dev, lr).  A collective blocks its caller until every rank has
+ * joined, so one thread cannot call the per-context entry points one after the other; these take all the contexts of
+ * the node at once (one context per device, every one with its own rows): each context's kernels in front of a
+ * collective are enqueued first, then all the collectives inside one ncclGroupStart / ncclGroupEnd, then what follows
+ * -- the kernels, sums and summation order of N processes with one GPU each (replicas bit-identical).
+ * Arrays over workers are context-major: worker k of context i at [i * workers_per_ctx + k].                       */
+int dsgd_comm_init_all(dsgd_ctx* const* ctxs, int32_t n_ctx);   /* rank i = ctxs[i]; replaces dsgd_comm_unique_id + dsgd_comm_init */
+/* column ranking + dimSparsity with both counts summed over the contexts (Main.scala:54-65 over the whole train set)  */
+int dsgd_build_dim_sparsity_devices(dsgd_ctx* const* ctxs, int32_t n_ctx, const int64_t* n_train_per_ctx);
+int dsgd_sync_step_devices(dsgd_ctx* const* ctxs, int32_t n_ctx, const int32_t* const* idx_per_worker,
+                           const int64_t* n_per_worker, int32_t workers_per_ctx, float lr, dsgd_batch_stats* stats /* summed; may be NULL */);
+int dsgd_sync_step_ranges_devices(dsgd_ctx* const* ctxs, int32_t n_ctx, const int64_t* row_begin, const int64_t* row_end,
+                                  int32_t workers_per_ctx, float lr, dsgd_batch_stats* stats /* summed; may be NULL */);
+/* Master.localLoss / localAccuracy over rows [row_begin[i], row_end[i]) of every context, tallies summed               */
+int dsgd_loss_acc_devices(dsgd_ctx* const* ctxs, int32_t n_ctx, const int64_t* row_begin, const int64_t* row_end, double* loss,
+                          double* acc, int64_t* counts /* 3 or NULL */);
+
 /* ---- introspection for benchmarks ---------------------------------------------------------
  * average device time (ms) of the dominant gradient kernel over its launches since the last
  * reset, measured with HIP events on the launch stream; n_launches may be NULL.               */

@@ -274,4 +274,109 @@ JNIEXPORT void JNICALL NATIVE(getWeights)(JNIEnv* env, jobject, jlong h, jfloatA
   if (rc) raise(env, rc);
 }
 
+// ---- several GPUs driven by ONE JVM thread (the dev role: master + every slave in one JVM, Main.scala:144-158) ----------
+// ctxs: one context per device (create / loadCsr each), rank i = ctxs[i]; arrays over workers are context-major.
+namespace {
+std::vector<dsgd_ctx*> ctx_list(JNIEnv* env, jlongArray ctxs) {
+  const jsize n = env->GetArrayLength(ctxs);
+  std::vector<jlong> h(static_cast<size_t>(n > 0 ? n : 0));
+  if (n > 0) env->GetLongArrayRegion(ctxs, 0, n, h.data());
+  std::vector<dsgd_ctx*> out;
+  for (jlong v : h) out.push_back(ctx(v));
+  return out;
+}
+}  // namespace
+
+JNIEXPORT void JNICALL NATIVE(commInitAll)(JNIEnv* env, jobject, jlongArray ctxs) {
+  std::vector<dsgd_ctx*> c = ctx_list(env, ctxs);
+  int rc = dsgd_comm_init_all(c.data(), static_cast<int32_t>(c.size()));
+  if (rc) raise(env, rc);
+}
+
+// Main.scala:54-65 over the WHOLE train set: column ranking and feature counts summed over the contexts
+JNIEXPORT void JNICALL NATIVE(buildDimSparsityDevices)(JNIEnv* env, jobject, jlongArray ctxs, jlongArray nTrain) {
+  std::vector<dsgd_ctx*> c = ctx_list(env, ctxs);
+  if (env->GetArrayLength(nTrain) != static_cast<jsize>(c.size())) {
+    env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "one nTrain per context");
+    return;
+  }
+  int rc;
+  {
+    LongElems nt(env, nTrain, JNI_ABORT);
+    rc = dsgd_build_dim_sparsity_devices(c.data(), static_cast<int32_t>(c.size()), reinterpret_cast<const int64_t*>(nt.p));
+  }
+  if (rc) raise(env, rc);
+}
+
+// Master.fit batch closure (core/Master.scala:184-197) over every device of the node: idxPerWorker holds
+// contexts x workersPerCtx lists; the mean runs over all of them (one all-reduce inside)
+JNIEXPORT jlong JNICALL NATIVE(syncStepDevices)(JNIEnv* env, jobject, jlongArray ctxs, jobjectArray idxPerWorker,
+                                               jint workersPerCtx, jfloat lr) {
+  std::vector<dsgd_ctx*> c = ctx_list(env, ctxs);
+  const jsize k = env->GetArrayLength(idxPerWorker);
+  if (workersPerCtx < 1 || k != static_cast<jsize>(c.size()) * workersPerCtx) {
+    env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "idxPerWorker must hold contexts x workersPerCtx lists");
+    return 0;
+  }
+  std::vector<std::vector<int32_t>> lists(static_cast<size_t>(k));
+  std::vector<const int32_t*> ptrs(static_cast<size_t>(k));
+  std::vector<int64_t> ns(static_cast<size_t>(k));
+  for (jsize i = 0; i < k; ++i) {
+    jintArray a = static_cast<jintArray>(env->GetObjectArrayElement(idxPerWorker, i));
+    const jsize n = a ? env->GetArrayLength(a) : 0;
+    lists[i].resize(n > 0 ? n : 1);
+    if (n > 0) env->GetIntArrayRegion(a, 0, n, reinterpret_cast<jint*>(lists[i].data()));
+    ptrs[i] = lists[i].data();
+    ns[i] = n;
+    if (a) env->DeleteLocalRef(a);
+  }
+  dsgd_batch_stats st{};
+  int rc = dsgd_sync_step_devices(c.data(), static_cast<int32_t>(c.size()), ptrs.data(), ns.data(), workersPerCtx, lr, &st);
+  if (rc) raise(env, rc);
+  return st.n_active;
+}
+
+JNIEXPORT jlong JNICALL NATIVE(syncStepRangesDevices)(JNIEnv* env, jobject, jlongArray ctxs, jlongArray rowBegin, jlongArray rowEnd,
+                                                     jint workersPerCtx, jfloat lr) {
+  std::vector<dsgd_ctx*> c = ctx_list(env, ctxs);
+  const jsize k = env->GetArrayLength(rowBegin);
+  if (workersPerCtx < 1 || env->GetArrayLength(rowEnd) != k || k != static_cast<jsize>(c.size()) * workersPerCtx) {
+    env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "rowBegin / rowEnd must hold contexts x workersPerCtx ranges");
+    return 0;
+  }
+  dsgd_batch_stats st{};
+  int rc;
+  {
+    LongElems rb(env, rowBegin, JNI_ABORT);
+    LongElems re(env, rowEnd, JNI_ABORT);
+    rc = dsgd_sync_step_ranges_devices(c.data(), static_cast<int32_t>(c.size()), reinterpret_cast<const int64_t*>(rb.p),
+                                       reinterpret_cast<const int64_t*>(re.p), workersPerCtx, lr, &st);
+  }
+  if (rc) raise(env, rc);
+  return st.n_active;
+}
+
+// Master.localLoss / localAccuracy with the tallies summed over the contexts; out = {loss, accuracy}
+JNIEXPORT void JNICALL NATIVE(lossAccDevices)(JNIEnv* env, jobject, jlongArray ctxs, jlongArray rowBegin, jlongArray rowEnd,
+                                             jdoubleArray out) {
+  std::vector<dsgd_ctx*> c = ctx_list(env, ctxs);
+  if (env->GetArrayLength(rowBegin) != static_cast<jsize>(c.size()) || env->GetArrayLength(rowEnd) != static_cast<jsize>(c.size())) {
+    env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "one row range per context");
+    return;
+  }
+  double la[2] = {0, 0};
+  int rc;
+  {
+    LongElems rb(env, rowBegin, JNI_ABORT);
+    LongElems re(env, rowEnd, JNI_ABORT);
+    rc = dsgd_loss_acc_devices(c.data(), static_cast<int32_t>(c.size()), reinterpret_cast<const int64_t*>(rb.p),
+                               reinterpret_cast<const int64_t*>(re.p), &la[0], &la[1], nullptr);
+  }
+  if (rc) {
+    raise(env, rc);
+    return;
+  }
+  env->SetDoubleArrayRegion(out, 0, 2, la);
+}
+
 }  // extern "C"

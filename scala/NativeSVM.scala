@@ -37,6 +37,13 @@ object NativeSVM {
   @native def asyncWait(ctx: Long): Unit
   @native def setWeights(ctx: Long, w: Array[Float]): Unit
   @native def getWeights(ctx: Long, wOut: Array[Float]): Unit
+  // several GPUs driven by ONE thread of this JVM (dev role: master + every slave in one JVM, Main.scala:144-158): one
+  // context per device, rank i = ctxs(i); arrays over workers are context-major (include/dsgd.h, dsgd_*_devices)
+  @native def commInitAll(ctxs: Array[Long]): Unit
+  @native def buildDimSparsityDevices(ctxs: Array[Long], nTrain: Array[Long]): Unit
+  @native def syncStepDevices(ctxs: Array[Long], idxPerWorker: Array[Array[Int]], workersPerCtx: Int, lr: Float): Long
+  @native def syncStepRangesDevices(ctxs: Array[Long], rowBegin: Array[Long], rowEnd: Array[Long], workersPerCtx: Int, lr: Float): Long
+  @native def lossAccDevices(ctxs: Array[Long], rowBegin: Array[Long], rowEnd: Array[Long], out: Array[Double]): Unit
 }
 
 /** Dense float[D+1] indexed by KEY is the exchange format: feature ids are 1-based map keys

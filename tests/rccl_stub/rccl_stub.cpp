@@ -6,6 +6,10 @@
 // ranking and dimSparsity counts, summed evaluation tallies, the asynchronous exchange) execute on real kernels.
 // Selected only by an explicit DSGD_RCCL_LIB=<path> in the environment; never built or loaded by the product.
 //
+// ncclGroupStart / ncclGroupEnd (ONE host thread driving several ranks: dsgd_*_devices): inside a group the calls are
+// recorded and return at once -- a blocking barrier would deadlock the one thread -- and ncclGroupEnd runs them phase by
+// phase: every recorded rank stages its buffer and ARRIVES at the barrier (without waiting), then all wait, then all sum.
+//
 // ncclAllReduce here is synchronous and host-staged: wait for the stream, copy the send buffer into this rank's slot
 // of the segment, barrier, add the slots in RANK ORDER (every rank computes the identical sum, as a real ring /
 // tree all-reduce delivers identical results to all ranks), copy back, barrier.  A stream-ordered collective that has
@@ -77,13 +81,14 @@ bool resolve_hip() {
   return hip_memcpy && hip_stream_sync;
 }
 
-bool barrier(Comm* c) {
+void arrive(Comm* c) {   // the last arrival of a round opens it for everybody
   c->local_sense = !c->local_sense;
   if (c->hdr->count.fetch_add(1) + 1 == c->n) {
     c->hdr->count.store(0);
     c->hdr->sense.store(c->local_sense);
-    return true;
   }
+}
+bool wait_round(Comm* c) {
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spin = 0; c->hdr->sense.load() != c->local_sense; ++spin) {
     if ((spin & 1023) == 1023) {
@@ -93,6 +98,23 @@ bool barrier(Comm* c) {
   }
   return true;
 }
+bool barrier(Comm* c) {
+  arrive(c);
+  return wait_round(c);
+}
+
+// calls recorded inside ncclGroupStart / ncclGroupEnd (per thread, as in NCCL)
+struct Op {
+  int kind;   // 0: communicator waiting for its peers, 1: all-reduce
+  Comm* c;
+  const void* send;
+  void* recv;
+  size_t count;
+  int dtype;
+  void* stream;
+};
+thread_local int g_depth = 0;
+thread_local std::vector<Op> g_ops;
 
 std::atomic<int> g_ids{0};
 thread_local char g_msg[160] = "no error";
@@ -111,6 +133,15 @@ struct StubUniqueId {
 int ncclGetUniqueId(StubUniqueId* id) {
   memset(id->internal, 0, sizeof(id->internal));
   snprintf(id->internal, sizeof(id->internal), "/dsgd_rccl_stub_%d_%d", (int)getpid(), g_ids.fetch_add(1));
+  return 0;
+}
+
+static int wait_ready(Comm* c) {
+  const auto t0 = std::chrono::steady_clock::now();
+  while (c->hdr->ready.load() < c->n) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kTimeoutS) return err("timed out waiting for the peers");
+  }
   return 0;
 }
 
@@ -154,13 +185,12 @@ int ncclCommInitRank(void** out, int n_ranks, StubUniqueId id, int rank) {
   c->slots = static_cast<char*>(p) + ((sizeof(Header) + 63) / 64) * 64;
   if (rank == 0) c->hdr->n_ranks = n_ranks;
   c->hdr->ready.fetch_add(1);
-  const auto t0 = std::chrono::steady_clock::now();
-  while (c->hdr->ready.load() < n_ranks) {
-    std::this_thread::sleep_for(std::chrono::milliseconds(1));
-    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kTimeoutS) return err("timed out waiting for the peers");
-  }
   *out = c;
-  return 0;
+  if (g_depth > 0) {   // the peers may be further ranks of THIS thread: wait at ncclGroupEnd
+    g_ops.push_back(Op{0, c, nullptr, nullptr, 0, 0, nullptr});
+    return 0;
+  }
+  return wait_ready(c);
 }
 
 int ncclCommDestroy(void* comm) {
@@ -173,25 +203,25 @@ int ncclCommDestroy(void* comm) {
 }
 
 // datatype / op codes of rccl.h: ncclUint32 = 3, ncclInt64 = 4, ncclFloat32 = 7, ncclFloat64 = 8; ncclSum = 0
-int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op, void* comm, void* stream) {
-  Comm* c = static_cast<Comm*>(comm);
-  if (!c) return err("null communicator");
-  if (op != 0) return err("only ncclSum");
-  const size_t es = dtype == 3 ? 4 : dtype == 4 ? 8 : dtype == 7 ? 4 : dtype == 8 ? 8 : 0;
-  if (!es) return err("unsupported datatype");
-  const size_t bytes = es * count;
-  if (bytes > kSlotBytes) return err("message larger than the stub's slot");
-  std::lock_guard<std::mutex> lk(c->mu);
-  if (hip_stream_sync(stream) != 0) return err("hipStreamSynchronize");
-  char* mine = c->slots + (size_t)c->rank * kSlotBytes;
-  if (hip_memcpy(mine, send, bytes, 2 /* hipMemcpyDeviceToHost */) != 0) return err("hipMemcpy D2H");
-  if (!barrier(c)) return err("barrier timeout (before the sum)");
+static size_t elem_size(int dtype) { return dtype == 3 ? 4 : dtype == 4 ? 8 : dtype == 7 ? 4 : dtype == 8 ? 8 : 0; }
+// first half: this rank's buffer into its slot (after everything enqueued on the stream in front of the collective)
+static int ar_stage(const Op& o) {
+  const size_t bytes = elem_size(o.dtype) * o.count;
+  if (hip_stream_sync(o.stream) != 0) return err("hipStreamSynchronize");
+  char* mine = o.c->slots + (size_t)o.c->rank * kSlotBytes;
+  if (hip_memcpy(mine, o.send, bytes, 2 /* hipMemcpyDeviceToHost */) != 0) return err("hipMemcpy D2H");
+  return 0;
+}
+// second half: the slots added in RANK ORDER (identical on every rank), the sum back on the device
+static int ar_combine(const Op& o) {
+  const size_t bytes = elem_size(o.dtype) * o.count;
+  Comm* c = o.c;
   std::vector<char> acc(bytes);
   memcpy(acc.data(), c->slots, bytes);
-  for (int r = 1; r < c->n; ++r) {   // rank order: identical on every rank
+  for (int r = 1; r < c->n; ++r) {
     const char* s = c->slots + (size_t)r * kSlotBytes;
-    for (size_t i = 0; i < count; ++i) {
-      switch (dtype) {
+    for (size_t i = 0; i < o.count; ++i) {
+      switch (o.dtype) {
         case 3: reinterpret_cast<uint32_t*>(acc.data())[i] += reinterpret_cast<const uint32_t*>(s)[i]; break;
         case 4: reinterpret_cast<int64_t*>(acc.data())[i] += reinterpret_cast<const int64_t*>(s)[i]; break;
         case 7: reinterpret_cast<float*>(acc.data())[i] += reinterpret_cast<const float*>(s)[i]; break;
@@ -199,9 +229,67 @@ int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op,
       }
     }
   }
-  if (hip_memcpy(recv, acc.data(), bytes, 1 /* hipMemcpyHostToDevice */) != 0) return err("hipMemcpy H2D");
+  if (hip_memcpy(o.recv, acc.data(), bytes, 1 /* hipMemcpyHostToDevice */) != 0) return err("hipMemcpy H2D");
+  return 0;
+}
+
+// datatype / op codes of rccl.h: ncclUint32 = 3, ncclInt64 = 4, ncclFloat32 = 7, ncclFloat64 = 8; ncclSum = 0
+int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op, void* comm, void* stream) {
+  Comm* c = static_cast<Comm*>(comm);
+  if (!c) return err("null communicator");
+  if (op != 0) return err("only ncclSum");
+  const size_t es = elem_size(dtype);
+  if (!es) return err("unsupported datatype");
+  if (es * count > kSlotBytes) return err("message larger than the stub's slot");
+  const Op o{1, c, send, recv, count, dtype, stream};
+  if (g_depth > 0) {   // recorded: a blocking barrier here would deadlock a thread that drives several ranks
+    for (const Op& q : g_ops)
+      if (q.kind == 1 && q.c == c) return err("two all-reduces on one communicator inside one group (one slot per rank)");
+    g_ops.push_back(o);
+    return 0;
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (int r = ar_stage(o)) return r;
+  if (!barrier(c)) return err("barrier timeout (before the sum)");
+  if (int r = ar_combine(o)) return r;
   if (!barrier(c)) return err("barrier timeout (after the sum)");   // nobody refills its slot before everybody has read
   return 0;
+}
+
+int ncclGroupStart() {
+  ++g_depth;
+  return 0;
+}
+
+int ncclGroupEnd() {
+  if (g_depth <= 0) return err("ncclGroupEnd without ncclGroupStart");
+  if (--g_depth > 0) return 0;
+  std::vector<Op> ops;
+  ops.swap(g_ops);
+  int rc = 0;
+  for (const Op& o : ops)
+    if (o.kind == 0 && !rc) rc = wait_ready(o.c);
+  std::vector<Op> ars;
+  for (const Op& o : ops)
+    if (o.kind == 1) ars.push_back(o);
+  if (rc || ars.empty()) return rc;
+  // phase by phase over all recorded ranks: stage + arrive (nobody waits yet) ... wait ... combine + arrive ... wait
+  for (const Op& o : ars) {
+    o.c->mu.lock();
+    if (!rc) rc = ar_stage(o);
+    arrive(o.c);
+  }
+  for (const Op& o : ars)
+    if (!wait_round(o.c) && !rc) rc = err("barrier timeout (before the sum)");
+  for (const Op& o : ars) {
+    if (!rc) rc = ar_combine(o);
+    arrive(o.c);
+  }
+  for (const Op& o : ars) {
+    if (!wait_round(o.c) && !rc) rc = err("barrier timeout (after the sum)");
+    o.c->mu.unlock();
+  }
+  return rc;
 }
 
 const char* ncclGetErrorString(int code) { return code == 0 ? "no error" : g_msg; }

@@ -204,6 +204,29 @@ def test_dense_two_ranks_equal_one_process_over_the_union(ranks):
         assert np.abs(dl.get_weights() - ranks[0]["w_dense"]).max() <= 2e-6 * scale
 
 
+def test_one_thread_driving_both_contexts_equals_the_two_processes(ranks, tmp_path):
+    """dsgd_comm_init_all / dsgd_build_dim_sparsity_devices / dsgd_sync_step_devices / dsgd_sync_step_ranges_devices /
+    dsgd_loss_acc_devices: ONE process and ONE thread drive two contexts (the reference's dev role, Main.scala:144-158);
+    every collective goes through ncclGroupStart / ncclGroupEnd.  Same kernels, same sums, same order: the column
+    ranking, every step's weights on both replicas, the summed statistics and the evaluation are those of the two rank
+    processes BIT FOR BIT -- which the tests above hold to the oracle with K = workers x world."""
+    proc = subprocess.run([sys.executable, os.path.join(HERE, "devices_worker.py"), str(tmp_path)], env=seam_env(),
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-4000:]
+    d = dict(np.load(os.path.join(str(tmp_path), "devices.npz")))
+    np.testing.assert_array_equal(d["ranks"][0], ranks[0]["ranks"])
+    np.testing.assert_array_equal(d["ranks"][1], ranks[0]["ranks"])
+    n_steps = ranks[0]["w_hist"].shape[0]
+    assert d["w_hist"].shape[:2] == (n_steps, 2)
+    for i in range(n_steps):
+        np.testing.assert_array_equal(d["w_hist"][i][0], d["w_hist"][i][1])            # the replicas agree ...
+        np.testing.assert_array_equal(d["w_hist"][i][0], ranks[0]["w_hist"][i])        # ... with the two processes
+        assert list(d["stats"][i]) == [int(ranks[0]["stats"][i][0] + ranks[1]["stats"][i][0]),
+                                       int(ranks[0]["stats"][i][1] + ranks[1]["stats"][i][1])]
+    np.testing.assert_array_equal(d["eval"], ranks[0]["eval"])
+    assert d["dup_refused"][0] == 1
+
+
 @pytest.mark.parametrize("mode", ["strong", "weak"])
 def test_bench_parity_gate_with_two_ranks(mode):
     """bench.py --gpus 2: the N > 1 parity gate EXECUTED (two ranks on the one device through the seam build + shim):

@@ -111,3 +111,52 @@ def test_two_processes_allreduce_through_the_shim():
         np.testing.assert_array_equal(r0, a0 + a1)     # ... added in rank order
     np.testing.assert_array_equal(res[0][1], np.arange(1000, dtype=np.uint32) * 3)
     np.testing.assert_array_equal(res[1][2], np.asarray([2, 4, 6, 3 * 10 ** 12], dtype=np.int64))
+
+
+def _one_thread_two_ranks(q):
+    """ONE thread drives both ranks (dsgd_*_devices): inside ncclGroupStart / ncclGroupEnd nothing may block."""
+    os.environ["DSGD_RCCL_STUB_HOSTMEM"] = "1"
+    lib = C.CDLL(LIB)
+    uid = Uid()
+    assert lib.ncclGetUniqueId(C.byref(uid)) == 0
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+    lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    comms = [C.c_void_p(), C.c_void_p()]
+    assert lib.ncclGroupStart() == 0
+    for r in range(2):
+        assert lib.ncclCommInitRank(C.byref(comms[r]), 2, uid, r) == 0      # returns at once: its peer is this thread's next call
+    assert lib.ncclGroupEnd() == 0
+    rng = np.random.default_rng(0)
+    ok = True
+    for it in range(5):
+        a = [rng.normal(size=47237).astype(np.float32) for _ in range(2)]
+        out = [np.empty_like(a[0]) for _ in range(2)]
+        assert lib.ncclGroupStart() == 0
+        for r in range(2):
+            assert lib.ncclAllReduce(a[r].ctypes.data, out[r].ctypes.data, a[r].size, 7, 0, comms[r], None) == 0
+        assert lib.ncclGroupEnd() == 0
+        ok = ok and np.array_equal(out[0], out[1]) and np.array_equal(out[0], a[0] + a[1])
+    # two all-reduces on ONE communicator inside one group: refused (one slot per rank), and the group still ends
+    assert lib.ncclGroupStart() == 0
+    x = np.ones(4, dtype=np.float32)
+    assert lib.ncclAllReduce(x.ctypes.data, x.ctypes.data, 4, 7, 0, comms[0], None) == 0
+    assert lib.ncclAllReduce(x.ctypes.data, x.ctypes.data, 4, 7, 0, comms[0], None) != 0
+    # (rank 1 joins so that the recorded one can complete)
+    y = np.ones(4, dtype=np.float32)
+    assert lib.ncclAllReduce(y.ctypes.data, y.ctypes.data, 4, 7, 0, comms[1], None) == 0
+    assert lib.ncclGroupEnd() == 0 and x[0] == 2.0 and y[0] == 2.0
+    assert lib.ncclGroupEnd() != 0    # unbalanced
+    for cm in comms:
+        assert lib.ncclCommDestroy(cm) == 0
+    q.put(ok)
+
+
+def test_one_thread_drives_two_ranks_inside_a_group():
+    build_stub()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_thread_two_ranks, args=(q,))
+    p.start()
+    assert q.get(timeout=120) is True
+    p.join(60)
+    assert p.exitcode == 0
