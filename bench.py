@@ -729,7 +729,7 @@ def hogwild_parity(dsgd_amd, device, workers=256, batch=100, rows=100000, checkp
                 if si == 0:
                     t1 = time.perf_counter()
                     trace = eng.async_read_trace()
-                    stats.append(hr.replay_forced(o, w_rep, split, batch, LR0, sseed, trace, fractions=(0.0, 1.0)))
+                    stats.append(hr.replay_forced(o, w_rep, split, batch, LR0, sseed, trace, fractions=(0.0, 0.5, 1.0)))
                     v = hr.verdict(o, eng.get_weights(), w_rep, hr.merge(stats))
                     v.update(loss_engine=loss, acc_engine=acc)
                     verdicts.append(v)
@@ -821,21 +821,24 @@ def epoch_lists(rng, n_train, k, b):
     return steps
 
 
-def time_to_target(dsgd_amd, device, n_rows=804414, oracle_budget_s=5.0, max_epochs_engine=60):
+def time_to_target(dsgd_amd, device, n_rows=804414, oracle_budget_s=5.0, max_epochs_engine=30):
     """Wall-clock time to the oracle's target test loss per batch size, on the reference's full=true shape.  Target = the
-    minimum over 10 epochs (max-epochs, application.conf:37) of the ORACLE's test loss at the reference's configuration
-    (3 workers x batch 100, lr 0.5).  Per configuration the engine runs whole epochs from resident plans until its test
-    loss is at or below the target (+ one test row of slack); an epoch's clock holds its steps AND the evaluation
-    passes the reference makes per epoch (core/Master.scala:206-209: loss and accuracy on the train and the test set --
-    one pass over each set yields both).  Building an epoch's plan (the host's shuffle and layout) is outside the
-    clock and reported.  The oracle runs the same lists (at most 10 epochs, at most `oracle_budget_s` per configuration)."""
+    MEDIAN over 10 epochs (max-epochs, application.conf:37) of the ORACLE's test loss at the reference's configuration
+    (3 workers x batch 100, lr 0.5) -- the curve of a constant-step run is noisy (0.18 after its first epoch, 0.35 after
+    its second, 0.20-0.25 afterwards on this data), so neither its minimum nor its last value is a level another
+    trajectory can be asked to reach.  Per configuration the engine runs whole epochs from resident plans until its test
+    loss is at or below the target; an epoch's clock holds its steps AND the evaluation passes the reference makes per
+    epoch (core/Master.scala:206-209: loss and accuracy on the train and the test set -- one pass over each set yields
+    both).  Building an epoch's plan (the host's shuffle and layout) is outside the clock and reported.  The oracle runs
+    the same lists (at most 10 epochs, at most `oracle_budget_s` per configuration); after the first epoch the two weight
+    vectors are compared (`epoch1_max_abs_diff`: thousands of steps without a re-synchronisation -- one row gated
+    differently, and fp32 against fp64 will do that once in a few thousand steps, sends a constant-step run elsewhere)."""
     from oracle import oracle as orc  # checker / target only
 
     data = dsgd_amd.synth.generate(n_rows, seed=0)
     n_train = int(n_rows * 0.8)
     o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, LAMBDA)
     o.set_dim_sparsity(o.dim_sparsity(n_train))
-    slack = 1.0 / (n_rows - n_train)
     t0 = time.perf_counter()
     w = np.zeros(data.dim + 1)
     ref_curve = []
@@ -843,9 +846,10 @@ def time_to_target(dsgd_amd, device, n_rows=804414, oracle_budget_s=5.0, max_epo
         for step in epoch_lists(np.random.default_rng(1000 + ep), n_train, 3, 100):
             o.sync_step(w, step, LR0)
         ref_curve.append(o.loss_acc(w, n_train, n_rows)[0])
-    target = min(ref_curve)
-    out = {"rows": n_rows, "train_rows": n_train, "target_test_loss": target, "target": "min over 10 oracle epochs at 3 x 100, lr 0.5",
-           "oracle_target_curve": ref_curve, "oracle_target_s": round(time.perf_counter() - t0, 1), "slack": slack, "configs": []}
+    target = float(np.median(ref_curve))
+    out = {"rows": n_rows, "train_rows": n_train, "target_test_loss": target,
+           "target": "median over 10 oracle epochs at 3 x 100, lr 0.5", "oracle_target_curve": ref_curve,
+           "oracle_target_s": round(time.perf_counter() - t0, 1), "configs": []}
     with dsgd_amd.Engine(data.dim, LAMBDA, device=device) as eng:
         eng.load_csr(data.row_ptr, data.col, data.val, data.label)
         eng.build_dim_sparsity(n_train)
@@ -854,9 +858,30 @@ def time_to_target(dsgd_amd, device, n_rows=804414, oracle_budget_s=5.0, max_epo
             whole = b is None
             bb = n_train if whole else b
             lr = LR0 * 100.0 / bb
+            # the oracle on the same lists (first: its epoch-1 weights are what the engine's are compared with)
+            t2 = time.perf_counter()
+            w = np.zeros(data.dim + 1)
+            o_reached, o_epochs, w_o1, exposed1 = None, 0, None, 0
+            for ep in range(10):
+                if time.perf_counter() - t2 > oracle_budget_s and ep > 0:
+                    break
+                if whole:
+                    o.sync_step_range_omp(w, 0, n_train, lr)
+                else:
+                    for step in epoch_lists(np.random.default_rng(1000 + ep), n_train, k, bb):
+                        o.sync_step(w, step, lr)
+                        if ep == 0:
+                            exposed1 += o.last_stats["min_abs_margin"] < 1e-5
+                o_epochs = ep + 1
+                if ep == 0:
+                    w_o1 = w.copy()
+                if o.loss_acc(w, n_train, n_rows)[0] <= target:
+                    o_reached = ep + 1
+                    break
+            t_oracle = time.perf_counter() - t2
             eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
             eng.synchronize()
-            clock, build_s, curve, reached, kern = 0.0, 0.0, [], None, None
+            clock, build_s, curve, reached, kern, diff1 = 0.0, 0.0, [], None, None, None
             for ep in range(max_epochs_engine):
                 if whole:
                     t1 = time.perf_counter()
@@ -876,30 +901,17 @@ def time_to_target(dsgd_amd, device, n_rows=804414, oracle_budget_s=5.0, max_epo
                 kern = eng.grad_kernel_name()
                 if not whole:
                     plan.destroy()
+                if ep == 0:
+                    diff1 = float(np.abs(eng.get_weights().astype(np.float64) - w_o1).max())
                 curve.append(loss)
-                if loss <= target + slack:
+                if loss <= target:
                     reached = ep + 1
-                    break
-            # the oracle on the same lists
-            t2 = time.perf_counter()
-            w = np.zeros(data.dim + 1)
-            o_reached, o_epochs = None, 0
-            for ep in range(10):
-                if time.perf_counter() - t2 > oracle_budget_s:
-                    break
-                if whole:
-                    o.sync_step_range_omp(w, 0, n_train, lr)
-                else:
-                    for step in epoch_lists(np.random.default_rng(1000 + ep), n_train, k, bb):
-                        o.sync_step(w, step, lr)
-                o_epochs = ep + 1
-                if o.loss_acc(w, n_train, n_rows)[0] <= target + slack:
-                    o_reached = ep + 1
                     break
             out["configs"].append({"workers": k, "batch": bb, "lr": lr, "engine_epochs": reached, "time_to_target_s": clock if reached else None,
                                    "engine_epochs_run": len(curve), "engine_clock_s": clock, "plan_build_s": round(build_s, 2),
-                                   "engine_test_loss_last": curve[-1], "kernel": kern, "oracle_epochs": o_reached,
-                                   "oracle_epochs_run": o_epochs, "oracle_s": round(time.perf_counter() - t2, 2),
+                                   "engine_test_loss": curve[:12], "kernel": kern, "oracle_epochs": o_reached,
+                                   "oracle_epochs_run": o_epochs, "oracle_s": round(t_oracle, 2),
+                                   "epoch1_max_abs_diff": diff1, "epoch1_steps_with_a_row_near_the_gate": int(exposed1),
                                    "evaluation": "2 passes per epoch inside the clock (train, test): loss and accuracy of each"})
     done = [c for c in out["configs"] if c["time_to_target_s"] is not None]
     out["fastest"] = min(done, key=lambda c: c["time_to_target_s"]) if done else None

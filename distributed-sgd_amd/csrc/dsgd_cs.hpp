@@ -16,16 +16,20 @@
 //     <= 16 with slice-local 16-bit column indices, one slot per lane, all of a step's slots in two 16-byte requests per
 //     array and lane.  The slots of step n + 1 are requested while the workgroup waits in step n's exchange;
 //   * per step ONE exchange between the workgroups: every slice publishes its partial x.w of the step's rows (300
-//     floats) and its share of w . ds, write-through (sc1) stores + one arrival on a device-scope counter; after the
-//     last arrival every slice reads all G partials (sc1 loads), adds them in slice order -- bitwise the same sum in
-//     every workgroup, so all take the same gate decisions (core/ml/SparseSVM.scala:27-28) -- scatters ITS entries of
-//     the active rows into ITS accumulators (ds_add_u32, exact integer sums), and finishes ITS columns: one rounding
-//     per worker's sum, the support-only regulariser (SparseSVM.scala:31), the fold over the workers, the mean, the
-//     update (Master.scala:194-197) -- the arithmetic of dsgd_fix_reduce_apply_kernel, column for column.
+//     floats) and its share of w . ds as 8-byte GRANULES {value, step tag} -- one write-through (sc1) store each, no
+//     flag, no drain: a granule is valid when its tag is the step's (MI355X_MICROARCH.md: data-tagged granules need no
+//     ordering; one hand-off ~1 us).  Every slice polls the G granules of each of its rows (sc1 loads), adds the
+//     partials in slice order -- bitwise the same sum in every workgroup, so all take the same gate decisions
+//     (core/ml/SparseSVM.scala:27-28) -- scatters ITS entries of the active rows into ITS accumulators (ds_add_u32,
+//     exact integer sums), and finishes ITS columns: one rounding per worker's sum, the support-only regulariser
+//     (SparseSVM.scala:31), the fold over the workers, the mean, the update (Master.scala:194-197) -- the arithmetic of
+//     dsgd_fix_reduce_apply_kernel, column for column.  The first form of this exchange (sc1 payload, drain, arrival on
+//     a device-scope counter, poll, sc1 loads of the payload: three dependent trips over the fabric) cost ~6.5 of a
+//     step's 11 us (3 x 100: 17.1 us, slower than the row-parallel kernels' 14.9).
 // The reference's synchronous semantics are untouched: every gradient of a step sees the weights of the step before.
-// Hand-off rules as MI355X_MICROARCH.md prescribes them: payload stored sc1, drained (s_waitcnt vmcnt(0)) before the
-// arrival; the consumer polls relaxed and reads the payload with sc1 loads; a bounded poll raises an abort word that
-// every workgroup honours (a launch can end with DevScalars::err = 8, never hang).
+// Two buffers alternate between steps: a slice can publish step t + 2 only after it has gathered step t + 1, which
+// needs every peer's step t + 1 granules, which a peer stores only after it has read everything of step t.  A bounded
+// poll raises an abort word that every workgroup honours (a launch can end with DevScalars::err = 8, never hang).
 #pragma once
 
 constexpr int CS_THREADS = 256;     // 4 waves: one per SIMD, 512 VGPRs each -- two register sets of 4 slots per lane
@@ -34,7 +38,8 @@ constexpr int CS_MAX_G = 16;        // slices = workgroups
 constexpr int CS_MAX_K = 8;         // hosted workers
 constexpr int CS_MAX_SPL = 4;       // slots (and rows) per lane
 constexpr int CS_MAX_SLOTS = CS_THREADS * CS_MAX_SPL;   // per (step, slice); also the most rows of a step
-constexpr int CS_XSTRIDE = CS_MAX_SLOTS + 64;           // floats per (parity, slice) of the exchange buffer: [row] partial x.w, [CS_MAX_SLOTS] share of w . ds
+constexpr int CS_XSTRIDE = CS_MAX_SLOTS + 64;           // granules per (parity, slice) of the exchange buffer: [row] partial x.w, [CS_MAX_SLOTS] share of w . ds
+constexpr unsigned int CS_POLL_LIMIT = 1u << 18;        // polls of one granule set before the launch is given up
 
 struct CsHdr {                // per (slice, step)
   unsigned int counts;        // slots of the step inside the slice (low 16 bits) | rows of the step << 16
@@ -49,9 +54,10 @@ struct CsArgs {
   const float* val;
   float* w;                         // ranked weights (read when the launch starts, written when it ends)
   const float* ds;
-  float* xbuf;                      // [2][G][CS_XSTRIDE]
-  unsigned int* sync;               // [0] arrivals of this launch, [1] abort
+  unsigned long long* xbuf;         // [2][G][CS_XSTRIDE] granules {value bits, step tag << 32}; zero when a launch starts
+  unsigned int* sync;               // [1] abort word (zero when a launch starts)
   DevScalars* sc;
+  unsigned long long* tprof;        // optional (tuning runs, DSGD_PLAN_PROF=1): cycles of thread 0 of slice 0 by phase, [15] = steps
   long long n_steps_plan, step_begin, step_end;
   int slot_stride, row_stride;
   float lr, lambda;
@@ -99,18 +105,42 @@ __device__ __forceinline__ void cs_issue(const CsArgs& a, int b, long long step,
   }
 }
 
-// thread 0: wait until `target` arrivals of this launch have been counted; false = aborted (by a peer or by the bound)
-__device__ __forceinline__ bool cs_wait(unsigned int* sync, unsigned int target) {
+// the G granules of exchange slot `at` (a row, or CS_MAX_SLOTS for the shares of w . ds), polled until all carry `tag`;
+// the values added in slice order.  false = given up (the abort word is raised for everybody).
+__device__ __forceinline__ bool cs_gather(const unsigned long long* xall, int G, int at, unsigned int tag, unsigned int* abort_word,
+                                          float& sum) {
+  unsigned long long v[CS_MAX_G];
   for (unsigned int spin = 0;; ++spin) {
-    if (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    bool all = true;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      v[g] = __hip_atomic_load(&xall[(long long)g * CS_XSTRIDE + at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      all = all && (unsigned int)(v[g] >> 32) == tag;
+    }
+    if (G > 8) {   // (workgroup-uniform: G is 8 or 16)
+#pragma unroll
+      for (int g = 8; g < CS_MAX_G; ++g) {
+        v[g] = __hip_atomic_load(&xall[(long long)g * CS_XSTRIDE + at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        all = all && (unsigned int)(v[g] >> 32) == tag;
+      }
+    } else {
+#pragma unroll
+      for (int g = 8; g < CS_MAX_G; ++g) v[g] = 0ull;
+    }
+    if (all) break;
     if ((spin & 63u) == 63u) {
-      if (spin > (1u << 20) || __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-        __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (spin > CS_POLL_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
       }
     }
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(1);
   }
+  float d = 0.0f;
+#pragma unroll
+  for (int g = 0; g < CS_MAX_G; ++g) d += __uint_as_float((unsigned int)v[g]);   // (the zeros of an 8-slice run change nothing)
+  sum = d;
+  return true;
 }
 
 // sum over the workgroup, the same bits on every thread (wave butterflies, then the four wave sums in order)
@@ -134,6 +164,7 @@ struct CsState {
   int b, Sb, Sp;
   float sp;       // this slice's share of w . ds of the current weights (the same bits on every thread)
   unsigned int n_act, n_rel;   // active rows counted (slice 0 only); steps of this launch behind us
+  unsigned long long tp[6], tl; // tuning runs: cycles by phase (dot, publish, exchange, scatter, sweep, reduce), last stamp
 };
 
 // One step.  `cur`: the step's slots (landed); `nxt` receives the next step's.  false = the launch was aborted.
@@ -148,6 +179,17 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL>&
   const int shift = __builtin_amdgcn_readfirstlane((int)cur.h.y);
   const float qscale = ldexpf(1.0f, shift - a.vexp);
   const double inv_scale = (double)ldexpf(1.0f, a.vexp - shift);
+  const bool prof = a.tprof != nullptr && b == 0 && tid == 0;
+  auto stamp = [&](int i) {
+    if (prof) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      z.tp[i] += now - z.tl;
+      z.tl = now;
+    }
+  };
+  // ---- 0: the NEXT step's slots are requested first (a whole step to land; vmcnt retires in order, so the polls of this
+  //         step's exchange return no earlier than these -- requested later they would be waited for at the next step's top) ----
+  cs_issue<SPL>(a, b, step + 1, nxt);
   // ---- 1: partial x.w of every slot from this slice's weights (ref: math/Vec.scala:58, math/Sparse.scala:46) ----
   int cc[SPL][CS_L];
   float vv[SPL][CS_L];
@@ -171,9 +213,13 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL>&
     const int slot = tid + CS_THREADS * i;
     if (slot < n_slots) ps[slot] = p;
   }
+  if (tid == 0) reinterpret_cast<int*>(red)[9] = 0;   // (this step's "given up" flag: raised in phase 3, read behind its barrier)
   __syncthreads();
-  // ---- 2: this slice's partial of every row (its slots in order), published write-through; then the arrival ----
-  float* xb = a.xbuf + ((long long)(z.n_rel & 1u) * G + b) * CS_XSTRIDE;
+  stamp(0);
+  // ---- 2: this slice's partial of every row (its slots in order), published as granules {value, tag}: write-through,
+  //         nothing waits for them ----
+  const unsigned int tag = z.n_rel + 1u;
+  unsigned long long* xb = a.xbuf + ((long long)(z.n_rel & 1u) * G + b) * CS_XSTRIDE;
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
     const int r = tid + CS_THREADS * i;
@@ -181,51 +227,38 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL>&
       const int f0 = (int)(cur.rf[i] & 0x7ffu), f1 = (int)((cur.rf[i] >> 16) & 0x7ffu);
       float t = 0.0f;
       for (int f = f0; f < f1; ++f) t += ps[f];
-      __hip_atomic_store(&xb[r], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&xb[r], ((unsigned long long)tag << 32) | __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (tid == 0) __hip_atomic_store(&xb[CS_MAX_SLOTS], z.sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the payload has left this CU before anybody is told
-  __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(&a.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- 3: the NEXT step's slots are requested now: they land while this workgroup waits for its peers ----
-  cs_issue<SPL>(a, b, step + 1, nxt);
-  if (tid == 0) reinterpret_cast<int*>(red)[9] = cs_wait(a.sync, (z.n_rel + 1u) * (unsigned int)G) ? 0 : 1;
-  __syncthreads();
-  if (reinterpret_cast<int*>(red)[9]) return false;
-  // ---- 4: every slice's partials, added in slice order: x.w, the gate, the row's coefficient ----
-  const float* xall = a.xbuf + (long long)(z.n_rel & 1u) * G * CS_XSTRIDE;
+  if (tid == 0) {
+    __hip_atomic_store(&xb[CS_MAX_SLOTS], ((unsigned long long)tag << 32) | __float_as_uint(z.sp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  stamp(1);
+  // ---- 3: every slice's granules of this thread's rows: x.w in slice order, the gate, the row's coefficient ----
+  const unsigned long long* xall = a.xbuf + (long long)(z.n_rel & 1u) * G * CS_XSTRIDE;
+  bool got = true;
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
     const int r = tid + CS_THREADS * i;
-    if (r < n_rows) {
-      float x[CS_MAX_G];
-#pragma unroll
-      for (int g = 0; g < 8; ++g) x[g] = __hip_atomic_load(&xall[(long long)g * CS_XSTRIDE + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (G > 8) {   // (workgroup-uniform: G is 8 or 16)
-#pragma unroll
-        for (int g = 8; g < CS_MAX_G; ++g) x[g] = __hip_atomic_load(&xall[(long long)g * CS_XSTRIDE + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-#pragma unroll
-        for (int g = 8; g < CS_MAX_G; ++g) x[g] = 0.0f;
-      }
+    if (r < n_rows && got) {
       float d = 0.0f;
-#pragma unroll
-      for (int g = 0; g < CS_MAX_G; ++g) d += x[g];            // (the zeros of an 8-slice run change nothing)
+      got = cs_gather(xall, G, r, tag, &a.sync[1], d);
       const bool ypos = (cur.rf[i] & 0x8000u) != 0u;
       const float yd = ypos ? d : -d;
-      const bool active = !(yd < 0.0f);                        // ref: core/ml/SparseSVM.scala:27-28
+      const bool active = got && !(yd < 0.0f);                 // ref: core/ml/SparseSVM.scala:27-28
       coef[r] = active ? (ypos ? qscale : -qscale) : 0.0f;
       z.n_act += (active && b == 0) ? 1u : 0u;
     }
   }
-  if (tid == 0) {   // s = 2 lambda (w . ds) of the weights this step's gradients see: the slices' shares in slice order
+  if (tid == CS_THREADS - 1) {   // s = 2 lambda (w . ds) of the weights this step's gradients see: the slices' shares in slice order
     float dsum = 0.0f;
-    for (int g = 0; g < G; ++g)
-      dsum += __hip_atomic_load(&xall[(long long)g * CS_XSTRIDE + CS_MAX_SLOTS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    got = got && cs_gather(xall, G, CS_MAX_SLOTS, tag, &a.sync[1], dsum);
     red[8] = a.lambda * 2.0f * dsum;
   }
+  if (!got) reinterpret_cast<int*>(red)[9] = 1;
   __syncthreads();
+  if (reinterpret_cast<int*>(red)[9]) return false;
+  stamp(2);
   const float s = red[8];
   const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
   // ---- 5: y * x of the active rows into the accumulator of the row's worker (exact integer sums; the non-zeros are
@@ -246,6 +279,7 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL>&
     }
   }
   __syncthreads();
+  stamp(3);
   // ---- 6: this slice's columns: per worker ONE rounding of the exact sum, the support-only regulariser, the fold over
   //         the workers, the mean, the update -- dsgd_fix_reduce_apply_kernel's arithmetic (fra_update_and_scalars) ----
   float spn = 0.0f;
@@ -268,7 +302,9 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL>&
     }
     spn += filt(wn * z.ds_l[i]);
   }
+  stamp(4);
   z.sp = cs_block_sum(spn, red);
+  stamp(5);
   ++z.n_rel;
   return true;
 }
@@ -291,6 +327,7 @@ __global__ void __launch_bounds__(CS_THREADS) dsgd_cs_step_kernel(CsArgs a) {
   z.red = z.coef + CS_MAX_SLOTS;
   z.n_act = 0u;
   z.n_rel = 0u;
+  for (int i = 0; i < 6; ++i) z.tp[i] = 0ull;
   float sp = 0.0f;
   for (int i = tid; i < z.Sp; i += CS_THREADS) {
     const float wv = i < z.Sb ? a.w[z.b + G * i] : 0.0f, dv = i < z.Sb ? a.ds[z.b + G * i] : 0.0f;
@@ -302,6 +339,7 @@ __global__ void __launch_bounds__(CS_THREADS) dsgd_cs_step_kernel(CsArgs a) {
   z.sp = cs_block_sum(sp, z.red);   // this slice's share of w . ds of the weights the launch starts from (also the barrier behind the set-up)
   CsSet<SPL> A, B;
   cs_issue<SPL>(a, z.b, a.step_begin, A);
+  z.tl = a.tprof ? __builtin_readcyclecounter() : 0ull;
   bool ok = true;
   for (long long step = a.step_begin; step < a.step_end; step += 2) {   // two register sets, rotated by unrolling
     ok = cs_step<SPL>(a, z, A, B, step);
@@ -314,6 +352,10 @@ __global__ void __launch_bounds__(CS_THREADS) dsgd_cs_step_kernel(CsArgs a) {
     return;   // (global w stays as the launch found it: the host rejects the run)
   }
   for (int i = tid; i < z.Sb; i += CS_THREADS) a.w[z.b + G * i] = z.w_l[i];
+  if (a.tprof && z.b == 0 && tid == 0) {
+    for (int i = 0; i < 6; ++i) a.tprof[i] += z.tp[i];
+    a.tprof[15] += (unsigned long long)(a.step_end - a.step_begin);
+  }
   if (z.b == 0) {
     const unsigned int n_act = wave_sum_u32(z.n_act);
     __syncthreads();

@@ -193,7 +193,7 @@ struct dsgd_ctx {
   bool cs_enable = true;                // DSGD_CS=0: small steps of resident plans through the row-parallel kernels
   int cs_g = 0;                         // DSGD_CS_G: slices (8 or 16; 0 = 8 up to four hosted workers, 16 beyond)
   long long cs_max_mb = 1024;           // DSGD_CS_MAX_MB: largest column-slice layout of one plan
-  float* d_cs_x = nullptr;              // exchange buffer of dsgd_cs_step_kernel: [2][CS_MAX_G][CS_XSTRIDE]
+  unsigned long long* d_cs_x = nullptr; // exchange buffer of dsgd_cs_step_kernel: [2][CS_MAX_G][CS_XSTRIDE] granules
   unsigned int* d_cs_sync = nullptr;    // its arrival counter and abort word
   bool vt_enable = true;                // DSGD_VT=0: index-list steps of resident plans through dsgd_mb_grad_kernel
   long long vt_pack_mb = 2048;          // DSGD_VT_PACK_MB: plans whose packed copy fits get one (0: descriptors only)
@@ -982,7 +982,7 @@ static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
   CS_SOFT(hipMemcpy(p->d_cs_col, col.data(), sizeof(unsigned short) * col.size(), hipMemcpyHostToDevice));
   CS_SOFT(hipMemcpy(p->d_cs_val, val.data(), sizeof(float) * val.size(), hipMemcpyHostToDevice));
   if (!c->d_cs_x) {
-    CS_SOFT(hipMalloc(&c->d_cs_x, sizeof(float) * 2 * CS_MAX_G * CS_XSTRIDE));
+    CS_SOFT(hipMalloc(&c->d_cs_x, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE));
     CS_SOFT(hipMalloc(&c->d_cs_sync, sizeof(unsigned int) * 2));
   }
   p->cs_G = G;
@@ -1020,6 +1020,7 @@ static int launch_cs(dsgd_ctx* c, dsgd_plan* p, long long step_begin, long long 
   a.xbuf = c->d_cs_x;
   a.sync = c->d_cs_sync;
   a.sc = c->d_sc;
+  a.tprof = c->d_tprof;
   a.n_steps_plan = p->n_steps;
   a.step_begin = step_begin;
   a.step_end = step_end;
@@ -1032,7 +1033,9 @@ static int launch_cs(dsgd_ctx* c, dsgd_plan* p, long long step_begin, long long 
   a.G = p->cs_G;
   a.K = p->n_workers;
   const size_t lds = sizeof(float) * (size_t)cs_lds_words(c->dp, a.G, a.K);
-  HIP_TRY(hipMemsetAsync(c->d_cs_sync, 0, sizeof(unsigned int) * 2, c->stream));   // arrivals are counted per launch
+  // a launch's step tags count from 1: the granules of the launch before it must not be mistaken for this one's
+  HIP_TRY(hipMemsetAsync(c->d_cs_x, 0, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_cs_sync, 0, sizeof(unsigned int) * 2, c->stream));
   size_t slot = 0;
   DSGD_TRY(prof_begin(c, &slot));
   c->ctr_known = false;

@@ -30,9 +30,12 @@ Three statements follow, each of which fails for a broken engine:
       really read is W at `read_at` plus whatever part of the updates in flight had landed.  So the recorded decisions
       cannot be reproduced row by row; what can be shown is WHERE along the interval [read_at, commit) the weights they
       were taken on lie: the fraction of rows whose recorded decision differs from the reference's gate y_i (x_i . W) >= 0
-      is evaluated on W_{read_at + f * lag} for f in FRACTIONS -- with many workers it must be lowest near the read end
-      (f = 0: the LDS copy of the hot weights is requested next to the atomic that returns `read_at`) and clearly higher at
-      the commit end (f = 1: staleness ignored).
+      is evaluated on W_{read_at + f * lag} for f in FRACTIONS.  Measured (256 workers x batch 100): 0.35 at f = 0, 0.10 at
+      f = 0.5, 0.42-0.50 at f = 1 -- the decisions were taken on weights from the MIDDLE of the interval: the LDS copy of the
+      hot weights is requested next to the atomic that returns `read_at`, but updates LAND before they COMMIT (an update's
+      atomics go out during its sweep, its commit number is drawn behind it) and the engine is bound by those atomics, so the
+      sweep is most of an iteration and about half of the updates in flight are already visible.  Asserted with many
+      workers: the best-fitting point lies clearly below the commit end (staleness ignored), and so does the read end.
   (C) SCALAR: the recorded s_c against 2 lambda (W_{read_at(c)} . ds): median within S_TOL_MEDIAN, 90th percentile
       within S_TOL_P90 of the run's largest |s| (the scalar is kept incrementally with one atomic per update, the same
       in-flight fuzz applies).
@@ -47,9 +50,9 @@ import numpy as np
 M64 = (1 << 64) - 1
 
 ACCOUNT_TOL = 2e-4     # (A): max_j |w_engine - W_n|_j <= ACCOUNT_TOL * max(1, |W_n|_inf)
-FRACTIONS = (0.0, 0.25, 0.5, 1.0)   # (B): where in [read_at, commit) the gates are compared
+FRACTIONS = (0.0, 0.25, 0.5, 0.75, 1.0)   # (B): where in [read_at, commit) the gates are compared
 STALE_LAG = 32.0       # (B): asserted for runs whose mean lag is at least this many updates ...
-STALE_RATIO = 0.97     # ...: differs(f = 0) <= STALE_RATIO * differs(f = 1)
+STALE_RATIO = 0.6      # ...: min_f differs(f) <= STALE_RATIO * differs(f = 1), and differs(f = 0) < differs(f = 1)
 S_TOL_MEDIAN = 0.02    # (C): relative to max_c |s_replay|
 S_TOL_P90 = 0.25
 
@@ -194,13 +197,14 @@ def verdict(o, w_engine, w_replay, stats, eval_range=None):
     s_scale = max(stats["s_max_abs"], 1e-300)
     s_p50, s_p90 = float(np.median(s_err)) / s_scale, float(np.quantile(s_err, 0.9)) / s_scale
     prof = [g / max(1, stats["rows"]) for g in stats["gate_differs"]]
-    stale_seen = stats["mean_lag"] < STALE_LAG or prof[0] <= STALE_RATIO * prof[-1]
+    stale_seen = stats["mean_lag"] < STALE_LAG or (min(prof) <= STALE_RATIO * prof[-1] and prof[0] < prof[-1])
     out = {
         "updates": stats["updates"], "max_lag": stats["max_lag"], "mean_lag": stats["mean_lag"],
         "account_max_abs_err": err, "account_err_over_tol": err / (ACCOUNT_TOL * scale), "account_tolerance": ACCOUNT_TOL,
         "rel_distance": dist, "wnorm_engine": float(np.sqrt(w_engine @ w_engine)), "wnorm_replay": nr,
         "rows": stats["rows"], "gate_fractions": list(stats["fractions"]), "gate_differs_at_fraction": prof,
-        "gate_rule": "differs(read end) <= %.2f x differs(commit end) once the mean lag reaches %d updates" % (STALE_RATIO, STALE_LAG),
+        "gate_rule": "min over f <= %.2f x differs(commit end) and differs(read end) < differs(commit end) once the mean lag reaches "
+                     "%d updates" % (STALE_RATIO, STALE_LAG),
         "s_max_abs": stats["s_max_abs"], "s_rel_err_median": s_p50, "s_rel_err_p90": s_p90, "s_rel_err_max": float(s_err.max()) / s_scale,
         "s_tolerances": [S_TOL_MEDIAN, S_TOL_P90],
     }

@@ -27,7 +27,7 @@ with dsgd_amd.Engine(data.dim, 1e-5) as eng:
     eng.load_csr(data.row_ptr, data.col, data.val, data.label)
     eng.build_dim_sparsity(n_train)
     rng = np.random.default_rng(1)
-    cases = ((1, 65536, 40), (1, 4096, 100), (3, 100, 200), (4, 200, 200), (1, 1000, 100), (1, 16384, 60), (8, 4096, 40))
+    cases = ((1, 65536, 40), (1, 4096, 100), (3, 100, 200), (4, 200, 200), (1, 100, 200), (1, 1000, 100), (1, 16384, 60), (8, 4096, 40))
     if only:
         cases = tuple(c for c in cases if (c[0], c[1]) in only)
     for k, b, steps in cases[:2] if quick else cases:
@@ -54,5 +54,7 @@ with dsgd_amd.Engine(data.dim, 1e-5) as eng:
         if cyc[15]:   # DSGD_PLAN_PROF=1: cycles of wave 0 of workgroup 0 per launch, by phase
             names = ("issue_ids_copy_clear", "row_records", "first_items", "barrier_in", "pass_requests", "pass_dot",
                      "pass_scatter", "barrier_out", "write_partial")
+            if "cs_step" in eng.grad_kernel_name():   # csrc/dsgd_cs.hpp: thread 0 of slice 0, cycles per STEP
+                names = ("dot", "publish", "exchange", "scatter", "sweep", "reduce")
             out["steps"][-1]["wave0_cycles_per_launch"] = {nm: cyc[i] / cyc[15] for i, nm in enumerate(names)}
 print(json.dumps(out, indent=1))

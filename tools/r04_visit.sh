@@ -42,7 +42,7 @@ import json; d=json.load(open('$OUT/mb_prof.json'))
 for s in d['steps']: print('%d x %6d: %7.1f us/step %7.1f GB/s (%.3f of 8 TB/s) %s shift %d' % (s['workers'], s['batch'], s['us_per_step'], s['GBps'], s['frac_of_8TBps'], s['kernel'], s['fix_shift']))" ;;
 mbcyc)
   echo "== phase cycles of wave 0 (DSGD_PLAN_PROF=1)"
-  DSGD_PLAN_PROF=1 timeout 300 python tools/mb_prof.py 2000000 --only=1x65536 --only=1x4096 --only=3x100 > $OUT/mb_cycles.json 2> $OUT/mb_cycles.err; tail -2 $OUT/mb_cycles.err; python -c "
+  DSGD_PLAN_PROF=1 timeout 300 python tools/mb_prof.py 2000000 --only=3x100 --only=4x200 --only=1x100 > $OUT/mb_cycles.json 2> $OUT/mb_cycles.err; tail -2 $OUT/mb_cycles.err; python -c "
 import json; d=json.load(open('$OUT/mb_cycles.json'))
 for s in d['steps']: print(s['workers'], s['batch'], round(s['us_per_step'],1), {k: int(v) for k, v in s.get('wave0_cycles_per_launch', {}).items()})" ;;
 mbtrace)
