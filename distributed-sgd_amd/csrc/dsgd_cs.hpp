@@ -143,13 +143,20 @@ __device__ __forceinline__ bool cs_gather(const unsigned long long* xall, int G,
   return true;
 }
 
+// Workgroup barrier that orders LDS only.  __syncthreads() is a workgroup-scope FENCE: it waits for every outstanding
+// memory operation of the wave (s_waitcnt vmcnt(0)) -- here that is the next step's slots, requested at the top of the
+// step precisely so that they stay in flight under it (measured with __syncthreads(): the first barrier of every step
+// waited out the whole HBM round trip, 1.9 us at 3 x 100 and 8 us at 4 x 200).  Everything the barriers of a step
+// order lives in LDS; what crosses workgroups goes through the tagged granules, which need no ordering.
+__device__ __forceinline__ void cs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // sum over the workgroup, the same bits on every thread (wave butterflies, then the four wave sums in order)
 __device__ __forceinline__ float cs_block_sum(float v, float* red4) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  __syncthreads();
+  cs_barrier();
   if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
-  __syncthreads();
+  cs_barrier();
   return (red4[0] + red4[1]) + (red4[2] + red4[3]);
 }
 
@@ -214,7 +221,7 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL>&
     if (slot < n_slots) ps[slot] = p;
   }
   if (tid == 0) reinterpret_cast<int*>(red)[9] = 0;   // (this step's "given up" flag: raised in phase 3, read behind its barrier)
-  __syncthreads();
+  cs_barrier();
   stamp(0);
   // ---- 2: this slice's partial of every row (its slots in order), published as granules {value, tag}: write-through,
   //         nothing waits for them ----
@@ -256,7 +263,7 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL>&
     red[8] = a.lambda * 2.0f * dsum;
   }
   if (!got) reinterpret_cast<int*>(red)[9] = 1;
-  __syncthreads();
+  cs_barrier();
   if (reinterpret_cast<int*>(red)[9]) return false;
   stamp(2);
   const float s = red[8];
@@ -278,29 +285,56 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL>&
       }
     }
   }
-  __syncthreads();
+  cs_barrier();
   stamp(3);
   // ---- 6: this slice's columns: per worker ONE rounding of the exact sum, the support-only regulariser, the fold over
   //         the workers, the mean, the update -- dsgd_fix_reduce_apply_kernel's arithmetic (fra_update_and_scalars) ----
+  // Four adjacent columns per thread and round, every LDS request of a round issued before the first is used (the first
+  // form walked one column at a time with a dependent LDS read per worker: 1,000 cycles per column, 9.8 of a 3 x 100
+  // step's 15.8 us).  Columns beyond this slice's last one hold zeros in all arrays.
   float spn = 0.0f;
-  for (int i = tid; i < z.Sb; i += CS_THREADS) {
-    float gsum = 0.0f;
-    for (int k = 0; k < K; ++k) {
-      const int tot = z.acc[k * Sp + i];
-      if (tot != 0) {
-        z.acc[k * Sp + i] = 0;
-        float gv = filt((float)((double)tot * inv_scale));
-        if (add && gv != 0.0f) gv = filt(gv + s);            // ref: core/ml/SparseSVM.scala:31, math/Vec.scala:65-75
-        gsum = filt(gsum + gv);                              // Vec.sum over the workers
+  {
+    const int n4 = Sp >> 2;
+    const float4* w4 = reinterpret_cast<const float4*>(z.w_l);
+    const float4* d4 = reinterpret_cast<const float4*>(z.ds_l);
+    int4* a4 = reinterpret_cast<int4*>(z.acc);
+    for (int i4 = tid; i4 < n4; i4 += CS_THREADS) {
+      int4 t[CS_MAX_K];
+#pragma unroll
+      for (int k = 0; k < CS_MAX_K; ++k) t[k] = k < K ? a4[k * n4 + i4] : make_int4(0, 0, 0, 0);
+      const float4 wo = w4[i4], dv = d4[i4];
+      int any = 0;
+#pragma unroll
+      for (int k = 0; k < CS_MAX_K; ++k) any |= t[k].x | t[k].y | t[k].z | t[k].w;
+      float wn[4] = {wo.x, wo.y, wo.z, wo.w};
+      if (any != 0) {
+        float gsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < CS_MAX_K; ++k) {
+          if (k < K) {
+            const int tk[4] = {t[k].x, t[k].y, t[k].z, t[k].w};
+            if ((tk[0] | tk[1] | tk[2] | tk[3]) != 0) a4[k * n4 + i4] = make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (tk[e] != 0) {
+                float gv = filt((float)((double)tk[e] * inv_scale));   // one rounding of the worker's exact sum
+                if (add && gv != 0.0f) gv = filt(gv + s);              // ref: core/ml/SparseSVM.scala:31, math/Vec.scala:65-75
+                gsum[e] = filt(gsum[e] + gv);                          // Vec.sum over the workers
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (gsum[e] != 0.0f) {
+            const float upd = filt(filt(gsum[e] / (float)K) * a.lr);   // Vec.mean, learningRate * grad (ref: core/Master.scala:194-197)
+            wn[e] = filt(wn[e] - upd);
+          }
+        }
+        reinterpret_cast<float4*>(z.w_l)[i4] = make_float4(wn[0], wn[1], wn[2], wn[3]);
       }
+      spn += (filt(wn[0] * dv.x) + filt(wn[1] * dv.y)) + (filt(wn[2] * dv.z) + filt(wn[3] * dv.w));
     }
-    float wn = z.w_l[i];
-    if (gsum != 0.0f) {
-      const float upd = filt(filt(gsum / (float)K) * a.lr);  // Vec.mean, learningRate * grad (ref: core/Master.scala:194-197)
-      wn = filt(wn - upd);
-      z.w_l[i] = wn;
-    }
-    spn += filt(wn * z.ds_l[i]);
   }
   stamp(4);
   z.sp = cs_block_sum(spn, red);

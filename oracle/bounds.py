@@ -7,6 +7,10 @@ j can therefore differ by at most
     lr/K * ( cnt_j * 2^-(shift+1) * vmax2        every contribution is off by at most half a grid unit
            + near_j )                            rows whose margin is within 1e-5 of zero may be gated differently
     + 8 * 2^-24 * (|w_j| + |w_j - w_j_before|)   fp32 roundings of the sum, the mean, the product and the subtraction
+    + 2 * 2^-24 * lr/K * sum_k |g_k,j|           (index lists) EACH worker's exact sum is rounded to fp32 once and regularised
+                                                 before the workers are folded: when two workers' gradients nearly cancel
+                                                 in a coordinate, those roundings are large against the NET update the
+                                                 line above prices (found at 2 workers x batch 7, lr 1)
     + 1e-9                                       the regulariser scalar s = 2*lambda*(w.ds) in fp32 vs fp64
 
 cnt_j = non-zeros of column j in the rows of the step, near_j = sum of |x_j| over the near-zero-margin rows
@@ -105,6 +109,13 @@ def list_bound(o, w_before, w_after_ref, lists, lr, shift, vmax2=None, parts=Fal
     quantum = vmax2 * 2.0 ** (-(shift + 1))
     tol = (lr / k) * (cnt * quantum + near)
     tol += 8.0 * 2.0 ** -24 * (np.abs(w_after_ref) + np.abs(w_after_ref - w_before)) + 1e-9
+    # every worker's own regularised sum, rounded once before the fold over the workers (Vec.sum, math/Vec.scala:128-131)
+    keep = o.last_stats
+    gabs = np.zeros(o.dim + 1)
+    for rows in lists:
+        gabs += np.abs(o.gradient(np.ascontiguousarray(w_before, dtype=np.float64), rows))
+    o.last_stats = keep
+    tol += 2.0 * 2.0 ** -24 * (lr / k) * gabs
     if parts:
         return tol, n_near, (lr / k) * near
     return tol, n_near
