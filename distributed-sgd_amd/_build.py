@@ -61,8 +61,8 @@ def build_hip(force: bool = False, out: str | None = None, defines: tuple = ()) 
     build (tests/rccl_stub/libdsgd_hip_seam.so, -DDSGD_TEST_COLLECTIVE_SEAM); the product is always built without."""
     header = os.path.join(HERE, "..", "include", "dsgd.h")
     target = out or HIP_LIB
-    if not force and not _stale(target, HIP_SRC, os.path.join(CSRC, "dsgd_kernels.hpp"), os.path.join(CSRC, "dsgd_batch.hpp"), os.path.join(CSRC, "dsgd_dense.hpp"),
-                              header, __file__):
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))   # every device header the .hip includes
+    if not force and not _stale(target, HIP_SRC, *headers, header, __file__):
         return target
     os.makedirs(os.path.dirname(target), exist_ok=True)
     stub_dir = tempfile.mkdtemp(prefix="dsgd_stub_")
