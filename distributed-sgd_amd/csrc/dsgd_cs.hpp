@@ -32,14 +32,15 @@
 // poll raises an abort word that every workgroup honours (a launch can end with DevScalars::err = 8, never hang).
 #pragma once
 
-constexpr int CS_THREADS = 256;     // 4 waves: one per SIMD, 512 VGPRs each -- two register sets of 4 slots per lane
+constexpr int CS_THREADS = 512;     // 8 waves, two per SIMD (<= 256 VGPRs): one or two slots per lane and register set, two sets
+constexpr int CS_THREADS_NARROW = 256;   // (tuning runs: DSGD_CS_NT=256)
 constexpr int CS_L = 16;            // entries per slot
 constexpr int CS_MAX_G = 16;        // slices = workgroups
 constexpr int CS_MAX_K = 8;         // hosted workers
-constexpr int CS_MAX_SPL = 4;       // slots (and rows) per lane
-constexpr int CS_MAX_SLOTS = CS_THREADS * CS_MAX_SPL;   // per (step, slice); also the most rows of a step
+constexpr int CS_MAX_SLOTS = 1024;   // per (step, slice); also the most rows of a step
 constexpr int CS_XSTRIDE = CS_MAX_SLOTS + 64;           // granules per (parity, slice) of the exchange buffer: [row] partial x.w, [CS_MAX_SLOTS] share of w . ds
 constexpr unsigned int CS_POLL_LIMIT = 1u << 18;        // polls of one granule set before the launch is given up
+constexpr int CS_MAX_CLT = 8;                           // listed columns per lane: a step may touch 4,096 columns of a slice
 
 struct CsHdr {                // per (slice, step)
   unsigned int counts;        // slots of the step inside the slice (low 16 bits) | rows of the step << 16
@@ -50,8 +51,11 @@ struct CsArgs {
   const CsHdr* hdr;                 // [G][n_steps]
   const unsigned int* slot_meta;    // [G][n_steps][slot_stride]: row of the step (bits 0-15) | worker (bits 16-19)
   const unsigned short* row_first;  // [G][n_steps][row_stride]: first slot of row r (bits 0-10; entry n_rows = n_slots) | label > 0 (bit 15)
-  const unsigned short* col;        // [G][n_steps][slot_stride][CS_L]: slice-local column (rank / G); padding: column 0, value 0
-  const float* val;
+  const uint4* col;                 // [G][n_steps][2][slot_stride]: 16-byte PIECES of the slots' 16 slice-local columns (rank / G, 16 bits
+  const float4* val;                //   each) and [G][n_steps][4][slot_stride] of their values: lane = slot, so every request of a wave is
+                                    //   one contiguous KiB (slot-major records -- 32- and 64-byte strides between lanes -- took 7 us to land
+                                    //   at 4 x 200); padding: column 0, value 0
+  const unsigned short* clist;      // [G][n_steps][cl_stride]: the distinct columns of the step inside the slice, ascending; 0xffff: none
   float* w;                         // ranked weights (read when the launch starts, written when it ends)
   const float* ds;
   unsigned long long* xbuf;         // [2][G][CS_XSTRIDE] granules {value bits, step tag << 32}; zero when a launch starts
@@ -59,7 +63,8 @@ struct CsArgs {
   DevScalars* sc;
   unsigned long long* tprof;        // optional (tuning runs, DSGD_PLAN_PROF=1): cycles of thread 0 of slice 0 by phase, [15] = steps
   long long n_steps_plan, step_begin, step_end;
-  int slot_stride, row_stride;
+  int slot_stride, row_stride, cl_stride;
+  unsigned int tag0;                // steps of the context's earlier launches
   float lr, lambda;
   int vexp, dp, G, K;
 };
@@ -68,40 +73,45 @@ __host__ __device__ constexpr int cs_lds_words(int dp, int G, int K) {
   return (2 + K) * ((((dp + G - 1) / G) + 3) & ~3) + 2 * CS_MAX_SLOTS + 32;
 }
 
-template <int SPL>
+template <int SPL, int CLT>
 struct CsSet {              // the slots of one step, as loaded (nothing is computed on them before their step runs)
   uint4 c[SPL][2];          // 16 slice-local columns, 16 bits each
   float4 v[SPL][4];
   unsigned int meta[SPL];
   unsigned int rf[SPL];     // row_first[r] | row_first[r + 1] << 16 of row r = tid + CS_THREADS * i
+  unsigned short cl[CLT];   // listed columns tid + CS_THREADS * i of the step
   uint2 h;                  // the step's header
 };
 
-template <int SPL>
-__device__ __forceinline__ void cs_issue(const CsArgs& a, int b, long long step, CsSet<SPL>& R) {
+template <int NT, int SPL, int CLT>
+__device__ __forceinline__ void cs_issue(const CsArgs& a, int b, long long step, CsSet<SPL, CLT>& R) {
   // every request unconditional, indices clamped (a step beyond the launch's last one re-reads the last and is never used)
   const long long sc = step < a.step_end ? step : a.step_end - 1;
   const long long sidx = (long long)b * a.n_steps_plan + sc;
   const uint2* hp = reinterpret_cast<const uint2*>(a.hdr + sidx);
   asm volatile("" : "+v"(hp));   // a vector load (vmcnt): a scalar one would share lgkmcnt with the LDS traffic of the whole step
   R.h = *hp;
-  const long long sbase = sidx * a.slot_stride, rbase = sidx * a.row_stride;
+  const long long sbase = sidx * a.slot_stride, rbase = sidx * a.row_stride, cbase = sidx * a.cl_stride;
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
-    int slot = (int)threadIdx.x + CS_THREADS * i;
+    int slot = (int)threadIdx.x + NT * i;
     slot = slot < a.slot_stride ? slot : a.slot_stride - 1;
-    const uint4* cp = reinterpret_cast<const uint4*>(a.col + (sbase + slot) * CS_L);
-    const float4* vp = reinterpret_cast<const float4*>(a.val + (sbase + slot) * CS_L);
-    R.c[i][0] = cp[0];
-    R.c[i][1] = cp[1];
-    R.v[i][0] = vp[0];
-    R.v[i][1] = vp[1];
-    R.v[i][2] = vp[2];
-    R.v[i][3] = vp[3];
+    R.c[i][0] = a.col[2 * sbase + slot];
+    R.c[i][1] = a.col[2 * sbase + a.slot_stride + slot];
+    R.v[i][0] = a.val[4 * sbase + slot];
+    R.v[i][1] = a.val[4 * sbase + a.slot_stride + slot];
+    R.v[i][2] = a.val[4 * sbase + 2 * a.slot_stride + slot];
+    R.v[i][3] = a.val[4 * sbase + 3 * a.slot_stride + slot];
     R.meta[i] = a.slot_meta[sbase + slot];
-    int r = (int)threadIdx.x + CS_THREADS * i;
+    int r = (int)threadIdx.x + NT * i;
     r = r < a.row_stride - 1 ? r : a.row_stride - 2;
     R.rf[i] = (unsigned int)a.row_first[rbase + r] | ((unsigned int)a.row_first[rbase + r + 1] << 16);
+  }
+#pragma unroll
+  for (int i = 0; i < CLT; ++i) {
+    const int e = (int)threadIdx.x + NT * i;
+    const unsigned short cl = a.clist[cbase + (e < a.cl_stride ? e : a.cl_stride - 1)];
+    R.cl[i] = e < a.cl_stride ? cl : (unsigned short)0xffffu;
   }
 }
 
@@ -150,14 +160,22 @@ __device__ __forceinline__ bool cs_gather(const unsigned long long* xall, int G,
 // order lives in LDS; what crosses workgroups goes through the tagged granules, which need no ordering.
 __device__ __forceinline__ void cs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// sum over the workgroup, the same bits on every thread (wave butterflies, then the four wave sums in order)
-__device__ __forceinline__ float cs_block_sum(float v, float* red4) {
+// sum over the workgroup, the same bits on every thread (wave butterflies, then the wave sums pairwise in order)
+template <int NT>
+__device__ __forceinline__ float cs_block_sum(float v, float* red16) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   cs_barrier();
-  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = v;
   cs_barrier();
-  return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+  float t[NT / 64];
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) t[i] = red16[i];
+#pragma unroll
+  for (int n = NT / 64; n > 1; n >>= 1)
+#pragma unroll
+    for (int i = 0; i < n / 2; ++i) t[i] = t[2 * i] + t[2 * i + 1];
+  return t[0];
 }
 
 // the LDS carve and the launch-long state of a workgroup
@@ -167,17 +185,27 @@ struct CsState {
   int* acc;       // [K][Sp], zero between steps
   float* ps;      // partial x.w per slot
   float* coef;    // per row of the step: +-2^shift / vmax2 (active) or 0
-  float* red;     // [0..3] wave sums, [8] s of the step, [9] abort flag
+  float* red;     // [0..15] wave sums, [16] s of the step, [17] abort flag, [18..31] the tuning counters
   int b, Sb, Sp;
   float sp;       // this slice's share of w . ds of the current weights (the same bits on every thread)
   unsigned int n_act, n_rel;   // active rows counted (slice 0 only); steps of this launch behind us
-  unsigned long long tp[6], tl; // tuning runs: cycles by phase (dot, publish, exchange, scatter, sweep, reduce), last stamp
+  unsigned long long* tp;      // tuning runs (LDS, thread 0 of slice 0): cycles by phase (dot, publish, exchange, scatter, sweep, reduce), [6] last stamp
 };
 
+// the 16 columns / values of slot i of a register set (compile-time indices only: the set stays in registers)
+#define CS_COL(R, i, j) ((int)(((j) & 1) ? ((&(R).c[i][(j) >> 3].x)[((j) >> 1) & 3] >> 16) : ((&(R).c[i][(j) >> 3].x)[((j) >> 1) & 3] & 0xffffu)))
+#define CS_VAL(R, i, j) ((&(R).v[i][(j) >> 2].x)[(j) & 3])
+
 // One step.  `cur`: the step's slots (landed); `nxt` receives the next step's.  false = the launch was aborted.
-template <int SPL>
-__device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL>& cur, CsSet<SPL>& nxt, long long step) {
-  const int tid = threadIdx.x, G = a.G, K = a.K, b = z.b, Sp = z.Sp;
+template <int NT, int SPL, int CLT>
+__device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, CLT>& cur, CsSet<SPL, CLT>& nxt, long long step) {
+  int tid = threadIdx.x, G = __builtin_amdgcn_readfirstlane(a.G), K = __builtin_amdgcn_readfirstlane(a.K), b = z.b,
+      Sp = __builtin_amdgcn_readfirstlane(z.Sp);
+  // what a step derives from these is recomputed in every step: hoisted out of the step loop, the lanes' addresses and
+  // scale factors were ~150 registers too many, and their reloads from scratch are vector-memory operations -- they
+  // retire in order BEHIND the next step's slots, so every one of them waited the prefetch out
+  asm volatile("" : "+v"(tid));
+  asm volatile("" : "+s"(G), "+s"(K), "+s"(Sp));
   float* const ps = z.ps;
   float* const coef = z.coef;
   float* const red = z.red;
@@ -190,46 +218,29 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL>&
   auto stamp = [&](int i) {
     if (prof) {
       const unsigned long long now = __builtin_readcyclecounter();
-      z.tp[i] += now - z.tl;
-      z.tl = now;
+      z.tp[i] += now - z.tp[6];
+      z.tp[6] = now;
     }
   };
-  // ---- 0: the NEXT step's slots are requested first (a whole step to land; vmcnt retires in order, so the polls of this
-  //         step's exchange return no earlier than these -- requested later they would be waited for at the next step's top) ----
-  cs_issue<SPL>(a, b, step + 1, nxt);
   // ---- 1: partial x.w of every slot from this slice's weights (ref: math/Vec.scala:58, math/Sparse.scala:46) ----
-  int cc[SPL][CS_L];
-  float vv[SPL][CS_L];
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
-    const unsigned int cw[8] = {cur.c[i][0].x, cur.c[i][0].y, cur.c[i][0].z, cur.c[i][0].w,
-                                cur.c[i][1].x, cur.c[i][1].y, cur.c[i][1].z, cur.c[i][1].w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      cc[i][2 * j] = (int)(cw[j] & 0xffffu);
-      cc[i][2 * j + 1] = (int)(cw[j] >> 16);
-    }
-    const float4 v0 = cur.v[i][0], v1 = cur.v[i][1], v2 = cur.v[i][2], v3 = cur.v[i][3];
-    const float t[CS_L] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
     float p = 0.0f;
 #pragma unroll
-    for (int j = 0; j < CS_L; ++j) {
-      vv[i][j] = t[j];
-      p += filt(t[j] * z.w_l[cc[i][j]]);
-    }
-    const int slot = tid + CS_THREADS * i;
+    for (int j = 0; j < CS_L; ++j) p += filt(CS_VAL(cur, i, j) * z.w_l[CS_COL(cur, i, j)]);
+    const int slot = tid + NT * i;
     if (slot < n_slots) ps[slot] = p;
   }
-  if (tid == 0) reinterpret_cast<int*>(red)[9] = 0;   // (this step's "given up" flag: raised in phase 3, read behind its barrier)
+  if (tid == 0) reinterpret_cast<int*>(red)[17] = 0;   // (this step's "given up" flag: raised in phase 3, read behind its barrier)
   cs_barrier();
   stamp(0);
   // ---- 2: this slice's partial of every row (its slots in order), published as granules {value, tag}: write-through,
   //         nothing waits for them ----
-  const unsigned int tag = z.n_rel + 1u;
+  const unsigned int tag = a.tag0 + z.n_rel + 1u;   // (tags run on across the launches of a context: nothing is cleared between them)
   unsigned long long* xb = a.xbuf + ((long long)(z.n_rel & 1u) * G + b) * CS_XSTRIDE;
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
-    const int r = tid + CS_THREADS * i;
+    const int r = tid + NT * i;
     if (r < n_rows) {
       const int f0 = (int)(cur.rf[i] & 0x7ffu), f1 = (int)((cur.rf[i] >> 16) & 0x7ffu);
       float t = 0.0f;
@@ -237,16 +248,20 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL>&
       __hip_atomic_store(&xb[r], ((unsigned long long)tag << 32) | __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (tid == 0) {
+  if (tid == 0)
     __hip_atomic_store(&xb[CS_MAX_SLOTS], ((unsigned long long)tag << 32) | __float_as_uint(z.sp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  // ---- the NEXT step's slots are requested HERE: they land while this workgroup waits for its peers' granules (vmcnt
+  //      retires in order, so the polls below return no earlier than these -- the exchange is a round trip anyway).
+  //      Requested at the top of the step they were waited for on the spot: beyond 256 registers the allocator parks
+  //      freshly loaded values in accumulation registers, and the move needs the value. ----
+  cs_issue<NT, SPL, CLT>(a, b, step + 1, nxt);
   stamp(1);
   // ---- 3: every slice's granules of this thread's rows: x.w in slice order, the gate, the row's coefficient ----
   const unsigned long long* xall = a.xbuf + (long long)(z.n_rel & 1u) * G * CS_XSTRIDE;
   bool got = true;
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
-    const int r = tid + CS_THREADS * i;
+    const int r = tid + NT * i;
     if (r < n_rows && got) {
       float d = 0.0f;
       got = cs_gather(xall, G, r, tag, &a.sync[1], d);
@@ -257,94 +272,92 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL>&
       z.n_act += (active && b == 0) ? 1u : 0u;
     }
   }
-  if (tid == CS_THREADS - 1) {   // s = 2 lambda (w . ds) of the weights this step's gradients see: the slices' shares in slice order
+  if (tid == NT - 1) {   // s = 2 lambda (w . ds) of the weights this step's gradients see: the slices' shares in slice order
     float dsum = 0.0f;
     got = got && cs_gather(xall, G, CS_MAX_SLOTS, tag, &a.sync[1], dsum);
-    red[8] = a.lambda * 2.0f * dsum;
+    red[16] = a.lambda * 2.0f * dsum;
   }
-  if (!got) reinterpret_cast<int*>(red)[9] = 1;
+  if (!got) reinterpret_cast<int*>(red)[17] = 1;
   cs_barrier();
-  if (reinterpret_cast<int*>(red)[9]) return false;
+  if (reinterpret_cast<int*>(red)[17]) return false;
   stamp(2);
-  const float s = red[8];
+  const float s = red[16];
   const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
-  // ---- 5: y * x of the active rows into the accumulator of the row's worker (exact integer sums; the non-zeros are
+  // ---- 4: y * x of the active rows into the accumulator of the row's worker (exact integer sums; the non-zeros are
   //         still in registers).  ref: core/Slave.scala:147-153 restricted to this slice's columns ----
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
-    const int slot = tid + CS_THREADS * i;
+    const int slot = tid + NT * i;
     if (slot < n_slots) {
       const float cf = coef[cur.meta[i] & 0xffffu];
       if (cf != 0.0f) {
         int* ak = z.acc + (int)((cur.meta[i] >> 16) & 15u) * Sp;
 #pragma unroll
         for (int j = 0; j < CS_L; ++j) {
-          const int q = __float2int_rn(vv[i][j] * cf);
-          if (q != 0) atomicAdd(&ak[cc[i][j]], q);
+          const int q = __float2int_rn(CS_VAL(cur, i, j) * cf);
+          if (q != 0) atomicAdd(&ak[CS_COL(cur, i, j)], q);
         }
       }
     }
   }
   cs_barrier();
   stamp(3);
-  // ---- 6: this slice's columns: per worker ONE rounding of the exact sum, the support-only regulariser, the fold over
-  //         the workers, the mean, the update -- dsgd_fix_reduce_apply_kernel's arithmetic (fra_update_and_scalars) ----
-  // Four adjacent columns per thread and round, every LDS request of a round issued before the first is used (the first
-  // form walked one column at a time with a dependent LDS read per worker: 1,000 cycles per column, 9.8 of a 3 x 100
-  // step's 15.8 us).  Columns beyond this slice's last one hold zeros in all arrays.
+  // ---- 5: the columns this step can have touched (the plan lists them: dense lanes -- a sweep over all 5,905 columns of
+  //         the slice spent 9.8 of a 3 x 100 step's 15.8 us on the ~80 % it does not touch): per worker ONE rounding
+  //         of the exact sum, the support-only regulariser, the fold over the workers, the mean, the update --
+  //         dsgd_fix_reduce_apply_kernel's arithmetic (fra_update_and_scalars) ----
+#pragma unroll
+  for (int i0 = 0; i0 < CLT; i0 += 4) {
+    int cidx[4], t[4][CS_MAX_K];
+    float wo[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {   // every LDS request of four columns before the first is used
+      const unsigned int cl = cur.cl[i0 + u];
+      cidx[u] = cl == 0xffffu ? -1 : (int)cl;
+      const int cc = cidx[u] < 0 ? 0 : cidx[u];
+#pragma unroll
+      for (int k = 0; k < CS_MAX_K; ++k) t[u][k] = k < K ? z.acc[k * Sp + cc] : 0;
+      wo[u] = z.w_l[cc];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (cidx[u] < 0) continue;
+      float gsum = 0.0f;
+#pragma unroll
+      for (int k = 0; k < CS_MAX_K; ++k) {
+        if (k < K && t[u][k] != 0) {
+          z.acc[k * Sp + cidx[u]] = 0;
+          float gv = filt((float)((double)t[u][k] * inv_scale));   // one rounding of the worker's exact sum
+          if (add && gv != 0.0f) gv = filt(gv + s);                // ref: core/ml/SparseSVM.scala:31, math/Vec.scala:65-75
+          gsum = filt(gsum + gv);                                  // Vec.sum over the workers
+        }
+      }
+      if (gsum != 0.0f) {
+        const float upd = filt(filt(gsum / (float)K) * a.lr);      // Vec.mean, learningRate * grad (ref: core/Master.scala:194-197)
+        z.w_l[cidx[u]] = filt(wo[u] - upd);
+      }
+    }
+  }
+  cs_barrier();
+  // ... and this slice's share of w . ds of the new weights: all columns, four per lane and round (padding holds zeros)
   float spn = 0.0f;
   {
-    const int n4 = Sp >> 2;
     const float4* w4 = reinterpret_cast<const float4*>(z.w_l);
     const float4* d4 = reinterpret_cast<const float4*>(z.ds_l);
-    int4* a4 = reinterpret_cast<int4*>(z.acc);
-    for (int i4 = tid; i4 < n4; i4 += CS_THREADS) {
-      int4 t[CS_MAX_K];
-#pragma unroll
-      for (int k = 0; k < CS_MAX_K; ++k) t[k] = k < K ? a4[k * n4 + i4] : make_int4(0, 0, 0, 0);
-      const float4 wo = w4[i4], dv = d4[i4];
-      int any = 0;
-#pragma unroll
-      for (int k = 0; k < CS_MAX_K; ++k) any |= t[k].x | t[k].y | t[k].z | t[k].w;
-      float wn[4] = {wo.x, wo.y, wo.z, wo.w};
-      if (any != 0) {
-        float gsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int k = 0; k < CS_MAX_K; ++k) {
-          if (k < K) {
-            const int tk[4] = {t[k].x, t[k].y, t[k].z, t[k].w};
-            if ((tk[0] | tk[1] | tk[2] | tk[3]) != 0) a4[k * n4 + i4] = make_int4(0, 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if (tk[e] != 0) {
-                float gv = filt((float)((double)tk[e] * inv_scale));   // one rounding of the worker's exact sum
-                if (add && gv != 0.0f) gv = filt(gv + s);              // ref: core/ml/SparseSVM.scala:31, math/Vec.scala:65-75
-                gsum[e] = filt(gsum[e] + gv);                          // Vec.sum over the workers
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (gsum[e] != 0.0f) {
-            const float upd = filt(filt(gsum[e] / (float)K) * a.lr);   // Vec.mean, learningRate * grad (ref: core/Master.scala:194-197)
-            wn[e] = filt(wn[e] - upd);
-          }
-        }
-        reinterpret_cast<float4*>(z.w_l)[i4] = make_float4(wn[0], wn[1], wn[2], wn[3]);
-      }
-      spn += (filt(wn[0] * dv.x) + filt(wn[1] * dv.y)) + (filt(wn[2] * dv.z) + filt(wn[3] * dv.w));
+    for (int i4 = tid; i4 < (Sp >> 2); i4 += NT) {
+      const float4 wv = w4[i4], dv = d4[i4];
+      spn += (filt(wv.x * dv.x) + filt(wv.y * dv.y)) + (filt(wv.z * dv.z) + filt(wv.w * dv.w));
     }
   }
   stamp(4);
-  z.sp = cs_block_sum(spn, red);
+  z.sp = cs_block_sum<NT>(spn, red);
   stamp(5);
   ++z.n_rel;
   return true;
 }
 
-template <int SPL>
-__global__ void __launch_bounds__(CS_THREADS) dsgd_cs_step_kernel(CsArgs a) {
+template <int NT, int SPL, int CLT>
+__global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int G = a.G, K = a.K;
@@ -361,31 +374,33 @@ __global__ void __launch_bounds__(CS_THREADS) dsgd_cs_step_kernel(CsArgs a) {
   z.red = z.coef + CS_MAX_SLOTS;
   z.n_act = 0u;
   z.n_rel = 0u;
-  for (int i = 0; i < 6; ++i) z.tp[i] = 0ull;
+  z.tp = reinterpret_cast<unsigned long long*>(z.red + 18);
+  if (tid == 0)
+    for (int i = 0; i < 6; ++i) z.tp[i] = 0ull;
   float sp = 0.0f;
-  for (int i = tid; i < z.Sp; i += CS_THREADS) {
+  for (int i = tid; i < z.Sp; i += NT) {
     const float wv = i < z.Sb ? a.w[z.b + G * i] : 0.0f, dv = i < z.Sb ? a.ds[z.b + G * i] : 0.0f;
     z.w_l[i] = wv;
     z.ds_l[i] = dv;
     sp += filt(wv * dv);
   }
-  for (int i = tid; i < K * z.Sp; i += CS_THREADS) z.acc[i] = 0;
-  z.sp = cs_block_sum(sp, z.red);   // this slice's share of w . ds of the weights the launch starts from (also the barrier behind the set-up)
-  CsSet<SPL> A, B;
-  cs_issue<SPL>(a, z.b, a.step_begin, A);
-  z.tl = a.tprof ? __builtin_readcyclecounter() : 0ull;
+  for (int i = tid; i < K * z.Sp; i += NT) z.acc[i] = 0;
+  z.sp = cs_block_sum<NT>(sp, z.red);   // this slice's share of w . ds of the weights the launch starts from (also the barrier behind the set-up)
+  CsSet<SPL, CLT> A, B;
+  cs_issue<NT, SPL, CLT>(a, z.b, a.step_begin, A);
+  if (tid == 0) z.tp[6] = a.tprof ? __builtin_readcyclecounter() : 0ull;
   bool ok = true;
   for (long long step = a.step_begin; step < a.step_end; step += 2) {   // two register sets, rotated by unrolling
-    ok = cs_step<SPL>(a, z, A, B, step);
+    ok = cs_step<NT, SPL, CLT>(a, z, A, B, step);
     if (!ok || step + 1 >= a.step_end) break;
-    ok = cs_step<SPL>(a, z, B, A, step + 1);
+    ok = cs_step<NT, SPL, CLT>(a, z, B, A, step + 1);
     if (!ok) break;
   }
   if (!ok) {
     if (tid == 0) atomicOr(&a.sc->err, 8);
     return;   // (global w stays as the launch found it: the host rejects the run)
   }
-  for (int i = tid; i < z.Sb; i += CS_THREADS) a.w[z.b + G * i] = z.w_l[i];
+  for (int i = tid; i < z.Sb; i += NT) a.w[z.b + G * i] = z.w_l[i];
   if (a.tprof && z.b == 0 && tid == 0) {
     for (int i = 0; i < 6; ++i) a.tprof[i] += z.tp[i];
     a.tprof[15] += (unsigned long long)(a.step_end - a.step_begin);
@@ -397,7 +412,8 @@ __global__ void __launch_bounds__(CS_THREADS) dsgd_cs_step_kernel(CsArgs a) {
     __syncthreads();
     if (tid == 0) {
       const unsigned int* r4 = reinterpret_cast<const unsigned int*>(z.red);
-      const unsigned int tot = r4[0] + r4[1] + r4[2] + r4[3];
+      unsigned int tot = 0u;
+      for (int i = 0; i < NT / 64; ++i) tot += r4[i];
       if (tot) atomicAdd(&a.sc->n_active, (unsigned long long)tot);
     }
   }

@@ -148,9 +148,10 @@ struct dsgd_plan {
   CsHdr* d_cs_hdr = nullptr;
   unsigned int* d_cs_meta = nullptr;
   unsigned short* d_cs_rf = nullptr;
-  unsigned short* d_cs_col = nullptr;
-  float* d_cs_val = nullptr;
-  int cs_G = 0, cs_spl = 0, cs_slot_stride = 0, cs_row_stride = 0;
+  uint4* d_cs_col = nullptr;
+  float4* d_cs_val = nullptr;
+  unsigned short* d_cs_cl = nullptr;
+  int cs_G = 0, cs_spl = 0, cs_nt = 0, cs_slot_stride = 0, cs_row_stride = 0, cs_cl_stride = 0;
   std::vector<int> cs_shift;    // per step
   long long cs_layout = -1;     // the layout generation (column ranking) the slices were built for
   bool cs_ok = false;
@@ -193,6 +194,8 @@ struct dsgd_ctx {
   bool cs_enable = true;                // DSGD_CS=0: small steps of resident plans through the row-parallel kernels
   int cs_g = 0;                         // DSGD_CS_G: slices (8 or 16; 0 = 8 up to four hosted workers, 16 beyond)
   long long cs_max_mb = 1024;           // DSGD_CS_MAX_MB: largest column-slice layout of one plan
+  int cs_nt = 0;                        // DSGD_CS_NT=256: tuning runs with 256 lanes per slice where a plan's steps fit them
+  unsigned int cs_tag0 = 0;             // column-slice steps launched so far (the exchange granules' tags run on)
   unsigned long long* d_cs_x = nullptr; // exchange buffer of dsgd_cs_step_kernel: [2][CS_MAX_G][CS_XSTRIDE] granules
   unsigned int* d_cs_sync = nullptr;    // its arrival counter and abort word
   bool vt_enable = true;                // DSGD_VT=0: index-list steps of resident plans through dsgd_mb_grad_kernel
@@ -496,6 +499,7 @@ static int check_err_flag(dsgd_ctx* c) {
     HIP_TRY(hipMemsetAsync(&c->d_sc->err, 0, sizeof(int), c->stream));
     if (err & 2)
       return fail(DSGD_ESTATE, "fixed-point gradient accumulator left its safe band; the step is invalid");
+    if (err & 8 && c->d_cs_sync) HIP_TRY(hipMemsetAsync(c->d_cs_sync, 0, sizeof(unsigned int) * 2, c->stream));   // the abort word
     if (err & 8)
       return fail(DSGD_ESTATE, "the column-slice kernel's exchange between its workgroups timed out; the run is invalid "
                                "(DSGD_CS=0 selects the row-parallel kernels)");
@@ -845,6 +849,8 @@ static void cs_free(dsgd_plan* p) {
   (void)hipFree(p->d_cs_rf);
   (void)hipFree(p->d_cs_col);
   (void)hipFree(p->d_cs_val);
+  (void)hipFree(p->d_cs_cl);
+  p->d_cs_cl = nullptr;
   p->d_cs_hdr = nullptr;
   p->d_cs_meta = nullptr;
   p->d_cs_rf = nullptr;
@@ -902,42 +908,61 @@ static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
       return 1;
     }
   }
-  // pass 1: slots per (slice, step) -> the strides of the layout
-  long long max_slots = 1, max_rows = 1;
+  // pass 1: slots and distinct columns per (slice, step) -> the strides of the layout
+  long long max_slots = 1, max_rows = 1, max_cols = 1;
   p->cs_shift.assign((size_t)n_steps, 21);
   {
     std::vector<int> cnt((size_t)G);
+    std::vector<long long> seen((size_t)c->dp, -1);   // the last step that touched the rank
     for (long long s = 0; s < n_steps; ++s) {
-      std::vector<long long> slots((size_t)G, 0);
+      std::vector<long long> slots((size_t)G, 0), cols((size_t)G, 0);
       long long worst_list = 1;
       for (int k = 0; k < K; ++k) worst_list = std::max(worst_list, p->offsets[(size_t)(s * K + k) + 1] - p->offsets[(size_t)(s * K + k)]);
       for (long long t = p->offsets[(size_t)(s * K)]; t < p->offsets[(size_t)((s + 1) * K)]; ++t) {
         std::fill(cnt.begin(), cnt.end(), 0);
-        for (long long e = pre[(size_t)t]; e < pre[(size_t)t + 1]; ++e) ++cnt[(size_t)(ecol[(size_t)e] % G)];
+        for (long long e = pre[(size_t)t]; e < pre[(size_t)t + 1]; ++e) {
+          const int rank = ecol[(size_t)e];
+          ++cnt[(size_t)(rank % G)];
+          if (seen[(size_t)rank] != s) {
+            seen[(size_t)rank] = s;
+            ++cols[(size_t)(rank % G)];
+          }
+        }
         for (int b = 0; b < G; ++b) slots[(size_t)b] += (cnt[(size_t)b] + CS_L - 1) / CS_L;
       }
-      for (int b = 0; b < G; ++b) max_slots = std::max(max_slots, slots[(size_t)b]);
+      for (int b = 0; b < G; ++b) {
+        max_slots = std::max(max_slots, slots[(size_t)b]);
+        max_cols = std::max(max_cols, cols[(size_t)b]);
+      }
       max_rows = std::max(max_rows, p->offsets[(size_t)((s + 1) * K)] - p->offsets[(size_t)(s * K)]);
       int bits = 0;
       while ((1LL << bits) < worst_list) ++bits;
       p->cs_shift[(size_t)s] = 30 - bits;   // at most one contribution per row and column: a worker's sums stay below 2^30
     }
   }
-  if (max_slots > CS_MAX_SLOTS || max_rows > CS_MAX_SLOTS) return DSGD_OK;
+  if (max_slots > CS_MAX_SLOTS || max_rows > CS_MAX_SLOTS || max_cols > (long long)CS_MAX_CLT * CS_THREADS) return DSGD_OK;
+  const long long big = std::max(max_slots, max_rows);
+  const bool one_fits = big <= CS_THREADS && max_cols <= 4 * CS_THREADS;                  // one slot per lane
+  const bool narrow_fits = big <= 2 * CS_THREADS_NARROW && max_cols <= 8 * CS_THREADS_NARROW;
   const int slot_stride = (int)((max_slots + 63) / 64 * 64), row_stride = (int)((max_rows + 1 + 63) / 64 * 64);
+  const int cl_stride = (int)((max_cols + CS_THREADS - 1) / CS_THREADS * CS_THREADS);
   const long long cells = (long long)G * n_steps;
-  const long long bytes = cells * ((long long)slot_stride * (4 + CS_L * 2 + CS_L * 4) + (long long)row_stride * 2 + 8);
+  const long long bytes = cells * ((long long)slot_stride * (4 + CS_L * 2 + CS_L * 4) + (long long)row_stride * 2 + (long long)cl_stride * 2 + 8);
   if (bytes > c->cs_max_mb * (1LL << 20)) return DSGD_OK;
   // pass 2: the layout
   std::vector<CsHdr> hdr((size_t)cells);
   std::vector<unsigned int> meta((size_t)(cells * slot_stride), 0u);
   std::vector<unsigned short> rf((size_t)(cells * row_stride), (unsigned short)0);
-  std::vector<unsigned short> col((size_t)(cells * slot_stride * CS_L), (unsigned short)0);
-  std::vector<float> val((size_t)(cells * slot_stride * CS_L), 0.0f);
+  std::vector<unsigned short> col((size_t)(cells * slot_stride * CS_L), (unsigned short)0);   // [cell][2 pieces][slot][8]
+  std::vector<float> val((size_t)(cells * slot_stride * CS_L), 0.0f);                         // [cell][4 pieces][slot][4]
+  std::vector<unsigned short> clist((size_t)(cells * cl_stride), (unsigned short)0xffffu);
   {
     std::vector<std::vector<std::pair<unsigned short, float>>> bucket((size_t)G);
+    std::vector<std::vector<unsigned short>> touched((size_t)G);
+    std::vector<long long> seen((size_t)c->dp, -1);
     for (long long s = 0; s < n_steps; ++s) {
       std::vector<int> cur((size_t)G, 0);
+      for (auto& v : touched) v.clear();
       int r = 0;
       for (int k = 0; k < K; ++k) {
         for (long long t = p->offsets[(size_t)(s * K + k)]; t < p->offsets[(size_t)(s * K + k) + 1]; ++t, ++r) {
@@ -945,6 +970,10 @@ static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
           for (long long e = pre[(size_t)t]; e < pre[(size_t)t + 1]; ++e) {
             const int rank = ecol[(size_t)e];
             bucket[(size_t)(rank % G)].emplace_back((unsigned short)(rank / G), eval[(size_t)e]);
+            if (seen[(size_t)rank] != s) {
+              seen[(size_t)rank] = s;
+              touched[(size_t)(rank % G)].push_back((unsigned short)(rank / G));
+            }
           }
           const unsigned short ypos = c->h_label[(size_t)p->h_idx[(size_t)t]] > 0 ? (unsigned short)0x8000u : (unsigned short)0;
           for (int b = 0; b < G; ++b) {
@@ -954,9 +983,11 @@ static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
             for (size_t j0 = 0; j0 < bk.size(); j0 += CS_L) {
               const long long slot = cell * slot_stride + cur[(size_t)b];
               meta[(size_t)slot] = (unsigned int)r | ((unsigned int)k << 16);
+              const long long sl = cur[(size_t)b];
               for (size_t j = j0; j < std::min(bk.size(), j0 + CS_L); ++j) {
-                col[(size_t)(slot * CS_L + (long long)(j - j0))] = bk[j].first;
-                val[(size_t)(slot * CS_L + (long long)(j - j0))] = bk[j].second;
+                const long long q = (long long)(j - j0);   // entry q of the slot: piece q / 8 of its columns, q / 4 of its values
+                col[(size_t)((((cell * 2 + q / 8) * slot_stride) + sl) * 8 + q % 8)] = bk[j].first;
+                val[(size_t)((((cell * 4 + q / 4) * slot_stride) + sl) * 4 + q % 4)] = bk[j].second;
               }
               ++cur[(size_t)b];
             }
@@ -968,6 +999,8 @@ static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
         rf[(size_t)(cell * row_stride + r)] = (unsigned short)cur[(size_t)b];   // the sentinel: one past the last row's slots
         hdr[(size_t)cell].counts = (unsigned int)cur[(size_t)b] | ((unsigned int)r << 16);
         hdr[(size_t)cell].shift = p->cs_shift[(size_t)s];
+        std::sort(touched[(size_t)b].begin(), touched[(size_t)b].end());
+        std::copy(touched[(size_t)b].begin(), touched[(size_t)b].end(), clist.begin() + (size_t)(cell * cl_stride));
       }
     }
   }
@@ -976,6 +1009,8 @@ static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
   CS_SOFT(hipMalloc(&p->d_cs_rf, sizeof(unsigned short) * rf.size()));
   CS_SOFT(hipMalloc(&p->d_cs_col, sizeof(unsigned short) * col.size()));
   CS_SOFT(hipMalloc(&p->d_cs_val, sizeof(float) * val.size()));
+  CS_SOFT(hipMalloc(&p->d_cs_cl, sizeof(unsigned short) * clist.size()));
+  CS_SOFT(hipMemcpy(p->d_cs_cl, clist.data(), sizeof(unsigned short) * clist.size(), hipMemcpyHostToDevice));
   CS_SOFT(hipMemcpy(p->d_cs_hdr, hdr.data(), sizeof(CsHdr) * hdr.size(), hipMemcpyHostToDevice));
   CS_SOFT(hipMemcpy(p->d_cs_meta, meta.data(), sizeof(unsigned int) * meta.size(), hipMemcpyHostToDevice));
   CS_SOFT(hipMemcpy(p->d_cs_rf, rf.data(), sizeof(unsigned short) * rf.size(), hipMemcpyHostToDevice));
@@ -984,11 +1019,15 @@ static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
   if (!c->d_cs_x) {
     CS_SOFT(hipMalloc(&c->d_cs_x, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE));
     CS_SOFT(hipMalloc(&c->d_cs_sync, sizeof(unsigned int) * 2));
+    CS_SOFT(hipMemset(c->d_cs_x, 0, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE));
+    CS_SOFT(hipMemset(c->d_cs_sync, 0, sizeof(unsigned int) * 2));
   }
   p->cs_G = G;
-  p->cs_spl = std::max(max_slots, max_rows) <= 2 * CS_THREADS ? 2 : 4;
+  p->cs_nt = (c->cs_nt == CS_THREADS_NARROW && narrow_fits) ? CS_THREADS_NARROW : CS_THREADS;
+  p->cs_spl = (p->cs_nt == CS_THREADS && one_fits) ? 1 : 2;
   p->cs_slot_stride = slot_stride;
   p->cs_row_stride = row_stride;
+  p->cs_cl_stride = cl_stride;
   p->cs_ok = true;
   return DSGD_OK;
 }
@@ -1015,6 +1054,8 @@ static int launch_cs(dsgd_ctx* c, dsgd_plan* p, long long step_begin, long long 
   a.row_first = p->d_cs_rf;
   a.col = p->d_cs_col;
   a.val = p->d_cs_val;
+  a.clist = p->d_cs_cl;
+  a.cl_stride = p->cs_cl_stride;
   a.w = c->d_w;
   a.ds = c->d_ds;
   a.xbuf = c->d_cs_x;
@@ -1033,14 +1074,24 @@ static int launch_cs(dsgd_ctx* c, dsgd_plan* p, long long step_begin, long long 
   a.G = p->cs_G;
   a.K = p->n_workers;
   const size_t lds = sizeof(float) * (size_t)cs_lds_words(c->dp, a.G, a.K);
-  // a launch's step tags count from 1: the granules of the launch before it must not be mistaken for this one's
-  HIP_TRY(hipMemsetAsync(c->d_cs_x, 0, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE, c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_cs_sync, 0, sizeof(unsigned int) * 2, c->stream));
+  // a step's granules carry the count of column-slice steps the context has launched: nothing to clear between launches
+  // (until the 32-bit count would wrap)
+  const unsigned long long n_launch = (unsigned long long)(step_end - step_begin);
+  if ((unsigned long long)c->cs_tag0 + n_launch + 1ull >= (1ull << 32)) {
+    HIP_TRY(hipMemsetAsync(c->d_cs_x, 0, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE, c->stream));
+    c->cs_tag0 = 0;
+  }
+  a.tag0 = c->cs_tag0;
+  c->cs_tag0 += (unsigned int)n_launch;
   size_t slot = 0;
   DSGD_TRY(prof_begin(c, &slot));
   c->ctr_known = false;
-  if (p->cs_spl == 2) hipLaunchKernelGGL(dsgd_cs_step_kernel<2>, dim3((unsigned)a.G), dim3(CS_THREADS), lds, c->stream, a);
-  else hipLaunchKernelGGL(dsgd_cs_step_kernel<4>, dim3((unsigned)a.G), dim3(CS_THREADS), lds, c->stream, a);
+  if (p->cs_nt == CS_THREADS_NARROW)
+    hipLaunchKernelGGL((dsgd_cs_step_kernel<CS_THREADS_NARROW, 2, 8>), dim3((unsigned)a.G), dim3(CS_THREADS_NARROW), lds, c->stream, a);
+  else if (p->cs_spl == 1)
+    hipLaunchKernelGGL((dsgd_cs_step_kernel<CS_THREADS, 1, 4>), dim3((unsigned)a.G), dim3(CS_THREADS), lds, c->stream, a);
+  else
+    hipLaunchKernelGGL((dsgd_cs_step_kernel<CS_THREADS, 2, 8>), dim3((unsigned)a.G), dim3(CS_THREADS), lds, c->stream, a);
   HIP_TRY(hipGetLastError());
   DSGD_TRY(prof_end(c, slot));
   c->last_grad_kernel = "dsgd_cs_step_kernel";
@@ -1766,6 +1817,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_CS")) c->cs_enable = atoi(e) != 0;             // 0: small plan steps through the row-parallel kernels
   if (const char* e = getenv("DSGD_CS_G")) c->cs_g = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 0);
   if (const char* e = getenv("DSGD_CS_MAX_MB")) c->cs_max_mb = std::max(0, atoi(e));
+  if (const char* e = getenv("DSGD_CS_NT")) c->cs_nt = atoi(e) == CS_THREADS_NARROW ? CS_THREADS_NARROW : 0;
   if (const char* e = getenv("DSGD_VT_TPW")) c->vt_tpw = std::max(1, atoi(e));
   if (const char* e = getenv("DSGD_VT_PACK_MB")) c->vt_pack_mb = std::max(0, atoi(e));
   if (const char* e = getenv("DSGD_HSPLIT")) c->hsplit = atoi(e);                 // hot/cold split rank (tests: wide models)
@@ -1787,8 +1839,9 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_vt_grad_kernel<true>);
   DSGD_ATTR(dsgd_vt_grad_kernel<false>);
   DSGD_ATTR(dsgd_plan_kernel);
-  DSGD_ATTR(dsgd_cs_step_kernel<2>);
-  DSGD_ATTR(dsgd_cs_step_kernel<4>);
+  DSGD_ATTR((dsgd_cs_step_kernel<CS_THREADS, 1, 4>));
+  DSGD_ATTR((dsgd_cs_step_kernel<CS_THREADS, 2, 8>));
+  DSGD_ATTR((dsgd_cs_step_kernel<CS_THREADS_NARROW, 2, 8>));
   DSGD_ATTR(dsgd_wseg_kernel<true>);
   DSGD_ATTR(dsgd_wseg_kernel<false>);
   DSGD_ATTR(dsgd_wseg_bound_kernel);
@@ -2373,6 +2426,7 @@ int dsgd_synchronize(dsgd_ctx* c, dsgd_batch_stats* stats) {
   if (err & 2)
     return fail(DSGD_ESTATE, "fixed-point gradient accumulator left its safe band; the steps since the last "
                              "synchronize are invalid");
+  if (err & 8 && c->d_cs_sync) HIP_TRY(hipMemsetAsync(c->d_cs_sync, 0, sizeof(unsigned int) * 2, c->stream));   // the abort word
   if (err & 8)
     return fail(DSGD_ESTATE, "the column-slice kernel's exchange between its workgroups timed out; the steps since the last "
                              "synchronize are invalid (DSGD_CS=0 selects the row-parallel kernels)");
@@ -2447,6 +2501,7 @@ int dsgd_plan_destroy(dsgd_ctx* c, dsgd_plan* p) {
   (void)hipFree(p->d_cs_rf);
   (void)hipFree(p->d_cs_col);
   (void)hipFree(p->d_cs_val);
+  (void)hipFree(p->d_cs_cl);
   delete p;
   return DSGD_OK;
 }
