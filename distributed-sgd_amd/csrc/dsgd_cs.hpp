@@ -115,27 +115,58 @@ __device__ __forceinline__ void cs_issue(const CsArgs& a, int b, long long step,
   }
 }
 
-// the G granules of exchange slot `at` (a row, or CS_MAX_SLOTS for the shares of w . ds), polled until all carry `tag`;
-// the values added in slice order.  false = given up (the abort word is raised for everybody).
-__device__ __forceinline__ bool cs_gather(const unsigned long long* xall, int G, int at, unsigned int tag, unsigned int* abort_word,
-                                          float& sum) {
-  unsigned long long v[CS_MAX_G];
+// granule `p` of slice g behind a buffer resource: an agent-scope (sc1) 8-byte load
+typedef unsigned int cs_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned long long cs_granule(__amdgpu_buffer_rsrc_t rs, unsigned int p, int g) {
+  const cs_u32x2 x = __builtin_bit_cast(cs_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(p * 8u), g * CS_XSTRIDE * 8, 16 /* sc1 */));
+  return ((unsigned long long)x.y << 32) | x.x;
+}
+
+// the G granules of each of N exchange slots at[] (a row, or CS_MAX_SLOTS for the shares of w . ds; at < 0: none), polled
+// TOGETHER until all carry `tag` (one slot after the other was one round trip per slot: 2.6 us of a 4 x 200 step); the
+// values added in slice order.  false = given up (the abort word is raised for everybody).
+template <int N>
+__device__ __forceinline__ bool cs_gather(const unsigned long long* xall, int G, const int (&at)[N], unsigned int tag,
+                                          unsigned int* abort_word, float (&sum)[N]) {
+  unsigned int v[N][CS_MAX_G];   // (the values; the tags are checked as they arrive)
+  // ONE scalar base and a 32-bit lane offset per slot (global_load ... v_off, s[base]): a 64-bit lane address per granule
+  // was 64 registers of addresses alone
+  // buffer loads: ONE resource, the slice's stride in a scalar, a 32-bit lane offset per slot -- a 64-bit lane address per
+  // granule was 64 registers of addresses alone
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(xall), 0, G * CS_XSTRIDE * 8, 0x00020000);
+  bool any = false;
+#pragma unroll
+  for (int n = 0; n < N; ++n) any = any || at[n] >= 0;
+  if (!any) return true;
   for (unsigned int spin = 0;; ++spin) {
+    asm volatile("" ::: "memory");   // (every poll reads memory again)
     bool all = true;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      v[g] = __hip_atomic_load(&xall[(long long)g * CS_XSTRIDE + at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      all = all && (unsigned int)(v[g] >> 32) == tag;
+    for (int n = 0; n < N; ++n) {
+      const unsigned int p = at[n] < 0 ? 0u : (unsigned int)at[n];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const unsigned long long x = cs_granule(rs, p, g);
+        v[n][g] = (unsigned int)x;
+        all = all && ((unsigned int)(x >> 32) == tag || at[n] < 0);
+      }
     }
     if (G > 8) {   // (workgroup-uniform: G is 8 or 16)
 #pragma unroll
-      for (int g = 8; g < CS_MAX_G; ++g) {
-        v[g] = __hip_atomic_load(&xall[(long long)g * CS_XSTRIDE + at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        all = all && (unsigned int)(v[g] >> 32) == tag;
+      for (int n = 0; n < N; ++n) {
+        const unsigned int p = at[n] < 0 ? 0u : (unsigned int)at[n];
+#pragma unroll
+        for (int g = 8; g < CS_MAX_G; ++g) {
+          const unsigned long long x = cs_granule(rs, p, g);
+          v[n][g] = (unsigned int)x;
+          all = all && ((unsigned int)(x >> 32) == tag || at[n] < 0);
+        }
       }
     } else {
 #pragma unroll
-      for (int g = 8; g < CS_MAX_G; ++g) v[g] = 0ull;
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int g = 8; g < CS_MAX_G; ++g) v[n][g] = 0u;
     }
     if (all) break;
     if ((spin & 63u) == 63u) {
@@ -146,10 +177,13 @@ __device__ __forceinline__ bool cs_gather(const unsigned long long* xall, int G,
     }
     __builtin_amdgcn_s_sleep(1);
   }
-  float d = 0.0f;
 #pragma unroll
-  for (int g = 0; g < CS_MAX_G; ++g) d += __uint_as_float((unsigned int)v[g]);   // (the zeros of an 8-slice run change nothing)
-  sum = d;
+  for (int n = 0; n < N; ++n) {
+    float d = 0.0f;
+#pragma unroll
+    for (int g = 0; g < CS_MAX_G; ++g) d += __uint_as_float(v[n][g]);   // (the zeros of an 8-slice run change nothing)
+    sum[n] = d;
+  }
   return true;
 }
 
@@ -213,7 +247,7 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, 
   const int n_rows = __builtin_amdgcn_readfirstlane((int)(cur.h.x >> 16));
   const int shift = __builtin_amdgcn_readfirstlane((int)cur.h.y);
   const float qscale = ldexpf(1.0f, shift - a.vexp);
-  const double inv_scale = (double)ldexpf(1.0f, a.vexp - shift);
+  const float inv_scale = ldexpf(1.0f, a.vexp - shift);
   const bool prof = a.tprof != nullptr && b == 0 && tid == 0;
   auto stamp = [&](int i) {
     if (prof) {
@@ -258,24 +292,34 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, 
   stamp(1);
   // ---- 3: every slice's granules of this thread's rows: x.w in slice order, the gate, the row's coefficient ----
   const unsigned long long* xall = a.xbuf + (long long)(z.n_rel & 1u) * G * CS_XSTRIDE;
-  bool got = true;
+  // (the shares of w . ds ride as "row" n_rows -- s = 2 lambda (w . ds) of the weights this step's gradients see -- unless
+  //  every lane position holds a row)
+  int at[SPL];
+  float dd[SPL];
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
     const int r = tid + NT * i;
-    if (r < n_rows && got) {
-      float d = 0.0f;
-      got = cs_gather(xall, G, r, tag, &a.sync[1], d);
+    at[i] = r < n_rows ? r : (r == n_rows ? CS_MAX_SLOTS : -1);
+  }
+  bool got = cs_gather<SPL>(xall, G, at, tag, &a.sync[1], dd);
+#pragma unroll
+  for (int i = 0; i < SPL; ++i) {
+    const int r = tid + NT * i;
+    if (r < n_rows) {
       const bool ypos = (cur.rf[i] & 0x8000u) != 0u;
-      const float yd = ypos ? d : -d;
+      const float yd = ypos ? dd[i] : -dd[i];
       const bool active = got && !(yd < 0.0f);                 // ref: core/ml/SparseSVM.scala:27-28
       coef[r] = active ? (ypos ? qscale : -qscale) : 0.0f;
       z.n_act += (active && b == 0) ? 1u : 0u;
+    } else if (r == n_rows) {
+      red[16] = a.lambda * 2.0f * dd[i];
     }
   }
-  if (tid == NT - 1) {   // s = 2 lambda (w . ds) of the weights this step's gradients see: the slices' shares in slice order
-    float dsum = 0.0f;
-    got = got && cs_gather(xall, G, CS_MAX_SLOTS, tag, &a.sync[1], dsum);
-    red[16] = a.lambda * 2.0f * dsum;
+  if (n_rows == NT * SPL && tid == NT - 1) {
+    const int at1[1] = {CS_MAX_SLOTS};
+    float d1[1];
+    got = cs_gather<1>(xall, G, at1, tag, &a.sync[1], d1) && got;
+    red[16] = a.lambda * 2.0f * d1[0];
   }
   if (!got) reinterpret_cast<int*>(red)[17] = 1;
   cs_barrier();
@@ -327,7 +371,9 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, 
       for (int k = 0; k < CS_MAX_K; ++k) {
         if (k < K && t[u][k] != 0) {
           z.acc[k * Sp + cidx[u]] = 0;
-          float gv = filt((float)((double)t[u][k] * inv_scale));   // one rounding of the worker's exact sum
+          // one rounding of the worker's exact sum (int -> fp32 rounds it to 24 bits; the power of two is exact: the same
+          // bits as rounding the fp64 product, as dsgd_fix_reduce_apply_kernel does)
+          float gv = filt((float)t[u][k] * inv_scale);
           if (add && gv != 0.0f) gv = filt(gv + s);                // ref: core/ml/SparseSVM.scala:31, math/Vec.scala:65-75
           gsum = filt(gsum + gv);                                  // Vec.sum over the workers
         }

@@ -191,9 +191,13 @@ def test_ragged_rows_and_long_rows():
     o, eng = make_pair(data, n_train)
     with eng:
         eng.set_weights(nonzero_weights(data.dim, rng, 20000))
-        for k, b in ((3, 100), (2, 200), (1, 64)):   # (a tenth of the rows needs ten slots per slice: 2 x 300 would leave the 1,024 slots)
+        for k, b in ((3, 100), (2, 150), (1, 64)):   # (a tenth of the rows needs ten slots per slice)
             for lists in batches(rng, n_train, k, b, 2):
                 plan_step(o, eng, lists, 0.5 * 100 / b, "column_slices_ragged")
+        # forty 1,200-entry rows in one step touch more than the 4,096 listed columns of a slice (of its 5,905): such a
+        # step is not a small one -- the plan falls back to the row-parallel kernels, same answer
+        for lists in batches(rng, n_train, 2, 200, 1):
+            plan_step(o, eng, lists, 0.25, "column_slices_ragged", kernel="dsgd_vt_grad_kernel")
 
 
 def test_eligibility_and_fallbacks(monkeypatch):
