@@ -70,7 +70,7 @@ struct CsArgs {
 };
 
 __host__ __device__ constexpr int cs_lds_words(int dp, int G, int K) {
-  return (2 + K) * ((((dp + G - 1) / G) + 3) & ~3) + 2 * CS_MAX_SLOTS + 32;
+  return (2 + K) * ((((dp + G - 1) / G) + 4) & ~3) + 2 * CS_MAX_SLOTS + 32;   // (a slice is padded by 1 .. 4 columns)
 }
 
 template <int SPL, int CLT>
@@ -226,6 +226,42 @@ struct CsState {
   unsigned long long* tp;      // tuning runs (LDS, thread 0 of slice 0): cycles by phase (dot, publish, exchange, scatter, sweep, reduce), [6] last stamp
 };
 
+// The listed columns of a step, KK hosted workers: per worker ONE rounding of the exact sum, the support-only
+// regulariser, the fold over the workers, the mean, the update -- dsgd_fix_reduce_apply_kernel's arithmetic
+// (fra_update_and_scalars), here without a branch: a lane without a column works on the slice's padding column (always
+// there: zero weight, zero accumulators), an untouched worker contributes the zero it would have been skipped for.
+template <int KK, int CLT>
+__device__ __forceinline__ void cs_sweep(CsState& z, const unsigned short (&cl)[CLT], int Sp, float inv_scale, float s, bool add, float lr) {
+  constexpr int U = CLT < 4 ? CLT : 4;
+#pragma unroll
+  for (int i0 = 0; i0 < CLT; i0 += U) {
+    int c[U], t[U][KK];
+    float wo[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {   // every LDS request of four columns before the first is used
+      c[u] = cl[i0 + u] == 0xffffu ? Sp - 1 : (int)cl[i0 + u];
+#pragma unroll
+      for (int k = 0; k < KK; ++k) t[u][k] = z.acc[k * Sp + c[u]];
+      wo[u] = z.w_l[c[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float gsum = 0.0f;
+#pragma unroll
+      for (int k = 0; k < KK; ++k) {
+        z.acc[k * Sp + c[u]] = 0;
+        // one rounding of the worker's exact sum (int -> fp32 rounds it to 24 bits; the power of two is exact: the same
+        // bits as rounding the fp64 product, as dsgd_fix_reduce_apply_kernel does)
+        const float g0 = filt((float)t[u][k] * inv_scale);
+        const float g1 = filt(g0 + s);                                 // ref: core/ml/SparseSVM.scala:31, math/Vec.scala:65-75
+        gsum = filt(gsum + ((add && g0 != 0.0f) ? g1 : g0));           // Vec.sum over the workers
+      }
+      const float upd = filt(filt(gsum / (float)KK) * lr);             // Vec.mean, learningRate * grad (ref: core/Master.scala:194-197)
+      z.w_l[c[u]] = gsum != 0.0f ? filt(wo[u] - upd) : wo[u];
+    }
+  }
+}
+
 // the 16 columns / values of slot i of a register set (compile-time indices only: the set stays in registers)
 #define CS_COL(R, i, j) ((int)(((j) & 1) ? ((&(R).c[i][(j) >> 3].x)[((j) >> 1) & 3] >> 16) : ((&(R).c[i][(j) >> 3].x)[((j) >> 1) & 3] & 0xffffu)))
 #define CS_VAL(R, i, j) ((&(R).v[i][(j) >> 2].x)[(j) & 3])
@@ -350,39 +386,15 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, 
   //         the slice spent 9.8 of a 3 x 100 step's 15.8 us on the ~80 % it does not touch): per worker ONE rounding
   //         of the exact sum, the support-only regulariser, the fold over the workers, the mean, the update --
   //         dsgd_fix_reduce_apply_kernel's arithmetic (fra_update_and_scalars) ----
-#pragma unroll
-  for (int i0 = 0; i0 < CLT; i0 += 4) {
-    int cidx[4], t[4][CS_MAX_K];
-    float wo[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {   // every LDS request of four columns before the first is used
-      const unsigned int cl = cur.cl[i0 + u];
-      cidx[u] = cl == 0xffffu ? -1 : (int)cl;
-      const int cc = cidx[u] < 0 ? 0 : cidx[u];
-#pragma unroll
-      for (int k = 0; k < CS_MAX_K; ++k) t[u][k] = k < K ? z.acc[k * Sp + cc] : 0;
-      wo[u] = z.w_l[cc];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (cidx[u] < 0) continue;
-      float gsum = 0.0f;
-#pragma unroll
-      for (int k = 0; k < CS_MAX_K; ++k) {
-        if (k < K && t[u][k] != 0) {
-          z.acc[k * Sp + cidx[u]] = 0;
-          // one rounding of the worker's exact sum (int -> fp32 rounds it to 24 bits; the power of two is exact: the same
-          // bits as rounding the fp64 product, as dsgd_fix_reduce_apply_kernel does)
-          float gv = filt((float)t[u][k] * inv_scale);
-          if (add && gv != 0.0f) gv = filt(gv + s);                // ref: core/ml/SparseSVM.scala:31, math/Vec.scala:65-75
-          gsum = filt(gsum + gv);                                  // Vec.sum over the workers
-        }
-      }
-      if (gsum != 0.0f) {
-        const float upd = filt(filt(gsum / (float)K) * a.lr);      // Vec.mean, learningRate * grad (ref: core/Master.scala:194-197)
-        z.w_l[cidx[u]] = filt(wo[u] - upd);
-      }
-    }
+  switch (K) {   // (straight-line code per worker count: the loop to CS_MAX_K under "k < K" was a branch per worker and column)
+    case 1: cs_sweep<1, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
+    case 2: cs_sweep<2, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
+    case 3: cs_sweep<3, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
+    case 4: cs_sweep<4, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
+    case 5: cs_sweep<5, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
+    case 6: cs_sweep<6, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
+    case 7: cs_sweep<7, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
+    default: cs_sweep<8, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
   }
   cs_barrier();
   // ... and this slice's share of w . ds of the new weights: all columns, four per lane and round (padding holds zeros)
@@ -411,7 +423,7 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
   z.b = blockIdx.x;
   const int S = (a.dp + G - 1) / G;                    // local columns of the widest slice
   z.Sb = (a.dp - z.b + G - 1) / G;                     // ... of this one (ranks b, b + G, ...)
-  z.Sp = (S + 3) & ~3;
+  z.Sp = (S + 4) & ~3;                                 // (at least one padding column: cs_sweep parks idle lanes on it)
   z.w_l = lds;
   z.ds_l = lds + z.Sp;
   z.acc = reinterpret_cast<int*>(lds + 2 * z.Sp);

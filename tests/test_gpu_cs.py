@@ -194,10 +194,10 @@ def test_ragged_rows_and_long_rows():
         for k, b in ((3, 100), (2, 150), (1, 64)):   # (a tenth of the rows needs ten slots per slice)
             for lists in batches(rng, n_train, k, b, 2):
                 plan_step(o, eng, lists, 0.5 * 100 / b, "column_slices_ragged")
-        # forty 1,200-entry rows in one step touch more than the 4,096 listed columns of a slice (of its 5,905): such a
+        # eighty 1,200-entry rows in one step touch more than the 4,096 listed columns of a slice (of its 5,905): such a
         # step is not a small one -- the plan falls back to the row-parallel kernels, same answer
-        for lists in batches(rng, n_train, 2, 200, 1):
-            plan_step(o, eng, lists, 0.25, "column_slices_ragged", kernel="dsgd_vt_grad_kernel")
+        for lists in batches(rng, n_train, 2, 400, 1):
+            plan_step(o, eng, lists, 0.125, "column_slices_ragged", kernel="dsgd_vt_grad_kernel")
 
 
 def test_eligibility_and_fallbacks(monkeypatch):
