@@ -44,7 +44,8 @@ constexpr int CS_MAX_CLT = 8;                           // listed columns per la
 
 struct CsHdr {                // per (slice, step)
   unsigned int counts;        // slots of the step inside the slice (low 16 bits) | rows of the step << 16
-  int shift;                  // fixed-point shift of the step: 30 - ceil(log2(largest list)) (the same in every slice)
+  int shift;                  // fixed-point shift of the step: 30 - ceil(log2(largest list)) (the same in every slice), low 16 bits
+                              //   | listed columns of the step inside the slice << 16
 };
 
 struct CsArgs {
@@ -230,15 +231,17 @@ struct CsState {
 // regulariser, the fold over the workers, the mean, the update -- dsgd_fix_reduce_apply_kernel's arithmetic
 // (fra_update_and_scalars), here without a branch: a lane without a column works on the slice's padding column (always
 // there: zero weight, zero accumulators), an untouched worker contributes the zero it would have been skipped for.
-template <int KK, int CLT>
-__device__ __forceinline__ void cs_sweep(CsState& z, const unsigned short (&cl)[CLT], int Sp, float inv_scale, float s, bool add, float lr) {
-  constexpr int U = CLT < 4 ? CLT : 4;
+template <int NT, int KK, int CLT>
+__device__ __forceinline__ void cs_sweep(CsState& z, const unsigned short (&cl)[CLT], int n_cols, int Sp, float inv_scale, float s, bool add,
+                                         float lr) {
+  constexpr int U = 2;   // columns per lane and round: every LDS request of a round before the first is used
 #pragma unroll
   for (int i0 = 0; i0 < CLT; i0 += U) {
+    if (i0 * NT >= n_cols) break;   // (workgroup-uniform: the list is dense from entry 0)
     int c[U], t[U][KK];
     float wo[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {   // every LDS request of four columns before the first is used
+    for (int u = 0; u < U; ++u) {
       c[u] = cl[i0 + u] == 0xffffu ? Sp - 1 : (int)cl[i0 + u];
 #pragma unroll
       for (int k = 0; k < KK; ++k) t[u][k] = z.acc[k * Sp + c[u]];
@@ -281,7 +284,8 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, 
   float* const red = z.red;
   const int n_slots = __builtin_amdgcn_readfirstlane((int)(cur.h.x & 0xffffu));
   const int n_rows = __builtin_amdgcn_readfirstlane((int)(cur.h.x >> 16));
-  const int shift = __builtin_amdgcn_readfirstlane((int)cur.h.y);
+  const int shift = __builtin_amdgcn_readfirstlane((int)(cur.h.y & 0xffffu));
+  const int n_cols = __builtin_amdgcn_readfirstlane((int)(cur.h.y >> 16));
   const float qscale = ldexpf(1.0f, shift - a.vexp);
   const float inv_scale = ldexpf(1.0f, a.vexp - shift);
   const bool prof = a.tprof != nullptr && b == 0 && tid == 0;
@@ -387,14 +391,14 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, 
   //         of the exact sum, the support-only regulariser, the fold over the workers, the mean, the update --
   //         dsgd_fix_reduce_apply_kernel's arithmetic (fra_update_and_scalars) ----
   switch (K) {   // (straight-line code per worker count: the loop to CS_MAX_K under "k < K" was a branch per worker and column)
-    case 1: cs_sweep<1, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
-    case 2: cs_sweep<2, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
-    case 3: cs_sweep<3, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
-    case 4: cs_sweep<4, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
-    case 5: cs_sweep<5, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
-    case 6: cs_sweep<6, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
-    case 7: cs_sweep<7, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
-    default: cs_sweep<8, CLT>(z, cur.cl, Sp, inv_scale, s, add, a.lr); break;
+    case 1: cs_sweep<NT, 1, CLT>(z, cur.cl, n_cols, Sp, inv_scale, s, add, a.lr); break;
+    case 2: cs_sweep<NT, 2, CLT>(z, cur.cl, n_cols, Sp, inv_scale, s, add, a.lr); break;
+    case 3: cs_sweep<NT, 3, CLT>(z, cur.cl, n_cols, Sp, inv_scale, s, add, a.lr); break;
+    case 4: cs_sweep<NT, 4, CLT>(z, cur.cl, n_cols, Sp, inv_scale, s, add, a.lr); break;
+    case 5: cs_sweep<NT, 5, CLT>(z, cur.cl, n_cols, Sp, inv_scale, s, add, a.lr); break;
+    case 6: cs_sweep<NT, 6, CLT>(z, cur.cl, n_cols, Sp, inv_scale, s, add, a.lr); break;
+    case 7: cs_sweep<NT, 7, CLT>(z, cur.cl, n_cols, Sp, inv_scale, s, add, a.lr); break;
+    default: cs_sweep<NT, 8, CLT>(z, cur.cl, n_cols, Sp, inv_scale, s, add, a.lr); break;
   }
   cs_barrier();
   // ... and this slice's share of w . ds of the new weights: all columns, four per lane and round (padding holds zeros)

@@ -277,6 +277,10 @@ struct dsgd_ctx {
   DevScalars* h_sc = nullptr;  // pinned
   // per-request steps: {n_active, err} written by the request's last kernel into host-mapped memory (no copy back);
   // n_active is read as a DIFFERENCE against the value the host last saw, so the request needs no memset either
+  int* h_req = nullptr;                   // host-mapped index lists of a per-request step (REQ_MAPPED_ITEMS entries) ...
+  int* d_req = nullptr;                   // ... their device address
+  const int* cur_idx = nullptr;           // where stage_lists put the lists of the request in flight
+  bool req_mapped = true;                 // DSGD_REQ_MAPPED=0: always the copy on the stream
   unsigned long long* h_mail = nullptr;   // host-mapped, two words
   unsigned long long* d_mail = nullptr;   // ... its device address
   bool ctr_known = false;                 // the host knows the device's n_active (ctr_last) and that err is clear
@@ -998,7 +1002,7 @@ static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
         const long long cell = (long long)b * n_steps + s;
         rf[(size_t)(cell * row_stride + r)] = (unsigned short)cur[(size_t)b];   // the sentinel: one past the last row's slots
         hdr[(size_t)cell].counts = (unsigned int)cur[(size_t)b] | ((unsigned int)r << 16);
-        hdr[(size_t)cell].shift = p->cs_shift[(size_t)s];
+        hdr[(size_t)cell].shift = p->cs_shift[(size_t)s] | (int)((unsigned int)touched[(size_t)b].size() << 16);
         std::sort(touched[(size_t)b].begin(), touched[(size_t)b].end());
         std::copy(touched[(size_t)b].begin(), touched[(size_t)b].end(), clist.begin() + (size_t)(cell * cl_stride));
       }
@@ -1817,6 +1821,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_CS")) c->cs_enable = atoi(e) != 0;             // 0: small plan steps through the row-parallel kernels
   if (const char* e = getenv("DSGD_CS_G")) c->cs_g = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 0);
   if (const char* e = getenv("DSGD_CS_MAX_MB")) c->cs_max_mb = std::max(0, atoi(e));
+  if (const char* e = getenv("DSGD_REQ_MAPPED")) c->req_mapped = atoi(e) != 0;
   if (const char* e = getenv("DSGD_CS_NT")) c->cs_nt = atoi(e) == CS_THREADS_NARROW ? CS_THREADS_NARROW : 0;
   if (const char* e = getenv("DSGD_VT_TPW")) c->vt_tpw = std::max(1, atoi(e));
   if (const char* e = getenv("DSGD_VT_PACK_MB")) c->vt_pack_mb = std::max(0, atoi(e));
@@ -1938,6 +1943,7 @@ int dsgd_destroy(dsgd_ctx* c) {
   (void)hipFree(c->d_cs_sync);
   if (c->h_sc) (void)hipHostFree(c->h_sc);
   if (c->h_mail) (void)hipHostFree(c->h_mail);
+  if (c->h_req) (void)hipHostFree(c->h_req);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   c->mu.unlock();
   delete c;
@@ -2190,6 +2196,7 @@ int dsgd_get_weights(dsgd_ctx* c, float* w_out) {
 }
 
 // stage host index lists for n_workers workers; returns the largest list length
+constexpr long long REQ_MAPPED_ITEMS = 16384;   // index entries of one request read in place from host memory (64 KiB)
 static int stage_lists(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int64_t* n_per_worker, int n_workers,
                        long long* max_items, long long* total) {
   long long tot = 0, mx = 0;
@@ -2200,19 +2207,36 @@ static int stage_lists(dsgd_ctx* c, const int32_t* const* idx_per_worker, const 
     tot += n_per_worker[k];
     mx = std::max<long long>(mx, n_per_worker[k]);
   }
-  DSGD_TRY(ensure_idx(c, tot));
   std::vector<WorkSeg> segs(n_workers);
   long long off = 0;
-  // one copy for all lists, on the stream (behind the previous step's kernels, which may still be reading d_idx)
-  DSGD_TRY(pin_acquire(c->pin_idx, sizeof(int) * (size_t)tot));
-  for (int k = 0; k < n_workers; ++k) {
-    memcpy(static_cast<int*>(c->pin_idx.p) + off, idx_per_worker[k], sizeof(int) * (size_t)n_per_worker[k]);
-    segs[k].begin = off;
-    segs[k].end = off + n_per_worker[k];
-    off += n_per_worker[k];
+  if (c->req_mapped && tot <= REQ_MAPPED_ITEMS) {
+    // the reference's batch sizes: the lists go into a host-mapped buffer the kernels read in place -- no copy on the
+    // stream in front of the launch (every per-request entry point returns behind its kernels: the buffer is free again)
+    if (!c->h_req) {
+      HIP_TRY(hipHostMalloc(&c->h_req, sizeof(int) * (size_t)REQ_MAPPED_ITEMS, hipHostMallocMapped));
+      HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_req), c->h_req, 0));
+    }
+    for (int k = 0; k < n_workers; ++k) {
+      memcpy(c->h_req + off, idx_per_worker[k], sizeof(int) * (size_t)n_per_worker[k]);
+      segs[k].begin = off;
+      segs[k].end = off + n_per_worker[k];
+      off += n_per_worker[k];
+    }
+    c->cur_idx = c->d_req;
+  } else {
+    DSGD_TRY(ensure_idx(c, tot));
+    // one copy for all lists, on the stream (behind the previous step's kernels, which may still be reading d_idx)
+    DSGD_TRY(pin_acquire(c->pin_idx, sizeof(int) * (size_t)tot));
+    for (int k = 0; k < n_workers; ++k) {
+      memcpy(static_cast<int*>(c->pin_idx.p) + off, idx_per_worker[k], sizeof(int) * (size_t)n_per_worker[k]);
+      segs[k].begin = off;
+      segs[k].end = off + n_per_worker[k];
+      off += n_per_worker[k];
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_idx, c->pin_idx.p, sizeof(int) * (size_t)tot, hipMemcpyHostToDevice, c->stream));
+    DSGD_TRY(pin_sent(c, c->pin_idx));
+    c->cur_idx = c->d_idx;
   }
-  HIP_TRY(hipMemcpyAsync(c->d_idx, c->pin_idx.p, sizeof(int) * (size_t)tot, hipMemcpyHostToDevice, c->stream));
-  DSGD_TRY(pin_sent(c, c->pin_idx));
   DSGD_TRY(upload_segs(c, segs));
   *max_items = mx;
   *total = tot;
@@ -2235,7 +2259,7 @@ int dsgd_gradient(dsgd_ctx* c, const float* w, const int32_t* idx, int64_t n, fl
   long long mx = 0, tot = 0;
   const int64_t nn = n;
   DSGD_TRY(stage_lists(c, &idx, &nn, 1, &mx, &tot));
-  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, 1, mx));
+  DSGD_TRY(launch_grad(c, c->cur_idx, c->d_segs, 1, mx));
   hipLaunchKernelGGL(dsgd_regularize_kernel, dim3((c->dp + 1023) / 1024, 1), dim3(1024), 0, c->stream, c->d_g,
                      (long long)c->dp, c->dp, c->d_sc);
   HIP_TRY(hipGetLastError());
@@ -2325,14 +2349,14 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
     if (fits && c->prof) {   // the reference's batch sizes: one persistent workgroup does the whole closure
       DSGD_TRY(reset_counters(c));
       DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
-      DSGD_TRY(launch_plan_kernel(c, c->d_idx, c->d_segs, 0, 1, lr));
+      DSGD_TRY(launch_plan_kernel(c, c->cur_idx, c->d_segs, 0, 1, lr));
       return finish_stats(c, stats, tot);
     }
     if (fits) {   // ... its statistics through the host-mapped mailbox (see below)
       if (!c->ctr_known) DSGD_TRY(reset_counters(c));
       const unsigned long long before = c->ctr_last;
       DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
-      DSGD_TRY(launch_plan_kernel(c, c->d_idx, c->d_segs, 0, 1, lr, true));
+      DSGD_TRY(launch_plan_kernel(c, c->cur_idx, c->d_segs, 0, 1, lr, true));
       return finish_mail(c, stats, tot, before);
     }
   }
@@ -2341,7 +2365,7 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
   if (c->comm || c->prof) {   // (the collective path / profiling brackets: the plain read-back)
     DSGD_TRY(reset_counters(c));
     DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
-    DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, n_workers, mx, true));
+    DSGD_TRY(launch_grad(c, c->cur_idx, c->d_segs, n_workers, mx, true));
     DSGD_TRY(launch_finish_sync(c, n_workers, lr));
     return finish_stats(c, stats, tot);
   }
@@ -2350,7 +2374,7 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
   if (!c->ctr_known) DSGD_TRY(reset_counters(c));
   const unsigned long long before = c->ctr_last;
   DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
-  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, n_workers, mx, true));
+  DSGD_TRY(launch_grad(c, c->cur_idx, c->d_segs, n_workers, mx, true));
   DSGD_TRY(launch_finish_sync(c, n_workers, lr, true));
   return finish_mail(c, stats, tot, before);
 }
@@ -2686,7 +2710,7 @@ int dsgd_async_step(dsgd_ctx* c, const int32_t* idx, int64_t n, float lr, float*
   long long mx = 0, tot = 0;
   const int64_t nn = n;
   DSGD_TRY(stage_lists(c, &idx, &nn, 1, &mx, &tot));
-  DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, 1, mx));
+  DSGD_TRY(launch_grad(c, c->cur_idx, c->d_segs, 1, mx));
   hipLaunchKernelGGL(dsgd_async_finish_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_w, c->d_g, c->dp, c->d_ds, (float)n,
                      lr, (float)c->cfg.lambda, delta_out ? c->d_tmp : (float*)nullptr, c->d_sc);
   HIP_TRY(hipGetLastError());
@@ -3299,7 +3323,7 @@ int dsgd_sync_step_devices(dsgd_ctx* const* ctxs, int32_t n_ctx, const int32_t* 
     long long mx = 0;
     DSGD_TRY(stage_lists(c, idx_per_worker + (size_t)i * workers_per_ctx, n_per_worker + (size_t)i * workers_per_ctx, workers_per_ctx,
                          &mx, &totals[(size_t)i]));
-    DSGD_TRY(launch_grad(c, c->d_idx, c->d_segs, workers_per_ctx, mx, true));
+    DSGD_TRY(launch_grad(c, c->cur_idx, c->d_segs, workers_per_ctx, mx, true));
     DSGD_TRY(finish_pre(c, workers_per_ctx, lr, false));
   }
   return devices_step_finish(ctxs, n_ctx, workers_per_ctx, lr, totals, stats);

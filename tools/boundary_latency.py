@@ -50,6 +50,8 @@ with dsgd_amd.Engine(data.dim, 1e-5) as eng:
         rec["forward_host_w_us"] = timed(lambda: eng.forward(nxt(), w=w), 300)
         # the fused step with host index lists (one worker): idx uploaded per call, nothing comes back but statistics
         rec["sync_step_host_idx_us"] = timed(lambda: eng.sync_step([nxt()], 0.0), 300)
+        if b == 100:   # the reference's own configuration (application.conf:15,27): three hosted workers per request
+            rec["sync_step_3x100_host_idx_us"] = timed(lambda: eng.sync_step([nxt(), nxt(), nxt()], 0.0), 300)
         # resident plan (what bench.py's sweep times): nothing crosses PCIe inside the loop
         plan = eng.plan([[l] for l in lists])
         eng.plan_run(plan, 0, len(lists), 0.0)

@@ -19,6 +19,7 @@ import dsgd_amd  # noqa: E402
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2000000
 quick = "--quick" in sys.argv
+single = "--single" in sys.argv   # one launch per step (the dispatch table of a trace then shows the cost of ONE step's launch)
 only = [tuple(int(x) for x in a.split("=")[1].split("x")) for a in sys.argv if a.startswith("--only=")]   # e.g. --only=1x65536
 data = dsgd_amd.synth.generate(rows, seed=0)
 n_train = int(rows * 0.8)
@@ -42,13 +43,17 @@ with dsgd_amd.Engine(data.dim, 1e-5) as eng:
         eng.synchronize()
         eng.debug_cycles(reset=True)
         t0 = time.perf_counter()
-        eng.plan_run(plan, 0, steps, 0.5 * 100 / b)
+        if single:
+            for i in range(steps):
+                eng.plan_run(plan, i, i + 1, 0.5 * 100 / b)
+        else:
+            eng.plan_run(plan, 0, steps, 0.5 * 100 / b)
         eng.synchronize()
         dt = (time.perf_counter() - t0) / steps
         cyc = eng.debug_cycles(reset=True)
         plan.destroy()
         alg = 8.0 * nnz + 12.0 * k * b
-        out["steps"].append({"workers": k, "batch": b, "us_per_step": 1e6 * dt, "kernel": eng.grad_kernel_name(),
+        out["steps"].append({"workers": k, "batch": b, "steps_per_launch": 1 if single else steps, "us_per_step": 1e6 * dt, "kernel": eng.grad_kernel_name(),
                              "algorithmic_bytes": alg, "GBps": alg / dt / 1e9, "frac_of_8TBps": alg / dt / 8e12,
                              "examples_per_s": k * b / dt, "fix_shift": eng.tuning_info()["fix_shift"]})
         if cyc[15]:   # DSGD_PLAN_PROF=1: cycles of wave 0 of workgroup 0 per launch, by phase

@@ -100,6 +100,22 @@ pmc)
     [ -n "$f" ] && python tools/pmc_summary.py "$f" "dsgd_" | grep -E "wseg_kernel<true|cdot|cgrad|cold|reduce|apply|bound" | tee -a $OUT/pmc_summary.txt
     rm -rf $OUT/pmc$i $OUT/pmc$i.out $OUT/pmc$i.err
   done ;;
+latency)
+  echo "== per-request latency at the boundary (tools/boundary_latency.py)"
+  timeout 300 python tools/boundary_latency.py 2000000 > $OUT/boundary_latency.json 2> $OUT/boundary_latency.err; tail -2 $OUT/boundary_latency.err; cat $OUT/boundary_latency.json
+  echo "-- with the copy on the stream (DSGD_REQ_MAPPED=0)"
+  DSGD_REQ_MAPPED=0 timeout 300 python tools/boundary_latency.py 2000000 > $OUT/boundary_latency_copy.json 2>> $OUT/boundary_latency.err; grep -E "sync_step|batch" $OUT/boundary_latency_copy.json ;;
+cstrace)
+  echo "== rocprofv3 kernel trace of the column-slice launches, one configuration per run"
+  rm -f $OUT/cs_dispatch_durations.txt $OUT/cs_kernel_stats.csv
+  for C in 3x100 4x200 1x100 "3x100 --single" "4x200 --single"; do
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cstrace -o cs -- python $REPO/tools/mb_prof.py 2000000 --only=$C > "$OUT/cstrace_$C.json" 2> $OUT/cstrace.err )
+    f=$(find $OUT/cstrace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && { echo "-- $C"; trace_summary "$f" | grep -E "per-kernel|cs_step|vt_grad|fix_reduce|plan_kernel"; python -c "
+import json; d=json.load(open('$OUT/cstrace_$C.json'))
+for s in d['steps']: print('   steps per launch', s.get('steps_per_launch'), ' us/step (host clock)', round(s['us_per_step'], 2), s['kernel'])"; } | tee -a $OUT/cs_dispatch_durations.txt
+    f=$(find $OUT/cstrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { echo "-- $C"; grep -E "Name|cs_step|vt_grad|fix_reduce|plan_kernel" "$f" | cut -c1-200; } >> $OUT/cs_kernel_stats.csv
+    rm -rf $OUT/cstrace
+  done ;;
 variants)
   echo "== A/B variants of the whole-shard step ($VARIANTS)"
   eval "timeout 900 python tools/variants.py $VARIANTS" 2>&1 | tee $OUT/variants.txt ;;
