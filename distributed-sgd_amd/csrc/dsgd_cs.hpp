@@ -227,6 +227,19 @@ struct CsState {
   unsigned long long* tp;      // tuning runs (LDS, thread 0 of slice 0): cycles by phase (dot, publish, exchange, scatter, sweep, reduce), [6] last stamp
 };
 
+// this lane's part of the slice's share of w . ds: all columns, four per lane and round (the padding holds zeros)
+template <int NT>
+__device__ __forceinline__ float cs_wds_share(const CsState& z) {
+  const float4* w4 = reinterpret_cast<const float4*>(z.w_l);
+  const float4* d4 = reinterpret_cast<const float4*>(z.ds_l);
+  float sp = 0.0f;
+  for (int i4 = threadIdx.x; i4 < (z.Sp >> 2); i4 += NT) {
+    const float4 wv = w4[i4], dv = d4[i4];
+    sp += (filt(wv.x * dv.x) + filt(wv.y * dv.y)) + (filt(wv.z * dv.z) + filt(wv.w * dv.w));
+  }
+  return sp;
+}
+
 // The listed columns of a step, KK hosted workers: per worker ONE rounding of the exact sum, the support-only
 // regulariser, the fold over the workers, the mean, the update -- dsgd_fix_reduce_apply_kernel's arithmetic
 // (fra_update_and_scalars), here without a branch: a lane without a column works on the slice's padding column (always
@@ -402,15 +415,7 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, 
   }
   cs_barrier();
   // ... and this slice's share of w . ds of the new weights: all columns, four per lane and round (padding holds zeros)
-  float spn = 0.0f;
-  {
-    const float4* w4 = reinterpret_cast<const float4*>(z.w_l);
-    const float4* d4 = reinterpret_cast<const float4*>(z.ds_l);
-    for (int i4 = tid; i4 < (Sp >> 2); i4 += NT) {
-      const float4 wv = w4[i4], dv = d4[i4];
-      spn += (filt(wv.x * dv.x) + filt(wv.y * dv.y)) + (filt(wv.z * dv.z) + filt(wv.w * dv.w));
-    }
-  }
+  const float spn = cs_wds_share<NT>(z);
   stamp(4);
   z.sp = cs_block_sum<NT>(spn, red);
   stamp(5);
@@ -421,6 +426,7 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, 
 template <int NT, int SPL, int CLT>
 __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const unsigned long long t_launch = a.tprof ? __builtin_readcyclecounter() : 0ull;
   const int tid = threadIdx.x;
   const int G = a.G, K = a.K;
   CsState z;
@@ -439,18 +445,38 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
   z.tp = reinterpret_cast<unsigned long long*>(z.red + 18);
   if (tid == 0)
     for (int i = 0; i < 6; ++i) z.tp[i] = 0ull;
-  float sp = 0.0f;
-  for (int i = tid; i < z.Sp; i += NT) {
-    const float wv = i < z.Sb ? a.w[z.b + G * i] : 0.0f, dv = i < z.Sb ? a.ds[z.b + G * i] : 0.0f;
-    z.w_l[i] = wv;
-    z.ds_l[i] = dv;
-    sp += filt(wv * dv);
-  }
-  for (int i = tid; i < K * z.Sp; i += NT) z.acc[i] = 0;
-  z.sp = cs_block_sum<NT>(sp, z.red);   // this slice's share of w . ds of the weights the launch starts from (also the barrier behind the set-up)
+  // the first step's slots are requested before anything else: they land with the weights (a launch of ONE step spent 12 of
+  // its 17.5 us in this set-up when the loads below went out one dependent pair at a time, the slots behind them)
   CsSet<SPL, CLT> A, B;
   cs_issue<NT, SPL, CLT>(a, z.b, a.step_begin, A);
-  if (tid == 0) z.tp[6] = a.tprof ? __builtin_readcyclecounter() : 0ull;
+  constexpr int UB = 6;
+  for (int i0 = tid; i0 < z.Sp; i0 += NT * UB) {
+    float wv[UB], dv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int i = i0 + NT * u;
+      const long long at = z.b + (long long)G * (i < z.Sb ? i : 0);
+      wv[u] = a.w[at];
+      dv[u] = a.ds[at];
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int i = i0 + NT * u;
+      if (i < z.Sp) {
+        z.w_l[i] = i < z.Sb ? wv[u] : 0.0f;
+        z.ds_l[i] = i < z.Sb ? dv[u] : 0.0f;
+      }
+    }
+  }
+  for (int i = tid; i < K * z.Sp; i += NT) z.acc[i] = 0;
+  cs_barrier();
+  // this slice's share of w . ds of the weights the launch starts from: the SAME pass, lane assignment and order as behind
+  // every step -- a plan run step by step and in one launch see the same bits
+  z.sp = cs_block_sum<NT>(cs_wds_share<NT>(z), z.red);
+  if (tid == 0 && a.tprof) {
+    z.tp[6] = __builtin_readcyclecounter();
+    if (z.b == 0) a.tprof[6] += z.tp[6] - t_launch;   // the set-up of the launch
+  }
   bool ok = true;
   for (long long step = a.step_begin; step < a.step_end; step += 2) {   // two register sets, rotated by unrolling
     ok = cs_step<NT, SPL, CLT>(a, z, A, B, step);
@@ -464,6 +490,7 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
   }
   for (int i = tid; i < z.Sb; i += NT) a.w[z.b + G * i] = z.w_l[i];
   if (a.tprof && z.b == 0 && tid == 0) {
+    a.tprof[7] += __builtin_readcyclecounter() - z.tp[6];   // the write-back
     for (int i = 0; i < 6; ++i) a.tprof[i] += z.tp[i];
     a.tprof[15] += (unsigned long long)(a.step_end - a.step_begin);
   }

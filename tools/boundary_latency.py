@@ -14,7 +14,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import ctypes as C  # noqa: E402
+
 import dsgd_amd  # noqa: E402
+from dsgd_amd._lib import BatchStats, check  # noqa: E402
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
 data = dsgd_amd.synth.generate(rows, seed=0)
@@ -52,6 +55,21 @@ with dsgd_amd.Engine(data.dim, 1e-5) as eng:
         rec["sync_step_host_idx_us"] = timed(lambda: eng.sync_step([nxt()], 0.0), 300)
         if b == 100:   # the reference's own configuration (application.conf:15,27): three hosted workers per request
             rec["sync_step_3x100_host_idx_us"] = timed(lambda: eng.sync_step([nxt(), nxt(), nxt()], 0.0), 300)
+        # the same calls AT THE C ABI: the argument arrays built once (what a JNI / cgo caller hands over is already in this
+        # form; the Python binding above spends ~11 us per call building them)
+        for label, k in (("sync_step_abi_us", 1),) + ((("sync_step_3x100_abi_us", 3),) if b == 100 else ()):
+            reqs = []
+            for r in range(16):
+                ls = [np.ascontiguousarray(nxt()) for _ in range(k)]
+                reqs.append((ls, (C.c_void_p * k)(*[a.ctypes.data for a in ls]), (C.c_int64 * k)(*[len(a) for a in ls])))
+            st = BatchStats()
+            fn, ctx, kk, lr0, stp = eng._lib.dsgd_sync_step, eng._ctx, C.c_int32(k), C.c_float(0.0), C.byref(st)
+            ctr = iter(range(10 ** 9))
+
+            def call():
+                r = reqs[next(ctr) % 16]
+                check(fn(ctx, r[1], r[2], kk, lr0, stp))
+            rec[label] = timed(call, 1000)
         # resident plan (what bench.py's sweep times): nothing crosses PCIe inside the loop
         plan = eng.plan([[l] for l in lists])
         eng.plan_run(plan, 0, len(lists), 0.0)

@@ -60,6 +60,6 @@ with dsgd_amd.Engine(data.dim, 1e-5) as eng:
             names = ("issue_ids_copy_clear", "row_records", "first_items", "barrier_in", "pass_requests", "pass_dot",
                      "pass_scatter", "barrier_out", "write_partial")
             if "cs_step" in eng.grad_kernel_name():   # csrc/dsgd_cs.hpp: thread 0 of slice 0, cycles per STEP
-                names = ("dot", "publish", "exchange", "scatter", "sweep", "reduce")
+                names = ("dot", "publish", "exchange", "scatter", "sweep", "reduce", "launch_setup", "launch_writeback")
             out["steps"][-1]["wave0_cycles_per_launch"] = {nm: cyc[i] / cyc[15] for i, nm in enumerate(names)}
 print(json.dumps(out, indent=1))

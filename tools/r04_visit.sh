@@ -50,6 +50,11 @@ mbcyc16)
   DSGD_CS_G=16 DSGD_PLAN_PROF=1 timeout 300 python tools/mb_prof.py 2000000 --only=3x100 --only=4x200 --only=1x100 > $OUT/mb_cycles16.json 2> $OUT/mb_cycles16.err; tail -2 $OUT/mb_cycles16.err; python -c "
 import json; d=json.load(open('$OUT/mb_cycles16.json'))
 for s in d['steps']: print(s['workers'], s['batch'], round(s['us_per_step'],1), {k: int(v) for k, v in s.get('wave0_cycles_per_launch', {}).items()})" ;;
+mbcyc1)
+  echo "== phase cycles, ONE step per launch"
+  DSGD_PLAN_PROF=1 timeout 300 python tools/mb_prof.py 2000000 --single --only=3x100 --only=4x200 > $OUT/mb_cycles1.json 2> $OUT/mb_cycles1.err; tail -2 $OUT/mb_cycles1.err; python -c "
+import json; d=json.load(open('$OUT/mb_cycles1.json'))
+for s in d['steps']: print(s['workers'], s['batch'], round(s['us_per_step'],1), {k: int(v) for k, v in s.get('wave0_cycles_per_launch', {}).items()})" ;;
 mbcyc256)
   echo "== phase cycles, 256 lanes per slice (DSGD_CS_NT=256)"
   DSGD_CS_NT=256 DSGD_PLAN_PROF=1 timeout 300 python tools/mb_prof.py 2000000 --only=3x100 --only=1x100 > $OUT/mb_cycles256.json 2> $OUT/mb_cycles256.err; tail -2 $OUT/mb_cycles256.err; python -c "
