@@ -1689,7 +1689,8 @@ struct PlanArgs {
   const WorkSeg* segs;       // one per step
   DevScalars* sc;
   unsigned long long* tprof; // optional (tuning runs): 16 words -- shader-clock cycles of thread 0 in nine phases of a batch, [15] = steps
-  unsigned long long* mail;  // optional (per-request steps): host-mapped {n_active, err} written when the launch ends
+  unsigned long long* mail;  // optional (per-request steps): host-mapped {n_active, err, mail_seq} written when the launch ends
+  unsigned long long mail_seq;
   long long step_begin, step_end;
   float lr, lambda;
   int vexp, dp;
@@ -1991,6 +1992,8 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
       __hip_atomic_store(&a.mail[1], (unsigned long long)(unsigned int)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     a.sc->s_reg = (float)(2.0 * (double)a.lambda * dot);
+    // the request's sequence number LAST, with release order: the host may take the two words above once it sees it
+    if (a.mail) __hip_atomic_store(&a.mail[2], a.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (a.tprof) {
       for (int i = 0; i < 9; ++i) a.tprof[i] += tp[i];
       a.tprof[15] += (unsigned long long)(a.step_end - a.step_begin);

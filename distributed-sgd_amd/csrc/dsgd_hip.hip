@@ -28,6 +28,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "../../include/dsgd.h"
@@ -281,7 +282,10 @@ struct dsgd_ctx {
   int* d_req = nullptr;                   // ... their device address
   const int* cur_idx = nullptr;           // where stage_lists put the lists of the request in flight
   bool req_mapped = true;                 // DSGD_REQ_MAPPED=0: always the copy on the stream
-  unsigned long long* h_mail = nullptr;   // host-mapped, two words
+  bool req_spin = true;                   // DSGD_REQ_SPIN=0: wait for the stream instead of polling the mailbox
+  bool req_plan = true;                   // DSGD_REQ_PLAN=0: one-worker requests through the row-parallel kernels as well
+  unsigned long long* h_mail = nullptr;   // host-mapped: {n_active, err, sequence number of the request that wrote them, -}
+  unsigned long long mail_seq = 0;        // requests answered through the mailbox so far
   unsigned long long* d_mail = nullptr;   // ... its device address
   bool ctr_known = false;                 // the host knows the device's n_active (ctr_last) and that err is clear
   unsigned long long ctr_last = 0;
@@ -1716,6 +1720,7 @@ static int launch_plan_kernel(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_se
   a.lambda = (float)c->cfg.lambda;
   a.tprof = c->d_tprof;
   a.mail = mail ? c->d_mail : nullptr;
+  a.mail_seq = mail ? ++c->mail_seq : 0ull;
   a.vexp = c->vexp;
   a.dp = c->dp;
   const size_t lds = sizeof(float) * (size_t)plan_lds_words(c->dp);
@@ -1801,8 +1806,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   HIP_TRY_B(hipMalloc(&c->d_perm, sizeof(int) * c->dp));
   HIP_TRY_B(hipMalloc(&c->d_sc, sizeof(DevScalars)));
   HIP_TRY_B(hipHostMalloc(&c->h_sc, sizeof(DevScalars), hipHostMallocDefault));
-  HIP_TRY_B(hipHostMalloc(&c->h_mail, 2 * sizeof(unsigned long long), hipHostMallocMapped));
-  c->h_mail[0] = c->h_mail[1] = 0;
+  HIP_TRY_B(hipHostMalloc(&c->h_mail, 4 * sizeof(unsigned long long), hipHostMallocMapped));
+  c->h_mail[0] = c->h_mail[1] = c->h_mail[2] = c->h_mail[3] = 0;
   HIP_TRY_B(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_mail), c->h_mail, 0));
   HIP_TRY_B(hipMemsetAsync(c->d_w, 0, sizeof(float) * c->dp, c->stream));
   HIP_TRY_B(hipMemsetAsync(c->d_ds, 0, sizeof(float) * c->dp, c->stream));
@@ -1822,6 +1827,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_CS_G")) c->cs_g = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 0);
   if (const char* e = getenv("DSGD_CS_MAX_MB")) c->cs_max_mb = std::max(0, atoi(e));
   if (const char* e = getenv("DSGD_REQ_MAPPED")) c->req_mapped = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_REQ_PLAN")) c->req_plan = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_REQ_SPIN")) c->req_spin = atoi(e) != 0;
   if (const char* e = getenv("DSGD_CS_NT")) c->cs_nt = atoi(e) == CS_THREADS_NARROW ? CS_THREADS_NARROW : 0;
   if (const char* e = getenv("DSGD_VT_TPW")) c->vt_tpw = std::max(1, atoi(e));
   if (const char* e = getenv("DSGD_VT_PACK_MB")) c->vt_pack_mb = std::max(0, atoi(e));
@@ -2312,8 +2319,20 @@ static int finish_stats(dsgd_ctx* c, dsgd_batch_stats* stats, long long total) {
 
 // the statistics of a per-request step from the host-mapped mailbox its last kernel wrote: n_active as the difference
 // against the value the host last saw (no memset in front of the request), the error flags as they are
-static int finish_mail(dsgd_ctx* c, dsgd_batch_stats* stats, long long total, unsigned long long before) {
-  HIP_TRY(hipStreamSynchronize(c->stream));
+static int finish_mail(dsgd_ctx* c, dsgd_batch_stats* stats, long long total, unsigned long long before, bool seq = false) {
+  // (seq: the request's ONE workgroup wrote its sequence number behind the two words, with release order, as its last
+  //  act -- the host polls the mapped word instead of waiting for the stream's completion signal; what the request
+  //  enqueues next is ordered behind the kernel by the stream as always)
+  bool seen = false;
+  if (seq) {
+    const volatile unsigned long long* m = c->h_mail;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned int spin = 0; !seen; ++spin) {
+      seen = __atomic_load_n(&m[2], __ATOMIC_ACQUIRE) == c->mail_seq;
+      if (!seen && (spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) break;
+    }
+  }
+  if (!seen) HIP_TRY(hipStreamSynchronize(c->stream));
   const unsigned long long now = c->h_mail[0];
   const int err = (int)c->h_mail[1];
   c->ctr_last = now;
@@ -2343,7 +2362,7 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
   {
     long long t = 0;
     for (int k = 0; k < n_workers; ++k) t += std::max<long long>(0, n_per_worker[k]);
-    bool fits = plan_kernel_ok(c, t, n_workers);
+    bool fits = c->req_plan && plan_kernel_ok(c, t, n_workers);
     for (int k = 0; k < n_workers && fits; ++k)
       fits = idx_per_worker[k] && list_fits_staged(c, idx_per_worker[k], n_per_worker[k]);
     if (fits && c->prof) {   // the reference's batch sizes: one persistent workgroup does the whole closure
@@ -2357,7 +2376,7 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
       const unsigned long long before = c->ctr_last;
       DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
       DSGD_TRY(launch_plan_kernel(c, c->cur_idx, c->d_segs, 0, 1, lr, true));
-      return finish_mail(c, stats, tot, before);
+      return finish_mail(c, stats, tot, before, c->req_spin);
     }
   }
   DSGD_TRY(ensure_g(c, n_workers));

@@ -109,7 +109,11 @@ latency)
   echo "== per-request latency at the boundary (tools/boundary_latency.py)"
   timeout 300 python tools/boundary_latency.py 2000000 > $OUT/boundary_latency.json 2> $OUT/boundary_latency.err; tail -2 $OUT/boundary_latency.err; cat $OUT/boundary_latency.json
   echo "-- with the copy on the stream (DSGD_REQ_MAPPED=0)"
-  DSGD_REQ_MAPPED=0 timeout 300 python tools/boundary_latency.py 2000000 > $OUT/boundary_latency_copy.json 2>> $OUT/boundary_latency.err; grep -E "sync_step|batch" $OUT/boundary_latency_copy.json ;;
+  DSGD_REQ_MAPPED=0 timeout 300 python tools/boundary_latency.py 2000000 > $OUT/boundary_latency_copy.json 2>> $OUT/boundary_latency.err; grep -E "sync_step|batch" $OUT/boundary_latency_copy.json
+  echo "-- waiting for the stream instead of polling the mailbox (DSGD_REQ_SPIN=0)"
+  DSGD_REQ_SPIN=0 timeout 300 python tools/boundary_latency.py 2000000 > $OUT/boundary_latency_nospin.json 2>> $OUT/boundary_latency.err; grep -E "sync_step|batch" $OUT/boundary_latency_nospin.json
+  echo "-- one-worker requests through the row-parallel kernels (DSGD_REQ_PLAN=0)"
+  DSGD_REQ_PLAN=0 timeout 300 python tools/boundary_latency.py 2000000 > $OUT/boundary_latency_noplan.json 2>> $OUT/boundary_latency.err; grep -E "sync_step|batch" $OUT/boundary_latency_noplan.json ;;
 cstrace)
   echo "== rocprofv3 kernel trace of the column-slice launches, one configuration per run"
   rm -f $OUT/cs_dispatch_durations.txt $OUT/cs_kernel_stats.csv
