@@ -283,7 +283,9 @@ struct dsgd_ctx {
   const int* cur_idx = nullptr;           // where stage_lists put the lists of the request in flight
   bool req_mapped = true;                 // DSGD_REQ_MAPPED=0: always the copy on the stream
   bool req_spin = true;                   // DSGD_REQ_SPIN=0: wait for the stream instead of polling the mailbox
-  bool req_plan = true;                   // DSGD_REQ_PLAN=0: one-worker requests through the row-parallel kernels as well
+  bool req_plan = false;                  // DSGD_REQ_PLAN=1: one-worker requests of <= 192 rows through the one-workgroup kernel (its
+                                          //   launch re-derives s in fp64 and sets up 147 KB of LDS for ONE step: 37 us per request at the
+                                          //   C ABI against 32 us through the row-parallel kernels -- profiles/r04_boundary_latency.json)
   unsigned long long* h_mail = nullptr;   // host-mapped: {n_active, err, sequence number of the request that wrote them, -}
   unsigned long long mail_seq = 0;        // requests answered through the mailbox so far
   unsigned long long* d_mail = nullptr;   // ... its device address

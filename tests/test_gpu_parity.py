@@ -489,6 +489,7 @@ def test_plan_kernel_and_multi_launch_path_agree_with_the_oracle(monkeypatch, k_
     rng = np.random.default_rng(31)
     steps = batches(rng, n_train, k_workers, batch, 30)
     ws = {}
+    monkeypatch.setenv("DSGD_REQ_PLAN", "1")   # (per-request steps take the row-parallel kernels by default since round 4)
     for mode in ("1", "0"):
         monkeypatch.setenv("DSGD_PLAN_KERNEL", mode)
         o, eng = make_pair(data, 1e-5, n_train)

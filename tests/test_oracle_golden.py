@@ -216,8 +216,8 @@ def test_fixture_kat_json_dict_and_c():
 
 
 def test_committed_jvm_expectation_is_what_the_oracle_produces_today():
-    """tests/golden/jvm_expected/: the Main.scala scenario on a small exported workload, as the JVM should log it
-    (see tests/golden/make_jvm_expected.py).  Regenerated here and compared with the committed file, so that whoever
+    """tests/golden/oracle_expected_for_jvm/: the Main.scala scenario on a small exported workload, as the JVM should log it
+    (see tests/golden/make_oracle_expected_for_jvm.py).  Regenerated here and compared with the committed file, so that whoever
     diffs the JVM's log against it diffs against the oracle the parity tests actually use."""
     import json
     import os
@@ -226,11 +226,11 @@ def test_committed_jvm_expectation_is_what_the_oracle_produces_today():
     golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     sys.path.insert(0, golden)
     try:
-        import make_jvm_expected as mk
+        import make_oracle_expected_for_jvm as mk
     finally:
         sys.path.remove(golden)
     now = mk.compute()
-    exp = json.load(open(os.path.join(golden, "jvm_expected", "expected.json")))
+    exp = json.load(open(os.path.join(golden, "oracle_expected_for_jvm", "expected.json")))
     assert now["config"] == exp["config"] and now["batches"] == exp["batches"] == 6
     for key in ("initial_loss", "initial_accuracy", "final_test_loss", "final_test_accuracy"):
         assert abs(now[key] - exp[key]) <= 1e-12 * max(1.0, abs(exp[key])), key
@@ -241,7 +241,7 @@ def test_committed_jvm_expectation_is_what_the_oracle_produces_today():
     import dsgd_amd
     from dsgd_amd import rcv1
 
-    back = rcv1.load(os.path.join(golden, "jvm_expected", "data"), full=False)
+    back = rcv1.load(os.path.join(golden, "oracle_expected_for_jvm", "data"), full=False)
     data = dsgd_amd.synth.generate(mk.ROWS, seed=0)
     assert back.n_rows == mk.ROWS and (back.col == data.col).all() and (back.label == data.label).all()
     assert np.abs(back.val - data.val).max() == 0.0
