@@ -1830,6 +1830,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_CS_MAX_MB")) c->cs_max_mb = std::max(0, atoi(e));
   if (const char* e = getenv("DSGD_REQ_MAPPED")) c->req_mapped = atoi(e) != 0;
   if (const char* e = getenv("DSGD_REQ_PLAN")) c->req_plan = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_STREAM_MIN")) c->stream_min = std::max(1LL, atoll(e));
   if (const char* e = getenv("DSGD_REQ_SPIN")) c->req_spin = atoi(e) != 0;
   if (const char* e = getenv("DSGD_CS_NT")) c->cs_nt = atoi(e) == CS_THREADS_NARROW ? CS_THREADS_NARROW : 0;
   if (const char* e = getenv("DSGD_VT_TPW")) c->vt_tpw = std::max(1, atoi(e));

@@ -78,13 +78,14 @@ def test_ranks_leave_the_clock_ramp_together(tmp_path):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The bench line the last GPU visit produced (profiles/r03_bench.json): the keys, types and internal arithmetic of
-    the driver's contract -- whole-job examples/s from the timed steps, the dominant kernel's roofline fraction from its
-    algorithmic bytes and its measured duration, a bounded CPU baseline, nothing quoted against a baseline that was
-    never published."""
+    """The bench line the last GPU visit produced (profiles/r04_bench.json): the keys, types and internal arithmetic of
+    the driver's contract -- whole-job examples/s from the timed steps (median of the repeats), the dominant kernel's
+    roofline fraction from its algorithmic bytes and its measured duration, a bounded CPU baseline, nothing quoted against
+    a baseline that was never published -- and that every quoted configuration carries the parity of the kernel that
+    produced it."""
     import json
 
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
@@ -92,28 +93,54 @@ def test_committed_bench_line_keeps_the_contract():
     assert d["unit"] == "examples/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None            # BASELINE.md publishes no number for this metric
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
-    # value = rows per step x GPUs / time per step
+    # value = rows per step x GPUs / time per step; the time is the MEDIAN of >= 5 repeats of the timed K steps
     rows = d["config"]["train_rows_per_gpu"] * d["n_gpus"]
     assert abs(d["value"] - rows / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    rp = d["repeats"]
+    assert rp["n"] >= 5 and rp["statistic"] == "median" and len(rp["ms_per_step"]) == rp["n"]
+    assert sorted(rp["ms_per_step"])[rp["n"] // 2] == d["ms_per_step"] and rp["ms_per_step_min"] <= d["ms_per_step"] <= rp["ms_per_step_max"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     # achieved = algorithmic bytes per launch / measured launch duration (HIP events inside the timed region)
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
-    assert r["kernel_launches"] == d["steps"] * d["n_gpus"] or r["kernel_launches"] == d["steps"]
+    assert r["kernel_launches"] == d["steps"] * rp["n"]
     assert r["traffic"] is None or 0.5 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 1.5 * r["algorithmic_bytes_per_launch"]
     assert 0.0 < r["frac"] <= 1.0 and 0.0 < r["step"]["frac"] <= r["frac"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == "examples/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    # the parity gate ran on the benchmarked configuration and stayed inside its derived bound
+    # the parity gate ran on the benchmarked configuration: inside the derived bound AND the stated 1e-5 tolerance
     assert d["parity_gate_rows"] == d["config"]["train_rows_per_gpu"]
-    assert all(st["worst_err_over_bound"] <= 1.0 for st in d["parity_gate"]["steps"])
-    # every quoted configuration carries its own parity evidence: the sweep rows (one step against the oracle under the
-    # derived bound, active rows equal up to the rows near the gate) and the 256-worker lock-free run (oracle band)
+    for st in d["parity_gate"]["steps"]:
+        assert st["worst_err_over_bound"] <= 1.0 and st["max_rel_err"] <= st["stated_tolerance"] == 1e-5
+    # every sweep row: the parity step IS step 0 of the timed plan, so the checked kernel is the timed kernel
     assert {(s["workers"], s["batch"]) for s in d["sweep"]} >= {(1, 100), (3, 100), (4, 200), (1, 4096), (1, 65536)}
     for s in d["sweep"]:
         pz = s["parity"]
-        assert pz["worst_err_over_bound"] <= 1.0 and abs(pz["n_active_engine"] - pz["n_active_oracle"]) <= pz["rows_near_gate"]
-    hb = d["hogwild"]["oracle_band"]
-    assert hb["workers"] == d["hogwild"]["workers"] == 256 and hb["batch"] == 100 and hb["inside"] is True
-    assert d["hogwild"]["atomics_per_s"] > 0
+        assert pz["kernel"] == s["kernel"] and pz["checked"] == "step 0 of the timed plan"
+        assert pz["worst_err_over_bound"] <= 1.0 and pz["max_rel_err"] <= pz["stated_tolerance"] == 1e-5
+        assert abs(pz["n_active_engine"] - pz["n_active_oracle"]) <= pz["rows_near_gate"]
+        assert 0.0 < s["frac_hbm_peak"] < 1.0
+    by = {(s["workers"], s["batch"]): s for s in d["sweep"]}
+    # the reference's own batch sizes run through the column-slice kernel, below 10 us per step from a resident plan
+    for cfg in ((3, 100), (4, 200)):
+        assert by[cfg]["kernel"] == "dsgd_cs_step_kernel" and by[cfg]["us_per_step"] < 10.0
+    # the 256-worker lock-free run: traced replay (can fail: both negative controls rejected) beside the oracle band
+    hw = d["hogwild"]
+    tr = hw["traced_replay"]
+    assert tr["workers"] == hw["workers"] == 256 and tr["batch"] == 100 and tr["agrees"] is True and tr["controls_rejected"] is True
+    assert all(all(cp["ok"].values()) and cp["account_err_over_tol"] <= 1.0 for cp in tr["checkpoints"])
+    assert all(v["rejected"] for v in tr["negative_controls"].values()) and len(tr["negative_controls"]) >= 2
+    assert hw["oracle_band"]["inside"] is True and hw["atomics_per_s"] > 0 and 0.0 < hw["frac_hbm_peak"] < 1.0
+    # the reference's own data-set sizes next to the headline, gated and with roofline fields
+    shapes = {rs["rows"]: rs for rs in d["reference_shapes"]}
+    assert set(shapes) == {804414, 23149}
+    for rs in shapes.values():
+        assert rs["parity_gate"]["max_rel_err"] <= 1e-5 and rs["parity_gate"]["worst_err_over_bound"] <= 1.0
+        assert rs["whole_shard"]["repeats"] >= 5 and 0.0 < rs["roofline"]["step"]["frac"] <= rs["roofline"]["frac"] <= 1.0
+        assert all(s["parity"]["kernel"] == s["kernel"] for s in rs["sweep"])
+    # wall-clock to the oracle's target loss, evaluation passes inside the clock, for the batch sizes of SURVEY.md 8(d)
+    tt = d["time_to_target"]
+    assert {(c["workers"], c["batch"]) for c in tt["configs"]} >= {(3, 100), (4, 200), (1, 4096), (1, 65536)}
+    assert tt["fastest"] is not None and tt["fastest"]["time_to_target_s"] > 0
+    assert all("evaluation" in c and (c["time_to_target_s"] is None) == (c["engine_epochs"] is None) for c in tt["configs"])

@@ -105,6 +105,18 @@ pmc)
     [ -n "$f" ] && python tools/pmc_summary.py "$f" "dsgd_" | grep -E "wseg_kernel<true|cdot|cgrad|cold|reduce|apply|bound" | tee -a $OUT/pmc_summary.txt
     rm -rf $OUT/pmc$i $OUT/pmc$i.out $OUT/pmc$i.err
   done ;;
+streammin)
+  echo "== whole-shard step at N = 23,149 / 100,000 by DSGD_STREAM_MIN (rows from which row ranges take the streaming kernels)"
+  for M in 8192 32768 131072; do
+    DSGD_STREAM_MIN=$M timeout 300 python -c "
+import sys, json; sys.path.insert(0, '.')
+import bench, dsgd_amd
+bench.SWEEP = ()
+for n in (23149, 100000):
+    r = bench.reference_shape(dsgd_amd, 0, n, with_parity=True, repeats=5, steps=20)
+    print('stream_min', $M, 'rows', n, round(r['whole_shard']['us_per_step'], 1), 'us', r['whole_shard']['kernel'], 'gate', r['parity_gate']['max_rel_err'])
+" 2>&1 | grep -E "stream_min|Error|error" | tee -a $OUT/streammin.txt
+  done ;;
 latency)
   echo "== per-request latency at the boundary (tools/boundary_latency.py)"
   timeout 300 python tools/boundary_latency.py 2000000 > $OUT/boundary_latency.json 2> $OUT/boundary_latency.err; tail -2 $OUT/boundary_latency.err; cat $OUT/boundary_latency.json
