@@ -57,8 +57,9 @@ struct CsArgs {
                                     //   one contiguous KiB (slot-major records -- 32- and 64-byte strides between lanes -- took 7 us to land
                                     //   at 4 x 200); padding: column 0, value 0
   const unsigned short* clist;      // [G][n_steps][cl_stride]: the distinct columns of the step inside the slice, ascending; 0xffff: none
-  float* w;                         // ranked weights (read when the launch starts, written when it ends)
-  const float* ds;
+  float* w;                         // the weights SLICE-MAJOR: [G][Sp], slice b's local column i = rank b + G * i (read when the launch
+                                    //   starts, written when it ends; dsgd_cs_slice_kernel / dsgd_cs_unslice_kernel convert)
+  const float* ds;                  // dimSparsity, the same layout
   unsigned long long* xbuf;         // [2][G][CS_XSTRIDE] granules {value bits, step tag << 32}; zero when a launch starts
   unsigned int* sync;               // [1] abort word (zero when a launch starts)
   DevScalars* sc;
@@ -445,27 +446,19 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
   z.tp = reinterpret_cast<unsigned long long*>(z.red + 18);
   if (tid == 0)
     for (int i = 0; i < 6; ++i) z.tp[i] = 0ull;
-  // the first step's slots are requested before anything else: they land with the weights (a launch of ONE step spent 12 of
-  // its 17.5 us in this set-up when the loads below went out one dependent pair at a time, the slots behind them)
+  // the first step's slots are requested before anything else: they land with the weights.  (The weights used to be picked
+  // out of the rank-ordered vector here -- every slice touched every 128-byte line of w and ds, 378 KB through ONE CU:
+  // 8.6 of the 18 us of a one-step launch.)
   CsSet<SPL, CLT> A, B;
   cs_issue<NT, SPL, CLT>(a, z.b, a.step_begin, A);
-  constexpr int UB = 6;
-  for (int i0 = tid; i0 < z.Sp; i0 += NT * UB) {
-    float wv[UB], dv[UB];
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int i = i0 + NT * u;
-      const long long at = z.b + (long long)G * (i < z.Sb ? i : 0);
-      wv[u] = a.w[at];
-      dv[u] = a.ds[at];
-    }
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int i = i0 + NT * u;
-      if (i < z.Sp) {
-        z.w_l[i] = i < z.Sb ? wv[u] : 0.0f;
-        z.ds_l[i] = i < z.Sb ? dv[u] : 0.0f;
-      }
+  {   // the slice's weights and dimSparsity values: two contiguous pieces (the padding holds zeros)
+    const float4* ws4 = reinterpret_cast<const float4*>(a.w + (long long)z.b * z.Sp);
+    const float4* ds4 = reinterpret_cast<const float4*>(a.ds + (long long)z.b * z.Sp);
+    float4* wl4 = reinterpret_cast<float4*>(z.w_l);
+    float4* dl4 = reinterpret_cast<float4*>(z.ds_l);
+    for (int i4 = tid; i4 < (z.Sp >> 2); i4 += NT) {
+      wl4[i4] = ws4[i4];
+      dl4[i4] = ds4[i4];
     }
   }
   for (int i = tid; i < K * z.Sp; i += NT) z.acc[i] = 0;
@@ -488,7 +481,11 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
     if (tid == 0) atomicOr(&a.sc->err, 8);
     return;   // (global w stays as the launch found it: the host rejects the run)
   }
-  for (int i = tid; i < z.Sb; i += NT) a.w[z.b + G * i] = z.w_l[i];
+  {
+    float4* ws4 = reinterpret_cast<float4*>(a.w + (long long)z.b * z.Sp);
+    const float4* wl4 = reinterpret_cast<const float4*>(z.w_l);
+    for (int i4 = tid; i4 < (z.Sp >> 2); i4 += NT) ws4[i4] = wl4[i4];
+  }
   if (a.tprof && z.b == 0 && tid == 0) {
     a.tprof[7] += __builtin_readcyclecounter() - z.tp[6];   // the write-back
     for (int i = 0; i < 6; ++i) a.tprof[i] += z.tp[i];
@@ -506,6 +503,20 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
       if (tot) atomicAdd(&a.sc->n_active, (unsigned long long)tot);
     }
   }
+}
+
+// rank-ordered vector -> slice-major [G][Sp] (the padding zero) and back; one lane per rank
+__global__ void __launch_bounds__(256) dsgd_cs_slice_kernel(const float* __restrict__ v, float* __restrict__ out, int dp, int G, int Sp) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < G * Sp) {
+    const int b = j / Sp, i = j - b * Sp;
+    const long long r = (long long)b + (long long)G * i;
+    out[j] = r < dp ? v[r] : 0.0f;
+  }
+}
+__global__ void __launch_bounds__(256) dsgd_cs_unslice_kernel(const float* __restrict__ sl, float* __restrict__ v, int dp, int G, int Sp) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < dp) v[r] = sl[(long long)(r % G) * Sp + r / G];
 }
 
 // one wave per listed row: its (ranked column, value) pairs copied to out[out_ptr[t] ...] (the host lays a plan's column

@@ -197,6 +197,9 @@ struct dsgd_ctx {
   long long cs_max_mb = 1024;           // DSGD_CS_MAX_MB: largest column-slice layout of one plan
   int cs_nt = 0;                        // DSGD_CS_NT=256: tuning runs with 256 lanes per slice where a plan's steps fit them
   unsigned int cs_tag0 = 0;             // column-slice steps launched so far (the exchange granules' tags run on)
+  float* d_cs_w = nullptr;              // the weights slice-major while cs_w_G != 0: then d_w is STALE -- every entry point that
+  float* d_cs_ds = nullptr;             //   is not a column-slice launch converts back first (bind); dimSparsity likewise (a copy)
+  int cs_w_G = 0;                       // slices of the slice-major state (0: the weights are in d_w, rank order)
   unsigned long long* d_cs_x = nullptr; // exchange buffer of dsgd_cs_step_kernel: [2][CS_MAX_G][CS_XSTRIDE] granules
   unsigned int* d_cs_sync = nullptr;    // its arrival counter and abort word
   bool vt_enable = true;                // DSGD_VT=0: index-list steps of resident plans through dsgd_mb_grad_kernel
@@ -356,8 +359,21 @@ static int check_ctx(dsgd_ctx* c) {
   if (!c) return fail(DSGD_EINVAL, "null context");
   return DSGD_OK;
 }
-static int bind(dsgd_ctx* c) {  // host threads migrate (JVM pool): bind the device on every call
+static int cs_sp(int dp, int G) { return (((dp + G - 1) / G) + 4) & ~3; }   // padded columns per slice (as the kernel computes it)
+// Consecutive column-slice launches keep the weights slice-major (a launch then loads and stores ONE contiguous piece per
+// workgroup); whatever else touches w first gets them back in rank order.  Every entry point binds, under the context
+// mutex: the one place.
+static int cs_unslice(dsgd_ctx* c) {
+  if (!c->cs_w_G) return DSGD_OK;
+  hipLaunchKernelGGL(dsgd_cs_unslice_kernel, dim3((c->dp + 255) / 256), dim3(256), 0, c->stream, c->d_cs_w, c->d_w, c->dp, c->cs_w_G,
+                     cs_sp(c->dp, c->cs_w_G));
+  HIP_TRY(hipGetLastError());
+  c->cs_w_G = 0;
+  return DSGD_OK;
+}
+static int bind(dsgd_ctx* c, bool keep_sliced = false) {  // host threads migrate (JVM pool): bind the device on every call
   HIP_TRY(hipSetDevice(c->cfg.device));
+  if (c->cs_w_G && !keep_sliced) return cs_unslice(c);
   return DSGD_OK;
 }
 static CsrView view(dsgd_ctx* c) {
@@ -1066,8 +1082,22 @@ static int launch_cs(dsgd_ctx* c, dsgd_plan* p, long long step_begin, long long 
   a.val = p->d_cs_val;
   a.clist = p->d_cs_cl;
   a.cl_stride = p->cs_cl_stride;
-  a.w = c->d_w;
-  a.ds = c->d_ds;
+  // the weights slice-major for this plan's slice count (they stay so until something else touches w: bind)
+  if (c->cs_w_G != p->cs_G) {
+    DSGD_TRY(cs_unslice(c));
+    const int Sp = cs_sp(c->dp, p->cs_G), n = p->cs_G * Sp;
+    if (!c->d_cs_w) {
+      const size_t cap = sizeof(float) * (size_t)(c->dp + (CS_MAX_G + 1) * 8);
+      HIP_TRY(hipMalloc(&c->d_cs_w, cap));
+      HIP_TRY(hipMalloc(&c->d_cs_ds, cap));
+    }
+    hipLaunchKernelGGL(dsgd_cs_slice_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_w, c->d_cs_w, c->dp, p->cs_G, Sp);
+    hipLaunchKernelGGL(dsgd_cs_slice_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_ds, c->d_cs_ds, c->dp, p->cs_G, Sp);
+    HIP_TRY(hipGetLastError());
+    c->cs_w_G = p->cs_G;   // (dimSparsity can only change through an entry point that converts back first)
+  }
+  a.w = c->d_cs_w;
+  a.ds = c->d_cs_ds;
   a.xbuf = c->d_cs_x;
   a.sync = c->d_cs_sync;
   a.sc = c->d_sc;
@@ -1951,6 +1981,8 @@ int dsgd_destroy(dsgd_ctx* c) {
   (void)hipFree(c->d_plan_gcold);
   (void)hipFree(c->d_cs_x);
   (void)hipFree(c->d_cs_sync);
+  (void)hipFree(c->d_cs_w);
+  (void)hipFree(c->d_cs_ds);
   if (c->h_sc) (void)hipHostFree(c->h_sc);
   if (c->h_mail) (void)hipHostFree(c->h_mail);
   if (c->h_req) (void)hipHostFree(c->h_req);
@@ -2463,7 +2495,7 @@ int dsgd_sync_step_ranges_async(dsgd_ctx* c, const int64_t* row_begin, const int
 int dsgd_synchronize(dsgd_ctx* c, dsgd_batch_stats* stats) {
   DSGD_TRY(check_ctx(c));
   std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c));
+  DSGD_TRY(bind(c, true));
   DSGD_TRY(read_scalars(c));
   DSGD_TRY(prof_collect(c));
   const long long act = (long long)c->h_sc->n_active;
@@ -2534,7 +2566,7 @@ int dsgd_plan_destroy(dsgd_ctx* c, dsgd_plan* p) {
   DSGD_TRY(check_ctx(c));
   if (!p) return DSGD_OK;
   std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c));
+  DSGD_TRY(bind(c, true));
   HIP_TRY(hipStreamSynchronize(c->stream));
   (void)hipFree(p->d_idx);
   (void)hipFree(p->d_segs);
@@ -2559,7 +2591,7 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
     return fail(DSGD_EINVAL, "steps [%lld, %lld) outside the plan's %lld steps", (long long)step_begin, (long long)step_end,
                 p->n_steps);
   std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c));
+  DSGD_TRY(bind(c, true));
   DSGD_TRY(require_data(c));
   DSGD_TRY(require_ds(c));
   DSGD_TRY(require_sync_mode(c));
@@ -2573,6 +2605,7 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
       return DSGD_OK;
     }
   }
+  DSGD_TRY(cs_unslice(c));   // (bound with the slice-major weights kept: the row-parallel kernels below read d_w)
   if (plan_kernel_ok(c, p->max_step_rows, p->n_workers) && p->fits && p->fits_rows == c->n_rows) {
     if (step_end > step_begin) DSGD_TRY(launch_plan_kernel(c, p->d_idx, p->d_segs, step_begin, step_end, lr));
     c->pending_samples += p->offsets[step_end * p->n_workers] - p->offsets[step_begin * p->n_workers];
@@ -3391,7 +3424,7 @@ int dsgd_loss_acc_devices(dsgd_ctx* const* ctxs, int32_t n_ctx, const int64_t* r
 int dsgd_prof_enable(dsgd_ctx* c, int32_t on) {
   DSGD_TRY(check_ctx(c));
   std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c));
+  DSGD_TRY(bind(c, true));
   HIP_TRY(hipStreamSynchronize(c->stream));
   DSGD_TRY(prof_collect(c));
   c->prof = on != 0;
@@ -3402,7 +3435,7 @@ int dsgd_prof_enable(dsgd_ctx* c, int32_t on) {
 int dsgd_prof_read(dsgd_ctx* c, double* ms_avg, int64_t* n_launches, int32_t reset) {
   DSGD_TRY(check_ctx(c));
   std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c));
+  DSGD_TRY(bind(c, true));
   HIP_TRY(hipStreamSynchronize(c->stream));
   DSGD_TRY(prof_collect(c));
   if (ms_avg) *ms_avg = c->prof_kn[0] ? c->prof_kms[0] / (double)c->prof_kn[0] : 0.0;
@@ -3419,7 +3452,7 @@ int dsgd_prof_read(dsgd_ctx* c, double* ms_avg, int64_t* n_launches, int32_t res
 int dsgd_prof_read_kinds(dsgd_ctx* c, double* ms_avg3, int64_t* n_launches3) {
   DSGD_TRY(check_ctx(c));
   std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c));
+  DSGD_TRY(bind(c, true));
   HIP_TRY(hipStreamSynchronize(c->stream));
   DSGD_TRY(prof_collect(c));
   for (int k = 0; k < 3; ++k) {
@@ -3432,7 +3465,7 @@ int dsgd_prof_read_kinds(dsgd_ctx* c, double* ms_avg3, int64_t* n_launches3) {
 int dsgd_range_nnz(dsgd_ctx* c, int64_t row_begin, int64_t row_end, int64_t* nnz, int64_t* cold_nnz) {
   DSGD_TRY(check_ctx(c));
   std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c));
+  DSGD_TRY(bind(c, true));
   DSGD_TRY(require_data(c));
   if (row_begin < 0 || row_end < row_begin || row_end > c->n_rows) return fail(DSGD_ERANGE, "row range [%lld, %lld) outside [0, %lld)", (long long)row_begin, (long long)row_end, c->n_rows);
   DSGD_TRY(prepare_layout(c));
@@ -3448,7 +3481,7 @@ int dsgd_debug_cycles(dsgd_ctx* c, uint64_t* out8, int32_t reset) {
   DSGD_TRY(check_ctx(c));
   if (!out8) return fail(DSGD_EINVAL, "null out8");
   std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c));
+  DSGD_TRY(bind(c, true));
   for (int i = 0; i < 16; ++i) out8[i] = 0;
   if (!c->d_tprof) return DSGD_OK;
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -200,6 +200,60 @@ def test_ragged_rows_and_long_rows():
             plan_step(o, eng, lists, 0.125, "column_slices_ragged", kernel="dsgd_vt_grad_kernel")
 
 
+def test_slice_major_weights_between_launches_are_seen_by_everything_else(mid):
+    """Consecutive column-slice launches keep the weights slice-major on the device (a launch then loads ONE contiguous
+    piece per workgroup); the rank-ordered vector is stale meanwhile.  Whatever else reads or writes the weights -- range
+    steps, a plan the column slices cannot take, per-request steps, evaluation, get / set -- must see them: every stage of
+    an interleaved sequence against the oracle (a stale vector would be off by ~1e-2, the tolerance is 1e-4)."""
+    data, n_train, o, eng = mid
+    rng = np.random.default_rng(77)
+    eng.set_weights(nonzero_weights(data.dim, rng))
+    w_ref = eng.get_weights().astype(np.float64)
+    steps = batches(rng, n_train, 3, 100, 7)
+    big = batches(rng, n_train, 1, 3000, 1)          # 3,000 rows in a step: the row-parallel kernels
+    plan, plan_big = eng.plan(steps), eng.plan(big)
+
+    def check(stage):
+        w = eng.get_weights().astype(np.float64)
+        assert np.abs(w - w_ref).max() <= 1e-4 * max(1.0, np.abs(w_ref).max()), stage
+
+    eng.plan_run(plan, 0, 1, 0.5)
+    eng.plan_run(plan, 1, 2, 0.5)                    # stays slice-major: no conversion in between
+    eng.synchronize()                                # ... nor here
+    eng.plan_run(plan, 2, 3, 0.5)
+    assert eng.grad_kernel_name() == CS
+    for ls in steps[:3]:
+        o.sync_step(w_ref, ls, 0.5)
+    check("three one-step launches")
+    eng.sync_step_ranges([(0, 5000)], 0.01)          # a range step straight after a launch
+    o.sync_step(w_ref, [np.arange(5000, dtype=np.int32)], 0.01)
+    check("range step")
+    eng.plan_run(plan, 3, 4, 0.5)
+    eng.plan_run(plan_big, 0, 1, 0.02)               # another plan, row-parallel, straight after
+    assert eng.grad_kernel_name() != CS
+    o.sync_step(w_ref, steps[3], 0.5)
+    o.sync_step(w_ref, big[0], 0.02)
+    check("row-parallel plan behind a column-slice launch")
+    eng.plan_run(plan, 4, 5, 0.5)
+    o.sync_step(w_ref, steps[4], 0.5)
+    loss, acc, counts = eng.loss_acc(n_train, data.n_rows)   # evaluation straight after a launch
+    l_ref, a_ref, c_ref, _ = o.loss_acc(w_ref, n_train, data.n_rows)
+    assert abs(loss - l_ref) < 1e-4 and abs(acc - a_ref) < 2e-3
+    eng.sync_step(steps[5], 0.5)                     # a per-request step
+    o.sync_step(w_ref, steps[5], 0.5)
+    eng.plan_run(plan, 6, 7, 0.5)
+    o.sync_step(w_ref, steps[6], 0.5)
+    check("per-request step between launches")
+    w_new = nonzero_weights(data.dim, np.random.default_rng(78))
+    eng.set_weights(w_new)                           # set_weights while the slice-major copy is live
+    eng.plan_run(plan, 0, 1, 0.5)
+    w_ref = w_new.astype(np.float64)
+    o.sync_step(w_ref, steps[0], 0.5)
+    check("set_weights behind a launch")
+    plan.destroy()
+    plan_big.destroy()
+
+
 def test_eligibility_and_fallbacks(monkeypatch):
     data = dsgd_amd.synth.generate(30000, seed=9)
     n_train = 24000
