@@ -179,7 +179,10 @@ struct dsgd_ctx {
   int* d_perm = nullptr;   // key  -> rank
   bool layout_ready = false;
   int hw_eval = DSGD_LDS_FLOATS;
-  long long stream_min = 8192;  // row ranges with at least this many rows use the streaming kernels
+  long long stream_min = 131072;  // row ranges with at least this many rows use the streaming kernels (DSGD_STREAM_MIN).  Four
+                                  //   launches of the split streams cost ~50 us whatever the range; the row-wise kernel + reduce
+                                  //   take 37 us for 18,519 rows and 57 us for 80,000 (streaming: 49 / 63 us;
+                                  //   profiles/r04_stream_min.txt)
   // nnz-streaming kernels (contiguous row ranges)
   StreamSeg* d_ssegs = nullptr;
   int ssegs_cap = 0;

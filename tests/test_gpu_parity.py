@@ -41,13 +41,19 @@ def _row_parallel_kernels_of_resident_plans():
     (tests/test_gpu_cs.py).  DSGD_CS is read when a context is created."""
     import os
 
-    old = os.environ.get("DSGD_CS")
-    os.environ["DSGD_CS"] = "0"
+    pins = {"DSGD_CS": "0",
+            # ... and the STREAMING kernels for row ranges from 8,192 rows on (the product switches to them at 131,072: below
+            # that the row-wise kernel is faster; the tests' data sets are 8 K .. 200 K rows and must reach the streaming
+            # kernels all the same).  test_row_ranges_below_the_streaming_threshold runs the product's choice.
+            "DSGD_STREAM_MIN": "8192"}
+    old = {k: os.environ.get(k) for k in pins}
+    os.environ.update(pins)
     yield
-    if old is None:
-        del os.environ["DSGD_CS"]
-    else:
-        os.environ["DSGD_CS"] = old
+    for k, v in old.items():
+        if v is None:
+            del os.environ[k]
+        else:
+            os.environ[k] = v
 
 
 def tol(w_ref):
@@ -479,6 +485,29 @@ def test_forced_shift_15_stays_inside_the_derived_bound(monkeypatch):
                 assert len(only_eng) == 0
         assert shifts == [15, 15, 15]
         assert eng.tuning_info()["fix_shift"] == 15
+
+
+@pytest.mark.parametrize("n_rows", [23149, 100000])
+def test_row_ranges_below_the_streaming_threshold(monkeypatch, n_rows):
+    """The product's own choice for row ranges of the reference's small data set (N = 23,149, application.conf:24) and
+    of 80,000 train rows: below DSGD_STREAM_MIN = 131,072 rows the row-wise kernel + fused reduce, not the four launches
+    of the split streams -- whole-shard and two-worker steps from non-zero weights under the derived bound."""
+    monkeypatch.delenv("DSGD_STREAM_MIN")
+    data = dsgd_amd.synth.generate(n_rows, seed=41)
+    n_train = int(n_rows * 0.8)
+    o, eng = make_pair(data, 1e-5, n_train)
+    with eng:
+        rng = np.random.default_rng(41)
+        w0 = np.zeros(data.dim + 1, dtype=np.float32)
+        hot = rng.choice(np.arange(1, data.dim + 1), size=8000, replace=False)
+        w0[hot] = rng.normal(scale=0.05, size=8000).astype(np.float32)
+        eng.set_weights(w0)
+        for ranges in ([(0, n_train)], [(0, n_train // 2), (n_train // 2, n_train)], [(0, n_train)]):
+            ranged_step(o, eng, ranges, 0.5 * 100 / n_train * len(ranges))
+            assert eng.grad_kernel_name() == "dsgd_mb_grad_kernel"
+        loss, acc, counts = eng.loss_acc(n_train, n_rows)
+        l_ref, a_ref, c_ref, mam = o.loss_acc(eng.get_weights().astype(np.float64), n_train, n_rows)
+        assert abs(loss - l_ref) <= 1e-6 and (counts == c_ref or mam < GATE_EPS)
 
 
 # ---- small batches: ONE persistent workgroup (dsgd_plan_kernel) vs the multi-launch path vs the oracle ---------------
