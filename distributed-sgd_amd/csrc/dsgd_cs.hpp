@@ -451,17 +451,32 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
   // 8.6 of the 18 us of a one-step launch.)
   CsSet<SPL, CLT> A, B;
   cs_issue<NT, SPL, CLT>(a, z.b, a.step_begin, A);
-  {   // the slice's weights and dimSparsity values: two contiguous pieces (the padding holds zeros)
+  for (int i = tid; i < K * z.Sp; i += NT) z.acc[i] = 0;
+  {   // the slice's weights and dimSparsity values: two contiguous pieces (the padding holds zeros), all requested at once
     const float4* ws4 = reinterpret_cast<const float4*>(a.w + (long long)z.b * z.Sp);
     const float4* ds4 = reinterpret_cast<const float4*>(a.ds + (long long)z.b * z.Sp);
     float4* wl4 = reinterpret_cast<float4*>(z.w_l);
     float4* dl4 = reinterpret_cast<float4*>(z.ds_l);
-    for (int i4 = tid; i4 < (z.Sp >> 2); i4 += NT) {
-      wl4[i4] = ws4[i4];
-      dl4[i4] = ds4[i4];
+    constexpr int UB = 4;
+    const int n4 = z.Sp >> 2;
+    for (int i0 = tid; i0 < n4; i0 += NT * UB) {
+      float4 wv[UB], dv[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int i4 = i0 + NT * u;
+        wv[u] = ws4[i4 < n4 ? i4 : n4 - 1];
+        dv[u] = ds4[i4 < n4 ? i4 : n4 - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int i4 = i0 + NT * u;
+        if (i4 < n4) {
+          wl4[i4] = wv[u];
+          dl4[i4] = dv[u];
+        }
+      }
     }
   }
-  for (int i = tid; i < K * z.Sp; i += NT) z.acc[i] = 0;
   cs_barrier();
   // this slice's share of w . ds of the weights the launch starts from: the SAME pass, lane assignment and order as behind
   // every step -- a plan run step by step and in one launch see the same bits
