@@ -451,15 +451,15 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
   // 8.6 of the 18 us of a one-step launch.)
   CsSet<SPL, CLT> A, B;
   cs_issue<NT, SPL, CLT>(a, z.b, a.step_begin, A);
-  for (int i = tid; i < K * z.Sp; i += NT) z.acc[i] = 0;
-  {   // the slice's weights and dimSparsity values: two contiguous pieces (the padding holds zeros), all requested at once
+  {   // the slice's weights and dimSparsity values: two contiguous pieces (the padding holds zeros), requested at once; the
+      // accumulators are cleared while the first requests are on their way (clearing first cost 1.3 us of a one-step launch)
     const float4* ws4 = reinterpret_cast<const float4*>(a.w + (long long)z.b * z.Sp);
     const float4* ds4 = reinterpret_cast<const float4*>(a.ds + (long long)z.b * z.Sp);
     float4* wl4 = reinterpret_cast<float4*>(z.w_l);
     float4* dl4 = reinterpret_cast<float4*>(z.ds_l);
     constexpr int UB = 4;
     const int n4 = z.Sp >> 2;
-    for (int i0 = tid; i0 < n4; i0 += NT * UB) {
+    for (int i0 = tid, round = 0; round == 0 || i0 < n4; i0 += NT * UB, ++round) {   // (every lane runs the first round)
       float4 wv[UB], dv[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
@@ -467,6 +467,8 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
         wv[u] = ws4[i4 < n4 ? i4 : n4 - 1];
         dv[u] = ds4[i4 < n4 ? i4 : n4 - 1];
       }
+      if (round == 0)
+        for (int i = tid; i < K * z.Sp; i += NT) z.acc[i] = 0;
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int i4 = i0 + NT * u;
