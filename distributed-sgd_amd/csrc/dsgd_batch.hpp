@@ -1286,6 +1286,7 @@ struct HogArgs {
   float lr, lambda;
   float qscale, inv_qscale;     // 2^shift / vmax2 and its inverse
   int batch, positional_bug, hl, wl, dp;   // hl: ranks with an LDS accumulator; wl: ranks with an LDS copy of w (whole 1 KiB pieces: a multiple of 256)
+  unsigned long long* tprof;    // PROF: [0..5] cycles by phase (batch, hot sweep, cold strip, drain, scalars, weight copy), [15] iterations
   unsigned int* trace;          // optional (dsgd_async_set_trace): one record per mini-batch update, indexed by its commit number
   long long trace_cap;          // ... records of HOG_TRACE_HDR + (batch + 31) / 32 words
 };
@@ -1323,7 +1324,7 @@ struct HogCtl {   // per iteration parity
 };
 
 __host__ __device__ constexpr int hog_lds_words(int hl, int wl, int dp) {
-  return wl + ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8 + HOG_MAX_BATCH / 32;
+  return wl + ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8 + HOG_MAX_BATCH / 32 + 8;
 }
 
 // Copy of w[0, wl) into LDS: each wave moves 1 KiB pieces straight from the fabric into LDS (global_load_lds_dwordx4:
@@ -1363,6 +1364,7 @@ __device__ __forceinline__ void hog_sampler(const HogArgs& a, int worker, unsign
 // Registers: the master's loss check (dsgd_eval_kernel, launched with 256-lane blocks while this engine runs: one wave
 // of 40 VGPRs per SIMD) must stay co-resident with the two waves per SIMD of this kernel (225 VGPRs -> 232 allocated):
 // 2 x 232 + 40 <= 512.
+template <bool PROF>   // PROF (DSGD_PLAN_PROF=1, tuning runs): thread 0 of worker 0 counts the cycles of an iteration by phase
 __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   BtLds L;
@@ -1378,8 +1380,19 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   unsigned int* redn = reinterpret_cast<unsigned int*>(red + 8);
   HogCtl* ctl = reinterpret_cast<HogCtl*>(red + 16);                       // 2 slots (iteration parity)
   unsigned int* gmask = reinterpret_cast<unsigned int*>(red + 24);         // traced runs: gate decisions of the mini-batch
+  unsigned int* tp = gmask + HOG_MAX_BATCH / 32;                           // PROF: six phase sums, [6] the last stamp (32-bit)
   const int tid = threadIdx.x;
   const int worker = blockIdx.x;
+  const bool prof = PROF && worker == 0 && tid == 0;
+  auto stamp = [&](int i) {
+    if (PROF && prof) {
+      const unsigned int now = (unsigned int)__builtin_readcyclecounter();
+      tp[i] += now - tp[6];
+      tp[6] = now;
+    }
+  };
+  if (PROF && prof)
+    for (int i = 0; i < 8; ++i) tp[i] = 0u;
   if (tid < HOG_MAX_BATCH / 32) gmask[tid] = 0u;
   unsigned int* const gm = a.trace ? gmask : nullptr;
   const long long begin = a.asg_begin[worker];
@@ -1441,6 +1454,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     bd = bt_build<HOG_THREADS, HOG_CAP>(L, B, 0, row);
     if (bd.x > 0) bt_items_issue<HOG_THREADS, HOG_R>(a.m, L, bd.y, items);
   }
+  if (PROF && prof) tp[6] = (unsigned int)__builtin_readcyclecounter();
   for (;;) {
     const HogCtl cur = ctl[it & 1];
     const unsigned long long mul = cur.mul, off = cur.off;
@@ -1464,6 +1478,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     const HogCtl nxt = ctl[(it + 1) & 1];
     const BtRow row_n = bt_rows_issue<HOG_CAP>(a.m, B, 0, [&](int t) { return row_at(nxt.mul, nxt.off, t); }, &a.st->err);
     __syncthreads();
+    stamp(0);
     // phase 2: mean, regularise on the support, scale, subtract from the shared w (ref: Slave.scala:98-101).
     // Dense sweep, consecutive lanes = consecutive ranks (the updates of the dense hot head coalesce); the dimSparsity
     // values of a pass are requested together, under the mask of the non-zero accumulators, before any is used.
@@ -1504,6 +1519,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         }
       }
     }
+    stamp(1);
     for (int wd = tid; wd < n_cw; wd += HOG_THREADS) {
       unsigned int bits = L.cbits[wd];
       if (!bits) continue;
@@ -1526,6 +1542,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         }
       }
     }
+    stamp(2);
     // one returning atomic per workgroup for the incremental regulariser scalar and the update counter: thread 0
     // continues with what they saw (no separate loads of the shared scalars in the next iteration)
 #pragma unroll
@@ -1536,6 +1553,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       redn[tid >> 6] = n_act;
     }
     __syncthreads();   // (drains this workgroup's updates of w: the barrier waits for every outstanding memory operation)
+    stamp(3);
     // The scalar s is kept by fp32 atomic increments (one per mini-batch, plus dsgd_update_grad's foreign updates): over
     // 10^6+ updates the rounding of every add accumulates like a random walk.  Every HOG_REDERIVE iterations worker 0
     // recomputes w . ds from the weights as they are now (fp64 partial sums) and adds the difference to the shared
@@ -1594,11 +1612,18 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       cn->stop = stop != 0 || (long long)u >= a.max_updates;
       hog_sampler(a, worker, it + 2, n_k, &ctl[it & 1]);   // (this iteration's slot is free: its fields are in registers)
     }
+    stamp(4);
     hog_wcache_wait();
     __syncthreads();
+    stamp(5);
     ++it;
     bd = bd_n;
+    if (PROF && prof) ++tp[7];
     if (ctl[it & 1].stop) break;
+  }
+  if (PROF && prof && a.tprof) {
+    for (int i = 0; i < 6; ++i) a.tprof[i] += tp[i];
+    a.tprof[15] += tp[7];
   }
   if (tid == 0) {
     a.it[worker] = it;

@@ -1882,7 +1882,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_eval_kernel<16>);
   DSGD_ATTR(dsgd_eval_kernel<8>);
   DSGD_ATTR(dsgd_colcount_kernel);
-  DSGD_ATTR(dsgd_hogwild_kernel);
+  DSGD_ATTR(dsgd_hogwild_kernel<false>);
+  DSGD_ATTR(dsgd_hogwild_kernel<true>);
   DSGD_ATTR(dsgd_mb_grad_kernel);
   DSGD_ATTR(dsgd_vt_grad_kernel<true>);
   DSGD_ATTR(dsgd_vt_grad_kernel<false>);
@@ -2867,7 +2868,9 @@ static int hog_launch(dsgd_ctx* c, long long max_updates) {
   a.trace = c->trace_cap > 0 ? c->d_trace : nullptr;
   a.trace_cap = c->trace_cap;
   const size_t lds = sizeof(float) * (size_t)hog_lds_words(a.hl, a.wl, c->dp);
-  hipLaunchKernelGGL(dsgd_hogwild_kernel, dim3(c->hog_n), dim3(HOG_THREADS), lds, c->async_stream, a);
+  a.tprof = c->d_tprof;
+  if (c->d_tprof) hipLaunchKernelGGL(dsgd_hogwild_kernel<true>, dim3(c->hog_n), dim3(HOG_THREADS), lds, c->async_stream, a);
+  else hipLaunchKernelGGL(dsgd_hogwild_kernel<false>, dim3(c->hog_n), dim3(HOG_THREADS), lds, c->async_stream, a);
   HIP_TRY(hipGetLastError());
   return DSGD_OK;
 }

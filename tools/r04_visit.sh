@@ -140,6 +140,13 @@ for s in d['steps']: print('   steps per launch', s.get('steps_per_launch'), ' u
 variants)
   echo "== A/B variants of the whole-shard step ($VARIANTS)"
   eval "timeout 900 python tools/variants.py $VARIANTS" 2>&1 | tee $OUT/variants.txt ;;
+hogcyc)
+  echo "== Hogwild: cycles of thread 0 of worker 0 per iteration by phase (DSGD_PLAN_PROF=1), 256 / 64 / 1 workers"
+  for W in 256 64 1; do
+    DSGD_PLAN_PROF=1 timeout 300 python tools/hog_prof.py 2000000 $W $((W * 150 + 300)) > $OUT/hog_cycles_$W.json 2> $OUT/hog_cycles.err; python -c "
+import json; d=json.load(open('$OUT/hog_cycles_$W.json'))
+r=d['runs'][-1]; print(d['workers'], 'workers', round(r['us_per_iteration_per_worker'],1), 'us/iteration', round(r['examples_per_s']/1e6,1), 'M ex/s', {k:int(v) for k,v in r.get('worker0_cycles_per_iteration',{}).items()})"
+  done ;;
 hog)
   timeout 300 python tools/hog_prof.py 8388608 256 60000 > $OUT/hogwild_8m.json 2> $OUT/hogwild_8m.err; cat $OUT/hogwild_8m.json ;;
 hogprof)
