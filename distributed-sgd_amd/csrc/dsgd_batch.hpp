@@ -1246,14 +1246,18 @@ __global__ void __launch_bounds__(1024) dsgd_vt_grad_kernel(VtArgs a) {
 // batch == 1 is a single uniform draw, as Slave.scala:84.  The wire-level worker (wire.SlaveWorker) replays the JVM
 // generator exactly for hosts that need it.
 struct HogState {
-  unsigned long long updates;   // mini-batch updates applied (MasterAsync counts these: MasterAsync.scala:83,171)
-  unsigned long long samples;   // rows whose gradient was computed
-  unsigned long long active;    // ... of which the gate let through
-  float s_reg;                  // 2 * lambda * (w . ds), maintained incrementally
+  unsigned long long updates;   // mini-batch updates applied (MasterAsync counts these: MasterAsync.scala:83,171): ONE returning atomic
+                                //   per update -- alone on its 128-byte line with words that are written rarely
+  unsigned long long samples;   // rows whose gradient was computed    } flushed by a worker every HOG_STATS_EVERY of its iterations
+  unsigned long long active;    // ... of which the gate let through    } and when it leaves (exact once the engine is joined; up to
+  unsigned long long atomics;   // lane-level atomicAdd(w[j], -delta_j)  } 16 iterations per worker behind while it runs)
   int done_blocks;
   int stop;                     // raised by the host (copy on a side stream): workers exit after their mini-batch
   int err;                      // a sampled row fell outside the data
-  unsigned long long atomics;   // lane-level atomicAdd(w[j], -delta_j) performed: the coordinates the updates really moved
+  // 2 * lambda * (w . ds), maintained incrementally: the OTHER returning atomic of an update, on a line of its own.  (Five
+  // atomics per update on one line -- 1,280 per round of 256 workers, served one after the other -- were 8 of an
+  // iteration's 45 us: profiles/r04_hogwild_phase_cycles.txt)
+  alignas(128) float s_reg;
 };
 
 // Traced runs (dsgd_async_set_trace; parity evidence for many workers, tests/test_gpu_hogwild_trace.py): the update
@@ -1313,8 +1317,9 @@ constexpr int HOG_MAX_BATCH = 4096;
 constexpr int HOG_HL = 20480;      // ranks with an LDS accumulator (80 KiB)
 constexpr int HOG_WL = 12288;      // ranks whose weight is gathered from an LDS copy refreshed every iteration (48 KiB;
                                    // with the tables 136 KiB: 16 KiB of dsgd_eval_kernel still fit the CU)
-constexpr int HOG_SW = 8;          // accumulator slots per thread and sweep pass
+constexpr int HOG_SW = 4;          // accumulator slots per thread and sweep pass (and as many dimSparsity values of the NEXT pass in flight)
 constexpr unsigned int HOG_ATOMIC_ONE = 1u << 13;   // active rows of a mini-batch (<= 4096) in the low 13 bits, weight atomics above
+constexpr int HOG_STATS_EVERY = 16;   // iterations between a worker's flushes of its sample / active / atomic counts
 constexpr int HOG_REDERIVE = 4096; // worker 0 re-derives s = 2 lambda (w . ds) from the weights every so many of its iterations
 
 struct HogCtl {   // per iteration parity
@@ -1324,7 +1329,7 @@ struct HogCtl {   // per iteration parity
 };
 
 __host__ __device__ constexpr int hog_lds_words(int hl, int wl, int dp) {
-  return wl + ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8 + HOG_MAX_BATCH / 32 + 8;
+  return wl + ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8 + HOG_MAX_BATCH / 32 + 8 + 4;
 }
 
 // Copy of w[0, wl) into LDS: each wave moves 1 KiB pieces straight from the fabric into LDS (global_load_lds_dwordx4:
@@ -1381,6 +1386,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   HogCtl* ctl = reinterpret_cast<HogCtl*>(red + 16);                       // 2 slots (iteration parity)
   unsigned int* gmask = reinterpret_cast<unsigned int*>(red + 24);         // traced runs: gate decisions of the mini-batch
   unsigned int* tp = gmask + HOG_MAX_BATCH / 32;                           // PROF: six phase sums, [6] the last stamp (32-bit)
+  unsigned int* stl = tp + 8;                                              // thread 0: samples / active rows / weight atomics not yet flushed
   const int tid = threadIdx.x;
   const int worker = blockIdx.x;
   const bool prof = PROF && worker == 0 && tid == 0;
@@ -1394,6 +1400,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   if (PROF && prof)
     for (int i = 0; i < 8; ++i) tp[i] = 0u;
   if (tid < HOG_MAX_BATCH / 32) gmask[tid] = 0u;
+  if (tid < 4) stl[tid] = 0u;
   unsigned int* const gm = a.trace ? gmask : nullptr;
   const long long begin = a.asg_begin[worker];
   const unsigned int n_k = (unsigned int)(a.asg_end[worker] - begin);   // < 2^31 rows per context
@@ -1484,6 +1491,16 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     // values of a pass are requested together, under the mask of the non-zero accumulators, before any is used.
     float ds_acc = 0.0f;
     int2 bd_n = make_int2(0, 0);
+    // (dimSparsity never changes: plain loads, requested ONE PASS AHEAD and for every slot -- requested under the mask of
+    //  the pass's own non-zero accumulators they were a dependent round trip per pass: the sweep was 12 of a lone worker's
+    //  25 us and 21 of 45 us with 256 workers)
+    // (one buffer resource over the hot head, the lane's offset in ONE register, the slot's in a scalar: beyond the head a
+    //  buffer load returns zero -- no clamps, no 64-bit lane addresses: the kernel has 3 registers to spare)
+    const __amdgpu_buffer_rsrc_t ds_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ds), 0, a.hl * 4, 0x00020000);
+    float dsn[HOG_SW];
+#pragma unroll
+    for (int e = 0; e < HOG_SW; ++e)
+      dsn[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ds_rs, tid * 4, e * HOG_THREADS * 4, 0));
     for (int j0 = 0, pass = 0; j0 < a.hl; j0 += HOG_THREADS * HOG_SW, ++pass) {
       int q[HOG_SW];
       float dsv[HOG_SW];
@@ -1491,12 +1508,11 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       for (int e = 0; e < HOG_SW; ++e) {
         const int j = j0 + e * HOG_THREADS + tid;
         q[e] = j < a.hl ? L.acc[j] : 0;
+        dsv[e] = dsn[e];
       }
 #pragma unroll
-      for (int e = 0; e < HOG_SW; ++e) {
-        dsv[e] = 0.0f;
-        if (q[e] != 0) dsv[e] = a.ds[j0 + e * HOG_THREADS + tid];
-      }
+      for (int e = 0; e < HOG_SW; ++e)
+        dsn[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ds_rs, tid * 4, (j0 + (HOG_SW + e) * HOG_THREADS) * 4, 0));
       if (pass == 0) {
         // the row records have landed behind the first pass's loads: tables and the non-zeros of the next sub-batch
         // (the tables of this iteration are no longer needed: every scatter is behind the barrier above)
@@ -1580,7 +1596,13 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         na += redn[i];
       }
       const float ds_term = -2.0f * a.lambda * tot;
-      s = atomicAdd(&a.st->s_reg, ds_term) + ds_term;
+      // the sampler of iteration + 2 first (a gcd loop, no memory; this iteration's slot is free: its fields are in
+      // registers), then the two returning atomics and the stop flag go out TOGETHER: one round trip
+      hog_sampler(a, worker, it + 2, n_k, &ctl[it & 1]);
+      const float s_seen = atomicAdd(&a.st->s_reg, ds_term);
+      const unsigned long long u_seen = atomicAdd(&a.st->updates, 1ull);
+      const int stop = __hip_atomic_load(&a.st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s = s_seen + ds_term;
       if (rederive) {
         double dot = 0.0;
         for (int i = 0; i < HOG_THREADS / 64; ++i) dot += dred[i];
@@ -1588,7 +1610,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         s = atomicAdd(&a.st->s_reg, corr) + corr;
       }
       const unsigned long long read_at = u;
-      u = atomicAdd(&a.st->updates, 1ull) + 1ull;
+      u = u_seen + 1ull;
       if (a.trace) {   // (one lane, once per mini-batch; the decisions were taken several barriers ago)
         const int mw = (B + 31) >> 5;
         if ((long long)u <= a.trace_cap) {
@@ -1603,14 +1625,20 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         }
         for (int i = 0; i < mw; ++i) gmask[i] = 0u;   // (the next gate is behind the barriers below)
       }
-      atomicAdd(&a.st->samples, (unsigned long long)B);
-      atomicAdd(&a.st->active, (unsigned long long)(na & (HOG_ATOMIC_ONE - 1u)));
-      atomicAdd(&a.st->atomics, (unsigned long long)(na >> 13));
-      const int stop = __hip_atomic_load(&a.st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // statistics: kept in LDS, flushed every HOG_STATS_EVERY iterations and when the worker leaves
+      const bool leaving = stop != 0 || (long long)u >= a.max_updates;
+      stl[0] += (unsigned int)B;
+      stl[1] += na & (HOG_ATOMIC_ONE - 1u);
+      stl[2] += na >> 13;
+      if (leaving || ((it + 1) & (unsigned long long)(HOG_STATS_EVERY - 1)) == 0) {
+        atomicAdd(&a.st->samples, (unsigned long long)stl[0]);
+        atomicAdd(&a.st->active, (unsigned long long)stl[1]);
+        atomicAdd(&a.st->atomics, (unsigned long long)stl[2]);
+        stl[0] = stl[1] = stl[2] = 0u;
+      }
       HogCtl* cn = &ctl[(it + 1) & 1];
       cn->s = s;
-      cn->stop = stop != 0 || (long long)u >= a.max_updates;
-      hog_sampler(a, worker, it + 2, n_k, &ctl[it & 1]);   // (this iteration's slot is free: its fields are in registers)
+      cn->stop = leaving;
     }
     stamp(4);
     hog_wcache_wait();
