@@ -1252,12 +1252,17 @@ struct HogState {
   unsigned long long active;    // ... of which the gate let through    } and when it leaves (exact once the engine is joined; up to
   unsigned long long atomics;   // lane-level atomicAdd(w[j], -delta_j)  } 16 iterations per worker behind while it runs)
   int done_blocks;
-  int stop;                     // raised by the host (copy on a side stream): workers exit after their mini-batch
   int err;                      // a sampled row fell outside the data
   // 2 * lambda * (w . ds), maintained incrementally: the OTHER returning atomic of an update, on a line of its own.  (Five
   // atomics per update on one line -- 1,280 per round of 256 workers, served one after the other -- were 8 of an
   // iteration's 45 us: profiles/r04_hogwild_phase_cycles.txt)
   alignas(128) float s_reg;
+  // raised by the host (a 4-byte copy on a side stream): workers exit after their mini-batch.  Read with a RETURNING
+  // atomic (fetch_or 0): an sc1 load is served by the XCD's L2, which a copy engine's write does not reach -- the flag was
+  // only ever seen fresh because the atomics on the same line had just dropped it, and stopped being seen (256 workers)
+  // the day the load was issued next to them instead of behind them.  On its own line: the third of three returning
+  // atomics that go out together.
+  alignas(128) int stop;
 };
 
 // Traced runs (dsgd_async_set_trace; parity evidence for many workers, tests/test_gpu_hogwild_trace.py): the update
@@ -1317,7 +1322,6 @@ constexpr int HOG_MAX_BATCH = 4096;
 constexpr int HOG_HL = 20480;      // ranks with an LDS accumulator (80 KiB)
 constexpr int HOG_WL = 12288;      // ranks whose weight is gathered from an LDS copy refreshed every iteration (48 KiB;
                                    // with the tables 136 KiB: 16 KiB of dsgd_eval_kernel still fit the CU)
-constexpr int HOG_SW = 4;          // accumulator slots per thread and sweep pass (and as many dimSparsity values of the NEXT pass in flight)
 constexpr unsigned int HOG_ATOMIC_ONE = 1u << 13;   // active rows of a mini-batch (<= 4096) in the low 13 bits, weight atomics above
 constexpr int HOG_STATS_EVERY = 16;   // iterations between a worker's flushes of its sample / active / atomic counts
 constexpr int HOG_REDERIVE = 4096; // worker 0 re-derives s = 2 lambda (w . ds) from the weights every so many of its iterations
@@ -1329,7 +1333,7 @@ struct HogCtl {   // per iteration parity
 };
 
 __host__ __device__ constexpr int hog_lds_words(int hl, int wl, int dp) {
-  return wl + ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8 + HOG_MAX_BATCH / 32 + 8 + 4;
+  return wl + ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8 + HOG_MAX_BATCH / 32 + 8 + 8;
 }
 
 // Copy of w[0, wl) into LDS: each wave moves 1 KiB pieces straight from the fabric into LDS (global_load_lds_dwordx4:
@@ -1355,6 +1359,16 @@ __device__ __forceinline__ void hog_wcache_issue(const float* __restrict__ w, fl
   }
 }
 __device__ __forceinline__ void hog_wcache_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// The stop flag, read where the host's copy engine wrote it: a RETURNING atomic executes at the memory side.  (Written as
+// fetch_or(p, 0) the compiler turns it back into an sc1 load -- an idempotent read-modify-write -- hence the asm; the wait
+// covers the two returning atomics issued just before it as well.)
+__device__ __forceinline__ int hog_read_stop(int* p) {
+  int v;
+  const int zero = 0;
+  asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p), "v"(zero) : "memory");
+  return v;
+}
 
 // the sampler of iteration `it`: rows base + (mul * t + off) mod n_k, t = 0..B-1 (distinct rows)
 __device__ __forceinline__ void hog_sampler(const HogArgs& a, int worker, unsigned long long it, unsigned int n_k,
@@ -1386,7 +1400,9 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   HogCtl* ctl = reinterpret_cast<HogCtl*>(red + 16);                       // 2 slots (iteration parity)
   unsigned int* gmask = reinterpret_cast<unsigned int*>(red + 24);         // traced runs: gate decisions of the mini-batch
   unsigned int* tp = gmask + HOG_MAX_BATCH / 32;                           // PROF: six phase sums, [6] the last stamp (32-bit)
-  unsigned int* stl = tp + 8;                                              // thread 0: samples / active rows / weight atomics not yet flushed
+  unsigned int* stl = tp + 8;                                              // thread 0: samples / active rows / weight atomics not yet flushed;
+                                                                           //   [4..5] the update count its weights were read at (a register
+                                                                           //   pair in every lane otherwise: the kernel has none to spare)
   const int tid = threadIdx.x;
   const int worker = blockIdx.x;
   const bool prof = PROF && worker == 0 && tid == 0;
@@ -1413,12 +1429,13 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   unsigned long long it = a.it[worker];
   hog_wcache_issue(a.w, wl, a.wl);   // (lands under the start-up loads below; waited for in front of the first barrier)
   // thread 0 carries the shared scalars between iterations: what its own returning atomics saw
-  unsigned long long u = 0;   // (between commits: the update count this iteration's weights were read at)
   float s = 0.0f;
   if (tid == 0) {
-    u = __hip_atomic_load(&a.st->updates, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long u = __hip_atomic_load(&a.st->updates, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stl[4] = (unsigned int)u;   // (between commits: the update count this iteration's weights were read at)
+    stl[5] = (unsigned int)(u >> 32);
     s = __hip_atomic_load(&a.st->s_reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int stop = __hip_atomic_load(&a.st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int stop = hog_read_stop(&a.st->stop);
     HogCtl* c0 = &ctl[it & 1];
     hog_sampler(a, worker, it, n_k, c0);
     c0->s = s;
@@ -1491,47 +1508,46 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     // values of a pass are requested together, under the mask of the non-zero accumulators, before any is used.
     float ds_acc = 0.0f;
     int2 bd_n = make_int2(0, 0);
-    // (dimSparsity never changes: plain loads, requested ONE PASS AHEAD and for every slot -- requested under the mask of
-    //  the pass's own non-zero accumulators they were a dependent round trip per pass: the sweep was 12 of a lone worker's
-    //  25 us and 21 of 45 us with 256 workers)
-    // (one buffer resource over the hot head, the lane's offset in ONE register, the slot's in a scalar: beyond the head a
-    //  buffer load returns zero -- no clamps, no 64-bit lane addresses: the kernel has 3 registers to spare)
-    const __amdgpu_buffer_rsrc_t ds_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ds), 0, a.hl * 4, 0x00020000);
-    float dsn[HOG_SW];
-#pragma unroll
-    for (int e = 0; e < HOG_SW; ++e)
-      dsn[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ds_rs, tid * 4, e * HOG_THREADS * 4, 0));
-    for (int j0 = 0, pass = 0; j0 < a.hl; j0 += HOG_THREADS * HOG_SW, ++pass) {
-      int q[HOG_SW];
-      float dsv[HOG_SW];
-#pragma unroll
-      for (int e = 0; e < HOG_SW; ++e) {
-        const int j = j0 + e * HOG_THREADS + tid;
-        q[e] = j < a.hl ? L.acc[j] : 0;
-        dsv[e] = dsn[e];
+    // A lane owns FOUR consecutive ranks per pass: one 16-byte LDS read tells it whether any of them was touched (78 % of
+    // the quads of a 100-row batch are empty -- 94 % of the accumulators), one 16-byte buffer load brings their dimSparsity
+    // values -- requested ONE PASS AHEAD and unconditionally (they never change; under the mask of the pass's own non-zero
+    // accumulators they were a dependent round trip per pass), through one resource over the hot head: beyond it a buffer
+    // load returns zero -- no clamps, no 64-bit lane addresses (the kernel has 3 registers to spare).  Slot by slot the
+    // sweep was 40 LDS reads and 40 tests per lane: 12 of a lone worker's 25 us, 21 of 45 us with 256 workers.
+    auto hot_entry = [&](int j, int qv, float dsj) {
+      float g = filt(((float)qv * a.inv_qscale) / fB);   // Vec.mean divides (ref: math/Vec.scala:139)
+      if (g == 0.0f) return;
+      if (add_s) g = filt(g + s_it);
+      const float delta = filt(g * a.lr);
+      if (delta != 0.0f) {
+        atomicAdd(&a.w[j], -delta);   // lock-free update of the ONE weight vector
+        ds_acc += delta * dsj;
+        n_act += HOG_ATOMIC_ONE;      // (counted in the upper bits of the active-row counter: no register to spare)
       }
-#pragma unroll
-      for (int e = 0; e < HOG_SW; ++e)
-        dsn[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ds_rs, tid * 4, (j0 + (HOG_SW + e) * HOG_THREADS) * 4, 0));
-      if (pass == 0) {
-        // the row records have landed behind the first pass's loads: tables and the non-zeros of the next sub-batch
-        // (the tables of this iteration are no longer needed: every scatter is behind the barrier above)
-        bd_n = bt_build<HOG_THREADS, HOG_CAP>(L, B, 0, row_n);
-        if (bd_n.x > 0) bt_items_issue<HOG_THREADS, HOG_R>(a.m, L, bd_n.y, items);
-      }
-#pragma unroll
-      for (int e = 0; e < HOG_SW; ++e) {
-        if (q[e] == 0) continue;
-        const int j = j0 + e * HOG_THREADS + tid;
-        L.acc[j] = 0;
-        float g = filt(((float)q[e] * a.inv_qscale) / fB);   // Vec.mean divides (ref: math/Vec.scala:139)
-        if (g == 0.0f) continue;
-        if (add_s) g = filt(g + s_it);
-        const float delta = filt(g * a.lr);
-        if (delta != 0.0f) {
-          atomicAdd(&a.w[j], -delta);   // lock-free update of the ONE weight vector
-          ds_acc += delta * dsv[e];
-          n_act += HOG_ATOMIC_ONE;      // (counted in the upper bits of the active-row counter: no register to spare)
+    };
+    {   // (a.hl is a multiple of four: the host rounds the hot head down, the remainder goes to the cold strip)
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t ds_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ds), 0, a.hl * 4, 0x00020000);
+      int4* acc4 = reinterpret_cast<int4*>(L.acc);
+      const int nq = a.hl >> 2;
+      f32x4 dsn = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ds_rs, tid * 16, 0, 0));
+      for (int q0 = 0, pass = 0; q0 < nq; q0 += HOG_THREADS, ++pass) {
+        const int qi = q0 + tid;
+        const int4 q = qi < nq ? acc4[qi] : make_int4(0, 0, 0, 0);
+        const f32x4 dsv = dsn;
+        dsn = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ds_rs, tid * 16, (q0 + HOG_THREADS) * 16, 0));
+        if (pass == 0) {
+          // the row records have landed behind the first pass's loads: tables and the non-zeros of the next sub-batch
+          // (the tables of this iteration are no longer needed: every scatter is behind the barrier above)
+          bd_n = bt_build<HOG_THREADS, HOG_CAP>(L, B, 0, row_n);
+          if (bd_n.x > 0) bt_items_issue<HOG_THREADS, HOG_R>(a.m, L, bd_n.y, items);
+        }
+        if ((q.x | q.y | q.z | q.w) != 0) {
+          acc4[qi] = make_int4(0, 0, 0, 0);
+          if (q.x) hot_entry(4 * qi, q.x, dsv[0]);
+          if (q.y) hot_entry(4 * qi + 1, q.y, dsv[1]);
+          if (q.z) hot_entry(4 * qi + 2, q.z, dsv[2]);
+          if (q.w) hot_entry(4 * qi + 3, q.w, dsv[3]);
         }
       }
     }
@@ -1601,7 +1617,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       hog_sampler(a, worker, it + 2, n_k, &ctl[it & 1]);
       const float s_seen = atomicAdd(&a.st->s_reg, ds_term);
       const unsigned long long u_seen = atomicAdd(&a.st->updates, 1ull);
-      const int stop = __hip_atomic_load(&a.st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int stop = hog_read_stop(&a.st->stop);
       s = s_seen + ds_term;
       if (rederive) {
         double dot = 0.0;
@@ -1609,8 +1625,10 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         const float corr = (float)(2.0 * (double)a.lambda * dot) - s;
         s = atomicAdd(&a.st->s_reg, corr) + corr;
       }
-      const unsigned long long read_at = u;
-      u = u_seen + 1ull;
+      const unsigned long long read_at = ((unsigned long long)stl[5] << 32) | stl[4];
+      const unsigned long long u = u_seen + 1ull;
+      stl[4] = (unsigned int)u;
+      stl[5] = (unsigned int)(u >> 32);
       if (a.trace) {   // (one lane, once per mini-batch; the decisions were taken several barriers ago)
         const int mw = (B + 31) >> 5;
         if ((long long)u <= a.trace_cap) {

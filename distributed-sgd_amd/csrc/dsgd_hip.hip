@@ -2862,7 +2862,7 @@ static int hog_launch(dsgd_ctx* c, long long max_updates) {
   a.inv_qscale = std::ldexp(1.0f, c->vexp - shift);
   a.batch = c->hog_batch;
   a.positional_bug = c->hog_bug;
-  a.hl = std::min(c->dp, c->hog_hl);
+  a.hl = std::min(c->dp, c->hog_hl) & ~3;   // (whole quads of ranks: the sweep reads four accumulators at once; the rest is cold strip)
   a.dp = c->dp;
   a.wl = std::min(c->hog_wl, c->dp) & ~255;
   a.trace = c->trace_cap > 0 ? c->d_trace : nullptr;
@@ -2937,7 +2937,7 @@ int dsgd_async_start(dsgd_ctx* c, const int64_t* assigned_begin, const int64_t* 
     HIP_TRY(hipHostMalloc(&c->h_one, sizeof(int), hipHostMallocDefault));
     *c->h_one = 1;
   }
-  const int hl = std::min(c->dp, c->hog_hl);
+  const int hl = std::min(c->dp, c->hog_hl) & ~3;
   const size_t strip = (size_t)std::max(1, c->dp - hl);
   if (n_workers > c->hog_workers) {
     (void)hipFree(c->d_gcold);

@@ -860,7 +860,9 @@ def test_hogwild_many_workers_inside_the_oracle_band(k, n_rows, checkpoints):
         eng.async_start(split, batch=batch, lr=0.5, max_updates=10**9, seed=6)
         eng.async_stop()
         u2, running = eng.async_updates()
-        assert not running and 0 <= u2 < 10**9
+        # (... promptly: every worker finishes the mini-batch it is in -- the flag is read where the host's copy engine wrote
+        #  it; served from a stale L2 line it went unseen by 256 workers for 4e8 updates: profiles/r04_hogwild_phase_cycles.txt)
+        assert not running and 0 <= u2 <= 8 * k
         st = eng.sync_step([np.arange(100, dtype=np.int32)], 0.5)  # synchronous calls work again afterwards
         assert st["n_samples"] == 100
 
