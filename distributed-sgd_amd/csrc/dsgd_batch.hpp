@@ -1322,6 +1322,7 @@ constexpr int HOG_MAX_BATCH = 4096;
 constexpr int HOG_HL = 20480;      // ranks with an LDS accumulator (80 KiB)
 constexpr int HOG_WL = 12288;      // ranks whose weight is gathered from an LDS copy refreshed every iteration (48 KiB;
                                    // with the tables 136 KiB: 16 KiB of dsgd_eval_kernel still fit the CU)
+constexpr int HOG_SW = 4;          // accumulator slots per thread and sweep pass (and as many dimSparsity values of the NEXT pass in flight)
 constexpr unsigned int HOG_ATOMIC_ONE = 1u << 13;   // active rows of a mini-batch (<= 4096) in the low 13 bits, weight atomics above
 constexpr int HOG_STATS_EVERY = 16;   // iterations between a worker's flushes of its sample / active / atomic counts
 constexpr int HOG_REDERIVE = 4096; // worker 0 re-derives s = 2 lambda (w . ds) from the weights every so many of its iterations
@@ -1508,46 +1509,49 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     // values of a pass are requested together, under the mask of the non-zero accumulators, before any is used.
     float ds_acc = 0.0f;
     int2 bd_n = make_int2(0, 0);
-    // A lane owns FOUR consecutive ranks per pass: one 16-byte LDS read tells it whether any of them was touched (78 % of
-    // the quads of a 100-row batch are empty -- 94 % of the accumulators), one 16-byte buffer load brings their dimSparsity
-    // values -- requested ONE PASS AHEAD and unconditionally (they never change; under the mask of the pass's own non-zero
-    // accumulators they were a dependent round trip per pass), through one resource over the hot head: beyond it a buffer
-    // load returns zero -- no clamps, no 64-bit lane addresses (the kernel has 3 registers to spare).  Slot by slot the
-    // sweep was 40 LDS reads and 40 tests per lane: 12 of a lone worker's 25 us, 21 of 45 us with 256 workers.
-    auto hot_entry = [&](int j, int qv, float dsj) {
-      float g = filt(((float)qv * a.inv_qscale) / fB);   // Vec.mean divides (ref: math/Vec.scala:139)
-      if (g == 0.0f) return;
-      if (add_s) g = filt(g + s_it);
-      const float delta = filt(g * a.lr);
-      if (delta != 0.0f) {
-        atomicAdd(&a.w[j], -delta);   // lock-free update of the ONE weight vector
-        ds_acc += delta * dsj;
-        n_act += HOG_ATOMIC_ONE;      // (counted in the upper bits of the active-row counter: no register to spare)
+    // (dimSparsity never changes: requested ONE PASS AHEAD and for every slot -- under the mask of the pass's own non-zero
+    //  accumulators the values were a dependent round trip per pass.  Consecutive lanes = consecutive ranks: a wave's atomic
+    //  instruction covers two 128-byte lines.  A lane owning FOUR consecutive ranks -- one 16-byte LDS read per quad, 78 % of
+    //  the quads empty -- was tried: 10 instead of 40 tests per lane, but its atomics spread over eight lines per
+    //  instruction: 38.9 -> 51.9 us per iteration with 256 workers, profiles/r04_hogwild_phase_cycles.txt)
+    // (one buffer resource over the hot head, the lane's offset in ONE register, the slot's in a scalar: beyond the head a
+    //  buffer load returns zero -- no clamps, no 64-bit lane addresses: the kernel has 3 registers to spare)
+    const __amdgpu_buffer_rsrc_t ds_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ds), 0, a.hl * 4, 0x00020000);
+    float dsn[HOG_SW];
+#pragma unroll
+    for (int e = 0; e < HOG_SW; ++e)
+      dsn[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ds_rs, tid * 4, e * HOG_THREADS * 4, 0));
+    for (int j0 = 0, pass = 0; j0 < a.hl; j0 += HOG_THREADS * HOG_SW, ++pass) {
+      int q[HOG_SW];
+      float dsv[HOG_SW];
+#pragma unroll
+      for (int e = 0; e < HOG_SW; ++e) {
+        const int j = j0 + e * HOG_THREADS + tid;
+        q[e] = j < a.hl ? L.acc[j] : 0;
+        dsv[e] = dsn[e];
       }
-    };
-    {   // (a.hl is a multiple of four: the host rounds the hot head down, the remainder goes to the cold strip)
-      typedef float f32x4 __attribute__((ext_vector_type(4)));
-      const __amdgpu_buffer_rsrc_t ds_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ds), 0, a.hl * 4, 0x00020000);
-      int4* acc4 = reinterpret_cast<int4*>(L.acc);
-      const int nq = a.hl >> 2;
-      f32x4 dsn = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ds_rs, tid * 16, 0, 0));
-      for (int q0 = 0, pass = 0; q0 < nq; q0 += HOG_THREADS, ++pass) {
-        const int qi = q0 + tid;
-        const int4 q = qi < nq ? acc4[qi] : make_int4(0, 0, 0, 0);
-        const f32x4 dsv = dsn;
-        dsn = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ds_rs, tid * 16, (q0 + HOG_THREADS) * 16, 0));
-        if (pass == 0) {
-          // the row records have landed behind the first pass's loads: tables and the non-zeros of the next sub-batch
-          // (the tables of this iteration are no longer needed: every scatter is behind the barrier above)
-          bd_n = bt_build<HOG_THREADS, HOG_CAP>(L, B, 0, row_n);
-          if (bd_n.x > 0) bt_items_issue<HOG_THREADS, HOG_R>(a.m, L, bd_n.y, items);
-        }
-        if ((q.x | q.y | q.z | q.w) != 0) {
-          acc4[qi] = make_int4(0, 0, 0, 0);
-          if (q.x) hot_entry(4 * qi, q.x, dsv[0]);
-          if (q.y) hot_entry(4 * qi + 1, q.y, dsv[1]);
-          if (q.z) hot_entry(4 * qi + 2, q.z, dsv[2]);
-          if (q.w) hot_entry(4 * qi + 3, q.w, dsv[3]);
+#pragma unroll
+      for (int e = 0; e < HOG_SW; ++e)
+        dsn[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ds_rs, tid * 4, (j0 + (HOG_SW + e) * HOG_THREADS) * 4, 0));
+      if (pass == 0) {
+        // the row records have landed behind the first pass's loads: tables and the non-zeros of the next sub-batch
+        // (the tables of this iteration are no longer needed: every scatter is behind the barrier above)
+        bd_n = bt_build<HOG_THREADS, HOG_CAP>(L, B, 0, row_n);
+        if (bd_n.x > 0) bt_items_issue<HOG_THREADS, HOG_R>(a.m, L, bd_n.y, items);
+      }
+#pragma unroll
+      for (int e = 0; e < HOG_SW; ++e) {
+        if (q[e] == 0) continue;
+        const int j = j0 + e * HOG_THREADS + tid;
+        L.acc[j] = 0;
+        float g = filt(((float)q[e] * a.inv_qscale) / fB);   // Vec.mean divides (ref: math/Vec.scala:139)
+        if (g == 0.0f) continue;
+        if (add_s) g = filt(g + s_it);
+        const float delta = filt(g * a.lr);
+        if (delta != 0.0f) {
+          atomicAdd(&a.w[j], -delta);   // lock-free update of the ONE weight vector
+          ds_acc += delta * dsv[e];
+          n_act += HOG_ATOMIC_ONE;      // (counted in the upper bits of the active-row counter: no register to spare)
         }
       }
     }

@@ -192,7 +192,9 @@ int dsgd_async_stop(dsgd_ctx* ctx); /* SlaveImpl.stopAsync, core/Slave.scala:187
  * "additionally report atomics/s").  s_engine / s_exact (may be NULL): the engine's incrementally kept regulariser scalar
  * s = 2 lambda (w . ds) as the device holds it (one atomic add per mini-batch and per dsgd_update_grad call, re-derived
  * from the weights every few thousand iterations), and the same quantity recomputed from the weights as they are now.
- * While the engine runs the two differ by the updates in flight.                                                  */
+ * While the engine runs the two differ by the updates in flight; counters [1..3] are flushed by every worker each 16 of
+ * its iterations and when it leaves: exact once the engine is joined, up to 16 mini-batches per worker behind before
+ * (counters[0], what MasterAsync polls, is exact at any time).                                                      */
 int dsgd_async_stats(dsgd_ctx* ctx, int64_t* counters, double* s_engine, double* s_exact);
 int dsgd_async_wait(dsgd_ctx* ctx); /* block until max_updates reached */
 /* Parity aid for the MANY-worker lock-free engine (nothing in the reference; tests/test_gpu_hogwild_trace.py, bench.py):
