@@ -1045,10 +1045,12 @@ static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
   CS_SOFT(hipMemcpy(p->d_cs_rf, rf.data(), sizeof(unsigned short) * rf.size(), hipMemcpyHostToDevice));
   CS_SOFT(hipMemcpy(p->d_cs_col, col.data(), sizeof(unsigned short) * col.size(), hipMemcpyHostToDevice));
   CS_SOFT(hipMemcpy(p->d_cs_val, val.data(), sizeof(float) * val.size(), hipMemcpyHostToDevice));
-  if (!c->d_cs_x) {
+  if (!c->d_cs_x) {   // (each buffer for itself: a failure between the two must not leave the first behind alone)
     CS_SOFT(hipMalloc(&c->d_cs_x, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE));
-    CS_SOFT(hipMalloc(&c->d_cs_sync, sizeof(unsigned int) * 2));
     CS_SOFT(hipMemset(c->d_cs_x, 0, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE));
+  }
+  if (!c->d_cs_sync) {
+    CS_SOFT(hipMalloc(&c->d_cs_sync, sizeof(unsigned int) * 2));
     CS_SOFT(hipMemset(c->d_cs_sync, 0, sizeof(unsigned int) * 2));
   }
   p->cs_G = G;
@@ -1089,11 +1091,9 @@ static int launch_cs(dsgd_ctx* c, dsgd_plan* p, long long step_begin, long long 
   if (c->cs_w_G != p->cs_G) {
     DSGD_TRY(cs_unslice(c));
     const int Sp = cs_sp(c->dp, p->cs_G), n = p->cs_G * Sp;
-    if (!c->d_cs_w) {
-      const size_t cap = sizeof(float) * (size_t)(c->dp + (CS_MAX_G + 1) * 8);
-      HIP_TRY(hipMalloc(&c->d_cs_w, cap));
-      HIP_TRY(hipMalloc(&c->d_cs_ds, cap));
-    }
+    const size_t cap = sizeof(float) * (size_t)(c->dp + (CS_MAX_G + 1) * 8);
+    if (!c->d_cs_w) HIP_TRY(hipMalloc(&c->d_cs_w, cap));
+    if (!c->d_cs_ds) HIP_TRY(hipMalloc(&c->d_cs_ds, cap));
     hipLaunchKernelGGL(dsgd_cs_slice_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_w, c->d_cs_w, c->dp, p->cs_G, Sp);
     hipLaunchKernelGGL(dsgd_cs_slice_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_ds, c->d_cs_ds, c->dp, p->cs_G, Sp);
     HIP_TRY(hipGetLastError());
