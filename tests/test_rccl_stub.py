@@ -43,6 +43,9 @@ def seam_env(env=None):
     env["DSGD_RCCL_LIB"] = build_stub()
     env["DSGD_LIB_PATH"] = build_seam()
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    # the rank processes hold 24,000 .. 50,000 train rows each: keep their row ranges on the STREAMING kernels (the product
+    # switches to them at 131,072 rows) -- streaming kernels + all-reduce is the path bench.py --gpus N times
+    env.setdefault("DSGD_STREAM_MIN", "8192")
     return env
 
 
