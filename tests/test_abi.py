@@ -77,6 +77,45 @@ def test_product_never_imports_the_oracle():
                 assert not pat.search(text), (dirpath, f, pat.search(text).group(0))
 
 
+def _kernel_notes(tmp_path):
+    """{kernel name: {metadata key: int}} of the gfx950 code object inside the shipped library."""
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", _lib.HIP_LIB, fat])
+    subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    notes = subprocess.run([llvm + "/llvm-readelf", "--notes", co], stdout=subprocess.PIPE, text=True, check=True).stdout
+    out, cur = {}, {}
+    for line in notes.splitlines():   # (a kernel's keys are sorted: .name sits in the middle of its block, "- " opens one)
+        if re.match(r"\s+- \.", line):
+            cur = {}
+        m = re.search(r"\.(\w+):\s+(\S+)", line)
+        if m:
+            if m.group(1) == "name":
+                out[m.group(2)] = cur
+            elif m.group(2).isdigit():
+                cur[m.group(1)] = int(m.group(2))
+    return out
+
+
+def test_column_slice_kernels_spill_nothing(tmp_path):
+    """csrc/dsgd_cs.hpp keeps the NEXT step's slots in registers under the exchange.  A spilled register is reloaded with a
+    vector-memory operation, and those retire in order BEHIND the prefetch: every reload waits the prefetch out (the
+    round's first forms had 150-195 spills and ran 15.6 us per 3 x 100 step instead of 6.2).  512-lane shapes run two
+    waves per SIMD: 256 registers each."""
+    kn = {k: v for k, v in _kernel_notes(tmp_path).items() if "dsgd_cs_step_kernel" in k}
+    assert len(kn) == 3, sorted(kn)
+    for k, v in kn.items():
+        # (the 80 bytes of private segment are the set-up's staging of the slice's dimSparsity piece: once per launch,
+        #  in front of the first barrier -- the step loop touches no scratch)
+        assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] <= 80, (k, v)
+        assert v.get("agpr_count", 0) == 0, (k, v)          # (values parked in accumulation registers need the value: a wait)
+        lanes = int(re.search(r"ILi(\d+)E", k).group(1))
+        assert v["vgpr_count"] <= (256 if lanes == 512 else 512), (k, v)
+
+
 def test_register_budget_of_the_async_engine_and_the_concurrent_loss_check(tmp_path):
     """MasterAsync checks the loss WHILE the persistent lock-free engine runs (core/MasterAsync.scala:96-162): the
     evaluation kernel must become resident beside workgroups that never leave their CU.  Per SIMD the engine holds
