@@ -120,7 +120,8 @@ int dsgd_sync_step(dsgd_ctx* ctx, const int32_t* const* idx_per_worker, const in
 
 /* Same, for batches that are whole contiguous row ranges (batch-size >= split size makes
  * slice(0, B) of the shuffled split the entire split; a sum does not depend on the order).
- * Streams the CSR rows [row_begin[k], row_end[k]) with fully coalesced reads.                  */
+ * From 131,072 rows on (DSGD_STREAM_MIN) the CSR rows [row_begin[k], row_end[k]) are streamed with fully coalesced
+ * reads; shorter ranges take the row-wise kernel (four streaming launches cost 50 us whatever the range).           */
 int dsgd_sync_step_ranges(dsgd_ctx* ctx, const int64_t* row_begin, const int64_t* row_end, int32_t n_workers,
                           float lr, dsgd_batch_stats* stats /* may be NULL */);
 
@@ -129,9 +130,12 @@ int dsgd_sync_step_ranges(dsgd_ctx* ctx, const int64_t* row_begin, const int64_t
  * no host->device traffic happens between steps (timed loops, hipGraph replay).                 */
 typedef struct dsgd_plan dsgd_plan;
 /* idx: concatenation of all lists; offsets: n_steps * n_workers + 1 prefix offsets into idx.
- * A plan is RESIDENT: at its first run its lists are laid out over the device's streams (16 bytes per 8 non-zeros) and,
- * up to DSGD_VT_PACK_MB (default 2048), copied in that order (about the rows' CSR bytes) -- a 3 x 100 step then costs
- * 15 us against 56 us for the same lists through dsgd_sync_step.                                   */
+ * A plan is RESIDENT: at its first run its lists are laid out for the device, once.  Steps of the reference's own size
+ * (<= 8 hosted workers, <= 1,024 rows per step: application.conf:15,27) become COLUMN SLICES -- dsgd_plan_run then runs
+ * ALL steps of [step_begin, step_end) in ONE persistent launch (5 us per 3 x 100 step, 9 us per 4 x 200; a launch of a
+ * single step 11 us: hand over as many steps per call as are known); larger steps are laid out over the device's streams
+ * (16 bytes per 8 non-zeros) and, up to DSGD_VT_PACK_MB (default 2048), copied in that order: two launches per step
+ * (18 us at 4,096 rows).  The same lists through dsgd_sync_step cost 32 us per call.                                  */
 int dsgd_plan_create(dsgd_ctx* ctx, const int32_t* idx, const int64_t* offsets, int64_t n_steps, int32_t n_workers,
                      dsgd_plan** out);
 int dsgd_plan_destroy(dsgd_ctx* ctx, dsgd_plan* plan);
