@@ -26,7 +26,8 @@ at N = 1; with N > 1 a step over the first --gate-rows train rows of EVERY rank 
 as world x workers workers (Master.scala:194: the mean runs over the workers).
 
 Inputs are generated on the host, uploaded once and resident in HBM before the timed region.
-Prints ONE JSON line (rank 0).
+Rank 0 writes the FULL result object to --detail (default gpurun_out/bench_detail.json) and prints ONE compact JSON line
+(< 8 KB: contract keys, roofline, cpu_baseline, one summary row per leg) as the LAST line of stdout.
 """
 
 from __future__ import annotations
@@ -48,6 +49,7 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12      # B/s, spec (MI355X_MICROARCH.md "Chip-level parameters")
 HBM_MEASURED = 6.29e12  # B/s, float4-copy ceiling from the same table
 LR0, LAMBDA = 0.5, 1e-5  # application.conf:18,21 (learning-rate is per batch of 100, application.conf:15)
+LINE_TARGET, LINE_LIMIT = 4096, 8192   # bytes of the final stdout line: aimed at / never exceeded (the driver keeps an 8 KB tail)
 STATED_TOL = 1e-5        # BASELINE.md's parity gate: max|w - w_oracle| <= 1e-5 * max(1, |w_oracle|_inf), asserted beside the derived bound
 
 
@@ -72,6 +74,9 @@ def parse(argv=None):
     ap.add_argument("--no-parity-gate", action="store_true", help="skip every oracle comparison (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for each CPU baseline leg")
     ap.add_argument("--clock-ramp", type=float, default=0.5, help="seconds of untimed lr=0 steps before the warmup steps")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="where the FULL result object goes (every leg with its parity records, curves and tables); the LAST "
+                         "stdout line is the compact summary of it (< %d bytes)" % LINE_LIMIT)
     return ap.parse_args(argv)
 
 
@@ -522,7 +527,128 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out, args.detail)
+
+
+def _sig(x, digits=6):
+    """numbers of the compact line: `digits` significant digits (the detail file keeps every bit)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(out, detail_path=None):
+    """The line of record: the driver's contract keys, `roofline` and `cpu_baseline` (numbers only, no prose), the parity
+    gate's worst error, epochs to target, and ONE summary row per extra leg.  Everything else -- per-step parity records,
+    sweep tables per shape, Hogwild checkpoints, loss curves, band tables -- lives in the detail file.  Returns the dict;
+    `emit` serialises it and refuses a line of LINE_LIMIT bytes or more (optional legs are dropped first, the contract
+    keys never)."""
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data") if k in out}
+    c["config"] = _pick(out.get("config", {}), "workload", "rows_per_gpu", "train_rows_per_gpu", "train_rows_job", "workers_per_gpu",
+                        "parallelism", "seed")
+    if "repeats" in out:
+        c["repeats"] = _pick(out["repeats"], "n", "statistic", "ms_per_step_min", "ms_per_step_max")
+    r = out.get("roofline")
+    if r:
+        c["roofline"] = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "physical_frac",
+                              "algorithmic_bytes_per_launch", "kernel_ms_avg", "kernel_launches", "kernel_share_of_nonzeros")
+        if "step" in r:
+            c["roofline"]["step"] = _pick(r["step"], "ms", "frac")
+        if "other_kernels" in r:
+            c["roofline"]["other_kernels_ms"] = {k: v["ms_avg"] for k, v in r["other_kernels"].items()}
+    for key in ("cpu_baseline", "cpu_literal"):
+        if key in out:
+            c[key] = _pick(out[key], "value", "unit", "cores", "kind")
+            c[key]["sample"] = str(out[key].get("sample", ""))[:160]
+    for key in ("parity_gate_rows", "parity_gate_max_rel_err", "replicas_bit_identical", "test_loss_after", "test_acc_after"):
+        if key in out:
+            c[key] = out[key]
+    if "parity_gate" in out and out["parity_gate"].get("steps"):
+        c["parity_gate_worst_err_over_bound"] = max(p["worst_err_over_bound"] for p in out["parity_gate"]["steps"])
+    if "epochs_to_target" in out:
+        c["epochs_to_target"] = _pick(out["epochs_to_target"], "engine_epochs", "oracle_epochs", "target_test_loss", "max_epochs")
+    legs = {}
+    for s in out.get("sweep", []):
+        row = _pick(s, "us_per_step", "frac_hbm_peak", "kernel")
+        if "parity" in s:
+            row["parity_max_rel_err"] = s["parity"]["max_rel_err"]
+        legs.setdefault("sweep", {})["%dx%d" % (s["workers"], s["batch"])] = row
+    for rs in out.get("reference_shapes", []):
+        row = {"us_per_step": rs["whole_shard"]["us_per_step"], "kernel_frac": rs["roofline"]["frac"],
+               "step_frac": rs["roofline"]["step"]["frac"], "kernel": rs["whole_shard"]["kernel"]}
+        if "parity_gate" in rs:
+            row["parity_max_rel_err"] = rs["parity_gate"]["max_rel_err"]
+        by = {(s["workers"], s["batch"]): s for s in rs.get("sweep", [])}
+        if (3, 100) in by:
+            row["3x100_us_per_step"] = by[(3, 100)]["us_per_step"]
+        legs.setdefault("reference_shapes", {})["N=%d" % rs["rows"]] = row
+    for key in ("fit", "per_request"):
+        if key in out:
+            legs[key] = out[key].get("summary", out[key])
+    hw = out.get("hogwild")
+    if hw:
+        legs["hogwild"] = _pick(hw, "workers", "batch", "examples_per_s", "frac_hbm_peak", "atomics_per_s")
+        tr = hw.get("traced_replay")
+        if tr:
+            legs["hogwild"]["traced_replay"] = _pick(tr, "accounting_agrees", "gates_are", "controls_rejected", "gate_check_4_workers")
+    tt = out.get("time_to_target")
+    if tt:
+        legs["time_to_target"] = _pick(tt, "rows", "target_test_loss", "fastest", "through")
+        c0 = tt["configs"][0] if tt.get("configs") else None
+        if c0:
+            legs["time_to_target"]["reference_config"] = _pick(c0, "workers", "batch", "time_to_target_s", "engine_epochs", "oracle_epochs",
+                                                               "first_divergent_step", "divergent_rows_all_near_gate",
+                                                               "forced_replay_account_err_over_tol", "epoch1_max_abs_diff")
+    if "eval_pass" in out:
+        legs["eval_pass"] = _pick(out["eval_pass"], "examples_per_s", "frac_hbm_peak")
+    dl = out.get("dense_logistic")
+    if dl and dl.get("batches"):
+        legs["dense_logistic"] = {str(b["batch"]): _pick(b, "examples_per_s", "kernel_frac_hbm_peak") for b in dl["batches"]}
+        if "mfma_variant" in dl:
+            legs["dense_logistic"]["mfma_65536"] = _pick(dl["mfma_variant"], "examples_per_s", "kernel_frac_hbm_peak")
+    if legs:
+        c["legs"] = legs
+    if detail_path:
+        c["detail"] = os.path.relpath(detail_path, ROOT) if os.path.isabs(detail_path) else detail_path
+    return _sig(c)
+
+
+def emit(out, detail_path, stream=None):
+    """Write the full object to `detail_path`, then print the compact line as the LAST stdout line.  A consumer that keeps
+    only a tail of the output (the driver: 8 KB) must still get the headline: the line is held below LINE_LIMIT by
+    dropping optional legs (largest first) -- never a contract key -- and the run fails rather than print a longer one."""
+    stream = stream or sys.stdout
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(out, f)
+        except OSError as e:
+            print("bench.py: could not write %s: %s" % (detail_path, e), file=sys.stderr)
+            detail_path = None
+    c = compact_line(out, detail_path)
+    line = json.dumps(c, separators=(",", ":"))
+    while len(line) >= LINE_LIMIT - 1024 and c.get("legs"):
+        biggest = max(c["legs"], key=lambda k: len(json.dumps(c["legs"][k])))
+        del c["legs"][biggest]
+        c.setdefault("legs_dropped_from_line", []).append(biggest)
+        line = json.dumps(c, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:
+        raise SystemExit("bench.py: the final line is %d bytes (limit %d)" % (len(line), LINE_LIMIT))
+    stream.flush()
+    print(line, file=stream, flush=True)
+    return line
 
 
 def roofline(eng, rows_key, n_train, nnz_train, bytes_per_row, kernel_ms, n_launch, n_steps, step_s, kinds):

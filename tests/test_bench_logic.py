@@ -217,3 +217,39 @@ def test_epoch_lists_visit_every_row_once():
     assert len(steps) == 4 and seen.max() < 1000
     one = bench.epoch_lists(np.random.default_rng(1), 1000, 1, 4096)
     assert len(one) == 1 and sorted(one[0][0].tolist()) == list(range(1000))
+
+
+def test_final_line_is_compact_and_parses(tmp_path):
+    """BENCH_r04 went unrecorded because the one JSON line had grown to 28 KB and the driver keeps an 8 KB tail.  The
+    LAST stdout line is now a compact summary (contract keys, roofline, cpu_baseline, one row per leg); the full object
+    goes to a file.  Fed with the fattest object a visit ever produced (profiles/r04_bench.json), the line must parse,
+    stay far below 8 KB, and keep every key of the driver's contract with the detail's values."""
+    import io
+
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    buf = io.StringIO()
+    detail = tmp_path / "sub" / "bench_detail.json"
+    line = bench.emit(full, str(detail), stream=buf)
+    printed = buf.getvalue()
+    assert printed.endswith(line + "\n") and printed.count("\n") == 1          # ONE line, the last one
+    assert len(line.encode()) < bench.LINE_LIMIT == 8192 and len(line.encode()) < 6144
+    c = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in c, key
+    assert c["metric"] == full["metric"] and c["n_gpus"] == 1 and c["dtype"] == "f32" and "workload" in c["config"]
+    assert abs(c["value"] - full["value"]) <= 1e-5 * full["value"] and abs(c["ms_per_step"] - full["ms_per_step"]) <= 1e-5 * full["ms_per_step"]
+    r = c["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and "traffic" in r
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) <= 1e-4 * r["achieved"]
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] >= 1 and c["cpu_baseline"]["sample"]
+    assert "legs_dropped_from_line" not in c and {"sweep", "reference_shapes", "hogwild", "time_to_target"} <= set(c["legs"])
+    assert json.load(open(detail)) == full                                       # nothing is lost: the file has it all
+    # a pathological object (a leg blown up a hundredfold) still yields a line under the limit: legs go, contract keys stay
+    fat = dict(full, sweep=full["sweep"] * 100)
+    for i, s in enumerate(fat["sweep"]):
+        fat["sweep"][i] = dict(s, batch=s["batch"] + i)
+    buf2 = io.StringIO()
+    line2 = bench.emit(fat, None, stream=buf2)
+    c2 = json.loads(line2)
+    assert len(line2) < bench.LINE_LIMIT and "sweep" in c2["legs_dropped_from_line"] and c2["value"] == c["value"] and "roofline" in c2
