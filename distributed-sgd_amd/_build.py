@@ -3,6 +3,7 @@
     libdsgd_hip.so    hipcc --offload-arch=gfx950   csrc/dsgd_hip.hip   (the product)
     libdsgd_synth.so  gcc -fopenmp                  csrc/synth.c        (synthetic RCV1-like data)
     libdsgd_rcv1.so   gcc                           csrc/rcv1.c         (RCV1-v2 text files -> CSR, Dataset.rcv1 semantics)
+    libdsgd_host.so   gcc -pthread                  csrc/jrand.c        (java.util.Random / scala.util.Random.shuffle: the epoch's index lists)
 
 hipcc cross-compiles gfx950 without a GPU, so this runs in the build container too.
 
@@ -32,6 +33,8 @@ SYNTH_SRC = os.path.join(CSRC, "synth.c")
 SYNTH_LIB = os.path.join(LIBDIR, "libdsgd_synth.so")
 RCV1_SRC = os.path.join(CSRC, "rcv1.c")
 RCV1_LIB = os.path.join(LIBDIR, "libdsgd_rcv1.so")
+JRAND_SRC = os.path.join(CSRC, "jrand.c")
+JRAND_LIB = os.path.join(LIBDIR, "libdsgd_host.so")
 
 
 def _stale(target: str, *sources: str) -> bool:
@@ -113,8 +116,17 @@ def build_rcv1(force: bool = False) -> str:
     return RCV1_LIB
 
 
+def build_host(force: bool = False) -> str:
+    """libdsgd_host.so: the reference's random stream (java.util.Random + scala.util.Random.shuffle) for the host mirrors."""
+    if not force and not _stale(JRAND_LIB, JRAND_SRC, __file__):
+        return JRAND_LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    _run(["gcc", "-O2", "-pthread", "-fPIC", "-shared", "-std=gnu11", "-Wall", JRAND_SRC, "-o", JRAND_LIB])
+    return JRAND_LIB
+
+
 def build_all(force: bool = False) -> dict:
-    return {"hip": build_hip(force), "synth": build_synth(force), "rcv1": build_rcv1(force)}
+    return {"hip": build_hip(force), "synth": build_synth(force), "rcv1": build_rcv1(force), "host": build_host(force)}
 
 
 if __name__ == "__main__":

@@ -69,10 +69,27 @@ struct CsArgs {
   unsigned int tag0;                // steps of the context's earlier launches
   float lr, lambda;
   int vexp, dp, G, K;
+  // per-request steps (dsgd_cs_request_kernel): host-mapped {n_active, err, sequence number} written when slice 0 leaves
+  unsigned long long* mail;
+  unsigned long long mail_seq;
+  // optional record of a plan's run (dsgd_plan_record): the gate decision of every row of every step (bit r of the step's
+  // words = row r was active, core/ml/SparseSVM.scala:27-28) and the regulariser scalar the step used -- what an oracle
+  // needs to REPLAY a trajectory with the engine's own decisions (oracle/sync_replay.py)
+  unsigned int* gate_rec;           // [n_steps_plan][gate_words], zero before the run
+  float* s_rec;                     // [n_steps_plan]
+  int gate_words;
+  int test_skip_publish;            // TEST BUILDS ONLY (DSGD_TEST_COLLECTIVE_SEAM): slice 1 dies at this step of the launch (1-based; 0: never)
 };
 
 __host__ __device__ constexpr int cs_lds_words(int dp, int G, int K) {
   return (2 + K) * ((((dp + G - 1) / G) + 4) & ~3) + 2 * CS_MAX_SLOTS + 32;   // (a slice is padded by 1 .. 4 columns)
+}
+
+// a per-request launch: the builder's scratch sits where the accumulators, partial dots and coefficients go afterwards
+__host__ __device__ constexpr int cs_req_lds_words(int dp, int G, int K) {
+  const int sp = (((dp + G - 1) / G) + 4) & ~3;
+  const int rest = K * sp + 2 * CS_MAX_SLOTS;
+  return 2 * sp + (rest > 7000 ? rest : 7000) + 32;   // 7000 >= CS_BUILD_WORDS (static_assert below)
 }
 
 template <int SPL, int CLT>
@@ -326,6 +343,11 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, 
   //         nothing waits for them ----
   const unsigned int tag = a.tag0 + z.n_rel + 1u;   // (tags run on across the launches of a context: nothing is cleared between them)
   unsigned long long* xb = a.xbuf + ((long long)(z.n_rel & 1u) * G + b) * CS_XSTRIDE;
+#ifdef DSGD_TEST_COLLECTIVE_SEAM
+  // (tests of the failure path: one slice DIES here -- publishes nothing more, writes nothing back; its peers must give
+  //  the launch up at their poll limit, not hang)
+  if (a.test_skip_publish > 0 && b == 1 && (long long)z.n_rel + 1 >= a.test_skip_publish) return false;
+#endif
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
     const int r = tid + NT * i;
@@ -350,10 +372,12 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, 
   //  every lane position holds a row)
   int at[SPL];
   float dd[SPL];
+  bool act[SPL];
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
     const int r = tid + NT * i;
     at[i] = r < n_rows ? r : (r == n_rows ? CS_MAX_SLOTS : -1);
+    act[i] = false;
   }
   bool got = cs_gather<SPL>(xall, G, at, tag, &a.sync[1], dd);
 #pragma unroll
@@ -365,8 +389,21 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, 
       const bool active = got && !(yd < 0.0f);                 // ref: core/ml/SparseSVM.scala:27-28
       coef[r] = active ? (ypos ? qscale : -qscale) : 0.0f;
       z.n_act += (active && b == 0) ? 1u : 0u;
+      act[i] = active;
     } else if (r == n_rows) {
       red[16] = a.lambda * 2.0f * dd[i];
+    }
+  }
+  if (a.gate_rec != nullptr && b == 0) {   // (workgroup-uniform) the decisions on record: a wave's 64 rows are two words
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+      const unsigned long long m = __ballot(act[i]);
+      const int r0 = (tid & ~63) + NT * i;
+      if ((tid & 63) == 0 && r0 < n_rows) {
+        unsigned int* g = a.gate_rec + step * (long long)a.gate_words + (r0 >> 5);
+        g[0] = (unsigned int)m;
+        if (r0 + 32 < n_rows) g[1] = (unsigned int)(m >> 32);
+      }
     }
   }
   if (n_rows == NT * SPL && tid == NT - 1) {
@@ -381,6 +418,7 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, 
   stamp(2);
   const float s = red[16];
   const bool add = (s != 0.0f) && (fabsf(s) > DSGD_EPS);
+  if (a.s_rec != nullptr && b == 0 && tid == 0) a.s_rec[step] = s;
   // ---- 4: y * x of the active rows into the accumulator of the row's worker (exact integer sums; the non-zeros are
   //         still in registers).  ref: core/Slave.scala:147-153 restricted to this slice's columns ----
 #pragma unroll
@@ -424,9 +462,37 @@ __device__ __forceinline__ bool cs_step(const CsArgs& a, CsState& z, CsSet<SPL, 
   return true;
 }
 
-template <int NT, int SPL, int CLT>
-__global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+// the slice's end of a launch: statistics, and for a per-request step the host-mapped mailbox (slice 0)
+template <int NT>
+__device__ __forceinline__ void cs_finish_stats(const CsArgs& a, CsState& z, bool ok) {
+  const int tid = threadIdx.x;
+  if (z.b != 0) return;
+  const unsigned int n_act = wave_sum_u32(ok ? z.n_act : 0u);
+  __syncthreads();
+  if ((tid & 63) == 0) reinterpret_cast<unsigned int*>(z.red)[tid >> 6] = n_act;
+  __threadfence();   // (this workgroup's error flags, if any, are out before thread 0 reads them)
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned int* r4 = reinterpret_cast<const unsigned int*>(z.red);
+    unsigned int tot = 0u;
+    for (int i = 0; i < NT / 64; ++i) tot += r4[i];
+    unsigned long long now = 0ull;
+    if (tot || a.mail) now = atomicAdd(&a.sc->n_active, (unsigned long long)tot) + tot;
+    if (a.mail) {
+      __hip_atomic_store(&a.mail[0], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const int err = __hip_atomic_load(&a.sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.mail[1], (unsigned long long)(unsigned int)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // the request's sequence number LAST, with release order: the host may take the two words above once it sees it
+      __hip_atomic_store(&a.mail[2], a.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// The launch: set-up (slice-major weights and dimSparsity into LDS, accumulators cleared), the steps, the write-back.
+// `pre`: called between the set-up's requests and their use (the per-request kernel lays the step's slots out there, with
+// the launch's LDS still free beyond the two vectors); returns false to give the launch up before its first step.
+template <int NT, int SPL, int CLT, bool REQ, class Pre>
+__device__ __forceinline__ void cs_launch_body(const CsArgs& a, float* lds, Pre pre) {
   const unsigned long long t_launch = a.tprof ? __builtin_readcyclecounter() : 0ull;
   const int tid = threadIdx.x;
   const int G = a.G, K = a.K;
@@ -444,13 +510,11 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
   z.n_act = 0u;
   z.n_rel = 0u;
   z.tp = reinterpret_cast<unsigned long long*>(z.red + 18);
-  if (tid == 0)
-    for (int i = 0; i < 6; ++i) z.tp[i] = 0ull;
   // the first step's slots are requested before anything else: they land with the weights.  (The weights used to be picked
   // out of the rank-ordered vector here -- every slice touched every 128-byte line of w and ds, 378 KB through ONE CU:
   // 8.6 of the 18 us of a one-step launch.)
   CsSet<SPL, CLT> A, B;
-  cs_issue<NT, SPL, CLT>(a, z.b, a.step_begin, A);
+  if (!REQ) cs_issue<NT, SPL, CLT>(a, z.b, a.step_begin, A);
   {   // the slice's weights and dimSparsity values: two contiguous pieces (the padding holds zeros), requested at once; the
       // accumulators are cleared while the first requests are on their way (clearing first cost 1.3 us of a one-step launch)
     const float4* ws4 = reinterpret_cast<const float4*>(a.w + (long long)z.b * z.Sp);
@@ -467,7 +531,7 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
         wv[u] = ws4[i4 < n4 ? i4 : n4 - 1];
         dv[u] = ds4[i4 < n4 ? i4 : n4 - 1];
       }
-      if (round == 0)
+      if (round == 0 && !REQ)
         for (int i = tid; i < K * z.Sp; i += NT) z.acc[i] = 0;
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
@@ -479,6 +543,25 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
       }
     }
   }
+  if (REQ) {
+    // a per-request step: ITS slots are laid out now, by this workgroup for its own slice (the LDS beyond the two vectors
+    // is the builder's scratch), written to the context's one-step layout and requested back like a plan's
+    const bool built = pre(reinterpret_cast<unsigned int*>(z.acc));
+    __threadfence();      // the layout this workgroup stored is what it loads next: out of the CU, the L1 lines dropped
+    __syncthreads();
+    if (!built) {         // (workgroup-uniform) the step does not fit the one-step layout: every peer is told, nobody publishes
+      if (tid == 0) {
+        __hip_atomic_store(&a.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicOr(&a.sc->err, 16);
+      }
+      cs_finish_stats<NT>(a, z, false);
+      return;
+    }
+    cs_issue<NT, SPL, CLT>(a, z.b, a.step_begin, A);
+    for (int i = tid; i < K * z.Sp; i += NT) z.acc[i] = 0;
+  }
+  if (tid == 0)
+    for (int i = 0; i < 6; ++i) z.tp[i] = 0ull;
   cs_barrier();
   // this slice's share of w . ds of the weights the launch starts from: the SAME pass, lane assignment and order as behind
   // every step -- a plan run step by step and in one launch see the same bits
@@ -495,8 +578,14 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
     if (!ok) break;
   }
   if (!ok) {
+    // Given up.  NO slice has written its weights back: a slice writes back only behind the LAST step's gather, which
+    // needs the last step's granules of all G slices -- published, by each, behind its gather of the step before, and so
+    // on down: whoever passes the last gather has seen every peer reach the last step, and a peer that has published its
+    // last granules polls nothing any more that could make it give up, except those same G granules, which are there.
+    // So either every slice writes back or none does; here none: global w is what the launch found, the host rejects it.
     if (tid == 0) atomicOr(&a.sc->err, 8);
-    return;   // (global w stays as the launch found it: the host rejects the run)
+    cs_finish_stats<NT>(a, z, false);
+    return;
   }
   {
     float4* ws4 = reinterpret_cast<float4*>(a.w + (long long)z.b * z.Sp);
@@ -508,18 +597,248 @@ __global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
     for (int i = 0; i < 6; ++i) a.tprof[i] += z.tp[i];
     a.tprof[15] += (unsigned long long)(a.step_end - a.step_begin);
   }
-  if (z.b == 0) {
-    const unsigned int n_act = wave_sum_u32(z.n_act);
-    __syncthreads();
-    if ((tid & 63) == 0) reinterpret_cast<unsigned int*>(z.red)[tid >> 6] = n_act;
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned int* r4 = reinterpret_cast<const unsigned int*>(z.red);
-      unsigned int tot = 0u;
-      for (int i = 0; i < NT / 64; ++i) tot += r4[i];
-      if (tot) atomicAdd(&a.sc->n_active, (unsigned long long)tot);
+  cs_finish_stats<NT>(a, z, true);
+}
+
+template <int NT, int SPL, int CLT>
+__global__ void __launch_bounds__(NT) dsgd_cs_step_kernel(CsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  cs_launch_body<NT, SPL, CLT, false>(a, lds, [](unsigned int*) { return true; });
+}
+
+// ---- the layout of a step's slots, built ON THE DEVICE ------------------------------------------------------------
+// Rounds 1-4 laid a plan's column slices out on the host: the listed rows' (rank, value) pairs gathered on the device,
+// copied back (8 bytes per non-zero), bucketed per slice by one host thread, copied up again -- 0.6 ms per 3 x 100 step
+// (1.3 s for the 2,146 steps of an epoch over 804,414 rows: a hundred times the 11 ms the epoch then RUNS), and nothing a
+// per-request step (core/Slave.scala:142-157 hands over fresh index lists every call) could use at all.  Here one
+// workgroup builds one (step, slice) cell from the resident ranked CSR: the step's rows, the entries whose rank is the
+// slice's (mod G) in CSR order, cut into slots of <= CS_L -- byte for byte the host's layout (the partial x.w of a slot and
+// of a row are sums in entry order: the same bits), so both builders can be checked against each other.
+//   pass 1 (FILL = false): slots and distinct columns of the cell -> device-wide maxima (the strides of the layout);
+//   pass 2 (FILL = true):  everything the step kernel may read of the cell: header, row_first, slot_meta, the column
+//                          and value pieces (zeros beyond a row's last entry and in the slots beyond the step's), the
+//                          sorted list of the step's columns inside the slice (0xffff beyond it).
+// The per-request kernel (dsgd_cs_request_kernel) calls pass 2 for ITS OWN slice in front of the step.
+constexpr int CS_BUILD_BITMAP_WORDS = 2048;   // a slice holds at most 65,536 columns
+constexpr int CS_BUILD_WORDS = (CS_MAX_SLOTS + 8) + CS_MAX_SLOTS + 2 * CS_MAX_SLOTS + CS_BUILD_BITMAP_WORDS + 64 + CS_THREADS;   // LDS words of scratch
+
+static_assert(CS_BUILD_WORDS <= 7000, "cs_req_lds_words reserves 7000 words for the builder");
+struct CsBuildArgs {
+  CsrView m;                 // the resident CSR, columns as frequency ranks
+  const int* idx;            // the lists' rows
+  const WorkSeg* segs;       // [n_steps][K]: positions [begin, end) in idx; a step's lists are contiguous
+  CsHdr* hdr;                // outputs: the arrays of CsArgs
+  unsigned int* slot_meta;
+  unsigned short* row_first;
+  unsigned short* col;
+  float* val;
+  unsigned short* clist;
+  unsigned int* maxima;      // [0] most slots of a cell, [1] most listed columns, [2] flags: 1 a row index outside the data,
+                             //   2 a cell that does not fit the strides, [3] most rows of a step
+  long long n_steps_plan;
+  int slot_stride, row_stride, cl_stride;
+  int dp, G, K;
+};
+
+// exclusive prefix sums over n <= 2 * NT values in LDS (in place), total returned on every thread; `tmp`: NT / 64 + 1 words
+template <int NT>
+__device__ __forceinline__ unsigned int cs_excl_scan(unsigned int* v, int n, unsigned int* tmp) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i0 = 2 * tid, i1 = 2 * tid + 1;
+  const unsigned int a0 = i0 < n ? v[i0] : 0u, a1 = i1 < n ? v[i1] : 0u;
+  unsigned int x = a0 + a1;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned int y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) tmp[wv] = x;
+  __syncthreads();
+  unsigned int base = 0u, total = 0u;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) {
+    const unsigned int t = tmp[i];
+    if (i < wv) base += t;
+    total += t;
+  }
+  const unsigned int excl = base + x - (a0 + a1);
+  if (i0 < n) v[i0] = excl;
+  if (i1 < n) v[i1] = excl + a0;
+  __syncthreads();
+  return total;
+}
+
+// One (step, slice) cell.  Returns true when the cell fits the strides (always in pass 1).  Workgroup-uniform.
+template <int NT, bool FILL>
+__device__ __forceinline__ bool cs_build_cell(const CsBuildArgs& a, int b, long long s, unsigned int* scratch) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int NW = NT / 64;
+  const int G = a.G, K = a.K;
+  const bool pow2 = (G & (G - 1)) == 0;
+  const int gsh = 31 - __clz(G);
+  // scratch: per-row slot counts (then their prefix), row lengths, row starts, the column bitmap, the scan's wave totals
+  unsigned int* nslot = scratch;                                   // [CS_MAX_SLOTS + 8]
+  unsigned int* rlen = nslot + CS_MAX_SLOTS + 8;                   // [CS_MAX_SLOTS]
+  unsigned long long* rst = reinterpret_cast<unsigned long long*>(rlen + CS_MAX_SLOTS);   // [CS_MAX_SLOTS] (8-byte aligned: even offset)
+  unsigned int* bitmap = reinterpret_cast<unsigned int*>(rst + CS_MAX_SLOTS);   // [CS_BUILD_BITMAP_WORDS]
+  unsigned int* tmp = bitmap + CS_BUILD_BITMAP_WORDS;              // [64], then the scan's [NT] per-thread totals
+  const WorkSeg* sg = a.segs + s * K;
+  const long long t0 = sg[0].begin;
+  const long long Rl = sg[K - 1].end - t0;
+  const int R = (int)(Rl < (long long)CS_MAX_SLOTS ? Rl : (long long)CS_MAX_SLOTS);
+  long long worst = 1;
+  for (int k = 0; k < K; ++k) worst = worst > sg[k].end - sg[k].begin ? worst : sg[k].end - sg[k].begin;
+  const int Sloc = (a.dp + G - 1) / G;                             // slice-local columns
+  const int bm_words = (Sloc + 31) >> 5;
+  for (int i = tid; i < bm_words; i += NT) bitmap[i] = 0u;
+  unsigned int bad = 0u;
+  // the rows of the step: where they start, how long they are (every lane its own row: two dependent loads, all in flight)
+  for (int r = tid; r < R; r += NT) {
+    long long row = a.idx[t0 + r];
+    if (row < 0 || row >= a.m.n_rows) {
+      bad = 1u;
+      row = 0;
+    }
+    const long long st = a.m.row_ptr[row], en = a.m.row_ptr[row + 1];
+    rst[r] = (unsigned long long)st;
+    rlen[r] = bad ? 0u : (unsigned int)(en - st);
+  }
+  __syncthreads();
+  // count: one wave per row, the row's entries 64 at a time
+  for (int r = wv; r < R; r += NW) {
+    const long long st = (long long)rst[r];
+    const int len = (int)rlen[r];
+    int cnt = 0;
+    for (int j0 = 0; j0 < len; j0 += 64) {
+      const int j = j0 + lane;
+      const int rank = j < len ? a.m.col[st + j] : -1;
+      const bool mine = rank >= 0 && (pow2 ? (rank & (G - 1)) == b : rank % G == b);
+      if (mine) {
+        const int lc = pow2 ? rank >> gsh : rank / G;
+        atomicOr(&bitmap[lc >> 5], 1u << (lc & 31));
+      }
+      cnt += __popcll(__ballot(mine));
+    }
+    if (lane == 0) nslot[r] = (unsigned int)((cnt + CS_L - 1) / CS_L);
+  }
+  __syncthreads();
+  const unsigned int n_slots = cs_excl_scan<NT>(nslot, R, tmp);   // nslot[r] = first slot of row r
+  // the distinct columns: per thread a run of bitmap words, exclusive prefix of their popcounts
+  const int wpt = (bm_words + NT - 1) / NT;                        // words per thread (<= 4)
+  unsigned int mypop = 0u;
+  for (int i = 0; i < wpt; ++i) {
+    const int wd = tid * wpt + i;
+    mypop += wd < bm_words ? (unsigned int)__popc(bitmap[wd]) : 0u;
+  }
+  unsigned int* cs_pop = tmp + 64;   // [NT]
+  cs_pop[tid] = mypop;
+  __syncthreads();
+  const unsigned int n_cols = cs_excl_scan<NT>(cs_pop, NT, tmp);
+  const unsigned int col_base = cs_pop[tid];
+  if (tid == 0) {
+    atomicMax(&a.maxima[0], n_slots);
+    atomicMax(&a.maxima[1], n_cols);
+    atomicMax(&a.maxima[3], (unsigned int)(Rl > 0x7fffffffLL ? 0x7fffffffLL : Rl));
+  }
+  if (__syncthreads_or(bad != 0u) && tid == 0) atomicOr(&a.maxima[2], 1u);
+  if (!FILL) return true;
+  const bool fits = Rl <= (long long)CS_MAX_SLOTS && (int)n_slots <= a.slot_stride && R + 1 <= a.row_stride &&
+                    (int)n_cols <= a.cl_stride && n_slots <= (unsigned int)CS_MAX_SLOTS;
+  if (!fits) {
+    if (tid == 0) atomicOr(&a.maxima[2], 2u);
+    return false;
+  }
+  const long long cell = (long long)b * a.n_steps_plan + s;
+  const long long sbase = cell * a.slot_stride, rbase = cell * a.row_stride, cbase = cell * a.cl_stride;
+  // everything the step kernel may read of the cell, zeroed first (coalesced 16-byte stores) ...
+  {
+    uint4* c4 = reinterpret_cast<uint4*>(a.col + 2 * sbase * 8);      // [2][slot_stride] pieces of 8 columns
+    uint4* v4 = reinterpret_cast<uint4*>(a.val + 4 * sbase * 4);      // [4][slot_stride] pieces of 4 values
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < 2 * a.slot_stride; i += NT) c4[i] = zero;
+    for (int i = tid; i < 4 * a.slot_stride; i += NT) v4[i] = zero;
+    for (int i = tid; i < a.slot_stride; i += NT) a.slot_meta[sbase + i] = 0u;
+  }
+  // ... the listed columns, ascending (0xffff beyond them) ...
+  {
+    unsigned int at = col_base;
+    for (int i = 0; i < wpt; ++i) {
+      const int wd = tid * wpt + i;
+      unsigned int bits = wd < bm_words ? bitmap[wd] : 0u;
+      while (bits) {
+        const int bit = __ffs((int)bits) - 1;
+        bits &= bits - 1u;
+        a.clist[cbase + at++] = (unsigned short)(wd * 32 + bit);
+      }
+    }
+    for (int i = (int)n_cols + tid; i < a.cl_stride; i += NT) a.clist[cbase + i] = (unsigned short)0xffffu;
+  }
+  // ... the first slot of every row with its label, the sentinel, the header
+  for (int r = tid; r <= R; r += NT) {
+    unsigned short v;
+    if (r < R) {
+      const long long row = a.idx[t0 + r];
+      const bool in = row >= 0 && row < a.m.n_rows;
+      v = (unsigned short)(nslot[r] | ((in && a.m.label[row] > 0) ? 0x8000u : 0u));
+    } else {
+      v = (unsigned short)n_slots;
+    }
+    a.row_first[rbase + r] = v;
+  }
+  if (tid == 0) {
+    int bits = 0;
+    while ((1LL << bits) < worst) ++bits;
+    CsHdr h;
+    h.counts = n_slots | ((unsigned int)R << 16);
+    h.shift = (30 - bits) | (int)(n_cols << 16);   // at most one contribution per row and column: a worker's sums stay below 2^30
+    a.hdr[cell] = h;
+  }
+  __syncthreads();   // (the zeros above are out -- vmcnt(0) -- before another lane stores an entry over them)
+  // fill: one wave per row again (the row's lines are in the caches), entry q of the row inside the slice -> slot q / 16
+  for (int r = wv; r < R; r += NW) {
+    const long long st = (long long)rst[r];
+    const int len = (int)rlen[r];
+    const unsigned int first = nslot[r];
+    int k = 0;
+    while (k + 1 < K && t0 + r >= sg[k].end) ++k;                // the worker whose list holds the row
+    int base = 0;
+    for (int j0 = 0; j0 < len; j0 += 64) {
+      const int j = j0 + lane;
+      const int rank = j < len ? a.m.col[st + j] : -1;
+      const float v = j < len ? a.m.val[st + j] : 0.0f;
+      const bool mine = rank >= 0 && (pow2 ? (rank & (G - 1)) == b : rank % G == b);
+      const unsigned long long mask = __ballot(mine);
+      if (mine) {
+        const int q = base + __popcll(mask & ((1ull << lane) - 1ull));
+        const long long sl = (long long)first + (q >> 4);
+        const int e = q & 15;
+        const int lc = pow2 ? rank >> gsh : rank / G;
+        a.col[((2 * sbase + (long long)(e >> 3) * a.slot_stride + sl) << 3) + (e & 7)] = (unsigned short)lc;
+        a.val[((4 * sbase + (long long)(e >> 2) * a.slot_stride + sl) << 2) + (e & 3)] = v;
+        if (e == 0) a.slot_meta[sbase + sl] = (unsigned int)r | ((unsigned int)k << 16);
+      }
+      base += __popcll(mask);
     }
   }
+  return true;
+}
+
+// a plan's cells: grid = n_steps x G workgroups (a step's G cells next to each other: they read the same rows)
+template <bool FILL>
+__global__ void __launch_bounds__(CS_THREADS) dsgd_cs_layout_kernel(CsBuildArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned int scratch[CS_BUILD_WORDS];
+  const long long cell = blockIdx.x;
+  const long long s = cell / a.G;
+  const int b = (int)(cell - s * a.G);
+  cs_build_cell<CS_THREADS, FILL>(a, b, s, scratch);
+}
+
+// A per-request step (dsgd_sync_step with the reference's batch sizes): ONE launch -- every slice's workgroup lays its own
+// cell of the step out (into the context's one-step layout, strides at their maxima), then runs the step.
+// ref: core/Slave.scala:142-157 + core/Master.scala:184-197 for the workers hosted here.
+__global__ void __launch_bounds__(CS_THREADS) dsgd_cs_request_kernel(CsArgs a, CsBuildArgs ba) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  cs_launch_body<CS_THREADS, 2, 8, true>(a, lds, [&](unsigned int* scratch) { return cs_build_cell<CS_THREADS, true>(ba, (int)blockIdx.x, 0, scratch); });
 }
 
 // rank-ordered vector -> slice-major [G][Sp] (the padding zero) and back; one lane per rank

@@ -70,6 +70,7 @@ enum { kFloat32 = 7, kInt64 = 4, kUint32 = 3, kSum = 0 };
 static int (*GetUniqueId)(unique_id_t*) = nullptr;
 static int (*CommInitRank)(comm_t*, int, unique_id_t, int) = nullptr;
 static int (*CommDestroy)(comm_t) = nullptr;
+static int (*CommAbort)(comm_t) = nullptr;   // optional: only used to give up a group that not every rank joined
 static int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
 static int (*GroupStart)() = nullptr;
 static int (*GroupEnd)() = nullptr;
@@ -99,6 +100,7 @@ static void load() {
   GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
   CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
   CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+  CommAbort = (decltype(CommAbort))dlsym(h, "ncclCommAbort");
   AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
   GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
   GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
@@ -156,6 +158,18 @@ struct dsgd_plan {
   std::vector<int> cs_shift;    // per step
   long long cs_layout = -1;     // the layout generation (column ranking) the slices were built for
   bool cs_ok = false;
+  bool cs_device_built = false; // laid out by dsgd_cs_layout_kernel (false: by the host, DSGD_CS_HOST_LAYOUT=1)
+  size_t cs_bytes[6] = {0, 0, 0, 0, 0, 0};   // sizes of the six layout arrays (hdr, meta, rf, col, val, cl) as taken from the cache
+  size_t idx_bytes = 0, segs_bytes = 0;
+  // what the plan's set-up enqueued on the context's BUILD stream (lists uploaded, cells laid out) ends with this event;
+  // the first run makes the launch stream wait for it
+  hipEvent_t built_ev = nullptr;
+  bool built_pending = false;
+  // dsgd_plan_record: gate decisions and regulariser scalars of the steps run (column-slice plans)
+  unsigned int* d_gate_rec = nullptr;
+  float* d_s_rec = nullptr;
+  int gate_words = 0;
+  size_t gate_bytes = 0, s_bytes = 0;
 };
 
 struct FusedArgs {
@@ -195,9 +209,11 @@ struct dsgd_ctx {
   std::vector<long long> h_hrp, h_ctp;  // slot offsets of the hot / cold stream (virtual tiles are built from them)
   std::vector<unsigned short> h_ccol;   // host copy of the 16-bit cold ranks (a virtual tile's descriptor carries its cold rank)
   long long layout_gen = 0;             // bumped whenever the split streams are rebuilt
+  bool layout_seen_by_build = false;    // the build stream is ordered behind the kernels that wrote the current split streams
   bool cs_enable = true;                // DSGD_CS=0: small steps of resident plans through the row-parallel kernels
   int cs_g = 0;                         // DSGD_CS_G: slices (8 or 16; 0 = 8 up to four hosted workers, 16 beyond)
-  long long cs_max_mb = 1024;           // DSGD_CS_MAX_MB: largest column-slice layout of one plan
+  long long cs_max_mb = 8192;           // DSGD_CS_MAX_MB: largest column-slice layout of one plan (device-built; the host
+                                        //   builder of DSGD_CS_HOST_LAYOUT=1 holds a copy of it in host memory as well)
   int cs_nt = 0;                        // DSGD_CS_NT=256: tuning runs with 256 lanes per slice where a plan's steps fit them
   unsigned int cs_tag0 = 0;             // column-slice steps launched so far (the exchange granules' tags run on)
   float* d_cs_w = nullptr;              // the weights slice-major while cs_w_G != 0: then d_w is STALE -- every entry point that
@@ -205,6 +221,34 @@ struct dsgd_ctx {
   int cs_w_G = 0;                       // slices of the slice-major state (0: the weights are in d_w, rank order)
   unsigned long long* d_cs_x = nullptr; // exchange buffer of dsgd_cs_step_kernel: [2][CS_MAX_G][CS_XSTRIDE] granules
   unsigned int* d_cs_sync = nullptr;    // its arrival counter and abort word
+  bool cs_host_layout = false;          // DSGD_CS_HOST_LAYOUT=1: a plan's slices laid out by the host (rounds 1-4; kept as the cross-check)
+  bool cs_req = true;                   // DSGD_CS_REQ=0: per-request steps of the reference's sizes through the row-parallel kernels
+  int cs_test_skip = 0;                 // (test builds: DSGD_TEST_CS_SKIP_PUBLISH -- slice 1 goes silent from this step of a launch on)
+  unsigned int* d_cs_max = nullptr;     // the layout kernels' maxima and flags (4 words) ...
+  unsigned int* h_cs_max = nullptr;     // ... and where pass 1's come back to (pinned)
+  hipStream_t build_stream = nullptr;   // a plan's set-up (uploads, layout kernels) runs here, beside the launch stream
+  // device blocks that plans hand back (dsgd_plan_destroy) and take again (dsgd_plan_create): an epoch of the reference is
+  // one plan (core/Master.scala:179-199), so plans come and go with every epoch -- hipMalloc / hipFree per plan (the
+  // latter synchronises the device) would sit in the fit loop
+  struct CacheBlock {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev = nullptr;            // recorded on the launch stream when the block came back: its last reader
+  };
+  std::vector<CacheBlock> cache;
+  size_t cache_bytes = 0;
+  size_t cache_cap = (size_t)8 << 30;   // DSGD_CACHE_MB
+  std::vector<hipEvent_t> ev_pool;      // events of blocks in use, for the next ones
+  // the one-step layout of per-request steps (dsgd_cs_request_kernel), strides at their maxima, per slice count
+  struct ReqLayout {
+    CsHdr* hdr = nullptr;
+    unsigned int* meta = nullptr;
+    unsigned short* rf = nullptr;
+    unsigned short* col = nullptr;
+    float* val = nullptr;
+    unsigned short* cl = nullptr;
+    int G = 0;
+  } req_layout;
   bool vt_enable = true;                // DSGD_VT=0: index-list steps of resident plans through dsgd_mb_grad_kernel
   long long vt_pack_mb = 2048;          // DSGD_VT_PACK_MB: plans whose packed copy fits get one (0: descriptors only)
   int vt_tpw = 1;                       // DSGD_VT_TPW: virtual tiles per wave the grid is sized for (measured: 1 beats 2-4 up to B = 65,536)
@@ -338,6 +382,8 @@ struct dsgd_ctx {
   bool async_running = false;
   bool join_in_progress = false;            // one thread blocks on the engine (without the mutex); the others wait for it
   std::condition_variable join_cv;
+  int join_rc = DSGD_OK;                    // what that thread's join returned: every waiter reports it
+  std::string join_err;
   // exchange mode: the rounds (engine launch, delta, all-reduce, apply) are enqueued by a helper thread so that
   // dsgd_async_start returns at once and dsgd_async_updates / dsgd_async_stop stay responsive
   std::thread exch_thread;
@@ -346,6 +392,8 @@ struct dsgd_ctx {
   std::string exch_err;
   // comm
   rccl::comm_t comm = nullptr;
+  bool comm_broken = false;   // a grouped collective failed half way: the communicator was aborted
+  bool comm_broken_ok = false;   // (set only inside dsgd_comm_destroy: the one call a broken context accepts)
   int world = 1, rank = 0;
   // profiling of the gradient kernel
   bool prof = false;
@@ -376,6 +424,9 @@ static int cs_unslice(dsgd_ctx* c) {
 }
 static int bind(dsgd_ctx* c, bool keep_sliced = false) {  // host threads migrate (JVM pool): bind the device on every call
   HIP_TRY(hipSetDevice(c->cfg.device));
+  if (c->comm_broken && !c->comm_broken_ok)
+    return fail(DSGD_ERCCL, "the context's communicator was aborted after a collective that not every rank joined: "
+                            "dsgd_comm_destroy, then attach a new one (without it the replicas would silently diverge)");
   if (c->cs_w_G && !keep_sliced) return cs_unslice(c);
   return DSGD_OK;
 }
@@ -526,9 +577,11 @@ static int check_err_flag(dsgd_ctx* c) {
   const int err = c->h_sc->err;
   if (err) {
     HIP_TRY(hipMemsetAsync(&c->d_sc->err, 0, sizeof(int), c->stream));
+    // the abort word FIRST, whatever else is set: left raised it would end every later column-slice launch at its first poll
+    if ((err & (8 | 16)) && c->d_cs_sync) HIP_TRY(hipMemsetAsync(c->d_cs_sync, 0, sizeof(unsigned int) * 2, c->stream));
     if (err & 2)
       return fail(DSGD_ESTATE, "fixed-point gradient accumulator left its safe band; the step is invalid");
-    if (err & 8 && c->d_cs_sync) HIP_TRY(hipMemsetAsync(c->d_cs_sync, 0, sizeof(unsigned int) * 2, c->stream));   // the abort word
+    if (err & 16) return 1;   // (a per-request step beyond the one-step layout: nothing was applied -- its peers' 8 comes with it)
     if (err & 8)
       return fail(DSGD_ESTATE, "the column-slice kernel's exchange between its workgroups timed out; the run is invalid "
                                "(DSGD_CS=0 selects the row-parallel kernels)");
@@ -872,13 +925,88 @@ static int launch_grad_vt(dsgd_ctx* c, dsgd_plan* p, long long step) {
       return 1;                       \
     }                                 \
   } while (0)
-static void cs_free(dsgd_plan* p) {
-  (void)hipFree(p->d_cs_hdr);
-  (void)hipFree(p->d_cs_meta);
-  (void)hipFree(p->d_cs_rf);
-  (void)hipFree(p->d_cs_col);
-  (void)hipFree(p->d_cs_val);
-  (void)hipFree(p->d_cs_cl);
+// ---- device blocks of plans, cached across plans (see dsgd_ctx::CacheBlock) -------------------------------------
+// take: the smallest cached block of at least `bytes` and at most twice that; the BUILD stream waits for the block's last
+// reader on the launch stream (an event recorded when it came back).  Otherwise hipMalloc.
+static int cache_take(dsgd_ctx* c, void** out, size_t bytes, size_t* got) {
+  bytes = (std::max<size_t>(bytes, 1) + 4095) & ~(size_t)4095;
+  int best = -1;
+  for (int i = 0; i < (int)c->cache.size(); ++i)
+    if (c->cache[i].bytes >= bytes && c->cache[i].bytes <= 2 * bytes + (1u << 16) && (best < 0 || c->cache[i].bytes < c->cache[best].bytes)) best = i;
+  if (best >= 0) {
+    dsgd_ctx::CacheBlock blk = c->cache[(size_t)best];
+    c->cache.erase(c->cache.begin() + best);
+    c->cache_bytes -= blk.bytes;
+    if (blk.ev) {
+      if (c->build_stream) HIP_TRY(hipStreamWaitEvent(c->build_stream, blk.ev, 0));
+      c->ev_pool.push_back(blk.ev);
+    }
+    *out = blk.p;
+    *got = blk.bytes;
+    return DSGD_OK;
+  }
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e != hipSuccess && !c->cache.empty()) {   // (memory is tight: give the cached blocks back and try once more)
+    (void)hipGetLastError();
+    for (auto& b : c->cache) {
+      (void)hipFree(b.p);
+      if (b.ev) c->ev_pool.push_back(b.ev);
+    }
+    c->cache.clear();
+    c->cache_bytes = 0;
+    e = hipMalloc(&q, bytes);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return 1;   // soft: the caller falls back
+  }
+  *out = q;
+  *got = bytes;
+  return DSGD_OK;
+}
+// give back: the block's last reader is whatever the launch stream holds now
+static void cache_give(dsgd_ctx* c, void* q, size_t bytes) {
+  if (!q) return;
+  if (bytes == 0 || c->cache_bytes + bytes > c->cache_cap || c->cache.size() >= 256) {
+    (void)hipFree(q);   // (not ours to keep: allocated outside the cache, or the cache is full)
+    return;
+  }
+  dsgd_ctx::CacheBlock blk;
+  blk.p = q;
+  blk.bytes = bytes;
+  if (!c->ev_pool.empty()) {
+    blk.ev = c->ev_pool.back();
+    c->ev_pool.pop_back();
+  } else if (hipEventCreateWithFlags(&blk.ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(q);
+    return;
+  }
+  if (hipEventRecord(blk.ev, c->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(c->stream);
+  }
+  c->cache.push_back(blk);
+  c->cache_bytes += bytes;
+}
+static void cache_drop_all(dsgd_ctx* c) {   // (dsgd_destroy: the streams are idle)
+  for (auto& b : c->cache) {
+    (void)hipFree(b.p);
+    if (b.ev) (void)hipEventDestroy(b.ev);
+  }
+  for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  c->cache.clear();
+  c->ev_pool.clear();
+  c->cache_bytes = 0;
+}
+
+static void cs_free(dsgd_ctx* c, dsgd_plan* p) {
+  void* q[6] = {p->d_cs_hdr, p->d_cs_meta, p->d_cs_rf, p->d_cs_col, p->d_cs_val, p->d_cs_cl};
+  for (int i = 0; i < 6; ++i) {
+    cache_give(c, q[i], p->cs_bytes[i]);   // (size 0: a block the host builder allocated itself -- freed)
+    p->cs_bytes[i] = 0;
+  }
   p->d_cs_cl = nullptr;
   p->d_cs_hdr = nullptr;
   p->d_cs_meta = nullptr;
@@ -887,9 +1015,165 @@ static void cs_free(dsgd_plan* p) {
   p->d_cs_val = nullptr;
   p->cs_ok = false;
 }
-static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
-  cs_free(p);
+static int ensure_build_stream(dsgd_ctx* c) {
+  if (!c->build_stream) HIP_TRY(hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking));
+  return DSGD_OK;
+}
+// the arrays every column-slice launch shares: the exchange buffer and its abort word (each for itself: a failure between
+// the two must not leave the first behind alone)
+static int ensure_cs_exchange(dsgd_ctx* c) {
+  if (!c->d_cs_x) {
+    unsigned long long* x = nullptr;
+    if (hipMalloc(&x, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE) != hipSuccess) {
+      (void)hipGetLastError();
+      return 1;
+    }
+    if (hipMemset(x, 0, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(x);
+      return 1;
+    }
+    c->d_cs_x = x;
+  }
+  if (!c->d_cs_sync) {
+    unsigned int* y = nullptr;
+    if (hipMalloc(&y, sizeof(unsigned int) * 2) != hipSuccess) {
+      (void)hipGetLastError();
+      return 1;
+    }
+    if (hipMemset(y, 0, sizeof(unsigned int) * 2) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(y);
+      return 1;
+    }
+    c->d_cs_sync = y;
+  }
+  return DSGD_OK;
+}
+static int ensure_cs_max(dsgd_ctx* c) {
+  if (!c->d_cs_max) HIP_TRY(hipMalloc(&c->d_cs_max, sizeof(unsigned int) * 4));
+  if (!c->h_cs_max) HIP_TRY(hipHostMalloc(&c->h_cs_max, sizeof(unsigned int) * 4, hipHostMallocDefault));
+  return DSGD_OK;
+}
+// slices for K hosted workers: 8 up to four (wider slices, fewer peers in the exchange), 16 beyond or for a wide model
+static int cs_pick_G(const dsgd_ctx* c, int K, bool request) {
+  auto fits = [&](int G) {
+    const int words = request ? cs_req_lds_words(c->dp, G, K) : cs_lds_words(c->dp, G, K);
+    return c->dp >= 4 * G && words <= DSGD_LDS_FLOATS && (c->dp + G - 1) / G <= 65536;
+  };
+  int G = c->cs_g ? c->cs_g : (K <= 4 ? 8 : 16);
+  if (!c->cs_g && G == 8 && !fits(8)) G = 16;
+  return fits(G) ? G : 0;
+}
+
+// A plan's column slices laid out by the device (csrc/dsgd_cs.hpp: dsgd_cs_layout_kernel), on the build stream: pass 1
+// counts (one read-back of four words: the strides), pass 2 fills.  Returns 1 for a soft failure (memory).
+static int cs_build_device_impl(dsgd_ctx* c, dsgd_plan* p) {
+  if (!c->layout_seen_by_build) {   // (once per column layout: the layout kernels read the ranked CSR the launch stream wrote)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->layout_seen_by_build = true;
+  }
+  cs_free(c, p);
   p->cs_layout = c->layout_gen;
+  p->cs_device_built = true;
+  const int K = p->n_workers;
+  const long long n_steps = p->n_steps, n_lists = n_steps * K;
+  if (K > CS_MAX_K || p->max_step_rows > CS_MAX_SLOTS) return DSGD_OK;
+  const int G = cs_pick_G(c, K, false);
+  if (!G) return DSGD_OK;
+  if (n_steps * (long long)G > 0x7fffffffLL) return DSGD_OK;
+  if ((long long)p->h_idx.size() != p->offsets[(size_t)n_lists]) return DSGD_OK;
+  for (long long r : p->h_idx)
+    if (r < 0 || r >= c->n_rows) return DSGD_OK;   // (the row-wise kernel reports the bad index)
+  p->cs_shift.assign((size_t)n_steps, 21);
+  for (long long st = 0; st < n_steps; ++st) {
+    long long worst_list = 1;
+    for (int k = 0; k < K; ++k) worst_list = std::max(worst_list, p->offsets[(size_t)(st * K + k) + 1] - p->offsets[(size_t)(st * K + k)]);
+    int bits = 0;
+    while ((1LL << bits) < worst_list) ++bits;
+    p->cs_shift[(size_t)st] = 30 - bits;   // at most one contribution per row and column: a worker's sums stay below 2^30
+  }
+  DSGD_TRY(ensure_build_stream(c));
+  DSGD_TRY(ensure_cs_max(c));
+  if (int rc = ensure_cs_exchange(c)) return rc;
+  hipStream_t bs = c->build_stream;
+  CsBuildArgs ba{};
+  ba.m = view(c);
+  ba.idx = p->d_idx;
+  ba.segs = p->d_segs;
+  ba.maxima = c->d_cs_max;
+  ba.n_steps_plan = n_steps;
+  ba.dp = c->dp;
+  ba.G = G;
+  ba.K = K;
+  HIP_TRY(hipMemsetAsync(c->d_cs_max, 0, sizeof(unsigned int) * 4, bs));
+  hipLaunchKernelGGL(dsgd_cs_layout_kernel<false>, dim3((unsigned)(n_steps * G)), dim3(CS_THREADS), 0, bs, ba);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(c->h_cs_max, c->d_cs_max, sizeof(unsigned int) * 4, hipMemcpyDeviceToHost, bs));
+  HIP_TRY(hipStreamSynchronize(bs));
+  const long long max_slots = std::max<long long>(1, c->h_cs_max[0]), max_cols = std::max<long long>(1, c->h_cs_max[1]);
+  const long long max_rows = std::max<long long>(1, p->max_step_rows);
+  if (c->h_cs_max[2] & 1u) return DSGD_OK;
+  if (max_slots > CS_MAX_SLOTS || max_rows > CS_MAX_SLOTS || max_cols > (long long)CS_MAX_CLT * CS_THREADS) return DSGD_OK;
+  const long long big = std::max(max_slots, max_rows);
+  const bool one_fits = big <= CS_THREADS && max_cols <= 4 * CS_THREADS;                  // one slot per lane
+  const bool narrow_fits = big <= 2 * CS_THREADS_NARROW && max_cols <= 8 * CS_THREADS_NARROW;
+  const int slot_stride = (int)((max_slots + 63) / 64 * 64), row_stride = (int)((max_rows + 1 + 63) / 64 * 64);
+  const int cl_stride = (int)((max_cols + CS_THREADS - 1) / CS_THREADS * CS_THREADS);
+  const long long cells = (long long)G * n_steps;
+  const long long bytes = cells * ((long long)slot_stride * (4 + CS_L * 2 + CS_L * 4) + (long long)row_stride * 2 + (long long)cl_stride * 2 + 8);
+  if (bytes > c->cs_max_mb * (1LL << 20)) return DSGD_OK;
+  const size_t want[6] = {sizeof(CsHdr) * (size_t)cells,
+                          sizeof(unsigned int) * (size_t)(cells * slot_stride),
+                          sizeof(unsigned short) * (size_t)(cells * row_stride),
+                          sizeof(unsigned short) * (size_t)(cells * slot_stride * CS_L),
+                          sizeof(float) * (size_t)(cells * slot_stride * CS_L),
+                          sizeof(unsigned short) * (size_t)(cells * cl_stride)};
+  void* got[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < 6; ++i) {
+    if (int rc = cache_take(c, &got[i], want[i], &p->cs_bytes[i])) {
+      for (int j = 0; j < i; ++j) {
+        cache_give(c, got[j], p->cs_bytes[j]);
+        p->cs_bytes[j] = 0;
+      }
+      return rc;
+    }
+  }
+  p->d_cs_hdr = static_cast<CsHdr*>(got[0]);
+  p->d_cs_meta = static_cast<unsigned int*>(got[1]);
+  p->d_cs_rf = static_cast<unsigned short*>(got[2]);
+  p->d_cs_col = static_cast<uint4*>(got[3]);
+  p->d_cs_val = static_cast<float4*>(got[4]);
+  p->d_cs_cl = static_cast<unsigned short*>(got[5]);
+  ba.hdr = p->d_cs_hdr;
+  ba.slot_meta = p->d_cs_meta;
+  ba.row_first = p->d_cs_rf;
+  ba.col = reinterpret_cast<unsigned short*>(p->d_cs_col);
+  ba.val = reinterpret_cast<float*>(p->d_cs_val);
+  ba.clist = p->d_cs_cl;
+  ba.slot_stride = slot_stride;
+  ba.row_stride = row_stride;
+  ba.cl_stride = cl_stride;
+  hipLaunchKernelGGL(dsgd_cs_layout_kernel<true>, dim3((unsigned)(n_steps * G)), dim3(CS_THREADS), 0, bs, ba);
+  HIP_TRY(hipGetLastError());
+  p->cs_G = G;
+  p->cs_nt = (c->cs_nt == CS_THREADS_NARROW && narrow_fits) ? CS_THREADS_NARROW : CS_THREADS;
+  p->cs_spl = (p->cs_nt == CS_THREADS && one_fits) ? 1 : 2;
+  p->cs_slot_stride = slot_stride;
+  p->cs_row_stride = row_stride;
+  p->cs_cl_stride = cl_stride;
+  p->cs_ok = true;
+  return DSGD_OK;
+}
+static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
+  cs_free(c, p);
+  p->cs_layout = c->layout_gen;
+  p->cs_device_built = false;
+  // (the lists were uploaded on the build stream: the gather below runs on the launch stream)
+  if (p->built_pending) {
+    HIP_TRY(hipStreamWaitEvent(c->stream, p->built_ev, 0));
+    p->built_pending = false;
+  }
   const int K = p->n_workers;
   const long long n_steps = p->n_steps, n_lists = n_steps * K;
   if (K > CS_MAX_K || p->max_step_rows > CS_MAX_SLOTS) return DSGD_OK;
@@ -1045,14 +1329,7 @@ static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
   CS_SOFT(hipMemcpy(p->d_cs_rf, rf.data(), sizeof(unsigned short) * rf.size(), hipMemcpyHostToDevice));
   CS_SOFT(hipMemcpy(p->d_cs_col, col.data(), sizeof(unsigned short) * col.size(), hipMemcpyHostToDevice));
   CS_SOFT(hipMemcpy(p->d_cs_val, val.data(), sizeof(float) * val.size(), hipMemcpyHostToDevice));
-  if (!c->d_cs_x) {   // (each buffer for itself: a failure between the two must not leave the first behind alone)
-    CS_SOFT(hipMalloc(&c->d_cs_x, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE));
-    CS_SOFT(hipMemset(c->d_cs_x, 0, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE));
-  }
-  if (!c->d_cs_sync) {
-    CS_SOFT(hipMalloc(&c->d_cs_sync, sizeof(unsigned int) * 2));
-    CS_SOFT(hipMemset(c->d_cs_sync, 0, sizeof(unsigned int) * 2));
-  }
+  if (ensure_cs_exchange(c)) return 1;
   p->cs_G = G;
   p->cs_nt = (c->cs_nt == CS_THREADS_NARROW && narrow_fits) ? CS_THREADS_NARROW : CS_THREADS;
   p->cs_spl = (p->cs_nt == CS_THREADS && one_fits) ? 1 : 2;
@@ -1066,15 +1343,69 @@ static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
 static int cs_build(dsgd_ctx* c, dsgd_plan* p) {
   int rc;
   try {
-    rc = cs_build_impl(c, p);
+    rc = c->cs_host_layout ? cs_build_impl(c, p) : cs_build_device_impl(c, p);
   } catch (const std::bad_alloc&) {   // (nothing may unwind across the C ABI)
     rc = 1;
   }
   if (rc == 1) {
-    cs_free(p);   // (cs_layout is stamped: the plan keeps the row-parallel kernels until the layout changes)
+    cs_free(c, p);   // (cs_layout is stamped: the plan keeps the row-parallel kernels until the layout changes)
     return DSGD_OK;
   }
   return rc;
+}
+
+// the weights slice-major for G slices (they stay so until something else touches w: bind)
+static int cs_ensure_sliced(dsgd_ctx* c, int G) {
+  if (c->cs_w_G == G) return DSGD_OK;
+  DSGD_TRY(cs_unslice(c));
+  const int Sp = cs_sp(c->dp, G), n = G * Sp;
+  const size_t cap = sizeof(float) * (size_t)(c->dp + (CS_MAX_G + 1) * 8);
+  if (!c->d_cs_w) HIP_TRY(hipMalloc(&c->d_cs_w, cap));
+  if (!c->d_cs_ds) HIP_TRY(hipMalloc(&c->d_cs_ds, cap));
+  hipLaunchKernelGGL(dsgd_cs_slice_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_w, c->d_cs_w, c->dp, G, Sp);
+  hipLaunchKernelGGL(dsgd_cs_slice_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_ds, c->d_cs_ds, c->dp, G, Sp);
+  HIP_TRY(hipGetLastError());
+  c->cs_w_G = G;   // (dimSparsity can only change through an entry point that converts back first)
+  return DSGD_OK;
+}
+// a step's granules carry the count of column-slice steps the context has launched: nothing to clear between launches
+// (until the 32-bit count would wrap)
+static int cs_take_tags(dsgd_ctx* c, unsigned long long n_launch, unsigned int* tag0) {
+  if ((unsigned long long)c->cs_tag0 + n_launch + 1ull >= (1ull << 32)) {
+    HIP_TRY(hipMemsetAsync(c->d_cs_x, 0, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE, c->stream));
+    c->cs_tag0 = 0;
+  }
+  *tag0 = c->cs_tag0;
+  c->cs_tag0 += (unsigned int)n_launch;
+  return DSGD_OK;
+}
+static void cs_common_args(dsgd_ctx* c, CsArgs& a, int G, int K, float lr) {
+  a.w = c->d_cs_w;
+  a.ds = c->d_cs_ds;
+  a.xbuf = c->d_cs_x;
+  a.sync = c->d_cs_sync;
+  a.sc = c->d_sc;
+  a.tprof = c->d_tprof;
+  a.lr = lr;
+  a.lambda = (float)c->cfg.lambda;
+  a.vexp = c->vexp;
+  a.dp = c->dp;
+  a.G = G;
+  a.K = K;
+  a.mail = nullptr;
+  a.mail_seq = 0ull;
+  a.gate_rec = nullptr;
+  a.s_rec = nullptr;
+  a.gate_words = 0;
+  a.test_skip_publish = c->cs_test_skip;
+}
+static void cs_after_launch(dsgd_ctx* c, int shift) {
+  c->last_grad_kernel = "dsgd_cs_step_kernel";
+  c->last_shift = shift;
+  c->fused_apply_pending = false;
+  c->s_dirty = true;    // the kernel carries s = 2 lambda (w . ds) itself; whoever needs it next recomputes it from the weights
+  c->s_lazy = false;
+  c->nsq_dirty = false;
 }
 
 // the steps [step_begin, step_end) of a plan with column slices: ONE launch
@@ -1087,45 +1418,18 @@ static int launch_cs(dsgd_ctx* c, dsgd_plan* p, long long step_begin, long long 
   a.val = p->d_cs_val;
   a.clist = p->d_cs_cl;
   a.cl_stride = p->cs_cl_stride;
-  // the weights slice-major for this plan's slice count (they stay so until something else touches w: bind)
-  if (c->cs_w_G != p->cs_G) {
-    DSGD_TRY(cs_unslice(c));
-    const int Sp = cs_sp(c->dp, p->cs_G), n = p->cs_G * Sp;
-    const size_t cap = sizeof(float) * (size_t)(c->dp + (CS_MAX_G + 1) * 8);
-    if (!c->d_cs_w) HIP_TRY(hipMalloc(&c->d_cs_w, cap));
-    if (!c->d_cs_ds) HIP_TRY(hipMalloc(&c->d_cs_ds, cap));
-    hipLaunchKernelGGL(dsgd_cs_slice_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_w, c->d_cs_w, c->dp, p->cs_G, Sp);
-    hipLaunchKernelGGL(dsgd_cs_slice_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_ds, c->d_cs_ds, c->dp, p->cs_G, Sp);
-    HIP_TRY(hipGetLastError());
-    c->cs_w_G = p->cs_G;   // (dimSparsity can only change through an entry point that converts back first)
-  }
-  a.w = c->d_cs_w;
-  a.ds = c->d_cs_ds;
-  a.xbuf = c->d_cs_x;
-  a.sync = c->d_cs_sync;
-  a.sc = c->d_sc;
-  a.tprof = c->d_tprof;
+  DSGD_TRY(cs_ensure_sliced(c, p->cs_G));
+  cs_common_args(c, a, p->cs_G, p->n_workers, lr);
   a.n_steps_plan = p->n_steps;
   a.step_begin = step_begin;
   a.step_end = step_end;
   a.slot_stride = p->cs_slot_stride;
   a.row_stride = p->cs_row_stride;
-  a.lr = lr;
-  a.lambda = (float)c->cfg.lambda;
-  a.vexp = c->vexp;
-  a.dp = c->dp;
-  a.G = p->cs_G;
-  a.K = p->n_workers;
+  a.gate_rec = p->d_gate_rec;
+  a.s_rec = p->d_s_rec;
+  a.gate_words = p->gate_words;
   const size_t lds = sizeof(float) * (size_t)cs_lds_words(c->dp, a.G, a.K);
-  // a step's granules carry the count of column-slice steps the context has launched: nothing to clear between launches
-  // (until the 32-bit count would wrap)
-  const unsigned long long n_launch = (unsigned long long)(step_end - step_begin);
-  if ((unsigned long long)c->cs_tag0 + n_launch + 1ull >= (1ull << 32)) {
-    HIP_TRY(hipMemsetAsync(c->d_cs_x, 0, sizeof(unsigned long long) * 2 * CS_MAX_G * CS_XSTRIDE, c->stream));
-    c->cs_tag0 = 0;
-  }
-  a.tag0 = c->cs_tag0;
-  c->cs_tag0 += (unsigned int)n_launch;
+  DSGD_TRY(cs_take_tags(c, (unsigned long long)(step_end - step_begin), &a.tag0));
   size_t slot = 0;
   DSGD_TRY(prof_begin(c, &slot));
   c->ctr_known = false;
@@ -1137,12 +1441,95 @@ static int launch_cs(dsgd_ctx* c, dsgd_plan* p, long long step_begin, long long 
     hipLaunchKernelGGL((dsgd_cs_step_kernel<CS_THREADS, 2, 8>), dim3((unsigned)a.G), dim3(CS_THREADS), lds, c->stream, a);
   HIP_TRY(hipGetLastError());
   DSGD_TRY(prof_end(c, slot));
-  c->last_grad_kernel = "dsgd_cs_step_kernel";
-  c->last_shift = p->cs_shift[(size_t)(step_end - 1)];
-  c->fused_apply_pending = false;
-  c->s_dirty = true;    // the kernel carries s = 2 lambda (w . ds) itself; whoever needs it next recomputes it from the weights
-  c->s_lazy = false;
-  c->nsq_dirty = false;
+  cs_after_launch(c, p->cs_shift[(size_t)(step_end - 1)]);
+  return DSGD_OK;
+}
+
+// A per-request step of the reference's sizes (<= CS_MAX_K hosted workers, <= CS_MAX_SLOTS rows): the lists staged by
+// stage_lists (c->cur_idx, c->d_segs) go through dsgd_cs_request_kernel -- every slice lays its cell out and runs the step,
+// ONE launch.  Returns 1 when the path is not available (the caller takes the row-parallel kernels).
+static int cs_request_ok(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int64_t* n_per_worker, int K, int* G_out) {
+  if (!c->cs_enable || !c->cs_req || c->comm || c->prof || K > CS_MAX_K) return 1;
+  long long tot = 0;
+  for (int k = 0; k < K; ++k) {
+    if (n_per_worker[k] <= 0 || !idx_per_worker[k]) return 1;   // (stage_lists reports it)
+    tot += n_per_worker[k];
+  }
+  if (tot > CS_MAX_SLOTS) return 1;
+  for (int k = 0; k < K; ++k)
+    for (int64_t t = 0; t < n_per_worker[k]; ++t)
+      if (idx_per_worker[k][t] < 0 || idx_per_worker[k][t] >= c->n_rows) return 1;   // (the row-wise kernel reports the bad index)
+  const int G = cs_pick_G(c, K, true);
+  if (!G) return 1;
+  *G_out = G;
+  return DSGD_OK;
+}
+static int launch_cs_request(dsgd_ctx* c, int G, int K, long long worst_list, float lr) {
+  dsgd_ctx::ReqLayout& L = c->req_layout;
+  constexpr int SLOT_STRIDE = CS_MAX_SLOTS, ROW_STRIDE = CS_MAX_SLOTS + 64, CL_STRIDE = CS_MAX_CLT * CS_THREADS;
+  if (L.G < G) {   // (grown once: 8 -> 16 slices)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(L.hdr);
+    (void)hipFree(L.meta);
+    (void)hipFree(L.rf);
+    (void)hipFree(L.col);
+    (void)hipFree(L.val);
+    (void)hipFree(L.cl);
+    L = dsgd_ctx::ReqLayout();
+    HIP_TRY(hipMalloc(&L.hdr, sizeof(CsHdr) * (size_t)G));
+    HIP_TRY(hipMalloc(&L.meta, sizeof(unsigned int) * (size_t)G * SLOT_STRIDE));
+    HIP_TRY(hipMalloc(&L.rf, sizeof(unsigned short) * (size_t)G * ROW_STRIDE));
+    HIP_TRY(hipMalloc(&L.col, sizeof(unsigned short) * (size_t)G * SLOT_STRIDE * CS_L));
+    HIP_TRY(hipMalloc(&L.val, sizeof(float) * (size_t)G * SLOT_STRIDE * CS_L));
+    HIP_TRY(hipMalloc(&L.cl, sizeof(unsigned short) * (size_t)G * CL_STRIDE));
+    L.G = G;
+  }
+  if (ensure_cs_exchange(c)) return fail(DSGD_ENOMEM, "out of device memory (column-slice exchange buffer)");
+  DSGD_TRY(ensure_cs_max(c));
+  DSGD_TRY(cs_ensure_sliced(c, G));
+  CsArgs a;
+  a.hdr = L.hdr;
+  a.slot_meta = L.meta;
+  a.row_first = L.rf;
+  a.col = reinterpret_cast<const uint4*>(L.col);
+  a.val = reinterpret_cast<const float4*>(L.val);
+  a.clist = L.cl;
+  a.cl_stride = CL_STRIDE;
+  cs_common_args(c, a, G, K, lr);
+  a.n_steps_plan = 1;
+  a.step_begin = 0;
+  a.step_end = 1;
+  a.slot_stride = SLOT_STRIDE;
+  a.row_stride = ROW_STRIDE;
+  a.mail = c->d_mail;
+  a.mail_seq = ++c->mail_seq;
+  CsBuildArgs ba{};
+  ba.m = view(c);
+  ba.idx = c->cur_idx;
+  ba.segs = c->d_segs;
+  ba.hdr = L.hdr;
+  ba.slot_meta = L.meta;
+  ba.row_first = L.rf;
+  ba.col = L.col;
+  ba.val = L.val;
+  ba.clist = L.cl;
+  ba.maxima = c->d_cs_max;   // (a request only ever raises flags here; nobody reads the maxima)
+  ba.n_steps_plan = 1;
+  ba.slot_stride = SLOT_STRIDE;
+  ba.row_stride = ROW_STRIDE;
+  ba.cl_stride = CL_STRIDE;
+  ba.dp = c->dp;
+  ba.G = G;
+  ba.K = K;
+  const size_t lds = sizeof(float) * (size_t)cs_req_lds_words(c->dp, G, K);
+  DSGD_TRY(cs_take_tags(c, 1ull, &a.tag0));
+  c->ctr_known = false;
+  hipLaunchKernelGGL(dsgd_cs_request_kernel, dim3((unsigned)G), dim3(CS_THREADS), lds, c->stream, a, ba);
+  HIP_TRY(hipGetLastError());
+  int bits = 0;
+  while ((1LL << bits) < worst_list) ++bits;
+  cs_after_launch(c, 30 - bits);
+  c->last_grad_kernel = "dsgd_cs_request_kernel";
   return DSGD_OK;
 }
 
@@ -1370,6 +1757,7 @@ static int build_split(dsgd_ctx* c) {
   hrp.assign((size_t)n_rows + 1, 0);
   ctp.assign((size_t)n_rows + 1, 0);
   ++c->layout_gen;
+  c->layout_seen_by_build = false;
   crp.assign((size_t)n_rows + 1, 0);
   c->wlong_rows.clear();
   hrp[0] = 0;
@@ -1861,6 +2249,12 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_CS")) c->cs_enable = atoi(e) != 0;             // 0: small plan steps through the row-parallel kernels
   if (const char* e = getenv("DSGD_CS_G")) c->cs_g = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 0);
   if (const char* e = getenv("DSGD_CS_MAX_MB")) c->cs_max_mb = std::max(0, atoi(e));
+  if (const char* e = getenv("DSGD_CS_HOST_LAYOUT")) c->cs_host_layout = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_CS_REQ")) c->cs_req = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_CACHE_MB")) c->cache_cap = (size_t)std::max(0, atoi(e)) << 20;
+#ifdef DSGD_TEST_COLLECTIVE_SEAM
+  if (const char* e = getenv("DSGD_TEST_CS_SKIP_PUBLISH")) c->cs_test_skip = std::max(0, atoi(e));
+#endif
   if (const char* e = getenv("DSGD_REQ_MAPPED")) c->req_mapped = atoi(e) != 0;
   if (const char* e = getenv("DSGD_REQ_PLAN")) c->req_plan = atoi(e) != 0;
   if (const char* e = getenv("DSGD_STREAM_MIN")) c->stream_min = std::max(1LL, atoll(e));
@@ -1911,12 +2305,16 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
 
 int dsgd_destroy(dsgd_ctx* c) {
   if (!c) return DSGD_OK;
-  c->mu.lock();   // a call still running on another thread finishes first
+  std::unique_lock<std::mutex> lk(c->mu);   // a call still running on another thread finishes first
   (void)hipSetDevice(c->cfg.device);
   // The persistent Hogwild kernel only exits on its stop flag: raise it and wait BEFORE any hipFree (hipFree
   // synchronises the device -- it would wait forever on that kernel, or free memory the kernel still reads).
   if (c->async_stream) {
     (void)hog_raise_stop(c);
+    // a thread inside dsgd_async_wait / dsgd_async_stop blocks on the engine WITHOUT the mutex (async_wait_released) and
+    // comes back for it: it is the one thread that joins exch_thread, and it still uses the context afterwards -- wait
+    // until it has left (the stop flag above lets it finish)
+    c->join_cv.wait(lk, [c] { return !c->join_in_progress; });
     if (c->exch_thread.joinable()) c->exch_thread.join();
     (void)hipStreamSynchronize(c->async_stream);
     c->async_running = false;
@@ -1983,6 +2381,19 @@ int dsgd_destroy(dsgd_ctx* c) {
   (void)hipFree(c->d_wdelta);
   (void)hipFree(c->d_tprof);
   (void)hipFree(c->d_plan_gcold);
+  if (c->build_stream) {
+    (void)hipStreamSynchronize(c->build_stream);
+    (void)hipStreamDestroy(c->build_stream);
+  }
+  cache_drop_all(c);
+  (void)hipFree(c->req_layout.hdr);
+  (void)hipFree(c->req_layout.meta);
+  (void)hipFree(c->req_layout.rf);
+  (void)hipFree(c->req_layout.col);
+  (void)hipFree(c->req_layout.val);
+  (void)hipFree(c->req_layout.cl);
+  (void)hipFree(c->d_cs_max);
+  if (c->h_cs_max) (void)hipHostFree(c->h_cs_max);
   (void)hipFree(c->d_cs_x);
   (void)hipFree(c->d_cs_sync);
   (void)hipFree(c->d_cs_w);
@@ -1991,7 +2402,7 @@ int dsgd_destroy(dsgd_ctx* c) {
   if (c->h_mail) (void)hipHostFree(c->h_mail);
   if (c->h_req) (void)hipHostFree(c->h_req);
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  c->mu.unlock();
+  lk.unlock();
   delete c;
   return DSGD_OK;
 }
@@ -2418,6 +2829,20 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
       return finish_mail(c, stats, tot, before, c->req_spin);
     }
   }
+  {
+    // the reference's own sizes (application.conf:15,27): the step laid out and run by the column-slice kernel, one launch
+    int G = 0;
+    if (cs_request_ok(c, idx_per_worker, n_per_worker, n_workers, &G) == DSGD_OK) {
+      if (!c->ctr_known) DSGD_TRY(reset_counters(c));
+      const unsigned long long before = c->ctr_last;
+      DSGD_TRY(stage_lists(c, idx_per_worker, n_per_worker, n_workers, &mx, &tot));
+      DSGD_TRY(launch_cs_request(c, G, n_workers, mx, lr));
+      const int rc = finish_mail(c, stats, tot, before, c->req_spin);
+      if (rc != 1) return rc;
+      // (the step does not fit the one-step layout -- more than CS_MAX_SLOTS slots or 4,096 columns in one slice: nothing
+      //  was applied; the row-parallel kernels below take it)
+    }
+  }
   DSGD_TRY(ensure_g(c, n_workers));
   DSGD_TRY(ensure_s(c, true));
   if (c->comm || c->prof) {   // (the collective path / profiling brackets: the plain read-back)
@@ -2505,10 +2930,10 @@ int dsgd_synchronize(dsgd_ctx* c, dsgd_batch_stats* stats) {
   const long long act = (long long)c->h_sc->n_active;
   const int err = c->h_sc->err;
   DSGD_TRY(reset_counters(c));
+  if ((err & (8 | 16)) && c->d_cs_sync) HIP_TRY(hipMemsetAsync(c->d_cs_sync, 0, sizeof(unsigned int) * 2, c->stream));   // the abort word, first
   if (err & 2)
     return fail(DSGD_ESTATE, "fixed-point gradient accumulator left its safe band; the steps since the last "
                              "synchronize are invalid");
-  if (err & 8 && c->d_cs_sync) HIP_TRY(hipMemsetAsync(c->d_cs_sync, 0, sizeof(unsigned int) * 2, c->stream));   // the abort word
   if (err & 8)
     return fail(DSGD_ESTATE, "the column-slice kernel's exchange between its workgroups timed out; the steps since the last "
                              "synchronize are invalid (DSGD_CS=0 selects the row-parallel kernels)");
@@ -2534,7 +2959,7 @@ int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, in
     mx = std::max<long long>(mx, offsets[i + 1] - offsets[i]);
   }
   std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c));
+  DSGD_TRY(bind(c, true));   // (nothing here touches w: slice-major weights stay as they are)
   dsgd_plan* p = new (std::nothrow) dsgd_plan();
   if (!p) return fail(DSGD_ENOMEM, "out of host memory");
   p->n_steps = n_steps;
@@ -2552,17 +2977,118 @@ int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, in
     segs[i].begin = offsets[i];
     segs[i].end = offsets[i + 1];
   }
-  hipError_t e = hipMalloc(&p->d_idx, sizeof(int) * (size_t)offsets[n_lists]);
-  if (e == hipSuccess) e = hipMalloc(&p->d_segs, sizeof(WorkSeg) * (size_t)n_lists);
-  if (e == hipSuccess) e = hipMemcpy(p->d_idx, idx, sizeof(int) * (size_t)offsets[n_lists], hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p->d_segs, segs.data(), sizeof(WorkSeg) * (size_t)n_lists, hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    (void)hipFree(p->d_idx);
-    (void)hipFree(p->d_segs);
-    delete p;
-    return fail(DSGD_EHIP, "plan upload: %s", hipGetErrorString(e));
+  // the lists go up on the context's BUILD stream (beside whatever the launch stream is running: the next epoch's plan
+  // can be set up while this epoch's steps run), into blocks earlier plans handed back
+  int rc = ensure_build_stream(c);
+  void *qi = nullptr, *qs = nullptr;
+  const size_t ib = sizeof(int) * (size_t)offsets[n_lists], sb = sizeof(WorkSeg) * (size_t)n_lists;
+  if (rc == DSGD_OK && (cache_take(c, &qi, ib, &p->idx_bytes) || cache_take(c, &qs, sb, &p->segs_bytes)))
+    rc = fail(DSGD_ENOMEM, "out of device memory (plan of %lld index entries)", (long long)offsets[n_lists]);
+  p->d_idx = static_cast<int*>(qi);
+  p->d_segs = static_cast<WorkSeg*>(qs);
+  if (rc == DSGD_OK && hipEventCreateWithFlags(&p->built_ev, hipEventDisableTiming) != hipSuccess) rc = fail(DSGD_EHIP, "hipEventCreate");
+  // (pageable sources: the runtime stages them and returns when they are staged; ordered on the build stream)
+  hipError_t e = hipSuccess;
+  if (rc == DSGD_OK) e = hipMemcpyAsync(p->d_idx, idx, ib, hipMemcpyHostToDevice, c->build_stream);
+  if (rc == DSGD_OK && e == hipSuccess) e = hipMemcpyAsync(p->d_segs, segs.data(), sb, hipMemcpyHostToDevice, c->build_stream);
+  if (rc == DSGD_OK && e == hipSuccess) e = hipStreamSynchronize(c->build_stream);   // (segs is a local: staged before it goes)
+  if (rc == DSGD_OK && e != hipSuccess) rc = fail(DSGD_EHIP, "plan upload: %s", hipGetErrorString(e));
+  // the column slices of the reference's own step sizes are laid out NOW (by the device, on the build stream), not inside
+  // the first dsgd_plan_run -- a call its callers time; without a column layout yet (no data / no dimSparsity) at the first run
+  if (rc == DSGD_OK && c->cs_enable && !c->comm && c->d_row_ptr && c->have_ds && !c->async_running) {
+    rc = prepare_layout(c);
+    if (rc == DSGD_OK) rc = cs_build(c, p);
   }
+  if (rc == DSGD_OK && hipEventRecord(p->built_ev, c->build_stream) != hipSuccess) rc = fail(DSGD_EHIP, "hipEventRecord");
+  if (rc != DSGD_OK) {
+    char msg[sizeof(g_err)];
+    snprintf(msg, sizeof(msg), "%s", g_err);
+    (void)hipStreamSynchronize(c->build_stream);
+    cs_free(c, p);
+    cache_give(c, p->d_idx, p->idx_bytes);
+    cache_give(c, p->d_segs, p->segs_bytes);
+    if (p->built_ev) (void)hipEventDestroy(p->built_ev);
+    delete p;
+    return fail(rc, "%s", msg);
+  }
+  p->built_pending = true;
   *out = p;
+  return DSGD_OK;
+}
+
+// gate decisions and regulariser scalars of a column-slice plan's steps on record (include/dsgd.h)
+int dsgd_plan_record(dsgd_ctx* c, dsgd_plan* p, int32_t on) {
+  DSGD_TRY(check_ctx(c));
+  if (!p) return fail(DSGD_EINVAL, "null plan");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c, true));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  cache_give(c, p->d_gate_rec, p->gate_bytes);
+  cache_give(c, p->d_s_rec, p->s_bytes);
+  p->d_gate_rec = nullptr;
+  p->d_s_rec = nullptr;
+  p->gate_words = 0;
+  if (!on) return DSGD_OK;
+  const int words = (int)((std::max<long long>(p->max_step_rows, 1) + 31) / 32);
+  void *g = nullptr, *sv = nullptr;
+  if (cache_take(c, &g, sizeof(unsigned int) * (size_t)p->n_steps * words, &p->gate_bytes) ||
+      cache_take(c, &sv, sizeof(float) * (size_t)p->n_steps, &p->s_bytes)) {
+    cache_give(c, g, p->gate_bytes);
+    return fail(DSGD_ENOMEM, "out of device memory (plan record)");
+  }
+  p->d_gate_rec = static_cast<unsigned int*>(g);
+  p->d_s_rec = static_cast<float*>(sv);
+  p->gate_words = words;
+  // (blocks from the cache were ordered against the BUILD stream: order them against the launch stream, which clears them)
+  HIP_TRY(hipStreamSynchronize(c->build_stream ? c->build_stream : c->stream));
+  HIP_TRY(hipMemsetAsync(p->d_gate_rec, 0, sizeof(unsigned int) * (size_t)p->n_steps * words, c->stream));
+  HIP_TRY(hipMemsetAsync(p->d_s_rec, 0, sizeof(float) * (size_t)p->n_steps, c->stream));
+  return DSGD_OK;
+}
+
+int dsgd_plan_read_record(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_end, uint32_t* gate_mask, float* s_used,
+                          int32_t* mask_words_out) {
+  DSGD_TRY(check_ctx(c));
+  if (!p) return fail(DSGD_EINVAL, "null plan");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c, true));
+  if (mask_words_out) *mask_words_out = p->gate_words;
+  if (!gate_mask && !s_used) return DSGD_OK;
+  if (!p->d_gate_rec) return fail(DSGD_ESTATE, "the plan keeps no record (dsgd_plan_record)");
+  if (!(p->cs_ok && p->cs_layout == c->layout_gen))
+    return fail(DSGD_EUNSUPPORTED, "only plans that run on column slices keep a record (see dsgd_plan_info)");
+  if (step_begin < 0 || step_end > p->n_steps || step_end < step_begin) return fail(DSGD_EINVAL, "steps outside the plan");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t n = (size_t)(step_end - step_begin);
+  if (gate_mask && n)
+    HIP_TRY(hipMemcpy(gate_mask, p->d_gate_rec + (size_t)step_begin * p->gate_words, sizeof(unsigned int) * n * (size_t)p->gate_words,
+                      hipMemcpyDeviceToHost));
+  if (s_used && n) HIP_TRY(hipMemcpy(s_used, p->d_s_rec + step_begin, sizeof(float) * n, hipMemcpyDeviceToHost));
+  return DSGD_OK;
+}
+
+#ifdef DSGD_TEST_COLLECTIVE_SEAM
+// TEST BUILDS ONLY (tests/rccl_stub/libdsgd_hip_seam.so; the product library has no such symbol): from step `from_step`
+// (1-based, counted inside each launch) on, slice 1 of every column-slice launch withholds its granules; 0 = off.
+extern "C" int dsgd_test_cs_skip_publish(dsgd_ctx* c, int32_t from_step) {
+  DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->cs_test_skip = from_step < 0 ? 0 : from_step;
+  return DSGD_OK;
+}
+#endif
+
+int dsgd_plan_info(dsgd_ctx* c, dsgd_plan* p, int32_t* vals, int32_t n) {
+  DSGD_TRY(check_ctx(c));
+  if (!p || !vals || n < 0 || n > 8) return fail(DSGD_EINVAL, "bad plan_info arguments");
+  std::lock_guard<std::mutex> lk(c->mu);
+  const bool cs = c->cs_enable && !c->comm && p->cs_ok && p->cs_layout == c->layout_gen;
+  const bool one_wg = !cs && plan_kernel_ok(c, p->max_step_rows, p->n_workers) && p->fits && p->fits_rows == c->n_rows;
+  const bool vt = !cs && !one_wg && c->vt_enable && p->vt_ok && p->vt_layout == c->layout_gen;
+  const int32_t all[8] = {cs ? 1 : (one_wg ? 2 : (vt ? 3 : (p->cs_layout == c->layout_gen || p->vt_layout == c->layout_gen ? 4 : 0))),
+                          cs ? p->cs_G : 0, cs ? p->cs_slot_stride : 0, cs ? p->cs_row_stride : 0, cs ? p->cs_cl_stride : 0,
+                          cs ? p->cs_spl : 0, (cs && p->cs_device_built) ? 1 : 0, p->gate_words};
+  for (int i = 0; i < n; ++i) vals[i] = all[i];
   return DSGD_OK;
 }
 
@@ -2570,20 +3096,30 @@ int dsgd_plan_destroy(dsgd_ctx* c, dsgd_plan* p) {
   DSGD_TRY(check_ctx(c));
   if (!p) return DSGD_OK;
   std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c, true));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  (void)hipFree(p->d_idx);
-  (void)hipFree(p->d_segs);
-  (void)hipFree(p->d_vt_lanes);
-  (void)hipFree(p->d_vt_segs);
-  (void)hipFree(p->d_vt_long);
-  (void)hipFree(p->d_vt_packed);
-  (void)hipFree(p->d_cs_hdr);
-  (void)hipFree(p->d_cs_meta);
-  (void)hipFree(p->d_cs_rf);
-  (void)hipFree(p->d_cs_col);
-  (void)hipFree(p->d_cs_val);
-  (void)hipFree(p->d_cs_cl);
+  c->comm_broken_ok = true;   // (a context whose communicator was given up can still let go of its plans)
+  const int brc = bind(c, true);
+  c->comm_broken_ok = false;
+  DSGD_TRY(brc);
+  // the plan's blocks go back to the context's cache behind everything the launch stream still holds (an event per block:
+  // no hipFree, no device synchronisation -- an epoch of the reference is one plan); a set-up that never ran is ordered
+  // in front of that first
+  if (p->built_pending) HIP_TRY(hipStreamWaitEvent(c->stream, p->built_ev, 0));
+  cache_give(c, p->d_idx, p->idx_bytes);
+  cache_give(c, p->d_segs, p->segs_bytes);
+  cs_free(c, p);
+  cache_give(c, p->d_gate_rec, p->gate_bytes);
+  cache_give(c, p->d_s_rec, p->s_bytes);
+  if (p->d_vt_lanes || p->d_vt_segs || p->d_vt_long || p->d_vt_packed) {   // (the larger steps' tiles: allocated per plan)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(p->d_vt_lanes);
+    (void)hipFree(p->d_vt_segs);
+    (void)hipFree(p->d_vt_long);
+    (void)hipFree(p->d_vt_packed);
+  }
+  if (p->built_ev) {
+    // (the event may still be pending on the build stream: destroying a recorded event is allowed, its resources go when it completes)
+    (void)hipEventDestroy(p->built_ev);
+  }
   delete p;
   return DSGD_OK;
 }
@@ -2602,7 +3138,19 @@ int dsgd_plan_run(dsgd_ctx* c, dsgd_plan* p, int64_t step_begin, int64_t step_en
   DSGD_TRY(prepare_layout(c));
   // the reference's own batch sizes: column slices, the whole range of steps in ONE launch (csrc/dsgd_cs.hpp)
   if (c->cs_enable && !c->comm) {
-    if (p->cs_layout != c->layout_gen) DSGD_TRY(cs_build(c, p));
+    if (p->cs_layout != c->layout_gen) {   // (created before the column layout existed, or the layout changed since)
+      DSGD_TRY(cs_build(c, p));
+      if (p->cs_device_built && c->build_stream) {
+        HIP_TRY(hipEventRecord(p->built_ev, c->build_stream));
+        p->built_pending = true;
+      }
+    }
+  }
+  if (p->built_pending) {   // the plan's set-up ran beside the launch stream: wait for it, once
+    HIP_TRY(hipStreamWaitEvent(c->stream, p->built_ev, 0));
+    p->built_pending = false;
+  }
+  if (c->cs_enable && !c->comm) {
     if (p->cs_ok && p->cs_layout == c->layout_gen) {
       if (step_end > step_begin) DSGD_TRY(launch_cs(c, p, step_begin, step_end, lr));
       c->pending_samples += p->offsets[step_end * p->n_workers] - p->offsets[step_begin * p->n_workers];
@@ -3056,7 +3604,10 @@ static int async_join(dsgd_ctx* c) {
 static int async_wait_released(dsgd_ctx* c, std::unique_lock<std::mutex>& lk) {
   if (c->join_in_progress) {
     c->join_cv.wait(lk, [c] { return !c->join_in_progress; });
-    return DSGD_OK;   // (the joining thread reports the engine's errors)
+    // the joining thread's result is every waiter's result (a failed run must not read as a success to the thread that
+    // happened to come second)
+    if (c->join_rc != DSGD_OK) return fail(c->join_rc, "%s", c->join_err.c_str());
+    return DSGD_OK;
   }
   c->join_in_progress = true;
   hipStream_t st = c->async_stream;
@@ -3064,11 +3615,14 @@ static int async_wait_released(dsgd_ctx* c, std::unique_lock<std::mutex>& lk) {
   if (c->exch_thread.joinable()) c->exch_thread.join();   // (it never takes the context's mutex)
   const hipError_t e = hipStreamSynchronize(st);
   lk.lock();
-  c->join_in_progress = false;
+  int rc = DSGD_OK;
+  if (e != hipSuccess) rc = fail(DSGD_EHIP, "hipStreamSynchronize(async stream): %s", hipGetErrorString(e));
+  else if (c->async_running) rc = async_join(c);   // (its own synchronisations return at once now)
+  c->join_rc = rc;
+  c->join_err = rc == DSGD_OK ? "" : g_err;
+  c->join_in_progress = false;   // (cleared LAST: dsgd_destroy and the other waiters go on only when the result is stored)
   c->join_cv.notify_all();
-  if (e != hipSuccess) return fail(DSGD_EHIP, "hipStreamSynchronize(async stream): %s", hipGetErrorString(e));
-  if (!c->async_running) return DSGD_OK;
-  return async_join(c);   // (its own synchronisations return at once now)
+  return rc;
 }
 
 int dsgd_async_stop(dsgd_ctx* c) {  // ref: SlaveImpl.stopAsync, core/Slave.scala:187-195
@@ -3185,6 +3739,7 @@ int dsgd_comm_init(dsgd_ctx* c, const char* unique_id, int32_t world_size, int32
   rccl::unique_id_t id;
   memcpy(id.internal, unique_id, DSGD_UNIQUE_ID_BYTES);
   RCCL_TRY(rccl::CommInitRank(&c->comm, world_size, id, rank));
+  c->comm_broken = false;
   c->world = world_size;
   c->rank = rank;
   return DSGD_OK;
@@ -3193,8 +3748,16 @@ int dsgd_comm_init(dsgd_ctx* c, const char* unique_id, int32_t world_size, int32
 int dsgd_comm_destroy(dsgd_ctx* c) {
   DSGD_TRY(check_ctx(c));
   std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c));
-  if (!c->comm) return DSGD_OK;
+  c->comm_broken_ok = true;
+  const int brc = bind(c);
+  c->comm_broken_ok = false;
+  DSGD_TRY(brc);
+  c->comm_broken = false;   // (an aborted communicator is gone already: the context may attach a new one)
+  if (!c->comm) {
+    c->world = 1;
+    c->rank = 0;
+    return DSGD_OK;
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   RCCL_TRY(rccl::CommDestroy(c->comm));
   c->comm = nullptr;
@@ -3245,13 +3808,36 @@ int group_shape(dsgd_ctx* const* ctxs, int n) {
 template <class Fn>
 int grouped(dsgd_ctx* const* ctxs, int n, Fn fn) {
   if (!ctxs[0]->comm) return DSGD_OK;
+  // all or nothing: whatever can be refused is refused BEFORE the group opens (a context that cannot be bound, a
+  // communicator a failed group left behind) -- a collective that only some ranks joined would hang every stream
+  for (int i = 0; i < n; ++i) {
+    if (ctxs[i]->comm_broken)
+      return fail(DSGD_ERCCL, "context %d: its communicator was abandoned after a collective that not every rank joined "
+                              "(dsgd_comm_destroy + dsgd_comm_init_all)", i);
+    DSGD_TRY(bind(ctxs[i]));
+  }
   RCCL_TRY(rccl::GroupStart());
-  int rc = DSGD_OK;
+  int rc = DSGD_OK, joined = 0;
   for (int i = 0; i < n && rc == DSGD_OK; ++i) {
     rc = bind(ctxs[i]);
     if (rc == DSGD_OK) rc = fn(ctxs[i], i);
+    if (rc == DSGD_OK) ++joined;
   }
+  char first_err[sizeof(g_err)];
+  snprintf(first_err, sizeof(first_err), "%s", g_err);
   const int re = rccl::GroupEnd();   // (always: a group that was started is ended)
+  if (rc != DSGD_OK && joined > 0) {
+    // some ranks' collectives are enqueued and the others' never will be: abort the communicators (their streams come
+    // back with an error instead of hanging) and refuse further collectives on them
+    for (int i = 0; i < n; ++i) {
+      ctxs[i]->comm_broken = true;
+      if (rccl::CommAbort && ctxs[i]->comm) {
+        (void)rccl::CommAbort(ctxs[i]->comm);
+        ctxs[i]->comm = nullptr;
+      }
+    }
+    return fail(rc, "%s (the group's communicators were aborted: only %d of %d ranks had joined)", first_err, joined, n);
+  }
   if (rc == DSGD_OK && re != 0) rc = fail(DSGD_ERCCL, "ncclGroupEnd: %s", rccl::GetErrorString(re));
   return rc;
 }
@@ -3525,6 +4111,10 @@ const char* dsgd_grad_kernel_name(dsgd_ctx* c) {
 
 int dsgd_device_ptrs(dsgd_ctx* c, void** w_dev, void** g_dev, void** stream) {
   DSGD_TRY(check_ctx(c));
+  std::lock_guard<std::mutex> lk(c->mu);
+  // (binding converts slice-major weights back: after a column-slice dsgd_plan_run the live weights are NOT in d_w until
+  //  some entry point binds -- this one does, on the stream it hands out)
+  DSGD_TRY(bind(c));
   if (w_dev) *w_dev = c->d_w;
   if (g_dev) *g_dev = c->d_gsum;
   if (stream) *stream = c->stream;

@@ -25,6 +25,33 @@ class Plan:
             check(_lib.load().dsgd_plan_destroy(self.engine._ctx, self.handle))
             self.handle = None
 
+    def info(self):
+        """How the plan will run: kind ('column_slices', 'one_workgroup', 'virtual_tiles', 'row_parallel', 'not_laid_out')
+        and, for column slices, the layout's shape; see dsgd_plan_info."""
+        v = (C.c_int32 * 8)()
+        check(_lib.load().dsgd_plan_info(self.engine._ctx, self.handle, v, C.c_int32(8)))
+        kinds = {0: "not_laid_out", 1: "column_slices", 2: "one_workgroup", 3: "virtual_tiles", 4: "row_parallel"}
+        return {"kind": kinds.get(int(v[0]), "?"), "slices": int(v[1]), "slot_stride": int(v[2]), "row_stride": int(v[3]),
+                "col_list_stride": int(v[4]), "slots_per_lane": int(v[5]), "device_built": bool(v[6]), "record_words": int(v[7])}
+
+    def record(self, on=True):
+        """Keep the gate decision of every row and the regulariser scalar of every step this plan runs (column slices)."""
+        check(_lib.load().dsgd_plan_record(self.engine._ctx, self.handle, C.c_int32(1 if on else 0)))
+
+    def read_record(self, step_begin=0, step_end=None):
+        """(mask, s): mask bool [steps, words * 32] -- bit r of a step = row r of the step (workers in order, each list in
+        order) was active; s float32 [steps] -- the regulariser scalar the step used."""
+        step_end = self.n_steps if step_end is None else step_end
+        lib = _lib.load()
+        mw = C.c_int32(0)
+        check(lib.dsgd_plan_read_record(self.engine._ctx, self.handle, C.c_int64(step_begin), C.c_int64(step_end), None, None, C.byref(mw)))
+        n, m = step_end - step_begin, mw.value
+        mask = np.zeros((n, max(m, 1)), dtype=np.uint32)
+        s = np.zeros(n, dtype=np.float32)
+        check(lib.dsgd_plan_read_record(self.engine._ctx, self.handle, C.c_int64(step_begin), C.c_int64(step_end), ptr(mask), ptr(s), None))
+        bits = ((mask[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).astype(bool).reshape(n, 32 * max(m, 1))
+        return bits, s
+
 
 class Engine:
     def __init__(self, n_features, lam, device=0, flags=0):
@@ -137,6 +164,17 @@ class Engine:
                 offs.append(offs[-1] + len(a))
         idx = np.concatenate(flat) if flat else np.zeros(0, np.int32)
         offsets = np.asarray(offs, dtype=np.int64)
+        h = C.c_void_p()
+        check(self._lib.dsgd_plan_create(self._ctx, ptr(idx), ptr(offsets), C.c_int64(n_steps), C.c_int32(n_workers), C.byref(h)))
+        return Plan(self, h, n_steps, n_workers, int(offsets[-1]))
+
+    def plan_flat(self, idx, offsets, n_steps, n_workers):
+        """A plan from the flat form: idx = all lists concatenated (step-major, worker-minor), offsets = n_steps * n_workers
+        + 1 prefix offsets (what host.epoch_lists returns: one epoch of Master.fit)."""
+        idx = i32(idx)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if len(offsets) != n_steps * n_workers + 1 or (n_steps and int(offsets[-1]) != len(idx)):
+            raise ValueError("offsets do not describe %d x %d lists over %d entries" % (n_steps, n_workers, len(idx)))
         h = C.c_void_p()
         check(self._lib.dsgd_plan_create(self._ctx, ptr(idx), ptr(offsets), C.c_int64(n_steps), C.c_int32(n_workers), C.byref(h)))
         return Plan(self, h, n_steps, n_workers, int(offsets[-1]))

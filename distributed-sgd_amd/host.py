@@ -16,7 +16,9 @@ the reference.  Citations are relative to /root/reference/src/main/scala/epfl/di
 
 All arithmetic happens behind a *backend* (the HIP `Engine`); this module only orchestrates.  A backend
 offers: sync_step(idx_lists, lr), gradient(idx) -> (g, stats), apply(g_mean, lr), loss_acc(lo, hi),
-get_weights(), set_weights(w), and for the asynchronous mode async_start/async_updates/async_stop.
+get_weights(), set_weights(w), optionally resident plans (plan_flat(idx, offsets, n_steps, n_workers) -> plan with
+.destroy(), plan_run(plan, step_begin, step_end, lr), synchronize()): an epoch of Master.fit then runs as ONE plan; and for
+the asynchronous mode async_start/async_updates/async_stop.
 """
 
 from __future__ import annotations
@@ -264,6 +266,75 @@ def scala_shuffle(xs: Sequence[int], rnd: JavaRandom) -> List[int]:
     return buf
 
 
+# ---- the same stream, natively (csrc/jrand.c -> lib/libdsgd_host.so) -----------------------------------------------
+_HOST_LIB = None
+
+
+def _host_lib():
+    """libdsgd_host.so or None (not built: the pure-Python restatement above is the fallback -- HOST logic, not the
+    compute path; the product's kernels have no fallback)."""
+    global _HOST_LIB
+    if _HOST_LIB is None:
+        import ctypes as C
+
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdsgd_host.so")
+        try:
+            lib = C.CDLL(path)
+            lib.dsgd_jrand_seed.restype = C.c_uint64
+            lib.dsgd_jrand_seed.argtypes = [C.c_int64]
+            lib.dsgd_jrand_shuffle.restype = C.c_int64
+            lib.dsgd_jrand_epoch_lists.restype = C.c_int
+            _HOST_LIB = lib
+        except OSError:
+            _HOST_LIB = False
+    return _HOST_LIB or None
+
+
+def epoch_lists(rnd: JavaRandom, split: Sequence[range], max_samples: int, batch_size: int, native: Optional[bool] = None):
+    """The index lists of ONE epoch of Master.fit (core/Master.scala:179-199), drawn from `rnd` exactly as the reference
+    draws them -- for every batch b in (0 until maxSamples by batchSize), for every worker k in order:
+    Random.shuffle(split_k).slice(b, b + batchSize) (:184: a fresh shuffle of the WHOLE split per worker and batch).
+
+    Returns (idx int32 [total], offsets int64 [n_steps * K + 1], n_steps): the flat form dsgd_plan_create takes.  Steps are
+    emitted up to the first one in which some worker's slice is empty (Vec.sum would throw in that slave, math/Vec.scala:129);
+    `rnd` advances over the steps emitted.  Natively (csrc/jrand.c: the epoch's shuffles in parallel, draw for draw the
+    same stream) when lib/libdsgd_host.so is there; `native=False` forces the pure-Python restatement."""
+    K = len(split)
+    lib = _host_lib() if native in (None, True) else None
+    if native is True and lib is None:
+        raise RuntimeError("libdsgd_host.so is not built")
+    if lib is not None and all(r.step == 1 for r in split):
+        import ctypes as C
+
+        n_steps_max = len(range(0, max_samples, batch_size))
+        sb = np.asarray([r.start for r in split], dtype=np.int64)
+        se = np.asarray([r.stop for r in split], dtype=np.int64)
+        cap = n_steps_max * sum(min(batch_size, len(r)) for r in split)
+        idx = np.empty(max(cap, 1), dtype=np.int32)
+        offsets = np.zeros(n_steps_max * K + 1, dtype=np.int64)
+        state = C.c_uint64(rnd.seed)
+        n_steps, draws = C.c_int64(0), C.c_int64(0)
+        rc = lib.dsgd_jrand_epoch_lists(C.byref(state), sb.ctypes.data_as(C.c_void_p), se.ctypes.data_as(C.c_void_p), C.c_int32(K),
+                                        C.c_int64(max_samples), C.c_int32(batch_size), idx.ctypes.data_as(C.c_void_p),
+                                        offsets.ctypes.data_as(C.c_void_p), C.byref(n_steps), C.byref(draws))
+        if rc != 0:
+            raise RuntimeError("dsgd_jrand_epoch_lists failed (%d)" % rc)
+        rnd.seed = int(state.value)
+        ns = int(n_steps.value)
+        return idx[:int(offsets[ns * K])], offsets[:ns * K + 1], ns
+    flat, offs, n_steps = [], [0], 0
+    for batch in range(0, max_samples, batch_size):
+        if any(batch >= len(r) for r in split):
+            break
+        for r in split:
+            shuffled = scala_shuffle(list(r), rnd)
+            flat.append(np.asarray(shuffled[batch:batch + batch_size], dtype=np.int32))
+            offs.append(offs[-1] + len(flat[-1]))
+        n_steps += 1
+    idx = np.concatenate(flat) if flat else np.zeros(0, dtype=np.int32)
+    return idx, np.asarray(offs, dtype=np.int64), n_steps
+
+
 # ---- distributed aggregate owned by the host (alternative to the in-library RCCL all-reduce) -----------------
 class HostAllReduceBackend:
     """Mean over world_size x hosted workers with the collective owned by the host (`torch.distributed`,
@@ -361,15 +432,28 @@ class MasterSync:
     data layout: rows [0, n_train) are the train set, [n_train, n_rows) the test set (Main.scala:52)."""
 
     def __init__(self, backend, n_train: int, n_rows: int, node_count: int, rnd: Optional[JavaRandom] = None, log=None,
-                 metrics: Optional[Metrics] = None):
+                 metrics: Optional[Metrics] = None, plans: Optional[bool] = None, prefetch: bool = True):
+        """plans: run an epoch's batches as ONE resident plan of the backend (Engine.plan_flat / plan_run: the column-slice
+        kernel runs all of the epoch's steps in one launch, 5 us per 3 x 100 step) instead of one backend.sync_step call per
+        batch (32 us each); None = whenever the backend offers plans.  The random stream, the lists, the order of the
+        steps and the arithmetic are the same either way; what changes is when the host sees a batch: the per-batch log
+        lines and the `master.sync.batch.duration` timer are written after the epoch's launch (one entry per batch, the
+        epoch's time shared evenly).  prefetch: draw the NEXT epoch's lists and lay its plan out while this epoch's steps
+        run (if fit stops after this epoch the stream is put back to where the reference's would be)."""
         self.backend, self.n_train, self.n_rows, self.node_count = backend, n_train, n_rows, node_count
         self.metrics = metrics or Metrics()
         self.rnd = rnd or JavaRandom(0)
         self.log = log or (lambda *a: None)
+        self.plans = hasattr(backend, "plan_flat") if plans is None else bool(plans)
+        self.prefetch = prefetch
         self.losses: List[float] = []
         self.accs: List[float] = []
         self.test_losses: List[float] = []
         self.test_accs: List[float] = []
+        self._pending = None
+        self.batch_loop_s = 0.0      # wall time of the batch loops (shuffles, plan set-up, steps): Master.scala:179-199
+        self.shuffle_s = 0.0         # ... of which drawing the lists (not overlapped by prefetch: see fit)
+        self.steps_run = 0
 
     def local_loss(self, test: bool = False):  # Master.scala:104-106
         lo, hi = (self.n_train, self.n_rows) if test else (0, self.n_train)
@@ -385,7 +469,61 @@ class MasterSync:
         max_samples = max(len(r) for r in split)              # :138
         self.backend.set_weights(np.asarray(initial_weights, dtype=np.float32))
         state = GradState(np.asarray(initial_weights, dtype=np.float32))
-        epoch = 0
+        self._pending = None   # (plans + prefetch) the next epoch's plan, laid out while the current one runs
+        try:
+            return self._fit_loop(state, 0, split, max_samples, max_epochs, batch_size, learning_rate, stopping_criterion)
+        finally:
+            self._drop_pending()
+
+    def _drop_pending(self):
+        p = getattr(self, "_pending", None)
+        if p is not None:
+            # the lists of an epoch that never ran: the stream goes back to where the reference's generator stands
+            self.rnd.seed = p["seed_before"]
+            if p["plan"] is not None:
+                p["plan"].destroy()
+            self._pending = None
+
+    def _draw_plan(self, split, max_samples, batch_size):
+        seed_before = self.rnd.seed
+        t0 = time.perf_counter()
+        idx, offsets, n_steps = epoch_lists(self.rnd, split, max_samples, batch_size)
+        dt = time.perf_counter() - t0
+        plan = self.backend.plan_flat(idx, offsets, n_steps, len(split)) if n_steps else None
+        return {"plan": plan, "n_steps": n_steps, "offsets": offsets, "seed_before": seed_before, "shuffle_s": dt}
+
+    def _epoch_through_a_plan(self, split, max_samples, batch_size, learning_rate, last):
+        """One epoch's batch loop (core/Master.scala:179-199) as one resident plan."""
+        K = len(split)
+        n_expected = len(range(0, max_samples, batch_size))
+        cur = getattr(self, "_pending", None)
+        self._pending = None
+        if cur is None:
+            cur = self._draw_plan(split, max_samples, batch_size)
+            self.shuffle_s += cur["shuffle_s"]       # (not hidden behind a running epoch)
+        t0 = time.perf_counter_ns()
+        if cur["n_steps"]:
+            self.backend.plan_run(cur["plan"], 0, cur["n_steps"], learning_rate)   # enqueued: ALL the epoch's steps, one launch
+        if self.prefetch and not last and cur["n_steps"] == n_expected:
+            self._pending = self._draw_plan(split, max_samples, batch_size)        # ... while they run
+        if cur["plan"] is not None:
+            cur["plan"].destroy()                                                    # (behind the run; no synchronisation)
+        self.backend.synchronize()
+        dt = time.perf_counter_ns() - t0
+        # what the per-batch closure would have logged and recorded (:181-183, Slave.scala:145-150), written now
+        offs = cur["offsets"]
+        for s_ in range(cur["n_steps"]):
+            batch = s_ * batch_size
+            self.log("samples %d - %d / %d" % (batch + 1, min(batch + batch_size, max_samples), max_samples))
+            with self.metrics._lock:
+                self.metrics.histograms.setdefault("master.sync.batch.duration", []).append(dt // max(1, cur["n_steps"]))
+            self.metrics.counter("slave.sync.backward", int(offs[(s_ + 1) * K] - offs[s_ * K]))
+        self.steps_run += cur["n_steps"]
+        if cur["n_steps"] < n_expected:
+            # the reference's next batch hands some slave an empty slice: Vec.sum throws there (math/Vec.scala:129)
+            raise ValueError("Cannot sum an empty list of vectors (batch %d of the epoch: a worker's slice is empty)" % cur["n_steps"])
+
+    def _fit_loop(self, state, epoch, split, max_samples, max_epochs, batch_size, learning_rate, stopping_criterion):
         while True:
             if self.losses:
                 self.log("loss after epoch %d: %s" % (epoch, self.losses[0]))
@@ -398,18 +536,27 @@ class MasterSync:
             if stopping_criterion(self.test_losses):            # :166
                 self.log("Converged to target: stopping computation")
                 return state.finish(self.losses[0] if self.losses else None)
-            for batch in range(0, max_samples, batch_size):    # :179
-                # :184 -- every worker's split is reshuffled for EVERY batch, then sliced
-                lists = []
-                for r in split:
-                    shuffled = scala_shuffle(list(r), self.rnd)
-                    lists.append(np.asarray(shuffled[batch:batch + batch_size], dtype=np.int32))
-                # a slice past the end of a short last split is empty: Vec.sum would throw in the slave
-                with self.metrics.timer("master.sync.batch.duration"):   # :183
-                    st = self.backend.sync_step(lists, learning_rate)    # :186-197
-                if st:
-                    self.metrics.counter("slave.sync.backward", st.get("n_samples", 0))  # Slave.scala:145-150
-            w = self.backend.get_weights()
+            t_loop = time.perf_counter()
+            if self.plans:
+                self._epoch_through_a_plan(split, max_samples, batch_size, learning_rate, last=(epoch + 1 >= max_epochs))
+            else:
+                for batch in range(0, max_samples, batch_size):    # :179
+                    self.log("samples %d - %d / %d" % (batch + 1, min(batch + batch_size, max_samples), max_samples))   # :181
+                    # :184 -- every worker's split is reshuffled for EVERY batch, then sliced
+                    t_sh = time.perf_counter()
+                    lists = []
+                    for r in split:
+                        shuffled = scala_shuffle(list(r), self.rnd)
+                        lists.append(np.asarray(shuffled[batch:batch + batch_size], dtype=np.int32))
+                    self.shuffle_s += time.perf_counter() - t_sh
+                    # a slice past the end of a short last split is empty: Vec.sum would throw in the slave
+                    with self.metrics.timer("master.sync.batch.duration"):   # :183
+                        st = self.backend.sync_step(lists, learning_rate)    # :186-197
+                    self.steps_run += 1
+                    if st:
+                        self.metrics.counter("slave.sync.backward", st.get("n_samples", 0))  # Slave.scala:145-150
+            w = self.backend.get_weights()   # (synchronises: the epoch's steps are done)
+            self.batch_loop_s += time.perf_counter() - t_loop
             state = state.replace_grad(w)
             # :206-209 -- four full passes per epoch; newest first
             l, a, _ = self.backend.loss_acc(0, self.n_train)

@@ -114,7 +114,9 @@ int dsgd_apply(dsgd_ctx* ctx, const float* g_mean /* D+1 */, float lr);
  * context: per-worker regularised sums, MEAN over workers, w <- w - lr * mean.  Index lists are
  * what `split.map(Random.shuffle(_)).slice(batch, batch + batchSize)` produced on the host.
  * If a communicator is attached (dsgd_comm_init) the mean runs over n_workers * world_size
- * workers with one RCCL all-reduce of the summed gradient.                    */
+ * workers with one RCCL all-reduce of the summed gradient.
+ * Steps of the reference's own sizes (<= 8 hosted workers, <= 1,024 rows in total, no communicator) run as ONE launch of
+ * the column-slice kernel, which lays the request's lists out itself (csrc/dsgd_cs.hpp: dsgd_cs_request_kernel).         */
 int dsgd_sync_step(dsgd_ctx* ctx, const int32_t* const* idx_per_worker, const int64_t* n_per_worker,
                    int32_t n_workers, float lr, dsgd_batch_stats* stats /* may be NULL */);
 
@@ -130,16 +132,38 @@ int dsgd_sync_step_ranges(dsgd_ctx* ctx, const int64_t* row_begin, const int64_t
  * no host->device traffic happens between steps (timed loops, hipGraph replay).                 */
 typedef struct dsgd_plan dsgd_plan;
 /* idx: concatenation of all lists; offsets: n_steps * n_workers + 1 prefix offsets into idx.
- * A plan is RESIDENT: at its first run its lists are laid out for the device, once.  Steps of the reference's own size
+ * A plan is RESIDENT and laid out for the device WHEN IT IS CREATED (data and dimSparsity present; otherwise at its first
+ * run), by the device itself, on a stream of its own beside the launch stream: dsgd_plan_create returns once the lists are
+ * staged and one 16-byte read-back has fixed the layout's strides; the rest of the set-up overlaps whatever the launch
+ * stream is running (the next epoch's plan can be created while this epoch's steps run).  Steps of the reference's own size
  * (<= 8 hosted workers, <= 1,024 rows per step: application.conf:15,27) become COLUMN SLICES -- dsgd_plan_run then runs
  * ALL steps of [step_begin, step_end) in ONE persistent launch (5 us per 3 x 100 step, 9 us per 4 x 200; a launch of a
  * single step 11 us: hand over as many steps per call as are known); larger steps are laid out over the device's streams
  * (16 bytes per 8 non-zeros) and, up to DSGD_VT_PACK_MB (default 2048), copied in that order: two launches per step
- * (18 us at 4,096 rows).  The same lists through dsgd_sync_step cost 32 us per call.                                  */
+ * (18 us at 4,096 rows).  One epoch of Master.fit (core/Master.scala:179-199) = one plan: the device blocks of a destroyed
+ * plan are kept by the context for the next one (DSGD_CACHE_MB, default 8192), dsgd_plan_destroy does not synchronise.
+ * The same lists through dsgd_sync_step (per request) run through the same column-slice kernel, one launch per call.   */
 int dsgd_plan_create(dsgd_ctx* ctx, const int32_t* idx, const int64_t* offsets, int64_t n_steps, int32_t n_workers,
                      dsgd_plan** out);
 int dsgd_plan_destroy(dsgd_ctx* ctx, dsgd_plan* plan);
 int dsgd_plan_run(dsgd_ctx* ctx, dsgd_plan* plan, int64_t step_begin, int64_t step_end, float lr);
+/* How a plan will run (nothing in the reference; benchmarks, tests): vals[0] = 1 column slices (dsgd_cs_step_kernel),
+ * 2 the one-workgroup kernel, 3 virtual tiles, 4 the row-parallel kernels, 0 not laid out yet; [1] slices, [2..4] slot /
+ * row / column-list strides, [5] slots per lane, [6] 1 if the device laid it out, [7] words per step of the record.
+ * n <= 8 slots.                                                                                                       */
+int dsgd_plan_info(dsgd_ctx* ctx, dsgd_plan* plan, int32_t* vals, int32_t n);
+/* Parity aid for LONG synchronous runs (nothing in the reference; tests/test_gpu_trajectory.py, bench.py): with the record
+ * on, every step a column-slice plan runs leaves the GATE DECISION of each of its rows (bit r of the step's words: row r
+ * of the step -- workers in order, each worker's list in order -- had y (x . w) >= 0, core/ml/SparseSVM.scala:27-28) and
+ * the regulariser scalar s = 2 lambda (w . ds) it used (SparseSVM.scala:31).  fp32 against fp64 decides a row on the gate
+ * differently once in a few thousand steps and a constant-step run then goes its own way; with the engine's decisions on
+ * record the oracle REPLAYS the trajectory exactly (oracle/sync_replay.py): the final weights must agree to rounding, and
+ * every decision that differs from the oracle's own must be a row whose margin lies inside the fp32 bound.
+ * dsgd_plan_record(on = 0) drops the record.  dsgd_plan_read_record copies the words of steps [step_begin, step_end)
+ * (*mask_words_out words each; gate_mask / s_used may be NULL to query the width).                                    */
+int dsgd_plan_record(dsgd_ctx* ctx, dsgd_plan* plan, int32_t on);
+int dsgd_plan_read_record(dsgd_ctx* ctx, dsgd_plan* plan, int64_t step_begin, int64_t step_end, uint32_t* gate_mask,
+                          float* s_used, int32_t* mask_words_out);
 int dsgd_sync_step_ranges_async(dsgd_ctx* ctx, const int64_t* row_begin, const int64_t* row_end, int32_t n_workers,
                                 float lr);
 int dsgd_synchronize(dsgd_ctx* ctx, dsgd_batch_stats* stats_accum /* may be NULL */);
@@ -279,7 +303,10 @@ int dsgd_debug_cycles(dsgd_ctx* ctx, uint64_t* out16, int32_t reset);
 
 /* name of the gradient kernel variant in use (for matching rocprofv3 kernel-trace rows)        */
 const char* dsgd_grad_kernel_name(dsgd_ctx* ctx);
-/* raw device pointers (float[D+1]) for hosts that own the collective (e.g. torch.distributed)  */
+/* raw device pointers (float[D+1], the library's internal column order: dsgd_column_ranks) for hosts that own the
+ * collective (e.g. torch.distributed).  The call brings the resident weights into that vector (a column-slice run keeps
+ * them slice-major elsewhere until some entry point needs them): *w_dev is current for work enqueued on *stream until the
+ * next dsgd_plan_run / dsgd_sync_step; ask again after those.                                                          */
 int dsgd_device_ptrs(dsgd_ctx* ctx, void** w_dev, void** g_dev, void** stream);
 
 /* ---- K8: dense logistic mini-batch step (BASELINE.json configs[4]) ------------------------------------------

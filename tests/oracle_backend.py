@@ -53,6 +53,27 @@ class OracleBackend:
         self.actives.append(self.o.last_stats["n_active"])
         return {"n_samples": sum(len(a) for a in lists), "n_active": self.o.last_stats["n_active"]}
 
+    # resident plans (the surface of dsgd_amd.Engine that host.MasterSync.fit uses): here simply the steps in order
+    class _Plan:
+        def __init__(self, idx, offsets, n_steps, k):
+            self.idx, self.offsets, self.n_steps, self.k, self.destroyed = np.asarray(idx), np.asarray(offsets), n_steps, k, False
+
+        def destroy(self):
+            self.destroyed = True
+
+    def plan_flat(self, idx, offsets, n_steps, n_workers):
+        self.plans_made = getattr(self, "plans_made", 0) + 1
+        return OracleBackend._Plan(idx, offsets, n_steps, n_workers)
+
+    def plan_run(self, plan, step_begin, step_end, lr):
+        assert not plan.destroyed
+        for s in range(step_begin, step_end):
+            o = plan.offsets[s * plan.k:(s + 1) * plan.k + 1]
+            self.sync_step([plan.idx[o[j]:o[j + 1]].astype(np.int32) for j in range(plan.k)], lr)
+
+    def synchronize(self):
+        return {"n_samples": 0, "n_active": 0}
+
     def loss_acc(self, lo, hi):
         loss, acc, counts, _ = self.o.loss_acc(self.w, lo, hi)
         return loss, acc, counts

@@ -215,3 +215,95 @@ def test_async_exchange_with_one_rank_changes_nothing():
         ex.run_round(lists, 0.5)
     np.testing.assert_array_equal(local.w, plain.w)   # bit for bit: the peers' part is exactly zero
     assert ex.rounds == 3
+
+
+# ---- the reference's random stream, natively (csrc/jrand.c) ---------------------------------------------------------
+def test_native_epoch_lists_are_the_reference_stream_draw_for_draw():
+    """host.epoch_lists: Master.scala:184's per-batch reshuffle of every split for one epoch.  The native form (the
+    epoch's shuffles drawn in parallel from jump-ahead states, rejections resolved exactly) against the pure-Python
+    restatement of java.util.Random / scala.util.Random.shuffle, lists and generator state alike; uneven splits, a batch
+    size that does not divide them, one worker, batch 1."""
+    assert host._host_lib() is not None, "libdsgd_host.so not built (__graft_entry__.build())"
+    for n, k, b, seed in ((1000, 3, 100, 0), (18519, 3, 100, 0), (997, 4, 64, 7), (130, 1, 1, 3), (5000, 8, 37, 11), (12, 5, 5, 1)):
+        split = host.split_vanilla(n, k)
+        mx = max(len(r) for r in split)
+        ra, rb = host.JavaRandom(seed), host.JavaRandom(seed)
+        ia, oa, na = host.epoch_lists(ra, split, mx, b, native=True)
+        ib, ob, nb = host.epoch_lists(rb, split, mx, b, native=False)
+        assert na == nb and np.array_equal(oa, ob) and np.array_equal(ia, ib), (n, k, b)
+        assert ra.seed == rb.seed                       # the generator stands where the JVM's would
+        assert ra.next_int(1000) == rb.next_int(1000)
+        if n == 18519:                                  # the reference's own shape: 62 steps of 3 x 100, every row id in its split
+            assert na == 62 and len(ia) == 62 * 300 - (62 * 100 - 6173) * 3
+            first = ia[:100]
+            assert first.min() >= 0 and first.max() < 6173 and len(set(first.tolist())) == 100
+    # a short last split: the epoch stops where the reference's slave would be handed an empty slice
+    split = host.split_vanilla(9, 4)                    # three groups of 3 (SplitStrategy.scala:14)
+    ia, oa, na = host.epoch_lists(host.JavaRandom(0), split, 3, 2, native=True)
+    ib, ob, nb = host.epoch_lists(host.JavaRandom(0), split, 3, 2, native=False)
+    assert na == nb == 2 and np.array_equal(ia, ib) and np.array_equal(oa, ob)
+
+
+def test_native_stream_with_rejections():
+    """nextInt(bound) rejects a raw value with probability ~bound / 2^31: visible only for large splits.  One shuffle of
+    600,000 elements consumes ~80 more raw values than it has draws; the parallel epoch form must land on the same lists
+    and the same generator state as shuffles drawn one after the other."""
+    import ctypes as C
+
+    lib = host._host_lib()
+    n = 600000
+    # sequential native shuffle against the pure-Python one (which follows java.util.Random's loop literally)
+    st = C.c_uint64(host.JavaRandom(5).seed)
+    buf = np.arange(n, dtype=np.int32)
+    used = lib.dsgd_jrand_shuffle(C.byref(st), buf.ctypes.data_as(C.c_void_p), C.c_int64(n))
+    rp = host.JavaRandom(5)
+    ref = host.scala_shuffle(range(n), rp)
+    assert np.array_equal(buf, np.asarray(ref, dtype=np.int32)) and st.value == rp.seed
+    assert used > n - 1                                 # rejections happened: the stream is longer than the draws
+    # the parallel epoch against shuffles drawn one after the other
+    split = host.split_vanilla(2 * n, 2)
+    r1 = host.JavaRandom(9)
+    idx, offs, ns = host.epoch_lists(r1, split, n, 250000, native=True)   # 3 steps x 2 workers = 6 shuffles of 600,000
+    st = C.c_uint64(host.JavaRandom(9).seed)
+    want = []
+    for step in range(3):
+        for r in split:
+            buf = np.arange(r.start, r.stop, dtype=np.int32)
+            lib.dsgd_jrand_shuffle(C.byref(st), buf.ctypes.data_as(C.c_void_p), C.c_int64(len(buf)))
+            want.append(buf[step * 250000:(step + 1) * 250000].copy())
+    assert ns == 3 and np.array_equal(idx, np.concatenate(want)) and r1.seed == st.value
+
+
+def test_fit_through_plans_is_fit_step_by_step():
+    """MasterSync.fit with an epoch as ONE plan (the path that reaches the 5 us kernel) against the per-batch form: the
+    same lists from the same stream, the same weights bit for bit, the same curves, counters and number of timer entries;
+    the prefetched plan of an epoch that never runs is dropped and the stream put back."""
+    data, n_train, o = small_problem()
+    crit = host.EarlyStopping.no_improvement(5, 0.01)
+    be_a, be_b = OracleBackend(o), OracleBackend(o)
+    logs_a, logs_b = [], []
+    ma = host.MasterSync(be_a, n_train, data.n_rows, 3, rnd=host.JavaRandom(0), plans=False, log=logs_a.append)
+    mb = host.MasterSync(be_b, n_train, data.n_rows, 3, rnd=host.JavaRandom(0), plans=True, log=logs_b.append)
+    sa = ma.fit(np.zeros(data.dim + 1), 3, 100, 0.5, crit)
+    sb = mb.fit(np.zeros(data.dim + 1), 3, 100, 0.5, crit)
+    np.testing.assert_array_equal(sa.grad, sb.grad)
+    assert be_a.steps == be_b.steps and ma.test_losses == mb.test_losses and ma.accs == mb.accs
+    assert ma.rnd.seed == mb.rnd.seed and be_b.plans_made == 3 and mb.steps_run == ma.steps_run == 24
+    ca, cb = ma.metrics.snapshot(), mb.metrics.snapshot()
+    assert ca["counters"] == cb["counters"] and len(ca["histograms"]["master.sync.batch.duration"]) == len(cb["histograms"]["master.sync.batch.duration"]) == 24
+    assert logs_a == logs_b
+    # stopped by the criterion after the first epoch: the prefetched second epoch is dropped, the stream stands where the
+    # per-batch form leaves it
+    be_c, be_d = OracleBackend(o), OracleBackend(o)
+    mc = host.MasterSync(be_c, n_train, data.n_rows, 3, rnd=host.JavaRandom(3), plans=False)
+    md = host.MasterSync(be_d, n_train, data.n_rows, 3, rnd=host.JavaRandom(3), plans=True, prefetch=True)
+    mc.fit(np.zeros(data.dim + 1), 10, 100, 0.5, lambda losses: len(losses) >= 1)
+    md.fit(np.zeros(data.dim + 1), 10, 100, 0.5, lambda losses: len(losses) >= 1)
+    assert mc.rnd.seed == md.rnd.seed and be_c.steps == be_d.steps and be_d.plans_made == 2
+    np.testing.assert_array_equal(be_c.w, be_d.w)
+    # a short last split: the reference's slave throws on the empty slice -- after the batches before it ran
+    be_e = OracleBackend(o)
+    me = host.MasterSync(be_e, 10, 12, 4, rnd=host.JavaRandom(0), plans=True)   # splits of 3, 3, 3, 1 rows (SplitStrategy.scala:14)
+    with pytest.raises(ValueError, match="empty list"):
+        me.fit(np.zeros(data.dim + 1), 1, 2, 0.5, crit)
+    assert be_e.steps == [[2, 2, 2, 1]]
