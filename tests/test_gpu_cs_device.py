@@ -278,7 +278,7 @@ def test_plans_come_and_go_without_synchronising(mid):
     st = eng.synchronize()
     assert st["n_samples"] == 6 * 30 * 300
     err = np.abs(eng.get_weights().astype(np.float64) - w_ref).max()
-    waivers.tight("cs_device:plan_cycles", err <= 1e-5 * max(1.0, np.abs(w_ref).max()), exposed > 0,
+    waivers.tight("column_slices:epoch", err <= 1e-5 * max(1.0, np.abs(w_ref).max()), exposed > 0,
                   "%d steps with a row within 1e-5 of the gate, err %.3g" % (exposed, err))
 
 

