@@ -522,6 +522,7 @@ def main():
         out["cpu_baseline"]["epochs_to_target"] = epochs_to_target(dsgd_amd, device)
         e = out["cpu_baseline"]["epochs_to_target"]
         out["epochs_to_target"] = {kk: e[kk] for kk in ("config", "target_test_loss", "engine_epochs", "oracle_epochs", "max_epochs")}
+        out["fit"] = e.pop("fit")
 
     if world > 1:
         dist.barrier()
@@ -811,19 +812,17 @@ def hogwild(eng, n_train, bytes_per_row, workers=256, batch=100, updates=60000):
                     "end-of-run evaluation of a constant-step lock-free run fluctuates by several points (see traced_replay)"}
 
 
-def hogwild_parity(dsgd_amd, device, workers=256, batch=100, rows=100000, checkpoints=(2048, 4096, 6144, 8192), n_seeds=2):
-    """Parity evidence for the BENCHMARKED Hogwild shape (256 workers x batch 100) on a shard small enough for the oracle.
-    PRIMARY: `traced_replay` -- the engine records every update's {worker, iteration, update count its weights were read
-    at, regulariser scalar, gate decision of every sampled row} in commit order; with the engine's own decisions the oracle
-    recomputes every update of core/Slave.scala:92-101 EXACTLY (oracle/hogwild_replay.py: a constant-step lock-free run
-    is chaotic, nothing that re-decides the gates can follow it) and three statements are asserted: the final weights
-    are the replayed ones to rounding (every update applied once, averaged, scaled, regularised as the reference does),
-    the recorded decisions fit the replayed weights at the read end of [read_at, commit) better than at the commit end,
-    the recorded scalar is 2 lambda (w . ds) of the weights at read_at; two deliberately broken replays (every update applied twice;
-    ONE update lost) must break the first -- the check can fail.  SECONDARY: `oracle_band` -- round 3's band between
-    the orderings the oracle can invent, kept as a sanity check only: it spans chance to near-perfect."""
-    from oracle import hogwild_band as hb  # checker only
-    from oracle import hogwild_replay as hr
+def hogwild_parity(dsgd_amd, device, workers=256, batch=100, rows=100000, updates=2048):
+    """Parity evidence for the BENCHMARKED Hogwild shape (256 workers x batch 100) on a shard small enough for the oracle:
+    the engine records every update's {worker, iteration, update count its weights were read at, regulariser scalar, gate
+    decision of every sampled row} in commit order; with the ENGINE'S OWN decisions the oracle recomputes every update of
+    core/Slave.scala:92-101 exactly (oracle/hogwild_replay.py -- a constant-step lock-free run is chaotic, nothing that
+    re-decides the gates can follow it).  What this pins is the ACCOUNTING: every update applied once, averaged, scaled,
+    regularised as the reference does (`accounting_agrees`), and that the check can fail (one lost update, every update
+    applied twice: both rejected).  The gates themselves are engine-recorded, not re-derived (`gates_are`); the gate
+    checks with teeth -- a single worker replayed exactly, four workers held to the near-gate rows -- and the oracle's band
+    of orderings run under `pytest -m gpu` (tests/test_gpu_hogwild_trace.py, tests/test_gpu_parity.py), not in every bench."""
+    from oracle import hogwild_replay as hr  # checker only
     from oracle import oracle as orc
 
     data = dsgd_amd.synth.generate(rows, seed=13)
@@ -831,65 +830,33 @@ def hogwild_parity(dsgd_amd, device, workers=256, batch=100, rows=100000, checkp
     o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, LAMBDA)
     o.set_dim_sparsity(o.dim_sparsity(n_train))
     split = split_vanilla(n_train, workers)
-    ev = (n_train, data.n_rows)
     t0 = time.perf_counter()
-    band = hb.band(o, split, batch, list(checkpoints), LR0, ev, n_seeds=n_seeds)
-    t_oracle = time.perf_counter() - t0
-    runs, traced = [], None
     with dsgd_amd.Engine(data.dim, LAMBDA, device=device) as eng:
         eng.load_csr(data.row_ptr, data.col, data.val, data.label)
         eng.build_dim_sparsity(n_train)
-        for si, seed in enumerate((5, 6, 7)):
-            eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
-            eng.async_set_trace(max(np.diff([0] + list(checkpoints))) + workers if si == 0 else 0)
-            curve, prev, total, segs, w_rep, stats, verdicts = [], 0, 0, [], np.zeros(data.dim + 1), [], []
-            t_rep = 0.0
-            for c, target in enumerate(checkpoints):
-                sseed = seed + 7919 * c
-                eng.async_start(split, batch=batch, lr=LR0, max_updates=target - prev, seed=sseed, positional_bug=False)
-                eng.async_wait()
-                total += eng.async_updates()[0]
-                prev = target
-                loss, acc, _ = eng.loss_acc(*ev)
-                curve.append((total, loss, acc))
-                if si == 0:
-                    t1 = time.perf_counter()
-                    trace = eng.async_read_trace()
-                    stats.append(hr.replay_forced(o, w_rep, split, batch, LR0, sseed, trace, fractions=(0.0, 0.5, 1.0)))
-                    v = hr.verdict(o, eng.get_weights(), w_rep, hr.merge(stats))
-                    v.update(loss_engine=loss, acc_engine=acc)
-                    verdicts.append(v)
-                    segs.append((sseed, trace))
-                    t_rep += time.perf_counter() - t1
-            w_end = eng.get_weights().astype(np.float64)
-            summ = hb.summarise(curve, w_end)
-            summ.update(inside=hb.inside(band, summ), updates=total, end_acc=curve[-1][2], end_loss=curve[-1][1])
-            runs.append(summ)
-            if si == 0:
-                t1 = time.perf_counter()
-                controls = {}
-                for fault in ("double_apply", "drop_one"):
-                    w_bad = np.zeros(data.dim + 1)
-                    with np.errstate(all="ignore"):
-                        for sseed, trace in segs:
-                            hr.replay_forced(o, w_bad, split, batch, LR0, sseed, trace, fault=fault, check=False)
-                        err = float(np.abs(w_end - w_bad).max())
-                    controls[fault] = {"account_max_abs_err": err,
-                                       "rejected": not err <= hr.ACCOUNT_TOL * max(1.0, float(np.abs(w_bad).max()))}
-                traced = {"rows": rows, "workers": workers, "batch": batch, "checkpoints": verdicts,
-                          "agrees": all(all(v["ok"].values()) for v in verdicts), "negative_controls": controls,
-                          "controls_rejected": all(v["rejected"] for v in controls.values()),
-                          "replay_seconds": round(t_rep, 1), "controls_seconds": round(time.perf_counter() - t1, 1)}
-    ok = all(all(r["inside"].values()) for r in runs)
-    band_out = {"rows": rows, "workers": workers, "batch": batch, "checkpoints": list(checkpoints), "oracle_seconds": round(t_oracle, 1),
-                "band": {q: {kk: band[q][kk] for kk in ("lo", "hi", "oracle_min", "oracle_max", "by_mode")} for q in ("loss", "acc", "wnorm")},
-                "margin": band["margin"], "oracle_end_of_run_acc_spread": band["end_of_run_acc_spread"],
-                "engine_runs": runs, "inside": ok, "role": "secondary sanity check (the band spans chance to near-perfect)"}
-    if not traced["agrees"] or not traced["controls_rejected"]:
+        eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+        eng.async_set_trace(updates + workers)
+        eng.async_start(split, batch=batch, lr=LR0, max_updates=updates, seed=5, positional_bug=False)
+        eng.async_wait()
+        trace = eng.async_read_trace()
+        w_end = eng.get_weights().astype(np.float64)
+    w_rep = np.zeros(data.dim + 1)
+    stats = hr.replay_forced(o, w_rep, split, batch, LR0, 5, trace, fractions=(0.0, 0.5, 1.0))
+    v = hr.verdict(o, w_end, w_rep, hr.merge([stats]))
+    controls = {}
+    for fault in ("double_apply", "drop_one"):
+        w_bad = np.zeros(data.dim + 1)
+        with np.errstate(all="ignore"):
+            hr.replay_forced(o, w_bad, split, batch, LR0, 5, trace, fault=fault, check=False)
+            err = float(np.abs(w_end - w_bad).max())
+        controls[fault] = {"account_max_abs_err": err, "rejected": not err <= hr.ACCOUNT_TOL * max(1.0, float(np.abs(w_bad).max()))}
+    traced = {"rows": rows, "workers": workers, "batch": batch, "updates": int(v.get("updates", updates)), "checkpoint": v,
+              "accounting_agrees": bool(all(v["ok"].values())), "gates_are": "engine-recorded (forced in the replay), not re-derived",
+              "negative_controls": controls, "controls_rejected": all(c["rejected"] for c in controls.values()),
+              "seconds": round(time.perf_counter() - t0, 1)}
+    if not traced["accounting_agrees"] or not traced["controls_rejected"]:
         raise SystemExit("Hogwild traced parity failed: %r" % traced)
-    if not ok:
-        raise SystemExit("Hogwild parity failed: an engine run left the oracle's band: %r" % band_out)
-    return {"traced_replay": traced, "oracle_band": band_out}
+    return {"traced_replay": traced}
 
 
 def reference_shape(dsgd_amd, device, n_rows, with_parity=True, repeats=5, steps=20):
@@ -931,114 +898,158 @@ def reference_shape(dsgd_amd, device, n_rows, with_parity=True, repeats=5, steps
     return res
 
 
-def epoch_lists(rng, n_train, k, b):
-    """The index lists of one epoch for k workers x batch b: every worker's split shuffled once, cut into consecutive
-    batches (steps in which some worker's slice is empty are dropped: Vec.sum requires a non-empty list).  The reference
-    reshuffles per BATCH (core/Master.scala:184); one shuffle per epoch visits every row exactly once per epoch and keeps the
-    host out of the way -- both sides of every comparison below get the same lists."""
-    split = split_vanilla(n_train, k)
-    perms = [lo + rng.permutation(hi - lo) for lo, hi in split]
-    n_steps = -(-max(hi - lo for lo, hi in split) // b)
-    steps = []
-    for s in range(n_steps):
-        ls = [p[s * b:(s + 1) * b].astype(np.int32) for p in perms]
-        if all(len(x) for x in ls):
-            steps.append(ls)
-    return steps
+class RecordingBackend:
+    """The engine behind host.MasterSync.fit, keeping the record of the FIRST `epochs` plans it runs (dsgd_plan_record: every
+    row's gate decision, every step's regulariser scalar) and the weights each of those epochs ended on -- what
+    oracle/sync_replay.py replays.  Everything else passes through."""
+
+    def __init__(self, eng, epochs=1):
+        self.eng, self.want, self.recs, self.kernels = eng, epochs, [], set()
+
+    def plan_flat(self, idx, offsets, n_steps, k):
+        plan = self.eng.plan_flat(idx, offsets, n_steps, k)
+        if len(self.recs) < self.want and n_steps:
+            plan.record(True)
+            rec = {"plan": plan, "k": k, "idx": np.array(idx, copy=True), "offsets": np.array(offsets, copy=True), "n_steps": n_steps}
+            self.recs.append(rec)
+            real = plan.destroy
+
+            def destroy():   # (fit destroys a plan right behind its run: the record is read first)
+                if "masks" not in rec and rec.get("ran"):
+                    rec["masks"], rec["s"] = plan.read_record()
+                    rec["w_end"] = self.eng.get_weights()
+                rec["plan"] = None
+                real()
+
+            plan.destroy = destroy
+        return plan
+
+    def plan_run(self, plan, a, b, lr):
+        self.eng.plan_run(plan, a, b, lr)
+        self.kernels.add(self.eng.grad_kernel_name())
+        for rec in self.recs:
+            if rec.get("plan") is plan:
+                rec["ran"] = True
+
+    def steps_of(self, rec):
+        o, k = rec["offsets"], rec["k"]
+        return [[rec["idx"][o[s * k + j]:o[s * k + j + 1]] for j in range(k)] for s in range(rec["n_steps"])]
+
+    def __getattr__(self, name):
+        return getattr(self.eng, name)
+
+
+def forced_replay(o, backend, w0, lr):
+    """oracle/sync_replay.py over what a RecordingBackend kept: (a) the engine's weights are the replayed ones to rounding,
+    (b) every decision that differs from the oracle's own gate on the replayed weights is a row inside fp32 resolution,
+    (c) the first step at which the two sides decide differently.  Raises SystemExit when (a) or (b) fails."""
+    from oracle import sync_replay as sr  # checker only
+
+    recs = [r for r in backend.recs if "masks" in r]
+    if not recs:
+        return None
+    t0 = time.perf_counter()
+    w = np.asarray(w0, dtype=np.float64).copy()
+    steps = [st for r in recs for st in backend.steps_of(r)]
+    stats = sr.replay(o, w, steps, lr, np.concatenate([r["masks"] for r in recs]), np.concatenate([r["s"] for r in recs]))
+    v = sr.verdict(stats, recs[-1]["w_end"], w)
+    out = {kk: v[kk] for kk in ("accounting_agrees", "account_err_over_tol", "account_max_abs_err", "decisions", "differing_decisions",
+                                "first_divergent_step", "divergent_rows_all_near_gate", "worst_margin_over_resolution", "s_agrees")}
+    out.update(steps=len(steps), replay_s=round(time.perf_counter() - t0, 1))
+    if not (v["accounting_agrees"] and v["divergent_rows_all_near_gate"] and v["s_agrees"]):
+        raise SystemExit("forced replay of the synchronous trajectory failed: %r (outside: %r)" % (out, v["outside"]))
+    return out
+
+
+def fit_through_the_mirror(dsgd_amd, host, eng_backend, o, n_train, n_rows, k, b, lr, max_epochs, criterion, seed=0):
+    """host.MasterSync.fit -- the mirror of core/Master.scala:120-218 that the dev role and a patched reference's resident
+    master run: every epoch's batches as ONE resident plan, the reference's random stream (java.util.Random seeded 0,
+    Main.scala:32; every split reshuffled for every batch, Master.scala:184) drawn natively, the next epoch's lists and plan
+    prepared while this epoch runs, the two evaluation passes per epoch (:206-209).  Returns (mirror, wall seconds)."""
+    m = host.MasterSync(eng_backend, n_train, n_rows, k, rnd=host.JavaRandom(seed))
+    t0 = time.perf_counter()
+    m.fit(np.zeros(o.dim + 1), max_epochs, b, lr, criterion)
+    return m, time.perf_counter() - t0
 
 
 def time_to_target(dsgd_amd, device, n_rows=804414, oracle_budget_s=5.0, max_epochs_engine=30):
-    """Wall-clock time to the oracle's target test loss per batch size, on the reference's full=true shape.  Target = the
-    MEDIAN over 10 epochs (max-epochs, application.conf:37) of the ORACLE's test loss at the reference's configuration
-    (3 workers x batch 100, lr 0.5) -- the curve of a constant-step run is noisy (0.18 after its first epoch, 0.35 after
-    its second, 0.20-0.25 afterwards on this data), so neither its minimum nor its last value is a level another
-    trajectory can be asked to reach.  Per configuration the engine runs whole epochs from resident plans until its test
-    loss is at or below the target; an epoch's clock holds its steps AND the evaluation passes the reference makes per
-    epoch (core/Master.scala:206-209: loss and accuracy on the train and the test set -- one pass over each set yields
-    both).  Building an epoch's plan (the host's shuffle and layout) is outside the clock and reported.  The oracle runs
-    the same lists (at most 10 epochs, at most `oracle_budget_s` per configuration); after the first epoch the two weight
-    vectors are compared (`epoch1_max_abs_diff`: thousands of steps without a re-synchronisation -- one row gated
-    differently, and fp32 against fp64 will do that once in a few thousand steps, sends a constant-step run elsewhere)."""
+    """Wall-clock time to the oracle's target test loss per batch size, on the reference's full=true shape, THROUGH
+    host.MasterSync.fit (fit_through_the_mirror).  Target = the MEDIAN over 10 epochs (max-epochs, application.conf:37) of
+    the ORACLE's test loss at the reference's configuration (3 workers x batch 100, lr 0.5) -- the curve of a constant-step
+    run is noisy, so neither its minimum nor its last value is a level another trajectory can be asked to reach.  A
+    configuration's clock is the whole fit: drawing the lists (the reference's per-batch reshuffle is O(rows) master work
+    per BATCH: 1.4 G draws per epoch here -- `shuffle_s` says what of it was not hidden behind the device), laying the
+    plans out, the steps, the evaluation passes.  The oracle runs the same mirror with the same stream (at most
+    `oracle_budget_s` past its first epoch).  The reference's own configuration (configs[0]) also carries the FORCED REPLAY of
+    its first epoch: the engine's recorded gate decisions replayed by the oracle -- `first_divergent_step`,
+    `divergent_rows_all_near_gate`, the accounting error -- next to the free-running difference after that epoch."""
+    from dsgd_amd import host
     from oracle import oracle as orc  # checker / target only
+    from oracle.backend import OracleBackend
 
     data = dsgd_amd.synth.generate(n_rows, seed=0)
     n_train = int(n_rows * 0.8)
     o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, LAMBDA)
     o.set_dim_sparsity(o.dim_sparsity(n_train))
     t0 = time.perf_counter()
-    w = np.zeros(data.dim + 1)
-    ref_curve = []
-    for ep in range(10):
-        for step in epoch_lists(np.random.default_rng(1000 + ep), n_train, 3, 100):
-            o.sync_step(w, step, LR0)
-        ref_curve.append(o.loss_acc(w, n_train, n_rows)[0])
+    mo, _ = fit_through_the_mirror(dsgd_amd, host, OracleBackend(o), o, n_train, n_rows, 3, 100, LR0, 10, lambda losses: False)
+    ref_curve = list(reversed(mo.test_losses))
     target = float(np.median(ref_curve))
-    out = {"rows": n_rows, "train_rows": n_train, "target_test_loss": target,
+    out = {"rows": n_rows, "train_rows": n_train, "target_test_loss": target, "through": "host.MasterSync.fit (plans, native random stream, prefetch)",
            "target": "median over 10 oracle epochs at 3 x 100, lr 0.5", "oracle_target_curve": ref_curve,
            "oracle_target_s": round(time.perf_counter() - t0, 1), "configs": []}
     with dsgd_amd.Engine(data.dim, LAMBDA, device=device) as eng:
         eng.load_csr(data.row_ptr, data.col, data.val, data.label)
         eng.build_dim_sparsity(n_train)
         eng.sync_step_ranges([(0, n_train)], 0.0)   # layout and first launches outside every clock
-        for k, b in ((3, 100), (4, 200), (1, 4096), (1, 65536), (1, None)):
-            whole = b is None
-            bb = n_train if whole else b
+        for ci, (k, b) in enumerate(((3, 100), (4, 200), (1, 4096), (1, 65536), (1, None))):
+            bb = n_train if b is None else b
             lr = LR0 * 100.0 / bb
-            # the oracle on the same lists (first: its epoch-1 weights are what the engine's are compared with)
+            # the oracle through the same mirror (its first epoch always; more while the budget lasts)
             t2 = time.perf_counter()
-            w = np.zeros(data.dim + 1)
-            o_reached, o_epochs, w_o1, exposed1 = None, 0, None, 0
-            for ep in range(10):
-                if time.perf_counter() - t2 > oracle_budget_s and ep > 0:
-                    break
-                if whole:
-                    o.sync_step_range_omp(w, 0, n_train, lr)
-                else:
-                    for step in epoch_lists(np.random.default_rng(1000 + ep), n_train, k, bb):
-                        o.sync_step(w, step, lr)
-                        if ep == 0:
-                            exposed1 += o.last_stats["min_abs_margin"] < 1e-5
-                o_epochs = ep + 1
-                if ep == 0:
-                    w_o1 = w.copy()
-                if o.loss_acc(w, n_train, n_rows)[0] <= target:
-                    o_reached = ep + 1
-                    break
+            ob = OracleBackend(o)
+            w_o1 = []
+
+            def crit_o(losses):
+                if len(losses) == 1 and not w_o1:
+                    w_o1.append(ob.w.copy())
+                return bool(losses) and (losses[0] <= target or time.perf_counter() - t2 > oracle_budget_s)
+
+            mo, _ = fit_through_the_mirror(dsgd_amd, host, ob, o, n_train, n_rows, k, bb, lr, 10, crit_o)
+            if not w_o1:
+                w_o1.append(ob.w.copy())
+            o_curve = list(reversed(mo.test_losses))
+            o_reached = next((i + 1 for i, l in enumerate(o_curve) if l <= target), None)
             t_oracle = time.perf_counter() - t2
-            eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
-            eng.synchronize()
-            clock, build_s, curve, reached, kern, diff1 = 0.0, 0.0, [], None, None, None
-            for ep in range(max_epochs_engine):
-                if whole:
-                    t1 = time.perf_counter()
-                    eng.sync_step_ranges([(0, n_train)], lr, asynchronous=True)
-                else:
-                    tb = time.perf_counter()
-                    plan = eng.plan(epoch_lists(np.random.default_rng(1000 + ep), n_train, k, bb))
-                    eng.plan_run(plan, 0, 0, lr)          # (the plan's layout is built at its first run: outside the clock)
-                    eng.synchronize()
-                    build_s += time.perf_counter() - tb
-                    t1 = time.perf_counter()
-                    eng.plan_run(plan, 0, plan.n_steps, lr)
-                eng.synchronize()
-                eng.loss_acc(0, n_train)                  # train loss + accuracy (Master.scala:206-207)
-                loss = eng.loss_acc(n_train, n_rows)[0]   # test loss + accuracy (Master.scala:208-209)
-                clock += time.perf_counter() - t1
-                kern = eng.grad_kernel_name()
-                if not whole:
-                    plan.destroy()
-                if ep == 0:
-                    diff1 = float(np.abs(eng.get_weights().astype(np.float64) - w_o1).max())
-                curve.append(loss)
-                if loss <= target:
-                    reached = ep + 1
-                    break
-            out["configs"].append({"workers": k, "batch": bb, "lr": lr, "engine_epochs": reached, "time_to_target_s": clock if reached else None,
-                                   "engine_epochs_run": len(curve), "engine_clock_s": clock, "plan_build_s": round(build_s, 2),
-                                   "engine_test_loss": curve[:12], "kernel": kern, "oracle_epochs": o_reached,
-                                   "oracle_epochs_run": o_epochs, "oracle_s": round(t_oracle, 2),
-                                   "epoch1_max_abs_diff": diff1, "epoch1_steps_with_a_row_near_the_gate": int(exposed1),
-                                   "evaluation": "2 passes per epoch inside the clock (train, test): loss and accuracy of each"})
+            exposed1 = int(sum(mm < 1e-5 for mm in ob.min_margins[:mo.steps_run // max(1, len(o_curve))]))
+            # the engine
+            rec = RecordingBackend(eng, epochs=1 if ci == 0 else 0)
+            w_e1 = []
+
+            def crit_e(losses):
+                if len(losses) == 1 and not w_e1:
+                    w_e1.append(eng.get_weights().astype(np.float64))
+                return bool(losses) and losses[0] <= target
+
+            m, fit_s = fit_through_the_mirror(dsgd_amd, host, rec, o, n_train, n_rows, k, bb, lr, max_epochs_engine, crit_e)
+            if not w_e1:
+                w_e1.append(eng.get_weights().astype(np.float64))
+            curve = list(reversed(m.test_losses))
+            reached = next((i + 1 for i, l in enumerate(curve) if l <= target), None)
+            cfg = {"workers": k, "batch": bb, "lr": lr, "engine_epochs": reached, "time_to_target_s": fit_s if reached else None,
+                   "engine_epochs_run": len(curve), "fit_s": fit_s, "batch_loop_s": m.batch_loop_s, "shuffle_s_not_hidden": m.shuffle_s,
+                   "steps": m.steps_run, "batch_loop_us_per_step": 1e6 * m.batch_loop_s / max(1, m.steps_run),
+                   "engine_test_loss": curve[:12], "kernel": sorted(rec.kernels) or [eng.grad_kernel_name()], "oracle_epochs": o_reached,
+                   "oracle_epochs_run": len(o_curve), "oracle_s": round(t_oracle, 2),
+                   "epoch1_max_abs_diff": float(np.abs(w_e1[0] - w_o1[0]).max()), "epoch1_steps_with_a_row_near_the_gate": exposed1,
+                   "evaluation": "2 passes per epoch inside the clock (train, test): loss and accuracy of each"}
+            if ci == 0:
+                fr = forced_replay(o, rec, np.zeros(data.dim + 1), lr)
+                if fr:
+                    cfg["forced_replay_epoch1"] = fr
+                    cfg.update(first_divergent_step=fr["first_divergent_step"], divergent_rows_all_near_gate=fr["divergent_rows_all_near_gate"],
+                               forced_replay_account_err_over_tol=fr["account_err_over_tol"])
+            out["configs"].append(cfg)
     done = [c for c in out["configs"] if c["time_to_target_s"] is not None]
     out["fastest"] = min(done, key=lambda c: c["time_to_target_s"]) if done else None
     if out["fastest"]:
@@ -1174,41 +1185,39 @@ def cpu_baseline(data, n_train, budget_s):
 
 def epochs_to_target(dsgd_amd, device):
     """Second half of BASELINE.json's metric on configs[1]'s shape (full=false: 23,149 rows, 80/20 split, 3 workers,
-    batch-size 100, lr 0.5, lambda 1e-5, max-epochs 10 -- application.conf): the target is the ORACLE's test loss
-    after the 10 epochs; reported: epochs until the engine's test loss is at or below it, and both loss curves.
-    Both sides get the same per-batch index lists (one fresh shuffle of every split per batch, Master.scala:184)."""
+    batch-size 100, lr 0.5, lambda 1e-5, max-epochs 10 -- application.conf), THROUGH host.MasterSync.fit on both sides with
+    the reference's random stream (java.util.Random seeded 0, Main.scala:32): the target is the ORACLE's best test loss
+    within the 10 epochs; reported: epochs until the engine's test loss is at or below it, both curves, and what the
+    boundary costs -- `fit`: microseconds per batch of the engine's batch loops (drawing the lists, laying the epoch's plan
+    out, the steps; Master.scala:179-199), with an epoch as ONE resident plan and, for comparison, one dsgd_sync_step per
+    batch (what the Scala patch called before round 5)."""
+    from dsgd_amd import host
     from oracle import oracle as orc  # checker / CPU baseline only
+    from oracle.backend import OracleBackend
 
     n_rows, k, batch, lr, epochs = 23149, 3, 100, LR0, 10
     n_train = int(n_rows * 0.8)
     data = dsgd_amd.synth.generate(n_rows, seed=0)
-    size = -(-n_train // k)
-    split = [np.arange(b, min(n_train, b + size)) for b in range(0, n_train, size)]
-    rng = np.random.default_rng(0)
-    lists = [[[rng.permutation(sp)[b:b + batch].astype(np.int32) for sp in split] for b in range(0, size, batch)]
-             for _ in range(epochs)]
     o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, LAMBDA)
     o.set_dim_sparsity(o.dim_sparsity(n_train))
-    w = np.zeros(data.dim + 1)
-    ref_curve = []
+    never = lambda losses: False
     t0 = time.perf_counter()
-    for ep in lists:
-        for step in ep:
-            o.sync_step(w, step, lr)
-        ref_curve.append(o.loss_acc(w, n_train, n_rows)[0])
+    mo, _ = fit_through_the_mirror(dsgd_amd, host, OracleBackend(o), o, n_train, n_rows, k, batch, lr, epochs, never)
     t_ref = time.perf_counter() - t0
-    curve = []
+    ref_curve = list(reversed(mo.test_losses))
     with dsgd_amd.Engine(data.dim, LAMBDA, device=device) as eng:
         eng.load_csr(data.row_ptr, data.col, data.val, data.label)
         eng.build_dim_sparsity(n_train)
-        eng.sync_step(lists[0][0], 0.0)  # layout + first launches outside the clock
-        eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
-        t0 = time.perf_counter()
-        for ep in lists:
-            for step in ep:
-                eng.sync_step(step, lr)
-            curve.append(eng.loss_acc(n_train, n_rows)[0])
-        t_eng = time.perf_counter() - t0
+        fit_through_the_mirror(dsgd_amd, host, eng, o, n_train, n_rows, k, batch, 0.0, 2, never)   # layout, first launches, block cache: outside the clock
+        rec = RecordingBackend(eng, epochs=epochs)
+        m, t_eng = fit_through_the_mirror(dsgd_amd, host, rec, o, n_train, n_rows, k, batch, lr, epochs, never)
+        curve = list(reversed(m.test_losses))
+        fr = forced_replay(o, rec, np.zeros(data.dim + 1), lr)
+        m2, t2 = fit_through_the_mirror(dsgd_amd, host, eng, o, n_train, n_rows, k, batch, lr, epochs, never)      # (unrecorded: the timing)
+        mp = host.MasterSync(eng, n_train, n_rows, k, rnd=host.JavaRandom(0), plans=False)
+        tp = time.perf_counter()
+        mp.fit(np.zeros(data.dim + 1), 2, batch, lr, never)
+        tp = time.perf_counter() - tp
     # Target: the BEST test loss the oracle reaches within max-epochs (the curve of a constant-step run is noisy: its
     # last-epoch loss is worse than its epoch-2 loss, which made "epochs to the last-epoch loss" trivially 2 for both
     # sides in round 2).  The hinge part moves in steps of 1/n_test (predictions are -1/0/+1): one test row of slack.
@@ -1217,14 +1226,25 @@ def epochs_to_target(dsgd_amd, device):
     reached = next((i + 1 for i, l in enumerate(curve) if l <= target + slack), None)
     reached_ref = next((i + 1 for i, l in enumerate(ref_curve) if l <= target + slack), None)
     half = 0.5 * 1.0   # loss at w = 0 is exactly 1 (every prediction is 0): first epoch at or below half of it
+    fit = {"through": "host.MasterSync.fit: an epoch = ONE resident plan, native random stream, next epoch prepared while this one runs",
+           "steps": m2.steps_run, "batch_loop_us_per_step": 1e6 * m2.batch_loop_s / max(1, m2.steps_run),
+           "shuffle_us_per_step_not_hidden": 1e6 * m2.shuffle_s / max(1, m2.steps_run), "fit_s_10_epochs_with_evaluation": t2,
+           "per_request_us_per_step": 1e6 * mp.batch_loop_s / max(1, mp.steps_run),
+           "per_request_note": "one dsgd_sync_step per batch, lists drawn by the pure-Python generator (shuffle included: %.0f us per step)"
+                               % (1e6 * mp.shuffle_s / max(1, mp.steps_run)),
+           "kernel": sorted(rec.kernels), "forced_replay_10_epochs": fr}
+    fit["summary"] = {"us_per_step": fit["batch_loop_us_per_step"], "per_request_us_per_step": fit["per_request_us_per_step"],
+                      "kernel": fit["kernel"][0] if fit["kernel"] else None,
+                      "forced_replay_agrees": bool(fr and fr["accounting_agrees"] and fr["divergent_rows_all_near_gate"]),
+                      "first_divergent_step": fr["first_divergent_step"] if fr else None}
     return {"config": "23149 rows, 3 workers x batch 100, lr 0.5, lambda 1e-5, 10 epochs", "target_test_loss": target,
-            "target": "min over the oracle's epochs", "slack": slack,
+            "target": "min over the oracle's epochs", "slack": slack, "through": "host.MasterSync.fit on both sides, java.util.Random(0)",
             "epochs_to_half_initial_loss": {"engine": next((i + 1 for i, l in enumerate(curve) if l <= half), None),
                                             "oracle": next((i + 1 for i, l in enumerate(ref_curve) if l <= half), None)},
             "max_curve_difference": float(np.abs(np.asarray(curve) - np.asarray(ref_curve)).max()),
             "max_epochs": epochs, "engine_epochs": reached, "oracle_epochs": reached_ref,
             "engine_test_loss": curve, "oracle_test_loss": ref_curve,
-            "engine_s": t_eng, "oracle_s": t_ref, "steps_per_epoch": len(lists[0])}
+            "engine_s": t_eng, "oracle_s": t_ref, "steps_per_epoch": m.steps_run // epochs, "fit": fit}
 
 
 if __name__ == "__main__":

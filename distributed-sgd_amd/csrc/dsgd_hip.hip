@@ -222,7 +222,11 @@ struct dsgd_ctx {
   unsigned long long* d_cs_x = nullptr; // exchange buffer of dsgd_cs_step_kernel: [2][CS_MAX_G][CS_XSTRIDE] granules
   unsigned int* d_cs_sync = nullptr;    // its arrival counter and abort word
   bool cs_host_layout = false;          // DSGD_CS_HOST_LAYOUT=1: a plan's slices laid out by the host (rounds 1-4; kept as the cross-check)
-  bool cs_req = true;                   // DSGD_CS_REQ=0: per-request steps of the reference's sizes through the row-parallel kernels
+  bool cs_req = false;                  // DSGD_CS_REQ=1: per-request steps of the reference's sizes through dsgd_cs_request_kernel.  OFF by
+                                        //   default: a slice's workgroup lays the step out before it runs it, one dependent trip to
+                                        //   memory per row and wave -- measured 126 us per 3 x 100 request against 40 us through the
+                                        //   row-parallel kernels (profiles/r05_probe_v1.json); the kernel is kept, tested, and is what
+                                        //   the abort-path test drives
   int cs_test_skip = 0;                 // (test builds: DSGD_TEST_CS_SKIP_PUBLISH -- slice 1 goes silent from this step of a launch on)
   unsigned int* d_cs_max = nullptr;     // the layout kernels' maxima and flags (4 words) ...
   unsigned int* h_cs_max = nullptr;     // ... and where pass 1's come back to (pinned)
@@ -2840,7 +2844,9 @@ int dsgd_sync_step(dsgd_ctx* c, const int32_t* const* idx_per_worker, const int6
       const int rc = finish_mail(c, stats, tot, before, c->req_spin);
       if (rc != 1) return rc;
       // (the step does not fit the one-step layout -- more than CS_MAX_SLOTS slots or 4,096 columns in one slice: nothing
-      //  was applied; the row-parallel kernels below take it)
+      //  was applied; the row-parallel kernels below take it.  They work on the rank-ordered vector: the slice-major
+      //  copy the request made is dropped -- left "live" it would overwrite their update at the next bind)
+      DSGD_TRY(cs_unslice(c));
     }
   }
   DSGD_TRY(ensure_g(c, n_workers));

@@ -329,10 +329,37 @@ int dsgd_jrand_epoch_lists(uint64_t* state, const int64_t* split_begin, const in
     start[j + 1] = start[j] + (len >= 2 ? len - 1 : 0);
   }
   const int64_t nominal = start[n_shuf];
+  const uint64_t s0 = *state;
+  {
+    /* Short epochs: a rejection is expected once in a thousand epochs (each draw rejects with probability bound / 2^31).
+     * Every shuffle is drawn at once from its NOMINAL start; if none of them saw a rejection the nominal starts were the
+     * true ones and the stream is exact -- one parallel pass instead of two.  Otherwise: the exact two-pass form below. */
+    double expect = 0.0;
+    for (int k = 0; k < n_splits; ++k) {
+      const double len = (double)(split_end[k] - split_begin[k]);
+      expect += (double)n_steps * len * len / 4294967296.0;
+    }
+    const char* force = getenv("DSGD_HOST_SPECULATE");   /* (tests: 1 = try the one-pass form whatever the odds, 0 = never) */
+    if (force ? atoi(force) != 0 : expect < 0.05) {
+      int64_t* zero = (int64_t*)calloc((size_t)(n_shuf + 1), sizeof(int64_t));
+      if (zero) {
+        atomic_int err0 = 0;
+        atomic_llong extra0 = 0;
+        struct jr_shuf_job sj0 = {s0, split_begin, split_end, n_splits, batch_size, start, zero, offsets_out, idx_out, &err0, &extra0};
+        jr_run(jr_shuf_task, &sj0, n_shuf, jr_threads(nominal));
+        free(zero);
+        if (!atomic_load(&err0) && atomic_load(&extra0) == 0) {
+          *state = jr_jump(s0, (uint64_t)nominal);
+          if (draws_out) *draws_out = nominal;
+          free(start);
+          return 0;
+        }
+      }
+    }
+  }
   /* ---- pass A: candidates for a rejection.  u is rejected for bound n iff u >= floor(2^31 / n) * n, never for a power of
    * two; floor(2^31 / n) * n > 2^31 - n >= 2^31 - max_len: only raw values above that can be rejected at all.  The stream
    * is scanned a little past its nominal end (every true rejection lengthens it by one). ---- */
-  const uint64_t s0 = *state;
   const uint32_t cand_min = (uint32_t)(0x80000000ULL - (uint64_t)max_len);
   int64_t scan = nominal + 64 + nominal / 4096;
   int64_t n_cand = 0, cap_cand = 1024;

@@ -443,6 +443,7 @@ class MasterSync:
         self.backend, self.n_train, self.n_rows, self.node_count = backend, n_train, n_rows, node_count
         self.metrics = metrics or Metrics()
         self.rnd = rnd or JavaRandom(0)
+        self._logging = log is not None
         self.log = log or (lambda *a: None)
         self.plans = hasattr(backend, "plan_flat") if plans is None else bool(plans)
         self.prefetch = prefetch
@@ -496,6 +497,21 @@ class MasterSync:
         """One epoch's batch loop (core/Master.scala:179-199) as one resident plan."""
         K = len(split)
         n_expected = len(range(0, max_samples, batch_size))
+        if batch_size >= max_samples and all(r.step == 1 for r in split) and hasattr(self.backend, "sync_step_ranges"):
+            # batch-size >= split size: slice(0, batchSize) of a shuffled split is the WHOLE split, and a sum does not
+            # depend on the order -- the step is a sum over contiguous row ranges (dsgd_sync_step_ranges: the streaming
+            # kernels).  The shuffles are still drawn: the generator must stand where the reference's stands.
+            t_sh = time.perf_counter()
+            epoch_lists(self.rnd, split, max_samples, batch_size)
+            self.shuffle_s += time.perf_counter() - t_sh
+            t0 = time.perf_counter_ns()
+            self.backend.sync_step_ranges([(r.start, r.stop) for r in split], learning_rate)
+            self.log("samples %d - %d / %d" % (1, max_samples, max_samples))
+            with self.metrics._lock:
+                self.metrics.histograms.setdefault("master.sync.batch.duration", []).append(time.perf_counter_ns() - t0)
+            self.metrics.counter("slave.sync.backward", sum(len(r) for r in split))
+            self.steps_run += 1
+            return
         cur = getattr(self, "_pending", None)
         self._pending = None
         if cur is None:
@@ -512,16 +528,23 @@ class MasterSync:
         dt = time.perf_counter_ns() - t0
         # what the per-batch closure would have logged and recorded (:181-183, Slave.scala:145-150), written now
         offs = cur["offsets"]
-        for s_ in range(cur["n_steps"]):
-            batch = s_ * batch_size
-            self.log("samples %d - %d / %d" % (batch + 1, min(batch + batch_size, max_samples), max_samples))
-            with self.metrics._lock:
-                self.metrics.histograms.setdefault("master.sync.batch.duration", []).append(dt // max(1, cur["n_steps"]))
-            self.metrics.counter("slave.sync.backward", int(offs[(s_ + 1) * K] - offs[s_ * K]))
+        if self._logging:
+            for s_ in range(cur["n_steps"]):
+                batch = s_ * batch_size
+                self.log("samples %d - %d / %d" % (batch + 1, min(batch + batch_size, max_samples), max_samples))
+        if cur["n_steps"]:
+            with self.metrics._lock:   # one entry per batch, as the per-batch closure records them
+                self.metrics.histograms.setdefault("master.sync.batch.duration", []).extend([dt // cur["n_steps"]] * cur["n_steps"])
+            self.metrics.counter("slave.sync.backward", int(offs[cur["n_steps"] * K]))
         self.steps_run += cur["n_steps"]
         if cur["n_steps"] < n_expected:
             # the reference's next batch hands some slave an empty slice: Vec.sum throws there (math/Vec.scala:129)
             raise ValueError("Cannot sum an empty list of vectors (batch %d of the epoch: a worker's slice is empty)" % cur["n_steps"])
+
+    def _finished(self, state):
+        if self.plans and state.updates:
+            state = GradState(self.backend.get_weights(), state.loss, state.start, state.updates, state.end)
+        return state.finish(self.losses[0] if self.losses else None)
 
     def _fit_loop(self, state, epoch, split, max_samples, max_epochs, batch_size, learning_rate, stopping_criterion):
         while True:
@@ -532,10 +555,10 @@ class MasterSync:
                 self.metrics.histogram("master.sync.acc", 100 * int(self.accs[0]))  # :151: 100 * accs.head.toLong
             if epoch >= max_epochs:                             # :154
                 self.log("Reached max number of epochs: stopping computation")
-                return state.finish(self.losses[0] if self.losses else None)
+                return self._finished(state)
             if stopping_criterion(self.test_losses):            # :166
                 self.log("Converged to target: stopping computation")
-                return state.finish(self.losses[0] if self.losses else None)
+                return self._finished(state)
             t_loop = time.perf_counter()
             if self.plans:
                 self._epoch_through_a_plan(split, max_samples, batch_size, learning_rate, last=(epoch + 1 >= max_epochs))
@@ -555,9 +578,15 @@ class MasterSync:
                     self.steps_run += 1
                     if st:
                         self.metrics.counter("slave.sync.backward", st.get("n_samples", 0))  # Slave.scala:145-150
-            w = self.backend.get_weights()   # (synchronises: the epoch's steps are done)
-            self.batch_loop_s += time.perf_counter() - t_loop
-            state = state.replace_grad(w)
+            if self.plans:
+                # (the weights stay on the device between the epochs: GradState.grad is filled when fit returns -- the
+                #  reference's master needs the vector every batch only because it ships it to the slaves)
+                self.batch_loop_s += time.perf_counter() - t_loop
+                state = state.replace_grad(state.grad)
+            else:
+                w = self.backend.get_weights()   # (synchronises: the epoch's steps are done)
+                self.batch_loop_s += time.perf_counter() - t_loop
+                state = state.replace_grad(w)
             # :206-209 -- four full passes per epoch; newest first
             l, a, _ = self.backend.loss_acc(0, self.n_train)
             tl, ta, _ = self.backend.loss_acc(self.n_train, self.n_rows)

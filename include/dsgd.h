@@ -115,8 +115,10 @@ int dsgd_apply(dsgd_ctx* ctx, const float* g_mean /* D+1 */, float lr);
  * what `split.map(Random.shuffle(_)).slice(batch, batch + batchSize)` produced on the host.
  * If a communicator is attached (dsgd_comm_init) the mean runs over n_workers * world_size
  * workers with one RCCL all-reduce of the summed gradient.
- * Steps of the reference's own sizes (<= 8 hosted workers, <= 1,024 rows in total, no communicator) run as ONE launch of
- * the column-slice kernel, which lays the request's lists out itself (csrc/dsgd_cs.hpp: dsgd_cs_request_kernel).         */
+ * 40 us per call at the reference's sizes (two row-parallel launches).  Hand an epoch's lists over as ONE plan instead
+ * (dsgd_plan_create / dsgd_plan_run below: 5 us per step) wherever they are known ahead -- Master.fit knows them.  With
+ * DSGD_CS_REQ=1 such a request runs as ONE launch of the column-slice kernel, which lays the lists out itself
+ * (csrc/dsgd_cs.hpp: dsgd_cs_request_kernel); measured SLOWER (126 us: the set-up is a latency chain), so off by default. */
 int dsgd_sync_step(dsgd_ctx* ctx, const int32_t* const* idx_per_worker, const int64_t* n_per_worker,
                    int32_t n_workers, float lr, dsgd_batch_stats* stats /* may be NULL */);
 
@@ -142,7 +144,7 @@ typedef struct dsgd_plan dsgd_plan;
  * (16 bytes per 8 non-zeros) and, up to DSGD_VT_PACK_MB (default 2048), copied in that order: two launches per step
  * (18 us at 4,096 rows).  One epoch of Master.fit (core/Master.scala:179-199) = one plan: the device blocks of a destroyed
  * plan are kept by the context for the next one (DSGD_CACHE_MB, default 8192), dsgd_plan_destroy does not synchronise.
- * The same lists through dsgd_sync_step (per request) run through the same column-slice kernel, one launch per call.   */
+ * The same lists through dsgd_sync_step (per request) cost 40 us per call.                                            */
 int dsgd_plan_create(dsgd_ctx* ctx, const int32_t* idx, const int64_t* offsets, int64_t n_steps, int32_t n_workers,
                      dsgd_plan** out);
 int dsgd_plan_destroy(dsgd_ctx* ctx, dsgd_plan* plan);

@@ -293,6 +293,8 @@ class Master {
       : model_(model), nTrain_(nTrain), nRows_(nRows), nodeCount_(nodeCount), rnd_(rnd) {}
 
   std::deque<double> losses, accs, testLosses, testAccs;  // newest first
+  bool usePlans = true;   // an epoch's batches as ONE resident plan (dsgd_plan_create / dsgd_plan_run); false: one dsgd_sync_step per batch
+  int64_t stepsRun = 0;
 
   double localLoss(const Vec& w, bool test = false) { return test ? model_.loss(w, nTrain_, nRows_) : model_.loss(w, 0, nTrain_); }  // :104
   double localAccuracy(const Vec& w, bool test = false) { return test ? model_.accuracy(w, nTrain_, nRows_) : model_.accuracy(w, 0, nTrain_); }  // :100
@@ -307,26 +309,51 @@ class Master {
       const std::optional<double> last = losses.empty() ? std::nullopt : std::optional<double>(losses.front());
       if (epoch >= maxEpochs) return state.finish(last);             // :154 "Reached max number of epochs"
       if (stoppingCriterion(testLosses)) return state.finish(last);   // :166 "Converged to target"
-      for (int64_t batch = 0; batch < maxSamples; batch += batchSize) {  // :179
-        // :184 -- every worker's split is reshuffled for EVERY batch, then sliced
-        std::vector<std::vector<int32_t>> lists;
+      // :179-199 -- the epoch's batches.  :184: every worker's split is reshuffled for EVERY batch, then sliced; nothing
+      // else consumes the generator inside the loop, so the epoch's lists are drawn first (the same draws in the same
+      // order) and, with plans, handed over as ONE resident plan: all batches in one launch (5 us per 3 x 100 batch
+      // against 40 us per dsgd_sync_step call).
+      std::vector<int32_t> flat;
+      std::vector<int64_t> offsets{0};
+      int64_t nSteps = 0;
+      bool emptySlice = false;
+      for (int64_t batch = 0; batch < maxSamples && !emptySlice; batch += batchSize) {
+        for (const auto& r : split)
+          if (batch >= r.second - r.first) emptySlice = true;   // the slave would be handed an empty slice: Vec.sum throws there
+        if (emptySlice) break;
         for (const auto& r : split) {
           std::vector<int32_t> idx((size_t)(r.second - r.first));
           for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int32_t)(r.first + (int64_t)i);
           idx = shuffle(std::move(idx), rnd_);
           const size_t b = (size_t)std::min<int64_t>(batch, (int64_t)idx.size());
           const size_t e = (size_t)std::min<int64_t>(batch + batchSize, (int64_t)idx.size());
-          lists.emplace_back(idx.begin() + (long)b, idx.begin() + (long)e);
+          flat.insert(flat.end(), idx.begin() + (long)b, idx.begin() + (long)e);
+          offsets.push_back((int64_t)flat.size());
         }
-        std::vector<const int32_t*> ptrs;
-        std::vector<int64_t> ns;
-        for (const auto& l : lists) {
-          ptrs.push_back(l.data());
-          ns.push_back((int64_t)l.size());
-        }
-        // :186-197 -- gradients of all workers, Vec.mean, w - lr * mean
-        check(dsgd_sync_step(model_.ctx(), ptrs.data(), ns.data(), (int32_t)lists.size(), (float)learningRate, nullptr));
+        ++nSteps;
       }
+      const int32_t K = (int32_t)split.size();
+      if (usePlans && nSteps > 0) {
+        dsgd_plan* plan = nullptr;
+        check(dsgd_plan_create(model_.ctx(), flat.data(), offsets.data(), nSteps, K, &plan));
+        int rc = dsgd_plan_run(model_.ctx(), plan, 0, nSteps, (float)learningRate);
+        if (rc == DSGD_OK) rc = dsgd_synchronize(model_.ctx(), nullptr);
+        dsgd_plan_destroy(model_.ctx(), plan);
+        check(rc);
+      } else {
+        for (int64_t st = 0; st < nSteps; ++st) {
+          std::vector<const int32_t*> ptrs;
+          std::vector<int64_t> ns;
+          for (int32_t k = 0; k < K; ++k) {
+            ptrs.push_back(flat.data() + offsets[(size_t)(st * K + k)]);
+            ns.push_back(offsets[(size_t)(st * K + k) + 1] - offsets[(size_t)(st * K + k)]);
+          }
+          // :186-197 -- gradients of all workers, Vec.mean, w - lr * mean
+          check(dsgd_sync_step(model_.ctx(), ptrs.data(), ns.data(), K, (float)learningRate, nullptr));
+        }
+      }
+      stepsRun += nSteps;
+      if (emptySlice) throw IllegalArgumentException("requirement failed: Cannot sum an empty list of vectors");  // math/Vec.scala:129
       Vec w(initialWeights.size());
       check(dsgd_get_weights(model_.ctx(), w.data()));
       state = state.replaceGrad(w);

@@ -9,7 +9,8 @@ import spire.math.Number
   * subclass whose batch-level entry points replace the bodies of `SlaveImpl.gradient` / `forward`
   * (core/Slave.scala:129-157), of the `Slave.asyncTask` iteration and `updateGrad` (core/Slave.scala:79-111,177-185), of
   * `Master.localLoss` / `localAccuracy` (core/Master.scala:100-107) and of the `Master.fit` batch closure
-  * (core/Master.scala:179-199) when `dsgd.backend = hip` (a new OPTIONAL key; every existing `dsgd { ... }` key of
+  * (core/Master.scala:179-199) -- a whole epoch of it as ONE resident plan (`fitEpoch`) -- when `dsgd.backend = hip` (a new
+  * OPTIONAL key; every existing `dsgd { ... }` key of
   * application.conf is untouched).  scala/patch/dsgd-hip-backend.diff is the patch that wires it in (it adds this file
   * as src/main/scala/epfl/distributed/core/ml/NativeSVM.scala).
   */
@@ -27,6 +28,12 @@ object NativeSVM {
   @native def forward(ctx: Long, w: Array[Float], idx: Array[Int], predOut: Array[Float]): Unit
   @native def syncStep(ctx: Long, idxPerWorker: Array[Array[Int]], lr: Float): Long
   @native def syncStepRanges(ctx: Long, rowBegin: Array[Long], rowEnd: Array[Long], lr: Float): Long
+  // an epoch of Master.fit as ONE resident plan (core/Master.scala:179-199): idx = the epoch's lists concatenated
+  // (batch-major, worker-minor), offsets = nSteps * nWorkers + 1 prefix offsets
+  @native def planCreate(ctx: Long, idx: Array[Int], offsets: Array[Long], nWorkers: Int): Long
+  @native def planRun(ctx: Long, plan: Long, stepBegin: Long, stepEnd: Long, lr: Float): Unit
+  @native def planSynchronize(ctx: Long): Long
+  @native def planDestroy(ctx: Long, plan: Long): Unit
   @native def lossAcc(ctx: Long, w: Array[Float], rowBegin: Long, rowEnd: Long, out: Array[Double]): Unit
   @native def asyncStep(ctx: Long, idx: Array[Int], lr: Float, deltaOut: Array[Float]): Unit
   @native def updateGrad(ctx: Long, keys: Array[Int], values: Array[Float]): Unit
@@ -121,6 +128,43 @@ class HipSVM(lambda: Number, dimSparsity: Vec, data: Array[(Vec, Int)], nTrain: 
     * regularised sums, mean over the workers, w <- w - learningRate * mean.  An empty list fails as Vec.sum does. */
   def syncStep(idxPerWorker: Seq[Seq[Int]], learningRate: Double): Long =
     NativeSVM.syncStep(ctx, idxPerWorker.map(_.toArray).toArray, learningRate.toFloat)
+
+  /** ONE EPOCH of Master.fit's batch loop (core/Master.scala:179-199) for the workers hosted by this context, as one resident
+    * plan: `batches(b)(k)` = the sample list of worker k in batch b, i.e. what
+    * `split.map(Random.shuffle(_)).slice(batch, batch + batchSize)` (:184) yields, drawn by the caller in the reference's own
+    * order.  All batches run in ONE launch of the column-slice kernel (5 us per 3 x 100 batch; `syncStep` per batch costs
+    * 40 us plus the JNI array traffic); the weights stay on the device.  Returns the number of active samples of the epoch.
+    * An empty list fails as Vec.sum does (math/Vec.scala:129) -- before anything runs. */
+  def fitEpoch(batches: Seq[Seq[Seq[Int]]], learningRate: Double): Long = {
+    val plan = createEpochPlan(batches)
+    try runEpochPlan(plan, batches.size, learningRate)
+    finally NativeSVM.planDestroy(ctx, plan)
+  }
+
+  /** The two halves of `fitEpoch`, for a master that lays the NEXT epoch's plan out while this epoch's batches run
+    * (planCreate works on a stream of its own beside the launch stream). */
+  def createEpochPlan(batches: Seq[Seq[Seq[Int]]]): Long = {
+    require(batches.nonEmpty, "an epoch needs at least one batch")
+    val nWorkers = batches.head.size
+    require(batches.forall(_.size == nWorkers), "every batch needs one list per worker")
+    val total   = batches.iterator.map(_.iterator.map(_.size).sum).sum
+    val idx     = new Array[Int](total)
+    val offsets = new Array[Long](batches.size * nWorkers + 1)
+    var at, i   = 0
+    batches.foreach(_.foreach { list =>
+      list.foreach { r => idx(at) = r; at += 1 }
+      i += 1
+      offsets(i) = at
+    })
+    NativeSVM.planCreate(ctx, idx, offsets, nWorkers)
+  }
+
+  def runEpochPlan(plan: Long, nBatches: Int, learningRate: Double): Long = {
+    NativeSVM.planRun(ctx, plan, 0, nBatches, learningRate.toFloat)
+    NativeSVM.planSynchronize(ctx)
+  }
+
+  def destroyEpochPlan(plan: Long): Unit = NativeSVM.planDestroy(ctx, plan)
 
   /** one iteration of Slave.asyncTask (core/Slave.scala:92-101) on the device-resident weights; returns the update that
     * is gossiped (core/Slave.scala:103-105) */

@@ -166,6 +166,15 @@ static void gpu_checks() {
     for (size_t j = 0; j < s.grad.size(); ++j) std::printf("%s%.9g", j ? ", " : "", (double)s.grad[j]);
     std::printf("], \"losses\": [%.9g, %.9g], \"test_losses\": [%.9g, %.9g]}\n", master.losses[0], master.losses[1], master.testLosses[0],
                 master.testLosses[1]);
+    // the same fit with one request per batch (usePlans = false): the same stream, the same lists, the same weights
+    SparseSVM model2(0.1, 6);
+    model2.load(kat_rows(6));
+    model2.buildDimSparsity(4);
+    Master master2(model2, 4, 6, 2, JavaRandom(0));
+    master2.usePlans = false;
+    const GradState s2 = master2.fit(Vec(7, 0.f), 2, 2, 0.25, EarlyStopping::noImprovement(5, 0.01));
+    CHECK(master.stepsRun == master2.stepsRun && master.stepsRun == 2);
+    for (size_t j = 0; j < s.grad.size(); ++j) CHECK(close_to(s.grad[j], s2.grad[j], 1e-7));
   }
 }
 

@@ -16,6 +16,7 @@ import dsgd_amd  # noqa: E402
 from dsgd_amd import _lib  # noqa: E402
 
 assert os.environ.get("DSGD_LIB_PATH", "").endswith("libdsgd_hip_seam.so")
+os.environ["DSGD_CS_REQ"] = "1"   # (per-request steps through the column-slice kernel are opt-in)
 lib = _lib.load()
 data = dsgd_amd.synth.generate(20000, seed=3)
 n_train = 16000

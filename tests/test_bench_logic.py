@@ -23,9 +23,21 @@ import bench  # noqa: E402
 class FakePlan:
     def __init__(self, steps):
         self.steps, self.n_steps = steps, len(steps)
+        self.rec, self.masks, self.s = False, {}, {}
 
     def destroy(self):
         pass
+
+    def record(self, on=True):
+        self.rec = bool(on)
+
+    def read_record(self, a=0, b=None):
+        b = self.n_steps if b is None else b
+        width = 32 * -(-max(sum(len(x) for x in st) for st in self.steps) // 32)
+        m = np.zeros((b - a, width), dtype=bool)
+        for i in range(a, b):
+            m[i - a, :len(self.masks[i])] = self.masks[i]
+        return m, np.asarray([self.s[i] for i in range(a, b)], dtype=np.float32)
 
 
 class FakeEngine:
@@ -71,8 +83,21 @@ class FakeEngine:
     def plan(self, steps):
         return FakePlan(steps)
 
+    def sync_step(self, lists, lr):
+        self.o.sync_step(self.w, lists, lr)
+        self.kern = "dsgd_mb_grad_kernel"
+        return {"n_samples": sum(len(a) for a in lists), "n_active": self.o.last_stats["n_active"]}
+
+    def plan_flat(self, idx, offsets, n_steps, k):
+        return FakePlan([[np.asarray(idx[offsets[s * k + j]:offsets[s * k + j + 1]], dtype=np.int32) for j in range(k)] for s in range(n_steps)])
+
     def plan_run(self, plan, a, b, lr):
-        for s in plan.steps[a:b]:
+        for i, s in enumerate(plan.steps[a:b], start=a):
+            if plan.rec:   # the decisions the oracle takes on these weights, the scalar it uses
+                rows = np.concatenate(s)
+                plan.masks[i] = np.array([not (self.o.label[r] * self.o.row_dot(int(r), self.w) < 0.0) for r in rows])
+                prod = self.w * self.o.ds
+                plan.s[i] = 2.0 * self.lam * float(prod[np.abs(prod) > 1e-20].sum())
             self.o.sync_step(self.w, s, lr)
             self.act += self.o.last_stats["n_active"]
             self.kern = "dsgd_plan_kernel" if len(s) == 1 and len(s[0]) <= 192 else self.kernel_for_plans
@@ -199,24 +224,31 @@ def test_reference_shape_and_time_to_target_dry_run(fake, monkeypatch):
     assert r["parity_gate"]["max_rel_err"] <= bench.STATED_TOL and r["roofline"]["bound"] == "hbm"
     assert {(s["workers"], s["batch"]) for s in r["sweep"]} == {(1, 100), (3, 100)}
     t = bench.time_to_target(dsgd_amd, 0, n_rows=3000, oracle_budget_s=3.0, max_epochs_engine=12)
-    assert [(c["workers"], c["batch"]) for c in t["configs"]] == [(3, 100), (4, 200), (1, 2400), (1, 2400), (1, 2400)] or \
-        len(t["configs"]) == 5
+    assert len(t["configs"]) == 5 and [(c["workers"], c["batch"]) for c in t["configs"]][:2] == [(3, 100), (4, 200)]
+    assert "MasterSync.fit" in t["through"]
     ref = t["configs"][0]
     # the stand-in engine IS the oracle: at the reference's configuration both reach the target in the same epoch
     assert ref["engine_epochs"] == ref["oracle_epochs"] and ref["engine_epochs"] is not None
     assert t["fastest"] is not None and t["target_test_loss"] == float(np.median(t["oracle_target_curve"]))
     assert all(c["epoch1_max_abs_diff"] is not None and c["epoch1_max_abs_diff"] < 1e-6 for c in t["configs"])   # the stand-in IS the oracle
+    # the reference's configuration carries the forced replay of its first epoch: no differing decision (the stand-in IS the
+    # oracle), the accounting agrees, and the fields the compact line quotes are there
+    fr = ref["forced_replay_epoch1"]
+    assert fr["accounting_agrees"] and fr["differing_decisions"] == 0 and ref["first_divergent_step"] is None
+    assert ref["divergent_rows_all_near_gate"] is True and ref["forced_replay_account_err_over_tol"] < 0.1   # (the stand-in hands its weights over as fp32)
+    assert ref["steps"] >= 8 and ref["batch_loop_us_per_step"] > 0 and all("fit_s" in c for c in t["configs"])
     json.dumps(t), json.dumps(r)   # everything in the line is JSON-serialisable
 
 
-def test_epoch_lists_visit_every_row_once():
-    steps = bench.epoch_lists(np.random.default_rng(1), 1000, 3, 100)
-    seen = np.concatenate([np.concatenate(s) for s in steps])
-    # (a step in which some worker's slice came out empty would be dropped: Vec.sum requires a non-empty list)
-    assert len(set(seen.tolist())) == len(seen) and all(len(s) == 3 for s in steps)
-    assert len(steps) == 4 and seen.max() < 1000
-    one = bench.epoch_lists(np.random.default_rng(1), 1000, 1, 4096)
-    assert len(one) == 1 and sorted(one[0][0].tolist()) == list(range(1000))
+def test_epochs_to_target_runs_through_the_mirror(fake):
+    """bench.epochs_to_target: both sides through host.MasterSync.fit with java.util.Random(0); the `fit` leg carries the
+    boundary's cost per batch (plans vs one request per batch) and the forced replay of the whole 10-epoch trajectory."""
+    e = bench.epochs_to_target(dsgd_amd, 0)
+    assert e["engine_epochs"] == e["oracle_epochs"] and e["max_curve_difference"] < 1e-6 and e["steps_per_epoch"] == 62
+    f = e["fit"]
+    assert f["steps"] == 620 and f["summary"]["forced_replay_agrees"] and f["forced_replay_10_epochs"]["steps"] == 620
+    assert f["batch_loop_us_per_step"] > 0 and f["per_request_us_per_step"] > 0
+    json.dumps(e)
 
 
 def test_final_line_is_compact_and_parses(tmp_path):

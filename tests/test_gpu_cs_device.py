@@ -33,6 +33,20 @@ CS, REQ = "dsgd_cs_step_kernel", "dsgd_cs_request_kernel"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _request_kernel_on():
+    """Per-request steps through the column-slice kernel are OPT-IN (DSGD_CS_REQ=1: one workgroup per slice lays the step
+    out before it can run it, and that set-up is latency-bound -- 126 us per 3 x 100 request against 40 us through the
+    row-parallel kernels, profiles/r05_probe.json); this module tests the path, so it switches it on."""
+    old = os.environ.get("DSGD_CS_REQ")
+    os.environ["DSGD_CS_REQ"] = "1"
+    yield
+    if old is None:
+        os.environ.pop("DSGD_CS_REQ", None)
+    else:
+        os.environ["DSGD_CS_REQ"] = old
+
+
 def make_pair(data, n_train, with_oracle=True):
     o = None
     if with_oracle:
@@ -156,6 +170,7 @@ def test_per_request_steps_run_on_column_slices(mid, k, b):
     w_a = eng.get_weights()
     eng.set_weights(w_start)
     plan = eng.plan(steps)
+    eng.synchronize()                                 # (the counters of the requests above are collected and cleared)
     eng.plan_run(plan, 0, len(steps), lr)
     st = eng.synchronize()
     plan.destroy()

@@ -48,7 +48,6 @@ def test_master_sync_fit_engine_vs_oracle():
         ce = CountingEngine(eng)
         m = host.MasterSync(ce, n_train, n_rows, node_count=3, rnd=host.JavaRandom(0), plans=False)   # one request per batch
         s = m.fit(np.zeros(data.dim + 1), 2, 100, 0.5, host.EarlyStopping.no_improvement(5, 0.01))
-        assert eng.grad_kernel_name() in ("dsgd_cs_request_kernel", "dsgd_wseg_kernel<false>", "dsgd_eval_kernel") or True
     assert s.updates == s_ref.updates == 2
     assert len(ce.actives) == len(ob.actives) == 28  # 2 epochs x ceil(ceil(4000/3)/100) batches of 3 x 100
     exposed = [i for i, mm in enumerate(ob.min_margins) if mm < 1e-5]
@@ -284,7 +283,7 @@ def test_lyrl2004_text_to_csr_to_one_epoch_on_the_gpu():
         ds = eng.build_dim_sparsity(n_train)
         np.testing.assert_array_equal(ds, o.ds.astype(np.float32))
         ce = CountingEngine(eng)
-        m = host.MasterSync(ce, n_train, n_rows, node_count=3, rnd=host.JavaRandom(0))
+        m = host.MasterSync(ce, n_train, n_rows, node_count=3, rnd=host.JavaRandom(0), plans=False)   # one request per batch: counted
         s = m.fit(np.zeros(dim + 1), 1, 4, 0.5, host.EarlyStopping.no_improvement(5, 0.01))
     assert len(ce.actives) == len(ob.actives) == 2   # ceil(ceil(19 / 3) / 4) batches
     if min(ob.min_margins) >= 1e-5:

@@ -228,7 +228,7 @@ def test_one_thread_driving_both_contexts_equals_the_two_processes(ranks, tmp_pa
 
 
 @pytest.mark.parametrize("mode", ["strong", "weak"])
-def test_bench_parity_gate_with_two_ranks(mode):
+def test_bench_parity_gate_with_two_ranks(mode, tmp_path):
     """bench.py --gpus 2: the N > 1 parity gate EXECUTED (two ranks on the one device through the seam build + shim):
     every rank steps over the first --gate-rows rows of its shard through the in-library all-reduce, rank 0 hosts both
     shards in the oracle as world x workers workers and holds the update to the derived bound and the stated 1e-5
@@ -240,10 +240,15 @@ def test_bench_parity_gate_with_two_ranks(mode):
     shape = ["--scaling", "strong", "--rows-total", "60000"] if mode == "strong" else ["--rows", "30000"]
     gate_rows = 8000 if mode == "strong" else 12000   # (below / above the row count from which ranges take the streaming kernels)
     cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--workers", "2", "--gate-rows", str(gate_rows),
-           "--steps", "3", "--warmup", "1", "--repeats", "2", "--clock-ramp", "0.05", "--no-cpu-baseline"] + shape
+           "--steps", "3", "--warmup", "1", "--repeats", "2", "--clock-ramp", "0.05", "--no-cpu-baseline",
+           "--detail", str(tmp_path / "detail.json")] + shape
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert proc.returncode == 0, proc.stderr[-4000:]
-    line = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][-1])
+    last = proc.stdout.splitlines()[-1]
+    compact = json.loads(last)                       # the LAST stdout line is the compact line of record ...
+    assert len(last) < 8192 and compact["n_gpus"] == 2 and compact["scaling"] == mode and compact["replicas_bit_identical"] is True
+    line = json.load(open(tmp_path / "detail.json"))   # ... and the full object is in the detail file
+    assert abs(compact["value"] - line["value"]) <= 1e-5 * line["value"] and compact["parity_gate_max_rel_err"] <= 1e-5
     assert line["n_gpus"] == 2 and line["scaling"] == mode and line["replicas_bit_identical"] is True
     g = line["parity_gate"]
     assert g["world"] == 2 and g["workers_total"] == 4 and g["rows_per_rank"] == gate_rows and len(g["steps"]) == 2

@@ -272,6 +272,15 @@ def test_native_stream_with_rejections():
             lib.dsgd_jrand_shuffle(C.byref(st), buf.ctypes.data_as(C.c_void_p), C.c_int64(len(buf)))
             want.append(buf[step * 250000:(step + 1) * 250000].copy())
     assert ns == 3 and np.array_equal(idx, np.concatenate(want)) and r1.seed == st.value
+    # short epochs are drawn in ONE speculative pass (no rejection expected); forced onto this stream -- which has hundreds --
+    # the speculation must notice and give way to the exact two-pass form
+    os.environ["DSGD_HOST_SPECULATE"] = "1"
+    try:
+        r2 = host.JavaRandom(9)
+        idx2, offs2, ns2 = host.epoch_lists(r2, split, n, 250000, native=True)
+    finally:
+        del os.environ["DSGD_HOST_SPECULATE"]
+    assert ns2 == 3 and np.array_equal(idx2, idx) and r2.seed == r1.seed
 
 
 def test_fit_through_plans_is_fit_step_by_step():

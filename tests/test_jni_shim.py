@@ -159,11 +159,39 @@ def test_shim_end_to_end_on_the_gpu(shim_lib):
     w = np.zeros(data.dim + 1, dtype=np.float32)
     (wj, _w) = jarr(w)
     call("getWeights", None, [C.c_int64, vp], h, C.byref(wj))
+    # an EPOCH as one plan through the shim (what the patched Master.fit calls: HipSVM.fitEpoch): 5 batches x 3 workers
+    steps = [[rng.permutation(1600)[:100].astype(np.int32) for _ in range(3)] for _ in range(5)]
+    flat = np.concatenate([a for st_ in steps for a in st_]).astype(np.int32)
+    offs = np.arange(0, 1501, 100, dtype=np.int64)
+    (fj, _f), (oj, _o) = jarr(flat), jarr(offs)
+    plan = call("planCreate", C.c_int64, [C.c_int64, vp, vp, C.c_int32], h, C.byref(fj), C.byref(oj), 3)
+    assert plan != 0
+    call("planSynchronize", C.c_int64, [C.c_int64], h)   # (collects and clears the counters of the request above)
+    call("planRun", None, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float], h, plan, 0, 5, 0.5)
+    act_epoch = call("planSynchronize", C.c_int64, [C.c_int64], h)
+    call("planDestroy", None, [C.c_int64, C.c_int64], h, plan)
+    w2 = np.zeros(data.dim + 1, dtype=np.float32)
+    (w2j, _w2) = jarr(w2)
+    call("getWeights", None, [C.c_int64, vp], h, C.byref(w2j))
+    # offsets that do not describe nSteps x nWorkers lists are refused before anything is taken
+    env_bad = Env()
+    fnb = getattr(lib, PREFIX + "planCreate")
+    fnb.restype, fnb.argtypes = C.c_int64, [vp, vp, C.c_int64, vp, vp, C.c_int32]
+    assert fnb(C.byref(env_bad), None, h, C.byref(fj), C.byref(oj), 4) == 0
+    assert env_bad.thrown_class == b"java/lang/IllegalArgumentException" and env_bad.n_get == 0
     call("destroy", None, [C.c_int64], h)
     with dsgd_amd.Engine(data.dim, 1e-5) as eng:
         eng.load_csr(data.row_ptr, data.col, data.val, data.label)
         eng.build_dim_sparsity(1600)
         st = eng.sync_step(lists, 0.5)
         w_ref = eng.get_weights()
+        p2 = eng.plan(steps)
+        eng.synchronize()
+        eng.plan_run(p2, 0, 5, 0.5)
+        st2 = eng.synchronize()
+        assert eng.grad_kernel_name() == "dsgd_cs_step_kernel"
+        w_ref2 = eng.get_weights()
+        p2.destroy()
     assert n_active == st["n_active"] == 300  # w = 0: every row is active
     assert np.abs(_w - w_ref).max() <= 1e-6 and np.abs(w_ref).max() > 0
+    assert act_epoch == st2["n_active"] and np.array_equal(_w2, w_ref2)   # the same plan, the same kernel: the same bits

@@ -46,7 +46,11 @@ def test_patch_applies_to_the_reference_tree(tmp_path):
                  "h.updateGrad(request.gradUpdate)", "h.setWeights(request.weights)"):
         assert call in slave, call
     assert "model.backward(w, x, y)" in slave and "model.regularize(grad, w)" in slave      # the JVM bodies are still there
-    assert "h.syncStep(lists, learningRate)" in master and "worker.gradient(req)" in master
+    # the resident (dev) master hands a whole EPOCH over as one plan: the lists drawn first, in the reference's own order
+    assert "h.fitEpoch(batches, learningRate)" in master and "worker.gradient(req)" in master
+    assert "split.map(Random.shuffle(_)).toSeq.take(nWorkers).map(_.slice(batch, batch + batchSize))" in master
+    assert master.count("split.map(Random.shuffle(_))") == 2      # ... and the per-request loop still draws them itself
+    assert 'Kamon.timer("master.sync.batch.duration").record(perBatch)' in master
     assert "h.lossAndAccuracy(weights, lo, hi)" in master
     # resident (dev) mode: the loss check evaluates the device weights in place -- a snapshot written back would discard
     # the updates the slave threads applied since it was taken
