@@ -76,6 +76,34 @@ def fit_leg(eng, n_train, n_rows, epochs, k=3, b=100):
     return res
 
 
+def with_a_communicator(eng, n_train, k=3, b=100, steps=300):
+    """The reference's configuration when a communicator is attached (the N-GPU path: the column-slice kernel declines, a
+    step is two row-parallel launches + one all-reduce of D + 1 floats + the update).  ONE rank here -- the all-reduce is
+    RCCL's single-rank path -- so this is the per-step cost WITHOUT link time: the kernels, the launches, the collective's
+    fixed cost."""
+    rng = np.random.default_rng(2)
+    size = -(-n_train // k)
+    lists = [[(j * size + rng.permutation(min(size, n_train - j * size))[:b]).astype(np.int32) for j in range(k)] for _ in range(steps)]
+    eng.comm_init(dsgd_amd.Engine.comm_unique_id(), 1, 0)
+    try:
+        plan = eng.plan(lists)
+        eng.plan_run(plan, 0, 20, 0.0)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        eng.plan_run(plan, 0, steps, 0.0)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        kern = eng.grad_kernel_name()
+        plan.destroy()
+        t1 = time.perf_counter()
+        for i in range(100):
+            eng.sync_step(lists[i], 0.0)
+        dr = time.perf_counter() - t1
+    finally:
+        eng.comm_destroy()
+    return {"world": 1, "plan_us_per_step": 1e6 * dt / steps, "kernel": kern, "per_request_us": 1e6 * dr / 100}
+
+
 def main():
     out = {"host_threads": host._host_lib().dsgd_host_threads(), "cpus": os.cpu_count()}
     # the random stream by thread count
@@ -110,6 +138,10 @@ def main():
                     out[key]["plan_cycle_3x100"] = plan_cycle(eng, n_train, 3, 100)
                     out[key]["plan_cycle_4x200"] = plan_cycle(eng, n_train, 4, 200, epochs=2)
                     out[key]["fit"] = fit_leg(eng, n_train, n_rows, 6 if n_rows < 100000 else 2)
+                    try:
+                        out[key]["with_communicator_3x100"] = with_a_communicator(eng, n_train)
+                    except Exception as e:   # (no RCCL on the box: say so)
+                        out[key]["with_communicator_3x100"] = {"error": str(e)[:200]}
         os.environ.pop("DSGD_CS_REQ", None)
     print(json.dumps(out, indent=1))
 

@@ -1,16 +1,35 @@
 #!/bin/bash
-# One GPU visit of round 5: tests first (the new column-slice work, then the whole GPU suite), the probe, a bench line.
-# usage: tools/r05_visit.sh <tag> [quick]
-tag=${1:-v}
-mode=${2:-full}
-mkdir -p gpurun_out
+# One GPU-box visit of round 5: pick the legs with arguments (the legs of tools/r04_visit.sh are available too).
+# usage (repo root, on the GPU box): bash tools/r05_visit.sh <tag> [build] [testcs] [probe] [testall] [bench] [benchprof] [pmc] [latency] [cstrace] ...
+TAG=$1; shift
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
 export TMPDIR=/tmp
-python -c "import __graft_entry__ as g; g.build()" > gpurun_out/${tag}_build.txt 2>&1
-timeout 900 python -m pytest tests/test_gpu_cs_device.py tests/test_gpu_cs.py -q -m gpu --tb=short > gpurun_out/${tag}_pytest_cs.txt 2>&1
-tail -5 gpurun_out/${tag}_pytest_cs.txt
-timeout 600 python tools/r05_probe.py > gpurun_out/${tag}_probe.json 2> gpurun_out/${tag}_probe.err
-tail -3 gpurun_out/${tag}_probe.err
-if [ "$mode" = "full" ]; then
-  timeout 1500 python -m pytest tests -q -m gpu --tb=short > gpurun_out/${tag}_pytest_gpu.txt 2>&1
-  tail -8 gpurun_out/${tag}_pytest_gpu.txt
-fi
+for leg in "$@"; do
+case $leg in
+build)
+  python -c "import __graft_entry__ as g; g.build()" > $OUT/build.txt 2>&1; tail -2 $OUT/build.txt ;;
+testcs)
+  echo "== the column-slice modules"
+  timeout 900 python -m pytest tests/test_gpu_cs_device.py tests/test_gpu_cs.py -q -m gpu --tb=short -rf > $OUT/pytest_cs.txt 2>&1
+  grep -E "^(E  |FAILED|ERROR)|passed|failed" $OUT/pytest_cs.txt | cut -c1-300 | head -60 ;;
+probe)
+  echo "== round-5 probe"
+  timeout 900 python tools/r05_probe.py > $OUT/probe.json 2> $OUT/probe.err; tail -3 $OUT/probe.err
+  python - <<PY
+import json
+d = json.load(open("$OUT/probe.json"))
+for key in ("rows=23149", "rows=804414"):
+    r = d[key]
+    print(key, "fit", {k: round(v["batch_loop_us_per_step"], 2) for k, v in r["fit"].items()}, "exposed shuffle", {k: round(v["shuffle_us_per_step_exposed"], 2) for k, v in r["fit"].items()})
+    print("   plan cycle (last)", {k: round(v, 3) if isinstance(v, float) else v for k, v in r["plan_cycle_3x100"][-1].items()})
+    print("   requests", {m: {c: round(v["us_per_request_python_binding"], 1) for c, v in r[m].items()} for m in r if m.startswith("requests")})
+    print("   with a communicator", r.get("with_communicator_3x100"))
+PY
+  ;;
+smoke)
+  python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.txt ;;
+*)
+  bash tools/r04_visit.sh $TAG $leg ;;
+esac
+done
