@@ -1230,8 +1230,8 @@ def epochs_to_target(dsgd_amd, device):
            "steps": m2.steps_run, "batch_loop_us_per_step": 1e6 * m2.batch_loop_s / max(1, m2.steps_run),
            "shuffle_us_per_step_not_hidden": 1e6 * m2.shuffle_s / max(1, m2.steps_run), "fit_s_10_epochs_with_evaluation": t2,
            "per_request_us_per_step": 1e6 * mp.batch_loop_s / max(1, mp.steps_run),
-           "per_request_note": "one dsgd_sync_step per batch, lists drawn by the pure-Python generator (shuffle included: %.0f us per step)"
-                               % (1e6 * mp.shuffle_s / max(1, mp.steps_run)),
+           "per_request_note": "one dsgd_sync_step per batch (what the Scala patch called before round 5), the epoch's lists from the "
+                               "same native generator (%.1f us per step of it)" % (1e6 * mp.shuffle_s / max(1, mp.steps_run)),
            "kernel": sorted(rec.kernels), "forced_replay_10_epochs": fr}
     fit["summary"] = {"us_per_step": fit["batch_loop_us_per_step"], "per_request_us_per_step": fit["per_request_us_per_step"],
                       "kernel": fit["kernel"][0] if fit["kernel"] else None,

@@ -2935,6 +2935,8 @@ int dsgd_synchronize(dsgd_ctx* c, dsgd_batch_stats* stats) {
   DSGD_TRY(prof_collect(c));
   const long long act = (long long)c->h_sc->n_active;
   const int err = c->h_sc->err;
+  const long long pending = c->pending_samples;
+  c->pending_samples = 0;   // (whatever the outcome: the rows of a rejected run are not carried into the next report)
   DSGD_TRY(reset_counters(c));
   if ((err & (8 | 16)) && c->d_cs_sync) HIP_TRY(hipMemsetAsync(c->d_cs_sync, 0, sizeof(unsigned int) * 2, c->stream));   // the abort word, first
   if (err & 2)
@@ -2946,9 +2948,8 @@ int dsgd_synchronize(dsgd_ctx* c, dsgd_batch_stats* stats) {
   if (err) return fail(DSGD_ERANGE, "sample index / key outside the loaded data");
   if (stats) {
     stats->n_active = act;
-    stats->n_samples = c->pending_samples;
+    stats->n_samples = pending;
   }
-  c->pending_samples = 0;
   return DSGD_OK;
 }
 

@@ -563,16 +563,19 @@ class MasterSync:
             if self.plans:
                 self._epoch_through_a_plan(split, max_samples, batch_size, learning_rate, last=(epoch + 1 >= max_epochs))
             else:
-                for batch in range(0, max_samples, batch_size):    # :179
+                # :184 -- every worker's split is reshuffled for EVERY batch, then sliced.  Nothing else draws from the
+                # generator inside the loop: the epoch's lists are drawn up front (the same draws in the same order;
+                # natively when lib/libdsgd_host.so is there), then one request per batch
+                t_sh = time.perf_counter()
+                idx, offs, n_steps = epoch_lists(self.rnd, split, max_samples, batch_size)
+                self.shuffle_s += time.perf_counter() - t_sh
+                K = len(split)
+                for s_, batch in enumerate(range(0, max_samples, batch_size)):    # :179
                     self.log("samples %d - %d / %d" % (batch + 1, min(batch + batch_size, max_samples), max_samples))   # :181
-                    # :184 -- every worker's split is reshuffled for EVERY batch, then sliced
-                    t_sh = time.perf_counter()
-                    lists = []
-                    for r in split:
-                        shuffled = scala_shuffle(list(r), self.rnd)
-                        lists.append(np.asarray(shuffled[batch:batch + batch_size], dtype=np.int32))
-                    self.shuffle_s += time.perf_counter() - t_sh
-                    # a slice past the end of a short last split is empty: Vec.sum would throw in the slave
+                    if s_ >= n_steps:
+                        # a slice past the end of a short last split is empty: Vec.sum throws in that slave (math/Vec.scala:129)
+                        raise ValueError("Cannot sum an empty list of vectors (batch %d of the epoch: a worker's slice is empty)" % s_)
+                    lists = [idx[offs[s_ * K + j]:offs[s_ * K + j + 1]] for j in range(K)]
                     with self.metrics.timer("master.sync.batch.duration"):   # :183
                         st = self.backend.sync_step(lists, learning_rate)    # :186-197
                     self.steps_run += 1

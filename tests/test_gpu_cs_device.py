@@ -151,7 +151,7 @@ def mid():
     eng.close()
 
 
-@pytest.mark.parametrize("k,b", [(3, 100), (4, 200), (1, 100), (1, 1), (2, 7), (8, 100), (1, 1000), (5, 64)])
+@pytest.mark.parametrize("k,b", [(3, 100), (4, 200), (1, 100), (1, 1), (2, 7), (8, 100), (1, 800), (5, 64)])
 def test_per_request_steps_run_on_column_slices(mid, k, b):
     data, n_train, o, eng = mid
     rng = np.random.default_rng(13 * b + k)
