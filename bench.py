@@ -850,7 +850,23 @@ def hogwild_parity(dsgd_amd, device, workers=256, batch=100, rows=100000, update
             hr.replay_forced(o, w_bad, split, batch, LR0, 5, trace, fault=fault, check=False)
             err = float(np.abs(w_end - w_bad).max())
         controls[fault] = {"account_max_abs_err": err, "rejected": not err <= hr.ACCOUNT_TOL * max(1.0, float(np.abs(w_bad).max()))}
+    # the gate check WITH TEETH: 4 workers (kube/dsgd.yaml:95), every decision of every update with at most one update in
+    # flight held to the reference's gate at both ends of [read_at, commit)
+    split4 = split_vanilla(n_train, 4)
+    with dsgd_amd.Engine(data.dim, LAMBDA, device=device) as eng:
+        eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+        eng.build_dim_sparsity(n_train)
+        eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+        eng.async_set_trace(1200)
+        eng.async_start(split4, batch=batch, lr=LR0, max_updates=1000, seed=9, positional_bug=False)
+        eng.async_wait()
+        trace4 = eng.async_read_trace()
+    g4 = hr.gate_check_small_lag(o, np.zeros(data.dim + 1), split4, batch, LR0, 9, trace4, max_lag=1)
+    if not g4["ok"]:
+        raise SystemExit("Hogwild gate check (4 workers) failed: %r" % g4)
+    gate4 = {kk: g4[kk] for kk in ("updates", "updates_checked", "rows_checked", "differ_at_both_ends", "explained_by_in_flight_or_resolution", "ok")}
     traced = {"rows": rows, "workers": workers, "batch": batch, "updates": int(v.get("updates", updates)), "checkpoint": v,
+              "gate_check_4_workers": gate4,
               "accounting_agrees": bool(all(v["ok"].values())), "gates_are": "engine-recorded (forced in the replay), not re-derived",
               "negative_controls": controls, "controls_rejected": all(c["rejected"] for c in controls.values()),
               "seconds": round(time.perf_counter() - t0, 1)}

@@ -214,3 +214,78 @@ def verdict(o, w_engine, w_replay, stats, eval_range=None):
     out["ok"] = {"accounting": bool(err <= ACCOUNT_TOL * scale), "staleness": bool(stale_seen),
                  "scalar": bool(s_p50 <= S_TOL_MEDIAN and s_p90 <= S_TOL_P90)}
     return out
+
+
+# ---- a gate check WITH TEETH for few workers ---------------------------------------------------------------------------
+# Statement (B) above only locates the decisions inside [read_at, commit): at 256 workers a tenth of the rows still
+# disagrees at the best-fitting point, so a gate bug that mis-decides a few per cent of the rows only under concurrency
+# would pass it.  With FEW workers most updates have nothing, or one update, in flight between their read and their commit:
+# then the weights a worker read are known up to that one update, and a recorded decision can be held to the reference's
+# gate row by row.
+GATE_SLACK = 8.0
+
+
+def gate_check_small_lag(o, w0, split, batch, lr, seed, trace, max_lag=1, positional_bug=False):
+    """Replay the traced run with its recorded decisions (exact weights W_c after every commit), then hold every decision
+    of every update with lag <= max_lag to the reference's gate y (x . W) >= 0 at BOTH ends of [read_at, commit): a
+    decision that differs at both ends is legitimate only for a row whose margin, at one of the ends, is no larger than
+    what the updates in flight can have moved it by while they were landing (sum_j |x_j| |delta_j| over them) plus the
+    fp32 resolution of its dot product.  Returns counts; `outside` lists the violations (empty for a correct engine)."""
+    worker, it, read_at = np.asarray(trace["worker"]), np.asarray(trace["it"]), np.asarray(trace["read_at"])
+    s_rec, mask = np.asarray(trace["s"], dtype=np.float64), np.asarray(trace["mask"])
+    n = len(worker)
+    out = {"updates": n, "updates_checked": 0, "rows_checked": 0, "differ_at_both_ends": 0, "explained_by_in_flight_or_resolution": 0, "outside": []}
+    w = np.asarray(w0, dtype=np.float64).copy()
+    window = {0: w.copy()}
+    dwin = {}
+    eps32 = 2.0 ** -24
+    for c in range(1, n + 1):
+        k = int(worker[c - 1])
+        b, e = split[k]
+        rows = hog_rows(seed, k, int(it[c - 1]), b, e - b, batch, positional_bug)
+        ra = int(read_at[c - 1])
+        lag = c - 1 - ra
+        if lag <= max_lag:
+            y = o.label[rows].astype(np.float64)
+            w_read, w_commit = window[ra], window[c - 1]
+            flat, rid = _entries(o, rows)
+            v = o.val[flat].astype(np.float64)
+            cols = o.col[flat]
+            m_read = y * np.bincount(rid, weights=v * w_read[cols], minlength=batch)
+            m_commit = y * np.bincount(rid, weights=v * w_commit[cols], minlength=batch)
+            # what the updates in flight can have done to the margin while landing coordinate by coordinate: any SUBSET of
+            # their coordinates may have been visible, so the margin the worker saw lies in [m_read - down, m_read + up]
+            down, up = np.zeros(batch), np.zeros(batch)
+            for cc in range(ra + 1, c):
+                t = y[rid] * v * dwin[cc][cols]            # W_commit = W_read - delta: the margin moves by -t per coordinate
+                down += np.bincount(rid, weights=np.maximum(t, 0.0), minlength=batch)
+                up += np.bincount(rid, weights=np.maximum(-t, 0.0), minlength=batch)
+            nnz = np.bincount(rid, minlength=batch)
+            res = (nnz + 32) * eps32 * np.bincount(rid, weights=np.abs(v * w_read[cols]), minlength=batch)
+            rec = mask[c - 1, :batch].astype(bool)
+            d_read, d_commit = ~(m_read < 0.0), ~(m_commit < 0.0)
+            both = (rec != d_read) & (rec != d_commit)
+            out["updates_checked"] += 1
+            out["rows_checked"] += batch
+            out["differ_at_both_ends"] += int(both.sum())
+            for r in np.flatnonzero(both):
+                slack = GATE_SLACK * res[r] + 1e-30
+                # recorded "inactive" needs a visible margin < 0, recorded "active" one >= 0, somewhere in the reachable range
+                reachable = (m_read[r] - down[r] - slack < 0.0) if not rec[r] else (m_read[r] + up[r] + slack >= 0.0)
+                if reachable:
+                    out["explained_by_in_flight_or_resolution"] += 1
+                else:
+                    out["outside"].append({"update": c, "row": int(rows[r]), "lag": int(lag), "recorded_active": bool(rec[r]),
+                                           "margin_read": float(m_read[r]), "margin_commit": float(m_commit[r]),
+                                           "reachable": [float(m_read[r] - down[r]), float(m_read[r] + up[r])], "resolution": float(slack)})
+        d = forced_delta(o, rows, mask[c - 1, :batch], float(s_rec[c - 1]), batch, lr)
+        w -= d
+        w[np.abs(w) <= 1e-20] = 0.0
+        window[c] = w.copy()
+        dwin[c] = d
+        old = c - max_lag - 3
+        window.pop(old, None)
+        dwin.pop(old, None)
+    out["ok"] = not out["outside"]
+    out["outside"] = out["outside"][:5]
+    return out

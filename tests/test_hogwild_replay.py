@@ -128,3 +128,32 @@ def test_inconsistent_traces_are_refused():
         hr.replay_forced(o, w, split, 10, 0.5, 1, bad)
     empty = {q: v[:0] for q, v in good.items()}
     assert hr.replay_forced(o, w, split, 10, 0.5, 1, empty)["updates"] == 0
+
+
+def test_small_lag_gate_check_on_a_modelled_schedule():
+    """hogwild_replay.gate_check_small_lag (the few-worker gate statement with teeth) on schedules whose staleness is known:
+    one worker (nothing in flight: every decision IS the gate at both ends) and two workers (exactly one update in flight,
+    the snapshot is the read end): no decision differs at both ends; flipped on a clear margin, one does and is outside."""
+    data, o, n_train = problem()
+    for k in (1, 2):
+        split = [(r.start, r.stop) for r in host.split_vanilla(n_train, k)]
+        _, trace = model_run(o, split, 50, 0.5, 7, 120)
+        g = hr.gate_check_small_lag(o, np.zeros(o.dim + 1), split, 50, 0.5, 7, trace, max_lag=1)
+        assert g["ok"] and g["updates_checked"] == 120 and g["rows_checked"] == 120 * 50 and g["differ_at_both_ends"] == 0, g
+        bad = {q: np.array(v, copy=True) for q, v in trace.items()}
+        c = 60                                              # flip the clearest row of update 60
+        w = np.zeros(o.dim + 1)
+        for cc in range(1, c):
+            j = int(trace["worker"][cc - 1])
+            rows = hr.hog_rows(7, j, int(trace["it"][cc - 1]), split[j][0], split[j][1] - split[j][0], 50)
+            w -= hr.forced_delta(o, rows, trace["mask"][cc - 1, :50], float(trace["s"][cc - 1]), 50, 0.5)
+        j = int(trace["worker"][c - 1])
+        rows = hr.hog_rows(7, j, int(trace["it"][c - 1]), split[j][0], split[j][1] - split[j][0], 50)
+        bad["mask"][c - 1, int(np.abs(hr.margins(o, w, rows)).argmax())] ^= True
+        gb = hr.gate_check_small_lag(o, np.zeros(o.dim + 1), split, 50, 0.5, 7, bad, max_lag=1)
+        assert not gb["ok"] and gb["outside"][0]["update"] == c, gb
+    # beyond the lag the check is asked for, updates are left out (16 equally fast workers: every update has 15 in flight)
+    split = [(r.start, r.stop) for r in host.split_vanilla(n_train, 16)]
+    _, trace = model_run(o, split, 50, 0.5, 7, 64)
+    g = hr.gate_check_small_lag(o, np.zeros(o.dim + 1), split, 50, 0.5, 7, trace, max_lag=1)
+    assert g["updates_checked"] == 2 and g["ok"]            # (only the first two updates of the run have lag <= 1)
