@@ -438,8 +438,9 @@ class MasterSync:
         batch (32 us each); None = whenever the backend offers plans.  The random stream, the lists, the order of the
         steps and the arithmetic are the same either way; what changes is when the host sees a batch: the per-batch log
         lines and the `master.sync.batch.duration` timer are written after the epoch's launch (one entry per batch, the
-        epoch's time shared evenly).  prefetch: draw the NEXT epoch's lists and lay its plan out while this epoch's steps
-        run (if fit stops after this epoch the stream is put back to where the reference's would be)."""
+        epoch's time shared evenly).  prefetch: while an epoch's steps run, the next epoch's plan is laid out and the lists of
+        the epoch after it are drawn on a helper thread (if fit stops early the stream is put back to where the reference's
+        would be: nothing of an epoch that never ran is kept)."""
         self.backend, self.n_train, self.n_rows, self.node_count = backend, n_train, n_rows, node_count
         self.metrics = metrics or Metrics()
         self.rnd = rnd or JavaRandom(0)
@@ -452,6 +453,8 @@ class MasterSync:
         self.test_losses: List[float] = []
         self.test_accs: List[float] = []
         self._pending = None
+        self._lists_future = None
+        self._executor = None
         self.batch_loop_s = 0.0      # wall time of the batch loops (shuffles, plan set-up, steps): Master.scala:179-199
         self.shuffle_s = 0.0         # ... of which drawing the lists (not overlapped by prefetch: see fit)
         self.steps_run = 0
@@ -477,23 +480,50 @@ class MasterSync:
             self._drop_pending()
 
     def _drop_pending(self):
-        p = getattr(self, "_pending", None)
+        """fit is over: whatever was drawn or laid out for epochs that never ran is dropped, and the stream goes back to
+        where the reference's generator stands (the draws are undone oldest first)."""
+        fut, self._lists_future = getattr(self, "_lists_future", None), None
+        ahead = fut.result() if fut is not None else None
+        p, self._pending = getattr(self, "_pending", None), None
         if p is not None:
-            # the lists of an epoch that never ran: the stream goes back to where the reference's generator stands
             self.rnd.seed = p["seed_before"]
             if p["plan"] is not None:
                 p["plan"].destroy()
-            self._pending = None
+        elif ahead is not None:
+            self.rnd.seed = ahead["seed_before"]
+        ex, self._executor = getattr(self, "_executor", None), None
+        if ex is not None:
+            ex.shutdown(wait=True)
 
-    def _draw_plan(self, split, max_samples, batch_size):
+    def _draw_lists(self, split, max_samples, batch_size):
         seed_before = self.rnd.seed
         t0 = time.perf_counter()
         idx, offsets, n_steps = epoch_lists(self.rnd, split, max_samples, batch_size)
-        dt = time.perf_counter() - t0
-        plan = self.backend.plan_flat(idx, offsets, n_steps, len(split)) if n_steps else None
-        return {"plan": plan, "n_steps": n_steps, "offsets": offsets, "seed_before": seed_before, "shuffle_s": dt}
+        return {"idx": idx, "offsets": offsets, "n_steps": n_steps, "seed_before": seed_before, "shuffle_s": time.perf_counter() - t0}
 
-    def _epoch_through_a_plan(self, split, max_samples, batch_size, learning_rate, last):
+    def _take_lists(self, split, max_samples, batch_size):
+        """The next epoch's lists: drawn ahead by the helper thread if one is at it (the wait, if any, counts as shuffle time
+        that was not hidden), otherwise drawn now."""
+        fut, self._lists_future = getattr(self, "_lists_future", None), None
+        t0 = time.perf_counter()
+        lists = fut.result() if fut is not None else self._draw_lists(split, max_samples, batch_size)
+        self.shuffle_s += time.perf_counter() - t0
+        return lists
+
+    def _draw_ahead(self, split, max_samples, batch_size):
+        """Start drawing the lists of the epoch after the next on a helper thread (the native generator releases the GIL):
+        the main thread lays the next epoch's plan out meanwhile.  One drawer at a time: the stream is sequential."""
+        if getattr(self, "_executor", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._executor = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dsgd-lists")
+        self._lists_future = self._executor.submit(self._draw_lists, split, max_samples, batch_size)
+
+    def _make_plan(self, lists, n_workers):
+        plan = self.backend.plan_flat(lists["idx"], lists["offsets"], lists["n_steps"], n_workers) if lists["n_steps"] else None
+        return {"plan": plan, "n_steps": lists["n_steps"], "offsets": lists["offsets"], "seed_before": lists["seed_before"]}
+
+    def _epoch_through_a_plan(self, split, max_samples, batch_size, learning_rate, epochs_left):
         """One epoch's batch loop (core/Master.scala:179-199) as one resident plan."""
         K = len(split)
         n_expected = len(range(0, max_samples, batch_size))
@@ -515,13 +545,17 @@ class MasterSync:
         cur = getattr(self, "_pending", None)
         self._pending = None
         if cur is None:
-            cur = self._draw_plan(split, max_samples, batch_size)
-            self.shuffle_s += cur["shuffle_s"]       # (not hidden behind a running epoch)
+            cur = self._make_plan(self._take_lists(split, max_samples, batch_size), K)
         t0 = time.perf_counter_ns()
         if cur["n_steps"]:
             self.backend.plan_run(cur["plan"], 0, cur["n_steps"], learning_rate)   # enqueued: ALL the epoch's steps, one launch
-        if self.prefetch and not last and cur["n_steps"] == n_expected:
-            self._pending = self._draw_plan(split, max_samples, batch_size)        # ... while they run
+        if self.prefetch and epochs_left > 1 and cur["n_steps"] == n_expected:
+            # ... and while they run: the next epoch's lists (drawn ahead already, from the second epoch on), the draw of the
+            # epoch after it started on the helper thread, the next epoch's plan laid out (the device's build stream)
+            nxt = self._take_lists(split, max_samples, batch_size)
+            if epochs_left > 2 and nxt["n_steps"] == n_expected:
+                self._draw_ahead(split, max_samples, batch_size)
+            self._pending = self._make_plan(nxt, K)
         if cur["plan"] is not None:
             cur["plan"].destroy()                                                    # (behind the run; no synchronisation)
         self.backend.synchronize()
@@ -561,7 +595,7 @@ class MasterSync:
                 return self._finished(state)
             t_loop = time.perf_counter()
             if self.plans:
-                self._epoch_through_a_plan(split, max_samples, batch_size, learning_rate, last=(epoch + 1 >= max_epochs))
+                self._epoch_through_a_plan(split, max_samples, batch_size, learning_rate, epochs_left=max_epochs - epoch)
             else:
                 # :184 -- every worker's split is reshuffled for EVERY batch, then sliced.  Nothing else draws from the
                 # generator inside the loop: the epoch's lists are drawn up front (the same draws in the same order;
