@@ -657,7 +657,11 @@ def roofline(eng, rows_key, n_train, nnz_train, bytes_per_row, kernel_ms, n_laun
     average duration from HIP events on the library's stream, the whole step against the same peak, the cold kernels."""
     launches_per_step = n_launch / max(1, n_steps)
     nnz_int, cold_int = eng.range_nnz(0, n_train)
-    alg_bytes = (8.0 * (nnz_train - cold_int) + 12.0 * n_train) / max(1.0, launches_per_step)  # per launch
+    # the chunked launch (csrc/dsgd_fstep.hpp) walks BOTH streams: every non-zero of the step is its own; the three
+    # streaming launches split them -- the dominant one (dsgd_wseg_kernel) reads the hot part
+    one_launch = eng.grad_kernel_name() == "dsgd_fstep_kernel"
+    own_nnz = nnz_train if one_launch else nnz_train - cold_int
+    alg_bytes = (8.0 * own_nnz + 12.0 * n_train) / max(1.0, launches_per_step)  # per launch
     achieved = alg_bytes / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
     # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc pass (tools/pmc_pass.sh: FETCH_SIZE,
     # x2 gfx950 correction) recorded in profiles/traffic.json -- it cannot be collected inside this run
@@ -667,6 +671,8 @@ def roofline(eng, rows_key, n_train, nnz_train, bytes_per_row, kernel_ms, n_laun
         try:
             tj = json.load(open(tpath))
             traffic = tj.get(str(rows_key))
+            if isinstance(traffic, dict):   # by dominant kernel: the chunked launch and the three streaming launches differ
+                traffic = traffic.get(eng.grad_kernel_name())
             traffic_source = tj.get("source", "profiles/traffic.json (committed rocprofv3 --pmc FETCH_SIZE pass)")
         except Exception:
             traffic = None
@@ -688,7 +694,7 @@ def roofline(eng, rows_key, n_train, nnz_train, bytes_per_row, kernel_ms, n_laun
         "algorithmic_bytes_per_example": bytes_per_row,
         "kernel_ms_avg": kernel_ms,
         "kernel_launches": n_launch,
-        "kernel_share_of_nonzeros": (nnz_train - cold_int) / max(1, nnz_train),
+        "kernel_share_of_nonzeros": own_nnz / max(1, nnz_train),
         # the whole step (all kernels, launch gaps included) against the same roofline
         "step": {"algorithmic_bytes": bytes_per_row * n_train, "ms": 1e3 * step_s,
                  "achieved": bytes_per_row * n_train / step_s / 1e9, "frac": bytes_per_row * n_train / step_s / HBM_PEAK},

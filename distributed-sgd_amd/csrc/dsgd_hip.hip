@@ -123,6 +123,7 @@ static bool available() {
 #include "dsgd_batch.hpp"
 #include "dsgd_cs.hpp"
 #include "dsgd_dense.hpp"
+#include "dsgd_fstep.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -300,6 +301,30 @@ struct dsgd_ctx {
   int bound_shift = 0;
   unsigned int* d_bound = nullptr;
   int max_shift = FIX_SHIFT;     // DSGD_FIX_SHIFT: cap of the per-launch fixed-point shift of the split layout
+  // Row chunks (csrc/dsgd_fstep.hpp): the whole gradient of a row range in ONE launch.  Per (row ranges, workgroups per
+  // worker) configuration the host cuts the ranges into chunks balanced by stream bytes and lays out wave tiles of both
+  // streams that end at the chunk boundaries; a few configurations stay cached (a fit alternates train steps only; the
+  // tests and the bench's legs bring their own).
+  struct FstepLayout {
+    std::vector<long long> ranges;   // row_begin, row_end per worker
+    int n_wg = 0;                    // workgroups (chunks) per worker
+    WTile* d_tiles = nullptr;
+    unsigned short* d_meta = nullptr;
+    WTile* d_ctiles = nullptr;
+    unsigned short* d_cmeta = nullptr;
+    FChunk* d_chunks = nullptr;
+    long long worst_rows = 1;        // rows of the largest chunk
+    int shift = -1;                  // the measured fixed-point shift of the hot accumulators (-1: not measured yet)
+    unsigned long long used = 0;
+  };
+  std::vector<FstepLayout> fstep_cache;
+  unsigned long long fstep_clock = 0;
+  bool fstep_enable = true;          // DSGD_FSTEP=0: row ranges through the three streaming launches / the row-wise kernel
+  long long fstep_min = 65536;       // DSGD_FSTEP_MIN / DSGD_FSTEP_MAX: row ranges of this many rows in total take the chunked launch
+  long long fstep_max = 1LL << 31;   //   (measured, whole-split steps, us: 80 K rows 56 -> 50-54, 643 K 118 -> 105, 1.6 M 213 -> 199,
+                                     //    3.2 M 374 -> 343, 6.7 M 699 -> 663; at 18.5 K rows the row-wise kernel stays ahead: 37 vs 35-41)
+  long long fstep_rows = 512;        // DSGD_FSTEP_ROWS: a chunk holds at least this many rows (fewer workgroups for small ranges:
+                                     //   every workgroup moves 378 KB of LDS tiles in and out whatever its chunk)
   bool fused_apply_pending = false;
   FusedArgs fused_args{};
   float* d_redpart = nullptr;    // per-block partial sums of w.ds and |w|^2 of the fused reduce + apply kernel
@@ -1642,13 +1667,10 @@ struct HostTiles {
   std::vector<int> r0;              // first row of every tile + sentinel n_rows
   std::vector<unsigned short> meta16;   // n_tiles x 64
 };
-static void build_wave_tiles(const long long* row_ptr, long long n_rows, const signed char* label, HostTiles& out,
-                             int max_rows = WS_MAXROWS) {
+// wave tiles of WHOLE rows over the rows [rb, re) of a stream given by its slot offsets (a window of <= WS_SLOTS slots that
+// starts at a multiple of 8; rows without a slot or longer than a tile close the open tile and stay out), appended to wt
+static void append_wave_tiles(const long long* row_ptr, long long rb, long long re, std::vector<WTile>& wt, int max_rows) {
   const long long amask = ~7LL;
-  std::vector<WTile>& wt = out.wt;
-  std::vector<int>& wr0 = out.r0;
-  wt.clear();
-  wr0.clear();
   long long start = -1;  // first row of the open tile
   auto close = [&](long long end_row) {
     if (start < 0) return;
@@ -1657,10 +1679,9 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
     t.r0 = (int)start;
     t.info = (int)(((end_row - start) & 0xffff) | ((row_ptr[end_row] - t.pos0) << 16));
     wt.push_back(t);
-    wr0.push_back((int)start);
     start = -1;
   };
-  for (long long i = 0; i < n_rows; ++i) {
+  for (long long i = rb; i < re; ++i) {
     const long long len = row_ptr[i + 1] - row_ptr[i];
     if (len > WS_MAXNNZ || len == 0) {
       close(i);
@@ -1669,10 +1690,13 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
     if (start >= 0 && (row_ptr[i + 1] - (row_ptr[start] & amask) > WS_SLOTS - 1 || i - start >= max_rows)) close(i);
     if (start < 0) start = i;
   }
-  close(n_rows);
-  wr0.push_back((int)n_rows);
+  close(re);
+}
+// the 64 lane descriptors of every tile: row-start bits of the lane's eight slots | label signs of the rows ending there << 8
+static void wave_tile_meta(const long long* row_ptr, const signed char* label, const std::vector<WTile>& wt,
+                           std::vector<unsigned short>& meta16) {
   const long long n_tiles = (long long)wt.size();
-  out.meta16.assign((size_t)std::max<long long>(n_tiles, 1) * 64, (unsigned short)0);
+  meta16.assign((size_t)std::max<long long>(n_tiles, 1) * 64, (unsigned short)0);
   for (long long t = 0; t < n_tiles; ++t) {
     const WTile& T = wt[(size_t)t];
     const int t_nrows = (int)(short)(T.info & 0xffff);
@@ -1692,9 +1716,20 @@ static void build_wave_tiles(const long long* row_ptr, long long n_rows, const s
           ++next;
         }
       }
-      out.meta16[(size_t)t * 64 + l] = (unsigned short)(bits | (ys << 8));
+      meta16[(size_t)t * 64 + l] = (unsigned short)(bits | (ys << 8));
     }
   }
+}
+static void build_wave_tiles(const long long* row_ptr, long long n_rows, const signed char* label, HostTiles& out,
+                             int max_rows = WS_MAXROWS) {
+  std::vector<WTile>& wt = out.wt;
+  std::vector<int>& wr0 = out.r0;
+  wt.clear();
+  wr0.clear();
+  append_wave_tiles(row_ptr, 0, n_rows, wt, max_rows);
+  for (const WTile& t : wt) wr0.push_back(t.r0);
+  wr0.push_back((int)n_rows);
+  wave_tile_meta(row_ptr, label, wt, out.meta16);
   if (wt.empty()) {
     WTile t;
     t.pos0 = 0;
@@ -1728,7 +1763,9 @@ static int upload_wave_tiles(dsgd_ctx* c, HostTiles& ht) {
 
 // split the ranked CSR into the hot stream (rank < hsplit) and the cold stream (rank - hsplit), both in row order with
 // wave tiles of whole rows; rows whose hot or cold part exceeds a wave tile stay on the long-row list and in neither.
+static void fstep_drop_all(dsgd_ctx* c);
 static int build_split(dsgd_ctx* c) {
+  fstep_drop_all(c);   // (the chunked tile tables index the streams built here)
   (void)hipFree(c->d_hcol); (void)hipFree(c->d_hval); (void)hipFree(c->d_hrow_ptr);
   (void)hipFree(c->d_ccol); (void)hipFree(c->d_cval); (void)hipFree(c->d_ctp); (void)hipFree(c->d_ctiles); (void)hipFree(c->d_cmeta);
   (void)hipFree(c->d_dcold); (void)hipFree(c->d_coef8);
@@ -2105,6 +2142,189 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
   return DSGD_OK;
 }
 
+// ---- row chunks: the whole gradient of a row range in one launch (csrc/dsgd_fstep.hpp) -------------------------------
+static void fstep_free(dsgd_ctx::FstepLayout& L) {
+  (void)hipFree(L.d_tiles);
+  (void)hipFree(L.d_meta);
+  (void)hipFree(L.d_ctiles);
+  (void)hipFree(L.d_cmeta);
+  (void)hipFree(L.d_chunks);
+  L = dsgd_ctx::FstepLayout();
+}
+static void fstep_drop_all(dsgd_ctx* c) {   // (the split streams are about to change, or the context goes away)
+  if (c->fstep_cache.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (dsgd_ctx::FstepLayout& L : c->fstep_cache) fstep_free(L);
+  c->fstep_cache.clear();
+}
+// can the chunked launch serve this context's layout at all?  (16-bit cold ids, every cold column inside the LDS tile)
+static bool fstep_possible(const dsgd_ctx* c) {
+  const int H = std::min(c->hsplit, c->dp);
+  const int nc = c->dp - H;
+  const int nc_lds = std::min(nc, DSGD_LDS_FLOATS - 16 * CT_STRIP - 64 - 4);
+  return c->fstep_enable && nc > 0 && nc <= nc_lds && c->cold_col16 && c->coldm_nnz > 0 && c->n_rows < (1LL << 31);
+}
+static int fstep_layout(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int n_wg, dsgd_ctx::FstepLayout** out) {
+  const int n_workers = (int)row_segs.size();
+  std::vector<long long> key;
+  for (const StreamSeg& sg : row_segs) {
+    key.push_back(sg.row_begin);
+    key.push_back(sg.row_end);
+  }
+  for (dsgd_ctx::FstepLayout& L : c->fstep_cache)
+    if (L.n_wg == n_wg && L.ranges == key) {
+      L.used = ++c->fstep_clock;
+      *out = &L;
+      return DSGD_OK;
+    }
+  if (c->fstep_cache.size() >= 8) {   // the least recently used configuration makes room
+    size_t v = 0;
+    for (size_t i = 1; i < c->fstep_cache.size(); ++i)
+      if (c->fstep_cache[i].used < c->fstep_cache[v].used) v = i;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    fstep_free(c->fstep_cache[v]);
+    c->fstep_cache.erase(c->fstep_cache.begin() + (long)v);
+  }
+  const std::vector<long long>&hrp = c->h_hrp, &ctp = c->h_ctp;
+  std::vector<WTile> wt, ct;
+  std::vector<FChunk> chunks((size_t)n_workers * (size_t)n_wg);
+  long long worst = 1;
+  for (int k = 0; k < n_workers; ++k) {
+    const long long rb = row_segs[(size_t)k].row_begin, re = row_segs[(size_t)k].row_end;
+    // a row's weight: its slots in the two streams (6 bytes each) plus what every row costs (descriptor share, dcold, coef8)
+    auto W = [&](long long i) { return hrp[(size_t)i] + ctp[(size_t)i] + 2 * i; };
+    const long long w0 = W(rb), wtot = W(re) - w0;
+    long long cut = rb;
+    for (int b = 0; b < n_wg; ++b) {
+      long long nxt = re;
+      if (b + 1 < n_wg) {
+        const long long target = w0 + (long long)((double)wtot * (double)(b + 1) / (double)n_wg);
+        long long lo = cut, hi = re;   // first row i in [cut, re] with W(i) >= target
+        while (lo < hi) {
+          const long long mid = (lo + hi) >> 1;
+          if (W(mid) >= target) hi = mid;
+          else lo = mid + 1;
+        }
+        nxt = lo;
+      }
+      FChunk& ch = chunks[(size_t)k * (size_t)n_wg + (size_t)b];
+      ch.row_begin = (int)cut;
+      ch.row_end = (int)nxt;
+      ch.tile_begin = (int)wt.size();
+      append_wave_tiles(hrp.data(), cut, nxt, wt, WS_MAXROWS);
+      ch.tile_end = (int)wt.size();
+      ch.ctile_begin = (int)ct.size();
+      append_wave_tiles(ctp.data(), cut, nxt, ct, CT_MAXROWS);
+      ch.ctile_end = (int)ct.size();
+      ch.long_begin = (int)(std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), cut) - c->wlong_rows.begin());
+      ch.long_end = (int)(std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), nxt) - c->wlong_rows.begin());
+      worst = std::max(worst, nxt - cut);
+      cut = nxt;
+    }
+  }
+  std::vector<unsigned short> meta, cmeta;
+  wave_tile_meta(hrp.data(), c->h_label.data(), wt, meta);
+  wave_tile_meta(ctp.data(), c->h_label.data(), ct, cmeta);
+  WTile pad;   // (the tables are never empty: a clamped record read must stay inside them)
+  pad.pos0 = 0;
+  pad.r0 = 0;
+  pad.info = 0xffff;
+  if (wt.empty()) wt.push_back(pad);
+  if (ct.empty()) ct.push_back(pad);
+  dsgd_ctx::FstepLayout L;
+  L.ranges = key;
+  L.n_wg = n_wg;
+  L.worst_rows = worst;
+  hipError_t e = hipMalloc(&L.d_tiles, sizeof(WTile) * wt.size());
+  if (e == hipSuccess) e = hipMalloc(&L.d_meta, sizeof(unsigned short) * meta.size());
+  if (e == hipSuccess) e = hipMalloc(&L.d_ctiles, sizeof(WTile) * ct.size());
+  if (e == hipSuccess) e = hipMalloc(&L.d_cmeta, sizeof(unsigned short) * cmeta.size());
+  if (e == hipSuccess) e = hipMalloc(&L.d_chunks, sizeof(FChunk) * chunks.size());
+  if (e == hipSuccess) e = hipMemcpy(L.d_tiles, wt.data(), sizeof(WTile) * wt.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(L.d_meta, meta.data(), sizeof(unsigned short) * meta.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(L.d_ctiles, ct.data(), sizeof(WTile) * ct.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(L.d_cmeta, cmeta.data(), sizeof(unsigned short) * cmeta.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(L.d_chunks, chunks.data(), sizeof(FChunk) * chunks.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    fstep_free(L);
+    return fail(DSGD_EHIP, "row-chunk layout: %s", hipGetErrorString(e));
+  }
+  L.used = ++c->fstep_clock;
+  c->fstep_cache.push_back(L);
+  *out = &c->fstep_cache.back();
+  return DSGD_OK;
+}
+
+// workgroups per worker of the chunked launch for these ranges (0: not this path)
+static int fstep_grid(const dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, long long tot) {
+  if (!fstep_possible(c) || tot < c->fstep_min || tot > c->fstep_max) return 0;
+  const int n_workers = (int)row_segs.size();
+  if (n_workers > c->n_cu) return 0;
+  long long smallest = tot;
+  for (const StreamSeg& sg : row_segs) smallest = std::min(smallest, sg.row_end - sg.row_begin);
+  const long long per_worker = std::max<long long>(1, c->n_cu / n_workers);
+  return (int)std::max<long long>(1, std::min(per_worker, smallest / std::max<long long>(1, c->fstep_rows)));
+}
+
+static int launch_fstep(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int n_wg) {
+  const int n_workers = (int)row_segs.size();
+  dsgd_ctx::FstepLayout* L = nullptr;
+  DSGD_TRY(fstep_layout(c, row_segs, n_wg, &L));
+  const int H = std::min(c->hsplit, c->dp);
+  const int nc = c->dp - H;   // (fstep_possible: all of them inside the LDS tile)
+  dim3 grid((unsigned)n_wg, (unsigned)n_workers);
+  DSGD_TRY(ensure_part(c, &c->d_part, &c->part_wgs, &c->part_stride, (long long)n_wg * n_workers, H));
+  DSGD_TRY(ensure_part(c, &c->d_partc, &c->partc_wgs, &c->partc_stride, (long long)n_wg * n_workers, nc));
+  // LDS: the largest of the three phases' tiles
+  const size_t lds_a = sizeof(float) * (size_t)(((nc + 3) & ~3) + 16 * CT_STRIP);
+  const size_t lds_b = sizeof(float) * (size_t)(16 * WS_COEF_STRIDE + 2 * H + 64 + 4);
+  const size_t lds_c = sizeof(float) * (size_t)(((nc + 64 + 3) & ~3) + 16 * CT_STRIP);
+  const size_t lds = std::max(lds_a, std::max(lds_b, lds_c));
+  // the fixed-point scale of the hot accumulators: one contribution per row and column, |contribution| <= 2^shift, a
+  // chunk's rows known -- refined once per configuration by the data (dsgd_fstep_bound_kernel)
+  int bits = 0;
+  while ((1LL << bits) < L->worst_rows) ++bits;
+  const int shift0 = std::max(1, std::min(c->max_shift, 30 - bits));
+  int shift = shift0;
+  if (c->fix_bound && shift0 < c->max_shift) {
+    if (L->shift < 0) {
+      if (!c->d_bound) HIP_TRY(hipMalloc(&c->d_bound, sizeof(unsigned int)));
+      HIP_TRY(hipMemsetAsync(c->d_bound, 0, sizeof(unsigned int), c->stream));
+      hipLaunchKernelGGL(dsgd_fstep_bound_kernel, grid, dim3(1024), sizeof(unsigned int) * (size_t)(H + 16), c->stream, c->d_hrow_ptr,
+                         c->d_hcol, c->d_hval, L->d_chunks, view(c), c->d_wlong_rows, H, std::ldexp(1.0f, shift0 - c->vexp), c->d_bound);
+      HIP_TRY(hipGetLastError());
+      unsigned int amax = 0;
+      HIP_TRY(hipMemcpyAsync(&amax, c->d_bound, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      int s2 = shift0;
+      const double room = (double)(1LL << 30) - (double)L->worst_rows;
+      while (s2 < c->max_shift && std::ldexp((double)amax, s2 + 1 - shift0) <= room) ++s2;
+      L->shift = s2;
+    }
+    shift = L->shift;
+  }
+  const float main_scale = std::ldexp(1.0f, shift - c->vexp);
+  c->last_shift = shift;
+  CsrView mh = view(c);
+  mh.row_ptr = c->d_hrow_ptr;
+  mh.col = reinterpret_cast<const int*>(c->d_hcol);   // 16-bit ranks; the kernel reinterprets the pointer
+  mh.val = c->d_hval;
+  size_t slot = 0;
+  DSGD_TRY(prof_begin(c, &slot));
+  c->ctr_known = false;
+  hipLaunchKernelGGL(dsgd_fstep_kernel, grid, dim3(1024), lds, c->stream, mh, view(c), L->d_tiles, L->d_meta, L->d_ctiles, L->d_cmeta,
+                     (const void*)c->d_ccol, c->d_cval, L->d_chunks, c->d_w, c->d_g64, (long long)c->dp, c->d_sc, H, nc, main_scale,
+                     c->fix_scale, c->d_coef8, c->d_dcold, c->d_wlong_rows, c->d_part, c->part_stride, c->d_partc, c->partc_stride,
+                     c->d_tprof);
+  HIP_TRY(hipGetLastError());
+  DSGD_TRY(prof_end(c, slot));
+  c->last_grad_kernel = "dsgd_fstep_kernel";
+  DSGD_TRY(ensure_redpart(c));
+  c->fused_args = {H, n_wg, H, nc, n_wg, 1.0 / (double)main_scale, 1.0 / (double)c->fix_scale};
+  c->fused_apply_pending = true;   // launched by launch_finish_sync, which knows lr
+  return DSGD_OK;
+}
+
 static int hog_raise_stop(dsgd_ctx* c);
 
 // small-batch steps as ONE persistent workgroup (dsgd_plan_kernel): eligible when no collective sits between the
@@ -2262,14 +2482,19 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_REQ_MAPPED")) c->req_mapped = atoi(e) != 0;
   if (const char* e = getenv("DSGD_REQ_PLAN")) c->req_plan = atoi(e) != 0;
   if (const char* e = getenv("DSGD_STREAM_MIN")) c->stream_min = std::max(1LL, atoll(e));
+  if (const char* e = getenv("DSGD_FSTEP")) c->fstep_enable = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_FSTEP_MIN")) c->fstep_min = std::max(1LL, atoll(e));
+  if (const char* e = getenv("DSGD_FSTEP_MAX")) c->fstep_max = std::max(1LL, atoll(e));
+  if (const char* e = getenv("DSGD_FSTEP_ROWS")) c->fstep_rows = std::max(1LL, atoll(e));
   if (const char* e = getenv("DSGD_REQ_SPIN")) c->req_spin = atoi(e) != 0;
   if (const char* e = getenv("DSGD_CS_NT")) c->cs_nt = atoi(e) == CS_THREADS_NARROW ? CS_THREADS_NARROW : 0;
   if (const char* e = getenv("DSGD_VT_TPW")) c->vt_tpw = std::max(1, atoi(e));
   if (const char* e = getenv("DSGD_VT_PACK_MB")) c->vt_pack_mb = std::max(0, atoi(e));
   if (const char* e = getenv("DSGD_HSPLIT")) c->hsplit = atoi(e);                 // hot/cold split rank (tests: wide models)
   if (getenv("DSGD_PLAN_PROF") && atoi(getenv("DSGD_PLAN_PROF"))) {
-    HIP_TRY_B(hipMalloc(&c->d_tprof, sizeof(unsigned long long) * 16));
-    HIP_TRY_B(hipMemsetAsync(c->d_tprof, 0, sizeof(unsigned long long) * 16, c->stream));
+    // (16 counters + four words per workgroup of the chunked launch's LAST run: start, end, cycles in the hot tiles, XCC id)
+    HIP_TRY_B(hipMalloc(&c->d_tprof, sizeof(unsigned long long) * (16 + 4 * 1024)));
+    HIP_TRY_B(hipMemsetAsync(c->d_tprof, 0, sizeof(unsigned long long) * (16 + 4 * 1024), c->stream));
   }
   c->hsplit = std::max(1, std::min(c->hsplit, (DSGD_LDS_FLOATS - 16 * WS_COEF_STRIDE - 4 - 64) / 2));   // (< 65536: 16-bit ranks)
   if (c->hsplit >= 8) c->hsplit &= ~3;   // 16-byte aligned tile boundaries: the LDS tiles are staged / written back in 16-byte pieces
@@ -2292,6 +2517,8 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_wseg_kernel<true>);
   DSGD_ATTR(dsgd_wseg_kernel<false>);
   DSGD_ATTR(dsgd_wseg_bound_kernel);
+  DSGD_ATTR(dsgd_fstep_kernel);
+  DSGD_ATTR(dsgd_fstep_bound_kernel);
   DSGD_ATTR((dsgd_cold_kernel<true, false, false>));
   DSGD_ATTR((dsgd_cold_kernel<true, false, true>));
   DSGD_ATTR((dsgd_cold_kernel<false, false, false>));
@@ -2349,6 +2576,7 @@ int dsgd_destroy(dsgd_ctx* c) {
   (void)hipFree(c->d_coef8);
   (void)hipFree(c->d_wtiles);
   (void)hipFree(c->d_wmeta);
+  fstep_drop_all(c);
   (void)hipFree(c->d_wlong_rows);
   (void)hipFree(c->d_part);
   (void)hipFree(c->d_partc);
@@ -2891,10 +3119,14 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
   DSGD_TRY(prepare_layout(c));
   DSGD_TRY(ensure_g(c, n_workers));
   DSGD_TRY(ensure_s(c, true));
-  if (tot >= c->stream_min) {
+  std::vector<StreamSeg> ssegs(n_workers);
+  for (int k = 0; k < n_workers; ++k) ssegs[k] = make_sseg(row_begin[k], row_end[k]);
+  const int fwg = fstep_grid(c, ssegs, tot);
+  if (fwg > 0) {
+    // shards of 10^4 .. 2 * 10^6 rows: row chunks, the three passes of the split streams in ONE launch (csrc/dsgd_fstep.hpp)
+    DSGD_TRY(launch_fstep(c, ssegs, fwg));
+  } else if (tot >= c->stream_min) {
     // whole contiguous ranges: the nnz-streaming kernel (coalesced 16-byte loads, no per-row latency chain)
-    std::vector<StreamSeg> ssegs(n_workers);
-    for (int k = 0; k < n_workers; ++k) ssegs[k] = make_sseg(row_begin[k], row_end[k]);
     DSGD_TRY(launch_stream<true>(c, ssegs));  // (the profiling events bracket the main kernel only)
   } else {
     DSGD_TRY(upload_segs(c, segs));
@@ -4085,6 +4317,16 @@ int dsgd_debug_cycles(dsgd_ctx* c, uint64_t* out8, int32_t reset) {
   if (!c->d_tprof) return DSGD_OK;
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipMemcpy(out8, c->d_tprof, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+  if (const char* path = getenv("DSGD_FSTEP_DUMP")) {   // tuning runs: the per-workgroup words of the chunked launch's last run
+    std::vector<unsigned long long> v(4 * 1024);
+    HIP_TRY(hipMemcpy(v.data(), c->d_tprof + 16, sizeof(unsigned long long) * v.size(), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(path, "a")) {
+      fprintf(f, "# wg start end hot_tile_cycles xcc\n");
+      for (int i = 0; i < 1024; ++i)
+        if (v[4 * i + 1]) fprintf(f, "%d %llu %llu %llu %llu\n", i, v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+      fclose(f);
+    }
+  }
   if (reset) HIP_TRY(hipMemset(c->d_tprof, 0, sizeof(unsigned long long) * 16));
   return DSGD_OK;
 }

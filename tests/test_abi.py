@@ -144,5 +144,5 @@ def test_register_budget_of_the_async_engine_and_the_concurrent_loss_check(tmp_p
     assert len(hog) == 1 and len(evals) == 4
     assert 2 * alloc(hog[0]) + alloc(max(evals)) <= 512, (hog, evals)
     for k, v in vg.items():   # 1024-lane workgroups: 4 waves per SIMD
-        if "dsgd_plan_kernel" in k or "dsgd_wseg_kernel" in k:
+        if "dsgd_plan_kernel" in k or "dsgd_wseg_kernel" in k or "dsgd_fstep_kernel" in k:
             assert v <= 128, (k, v)

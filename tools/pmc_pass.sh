@@ -12,6 +12,6 @@ for P in "$@"; do
   echo "== pmc pass $i: $P" | tee -a $OUT/pmc_summary.txt
   ( cd /tmp && timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc$i -o pmc -- python $REPO/tools/pmc_step.py 8388608 3 > $OUT/pmc$i.out 2> $OUT/pmc$i.err )
   f=$(find $OUT/pmc$i -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then python tools/pmc_summary.py "$f" "dsgd_" | grep -E "wseg|cdot|cgrad" | tee -a $OUT/pmc_summary.txt; else tail -3 $OUT/pmc$i.err; fi
+  if [ -n "$f" ]; then python tools/pmc_summary.py "$f" "dsgd_" | grep -E "fstep|wseg|cold|reduce_apply" | tee -a $OUT/pmc_summary.txt; else tail -3 $OUT/pmc$i.err; fi
   rm -rf $OUT/pmc$i
 done

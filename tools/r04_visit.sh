@@ -93,7 +93,7 @@ benchprof)
   echo "== rocprofv3 kernel trace of the bench step"
   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sweep --no-parity-gate > $OUT/bench_prof.json 2> $OUT/bench_prof.err )
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv && head -8 "$f" | cut -c1-160
-  f=$(find $OUT/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && trace_summary "$f" > $OUT/dispatch_durations.txt && grep -E "wseg_kernel<true|cdot|cgrad|cold|reduce" $OUT/dispatch_durations.txt
+  f=$(find $OUT/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && trace_summary "$f" > $OUT/dispatch_durations.txt && grep -E "fstep|wseg_kernel<true|cdot|cgrad|cold|reduce" $OUT/dispatch_durations.txt
   rm -rf $OUT/prof ;;
 pmc)
   i=0
@@ -102,7 +102,7 @@ pmc)
     echo "== pmc pass $i: $P" | tee -a $OUT/pmc_summary.txt
     ( cd /tmp && timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc$i -o pmc -- python $REPO/tools/pmc_step.py 8388608 3 > $OUT/pmc$i.out 2> $OUT/pmc$i.err )
     f=$(find $OUT/pmc$i -name "*counter_collection.csv" | head -1)
-    [ -n "$f" ] && python tools/pmc_summary.py "$f" "dsgd_" | grep -E "wseg_kernel<true|cdot|cgrad|cold|reduce|apply|bound" | tee -a $OUT/pmc_summary.txt
+    [ -n "$f" ] && python tools/pmc_summary.py "$f" "dsgd_" | grep -E "fstep|wseg_kernel<true|cdot|cgrad|cold|reduce|apply|bound" | tee -a $OUT/pmc_summary.txt
     rm -rf $OUT/pmc$i $OUT/pmc$i.out $OUT/pmc$i.err
   done ;;
 streammin)
