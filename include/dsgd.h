@@ -154,7 +154,7 @@ int dsgd_plan_run(dsgd_ctx* ctx, dsgd_plan* plan, int64_t step_begin, int64_t st
  * row / column-list strides, [5] slots per lane, [6] 1 if the device laid it out, [7] words per step of the record.
  * n <= 8 slots.                                                                                                       */
 int dsgd_plan_info(dsgd_ctx* ctx, dsgd_plan* plan, int32_t* vals, int32_t n);
-/* Parity aid for LONG synchronous runs (nothing in the reference; tests/test_gpu_trajectory.py, bench.py): with the record
+/* Parity aid for LONG synchronous runs (nothing in the reference; tests/test_gpu_cs_device.py, tests/test_gpu_host.py, tests/test_sync_replay.py, bench.py): with the record
  * on, every step a column-slice plan runs leaves the GATE DECISION of each of its rows (bit r of the step's words: row r
  * of the step -- workers in order, each worker's list in order -- had y (x . w) >= 0, core/ml/SparseSVM.scala:27-28) and
  * the regulariser scalar s = 2 lambda (w . ds) it used (SparseSVM.scala:31).  fp32 against fp64 decides a row on the gate
