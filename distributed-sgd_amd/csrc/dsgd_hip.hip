@@ -124,6 +124,7 @@ static bool available() {
 #include "dsgd_cs.hpp"
 #include "dsgd_dense.hpp"
 #include "dsgd_fstep.hpp"
+#include "dsgd_tcol.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -325,6 +326,28 @@ struct dsgd_ctx {
                                      //    3.2 M 374 -> 343, 6.7 M 699 -> 663; at 18.5 K rows the row-wise kernel stays ahead: 37 vs 35-41)
   long long fstep_rows = 512;        // DSGD_FSTEP_ROWS: a chunk holds at least this many rows (fewer workgroups for small ranges:
                                      //   every workgroup moves 378 KB of LDS tiles in and out whatever its chunk)
+  // Column lists (csrc/dsgd_tcol.hpp): whole-split steps of 10^3 .. 10^5 rows as dot + column-wise gradient + reduce, no
+  // partials.  Per (row ranges) configuration the device sorts the ranges' entries by (worker, column) once; a few
+  // configurations stay cached.
+  struct TcolLayout {
+    std::vector<long long> ranges;   // row_begin, row_end per worker
+    long long gen = -1;              // layout_gen the ranked columns belong to
+    long long n_ent = 0;             // entries of the ranges' rows
+    int share = 0, n_wg = 0;         // entries per workgroup of the gradient kernel, its workgroups
+    int* d_ent_row = nullptr;
+    float* d_ent_val = nullptr;
+    unsigned int* d_ent_cid = nullptr;
+    int* d_key_of_cid = nullptr;
+    unsigned long long used = 0;
+  };
+  std::vector<TcolLayout> tcol_cache;
+  unsigned long long tcol_clock = 0;
+  signed char* d_tc_act = nullptr;   // n_rows: the gate's decision per row of the last column-list step
+  long long tc_act_rows = 0;
+  bool tcol_enable = true;           // DSGD_TCOL=0: such ranges through the row-wise kernel
+  long long tcol_min = 2048;         // DSGD_TCOL_MIN / DSGD_TCOL_MAX: row ranges of this many rows in total take the column lists
+  long long tcol_max = 65535;        //   (above: row chunks, dsgd_fstep.hpp)
+  int tcol_share = 0;                // DSGD_TCOL_SHARE: entries per workgroup of the gradient kernel (0: entries / CUs, within [1024, 8192])
   bool fused_apply_pending = false;
   FusedArgs fused_args{};
   float* d_redpart = nullptr;    // per-block partial sums of w.ds and |w|^2 of the fused reduce + apply kernel
@@ -1764,8 +1787,10 @@ static int upload_wave_tiles(dsgd_ctx* c, HostTiles& ht) {
 // split the ranked CSR into the hot stream (rank < hsplit) and the cold stream (rank - hsplit), both in row order with
 // wave tiles of whole rows; rows whose hot or cold part exceeds a wave tile stay on the long-row list and in neither.
 static void fstep_drop_all(dsgd_ctx* c);
+static void tcol_drop_all(dsgd_ctx* c);
 static int build_split(dsgd_ctx* c) {
-  fstep_drop_all(c);   // (the chunked tile tables index the streams built here)
+  fstep_drop_all(c);
+  tcol_drop_all(c);   // (sorted by the ranks about to change)   // (the chunked tile tables index the streams built here)
   (void)hipFree(c->d_hcol); (void)hipFree(c->d_hval); (void)hipFree(c->d_hrow_ptr);
   (void)hipFree(c->d_ccol); (void)hipFree(c->d_cval); (void)hipFree(c->d_ctp); (void)hipFree(c->d_ctiles); (void)hipFree(c->d_cmeta);
   (void)hipFree(c->d_dcold); (void)hipFree(c->d_coef8);
@@ -2325,6 +2350,171 @@ static int launch_fstep(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int
   return DSGD_OK;
 }
 
+// ---- column lists: whole-split steps of 10^3 .. 10^5 rows (csrc/dsgd_tcol.hpp) ----------------------------------------
+static void tcol_free(dsgd_ctx::TcolLayout& L) {
+  (void)hipFree(L.d_ent_row);
+  (void)hipFree(L.d_ent_val);
+  (void)hipFree(L.d_ent_cid);
+  (void)hipFree(L.d_key_of_cid);
+  L = dsgd_ctx::TcolLayout();
+}
+static void tcol_drop_all(dsgd_ctx* c) {   // (the ranked CSR is about to change, or the context goes away)
+  if (!c->tcol_cache.empty()) {
+    (void)hipStreamSynchronize(c->stream);
+    for (dsgd_ctx::TcolLayout& L : c->tcol_cache) tcol_free(L);
+    c->tcol_cache.clear();
+  }
+  (void)hipFree(c->d_tc_act);
+  c->d_tc_act = nullptr;
+  c->tc_act_rows = 0;
+}
+static bool tcol_wanted(const dsgd_ctx* c, long long tot, int n_workers) {
+  return c->tcol_enable && tot >= c->tcol_min && tot <= c->tcol_max && n_workers <= 64 && c->n_rows < (1LL << 31) &&
+         (long long)n_workers * c->dp < (1LL << 24);
+}
+// the layout of these ranges (c->d_segs holds them): 1 = not possible (too many entries, no memory: the caller's other path)
+static int tcol_layout(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long mx, dsgd_ctx::TcolLayout** out) {
+  const int n_workers = (int)segs.size();
+  std::vector<long long> key;
+  for (const WorkSeg& sg : segs) {
+    key.push_back(sg.begin);
+    key.push_back(sg.end);
+  }
+  for (dsgd_ctx::TcolLayout& L : c->tcol_cache)
+    if (L.gen == c->layout_gen && L.ranges == key) {
+      L.used = ++c->tcol_clock;
+      *out = &L;
+      return DSGD_OK;
+    }
+  for (size_t i = 0; i < c->tcol_cache.size();)   // layouts of an earlier ranking
+    if (c->tcol_cache[i].gen != c->layout_gen) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      tcol_free(c->tcol_cache[i]);
+      c->tcol_cache.erase(c->tcol_cache.begin() + (long)i);
+    } else {
+      ++i;
+    }
+  if (c->tcol_cache.size() >= 8) {   // the least recently used configuration makes room
+    size_t v = 0;
+    for (size_t i = 1; i < c->tcol_cache.size(); ++i)
+      if (c->tcol_cache[i].used < c->tcol_cache[v].used) v = i;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    tcol_free(c->tcol_cache[v]);
+    c->tcol_cache.erase(c->tcol_cache.begin() + (long)v);
+  }
+  const int n_keys = n_workers * c->dp;
+  unsigned int *d_cnt = nullptr, *d_cursor = nullptr;
+  int* d_cid = nullptr;
+  unsigned long long* d_tot = nullptr;
+  dsgd_ctx::TcolLayout L;
+  auto give_up = [&](int rc) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_cnt);
+    (void)hipFree(d_cursor);
+    (void)hipFree(d_cid);
+    (void)hipFree(d_tot);
+    tcol_free(L);
+    return rc;
+  };
+#define TC_SOFT(expr)                        \
+  do {                                       \
+    if ((expr) != hipSuccess) {              \
+      (void)hipGetLastError();               \
+      return give_up(1);                     \
+    }                                        \
+  } while (0)
+  TC_SOFT(hipMalloc(&d_cnt, sizeof(unsigned int) * (size_t)n_keys));
+  TC_SOFT(hipMalloc(&d_cursor, sizeof(unsigned int) * (size_t)n_keys));
+  TC_SOFT(hipMalloc(&d_cid, sizeof(int) * (size_t)n_keys));
+  TC_SOFT(hipMalloc(&d_tot, sizeof(unsigned long long) * 2));
+  TC_SOFT(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * (size_t)n_keys, c->stream));
+  const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((mx + TC_ROWS_PER_WG - 1) / TC_ROWS_PER_WG, 4096)), (unsigned)n_workers);
+  hipLaunchKernelGGL(dsgd_tc_count_kernel, grid, dim3(TC_THREADS), 0, c->stream, view(c), c->d_segs, c->dp, d_cnt);
+  hipLaunchKernelGGL(dsgd_tc_scan_kernel, dim3(1), dim3(TC_THREADS), 0, c->stream, d_cnt, n_keys, d_cursor, d_cid, d_tot);
+  TC_SOFT(hipGetLastError());
+  unsigned long long tot[2] = {0, 0};
+  TC_SOFT(hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, c->stream));
+  TC_SOFT(hipStreamSynchronize(c->stream));
+  if (tot[0] == 0 || tot[0] >= (1ULL << 31)) return give_up(1);
+  L.ranges = key;
+  L.gen = c->layout_gen;
+  L.n_ent = (long long)tot[0];
+  long long share = c->tcol_share > 0 ? c->tcol_share : (L.n_ent + c->n_cu - 1) / std::max(1, c->n_cu);
+  share = std::max<long long>(1024, std::min<long long>(TC_MAX_SHARE, (share + 63) & ~63LL));
+  if (c->tcol_share > 0) share = std::max<long long>(64, std::min<long long>(TC_MAX_SHARE, c->tcol_share));
+  L.share = (int)share;
+  L.n_wg = (int)((L.n_ent + share - 1) / share);
+  TC_SOFT(hipMalloc(&L.d_ent_row, sizeof(int) * (size_t)L.n_ent));
+  TC_SOFT(hipMalloc(&L.d_ent_val, sizeof(float) * (size_t)L.n_ent));
+  TC_SOFT(hipMalloc(&L.d_ent_cid, sizeof(unsigned int) * (size_t)L.n_ent));
+  TC_SOFT(hipMalloc(&L.d_key_of_cid, sizeof(int) * (size_t)std::max<unsigned long long>(1, tot[1])));
+  hipLaunchKernelGGL(dsgd_tc_fill_kernel, grid, dim3(TC_THREADS), 0, c->stream, view(c), c->d_segs, c->dp, d_cursor, d_cid, L.d_ent_row,
+                     L.d_ent_val, L.d_ent_cid, L.d_key_of_cid);
+  TC_SOFT(hipGetLastError());
+  TC_SOFT(hipStreamSynchronize(c->stream));
+#undef TC_SOFT
+  (void)hipFree(d_cnt);
+  (void)hipFree(d_cursor);
+  (void)hipFree(d_cid);
+  (void)hipFree(d_tot);
+  L.used = ++c->tcol_clock;
+  c->tcol_cache.push_back(L);
+  *out = &c->tcol_cache.back();
+  return DSGD_OK;
+}
+// the gradient of the ranges in c->d_segs by column lists; 1 = declined (nothing launched: the caller's other path)
+static int launch_tcol(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long mx) {
+  const int n_workers = (int)segs.size();
+  dsgd_ctx::TcolLayout* L = nullptr;
+  const int lrc = tcol_layout(c, segs, mx, &L);
+  if (lrc != DSGD_OK) return lrc;
+  if (c->tc_act_rows < c->n_rows) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_tc_act);
+    c->d_tc_act = nullptr;
+    c->tc_act_rows = 0;
+    HIP_TRY(hipMalloc(&c->d_tc_act, (size_t)std::max<long long>(c->n_rows, 1)));
+    c->tc_act_rows = c->n_rows;
+  }
+  const int shift = std::max(1, std::min(c->max_shift, 30));   // 64-bit sums: nothing to bound (|contribution| <= 2^shift)
+  c->last_shift = shift;
+  const float scale = std::ldexp(1.0f, shift - c->vexp);
+  size_t slot = 0;
+  DSGD_TRY(prof_begin(c, &slot));
+  c->ctr_known = false;
+  const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((mx + TC_ROWS_PER_WG - 1) / TC_ROWS_PER_WG, 4096)), (unsigned)n_workers);
+  hipLaunchKernelGGL(dsgd_tc_dot_kernel, grid, dim3(TC_THREADS), 0, c->stream, view(c), c->d_w, c->d_segs, c->d_tc_act, c->d_sc);
+  HIP_TRY(hipGetLastError());
+  TcGradArgs a;
+  a.ent_row = L->d_ent_row;
+  a.ent_val = L->d_ent_val;
+  a.ent_cid = L->d_ent_cid;
+  a.key_of_cid = L->d_key_of_cid;
+  a.act = c->d_tc_act;
+  a.g64 = c->d_g64;
+  a.n_ent = L->n_ent;
+  a.share = L->share;
+  a.scale = scale;
+  {
+    const dim3 g2((unsigned)L->n_wg);
+    const size_t lds = sizeof(long long) * (size_t)L->share;
+    const int nr = (L->share + TC_THREADS - 1) / TC_THREADS;
+    if (nr <= 1) hipLaunchKernelGGL(dsgd_tc_grad_kernel<1>, g2, dim3(TC_THREADS), lds, c->stream, a);
+    else if (nr <= 2) hipLaunchKernelGGL(dsgd_tc_grad_kernel<2>, g2, dim3(TC_THREADS), lds, c->stream, a);
+    else if (nr <= 4) hipLaunchKernelGGL(dsgd_tc_grad_kernel<4>, g2, dim3(TC_THREADS), lds, c->stream, a);
+    else if (nr <= 6) hipLaunchKernelGGL(dsgd_tc_grad_kernel<6>, g2, dim3(TC_THREADS), lds, c->stream, a);
+    else hipLaunchKernelGGL(dsgd_tc_grad_kernel<8>, g2, dim3(TC_THREADS), lds, c->stream, a);
+  }
+  HIP_TRY(hipGetLastError());
+  DSGD_TRY(prof_end(c, slot));
+  c->last_grad_kernel = "dsgd_tc_grad_kernel";
+  DSGD_TRY(ensure_redpart(c));
+  const double inv = 1.0 / (double)scale;
+  c->fused_args = {0, 0, (c->dp + 3) & ~3, 0, 0, inv, inv};   // no partials: the exact sums are in the 64-bit accumulators
+  c->fused_apply_pending = true;   // launched by launch_finish_sync, which knows lr
+  return DSGD_OK;
+}
+
 static int hog_raise_stop(dsgd_ctx* c);
 
 // small-batch steps as ONE persistent workgroup (dsgd_plan_kernel): eligible when no collective sits between the
@@ -2486,6 +2676,10 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_FSTEP_MIN")) c->fstep_min = std::max(1LL, atoll(e));
   if (const char* e = getenv("DSGD_FSTEP_MAX")) c->fstep_max = std::max(1LL, atoll(e));
   if (const char* e = getenv("DSGD_FSTEP_ROWS")) c->fstep_rows = std::max(1LL, atoll(e));
+  if (const char* e = getenv("DSGD_TCOL")) c->tcol_enable = atoi(e) != 0;
+  if (const char* e = getenv("DSGD_TCOL_MIN")) c->tcol_min = std::max(1LL, atoll(e));
+  if (const char* e = getenv("DSGD_TCOL_MAX")) c->tcol_max = std::max(1LL, atoll(e));
+  if (const char* e = getenv("DSGD_TCOL_SHARE")) c->tcol_share = std::max(0, atoi(e));
   if (const char* e = getenv("DSGD_REQ_SPIN")) c->req_spin = atoi(e) != 0;
   if (const char* e = getenv("DSGD_CS_NT")) c->cs_nt = atoi(e) == CS_THREADS_NARROW ? CS_THREADS_NARROW : 0;
   if (const char* e = getenv("DSGD_VT_TPW")) c->vt_tpw = std::max(1, atoi(e));
@@ -2519,6 +2713,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_wseg_bound_kernel);
   DSGD_ATTR(dsgd_fstep_kernel);
   DSGD_ATTR(dsgd_fstep_bound_kernel);
+  DSGD_ATTR(dsgd_tc_grad_kernel<8>);
   DSGD_ATTR((dsgd_cold_kernel<true, false, false>));
   DSGD_ATTR((dsgd_cold_kernel<true, false, true>));
   DSGD_ATTR((dsgd_cold_kernel<false, false, false>));
@@ -2577,6 +2772,7 @@ int dsgd_destroy(dsgd_ctx* c) {
   (void)hipFree(c->d_wtiles);
   (void)hipFree(c->d_wmeta);
   fstep_drop_all(c);
+  tcol_drop_all(c);
   (void)hipFree(c->d_wlong_rows);
   (void)hipFree(c->d_part);
   (void)hipFree(c->d_partc);
@@ -3130,7 +3326,10 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
     DSGD_TRY(launch_stream<true>(c, ssegs));  // (the profiling events bracket the main kernel only)
   } else {
     DSGD_TRY(upload_segs(c, segs));
-    DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx, true));
+    // 10^3 .. 10^5 rows: column lists (csrc/dsgd_tcol.hpp) -- dot, column-wise gradient, reduce: no partials
+    int trc = tcol_wanted(c, tot, n_workers) ? launch_tcol(c, segs, mx) : 1;
+    if (trc != DSGD_OK && trc != 1) return trc;
+    if (trc == 1) DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx, true));
   }
   if (finish) DSGD_TRY(launch_finish_sync(c, n_workers, lr));
   *total = tot;
