@@ -659,7 +659,8 @@ def roofline(eng, rows_key, n_train, nnz_train, bytes_per_row, kernel_ms, n_laun
     nnz_int, cold_int = eng.range_nnz(0, n_train)
     # the chunked launch (csrc/dsgd_fstep.hpp) walks BOTH streams: every non-zero of the step is its own; the three
     # streaming launches split them -- the dominant one (dsgd_wseg_kernel) reads the hot part
-    one_launch = eng.grad_kernel_name() == "dsgd_fstep_kernel"
+    # (the column lists, csrc/dsgd_tcol.hpp, likewise: their dot + gradient launches are bracketed together)
+    one_launch = eng.grad_kernel_name() in ("dsgd_fstep_kernel", "dsgd_tc_grad_kernel")
     own_nnz = nnz_train if one_launch else nnz_train - cold_int
     alg_bytes = (8.0 * own_nnz + 12.0 * n_train) / max(1.0, launches_per_step)  # per launch
     achieved = alg_bytes / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0

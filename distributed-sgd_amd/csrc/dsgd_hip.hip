@@ -334,19 +334,21 @@ struct dsgd_ctx {
     long long gen = -1;              // layout_gen the ranked columns belong to
     long long n_ent = 0;             // entries of the ranges' rows
     int share = 0, n_wg = 0;         // entries per workgroup of the gradient kernel, its workgroups
-    int* d_ent_row = nullptr;
+    int bm_words = 0;                // words of the step's bitmap (every worker's range padded to 64 rows; a multiple of 4)
+    unsigned int* d_ent_pk = nullptr;
     float* d_ent_val = nullptr;
-    unsigned int* d_ent_cid = nullptr;
+    TcShare* d_shares = nullptr;
     int* d_key_of_cid = nullptr;
+    int* d_bit_base = nullptr;       // [workers]
+    unsigned int* d_bitmap = nullptr;   // the gate's decisions of the last step over these ranges
     unsigned long long used = 0;
   };
   std::vector<TcolLayout> tcol_cache;
   unsigned long long tcol_clock = 0;
-  signed char* d_tc_act = nullptr;   // n_rows: the gate's decision per row of the last column-list step
-  long long tc_act_rows = 0;
   bool tcol_enable = true;           // DSGD_TCOL=0: such ranges through the row-wise kernel
   long long tcol_min = 2048;         // DSGD_TCOL_MIN / DSGD_TCOL_MAX: row ranges of this many rows in total take the column lists
   long long tcol_max = 65535;        //   (above: row chunks, dsgd_fstep.hpp)
+  int tcol_dot_wgs = 0;              // DSGD_TCOL_DOT_WGS: at most this many workgroups per worker in the dot kernel (0: one per 64 rows)
   int tcol_share = 0;                // DSGD_TCOL_SHARE: entries per workgroup of the gradient kernel (0: entries / CUs, within [1024, 8192])
   bool fused_apply_pending = false;
   FusedArgs fused_args{};
@@ -2352,25 +2354,26 @@ static int launch_fstep(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int
 
 // ---- column lists: whole-split steps of 10^3 .. 10^5 rows (csrc/dsgd_tcol.hpp) ----------------------------------------
 static void tcol_free(dsgd_ctx::TcolLayout& L) {
-  (void)hipFree(L.d_ent_row);
+  (void)hipFree(L.d_ent_pk);
   (void)hipFree(L.d_ent_val);
-  (void)hipFree(L.d_ent_cid);
+  (void)hipFree(L.d_shares);
   (void)hipFree(L.d_key_of_cid);
+  (void)hipFree(L.d_bit_base);
+  (void)hipFree(L.d_bitmap);
   L = dsgd_ctx::TcolLayout();
 }
 static void tcol_drop_all(dsgd_ctx* c) {   // (the ranked CSR is about to change, or the context goes away)
-  if (!c->tcol_cache.empty()) {
-    (void)hipStreamSynchronize(c->stream);
-    for (dsgd_ctx::TcolLayout& L : c->tcol_cache) tcol_free(L);
-    c->tcol_cache.clear();
-  }
-  (void)hipFree(c->d_tc_act);
-  c->d_tc_act = nullptr;
-  c->tc_act_rows = 0;
+  if (c->tcol_cache.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (dsgd_ctx::TcolLayout& L : c->tcol_cache) tcol_free(L);
+  c->tcol_cache.clear();
 }
 static bool tcol_wanted(const dsgd_ctx* c, long long tot, int n_workers) {
   return c->tcol_enable && tot >= c->tcol_min && tot <= c->tcol_max && n_workers <= 64 && c->n_rows < (1LL << 31) &&
-         (long long)n_workers * c->dp < (1LL << 24);
+         (long long)n_workers * c->dp < (1LL << 24) && tot + 64LL * n_workers <= TC_MAX_BITS;
+}
+static dim3 tcol_row_grid(long long mx, int n_workers) {
+  return dim3((unsigned)std::max<long long>(1, std::min<long long>((mx + TC_ROWS_PER_WG - 1) / TC_ROWS_PER_WG, 8192)), (unsigned)n_workers);
 }
 // the layout of these ranges (c->d_segs holds them): 1 = not possible (too many entries, no memory: the caller's other path)
 static int tcol_layout(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long mx, dsgd_ctx::TcolLayout** out) {
@@ -2403,13 +2406,14 @@ static int tcol_layout(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long 
     c->tcol_cache.erase(c->tcol_cache.begin() + (long)v);
   }
   const int n_keys = n_workers * c->dp;
-  unsigned int *d_cnt = nullptr, *d_cursor = nullptr;
+  unsigned int *d_cnt = nullptr, *d_ptr = nullptr, *d_cursor = nullptr;
   int* d_cid = nullptr;
   unsigned long long* d_tot = nullptr;
   dsgd_ctx::TcolLayout L;
   auto give_up = [&](int rc) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(d_cnt);
+    (void)hipFree(d_ptr);
     (void)hipFree(d_cursor);
     (void)hipFree(d_cid);
     (void)hipFree(d_tot);
@@ -2423,37 +2427,54 @@ static int tcol_layout(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long 
       return give_up(1);                     \
     }                                        \
   } while (0)
+  // every worker's rows padded to whole 64-row blocks of the bitmap (a workgroup of the dot kernel writes two whole words)
+  std::vector<int> bit_base((size_t)n_workers);
+  long long bits = 0;
+  for (int k = 0; k < n_workers; ++k) {
+    bit_base[(size_t)k] = (int)bits;
+    bits += ((segs[(size_t)k].end - segs[(size_t)k].begin + 63) / 64) * 64;
+  }
+  if (bits > TC_MAX_BITS) return give_up(1);
+  L.bm_words = (int)(((bits >> 5) + 3) & ~3LL);
   TC_SOFT(hipMalloc(&d_cnt, sizeof(unsigned int) * (size_t)n_keys));
+  TC_SOFT(hipMalloc(&d_ptr, sizeof(unsigned int) * ((size_t)n_keys + 1)));
   TC_SOFT(hipMalloc(&d_cursor, sizeof(unsigned int) * (size_t)n_keys));
   TC_SOFT(hipMalloc(&d_cid, sizeof(int) * (size_t)n_keys));
   TC_SOFT(hipMalloc(&d_tot, sizeof(unsigned long long) * 2));
+  TC_SOFT(hipMalloc(&L.d_bit_base, sizeof(int) * (size_t)n_workers));
+  TC_SOFT(hipMalloc(&L.d_bitmap, sizeof(unsigned int) * (size_t)L.bm_words));
+  TC_SOFT(hipMemcpyAsync(L.d_bit_base, bit_base.data(), sizeof(int) * (size_t)n_workers, hipMemcpyHostToDevice, c->stream));
+  TC_SOFT(hipMemsetAsync(L.d_bitmap, 0, sizeof(unsigned int) * (size_t)L.bm_words, c->stream));
   TC_SOFT(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * (size_t)n_keys, c->stream));
-  const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((mx + TC_ROWS_PER_WG - 1) / TC_ROWS_PER_WG, 4096)), (unsigned)n_workers);
+  const dim3 grid = tcol_row_grid(mx, n_workers);
   hipLaunchKernelGGL(dsgd_tc_count_kernel, grid, dim3(TC_THREADS), 0, c->stream, view(c), c->d_segs, c->dp, d_cnt);
-  hipLaunchKernelGGL(dsgd_tc_scan_kernel, dim3(1), dim3(TC_THREADS), 0, c->stream, d_cnt, n_keys, d_cursor, d_cid, d_tot);
+  hipLaunchKernelGGL(dsgd_tc_scan_kernel, dim3(1), dim3(TC_THREADS), 0, c->stream, d_cnt, n_keys, d_ptr, d_cursor, d_cid, d_tot);
   TC_SOFT(hipGetLastError());
   unsigned long long tot[2] = {0, 0};
   TC_SOFT(hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, c->stream));
-  TC_SOFT(hipStreamSynchronize(c->stream));
+  TC_SOFT(hipStreamSynchronize(c->stream));   // (also: bit_base is a local)
   if (tot[0] == 0 || tot[0] >= (1ULL << 31)) return give_up(1);
   L.ranges = key;
   L.gen = c->layout_gen;
   L.n_ent = (long long)tot[0];
-  long long share = c->tcol_share > 0 ? c->tcol_share : (L.n_ent + c->n_cu - 1) / std::max(1, c->n_cu);
+  long long share = (L.n_ent + c->n_cu - 1) / std::max(1, c->n_cu);
   share = std::max<long long>(1024, std::min<long long>(TC_MAX_SHARE, (share + 63) & ~63LL));
-  if (c->tcol_share > 0) share = std::max<long long>(64, std::min<long long>(TC_MAX_SHARE, c->tcol_share));
+  if (c->tcol_share > 0) share = std::max<long long>(64, std::min<long long>(TC_MAX_SHARE, (c->tcol_share + 1) & ~1));
   L.share = (int)share;
   L.n_wg = (int)((L.n_ent + share - 1) / share);
-  TC_SOFT(hipMalloc(&L.d_ent_row, sizeof(int) * (size_t)L.n_ent));
+  TC_SOFT(hipMalloc(&L.d_ent_pk, sizeof(unsigned int) * (size_t)L.n_ent));
   TC_SOFT(hipMalloc(&L.d_ent_val, sizeof(float) * (size_t)L.n_ent));
-  TC_SOFT(hipMalloc(&L.d_ent_cid, sizeof(unsigned int) * (size_t)L.n_ent));
+  TC_SOFT(hipMalloc(&L.d_shares, sizeof(TcShare) * (size_t)L.n_wg));
   TC_SOFT(hipMalloc(&L.d_key_of_cid, sizeof(int) * (size_t)std::max<unsigned long long>(1, tot[1])));
-  hipLaunchKernelGGL(dsgd_tc_fill_kernel, grid, dim3(TC_THREADS), 0, c->stream, view(c), c->d_segs, c->dp, d_cursor, d_cid, L.d_ent_row,
-                     L.d_ent_val, L.d_ent_cid, L.d_key_of_cid);
+  hipLaunchKernelGGL(dsgd_tc_shares_kernel, dim3((unsigned)((L.n_wg + 255) / 256)), dim3(256), 0, c->stream, d_ptr, d_cid, n_keys, L.n_ent,
+                     L.share, L.n_wg, L.d_shares);
+  hipLaunchKernelGGL(dsgd_tc_fill_kernel, grid, dim3(TC_THREADS), 0, c->stream, view(c), c->d_segs, c->dp, d_cursor, d_cid, L.d_shares, L.share,
+                     L.d_bit_base, L.d_ent_pk, L.d_ent_val, L.d_key_of_cid);
   TC_SOFT(hipGetLastError());
   TC_SOFT(hipStreamSynchronize(c->stream));
 #undef TC_SOFT
   (void)hipFree(d_cnt);
+  (void)hipFree(d_ptr);
   (void)hipFree(d_cursor);
   (void)hipFree(d_cid);
   (void)hipFree(d_tot);
@@ -2468,36 +2489,32 @@ static int launch_tcol(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long 
   dsgd_ctx::TcolLayout* L = nullptr;
   const int lrc = tcol_layout(c, segs, mx, &L);
   if (lrc != DSGD_OK) return lrc;
-  if (c->tc_act_rows < c->n_rows) {
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(c->d_tc_act);
-    c->d_tc_act = nullptr;
-    c->tc_act_rows = 0;
-    HIP_TRY(hipMalloc(&c->d_tc_act, (size_t)std::max<long long>(c->n_rows, 1)));
-    c->tc_act_rows = c->n_rows;
-  }
   const int shift = std::max(1, std::min(c->max_shift, 30));   // 64-bit sums: nothing to bound (|contribution| <= 2^shift)
   c->last_shift = shift;
   const float scale = std::ldexp(1.0f, shift - c->vexp);
   size_t slot = 0;
   DSGD_TRY(prof_begin(c, &slot));
   c->ctr_known = false;
-  const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((mx + TC_ROWS_PER_WG - 1) / TC_ROWS_PER_WG, 4096)), (unsigned)n_workers);
-  hipLaunchKernelGGL(dsgd_tc_dot_kernel, grid, dim3(TC_THREADS), 0, c->stream, view(c), c->d_w, c->d_segs, c->d_tc_act, c->d_sc);
+  dim3 dgrid = tcol_row_grid(mx, n_workers);
+  if (c->tcol_dot_wgs > 0) dgrid.x = (unsigned)std::min<long long>(dgrid.x, c->tcol_dot_wgs);
+  hipLaunchKernelGGL(dsgd_tc_dot_kernel, dgrid, dim3(TC_THREADS), 0, c->stream, view(c), c->d_w, c->d_segs,
+                     L->d_bit_base, L->d_bitmap, std::min(TC_WL, c->dp & ~3));
   HIP_TRY(hipGetLastError());
   TcGradArgs a;
-  a.ent_row = L->d_ent_row;
+  a.ent_pk = L->d_ent_pk;
   a.ent_val = L->d_ent_val;
-  a.ent_cid = L->d_ent_cid;
+  a.shares = L->d_shares;
   a.key_of_cid = L->d_key_of_cid;
-  a.act = c->d_tc_act;
+  a.bitmap = L->d_bitmap;
   a.g64 = c->d_g64;
+  a.sc = c->d_sc;
   a.n_ent = L->n_ent;
   a.share = L->share;
+  a.bm_words = L->bm_words;
   a.scale = scale;
   {
     const dim3 g2((unsigned)L->n_wg);
-    const size_t lds = sizeof(long long) * (size_t)L->share;
+    const size_t lds = sizeof(long long) * (size_t)L->share + sizeof(unsigned int) * (size_t)L->bm_words + 64;
     const int nr = (L->share + TC_THREADS - 1) / TC_THREADS;
     if (nr <= 1) hipLaunchKernelGGL(dsgd_tc_grad_kernel<1>, g2, dim3(TC_THREADS), lds, c->stream, a);
     else if (nr <= 2) hipLaunchKernelGGL(dsgd_tc_grad_kernel<2>, g2, dim3(TC_THREADS), lds, c->stream, a);
@@ -2680,6 +2697,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_TCOL_MIN")) c->tcol_min = std::max(1LL, atoll(e));
   if (const char* e = getenv("DSGD_TCOL_MAX")) c->tcol_max = std::max(1LL, atoll(e));
   if (const char* e = getenv("DSGD_TCOL_SHARE")) c->tcol_share = std::max(0, atoi(e));
+  if (const char* e = getenv("DSGD_TCOL_DOT_WGS")) c->tcol_dot_wgs = std::max(0, atoi(e));
   if (const char* e = getenv("DSGD_REQ_SPIN")) c->req_spin = atoi(e) != 0;
   if (const char* e = getenv("DSGD_CS_NT")) c->cs_nt = atoi(e) == CS_THREADS_NARROW ? CS_THREADS_NARROW : 0;
   if (const char* e = getenv("DSGD_VT_TPW")) c->vt_tpw = std::max(1, atoi(e));
@@ -2713,7 +2731,16 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_wseg_bound_kernel);
   DSGD_ATTR(dsgd_fstep_kernel);
   DSGD_ATTR(dsgd_fstep_bound_kernel);
-  DSGD_ATTR(dsgd_tc_grad_kernel<8>);
+  {   // the column lists' gradient kernel: its table, the bitmap, 16 words
+    const int tc_lds = (int)(sizeof(long long) * TC_MAX_SHARE + TC_MAX_BITS / 8 + 64);
+#define DSGD_ATTR_TC(fn) HIP_TRY_B(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, tc_lds))
+    DSGD_ATTR_TC(dsgd_tc_grad_kernel<1>);
+    DSGD_ATTR_TC(dsgd_tc_grad_kernel<2>);
+    DSGD_ATTR_TC(dsgd_tc_grad_kernel<4>);
+    DSGD_ATTR_TC(dsgd_tc_grad_kernel<6>);
+    DSGD_ATTR_TC(dsgd_tc_grad_kernel<8>);
+#undef DSGD_ATTR_TC
+  }
   DSGD_ATTR((dsgd_cold_kernel<true, false, false>));
   DSGD_ATTR((dsgd_cold_kernel<true, false, true>));
   DSGD_ATTR((dsgd_cold_kernel<false, false, false>));
@@ -3317,8 +3344,16 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
   DSGD_TRY(ensure_s(c, true));
   std::vector<StreamSeg> ssegs(n_workers);
   for (int k = 0; k < n_workers; ++k) ssegs[k] = make_sseg(row_begin[k], row_end[k]);
-  const int fwg = fstep_grid(c, ssegs, tot);
-  if (fwg > 0) {
+  // 10^3 .. 10^5 rows: column lists (csrc/dsgd_tcol.hpp) -- dot, column-wise gradient, reduce: no partials
+  int trc = 1;
+  if (tcol_wanted(c, tot, n_workers)) {
+    DSGD_TRY(upload_segs(c, segs));
+    trc = launch_tcol(c, segs, mx);
+    if (trc != DSGD_OK && trc != 1) return trc;
+  }
+  const int fwg = trc == 1 ? fstep_grid(c, ssegs, tot) : 0;
+  if (trc == DSGD_OK) {
+  } else if (fwg > 0) {
     // shards of 10^4 .. 2 * 10^6 rows: row chunks, the three passes of the split streams in ONE launch (csrc/dsgd_fstep.hpp)
     DSGD_TRY(launch_fstep(c, ssegs, fwg));
   } else if (tot >= c->stream_min) {
@@ -3326,10 +3361,7 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
     DSGD_TRY(launch_stream<true>(c, ssegs));  // (the profiling events bracket the main kernel only)
   } else {
     DSGD_TRY(upload_segs(c, segs));
-    // 10^3 .. 10^5 rows: column lists (csrc/dsgd_tcol.hpp) -- dot, column-wise gradient, reduce: no partials
-    int trc = tcol_wanted(c, tot, n_workers) ? launch_tcol(c, segs, mx) : 1;
-    if (trc != DSGD_OK && trc != 1) return trc;
-    if (trc == 1) DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx, true));
+    DSGD_TRY(launch_grad(c, nullptr, c->d_segs, n_workers, mx, true));
   }
   if (finish) DSGD_TRY(launch_finish_sync(c, n_workers, lr));
   *total = tot;

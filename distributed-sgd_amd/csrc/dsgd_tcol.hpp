@@ -11,15 +11,19 @@
 // set-ups per workgroup for 10 us of tiles.  A whole-split step repeats the SAME rows every time, so the transposed
 // matrix can be laid out once per (ranges) configuration and the gradient taken COLUMN by column, where a sum is local:
 //
-//   dsgd_tc_dot_kernel    one 16-lane group per row: x.w with the weights gathered from L2 (189 KB: resident), the
-//                         gate (core/ml/SparseSVM.scala:27-28), ONE byte per row out: active or not.  No LDS, no set-up.
-//   dsgd_tc_grad_kernel   the entries of the ranges' rows SORTED BY (worker, column) -- {row, y * value, column id} --
-//                         cut into equal shares, one per workgroup.  A share covers a contiguous run of columns: its
-//                         fixed-point sums live in an LDS table indexed by (column - first column of the share), exact
+//   dsgd_tc_dot_kernel    one 16-lane group per row, 64 consecutive rows per workgroup: x.w with the 4,096 hottest
+//                         weights (79 % of RCV1-like non-zeros) from a 16 KB LDS copy and the rest gathered from L2, the
+//                         gate (core/ml/SparseSVM.scala:27-28), ONE BIT per row out -- the workgroup's 64 rows are two
+//                         whole words of the step's bitmap: plain stores, nothing to clear between steps.
+//   dsgd_tc_grad_kernel   the entries of the ranges' rows SORTED BY (worker, column) -- 8 bytes each: {bit of the row,
+//                         column relative to the share's first} packed, y * value -- cut into equal shares, one per
+//                         workgroup.  The bitmap (rows / 8 bytes) is copied into LDS; a share covers a contiguous run of
+//                         columns: its fixed-point sums live in an LDS table indexed by the relative column, exact
 //                         64-bit integers (no bound to derive), a wave whose 64 entries fall into ONE column (the hot
 //                         head) adds its sum once.  A column wholly inside a share is written to the worker's 64-bit
 //                         global accumulator by that share alone; a column cut by a share boundary gets one atomic per
-//                         share.  No partials: D words leave the launch, not workgroups x D.
+//                         share.  No partials: D words leave the launch, not workgroups x D.  Workgroup 0 counts the
+//                         bitmap's bits: the step's active rows, one atomic.
 //   dsgd_fix_reduce_apply_kernel (as behind every other gradient kernel, with zero partials): one rounding of each exact
 //                         sum, the support-only regulariser, the fold over the workers, mean, update, the next scalar.
 //
@@ -34,10 +38,18 @@
 constexpr int TC_G = 16;                 // lanes per row
 constexpr int TC_UNR = 5;                // register-held rounds of a row: 80 non-zeros (RCV1's mean row: 75)
 constexpr int TC_THREADS = 1024;
-constexpr int TC_ROWS_PER_WG = TC_THREADS / TC_G;
+constexpr int TC_ROWS_PER_WG = TC_THREADS / TC_G;   // 64: two words of the bitmap
 constexpr int TC_MAX_SHARE = 8192;       // entries per workgroup of the gradient kernel: 64 KB of LDS for its 64-bit table
+constexpr int TC_DC_BITS = 13;           // packed entry: relative column (< TC_MAX_SHARE) below, bit of the row above
+constexpr int TC_MAX_BITS = 1 << (32 - TC_DC_BITS);   // 524,288 bits of bitmap (every worker's range padded to 64 rows)
+constexpr int TC_WL = 4096;              // hottest ranks with an LDS copy of their weight in the dot kernel (one 16-byte piece per lane)
 
-// ---- the layout: count, scan, fill ---------------------------------------------------------------------------------
+struct TcShare {     // per share of the gradient kernel
+  unsigned int cid0; // compact id of its first column
+  int n_local;       // columns it touches
+};
+
+// ---- the layout: count, scan, shares, fill ---------------------------------------------------------------------------
 // grid (x, workers): a 16-lane group per row of worker blockIdx.y's range
 __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_count_kernel(CsrView m, const WorkSeg* __restrict__ segs, int dp,
                                                                   unsigned int* __restrict__ cnt) {
@@ -50,10 +62,11 @@ __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_count_kernel(CsrView m, co
     for (long long p = m.row_ptr[row] + sub; p < m.row_ptr[row + 1]; p += TC_G) atomicAdd(&mine[m.col[p]], 1u);
 }
 
-// ONE workgroup: cursor[key] = entries in front of key's first; cid[key] = non-empty keys in front of it; totals = {entries, non-empty keys}
+// ONE workgroup: ptr[key] = cursor[key] = entries in front of key's first (ptr[n_keys] = all); cid[key] = non-empty keys in
+// front of it; totals = {entries, non-empty keys}
 __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_scan_kernel(const unsigned int* __restrict__ cnt, int n_keys,
-                                                                 unsigned int* __restrict__ cursor, int* __restrict__ cid,
-                                                                 unsigned long long* __restrict__ totals) {
+                                                                 unsigned int* __restrict__ ptr, unsigned int* __restrict__ cursor,
+                                                                 int* __restrict__ cid, unsigned long long* __restrict__ totals) {
   __shared__ unsigned long long se[TC_THREADS];
   __shared__ unsigned int sn[TC_THREADS];
   const int tid = threadIdx.x;
@@ -69,7 +82,7 @@ __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_scan_kernel(const unsigned
   se[tid] = e;
   sn[tid] = n;
   __syncthreads();
-  // exclusive prefix over the 1024 per-thread totals (Hillis-Steele in LDS: once per configuration)
+  // inclusive prefix over the 1024 per-thread totals (Hillis-Steele in LDS: once per configuration)
   for (int off = 1; off < TC_THREADS; off <<= 1) {
     unsigned long long ae = 0;
     unsigned int an = 0;
@@ -86,64 +99,112 @@ __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_scan_kernel(const unsigned
   unsigned int bn = sn[tid] - n;
   for (int k = k0; k < k1; ++k) {
     const unsigned int c = cnt[k];
+    ptr[k] = (unsigned int)be;
     cursor[k] = (unsigned int)be;
     cid[k] = (int)bn;
     be += c;
     bn += c != 0u;
   }
   if (tid == TC_THREADS - 1) {
+    ptr[n_keys] = (unsigned int)se[tid];
     totals[0] = se[tid];
     totals[1] = sn[tid];
   }
 }
 
-// the entries to their places: {row, y * value, compact column id}; key_of_cid[id] = worker * dp + column
+// the key that holds entry position `pos`: the LAST key with ptr[key] <= pos (empty keys share their ptr with the next)
+__device__ __forceinline__ int tc_key_at(const unsigned int* __restrict__ ptr, int n_keys, unsigned int pos) {
+  int lo = 0, hi = n_keys;   // first key with ptr[key] > pos
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (ptr[mid] > pos) hi = mid;
+    else lo = mid + 1;
+  }
+  return lo - 1;
+}
+// one lane per share: the compact ids of its first and last column
+__global__ void __launch_bounds__(256) dsgd_tc_shares_kernel(const unsigned int* __restrict__ ptr, const int* __restrict__ cid,
+                                                            int n_keys, long long n_ent, int share, int n_shares,
+                                                            TcShare* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_shares) return;
+  const long long e0 = (long long)b * share;
+  const long long e1 = e0 + share < n_ent ? e0 + share : n_ent;
+  const int c0 = cid[tc_key_at(ptr, n_keys, (unsigned int)e0)], c1 = cid[tc_key_at(ptr, n_keys, (unsigned int)(e1 - 1))];
+  TcShare r;
+  r.cid0 = (unsigned int)c0;
+  r.n_local = c1 - c0 + 1;
+  out[b] = r;
+}
+
+// the entries to their places: {bit of the row << 13 | column relative to the share's first, y * value};
+// key_of_cid[id] = worker * dp + column.  bit_base[k]: first bit of worker k's rows in the step's bitmap.
 __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_fill_kernel(CsrView m, const WorkSeg* __restrict__ segs, int dp,
                                                                  unsigned int* __restrict__ cursor, const int* __restrict__ cid,
-                                                                 int* __restrict__ ent_row, float* __restrict__ ent_val,
-                                                                 unsigned int* __restrict__ ent_cid, int* __restrict__ key_of_cid) {
+                                                                 const TcShare* __restrict__ shares, int share,
+                                                                 const int* __restrict__ bit_base,
+                                                                 unsigned int* __restrict__ ent_pk, float* __restrict__ ent_val,
+                                                                 int* __restrict__ key_of_cid) {
   const WorkSeg sg = segs[blockIdx.y];
   const int sub = threadIdx.x & (TC_G - 1);
   const long long group = ((long long)blockIdx.x * TC_THREADS + threadIdx.x) / TC_G;
   const long long n_groups = (long long)gridDim.x * TC_ROWS_PER_WG;
   const long long kbase = (long long)blockIdx.y * dp;
+  const unsigned int bb = (unsigned int)bit_base[blockIdx.y];
   for (long long row = sg.begin + group; row < sg.end; row += n_groups) {
     const float y = (float)m.label[row];
+    const unsigned int bit = bb + (unsigned int)(row - sg.begin);
     for (long long p = m.row_ptr[row] + sub; p < m.row_ptr[row + 1]; p += TC_G) {
       const long long key = kbase + m.col[p];
       const unsigned int at = atomicAdd(&cursor[key], 1u);
       const int id = cid[key];
-      ent_row[at] = (int)row;
+      const unsigned int dc = (unsigned int)id - shares[at / (unsigned int)share].cid0;
+      ent_pk[at] = (bit << TC_DC_BITS) | dc;
       ent_val[at] = y * m.val[p];          // (+-1 times a value: exact)
-      ent_cid[at] = (unsigned int)id;
       key_of_cid[id] = (int)key;           // (every entry of the column stores the same word)
     }
   }
 }
 
-// ---- pass 1: x.w and the gate, one byte per row ---------------------------------------------------------------------
+// ---- pass 1: x.w and the gate, one bit per row ----------------------------------------------------------------------
 // ref: math/Vec.scala:58 -> math/Sparse.scala:46 (the products filtered at 1e-20), core/ml/SparseSVM.scala:27-28 (the gate)
+// grid (x, workers); workgroup (x, k) owns the 64-row blocks x, x + gridDim.x, ... of worker k: block b = the rows
+// sg.begin + 64 b .. + 63 = words bit_base[k] / 32 + 2 b and the next of the bitmap (bits beyond the range's last row: zero).
+// (A persistent form -- two workgroups per CU walking their blocks with the next block's row records and non-zeros
+//  requested ahead, LDS-only barriers -- was measured SLOWER: 10.0 -> 20.4 us at 18,519 rows, 22 -> 52 at 80,441.  The
+//  kernel is not waiting for round trips, it is at the texture addresser's instruction rate -- 18 four-byte load
+//  instructions per wave and block -- and the requests a prefetch issues for blocks that do not exist are instructions too.)
 __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_dot_kernel(CsrView m, const float* __restrict__ w,
-                                                                const WorkSeg* __restrict__ segs, signed char* __restrict__ act,
-                                                                DevScalars* __restrict__ sc) {
-  __shared__ unsigned int wg_active;
+                                                                const WorkSeg* __restrict__ segs, const int* __restrict__ bit_base,
+                                                                unsigned int* __restrict__ bitmap, int wl) {
+  __shared__ __attribute__((aligned(16))) float wlds[TC_WL];
+  __shared__ unsigned int mask[2];
   const WorkSeg sg = segs[blockIdx.y];
-  const int sub = threadIdx.x & (TC_G - 1);
-  const long long group = ((long long)blockIdx.x * TC_THREADS + threadIdx.x) / TC_G;
-  const long long n_groups = (long long)gridDim.x * TC_ROWS_PER_WG;
-  if (threadIdx.x == 0) wg_active = 0u;
-  __syncthreads();
-  unsigned int n_act = 0;
-  for (long long row = sg.begin + group; row < sg.end; row += n_groups) {
+  const int tid = threadIdx.x, sub = tid & (TC_G - 1), grp = tid >> 4;
+  unsigned int* words = bitmap + (bit_base[blockIdx.y] >> 5);
+  // the hottest weights: one 16-byte piece per lane, requested first, stored behind the row's own requests
+  const float4 wpiece = reinterpret_cast<const float4*>(w)[4 * tid < wl ? tid : 0];
+  bool staged = false;
+  typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
+  for (long long blk = blockIdx.x; blk * TC_ROWS_PER_WG < sg.end - sg.begin; blk += gridDim.x) {
+    const long long row = sg.begin + blk * TC_ROWS_PER_WG + grp;
+    const bool in_range = row < sg.end;
+    const long long rowc = in_range ? row : sg.end - 1;
     // every request unconditional, positions clamped into the row (the internal CSR holds no empty row), a lane's surplus
     // values zeroed: behind a conditional load the compiler waits for each gather on its own -- five dependent L2 round
     // trips per row instead of one
-    const long long st = m.row_ptr[row], en = m.row_ptr[row + 1];
-    const float y = (float)m.label[row];
+    const long long st = m.row_ptr[rowc], en = m.row_ptr[rowc + 1];
+    const float y = (float)m.label[rowc];
+    if (tid < 2) mask[tid] = 0u;
+    if (!staged) {
+      if (4 * tid < wl) reinterpret_cast<float4*>(wlds)[tid] = wpiece;
+      staged = true;
+    }
+    __syncthreads();
     float acc = 0.0f;
     for (long long p0 = st + sub; p0 - sub < en; p0 += TC_UNR * TC_G) {   // (one round for rows of up to 80 non-zeros)
       int cc[TC_UNR];
-      float vv[TC_UNR], ww[TC_UNR];
+      float vv[TC_UNR], wg[TC_UNR], wh[TC_UNR];
 #pragma unroll
       for (int k = 0; k < TC_UNR; ++k) {
         const long long p = p0 + k * TC_G;
@@ -152,82 +213,102 @@ __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_dot_kernel(CsrView m, cons
         vv[k] = m.val[pc];
         vv[k] = p < en ? vv[k] : 0.0f;
       }
+      // hot ranks from the LDS copy, the rest from L2 -- with UNCONDITIONAL global loads (the hot lanes all read w[0]: one
+      // line): a fully divergent 4-byte gather costs the texture path 64 cycles per wave instruction
 #pragma unroll
-      for (int k = 0; k < TC_UNR; ++k) ww[k] = w[cc[k]];
+      for (int k = 0; k < TC_UNR; ++k) wg[k] = w[cc[k] < wl ? 0 : cc[k]];
 #pragma unroll
-      for (int k = 0; k < TC_UNR; ++k) acc += filt(vv[k] * ww[k]);   // ref: math/Sparse.scala:46 (products filtered at 1e-20)
+      for (int k = 0; k < TC_UNR; ++k) wh[k] = ((lds_cvfloat*)wlds)[cc[k] < wl ? cc[k] : 0];
+#pragma unroll
+      for (int k = 0; k < TC_UNR; ++k) acc += filt(vv[k] * (cc[k] < wl ? wh[k] : wg[k]));   // ref: math/Sparse.scala:46
     }
     const float d = group_sum<TC_G>(acc);
     const float yd = y * d;
-    const bool active = !(yd < 0.0f);
-    if (sub == 0) {
-      act[row] = active ? 1 : 0;
-      n_act += active ? 1u : 0u;
-    }
+    const bool active = in_range && !(yd < 0.0f);
+    if (sub == 0 && active) atomicOr(&mask[grp >> 5], 1u << (grp & 31));
+    __syncthreads();
+    if (tid < 2) words[2 * blk + tid] = mask[tid];
   }
-  n_act = wave_sum_u32(n_act);
-  if ((threadIdx.x & 63) == 0 && n_act) atomicAdd(&wg_active, n_act);
-  __syncthreads();
-  if (threadIdx.x == 0 && wg_active) atomicAdd(&sc->n_active, (unsigned long long)wg_active);   // one atomic per workgroup
 }
 
 // ---- pass 2: the gradient, column by column -------------------------------------------------------------------------
 // ref: core/Slave.scala:147-153 (Vec.sum of the gated sub-gradients), column-major
 struct TcGradArgs {
-  const int* ent_row;
+  const unsigned int* ent_pk;
   const float* ent_val;
-  const unsigned int* ent_cid;
+  const TcShare* shares;
   const int* key_of_cid;
-  const signed char* act;
+  const unsigned int* bitmap;
   long long* g64;            // [workers][dp] 64-bit fixed-point accumulators, zero between steps: index = key
+  DevScalars* sc;
   long long n_ent;
   int share;                 // entries per workgroup (<= TC_MAX_SHARE)
+  int bm_words;              // words of the bitmap (a multiple of 4)
   float scale;               // 2^shift / vmax2
 };
 
-// NR: rounds of 1024 entries a share holds at most.  No loop: ALL of a lane's entries are requested at once, then all of
-// their rows' gate bytes -- two dependent round trips per workgroup, whatever the share.
+// NR: rounds of 1024 entries a share holds at most.  No loop: ALL of a lane's entries are requested at once, next to the
+// bitmap -- one round trip per workgroup, whatever the share.
 template <int NR>
 __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_grad_kernel(TcGradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) long long tc_tab[];   // [share]
+  extern __shared__ __attribute__((aligned(16))) long long tc_tab[];   // [share], then the bitmap, then 16 words
+  unsigned int* bm = reinterpret_cast<unsigned int*>(tc_tab + a.share);
+  unsigned int* red = bm + a.bm_words;   // [16] (in the dynamic allocation: the launch sizes it)
   const int tid = threadIdx.x;
   const long long e0 = (long long)blockIdx.x * a.share;
   const long long e1 = e0 + a.share < a.n_ent ? e0 + a.share : a.n_ent;
   if (e0 >= e1) return;
-  int row[NR];
+  unsigned int pk[NR];
   float val[NR];
-  unsigned int cid[NR];
 #pragma unroll
   for (int u = 0; u < NR; ++u) {   // (clamped: a lane beyond the share re-reads its last entry and contributes nothing)
     const long long e = e0 + tid + (long long)u * TC_THREADS;
     const long long ec = e < e1 ? e : e1 - 1;
-    row[u] = a.ent_row[ec];
+    pk[u] = a.ent_pk[ec];
     val[u] = a.ent_val[ec];
-    cid[u] = a.ent_cid[ec];
   }
-  const unsigned int cid0 = a.ent_cid[e0], cid1 = a.ent_cid[e1 - 1];   // (sorted by column id: the share's first and last)
-  int on[NR];
-#pragma unroll
-  for (int u = 0; u < NR; ++u) on[u] = (int)a.act[row[u]];
-  const int n_local = (int)(cid1 - cid0) + 1;
-  for (int j = tid; j < n_local; j += TC_THREADS) tc_tab[j] = 0;
-#pragma unroll
-  for (int u = 0; u < NR; ++u) asm volatile("" : "+v"(on[u]));   // (the gate bytes stay requested together, up there)
-  __syncthreads();
-  // where the table's sums go: requested now, used behind the adds (in the write-out loop each would be a round trip of
-  // its own, behind the atomics of the round before)
+  const TcShare sh = a.shares[blockIdx.x];
+  const int n_local = sh.n_local;
+  // where the table's sums go: requested now, used behind the adds
   int key[NR];
 #pragma unroll
   for (int u = 0; u < NR; ++u) {
     const int j = tid + u * TC_THREADS;
-    key[u] = a.key_of_cid[cid0 + (unsigned int)(j < n_local ? j : n_local - 1)];
+    key[u] = a.key_of_cid[sh.cid0 + (unsigned int)(j < n_local ? j : n_local - 1)];
+  }
+  // the step's gate decisions: rows / 8 bytes, every workgroup its own copy
+  unsigned int n_act = 0;
+  {
+    const uint4* b4 = reinterpret_cast<const uint4*>(a.bitmap);
+    const int n4 = a.bm_words >> 2;
+    for (int i = tid; i < n4; i += TC_THREADS) {
+      const uint4 v = b4[i];
+      reinterpret_cast<uint4*>(bm)[i] = v;
+      n_act += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+  }
+  for (int j = tid; j < n_local; j += TC_THREADS) tc_tab[j] = 0;
+  if (blockIdx.x == 0) {   // (workgroup-uniform) the step's active rows: one atomic
+    n_act = wave_sum_u32(n_act);
+    if ((tid & 63) == 0) red[tid >> 6] = n_act;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0) {
+    unsigned int t = 0;
+    for (int i = 0; i < TC_THREADS / 64; ++i) t += red[i];
+    if (t) atomicAdd(&a.sc->n_active, (unsigned long long)t);
   }
 #pragma unroll
   for (int u = 0; u < NR; ++u) {
     const long long e = e0 + tid + (long long)u * TC_THREADS;
-    const int dc = (int)(cid[u] - cid0);
-    const int q = (e < e1 && on[u]) ? __float2int_rn(val[u] * a.scale) : 0;
-    // a wave inside ONE column (the head of the ranking: thousands of entries per column): one add for its 64 entries
+    const int dc = (int)(pk[u] & ((1u << TC_DC_BITS) - 1u));
+    const unsigned int bit = pk[u] >> TC_DC_BITS;
+    const bool on = ((bm[bit >> 5] >> (bit & 31u)) & 1u) != 0u;
+    const int q = (e < e1 && on) ? __float2int_rn(val[u] * a.scale) : 0;
+    // a wave inside ONE column (the head of the ranking: thousands of entries per column): one add for its 64 entries.
+    // (A segmented sum over the runs of equal columns in front of the adds -- one add per run -- was measured SLOWER:
+    //  twelve lane exchanges per round cost more than the same-address adds they save: 5.5 -> 7.2 us at 18,519 rows,
+    //  20.9 -> 27.6 at 80,441.)
     const int dcf = __builtin_amdgcn_readfirstlane(dc);
     if (__all(dc == dcf || q == 0)) {
       int s = q;

@@ -21,6 +21,13 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="no gfx9
 FSTEP = "dsgd_fstep_kernel"
 
 
+@pytest.fixture(autouse=True)
+def _no_column_lists(monkeypatch):
+    """Ranges below 65,536 rows are the column lists' in the product (tests/test_gpu_tcol.py); this module forces the
+    chunked launch onto them."""
+    monkeypatch.setenv("DSGD_TCOL", "0")
+
+
 def some_weights(dim, seed, n=8000, scale=0.05):
     rng = np.random.default_rng(seed)
     w0 = np.zeros(dim + 1, dtype=np.float32)

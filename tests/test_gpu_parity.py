@@ -47,7 +47,9 @@ def _row_parallel_kernels_of_resident_plans():
             # kernels all the same).  test_row_ranges_below_the_streaming_threshold runs the product's choice.
             "DSGD_STREAM_MIN": "8192",
             # ... as THREE launches: the chunked one-launch form of the same passes has its own module (tests/test_gpu_fstep.py)
-            "DSGD_FSTEP": "0"}
+            "DSGD_FSTEP": "0",
+            # ... and not as column lists (2,048 .. 65,535 rows in the product: tests/test_gpu_tcol.py)
+            "DSGD_TCOL": "0"}
     old = {k: os.environ.get(k) for k in pins}
     os.environ.update(pins)
     yield
@@ -492,11 +494,12 @@ def test_forced_shift_15_stays_inside_the_derived_bound(monkeypatch):
 @pytest.mark.parametrize("n_rows", [23149, 100000])
 def test_row_ranges_below_the_streaming_threshold(monkeypatch, n_rows):
     """The product's own choice for row ranges of the reference's small data set (N = 23,149, application.conf:24) and
-    of 80,000 train rows: below DSGD_FSTEP_MIN = 65,536 rows the row-wise kernel + fused reduce, from there on the chunked
-    one-launch form of the split streams (tests/test_gpu_fstep.py) -- whole-shard and two-worker steps from non-zero
-    weights under the derived bound."""
+    of 80,000 train rows: 2,048 .. 65,535 rows the column lists (tests/test_gpu_tcol.py), from DSGD_FSTEP_MIN = 65,536 rows
+    on the chunked one-launch form of the split streams (tests/test_gpu_fstep.py) -- whole-shard and two-worker steps from
+    non-zero weights under the derived bound."""
     monkeypatch.delenv("DSGD_STREAM_MIN")
     monkeypatch.delenv("DSGD_FSTEP")
+    monkeypatch.delenv("DSGD_TCOL")
     data = dsgd_amd.synth.generate(n_rows, seed=41)
     n_train = int(n_rows * 0.8)
     o, eng = make_pair(data, 1e-5, n_train)
@@ -508,7 +511,7 @@ def test_row_ranges_below_the_streaming_threshold(monkeypatch, n_rows):
         eng.set_weights(w0)
         for ranges in ([(0, n_train)], [(0, n_train // 2), (n_train // 2, n_train)], [(0, n_train)]):
             ranged_step(o, eng, ranges, 0.5 * 100 / n_train * len(ranges))
-            assert eng.grad_kernel_name() == ("dsgd_mb_grad_kernel" if n_train < 65536 else "dsgd_fstep_kernel")
+            assert eng.grad_kernel_name() == ("dsgd_tc_grad_kernel" if n_train < 65536 else "dsgd_fstep_kernel")
         loss, acc, counts = eng.loss_acc(n_train, n_rows)
         l_ref, a_ref, c_ref, mam = o.loss_acc(eng.get_weights().astype(np.float64), n_train, n_rows)
         assert abs(loss - l_ref) <= 1e-6 and (counts == c_ref or mam < GATE_EPS)

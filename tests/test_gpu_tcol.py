@@ -79,12 +79,12 @@ def test_column_lists_from_zero_weights_and_a_trajectory(monkeypatch):
 
 @pytest.mark.parametrize("share", ["0", "64", "1000", "8192"])
 def test_column_lists_equal_the_chunked_launch_bit_for_bit(monkeypatch, share):
-    """Same fixed-point grid (shift capped to 15 on both sides) => the integer sums do not care whether they were formed
-    row by row or column by column, nor where a share ends (shares of 64 entries: most columns are cut; 8,192: the LDS
-    table at its largest): the same bits as the chunked launch, provided both gate the same rows (the two kernels add a
-    row's products in different orders: a row within rounding of the gate may differ -- counted, not hidden)."""
+    """Same fixed-point grid (shift 21 on both sides, hot and cold columns alike: chunks of 512 rows leave the chunked
+    launch at the cap too) => the integer sums do not care whether they were formed row by row or column by column, nor
+    where a share ends (shares of 64 entries: most columns are cut; 8,192: the LDS table at its largest): the same bits as
+    the chunked launch, provided both gate the same rows (the two kernels add a row's products in different orders: a row
+    within rounding of the gate may differ -- counted, not hidden)."""
     clean(monkeypatch)
-    monkeypatch.setenv("DSGD_FIX_SHIFT", "15")
     monkeypatch.setenv("DSGD_TCOL_SHARE", share)
     n_rows, n_train = 60000, 50000
     data = dsgd_amd.synth.generate(n_rows, seed=61)
@@ -102,7 +102,7 @@ def test_column_lists_equal_the_chunked_launch_bit_for_bit(monkeypatch, share):
                 st = eng.sync_step_ranges(ranges, 0.5 * 100 / n_train * len(ranges))
                 acts.append(st["n_active"])
                 assert eng.grad_kernel_name() == (TCOL if tcol == "1" else "dsgd_fstep_kernel")
-                assert eng.tuning_info()["fix_shift"] == 15
+                assert eng.tuning_info()["fix_shift"] == 21
             res[tcol] = (eng.get_weights(), acts)
     same_gates = res["1"][1] == res["0"][1]
     same_bits = bool(np.array_equal(res["1"][0], res["0"][0]))

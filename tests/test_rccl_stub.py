@@ -46,6 +46,7 @@ def seam_env(env=None):
     # the rank processes hold 24,000 .. 50,000 train rows each: keep their row ranges on the STREAMING kernels (the product
     # switches to them at 131,072 rows) -- streaming kernels + all-reduce is the path bench.py --gpus N times
     env.setdefault("DSGD_STREAM_MIN", "8192")
+    env.setdefault("DSGD_TCOL", "0")   # (the column lists would take ranges of that size: tests/test_gpu_tcol.py has them)
     return env
 
 

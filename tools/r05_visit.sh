@@ -29,7 +29,7 @@ PY
   ;;
 testtc)
   echo "== the column-list module"
-  timeout 900 python -m pytest tests/test_gpu_tcol.py -q -m gpu --tb=short -rf -x > $OUT/pytest_tcol.txt 2>&1
+  timeout 900 python -m pytest tests/test_gpu_tcol.py -q -m gpu --tb=short -rf > $OUT/pytest_tcol.txt 2>&1
   grep -E "^(E  |FAILED|ERROR)|passed|failed" $OUT/pytest_tcol.txt | cut -c1-300 | head -60 ;;
 tcprobe)
   echo "== column lists vs the row-wise kernel vs row chunks"
@@ -40,7 +40,7 @@ tcprof)
   cd /tmp
   for sz in ${TC_PROF_SIZES:-23149 100552}; do
     rm -rf /tmp/tcprof_$sz
-    PROBE_WORKERS=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tcprof_$sz -o tc -- python $OLDPWD/tools/tcol_probe.py $sz columns > /dev/null 2> $OUT/tcprof_$sz.err
+    PROBE_WORKERS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tcprof_$sz -o tc -- python $OLDPWD/tools/tcol_probe.py $sz columns > /dev/null 2> $OUT/tcprof_$sz.err
     f=$(find /tmp/tcprof_$sz -name "*kernel_stats.csv" | head -1)
     [ -n "$f" ] && cp $f $OUT/tcol_kernel_stats_$sz.csv && grep -E "dsgd_tc_|fix_reduce_apply" $f | awk -F'","' '{print $1, $2, $4}' | cut -c1-200
   done
