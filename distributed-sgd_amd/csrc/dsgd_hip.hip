@@ -347,8 +347,9 @@ struct dsgd_ctx {
   unsigned long long tcol_clock = 0;
   bool tcol_enable = true;           // DSGD_TCOL=0: such ranges through the row-wise kernel
   long long tcol_min = 2048;         // DSGD_TCOL_MIN / DSGD_TCOL_MAX: row ranges of this many rows in total take the column lists
-  long long tcol_max = 65535;        //   (above: row chunks, dsgd_fstep.hpp)
-  int tcol_dot_wgs = 0;              // DSGD_TCOL_DOT_WGS: at most this many workgroups per worker in the dot kernel (0: one per 64 rows)
+  long long tcol_max = 98303;        //   (above: row chunks, dsgd_fstep.hpp.  Measured, whole-split steps, us, row-wise / chunks / columns:
+                                     //    4,800 rows 22.7 / 27.4 / 18.1; 18,519: 30.9 / 34.8 / 20.6; 40,000: 36.6 / 42.7 / 31.7; 80,441: 49 / 48 / 42.8;
+                                     //    160,000: 73 / 57.5 / 73; 320,000: 117 / 65 / 162 -- profiles/r05_tcol_probe_*.json)
   int tcol_share = 0;                // DSGD_TCOL_SHARE: entries per workgroup of the gradient kernel (0: entries / CUs, within [1024, 8192])
   bool fused_apply_pending = false;
   FusedArgs fused_args{};
@@ -2459,11 +2460,16 @@ static int tcol_layout(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long 
   L.n_ent = (long long)tot[0];
   long long share = (L.n_ent + c->n_cu - 1) / std::max(1, c->n_cu);
   share = std::max<long long>(1024, std::min<long long>(TC_MAX_SHARE, (share + 63) & ~63LL));
-  if (c->tcol_share > 0) share = std::max<long long>(64, std::min<long long>(TC_MAX_SHARE, (c->tcol_share + 1) & ~1));
+  if (c->tcol_share > 0) share = std::max<long long>(64, std::min<long long>(TC_MAX_SHARE, (c->tcol_share + 3) & ~3));   // (whole 16-byte pieces)
   L.share = (int)share;
   L.n_wg = (int)((L.n_ent + share - 1) / share);
-  TC_SOFT(hipMalloc(&L.d_ent_pk, sizeof(unsigned int) * (size_t)L.n_ent));
-  TC_SOFT(hipMalloc(&L.d_ent_val, sizeof(float) * (size_t)L.n_ent));
+  {   // whole 16-byte pieces; the last one's padding is zero
+    const size_t n_pad = ((size_t)L.n_ent + 3) & ~(size_t)3;
+    TC_SOFT(hipMalloc(&L.d_ent_pk, sizeof(unsigned int) * n_pad));
+    TC_SOFT(hipMalloc(&L.d_ent_val, sizeof(float) * n_pad));
+    TC_SOFT(hipMemsetAsync(L.d_ent_pk + (n_pad - 4), 0, sizeof(unsigned int) * 4, c->stream));
+    TC_SOFT(hipMemsetAsync(L.d_ent_val + (n_pad - 4), 0, sizeof(float) * 4, c->stream));
+  }
   TC_SOFT(hipMalloc(&L.d_shares, sizeof(TcShare) * (size_t)L.n_wg));
   TC_SOFT(hipMalloc(&L.d_key_of_cid, sizeof(int) * (size_t)std::max<unsigned long long>(1, tot[1])));
   hipLaunchKernelGGL(dsgd_tc_shares_kernel, dim3((unsigned)((L.n_wg + 255) / 256)), dim3(256), 0, c->stream, d_ptr, d_cid, n_keys, L.n_ent,
@@ -2495,10 +2501,11 @@ static int launch_tcol(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long 
   size_t slot = 0;
   DSGD_TRY(prof_begin(c, &slot));
   c->ctr_known = false;
+  // 32 rows (512 lanes) per workgroup while that leaves the CUs a few workgroups each: finer grains fill them evenly
+  // (18,519 rows: 290 workgroups of 64 rows leave 34 CUs with two and the rest with one)
   dim3 dgrid = tcol_row_grid(mx, n_workers);
-  if (c->tcol_dot_wgs > 0) dgrid.x = (unsigned)std::min<long long>(dgrid.x, c->tcol_dot_wgs);
-  hipLaunchKernelGGL(dsgd_tc_dot_kernel, dgrid, dim3(TC_THREADS), 0, c->stream, view(c), c->d_w, c->d_segs,
-                     L->d_bit_base, L->d_bitmap, std::min(TC_WL, c->dp & ~3));
+  hipLaunchKernelGGL(dsgd_tc_dot_kernel<TC_THREADS>, dgrid, dim3(TC_THREADS), 0, c->stream, view(c), c->d_w, c->d_segs, L->d_bit_base,
+                     L->d_bitmap, std::min(TC_WL, c->dp & ~3));
   HIP_TRY(hipGetLastError());
   TcGradArgs a;
   a.ent_pk = L->d_ent_pk;
@@ -2515,12 +2522,8 @@ static int launch_tcol(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long 
   {
     const dim3 g2((unsigned)L->n_wg);
     const size_t lds = sizeof(long long) * (size_t)L->share + sizeof(unsigned int) * (size_t)L->bm_words + 64;
-    const int nr = (L->share + TC_THREADS - 1) / TC_THREADS;
-    if (nr <= 1) hipLaunchKernelGGL(dsgd_tc_grad_kernel<1>, g2, dim3(TC_THREADS), lds, c->stream, a);
-    else if (nr <= 2) hipLaunchKernelGGL(dsgd_tc_grad_kernel<2>, g2, dim3(TC_THREADS), lds, c->stream, a);
-    else if (nr <= 4) hipLaunchKernelGGL(dsgd_tc_grad_kernel<4>, g2, dim3(TC_THREADS), lds, c->stream, a);
-    else if (nr <= 6) hipLaunchKernelGGL(dsgd_tc_grad_kernel<6>, g2, dim3(TC_THREADS), lds, c->stream, a);
-    else hipLaunchKernelGGL(dsgd_tc_grad_kernel<8>, g2, dim3(TC_THREADS), lds, c->stream, a);
+    if (L->share <= 4 * TC_THREADS) hipLaunchKernelGGL(dsgd_tc_grad_kernel<1>, g2, dim3(TC_THREADS), lds, c->stream, a);
+    else hipLaunchKernelGGL(dsgd_tc_grad_kernel<2>, g2, dim3(TC_THREADS), lds, c->stream, a);
   }
   HIP_TRY(hipGetLastError());
   DSGD_TRY(prof_end(c, slot));
@@ -2697,7 +2700,6 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_TCOL_MIN")) c->tcol_min = std::max(1LL, atoll(e));
   if (const char* e = getenv("DSGD_TCOL_MAX")) c->tcol_max = std::max(1LL, atoll(e));
   if (const char* e = getenv("DSGD_TCOL_SHARE")) c->tcol_share = std::max(0, atoi(e));
-  if (const char* e = getenv("DSGD_TCOL_DOT_WGS")) c->tcol_dot_wgs = std::max(0, atoi(e));
   if (const char* e = getenv("DSGD_REQ_SPIN")) c->req_spin = atoi(e) != 0;
   if (const char* e = getenv("DSGD_CS_NT")) c->cs_nt = atoi(e) == CS_THREADS_NARROW ? CS_THREADS_NARROW : 0;
   if (const char* e = getenv("DSGD_VT_TPW")) c->vt_tpw = std::max(1, atoi(e));
@@ -2736,9 +2738,6 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
 #define DSGD_ATTR_TC(fn) HIP_TRY_B(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, tc_lds))
     DSGD_ATTR_TC(dsgd_tc_grad_kernel<1>);
     DSGD_ATTR_TC(dsgd_tc_grad_kernel<2>);
-    DSGD_ATTR_TC(dsgd_tc_grad_kernel<4>);
-    DSGD_ATTR_TC(dsgd_tc_grad_kernel<6>);
-    DSGD_ATTR_TC(dsgd_tc_grad_kernel<8>);
 #undef DSGD_ATTR_TC
   }
   DSGD_ATTR((dsgd_cold_kernel<true, false, false>));

@@ -168,26 +168,36 @@ __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_fill_kernel(CsrView m, con
 
 // ---- pass 1: x.w and the gate, one bit per row ----------------------------------------------------------------------
 // ref: math/Vec.scala:58 -> math/Sparse.scala:46 (the products filtered at 1e-20), core/ml/SparseSVM.scala:27-28 (the gate)
-// grid (x, workers); workgroup (x, k) owns the 64-row blocks x, x + gridDim.x, ... of worker k: block b = the rows
-// sg.begin + 64 b .. + 63 = words bit_base[k] / 32 + 2 b and the next of the bitmap (bits beyond the range's last row: zero).
+// grid (x, workers); workgroup (x, k) owns the blocks x, x + gridDim.x, ... of ROWS = 32 or 64 rows of worker k: block b =
+// the rows sg.begin + ROWS b .. = whole words of the bitmap from bit_base[k] / 32 + (ROWS / 32) b (bits beyond the range's last
+// row: zero; every worker's rows are padded to 64).
 // (A persistent form -- two workgroups per CU walking their blocks with the next block's row records and non-zeros
 //  requested ahead, LDS-only barriers -- was measured SLOWER: 10.0 -> 20.4 us at 18,519 rows, 22 -> 52 at 80,441.  The
-//  kernel is not waiting for round trips, it is at the texture addresser's instruction rate -- 18 four-byte load
-//  instructions per wave and block -- and the requests a prefetch issues for blocks that do not exist are instructions too.)
-__global__ void __launch_bounds__(TC_THREADS) dsgd_tc_dot_kernel(CsrView m, const float* __restrict__ w,
-                                                                const WorkSeg* __restrict__ segs, const int* __restrict__ bit_base,
-                                                                unsigned int* __restrict__ bitmap, int wl) {
+//  -- not understood; the evidence is in profiles/r05_tcol_probe_v9_*.json.)
+// What the 9-10 us of this kernel at 18,519 rows are (profiles/r05_tcol_dot_decomposition.txt): NOT its requests -- with
+// four of a row's five rounds of non-zeros left out it takes 9.1 us, with every gather from L2 left out 9.3 -- but the launch
+// and ONE chain of dependent round trips per workgroup (row records -> non-zeros -> weights outside the LDS copy -> the
+// bitmap word); at 80,441 rows (1,257 workgroups, two resident per CU) 2.5 such lifetimes one after the other: 22 us.
+// Workgroups of 512 lanes (32 rows = one word) were measured three times SLOWER (33 us at 18,519 rows); so was a
+// persistent form with the next block's requests in flight (below).
+template <int NT>   // NT lanes of a workgroup: 1024 (64 rows = two words of the bitmap)
+__global__ void __launch_bounds__(NT) dsgd_tc_dot_kernel(CsrView m, const float* __restrict__ w,
+                                                        const WorkSeg* __restrict__ segs, const int* __restrict__ bit_base,
+                                                        unsigned int* __restrict__ bitmap, int wl) {
+  constexpr int ROWS = NT / TC_G, WORDS = ROWS / 32;
   __shared__ __attribute__((aligned(16))) float wlds[TC_WL];
   __shared__ unsigned int mask[2];
   const WorkSeg sg = segs[blockIdx.y];
   const int tid = threadIdx.x, sub = tid & (TC_G - 1), grp = tid >> 4;
   unsigned int* words = bitmap + (bit_base[blockIdx.y] >> 5);
-  // the hottest weights: one 16-byte piece per lane, requested first, stored behind the row's own requests
-  const float4 wpiece = reinterpret_cast<const float4*>(w)[4 * tid < wl ? tid : 0];
+  // the hottest weights: 16-byte pieces, requested first, stored behind the row's own requests
+  float4 wpiece[TC_WL / 4 / NT];
+#pragma unroll
+  for (int i = 0; i < TC_WL / 4 / NT; ++i) wpiece[i] = reinterpret_cast<const float4*>(w)[4 * (tid + i * NT) < wl ? tid + i * NT : 0];
   bool staged = false;
   typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
-  for (long long blk = blockIdx.x; blk * TC_ROWS_PER_WG < sg.end - sg.begin; blk += gridDim.x) {
-    const long long row = sg.begin + blk * TC_ROWS_PER_WG + grp;
+  for (long long blk = blockIdx.x; blk * ROWS < sg.end - sg.begin; blk += gridDim.x) {
+    const long long row = sg.begin + blk * ROWS + grp;
     const bool in_range = row < sg.end;
     const long long rowc = in_range ? row : sg.end - 1;
     // every request unconditional, positions clamped into the row (the internal CSR holds no empty row), a lane's surplus
@@ -195,9 +205,11 @@ __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_dot_kernel(CsrView m, cons
     // trips per row instead of one
     const long long st = m.row_ptr[rowc], en = m.row_ptr[rowc + 1];
     const float y = (float)m.label[rowc];
-    if (tid < 2) mask[tid] = 0u;
+    if (tid < WORDS) mask[tid] = 0u;
     if (!staged) {
-      if (4 * tid < wl) reinterpret_cast<float4*>(wlds)[tid] = wpiece;
+#pragma unroll
+      for (int i = 0; i < TC_WL / 4 / NT; ++i)
+        if (4 * (tid + i * NT) < wl) reinterpret_cast<float4*>(wlds)[tid + i * NT] = wpiece[i];
       staged = true;
     }
     __syncthreads();
@@ -227,7 +239,7 @@ __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_dot_kernel(CsrView m, cons
     const bool active = in_range && !(yd < 0.0f);
     if (sub == 0 && active) atomicOr(&mask[grp >> 5], 1u << (grp & 31));
     __syncthreads();
-    if (tid < 2) words[2 * blk + tid] = mask[tid];
+    if (tid < WORDS) words[WORDS * blk + tid] = mask[tid];
   }
 }
 
@@ -247,9 +259,12 @@ struct TcGradArgs {
   float scale;               // 2^shift / vmax2
 };
 
-// NR: rounds of 1024 entries a share holds at most.  No loop: ALL of a lane's entries are requested at once, next to the
-// bitmap -- one round trip per workgroup, whatever the share.
-template <int NR>
+// NP: 4-entry pieces per lane (a share holds at most 4096 NP entries).  A lane owns 4 NP CONSECUTIVE entries of the sorted
+// list: two 16-byte requests per piece (a quarter of the load instructions of one entry per lane and request -- the
+// kernel sits at the texture addresser's instruction rate, not at bytes), and a lane adds a run of equal columns up in a
+// register before it touches the table: one LDS add per run and lane (in the head of the ranking: per lane; per WAVE when
+// all of its lanes end in the same column).
+template <int NP>
 __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_grad_kernel(TcGradArgs a) {
   extern __shared__ __attribute__((aligned(16))) long long tc_tab[];   // [share], then the bitmap, then 16 words
   unsigned int* bm = reinterpret_cast<unsigned int*>(tc_tab + a.share);
@@ -258,14 +273,18 @@ __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_grad_kernel(TcGradArgs a) 
   const long long e0 = (long long)blockIdx.x * a.share;
   const long long e1 = e0 + a.share < a.n_ent ? e0 + a.share : a.n_ent;
   if (e0 >= e1) return;
-  unsigned int pk[NR];
-  float val[NR];
+  constexpr int NR = 4 * NP;
+  uint4 pk4[NP];
+  float4 val4[NP];
+  // (the arrays are padded to whole pieces: a piece beyond the share's end is requested -- clamped to the list's last
+  //  piece -- and its entries masked by their positions)
+  const long long last_piece = ((a.n_ent + 3) >> 2) - 1;
 #pragma unroll
-  for (int u = 0; u < NR; ++u) {   // (clamped: a lane beyond the share re-reads its last entry and contributes nothing)
-    const long long e = e0 + tid + (long long)u * TC_THREADS;
-    const long long ec = e < e1 ? e : e1 - 1;
-    pk[u] = a.ent_pk[ec];
-    val[u] = a.ent_val[ec];
+  for (int p = 0; p < NP; ++p) {
+    long long piece = (e0 >> 2) + (long long)tid * NP + p;
+    piece = piece < last_piece ? piece : last_piece;
+    pk4[p] = reinterpret_cast<const uint4*>(a.ent_pk)[piece];
+    val4[p] = reinterpret_cast<const float4*>(a.ent_val)[piece];
   }
   const TcShare sh = a.shares[blockIdx.x];
   const int n_local = sh.n_local;
@@ -298,25 +317,41 @@ __global__ void __launch_bounds__(TC_THREADS) dsgd_tc_grad_kernel(TcGradArgs a) 
     for (int i = 0; i < TC_THREADS / 64; ++i) t += red[i];
     if (t) atomicAdd(&a.sc->n_active, (unsigned long long)t);
   }
+  const long long ebase = e0 + (long long)tid * NR;
+  int run_dc = -1, run = 0;
 #pragma unroll
   for (int u = 0; u < NR; ++u) {
-    const long long e = e0 + tid + (long long)u * TC_THREADS;
-    const int dc = (int)(pk[u] & ((1u << TC_DC_BITS) - 1u));
-    const unsigned int bit = pk[u] >> TC_DC_BITS;
+    const unsigned int pk = (&pk4[u >> 2].x)[u & 3];
+    const float val = (&val4[u >> 2].x)[u & 3];
+    const int dc = (int)(pk & ((1u << TC_DC_BITS) - 1u));
+    const unsigned int bit = pk >> TC_DC_BITS;
     const bool on = ((bm[bit >> 5] >> (bit & 31u)) & 1u) != 0u;
-    const int q = (e < e1 && on) ? __float2int_rn(val[u] * a.scale) : 0;
-    // a wave inside ONE column (the head of the ranking: thousands of entries per column): one add for its 64 entries.
-    // (A segmented sum over the runs of equal columns in front of the adds -- one add per run -- was measured SLOWER:
-    //  twelve lane exchanges per round cost more than the same-address adds they save: 5.5 -> 7.2 us at 18,519 rows,
-    //  20.9 -> 27.6 at 80,441.)
-    const int dcf = __builtin_amdgcn_readfirstlane(dc);
-    if (__all(dc == dcf || q == 0)) {
-      int s = q;
+    const int q = (ebase + u < e1 && on) ? __float2int_rn(val * a.scale) : 0;   // (4 NP x 2^21 < 2^31)
+    if (u > 0 && dc != run_dc && ebase + u < e1) {   // the lane's run of one column ends: its sum into the table
+      if (run != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&tc_tab[run_dc]), (unsigned long long)(long long)run);
+      run = 0;
+    }
+    if (u == 0 || ebase + u < e1) run_dc = dc;
+    run += q;
+  }
+  {
+    // the lane's last run.  A wave inside ONE column (the head of the ranking: thousands of entries per column): one add for
+    // all of its lanes.  (Lanes beyond the share's end carry run = 0.)
+    const bool mine = ebase < e1;
+    const int dcf = __builtin_amdgcn_readfirstlane(run_dc);
+    if (__all(!mine || run == 0 || run_dc == dcf)) {
+      long long s = mine ? (long long)run : 0;
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);   // (64 x 2^21 < 2^31)
-      if ((tid & 63) == 0 && s != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&tc_tab[dcf]), (unsigned long long)(long long)s);
-    } else if (q != 0) {
-      atomicAdd(reinterpret_cast<unsigned long long*>(&tc_tab[dc]), (unsigned long long)(long long)q);
+      for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+      // (lane 0 may itself be beyond the end or hold a different, empty run: the common column is any contributing lane's)
+      const unsigned long long has = __ballot(mine && run != 0);
+      if (has) {
+        const int src = __builtin_ctzll(has);
+        const int dcc = __shfl(run_dc, src, 64);
+        if ((tid & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&tc_tab[dcc]), (unsigned long long)s);
+      }
+    } else if (mine && run != 0) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(&tc_tab[run_dc]), (unsigned long long)(long long)run);
     }
   }
   __syncthreads();

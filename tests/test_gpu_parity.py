@@ -494,8 +494,8 @@ def test_forced_shift_15_stays_inside_the_derived_bound(monkeypatch):
 @pytest.mark.parametrize("n_rows", [23149, 100000])
 def test_row_ranges_below_the_streaming_threshold(monkeypatch, n_rows):
     """The product's own choice for row ranges of the reference's small data set (N = 23,149, application.conf:24) and
-    of 80,000 train rows: 2,048 .. 65,535 rows the column lists (tests/test_gpu_tcol.py), from DSGD_FSTEP_MIN = 65,536 rows
-    on the chunked one-launch form of the split streams (tests/test_gpu_fstep.py) -- whole-shard and two-worker steps from
+    of 80,000 train rows: 2,048 .. 98,303 rows the column lists (tests/test_gpu_tcol.py; beyond them the chunked one-launch
+    form of the split streams, tests/test_gpu_fstep.py) -- whole-shard and two-worker steps from
     non-zero weights under the derived bound."""
     monkeypatch.delenv("DSGD_STREAM_MIN")
     monkeypatch.delenv("DSGD_FSTEP")
@@ -511,7 +511,7 @@ def test_row_ranges_below_the_streaming_threshold(monkeypatch, n_rows):
         eng.set_weights(w0)
         for ranges in ([(0, n_train)], [(0, n_train // 2), (n_train // 2, n_train)], [(0, n_train)]):
             ranged_step(o, eng, ranges, 0.5 * 100 / n_train * len(ranges))
-            assert eng.grad_kernel_name() == ("dsgd_tc_grad_kernel" if n_train < 65536 else "dsgd_fstep_kernel")
+            assert eng.grad_kernel_name() == "dsgd_tc_grad_kernel"
         loss, acc, counts = eng.loss_acc(n_train, n_rows)
         l_ref, a_ref, c_ref, mam = o.loss_acc(eng.get_weights().astype(np.float64), n_train, n_rows)
         assert abs(loss - l_ref) <= 1e-6 and (counts == c_ref or mam < GATE_EPS)

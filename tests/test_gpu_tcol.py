@@ -32,11 +32,9 @@ def clean(monkeypatch):
 
 @pytest.mark.parametrize("n_rows", [23149, 100552])
 def test_column_lists_match_oracle(monkeypatch, n_rows):
-    """N = 23,149 (the product's choice there) and 80,441 train rows (one GPU of eight's share of RCV1, forced onto the
-    column lists): whole-split steps from non-zero weights, one / two / three workers (SplitStrategy.vanilla's contiguous
+    """N = 23,149 and 80,441 train rows (one GPU of eight's share of RCV1) -- the product's choice for both: whole-split steps from non-zero weights, one / two / three workers (SplitStrategy.vanilla's contiguous
     ranges, and uneven ones), under the derived bound; tallies of the test rows exact; the same step twice = the same bits."""
     clean(monkeypatch)
-    monkeypatch.setenv("DSGD_TCOL_MAX", "200000")
     data = dsgd_amd.synth.generate(n_rows, seed=53)
     n_train = int(n_rows * 0.8)
     o, eng = make_pair(data, 1e-5, n_train)
@@ -92,7 +90,7 @@ def test_column_lists_equal_the_chunked_launch_bit_for_bit(monkeypatch, share):
     res = {}
     for tcol in ("1", "0"):
         monkeypatch.setenv("DSGD_TCOL", tcol)
-        monkeypatch.setenv("DSGD_FSTEP_MIN", "100000" if tcol == "1" else "8192")
+        monkeypatch.setenv("DSGD_FSTEP_MIN", "8192")
         with dsgd_amd.Engine(data.dim, 1e-5) as eng:
             eng.load_csr(data.row_ptr, data.col, data.val, data.label)
             eng.build_dim_sparsity(n_train)

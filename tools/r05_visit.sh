@@ -39,10 +39,13 @@ tcprof)
   echo "== column lists under rocprofv3 (kernel trace)"
   cd /tmp
   for sz in ${TC_PROF_SIZES:-23149 100552}; do
-    rm -rf /tmp/tcprof_$sz
-    PROBE_WORKERS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tcprof_$sz -o tc -- python $OLDPWD/tools/tcol_probe.py $sz columns > /dev/null 2> $OUT/tcprof_$sz.err
-    f=$(find /tmp/tcprof_$sz -name "*kernel_stats.csv" | head -1)
-    [ -n "$f" ] && cp $f $OUT/tcol_kernel_stats_$sz.csv && grep -E "dsgd_tc_|fix_reduce_apply" $f | awk -F'","' '{print $1, $2, $4}' | cut -c1-200
+    for var in ${TC_PROF_VARIANTS:-columns}; do
+      rm -rf /tmp/tcprof_$sz
+      PROBE_WORKERS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tcprof_$sz -o tc -- python $OLDPWD/tools/tcol_probe.py $sz $var > /dev/null 2> $OUT/tcprof_${sz}_$var.err
+      f=$(find /tmp/tcprof_$sz -name "*kernel_stats.csv" | head -1)
+      echo "-- $sz $var"
+      [ -n "$f" ] && cp $f $OUT/tcol_kernel_stats_${sz}_$var.csv && grep -E "dsgd_tc_dot|dsgd_tc_grad|fix_reduce_apply|mb_grad" $f | awk -F'","' '{print substr($1,1,60), $2, $4}'
+    done
   done
   cd $OLDPWD ;;
 smoke)
