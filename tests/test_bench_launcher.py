@@ -78,14 +78,14 @@ def test_ranks_leave_the_clock_ramp_together(tmp_path):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The bench line the last GPU visit produced (profiles/r04_bench.json): the keys, types and internal arithmetic of
+    """The full object of the bench line the last GPU visit produced (profiles/r05_bench_detail_*.json): the keys, types and internal arithmetic of
     the driver's contract -- whole-job examples/s from the timed steps (median of the repeats), the dominant kernel's
     roofline fraction from its algorithmic bytes and its measured duration, a bounded CPU baseline, nothing quoted against
     a baseline that was never published -- and that every quoted configuration carries the parity of the kernel that
     produced it."""
     import json
 
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_detail_v10.json")))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
@@ -125,13 +125,16 @@ def test_committed_bench_line_keeps_the_contract():
     # the reference's own batch sizes run through the column-slice kernel, below 10 us per step from a resident plan
     for cfg in ((3, 100), (4, 200)):
         assert by[cfg]["kernel"] == "dsgd_cs_step_kernel" and by[cfg]["us_per_step"] < 10.0
-    # the 256-worker lock-free run: traced replay (can fail: both negative controls rejected) beside the oracle band
+    # the 256-worker lock-free run: traced replay (can fail: both negative controls rejected) 
     hw = d["hogwild"]
     tr = hw["traced_replay"]
-    assert tr["workers"] == hw["workers"] == 256 and tr["batch"] == 100 and tr["agrees"] is True and tr["controls_rejected"] is True
-    assert all(all(cp["ok"].values()) and cp["account_err_over_tol"] <= 1.0 for cp in tr["checkpoints"])
+    assert tr["workers"] == hw["workers"] == 256 and tr["batch"] == 100 and tr["accounting_agrees"] is True and tr["controls_rejected"] is True
+    assert tr["gates_are"].startswith("engine-recorded")                 # (what the accounting replay does NOT re-derive ...
+    g4 = tr["gate_check_4_workers"]                                       #  ... and the statement that does, at 4 workers)
+    assert g4["ok"] is True and g4["updates_checked"] > 0 and g4["differ_at_both_ends"] <= g4["explained_by_in_flight_or_resolution"]
+    assert tr["checkpoint"]["account_err_over_tol"] <= 1.0
     assert all(v["rejected"] for v in tr["negative_controls"].values()) and len(tr["negative_controls"]) >= 2
-    assert hw["oracle_band"]["inside"] is True and hw["atomics_per_s"] > 0 and 0.0 < hw["frac_hbm_peak"] < 1.0
+    assert hw["atomics_per_s"] > 0 and 0.0 < hw["frac_hbm_peak"] < 1.0
     # the reference's own data-set sizes next to the headline, gated and with roofline fields
     shapes = {rs["rows"]: rs for rs in d["reference_shapes"]}
     assert set(shapes) == {804414, 23149}
@@ -139,8 +142,19 @@ def test_committed_bench_line_keeps_the_contract():
         assert rs["parity_gate"]["max_rel_err"] <= 1e-5 and rs["parity_gate"]["worst_err_over_bound"] <= 1.0
         assert rs["whole_shard"]["repeats"] >= 5 and 0.0 < rs["roofline"]["step"]["frac"] <= rs["roofline"]["frac"] <= 1.0
         assert all(s["parity"]["kernel"] == s["kernel"] for s in rs["sweep"])
-    # wall-clock to the oracle's target loss, evaluation passes inside the clock, for the batch sizes of SURVEY.md 8(d)
+    # the whole-split step at N = 23,149 runs as column lists (csrc/dsgd_tcol.hpp), at N = 804,414 as row chunks
+    assert shapes[23149]["whole_shard"]["kernel"] == "dsgd_tc_grad_kernel" and shapes[804414]["whole_shard"]["kernel"] == "dsgd_fstep_kernel"
+    # wall-clock to the oracle's target loss THROUGH host.MasterSync.fit (what a patched Master.fit runs), evaluation passes
+    # inside the clock, for the batch sizes of SURVEY.md 8(d); the reference's configuration with its forced replay
     tt = d["time_to_target"]
+    assert tt["through"].startswith("host.MasterSync.fit")
     assert {(c["workers"], c["batch"]) for c in tt["configs"]} >= {(3, 100), (4, 200), (1, 4096), (1, 65536)}
     assert tt["fastest"] is not None and tt["fastest"]["time_to_target_s"] > 0
     assert all("evaluation" in c and (c["time_to_target_s"] is None) == (c["engine_epochs"] is None) for c in tt["configs"])
+    ref = {(c["workers"], c["batch"]): c for c in tt["configs"]}[(3, 100)]
+    assert ref["divergent_rows_all_near_gate"] is True and ref["forced_replay_account_err_over_tol"] <= 1.0
+    # an epoch as ONE plan: the fit's cost per 3 x 100 step, shuffle included, and its forced replay over 10 epochs
+    fit = d["fit"]
+    assert fit["kernel"] == ["dsgd_cs_step_kernel"] and 0.0 < fit["batch_loop_us_per_step"] < 15.0 < fit["per_request_us_per_step"]
+    fr = fit["forced_replay_10_epochs"]
+    assert fr["accounting_agrees"] is True and fr["account_err_over_tol"] <= 1.0 and fr["divergent_rows_all_near_gate"] is True
