@@ -1521,6 +1521,13 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
 #pragma unroll
     for (int e = 0; e < HOG_SW; ++e)
       dsn[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ds_rs, tid * 4, e * HOG_THREADS * 4, 0));
+    // TWO sweeps (round 5).  vmcnt retires in order: with the updates issued inside the pass that also requests the next
+    // pass's dimSparsity values, every pass waited for its predecessor's atomics to be ACKNOWLEDGED by the memory side
+    // before its own loads could "return" -- ten round trips over the fabric in a row, 27 K cycles of a 59 K-cycle
+    // iteration with ONE worker on an idle chip (profiles/r04_hogwild_phase_cycles.txt).  Now the first sweep only loads
+    // (deltas computed, their dimSparsity terms summed, the delta left in the accumulator's slot) and the second only
+    // updates (no load behind an atomic: the updates leave back to back, acknowledged once, at the drain).  The same
+    // terms in the same order per lane: the same bits.
     for (int j0 = 0, pass = 0; j0 < a.hl; j0 += HOG_THREADS * HOG_SW, ++pass) {
       int q[HOG_SW];
       float dsv[HOG_SW];
@@ -1543,16 +1550,29 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       for (int e = 0; e < HOG_SW; ++e) {
         if (q[e] == 0) continue;
         const int j = j0 + e * HOG_THREADS + tid;
-        L.acc[j] = 0;
         float g = filt(((float)q[e] * a.inv_qscale) / fB);   // Vec.mean divides (ref: math/Vec.scala:139)
-        if (g == 0.0f) continue;
-        if (add_s) g = filt(g + s_it);
+        if (add_s && g != 0.0f) g = filt(g + s_it);
         const float delta = filt(g * a.lr);
+        L.acc[j] = __float_as_int(delta);   // (0.0f = all bits clear: nothing to apply)
         if (delta != 0.0f) {
-          atomicAdd(&a.w[j], -delta);   // lock-free update of the ONE weight vector
           ds_acc += delta * dsv[e];
           n_act += HOG_ATOMIC_ONE;      // (counted in the upper bits of the active-row counter: no register to spare)
         }
+      }
+    }
+    for (int j0 = 0; j0 < a.hl; j0 += HOG_THREADS * HOG_SW) {
+      int d[HOG_SW];
+#pragma unroll
+      for (int e = 0; e < HOG_SW; ++e) {
+        const int j = j0 + e * HOG_THREADS + tid;
+        d[e] = j < a.hl ? L.acc[j] : 0;
+      }
+#pragma unroll
+      for (int e = 0; e < HOG_SW; ++e) {
+        if (d[e] == 0) continue;
+        const int j = j0 + e * HOG_THREADS + tid;
+        L.acc[j] = 0;
+        atomicAdd(&a.w[j], -__int_as_float(d[e]));   // lock-free update of the ONE weight vector
       }
     }
     stamp(1);
