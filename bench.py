@@ -906,16 +906,20 @@ def reference_shape(dsgd_amd, device, n_rows, with_parity=True, repeats=5, steps
         for _ in range(30):
             eng.sync_step_ranges(ranges, lr, asynchronous=True)
         eng.synchronize()
+        # the steps as a caller sees them (no event records: two records per step are 6 us -- a fifth of a 23,149-row step),
+        # then the same steps with the gradient launches bracketed for the kernel's own duration
+        times = timed_steps(eng, ranges, lr, steps, repeats, lambda e: e.synchronize(), lambda: None, 1, None)
         eng.prof_enable(2)
         eng.prof_read(reset=True)
-        times = timed_steps(eng, ranges, lr, steps, repeats, lambda e: e.synchronize(), lambda: None, 1, None)
+        times_ev = timed_steps(eng, ranges, lr, steps, repeats, lambda e: e.synchronize(), lambda: None, 1, None)
         kernel_ms, n_launch = eng.prof_read(reset=True)
         eng.prof_enable(0)
         dt = float(np.median(times))
         res["whole_shard"] = {"examples_per_s": n_train * steps / dt, "us_per_step": 1e6 * dt / steps,
                               "us_per_step_min": 1e6 * min(times) / steps, "us_per_step_max": 1e6 * max(times) / steps,
+                              "us_per_step_with_event_records": 1e6 * float(np.median(times_ev)) / steps,
                               "repeats": len(times), "steps": steps, "kernel": eng.grad_kernel_name()}
-        res["roofline"] = roofline(eng, None, n_train, nnz_train, bytes_per_row, kernel_ms, n_launch, steps * len(times), dt / steps, None)
+        res["roofline"] = roofline(eng, None, n_train, nnz_train, bytes_per_row, kernel_ms, n_launch, steps * len(times_ev), dt / steps, None)
         cfgs = tuple(c for c in SWEEP if c[0] * c[1] <= n_train)
         res["sweep"] = sweep(eng, data, n_train, with_parity=with_parity, configs=cfgs)
     return res

@@ -1793,7 +1793,7 @@ static void fstep_drop_all(dsgd_ctx* c);
 static void tcol_drop_all(dsgd_ctx* c);
 static int build_split(dsgd_ctx* c) {
   fstep_drop_all(c);
-  tcol_drop_all(c);   // (sorted by the ranks about to change)   // (the chunked tile tables index the streams built here)
+  tcol_drop_all(c);   // (the chunked tile tables index the streams built here; the column lists are sorted by the ranks about to change)
   (void)hipFree(c->d_hcol); (void)hipFree(c->d_hval); (void)hipFree(c->d_hrow_ptr);
   (void)hipFree(c->d_ccol); (void)hipFree(c->d_cval); (void)hipFree(c->d_ctp); (void)hipFree(c->d_ctiles); (void)hipFree(c->d_cmeta);
   (void)hipFree(c->d_dcold); (void)hipFree(c->d_coef8);

@@ -36,10 +36,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WORLD = 2
 
 
-@pytest.fixture(scope="module")
-def ranks(tmp_path_factory):
+@pytest.fixture(scope="module", params=["streaming_kernels", "column_lists"])
+def ranks(request, tmp_path_factory):
+    """Two rank processes, twice: their row ranges (24,000 .. 50,000 train rows each) on the streaming kernels -- the path
+    bench.py --gpus N times in weak mode -- and on the column lists (csrc/dsgd_tcol.hpp) -- the product's choice for ranges
+    of that size, i.e. `bench.py --gpus 8 --scaling strong --rows-total 804414`.  The collective sits between the exact
+    column sums and the update in both."""
     wd = str(tmp_path_factory.mktemp("world2"))
     env = seam_env()   # the seam build of the library (DSGD_LIB_PATH) over the shim (DSGD_RCCL_LIB)
+    env["DSGD_TCOL"] = "1" if request.param == "column_lists" else "0"
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "world2_worker.py"), str(r), str(WORLD), wd], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(WORLD)]
     outs = []
@@ -52,7 +57,11 @@ def ranks(tmp_path_factory):
                 p.kill()
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-4000:])
-    return [dict(np.load(os.path.join(wd, "out_%d.npz" % r))) for r in range(WORLD)]
+    outs = [dict(np.load(os.path.join(wd, "out_%d.npz" % r))) for r in range(WORLD)]
+    for o_ in outs:   # the mode took effect in the rank processes
+        assert str(o_["range_kernel"]) == ("dsgd_tc_grad_kernel" if request.param == "column_lists" else "dsgd_wseg_kernel<true>"), o_["range_kernel"]
+        o_["_tcol"] = env["DSGD_TCOL"]
+    return outs
 
 
 @pytest.fixture(scope="module")
@@ -210,7 +219,9 @@ def test_one_thread_driving_both_contexts_equals_the_two_processes(ranks, tmp_pa
     every collective goes through ncclGroupStart / ncclGroupEnd.  Same kernels, same sums, same order: the column
     ranking, every step's weights on both replicas, the summed statistics and the evaluation are those of the two rank
     processes BIT FOR BIT -- which the tests above hold to the oracle with K = workers x world."""
-    proc = subprocess.run([sys.executable, os.path.join(HERE, "devices_worker.py"), str(tmp_path)], env=seam_env(),
+    env = seam_env()
+    env["DSGD_TCOL"] = ranks[0]["_tcol"]   # (the same kernels as the rank processes of this round)
+    proc = subprocess.run([sys.executable, os.path.join(HERE, "devices_worker.py"), str(tmp_path)], env=env,
                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert proc.returncode == 0, proc.stdout[-4000:]
     d = dict(np.load(os.path.join(str(tmp_path), "devices.npz")))

@@ -51,6 +51,7 @@ def main():
         # whole-range steps: one hosted worker per rank, then two
         for step, ranges in enumerate(([(0, ntl)], [(0, ntl)], [(0, ntl // 3), (ntl // 3, ntl)])):
             st = eng.sync_step_ranges(ranges, CFG["lr_range"] * len(ranges) * world)
+            out["range_kernel"] = np.asarray(eng.grad_kernel_name())
             w_hist.append(eng.get_weights())
             shifts.append(eng.tuning_info()["fix_shift"])
             stats.append([st["n_samples"], st["n_active"]])
