@@ -3,6 +3,7 @@
 # usage (repo root, on the GPU box): bash tools/r05_visit.sh <tag> [build] [testcs] [probe] [testall] [bench] [benchprof] [pmc] [latency] [cstrace] ...
 TAG=$1; shift
 OUT=$PWD/gpurun_out/$TAG
+REPO=$PWD
 mkdir -p $OUT
 export TMPDIR=/tmp
 for leg in "$@"; do
@@ -41,13 +42,26 @@ tcprof)
   for sz in ${TC_PROF_SIZES:-23149 100552}; do
     for var in ${TC_PROF_VARIANTS:-columns}; do
       rm -rf /tmp/tcprof_$sz
-      PROBE_WORKERS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tcprof_$sz -o tc -- python $OLDPWD/tools/tcol_probe.py $sz $var > /dev/null 2> $OUT/tcprof_${sz}_$var.err
+      PROBE_WORKERS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tcprof_$sz -o tc -- python $REPO/tools/tcol_probe.py $sz $var > /dev/null 2> $OUT/tcprof_${sz}_$var.err
       f=$(find /tmp/tcprof_$sz -name "*kernel_stats.csv" | head -1)
       echo "-- $sz $var"
       [ -n "$f" ] && cp $f $OUT/tcol_kernel_stats_${sz}_$var.csv && grep -E "dsgd_tc_dot|dsgd_tc_grad|fix_reduce_apply|mb_grad" $f | awk -F'","' '{print substr($1,1,60), $2, $4}'
     done
   done
-  cd $OLDPWD ;;
+  cd $REPO ;;
+tcpmc)
+  # rocprofv3 --pmc passes over whole-split steps of N = 23,149 and 100,552 rows (the column lists' kernels)
+  for sz in 23149 100552; do
+    i=0
+    for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+      i=$((i+1))
+      echo "== $sz rows, pmc pass $i: $P" | tee -a $OUT/tcol_pmc_summary.txt
+      ( cd /tmp && DSGD_TCOL_MAX=200000 timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/tcpmc$i -o pmc -- python $REPO/tools/pmc_step.py $sz 20 > $OUT/tcpmc$i.out 2> $OUT/tcpmc$i.err )
+      f=$(find $OUT/tcpmc$i -name "*counter_collection.csv" | head -1)
+      [ -n "$f" ] && python tools/pmc_summary.py "$f" "dsgd_" | grep -E "tc_dot|tc_grad|reduce_apply" | tee -a $OUT/tcol_pmc_summary.txt
+      rm -rf $OUT/tcpmc$i $OUT/tcpmc$i.out $OUT/tcpmc$i.err
+    done
+  done ;;
 smoke)
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.txt ;;
 *)
