@@ -2387,6 +2387,7 @@ static int tcol_layout(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long 
   for (dsgd_ctx::TcolLayout& L : c->tcol_cache)
     if (L.gen == c->layout_gen && L.ranges == key) {
       L.used = ++c->tcol_clock;
+      if (L.n_wg == 0) return 1;   // (declined before -- no memory, too many entries: not tried again step after step)
       *out = &L;
       return DSGD_OK;
     }
@@ -2419,6 +2420,12 @@ static int tcol_layout(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long 
     (void)hipFree(d_cid);
     (void)hipFree(d_tot);
     tcol_free(L);
+    if (rc == 1) {   // remembered as declined (n_wg = 0): the caller's other path takes this configuration from now on
+      L.ranges = key;
+      L.gen = c->layout_gen;
+      L.used = ++c->tcol_clock;
+      c->tcol_cache.push_back(L);
+    }
     return rc;
   };
 #define TC_SOFT(expr)                        \

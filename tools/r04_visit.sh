@@ -91,7 +91,7 @@ benchquick)
   timeout 600 python bench.py --no-cpu-baseline --no-sweep --no-parity-gate 2> $OUT/benchq.err > $OUT/benchq.json; tail -3 $OUT/benchq.err; cut -c1-900 $OUT/benchq.json ;;
 benchprof)
   echo "== rocprofv3 kernel trace of the bench step"
-  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sweep --no-parity-gate > $OUT/bench_prof.json 2> $OUT/bench_prof.err )
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sweep --no-parity-gate --detail $OUT/bench_prof_detail.json > $OUT/bench_prof.json 2> $OUT/bench_prof.err )
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv && head -8 "$f" | cut -c1-160
   f=$(find $OUT/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && trace_summary "$f" > $OUT/dispatch_durations.txt && grep -E "fstep|wseg_kernel<true|cdot|cgrad|cold|reduce" $OUT/dispatch_durations.txt
   rm -rf $OUT/prof ;;
