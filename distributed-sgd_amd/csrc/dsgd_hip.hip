@@ -345,8 +345,9 @@ struct dsgd_ctx {
   };
   std::vector<TcolLayout> tcol_cache;
   unsigned long long tcol_clock = 0;
+  int tcol_miss_streak = 0;          // layouts built in a row without one being used again
   bool tcol_enable = true;           // DSGD_TCOL=0: such ranges through the row-wise kernel
-  long long tcol_min = 2048;         // DSGD_TCOL_MIN / DSGD_TCOL_MAX: row ranges of this many rows in total take the column lists
+  long long tcol_min = 512;          // DSGD_TCOL_MIN / DSGD_TCOL_MAX: row ranges of this many rows in total take the column lists
   long long tcol_max = 98303;        //   (above: row chunks, dsgd_fstep.hpp.  Measured, whole-split steps, us, row-wise / chunks / columns:
                                      //    4,800 rows 22.7 / 27.4 / 18.1; 18,519: 30.9 / 34.8 / 20.6; 40,000: 36.6 / 42.7 / 31.7; 80,441: 49 / 48 / 42.8;
                                      //    160,000: 73 / 57.5 / 73; 320,000: 117 / 65 / 162 -- profiles/r05_tcol_probe_*.json)
@@ -2388,9 +2389,16 @@ static int tcol_layout(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long 
     if (L.gen == c->layout_gen && L.ranges == key) {
       L.used = ++c->tcol_clock;
       if (L.n_wg == 0) return 1;   // (declined before -- no memory, too many entries: not tried again step after step)
+      c->tcol_miss_streak = 0;
       *out = &L;
       return DSGD_OK;
     }
+  // A caller that never repeats a configuration (mini-batches over ever new row ranges) would pay a layout -- milliseconds --
+  // for every 20 us step: more misses in a row than the cache holds, and the column lists leave such a context alone.
+  if (++c->tcol_miss_streak > 12) {
+    c->tcol_enable = false;
+    return 1;
+  }
   for (size_t i = 0; i < c->tcol_cache.size();)   // layouts of an earlier ranking
     if (c->tcol_cache[i].gen != c->layout_gen) {
       HIP_TRY(hipStreamSynchronize(c->stream));

@@ -124,10 +124,10 @@ int dsgd_sync_step(dsgd_ctx* ctx, const int32_t* const* idx_per_worker, const in
 
 /* Same, for batches that are whole contiguous row ranges (batch-size >= split size makes
  * slice(0, B) of the shuffled split the entire split; a sum does not depend on the order).
- * By the rows of the step: 2,048 .. 98,303 COLUMN LISTS (csrc/dsgd_tcol.hpp: the ranges' entries sorted by column once
+ * By the rows of the step: 512 .. 98,303 COLUMN LISTS (csrc/dsgd_tcol.hpp: the ranges' entries sorted by column once
  * per configuration; dot kernel -> one bit per row -> column-wise exact sums: no per-workgroup partials; DSGD_TCOL_MIN /
  * _MAX); beyond them ROW CHUNKS (csrc/dsgd_fstep.hpp: cold x.w, hot tiles and cold gradient of a chunk of rows in ONE
- * launch; DSGD_FSTEP_MIN); below 2,048 the row-wise kernel.  Layouts are cached per (ranges) configuration (eight each).
+ * launch; DSGD_FSTEP_MIN); below 512 the row-wise kernel.  Layouts are cached per (ranges) configuration (eight each).
  * Every path accumulates the same fixed-point integers: same gate decisions => the same bits.                          */
 int dsgd_sync_step_ranges(dsgd_ctx* ctx, const int64_t* row_begin, const int64_t* row_end, int32_t n_workers,
                           float lr, dsgd_batch_stats* stats /* may be NULL */);

@@ -116,6 +116,22 @@ def test_column_slice_kernels_spill_nothing(tmp_path):
         assert v["vgpr_count"] <= (256 if lanes == 512 else 512), (k, v)
 
 
+def test_column_list_kernels_spill_nothing_and_keep_two_workgroups_per_cu(tmp_path):
+    """csrc/dsgd_tcol.hpp: every request of the dot kernel and of the gradient kernel is issued before the first is used
+    -- a scratch reload would retire behind them.  The dot kernel's 1024-lane workgroups run two per CU (64 registers),
+    the gradient kernel's 4-entry-piece form too; its 8-entry form (shares above 4,096 entries) one and a half."""
+    kn = {k: v for k, v in _kernel_notes(tmp_path).items() if "dsgd_tc_" in k}
+    names = sorted(kn)
+    for want in ("dsgd_tc_dot_kernel", "dsgd_tc_grad_kernel", "dsgd_tc_count_kernel", "dsgd_tc_scan_kernel", "dsgd_tc_shares_kernel", "dsgd_tc_fill_kernel"):
+        assert any(want in k for k in names), (want, names)
+    for k, v in kn.items():
+        assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
+        if "dsgd_tc_dot_kernel" in k or "dsgd_tc_grad_kernelILi1E" in k:
+            assert v["vgpr_count"] <= 64, (k, v)
+        if "dsgd_tc_grad_kernelILi2E" in k:
+            assert v["vgpr_count"] <= 96, (k, v)
+
+
 def test_register_budget_of_the_async_engine_and_the_concurrent_loss_check(tmp_path):
     """MasterAsync checks the loss WHILE the persistent lock-free engine runs (core/MasterAsync.scala:96-162): the
     evaluation kernel must become resident beside workgroups that never leave their CU.  Per SIMD the engine holds

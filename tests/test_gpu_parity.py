@@ -494,7 +494,7 @@ def test_forced_shift_15_stays_inside_the_derived_bound(monkeypatch):
 @pytest.mark.parametrize("n_rows", [23149, 100000])
 def test_row_ranges_below_the_streaming_threshold(monkeypatch, n_rows):
     """The product's own choice for row ranges of the reference's small data set (N = 23,149, application.conf:24) and
-    of 80,000 train rows: 2,048 .. 98,303 rows the column lists (tests/test_gpu_tcol.py; beyond them the chunked one-launch
+    of 80,000 train rows: 512 .. 98,303 rows the column lists (tests/test_gpu_tcol.py; beyond them the chunked one-launch
     form of the split streams, tests/test_gpu_fstep.py) -- whole-shard and two-worker steps from
     non-zero weights under the derived bound."""
     monkeypatch.delenv("DSGD_STREAM_MIN")

@@ -132,7 +132,7 @@ def test_ranges_the_column_lists_decline(monkeypatch):
     data = dsgd_amd.synth.generate(30000, seed=5)
     o, eng = make_pair(data, 1e-5, 25000)
     with eng:
-        for ranges, tc in (([(0, 25000)], True), ([(0, 1500)], False), ([(0, 1500), (1500, 3000)], True), ([(0, 2048)], True)):
+        for ranges, tc in (([(0, 25000)], True), ([(0, 300)], False), ([(0, 300), (300, 600)], True), ([(0, 512)], True)):
             ranged_step(o, eng, ranges, 0.5 * 100 / 25000)
             assert (eng.grad_kernel_name() == TCOL) == tc, ranges
     monkeypatch.setenv("DSGD_TCOL_MAX", "20000")
@@ -206,3 +206,26 @@ def test_asynchronous_range_steps_and_a_communicator_of_one(monkeypatch):
     assert out[0][1] == out[1][1] == out[2][1]
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][0], out[2][0])
+
+
+def test_a_caller_that_never_repeats_its_ranges_is_left_alone(monkeypatch):
+    """A layout costs milliseconds, a step 20 us: thirteen configurations in a row without one being used again (more than
+    the cache of eight could ever serve) and the context's ranges go back to the row-wise kernel -- every step, before and
+    after, under the derived bound."""
+    clean(monkeypatch)
+    data = dsgd_amd.synth.generate(30000, seed=11)
+    o, eng = make_pair(data, 1e-5, 25000)
+    with eng:
+        eng.set_weights(some_weights(data.dim, 11))
+        names = []
+        for i in range(16):
+            ranged_step(o, eng, [(100 * i, 100 * i + 4000)], 0.5 * 100 / 4000)
+            names.append(eng.grad_kernel_name())
+        assert names[:12] == [TCOL] * 12 and names[-1] == "dsgd_mb_grad_kernel", names
+        # a configuration that IS repeated keeps its column lists in a fresh context
+    o, eng = make_pair(data, 1e-5, 25000)
+    with eng:
+        for _ in range(20):
+            eng.sync_step_ranges([(0, 4000)], 1e-3, asynchronous=True)
+        eng.synchronize()
+        assert eng.grad_kernel_name() == TCOL
