@@ -62,6 +62,11 @@ tcpmc)
       rm -rf $OUT/tcpmc$i $OUT/tcpmc$i.out $OUT/tcpmc$i.err
     done
   done ;;
+latency5)
+  echo "== per-request latency at the boundary (tools/boundary_latency.py): as built, and with the one-launch request kernel"
+  timeout 300 python tools/boundary_latency.py 2000000 > $OUT/boundary_latency.json 2> $OUT/boundary_latency.err; tail -2 $OUT/boundary_latency.err; cat $OUT/boundary_latency.json
+  echo "-- DSGD_CS_REQ=1"
+  DSGD_CS_REQ=1 timeout 300 python tools/boundary_latency.py 2000000 > $OUT/boundary_latency_cs_req.json 2>> $OUT/boundary_latency.err; grep -E "sync_step|batch" $OUT/boundary_latency_cs_req.json ;;
 smoke)
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.txt ;;
 *)
