@@ -85,7 +85,7 @@ def test_committed_bench_line_keeps_the_contract():
     produced it."""
     import json
 
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_detail_v10.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_detail.json")))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
