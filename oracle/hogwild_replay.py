@@ -230,7 +230,7 @@ def gate_check_small_lag(o, w0, split, batch, lr, seed, trace, max_lag=1, positi
     of every update with lag <= max_lag to the reference's gate y (x . W) >= 0 at BOTH ends of [read_at, commit): a
     decision that differs at both ends is legitimate only for a row whose margin, at one of the ends, is no larger than
     what the updates in flight can have moved it by while they were landing (sum_j |x_j| |delta_j| over them) plus the
-    fp32 resolution of its dot product.  Returns counts; `outside` lists the violations (empty for a correct engine)."""
+    fp32 resolution of its dot product and of the replayed weights themselves.  Returns counts; `outside` lists the violations (empty for a correct engine)."""
     worker, it, read_at = np.asarray(trace["worker"]), np.asarray(trace["it"]), np.asarray(trace["read_at"])
     s_rec, mask = np.asarray(trace["s"], dtype=np.float64), np.asarray(trace["mask"])
     n = len(worker)
@@ -262,6 +262,11 @@ def gate_check_small_lag(o, w0, split, batch, lr, seed, trace, max_lag=1, positi
                 up += np.bincount(rid, weights=np.maximum(-t, 0.0), minlength=batch)
             nnz = np.bincount(rid, minlength=batch)
             res = (nnz + 32) * eps32 * np.bincount(rid, weights=np.abs(v * w_read[cols]), minlength=batch)
+            # ... and the weights the worker read are the ENGINE's fp32 weights, which the replay (fp64, recorded decisions)
+            # follows to its accounting error only -- a few 1e-7 .. 1e-5 of |w|inf per coordinate after hundreds of atomic
+            # updates (replay_forced's statement; 2e-4 |w|inf is its tolerance): a margin inside sum_j |x_j| times a
+            # conservative 1e-6 |w|inf of the gate cannot be told apart (found on a 2-worker run: lag 0, margin -1.6e-5)
+            res = res + np.bincount(rid, weights=np.abs(v), minlength=batch) * 1e-6 * max(1.0, float(np.abs(w_read).max())) / GATE_SLACK
             rec = mask[c - 1, :batch].astype(bool)
             d_read, d_commit = ~(m_read < 0.0), ~(m_commit < 0.0)
             both = (rec != d_read) & (rec != d_commit)
