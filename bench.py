@@ -602,7 +602,7 @@ def compact_line(out, detail_path=None):
         legs["hogwild"] = _pick(hw, "workers", "batch", "examples_per_s", "frac_hbm_peak", "atomics_per_s")
         tr = hw.get("traced_replay")
         if tr:
-            legs["hogwild"]["traced_replay"] = _pick(tr, "accounting_agrees", "gates_are", "controls_rejected", "gate_check_4_workers")
+            legs["hogwild"]["traced_replay"] = _pick(tr, "accounting_agrees", "gates_are", "controls_rejected", "gate_check", "gate_check_4_workers")
     tt = out.get("time_to_target")
     if tt:
         legs["time_to_target"] = _pick(tt, "rows", "target_test_loss", "fastest", "through")
@@ -828,7 +828,11 @@ def hogwild_parity(dsgd_amd, device, workers=256, batch=100, rows=100000, update
     regularised as the reference does (`accounting_agrees`), and that the check can fail (one lost update, every update
     applied twice: both rejected).  The gates themselves are engine-recorded, not re-derived (`gates_are`); the gate
     checks with teeth -- a single worker replayed exactly, four workers held to the near-gate rows -- and the oracle's band
-    of orderings run under `pytest -m gpu` (tests/test_gpu_hogwild_trace.py, tests/test_gpu_parity.py), not in every bench."""
+    of orderings run under `pytest -m gpu` (tests/test_gpu_hogwild_trace.py, tests/test_gpu_parity.py), not in every bench.
+    Round 6: the engine also records the x . w EVERY sampled row was gated on and an update count known to be in the
+    weights it read; `gate_check` holds every decision of THIS 256-worker run to the reference's rule on its recorded d and
+    every d to the range the replayed weights allow (hogwild_replay.gate_check_recorded_dots: rigorous, 100 % of the rows),
+    with two negative controls (a decision flipped against its d; a d moved out of its range)."""
     from oracle import hogwild_replay as hr  # checker only
     from oracle import oracle as orc
 
@@ -857,8 +861,33 @@ def hogwild_parity(dsgd_amd, device, workers=256, batch=100, rows=100000, update
             hr.replay_forced(o, w_bad, split, batch, LR0, 5, trace, fault=fault, check=False)
             err = float(np.abs(w_end - w_bad).max())
         controls[fault] = {"account_max_abs_err": err, "rejected": not err <= hr.ACCOUNT_TOL * max(1.0, float(np.abs(w_bad).max()))}
-    # the gate check WITH TEETH: 4 workers (kube/dsgd.yaml:95), every decision of every update with at most one update in
-    # flight held to the reference's gate at both ends of [read_at, commit)
+    # every decision of the benchmarked shape: rule on the recorded x . w, and the x . w inside what the replay allows
+    g = hr.gate_check_recorded_dots(o, np.zeros(data.dim + 1), split, batch, LR0, 5, trace, prefix_every=16, collect=True)
+    gate = {kk: g[kk] for kk in ("updates", "rows", "gate_rows_checked", "empty_rows", "rule_violations", "range_violations", "max_window",
+                                 "mean_window", "share_pinned_by_the_replay", "width_over_abs_d_median", "states_share_inside", "ok")}
+    gate["checks"] = "decision == !(y d < 0) on the recorded d (SparseSVM.scala:27-28); d inside sum_j x_j [min, max] of the replayed weights from seen_from to the updates in flight at the commit, + fp32 resolution"
+    if not g["ok"]:
+        raise SystemExit("Hogwild gate check (%d workers) failed: %r %r" % (workers, g["outside_rule"], g["outside_range"]))
+    ctl = {}
+    u_c, t_c = len(trace["worker"]) // 2, 5
+    bad = dict(trace, mask=np.array(trace["mask"], copy=True))
+    bad["mask"][u_c, t_c] ^= True
+    bad["n_active"] = bad["mask"][:, :batch].sum(axis=1).astype(np.int32)
+    gb = hr.gate_check_recorded_dots(o, np.zeros(data.dim + 1), split, batch, LR0, 5, bad, prefix_every=0)
+    ctl["decision_flipped_against_its_d"] = {"rule_violations": gb["rule_violations"], "rejected": not gb["ok"]}
+    bad = dict(trace, dot=np.array(trace["dot"], copy=True), mask=np.array(trace["mask"], copy=True))
+    bad["dot"][u_c, t_c] = np.float32(g["hi"][u_c, t_c] + 0.05 * (g["hi"][u_c, t_c] - g["lo"][u_c, t_c]) + 1e-3)
+    k_c = int(trace["worker"][u_c])
+    y_c = float(o.label[hr.hog_rows(5, k_c, int(trace["it"][u_c]), split[k_c][0], split[k_c][1] - split[k_c][0], batch)[t_c]])
+    bad["mask"][u_c, t_c] = not (y_c * float(bad["dot"][u_c, t_c]) < 0.0)
+    bad["n_active"] = bad["mask"][:, :batch].sum(axis=1).astype(np.int32)
+    gb = hr.gate_check_recorded_dots(o, np.zeros(data.dim + 1), split, batch, LR0, 5, bad, prefix_every=0)
+    ctl["d_moved_out_of_its_range"] = {"range_violations": gb["range_violations"], "rule_violations": gb["rule_violations"], "rejected": not gb["ok"]}
+    gate["negative_controls"] = ctl
+    if not all(c["rejected"] for c in ctl.values()):
+        raise SystemExit("Hogwild gate check: a negative control was not rejected: %r" % ctl)
+    # the few-worker statement of round 5: 4 workers (kube/dsgd.yaml:95), every decision of every update with at most one
+    # update in flight held to the reference's gate at both ends of [read_at, commit)
     split4 = split_vanilla(n_train, 4)
     with dsgd_amd.Engine(data.dim, LAMBDA, device=device) as eng:
         eng.load_csr(data.row_ptr, data.col, data.val, data.label)
@@ -873,8 +902,9 @@ def hogwild_parity(dsgd_amd, device, workers=256, batch=100, rows=100000, update
         raise SystemExit("Hogwild gate check (4 workers) failed: %r" % g4)
     gate4 = {kk: g4[kk] for kk in ("updates", "updates_checked", "rows_checked", "differ_at_both_ends", "explained_by_in_flight_or_resolution", "ok")}
     traced = {"rows": rows, "workers": workers, "batch": batch, "updates": int(v.get("updates", updates)), "checkpoint": v,
-              "gate_check_4_workers": gate4,
-              "accounting_agrees": bool(all(v["ok"].values())), "gates_are": "engine-recorded (forced in the replay), not re-derived",
+              "gate_check": gate, "gate_check_4_workers": gate4,
+              "accounting_agrees": bool(all(v["ok"].values())),
+              "gates_are": "engine-recorded; every one of them checked against the rule on its recorded x . w, every x . w against the replayed weights (gate_check)",
               "negative_controls": controls, "controls_rejected": all(c["rejected"] for c in controls.values()),
               "seconds": round(time.perf_counter() - t0, 1)}
     if not traced["accounting_agrees"] or not traced["controls_rejected"]:

@@ -26,7 +26,7 @@ SYMBOLS = [
     "dsgd_loss_acc", "dsgd_async_step", "dsgd_update_grad", "dsgd_async_start", "dsgd_async_updates",
     "dsgd_async_stop", "dsgd_async_wait", "dsgd_comm_unique_id", "dsgd_comm_init", "dsgd_comm_destroy",
     "dsgd_prof_enable", "dsgd_prof_read", "dsgd_prof_read_kinds", "dsgd_range_nnz", "dsgd_grad_kernel_name",
-    "dsgd_device_ptrs", "dsgd_async_set_exchange", "dsgd_async_stats", "dsgd_async_set_trace", "dsgd_async_read_trace", "dsgd_tuning_info", "dsgd_column_ranks", "dsgd_debug_cycles",
+    "dsgd_device_ptrs", "dsgd_async_set_exchange", "dsgd_async_stats", "dsgd_async_set_trace", "dsgd_async_read_trace", "dsgd_async_read_trace_dots", "dsgd_tuning_info", "dsgd_column_ranks", "dsgd_debug_cycles",
     "dsgd_comm_init_all", "dsgd_build_dim_sparsity_devices", "dsgd_sync_step_devices", "dsgd_sync_step_ranges_devices",
     "dsgd_loss_acc_devices",
     "dsgd_dense_create", "dsgd_dense_destroy", "dsgd_dense_generate", "dsgd_dense_load", "dsgd_dense_set_weights",

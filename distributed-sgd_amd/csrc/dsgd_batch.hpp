@@ -244,8 +244,10 @@ __device__ __forceinline__ void bt_items_dot(const BtLds& L, const BtItems<R>& i
 }
 
 // x.w per row in chunk order, gate; returns this thread's count of active rows (0 or 1).
-// gmask (LDS, may be null; traced runs of the lock-free engine): bit b0 + row of the mini-batch set for an active row.
-__device__ __forceinline__ unsigned int bt_gate(const BtLds& L, int nbf, unsigned int* gmask = nullptr, int b0 = 0) {
+// gmask (LDS, may be null; traced runs of the lock-free engine): bit b0 + row of the mini-batch set for an active row;
+// gdot (global, null unless gmask is set): the x.w the row was gated on, entry b0 + row.
+__device__ __forceinline__ unsigned int bt_gate(const BtLds& L, int nbf, unsigned int* gmask = nullptr, int b0 = 0,
+                                                float* gdot = nullptr) {
   const int tid = threadIdx.x;
   if (tid >= nbf) return 0u;
   const int f0 = L.ifirst[tid], n = (L.rlen[tid] + BT_CH - 1) / BT_CH;
@@ -255,6 +257,7 @@ __device__ __forceinline__ unsigned int bt_gate(const BtLds& L, int nbf, unsigne
   const bool active = L.rlen[tid] > 0 && !(yy * d < 0.0f);   // ref: core/ml/SparseSVM.scala:27-28
   L.rcoef[tid] = active ? yy : 0.0f;
   if (gmask && active) atomicOr(&gmask[(unsigned int)(b0 + tid) >> 5], 1u << ((b0 + tid) & 31));
+  if (gdot) gdot[b0 + tid] = d;
   return active ? 1u : 0u;
 }
 
@@ -275,7 +278,8 @@ __device__ __forceinline__ void bt_scatter(const BtLds& L, float* __restrict__ g
 // left in slot 0 by bt_build.  Three workgroup barriers.
 template <int THREADS, int COLD, class WLoad>
 __device__ __forceinline__ unsigned int bt_giant_row(const CsrView& m, const BtLds& L, float* __restrict__ gcold,
-                                                     WLoad wload, float qscale, unsigned int* gmask = nullptr, int b0 = 0) {
+                                                     WLoad wload, float qscale, unsigned int* gmask = nullptr, int b0 = 0,
+                                                     float* gdot = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long s0 = L.rst[0];
   const int ln = L.rlen[0];
@@ -290,6 +294,7 @@ __device__ __forceinline__ unsigned int bt_giant_row(const CsrView& m, const BtL
   float d = 0.0f;
   for (int i = 0; i < THREADS / 64; ++i) d += L.pdot[i];
   unsigned int n_act = 0;
+  if (gdot && tid == 0) gdot[b0] = d;
   if (!(yy * d < 0.0f)) {
     n_act = tid == 0 ? 1u : 0u;
     if (gmask && tid == 0) atomicOr(&gmask[(unsigned int)b0 >> 5], 1u << (b0 & 31));
@@ -304,14 +309,14 @@ __device__ __forceinline__ unsigned int bt_giant_row(const CsrView& m, const BtL
 template <int THREADS, int R, int COLD, class RowOf, class WLoad>
 __device__ __forceinline__ unsigned int bt_batch(const CsrView& m, const BtLds& L, float* __restrict__ gcold, int B, int b0,
                                                  RowOf row_of, WLoad wload, float qscale, int* bad,
-                                                 unsigned int* gmask = nullptr) {
+                                                 unsigned int* gmask = nullptr, float* gdot = nullptr) {
   constexpr int CAP = THREADS / BT_G * R;
   unsigned int n_act = 0;
   while (b0 < B) {   // workgroup-uniform
     const BtRow row = bt_rows_issue<CAP>(m, B, b0, row_of, bad);
     const int2 bd = bt_build<THREADS, CAP>(L, B, b0, row);
     if (bd.x == 0) {
-      n_act += bt_giant_row<THREADS, COLD>(m, L, gcold, wload, qscale, gmask, b0);
+      n_act += bt_giant_row<THREADS, COLD>(m, L, gcold, wload, qscale, gmask, b0, gdot);
       b0 += 1;
       continue;
     }
@@ -319,7 +324,7 @@ __device__ __forceinline__ unsigned int bt_batch(const CsrView& m, const BtLds& 
     bt_items_issue<THREADS, R>(m, L, bd.y, it);
     bt_items_dot<THREADS, R>(L, it, wload);
     __syncthreads();
-    n_act += bt_gate(L, bd.x, gmask, b0);
+    n_act += bt_gate(L, bd.x, gmask, b0, gdot);
     __syncthreads();
     bt_scatter<R, COLD>(L, gcold, it, qscale);
     b0 += bd.x;
@@ -1273,13 +1278,23 @@ struct HogState {
 //          commit returned (the launch's starting count for a first iteration); the LDS copy of the hot weights is
 //          requested right next to that atomic
 //   [4] the regulariser scalar s = 2 lambda (w . ds) the iteration used (fp32 bits)   [5] its active rows
-//   [6..] the GATE DECISIONS of its mini-batch: bit t = row t of the sample was active (core/ml/SparseSVM.scala:27-28).
+//   [6] seen_from (low 32 bits): the update count thread 0 read with a returning atomic BEFORE the barrier behind which the
+//       workgroup requests its LDS copy of the hot weights -- every update committed up to there had landed when any
+//       weight of this iteration was read (an update's atomics are drained before its commit number is drawn), so the
+//       weights the iteration saw contain ALL of the updates 1..seen_from; seen_from <= read_at (the copy is requested
+//       before the worker's own commit returns)   [7] flags: bit 0 = first iteration of this launch (its copy was
+//       requested at start-up: only the run's starting weights are known to be contained, seen_from := 0)
+//   [8..] the GATE DECISIONS of its mini-batch: bit t = row t of the sample was active (core/ml/SparseSVM.scala:27-28)
+//   [8 + ceil(B / 32) ..] B floats: the x . w every sampled row was GATED ON (what bt_gate / bt_giant_row compared with
+//       zero), row t of the sample at word t -- oracle/hogwild_replay.gate_check_recorded_dots holds each of them to the
+//       reference's rule and to the range of the replayed weights it can have been computed from.
 // A constant-step run from w = 0 is chaotic (a 1e-7 perturbation of the initial weights moves the test loss by 0.1 after 400
 // updates: every margin starts AT the gate), so no replay that re-decides the gates can follow the engine.  With the
 // engine's own decisions and scalar on record the oracle recomputes every update EXACTLY (oracle/hogwild_replay.py):
 // the final weights must then agree to rounding -- every update applied once, with the reference's rule -- and the
 // recorded decisions are checked against the margins of the replayed weights at `read_at`.
-constexpr int HOG_TRACE_HDR = 6;
+constexpr int HOG_TRACE_HDR = 8;
+__host__ __device__ constexpr long long hog_trace_words(int batch) { return HOG_TRACE_HDR + (batch + 31) / 32 + batch; }
 
 struct HogArgs {
   CsrView m;
@@ -1297,7 +1312,8 @@ struct HogArgs {
   int batch, positional_bug, hl, wl, dp;   // hl: ranks with an LDS accumulator; wl: ranks with an LDS copy of w (whole 1 KiB pieces: a multiple of 256)
   unsigned long long* tprof;    // PROF: [0..5] cycles by phase (batch, hot sweep, cold strip, drain, scalars, weight copy), [15] iterations
   unsigned int* trace;          // optional (dsgd_async_set_trace): one record per mini-batch update, indexed by its commit number
-  long long trace_cap;          // ... records of HOG_TRACE_HDR + (batch + 31) / 32 words
+  long long trace_cap;          // ... records of hog_trace_words(batch) words
+  float* tdot;                  // traced runs: n_workers x batch, the x . w of the mini-batch in flight (copied into its record at the commit)
 };
 
 __device__ __forceinline__ unsigned long long hog_mix(unsigned long long z) {
@@ -1334,7 +1350,7 @@ struct HogCtl {   // per iteration parity
 };
 
 __host__ __device__ constexpr int hog_lds_words(int hl, int wl, int dp) {
-  return wl + ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8 + HOG_MAX_BATCH / 32 + 8 + 8;
+  return wl + ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8 + HOG_MAX_BATCH / 32 + 8 + 8 + 2;
 }
 
 // Copy of w[0, wl) into LDS: each wave moves 1 KiB pieces straight from the fabric into LDS (global_load_lds_dwordx4:
@@ -1370,6 +1386,13 @@ __device__ __forceinline__ int hog_read_stop(int* p) {
   asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p), "v"(zero) : "memory");
   return v;
 }
+// the update counter, read where the commits' returning atomics execute (traced runs only: seen_from)
+__device__ __forceinline__ unsigned long long hog_read_u64(unsigned long long* p) {
+  unsigned long long v;
+  const unsigned long long zero = 0ull;
+  asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p), "v"(zero) : "memory");
+  return v;
+}
 
 // the sampler of iteration `it`: rows base + (mul * t + off) mod n_k, t = 0..B-1 (distinct rows)
 __device__ __forceinline__ void hog_sampler(const HogArgs& a, int worker, unsigned long long it, unsigned int n_k,
@@ -1384,7 +1407,9 @@ __device__ __forceinline__ void hog_sampler(const HogArgs& a, int worker, unsign
 // Registers: the master's loss check (dsgd_eval_kernel, launched with 256-lane blocks while this engine runs: one wave
 // of 40 VGPRs per SIMD) must stay co-resident with the two waves per SIMD of this kernel (225 VGPRs -> 232 allocated):
 // 2 x 232 + 40 <= 512.
-template <bool PROF>   // PROF (DSGD_PLAN_PROF=1, tuning runs): thread 0 of worker 0 counts the cycles of an iteration by phase
+// TRACE: the traced form (dsgd_async_set_trace) is its own instantiation -- the recording costs 6 registers the untraced
+// engine does not have (236 -> 240 allocated: 2 x 240 + 40 > 512).
+template <bool PROF, bool TRACE>   // PROF (DSGD_PLAN_PROF=1, tuning runs): thread 0 of worker 0 counts the cycles of an iteration by phase
 __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   BtLds L;
@@ -1403,7 +1428,9 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   unsigned int* tp = gmask + HOG_MAX_BATCH / 32;                           // PROF: six phase sums, [6] the last stamp (32-bit)
   unsigned int* stl = tp + 8;                                              // thread 0: samples / active rows / weight atomics not yet flushed;
                                                                            //   [4..5] the update count its weights were read at (a register
-                                                                           //   pair in every lane otherwise: the kernel has none to spare)
+                                                                           //   pair in every lane otherwise: the kernel has none to spare);
+                                                                           //   traced runs: [3] / [6] seen_from of the next / this iteration, [7] flags
+  unsigned int* ctl_rec = stl + 8;                                         // traced runs: the record number of the update just committed (2 words)
   const int tid = threadIdx.x;
   const int worker = blockIdx.x;
   const bool prof = PROF && worker == 0 && tid == 0;
@@ -1418,7 +1445,12 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     for (int i = 0; i < 8; ++i) tp[i] = 0u;
   if (tid < HOG_MAX_BATCH / 32) gmask[tid] = 0u;
   if (tid < 4) stl[tid] = 0u;
-  unsigned int* const gm = a.trace ? gmask : nullptr;
+  unsigned int* const gm = TRACE ? gmask : nullptr;
+  float* const gdot = TRACE ? a.tdot + (long long)worker * a.batch : nullptr;
+  if (tid == 0) {   // traced runs: seen_from / flags of the record in the making (bit 0: the first iteration of this launch)
+    stl[6] = 0u;
+    stl[7] = 1u;
+  }
   const long long begin = a.asg_begin[worker];
   const unsigned int n_k = (unsigned int)(a.asg_end[worker] - begin);   // < 2^31 rows per context
   const long long base = a.positional_bug ? 0 : begin;   // ref: core/Slave.scala:87 indexes `data` by POSITION
@@ -1492,13 +1524,13 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     if (bd.x > 0) {
       bt_items_dot<HOG_THREADS, HOG_R>(L, items, wload);
       __syncthreads();
-      n_act += bt_gate(L, bd.x, gm, 0);
+      n_act += bt_gate(L, bd.x, gm, 0, gdot);
       __syncthreads();
       bt_scatter<HOG_R, 1>(L, gc, items, a.qscale);
       done = bd.x;
     }
     // ... and whatever did not fit its item slots (long rows, batches beyond 128 rows)
-    if (done < B) n_act += bt_batch<HOG_THREADS, HOG_R, 1>(a.m, L, gc, B, done, row_of, wload, a.qscale, &a.st->err, gm);
+    if (done < B) n_act += bt_batch<HOG_THREADS, HOG_R, 1>(a.m, L, gc, B, done, row_of, wload, a.qscale, &a.st->err, gm, gdot);
     // the next iteration's sample does not depend on w: request its row records now
     const HogCtl nxt = ctl[(it + 1) & 1];
     const BtRow row_n = bt_rows_issue<HOG_CAP>(a.m, B, 0, [&](int t) { return row_at(nxt.mul, nxt.off, t); }, &a.st->err);
@@ -1608,6 +1640,9 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       red[tid >> 6] = ds_acc;
       redn[tid >> 6] = n_act;
     }
+    // traced runs: the count of updates that have LANDED before any weight of the next iteration is requested (the copy of
+    // the hot weights goes out behind the barrier below; the value is back before this thread reaches it)
+    if (TRACE && tid == 0) stl[3] = (unsigned int)hog_read_u64(&a.st->updates);
     __syncthreads();   // (drains this workgroup's updates of w: the barrier waits for every outstanding memory operation)
     stamp(3);
     // The scalar s is kept by fp32 atomic increments (one per mini-batch, plus dsgd_update_grad's foreign updates): over
@@ -1653,19 +1688,26 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       const unsigned long long u = u_seen + 1ull;
       stl[4] = (unsigned int)u;
       stl[5] = (unsigned int)(u >> 32);
-      if (a.trace) {   // (one lane, once per mini-batch; the decisions were taken several barriers ago)
+      if (TRACE) {   // (one lane, once per mini-batch; the decisions were taken several barriers ago)
         const int mw = (B + 31) >> 5;
-        if ((long long)u <= a.trace_cap) {
-          unsigned int* rec = a.trace + (u - 1) * (unsigned long long)(HOG_TRACE_HDR + mw);
+        const bool kept = (long long)u <= a.trace_cap;
+        if (kept) {
+          unsigned int* rec = a.trace + (u - 1) * (unsigned long long)hog_trace_words(B);
           rec[0] = (unsigned int)worker;
           rec[1] = (unsigned int)it;
           rec[2] = (unsigned int)read_at;
           rec[3] = (unsigned int)(read_at >> 32);
           rec[4] = __float_as_uint(s_it);
           rec[5] = na & (HOG_ATOMIC_ONE - 1u);
+          rec[6] = stl[6];   // seen_from of THIS iteration (the count read in front of the barrier its weight copy went out behind)
+          rec[7] = stl[7];
           for (int i = 0; i < mw; ++i) rec[HOG_TRACE_HDR + i] = gmask[i];
         }
         for (int i = 0; i < mw; ++i) gmask[i] = 0u;   // (the next gate is behind the barriers below)
+        stl[6] = stl[3];   // ... of the next iteration: read in front of the drain barrier above
+        stl[7] = 0u;
+        ctl_rec[0] = kept ? (unsigned int)(u - 1) : 0xFFFFFFFFu;   // the record every thread adds its row's x . w to, below
+        ctl_rec[1] = kept ? (unsigned int)((u - 1) >> 32) : 0xFFFFFFFFu;
       }
       // statistics: kept in LDS, flushed every HOG_STATS_EVERY iterations and when the worker leaves
       const bool leaving = stop != 0 || (long long)u >= a.max_updates;
@@ -1685,6 +1727,13 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     stamp(4);
     hog_wcache_wait();
     __syncthreads();
+    if (TRACE) {   // the x . w of this mini-batch (written by bt_gate several barriers ago; read past L1) into its record
+      const unsigned long long r = ((unsigned long long)ctl_rec[1] << 32) | ctl_rec[0];
+      if (r != ~0ull) {
+        float* dst = reinterpret_cast<float*>(a.trace + r * (unsigned long long)hog_trace_words(B) + HOG_TRACE_HDR + ((B + 31) >> 5));
+        for (int t = tid; t < B; t += HOG_THREADS) dst[t] = __hip_atomic_load(&gdot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     stamp(5);
     ++it;
     bd = bd_n;

@@ -421,6 +421,9 @@ struct dsgd_ctx {
   long long trace_cap = 0;                  // records asked for
   long long trace_words = 0;                // words allocated at d_trace
   int trace_mw = 0;                         // mask words per record of the last traced run ((batch + 31) / 32)
+  int trace_batch = 0;                      // ... and its batch size (a record carries one x . w per sampled row)
+  float* d_tdot = nullptr;                  // traced runs: n_workers x batch, the x . w of every worker's mini-batch in flight
+  long long tdot_words = 0;
   int* h_one = nullptr;        // pinned constant 1: source of the stop-flag copy
   // small-batch plan kernel (one persistent workgroup): cold strip and the multi-worker sum buffer
   unsigned long long* d_tprof = nullptr;   // DSGD_PLAN_PROF=1: phase cycle counters of dsgd_plan_kernel (tuning runs)
@@ -2734,8 +2737,10 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   DSGD_ATTR(dsgd_eval_kernel<16>);
   DSGD_ATTR(dsgd_eval_kernel<8>);
   DSGD_ATTR(dsgd_colcount_kernel);
-  DSGD_ATTR(dsgd_hogwild_kernel<false>);
-  DSGD_ATTR(dsgd_hogwild_kernel<true>);
+  DSGD_ATTR((dsgd_hogwild_kernel<false, false>));
+  DSGD_ATTR((dsgd_hogwild_kernel<true, false>));
+  DSGD_ATTR((dsgd_hogwild_kernel<false, true>));
+  DSGD_ATTR((dsgd_hogwild_kernel<true, true>));
   DSGD_ATTR(dsgd_mb_grad_kernel);
   DSGD_ATTR(dsgd_vt_grad_kernel<true>);
   DSGD_ATTR(dsgd_vt_grad_kernel<false>);
@@ -2846,6 +2851,7 @@ int dsgd_destroy(dsgd_ctx* c) {
   if (c->h_one) (void)hipHostFree(c->h_one);
   (void)hipFree(c->d_hog_it);
   (void)hipFree(c->d_trace);
+  (void)hipFree(c->d_tdot);
   (void)hipFree(c->d_wprev);
   (void)hipFree(c->d_wdelta);
   (void)hipFree(c->d_tprof);
@@ -3899,10 +3905,17 @@ static int hog_launch(dsgd_ctx* c, long long max_updates) {
   a.wl = std::min(c->hog_wl, c->dp) & ~255;
   a.trace = c->trace_cap > 0 ? c->d_trace : nullptr;
   a.trace_cap = c->trace_cap;
+  a.tdot = c->d_tdot;
   const size_t lds = sizeof(float) * (size_t)hog_lds_words(a.hl, a.wl, c->dp);
   a.tprof = c->d_tprof;
-  if (c->d_tprof) hipLaunchKernelGGL(dsgd_hogwild_kernel<true>, dim3(c->hog_n), dim3(HOG_THREADS), lds, c->async_stream, a);
-  else hipLaunchKernelGGL(dsgd_hogwild_kernel<false>, dim3(c->hog_n), dim3(HOG_THREADS), lds, c->async_stream, a);
+  const dim3 grid(c->hog_n), block(HOG_THREADS);
+  if (a.trace) {
+    if (c->d_tprof) hipLaunchKernelGGL((dsgd_hogwild_kernel<true, true>), grid, block, lds, c->async_stream, a);
+    else hipLaunchKernelGGL((dsgd_hogwild_kernel<false, true>), grid, block, lds, c->async_stream, a);
+  } else {
+    if (c->d_tprof) hipLaunchKernelGGL((dsgd_hogwild_kernel<true, false>), grid, block, lds, c->async_stream, a);
+    else hipLaunchKernelGGL((dsgd_hogwild_kernel<false, false>), grid, block, lds, c->async_stream, a);
+  }
   HIP_TRY(hipGetLastError());
   return DSGD_OK;
 }
@@ -3983,15 +3996,24 @@ int dsgd_async_start(dsgd_ctx* c, const int64_t* assigned_begin, const int64_t* 
     HIP_TRY(hipMalloc(&c->d_hog_it, sizeof(unsigned long long) * (size_t)n_workers));
     c->hog_workers = n_workers;
   }
-  if (c->trace_cap > 0) {   // traced run: records of HOG_TRACE_HDR + ceil(batch / 32) words
+  if (c->trace_cap > 0) {   // traced run: records of hog_trace_words(batch) words (header, gate masks, one x . w per row)
     c->trace_mw = (batch + 31) / 32;
-    const long long need = c->trace_cap * (HOG_TRACE_HDR + c->trace_mw);
+    c->trace_batch = batch;
+    const long long need = c->trace_cap * hog_trace_words(batch);
     if (need > c->trace_words) {
       (void)hipFree(c->d_trace);
       c->d_trace = nullptr;
       c->trace_words = 0;
       HIP_TRY(hipMalloc(&c->d_trace, sizeof(unsigned int) * (size_t)need));
       c->trace_words = need;
+    }
+    const long long need_dot = (long long)n_workers * batch;
+    if (need_dot > c->tdot_words) {
+      (void)hipFree(c->d_tdot);
+      c->d_tdot = nullptr;
+      c->tdot_words = 0;
+      HIP_TRY(hipMalloc(&c->d_tdot, sizeof(float) * (size_t)need_dot));
+      c->tdot_words = need_dot;
     }
   }
   if (exchange && !c->d_wprev) {
@@ -4153,9 +4175,13 @@ int dsgd_async_set_trace(dsgd_ctx* c, int64_t capacity) {
   c->trace_cap = capacity;   // (the buffer is sized at dsgd_async_start: a record's length depends on the batch size)
   if (capacity == 0) {
     (void)hipFree(c->d_trace);   // (no engine is resident: hipFree's device synchronisation returns)
+    (void)hipFree(c->d_tdot);
     c->d_trace = nullptr;
+    c->d_tdot = nullptr;
     c->trace_words = 0;
+    c->tdot_words = 0;
     c->trace_mw = 0;
+    c->trace_batch = 0;
   }
   return DSGD_OK;
 }
@@ -4173,7 +4199,7 @@ int dsgd_async_read_trace(dsgd_ctx* c, int32_t* worker, uint32_t* iteration, int
   DSGD_TRY(async_refresh(c));
   const long long have = std::min<long long>((long long)c->h_hog->updates, c->trace_cap);
   const long long m = std::min<long long>(have, n);
-  const int mw = c->trace_mw, rw = HOG_TRACE_HDR + mw;
+  const int mw = c->trace_mw, rw = (int)hog_trace_words(c->trace_batch);
   if (n_out) *n_out = have;
   if (mask_words_out) *mask_words_out = mw;
   if (m == 0) return DSGD_OK;
@@ -4192,6 +4218,37 @@ int dsgd_async_read_trace(dsgd_ctx* c, int32_t* worker, uint32_t* iteration, int
     memcpy(&s_used[i], &r[4], sizeof(float));
     n_active[i] = (int32_t)r[5];
     memcpy(gate_mask + (size_t)i * (size_t)mw, r + HOG_TRACE_HDR, sizeof(unsigned int) * (size_t)mw);
+  }
+  return DSGD_OK;
+}
+
+int dsgd_async_read_trace_dots(dsgd_ctx* c, int64_t* seen_from, float* dots, int64_t n, int32_t* batch_out) {
+  DSGD_TRY(check_ctx(c));
+  if (n < 0 || (n > 0 && (!seen_from || !dots))) return fail(DSGD_EINVAL, "bad trace arguments");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c));
+  if (c->async_running) return fail(DSGD_ESTATE, "async computation running (dsgd_async_wait / dsgd_async_stop first)");
+  if (!c->d_trace || !c->d_hog || c->trace_mw == 0)
+    return fail(DSGD_ESTATE, "no traced run on this context (dsgd_async_set_trace, then dsgd_async_start)");
+  DSGD_TRY(async_refresh(c));
+  const long long have = std::min<long long>((long long)c->h_hog->updates, c->trace_cap);
+  const long long m = std::min<long long>(have, n);
+  const int B = c->trace_batch, mw = c->trace_mw, rw = (int)hog_trace_words(B);
+  if (batch_out) *batch_out = B;
+  if (m == 0) return DSGD_OK;
+  std::vector<unsigned int> recs;
+  try {
+    recs.resize((size_t)m * (size_t)rw);
+  } catch (const std::bad_alloc&) {
+    return fail(DSGD_ENOMEM, "out of host memory");
+  }
+  HIP_TRY(hipMemcpy(recs.data(), c->d_trace, sizeof(unsigned int) * recs.size(), hipMemcpyDeviceToHost));
+  for (long long i = 0; i < m; ++i) {
+    const unsigned int* r = recs.data() + (size_t)i * (size_t)rw;
+    const unsigned long long read_at = ((unsigned long long)r[3] << 32) | r[2];
+    // the low word of seen_from, at most 2^32 - 1 updates below read_at; a launch's first iteration knows only the run's start
+    seen_from[i] = (r[7] & 1u) ? 0 : (int64_t)(read_at - (unsigned long long)((unsigned int)read_at - r[6]));
+    memcpy(dots + (size_t)i * (size_t)B, r + HOG_TRACE_HDR + mw, sizeof(float) * (size_t)B);
   }
   return DSGD_OK;
 }

@@ -263,7 +263,15 @@ class Engine:
             check(self._lib.dsgd_async_read_trace(self._ctx, ptr(worker), ptr(it), ptr(read_at), ptr(s), ptr(n_active), ptr(mask),
                                                   C.c_int64(k), None, None))
         bits = ((mask[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).astype(bool).reshape(k, 32 * m)
-        return {"worker": worker, "it": it, "read_at": read_at, "s": s, "n_active": n_active, "mask": bits}
+        # what every decision was taken on: the x . w of each sampled row, and the update count known to be in the weights
+        bo = C.c_int32(0)
+        check(self._lib.dsgd_async_read_trace_dots(self._ctx, None, None, C.c_int64(0), C.byref(bo)))
+        seen_from = np.zeros(k, dtype=np.int64)
+        dots = np.zeros((k, max(1, bo.value)), dtype=np.float32)
+        if k:
+            check(self._lib.dsgd_async_read_trace_dots(self._ctx, ptr(seen_from), ptr(dots), C.c_int64(k), None))
+        return {"worker": worker, "it": it, "read_at": read_at, "s": s, "n_active": n_active, "mask": bits,
+                "seen_from": seen_from, "dot": dots}
 
     # -- multi-GPU ---------------------------------------------------------------------------------
     @staticmethod

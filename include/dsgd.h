@@ -244,6 +244,14 @@ int dsgd_async_wait(dsgd_ctx* ctx); /* block until max_updates reached */
 int dsgd_async_set_trace(dsgd_ctx* ctx, int64_t capacity);
 int dsgd_async_read_trace(dsgd_ctx* ctx, int32_t* worker, uint32_t* iteration, int64_t* read_at, float* s_used,
                           int32_t* n_active, uint32_t* gate_mask, int64_t n, int64_t* n_out, int32_t* mask_words_out);
+/* ... and what every recorded decision was TAKEN ON (round 6): dots holds *batch_out floats per record, entry t = the
+ * fp32 x . w row t of the update's sample was gated on; seen_from[i] <= read_at[i] is an update count read (returning
+ * atomic) before the iteration requested any weight: every update with a commit number <= seen_from had fully landed in
+ * the weights the iteration saw (0 for a launch's first iteration: only the run's starting weights are known to be in).
+ * With these the oracle checks EVERY decision of a run of any worker count (oracle/hogwild_replay.gate_check_recorded_dots):
+ * decision == !(y d < 0) for the recorded d (core/ml/SparseSVM.scala:27-28), and d inside the range x . w can take over
+ * the replayed weights between seen_from and the updates still in flight at the commit (core/Slave.scala:92).       */
+int dsgd_async_read_trace_dots(dsgd_ctx* ctx, int64_t* seen_from, float* dots, int64_t n, int32_t* batch_out);
 
 /* ---- multi-GPU (one process per GPU) ---------------------------------------
  * The synchronous master's aggregate (core/Master.scala:190-194: Future.sequence barrier +

@@ -294,3 +294,186 @@ def gate_check_small_lag(o, w0, split, batch, lr, seed, trace, max_lag=1, positi
     out["ok"] = not out["outside"]
     out["outside"] = out["outside"][:5]
     return out
+
+
+# ---- EVERY decision of a run of ANY worker count, held to what it was taken on (round 6) --------------------------------
+# The engine also records the x . w every sampled row was gated on and `seen_from`, an update count it read before it
+# requested any weight of the iteration (dsgd_async_read_trace_dots, include/dsgd.h).  Two statements per ROW, for 100 % of
+# the rows of 100 % of the updates:
+#   (a) RULE: recorded decision == !(y d < 0) for the recorded d                      (core/ml/SparseSVM.scala:27-28)
+#   (b) RANGE: d is an x . w of weights the iteration CAN have read (core/Slave.scala:92): coordinate by coordinate between
+#       the smallest and the largest value the replayed history allows.  What an iteration with commit number c can have
+#       seen of coordinate j is W_lo[j], lo = seen_from (all of the updates 1..lo had landed), minus ANY SUBSET of the
+#       deltas on j of the updates that may have been landing while it read:
+#           S(c) = {lo < u < c}  +  {the first update of every OTHER worker with a commit number > c}
+#       (updates land before they commit, in any order across workers; a worker's second update after c starts its sweep
+#       after its first one committed, i.e. after c; the iteration's own update c goes out behind its reads; the worker's
+#       OWN previous update, commit number read_at, is not in S either: its atomics were drained before the worker
+#       requested any weight of this iteration, so it is part of what was seen for certain).  Hence
+#           w_j in [W_lo[j] - sum_{u in S} max(delta_u[j], 0),  W_lo[j] - sum_{u in S} min(delta_u[j], 0)]
+#       and d in the interval sum_j x_j * [.,.], widened by the fp32 resolution of the dot product and by the accounting
+#       error of the replay (statement (A): the replayed weights follow the engine's fp32 weights to ~1e-6 |w|inf).
+#       This is RIGOROUS: a correct engine has no row outside, whatever the interleaving.  Also reported, not rigorous:
+#       the narrower interval of the coordinates' values over the replayed STATES W_t, lo <= t < c (plus the in-flight
+#       part beyond c) -- the states differ from what can be read by the order in which concurrent updates land.
+# How sharp the statement is is reported with it: the share of rows whose interval excludes zero (their decision is then
+# pinned by the replayed weights alone, whatever d says) and the interval's width against |d|.
+DOT_ACC = 1e-6          # accounting error of the replayed weights per coordinate, relative to max(1, |W|inf)  (5e-7 measured)
+DOT_RES = 8.0           # fp32 resolution of a dot product of nnz terms: DOT_RES * (nnz + 32) * 2^-24 * sum |x_j| |w_j|
+
+
+def _lookup(cols_sorted, vals, query):
+    """values of a sparse vector (ascending columns) at the columns `query` (0 where absent)"""
+    if len(cols_sorted) == 0:
+        return np.zeros(len(query))
+    pos = np.minimum(np.searchsorted(cols_sorted, query), len(cols_sorted) - 1)
+    return np.where(cols_sorted[pos] == query, vals[pos], 0.0)
+
+
+def _sparse_delta(o, rows, active, s, batch, lr):
+    d = forced_delta(o, rows, active, s, batch, lr)
+    nz = np.flatnonzero(d)
+    return nz.astype(np.int32), d[nz]
+
+
+def gate_check_recorded_dots(o, w0, split, batch, lr, seed, trace, positional_bug=False, prefix_every=1, collect=False):
+    """Statements (a) and (b) above for every row of every update of one traced run started from `w0`.  Returns counts,
+    the first few violations (`outside_rule`, `outside_range`: empty for a correct engine) and the sharpness figures.
+    prefix_every: the non-rigorous states-only interval is evaluated for every prefix_every-th update (0: never).
+    collect: also return the per-row intervals ("lo", "hi": [n, batch]) for the negative controls."""
+    worker, it, read_at = np.asarray(trace["worker"]), np.asarray(trace["it"]), np.asarray(trace["read_at"])
+    s_rec, mask = np.asarray(trace["s"], dtype=np.float64), np.asarray(trace["mask"])
+    seen, dots = np.asarray(trace["seen_from"], dtype=np.int64), np.asarray(trace["dot"], dtype=np.float64)
+    n, k_workers, dim1 = len(worker), len(split), o.dim + 1
+    out = {"updates": n, "rows": 0, "gate_rows_checked": 0, "empty_rows": 0, "rule_violations": 0, "range_violations": 0,
+           "outside_rule": [], "outside_range": [], "rows_pinned_by_the_replay": 0, "states_rows": 0, "states_inside": 0,
+           "max_window": 0, "mean_window": 0.0}
+    if n == 0:
+        out["ok"] = True
+        return out
+    commit = np.arange(1, n + 1, dtype=np.int64)
+    if np.any(seen < 0) or np.any(seen > read_at) or np.any(read_at >= commit):
+        raise ValueError("trace inconsistent: seen_from <= read_at < commit violated")
+    # pass 1: every update's delta with the recorded decisions (sparse), the rows it sampled
+    w = np.asarray(w0, dtype=np.float64).copy()
+    rows_of, dcols, dvals = [], [], []
+    winf = 1.0
+    for c in range(1, n + 1):
+        k = int(worker[c - 1])
+        b, e = split[k]
+        rows = hog_rows(seed, k, int(it[c - 1]), b, e - b, batch, positional_bug)
+        cols, vals = _sparse_delta(o, rows, mask[c - 1, :batch], float(s_rec[c - 1]), batch, lr)
+        w[cols] -= vals
+        winf = max(winf, float(np.abs(w[cols]).max()) if len(cols) else 0.0)
+        rows_of.append(rows)
+        dcols.append(cols)
+        dvals.append(vals)
+    w_final = w
+    # a worker's updates in commit order, to find "the first update of worker k beyond c"
+    by_worker = [np.flatnonzero(worker == k) + 1 for k in range(k_workers)]
+    nxt = [0] * k_workers                      # position in by_worker[k] of its first update with a commit number >= c
+    window = commit - 1 - seen                 # updates between what is known to be in and the commit
+    out["max_window"], out["mean_window"] = int(window.max()), float(window.mean())
+    ring_n = 1
+    while ring_n < int(window.max()) + 2:
+        ring_n *= 2
+    if 2 * ring_n * dim1 * 8 > 6 << 30:
+        raise MemoryError("a window of %d updates needs a %d-entry ring" % (int(window.max()), ring_n))
+    cp_ring, cn_ring = np.zeros((ring_n, dim1)), np.zeros((ring_n, dim1))   # cumulative positive / negative parts after t updates
+    cp, cn = np.zeros(dim1), np.zeros(dim1)
+    pa, na = np.zeros(dim1), np.zeros(dim1)    # the same over every worker's first update with a commit number >= c
+    for k in range(k_workers):
+        if len(by_worker[k]):
+            u = int(by_worker[k][0]) - 1
+            np.add.at(pa, dcols[u], np.maximum(dvals[u], 0.0))
+            np.add.at(na, dcols[u], np.minimum(dvals[u], 0.0))
+    w0 = np.asarray(w0, dtype=np.float64)
+    eps32 = 2.0 ** -24
+    acc = DOT_ACC * winf
+    lo_all = np.zeros((n, batch)) if collect else None
+    hi_all = np.zeros((n, batch)) if collect else None
+    width_over_d = []
+    for c in range(1, n + 1):
+        k = int(worker[c - 1])
+        cols_c, vals_c = dcols[c - 1], dvals[c - 1]
+        # the iteration's own update is not among what it can have read: out of the in-flight sums ...
+        pa[cols_c] -= np.maximum(vals_c, 0.0)
+        na[cols_c] -= np.minimum(vals_c, 0.0)
+        rows = rows_of[c - 1]
+        y = o.label[rows].astype(np.float64)
+        flat, rid = _entries(o, rows)
+        v = o.val[flat].astype(np.float64)
+        cols = o.col[flat]
+        lo_t = int(seen[c - 1])
+        base = w0[cols] - cp_ring[lo_t % ring_n, cols] - cn_ring[lo_t % ring_n, cols]                  # W_lo
+        p = cp[cols] - cp_ring[lo_t % ring_n, cols] + pa[cols]                                        # subsets can take this much off ...
+        q = cn[cols] - cn_ring[lo_t % ring_n, cols] + na[cols]                                        # ... or add this much (q <= 0)
+        ra = int(read_at[c - 1])
+        if ra > lo_t:                           # the worker's own previous update: seen for certain, not a maybe
+            own = _lookup(dcols[ra - 1], dvals[ra - 1], cols)
+            base = base - own
+            p = p - np.maximum(own, 0.0)
+            q = q - np.minimum(own, 0.0)
+        w_min, w_max = base - np.maximum(p, 0.0), base - np.minimum(q, 0.0)
+        t_lo = np.where(v >= 0.0, v * w_min, v * w_max)
+        t_hi = np.where(v >= 0.0, v * w_max, v * w_min)
+        d_lo = np.bincount(rid, weights=t_lo, minlength=batch)
+        d_hi = np.bincount(rid, weights=t_hi, minlength=batch)
+        nnz = np.bincount(rid, minlength=batch)
+        mag = np.bincount(rid, weights=np.abs(v) * np.maximum(np.abs(w_min), np.abs(w_max)), minlength=batch)
+        slack = DOT_RES * (nnz + 32) * eps32 * mag + np.bincount(rid, weights=np.abs(v), minlength=batch) * acc + 1e-30
+        d = dots[c - 1, :batch]
+        rec = mask[c - 1, :batch].astype(bool)
+        live = nnz > 0                          # (a row without non-zeros contributes nothing whatever its decision)
+        out["rows"] += batch
+        out["empty_rows"] += int((~live).sum())
+        out["gate_rows_checked"] += int(live.sum())
+        rule_bad = live & (rec != ~(y * d < 0.0))                                                     # (a)
+        range_bad = live & ((d < d_lo - slack) | (d > d_hi + slack))                                  # (b)
+        out["rule_violations"] += int(rule_bad.sum())
+        out["range_violations"] += int(range_bad.sum())
+        for r in np.flatnonzero(rule_bad)[:2]:
+            if len(out["outside_rule"]) < 5:
+                out["outside_rule"].append({"update": c, "row": int(rows[r]), "t": int(r), "d": float(d[r]), "y": float(y[r]), "recorded_active": bool(rec[r])})
+        for r in np.flatnonzero(range_bad)[:2]:
+            if len(out["outside_range"]) < 5:
+                out["outside_range"].append({"update": c, "row": int(rows[r]), "t": int(r), "d": float(d[r]), "range": [float(d_lo[r]), float(d_hi[r])],
+                                             "slack": float(slack[r]), "window": int(window[c - 1])})
+        pinned = live & ((y * (d_lo - slack) >= 0.0) & (y * (d_hi + slack) >= 0.0) | (y * (d_lo - slack) < 0.0) & (y * (d_hi + slack) < 0.0))
+        out["rows_pinned_by_the_replay"] += int(pinned.sum())
+        width_over_d.append((d_hi - d_lo)[live] / np.maximum(np.abs(d[live]), 1e-12))
+        if collect:
+            lo_all[c - 1], hi_all[c - 1] = d_lo - slack, d_hi + slack
+        if prefix_every and c % prefix_every == 0:
+            # the narrower, NOT rigorous interval: each coordinate somewhere among its values in the states W_t, lo <= t < c
+            ucols, inv = np.unique(cols, return_inverse=True)
+            ts = np.arange(lo_t, c, dtype=np.int64) % ring_n
+            hist = w0[ucols][None, :] - cp_ring[np.ix_(ts, ucols)] - cn_ring[np.ix_(ts, ucols)]
+            if ra > lo_t:                       # (every state before the own previous update lacks it: shifted as above)
+                pre = (np.arange(lo_t, c) < ra)[:, None] * _lookup(dcols[ra - 1], dvals[ra - 1], ucols)[None, :]
+                hist = hist - pre
+            s_min, s_max = hist.min(axis=0)[inv] - np.maximum(pa[cols], 0.0), hist.max(axis=0)[inv] - np.minimum(na[cols], 0.0)
+            j_lo = np.bincount(rid, weights=np.where(v >= 0.0, v * s_min, v * s_max), minlength=batch)
+            j_hi = np.bincount(rid, weights=np.where(v >= 0.0, v * s_max, v * s_min), minlength=batch)
+            out["states_rows"] += int(live.sum())
+            out["states_inside"] += int((live & (d >= j_lo - slack) & (d <= j_hi + slack)).sum())
+        # ... and on to state c: the update joins the history, its worker's next one the in-flight set
+        cp[cols_c] += np.maximum(vals_c, 0.0)
+        cn[cols_c] += np.minimum(vals_c, 0.0)
+        cp_ring[c % ring_n] = cp
+        cn_ring[c % ring_n] = cn
+        nxt[k] += 1
+        if nxt[k] < len(by_worker[k]):
+            u = int(by_worker[k][nxt[k]]) - 1
+            pa[dcols[u]] += np.maximum(dvals[u], 0.0)
+            na[dcols[u]] += np.minimum(dvals[u], 0.0)
+    wod = np.concatenate(width_over_d) if width_over_d else np.zeros(1)
+    out["width_over_abs_d_median"] = float(np.median(wod))
+    out["width_over_abs_d_p10"] = float(np.quantile(wod, 0.1))
+    out["share_pinned_by_the_replay"] = out["rows_pinned_by_the_replay"] / max(1, out["gate_rows_checked"])
+    out["states_share_inside"] = out["states_inside"] / max(1, out["states_rows"]) if out["states_rows"] else None
+    out["ok"] = out["rule_violations"] == 0 and out["range_violations"] == 0
+    out["w_replayed"] = w_final
+    if collect:
+        out["lo"], out["hi"] = lo_all, hi_all
+    return out

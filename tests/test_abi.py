@@ -155,7 +155,8 @@ def test_register_budget_of_the_async_engine_and_the_concurrent_loss_check(tmp_p
         if m and name:
             vg[name] = int(m.group(1))
     alloc = lambda n: -(-n // 8) * 8
-    hog = [v for k, v in vg.items() if "dsgd_hogwild_kernelILb0E" in k]   # (<true> is the tuning variant with phase counters)
+    # (<true, .> is the tuning variant with phase counters, <., true> the traced form: parity runs, no concurrent check)
+    hog = [v for k, v in vg.items() if "dsgd_hogwild_kernelILb0ELb0E" in k]
     evals = [v for k, v in vg.items() if "dsgd_eval_kernel" in k]
     assert len(hog) == 1 and len(evals) == 4
     assert 2 * alloc(hog[0]) + alloc(max(evals)) <= 512, (hog, evals)

@@ -40,6 +40,8 @@ def check_trace(trace, k, updates, target):
         assert np.array_equal(it[m], np.arange(len(m), dtype=it.dtype)), "worker %d: iterations out of order" % j
         assert np.array_equal(read_at[m][1:], commit[m][:-1]), "worker %d: read_at is not its previous commit" % j
     assert np.array_equal(trace["mask"][:, :BATCH].sum(axis=1), trace["n_active"]) and not trace["mask"][:, BATCH:].any()
+    # what is known to be in the weights of an iteration was counted before its worker's previous commit
+    assert trace["dot"].shape == (updates, BATCH) and np.all(trace["seen_from"] >= 0) and np.all(trace["seen_from"] <= read_at)
 
 
 def traced_run(k, n_rows, checkpoints, data_seed=13):
@@ -125,6 +127,11 @@ def test_trace_api_states():
         eng.async_wait()
         tr = eng.async_read_trace()
         assert tr["mask"].shape == (6, 320) and np.array_equal(tr["mask"][:, :300].sum(axis=1), tr["n_active"])
+        # ... and leaves the x . w of every one of the 300 rows: the decisions are the rule on them (SparseSVM.scala:27-28)
+        assert tr["dot"].shape == (6, 300) and np.count_nonzero(tr["dot"]) > 0.9 * 6 * 300
+        for i in range(6):
+            y = data.label[hr.hog_rows(2, 0, int(tr["it"][i]), 0, 3200, 300)].astype(np.float64)
+            assert np.array_equal(tr["mask"][i, :300], ~(y * tr["dot"][i].astype(np.float64) < 0.0))
         eng.async_set_trace(0)
         eng.async_start([(0, 3200)], batch=10, lr=0.5, max_updates=5, seed=1, positional_bug=False)   # untraced runs go on as before
         eng.async_wait()
@@ -188,3 +195,83 @@ def test_gate_decisions_of_four_workers_are_the_reference_gate():
     bad["mask"][c - 1, int(m.argmax())] ^= True
     gb = hr.gate_check_small_lag(o, np.zeros(data.dim + 1), split, BATCH, LR, seed, bad, max_lag=1)
     assert not gb["ok"] and any(v["update"] == c for v in gb["outside"]), gb
+
+
+@pytest.mark.parametrize("k,n_rows,n_upd,prefix_every", [
+    (4, 40000, 1500, 1),
+    (64, 40000, 3200, 2),
+    (256, 100000, 6144, 16),                        # the benchmarked shape (bench.py hogwild: 256 workers x batch 100)
+])
+def test_every_gate_decision_is_the_rule_on_weights_it_can_have_read(k, n_rows, n_upd, prefix_every):
+    """Round 6: the gate statement with teeth at ANY worker count, 100 % of the rows of 100 % of the updates.  The engine
+    records the x . w every sampled row was gated on and `seen_from`, an update count read before the iteration requested
+    any weight.  (a) every recorded decision is the reference's rule !(y d < 0) on its recorded d
+    (core/ml/SparseSVM.scala:27-28); (b) every d lies between the smallest and the largest x . w the replayed weights
+    allow: everything up to seen_from and the worker's own previous update in, any subset of the updates in flight
+    (oracle/hogwild_replay.gate_check_recorded_dots -- rigorous: no row of a correct engine is outside, whatever the
+    interleaving).  Negative controls: a decision flipped against its own d; a d moved just outside its range; the d's of
+    every update replaced by those its worker recorded three iterations earlier (a stale-product engine: the rule still
+    holds on the recorded numbers, the range must object)."""
+    data = dsgd_amd.synth.generate(n_rows, seed=17)
+    n_train = int(n_rows * 0.8)
+    o = orc.Oracle(data.dim, data.row_ptr, data.col, data.val, data.label, LAM)
+    o.set_dim_sparsity(o.dim_sparsity(n_train))
+    split = [(r.start, r.stop) for r in host.split_vanilla(n_train, k)]
+    seed = 20260 + k
+    with dsgd_amd.Engine(data.dim, LAM) as eng:
+        eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+        eng.build_dim_sparsity(n_train)
+        eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+        eng.async_set_trace(n_upd + k)
+        eng.async_start(split, batch=BATCH, lr=LR, max_updates=n_upd, seed=seed, positional_bug=False)
+        eng.async_wait()
+        u, _ = eng.async_updates()
+        trace = eng.async_read_trace()
+        w_eng = eng.get_weights().astype(np.float64)
+        eng.async_set_trace(0)
+    check_trace(trace, k, u, n_upd)
+    w0 = np.zeros(data.dim + 1)
+    g = hr.gate_check_recorded_dots(o, w0, split, BATCH, LR, seed, trace, prefix_every=prefix_every, collect=True)
+    show = {q: v for q, v in g.items() if q not in ("w_replayed", "lo", "hi")}
+    print("k=%d: %d updates, %d rows checked (%d empty): rule violations %d, range violations %d; window (updates between seen_from and "
+          "the commit) mean %.1f max %d; rows whose decision the replay alone pins: %.3f; range width / |d| median %.2f (p10 %.2f); "
+          "inside the states-only interval (not rigorous): %s" % (
+              k, g["updates"], g["gate_rows_checked"], g["empty_rows"], g["rule_violations"], g["range_violations"], g["mean_window"],
+              g["max_window"], g["share_pinned_by_the_replay"], g["width_over_abs_d_median"], g["width_over_abs_d_p10"], g["states_share_inside"]))
+    assert g["ok"], show
+    assert g["gate_rows_checked"] + g["empty_rows"] == u * BATCH and g["empty_rows"] <= 0.001 * u * BATCH
+    # the replay these ranges were built from IS the engine's run (accounting, statement (A))
+    assert np.abs(w_eng - g["w_replayed"]).max() <= hr.ACCOUNT_TOL * max(1.0, np.abs(g["w_replayed"]).max())
+    if k <= 4:     # few workers: a real share of the rows is pinned by the replayed weights alone (0.38 measured: the margins of
+        assert g["share_pinned_by_the_replay"] > 0.15, show   # a constant-step run are as small as what a few updates move them by)
+    # -- negative controls --
+    c, t = u // 2, 7
+    kk = int(trace["worker"][c])
+    y = float(o.label[hr.hog_rows(seed, kk, int(trace["it"][c]), split[kk][0], split[kk][1] - split[kk][0], BATCH)[t]])
+    bad = {q: np.array(v, copy=True) for q, v in trace.items()}
+    bad["mask"][c, t] ^= True
+    bad["n_active"] = bad["mask"][:, :BATCH].sum(axis=1).astype(np.int32)
+    g1 = hr.gate_check_recorded_dots(o, w0, split, BATCH, LR, seed, bad, prefix_every=0)
+    assert not g1["ok"] and g1["rule_violations"] >= 1 and g1["outside_rule"][0]["update"] == c + 1, g1["outside_rule"]
+    bad = {q: np.array(v, copy=True) for q, v in trace.items()}
+    bad["dot"][c, t] = np.float32(g["hi"][c, t] + 0.05 * (g["hi"][c, t] - g["lo"][c, t]) + 1e-3)
+    bad["mask"][c, t] = not (y * float(bad["dot"][c, t]) < 0.0)
+    bad["n_active"] = bad["mask"][:, :BATCH].sum(axis=1).astype(np.int32)
+    g2 = hr.gate_check_recorded_dots(o, w0, split, BATCH, LR, seed, bad, prefix_every=0)
+    assert not g2["ok"] and any(v["update"] == c + 1 and v["t"] == t for v in g2["outside_range"]), g2["outside_range"]
+    # a stale-product engine: every update gated on the products its worker computed three iterations before (other rows,
+    # older weights); decisions re-derived from those numbers so that the rule holds
+    bad = {q: np.array(v, copy=True) for q, v in trace.items()}
+    for j in range(k):
+        m = np.flatnonzero(trace["worker"] == j)
+        if len(m) > 3:
+            bad["dot"][m[3:]] = trace["dot"][m[:-3]]
+    for i in range(u):
+        kk = int(trace["worker"][i])
+        yy = o.label[hr.hog_rows(seed, kk, int(trace["it"][i]), split[kk][0], split[kk][1] - split[kk][0], BATCH)].astype(np.float64)
+        bad["mask"][i, :BATCH] = ~(yy * bad["dot"][i].astype(np.float64) < 0.0)
+    bad["n_active"] = bad["mask"][:, :BATCH].sum(axis=1).astype(np.int32)
+    g3 = hr.gate_check_recorded_dots(o, w0, split, BATCH, LR, seed, bad, prefix_every=0)
+    print("k=%d control 'stale products': rule violations %d, range violations %d of %d rows (%.1f %%)" % (
+        k, g3["rule_violations"], g3["range_violations"], g3["gate_rows_checked"], 100.0 * g3["range_violations"] / g3["gate_rows_checked"]))
+    assert g3["rule_violations"] == 0 and not g3["ok"]

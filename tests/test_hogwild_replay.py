@@ -157,3 +157,117 @@ def test_small_lag_gate_check_on_a_modelled_schedule():
     _, trace = model_run(o, split, 50, 0.5, 7, 64)
     g = hr.gate_check_small_lag(o, np.zeros(o.dim + 1), split, 50, 0.5, 7, trace, max_lag=1)
     assert g["updates_checked"] == 2 and g["ok"]            # (only the first two updates of the run have lag <= 1)
+
+
+# ---- every decision held to the x . w it was taken on (hogwild_replay.gate_check_recorded_dots, round 6) ----------------
+def landing_model_run(o, split, batch, lr, seed, n_updates, rng, stale_bug=0):
+    """A schedule model with what makes the real engine hard: workers advance in RANDOM interleaving, an update LANDS
+    coordinate by coordinate (three chunks at three different moments) BEFORE it draws its commit number, and an
+    iteration READS its weights in three chunks at three different moments -- so what it sees is a mixture no single
+    replayed state equals.  `seen_from` is the commit count a worker notes before it reads anything of its next iteration
+    (and before its own commit), as the engine does.  stale_bug > 0: the worker gates on weights it cached that many
+    iterations ago (the kind of defect the range statement exists to catch).  Returns the trace with dots / seen_from."""
+    k = len(split)
+    w_live = np.zeros(o.dim + 1)
+    w_committed = np.zeros(o.dim + 1)     # (w_live also holds what uncommitted updates have landed when the run ends)
+    commits = 0
+    tr = {q: [] for q in ("worker", "it", "read_at", "s", "n_active", "mask", "seen_from", "dot")}
+    st = [{"phase": 0, "it": 0, "read_at": 0, "seen": 0, "seen_next": 0} for _ in range(k)]
+    while commits < n_updates:
+        j = int(rng.integers(k))
+        s = st[j]
+        ph = s["phase"]
+        if ph == 0:      # the iteration's sample; first third of the reads
+            b, e = split[j]
+            s["rows"] = hr.hog_rows(seed, j, s["it"], b, e - b, batch)
+            flat, rid = hr._entries(o, s["rows"])
+            s["flat"], s["rid"] = flat, rid
+            s["cols"] = o.col[flat]
+            s["part"] = rng.integers(3, size=len(flat))
+            s["wv"] = np.zeros(len(flat))
+            s["s"] = np.float32(2.0 * o.lam * (w_live @ o.ds))
+        if ph in (0, 1, 2):
+            m = s["part"] == ph
+            s["wv"][m] = w_live[s["cols"][m]]
+        if ph == 2:      # x . w in fp32, the gate, the update to land
+            wv = s["wv"]
+            prod = (o.val[s["flat"]].astype(np.float32) * wv.astype(np.float32)).astype(np.float32)
+            d = np.zeros(batch, dtype=np.float32)
+            np.add.at(d, s["rid"], prod)
+            if stale_bug and s["it"] >= stale_bug:
+                d = s["dhist"][-stale_bug] * np.float32(1.0)   # the x . w of ANOTHER sample, many updates ago: weights AND rows stale
+            s.setdefault("dhist", []).append(d.copy())
+            y = o.label[s["rows"]].astype(np.float64)
+            s["active"] = ~(y * d.astype(np.float64) < 0.0)
+            s["d"] = d
+            delta = hr.forced_delta(o, s["rows"], s["active"], float(s["s"]), batch, lr)
+            nz = np.flatnonzero(delta)
+            s["dcols"], s["dvals"] = nz, delta[nz]
+            s["dpart"] = rng.integers(3, size=len(nz))
+        if ph in (3, 4, 5):   # landing, a third of the coordinates at a time
+            m = s["dpart"] == ph - 3
+            w_live[s["dcols"][m]] -= s["dvals"][m]
+        if ph == 6:      # noted before the next iteration requests any weight, and before the own commit
+            s["seen_next"] = commits
+        if ph == 7:      # commit
+            commits += 1
+            w_committed[s["dcols"]] -= s["dvals"]
+            mk = np.zeros(32 * ((batch + 31) // 32), dtype=bool)
+            mk[:batch] = s["active"]
+            for q, v in (("worker", j), ("it", s["it"]), ("read_at", s["read_at"]), ("s", s["s"]), ("n_active", int(s["active"].sum())),
+                         ("mask", mk), ("seen_from", s["seen"]), ("dot", s["d"])):
+                tr[q].append(v)
+            s["read_at"], s["seen"], s["it"] = commits, s["seen_next"], s["it"] + 1
+        s["phase"] = (ph + 1) % 8
+    return w_committed, {"worker": np.asarray(tr["worker"], np.int32), "it": np.asarray(tr["it"], np.uint32),
+                    "read_at": np.asarray(tr["read_at"], np.int64), "s": np.asarray(tr["s"], np.float32),
+                    "n_active": np.asarray(tr["n_active"], np.int32), "mask": np.stack(tr["mask"]),
+                    "seen_from": np.asarray(tr["seen_from"], np.int64), "dot": np.stack(tr["dot"])}
+
+
+@pytest.mark.parametrize("k,seed", [(1, 0), (3, 1), (8, 2), (24, 3)])
+def test_recorded_dots_of_a_landing_model_are_inside_their_ranges(k, seed):
+    """No false alarm, whatever the interleaving: rule and range hold for every row of every update of the landing model;
+    the weights the check replays are the model's to rounding."""
+    data, o, n_train = problem()
+    split = [(r.start, r.stop) for r in host.split_vanilla(n_train, k)]
+    n_upd = 60 + 12 * k
+    w_model, trace = landing_model_run(o, split, 40, 0.5, 5, n_upd, np.random.default_rng(seed))
+    g = hr.gate_check_recorded_dots(o, np.zeros(o.dim + 1), split, 40, 0.5, 5, trace)
+    assert g["ok"] and g["gate_rows_checked"] + g["empty_rows"] == n_upd * 40 == g["rows"], {q: v for q, v in g.items() if q != "w_replayed"}
+    assert np.abs(g["w_replayed"] - w_model).max() <= 1e-9
+    if k == 1:   # nothing in flight: the interval is a point (to resolution), every clear row is pinned by the replay alone
+        assert g["max_window"] <= 1 and g["share_pinned_by_the_replay"] > 0.9 and g["states_share_inside"] == 1.0
+
+
+def test_recorded_dots_controls_are_caught():
+    """Teeth: (1) a decision flipped against its own recorded d breaks the RULE; (2) a d moved outside its range breaks the
+    RANGE; (3) an engine that gates on STALE products (the x . w it computed three iterations earlier) is caught on a
+    large share of its rows although every decision still obeys the rule on the recorded d."""
+    data, o, n_train = problem()
+    k = 8
+    split = [(r.start, r.stop) for r in host.split_vanilla(n_train, k)]
+    _, trace = landing_model_run(o, split, 40, 0.5, 5, 200, np.random.default_rng(11))
+    good = hr.gate_check_recorded_dots(o, np.zeros(o.dim + 1), split, 40, 0.5, 5, trace, collect=True)
+    assert good["ok"]
+    bad = {q: np.array(v, copy=True) for q, v in trace.items()}
+    bad["mask"][120, 7] ^= True
+    bad["n_active"][120] += 1 if bad["mask"][120, 7] else -1
+    g1 = hr.gate_check_recorded_dots(o, np.zeros(o.dim + 1), split, 40, 0.5, 5, bad)
+    assert not g1["ok"] and g1["rule_violations"] >= 1 and g1["outside_rule"][0]["update"] == 121
+    bad = {q: np.array(v, copy=True) for q, v in trace.items()}
+    width = good["hi"][150, 3] - good["lo"][150, 3]
+    bad["dot"][150, 3] = np.float32(good["hi"][150, 3] + 0.05 * width + 1e-4)
+    y = float(o.label[hr.hog_rows(5, int(trace["worker"][150]), int(trace["it"][150]), *_span(split, trace, 150), 40)[3]])
+    bad["mask"][150, 3] = not (y * float(bad["dot"][150, 3]) < 0.0)          # (keeps the rule: only the range can object)
+    bad["n_active"][150] = int(bad["mask"][150, :40].sum())
+    g2 = hr.gate_check_recorded_dots(o, np.zeros(o.dim + 1), split, 40, 0.5, 5, bad)
+    assert not g2["ok"] and g2["rule_violations"] == 0 and any(v["update"] == 151 and v["t"] == 3 for v in g2["outside_range"]), g2["outside_range"]
+    _, stale = landing_model_run(o, split, 40, 0.5, 5, 200, np.random.default_rng(11), stale_bug=3)
+    g3 = hr.gate_check_recorded_dots(o, np.zeros(o.dim + 1), split, 40, 0.5, 5, stale)
+    assert g3["rule_violations"] == 0 and g3["range_violations"] > 0.2 * g3["gate_rows_checked"], {q: v for q, v in g3.items() if q != "w_replayed"}
+
+
+def _span(split, trace, i):
+    b, e = split[int(trace["worker"][i])]
+    return b, e - b
