@@ -551,8 +551,11 @@ __device__ __forceinline__ void cs_launch_body(const CsArgs& a, float* lds, Pre 
     __syncthreads();
     if (!built) {         // (workgroup-uniform) the step does not fit the one-step layout: every peer is told, nobody publishes
       if (tid == 0) {
-        __hip_atomic_store(&a.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicOr(&a.sc->err, 16);
+        // the soft-fallback flag FIRST, the abort word behind it with release order: a peer that sees the abort (and raises
+        // 8, "timed out") can only publish a report in which 16 already stands -- finish_mail then reads "fall back", not a
+        // hard error
+        __hip_atomic_fetch_or(&a.sc->err, 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.sync[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
       cs_finish_stats<NT>(a, z, false);
       return;

@@ -240,10 +240,12 @@ struct dsgd_ctx {
     void* p = nullptr;
     size_t bytes = 0;
     hipEvent_t ev = nullptr;            // recorded on the launch stream when the block came back: its last reader
+    unsigned long long tick = 0;        // cache_tick when it came back: a block no plan took for CACHE_MAX_AGE hand-backs is freed
   };
   std::vector<CacheBlock> cache;
   size_t cache_bytes = 0;
-  size_t cache_cap = (size_t)8 << 30;   // DSGD_CACHE_MB
+  unsigned long long cache_tick = 0;
+  size_t cache_cap = (size_t)8 << 30;   // DSGD_CACHE_MB (dsgd_cache_trim gives blocks back on request)
   std::vector<hipEvent_t> ev_pool;      // events of blocks in use, for the next ones
   // the one-step layout of per-request steps (dsgd_cs_request_kernel), strides at their maxima, per slice count
   struct ReqLayout {
@@ -346,6 +348,7 @@ struct dsgd_ctx {
   std::vector<TcolLayout> tcol_cache;
   unsigned long long tcol_clock = 0;
   int tcol_miss_streak = 0;          // layouts built in a row without one being used again
+  int tcol_cooldown = 0;             // steps the column lists still sit out after such a streak (then they try again)
   bool tcol_enable = true;           // DSGD_TCOL=0: such ranges through the row-wise kernel
   long long tcol_min = 512;          // DSGD_TCOL_MIN / DSGD_TCOL_MAX: row ranges of this many rows in total take the column lists
   long long tcol_max = 98303;        //   (above: row chunks, dsgd_fstep.hpp.  Measured, whole-split steps, us, row-wise / chunks / columns:
@@ -1024,9 +1027,30 @@ static int cache_take(dsgd_ctx* c, void** out, size_t bytes, size_t* got) {
   *got = bytes;
   return DSGD_OK;
 }
+// blocks beyond `keep_bytes` (oldest first) or older than CACHE_MAX_AGE hand-backs go back to the device: a block whose
+// last reader has finished is freed at once, one still being read stays (hipFree would wait for the device)
+constexpr unsigned long long CACHE_MAX_AGE = 48;   // (an epoch's plan hands back ~10 blocks: blocks unused for ~5 plans)
+static void cache_trim(dsgd_ctx* c, size_t keep_bytes, bool aged_only) {
+  for (size_t i = 0; i < c->cache.size();) {
+    dsgd_ctx::CacheBlock& b = c->cache[i];
+    const bool aged = c->cache_tick - b.tick > CACHE_MAX_AGE;
+    const bool over = !aged_only && c->cache_bytes > keep_bytes;
+    if ((aged || over) && (!b.ev || hipEventQuery(b.ev) == hipSuccess)) {
+      (void)hipFree(b.p);
+      if (b.ev) c->ev_pool.push_back(b.ev);
+      c->cache_bytes -= b.bytes;
+      c->cache.erase(c->cache.begin() + (long)i);
+    } else {
+      (void)hipGetLastError();   // (hipErrorNotReady of the query)
+      ++i;
+    }
+  }
+}
 // give back: the block's last reader is whatever the launch stream holds now
 static void cache_give(dsgd_ctx* c, void* q, size_t bytes) {
   if (!q) return;
+  ++c->cache_tick;
+  if ((c->cache_tick & 15) == 0) cache_trim(c, c->cache_cap, true);
   if (bytes == 0 || c->cache_bytes + bytes > c->cache_cap || c->cache.size() >= 256) {
     (void)hipFree(q);   // (not ours to keep: allocated outside the cache, or the cache is full)
     return;
@@ -1046,6 +1070,7 @@ static void cache_give(dsgd_ctx* c, void* q, size_t bytes) {
     (void)hipGetLastError();
     (void)hipStreamSynchronize(c->stream);
   }
+  blk.tick = c->cache_tick;
   c->cache.push_back(blk);
   c->cache_bytes += bytes;
 }
@@ -2398,8 +2423,14 @@ static int tcol_layout(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long 
     }
   // A caller that never repeats a configuration (mini-batches over ever new row ranges) would pay a layout -- milliseconds --
   // for every 20 us step: more misses in a row than the cache holds, and the column lists leave such a context alone.
+  // Not for good: after TCOL_COOLDOWN declined steps they try again -- a fit that settles on fixed splits after
+  // a phase of ever new ranges gets its column lists back; a context that keeps changing pays 4 layouts per 256 steps.
+  if (c->tcol_cooldown > 0) {
+    if (--c->tcol_cooldown == 0) c->tcol_miss_streak = 8;
+    return 1;
+  }
   if (++c->tcol_miss_streak > 12) {
-    c->tcol_enable = false;
+    c->tcol_cooldown = 256;
     return 1;
   }
   for (size_t i = 0; i < c->tcol_cache.size();)   // layouts of an earlier ranking
@@ -2431,6 +2462,7 @@ static int tcol_layout(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long 
     (void)hipFree(d_cid);
     (void)hipFree(d_tot);
     tcol_free(L);
+    if (rc == 2) return 1;   // out of memory / a failed call: declined for THIS step only (memory may be there the next time)
     if (rc == 1) {   // remembered as declined (n_wg = 0): the caller's other path takes this configuration from now on
       L.ranges = key;
       L.gen = c->layout_gen;
@@ -2443,7 +2475,7 @@ static int tcol_layout(dsgd_ctx* c, const std::vector<WorkSeg>& segs, long long 
   do {                                       \
     if ((expr) != hipSuccess) {              \
       (void)hipGetLastError();               \
-      return give_up(1);                     \
+      return give_up(2);                     \
     }                                        \
   } while (0)
   // every worker's rows padded to whole 64-row blocks of the bitmap (a workgroup of the dot kernel writes two whole words)
@@ -3434,6 +3466,26 @@ int dsgd_synchronize(dsgd_ctx* c, dsgd_batch_stats* stats) {
     stats->n_samples = pending;
   }
   return DSGD_OK;
+}
+
+int dsgd_cache_trim(dsgd_ctx* c, int64_t keep_bytes, int64_t* held_out) {
+  DSGD_TRY(check_ctx(c));
+  if (keep_bytes < 0) return fail(DSGD_EINVAL, "negative keep_bytes");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c, true));
+  cache_trim(c, (size_t)keep_bytes, false);
+  if (held_out) *held_out = (int64_t)c->cache_bytes;
+  return DSGD_OK;
+}
+
+int dsgd_plan_create_n(dsgd_ctx* c, const int32_t* idx, int64_t n_idx, const int64_t* offsets, int64_t n_steps,
+                       int32_t n_workers, dsgd_plan** out) {
+  DSGD_TRY(check_ctx(c));
+  if (!idx || !offsets || !out || n_steps < 1 || n_workers < 1 || n_idx < 0) return fail(DSGD_EINVAL, "bad plan arguments");
+  if (n_steps > INT64_MAX / n_workers) return fail(DSGD_EINVAL, "n_steps * n_workers overflows");
+  if (offsets[n_steps * n_workers] != n_idx)
+    return fail(DSGD_EINVAL, "offsets end at %lld but idx holds %lld entries", (long long)offsets[n_steps * n_workers], (long long)n_idx);
+  return dsgd_plan_create(c, idx, offsets, n_steps, n_workers, out);
 }
 
 int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, int64_t n_steps, int32_t n_workers,

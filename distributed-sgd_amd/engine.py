@@ -165,7 +165,7 @@ class Engine:
         idx = np.concatenate(flat) if flat else np.zeros(0, np.int32)
         offsets = np.asarray(offs, dtype=np.int64)
         h = C.c_void_p()
-        check(self._lib.dsgd_plan_create(self._ctx, ptr(idx), ptr(offsets), C.c_int64(n_steps), C.c_int32(n_workers), C.byref(h)))
+        check(self._lib.dsgd_plan_create_n(self._ctx, ptr(idx), C.c_int64(len(idx)), ptr(offsets), C.c_int64(n_steps), C.c_int32(n_workers), C.byref(h)))
         return Plan(self, h, n_steps, n_workers, int(offsets[-1]))
 
     def plan_flat(self, idx, offsets, n_steps, n_workers):
@@ -176,8 +176,14 @@ class Engine:
         if len(offsets) != n_steps * n_workers + 1 or (n_steps and int(offsets[-1]) != len(idx)):
             raise ValueError("offsets do not describe %d x %d lists over %d entries" % (n_steps, n_workers, len(idx)))
         h = C.c_void_p()
-        check(self._lib.dsgd_plan_create(self._ctx, ptr(idx), ptr(offsets), C.c_int64(n_steps), C.c_int32(n_workers), C.byref(h)))
+        check(self._lib.dsgd_plan_create_n(self._ctx, ptr(idx), C.c_int64(len(idx)), ptr(offsets), C.c_int64(n_steps), C.c_int32(n_workers), C.byref(h)))
         return Plan(self, h, n_steps, n_workers, int(offsets[-1]))
+
+    def cache_trim(self, keep_bytes=0):
+        """Give the device blocks of destroyed plans back (all but keep_bytes); returns the bytes still held."""
+        held = C.c_int64(0)
+        check(self._lib.dsgd_cache_trim(self._ctx, C.c_int64(keep_bytes), C.byref(held)))
+        return held.value
 
     def plan_run(self, plan, step_begin, step_end, lr):
         check(self._lib.dsgd_plan_run(self._ctx, plan.handle, C.c_int64(step_begin), C.c_int64(step_end), C.c_float(lr)))

@@ -303,9 +303,12 @@ def epoch_lists(rnd: JavaRandom, split: Sequence[range], max_samples: int, batch
     lib = _host_lib() if native in (None, True) else None
     if native is True and lib is None:
         raise RuntimeError("libdsgd_host.so is not built")
-    if lib is not None and all(r.step == 1 for r in split):
+    # (an empty split takes the Python path, which stops where the reference's Vec.sum throws; a batch size beyond the
+    #  longest split selects whole splits either way -- clamped: the native side takes it as an int32)
+    if lib is not None and all(r.step == 1 and len(r) > 0 for r in split):
         import ctypes as C
 
+        batch_size = max(1, min(int(batch_size), max(max_samples, max(len(r) for r in split)), 2 ** 31 - 1))
         n_steps_max = len(range(0, max_samples, batch_size))
         sb = np.asarray([r.start for r in split], dtype=np.int64)
         se = np.asarray([r.stop for r in split], dtype=np.int64)
@@ -547,17 +550,20 @@ class MasterSync:
         if cur is None:
             cur = self._make_plan(self._take_lists(split, max_samples, batch_size), K)
         t0 = time.perf_counter_ns()
-        if cur["n_steps"]:
-            self.backend.plan_run(cur["plan"], 0, cur["n_steps"], learning_rate)   # enqueued: ALL the epoch's steps, one launch
-        if self.prefetch and epochs_left > 1 and cur["n_steps"] == n_expected:
-            # ... and while they run: the next epoch's lists (drawn ahead already, from the second epoch on), the draw of the
-            # epoch after it started on the helper thread, the next epoch's plan laid out (the device's build stream)
-            nxt = self._take_lists(split, max_samples, batch_size)
-            if epochs_left > 2 and nxt["n_steps"] == n_expected:
-                self._draw_ahead(split, max_samples, batch_size)
-            self._pending = self._make_plan(nxt, K)
-        if cur["plan"] is not None:
-            cur["plan"].destroy()                                                    # (behind the run; no synchronisation)
+        try:
+            if cur["n_steps"]:
+                self.backend.plan_run(cur["plan"], 0, cur["n_steps"], learning_rate)   # enqueued: ALL the epoch's steps, one launch
+            if self.prefetch and epochs_left > 1 and cur["n_steps"] == n_expected:
+                # ... and while they run: the next epoch's lists (drawn ahead already, from the second epoch on), the draw of the
+                # epoch after it started on the helper thread, the next epoch's plan laid out (the device's build stream)
+                nxt = self._take_lists(split, max_samples, batch_size)
+                if epochs_left > 2 and nxt["n_steps"] == n_expected:
+                    self._draw_ahead(split, max_samples, batch_size)
+                self._pending = self._make_plan(nxt, K)
+        finally:
+            if cur["plan"] is not None:        # (also when the run or the next plan's set-up failed: the device blocks go back)
+                cur["plan"].destroy()                                                # (behind the run; no synchronisation)
+                cur["plan"] = None
         self.backend.synchronize()
         dt = time.perf_counter_ns() - t0
         # what the per-batch closure would have logged and recorded (:181-183, Slave.scala:145-150), written now

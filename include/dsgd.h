@@ -150,7 +150,17 @@ typedef struct dsgd_plan dsgd_plan;
  * The same lists through dsgd_sync_step (per request) cost 40 us per call.                                            */
 int dsgd_plan_create(dsgd_ctx* ctx, const int32_t* idx, const int64_t* offsets, int64_t n_steps, int32_t n_workers,
                      dsgd_plan** out);
+/* The same with the length of idx stated: DSGD_EINVAL unless offsets[n_steps * n_workers] == n_idx -- the form a binding
+ * that holds idx as a managed array must use (the lists are read up to offsets[last]: a JVM array shorter than that
+ * would be read past its end).  The JNI shim, the Python binding and include/dsgd.hpp all go through this one.       */
+int dsgd_plan_create_n(dsgd_ctx* ctx, const int32_t* idx, int64_t n_idx, const int64_t* offsets, int64_t n_steps,
+                       int32_t n_workers, dsgd_plan** out);
 int dsgd_plan_destroy(dsgd_ctx* ctx, dsgd_plan* plan);
+/* The device blocks destroyed plans leave with the context (up to DSGD_CACHE_MB, default 8192 MiB, read at dsgd_create;
+ * a block no plan took again within ~5 plans is freed by itself): give back all but keep_bytes of them now (blocks the
+ * launch stream is still reading stay); *held_out (may be NULL) = bytes still held.  For hosts that run several
+ * contexts on one GPU (the dev role's JVM workers, Main.scala:144-158) and want the memory between fits.            */
+int dsgd_cache_trim(dsgd_ctx* ctx, int64_t keep_bytes, int64_t* held_out);
 int dsgd_plan_run(dsgd_ctx* ctx, dsgd_plan* plan, int64_t step_begin, int64_t step_end, float lr);
 /* How a plan will run (nothing in the reference; benchmarks, tests): vals[0] = 1 column slices (dsgd_cs_step_kernel),
  * 2 the one-workgroup kernel, 3 virtual tiles, 4 the row-parallel kernels, 0 not laid out yet; [1] slices, [2..4] slot /

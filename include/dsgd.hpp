@@ -335,7 +335,7 @@ class Master {
       const int32_t K = (int32_t)split.size();
       if (usePlans && nSteps > 0) {
         dsgd_plan* plan = nullptr;
-        check(dsgd_plan_create(model_.ctx(), flat.data(), offsets.data(), nSteps, K, &plan));
+        check(dsgd_plan_create_n(model_.ctx(), flat.data(), (int64_t)flat.size(), offsets.data(), nSteps, K, &plan));
         int rc = dsgd_plan_run(model_.ctx(), plan, 0, nSteps, (float)learningRate);
         if (rc == DSGD_OK) rc = dsgd_synchronize(model_.ctx(), nullptr);
         dsgd_plan_destroy(model_.ctx(), plan);

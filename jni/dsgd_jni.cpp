@@ -172,8 +172,9 @@ JNIEXPORT jlong JNICALL NATIVE(planCreate)(JNIEnv* env, jobject, jlong h, jintAr
   {
     IntElems iv(env, idx, JNI_ABORT);
     LongElems ov(env, offsets, JNI_ABORT);
-    rc = dsgd_plan_create(ctx(h), reinterpret_cast<const int32_t*>(iv.p), reinterpret_cast<const int64_t*>(ov.p),
-                          (nOff - 1) / nWorkers, nWorkers, &plan);
+    // (the stated length: offsets that end beyond the pinned array are refused instead of read)
+    rc = dsgd_plan_create_n(ctx(h), reinterpret_cast<const int32_t*>(iv.p), (int64_t)env->GetArrayLength(idx),
+                            reinterpret_cast<const int64_t*>(ov.p), (nOff - 1) / nWorkers, nWorkers, &plan);
   }
   if (rc) {
     raise(env, rc);

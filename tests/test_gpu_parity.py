@@ -311,6 +311,43 @@ def test_plan_run_equals_step_by_step():
         waivers.tight("plan_run:replay", np.abs(w_b - w_a).max() <= tol(w_ref), flips > 0, "%d flips" % flips)
 
 
+def test_plan_blocks_come_back_and_the_stated_idx_length_is_checked():
+    """(1) dsgd_plan_create_n refuses offsets that end beyond (or short of) the idx array a binding holds --
+    dsgd_plan_create would read the lists up to offsets[last]; (2) the device blocks destroyed plans leave with the
+    context can be given back (dsgd_cache_trim) and the next plan still runs to the same bits."""
+    import ctypes as C
+
+    from dsgd_amd import _lib
+    data = dsgd_amd.synth.generate(4096, seed=9)
+    o, eng = make_pair(data, 1e-5, 3276)
+    rng = np.random.default_rng(3)
+    steps = batches(rng, 3276, 3, 100, 6)
+    with eng:
+        plan = eng.plan(steps)
+        eng.plan_run(plan, 0, 6, 0.5)
+        eng.synchronize()
+        w_a = eng.get_weights()
+        plan.destroy()
+        eng.synchronize()
+        held = eng.cache_trim(1 << 62)            # nothing asked back: what the destroyed plan left
+        assert held > 0
+        assert eng.cache_trim(0) == 0             # (the launch stream is idle: every block goes back)
+        eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+        plan = eng.plan(steps)
+        eng.plan_run(plan, 0, 6, 0.5)
+        eng.synchronize()
+        assert np.array_equal(eng.get_weights(), w_a)
+        plan.destroy()
+        flat = np.concatenate([np.asarray(a, dtype=np.int32) for st in steps for a in st])
+        offs = np.arange(0, 1801, 100, dtype=np.int64)
+        lib = _lib.load()
+        for n_idx in (len(flat) - 1, len(flat) + 5):
+            h = C.c_void_p()
+            rc = lib.dsgd_plan_create_n(eng._ctx, flat.ctypes.data_as(C.c_void_p), C.c_int64(n_idx), offs.ctypes.data_as(C.c_void_p),
+                                        C.c_int64(6), C.c_int32(3), C.byref(h))
+            assert rc != 0 and not h.value and b"idx holds" in lib.dsgd_last_error()
+
+
 # ---- error behaviour mirrors the reference's require / exceptions ----------------------------------
 def test_error_behaviour():
     data = dsgd_amd.synth.generate(256, seed=4)

@@ -316,3 +316,17 @@ def test_fit_through_plans_is_fit_step_by_step():
     with pytest.raises(ValueError, match="empty list"):
         me.fit(np.zeros(data.dim + 1), 1, 2, 0.5, crit)
     assert be_e.steps == [[2, 2, 2, 1]]
+
+
+def test_epoch_lists_edge_cases_native_equals_python():
+    """a batch size beyond int32 selects whole splits natively as in the Python restatement (same lists, same
+    generator state); an empty split ends the epoch before its first batch on both paths (the reference's Vec.sum throws
+    there, math/Vec.scala:129 -- MasterSync raises it)."""
+    split = [range(0, 50), range(50, 90)]
+    ra, rb = host.JavaRandom(0), host.JavaRandom(0)
+    a = host.epoch_lists(ra, split, 50, 2 ** 40)
+    b = host.epoch_lists(rb, split, 50, 2 ** 40, native=False)
+    assert a[2] == b[2] == 1 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and ra.seed == rb.seed
+    for native in (None, False):
+        idx, offs, n = host.epoch_lists(host.JavaRandom(0), [range(0, 50), range(50, 50)], 50, 10, native=native)
+        assert n == 0 and len(idx) == 0

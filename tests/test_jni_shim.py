@@ -179,6 +179,13 @@ def test_shim_end_to_end_on_the_gpu(shim_lib):
     fnb.restype, fnb.argtypes = C.c_int64, [vp, vp, C.c_int64, vp, vp, C.c_int32]
     assert fnb(C.byref(env_bad), None, h, C.byref(fj), C.byref(oj), 4) == 0
     assert env_bad.thrown_class == b"java/lang/IllegalArgumentException" and env_bad.n_get == 0
+    # ... and offsets that end BEYOND the idx array (the lists would be read past the pinned JVM array)
+    offs_long = offs.copy()
+    offs_long[-1] += 7
+    (olj, _ol) = jarr(offs_long)
+    env_bad = Env()
+    assert fnb(C.byref(env_bad), None, h, C.byref(fj), C.byref(olj), 3) == 0
+    assert env_bad.thrown_class == b"java/lang/IllegalArgumentException", env_bad.thrown_class
     call("destroy", None, [C.c_int64], h)
     with dsgd_amd.Engine(data.dim, 1e-5) as eng:
         eng.load_csr(data.row_ptr, data.col, data.val, data.label)
