@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
   const bool prof = tprof != nullptr && tid == 0;
   unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long t_first = t_prev;
+  const unsigned long long rt_first = prof ? wall_clock64() : 0ull;   // (100 MHz, one clock for the whole device: start offsets)
 #define DSGD_FPROF(I)                                              \
   if (prof) {                                                      \
     const unsigned long long t_now = __builtin_readcyclecounter(); \
@@ -77,9 +78,6 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
   // ---- phase A: cold part of x.w of the chunk's rows ------------------------------------------------------------
   {
     float* strip = lds + ((nc_lds + 3) & ~3) + wave * CT_STRIP;
-    wg_copy_in(lds, w + hw, nc_lds, tid, 1024, is_aligned16(w + hw));
-    __syncthreads();
-    DSGD_FPROF(0)
     CTabs tt;
     tt.tiles = ctiles;
     tt.meta = cmeta;
@@ -91,9 +89,13 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
     tt.t_lo = ch.ctile_begin;
     tt.t_hi = ch.ctile_end;
     int tile = tt.t_lo + wave;
-    if (tile < tt.t_hi) {
-      CRegs<true> A, B, C, D;
-      WTile wt = ctiles[c_map(tt, tile)];
+    const bool any = tile < tt.t_hi;   // (wave-uniform)
+    // the first three tiles' streams are requested BEFORE the weight tile is set up: they need registers only, and land
+    // while the copy runs (round 6: every phase's first requests used to go out behind its set-up -- one exposed round
+    // trip over the fabric per phase)
+    CRegs<true> A, B, C, D;
+    WTile wt = ctiles[c_map(tt, tile)];
+    if (any) {
       c_issue<true, false>(tt, tile, lane, wt, A);
       __builtin_amdgcn_sched_barrier(0);
       wt = ctiles[c_map(tt, tile + stride)];
@@ -103,6 +105,11 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
       c_issue<true, false>(tt, tile + 2 * stride, lane, wt, C);
       __builtin_amdgcn_sched_barrier(0);
       wt = ctiles[c_map(tt, tile + 3 * stride)];
+    }
+    wg_copy_in(lds, w + hw, nc_lds, tid, 1024, is_aligned16(w + hw));
+    __syncthreads();
+    DSGD_FPROF(0)
+    if (any) {
 #define DSGD_FA(CUR, FAR)                                            \
   {                                                                  \
     const WTile wt_now = wt;                                         \
@@ -143,44 +150,88 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
     x.hg = hw;
     x.fix_scale = fix_scale;
     x.cold_scale = cold_scale;
+    // The chunk's hot tiles go to the waves AS THEY COME FREE (round 6): a wave's first four tiles are fixed (tile_begin +
+    // wave + 16 i: their requests go out before the set-up below, registers only), every further one is drawn from a
+    // counter in LDS one iteration before its record is fetched.  A strided walk made the workgroup wait for its slowest
+    // wave -- the one that also had one of the chunk's LONG ROWS to do behind its tiles (rows that fit no tile; 0.75 us of
+    // the workgroup's time each, up to ten per chunk: the workgroups with the most of them were the launch's last,
+    // profiles/r06_fstep_wg_times.txt).  Now a wave with a long row does it FIRST, from registers (w_long_row_regs: four
+    // round trips in a row -- row id, bounds, stream, cold weights -- instead of two dozen; ~10 us of the wave's time all
+    // the same: a round trip through this kernel's own queues is 2-3 us), requests its first tiles behind it, and draws
+    // fewer tiles than the others; the chunks are cut with that cost in their weight (dsgd_hip.hip: fstep_layout).
+    // Which wave adds a tile's rows to the workgroup's integer accumulators does not change any sum: the same bits.
+    int* const tile_ctr = x.gl + hw + 64;   // (the four words LDS had left: dsgd_hip.hip launch_fstep)
+    unsigned int n_all = 0, n_neg = 0, n_pos = 0;
+    const int t_end = ch.tile_end;
+    int qa = ch.tile_begin + wave, qb = qa + stride, qc = qb + stride, qd = qc + stride;
+    const bool any = qa < t_end;                                 // (wave-uniform)
+    const bool has_long = ch.long_begin + wave < ch.long_end;    // (wave-uniform)
+    WRegs A, B, C, D;
+    WTile wt = w_fetch(tt, qa, t_end);
+#define DSGD_FB_PROLOGUE                                 \
+  {                                                      \
+    w_issue_cols(m, qa, t_end, lane, wt, A);             \
+    w_issue_vals(m, tt, x.dcold, lane, A);               \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    wt = w_fetch(tt, qb, t_end);                         \
+    w_issue_cols(m, qb, t_end, lane, wt, B);             \
+    w_issue_vals(m, tt, x.dcold, lane, B);               \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    wt = w_fetch(tt, qc, t_end);                         \
+    w_issue_cols(m, qc, t_end, lane, wt, C);             \
+    w_issue_vals(m, tt, x.dcold, lane, C);               \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    wt = w_fetch(tt, qd, t_end);                         \
+  }
+    if (!has_long) {
+      if (any) DSGD_FB_PROLOGUE
+    }
     if (is_aligned16(x.gl)) wg_zero(x.gl, hw + 64, tid, 1024);
     else
       for (int j = tid; j < hw + 64; j += 1024) x.gl[j] = 0;
     wg_copy_in(wl, w, hw, tid, 1024, is_aligned16(wl) && is_aligned16(w));
-    if (tid == 0) wl[hw] = 0.0f;
+    if (tid == 0) {
+      wl[hw] = 0.0f;
+      tile_ctr[0] = ch.tile_begin + 4 * stride;
+    }
     __syncthreads();
     DSGD_FPROF(2)
 
-    unsigned int n_all = 0, n_neg = 0, n_pos = 0;
-    const int t_end = ch.tile_end;
-    int tile = ch.tile_begin + wave;
-    if (tile < t_end) {
-      WRegs A, B, C, D;
-      WTile wt = w_fetch(tt, tile, t_end);
-      w_issue_cols(m, tile, t_end, lane, wt, A);
-      w_issue_vals(m, tt, x.dcold, lane, A);
-      __builtin_amdgcn_sched_barrier(0);
-      wt = w_fetch(tt, tile + stride, t_end);
-      w_issue_cols(m, tile + stride, t_end, lane, wt, B);
-      w_issue_vals(m, tt, x.dcold, lane, B);
-      __builtin_amdgcn_sched_barrier(0);
-      wt = w_fetch(tt, tile + 2 * stride, t_end);
-      w_issue_cols(m, tile + 2 * stride, t_end, lane, wt, C);
-      w_issue_vals(m, tt, x.dcold, lane, C);
-      __builtin_amdgcn_sched_barrier(0);
-      wt = w_fetch(tt, tile + 3 * stride, t_end);
-#define DSGD_FB(CUR, FAR) w_tile<true>(m, tt, x, tile, stride, t_end, CUR, FAR, wt, n_all, n_neg, n_pos)
+    if (has_long) {   // (the registers of the first tiles' requests are not live yet on this path: the row sits in them)
+      const unsigned long long t_l0 = prof ? __builtin_readcyclecounter() : 0ull;
+      for (int t = ch.long_begin + wave; t < ch.long_end; t += stride)
+        w_long_row_regs(mfull, w, x, (long long)long_rows[t], n_all, n_neg, n_pos);
+      if (prof) {   // [10] cycles wave 0 spent on its long rows, [11] how many workgroups had one
+        atomicAdd(&tprof[10], __builtin_readcyclecounter() - t_l0);
+        atomicAdd(&tprof[11], 1ull);
+      }
+      if (any) DSGD_FB_PROLOGUE
+    }
+#undef DSGD_FB_PROLOGUE
+    if (any) {
+      // lane 0 draws; the value is picked up (readfirstlane) an iteration later, when it names the record to fetch
+      auto draw = [&]() -> int {
+        int v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return v;
+      };
+      int qe = __builtin_amdgcn_readfirstlane(draw());
+      int pend = draw();
+#define DSGD_FB(CUR, FAR)                                                                \
+  {                                                                                      \
+    w_tile_q<true>(m, tt, x, qd, qe, t_end, CUR, FAR, wt, n_all, n_neg, n_pos);           \
+    qa = qb; qb = qc; qc = qd; qd = qe;                                                  \
+    qe = __builtin_amdgcn_readfirstlane(pend);                                           \
+    pend = draw();                                                                       \
+  }
       for (;;) {
-        DSGD_FB(A, D); tile += stride; if (tile >= t_end) break;
-        DSGD_FB(B, A); tile += stride; if (tile >= t_end) break;
-        DSGD_FB(C, B); tile += stride; if (tile >= t_end) break;
-        DSGD_FB(D, C); tile += stride; if (tile >= t_end) break;
+        DSGD_FB(A, D); if (qa >= t_end) break;
+        DSGD_FB(B, A); if (qa >= t_end) break;
+        DSGD_FB(C, B); if (qa >= t_end) break;
+        DSGD_FB(D, C); if (qa >= t_end) break;
       }
 #undef DSGD_FB
     }
-    // the chunk's rows that fit no tile: one wave per row, from the whole ranked CSR
-    for (int t = ch.long_begin + wave; t < ch.long_end; t += stride)
-      w_long_row<true>(mfull, w, x, (long long)long_rows[t], n_all, n_neg, n_pos);
 
     n_all = wave_sum_u32(n_all);
     __builtin_amdgcn_wave_barrier();
@@ -189,24 +240,11 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
     const unsigned long long t_b0 = t_prev;
     DSGD_FPROF(3)
     if (prof && wg < 1024) tprof[16 + 4 * wg + 2] = t_prev - t_b0;
-    if (tid == 0) {
-      unsigned int t_all = 0;
-      for (int i = 0; i < 16; ++i) t_all += reinterpret_cast<const unsigned int*>(strips + i * WS_COEF_STRIDE)[0];
-      if (t_all) atomicAdd(&sc->n_active, (unsigned long long)t_all);   // one atomic per workgroup
-    }
-    int* mine = part + (long long)wg * part_stride;
-    wg_copy_out(mine, x.gl, hw, tid, 1024, is_aligned16(mine) && is_aligned16(x.gl));
-    __syncthreads();   // the gradient words have been read: the LDS tile is free
-    DSGD_FPROF(4)
   }
-
   // ---- phase C: the cold gradient columns of the chunk's rows ----------------------------------------------------
   {
-    const int n_tile = nc_lds + 64;
-    float* strip = lds + ((n_tile + 3) & ~3) + wave * CT_STRIP;
-    wg_zero(reinterpret_cast<int*>(lds), n_tile, tid, 1024);
-    __syncthreads();
-    DSGD_FPROF(5)
+    // (its first requests -- the cold stream again, the rows' coefficients: registers only -- go out before phase B's
+    //  partial sums leave and the tile is cleared)
     CTabs tt;
     tt.tiles = ctiles;
     tt.meta = cmeta;
@@ -217,11 +255,11 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
     tt.row_end = ch.row_end;
     tt.t_lo = ch.ctile_begin;
     tt.t_hi = ch.ctile_end;
-    long long* g64cold = g64_base + (long long)blockIdx.y * g_stride + hw;
     int tile = tt.t_lo + wave;
-    if (tile < tt.t_hi) {
-      CRegs<true> A, B, C, D;
-      WTile wt = ctiles[c_map(tt, tile)];
+    const bool any = tile < tt.t_hi;   // (wave-uniform)
+    CRegs<true> A, B, C, D;
+    WTile wt = ctiles[c_map(tt, tile)];
+    if (any) {
       c_issue<true, true>(tt, tile, lane, wt, A);
       __builtin_amdgcn_sched_barrier(0);
       wt = ctiles[c_map(tt, tile + stride)];
@@ -231,6 +269,27 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
       c_issue<true, true>(tt, tile + 2 * stride, lane, wt, C);
       __builtin_amdgcn_sched_barrier(0);
       wt = ctiles[c_map(tt, tile + 3 * stride)];
+    }
+    {   // phase B's finish: the active-row count, the workgroup's exact hot partial sums out
+      float* strips = lds + ((hw + 4) & ~3);
+      int* gl = reinterpret_cast<int*>(strips + 16 * WS_COEF_STRIDE);
+      if (tid == 0) {
+        unsigned int t_all = 0;
+        for (int i = 0; i < 16; ++i) t_all += reinterpret_cast<const unsigned int*>(strips + i * WS_COEF_STRIDE)[0];
+        if (t_all) atomicAdd(&sc->n_active, (unsigned long long)t_all);   // one atomic per workgroup
+      }
+      int* mine = part + (long long)wg * part_stride;
+      wg_copy_out(mine, gl, hw, tid, 1024, is_aligned16(mine) && is_aligned16(gl));
+      __syncthreads();   // the gradient words have been read: the LDS tile is free
+      DSGD_FPROF(4)
+    }
+    const int n_tile = nc_lds + 64;
+    float* strip = lds + ((n_tile + 3) & ~3) + wave * CT_STRIP;
+    wg_zero(reinterpret_cast<int*>(lds), n_tile, tid, 1024);
+    __syncthreads();
+    DSGD_FPROF(5)
+    long long* g64cold = g64_base + (long long)blockIdx.y * g_stride + hw;
+    if (any) {
 #define DSGD_FC(CUR, FAR)                                                                              \
   {                                                                                                    \
     const WTile wt_now = wt;                                                                           \
@@ -260,9 +319,13 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
         if (wg < 1024) {
           unsigned int xcc;
           asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-          tprof[16 + 4 * wg] = t_first;
-          tprof[16 + 4 * wg + 1] = t_prev;
-          tprof[16 + 4 * wg + 3] = xcc;
+          tprof[16 + 4 * wg] = rt_first;
+          tprof[16 + 4 * wg + 1] = wall_clock64();
+          // the XCD and what the chunk held: hot tiles << 8, cold tiles << 24, rows << 40, long rows << 56
+          tprof[16 + 4 * wg + 3] = (unsigned long long)(xcc & 0xffu) | ((unsigned long long)(ch.tile_end - ch.tile_begin) << 8) |
+                                   ((unsigned long long)(ch.ctile_end - ch.ctile_begin) << 24) |
+                                   ((unsigned long long)(ch.row_end - ch.row_begin) << 40) |
+                                   ((unsigned long long)(ch.long_end - ch.long_begin) << 56);
         }
       }
     }

@@ -267,6 +267,7 @@ struct dsgd_ctx {
   long long n_wtiles = 0;
   std::vector<int> h_wtile_r0;          // first row of every wave tile (+ sentinel n_rows)
   std::vector<long long> wlong_rows;    // rows that fit no wave tile (sorted): one wave per row, from the whole CSR
+  std::vector<long long> wlong_weight;  // prefix sums of their weights in the row chunks' balance (slots; fstep_layout)
   int* d_wlong_rows = nullptr;          // the same list on the device
   int* d_part = nullptr;                // per-workgroup partial sums of the wseg gradient kernel: part_wgs x part_stride
   long long part_wgs = 0;
@@ -1875,6 +1876,13 @@ static int build_split(dsgd_ctx* c) {
       crp[i + 1] = crp[i] + cold;
     }
   }
+  // (what a long row weighs when row chunks are cut: its own non-zeros plus ~1,300 slots' worth of its wave's waiting --
+  //  0.7 us per long row measured against 75 us for a chunk of ~200 K slots, profiles/r06_fstep_wg_times.txt)
+  c->wlong_weight.assign(c->wlong_rows.size() + 1, 0);
+  for (size_t k = 0; k < c->wlong_rows.size(); ++k) {
+    const long long i = c->wlong_rows[k];
+    c->wlong_weight[k + 1] = c->wlong_weight[k] + (rp[(size_t)i + 1] - rp[(size_t)i]) + 1300;
+  }
   c->hot_nnz = hrp[n_rows];
   c->coldm_nnz = ctp[n_rows];
   HIP_TRY(hipMalloc(&c->d_hcol, sizeof(unsigned short) * (size_t)(c->hot_nnz + WS_PAD)));
@@ -2248,8 +2256,14 @@ static int fstep_layout(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int
   long long worst = 1;
   for (int k = 0; k < n_workers; ++k) {
     const long long rb = row_segs[(size_t)k].row_begin, re = row_segs[(size_t)k].row_end;
-    // a row's weight: its slots in the two streams (6 bytes each) plus what every row costs (descriptor share, dcold, coef8)
-    auto W = [&](long long i) { return hrp[(size_t)i] + ctp[(size_t)i] + 2 * i; };
+    // a row's weight: its slots in the two streams (6 bytes each) plus what every row costs (descriptor share, dcold, coef8);
+    // a LONG row (in neither stream) its own non-zeros plus what its wave waits for it: ~10 us, five tiles' worth (round 6:
+    // the chunks with the most long rows were the launch's last, 0.7-0.9 us per long row)
+    const std::vector<long long>& lrw = c->wlong_weight;   // prefix sums over the long-row list
+    auto W = [&](long long i) {
+      const size_t nl = (size_t)(std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), i) - c->wlong_rows.begin());
+      return hrp[(size_t)i] + ctp[(size_t)i] + 2 * i + lrw[nl];
+    };
     const long long w0 = W(rb), wtot = W(re) - w0;
     long long cut = rb;
     for (int b = 0; b < n_wg; ++b) {
@@ -2272,6 +2286,32 @@ static int fstep_layout(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int
       ch.tile_end = (int)wt.size();
       ch.ctile_begin = (int)ct.size();
       append_wave_tiles(ctp.data(), cut, nxt, ct, CT_MAXROWS);
+      {
+        // The chunk's cold tiles are walked twice by 16 waves with a stride of 16: 29-35 tiles of ~90 rows left some waves
+        // three tiles and most two (phases A and C: 11 of a workgroup's 70 us).  Smaller tiles in a number just below a
+        // multiple of 16 give every wave the same count (round 6).
+        const size_t c0 = (size_t)ch.ctile_begin;
+        auto waste = [](size_t n) { return n == 0 ? 1.0 : (double)((n + 15) / 16 * 16) / (double)n; };
+        size_t n_best = ct.size() - c0;
+        if (n_best % 16 != 0 && nxt > cut) {
+          int mr_best = CT_MAXROWS;
+          const long long target = (long long)((n_best + 15) / 16 * 16);
+          int mr = (int)std::min<long long>(CT_MAXROWS, std::max<long long>(8, (nxt - cut + target - 1) / target));
+          std::vector<WTile> tmp;
+          for (int tries = 0; tries < 6 && mr >= 8 && waste(n_best) > 1.04; ++tries, --mr) {
+            tmp.clear();
+            append_wave_tiles(ctp.data(), cut, nxt, tmp, mr);
+            if (waste(tmp.size()) < waste(n_best) && tmp.size() <= 3 * (size_t)target) {
+              n_best = tmp.size();
+              mr_best = mr;
+            }
+          }
+          if (mr_best != CT_MAXROWS) {
+            ct.resize(c0);
+            append_wave_tiles(ctp.data(), cut, nxt, ct, mr_best);
+          }
+        }
+      }
       ch.ctile_end = (int)ct.size();
       ch.long_begin = (int)(std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), cut) - c->wlong_rows.begin());
       ch.long_end = (int)(std::lower_bound(c->wlong_rows.begin(), c->wlong_rows.end(), nxt) - c->wlong_rows.begin());
@@ -2334,7 +2374,7 @@ static int launch_fstep(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int
   DSGD_TRY(ensure_part(c, &c->d_partc, &c->partc_wgs, &c->partc_stride, (long long)n_wg * n_workers, nc));
   // LDS: the largest of the three phases' tiles
   const size_t lds_a = sizeof(float) * (size_t)(((nc + 3) & ~3) + 16 * CT_STRIP);
-  const size_t lds_b = sizeof(float) * (size_t)(16 * WS_COEF_STRIDE + 2 * H + 64 + 4);
+  const size_t lds_b = sizeof(float) * (size_t)(16 * WS_COEF_STRIDE + 2 * H + 64 + 4 + 4);   // (+ 4: the hot tiles' counter)
   const size_t lds_c = sizeof(float) * (size_t)(((nc + 64 + 3) & ~3) + 16 * CT_STRIP);
   const size_t lds = std::max(lds_a, std::max(lds_b, lds_c));
   // the fixed-point scale of the hot accumulators: one contribution per row and column, |contribution| <= 2^shift, a

@@ -979,16 +979,29 @@ __device__ __forceinline__ void w_scatter(const WCtx& x, const int (&cc)[8], con
 // requests of a tile -- column ranks, values, lane descriptors, the cold parts of its rows' x.w -- need the tile record
 // only and are issued FIRST, so that three tiles are on their way while the wave works on tile t.  The tiles hold the
 // HOT part of the matrix only (every column rank < hw = hg): no gathers, no clamps, no cold checks.
+// (w_tile_q: the tile whose requests go out, t_issue, and the one whose record is fetched, t_fetch, are named by the
+//  caller -- the row-chunk kernel hands a workgroup's tiles to its waves as they come free, csrc/dsgd_fstep.hpp;
+//  w_tile is the strided walk of the streaming kernel)
+template <bool SCATTER>
+__device__ __forceinline__ void w_tile_q(const CsrView& m, const WTables& tt, const WCtx& x, int t_issue, int t_fetch,
+                                         int t_end, WRegs& cur, WRegs& far, WTile& wt_far, unsigned int& n_all,
+                                         unsigned int& n_neg, unsigned int& n_pos);
 template <bool SCATTER>
 __device__ __forceinline__ void w_tile(const CsrView& m, const WTables& tt, const WCtx& x, int tile,
                                        int stride, int t_end, WRegs& cur, WRegs& far,
                                        WTile& wt_far, unsigned int& n_all, unsigned int& n_neg, unsigned int& n_pos) {
+  w_tile_q<SCATTER>(m, tt, x, tile + 3 * stride, tile + 4 * stride, t_end, cur, far, wt_far, n_all, n_neg, n_pos);
+}
+template <bool SCATTER>
+__device__ __forceinline__ void w_tile_q(const CsrView& m, const WTables& tt, const WCtx& x, int t_issue, int t_fetch,
+                                         int t_end, WRegs& cur, WRegs& far, WTile& wt_far, unsigned int& n_all,
+                                         unsigned int& n_neg, unsigned int& n_pos) {
   const int lane = threadIdx.x & 63;
   // the record load goes out BEFORE this iteration's stream loads: vmcnt retires in order, so next iteration's
   // wait for it does not drain the stream loads issued behind it
   const WTile wt_now = wt_far;                                              // record fetched last iteration
-  wt_far = w_fetch(tt, tile + 4 * stride, t_end);                           // record used next iteration
-  w_issue_cols(m, tile + 3 * stride, t_end, lane, wt_now, far);
+  wt_far = w_fetch(tt, t_fetch, t_end);                                     // record used next iteration
+  w_issue_cols(m, t_issue, t_end, lane, wt_now, far);
   w_issue_vals(m, tt, x.dcold, lane, far);   // (values with the column ids: the window descriptor stays in scalar registers)
 
   const int nrows = cur.nrows;                          // wave-uniform; -1: the whole tile is padding
@@ -1233,6 +1246,80 @@ __device__ __forceinline__ void w_long_row(const CsrView& m, const float* __rest
     n_all += 1;
     n_neg += yd < 0.0f;
     n_pos += yd > 0.0f;
+  }
+}
+
+// The same row with up to LR_IT x 256 of its non-zeros held in REGISTERS (the row-chunk kernel, csrc/dsgd_fstep.hpp): every
+// stream request goes out before the first is used, every weight gather before the first product, and the scatter runs
+// from the registers -- four round trips in a row (row id, bounds, stream, cold weights) instead of one per 256 non-zeros
+// for x.w plus one per 64 for the scatter.  Same products, same order of additions as w_long_row (a[k] over the
+// 256-element pieces in turn, then (a0 + a1) + (a2 + a3), then the wave sum), the same q per entry into the same
+// accumulators: the same bits.
+constexpr int LR_IT = 5;   // 1,280 non-zeros; longer rows take w_long_row
+__device__ __forceinline__ void w_long_row_regs(const CsrView& m, const float* __restrict__ w, const WCtx& x, long long row,
+                                                unsigned int& n_all, unsigned int& n_neg, unsigned int& n_pos) {
+  typedef __attribute__((address_space(3))) const float lds_cfloat;
+  const int lane = threadIdx.x & 63;
+  const long long start = m.row_ptr[row], end = m.row_ptr[row + 1];
+  if (end - start > 256LL * LR_IT) {
+    w_long_row<true>(m, w, x, row, n_all, n_neg, n_pos);
+    return;
+  }
+  const float y = (float)m.label[row];
+  int c[LR_IT][4];
+  float v[LR_IT][4], wv[LR_IT][4];
+#pragma unroll
+  for (int i = 0; i < LR_IT; ++i) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long p = start + lane + 256 * i + 64 * k;
+      const bool in = p < end;
+      c[i][k] = in ? m.col[p] : -1;
+      v[i][k] = in ? m.val[p] : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LR_IT; ++i) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wv[i][k] = c[i][k] >= x.hw ? w[c[i][k]] : 0.0f;   // the few cold ranks: global, together
+  }
+#pragma unroll
+  for (int i = 0; i < LR_IT; ++i) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cc = c[i][k];
+      const float hot = ((lds_cfloat*)x.wl)[(cc >= 0 && cc < x.hw) ? cc : x.hw];   // (wl[hw] is the zero slot)
+      wv[i][k] = (cc >= 0 && cc < x.hw) ? hot : wv[i][k];
+    }
+  }
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < LR_IT; ++i) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] += filt(v[i][k] * wv[i][k]);       // ref: math/Sparse.scala:46
+  }
+  const float d = group_sum<64>((a[0] + a[1]) + (a[2] + a[3]));
+  const bool active = !(y * d < 0.0f);     // ref: core/ml/SparseSVM.scala:27-28
+  if (lane == 0) {
+    x.coef8[row] = (signed char)(active ? (int)y : 0);
+    n_all += active;
+  }
+  if (active) {
+    const float cs = y * x.fix_scale, cq = y * x.cold_scale;
+#pragma unroll
+    for (int i = 0; i < LR_IT; ++i) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int cc = c[i][k];
+        if (cc >= 0 && cc < x.hg) {
+          const int q = __float2int_rn(v[i][k] * cs);
+          if (q != 0) atomicAdd(&x.gl[cc], q);   // (these rows are part of the launch's row bound: no overflow)
+        } else if (cc >= 0) {
+          const int q = __float2int_rn(v[i][k] * cq);
+          if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&x.g64[cc]), (unsigned long long)(long long)q);
+        }
+      }
+    }
   }
 }
 

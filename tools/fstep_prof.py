@@ -48,5 +48,7 @@ for rows in sizes:
             row["phase_us_avg_per_workgroup"] = {nm: round(cyc[i] / n / 2350.0, 2) for i, nm in enumerate(NAMES)}
             row["workgroup_total_us_avg"] = round(cyc[8] / n / 2350.0, 2)
             row["workgroup_total_us_slowest_ever"] = round(cyc[9] / 2350.0, 2)
+            if cyc[11]:
+                row["long_row_us_of_wave0"] = round(cyc[10] / float(cyc[11]) / 2350.0, 2)
         out.append(row)
         print(json.dumps(row), flush=True)
