@@ -90,24 +90,29 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
     tt.t_hi = ch.ctile_end;
     int tile = tt.t_lo + wave;
     const bool any = tile < tt.t_hi;   // (wave-uniform)
-    // the first three tiles' streams are requested BEFORE the weight tile is set up: they need registers only, and land
-    // while the copy runs (round 6: every phase's first requests used to go out behind its set-up -- one exposed round
-    // trip over the fabric per phase)
+    // The first three tiles' streams are requested BEFORE the weight tile is set up and stay in flight ACROSS the set-up
+    // (round 6: every phase's first requests used to go out behind its set-up -- one exposed round trip through this
+    // kernel's own queues, 2-3 us, per phase): the copy's requests first, the tiles' behind them (vmcnt retires in
+    // order: the wait in front of the LDS writes covers the copy alone), a barrier that orders LDS only.
     CRegs<true> A, B, C, D;
-    WTile wt = ctiles[c_map(tt, tile)];
+    // (the four tile records in ONE round trip: fetched one after the other, each in front of the requests it describes,
+    //  they were three dependent scalar round trips in a row at the head of every phase)
+    const WTile wt0 = ctiles[c_map(tt, tile)], wt1 = ctiles[c_map(tt, tile + stride)], wt2 = ctiles[c_map(tt, tile + 2 * stride)];
+    WTile wt = ctiles[c_map(tt, tile + 3 * stride)];
+    WgCopy8 cp;
+    wg_copy_in_issue(w + hw, nc_lds, tid, 1024, is_aligned16(w + hw), cp);
+    __builtin_amdgcn_sched_barrier(0);
     if (any) {
-      c_issue<true, false>(tt, tile, lane, wt, A);
+      c_issue<true, false>(tt, tile, lane, wt0, A);
       __builtin_amdgcn_sched_barrier(0);
-      wt = ctiles[c_map(tt, tile + stride)];
-      c_issue<true, false>(tt, tile + stride, lane, wt, B);
+      c_issue<true, false>(tt, tile + stride, lane, wt1, B);
       __builtin_amdgcn_sched_barrier(0);
-      wt = ctiles[c_map(tt, tile + 2 * stride)];
-      c_issue<true, false>(tt, tile + 2 * stride, lane, wt, C);
+      c_issue<true, false>(tt, tile + 2 * stride, lane, wt2, C);
       __builtin_amdgcn_sched_barrier(0);
-      wt = ctiles[c_map(tt, tile + 3 * stride)];
     }
-    wg_copy_in(lds, w + hw, nc_lds, tid, 1024, is_aligned16(w + hw));
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    wg_copy_in_store(lds, w + hw, nc_lds, tid, 1024, is_aligned16(w + hw), cp);
+    lds_barrier();
     DSGD_FPROF(0)
     if (any) {
 #define DSGD_FA(CUR, FAR)                                            \
@@ -167,34 +172,36 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
     const bool any = qa < t_end;                                 // (wave-uniform)
     const bool has_long = ch.long_begin + wave < ch.long_end;    // (wave-uniform)
     WRegs A, B, C, D;
-    WTile wt = w_fetch(tt, qa, t_end);
+    const WTile wt0 = w_fetch(tt, qa, t_end), wt1 = w_fetch(tt, qb, t_end), wt2 = w_fetch(tt, qc, t_end);   // (one round trip)
+    WTile wt = w_fetch(tt, qd, t_end);
 #define DSGD_FB_PROLOGUE                                 \
   {                                                      \
-    w_issue_cols(m, qa, t_end, lane, wt, A);             \
+    w_issue_cols(m, qa, t_end, lane, wt0, A);            \
     w_issue_vals(m, tt, x.dcold, lane, A);               \
     __builtin_amdgcn_sched_barrier(0);                   \
-    wt = w_fetch(tt, qb, t_end);                         \
-    w_issue_cols(m, qb, t_end, lane, wt, B);             \
+    w_issue_cols(m, qb, t_end, lane, wt1, B);            \
     w_issue_vals(m, tt, x.dcold, lane, B);               \
     __builtin_amdgcn_sched_barrier(0);                   \
-    wt = w_fetch(tt, qc, t_end);                         \
-    w_issue_cols(m, qc, t_end, lane, wt, C);             \
+    w_issue_cols(m, qc, t_end, lane, wt2, C);            \
     w_issue_vals(m, tt, x.dcold, lane, C);               \
     __builtin_amdgcn_sched_barrier(0);                   \
-    wt = w_fetch(tt, qd, t_end);                         \
   }
+    WgCopy8 cp;
+    wg_copy_in_issue(w, hw, tid, 1024, is_aligned16(wl) && is_aligned16(w), cp);
+    __builtin_amdgcn_sched_barrier(0);
     if (!has_long) {
       if (any) DSGD_FB_PROLOGUE
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (is_aligned16(x.gl)) wg_zero(x.gl, hw + 64, tid, 1024);
     else
       for (int j = tid; j < hw + 64; j += 1024) x.gl[j] = 0;
-    wg_copy_in(wl, w, hw, tid, 1024, is_aligned16(wl) && is_aligned16(w));
+    wg_copy_in_store(wl, w, hw, tid, 1024, is_aligned16(wl) && is_aligned16(w), cp);
     if (tid == 0) {
       wl[hw] = 0.0f;
       tile_ctr[0] = ch.tile_begin + 4 * stride;
     }
-    __syncthreads();
+    lds_barrier();   // (LDS only: the first tiles' requests stay in flight)
     DSGD_FPROF(2)
 
     if (has_long) {   // (the registers of the first tiles' requests are not live yet on this path: the row sits in them)
@@ -258,17 +265,15 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
     int tile = tt.t_lo + wave;
     const bool any = tile < tt.t_hi;   // (wave-uniform)
     CRegs<true> A, B, C, D;
-    WTile wt = ctiles[c_map(tt, tile)];
+    const WTile wt0 = ctiles[c_map(tt, tile)], wt1 = ctiles[c_map(tt, tile + stride)], wt2 = ctiles[c_map(tt, tile + 2 * stride)];
+    WTile wt = ctiles[c_map(tt, tile + 3 * stride)];
     if (any) {
-      c_issue<true, true>(tt, tile, lane, wt, A);
+      c_issue<true, true>(tt, tile, lane, wt0, A);
       __builtin_amdgcn_sched_barrier(0);
-      wt = ctiles[c_map(tt, tile + stride)];
-      c_issue<true, true>(tt, tile + stride, lane, wt, B);
+      c_issue<true, true>(tt, tile + stride, lane, wt1, B);
       __builtin_amdgcn_sched_barrier(0);
-      wt = ctiles[c_map(tt, tile + 2 * stride)];
-      c_issue<true, true>(tt, tile + 2 * stride, lane, wt, C);
+      c_issue<true, true>(tt, tile + 2 * stride, lane, wt2, C);
       __builtin_amdgcn_sched_barrier(0);
-      wt = ctiles[c_map(tt, tile + 3 * stride)];
     }
     {   // phase B's finish: the active-row count, the workgroup's exact hot partial sums out
       float* strips = lds + ((hw + 4) & ~3);
@@ -280,13 +285,13 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
       }
       int* mine = part + (long long)wg * part_stride;
       wg_copy_out(mine, gl, hw, tid, 1024, is_aligned16(mine) && is_aligned16(gl));
-      __syncthreads();   // the gradient words have been read: the LDS tile is free
+      lds_barrier();   // the gradient words have been READ (LDS only: their stores and the tiles' requests stay in flight)
       DSGD_FPROF(4)
     }
     const int n_tile = nc_lds + 64;
     float* strip = lds + ((n_tile + 3) & ~3) + wave * CT_STRIP;
     wg_zero(reinterpret_cast<int*>(lds), n_tile, tid, 1024);
-    __syncthreads();
+    lds_barrier();
     DSGD_FPROF(5)
     long long* g64cold = g64_base + (long long)blockIdx.y * g_stride + hw;
     if (any) {

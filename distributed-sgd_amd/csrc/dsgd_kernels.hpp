@@ -56,6 +56,46 @@ __device__ __forceinline__ void wg_copy_in(float* lds_dst, const float* __restri
   }
   for (int j = 4 * n4 + tid; j < n; j += nthreads) lds_dst[j] = src[j];
 }
+// The same copy in two halves (round 6, the row-chunk kernel): the requests go out, the caller issues OTHER requests behind
+// them (the first tiles of the phase: registers only), then the values are written to LDS -- vmcnt retires in order, so
+// the wait in front of the LDS writes covers the copy's own requests and nothing issued behind them.  With lds_barrier()
+// (below) instead of __syncthreads() the phase's first tiles stay in flight across the whole set-up.
+struct WgCopy8 {
+  float4 t[8];
+};
+__device__ __forceinline__ void wg_copy_in_issue(const float* __restrict__ src, int n, int tid, int nthreads, bool aligned,
+                                                 WgCopy8& r) {
+  const int n4 = aligned ? n >> 2 : 0;
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int j = u * nthreads + tid;
+    r.t[u] = s4[j < n4 ? j : (n4 > 0 ? n4 - 1 : 0)];
+  }
+}
+__device__ __forceinline__ void wg_copy_in_store(float* lds_dst, const float* __restrict__ src, int n, int tid, int nthreads,
+                                                 bool aligned, WgCopy8& r) {
+  const int n4 = aligned ? n >> 2 : 0;
+  float4* d4 = reinterpret_cast<float4*>(lds_dst);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(r.t[u].x), "+v"(r.t[u].y), "+v"(r.t[u].z), "+v"(r.t[u].w));
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int j = u * nthreads + tid;
+    if (j < n4) d4[j] = r.t[u];
+  }
+  // (what eight pieces per lane do not cover -- models wider than RCV1 -- and the unaligned tail: plain loops)
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  for (int j = 8 * nthreads + tid; j < n4; j += nthreads) d4[j] = s4[j];
+  for (int j = 4 * n4 + tid; j < n; j += nthreads) lds_dst[j] = src[j];
+}
+// a workgroup barrier that orders LDS only: global requests issued in front of it stay in flight (__syncthreads() waits
+// for every outstanding memory operation of the wave: vmcnt(0))
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 __device__ __forceinline__ void wg_zero(int* lds_dst, int n, int tid, int nthreads) {   // lds_dst 16-byte aligned
   const int n4 = n >> 2;
   for (int j = tid; j < n4; j += nthreads) reinterpret_cast<int4*>(lds_dst)[j] = make_int4(0, 0, 0, 0);
