@@ -21,7 +21,7 @@ UNIQUE_ID_BYTES = 128
 SYMBOLS = [
     "dsgd_abi_version", "dsgd_last_error", "dsgd_device_count", "dsgd_create", "dsgd_destroy", "dsgd_load_csr",
     "dsgd_n_rows", "dsgd_set_dim_sparsity", "dsgd_build_dim_sparsity", "dsgd_set_weights", "dsgd_get_weights",
-    "dsgd_gradient", "dsgd_apply", "dsgd_sync_step", "dsgd_sync_step_ranges", "dsgd_plan_create", "dsgd_plan_create_n", "dsgd_cache_trim",
+    "dsgd_gradient", "dsgd_apply", "dsgd_sync_step", "dsgd_sync_step_ranges", "dsgd_plan_create", "dsgd_plan_create_n", "dsgd_plan_create_from_seed", "dsgd_plan_read_lists", "dsgd_cache_trim",
     "dsgd_plan_destroy", "dsgd_plan_run", "dsgd_plan_info", "dsgd_plan_record", "dsgd_plan_read_record", "dsgd_sync_step_ranges_async", "dsgd_synchronize", "dsgd_forward",
     "dsgd_loss_acc", "dsgd_async_step", "dsgd_update_grad", "dsgd_async_start", "dsgd_async_updates",
     "dsgd_async_stop", "dsgd_async_wait", "dsgd_comm_unique_id", "dsgd_comm_init", "dsgd_comm_destroy",

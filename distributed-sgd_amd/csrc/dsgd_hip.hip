@@ -125,6 +125,7 @@ static bool available() {
 #include "dsgd_dense.hpp"
 #include "dsgd_fstep.hpp"
 #include "dsgd_tcol.hpp"
+#include "dsgd_shuffle.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -140,7 +141,8 @@ struct dsgd_plan {
   bool fits = false;            // every list fits the staged sub-batch of dsgd_plan_kernel (rows and work items)
   long long fits_rows = -1;     // ... of the data set with this many rows (the one loaded at plan creation)
   // virtual tiles (dsgd_vt_grad_kernel): the lists laid out over the split streams, built at the first run that needs them
-  std::vector<int> h_idx;       // host copy of the lists
+  std::vector<int> h_idx;       // host copy of the lists (a plan drawn on the device fetches it only if a host builder asks: plan_host_idx)
+  bool idx_trusted = false;     // the lists were drawn by the library inside the caller's row ranges: nothing to validate
   VtLane* d_vt_lanes = nullptr; // 64 descriptors per tile
   WorkSeg* d_vt_segs = nullptr; // tile range of every list, then (n_lists further entries) its range of d_vt_long
   MbRec* d_vt_long = nullptr;   // rows of the lists that sit in no tile (long-row list, more than 64 cold entries)
@@ -768,6 +770,7 @@ static int launch_grad_mb(dsgd_ctx* c, const int* d_idx, const WorkSeg* d_segs, 
       return 1;                       \
     }                                 \
   } while (0)
+static int plan_host_idx(dsgd_ctx* c, dsgd_plan* p);
 static int vt_build_impl(dsgd_ctx* c, dsgd_plan* p) {
   p->vt_layout = c->layout_gen;
   p->vt_ok = false;
@@ -782,6 +785,7 @@ static int vt_build_impl(dsgd_ctx* c, dsgd_plan* p) {
   const int H = std::min(c->hsplit, c->dp);
   const long long n_lists = (long long)p->n_steps * p->n_workers;
   if (!c->cold_col16 || c->dp <= H || c->hot_nnz + WS_PAD >= (1LL << 32) || c->coldm_nnz + WS_PAD >= (1LL << 32)) return DSGD_OK;
+  DSGD_TRY(plan_host_idx(c, p));
   if (c->h_hrp.size() != (size_t)c->n_rows + 1 || (long long)p->h_idx.size() != p->offsets[n_lists]) return DSGD_OK;
   if ((long long)c->h_ccol.size() != c->coldm_nnz) return DSGD_OK;
   const std::vector<long long>&hrp = c->h_hrp, &ctp = c->h_ctp, &crp = c->h_crow_ptr;
@@ -1100,6 +1104,17 @@ static void cs_free(dsgd_ctx* c, dsgd_plan* p) {
   p->d_cs_val = nullptr;
   p->cs_ok = false;
 }
+// the host copy of a plan's lists: plans drawn on the device (dsgd_plan_create_from_seed) have none until a HOST builder
+// (virtual tiles, DSGD_CS_HOST_LAYOUT=1) needs it
+static int plan_host_idx(dsgd_ctx* c, dsgd_plan* p) {
+  const long long n_lists = (long long)p->n_steps * p->n_workers;
+  const long long n = p->offsets.empty() ? 0 : p->offsets[(size_t)n_lists];
+  if ((long long)p->h_idx.size() == n || !p->d_idx) return DSGD_OK;
+  if (p->built_pending && p->built_ev) HIP_TRY(hipEventSynchronize(p->built_ev));
+  p->h_idx.resize((size_t)n);
+  HIP_TRY(hipMemcpy(p->h_idx.data(), p->d_idx, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+  return DSGD_OK;
+}
 static int ensure_build_stream(dsgd_ctx* c) {
   if (!c->build_stream) HIP_TRY(hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking));
   return DSGD_OK;
@@ -1167,9 +1182,11 @@ static int cs_build_device_impl(dsgd_ctx* c, dsgd_plan* p) {
   const int G = cs_pick_G(c, K, false);
   if (!G) return DSGD_OK;
   if (n_steps * (long long)G > 0x7fffffffLL) return DSGD_OK;
-  if ((long long)p->h_idx.size() != p->offsets[(size_t)n_lists]) return DSGD_OK;
-  for (long long r : p->h_idx)
-    if (r < 0 || r >= c->n_rows) return DSGD_OK;   // (the row-wise kernel reports the bad index)
+  if (!p->idx_trusted) {
+    if ((long long)p->h_idx.size() != p->offsets[(size_t)n_lists]) return DSGD_OK;
+    for (long long r : p->h_idx)
+      if (r < 0 || r >= c->n_rows) return DSGD_OK;   // (the row-wise kernel reports the bad index)
+  }
   p->cs_shift.assign((size_t)n_steps, 21);
   for (long long st = 0; st < n_steps; ++st) {
     long long worst_list = 1;
@@ -1265,6 +1282,7 @@ static int cs_build_impl(dsgd_ctx* c, dsgd_plan* p) {
   int G = c->cs_g ? c->cs_g : (K <= 4 ? 8 : 16);
   if (!c->cs_g && G == 8 && cs_lds_words(c->dp, 8, K) > DSGD_LDS_FLOATS) G = 16;   // (a wide model: narrower slices)
   if (c->dp < 4 * G || cs_lds_words(c->dp, G, K) > DSGD_LDS_FLOATS || (c->dp + G - 1) / G > 65536) return DSGD_OK;
+  DSGD_TRY(plan_host_idx(c, p));
   if (c->h_row_ptr.size() != (size_t)c->n_rows + 1 || (long long)p->h_idx.size() != p->offsets[n_lists]) return DSGD_OK;
   const long long N = p->offsets[n_lists];
   std::vector<long long> pre((size_t)N + 1);
@@ -3528,10 +3546,17 @@ int dsgd_plan_create_n(dsgd_ctx* c, const int32_t* idx, int64_t n_idx, const int
   return dsgd_plan_create(c, idx, offsets, n_steps, n_workers, out);
 }
 
-int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, int64_t n_steps, int32_t n_workers,
-                     dsgd_plan** out) {
-  DSGD_TRY(check_ctx(c));
-  if (!idx || !offsets || !out || n_steps < 1 || n_workers < 1) return fail(DSGD_EINVAL, "bad plan arguments");
+// A plan's frame: offsets checked, the two device blocks taken from the cache, the list ranges uploaded (build stream).
+// The caller fills p->d_idx on the build stream and calls plan_finish; on failure everything is given back.
+static void plan_abandon(dsgd_ctx* c, dsgd_plan* p) {
+  (void)hipStreamSynchronize(c->build_stream);
+  cs_free(c, p);
+  cache_give(c, p->d_idx, p->idx_bytes);
+  cache_give(c, p->d_segs, p->segs_bytes);
+  if (p->built_ev) (void)hipEventDestroy(p->built_ev);
+  delete p;
+}
+static int plan_frame(dsgd_ctx* c, const int64_t* offsets, int64_t n_steps, int32_t n_workers, dsgd_plan** out) {
   const int64_t n_lists = n_steps * n_workers;
   if (offsets[0] != 0) return fail(DSGD_EINVAL, "offsets[0] must be 0");
   long long mx = 0;
@@ -3540,20 +3565,15 @@ int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, in
       return fail(DSGD_EINVAL, "list %lld is empty: Vec.sum requires a non-empty list", (long long)i);
     mx = std::max<long long>(mx, offsets[i + 1] - offsets[i]);
   }
-  std::lock_guard<std::mutex> lk(c->mu);
-  DSGD_TRY(bind(c, true));   // (nothing here touches w: slice-major weights stay as they are)
   dsgd_plan* p = new (std::nothrow) dsgd_plan();
   if (!p) return fail(DSGD_ENOMEM, "out of host memory");
   p->n_steps = n_steps;
   p->n_workers = n_workers;
   p->max_items = mx;
   p->offsets.assign(offsets, offsets + n_lists + 1);
-  p->h_idx.assign(idx, idx + offsets[n_lists]);
   for (int64_t st = 0; st < n_steps; ++st)
     p->max_step_rows = std::max<long long>(p->max_step_rows, offsets[(st + 1) * n_workers] - offsets[st * n_workers]);
-  p->fits = true;
   p->fits_rows = c->n_rows;
-  for (int64_t i = 0; i < n_lists && p->fits; ++i) p->fits = list_fits_staged(c, idx + offsets[i], offsets[i + 1] - offsets[i]);
   std::vector<WorkSeg> segs((size_t)n_lists);
   for (int64_t i = 0; i < n_lists; ++i) {
     segs[i].begin = offsets[i];
@@ -3569,15 +3589,25 @@ int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, in
   p->d_idx = static_cast<int*>(qi);
   p->d_segs = static_cast<WorkSeg*>(qs);
   if (rc == DSGD_OK && hipEventCreateWithFlags(&p->built_ev, hipEventDisableTiming) != hipSuccess) rc = fail(DSGD_EHIP, "hipEventCreate");
-  // (pageable sources: the runtime stages them and returns when they are staged; ordered on the build stream)
   hipError_t e = hipSuccess;
-  if (rc == DSGD_OK) e = hipMemcpyAsync(p->d_idx, idx, ib, hipMemcpyHostToDevice, c->build_stream);
-  if (rc == DSGD_OK && e == hipSuccess) e = hipMemcpyAsync(p->d_segs, segs.data(), sb, hipMemcpyHostToDevice, c->build_stream);
+  if (rc == DSGD_OK) e = hipMemcpyAsync(p->d_segs, segs.data(), sb, hipMemcpyHostToDevice, c->build_stream);
   if (rc == DSGD_OK && e == hipSuccess) e = hipStreamSynchronize(c->build_stream);   // (segs is a local: staged before it goes)
   if (rc == DSGD_OK && e != hipSuccess) rc = fail(DSGD_EHIP, "plan upload: %s", hipGetErrorString(e));
+  if (rc != DSGD_OK) {
+    char msg[sizeof(g_err)];
+    snprintf(msg, sizeof(msg), "%s", g_err);
+    plan_abandon(c, p);
+    return fail(rc, "%s", msg);
+  }
+  *out = p;
+  return DSGD_OK;
+}
+// the lists are in p->d_idx (enqueued on the build stream): lay the plan out for the device, close its set-up
+static int plan_finish(dsgd_ctx* c, dsgd_plan* p, dsgd_plan** out) {
+  int rc = DSGD_OK;
   // the column slices of the reference's own step sizes are laid out NOW (by the device, on the build stream), not inside
   // the first dsgd_plan_run -- a call its callers time; without a column layout yet (no data / no dimSparsity) at the first run
-  if (rc == DSGD_OK && c->cs_enable && !c->comm && c->d_row_ptr && c->have_ds && !c->async_running) {
+  if (c->cs_enable && !c->comm && c->d_row_ptr && c->have_ds && !c->async_running) {
     rc = prepare_layout(c);
     if (rc == DSGD_OK) rc = cs_build(c, p);
   }
@@ -3585,16 +3615,262 @@ int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, in
   if (rc != DSGD_OK) {
     char msg[sizeof(g_err)];
     snprintf(msg, sizeof(msg), "%s", g_err);
-    (void)hipStreamSynchronize(c->build_stream);
-    cs_free(c, p);
-    cache_give(c, p->d_idx, p->idx_bytes);
-    cache_give(c, p->d_segs, p->segs_bytes);
-    if (p->built_ev) (void)hipEventDestroy(p->built_ev);
-    delete p;
+    plan_abandon(c, p);
     return fail(rc, "%s", msg);
   }
   p->built_pending = true;
   *out = p;
+  return DSGD_OK;
+}
+
+int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, int64_t n_steps, int32_t n_workers,
+                     dsgd_plan** out) {
+  DSGD_TRY(check_ctx(c));
+  if (!idx || !offsets || !out || n_steps < 1 || n_workers < 1) return fail(DSGD_EINVAL, "bad plan arguments");
+  const int64_t n_lists = n_steps * n_workers;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c, true));   // (nothing here touches w: slice-major weights stay as they are)
+  dsgd_plan* p = nullptr;
+  DSGD_TRY(plan_frame(c, offsets, n_steps, n_workers, &p));
+  p->h_idx.assign(idx, idx + offsets[n_lists]);
+  p->fits = true;
+  for (int64_t i = 0; i < n_lists && p->fits; ++i) p->fits = list_fits_staged(c, idx + offsets[i], offsets[i + 1] - offsets[i]);
+  // (pageable sources: the runtime stages them and returns when they are staged; ordered on the build stream)
+  hipError_t e = hipMemcpyAsync(p->d_idx, idx, sizeof(int) * (size_t)offsets[n_lists], hipMemcpyHostToDevice, c->build_stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->build_stream);
+  if (e != hipSuccess) {
+    plan_abandon(c, p);
+    return fail(DSGD_EHIP, "plan upload: %s", hipGetErrorString(e));
+  }
+  return plan_finish(c, p, out);
+}
+
+// ---- an epoch's lists drawn on the device, draw for draw the reference's stream (csrc/dsgd_shuffle.hpp) ---------------------
+int dsgd_plan_create_from_seed(dsgd_ctx* c, uint64_t* jstate, const int64_t* split_begin, const int64_t* split_end, int32_t n_splits,
+                               int64_t max_samples, int32_t batch_size, dsgd_plan** out, int64_t* n_steps_out, int64_t* draws_out) {
+  DSGD_TRY(check_ctx(c));
+  if (!jstate || !split_begin || !split_end || !out || !n_steps_out || n_splits < 1 || batch_size < 1)
+    return fail(DSGD_EINVAL, "bad arguments");
+  *out = nullptr;
+  *n_steps_out = 0;
+  if (draws_out) *draws_out = 0;
+  long long max_len = 0;
+  for (int k = 0; k < n_splits; ++k) {
+    const long long len = split_end[k] - split_begin[k];
+    if (len < 1 || split_begin[k] < 0) return fail(DSGD_EINVAL, "worker %d has no rows", k);
+    max_len = std::max(max_len, len);
+  }
+  if (batch_size > JR_MAX_TAKE || max_len > JR_MAX_LEN)
+    return fail(DSGD_EUNSUPPORTED, "device-drawn lists serve batches up to %d rows of splits up to %d rows (draw them on the host)", JR_MAX_TAKE, JR_MAX_LEN);
+  // steps the reference runs before an empty slice (core/Master.scala:184-188; the slave's Vec.sum throws on it)
+  long long n_steps = 0;
+  for (long long b = 0; b < max_samples; b += batch_size) {
+    bool ok = true;
+    for (int k = 0; k < n_splits; ++k) ok = ok && b < split_end[k] - split_begin[k];
+    if (!ok) break;
+    ++n_steps;
+  }
+  if (n_steps == 0) return DSGD_OK;
+  const long long n_shuf = n_steps * n_splits;
+  std::vector<int64_t> offsets((size_t)n_shuf + 1, 0);
+  std::vector<long long> start((size_t)n_shuf + 1, 0);   // nominal raw index of every shuffle's start (no rejections)
+  for (long long q = 0; q < n_shuf; ++q) {
+    const long long len = split_end[q % n_splits] - split_begin[q % n_splits], b = (q / n_splits) * (long long)batch_size;
+    offsets[(size_t)q + 1] = offsets[(size_t)q] + std::min<long long>(batch_size, len - b);
+    start[(size_t)q + 1] = start[(size_t)q] + (len >= 2 ? len - 1 : 0);
+  }
+  const long long nominal = start[(size_t)n_shuf];
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c, true));
+  for (int k = 0; k < n_splits; ++k)
+    if (split_end[k] > c->n_rows) return fail(DSGD_ERANGE, "worker %d's rows [%lld, %lld) outside the %lld loaded", k, (long long)split_begin[k], (long long)split_end[k], c->n_rows);
+  DSGD_TRY(ensure_build_stream(c));
+  hipStream_t bs = c->build_stream;
+  const unsigned long long s0 = *jstate & JR_MASK;
+  // ---- pass A on the device: the candidates for a rejection; the walk over them here ----
+  std::vector<JrShuf> shuf((size_t)n_shuf);
+  std::vector<int> rej_list;
+  long long rej_total = 0;
+  {
+    const unsigned int cand_min = (unsigned int)(0x80000000ULL - (unsigned long long)max_len);
+    const int per_lane = (int)std::max<long long>(1, std::min<long long>(1024, (1LL << 30) / max_len));
+    long long scan = nominal + 64 + nominal / 4096;
+    for (int attempt = 0;; ++attempt) {
+      const long long span = (long long)JR_SCAN_THREADS * per_lane;
+      const long long n_wg = (scan + span - 1) / span;
+      const long long cap = (long long)((double)scan * (double)max_len / 2147483648.0 * 2.0) + 65536;
+      long long* d_ci = nullptr;
+      unsigned int* d_cu = nullptr;
+      unsigned long long *d_base = nullptr, *d_tot = nullptr;
+      auto drop = [&]() {
+        (void)hipFree(d_ci);
+        (void)hipFree(d_cu);
+        (void)hipFree(d_base);
+        (void)hipFree(d_tot);
+      };
+      hipError_t e = n_wg > 0x7fffffffLL ? hipErrorInvalidValue : hipMalloc(&d_ci, sizeof(long long) * (size_t)cap);
+      if (e == hipSuccess) e = hipMalloc(&d_cu, sizeof(unsigned int) * (size_t)cap);
+      if (e == hipSuccess) e = hipMalloc(&d_base, sizeof(unsigned long long) * (size_t)n_wg);
+      if (e == hipSuccess) e = hipMalloc(&d_tot, sizeof(unsigned long long) * 2);
+      if (e == hipSuccess) e = hipMemsetAsync(d_tot, 0, sizeof(unsigned long long) * 2, bs);
+      std::vector<unsigned long long> base((size_t)n_wg);
+      unsigned long long tot[2] = {0, 0};
+      if (e == hipSuccess) {
+        JrScanArgs sa;
+        sa.s0 = s0;
+        sa.scan = scan;
+        sa.per_lane = per_lane;
+        sa.cand_min = cand_min;
+        sa.cap = cap;
+        sa.cand_i = d_ci;
+        sa.cand_u = d_cu;
+        sa.wg_base = d_base;
+        sa.total = d_tot;
+        hipLaunchKernelGGL(dsgd_jr_scan_kernel, dim3((unsigned)n_wg), dim3(JR_SCAN_THREADS), 0, bs, sa);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, bs);
+      if (e == hipSuccess) e = hipMemcpyAsync(base.data(), d_base, sizeof(unsigned long long) * (size_t)n_wg, hipMemcpyDeviceToHost, bs);
+      if (e == hipSuccess) e = hipStreamSynchronize(bs);
+      std::vector<long long> ci;
+      std::vector<unsigned int> cu;
+      if (e == hipSuccess && tot[1] == 0 && tot[0] > 0) {
+        ci.resize((size_t)tot[0]);
+        cu.resize((size_t)tot[0]);
+        e = hipMemcpy(ci.data(), d_ci, sizeof(long long) * ci.size(), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(cu.data(), d_cu, sizeof(unsigned int) * cu.size(), hipMemcpyDeviceToHost);
+      }
+      drop();
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DSGD_EHIP, "scanning the random stream: %s", hipGetErrorString(e));
+      }
+      if (tot[1] != 0) return fail(DSGD_EUNSUPPORTED, "more rejection candidates than the device scan holds (draw the lists on the host)");
+      // walk the candidates in raw order (workgroup by workgroup, each block in order): `rej` = rejections so far.  Raw index
+      // i serves draw d = i - rej of the epoch; draw d belongs to shuffle j (start[j] <= d < start[j + 1]), bound len_j - (d - start[j])
+      long long rej = 0, j = 0;
+      bool beyond = false;
+      rej_list.clear();
+      for (long long q = 0; q < n_shuf; ++q) shuf[(size_t)q] = JrShuf{start[(size_t)q], 0, 0};
+      long long next_begin = 0;   // shuffles < next_begin have their record closed
+      auto close_upto = [&](long long jj) {   // shuffles before jj start with the rejections counted so far ... hmm: see below
+        for (; next_begin < jj; ++next_begin) {
+          shuf[(size_t)next_begin].rej_end = (int)rej_list.size();
+          if (next_begin + 1 < n_shuf) {
+            shuf[(size_t)next_begin + 1].raw0 = start[(size_t)next_begin + 1] + rej;
+            shuf[(size_t)next_begin + 1].rej_begin = (int)rej_list.size();
+          }
+        }
+      };
+      for (long long w = 0; w < n_wg && !beyond; ++w) {
+        const unsigned long long bw = base[(size_t)w];
+        const unsigned long long at = bw >> 16, cnt = bw & 0xffffULL;
+        for (unsigned long long t = 0; t < cnt; ++t) {
+          const long long d = ci[(size_t)(at + t)] - rej;
+          if (d >= nominal) {
+            beyond = true;
+            break;
+          }
+          while (start[(size_t)j + 1] <= d) ++j;
+          close_upto(j);
+          const long long len = split_end[j % n_splits] - split_begin[j % n_splits];
+          const unsigned int n = (unsigned int)(len - (d - start[(size_t)j]));
+          if ((n & (n - 1)) != 0 && cu[(size_t)(at + t)] >= (0x80000000u / n) * n) {
+            rej_list.push_back((int)(ci[(size_t)(at + t)] - shuf[(size_t)j].raw0));
+            ++rej;
+          }
+        }
+      }
+      close_upto(n_shuf);
+      if (nominal + rej > scan) {   // more rejections than the margin scanned: scan further and walk again
+        if (attempt >= 3) return fail(DSGD_EUNSUPPORTED, "the random stream keeps outrunning its scan (draw the lists on the host)");
+        scan = nominal + rej + 64 + rej / 8;
+        continue;
+      }
+      rej_total = rej;
+      break;
+    }
+  }
+  for (long long q = 0; q < n_shuf; ++q)
+    if (shuf[(size_t)q].rej_end - shuf[(size_t)q].rej_begin > JR_MAX_REJ)
+      return fail(DSGD_EUNSUPPORTED, "more than %d rejections inside one shuffle (draw the lists on the host)", JR_MAX_REJ);
+  // ---- the plan's frame, then pass B straight into its index buffer ----
+  dsgd_plan* p = nullptr;
+  DSGD_TRY(plan_frame(c, offsets.data(), n_steps, n_splits, &p));
+  p->idx_trusted = true;
+  p->fits = false;   // (the one-workgroup kernel's test reads the lists on the host; these plans run on column slices)
+  JrShuf* d_shuf = nullptr;
+  int *d_rej = nullptr, *d_err = nullptr;
+  long long *d_sb = nullptr, *d_off = nullptr;
+  auto drop2 = [&]() {
+    (void)hipFree(d_shuf);
+    (void)hipFree(d_rej);
+    (void)hipFree(d_err);
+    (void)hipFree(d_sb);
+    (void)hipFree(d_off);
+  };
+  std::vector<long long> sb2(2 * (size_t)n_splits);
+  for (int k = 0; k < n_splits; ++k) {
+    sb2[(size_t)k] = split_begin[k];
+    sb2[(size_t)n_splits + (size_t)k] = split_end[k];
+  }
+  int h_err = 0;
+  hipError_t e = hipMalloc(&d_shuf, sizeof(JrShuf) * (size_t)n_shuf);
+  if (e == hipSuccess) e = hipMalloc(&d_rej, sizeof(int) * std::max<size_t>(1, rej_list.size()));
+  if (e == hipSuccess) e = hipMalloc(&d_err, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&d_sb, sizeof(long long) * sb2.size());
+  if (e == hipSuccess) e = hipMalloc(&d_off, sizeof(long long) * offsets.size());
+  if (e == hipSuccess) e = hipMemcpyAsync(d_shuf, shuf.data(), sizeof(JrShuf) * (size_t)n_shuf, hipMemcpyHostToDevice, bs);
+  if (e == hipSuccess && !rej_list.empty()) e = hipMemcpyAsync(d_rej, rej_list.data(), sizeof(int) * rej_list.size(), hipMemcpyHostToDevice, bs);
+  if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, sizeof(int), bs);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_sb, sb2.data(), sizeof(long long) * sb2.size(), hipMemcpyHostToDevice, bs);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_off, offsets.data(), sizeof(long long) * offsets.size(), hipMemcpyHostToDevice, bs);
+  if (e == hipSuccess) {
+    static const JrAffine back_one = jr_inverse_step();
+    static const JrAffine back_block = jr_power(back_one, JR_SLICE_THREADS);
+    JrSliceArgs a;
+    a.s0 = s0;
+    a.back_block = back_block;
+    a.back_one = back_one;
+    a.shuf = d_shuf;
+    a.rej = d_rej;
+    a.split_begin = d_sb;
+    a.split_end = d_sb + n_splits;
+    a.offsets = d_off;
+    a.idx_out = p->d_idx;
+    a.n_splits = n_splits;
+    a.batch_size = batch_size;
+    a.err = d_err;
+    hipLaunchKernelGGL(dsgd_jr_slice_kernel, dim3((unsigned)n_shuf), dim3(JR_SLICE_THREADS), jr_slice_lds_bytes(max_len), bs, a);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, bs);
+  if (e == hipSuccess) e = hipStreamSynchronize(bs);
+  drop2();
+  if (e != hipSuccess || h_err) {
+    (void)hipGetLastError();
+    plan_abandon(c, p);
+    if (h_err) return fail(DSGD_EUNSUPPORTED, "a shuffle left the limits of the device form (draw the lists on the host)");
+    return fail(DSGD_EHIP, "drawing the lists: %s", hipGetErrorString(e));
+  }
+  DSGD_TRY(plan_finish(c, p, out));
+  *n_steps_out = n_steps;
+  *jstate = jr_jump_dev(s0, (unsigned long long)(nominal + rej_total));
+  if (draws_out) *draws_out = nominal + rej_total;
+  return DSGD_OK;
+}
+
+// the lists of a plan as the device holds them (tests: the device-drawn lists against csrc/jrand.c's)
+int dsgd_plan_read_lists(dsgd_ctx* c, dsgd_plan* p, int32_t* idx_out, int64_t n, int64_t* offsets_out, int64_t n_offsets) {
+  DSGD_TRY(check_ctx(c));
+  if (!p || n < 0 || n_offsets < 0 || (n > 0 && !idx_out) || (n_offsets > 0 && !offsets_out)) return fail(DSGD_EINVAL, "bad arguments");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DSGD_TRY(bind(c, true));
+  const long long n_lists = (long long)p->n_steps * p->n_workers;
+  if (n > p->offsets[(size_t)n_lists] || n_offsets > n_lists + 1) return fail(DSGD_EINVAL, "more entries asked for than the plan holds");
+  if (p->built_pending && p->built_ev) HIP_TRY(hipEventSynchronize(p->built_ev));
+  if (n) HIP_TRY(hipMemcpy(idx_out, p->d_idx, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < n_offsets; ++i) offsets_out[i] = p->offsets[(size_t)i];
   return DSGD_OK;
 }
 

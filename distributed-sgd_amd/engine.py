@@ -179,6 +179,32 @@ class Engine:
         check(self._lib.dsgd_plan_create_n(self._ctx, ptr(idx), C.c_int64(len(idx)), ptr(offsets), C.c_int64(n_steps), C.c_int32(n_workers), C.byref(h)))
         return Plan(self, h, n_steps, n_workers, int(offsets[-1]))
 
+    def plan_from_seed(self, jstate, split, max_samples, batch_size):
+        """One epoch of Master.fit as a plan whose lists the DEVICE draws, draw for draw the reference's stream
+        (dsgd_plan_create_from_seed).  jstate: java.util.Random's internal 48-bit state in front of the epoch; split: the
+        workers' row ranges (SplitStrategy.vanilla).  Returns (plan or None, n_steps, new jstate, draws); raises
+        DsgdError with code EUNSUPPORTED when the device form does not apply (draw the lists on the host then)."""
+        sb = np.asarray([r.start if isinstance(r, range) else r[0] for r in split], dtype=np.int64)
+        se = np.asarray([r.stop if isinstance(r, range) else r[1] for r in split], dtype=np.int64)
+        st = C.c_uint64(int(jstate))
+        h = C.c_void_p()
+        n_steps, draws = C.c_int64(0), C.c_int64(0)
+        check(self._lib.dsgd_plan_create_from_seed(self._ctx, C.byref(st), ptr(sb), ptr(se), C.c_int32(len(sb)), C.c_int64(max_samples),
+                                                   C.c_int32(batch_size), C.byref(h), C.byref(n_steps), C.byref(draws)))
+        if not h.value:
+            return None, 0, int(st.value), 0
+        total = int(sum(min(batch_size, int(e - b) - s_ * batch_size) for s_ in range(n_steps.value) for b, e in zip(sb, se)))
+        return Plan(self, h, n_steps.value, len(sb), total), n_steps.value, int(st.value), draws.value
+
+    def plan_lists(self, plan):
+        """(idx, offsets) of a plan as the device holds them (tests)."""
+        n_lists = plan.n_steps * plan.n_workers
+        offsets = np.zeros(n_lists + 1, dtype=np.int64)
+        check(self._lib.dsgd_plan_read_lists(self._ctx, plan.handle, None, C.c_int64(0), ptr(offsets), C.c_int64(n_lists + 1)))
+        idx = np.zeros(int(offsets[-1]), dtype=np.int32)
+        check(self._lib.dsgd_plan_read_lists(self._ctx, plan.handle, ptr(idx), C.c_int64(len(idx)), None, C.c_int64(0)))
+        return idx, offsets
+
     def cache_trim(self, keep_bytes=0):
         """Give the device blocks of destroyed plans back (all but keep_bytes); returns the bytes still held."""
         held = C.c_int64(0)

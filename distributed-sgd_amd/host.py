@@ -450,6 +450,14 @@ class MasterSync:
         self._logging = log is not None
         self.log = log or (lambda *a: None)
         self.plans = hasattr(backend, "plan_flat") if plans is None else bool(plans)
+        # the epoch's lists drawn BY THE DEVICE, draw for draw the same stream (Engine.plan_from_seed, csrc/dsgd_shuffle.hpp):
+        # 14 ms per epoch of RCV1 at full = true against 195 ms on 32 host threads; off by itself where the device form does
+        # not apply (batches beyond 1,024 rows, splits beyond 2^20 rows) or DSGD_DEVICE_LISTS=0
+        self.device_lists = self.plans and hasattr(backend, "plan_from_seed") and os.environ.get("DSGD_DEVICE_LISTS", "1") != "0"
+        # ... and only for epochs of at least this many draws: the device form has ~1.5 ms of fixed cost per epoch (two
+        # synchronisations, the host's walk over the candidates), the host draws 7 G values per second -- the full = false
+        # configuration (1.15 M draws per epoch) is cheaper on the host (profiles/r06_fit_loop.txt)
+        self.device_lists_min_draws = int(os.environ.get("DSGD_DEVICE_LISTS_MIN_DRAWS", 8 << 20))
         self.prefetch = prefetch
         self.losses: List[float] = []
         self.accs: List[float] = []
@@ -524,7 +532,29 @@ class MasterSync:
 
     def _make_plan(self, lists, n_workers):
         plan = self.backend.plan_flat(lists["idx"], lists["offsets"], lists["n_steps"], n_workers) if lists["n_steps"] else None
-        return {"plan": plan, "n_steps": lists["n_steps"], "offsets": lists["offsets"], "seed_before": lists["seed_before"]}
+        return {"plan": plan, "n_steps": lists["n_steps"], "n_samples": int(lists["offsets"][lists["n_steps"] * n_workers]),
+                "seed_before": lists["seed_before"]}
+
+    def _next_plan(self, split, max_samples, batch_size, n_workers, ahead_ok=False):
+        """The next epoch as a plan: its lists drawn by the device where that applies, else by the host (csrc/jrand.c)."""
+        draws = len(range(0, max_samples, batch_size)) * sum(len(r) - 1 for r in split)
+        if self.device_lists and draws >= self.device_lists_min_draws and all(r.step == 1 for r in split):
+            seed_before = self.rnd.seed
+            t0 = time.perf_counter()
+            try:
+                plan, n_steps, state, _ = self.backend.plan_from_seed(seed_before, split, max_samples, batch_size)
+            except Exception as e:   # (DSGD_EUNSUPPORTED: outside the device form -- the host draws from here on)
+                if getattr(e, "code", None) != -7:
+                    raise
+                self.device_lists = False
+            else:
+                self.rnd.seed = state
+                self.shuffle_s += time.perf_counter() - t0
+                return {"plan": plan, "n_steps": n_steps, "n_samples": plan.n_samples if plan is not None else 0, "seed_before": seed_before}
+        lists = self._take_lists(split, max_samples, batch_size)
+        if ahead_ok and lists["n_steps"] == len(range(0, max_samples, batch_size)):
+            self._draw_ahead(split, max_samples, batch_size)
+        return self._make_plan(lists, n_workers)
 
     def _epoch_through_a_plan(self, split, max_samples, batch_size, learning_rate, epochs_left):
         """One epoch's batch loop (core/Master.scala:179-199) as one resident plan."""
@@ -548,7 +578,7 @@ class MasterSync:
         cur = getattr(self, "_pending", None)
         self._pending = None
         if cur is None:
-            cur = self._make_plan(self._take_lists(split, max_samples, batch_size), K)
+            cur = self._next_plan(split, max_samples, batch_size, K)
         t0 = time.perf_counter_ns()
         try:
             if cur["n_steps"]:
@@ -556,10 +586,7 @@ class MasterSync:
             if self.prefetch and epochs_left > 1 and cur["n_steps"] == n_expected:
                 # ... and while they run: the next epoch's lists (drawn ahead already, from the second epoch on), the draw of the
                 # epoch after it started on the helper thread, the next epoch's plan laid out (the device's build stream)
-                nxt = self._take_lists(split, max_samples, batch_size)
-                if epochs_left > 2 and nxt["n_steps"] == n_expected:
-                    self._draw_ahead(split, max_samples, batch_size)
-                self._pending = self._make_plan(nxt, K)
+                self._pending = self._next_plan(split, max_samples, batch_size, K, ahead_ok=epochs_left > 2)
         finally:
             if cur["plan"] is not None:        # (also when the run or the next plan's set-up failed: the device blocks go back)
                 cur["plan"].destroy()                                                # (behind the run; no synchronisation)
@@ -567,7 +594,6 @@ class MasterSync:
         self.backend.synchronize()
         dt = time.perf_counter_ns() - t0
         # what the per-batch closure would have logged and recorded (:181-183, Slave.scala:145-150), written now
-        offs = cur["offsets"]
         if self._logging:
             for s_ in range(cur["n_steps"]):
                 batch = s_ * batch_size
@@ -575,7 +601,7 @@ class MasterSync:
         if cur["n_steps"]:
             with self.metrics._lock:   # one entry per batch, as the per-batch closure records them
                 self.metrics.histograms.setdefault("master.sync.batch.duration", []).extend([dt // cur["n_steps"]] * cur["n_steps"])
-            self.metrics.counter("slave.sync.backward", int(offs[cur["n_steps"] * K]))
+            self.metrics.counter("slave.sync.backward", cur["n_samples"])
         self.steps_run += cur["n_steps"]
         if cur["n_steps"] < n_expected:
             # the reference's next batch hands some slave an empty slice: Vec.sum throws there (math/Vec.scala:129)

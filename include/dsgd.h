@@ -155,6 +155,25 @@ int dsgd_plan_create(dsgd_ctx* ctx, const int32_t* idx, const int64_t* offsets, 
  * would be read past its end).  The JNI shim, the Python binding and include/dsgd.hpp all go through this one.       */
 int dsgd_plan_create_n(dsgd_ctx* ctx, const int32_t* idx, int64_t n_idx, const int64_t* offsets, int64_t n_steps,
                        int32_t n_workers, dsgd_plan** out);
+/* One EPOCH of Master.fit as a plan whose lists are DRAWN BY THE DEVICE, draw for draw the reference's random stream
+ * (core/Master.scala:184: for every batch every worker's whole split is reshuffled -- scala.util.Random.shuffle over
+ * java.util.Random -- and sliced; 1.38 G draws per epoch of RCV1 at full = true, which a host reproduces in 0.19 s on 32
+ * threads while the epoch's 2,146 steps run in 10 ms).  *jstate is java.util.Random's 48-bit internal state (what
+ * `new java.util.Random(seed)` holds: (seed ^ 0x5DEECE66D) & (2^48 - 1)) in front of the epoch's first draw; on success it
+ * is the state behind the last draw of the steps emitted (*draws_out raw values later), exactly as the JVM's generator
+ * would stand.  split k = rows [split_begin[k], split_end[k]) (SplitStrategy.vanilla, the caller's); the steps are those of
+ * `0 until max_samples by batch_size` up to the first one that hands some worker an EMPTY slice (*n_steps_out of them: the
+ * reference's slave throws there, math/Vec.scala:129; 0 steps: *out = NULL).  csrc/dsgd_shuffle.hpp: the raw stream is
+ * scanned for rejection candidates by every lane of the device at once, the host walks the ~10^5 candidates (the one
+ * sequential part), and every (batch, worker) list is traced backwards through its Fisher-Yates by one workgroup straight
+ * into the plan's index buffer.  DSGD_EUNSUPPORTED (nothing drawn, *jstate untouched): batch_size > 1,024, a split of more
+ * than 2^20 rows, or a stream outside the device form's limits -- draw the lists on the host then (the Python / C++ host
+ * mirrors do: csrc/jrand.c) and use dsgd_plan_create_n.  tests/test_gpu_shuffle.py: equal to csrc/jrand.c entry for entry. */
+int dsgd_plan_create_from_seed(dsgd_ctx* ctx, uint64_t* jstate, const int64_t* split_begin, const int64_t* split_end,
+                               int32_t n_splits, int64_t max_samples, int32_t batch_size, dsgd_plan** out,
+                               int64_t* n_steps_out, int64_t* draws_out);
+/* the lists of a plan as the device holds them: the first n entries and the first n_offsets prefix offsets (tests) */
+int dsgd_plan_read_lists(dsgd_ctx* ctx, dsgd_plan* plan, int32_t* idx_out, int64_t n, int64_t* offsets_out, int64_t n_offsets);
 int dsgd_plan_destroy(dsgd_ctx* ctx, dsgd_plan* plan);
 /* The device blocks destroyed plans leave with the context (up to DSGD_CACHE_MB, default 8192 MiB, read at dsgd_create;
  * a block no plan took again within ~5 plans is freed by itself): give back all but keep_bytes of them now (blocks the

@@ -31,6 +31,7 @@ object NativeSVM {
   // an epoch of Master.fit as ONE resident plan (core/Master.scala:179-199): idx = the epoch's lists concatenated
   // (batch-major, worker-minor), offsets = nSteps * nWorkers + 1 prefix offsets
   @native def planCreate(ctx: Long, idx: Array[Int], offsets: Array[Long], nWorkers: Int): Long
+  @native def planCreateFromSeed(ctx: Long, state: Array[Long], splitBegin: Array[Long], splitEnd: Array[Long], maxSamples: Long, batchSize: Int): Long
   @native def planRun(ctx: Long, plan: Long, stepBegin: Long, stepEnd: Long, lr: Float): Unit
   @native def planSynchronize(ctx: Long): Long
   @native def planDestroy(ctx: Long, plan: Long): Unit
@@ -157,6 +158,32 @@ class HipSVM(lambda: Number, dimSparsity: Vec, data: Array[(Vec, Int)], nTrain: 
       offsets(i) = at
     })
     NativeSVM.planCreate(ctx, idx, offsets, nWorkers)
+  }
+
+  /** `fitEpoch` with the epoch's sample lists DRAWN BY THE DEVICE -- draw for draw what
+    * `split.map(Random.shuffle(_)).slice(batch, batch + batchSize)` (core/Master.scala:184) would have drawn from `rnd`, which is
+    * left exactly where those shuffles would have left it.  The reference reshuffles every worker's whole split for EVERY
+    * batch: 1.38 G draws per epoch of RCV1 (seconds on the JVM) for 644 K list entries; the device scans the raw stream,
+    * the library walks the rejection candidates, and every list is traced backwards through its Fisher-Yates by one
+    * workgroup (14 ms).  `split(k)` must be the contiguous range SplitStrategy.vanilla hands worker k.  Returns the number
+    * of batches run -- fewer than `0 until maxSamples by batchSize` holds only if a batch would hand some worker an empty
+    * slice (the reference's slave throws there: the caller raises the same error) -- or None when the epoch is outside the
+    * device form (batches beyond 1,024 rows, splits beyond 2^20 rows): the caller then draws the lists itself (`fitEpoch`). */
+  def fitEpochFromSeed(rnd: java.util.Random, split: Seq[Range], maxSamples: Int, batchSize: Int, learningRate: Double): Option[Int] = {
+    if (split.exists(r => r.step != 1 || r.isEmpty)) return None
+    val seedField = classOf[java.util.Random].getDeclaredField("seed")   // (an AtomicLong; 48 bits, already scrambled)
+    seedField.setAccessible(true)
+    val seed  = seedField.get(rnd).asInstanceOf[java.util.concurrent.atomic.AtomicLong]
+    val state = Array(seed.get(), 0L, 0L)
+    val plan =
+      try NativeSVM.planCreateFromSeed(ctx, state, split.map(_.start.toLong).toArray, split.map(r => (r.last + 1).toLong).toArray, maxSamples.toLong, batchSize)
+      catch { case _: UnsupportedOperationException => return None }
+    seed.set(state(0))
+    if (plan != 0L) {
+      try runEpochPlan(plan, state(1).toInt, learningRate)
+      finally NativeSVM.planDestroy(ctx, plan)
+    }
+    Some(state(1).toInt)
   }
 
   def runEpochPlan(plan: Long, nBatches: Int, learningRate: Double): Long = {

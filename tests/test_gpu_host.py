@@ -293,3 +293,27 @@ def test_lyrl2004_text_to_csr_to_one_epoch_on_the_gpu():
         assert set(np.flatnonzero(s.grad)) == set(np.flatnonzero(s_ref.grad))
         assert m.test_accs[0] == ref.test_accs[0]
         assert abs(m.test_losses[0] - ref.test_losses[0]) <= 1e-6
+
+
+def test_master_sync_fit_with_the_lists_drawn_by_the_device(monkeypatch):
+    """host.MasterSync.fit with the epoch's lists drawn by the device (Engine.plan_from_seed: from 8 M draws per epoch on by
+    itself, forced here on a small shape) runs the same steps on the same lists as with the host's generator: the same
+    weights bit for bit, the generator left in the same state -- also when fit stops early and a plan drawn ahead is dropped."""
+    n_rows = 30000
+    data = dsgd_amd.synth.generate(n_rows, seed=21)
+    n_train = int(n_rows * 0.8)
+    out = {}
+    for mode in ("device", "host"):
+        monkeypatch.setenv("DSGD_DEVICE_LISTS", "1" if mode == "device" else "0")
+        monkeypatch.setenv("DSGD_DEVICE_LISTS_MIN_DRAWS", "0")
+        with dsgd_amd.Engine(data.dim, 1e-5) as eng:
+            eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+            eng.build_dim_sparsity(n_train)
+            m = host.MasterSync(eng, n_train, n_rows, node_count=3, rnd=host.JavaRandom(0), plans=True)
+            assert m.device_lists == (mode == "device")
+            seen = []
+            s = m.fit(np.zeros(data.dim + 1), 5, 100, 0.5, lambda losses: len(losses) >= 3 or seen.append(1) is not None and False)
+            assert m.device_lists == (mode == "device")          # (the device form applied: no fall-back happened)
+            out[mode] = (np.array(s.grad, copy=True), m.rnd.seed, m.steps_run, list(m.test_losses))
+    assert out["device"][2] == out["host"][2] > 0 and out["device"][1] == out["host"][1]
+    assert np.array_equal(out["device"][0], out["host"][0]) and out["device"][3] == out["host"][3]

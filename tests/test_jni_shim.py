@@ -186,6 +186,25 @@ def test_shim_end_to_end_on_the_gpu(shim_lib):
     env_bad = Env()
     assert fnb(C.byref(env_bad), None, h, C.byref(fj), C.byref(olj), 3) == 0
     assert env_bad.thrown_class == b"java/lang/IllegalArgumentException", env_bad.thrown_class
+    # ... and an epoch whose lists the DEVICE draws (HipSVM.fitEpochFromSeed): state = {generator state, batches out, draws out}
+    from dsgd_amd import host
+    split = host.split_vanilla(1600, 3)
+    rnd = host.JavaRandom(0)
+    state = np.asarray([rnd.seed, 0, 0], dtype=np.int64)
+    sb = np.asarray([r.start for r in split], dtype=np.int64)
+    se = np.asarray([r.stop for r in split], dtype=np.int64)
+    (sj, _s), (bj, _b), (ej, _e) = jarr(state), jarr(sb), jarr(se)
+    plan_s = call("planCreateFromSeed", C.c_int64, [C.c_int64, vp, vp, vp, C.c_int64, C.c_int32], h, C.byref(sj), C.byref(bj), C.byref(ej), 534, 100)
+    idx_h, offs_h, n_h = host.epoch_lists(rnd, split, 534, 100)
+    assert plan_s != 0 and _s[1] == n_h == 6 and _s[0] == rnd.seed and _s[2] == 6 * (533 + 533 + 531)
+    call("planRun", None, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float], h, plan_s, 0, int(_s[1]), 0.5)
+    call("planSynchronize", C.c_int64, [C.c_int64], h)
+    call("planDestroy", None, [C.c_int64, C.c_int64], h, plan_s)
+    env_bad = Env()
+    fns = getattr(lib, PREFIX + "planCreateFromSeed")
+    fns.restype, fns.argtypes = C.c_int64, [vp, vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_int32]
+    assert fns(C.byref(env_bad), None, h, C.byref(sj), C.byref(bj), C.byref(ej), 534, 5000) == 0      # outside the device form
+    assert env_bad.thrown_class == b"java/lang/UnsupportedOperationException", env_bad.thrown_class
     call("destroy", None, [C.c_int64], h)
     with dsgd_amd.Engine(data.dim, 1e-5) as eng:
         eng.load_csr(data.row_ptr, data.col, data.val, data.label)
