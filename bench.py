@@ -509,7 +509,9 @@ def main():
         if gated:
             out["hogwild"].update(hogwild_parity(dsgd_amd, device))
         out["reference_shapes"] = [reference_shape(dsgd_amd, device, n, with_parity=gated, repeats=max(1, args.repeats))
-                                   for n in (804414, 23149)]   # DatasetTests.scala:18 (full = true), application.conf:24 (full = false)
+                                   for n in (804414, 23149, 100552)]   # DatasetTests.scala:18 (full = true), application.conf:24 (full
+        # = false), and what ONE GPU of eight holds of the former (SplitStrategy.scala:13-14: ceil(804414 / 8) rows; 80,441 of
+        # them train) -- the per-GPU step of an 8-GPU strong-scaled run, to which a 189 KB all-reduce is added there
         if gated:
             out["time_to_target"] = time_to_target(dsgd_amd, device)
         out["dense_logistic"] = dense_logistic(dsgd_amd, device)

@@ -3687,6 +3687,11 @@ int dsgd_plan_create_from_seed(dsgd_ctx* c, uint64_t* jstate, const int64_t* spl
   DSGD_TRY(ensure_build_stream(c));
   hipStream_t bs = c->build_stream;
   const unsigned long long s0 = *jstate & JR_MASK;
+  const bool seed_prof = getenv("DSGD_SEED_PROF") != nullptr;   // (tuning: where an epoch's 14 ms go)
+  const auto tp0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (seed_prof) fprintf(stderr, "[dsgd_plan_create_from_seed] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+  };
   // ---- pass A on the device: the candidates for a rejection; the walk over them here ----
   std::vector<JrShuf> shuf((size_t)n_shuf);
   std::vector<int> rej_list;
@@ -3740,7 +3745,9 @@ int dsgd_plan_create_from_seed(dsgd_ctx* c, uint64_t* jstate, const int64_t* spl
         e = hipMemcpy(ci.data(), d_ci, sizeof(long long) * ci.size(), hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemcpy(cu.data(), d_cu, sizeof(unsigned int) * cu.size(), hipMemcpyDeviceToHost);
       }
+      lap("scan + candidates on the host");
       drop();
+      lap("... scan buffers freed");
       if (e != hipSuccess) {
         (void)hipGetLastError();
         return fail(DSGD_EHIP, "scanning the random stream: %s", hipGetErrorString(e));
@@ -3788,6 +3795,7 @@ int dsgd_plan_create_from_seed(dsgd_ctx* c, uint64_t* jstate, const int64_t* spl
         continue;
       }
       rej_total = rej;
+      lap("candidates walked");
       break;
     }
   }
@@ -3797,6 +3805,7 @@ int dsgd_plan_create_from_seed(dsgd_ctx* c, uint64_t* jstate, const int64_t* spl
   // ---- the plan's frame, then pass B straight into its index buffer ----
   dsgd_plan* p = nullptr;
   DSGD_TRY(plan_frame(c, offsets.data(), n_steps, n_splits, &p));
+  lap("plan frame");
   p->idx_trusted = true;
   p->fits = false;   // (the one-workgroup kernel's test reads the lists on the host; these plans run on column slices)
   JrShuf* d_shuf = nullptr;
@@ -3846,7 +3855,9 @@ int dsgd_plan_create_from_seed(dsgd_ctx* c, uint64_t* jstate, const int64_t* spl
   }
   if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, bs);
   if (e == hipSuccess) e = hipStreamSynchronize(bs);
+  lap("lists drawn (slice kernel)");
   drop2();
+  lap("... slice buffers freed");
   if (e != hipSuccess || h_err) {
     (void)hipGetLastError();
     plan_abandon(c, p);
@@ -3854,6 +3865,7 @@ int dsgd_plan_create_from_seed(dsgd_ctx* c, uint64_t* jstate, const int64_t* spl
     return fail(DSGD_EHIP, "drawing the lists: %s", hipGetErrorString(e));
   }
   DSGD_TRY(plan_finish(c, p, out));
+  lap("plan laid out");
   *n_steps_out = n_steps;
   *jstate = jr_jump_dev(s0, (unsigned long long)(nominal + rej_total));
   if (draws_out) *draws_out = nominal + rej_total;

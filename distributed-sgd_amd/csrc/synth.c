@@ -130,14 +130,18 @@ void dsgd_synth_destroy(synth_t* g) {
   free(g);
 }
 
-synth_t* dsgd_synth_create(uint64_t seed, int32_t dim) {
-  if (dim < 1) return NULL;
+/* the same generator with another column-frequency exponent / mean row length (the dispatcher's thresholds were measured on
+ * Zipf(1.1) rows of ~75 non-zeros: tests/test_gpu_dispatch.py holds the choice to shapes they were NOT tuned on) */
+synth_t* dsgd_synth_create_shaped(uint64_t seed, int32_t dim, double zipf_alpha, double nnz_mean);
+synth_t* dsgd_synth_create(uint64_t seed, int32_t dim) { return dsgd_synth_create_shaped(seed, dim, 1.1, 75.0); }
+synth_t* dsgd_synth_create_shaped(uint64_t seed, int32_t dim, double zipf_alpha, double nnz_mean) {
+  if (dim < 1 || !(zipf_alpha > 0.0) || !(nnz_mean >= 1.0)) return NULL;
   synth_t* g = (synth_t*)calloc(1, sizeof(synth_t));
   g->seed = seed;
   g->dim = dim;
-  g->zipf_alpha = 1.1;
+  g->zipf_alpha = zipf_alpha;
   g->nnz_sigma = 0.8;
-  g->nnz_mu = log(75.0) - 0.5 * 0.8 * 0.8; /* E[lognormal] = 75 before clipping */
+  g->nnz_mu = log(nnz_mean) - 0.5 * 0.8 * 0.8; /* E[lognormal] = nnz_mean (75) before clipping */
   g->label_noise = 0.1;
   g->pos_fraction = 0.47;
   /* fixed random permutation rank -> feature id (Fisher-Yates on a seeded stream) */

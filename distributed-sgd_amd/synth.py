@@ -23,6 +23,8 @@ def _load():
         lib = C.CDLL(SYNTH_LIB)
         lib.dsgd_synth_create.restype = C.c_void_p
         lib.dsgd_synth_create.argtypes = [C.c_uint64, C.c_int32]
+        lib.dsgd_synth_create_shaped.restype = C.c_void_p
+        lib.dsgd_synth_create_shaped.argtypes = [C.c_uint64, C.c_int32, C.c_double, C.c_double]
         lib.dsgd_synth_destroy.argtypes = [C.c_void_p]
         lib.dsgd_synth_row_ptr.restype = C.c_int64
         lib.dsgd_synth_row_ptr.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
@@ -60,10 +62,15 @@ class Csr:
                    self.val[b:e].copy(), self.label[begin:end].copy())
 
 
-def generate(n_rows, seed=0, dim=RCV1_DIM, row0=0):
-    """Rows [row0, row0 + n_rows) of the infinite synthetic stream for (seed, dim)."""
+def generate(n_rows, seed=0, dim=RCV1_DIM, row0=0, zipf=None, nnz_mean=None):
+    """Rows [row0, row0 + n_rows) of the infinite synthetic stream for (seed, dim); zipf / nnz_mean: another column-frequency
+    exponent / mean row length than the RCV1-like 1.1 / 75."""
     lib = _load()
-    g = lib.dsgd_synth_create(C.c_uint64(seed), C.c_int32(dim))
+    if zipf is None and nnz_mean is None:
+        g = lib.dsgd_synth_create(C.c_uint64(seed), C.c_int32(dim))
+    else:
+        g = lib.dsgd_synth_create_shaped(C.c_uint64(seed), C.c_int32(dim), C.c_double(1.1 if zipf is None else zipf),
+                                         C.c_double(75.0 if nnz_mean is None else nnz_mean))
     if not g:
         raise ValueError("bad generator arguments")
     try:
