@@ -357,6 +357,9 @@ struct dsgd_ctx {
   long long tcol_max = 98303;        //   (above: row chunks, dsgd_fstep.hpp.  Measured, whole-split steps, us, row-wise / chunks / columns:
                                      //    4,800 rows 22.7 / 27.4 / 18.1; 18,519: 30.9 / 34.8 / 20.6; 40,000: 36.6 / 42.7 / 31.7; 80,441: 49 / 48 / 42.8;
                                      //    160,000: 73 / 57.5 / 73; 320,000: 117 / 65 / 162 -- profiles/r05_tcol_probe_*.json)
+  long long tcol_max_nnz = 4500000;  // DSGD_TCOL_MAX_NNZ: ... and of at most this many non-zeros where row chunks can take over (round 6: the
+                                     //   crossover is a matter of ENTRIES -- 80 K rows of 150 non-zeros: columns 67.8 us, chunks 51.7; of 40: 33.3 / 37.8;
+                                     //   RCV1-like rows of 75: columns win up to ~60 K rows = 4.5 M entries, profiles/r06_dispatch_table.txt)
   int tcol_share = 0;                // DSGD_TCOL_SHARE: entries per workgroup of the gradient kernel (0: entries / CUs, within [1024, 8192])
   bool fused_apply_pending = false;
   FusedArgs fused_args{};
@@ -2371,8 +2374,9 @@ static int fstep_layout(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int
 }
 
 // workgroups per worker of the chunked launch for these ranges (0: not this path)
-static int fstep_grid(const dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, long long tot) {
-  if (!fstep_possible(c) || tot < c->fstep_min || tot > c->fstep_max) return 0;
+static int fstep_grid(const dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, long long tot, long long ent) {
+  // (from DSGD_FSTEP_MIN rows on -- or from 8,192 rows on when the range holds more entries than the column lists take)
+  if (!fstep_possible(c) || tot > c->fstep_max || (tot < c->fstep_min && !(ent > c->tcol_max_nnz && tot >= 8192))) return 0;
   const int n_workers = (int)row_segs.size();
   if (n_workers > c->n_cu) return 0;
   long long smallest = tot;
@@ -2807,6 +2811,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_TCOL")) c->tcol_enable = atoi(e) != 0;
   if (const char* e = getenv("DSGD_TCOL_MIN")) c->tcol_min = std::max(1LL, atoll(e));
   if (const char* e = getenv("DSGD_TCOL_MAX")) c->tcol_max = std::max(1LL, atoll(e));
+  if (const char* e = getenv("DSGD_TCOL_MAX_NNZ")) c->tcol_max_nnz = std::max(1LL, atoll(e));
   if (const char* e = getenv("DSGD_TCOL_SHARE")) c->tcol_share = std::max(0, atoi(e));
   if (const char* e = getenv("DSGD_REQ_SPIN")) c->req_spin = atoi(e) != 0;
   if (const char* e = getenv("DSGD_CS_NT")) c->cs_nt = atoi(e) == CS_THREADS_NARROW ? CS_THREADS_NARROW : 0;
@@ -3456,12 +3461,18 @@ static int ranges_enqueue(dsgd_ctx* c, const int64_t* row_begin, const int64_t* 
   for (int k = 0; k < n_workers; ++k) ssegs[k] = make_sseg(row_begin[k], row_end[k]);
   // 10^3 .. 10^5 rows: column lists (csrc/dsgd_tcol.hpp) -- dot, column-wise gradient, reduce: no partials
   int trc = 1;
-  if (tcol_wanted(c, tot, n_workers)) {
+  long long ent = tot * 75;   // non-zeros of the ranges (the host's copy of the row offsets; else RCV1's mean row)
+  if (c->h_row_ptr.size() == (size_t)c->n_rows + 1) {
+    ent = 0;
+    for (int k = 0; k < n_workers; ++k) ent += c->h_row_ptr[(size_t)row_end[k]] - c->h_row_ptr[(size_t)row_begin[k]];
+  }
+  const bool chunks_could = fstep_grid(c, ssegs, tot, ent) > 0;
+  if (tcol_wanted(c, tot, n_workers) && !(chunks_could && ent > c->tcol_max_nnz)) {
     DSGD_TRY(upload_segs(c, segs));
     trc = launch_tcol(c, segs, mx);
     if (trc != DSGD_OK && trc != 1) return trc;
   }
-  const int fwg = trc == 1 ? fstep_grid(c, ssegs, tot) : 0;
+  const int fwg = trc == 1 ? fstep_grid(c, ssegs, tot, ent) : 0;
   if (trc == DSGD_OK) {
   } else if (fwg > 0) {
     // shards of 10^4 .. 2 * 10^6 rows: row chunks, the three passes of the split streams in ONE launch (csrc/dsgd_fstep.hpp)

@@ -548,7 +548,9 @@ def test_row_ranges_below_the_streaming_threshold(monkeypatch, n_rows):
         eng.set_weights(w0)
         for ranges in ([(0, n_train)], [(0, n_train // 2), (n_train // 2, n_train)], [(0, n_train)]):
             ranged_step(o, eng, ranges, 0.5 * 100 / n_train * len(ranges))
-            assert eng.grad_kernel_name() == "dsgd_tc_grad_kernel"
+            # (round 6: column lists up to 4.5 M non-zeros in the ranges of a step -- 80,000 rows hold 6 M and take the row
+            #  chunks; tests/test_gpu_dispatch.py holds the choice to the measured best)
+            assert eng.grad_kernel_name() == ("dsgd_fstep_kernel" if n_rows == 100000 else "dsgd_tc_grad_kernel")
         loss, acc, counts = eng.loss_acc(n_train, n_rows)
         l_ref, a_ref, c_ref, mam = o.loss_acc(eng.get_weights().astype(np.float64), n_train, n_rows)
         assert abs(loss - l_ref) <= 1e-6 and (counts == c_ref or mam < GATE_EPS)

@@ -21,7 +21,7 @@ from test_gpu_parity import GATE_EPS, make_pair, ragged_data, ranged_step
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="no gfx950 device")]
 
 TCOL = "dsgd_tc_grad_kernel"
-KNOBS = ("DSGD_TCOL", "DSGD_TCOL_MIN", "DSGD_TCOL_MAX", "DSGD_TCOL_SHARE", "DSGD_FSTEP", "DSGD_FSTEP_MIN", "DSGD_FSTEP_MAX",
+KNOBS = ("DSGD_TCOL", "DSGD_TCOL_MIN", "DSGD_TCOL_MAX", "DSGD_TCOL_MAX_NNZ", "DSGD_TCOL_SHARE", "DSGD_FSTEP", "DSGD_FSTEP_MIN", "DSGD_FSTEP_MAX",
          "DSGD_FSTEP_ROWS", "DSGD_STREAM_MIN", "DSGD_FIX_SHIFT")
 
 
@@ -32,9 +32,12 @@ def clean(monkeypatch):
 
 @pytest.mark.parametrize("n_rows", [23149, 100552])
 def test_column_lists_match_oracle(monkeypatch, n_rows):
-    """N = 23,149 and 80,441 train rows (one GPU of eight's share of RCV1) -- the product's choice for both: whole-split steps from non-zero weights, one / two / three workers (SplitStrategy.vanilla's contiguous
+    """N = 23,149 (the product's choice) and 80,441 train rows (one GPU of eight's share of RCV1: until round 6 the product's
+    choice too -- now row chunks from 4.5 M non-zeros on, tests/test_gpu_dispatch.py; the column lists are asked for by
+    DSGD_TCOL_MAX_NNZ): whole-split steps from non-zero weights, one / two / three workers (SplitStrategy.vanilla's contiguous
     ranges, and uneven ones), under the derived bound; tallies of the test rows exact; the same step twice = the same bits."""
     clean(monkeypatch)
+    monkeypatch.setenv("DSGD_TCOL_MAX_NNZ", "1000000000")
     data = dsgd_amd.synth.generate(n_rows, seed=53)
     n_train = int(n_rows * 0.8)
     o, eng = make_pair(data, 1e-5, n_train)

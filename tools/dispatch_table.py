@@ -21,7 +21,7 @@ import dsgd_amd  # noqa: E402
 
 FAMILIES = {
     "default": {},
-    "column_lists": {"DSGD_TCOL_MIN": "1", "DSGD_TCOL_MAX": "100000000", "DSGD_FSTEP": "0"},
+    "column_lists": {"DSGD_TCOL_MIN": "1", "DSGD_TCOL_MAX": "100000000", "DSGD_TCOL_MAX_NNZ": "100000000000", "DSGD_FSTEP": "0"},
     "row_chunks": {"DSGD_TCOL": "0", "DSGD_FSTEP_MIN": "1"},
     "three_launches": {"DSGD_TCOL": "0", "DSGD_FSTEP": "0", "DSGD_STREAM_MIN": "1"},
     "row_wise": {"DSGD_TCOL": "0", "DSGD_FSTEP": "0", "DSGD_STREAM_MIN": "1000000000"},
