@@ -265,10 +265,19 @@ __global__ void __launch_bounds__(JR_SLICE_THREADS) dsgd_jr_slice_kernel(JrSlice
     long long raw_mine = 0;
     unsigned long long s_mine = 0;
     bool have = false;
+    // Rejection i happened while draw T_i = rej[i] - i was being served (T ascending): draw m is served by raw value
+    // m + #{T_i <= m}.  The blocks walk the draws DOWNWARDS, so the count for the block's highest draw only ever falls
+    // (a uniform pointer), and a lane differs from it only if a rejection lies INSIDE the block (10 per 214 K draws).
+    int cnt_hi = n_rej;
     for (long long n0 = n_first; n0 <= len; n0 += JR_SLICE_THREADS, n_mine += JR_SLICE_THREADS) {
       int kk = -1;
+      const long long m_hi = len - n0;
+      while (cnt_hi > 0 && (long long)(rej[cnt_hi - 1] - (cnt_hi - 1)) > m_hi) --cnt_hi;   // (uniform)
       if (n_mine <= len) {
-        const long long raw = jr_raw_of_draw(len - n_mine, rej, n_rej);
+        const long long m = len - n_mine;
+        int cnt = cnt_hi;
+        while (cnt > 0 && (long long)(rej[cnt - 1] - (cnt - 1)) > m) --cnt;                // (rarely one iteration)
+        const long long raw = m + cnt;
         if (!have) {   // (first block of this lane -- or a lane that was beyond the end never comes back)
           s_mine = jr_jump_dev(s_first, (unsigned long long)(raw + 1));
           have = true;

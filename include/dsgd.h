@@ -55,6 +55,16 @@ enum {
 
 typedef struct dsgd_ctx dsgd_ctx;
 
+/* MODEL WIDTH.  Any D >= 1 gives the same results; what a wide model costs (measured, whole-split steps of 800,000
+ * RCV1-like rows of 75 non-zeros, profiles/r06_dispatch_table.txt): the matrix is split by column frequency into the
+ * 18,396 hottest columns (weights and gradient of a workgroup in LDS, 16-bit ranks in the stream) and the rest, whose
+ * weights / gradient must fit ONE LDS tile of 36,796 words for the one-launch row chunks (csrc/dsgd_fstep.hpp):
+ *   D <= 55,191   (RCV1: 47,236)  row chunks: 97 us per step at D = 47,236, 108 us at D = 20,000
+ *   D <= 83,931                   the three streaming launches, cold columns beyond the tile gathered from L2 and added
+ *                                 through 64-bit global atomics: 155 us at D = 70,000 (+ 50 %)
+ *   D  > 83,931                   more than 65,536 cold columns: 32-bit cold column words (8 instead of 6 bytes per cold
+ *                                 non-zero, 7.5 % of RCV1-like non-zeros), otherwise as the line above
+ * dsgd_grad_kernel_name() says which family ran; tests/test_gpu_dispatch.py holds the choice to the best family.    */
 typedef struct {
   int32_t n_features; /* D; 47236 for RCV1 (utils/Dataset.scala:16)                              */
   int32_t device;     /* HIP device ordinal                                                      */
