@@ -1818,7 +1818,7 @@ __device__ __forceinline__ void cd_tile(const CRegs<COL16>& cur, float* strip, f
 
 // cold gradient columns: q = round(value * coef[row] * scale) accumulated in the LDS tile of 32-bit integers at the
 // cold scale (shift 21) with returning atomics: whoever SEES |old| >= 2^28 moves the word into the 64-bit global
-// accumulator, |old| >= 2^30 raises DevScalars::err.  ref: core/Slave.scala:147-153 restricted to the
+// accumulator, |old| >= 2^30 raises DevScalars::err (profiles/DESIGN_notes_r01-r05.md 3.5).  ref: core/Slave.scala:147-153 restricted to the
 // cold columns.
 template <bool COL16, bool WIDE>
 __device__ __forceinline__ void cg_tile(const CRegs<COL16>& cur, float* strip, int* gc, long long* __restrict__ g64cold,
