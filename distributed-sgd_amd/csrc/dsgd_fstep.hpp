@@ -50,7 +50,8 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
                                                          float cold_scale, signed char* coef8, float* dcold,
                                                          const int* __restrict__ long_rows, int* __restrict__ part,
                                                          int part_stride, int* __restrict__ partc, int partc_stride,
-                                                         unsigned long long* __restrict__ tprof) {
+                                                         unsigned long long* __restrict__ tprof,
+                                                         unsigned long long* __restrict__ wg_time) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,6 +61,9 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
   }
   const FChunk ch = chunks[blockIdx.y * gridDim.x + blockIdx.x];
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  // how long this workgroup takes (device-wide 100 MHz clock), summed over launches: the host cuts the chunks again by it
+  // (dsgd_hip.hip: fstep_rebalance -- a CU's speed differs by a few per cent by where it sits, stably over a run)
+  const unsigned long long wg_t0 = (wg_time != nullptr && tid == 0) ? wall_clock64() : 0ull;
   constexpr int stride = 16;   // the waves of THIS workgroup share the chunk's tiles
   // tuning runs (DSGD_PLAN_PROF=1): shader-clock cycles of thread 0 by phase, summed over the workgroups
   //   [0] A set-up  [1] A tiles  [2] B set-up  [3] B tiles + long rows  [4] B partial out  [5] C set-up  [6] C tiles
@@ -312,6 +316,7 @@ __global__ void __launch_bounds__(1024) dsgd_fstep_kernel(CsrView m, CsrView mfu
     }
     __syncthreads();
     DSGD_FPROF(6)
+    if (wg_time != nullptr && tid == 0) wg_time[wg] += wall_clock64() - wg_t0;   // (this workgroup is the word's only writer)
     int* minec = partc + (long long)wg * partc_stride;
     wg_copy_out(minec, reinterpret_cast<int*>(lds), nc_lds, tid, 1024, is_aligned16(minec));
     if (tprof) {

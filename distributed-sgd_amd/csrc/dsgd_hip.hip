@@ -322,10 +322,22 @@ struct dsgd_ctx {
     long long worst_rows = 1;        // rows of the largest chunk
     int shift = -1;                  // the measured fixed-point shift of the hot accumulators (-1: not measured yet)
     unsigned long long used = 0;
+    // measured balance (round 6): the workgroups' own durations, summed by the kernel over `launches` launches, re-cut the
+    // chunks once or twice per configuration (a chunk's share of the weight follows its workgroup's measured rate)
+    unsigned long long* d_times = nullptr;
+    unsigned long long* h_times = nullptr;   // pinned
+    hipEvent_t times_ev = nullptr;
+    std::vector<double> share;       // per chunk: its share of its worker's weight (empty: equal shares)
+    int launches = 0, rebalances = 0;
+    bool times_pending = false;
   };
   std::vector<FstepLayout> fstep_cache;
   unsigned long long fstep_clock = 0;
   bool fstep_enable = true;          // DSGD_FSTEP=0: row ranges through the three streaming launches / the row-wise kernel
+  bool fstep_rebalance = false;      // DSGD_FSTEP_REBALANCE=1: the chunks re-cut by their workgroups' measured durations (measured: 98.4 ->
+                                     //   97.5 us at N = 804,414, nothing at 2 M / 6.7 M rows, and two layout rebuilds per configuration --
+                                     //   which workgroup is slow is not a stable property of its chunk: OFF, profiles/r06_fstep_wg_times.txt)
+  int last_fstep_rebalances = 0;     // ... how often the configuration of the last chunked launch has been re-cut (dsgd_tuning_info)
   long long fstep_min = 65536;       // DSGD_FSTEP_MIN / DSGD_FSTEP_MAX: row ranges of this many rows in total take the chunked launch
   long long fstep_max = 1LL << 31;   //   (measured, whole-split steps, us: 80 K rows 56 -> 50-54, 643 K 118 -> 105, 1.6 M 213 -> 199,
                                      //    3.2 M 374 -> 343, 6.7 M 699 -> 663; at 18.5 K rows the row-wise kernel stays ahead: 37 vs 35-41)
@@ -2230,6 +2242,9 @@ static int launch_stream(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs) {
 
 // ---- row chunks: the whole gradient of a row range in one launch (csrc/dsgd_fstep.hpp) -------------------------------
 static void fstep_free(dsgd_ctx::FstepLayout& L) {
+  (void)hipFree(L.d_times);
+  if (L.h_times) (void)hipHostFree(L.h_times);
+  if (L.times_ev) (void)hipEventDestroy(L.times_ev);
   (void)hipFree(L.d_tiles);
   (void)hipFree(L.d_meta);
   (void)hipFree(L.d_ctiles);
@@ -2250,6 +2265,7 @@ static bool fstep_possible(const dsgd_ctx* c) {
   const int nc_lds = std::min(nc, DSGD_LDS_FLOATS - 16 * CT_STRIP - 64 - 4);
   return c->fstep_enable && nc > 0 && nc <= nc_lds && c->cold_col16 && c->coldm_nnz > 0 && c->n_rows < (1LL << 31);
 }
+static int fstep_build(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int n_wg, dsgd_ctx::FstepLayout& L);
 static int fstep_layout(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int n_wg, dsgd_ctx::FstepLayout** out) {
   const int n_workers = (int)row_segs.size();
   std::vector<long long> key;
@@ -2271,6 +2287,18 @@ static int fstep_layout(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int
     fstep_free(c->fstep_cache[v]);
     c->fstep_cache.erase(c->fstep_cache.begin() + (long)v);
   }
+  dsgd_ctx::FstepLayout L;
+  L.ranges = key;
+  L.n_wg = n_wg;
+  DSGD_TRY(fstep_build(c, row_segs, n_wg, L));
+  L.used = ++c->fstep_clock;
+  c->fstep_cache.push_back(L);
+  *out = &c->fstep_cache.back();
+  return DSGD_OK;
+}
+// the tile tables and chunk records of a configuration (L.share: the chunks' shares of their worker's weight, or empty)
+static int fstep_build(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int n_wg, dsgd_ctx::FstepLayout& L) {
+  const int n_workers = (int)row_segs.size();
   const std::vector<long long>&hrp = c->h_hrp, &ctp = c->h_ctp;
   std::vector<WTile> wt, ct;
   std::vector<FChunk> chunks((size_t)n_workers * (size_t)n_wg);
@@ -2287,10 +2315,14 @@ static int fstep_layout(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int
     };
     const long long w0 = W(rb), wtot = W(re) - w0;
     long long cut = rb;
+    double share_total = 0.0, share_run = 0.0;
+    const bool shares = L.share.size() == (size_t)n_workers * (size_t)n_wg;
+    for (int b = 0; b < n_wg; ++b) share_total += shares ? L.share[(size_t)k * (size_t)n_wg + (size_t)b] : 1.0;
     for (int b = 0; b < n_wg; ++b) {
       long long nxt = re;
+      share_run += shares ? L.share[(size_t)k * (size_t)n_wg + (size_t)b] : 1.0;
       if (b + 1 < n_wg) {
-        const long long target = w0 + (long long)((double)wtot * (double)(b + 1) / (double)n_wg);
+        const long long target = w0 + (long long)((double)wtot * share_run / share_total);
         long long lo = cut, hi = re;   // first row i in [cut, re] with W(i) >= target
         while (lo < hi) {
           const long long mid = (lo + hi) >> 1;
@@ -2349,10 +2381,18 @@ static int fstep_layout(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int
   pad.info = 0xffff;
   if (wt.empty()) wt.push_back(pad);
   if (ct.empty()) ct.push_back(pad);
-  dsgd_ctx::FstepLayout L;
-  L.ranges = key;
-  L.n_wg = n_wg;
   L.worst_rows = worst;
+  L.shift = -1;
+  (void)hipFree(L.d_tiles);
+  (void)hipFree(L.d_meta);
+  (void)hipFree(L.d_ctiles);
+  (void)hipFree(L.d_cmeta);
+  (void)hipFree(L.d_chunks);
+  L.d_tiles = nullptr;
+  L.d_meta = nullptr;
+  L.d_ctiles = nullptr;
+  L.d_cmeta = nullptr;
+  L.d_chunks = nullptr;
   hipError_t e = hipMalloc(&L.d_tiles, sizeof(WTile) * wt.size());
   if (e == hipSuccess) e = hipMalloc(&L.d_meta, sizeof(unsigned short) * meta.size());
   if (e == hipSuccess) e = hipMalloc(&L.d_ctiles, sizeof(WTile) * ct.size());
@@ -2363,14 +2403,63 @@ static int fstep_layout(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int
   if (e == hipSuccess) e = hipMemcpy(L.d_ctiles, ct.data(), sizeof(WTile) * ct.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(L.d_cmeta, cmeta.data(), sizeof(unsigned short) * cmeta.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(L.d_chunks, chunks.data(), sizeof(FChunk) * chunks.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !L.d_times) {
+    e = hipMalloc(&L.d_times, sizeof(unsigned long long) * chunks.size());
+    if (e == hipSuccess) e = hipHostMalloc(&L.h_times, sizeof(unsigned long long) * chunks.size(), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&L.times_ev, hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipMemset(L.d_times, 0, sizeof(unsigned long long) * chunks.size());
+  L.launches = 0;
+  L.times_pending = false;
   if (e != hipSuccess) {
     fstep_free(L);
     return fail(DSGD_EHIP, "row-chunk layout: %s", hipGetErrorString(e));
   }
-  L.used = ++c->fstep_clock;
-  c->fstep_cache.push_back(L);
-  *out = &c->fstep_cache.back();
   return DSGD_OK;
+}
+// Measured balance (opt-in, DSGD_FSTEP_REBALANCE=1): after FSTEP_CAL launches of a configuration the workgroups' summed durations come back (asynchronously);
+// a later launch that finds them cuts the chunks again -- chunk b's share of the weight times (mean time / its time),
+// within 15 % -- twice at most.  The slowest workgroup ends the launch: at N = 804,414 it ran 8 us behind the average of 75,
+// the same workgroups every time (profiles/r06_fstep_wg_times.txt).  Integer sums: the re-cut changes no bit.
+constexpr int FSTEP_CAL = 24;
+static int fstep_maybe_rebalance(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, dsgd_ctx::FstepLayout* L) {
+  if (!c->fstep_rebalance || L->rebalances >= 2 || !L->d_times || c->d_tprof) return DSGD_OK;
+  const size_t n = (size_t)L->n_wg * row_segs.size();
+  if (!L->times_pending) {
+    if (L->launches >= FSTEP_CAL) {
+      HIP_TRY(hipMemcpyAsync(L->h_times, L->d_times, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipEventRecord(L->times_ev, c->stream));
+      L->times_pending = true;
+    }
+    return DSGD_OK;
+  }
+  if (hipEventQuery(L->times_ev) != hipSuccess) {
+    (void)hipGetLastError();
+    return DSGD_OK;
+  }
+  // (the copy covered exactly the launches enqueued in front of it; launches since then run on the old cut and are dropped)
+  std::vector<double> share(n, 1.0);
+  const bool had = L->share.size() == n;
+  bool usable = true;
+  for (size_t k = 0; k < row_segs.size() && usable; ++k) {
+    double mean = 0.0;
+    for (int b = 0; b < L->n_wg; ++b) mean += (double)L->h_times[k * (size_t)L->n_wg + (size_t)b];
+    mean /= (double)L->n_wg;
+    if (!(mean > 0.0)) usable = false;
+    for (int b = 0; b < L->n_wg && usable; ++b) {
+      const size_t i = k * (size_t)L->n_wg + (size_t)b;
+      const double t = (double)L->h_times[i];
+      double f = t > 0.0 ? mean / t : 1.0;
+      f = std::min(1.15, std::max(0.85, f));
+      share[i] = (had ? L->share[i] : 1.0) * f;
+    }
+  }
+  L->times_pending = false;
+  ++L->rebalances;
+  if (!usable) return DSGD_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));   // (the tables in use go away)
+  L->share = share;
+  return fstep_build(c, row_segs, L->n_wg, *L);
 }
 
 // workgroups per worker of the chunked launch for these ranges (0: not this path)
@@ -2389,6 +2478,9 @@ static int launch_fstep(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int
   const int n_workers = (int)row_segs.size();
   dsgd_ctx::FstepLayout* L = nullptr;
   DSGD_TRY(fstep_layout(c, row_segs, n_wg, &L));
+  DSGD_TRY(fstep_maybe_rebalance(c, row_segs, L));
+  ++L->launches;
+  c->last_fstep_rebalances = L->rebalances;
   const int H = std::min(c->hsplit, c->dp);
   const int nc = c->dp - H;   // (fstep_possible: all of them inside the LDS tile)
   dim3 grid((unsigned)n_wg, (unsigned)n_workers);
@@ -2434,7 +2526,7 @@ static int launch_fstep(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int
   hipLaunchKernelGGL(dsgd_fstep_kernel, grid, dim3(1024), lds, c->stream, mh, view(c), L->d_tiles, L->d_meta, L->d_ctiles, L->d_cmeta,
                      (const void*)c->d_ccol, c->d_cval, L->d_chunks, c->d_w, c->d_g64, (long long)c->dp, c->d_sc, H, nc, main_scale,
                      c->fix_scale, c->d_coef8, c->d_dcold, c->d_wlong_rows, c->d_part, c->part_stride, c->d_partc, c->partc_stride,
-                     c->d_tprof);
+                     c->d_tprof, (c->fstep_rebalance && L->rebalances < 2) ? L->d_times : nullptr);
   HIP_TRY(hipGetLastError());
   DSGD_TRY(prof_end(c, slot));
   c->last_grad_kernel = "dsgd_fstep_kernel";
@@ -2808,6 +2900,7 @@ int dsgd_create(const dsgd_config* cfg, dsgd_ctx** out) {
   if (const char* e = getenv("DSGD_FSTEP_MIN")) c->fstep_min = std::max(1LL, atoll(e));
   if (const char* e = getenv("DSGD_FSTEP_MAX")) c->fstep_max = std::max(1LL, atoll(e));
   if (const char* e = getenv("DSGD_FSTEP_ROWS")) c->fstep_rows = std::max(1LL, atoll(e));
+  if (const char* e = getenv("DSGD_FSTEP_REBALANCE")) c->fstep_rebalance = atoi(e) != 0;
   if (const char* e = getenv("DSGD_TCOL")) c->tcol_enable = atoi(e) != 0;
   if (const char* e = getenv("DSGD_TCOL_MIN")) c->tcol_min = std::max(1LL, atoll(e));
   if (const char* e = getenv("DSGD_TCOL_MAX")) c->tcol_max = std::max(1LL, atoll(e));
@@ -5026,10 +5119,10 @@ int dsgd_debug_cycles(dsgd_ctx* c, uint64_t* out8, int32_t reset) {
 
 int dsgd_tuning_info(dsgd_ctx* c, int32_t* vals, int32_t n) {
   DSGD_TRY(check_ctx(c));
-  if (!vals || n < 0 || n > 6) return fail(DSGD_EINVAL, "bad tuning_info arguments");
+  if (!vals || n < 0 || n > 7) return fail(DSGD_EINVAL, "bad tuning_info arguments");
   std::lock_guard<std::mutex> lk(c->mu);
-  const int32_t all[6] = {4 /* split layout: the only one */, std::min(c->hsplit, c->dp), c->last_shift,
-                          c->cold_col16 ? 1 : 0, c->plan_kernel ? 1 : 0, c->fix_bound ? 1 : 0};
+  const int32_t all[7] = {4 /* split layout: the only one */, std::min(c->hsplit, c->dp), c->last_shift,
+                          c->cold_col16 ? 1 : 0, c->plan_kernel ? 1 : 0, c->fix_bound ? 1 : 0, c->last_fstep_rebalances};
   for (int i = 0; i < n; ++i) vals[i] = all[i];
   return DSGD_OK;
 }

@@ -344,9 +344,9 @@ class Engine:
         return a.value, b.value
 
     def tuning_info(self):
-        v = (C.c_int32 * 6)()
-        check(self._lib.dsgd_tuning_info(self._ctx, v, C.c_int32(6)))
-        return dict(zip(("stream_mode", "hsplit", "fix_shift", "cold_packed", "plan_kernel", "fix_bound"), [int(x) for x in v]))
+        v = (C.c_int32 * 7)()
+        check(self._lib.dsgd_tuning_info(self._ctx, v, C.c_int32(7)))
+        return dict(zip(("stream_mode", "hsplit", "fix_shift", "cold_packed", "plan_kernel", "fix_bound", "fstep_rebalances"), [int(x) for x in v]))
 
     def column_ranks(self):
         """Internal frequency rank of every key (D + 1 entries); identical on all ranks of a communicator."""

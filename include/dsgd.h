@@ -339,8 +339,10 @@ int dsgd_range_nnz(dsgd_ctx* ctx, int64_t row_begin, int64_t row_end, int64_t* n
  * vals[0] = layout generation (4 = matrix split by column rank, the only one), [1] = hot/cold split rank, [2] =
  * fixed-point shift of the last gradient launch (whole ranges and index lists alike; not the one-workgroup plan
  * kernel, which derives 30 - ceil(log2 batch) per batch), [3] = 1 if the cold stream is packed, [4] = 1 if small
- * batches run in the persistent plan kernel, [5] = 1 if the data-dependent fixed-point bound is enabled.
- * n = number of slots the caller provides (<= 6).                                                                 */
+ * batches run in the persistent plan kernel, [5] = 1 if the data-dependent fixed-point bound is enabled, [6] = how often
+ * the row chunks of the last chunked launch's configuration have been re-cut by their workgroups' measured durations (0-2;
+ * only with DSGD_FSTEP_REBALANCE=1: measured at 1 %, off by default -- the re-cut moves rows between workgroups, it changes no bit of any sum).
+ * n = number of slots the caller provides (<= 7).                                                                 */
 int dsgd_tuning_info(dsgd_ctx* ctx, int32_t* vals, int32_t n);
 
 /* Layout introspection (tests of the multi-GPU path): the internal frequency rank of every key, D + 1 entries.  With a

@@ -177,3 +177,34 @@ def test_more_configurations_than_the_cache_holds(monkeypatch):
             eng.set_weights(w0)
             eng.sync_step_ranges(rg, 1e-3)
             np.testing.assert_array_equal(eng.get_weights(), w1)
+
+
+def test_chunks_recut_by_measured_time_change_no_bit(monkeypatch):
+    """Round 6: after 24 launches of a configuration the workgroups' own durations re-cut its chunks (twice at most;
+    dsgd_tuning_info slot 6).  Rows move between workgroups -- integer partial sums do not care: a step from the same
+    weights gives the same bits before the first re-cut, after it, and with the re-cut switched off."""
+    monkeypatch.setenv("DSGD_TCOL", "0")
+    monkeypatch.setenv("DSGD_FSTEP_MIN", "8192")
+    data = dsgd_amd.synth.generate(150000, seed=15)
+    n_train = 120000
+    w0 = some_weights(data.dim, 15)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DSGD_FSTEP_REBALANCE", mode)
+        with dsgd_amd.Engine(data.dim, 1e-5) as eng:
+            eng.load_csr(data.row_ptr, data.col, data.val, data.label)
+            eng.build_dim_sparsity(n_train)
+            seen = []
+            for rep in range(5):
+                eng.set_weights(w0)
+                eng.sync_step_ranges([(0, n_train)], 1e-3)
+                assert eng.grad_kernel_name() == FSTEP
+                seen.append((eng.tuning_info()["fstep_rebalances"], eng.get_weights()))
+                for _ in range(30):
+                    eng.sync_step_ranges([(0, n_train)], 1e-6, asynchronous=True)
+                eng.synchronize()
+            outs[mode] = seen
+    assert [r for r, _ in outs["0"]] == [0] * 5
+    assert outs["1"][0][0] == 0 and outs["1"][-1][0] >= 1, [r for r, _ in outs["1"]]
+    for _, w in outs["1"] + outs["0"]:
+        assert np.array_equal(w, outs["1"][0][1])

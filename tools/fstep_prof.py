@@ -19,6 +19,7 @@ import dsgd_amd  # noqa: E402
 sizes = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "804414").split(",")]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+warmup = int(sys.argv[4]) if len(sys.argv) > 4 else 20   # (100+: behind the measured re-cuts of the row chunks, 24 launches each)
 NAMES = ("A_setup", "A_tiles", "B_setup", "B_tiles", "B_out", "C_setup", "C_tiles", "C_out")
 out = []
 for rows in sizes:
@@ -30,8 +31,10 @@ for rows in sizes:
         eng.load_csr(data.row_ptr, data.col, data.val, data.label)
         eng.build_dim_sparsity(n_train)
         lr = 0.5 * 100 / n_train * k
-        for _ in range(20):
+        for _ in range(warmup):
             eng.sync_step_ranges(ranges, lr, asynchronous=True)
+            if _ % 10 == 9:
+                eng.synchronize()
         eng.synchronize()
         eng.debug_cycles(reset=True)
         t0 = time.perf_counter()
@@ -41,7 +44,8 @@ for rows in sizes:
         dt = (time.perf_counter() - t0) / steps
         cyc = eng.debug_cycles(reset=True)
         row = {"rows": rows, "train_rows": n_train, "workers": k, "us_per_step": 1e6 * dt, "kernel": eng.grad_kernel_name(),
-               "algorithmic_MB": (8.0 * int(data.row_ptr[n_train]) + 12.0 * n_train) / 1e6}
+               "algorithmic_MB": (8.0 * int(data.row_ptr[n_train]) + 12.0 * n_train) / 1e6,
+               "chunks_recut": eng.tuning_info().get("fstep_rebalances")}
         if cyc[15]:
             n = float(cyc[15])
             row["workgroups_per_launch"] = n / steps
