@@ -249,6 +249,10 @@ struct dsgd_ctx {
   unsigned long long cache_tick = 0;
   size_t cache_cap = (size_t)8 << 30;   // DSGD_CACHE_MB (dsgd_cache_trim gives blocks back on request)
   std::vector<hipEvent_t> ev_pool;      // events of blocks in use, for the next ones
+  // scratch of dsgd_plan_create_from_seed, kept across epochs (grow-only): a hipFree per epoch would wait for the whole
+  // device -- i.e. for the epoch that is running on the launch stream while the next one's lists are drawn
+  void* seed_scratch[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t seed_scratch_bytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   // the one-step layout of per-request steps (dsgd_cs_request_kernel), strides at their maxima, per slice count
   struct ReqLayout {
     CsHdr* hdr = nullptr;
@@ -3049,6 +3053,7 @@ int dsgd_destroy(dsgd_ctx* c) {
     (void)hipStreamDestroy(c->build_stream);
   }
   cache_drop_all(c);
+  for (int i = 0; i < 9; ++i) (void)hipFree(c->seed_scratch[i]);
   (void)hipFree(c->req_layout.hdr);
   (void)hipFree(c->req_layout.meta);
   (void)hipFree(c->req_layout.rf);
@@ -3749,6 +3754,20 @@ int dsgd_plan_create(dsgd_ctx* c, const int32_t* idx, const int64_t* offsets, in
   return plan_finish(c, p, out);
 }
 
+// slot `i` of the from-seed scratch with room for `bytes`
+static hipError_t seed_scratch(dsgd_ctx* c, int i, size_t bytes, void** out) {
+  if (c->seed_scratch_bytes[i] < bytes) {
+    (void)hipFree(c->seed_scratch[i]);
+    c->seed_scratch[i] = nullptr;
+    c->seed_scratch_bytes[i] = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    const hipError_t e = hipMalloc(&c->seed_scratch[i], want);
+    if (e != hipSuccess) return e;
+    c->seed_scratch_bytes[i] = want;
+  }
+  *out = c->seed_scratch[i];
+  return hipSuccess;
+}
 // ---- an epoch's lists drawn on the device, draw for draw the reference's stream (csrc/dsgd_shuffle.hpp) ---------------------
 int dsgd_plan_create_from_seed(dsgd_ctx* c, uint64_t* jstate, const int64_t* split_begin, const int64_t* split_end, int32_t n_splits,
                                int64_t max_samples, int32_t batch_size, dsgd_plan** out, int64_t* n_steps_out, int64_t* draws_out) {
@@ -3811,16 +3830,11 @@ int dsgd_plan_create_from_seed(dsgd_ctx* c, uint64_t* jstate, const int64_t* spl
       long long* d_ci = nullptr;
       unsigned int* d_cu = nullptr;
       unsigned long long *d_base = nullptr, *d_tot = nullptr;
-      auto drop = [&]() {
-        (void)hipFree(d_ci);
-        (void)hipFree(d_cu);
-        (void)hipFree(d_base);
-        (void)hipFree(d_tot);
-      };
-      hipError_t e = n_wg > 0x7fffffffLL ? hipErrorInvalidValue : hipMalloc(&d_ci, sizeof(long long) * (size_t)cap);
-      if (e == hipSuccess) e = hipMalloc(&d_cu, sizeof(unsigned int) * (size_t)cap);
-      if (e == hipSuccess) e = hipMalloc(&d_base, sizeof(unsigned long long) * (size_t)n_wg);
-      if (e == hipSuccess) e = hipMalloc(&d_tot, sizeof(unsigned long long) * 2);
+      auto drop = [&]() {};   // (the buffers are the context's scratch: kept)
+      hipError_t e = n_wg > 0x7fffffffLL ? hipErrorInvalidValue : seed_scratch(c, 0, sizeof(long long) * (size_t)cap, (void**)&d_ci);
+      if (e == hipSuccess) e = seed_scratch(c, 1, sizeof(unsigned int) * (size_t)cap, (void**)&d_cu);
+      if (e == hipSuccess) e = seed_scratch(c, 2, sizeof(unsigned long long) * (size_t)n_wg, (void**)&d_base);
+      if (e == hipSuccess) e = seed_scratch(c, 3, sizeof(unsigned long long) * 2, (void**)&d_tot);
       if (e == hipSuccess) e = hipMemsetAsync(d_tot, 0, sizeof(unsigned long long) * 2, bs);
       std::vector<unsigned long long> base((size_t)n_wg);
       unsigned long long tot[2] = {0, 0};
@@ -3846,8 +3860,9 @@ int dsgd_plan_create_from_seed(dsgd_ctx* c, uint64_t* jstate, const int64_t* spl
       if (e == hipSuccess && tot[1] == 0 && tot[0] > 0) {
         ci.resize((size_t)tot[0]);
         cu.resize((size_t)tot[0]);
-        e = hipMemcpy(ci.data(), d_ci, sizeof(long long) * ci.size(), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(cu.data(), d_cu, sizeof(unsigned int) * cu.size(), hipMemcpyDeviceToHost);
+        e = hipMemcpyAsync(ci.data(), d_ci, sizeof(long long) * ci.size(), hipMemcpyDeviceToHost, bs);
+        if (e == hipSuccess) e = hipMemcpyAsync(cu.data(), d_cu, sizeof(unsigned int) * cu.size(), hipMemcpyDeviceToHost, bs);
+        if (e == hipSuccess) e = hipStreamSynchronize(bs);
       }
       lap("scan + candidates on the host");
       drop();
@@ -3915,24 +3930,18 @@ int dsgd_plan_create_from_seed(dsgd_ctx* c, uint64_t* jstate, const int64_t* spl
   JrShuf* d_shuf = nullptr;
   int *d_rej = nullptr, *d_err = nullptr;
   long long *d_sb = nullptr, *d_off = nullptr;
-  auto drop2 = [&]() {
-    (void)hipFree(d_shuf);
-    (void)hipFree(d_rej);
-    (void)hipFree(d_err);
-    (void)hipFree(d_sb);
-    (void)hipFree(d_off);
-  };
+  auto drop2 = [&]() {};   // (scratch of the context)
   std::vector<long long> sb2(2 * (size_t)n_splits);
   for (int k = 0; k < n_splits; ++k) {
     sb2[(size_t)k] = split_begin[k];
     sb2[(size_t)n_splits + (size_t)k] = split_end[k];
   }
   int h_err = 0;
-  hipError_t e = hipMalloc(&d_shuf, sizeof(JrShuf) * (size_t)n_shuf);
-  if (e == hipSuccess) e = hipMalloc(&d_rej, sizeof(int) * std::max<size_t>(1, rej_list.size()));
-  if (e == hipSuccess) e = hipMalloc(&d_err, sizeof(int));
-  if (e == hipSuccess) e = hipMalloc(&d_sb, sizeof(long long) * sb2.size());
-  if (e == hipSuccess) e = hipMalloc(&d_off, sizeof(long long) * offsets.size());
+  hipError_t e = seed_scratch(c, 4, sizeof(JrShuf) * (size_t)n_shuf, (void**)&d_shuf);
+  if (e == hipSuccess) e = seed_scratch(c, 5, sizeof(int) * std::max<size_t>(1, rej_list.size()), (void**)&d_rej);
+  if (e == hipSuccess) e = seed_scratch(c, 6, sizeof(int), (void**)&d_err);
+  if (e == hipSuccess) e = seed_scratch(c, 7, sizeof(long long) * sb2.size(), (void**)&d_sb);
+  if (e == hipSuccess) e = seed_scratch(c, 8, sizeof(long long) * offsets.size(), (void**)&d_off);
   if (e == hipSuccess) e = hipMemcpyAsync(d_shuf, shuf.data(), sizeof(JrShuf) * (size_t)n_shuf, hipMemcpyHostToDevice, bs);
   if (e == hipSuccess && !rej_list.empty()) e = hipMemcpyAsync(d_rej, rej_list.data(), sizeof(int) * rej_list.size(), hipMemcpyHostToDevice, bs);
   if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, sizeof(int), bs);
