@@ -965,23 +965,34 @@ class RecordingBackend:
     def __init__(self, eng, epochs=1):
         self.eng, self.want, self.recs, self.kernels = eng, epochs, [], set()
 
+    def _track(self, plan, k, idx, offsets, n_steps):
+        plan.record(True)
+        rec = {"plan": plan, "k": k, "idx": np.array(idx, copy=True), "offsets": np.array(offsets, copy=True), "n_steps": n_steps}
+        self.recs.append(rec)
+        real = plan.destroy
+
+        def destroy():   # (fit destroys a plan right behind its run: the record is read first)
+            if "masks" not in rec and rec.get("ran"):
+                rec["masks"], rec["s"] = plan.read_record()
+                rec["w_end"] = self.eng.get_weights()
+            rec["plan"] = None
+            real()
+
+        plan.destroy = destroy
+
     def plan_flat(self, idx, offsets, n_steps, k):
         plan = self.eng.plan_flat(idx, offsets, n_steps, k)
         if len(self.recs) < self.want and n_steps:
-            plan.record(True)
-            rec = {"plan": plan, "k": k, "idx": np.array(idx, copy=True), "offsets": np.array(offsets, copy=True), "n_steps": n_steps}
-            self.recs.append(rec)
-            real = plan.destroy
-
-            def destroy():   # (fit destroys a plan right behind its run: the record is read first)
-                if "masks" not in rec and rec.get("ran"):
-                    rec["masks"], rec["s"] = plan.read_record()
-                    rec["w_end"] = self.eng.get_weights()
-                rec["plan"] = None
-                real()
-
-            plan.destroy = destroy
+            self._track(plan, k, idx, offsets, n_steps)
         return plan
+
+    def plan_from_seed(self, jstate, split, max_samples, batch_size):
+        """An epoch whose lists the DEVICE draws (csrc/dsgd_shuffle.hpp): what it drew is read back for the replay."""
+        plan, n_steps, state, draws = self.eng.plan_from_seed(jstate, split, max_samples, batch_size)
+        if plan is not None and len(self.recs) < self.want and n_steps:
+            idx, offsets = self.eng.plan_lists(plan)
+            self._track(plan, len(split), idx, offsets, n_steps)
+        return plan, n_steps, state, draws
 
     def plan_run(self, plan, a, b, lr):
         self.eng.plan_run(plan, a, b, lr)
@@ -1054,7 +1065,7 @@ def time_to_target(dsgd_amd, device, n_rows=804414, oracle_budget_s=5.0, max_epo
     mo, _ = fit_through_the_mirror(dsgd_amd, host, OracleBackend(o), o, n_train, n_rows, 3, 100, LR0, 10, lambda losses: False)
     ref_curve = list(reversed(mo.test_losses))
     target = float(np.median(ref_curve))
-    out = {"rows": n_rows, "train_rows": n_train, "target_test_loss": target, "through": "host.MasterSync.fit (plans, native random stream, prefetch)",
+    out = {"rows": n_rows, "train_rows": n_train, "target_test_loss": target, "through": "host.MasterSync.fit (an epoch = one plan; its lists drawn by the device from 8 M draws per epoch on, else by csrc/jrand.c; prefetch)",
            "target": "median over 10 oracle epochs at 3 x 100, lr 0.5", "oracle_target_curve": ref_curve,
            "oracle_target_s": round(time.perf_counter() - t0, 1), "configs": []}
     with dsgd_amd.Engine(data.dim, LAMBDA, device=device) as eng:

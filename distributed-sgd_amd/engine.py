@@ -345,7 +345,8 @@ class Engine:
 
     def tuning_info(self):
         v = (C.c_int32 * 7)()
-        check(self._lib.dsgd_tuning_info(self._ctx, v, C.c_int32(7)))
+        if self._lib.dsgd_tuning_info(self._ctx, v, C.c_int32(7)) != 0:   # (an older build in an A/B run: six slots)
+            check(self._lib.dsgd_tuning_info(self._ctx, v, C.c_int32(6)))
         return dict(zip(("stream_mode", "hsplit", "fix_shift", "cold_packed", "plan_kernel", "fix_bound", "fstep_rebalances"), [int(x) for x in v]))
 
     def column_ranks(self):

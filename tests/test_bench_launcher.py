@@ -78,14 +78,14 @@ def test_ranks_leave_the_clock_ramp_together(tmp_path):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The full object of the bench line the last GPU visit produced (profiles/r05_bench_detail_*.json): the keys, types and internal arithmetic of
+    """The full object of the bench line the last GPU visit produced (profiles/r06_bench_detail.json): the keys, types and internal arithmetic of
     the driver's contract -- whole-job examples/s from the timed steps (median of the repeats), the dominant kernel's
     roofline fraction from its algorithmic bytes and its measured duration, a bounded CPU baseline, nothing quoted against
     a baseline that was never published -- and that every quoted configuration carries the parity of the kernel that
     produced it."""
     import json
 
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_detail.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_detail.json")))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
@@ -130,20 +130,25 @@ def test_committed_bench_line_keeps_the_contract():
     tr = hw["traced_replay"]
     assert tr["workers"] == hw["workers"] == 256 and tr["batch"] == 100 and tr["accounting_agrees"] is True and tr["controls_rejected"] is True
     assert tr["gates_are"].startswith("engine-recorded")                 # (what the accounting replay does NOT re-derive ...
-    g4 = tr["gate_check_4_workers"]                                       #  ... and the statement that does, at 4 workers)
+    gc = tr["gate_check"]                                                 #  ... and the statement that checks EVERY one of them, at 256 workers:
+    assert gc["ok"] is True and gc["gate_rows_checked"] == gc["rows"] - gc["empty_rows"] == gc["updates"] * tr["batch"]   # rule on the recorded x . w,
+    assert gc["rule_violations"] == 0 and gc["range_violations"] == 0 and gc["max_window"] >= 200                        # that x . w inside its range)
+    assert all(v["rejected"] for v in gc["negative_controls"].values()) and len(gc["negative_controls"]) == 2
+    g4 = tr["gate_check_4_workers"]                                       #  ... beside round 5's few-worker statement
     assert g4["ok"] is True and g4["updates_checked"] > 0 and g4["differ_at_both_ends"] <= g4["explained_by_in_flight_or_resolution"]
     assert tr["checkpoint"]["account_err_over_tol"] <= 1.0
     assert all(v["rejected"] for v in tr["negative_controls"].values()) and len(tr["negative_controls"]) >= 2
     assert hw["atomics_per_s"] > 0 and 0.0 < hw["frac_hbm_peak"] < 1.0
     # the reference's own data-set sizes next to the headline, gated and with roofline fields
     shapes = {rs["rows"]: rs for rs in d["reference_shapes"]}
-    assert set(shapes) == {804414, 23149}
+    assert set(shapes) == {804414, 23149, 100552}   # (the last: one GPU of eight's share of RCV1, SplitStrategy.scala:13-14)
     for rs in shapes.values():
         assert rs["parity_gate"]["max_rel_err"] <= 1e-5 and rs["parity_gate"]["worst_err_over_bound"] <= 1.0
         assert rs["whole_shard"]["repeats"] >= 5 and 0.0 < rs["roofline"]["step"]["frac"] <= rs["roofline"]["frac"] <= 1.0
         assert all(s["parity"]["kernel"] == s["kernel"] for s in rs["sweep"])
     # the whole-split step at N = 23,149 runs as column lists (csrc/dsgd_tcol.hpp), at N = 804,414 as row chunks
     assert shapes[23149]["whole_shard"]["kernel"] == "dsgd_tc_grad_kernel" and shapes[804414]["whole_shard"]["kernel"] == "dsgd_fstep_kernel"
+    assert shapes[100552]["whole_shard"]["kernel"] == "dsgd_fstep_kernel"      # (6 M non-zeros: beyond the column lists since round 6)
     # wall-clock to the oracle's target loss THROUGH host.MasterSync.fit (what a patched Master.fit runs), evaluation passes
     # inside the clock, for the batch sizes of SURVEY.md 8(d); the reference's configuration with its forced replay
     tt = d["time_to_target"]

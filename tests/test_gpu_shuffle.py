@@ -128,3 +128,27 @@ def test_an_epoch_of_rcv1_full_is_drawn_on_the_device_draw_for_draw():
         eng.synchronize()
         assert np.array_equal(eng.get_weights(), w_dev)
         plan_h.destroy()
+
+
+def test_device_drawn_plans_beyond_the_column_slices_run_like_host_drawn_ones():
+    """Steps of more than 1,024 rows do not run on column slices: their plan is laid out on the HOST at its first run, which
+    fetches the device-drawn lists back (plan_host_idx).  2 workers x 700 rows per step: the same weights as the plan made
+    from the host's lists, bit for bit."""
+    n_train = 20000
+    data, eng = engine(n_train + 500, seed=8, ds_rows=n_train)
+    with eng:
+        split = host.split_vanilla(n_train, 2)
+        rnd = host.JavaRandom(0)
+        state = rnd.seed
+        idx_h, offs_h, n_h = host.epoch_lists(rnd, split, 10000, 700, native=True)
+        plan, n_d, state_d, _ = eng.plan_from_seed(state, split, 10000, 700)
+        assert n_d == n_h == 15 and state_d == rnd.seed
+        out = []
+        for p in (plan, eng.plan_flat(idx_h, offs_h, n_h, 2)):
+            eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+            eng.plan_run(p, 0, n_h, 0.05)
+            eng.synchronize()
+            out.append((eng.get_weights(), p.info()["kind"], eng.grad_kernel_name()))
+            p.destroy()
+        assert out[0][1] == out[1][1] != "column_slices" and out[0][2] == out[1][2], out
+        assert np.array_equal(out[0][0], out[1][0]) and np.abs(out[0][0]).max() > 0
