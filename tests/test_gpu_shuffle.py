@@ -152,3 +152,29 @@ def test_device_drawn_plans_beyond_the_column_slices_run_like_host_drawn_ones():
             p.destroy()
         assert out[0][1] == out[1][1] != "column_slices" and out[0][2] == out[1][2], out
         assert np.array_equal(out[0][0], out[1][0]) and np.abs(out[0][0]).max() > 0
+
+
+def test_random_small_epochs_device_equals_host():
+    """Forty random configurations (1-8 workers, splits of 1-6,000 rows incl. powers of two -- java.util.Random.nextInt takes
+    another branch there --, batches of 1-700, arbitrary generator states): lists, step counts and final states equal."""
+    data, eng = engine(50000, seed=2)
+    rng = np.random.default_rng(20260930)
+    with eng:
+        for case in range(40):
+            k = int(rng.integers(1, 9))
+            lens = [int(rng.choice([1, 2, 3, 64, 100, 1024, 4096, int(rng.integers(1, 6001))])) for _ in range(k)]
+            split, at = [], 0
+            for ln in lens:
+                split.append(range(at, at + ln))
+                at += ln
+            batch = int(rng.choice([1, 7, 100, 256, int(rng.integers(1, 701))]))
+            state = int(rng.integers(0, 1 << 48))
+            max_samples = max(lens)
+            (idx_h, offs_h, n_h, state_h), (plan, n_d, state_d, draws) = both(eng, state, split, max_samples, batch)
+            assert n_d == n_h and state_d == state_h, (case, lens, batch)
+            if n_h == 0:
+                assert plan is None
+                continue
+            idx_d, offs_d = eng.plan_lists(plan)
+            assert np.array_equal(offs_d, offs_h) and np.array_equal(idx_d, idx_h), (case, lens, batch, int(np.flatnonzero(idx_d != idx_h)[0]) if len(idx_d) == len(idx_h) else -1)
+            plan.destroy()

@@ -1,5 +1,9 @@
 #!/bin/bash
-# A/B on ONE box: whole-split steps through the round-5 library (tools/ab/libdsgd_hip_r05.so, built from c64ce6f) and the tree's
+# A/B on ONE box: whole-split steps through the round-5 library and the tree's.  The round-5 library is not in the history
+# (built artefacts are git-ignored); build it where hipcc is, it travels with the snapshot:
+#   mkdir -p /tmp/r05src tools/ab && git archive c64ce6f distributed-sgd_amd/csrc include | tar -x -C /tmp/r05src && (cd /tmp/r05src &&
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -w -Iinclude distributed-sgd_amd/csrc/dsgd_hip.hip \
+#         -o $OLDPWD/tools/ab/libdsgd_hip_r05.so -Wl,-rpath,/opt/rocm/lib -ldl -lpthread -L/opt/rocm/lib -lamdhip64)
 sizes=${1:-804414}
 out=gpurun_out/r06_ab_${2:-a}.txt
 : > $out
