@@ -2271,7 +2271,6 @@ static bool fstep_possible(const dsgd_ctx* c) {
 }
 static int fstep_build(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int n_wg, dsgd_ctx::FstepLayout& L);
 static int fstep_layout(dsgd_ctx* c, const std::vector<StreamSeg>& row_segs, int n_wg, dsgd_ctx::FstepLayout** out) {
-  const int n_workers = (int)row_segs.size();
   std::vector<long long> key;
   for (const StreamSeg& sg : row_segs) {
     key.push_back(sg.row_begin);
