@@ -129,6 +129,13 @@ __global__ void __launch_bounds__(1024) dsgd_dense_step_kernel(DenseArgs a) {
 // of 16 macro-steps m, the float4 X[row i][256v + 16m + 4q ..]: 64 VGPRs hold the tile for both products.  The
 // gradient product stays on the VALU: r_i * x summed over the 16 rows with the DPP butterfly of group_sum<16>, lane i
 // keeping the four sums of macro-step m == i.
+// (Round 6 measured the tile turned round as well -- rows on l / 16, X as the B operand: g = X^T r on the matrix cores with
+//  A[m][k] = r[row k] for every m, z = X w on the VALU with one 16-lane DPP sum per row.  An MFMA contracts over l / 16 only,
+//  so ONE register layout serves one of the two products; and the 16 identical result rows of a matrix-VECTOR product cost
+//  64 accumulator registers per lane, which leaves a 1,024-lane workgroup room for blocks of FOUR rows, one workgroup per
+//  CU, two barriers per block: 243 us per 65,536-row step against 185 for the VALU kernel (0.55 / 0.73 of 8 TB/s by wall
+//  time, tools/dense_check.py; 128 VGPRs + 56 bytes of scratch) -- slower than this form (0.61).  Not kept;
+//  profiles/r06_dense_pmc_summary.txt.)
 typedef float dn_f32x4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(1024) dsgd_dense_step_mfma_kernel(DenseArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wl[];   // D weights
