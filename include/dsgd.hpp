@@ -70,6 +70,9 @@ class JavaRandom {
     }
     return r;
   }
+  // the 48-bit internal state (what dsgd_plan_create_from_seed takes and hands back: the device draws an epoch's lists)
+  uint64_t state() const { return (uint64_t)seed_; }
+  void setState(uint64_t s) { seed_ = (int64_t)(s & ((1ULL << 48) - 1)); }
 
  private:
   int64_t seed_;
@@ -294,6 +297,9 @@ class Master {
 
   std::deque<double> losses, accs, testLosses, testAccs;  // newest first
   bool usePlans = true;   // an epoch's batches as ONE resident plan (dsgd_plan_create / dsgd_plan_run); false: one dsgd_sync_step per batch
+  // ... and the plan's lists DRAWN BY THE DEVICE, draw for draw the same stream (dsgd_plan_create_from_seed), for epochs of at
+  // least this many draws (the device form has ~1.5 ms of fixed cost; < 0: never); outside its limits the host draws as ever
+  int64_t deviceListsMinDraws = 8 << 20;
   int64_t stepsRun = 0;
 
   double localLoss(const Vec& w, bool test = false) { return test ? model_.loss(w, nTrain_, nRows_) : model_.loss(w, 0, nTrain_); }  // :104
@@ -316,8 +322,38 @@ class Master {
       std::vector<int32_t> flat;
       std::vector<int64_t> offsets{0};
       int64_t nSteps = 0;
-      bool emptySlice = false;
-      for (int64_t batch = 0; batch < maxSamples && !emptySlice; batch += batchSize) {
+      bool emptySlice = false, ranOnDevice = false;
+      {
+        int64_t nExpected = 0, perBatch = 0;
+        for (int64_t batch = 0; batch < maxSamples; batch += batchSize) ++nExpected;
+        for (const auto& r : split) perBatch += r.second - r.first - 1;
+        if (usePlans && deviceListsMinDraws >= 0 && nExpected * perBatch >= deviceListsMinDraws) {
+          std::vector<int64_t> sb, se;
+          for (const auto& r : split) {
+            sb.push_back(r.first);
+            se.push_back(r.second);
+          }
+          uint64_t st = rnd_.state();
+          dsgd_plan* plan = nullptr;
+          int64_t n = 0;
+          const int rc = dsgd_plan_create_from_seed(model_.ctx(), &st, sb.data(), se.data(), (int32_t)split.size(), maxSamples, batchSize, &plan, &n, nullptr);
+          if (rc == DSGD_OK) {
+            rnd_.setState(st);
+            if (plan) {
+              int rr = dsgd_plan_run(model_.ctx(), plan, 0, n, (float)learningRate);
+              if (rr == DSGD_OK) rr = dsgd_synchronize(model_.ctx(), nullptr);
+              dsgd_plan_destroy(model_.ctx(), plan);
+              check(rr);
+            }
+            nSteps = n;
+            emptySlice = n < nExpected;
+            ranOnDevice = true;
+          } else if (rc != DSGD_EUNSUPPORTED) {
+            check(rc);
+          }
+        }
+      }
+      for (int64_t batch = 0; !ranOnDevice && batch < maxSamples && !emptySlice; batch += batchSize) {
         for (const auto& r : split)
           if (batch >= r.second - r.first) emptySlice = true;   // the slave would be handed an empty slice: Vec.sum throws there
         if (emptySlice) break;
@@ -333,7 +369,8 @@ class Master {
         ++nSteps;
       }
       const int32_t K = (int32_t)split.size();
-      if (usePlans && nSteps > 0) {
+      if (ranOnDevice) {
+      } else if (usePlans && nSteps > 0) {
         dsgd_plan* plan = nullptr;
         check(dsgd_plan_create_n(model_.ctx(), flat.data(), (int64_t)flat.size(), offsets.data(), nSteps, K, &plan));
         int rc = dsgd_plan_run(model_.ctx(), plan, 0, nSteps, (float)learningRate);

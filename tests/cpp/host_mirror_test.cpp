@@ -175,6 +175,16 @@ static void gpu_checks() {
     const GradState s2 = master2.fit(Vec(7, 0.f), 2, 2, 0.25, EarlyStopping::noImprovement(5, 0.01));
     CHECK(master.stepsRun == master2.stepsRun && master.stepsRun == 2);
     for (size_t j = 0; j < s.grad.size(); ++j) CHECK(close_to(s.grad[j], s2.grad[j], 1e-7));
+    // ... and with the epoch's lists DRAWN BY THE DEVICE (dsgd_plan_create_from_seed, forced for this tiny epoch): the same
+    // stream, so the same lists, the same weights bit for bit as the plan made from the host's draws
+    SparseSVM model3(0.1, 6);
+    model3.load(kat_rows(6));
+    model3.buildDimSparsity(4);
+    Master master3(model3, 4, 6, 2, JavaRandom(0));
+    master3.deviceListsMinDraws = 0;
+    const GradState s3 = master3.fit(Vec(7, 0.f), 2, 2, 0.25, EarlyStopping::noImprovement(5, 0.01));
+    CHECK(master3.stepsRun == 2 && s3.updates == s.updates);
+    for (size_t j = 0; j < s.grad.size(); ++j) CHECK(s.grad[j] == s3.grad[j]);
   }
 }
 
