@@ -26,6 +26,7 @@
 // Fixed point: q = round(y*x * 2^shift / vmax2), shift = 30 - ceil(log2 batch): a column receives at most one
 // contribution per row, so no 32-bit word can pass 2^30; contributions below half a grid unit vanish (this
 // absorbs the reference's 1e-20 filter on y*x, math/Vec.scala:42 -> math/Sparse.scala:108-118).
+constexpr int HBIT_WORDS = 1024;   // COLD = 3: words of the bitmap of touched LDS accumulators (ranks hh + word + 1024 * bit)
 constexpr int BT_G = 16;     // lanes per work item
 constexpr int BT_K = 8;      // non-zeros per lane and item
 constexpr int BT_CH = BT_G * BT_K;   // 128 non-zeros per item
@@ -35,6 +36,8 @@ struct BtLds {
   unsigned int* cbits;   // one bit per rank >= hl: the strip entry was touched by this batch
   long long* g64;        // COLD = 2: 64-bit fixed-point global accumulators of the ranks >= hl (indexed by rank)
   int hl;
+  unsigned int* hbits;   // COLD = 3: one bit per rank in [hh, hl): the LDS accumulator was touched by this batch
+  int hh;
   // sub-batch tables: cap = item slots (NG x R) = most rows of a sub-batch
   long long* rst;        // [cap] first non-zero of the row
   int* rlen;             // [cap] its length
@@ -79,18 +82,25 @@ struct BtRow {
 //      atomics stay in this XCD's L2 instead of crossing the fabric)
 //   2  64-bit fixed-point global accumulators on the same grid as the LDS ones (mid-size batches spread over many
 //      workgroups: dsgd_fix_reduce_* adds them to the partial sums exactly)
+//   3  as 1, and the LDS accumulators beyond the dense head [0, hh) are marked in a second bitmap (the lock-free engine:
+//      its update walks the touched ranks instead of sweeping all of them)
 template <int COLD>
 __device__ __forceinline__ void bt_add(const BtLds& L, float* __restrict__ gcold, int c, float xv, float qscale) {
   if (c < L.hl) {
     const int q = __float2int_rn(xv * qscale);
-    if (q != 0) atomicAdd(&L.acc[c], q);   // ds_add_u32
+    if (q != 0) {
+      atomicAdd(&L.acc[c], q);   // ds_add_u32
+      // (interleaved: word = low bits of the rank, so that every word -- every lane of the update -- holds its share of
+      //  the dense ranks near the head and of the sparse ones far from it)
+      if (COLD == 3 && c >= L.hh) atomicOr(&L.hbits[(unsigned int)(c - L.hh) & (HBIT_WORDS - 1)], 1u << ((unsigned int)(c - L.hh) / HBIT_WORDS));
+    }
   } else if (COLD == 2) {
     const int q = __float2int_rn(xv * qscale);
     if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&L.g64[c]), (unsigned long long)(long long)q);
   } else {
     const float f = filt(xv);
     if (f != 0.0f) {
-      if (COLD == 1) __hip_atomic_fetch_add(&gcold[c - L.hl], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (COLD == 1 || COLD == 3) __hip_atomic_fetch_add(&gcold[c - L.hl], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       else atomicAdd(&gcold[c - L.hl], f);
       atomicOr(&L.cbits[(unsigned int)(c - L.hl) >> 5], 1u << ((c - L.hl) & 31));
     }
@@ -671,6 +681,8 @@ __global__ void __launch_bounds__(MB_THREADS) dsgd_mb_grad_kernel(MbArgs a) {
   L.acc = reinterpret_cast<int*>(lds);
   L.cbits = nullptr;
   L.g64 = a.g64_base + (long long)blockIdx.y * a.g_stride;
+  L.hbits = nullptr;
+  L.hh = 0;
   float* wl = lds + ((a.hl + 3) & ~3);
   MbRec* recs = reinterpret_cast<MbRec*>(wl + a.wl) + wave * 64;   // this wave's strip
   // active rows of the workgroup: ONE global atomic per workgroup at the end (one per wave -- 3,072 same-address atomics
@@ -1188,6 +1200,8 @@ __global__ void __launch_bounds__(1024) dsgd_vt_grad_kernel(VtArgs a) {
         L.acc = gl;
         L.cbits = nullptr;
         L.g64 = g64;
+        L.hbits = nullptr;
+        L.hh = 0;
         const MbWeights wload{wl, a.w, H};
         float acc = 0.0f;
         for (int off = lane * BT_K; off < rec.len; off += 64 * BT_K) {
@@ -1310,7 +1324,9 @@ struct HogArgs {
   float lr, lambda;
   float qscale, inv_qscale;     // 2^shift / vmax2 and its inverse
   int batch, positional_bug, hl, wl, dp;   // hl: ranks with an LDS accumulator; wl: ranks with an LDS copy of w (whole 1 KiB pieces: a multiple of 256)
-  unsigned long long* tprof;    // PROF: [0..5] cycles by phase (batch, hot sweep, cold strip, drain, scalars, weight copy), [15] iterations
+  int hh;                       // hog_hh(hl): the dense head of the update
+  unsigned long long* tprof;    // PROF: [0..6] cycles by phase (batch, update head, update rounds + updates, drain, scalars + weight copy,
+                                //   next tables, next requests), [12] update rounds, [15] iterations (tools/hog_prof.py)
   unsigned int* trace;          // optional (dsgd_async_set_trace): one record per mini-batch update, indexed by its commit number
   long long trace_cap;          // ... records of hog_trace_words(batch) words
   float* tdot;                  // traced runs: n_workers x batch, the x . w of the mini-batch in flight (copied into its record at the commit)
@@ -1349,8 +1365,13 @@ struct HogCtl {   // per iteration parity
   int stop;
 };
 
+constexpr int HOG_TS = 8, HOG_CS = 2;   // touched accumulators / strip entries a lane takes per round of the update
+constexpr int HOG_HH = HOG_THREADS * HOG_SW;   // 2,048: the dense head of the update (every accumulator read); beyond it a bitmap of touched ranks
+static_assert(HOG_HL - HOG_HH <= 32 * HBIT_WORDS && HBIT_WORDS <= 2 * HOG_THREADS, "one trip of the update takes every word of the accumulators' bitmap");
+__host__ __device__ constexpr int hog_hh(int hl) { return hl < HOG_HH ? hl : HOG_HH; }
+__host__ __device__ constexpr int hog_hbit_words(int hl) { return hl > hog_hh(hl) ? HBIT_WORDS : 0; }
 __host__ __device__ constexpr int hog_lds_words(int hl, int wl, int dp) {
-  return wl + ((hl + (dp - hl + 31) / 32 + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8 + HOG_MAX_BATCH / 32 + 8 + 8 + 2;
+  return wl + ((hl + (dp - hl + 31) / 32 + hog_hbit_words(hl) + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8 + HOG_MAX_BATCH / 32 + 16 + 8 + 2;
 }
 
 // Copy of w[0, wl) into LDS: each wave moves 1 KiB pieces straight from the fabric into LDS (global_load_lds_dwordx4:
@@ -1415,18 +1436,23 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   BtLds L;
   L.hl = a.hl;
   L.g64 = nullptr;
+  L.hbits = nullptr;
+  L.hh = 0;
   float* wl = lds;                                           // copy of w[0, a.wl), 16-byte aligned
   L.acc = reinterpret_cast<int*>(lds + a.wl);
   const int n_cw = (a.dp - a.hl + 31) / 32;                  // bitmap words of the cold strip (0 when dp <= hl)
   L.cbits = reinterpret_cast<unsigned int*>(lds + a.wl + a.hl);
-  int* tables = reinterpret_cast<int*>(lds) + a.wl + ((a.hl + n_cw + 1) & ~1);
+  const int n_hw = hog_hbit_words(a.hl);                     // bitmap words of the accumulators beyond the dense head
+  L.hh = a.hh;
+  L.hbits = L.cbits + n_cw;
+  int* tables = reinterpret_cast<int*>(lds) + a.wl + ((a.hl + n_cw + n_hw + 1) & ~1);
   bt_carve(L, tables, HOG_CAP);
   float* red = reinterpret_cast<float*>(tables + bt_lds_words(HOG_CAP));   // 8 floats + 8 counters
   unsigned int* redn = reinterpret_cast<unsigned int*>(red + 8);
   HogCtl* ctl = reinterpret_cast<HogCtl*>(red + 16);                       // 2 slots (iteration parity)
   unsigned int* gmask = reinterpret_cast<unsigned int*>(red + 24);         // traced runs: gate decisions of the mini-batch
-  unsigned int* tp = gmask + HOG_MAX_BATCH / 32;                           // PROF: six phase sums, [6] the last stamp (32-bit)
-  unsigned int* stl = tp + 8;                                              // thread 0: samples / active rows / weight atomics not yet flushed;
+  unsigned int* tp = gmask + HOG_MAX_BATCH / 32;                           // PROF: phase sums [0..13], [14] the last stamp (32-bit), [15] iterations
+  unsigned int* stl = tp + 16;                                             // thread 0: samples / active rows / weight atomics not yet flushed;
                                                                            //   [4..5] the update count its weights were read at (a register
                                                                            //   pair in every lane otherwise: the kernel has none to spare);
                                                                            //   traced runs: [3] / [6] seen_from of the next / this iteration, [7] flags
@@ -1437,12 +1463,12 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   auto stamp = [&](int i) {
     if (PROF && prof) {
       const unsigned int now = (unsigned int)__builtin_readcyclecounter();
-      tp[i] += now - tp[6];
-      tp[6] = now;
+      tp[i] += now - tp[14];
+      tp[14] = now;
     }
   };
   if (PROF && prof)
-    for (int i = 0; i < 8; ++i) tp[i] = 0u;
+    for (int i = 0; i < 16; ++i) tp[i] = 0u;
   if (tid < HOG_MAX_BATCH / 32) gmask[tid] = 0u;
   if (tid < 4) stl[tid] = 0u;
   unsigned int* const gm = TRACE ? gmask : nullptr;
@@ -1456,7 +1482,8 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   const long long base = a.positional_bug ? 0 : begin;   // ref: core/Slave.scala:87 indexes `data` by POSITION
   const double inv_n = 1.0 / (double)n_k;
   float* gc = a.gcold + (long long)worker * (a.dp > a.hl ? a.dp - a.hl : 1);
-  for (int j = tid; j < a.hl + n_cw; j += HOG_THREADS) L.acc[j] = 0;   // accumulators and bitmap
+  for (int j = tid; j < a.hl + n_cw + n_hw; j += HOG_THREADS) L.acc[j] = 0;   // accumulators and both bitmaps
+
   const int B = a.batch;
   const float fB = (float)B;
   unsigned long long it = a.it[worker];
@@ -1511,7 +1538,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     bd = bt_build<HOG_THREADS, HOG_CAP>(L, B, 0, row);
     if (bd.x > 0) bt_items_issue<HOG_THREADS, HOG_R>(a.m, L, bd.y, items);
   }
-  if (PROF && prof) tp[6] = (unsigned int)__builtin_readcyclecounter();
+  if (PROF && prof) tp[14] = (unsigned int)__builtin_readcyclecounter();
   for (;;) {
     const HogCtl cur = ctl[it & 1];
     const unsigned long long mul = cur.mul, off = cur.off;
@@ -1526,107 +1553,178 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       __syncthreads();
       n_act += bt_gate(L, bd.x, gm, 0, gdot);
       __syncthreads();
-      bt_scatter<HOG_R, 1>(L, gc, items, a.qscale);
+      bt_scatter<HOG_R, 3>(L, gc, items, a.qscale);
       done = bd.x;
     }
     // ... and whatever did not fit its item slots (long rows, batches beyond 128 rows)
-    if (done < B) n_act += bt_batch<HOG_THREADS, HOG_R, 1>(a.m, L, gc, B, done, row_of, wload, a.qscale, &a.st->err, gm, gdot);
+    if (done < B) n_act += bt_batch<HOG_THREADS, HOG_R, 3>(a.m, L, gc, B, done, row_of, wload, a.qscale, &a.st->err, gm, gdot);
     // the next iteration's sample does not depend on w: request its row records now
     const HogCtl nxt = ctl[(it + 1) & 1];
     const BtRow row_n = bt_rows_issue<HOG_CAP>(a.m, B, 0, [&](int t) { return row_at(nxt.mul, nxt.off, t); }, &a.st->err);
+    // dimSparsity of this lane's slots of the dense head (one buffer resource over the head: beyond it a load returns zero);
+    // requested with the row records: both are waited for at the barrier
+    const __amdgpu_buffer_rsrc_t ds_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ds), 0, a.hh * 4, 0x00020000);
+    float dsh[HOG_SW];
+#pragma unroll
+    for (int e = 0; e < HOG_SW; ++e)
+      dsh[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ds_rs, tid * 4, e * HOG_THREADS * 4, 0));
     __syncthreads();
     stamp(0);
     // phase 2: mean, regularise on the support, scale, subtract from the shared w (ref: Slave.scala:98-101).
-    // Dense sweep, consecutive lanes = consecutive ranks (the updates of the dense hot head coalesce); the dimSparsity
-    // values of a pass are requested together, under the mask of the non-zero accumulators, before any is used.
+    // Round 6: the update WALKS THE TOUCHED RANKS.  Rounds 3-5 swept every LDS accumulator (40 slots per lane, twice; the
+    // dimSparsity value of every slot requested a pass ahead: ten dependent round trips per iteration, 14.5 of its 38 us,
+    // profiles/r05_hogwild_phase_cycles.txt) and then the cold strip's bitmap one bit -- one round trip -- at a time
+    // (5.5 us).  Now (profiles/r06_hogwild_notes.txt):
+    //   1. a dense HEAD of hh = 2,048 ranks, 4 slots per lane, their dimSparsity values requested with the row records;
+    //   2. the other accumulators through a bitmap set by the scatter (bt_add<3>), the cold strip through its own: a lane
+    //      takes up to eight touched accumulators and two strip entries at a time and requests everything they need
+    //      TOGETHER (dimSparsity values; the strip entries with their take-and-clear exchange) -- one round trip for
+    //      nearly every lane; the accumulators' deltas go back into their slots;
+    //   3. the updates, with no load behind them: the head, then the accumulators BY BIT POSITION (consecutive lanes =
+    //      consecutive ranks: the memory side serves ~21 G requests/s whether a request carries one word of a line or
+    //      sixteen, tools/microbench7.hip -- with 256 workers an iteration is bound by that rate: without any update
+    //      it takes 24 us, with them 37), the strip's as they are computed.
+    // The same arithmetic per rank as before; the terms of the regulariser's increment are added in another order.
     float ds_acc = 0.0f;
-    int2 bd_n = make_int2(0, 0);
-    // (dimSparsity never changes: requested ONE PASS AHEAD and for every slot -- under the mask of the pass's own non-zero
-    //  accumulators the values were a dependent round trip per pass.  Consecutive lanes = consecutive ranks: a wave's atomic
-    //  instruction covers two 128-byte lines.  A lane owning FOUR consecutive ranks -- one 16-byte LDS read per quad, 78 % of
-    //  the quads empty -- was tried: 10 instead of 40 tests per lane, but its atomics spread over eight lines per
-    //  instruction: 38.9 -> 51.9 us per iteration with 256 workers, profiles/r04_hogwild_phase_cycles.txt)
-    // (one buffer resource over the hot head, the lane's offset in ONE register, the slot's in a scalar: beyond the head a
-    //  buffer load returns zero -- no clamps, no 64-bit lane addresses: the kernel has 3 registers to spare)
-    const __amdgpu_buffer_rsrc_t ds_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ds), 0, a.hl * 4, 0x00020000);
-    float dsn[HOG_SW];
+    auto hot_delta = [&](int q) -> float {
+      float g = filt(((float)q * a.inv_qscale) / fB);   // Vec.mean divides (ref: math/Vec.scala:139)
+      if (add_s && g != 0.0f) g = filt(g + s_it);
+      return filt(g * a.lr);
+    };
+    float dh[HOG_SW];
 #pragma unroll
-    for (int e = 0; e < HOG_SW; ++e)
-      dsn[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ds_rs, tid * 4, e * HOG_THREADS * 4, 0));
-    // TWO sweeps (round 5).  vmcnt retires in order: with the updates issued inside the pass that also requests the next
-    // pass's dimSparsity values, every pass waited for its predecessor's atomics to be ACKNOWLEDGED by the memory side
-    // before its own loads could "return" -- ten round trips over the fabric in a row, 27 K cycles of a 59 K-cycle
-    // iteration with ONE worker on an idle chip (profiles/r04_hogwild_phase_cycles.txt).  Now the first sweep only loads
-    // (deltas computed, their dimSparsity terms summed, the delta left in the accumulator's slot) and the second only
-    // updates (no load behind an atomic: the updates leave back to back, acknowledged once, at the drain).  The same
-    // terms in the same order per lane: the same bits.
-    for (int j0 = 0, pass = 0; j0 < a.hl; j0 += HOG_THREADS * HOG_SW, ++pass) {
-      int q[HOG_SW];
-      float dsv[HOG_SW];
-#pragma unroll
-      for (int e = 0; e < HOG_SW; ++e) {
-        const int j = j0 + e * HOG_THREADS + tid;
-        q[e] = j < a.hl ? L.acc[j] : 0;
-        dsv[e] = dsn[e];
-      }
-#pragma unroll
-      for (int e = 0; e < HOG_SW; ++e)
-        dsn[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ds_rs, tid * 4, (j0 + (HOG_SW + e) * HOG_THREADS) * 4, 0));
-      if (pass == 0) {
-        // the row records have landed behind the first pass's loads: tables and the non-zeros of the next sub-batch
-        // (the tables of this iteration are no longer needed: every scatter is behind the barrier above)
-        bd_n = bt_build<HOG_THREADS, HOG_CAP>(L, B, 0, row_n);
-        if (bd_n.x > 0) bt_items_issue<HOG_THREADS, HOG_R>(a.m, L, bd_n.y, items);
-      }
-#pragma unroll
-      for (int e = 0; e < HOG_SW; ++e) {
-        if (q[e] == 0) continue;
-        const int j = j0 + e * HOG_THREADS + tid;
-        float g = filt(((float)q[e] * a.inv_qscale) / fB);   // Vec.mean divides (ref: math/Vec.scala:139)
-        if (add_s && g != 0.0f) g = filt(g + s_it);
-        const float delta = filt(g * a.lr);
-        L.acc[j] = __float_as_int(delta);   // (0.0f = all bits clear: nothing to apply)
-        if (delta != 0.0f) {
-          ds_acc += delta * dsv[e];
-          n_act += HOG_ATOMIC_ONE;      // (counted in the upper bits of the active-row counter: no register to spare)
+    for (int e = 0; e < HOG_SW; ++e) {
+      const int j = e * HOG_THREADS + tid;
+      const int q = j < a.hh ? L.acc[j] : 0;
+      dh[e] = 0.0f;
+      if (q != 0) {
+        L.acc[j] = 0;
+        dh[e] = hot_delta(q);
+        if (dh[e] != 0.0f) {
+          ds_acc += dh[e] * dsh[e];
+          n_act += HOG_ATOMIC_ONE;      // (counted in the upper bits of the active-row counter)
         }
       }
     }
-    for (int j0 = 0; j0 < a.hl; j0 += HOG_THREADS * HOG_SW) {
-      int d[HOG_SW];
-#pragma unroll
-      for (int e = 0; e < HOG_SW; ++e) {
-        const int j = j0 + e * HOG_THREADS + tid;
-        d[e] = j < a.hl ? L.acc[j] : 0;
-      }
-#pragma unroll
-      for (int e = 0; e < HOG_SW; ++e) {
-        if (d[e] == 0) continue;
-        const int j = j0 + e * HOG_THREADS + tid;
-        L.acc[j] = 0;
-        atomicAdd(&a.w[j], -__int_as_float(d[e]));   // lock-free update of the ONE weight vector
-      }
-    }
     stamp(1);
-    for (int wd = tid; wd < n_cw; wd += HOG_THREADS) {
-      unsigned int bits = L.cbits[wd];
-      if (!bits) continue;
-      L.cbits[wd] = 0u;
-      while (bits) {
-        const int b = __builtin_ctz(bits);
-        bits &= bits - 1u;
-        const int jc = wd * 32 + b;
-        const float dsj = a.ds[a.hl + jc];
-        // take-and-clear the private strip entry (written with L2 atomics of this workgroup: read it there)
-        const float v = __hip_atomic_exchange(&gc[jc], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        float g = filt(v / fB);
-        if (g == 0.0f) continue;
-        if (add_s) g = filt(g + s_it);
-        const float delta = filt(g * a.lr);
-        if (delta != 0.0f) {
-          atomicAdd(&a.w[a.hl + jc], -delta);
-          ds_acc += delta * dsj;
-          n_act += HOG_ATOMIC_ONE;
+    bool walked = false;
+    unsigned long long hb_all = 0ull;   // this lane's two words of the accumulators' bitmap (the first trip takes them all)
+    for (int wb = 0; wb < n_cw || !walked; wb += 2 * HOG_THREADS) {   // (RCV1: 837 words of cold bitmap -- ONE trip)
+      // two bitmap words of each kind per lane, taken as one 64-bit mask
+      unsigned long long hb = 0ull, cb = 0ull;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int wd = wb + h * HOG_THREADS + tid;
+        if (wd < n_hw) {   // (n_hw <= 2 x HOG_THREADS: the first trip takes them all)
+          const unsigned int v = L.hbits[wd];
+          if (v) L.hbits[wd] = 0u;
+          hb |= (unsigned long long)v << (32 * h);
+        }
+        if (wd < n_cw) {
+          const unsigned int v = L.cbits[wd];
+          if (v) L.cbits[wd] = 0u;
+          cb |= (unsigned long long)v << (32 * h);
+        }
+      }
+      if (wb == 0) hb_all = hb;
+      do {
+        int jt[HOG_TS], jc[HOG_CS];
+#pragma unroll
+        for (int e = 0; e < HOG_TS; ++e) {
+          jt[e] = -1;
+          if (hb) {
+            const int b = __builtin_ctzll(hb);
+            hb &= hb - 1ull;
+            jt[e] = a.hh + (b & 31) * HBIT_WORDS + (b >> 5) * HOG_THREADS + tid;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < HOG_CS; ++e) {
+          jc[e] = -1;
+          if (cb) {
+            const int b = __builtin_ctzll(cb);
+            cb &= cb - 1ull;
+            jc[e] = (wb + (b >> 5) * HOG_THREADS + tid) * 32 + (b & 31);
+          }
+        }
+        float dt[HOG_TS], dst[HOG_TS], gs[HOG_CS], dsc[HOG_CS];
+#pragma unroll
+        for (int e = 0; e < HOG_CS; ++e) {
+          gs[e] = dsc[e] = 0.0f;
+          if (jc[e] >= 0) {
+            // take-and-clear the private strip entry (written with L2 atomics of this workgroup: read it there)
+            gs[e] = __hip_atomic_exchange(&gc[jc[e]], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            dsc[e] = a.ds[a.hl + jc[e]];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < HOG_TS; ++e) {
+          dt[e] = dst[e] = 0.0f;
+          if (jt[e] >= 0) {
+            dst[e] = a.ds[jt[e]];
+            const int q = L.acc[jt[e]];
+            dt[e] = q != 0 ? hot_delta(q) : 0.0f;
+            L.acc[jt[e]] = __float_as_int(dt[e]);   // (0.0f = all bits clear: nothing to apply)
+          }
+        }
+        // ---- everything requested.  EVERY loaded value is consumed before the first update goes out: an update between
+        // two uses made the compiler wait for the update in front of it (conditional updates: it cannot count what is
+        // in flight behind a load) -- fourteen acknowledgements in a row, 11.7 us (ISA + phase counters).
+#pragma unroll
+        for (int e = 0; e < HOG_TS; ++e) {
+          if (dt[e] != 0.0f) {
+            ds_acc += dt[e] * dst[e];
+            n_act += HOG_ATOMIC_ONE;
+          }
+        }
+        float dc[HOG_CS];
+#pragma unroll
+        for (int e = 0; e < HOG_CS; ++e) {
+          dc[e] = 0.0f;
+          if (jc[e] < 0) continue;
+          float g = filt(gs[e] / fB);
+          if (g == 0.0f) continue;
+          if (add_s) g = filt(g + s_it);
+          dc[e] = filt(g * a.lr);
+          if (dc[e] != 0.0f) {
+            ds_acc += dc[e] * dsc[e];
+            n_act += HOG_ATOMIC_ONE;
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing is pending: said aloud, so that no wait lands between the updates)
+        // ---- the strip's updates, back to back ----
+        walked = true;
+#pragma unroll
+        for (int e = 0; e < HOG_CS; ++e)
+          if (dc[e] != 0.0f) atomicAdd(&a.w[a.hl + jc[e]], -dc[e]);
+        if (PROF && prof) ++tp[12];   // rounds
+      } while (hb | cb);
+    }
+    // The accumulators' updates by BIT POSITION: bit b of the words of 512 consecutive lanes = 512 consecutive ranks, so a
+    // wave's instruction covers whole lines where neighbours were touched (the memory side serves ~21 G REQUESTS/s,
+    // a line with sixteen words as fast as one with a single word: tools/microbench7.hip).  The deltas wait in the
+    // accumulators' own slots.
+    {
+#pragma unroll
+      for (int e = 0; e < HOG_SW; ++e)
+        if (dh[e] != 0.0f) atomicAdd(&a.w[e * HOG_THREADS + tid], -dh[e]);   // lock-free update of the ONE weight vector
+      const int nb = (a.hl - a.hh + HBIT_WORDS - 1) / HBIT_WORDS;   // bit positions in use (RCV1: 18)
+      for (int b0 = 0; b0 < nb; b0 += 6) {   // (twelve slots read together, then their updates: no LDS round trip per update)
+        int d[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int b = b0 + (i >> 1), h = i & 1;
+          const int j = a.hh + b * HBIT_WORDS + h * HOG_THREADS + tid;
+          d[i] = 0;
+          if (b < nb && ((hb_all >> (32 * h + b)) & 1ull)) {
+            d[i] = L.acc[j];
+            L.acc[j] = 0;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int j = a.hh + (b0 + (i >> 1)) * HBIT_WORDS + (i & 1) * HOG_THREADS + tid;
+          if (d[i] != 0) atomicAdd(&a.w[j], -__int_as_float(d[i]));
         }
       }
     }
@@ -1725,8 +1823,13 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       cn->stop = leaving;
     }
     stamp(4);
+    // The tables of the next sub-batch (its row records were drained by the barrier behind the scatter; this iteration's
+    // tables are no longer needed): LDS only.  Its two barriers publish the next iteration's control words and the
+    // weight copy.  Then the request for its non-zeros -- BEHIND the update: vmcnt retires in order, and in front of the
+    // update's requests these (random rows of a matrix of gigabytes) held every one of them back for ~7 us.
     hog_wcache_wait();
-    __syncthreads();
+    const int2 bd_n = bt_build<HOG_THREADS, HOG_CAP>(L, B, 0, row_n);
+    stamp(5);
     if (TRACE) {   // the x . w of this mini-batch (written by bt_gate several barriers ago; read past L1) into its record
       const unsigned long long r = ((unsigned long long)ctl_rec[1] << 32) | ctl_rec[0];
       if (r != ~0ull) {
@@ -1734,15 +1837,16 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         for (int t = tid; t < B; t += HOG_THREADS) dst[t] = __hip_atomic_load(&gdot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    stamp(5);
+    if (bd_n.x > 0) bt_items_issue<HOG_THREADS, HOG_R>(a.m, L, bd_n.y, items);
+    stamp(6);
     ++it;
     bd = bd_n;
-    if (PROF && prof) ++tp[7];
+    if (PROF && prof) ++tp[15];
     if (ctl[it & 1].stop) break;
   }
   if (PROF && prof && a.tprof) {
-    for (int i = 0; i < 6; ++i) a.tprof[i] += tp[i];
-    a.tprof[15] += tp[7];
+    for (int i = 0; i < 14; ++i) a.tprof[i] += tp[i];
+    a.tprof[15] += tp[15];
   }
   if (tid == 0) {
     a.it[worker] = it;
@@ -1897,6 +2001,8 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
   BtLds L;
   L.hl = hl;
   L.g64 = nullptr;
+  L.hbits = nullptr;
+  L.hh = 0;
   L.acc = reinterpret_cast<int*>(lds);
   float* wl = lds + hl;                       // hot weights
   float* dsl = lds + 2 * hl;                  // hot dimSparsity

@@ -4392,9 +4392,10 @@ static int hog_launch(dsgd_ctx* c, long long max_updates) {
   a.inv_qscale = std::ldexp(1.0f, c->vexp - shift);
   a.batch = c->hog_batch;
   a.positional_bug = c->hog_bug;
-  a.hl = std::min(c->dp, c->hog_hl) & ~3;   // (whole quads of ranks: the sweep reads four accumulators at once; the rest is cold strip)
+  a.hl = std::min(c->dp, c->hog_hl) & ~3;   // (whole quads of ranks; the rest is cold strip)
   a.dp = c->dp;
   a.wl = std::min(c->hog_wl, c->dp) & ~255;
+  a.hh = hog_hh(a.hl);
   a.trace = c->trace_cap > 0 ? c->d_trace : nullptr;
   a.trace_cap = c->trace_cap;
   a.tdot = c->d_tdot;

@@ -38,8 +38,10 @@ with dsgd_amd.Engine(data.dim, 1e-5) as eng:
                     "us_per_iteration_per_worker": 1e6 * dt * workers / max(1, u)})
         cyc = eng.debug_cycles(reset=True)
         if cyc[15]:   # DSGD_PLAN_PROF=1: cycles of thread 0 of worker 0 per iteration, by phase
-            names = ("batch_dot_gate_scatter", "hot_sweep", "cold_strip", "reduce_and_drain", "scalars_and_requests", "weight_copy_wait")
+            names = ("batch_dot_gate_scatter", "update_head", "update_rounds", "reduce_and_drain", "scalars_and_weight_copy",
+                     "next_tables", "next_requests")
             res[-1]["worker0_cycles_per_iteration"] = {nm: cyc[i] / cyc[15] for i, nm in enumerate(names)}
+            res[-1]["worker0_update_rounds_per_iteration"] = cyc[12] / cyc[15]
             res[-1]["worker0_iterations"] = cyc[15]
     loss, acc, _ = eng.loss_acc(n_train, rows)
 print(json.dumps({"rows": rows, "workers": workers, "batch": batch, "runs": res, "test_loss": loss, "test_acc": acc}))
