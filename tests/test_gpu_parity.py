@@ -841,6 +841,34 @@ def test_hogwild_single_worker_replays_the_oracle():
                           "batch %d: a replayed row within 1e-5 of the gate, err %.3g" % (batch, np.abs(w - w_ref).max()))
 
 
+@pytest.mark.parametrize("dim", [1500, 6000, 70000])
+def test_hogwild_single_worker_on_other_model_widths(dim):
+    """The update of the lock-free engine walks a dense head of 2,048 ranks, a bitmap of the other LDS accumulators and
+    the cold strip's bitmap two words per lane at a time (csrc/dsgd_batch.hpp): models whose every rank sits in the head
+    (D = 1,500), with accumulators beyond it and next to no strip (6,000), and with a strip of more words than one
+    trip takes (70,000: 1,548) replay the oracle as RCV1's width does."""
+    data = dsgd_amd.synth.generate(6000, seed=31, dim=dim)
+    n_train = 4800
+    o, eng = make_pair(data, 1e-5, n_train)
+    with eng:
+        for batch, n_upd in ((100, 30), (7, 40)):
+            eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
+            w_ref = np.zeros(data.dim + 1)
+            begin, end = 500, 4500
+            eng.async_start([(begin, end)], batch=batch, lr=0.5, max_updates=n_upd, seed=5, positional_bug=False)
+            eng.async_wait()
+            updates, running = eng.async_updates()
+            assert updates == n_upd and not running
+            exposed = False
+            for it in range(n_upd):
+                o.async_step(w_ref, hog_rows(5, 0, it, begin, end - begin, batch, False), 0.5)
+                exposed = exposed or o.last_stats["min_abs_margin"] < GATE_EPS
+            w = eng.get_weights().astype(np.float64)
+            assert np.count_nonzero(w) > 0.5 * np.count_nonzero(w_ref)
+            waivers.tight("hogwild_single_worker_widths", np.abs(w - w_ref).max() <= 4 * tol(w_ref), exposed,
+                          "D %d batch %d: a replayed row within 1e-5 of the gate, err %.3g" % (dim, batch, np.abs(w - w_ref).max()))
+
+
 def engine_hogwild_curve(eng, split, batch, lr, checkpoints, eval_range, seed, poll_first_segment=False):
     """The lock-free engine run in segments ending at the checkpoints (every segment a fresh dsgd_async_start with its
     own sampling seed); returns ([(updates, loss, acc)], final weights, per-segment update counts)."""
