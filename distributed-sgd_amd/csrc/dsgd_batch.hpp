@@ -1325,6 +1325,9 @@ struct HogArgs {
   float qscale, inv_qscale;     // 2^shift / vmax2 and its inverse
   int batch, positional_bug, hl, wl, dp;   // hl: ranks with an LDS accumulator; wl: ranks with an LDS copy of w (whole 1 KiB pieces: a multiple of 256)
   int hh;                       // hog_hh(hl): the dense head of the update
+  int direct;                   // few workers (<= HOG_DIRECT_MAX): a lane issues its touched accumulators' updates itself, in its own
+                                //   order (one request per word, no second walk: 16.2 instead of 18.4 us per iteration at 4 workers);
+                                //   many workers: by bit position (fewer requests: 36.5 instead of 40-43 us at 256)
   unsigned long long* tprof;    // PROF: [0..6] cycles by phase (batch, update head, update rounds + updates, drain, scalars + weight copy,
                                 //   next tables, next requests), [12] update rounds, [15] iterations (tools/hog_prof.py)
   unsigned int* trace;          // optional (dsgd_async_set_trace): one record per mini-batch update, indexed by its commit number
@@ -1365,6 +1368,7 @@ struct HogCtl {   // per iteration parity
   int stop;
 };
 
+constexpr int HOG_DIRECT_MAX = 128;    // workers up to which the updates go out word by word (HogArgs::direct)
 constexpr int HOG_TS = 8, HOG_CS = 2;   // touched accumulators / strip entries a lane takes per round of the update
 constexpr int HOG_HH = HOG_THREADS * HOG_SW;   // 2,048: the dense head of the update (every accumulator read); beyond it a bitmap of touched ranks
 static_assert(HOG_HL - HOG_HH <= 32 * HBIT_WORDS && HBIT_WORDS <= 2 * HOG_THREADS, "one trip of the update takes every word of the accumulators' bitmap");
@@ -1664,7 +1668,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
             dst[e] = a.ds[jt[e]];
             const int q = L.acc[jt[e]];
             dt[e] = q != 0 ? hot_delta(q) : 0.0f;
-            L.acc[jt[e]] = __float_as_int(dt[e]);   // (0.0f = all bits clear: nothing to apply)
+            L.acc[jt[e]] = a.direct ? 0 : __float_as_int(dt[e]);   // (0.0f = all bits clear: nothing to apply)
           }
         }
         // ---- everything requested.  EVERY loaded value is consumed before the first update goes out: an update between
@@ -1692,8 +1696,13 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
           }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing is pending: said aloud, so that no wait lands between the updates)
-        // ---- the strip's updates, back to back ----
+        // ---- the strip's updates (few workers: the accumulators' too), back to back ----
         walked = true;
+        if (a.direct) {
+#pragma unroll
+          for (int e = 0; e < HOG_TS; ++e)
+            if (dt[e] != 0.0f) atomicAdd(&a.w[jt[e]], -dt[e]);
+        }
 #pragma unroll
         for (int e = 0; e < HOG_CS; ++e)
           if (dc[e] != 0.0f) atomicAdd(&a.w[a.hl + jc[e]], -dc[e]);
@@ -1708,7 +1717,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
 #pragma unroll
       for (int e = 0; e < HOG_SW; ++e)
         if (dh[e] != 0.0f) atomicAdd(&a.w[e * HOG_THREADS + tid], -dh[e]);   // lock-free update of the ONE weight vector
-      const int nb = (a.hl - a.hh + HBIT_WORDS - 1) / HBIT_WORDS;   // bit positions in use (RCV1: 18)
+      const int nb = a.direct ? 0 : (a.hl - a.hh + HBIT_WORDS - 1) / HBIT_WORDS;   // bit positions in use (RCV1: 18)
       for (int b0 = 0; b0 < nb; b0 += 6) {   // (twelve slots read together, then their updates: no LDS round trip per update)
         int d[12];
 #pragma unroll
@@ -1741,7 +1750,13 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     // traced runs: the count of updates that have LANDED before any weight of the next iteration is requested (the copy of
     // the hot weights goes out behind the barrier below; the value is back before this thread reaches it)
     if (TRACE && tid == 0) stl[3] = (unsigned int)hog_read_u64(&a.st->updates);
-    __syncthreads();   // (drains this workgroup's updates of w: the barrier waits for every outstanding memory operation)
+    // Every wave waits for the acknowledgement of ITS updates of w, then the barrier: the commit number below is drawn when
+    // the whole update has been performed -- what `seen_from` and the next weight copy rely on.  (Said in asm: this
+    // compiler's __syncthreads() waits for LDS operations only -- `s_waitcnt lgkmcnt(0); s_barrier` in the ISA -- and
+    // without the wait a commit could overtake the updates of the other waves: tests/test_gpu_hogwild_trace.py's
+    // small-lag statement found decisions taken on weights that missed part of a COMMITTED update, 38 of 141,700.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     stamp(3);
     // The scalar s is kept by fp32 atomic increments (one per mini-batch, plus dsgd_update_grad's foreign updates): over
     // 10^6+ updates the rounding of every add accumulates like a random walk.  Every HOG_REDERIVE iterations worker 0

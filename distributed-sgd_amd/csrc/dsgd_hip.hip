@@ -4396,6 +4396,7 @@ static int hog_launch(dsgd_ctx* c, long long max_updates) {
   a.dp = c->dp;
   a.wl = std::min(c->hog_wl, c->dp) & ~255;
   a.hh = hog_hh(a.hl);
+  a.direct = c->hog_n <= HOG_DIRECT_MAX ? 1 : 0;
   a.trace = c->trace_cap > 0 ? c->d_trace : nullptr;
   a.trace_cap = c->trace_cap;
   a.tdot = c->d_tdot;

@@ -227,41 +227,71 @@ GATE_SLACK = 8.0
 
 def gate_check_small_lag(o, w0, split, batch, lr, seed, trace, max_lag=1, positional_bug=False):
     """Replay the traced run with its recorded decisions (exact weights W_c after every commit), then hold every decision
-    of every update with lag <= max_lag to the reference's gate y (x . W) >= 0 at BOTH ends of [read_at, commit): a
-    decision that differs at both ends is legitimate only for a row whose margin, at one of the ends, is no larger than
-    what the updates in flight can have moved it by while they were landing (sum_j |x_j| |delta_j| over them) plus the
-    fp32 resolution of its dot product and of the replayed weights themselves.  Returns counts; `outside` lists the violations (empty for a correct engine)."""
+    of every update with at most max_lag OTHER updates between what it is known to have read and its commit to the
+    reference's gate y (x . W) >= 0 at BOTH ends of that stretch: a decision that differs at both ends is legitimate only
+    for a row whose margin, at one of the ends, is no larger than what the updates in flight can have moved it by while
+    they were landing (sum_j |x_j| |delta_j| over them) plus the fp32 resolution of its dot product and of the replayed
+    weights themselves.  Returns counts; `outside` lists the violations (empty for a correct engine).
+    What is known to have been read: traces of the engine carry `seen_from` (an update count read BEFORE any weight of
+    the iteration was requested: updates 1..seen_from had landed) and the worker's own previous update (commit number
+    read_at: acknowledged before the copy was requested) -- the stretch starts at seen_from, NOT at read_at: the copy of
+    the weights goes out before the worker's own commit number comes back, and an update of another worker committed in
+    between carries a number <= read_at without being in the copy (found in round 6, when the engine's timing changed:
+    58 of 143,000 rows).  Such traces also get, as in flight, the FIRST update of every other worker beyond the commit
+    (updates land before they commit).  A trace without `seen_from` (hand-made schedules) is read as before:
+    everything up to read_at in, the updates in (read_at, commit) in flight."""
     worker, it, read_at = np.asarray(trace["worker"]), np.asarray(trace["it"]), np.asarray(trace["read_at"])
     s_rec, mask = np.asarray(trace["s"], dtype=np.float64), np.asarray(trace["mask"])
+    seen = np.asarray(trace["seen_from"], dtype=np.int64) if "seen_from" in trace else None
     n = len(worker)
     out = {"updates": n, "updates_checked": 0, "rows_checked": 0, "differ_at_both_ends": 0, "explained_by_in_flight_or_resolution": 0, "outside": []}
-    w = np.asarray(w0, dtype=np.float64).copy()
-    window = {0: w.copy()}
-    dwin = {}
-    eps32 = 2.0 ** -24
+    # pass 1: every update's delta with the recorded decisions (sparse), the rows it sampled
+    rows_of, dcols, dvals = [], [], []
     for c in range(1, n + 1):
         k = int(worker[c - 1])
         b, e = split[k]
         rows = hog_rows(seed, k, int(it[c - 1]), b, e - b, batch, positional_bug)
+        cols, vals = _sparse_delta(o, rows, mask[c - 1, :batch], float(s_rec[c - 1]), batch, lr)
+        rows_of.append(rows)
+        dcols.append(cols)
+        dvals.append(vals)
+    by_worker = [np.flatnonzero(worker == k) + 1 for k in range(len(split))]
+    w = np.asarray(w0, dtype=np.float64).copy()
+    window = {0: w.copy()}
+    eps32 = 2.0 ** -24
+    keep = max_lag + 4
+    for c in range(1, n + 1):
+        k = int(worker[c - 1])
+        rows = rows_of[c - 1]
         ra = int(read_at[c - 1])
-        lag = c - 1 - ra
-        if lag <= max_lag:
+        lo = int(seen[c - 1]) if seen is not None else ra
+        own = ra if (seen is not None and ra > lo) else 0            # the worker's own previous update: in for certain
+        flying = [cc for cc in range(lo + 1, c) if cc != own]
+        lag = len(flying)
+        if lag <= max_lag and lo in window:
+            if seen is not None:                                     # ... and what can have landed ahead of its commit
+                for kk in range(len(split)):
+                    if kk != k:
+                        pos = int(np.searchsorted(by_worker[kk], c, side="right"))
+                        if pos < len(by_worker[kk]):
+                            flying.append(int(by_worker[kk][pos]))
             y = o.label[rows].astype(np.float64)
-            w_read, w_commit = window[ra], window[c - 1]
+            w_read, w_commit = window[lo], window[c - 1]
             flat, rid = _entries(o, rows)
             v = o.val[flat].astype(np.float64)
             cols = o.col[flat]
-            m_read = y * np.bincount(rid, weights=v * w_read[cols], minlength=batch)
+            wr = w_read[cols] - (_lookup(dcols[own - 1], dvals[own - 1], cols) if own else 0.0)
+            m_read = y * np.bincount(rid, weights=v * wr, minlength=batch)
             m_commit = y * np.bincount(rid, weights=v * w_commit[cols], minlength=batch)
             # what the updates in flight can have done to the margin while landing coordinate by coordinate: any SUBSET of
             # their coordinates may have been visible, so the margin the worker saw lies in [m_read - down, m_read + up]
             down, up = np.zeros(batch), np.zeros(batch)
-            for cc in range(ra + 1, c):
-                t = y[rid] * v * dwin[cc][cols]            # W_commit = W_read - delta: the margin moves by -t per coordinate
+            for cc in flying:
+                t = y[rid] * v * _lookup(dcols[cc - 1], dvals[cc - 1], cols)   # W_after = W_before - delta: the margin moves by -t per coordinate
                 down += np.bincount(rid, weights=np.maximum(t, 0.0), minlength=batch)
                 up += np.bincount(rid, weights=np.maximum(-t, 0.0), minlength=batch)
             nnz = np.bincount(rid, minlength=batch)
-            res = (nnz + 32) * eps32 * np.bincount(rid, weights=np.abs(v * w_read[cols]), minlength=batch)
+            res = (nnz + 32) * eps32 * np.bincount(rid, weights=np.abs(v * wr), minlength=batch)
             # ... and the weights the worker read are the ENGINE's fp32 weights, which the replay (fp64, recorded decisions)
             # follows to its accounting error only -- a few 1e-7 .. 1e-5 of |w|inf per coordinate after hundreds of atomic
             # updates (replay_forced's statement; 2e-4 |w|inf is its tolerance): a margin inside sum_j |x_j| times a
@@ -283,14 +313,10 @@ def gate_check_small_lag(o, w0, split, batch, lr, seed, trace, max_lag=1, positi
                     out["outside"].append({"update": c, "row": int(rows[r]), "lag": int(lag), "recorded_active": bool(rec[r]),
                                            "margin_read": float(m_read[r]), "margin_commit": float(m_commit[r]),
                                            "reachable": [float(m_read[r] - down[r]), float(m_read[r] + up[r])], "resolution": float(slack)})
-        d = forced_delta(o, rows, mask[c - 1, :batch], float(s_rec[c - 1]), batch, lr)
-        w -= d
+        w[dcols[c - 1]] -= dvals[c - 1]
         w[np.abs(w) <= 1e-20] = 0.0
         window[c] = w.copy()
-        dwin[c] = d
-        old = c - max_lag - 3
-        window.pop(old, None)
-        dwin.pop(old, None)
+        window.pop(c - keep, None)
     out["ok"] = not out["outside"]
     out["outside"] = out["outside"][:5]
     return out

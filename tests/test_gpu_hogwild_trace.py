@@ -158,9 +158,11 @@ def gate_run(data, o, n_train, k, n_upd, seed):
 
 
 def test_gate_decisions_of_four_workers_are_the_reference_gate():
-    """The many-worker statement with TEETH.  An update with at most one update in flight between the read of its weights
+    """The many-worker statement with TEETH (round 5; since round 6 tests/test_gpu_hogwild_trace.py also holds EVERY row of
+    every update to its recorded x . w, below).  An update with at most one other update between what it is KNOWN to
+    have read (`seen_from`, an update count read before any weight was requested, plus the worker's own previous update)
     and its commit read weights that are known up to that one update: every recorded decision of those updates is held
-    to the reference's gate y (x . W) >= 0 (core/ml/SparseSVM.scala:27-28) at BOTH ends of [read_at, commit).  A decision
+    to the reference's gate y (x . W) >= 0 (core/ml/SparseSVM.scala:27-28) at BOTH ends of that stretch.  A decision
     that differs at both ends must belong to a row whose margin is no larger than what the update in flight can have moved
     it by while landing, plus fp32 resolution (oracle/hogwild_replay.gate_check_small_lag).  How many updates of a
     4-worker run (the reference deploys 4 slaves: kube/dsgd.yaml:95) qualify depends on how the four workgroups happen to
@@ -182,7 +184,8 @@ def test_gate_decisions_of_four_workers_are_the_reference_gate():
     # negative control: flip the decision of the row with the CLEAREST margin of a checked update
     bad = {kk: np.array(v, copy=True) for kk, v in trace.items()}
     commit = np.arange(1, len(bad["worker"]) + 1)
-    quiet = np.flatnonzero((commit - 1 - bad["read_at"]) == 0)              # updates with nothing in flight
+    own_in = (bad["read_at"] > bad["seen_from"]).astype(np.int64)            # the worker's own previous update: in for certain
+    quiet = np.flatnonzero((commit - 1 - bad["seen_from"] - own_in) == 0)    # updates with nothing committed in flight
     c = int(quiet[min(40, len(quiet) - 1)]) + 1                             # ... one well into the run
     w = np.zeros(data.dim + 1)
     for cc in range(1, c):

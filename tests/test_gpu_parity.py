@@ -929,7 +929,10 @@ def test_hogwild_many_workers_inside_the_oracle_band(k, n_rows, checkpoints):
             band["wnorm"]["hi"], [(round(r[0]["loss"], 3), round(r[0]["acc"], 3), round(r[0]["wnorm"], 2)) for r in runs]))
         for summ, ok, counts in runs:
             assert all(ok.values()), (summ, ok, {q: band[q] for q in ("loss", "acc", "wnorm")}, counts)
-        assert min(r[0]["acc"] for r in runs) > 0.55
+        # (better than chance, and no worse than the oracle's own orderings -- at 256 workers 8,192 updates are 32 per worker
+        #  from w = 0, the first rounds of 256 simultaneous steps overshoot, and the oracle's band itself reaches down to 0.51:
+        #  a fixed 0.55 here passed or failed with the box's interleaving, 0.537 / 0.557 / 0.603 on one visit)
+        assert min(r[0]["acc"] for r in runs) > max(0.5, band["acc"]["lo"])
         # stop() interrupts a run that would otherwise go on for a long time
         eng.async_start(split, batch=batch, lr=0.5, max_updates=10**9, seed=6)
         eng.async_stop()
