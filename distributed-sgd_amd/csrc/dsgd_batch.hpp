@@ -1566,7 +1566,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     const HogCtl nxt = ctl[(it + 1) & 1];
     const BtRow row_n = bt_rows_issue<HOG_CAP>(a.m, B, 0, [&](int t) { return row_at(nxt.mul, nxt.off, t); }, &a.st->err);
     // dimSparsity of this lane's slots of the dense head (one buffer resource over the head: beyond it a load returns zero);
-    // requested with the row records: both are waited for at the barrier
+    // requested with the row records, used behind the barrier
     const __amdgpu_buffer_rsrc_t ds_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ds), 0, a.hh * 4, 0x00020000);
     float dsh[HOG_SW];
 #pragma unroll
@@ -1838,8 +1838,8 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
       cn->stop = leaving;
     }
     stamp(4);
-    // The tables of the next sub-batch (its row records were drained by the barrier behind the scatter; this iteration's
-    // tables are no longer needed): LDS only.  Its two barriers publish the next iteration's control words and the
+    // The tables of the next sub-batch (its row records were requested in front of the update and waited for with the
+    // update's own loads; this iteration's tables are no longer needed): LDS only.  Its two barriers publish the next iteration's control words and the
     // weight copy.  Then the request for its non-zeros -- BEHIND the update: vmcnt retires in order, and in front of the
     // update's requests these (random rows of a matrix of gigabytes) held every one of them back for ~7 us.
     hog_wcache_wait();
@@ -2164,10 +2164,11 @@ __global__ void __launch_bounds__(PLAN_THREADS) dsgd_plan_kernel(PlanArgs a) {
     __syncthreads();   // every contribution of this batch is in the accumulators (and the strip's atomics are performed)
     stamp(5, tl);
     // ---- nothing of batch n+1 / n+2 depends on w until the weight gather: request it all now, UNDER the sweep.
-    // (__syncthreads() drains every outstanding memory operation of the wave -- it is a workgroup-scope fence -- so
-    // requests placed in front of the barrier above were waited for on the spot: the phase counters showed 9,000
-    // cycles there.  Behind it they have the whole sweep to land before the next barrier.)  What consumes last
-    // iteration's loads (the row ids) goes first, the fresh requests last.
+    // (Round 3 measured 9,000 cycles at the barrier above with these requests in front of it and concluded that
+    // __syncthreads() waits for vector memory operations.  It does not with this compiler: the ISA is `s_waitcnt
+    // lgkmcnt(0); s_barrier` -- a workgroup-scope fence needs no vmcnt wait when a workgroup lives on one CU; what
+    // must be PERFORMED device-wide before a flag goes out waits in asm, e.g. dsgd_hogwild_kernel in front of its
+    // commit.)  What consumes last iteration's loads (the row ids) goes first, the fresh requests last.
     row_next = rows_of(sl[2], rid_next2);
     rid_next2 = load_rid(sb[3], sl[3]);
     long long vb4, ve4;
