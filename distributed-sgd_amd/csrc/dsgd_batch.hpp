@@ -1375,7 +1375,7 @@ static_assert(HOG_HL - HOG_HH <= 32 * HBIT_WORDS && HBIT_WORDS <= 2 * HOG_THREAD
 __host__ __device__ constexpr int hog_hh(int hl) { return hl < HOG_HH ? hl : HOG_HH; }
 __host__ __device__ constexpr int hog_hbit_words(int hl) { return hl > hog_hh(hl) ? HBIT_WORDS : 0; }
 __host__ __device__ constexpr int hog_lds_words(int hl, int wl, int dp) {
-  return wl + ((hl + (dp - hl + 31) / 32 + hog_hbit_words(hl) + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 8 + HOG_MAX_BATCH / 32 + 16 + 8 + 2;
+  return wl + ((hl + (dp - hl + 31) / 32 + hog_hbit_words(hl) + 1) & ~1) + bt_lds_words(HOG_CAP) + 16 + 12 + HOG_MAX_BATCH / 32 + 16 + 8 + 2;
 }
 
 // Copy of w[0, wl) into LDS: each wave moves 1 KiB pieces straight from the fabric into LDS (global_load_lds_dwordx4:
@@ -1453,8 +1453,8 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   bt_carve(L, tables, HOG_CAP);
   float* red = reinterpret_cast<float*>(tables + bt_lds_words(HOG_CAP));   // 8 floats + 8 counters
   unsigned int* redn = reinterpret_cast<unsigned int*>(red + 8);
-  HogCtl* ctl = reinterpret_cast<HogCtl*>(red + 16);                       // 2 slots (iteration parity)
-  unsigned int* gmask = reinterpret_cast<unsigned int*>(red + 24);         // traced runs: gate decisions of the mini-batch
+  HogCtl* ctl = reinterpret_cast<HogCtl*>(red + 16);                       // 3 slots (iteration mod 3: this one, the next, the one being sampled)
+  unsigned int* gmask = reinterpret_cast<unsigned int*>(red + 28);         // traced runs: gate decisions of the mini-batch
   unsigned int* tp = gmask + HOG_MAX_BATCH / 32;                           // PROF: phase sums [0..13], [14] the last stamp (32-bit), [15] iterations
   unsigned int* stl = tp + 16;                                             // thread 0: samples / active rows / weight atomics not yet flushed;
                                                                            //   [4..5] the update count its weights were read at (a register
@@ -1491,6 +1491,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   const int B = a.batch;
   const float fB = (float)B;
   unsigned long long it = a.it[worker];
+  int sl = 0;   // control slot of iteration `it` (rotates 0, 1, 2)
   hog_wcache_issue(a.w, wl, a.wl);   // (lands under the start-up loads below; waited for in front of the first barrier)
   // thread 0 carries the shared scalars between iterations: what its own returning atomics saw
   float s = 0.0f;
@@ -1500,11 +1501,11 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     stl[5] = (unsigned int)(u >> 32);
     s = __hip_atomic_load(&a.st->s_reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int stop = hog_read_stop(&a.st->stop);
-    HogCtl* c0 = &ctl[it & 1];
+    HogCtl* c0 = &ctl[sl];
     hog_sampler(a, worker, it, n_k, c0);
     c0->s = s;
     c0->stop = stop != 0 || (long long)u >= a.max_updates;
-    hog_sampler(a, worker, it + 1, n_k, &ctl[(it + 1) & 1]);
+    hog_sampler(a, worker, it + 1, n_k, &ctl[sl == 2 ? 0 : sl + 1]);
   }
   hog_wcache_wait();
   __syncthreads();
@@ -1529,7 +1530,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     if (r >= (long long)n_k) r -= n_k;
     return base + r;
   };
-  if (ctl[it & 1].stop) {
+  if (ctl[sl].stop) {
     if (tid == 0) atomicAdd(&a.st->done_blocks, 1);
     return;
   }
@@ -1537,14 +1538,19 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
   BtItems<HOG_R> items;
   int2 bd;
   {
-    const unsigned long long mul = ctl[it & 1].mul, off = ctl[it & 1].off;
+    const unsigned long long mul = ctl[sl].mul, off = ctl[sl].off;
     const BtRow row = bt_rows_issue<HOG_CAP>(a.m, B, 0, [&](int t) { return row_at(mul, off, t); }, &a.st->err);
     bd = bt_build<HOG_THREADS, HOG_CAP>(L, B, 0, row);
     if (bd.x > 0) bt_items_issue<HOG_THREADS, HOG_R>(a.m, L, bd.y, items);
   }
   if (PROF && prof) tp[14] = (unsigned int)__builtin_readcyclecounter();
   for (;;) {
-    const HogCtl cur = ctl[it & 1];
+    const HogCtl cur = ctl[sl];
+    const int sl1 = sl == 2 ? 0 : sl + 1, sl2 = sl == 0 ? 2 : sl - 1;   // the slots of iterations it + 1 and it + 2 (= it - 1: free)
+    // The sampler of iteration + 2 -- two 64-bit remainders and a gcd loop, ~3,000 cycles of one lane; in front of the
+    // commit's atomics until round 6: 1.4 us on every worker's critical path -- by a lane of its own, HERE: its wave is
+    // about to wait for the sub-batch's non-zeros anyway.
+    if (tid == 64) hog_sampler(a, worker, it + 2, n_k, &ctl[sl2]);
     const unsigned long long mul = cur.mul, off = cur.off;
     const float s_it = cur.s;
     const bool add_s = (s_it != 0.0f) && (fabsf(s_it) > DSGD_EPS);
@@ -1563,7 +1569,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     // ... and whatever did not fit its item slots (long rows, batches beyond 128 rows)
     if (done < B) n_act += bt_batch<HOG_THREADS, HOG_R, 3>(a.m, L, gc, B, done, row_of, wload, a.qscale, &a.st->err, gm, gdot);
     // the next iteration's sample does not depend on w: request its row records now
-    const HogCtl nxt = ctl[(it + 1) & 1];
+    const HogCtl nxt = ctl[sl1];
     const BtRow row_n = bt_rows_issue<HOG_CAP>(a.m, B, 0, [&](int t) { return row_at(nxt.mul, nxt.off, t); }, &a.st->err);
     // dimSparsity of this lane's slots of the dense head (one buffer resource over the head: beyond it a load returns zero);
     // requested with the row records, used behind the barrier
@@ -1784,9 +1790,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         na += redn[i];
       }
       const float ds_term = -2.0f * a.lambda * tot;
-      // the sampler of iteration + 2 first (a gcd loop, no memory; this iteration's slot is free: its fields are in
-      // registers), then the two returning atomics and the stop flag go out TOGETHER: one round trip
-      hog_sampler(a, worker, it + 2, n_k, &ctl[it & 1]);
+      // the two returning atomics and the stop flag go out TOGETHER: one round trip
       const float s_seen = atomicAdd(&a.st->s_reg, ds_term);
       const unsigned long long u_seen = atomicAdd(&a.st->updates, 1ull);
       const int stop = hog_read_stop(&a.st->stop);
@@ -1833,7 +1837,7 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
         atomicAdd(&a.st->atomics, (unsigned long long)stl[2]);
         stl[0] = stl[1] = stl[2] = 0u;
       }
-      HogCtl* cn = &ctl[(it + 1) & 1];
+      HogCtl* cn = &ctl[sl1];
       cn->s = s;
       cn->stop = leaving;
     }
@@ -1857,7 +1861,8 @@ __global__ void __launch_bounds__(HOG_THREADS) dsgd_hogwild_kernel(HogArgs a) {
     ++it;
     bd = bd_n;
     if (PROF && prof) ++tp[15];
-    if (ctl[it & 1].stop) break;
+    sl = sl1;
+    if (ctl[sl].stop) break;
   }
   if (PROF && prof && a.tprof) {
     for (int i = 0; i < 14; ++i) a.tprof[i] += tp[i];
