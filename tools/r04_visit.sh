@@ -85,7 +85,8 @@ mbprof)
   done ;;
 bench)
   echo "== bench (default flags)"
-  timeout 900 python bench.py 2> $OUT/bench.err > $OUT/bench.json; tail -3 $OUT/bench.err; cut -c1-600 $OUT/bench.json ;;
+  timeout 900 python bench.py 2> $OUT/bench.err > $OUT/bench.json; tail -3 $OUT/bench.err; cut -c1-600 $OUT/bench.json
+  cp gpurun_out/bench_detail.json $OUT/bench_detail.json 2>/dev/null ;;   # (the next bench run of any kind overwrites it)
 benchquick)
   echo "== bench (no cpu baseline, no sweep, no gate)"
   timeout 600 python bench.py --no-cpu-baseline --no-sweep --no-parity-gate 2> $OUT/benchq.err > $OUT/benchq.json; tail -3 $OUT/benchq.err; cut -c1-900 $OUT/benchq.json ;;
