@@ -89,8 +89,9 @@ __device__ __forceinline__ void wg_copy_in_store(float* lds_dst, const float* __
   for (int j = 8 * nthreads + tid; j < n4; j += nthreads) d4[j] = s4[j];
   for (int j = 4 * n4 + tid; j < n; j += nthreads) lds_dst[j] = src[j];
 }
-// a workgroup barrier that orders LDS only: global requests issued in front of it stay in flight (__syncthreads() waits
-// for every outstanding memory operation of the wave: vmcnt(0))
+// a workgroup barrier that orders LDS only.  (Neither this nor __syncthreads() waits for vector memory operations with
+// this compiler -- both are `s_waitcnt lgkmcnt(0); s_barrier` in the ISA, a workgroup lives on one CU -- but
+// __syncthreads() is also a compiler fence for global accesses; requests issued in front of either stay in flight.)
 __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
