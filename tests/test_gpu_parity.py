@@ -841,8 +841,9 @@ def test_hogwild_single_worker_replays_the_oracle():
                           "batch %d: a replayed row within 1e-5 of the gate, err %.3g" % (batch, np.abs(w - w_ref).max()))
 
 
-@pytest.mark.parametrize("dim", [1500, 6000, 70000])
-def test_hogwild_single_worker_on_other_model_widths(dim):
+@pytest.mark.parametrize("dim,batches", [(1500, ((100, 30), (7, 40))), (6000, ((100, 30), (7, 40))), (70000, ((100, 30), (7, 40))),
+                                         (47236, ((300, 12), (1000, 4)))])   # (batches beyond the 128 staged rows: the leftovers' path)
+def test_hogwild_single_worker_on_other_model_widths(dim, batches):
     """The update of the lock-free engine walks a dense head of 2,048 ranks, a bitmap of the other LDS accumulators and
     the cold strip's bitmap two words per lane at a time (csrc/dsgd_batch.hpp): models whose every rank sits in the head
     (D = 1,500), with accumulators beyond it and next to no strip (6,000), and with a strip of more words than one
@@ -851,7 +852,7 @@ def test_hogwild_single_worker_on_other_model_widths(dim):
     n_train = 4800
     o, eng = make_pair(data, 1e-5, n_train)
     with eng:
-        for batch, n_upd in ((100, 30), (7, 40)):
+        for batch, n_upd in batches:
             eng.set_weights(np.zeros(data.dim + 1, dtype=np.float32))
             w_ref = np.zeros(data.dim + 1)
             begin, end = 500, 4500
